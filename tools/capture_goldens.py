@@ -1,0 +1,565 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the imported reference (runs only in the build container).
+
+    python tools/capture_goldens.py            # rewrites tests/golden/*.npz|json
+
+The reference has no tests of its own, so parity is pinned by running the
+reference's Python here, on inputs authored in this repository, and committing the inputs
+together with the reference's outputs.  Every case is stored twice: the reference run in
+fp32 and the same reference run in fp64 (`model.double()`), which gives the tolerance
+policy of DESIGN.md something to measure fp32 conditioning against.
+
+Families:
+  g1  log-space primitives                     util.py:17-47
+  g2  BatchBayesianLogicCell.forward           batch_base_ops.py:153-215, 62-151
+  g3  FilterBatch / RelateBatch.forward        batch_base_ops.py:311-405, 483-596
+  g4  whole-interpreter runs, all 16 ops+end   batch_base_interpreter.py:72-183
+  g5  neural oracle (reduced dims) end-to-end  classifier_oracle.py:145-156 + MLPs
+  g6  loss values and gradients                trainer.py:181-262
+  g7  collate_programs                         data_pipeline.py:647-746
+  g8  gather_results                           data_parallel.py:15-50
+"""
+
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import mini_ontology  # noqa: E402
+import ref_harness  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
+
+import torch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+ref = ref_harness.import_reference()
+paths = mini_ontology.write(os.path.join(OUT, "mini_ontology"))
+ontology = ref_harness.build_ontology(ref, paths)
+C = len(ontology._vocabulary["idx_to_arg"])
+CR = len(ontology._relation_index)
+op = syn.op
+
+
+def both_dtypes():
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        ref_harness.set_fp64(ref, dt == torch.float64)
+        yield dt, tag
+    ref_harness.set_fp64(ref, False)
+
+
+def save(name, arrays, meta):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote", name, "arrays:", len(arrays), "bytes:", os.path.getsize(os.path.join(OUT, name + ".npz")))
+
+
+# ---------------------------------------------------------------------------------------- g1
+def g1():
+    u = ref.util
+    arrays = {}
+    x = np.concatenate([np.linspace(-60, 0, 241), -np.logspace(-8, 1.7, 120), [-30.0, -46.0517, -1e-7, 0.0]])
+    y = np.concatenate([np.linspace(0, -60, 241)[::-1] * 0.37, -np.logspace(-7, 1.5, 120), [-0.5, -30.0, -2e-7, 0.0]])
+    p = np.concatenate([np.linspace(0, 1, 200), np.logspace(-30, 0, 100), [0.0, 1e-20, 1e-21, 1.0]])
+    for dt, tag in both_dtypes():
+        tx, ty, tp = (torch.tensor(v, dtype=dt) for v in (x, y, p))
+        arrays["safe_log_" + tag] = u.safe_log(tp).numpy()
+        arrays["safe_exp_" + tag] = u.safe_exp(tx).numpy()
+        arrays["log_and_" + tag] = u.log_and(tx, ty).numpy()
+        arrays["log_or_" + tag] = u.log_or(tx, ty).numpy()
+        arrays["log_not_" + tag] = u.log_not(tx).numpy()
+        for a in (0.0, 1.0, 0.25):
+            arrays["log_pnot_a%g_%s" % (a, tag)] = u.log_parametric_not(tx, a, 1).numpy()
+        arrays["log_or_tensor_" + tag] = u.log_or_tensor(tx.view(-1, 5), 1).numpy()
+    arrays["x"], arrays["y"], arrays["p"] = x, y, p
+    save("g1_primitives", arrays, {"source": "util.py:17-47", "torch": torch.__version__})
+
+
+# ---------------------------------------------------------------------------------------- g2
+def flat_problem(rng, n_list, k_list, arity, family="mix10"):
+    """A flat-layout logic-cell problem as the reference sees it.
+    n_list: objects per image (= per question); k_list: predicates per question."""
+    Q = len(n_list)
+    O = int(sum(n_list))
+    img = np.repeat(np.arange(Q), n_list)
+    pq = np.repeat(np.arange(Q), k_list)
+    P = len(pq)
+    prior = np.minimum(syn.table_log_likelihood(rng, (Q, arity, O), "unif") * 0.3, 0).astype(np.float32)
+    if arity == 1:
+        ll = np.full((P, O, 1), -30, np.float32)
+        for p_ in range(P):
+            m = img == pq[p_]
+            ll[p_, m, 0] = syn.table_log_likelihood(rng, (int(m.sum()),), family)
+    else:
+        ll = np.full((P, O, O, 1), -30, np.float32)
+        for p_ in range(P):
+            idx = np.nonzero(img == pq[p_])[0]
+            n = len(idx)
+            t = syn.table_log_likelihood(rng, (n, n), family)
+            t[np.arange(n), np.arange(n)] = -30
+            ll[np.ix_([p_], idx, idx, [0])] = t[None, :, :, None]
+    return {"img": img, "pq": pq, "prior": prior, "ll": ll, "Q": Q, "O": O, "P": P}
+
+
+def sparse_map(rows, cols, shape, dtype):
+    ind = torch.stack([torch.as_tensor(rows, dtype=torch.int64), torch.as_tensor(cols, dtype=torch.int64)])
+    return torch.sparse_coo_tensor(ind, torch.ones(len(rows), dtype=dtype), shape)
+
+
+def g2():
+    arrays, meta = {}, {"source": "batch_base_ops.py:153-215,62-151", "cases": []}
+    rng = np.random.RandomState(20)
+    specs = [
+        # name, n_list, k_list, arity, quantifier mode, negation
+        ("a1_single", [5], [1], 1, "exists", False),
+        ("a1_batch", [1, 2, 5], [1, 1, 1], 1, "mixed", True),
+        ("a1_expand", [4, 6, 3], [2, 1, 3], 1, "mixed", True),
+        ("a2_single", [5], [1], 2, "exists", False),
+        ("a2_n1", [1, 3], [1, 1], 2, "exists", False),
+        ("a2_batch", [2, 5, 4], [1, 1, 1], 2, "mixed", False),
+        ("a2_batch_neg", [3, 6, 2], [1, 1, 1], 2, "mixed", True),
+        ("a2_expand", [4, 5, 3], [2, 1, 2], 2, "mixed", True),
+        ("a2_forall", [6, 4], [1, 1], 2, "forall", False),
+        ("a2_n36", [36, 36, 36], [1, 1, 1], 2, "mixed", False),
+        ("a2_stress_mix05", [12, 9], [1, 2], 2, "exists", False),
+        ("a2_stress_weak", [12, 9], [1, 1], 2, "exists", False),
+    ]
+    for name, n_list, k_list, arity, qmode, neg in specs:
+        fam = "mix05" if "mix05" in name else ("weak" if "weak" in name else "mix10")
+        pr = flat_problem(rng, n_list, k_list, arity, fam)
+        Q, O, P = pr["Q"], pr["O"], pr["P"]
+        if qmode == "exists":
+            quant = np.ones((P, arity), np.float32)
+        elif qmode == "forall":
+            quant = np.zeros((P, arity), np.float32)
+        else:
+            quant = (rng.uniform(size=(Q, arity)) < 0.6).astype(np.float32)[pr["pq"]]
+        is_neg = (rng.uniform(size=P) < 0.5).astype(np.float32) if neg else None
+        for dt, tag in both_dtypes():
+            cell = ref.base_ops.BatchBayesianLogicCell(arity)
+            bom = sparse_map(pr["img"], np.arange(O), (Q, O), dt)
+            pqm = sparse_map(np.arange(P), pr["pq"], (P, Q), dt) if P != Q else None
+            out = cell(torch.tensor(pr["prior"], dtype=dt), torch.tensor(pr["ll"], dtype=dt),
+                       torch.tensor(quant, dtype=dt), list(range(arity)), bom, pqm,
+                       None if is_neg is None else torch.tensor(is_neg, dtype=dt))
+            arrays[name + "_out_" + tag] = out.numpy()
+        arrays[name + "_prior"] = pr["prior"]
+        arrays[name + "_ll"] = pr["ll"]
+        arrays[name + "_quant"] = quant
+        arrays[name + "_img"] = pr["img"]
+        arrays[name + "_pq"] = pr["pq"]
+        if is_neg is not None:
+            arrays[name + "_neg"] = is_neg
+        meta["cases"].append({"name": name, "n": n_list, "k": k_list, "arity": arity, "family": fam, "neg": neg})
+    save("g2_logic_cell", arrays, meta)
+
+
+# ---------------------------------------------------------------------------------------- interpreter runs
+def run_reference(questions, split=1, dtype=torch.float32, training=False, return_trace=True, normalize=True,
+                  grad_tables=False):
+    qs = copy.deepcopy(questions)
+    collater = ref_harness.make_collater(ref, split, "table")
+    pbs = collater.collate(qs)
+    model = ref_harness.build_table_interpreter(ref, ontology, normalize)
+    leaves = []
+    for pb in pbs:
+        pb.create_sparse_tensors()
+        if dtype == torch.float64:
+            pb.to(torch.float64)
+            pb._object_batch_index = pb._object_batch_index.long()
+        if grad_tables:
+            pb._object_features = pb._object_features.clone().requires_grad_(True)
+            pb._meta_data["R"] = pb._meta_data["R"].clone().requires_grad_(True)
+            leaves.append((pb._object_features, pb._meta_data["R"]))
+    if dtype == torch.float64:
+        model = model.double()
+    if training:
+        model.train()
+    with torch.set_grad_enabled(grad_tables):
+        res = model(pbs, training, return_trace=return_trace)
+    return res, pbs, leaves
+
+
+def scene_for(qid, n, family="mix10"):
+    return syn.table_scene(qid, n, C, CR, family)
+
+
+def pack_result(arrays, meta, tag, res, traces):
+    lp = res["log_probability"]
+    arrays["lp_" + tag] = lp.detach().numpy()
+    if tag == "f32":
+        meta["answer"] = res["answer"]
+        meta["options"] = res["options"]
+        meta["type"] = int(res["type"])
+        meta["answer_log_probability"] = res["answer_log_probability"]
+    k = 0
+    for b, trace in enumerate(traces):
+        for i, x in enumerate(trace):
+            if isinstance(x, ref.base_types.BatchVariableSet):
+                arrays["trace_%s_b%d_op%d_att" % (tag, b, i)] = x._log_attention.detach().numpy()
+                arrays["trace_%s_b%d_op%d_quant" % (tag, b, i)] = x._quantifier.detach().numpy()
+                if tag == "f32":
+                    meta.setdefault("trace_names", {})["b%d_op%d" % (b, i)] = list(x._name)
+                k += 1
+    return k
+
+
+def questions_to_meta(questions):
+    out = []
+    for q in questions:
+        out.append({"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "n": q["scene"]["n"]})
+    return out
+
+
+def capture_run(name, questions, split=1, normalize=True, arrays=None, meta=None):
+    arrays = {} if arrays is None else arrays
+    meta = {} if meta is None else meta
+    meta.update({"questions": questions_to_meta(questions), "split": split, "normalize": normalize,
+                 "source": "batch_base_interpreter.py:72-183"})
+    for i, q in enumerate(questions):
+        arrays["A_%d" % i] = q["scene"]["A"]
+        arrays["R_%d" % i] = q["scene"]["R"]
+    for dt, tag in both_dtypes():
+        (res, traces), pbs, _ = run_reference(questions, split, dt, normalize=normalize)
+        pack_result(arrays, meta, tag, res, traces)
+        if tag == "f32":
+            meta["op_names"] = [[ob._op_name for ob in pb._op_batch_list] for pb in pbs]
+            meta["dependencies"] = [pb._dependencies for pb in pbs]
+    save(name, arrays, meta)
+
+
+def g4():
+    Q = syn.question
+    n_of = lambda i: [5, 7, 3, 6, 4, 8, 2, 5][i % 8]
+
+    def mk(i, branches, last, answer="yes", fam="mix10"):
+        return Q(100 + i, branches, last, answer, scene_for(100 + i, n_of(i), fam))
+
+    # exist: ragged program lengths, negation, '_' select, both relate directions, two relates
+    qs = [
+        mk(0, [[op("select", "dog")]], op("exist")),
+        mk(1, [[op("select", "cat"), op("filter", "red")]], op("exist"), "no"),
+        mk(2, [[op("select", "_"), op("filter", "not(blue)"), op("relate", "on", True, "table")]], op("exist")),
+        mk(3, [[op("select", "man"), op("relate", "to the left of", False, "car"), op("filter", "small"),
+                op("relate", "near", True, "_")]], op("exist")),
+        mk(4, [[op("select", "chair"), op("filter", "wood"), op("filter", "large"),
+                op("relate", "not(under)", False, "cup")]], op("exist"), "no"),
+        mk(5, [[op("select", "scene"), op("relate", "holding", True, "tree"), op("relate", "behind", False, "dog"),
+                op("filter", "black")]], op("exist")),
+    ]
+    capture_run("g4_exist", qs)
+    capture_run("g4_exist_split3", qs, split=3)
+
+    # the BASELINE configs[0] shape at N=36 (3 questions)
+    nouns, attrs, rels = ["dog", "table", "cup", "car", "tree", "cat", "chair", "man"], \
+        ["red", "blue", "small", "large", "white", "black"], ["on", "to the left of", "to the right of", "under", "near"]
+    qs36 = []
+    for i in range(3):
+        br, last = syn.three_hop_program(500 + i, nouns, attrs, rels)
+        qs36.append(Q(500 + i, br, last, "yes", scene_for(500 + i, 36)))
+    capture_run("g4_threehop_n36", qs36)
+
+    qs = [
+        mk(10, [[op("select", "dog"), op("filter", "small")]], op("verify_attrs", ["red", "large"])),
+        mk(11, [[op("select", "cup")]], op("verify_attrs", ["glass"]), "no"),
+        mk(12, [[op("select", "car"), op("relate", "near", True, "bus")]], op("verify_attrs", ["not(white)", "metal"])),
+    ]
+    capture_run("g4_verify_attrs", qs)
+
+    qs = [
+        mk(20, [[op("select", "dog")]], op("choose_attr", ["red", "blue"]), "red"),
+        mk(21, [[op("select", "table"), op("filter", "wood")]], op("choose_attr", ["small", "large"]), "large"),
+        mk(22, [[op("select", "man"), op("relate", "holding", True, "cup")]], op("choose_attr", ["sitting", "standing"]), "sitting"),
+    ]
+    capture_run("g4_choose_attr", qs)
+    capture_run("g4_choose_attr_nonorm", qs, normalize=False)
+
+    qs = [
+        mk(30, [[op("select", "dog")]], op("query_attr", "color"), "black"),
+        mk(31, [[op("select", "animal"), op("filter", "small")]], op("query_attr", "name"), "cat"),
+        mk(32, [[op("select", "chair")]], op("query_attr", "material"), "wood"),
+        mk(33, [[op("select", "cup")]], op("query_attr", "name"), "cup"),
+    ]
+    capture_run("g4_query_attr", qs)
+
+    qs = [
+        mk(40, [[op("select", "dog")]], op("verify_rel", "on", True, "couch")),
+        mk(41, [[op("select", "man"), op("filter", "standing")]], op("verify_rel", "to the right of", False, "bus"), "no"),
+        mk(42, [[op("select", "cup")]], op("verify_rel", "not(near)", True, "_")),
+    ]
+    capture_run("g4_verify_rel", qs)
+
+    qs = [
+        mk(50, [[op("select", "dog")]], op("choose_rel", ["to the left of", "to the right of"], True, "cat"), "to the left of"),
+        mk(51, [[op("select", "woman"), op("filter", "large")]], op("choose_rel", ["on", "under"], False, "table"), "on"),
+        mk(52, [[op("select", "boy")]], op("choose_rel", ["near", "behind"], True, "_"), "near"),
+    ]
+    capture_run("g4_choose_rel", qs)
+
+    two = lambda i, last, ans="yes": mk(i, [[op("select", "dog"), op("filter", "red")],
+                                            [op("select", "cat"), op("relate", "near", bool(i % 2), "table")]], last, ans)
+    two_b = lambda i, last, ans="yes": mk(i, [[op("select", "car")], [op("select", "bus"), op("filter", "not(large)")]], last, ans)
+    for name in ("and", "or"):
+        capture_run("g4_" + name, [two(60, op(name)), two_b(61, op(name), "no"), two(62, op(name))])
+    for name in ("two_same", "two_different"):
+        capture_run("g4_" + name, [two(70, op(name, "color")), two_b(71, op(name, "material"), "no"), two(73, op(name, "size"))])
+    for name in ("all_same", "all_different"):
+        capture_run("g4_" + name, [mk(80, [[op("select", "dog")]], op(name, "color")),
+                                   mk(81, [[op("select", "furniture"), op("filter", "wood")]], op(name, "name"), "no"),
+                                   mk(82, [[op("select", "cup"), op("relate", "on", False, "table")]], op(name, "size"))])
+    capture_run("g4_compare", [two(90, op("compare", "large", False), "dog"), two_b(91, op("compare", "red", True), "bus"),
+                               two(92, op("compare", "not(small)", True), "cat")])
+
+    # stress families (probability-space comparison only)
+    for fam in ("mix05", "weak"):
+        qsf = [mk(200 + i, [[op("select", "dog"), op("filter", "red"), op("relate", "on", bool(i % 2), "table")]],
+                  op("exist"), "yes", fam) for i in range(4)]
+        capture_run("g4_stress_" + fam, qsf)
+
+    # implicit `end`: a hand-built ProgramBatch whose last op is not terminal (batch_gqa_interpreter.py:75-76)
+    arrays, meta = {}, {"source": "batch_gqa_interpreter.py:72-78", "implicit_end": True}
+    qs = [mk(95, [[op("select", "dog"), op("filter", "red")]], op("exist")), mk(96, [[op("select", "cat"), op("filter", "blue")]], op("exist"))]
+    for i, q in enumerate(qs):
+        arrays["A_%d" % i], arrays["R_%d" % i] = q["scene"]["A"], q["scene"]["R"]
+    for dt, tag in both_dtypes():
+        collater = ref_harness.make_collater(ref, 1, "table")
+        pb = collater.collate(copy.deepcopy(qs))[0]
+        pb2 = ref.data_pipeline.ProgramBatch(pb.device, pb._op_batch_list[:-1], pb._dependencies[:-1], pb._answers,
+                                             pb._object_features, pb._object_batch_index, pb._original_dicts, pb._meta_data)
+        pb2.create_sparse_tensors()
+        model = ref_harness.build_table_interpreter(ref, ontology)
+        if dt == torch.float64:
+            pb2.to(torch.float64)
+            pb2._object_batch_index = pb2._object_batch_index.long()
+            model = model.double()
+        with torch.no_grad():
+            res, traces = model([pb2], False, return_trace=True)
+        pack_result(arrays, meta, tag, res, [[t for t in traces[0] if not isinstance(t, dict)]])
+    meta["questions"] = questions_to_meta(qs)
+    save("g4_end", arrays, meta)
+
+
+# ---------------------------------------------------------------------------------------- g3
+def g3():
+    """FilterBatch / RelateBatch called directly, incl. None/'_'/'not(x)' tokens and list predicate maps."""
+    arrays, meta = {}, {"source": "batch_base_ops.py:311-405,483-596", "cases": []}
+    n_list = [4, 6, 3]
+    scenes = [scene_for(300 + i, n) for i, n in enumerate(n_list)]
+    for i, s in enumerate(scenes):
+        arrays["A_%d" % i], arrays["R_%d" % i] = s["A"], s["R"]
+    Qn, O = len(n_list), sum(n_list)
+    img = np.repeat(np.arange(Qn), n_list)
+    rng = np.random.RandomState(33)
+    att0 = np.minimum(syn.table_log_likelihood(rng, (Qn, O), "unif") * 0.3, 0)
+    att1 = np.minimum(syn.table_log_likelihood(rng, (Qn, O), "unif") * 0.3, 0)
+    arrays["att0"], arrays["att1"], arrays["img"] = att0, att1, img
+    cases = [
+        ("filter_plain", "filter", ["red", "small", "wood"], None, True),
+        ("filter_none", "filter", ["red", None, "_"], None, True),
+        ("filter_neg", "filter", ["not(red)", "large", " blue "], None, True),
+        ("filter_neg_none", "filter", [None, "not(metal)", "glass"], None, True),
+        ("filter_expand", "filter", ["red", "blue", "small", "wood", "metal", "glass"], [0, 0, 1, 2, 2, 2], True),
+        ("filter_expand_nonorm", "filter", ["red", "blue", "small", "wood", "metal", "glass"], [0, 0, 1, 2, 2, 2], False),
+        ("relate_plain", "relate", ["on", "near", "under"], None, True),
+        ("relate_none", "relate", ["on", None, "_"], None, True),
+        ("relate_neg", "relate", ["not(on)", "to the left of", "not(behind)"], None, True),
+        ("relate_expand", "relate", ["on", "under", "near", "holding", "behind"], [0, 0, 1, 2, 2], True),
+        ("relate_forall", "relate", ["on", "near", "under"], None, True),
+    ]
+    for name, kind, tokens, pqm, normalized in cases:
+        for dt, tag in both_dtypes():
+            oracle = ref.ClassifierOracle(ontology, None, None, None, normalize=True, cached=True)
+            A = torch.tensor(np.concatenate([s["A"] for s in scenes]), dtype=dt)
+            R = torch.tensor(np.concatenate([s["R"] for s in scenes]), dtype=dt)
+            bi = torch.tensor(img)
+            ind = ref.util.find_sparse_pair_indices(bi, bi, torch.device("cpu"), True)
+            world = ref.base_types.BatchWorld(torch.device("cpu"), O, A, {"features": R, "index": list(ind)}, bi,
+                                              {"index": {}, "embedding": torch.zeros(1, 1)}).to(dt)
+            q0 = torch.tensor([1.0, 0.0, 1.0] if name == "relate_forall" else [1.0] * 3, dtype=dt)
+            q1 = torch.tensor([0.0, 1.0, 1.0] if name == "relate_forall" else [1.0] * 3, dtype=dt)
+            vs0 = world.variable_set(["a", "b", "c"], quantifier=q0, log_attention=torch.tensor(att0, dtype=dt))
+            vs1 = world.variable_set(["d", "e", "f"], quantifier=q1, log_attention=torch.tensor(att1, dtype=dt))
+            # A python-list map works in fp32 only (the reference builds it with the legacy FloatTensor
+            # constructor, batch_base_ops.py:324-335); the fp64 pass hands over a ready sparse map instead.
+            if pqm is None:
+                pq_arg = None
+            elif dt == torch.float32:
+                pq_arg = list(pqm)
+            else:
+                pq_arg = sparse_map(np.arange(len(pqm)), pqm, (len(pqm), Qn), dt)
+            if kind == "filter":
+                f = ref.base_ops.FilterBatch(oracle)
+                out = f("id", world, vs0, list(tokens), pq_arg, normalized_probability=normalized)
+                arrays[name + "_att_" + tag] = out._log_attention.numpy()
+                arrays[name + "_quant_" + tag] = out._quantifier.numpy()
+            else:
+                r = ref.base_ops.RelateBatch(oracle)
+                s_, o_ = r("id", world, vs0, vs1, list(tokens), pq_arg, normalized_probability=normalized)
+                arrays[name + "_satt_" + tag] = s_._log_attention.numpy()
+                arrays[name + "_oatt_" + tag] = o_._log_attention.numpy()
+                arrays[name + "_quant_" + tag] = s_._quantifier.numpy()
+        meta["cases"].append({"name": name, "kind": kind, "tokens": tokens, "pqm": pqm, "normalized": normalized,
+                              "quant0": [1.0, 0.0, 1.0] if name == "relate_forall" else [1.0] * 3,
+                              "quant1": [0.0, 1.0, 1.0] if name == "relate_forall" else [1.0] * 3})
+    meta["n"] = n_list
+    save("g3_filter_relate", arrays, meta)
+
+
+# ---------------------------------------------------------------------------------------- g5
+def g5():
+    """Neural oracle at reduced dims with deterministic weights: raw object features -> tables -> answers."""
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_interpreter_experiments as gie
+    cfg = dict(box_features_dim=32, oracle_input_dim=16, oracle_output_dim=1, word_embedding_dim=mini_ontology.EMBEDDING_DIM,
+               classifier_oracle=True, featurizer_layers_config=[], attribute_network_layers_config=[8],
+               relation_network_layers_config=[8], operator_layers_config=[], normalize_oracle=True, dropout=0.0,
+               freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+               freeze_embedding_network=False, activate_attention_transfer=False, attention_transfer_state_dim=0,
+               freeze_attention_network=False, trainable_gate=False, likelihood_threshold=0, hard_mode=False,
+               verbose=False, model_name="g5", gpu_num=1)
+    exp = gie.GQAObjectBoxExperiment()
+    exp._local_rank = 0
+    torch.manual_seed(0)
+    model = exp.build_model(cfg, ontology, None)
+    model.eval()
+    arrays, meta = {}, {"source": "classifier_oracle.py:145-156; gqa_interpreter_experiments.py:18-77,107-240", "config": cfg}
+    for k, v in model.state_dict().items():
+        if k.startswith("_featurizer.") or k.startswith("_oracle."):   # every op module aliases the same oracle
+            arrays["w:" + k] = v.numpy()
+    n_list = [5, 7, 4]
+    nouns, attrs, rels = ["dog", "table", "cup", "car"], ["red", "blue", "small"], ["on", "near", "under"]
+    qs = []
+    for i, n in enumerate(n_list):
+        br, last = syn.three_hop_program(700 + i, nouns, attrs, rels)
+        q = syn.question(700 + i, br, last, "yes", syn.feature_scene(700 + i, n, cfg["box_features_dim"]))
+        qs.append(q)
+        arrays["X_%d" % i] = q["scene"]["X"]
+    for dt, tag in both_dtypes():
+        m = copy.deepcopy(model).double() if dt == torch.float64 else model
+        collater = ref_harness.make_collater(ref, 1, "feature")
+        pbs = collater.collate(copy.deepcopy(qs))
+        for pb in pbs:
+            pb.create_sparse_tensors()
+            if dt == torch.float64:
+                pb.to(torch.float64)
+                pb._object_batch_index = pb._object_batch_index.long()
+        with torch.no_grad():
+            world = m.build_scene(pbs[0].device, pbs[0]._object_features, pbs[0]._object_batch_index, pbs[0]._meta_data)
+            arrays["A_" + tag] = world._attribute_features.numpy()
+            arrays["R_" + tag] = world._relation_features["features"].numpy()
+            res, traces = m(pbs, False, return_trace=True)
+        pack_result(arrays, meta, tag, res, traces)
+    meta["questions"] = questions_to_meta(qs)
+    meta["relation_index"] = list(ontology._relation_index)
+    save("g5_neural_oracle", arrays, meta)
+
+
+# ---------------------------------------------------------------------------------------- g6
+def g6():
+    """Loss values and gradients w.r.t. the tables (trainer.py:181-262) for BINARY and QUERY batches."""
+    from nsvqa.train.trainer import VQATrainer
+    fake = types.SimpleNamespace(_device=torch.device("cpu"), _config={})
+    Q = syn.question
+    sets = {
+        "binary": [Q(800 + i, [[op("select", "dog"), op("filter", "red"), op("relate", "on", bool(i % 2), "table")]], op("exist"),
+                     "yes" if i % 2 == 0 else "no", scene_for(800 + i, 4 + i)) for i in range(3)],
+        "query": [Q(810 + i, [[op("select", "cat"), op("filter", "small")]], op("choose_attr", ["red", "blue"]),
+                    "red" if i % 2 == 0 else "blue", scene_for(810 + i, 5 + i)) for i in range(3)],
+        "query_rel": [Q(820 + i, [[op("select", "man")]], op("choose_rel", ["on", "under"], bool(i % 2), "table"),
+                        "on" if i % 2 == 0 else "under", scene_for(820 + i, 4 + i)) for i in range(3)],
+    }
+    for name, qs in sets.items():
+        arrays, meta = {}, {"source": "trainer.py:181-262,429-442", "questions": questions_to_meta(qs)}
+        for i, q in enumerate(qs):
+            arrays["A_%d" % i], arrays["R_%d" % i] = q["scene"]["A"], q["scene"]["R"]
+        for dt, tag in both_dtypes():
+            res, pbs, leaves = run_reference(qs, 1, dt, training=True, return_trace=False, grad_tables=True)
+            if dt == torch.float64:
+                # _compute_loss builds fp32 targets; run it on an fp32 view of fp64 log-probs would lose the point,
+                # so restate the two formulas here in fp64 exactly as trainer.py:185-194,207-230 does.
+                lp = res["log_probability"]
+                if res["type"] == ref.base_types.QuestionType.BINARY:
+                    target = torch.tensor([a == "yes" for pb in pbs for a in pb._answers], dtype=dt)
+                    loss = torch.nn.functional.binary_cross_entropy(lp.exp(), target, reduction="sum")
+                else:
+                    answers = [a for pb in pbs for a in pb._answers]
+                    target = [[a == o for o in opt] for a, opt in zip(answers, res["options"])]
+                    seg = torch.tensor([i for i, t in enumerate(target) for _ in t])
+                    tflat = torch.tensor([x for t in target for x in t], dtype=dt)
+                    denom = torch.zeros(len(target), dtype=dt).index_add(0, seg, lp.exp())
+                    loss = ref.util.safe_log(denom).sum() - (tflat * lp).sum()
+            else:
+                loss = VQATrainer._compute_loss(fake, pbs, res)
+            loss = loss / sum(pb.batch_size() for pb in pbs)
+            loss.backward()
+            arrays["loss_" + tag] = loss.detach().numpy()
+            arrays["lp_" + tag] = res["log_probability"].detach().numpy()
+            for key, leaf in (("gA_", leaves[0][0]), ("gR_", leaves[0][1])):
+                arrays[key + tag] = (torch.zeros_like(leaf) if leaf.grad is None else leaf.grad).detach().numpy()
+            if tag == "f32":
+                meta["options"] = res["options"]
+                meta["type"] = int(res["type"])
+        save("g6_loss_" + name, arrays, meta)
+
+
+# ---------------------------------------------------------------------------------------- g7 / g8
+def g7():
+    Q = syn.question
+    qs = [
+        Q(0, [[op("select", "dog")]], op("exist")),
+        Q(1, [[op("select", "cat"), op("filter", "red"), op("filter", "small")]], op("exist")),
+        Q(2, [[op("select", "_"), op("relate", "on", True, "table"), op("filter", "blue"), op("relate", "near", False, "cup")]], op("exist")),
+        Q(3, [[op("select", "man"), op("filter", "large"), op("relate", "under", True, "_"), op("filter", "wood"), op("filter", "black")]], op("exist")),
+    ]
+    qs2 = [
+        Q(4, [[op("select", "dog"), op("filter", "red")], [op("select", "cat")]], op("two_same", "color")),
+        Q(5, [[op("select", "car")], [op("select", "bus"), op("relate", "near", True, "tree"), op("filter", "small")]], op("two_same", "size")),
+    ]
+    qs3 = [Q(6, [[op("select", "dog")]], op("choose_attr", ["red", "blue"])), Q(7, [[op("select", "cat"), op("filter", "small")]], op("choose_attr", ["white", "black"]))]
+    meta = {"source": "data_pipeline.py:647-746,31-143", "cases": []}
+    for name, questions in (("ragged_exist", qs), ("two_branch", qs2), ("choose", qs3)):
+        collater = ref.data_pipeline.ProgramCollaterBase("select", "relate", "filter", 1)
+        obl, deps = collater.collate_programs(copy.deepcopy(questions))
+        meta["cases"].append({
+            "name": name, "questions": [{"program": q["program"]} for q in questions], "dependencies": deps,
+            "ops": [{"op_name": ob._op_name, "is_terminal": ob._is_terminal, "arguments": ob._arguments,
+                     "mask": ob._mask.tolist(), "predicate_num": ob._predicate_num,
+                     "question_index": None if ob._question_index is None else ob._question_index.tolist()} for ob in obl]})
+    collater = ref.data_pipeline.ProgramCollaterBase("select", "relate", "filter", 3)
+    pbs = collater.collate(copy.deepcopy(qs))
+    meta["split3_sizes"] = [pb.batch_size() for pb in pbs]
+    meta["split3_ops"] = [[ob._op_name for ob in pb._op_batch_list] for pb in pbs]
+    save("g7_collate", {"dummy": np.zeros(1)}, meta)
+
+
+def g8():
+    QT = ref.base_types.QuestionType
+    from nsvqa.nn.interpreter.data_parallel import gather_results
+    outs = [{"answer": [["yes"], ["no"]], "log_probability": torch.tensor([-0.1, -2.0]), "options": ["no", "yes"], "variable_set": None,
+             "type": QT.BINARY, "cumulative_loss": 0, "variable_sets_num": 3, "answer_log_probability": [[-0.1], [-0.14]]},
+            {"answer": [["no"], ["yes"]], "log_probability": torch.tensor([-3.0, -0.2]), "options": ["no", "yes"], "variable_set": None,
+             "type": QT.BINARY, "cumulative_loss": 0, "variable_sets_num": 4, "answer_log_probability": [[-0.05], [-0.2]]}]
+    res = gather_results(outs, torch.device("cpu"), False)
+    outs_q = [{"answer": [["red"]], "log_probability": torch.tensor([-0.1, -2.0]), "options": [["red", "blue"]], "variable_set": None,
+               "type": QT.QUERY, "cumulative_loss": 0, "variable_sets_num": 1, "answer_log_probability": [[-0.1]]},
+              {"answer": [["on"]], "log_probability": torch.tensor([-0.3, -1.0]), "options": [["on", "under"]], "variable_set": None,
+               "type": QT.QUERY, "cumulative_loss": 0, "variable_sets_num": 2, "answer_log_probability": [[-0.3]]}]
+    res_q = gather_results(outs_q, torch.device("cpu"), False)
+    meta = {"source": "data_parallel.py:15-50",
+            "binary": {k: (v if not isinstance(v, torch.Tensor) else v.tolist()) for k, v in res.items() if k != "type"},
+            "query": {k: (v if not isinstance(v, torch.Tensor) else v.tolist()) for k, v in res_q.items() if k != "type"}}
+    meta["binary"]["type"], meta["query"]["type"] = int(res["type"]), int(res_q["type"])
+    save("g8_gather", {"dummy": np.zeros(1)}, meta)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,217 @@
+"""Pins the CPU oracle (oracle/dfol_oracle.py) to the goldens captured from the reference.
+
+fp64: the oracle must reproduce the reference's fp64 outputs to 1e-9 — same algorithm, only the
+summation order differs.  fp32: tolerance policy of tests/golden_util.check_logprob.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+from oracle import dfol_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ontology(mini_ontology_paths):
+    p = mini_ontology_paths
+    return orc.Ontology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+
+
+def test_g1_primitives():
+    a, _ = gu.load("g1_primitives")
+    for tag, dt, tol in (("f64", np.float64, 1e-12), ("f32", np.float32, 3e-6)):
+        x, y, p = (a[k].astype(dt) for k in ("x", "y", "p"))
+        assert np.allclose(orc.safe_log(p), a["safe_log_" + tag], rtol=tol, atol=tol)
+        assert np.allclose(orc.safe_exp(x), a["safe_exp_" + tag], rtol=tol, atol=1e-30)
+        assert np.allclose(orc.log_and(x, y), a["log_and_" + tag], rtol=tol, atol=tol)
+        for al in (0.0, 1.0, 0.25):
+            got, ref = orc.log_parametric_not(x, dt(al), 1), a["log_pnot_a%g_%s" % (al, tag)]
+            # ill-conditioned near x -> 0- for alpha = 1: compare in probability space there
+            assert np.allclose(np.exp(got), np.exp(ref), atol=2e-7 if dt == np.float32 else 1e-14)
+        for got, ref in ((orc.log_not(x), a["log_not_" + tag]), (orc.log_or(x, y), a["log_or_" + tag]),
+                         (orc.log_or_tensor(x.reshape(-1, 5), 1), a["log_or_tensor_" + tag])):
+            assert np.allclose(np.exp(got), np.exp(ref), atol=4e-7 if dt == np.float32 else 1e-14)
+            if dt == np.float64:
+                assert np.allclose(got, ref, rtol=1e-9, atol=1e-9)
+    # exact structural facts
+    assert orc.safe_log(np.float32([0.0]))[0] == np.float32(np.log(np.float32(1e-20)))
+    assert orc.log_not(np.float32([0.0]))[0] == np.float32(np.log(np.float32(1e-20)))
+
+
+def _bom(img, dt):
+    Q = int(img.max()) + 1
+    b = np.zeros((Q, len(img)), dt)
+    b[img, np.arange(len(img))] = 1
+    return b
+
+
+def test_g2_logic_cell():
+    a, meta = gu.load("g2_logic_cell")
+    for case in meta["cases"]:
+        n = case["name"]
+        img, pq = a[n + "_img"], a[n + "_pq"]
+        neg = a[n + "_neg"] if (n + "_neg") in a.files else None
+        Q = int(img.max()) + 1
+        for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+            out = orc.logic_cell(a[n + "_prior"].astype(dt), a[n + "_ll"].astype(dt), a[n + "_quant"].astype(dt),
+                                 _bom(img, dt), pq if len(pq) != Q else None, None if neg is None else neg.astype(dt))
+            ref = a[n + "_out_" + tag]
+            own = img[None, :] == pq[:, None]              # only a predicate's own image is meaningful
+            own = np.broadcast_to(own[:, None, :], ref.shape)
+            if dt == np.float64:
+                assert np.allclose(out[own], ref[own], rtol=1e-9, atol=1e-9), n
+            else:
+                gu.check_logprob(out[own], ref[own], a[n + "_out_f64"][own], n, lp_tol=2e-4)
+
+
+def test_block_form_equals_flat():
+    """The per-predicate block form (what the HIP kernels compute) == the flat form on each image."""
+    a, meta = gu.load("g2_logic_cell")
+    for case in meta["cases"]:
+        if case["arity"] != 2:
+            continue
+        n = case["name"]
+        img, pq = a[n + "_img"], a[n + "_pq"]
+        neg = a[n + "_neg"] if (n + "_neg") in a.files else None
+        ref = a[n + "_out_f64"]
+        prior, ll, quant = a[n + "_prior"].astype(np.float64), a[n + "_ll"].astype(np.float64), a[n + "_quant"]
+        for p in range(len(pq)):
+            idx = np.nonzero(img == pq[p])[0]
+            if len(idx) < 2 or (len(pq) == 1 and quant[p].min() == 0):
+                continue
+            ps, po = orc.relate_block(prior[pq[p], 0, idx], prior[pq[p], 1, idx], ll[p][np.ix_(idx, idx)][:, :, 0],
+                                      quant[p, 0], quant[p, 1], 0.0 if neg is None else neg[p], neg is not None)
+            assert np.allclose(ps, ref[p, 0, idx], rtol=1e-9, atol=1e-9), n
+            assert np.allclose(po, ref[p, 1, idx], rtol=1e-9, atol=1e-9), n
+
+
+def _world(ontology, a, meta, dt):
+    n_list = meta["n"]
+    img = np.repeat(np.arange(len(n_list)), n_list)
+    A = np.concatenate([a["A_%d" % i] for i in range(len(n_list))])
+    R = np.concatenate([a["R_%d" % i] for i in range(len(n_list))])
+    return orc.World(ontology, A, R, img, dt, True)
+
+
+def test_g3_filter_relate(ontology):
+    a, meta = gu.load("g3_filter_relate")
+    for case in meta["cases"]:
+        n = case["name"]
+        for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+            w = _world(ontology, a, meta, dt)
+            vs0 = w.variable_set(["a", "b", "c"], case["quant0"], a["att0"].astype(dt))
+            vs1 = w.variable_set(["d", "e", "f"], case["quant1"], a["att1"].astype(dt))
+            pq = case["pqm"] if case["pqm"] is not None else np.arange(len(case["tokens"]))
+            own = w.img[None, :] == np.asarray(pq)[:, None]
+            if case["kind"] == "filter":
+                out = orc.filter_batch(w, vs0, list(case["tokens"]), case["pqm"], normalized_probability=case["normalized"])
+                pairs = [(out.att, a[n + "_att_" + tag], a[n + "_att_f64"])]
+                assert np.array_equal(out.quant, a[n + "_quant_" + tag])
+            else:
+                s, o = orc.relate_batch(w, vs0, vs1, list(case["tokens"]), case["pqm"], normalized_probability=case["normalized"])
+                pairs = [(s.att, a[n + "_satt_" + tag], a[n + "_satt_f64"]), (o.att, a[n + "_oatt_" + tag], a[n + "_oatt_f64"])]
+                assert np.array_equal(s.quant, a[n + "_quant_" + tag])
+            for got, ref, ref64 in pairs:
+                if dt == np.float64:
+                    assert np.allclose(got[own], ref[own], rtol=1e-9, atol=1e-9), n
+                else:
+                    gu.check_logprob(got[own], ref[own], ref64[own], n, lp_tol=2e-4)
+
+
+@pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS + ["g4_end"])
+def test_g4_interpreter(ontology, name):
+    a, meta = gu.load(name)
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    if name == "g4_end":
+        for q in qs:                       # the golden was produced from a hand-built batch without its terminal op
+            q["program"]["last_op"] = {"operator": "end", "arguments": []}
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        res = orc.run_questions(ontology, qs, scenes, dt, split=meta.get("split", 1), normalize=meta.get("normalize", True))
+        if dt == np.float64:
+            assert np.allclose(res["log_probability"], a["lp_f64"], rtol=1e-8, atol=1e-8), name
+        elif name in gu.G4_STRESS:
+            assert np.abs(np.exp(res["log_probability"]) - np.exp(a["lp_f32"])).max() <= 1e-6
+        else:
+            gu.check_logprob(res["log_probability"], a["lp_f32"], a["lp_f64"], name)
+            assert res["answer"] == meta["answer"], name
+            assert res["type"] == meta["type"]
+
+
+def test_g4_trace(ontology):
+    """Per-op attentions of the batched canonical op sequence (mask gating included)."""
+    a, meta = gu.load("g4_exist")
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    res, traces = orc.run_questions(ontology, qs, scenes, np.float64, return_trace=True)
+    img = np.repeat(np.arange(len(scenes)), [s["n"] for s in scenes])
+    own = img[None, :] == np.arange(len(scenes))[:, None]
+    k = 0
+    for i, x in enumerate(traces[0]):
+        key = "trace_f64_b0_op%d_att" % i
+        if key in a.files:
+            assert np.allclose(x.att[own], a[key][own], rtol=1e-9, atol=1e-9), i
+            assert np.array_equal(x.quant, a["trace_f64_b0_op%d_quant" % i])
+            assert x.names == meta["trace_names"]["b0_op%d" % i]
+            k += 1
+    assert k >= 5
+
+
+def test_g5_neural_oracle(ontology):
+    a, meta = gu.load("g5_neural_oracle")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    qs, scenes = gu.questions_and_scenes(a, meta, "X")
+    assert list(ontology.relation_index) == meta["relation_index"]
+    for tag, dt, tol in (("f64", np.float64, 1e-10), ("f32", np.float32, 2e-5)):
+        img = np.repeat(np.arange(len(scenes)), [s["n"] for s in scenes])
+        X = np.concatenate([s["X"] for s in scenes]).astype(dt)
+        A, R = orc.tables_from_features(X, img, weights, ontology, dt)
+        assert np.allclose(A, a["A_" + tag], rtol=tol, atol=tol)
+        assert np.allclose(R, a["R_" + tag], rtol=tol, atol=tol)
+        res = orc.run_questions(ontology, qs, scenes, dt, weights=weights)
+        if dt == np.float64:
+            assert np.allclose(res["log_probability"], a["lp_f64"], rtol=1e-8, atol=1e-8)
+        else:
+            gu.check_logprob(res["log_probability"], a["lp_f32"], a["lp_f64"], "g5")
+
+
+@pytest.mark.parametrize("name", ["g6_loss_binary", "g6_loss_query", "g6_loss_query_rel"])
+def test_g6_loss(ontology, name):
+    a, meta = gu.load(name)
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        res = orc.run_questions(ontology, qs, scenes, dt, give_answer=False)
+        loss = float(orc.compute_loss(res, [q["answer"] for q in qs]) / len(qs))
+        l32, l64 = float(a["loss_f32"]), float(a["loss_f64"])
+        if dt == np.float64:
+            assert abs(loss - l64) <= 1e-9 * max(1.0, abs(l64)), (name, loss, l64)
+        else:   # the loss inherits the conditioning of the log-probabilities: yardstick = the reference's own fp32 error
+            assert abs(loss - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (name, loss, l32, l64)
+
+
+def test_g7_collate():
+    _, meta = gu.load("g7_collate")
+    for case in meta["cases"]:
+        ops, deps = orc.collate_programs(case["questions"])
+        assert deps == case["dependencies"], case["name"]
+        assert len(ops) == len(case["ops"])
+        for mine, ref in zip(ops, case["ops"]):
+            for k in ("op_name", "is_terminal", "arguments", "mask", "predicate_num", "question_index"):
+                assert mine[k] == ref[k], (case["name"], ref["op_name"], k)
+    sizes = [len(c) for c in orc.split_questions(list(range(4)), 3)]
+    assert sizes == meta["split3_sizes"]
+
+
+def test_g8_gather():
+    _, meta = gu.load("g8_gather")
+    outs = [{"answer": [["yes"], ["no"]], "log_probability": np.array([-0.1, -2.0]), "options": ["no", "yes"], "type": orc.BINARY,
+             "answer_log_probability": [[-0.1], [-0.14]]},
+            {"answer": [["no"], ["yes"]], "log_probability": np.array([-3.0, -0.2]), "options": ["no", "yes"], "type": orc.BINARY,
+             "answer_log_probability": [[-0.05], [-0.2]]}]
+    res = orc.gather_results(outs)
+    ref = meta["binary"]
+    assert res["answer"] == ref["answer"] and res["options"] == ref["options"] and res["type"] == ref["type"]
+    assert np.allclose(res["log_probability"], ref["log_probability"])
+    assert res["answer_log_probability"] == ref["answer_log_probability"]

@@ -1,0 +1,231 @@
+"""ctypes binding of the C-ABI library (include/dfol_vqa.h, built from csrc/ by hipcc).
+
+There is no CPU fallback: if `libdfolvqa.so` is missing, or a tensor is not a contiguous CUDA
+(ROCm) tensor of the declared dtype, the call raises.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfolvqa.so")
+_lib = None
+
+TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
+WANT_SUBJECT, WANT_OBJECT = 1, 2
+ACT_NONE, ACT_SIGMOID, ACT_ELU, ACT_LOGSIGMOID = 0, 1, 2, 3
+LOGIC_AND, LOGIC_OR, LOGIC_NOT = 0, 1, 2
+
+
+class DfolError(RuntimeError):
+    pass
+
+
+_p, _i32, _i64, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes, exactly as declared in include/dfol_vqa.h
+SIGNATURES = {
+    "dfol_attr_gather_f32": [_p, _i64, _p, _p, _p, _i32, _i32, _f, _p, _p],
+    "dfol_rel_gather_f32": [_p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p],
+    "dfol_option_normalize_f32": [_p, _p, _i32, _p, _p, _i32, _i32, _p],
+    "dfol_filter_fwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p],
+    "dfol_relate_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "dfol_quantify_fwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_gate_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
+    "dfol_gather_rows_f32": [_p, _p, _i32, _i32, _p, _p],
+    "dfol_segment_sum_rows_f32": [_p, _p, _i32, _i32, _p, _p],
+    "dfol_logic_f32": [_i32, _p, _p, _i64, _p, _p],
+    "dfol_parametric_not_f32": [_p, _p, _i32, _i32, _p, _p],
+    "dfol_segment_or_f32": [_p, _p, _i32, _p, _p],
+    "dfol_implication_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_compare_f32": [_p, _p, _p, _i32, _p, _p],
+    "dfol_linear_act_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    "dfol_box_positions_f32": [_p, _i64, _i32, _i32, _p, _i64, _i32, _p],
+    "dfol_pair_features_f32": [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _i64, _p],
+}
+
+
+def load():
+    """Load the library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DfolError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dfol_last_error.restype = ctypes.c_char_p
+    lib.dfol_abi_version.restype = ctypes.c_int
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise DfolError("missing tensor argument")
+    if not t.is_cuda:
+        raise DfolError("the HIP path needs tensors on the GPU (got a %s tensor); there is no CPU fallback" % t.device)
+    if dtype is not None and t.dtype != dtype:
+        raise DfolError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise DfolError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise DfolError("%s failed (%d): %s" % (name, rc, lib.dfol_last_error().decode()))
+
+
+F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
+
+
+# ---- thin typed wrappers (tensor in / tensor out), one per entry point -------------------------------
+def attr_gather(table, obj_off, pred_q, pred_col, NS, default_ll=-30.0):
+    P = pred_q.numel()
+    ll = torch.empty(P, NS, dtype=F32, device=table.device)
+    assert table.stride(1) == 1
+    call("dfol_attr_gather_f32", table.data_ptr(), table.stride(0), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32),
+         P, NS, default_ll, _ptr(ll), _stream())
+    return ll
+
+
+def rel_gather(table, pair_off, n_obj, pred_q, pred_col, NS, orientation=TILE_SUBJECT_ROWS, default_ll=-30.0):
+    P = pred_q.numel()
+    tile = torch.empty(P, NS, NS, dtype=F32, device=table.device)
+    assert table.stride(1) == 1
+    call("dfol_rel_gather_f32", table.data_ptr(), table.stride(0), _ptr(pair_off, I64), _ptr(n_obj, I32), _ptr(pred_q, I32),
+         _ptr(pred_col, I32), P, NS, orientation, default_ll, _ptr(tile), _stream())
+    return tile
+
+
+def option_normalize_(ll, seg_off, pred_q, n_obj, NS):
+    rank = ll.dim() - 1
+    call("dfol_option_normalize_f32", _ptr(ll, F32), _ptr(seg_off, I32), seg_off.numel() - 1, _ptr(pred_q, I32), _ptr(n_obj, I32),
+         NS, rank, _stream())
+    return ll
+
+
+def filter_fwd(att_in, ll, pred_q, n_obj, neg=None, active=None):
+    P, NS = ll.shape
+    out = torch.empty(P, NS, dtype=F32, device=ll.device)
+    call("dfol_filter_fwd_f32", _ptr(att_in, F32), _ptr(ll, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), _ptr(neg, U8, True),
+         0 if neg is None else 1, _ptr(active, U8, True), P, NS, _ptr(out), _stream())
+    return out
+
+
+def relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg=None, active=None, want=None,
+               orientation=TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True):
+    P, NS = tile.shape[0], tile.shape[1]
+    post_s = torch.empty(P, NS, dtype=F32, device=tile.device) if need_s else None
+    post_o = torch.empty(P, NS, dtype=F32, device=tile.device) if need_o else None
+    call("dfol_relate_fwd_f32", _ptr(prior_s, F32), _ptr(prior_o, F32), _ptr(tile, F32), _ptr(pred_q, I32), _ptr(n_obj, I32),
+         _ptr(quant_s, F32), _ptr(quant_o, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True),
+         _ptr(want, U8, True), P, NS, orientation, 1 if lone_forall_identity else 0, _ptr(post_s, F32, True),
+         _ptr(post_o, F32, True), _stream())
+    return post_s, post_o
+
+
+def quantify_fwd(att, quant, pred_q, n_obj):
+    P, NS = att.shape
+    lp = torch.empty(P, dtype=F32, device=att.device)
+    call("dfol_quantify_fwd_f32", _ptr(att, F32), _ptr(quant, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, _ptr(lp), _stream())
+    return lp
+
+
+def gate(x_att, y_att, x_quant, y_quant, g):
+    P, NS = x_att.shape
+    out = torch.empty_like(x_att)
+    outq = torch.empty_like(x_quant)
+    call("dfol_gate_f32", _ptr(x_att, F32), _ptr(y_att, F32), _ptr(x_quant, F32), _ptr(y_quant, F32), _ptr(g, F32), P, NS,
+         _ptr(out), _ptr(outq), _stream())
+    return out, outq
+
+
+def gather_rows(src, idx):
+    src2 = src.reshape(src.shape[0], -1)
+    P, width = idx.numel(), src2.shape[1]
+    out = torch.empty((P,) + tuple(src.shape[1:]), dtype=F32, device=src.device)
+    call("dfol_gather_rows_f32", _ptr(src2, F32), _ptr(idx, I32), P, width, _ptr(out), _stream())
+    return out
+
+
+def segment_sum_rows(src, seg_off):
+    Q, width = seg_off.numel() - 1, src.shape[1]
+    out = torch.empty(Q, width, dtype=F32, device=src.device)
+    call("dfol_segment_sum_rows_f32", _ptr(src, F32), _ptr(seg_off, I32), Q, width, _ptr(out), _stream())
+    return out
+
+
+def logic(op, a, b=None):
+    out = torch.empty_like(a)
+    call("dfol_logic_f32", op, _ptr(a, F32), _ptr(b, F32, True), a.numel(), _ptr(out), _stream())
+    return out
+
+
+def parametric_not(x, alpha):
+    x2 = x.reshape(alpha.numel(), -1)
+    out = torch.empty_like(x2)
+    call("dfol_parametric_not_f32", _ptr(x2, F32), _ptr(alpha, F32), x2.shape[0], x2.shape[1], _ptr(out), _stream())
+    return out.reshape(x.shape)
+
+
+def segment_or(lp, seg_off):
+    Q = seg_off.numel() - 1
+    out = torch.empty(Q, dtype=F32, device=lp.device)
+    call("dfol_segment_or_f32", _ptr(lp, F32), _ptr(seg_off, I32), Q, _ptr(out), _stream())
+    return out
+
+
+def implication(prior, x, pred_q, n_obj):
+    P, NS = x.shape
+    out = torch.empty_like(x)
+    call("dfol_implication_f32", _ptr(prior, F32), _ptr(x, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, _ptr(out), _stream())
+    return out
+
+
+def compare(lp1, lp2, is_less):
+    Q = lp1.numel()
+    out = torch.empty(Q, 2, dtype=F32, device=lp1.device)
+    call("dfol_compare_f32", _ptr(lp1, F32), _ptr(lp2, F32), _ptr(is_less, F32), Q, _ptr(out), _stream())
+    return out
+
+
+def linear_act(x, weight, bias, act, out=None):
+    """y = act(x @ weight.T + bias); x may be a column slice of a wider matrix (row stride = x.stride(0))."""
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=x.device)
+    for t in (x, weight, out):
+        if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
+            raise DfolError("linear_act needs fp32 GPU matrices with unit column stride")
+    call("dfol_linear_act_f32", x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias, F32, True),
+         out.data_ptr(), out.stride(0), M, N, K, act, _stream())
+    return out
+
+
+def box_positions(raw, obj, pos_col):
+    call("dfol_box_positions_f32", raw.data_ptr(), raw.stride(0), raw.shape[1], raw.shape[0], obj.data_ptr(), obj.stride(0),
+         pos_col, _stream())
+
+
+def pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs):
+    out = torch.empty(pairs, 2 * D + 4, dtype=F32, device=obj.device)
+    call("dfol_pair_features_f32", obj.data_ptr(), obj.stride(0), D, _ptr(obj_off, I32), _ptr(pair_off, I64), Q, max_n,
+         out.data_ptr(), out.stride(0), _stream())
+    return out

@@ -1,0 +1,67 @@
+// Shared device helpers and ABI plumbing for the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dfol_vqa.h"
+
+#define DFOL_EPS 1e-20f          // util.py:25
+#define DFOL_WAVE 64
+
+void dfol_set_error(const char* fmt, ...);
+
+#define DFOL_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            dfol_set_error(__VA_ARGS__);        \
+            return 1;                           \
+        }                                       \
+    } while (0)
+
+#define DFOL_LAUNCH_CHECK(name)                                                          \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            dfol_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));        \
+            return 2;                                                                    \
+        }                                                                                \
+    } while (0)
+
+// ---- transcendental helpers -----------------------------------------------------------------------
+// The logic kernels evaluate exp and log once or twice per byte they stream, so they use the hardware
+// v_exp_f32 / v_log_f32 directly (1 ulp each; arguments are log-probabilities <= 0 and probabilities in
+// [1e-20, 2], so neither overflow nor denormal-input handling is needed).  -DDFOL_PRECISE_MATH swaps in
+// the libm versions for A/B parity runs.
+__device__ __forceinline__ float dfol_exp(float x) {
+#ifdef DFOL_PRECISE_MATH
+    return expf(x);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
+}
+
+__device__ __forceinline__ float dfol_log(float x) {
+#ifdef DFOL_PRECISE_MATH
+    return logf(x);
+#else
+    return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+#endif
+}
+
+// util.py:22-25
+__device__ __forceinline__ float dfol_slog(float x) { return dfol_log(fmaxf(x, DFOL_EPS)); }
+// util.py:35-36
+__device__ __forceinline__ float dfol_lnot(float x) { return dfol_slog(1.0f - dfol_exp(x)); }
+// util.py:46-47 with beta = 1:  log(max(alpha + (1 - 2 alpha) e^x, eps)); c = 1 - 2 alpha
+__device__ __forceinline__ float dfol_pnot(float x, float alpha, float c) { return dfol_slog(alpha + c * dfol_exp(x)); }
+
+// Sum over all 64 lanes; every lane gets the total.
+__device__ __forceinline__ float dfol_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+static inline int dfol_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

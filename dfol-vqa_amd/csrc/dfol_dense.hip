@@ -1,0 +1,232 @@
+// Dense contractions of the visual oracle for gfx950: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Y = act(X W^T + b) with both operands K-contiguous (torch nn.Linear layout).  128x128 block tile,
+// four wavefronts in a 2x2 arrangement, each owning a 64x64 sub-tile as 2x2 MFMA tiles of 32x32.
+// K is consumed in chunks of 32 staged through LDS.  The MFMA's K index is only a summation index, so a
+// lane takes the 16 *contiguous* k of its half (k = 16*(lane>>5) + t at step t) instead of the
+// interleaved k = 2t + (lane>>5): that turns 16 ds_read_b32 per operand tile into 4 conflict-free
+// ds_read_b128 (row pitch 36 floats).
+#include "dfol_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, PITCH = 36;
+
+template <int ALIGN>
+__device__ __forceinline__ float4 load4(const float* __restrict__ base, int64_t ld, int row, int col, int rows, int cols) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= rows || col >= cols) return v;
+    const float* p = base + (int64_t)row * ld + col;
+    if (col + 3 < cols) {
+        if (ALIGN == 4) return *reinterpret_cast<const float4*>(p);
+        if (ALIGN == 2) {
+            const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+            return make_float4(a.x, a.y, b.x, b.y);
+        }
+        return make_float4(p[0], p[1], p[2], p[3]);
+    }
+    v.x = p[0];
+    if (col + 1 < cols) v.y = p[1];
+    if (col + 2 < cols) v.z = p[2];
+    return v;
+}
+
+template <int ACT>
+__device__ __forceinline__ float activate(float x) {
+    if (ACT == DFOL_ACT_SIGMOID) return 1.0f / (1.0f + expf(-x));
+    if (ACT == DFOL_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == DFOL_ACT_LOGSIGMOID) return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+    return x;
+}
+
+template <int ACT, int ALIGN_X, int ALIGN_W>
+__global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
+                                                         int64_t ldw, const float* __restrict__ bias, float* __restrict__ Y,
+                                                         int64_t ldy, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order is not needed here: W (<= 2.8 MB) stays L2-resident on every XCD.
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;        // loader: 32 rows x 8 float4 per pass, 4 passes
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, lk, M, K);
+        rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, lk, N, K);
+    }
+
+    const int half = lane >> 5, r32 = lane & 31;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * PITCH + lk]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PITCH + lk]) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + BK < K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, k0 + BK + lk, M, K);
+                rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, k0 + BK + lk, N, K);
+            }
+        }
+        float a[2][16], b[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* pa = &As[(wm * 64 + t * 32 + r32) * PITCH + half * 16];
+            const float* pb = &Bs[(wn * 64 + t * 32 + r32) * PITCH + half * 16];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 fa = *reinterpret_cast<const float4*>(pa + 4 * v);
+                const float4 fb = *reinterpret_cast<const float4*>(pb + 4 * v);
+                a[t][4 * v + 0] = fa.x; a[t][4 * v + 1] = fa.y; a[t][4 * v + 2] = fa.z; a[t][4 * v + 3] = fa.w;
+                b[t][4 * v + 0] = fb.x; b[t][4 * v + 1] = fb.y; b[t][4 * v + 2] = fb.z; b[t][4 * v + 3] = fb.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r32;
+            if (n >= N) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M) Y[(int64_t)m * ldy + n] = activate<ACT>(acc[i][j][e] + bv);
+            }
+        }
+}
+
+int align_of(const float* p, int64_t ld) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    if (a % 16 == 0 && ld % 4 == 0) return 4;
+    if (a % 8 == 0 && ld % 2 == 0) return 2;
+    return 1;
+}
+
+template <int ACT>
+void launch_linear(hipStream_t st, dim3 grid, int ax, int aw, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                   const float* bias, float* Y, int64_t ldy, int M, int N, int K) {
+#define DFOL_LIN(AX, AW) \
+    hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K)
+    if (ax == 4 && aw == 4) DFOL_LIN(4, 4);
+    else if (ax == 2 && aw == 4) DFOL_LIN(2, 4);
+    else if (ax == 4 && aw == 2) DFOL_LIN(4, 2);
+    else if (ax == 2 && aw == 2) DFOL_LIN(2, 2);
+    else DFOL_LIN(1, 1);
+#undef DFOL_LIN
+}
+
+}  // namespace
+
+extern "C" int dfol_linear_act_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                                   int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    DFOL_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_act: bad sizes M=%d N=%d K=%d", M, N, K);
+    DFOL_REQUIRE(ldx >= K && ldw >= K && ldy >= N, "linear_act: leading dimensions too small");
+    DFOL_REQUIRE(act >= 0 && act <= 3, "linear_act: unknown activation %d", act);
+    if (M == 0) return 0;
+    DFOL_REQUIRE(X && W && Y, "linear_act: null pointer");
+    const dim3 grid(dfol_cdiv(N, BN), dfol_cdiv(M, BM));
+    DFOL_REQUIRE(grid.y <= 65535, "linear_act: M=%d too large for one launch", M);
+    hipStream_t st = (hipStream_t)stream;
+    const int ax = align_of(X, ldx), aw = align_of(W, ldw);
+    switch (act) {
+        case DFOL_ACT_NONE: launch_linear<DFOL_ACT_NONE>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
+        case DFOL_ACT_SIGMOID: launch_linear<DFOL_ACT_SIGMOID>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
+        case DFOL_ACT_ELU: launch_linear<DFOL_ACT_ELU>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
+        default: launch_linear<DFOL_ACT_LOGSIGMOID>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
+    }
+    DFOL_LAUNCH_CHECK("linear_act");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void box_positions_kernel(const float* __restrict__ raw, int64_t ld_raw, int raw_cols, int O, float* __restrict__ obj,
+                                     int64_t ld_obj, int pos_col) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= O) return;
+    const float* t = raw + (int64_t)o * ld_raw + raw_cols - 6;      // (W, H, x, y, w, h)
+    const float Wc = fmaxf(t[0], 1.f), Hc = fmaxf(t[1], 1.f);      // clamp(1), batch_gqa_boxfeatures_pipeline.py:209
+    float* d = obj + (int64_t)o * ld_obj + pos_col;
+    d[0] = t[2] / Wc;
+    d[1] = t[3] / Hc;
+    d[2] = t[4] / Wc;
+    d[3] = t[5] / Hc;
+}
+
+extern "C" int dfol_box_positions_f32(const float* raw, int64_t ld_raw, int32_t raw_cols, int32_t O, float* obj, int64_t ld_obj,
+                                      int32_t pos_col, void* stream) {
+    DFOL_REQUIRE(O >= 0 && raw_cols >= 6 && ld_raw >= raw_cols && pos_col >= 0 && ld_obj >= pos_col + 4, "box_positions: bad sizes");
+    if (O == 0) return 0;
+    DFOL_REQUIRE(raw && obj, "box_positions: null pointer");
+    hipLaunchKernelGGL(box_positions_kernel, dim3(dfol_cdiv(O, 256)), dim3(256), 0, (hipStream_t)stream, raw, ld_raw, raw_cols, O,
+                       obj, ld_obj, pos_col);
+    DFOL_LAUNCH_CHECK("box_positions");
+    return 0;
+}
+
+// One block per (image, subject); threads sweep the (object, feature) plane of that subject's pair rows.
+__global__ void pair_features_kernel(const float* __restrict__ obj, int64_t ld_obj, int D, const int32_t* __restrict__ obj_off,
+                                     const int64_t* __restrict__ pair_off, int max_n, float* __restrict__ pair, int64_t ld_pair) {
+    const int q = blockIdx.x / max_n, s = blockIdx.x % max_n;
+    const int first = obj_off[q], n = obj_off[q + 1] - first;
+    if (s >= n) return;
+    const float* fs = obj + (int64_t)(first + s) * ld_obj;
+    const int width = 2 * D + 4;
+    for (int e = threadIdx.x; e < (n - 1) * width; e += blockDim.x) {
+        const int k = e / width, f = e - k * width;           // k-th partner of s
+        const int o = k < s ? k : k + 1;
+        const float* fo = obj + (int64_t)(first + o) * ld_obj;
+        float v;
+        if (f < D) v = fs[f];
+        else if (f < 2 * D) v = fo[f - D];
+        else {
+            const float x1 = fs[D - 4], y1 = fs[D - 3], w1 = fs[D - 2], h1 = fs[D - 1];
+            const float x2 = fo[D - 4], y2 = fo[D - 3], w2 = fo[D - 2], h2 = fo[D - 1];
+            const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;   // :271-272
+            const float dist = sqrtf(dx * dx + dy * dy);
+            const int g = f - 2 * D;
+            if (g == 0) v = dist;
+            else if (g == 1) v = asinf(dy / fmaxf(dist, 1e-10f));                                   // :275
+            else if (g == 2) v = (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f);            // :276
+            else v = (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f);                        // :277
+        }
+        pair[(pair_off[q] + (int64_t)s * (n - 1) + k) * ld_pair + f] = v;
+    }
+}
+
+extern "C" int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t D, const int32_t* obj_off, const int64_t* pair_off,
+                                      int32_t Q, int32_t max_n, float* pair, int64_t ld_pair, void* stream) {
+    DFOL_REQUIRE(Q >= 0 && D >= 4 && max_n >= 0 && ld_obj >= D && ld_pair >= 2 * D + 4, "pair_features: bad sizes");
+    if (Q == 0 || max_n <= 1) return 0;
+    DFOL_REQUIRE(obj && obj_off && pair_off && pair, "pair_features: null pointer");
+    hipLaunchKernelGGL(pair_features_kernel, dim3((unsigned)Q * max_n), dim3(256), 0, (hipStream_t)stream, obj, ld_obj, D, obj_off,
+                       pair_off, max_n, pair, ld_pair);
+    DFOL_LAUNCH_CHECK("pair_features");
+    return 0;
+}

@@ -1,0 +1,522 @@
+// Soft-logic kernels of the ∇-FOL interpreter for gfx950 (MI355X): HBM-bound, fp32.
+//
+// Layout: one block per predicate (include/dfol_vqa.h "BLOCK LAYOUT").  The kernels stream each
+// likelihood block exactly once with 16-byte coalesced loads, keep priors and running sums in
+// registers, reduce rows with cross-lane shuffles inside a 64-wide wavefront and never use atomics,
+// so results are deterministic.
+#include <stdarg.h>
+
+#include "dfol_common.h"
+
+static thread_local char g_err[512] = "";
+
+void dfol_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dfol_last_error(void) { return g_err; }
+extern "C" int dfol_abi_version(void) { return DFOL_ABI_VERSION; }
+
+// =====================================================================================================
+// gathers from cached tables
+// =====================================================================================================
+__global__ void attr_gather_kernel(const float* __restrict__ table, int64_t ld, const int32_t* __restrict__ obj_off,
+                                   const int32_t* __restrict__ pred_q, const int32_t* __restrict__ pred_col, int P, int NS,
+                                   float dflt, float* __restrict__ ll) {
+    const int p = blockIdx.x;
+    const int o = blockIdx.y * blockDim.x + threadIdx.x;
+    if (o >= NS) return;
+    const int q = pred_q[p];
+    const int col = pred_col[p];
+    const int first = obj_off[q];
+    const int n = obj_off[q + 1] - first;
+    float v = dflt;
+    if (col >= 0 && o < n) v = table[(int64_t)(first + o) * ld + col];
+    ll[(int64_t)p * NS + o] = v;
+}
+
+extern "C" int dfol_attr_gather_f32(const float* table, int64_t ld_table, const int32_t* obj_off, const int32_t* pred_q,
+                                    const int32_t* pred_col, int32_t P, int32_t NS, float default_ll, float* ll, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0, "attr_gather: bad sizes P=%d NS=%d (NS must be a positive multiple of 4)", P, NS);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(table && obj_off && pred_q && pred_col && ll, "attr_gather: null pointer");
+    dim3 grid(P, dfol_cdiv(NS, 64));
+    hipLaunchKernelGGL(attr_gather_kernel, grid, dim3(64), 0, (hipStream_t)stream, table, ld_table, obj_off, pred_q, pred_col, P,
+                       NS, default_ll, ll);
+    DFOL_LAUNCH_CHECK("attr_gather");
+    return 0;
+}
+
+__global__ void rel_gather_kernel(const float* __restrict__ table, int64_t ld, const int64_t* __restrict__ pair_off,
+                                  const int32_t* __restrict__ n_obj, const int32_t* __restrict__ pred_q,
+                                  const int32_t* __restrict__ pred_col, int NS, int transposed, float dflt,
+                                  float* __restrict__ tile) {
+    const int p = blockIdx.x;
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;   // element of the NS x NS tile
+    if (e >= NS * NS) return;
+    const int r = e / NS, c = e - r * NS;
+    const int q = pred_q[p];
+    const int col = pred_col[p];
+    const int n = n_obj[q];
+    const int s = transposed ? c : r, o = transposed ? r : c;
+    float v = dflt;
+    if (col >= 0 && s < n && o < n && s != o) {
+        const int64_t pair = pair_off[q] + (int64_t)s * (n - 1) + (o > s ? o - 1 : o);   // util.py:96-98 order
+        v = table[pair * ld + col];
+    }
+    tile[(int64_t)p * NS * NS + e] = v;
+}
+
+extern "C" int dfol_rel_gather_f32(const float* table, int64_t ld_table, const int64_t* pair_off, const int32_t* n_obj,
+                                   const int32_t* pred_q, const int32_t* pred_col, int32_t P, int32_t NS, int32_t orientation,
+                                   float default_ll, float* tile, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0, "rel_gather: bad sizes P=%d NS=%d", P, NS);
+    DFOL_REQUIRE(orientation == 0 || orientation == 1, "rel_gather: bad orientation %d", orientation);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(table && pair_off && n_obj && pred_q && pred_col && tile, "rel_gather: null pointer");
+    dim3 grid(P, dfol_cdiv((int64_t)NS * NS, 256));
+    hipLaunchKernelGGL(rel_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, table, ld_table, pair_off, n_obj, pred_q,
+                       pred_col, NS, orientation, default_ll, tile);
+    DFOL_LAUNCH_CHECK("rel_gather");
+    return 0;
+}
+
+// =====================================================================================================
+// option normalisation
+// =====================================================================================================
+__global__ void option_normalize_kernel(float* __restrict__ ll, const int32_t* __restrict__ seg_off,
+                                        const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, int NS, int rank) {
+    const int seg = blockIdx.x;
+    const int p0 = seg_off[seg], p1 = seg_off[seg + 1];
+    if (p1 <= p0) return;
+    const int n = n_obj[pred_q[p0]];
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;
+    const int64_t stride = rank == 2 ? (int64_t)NS * NS : NS;
+    if (rank == 2) {
+        if (e >= NS * NS) return;
+        const int r = e / NS, c = e - r * NS;
+        if (r >= n || c >= n || r == c) return;
+    } else if (e >= n) {
+        return;
+    }
+    float sum = 0.f;
+    for (int p = p0; p < p1; ++p) sum += dfol_exp(ll[p * stride + e]);
+    const float denom = dfol_slog(sum);
+    for (int p = p0; p < p1; ++p) ll[p * stride + e] -= denom;
+}
+
+extern "C" int dfol_option_normalize_f32(float* ll, const int32_t* seg_off, int32_t S, const int32_t* pred_q,
+                                         const int32_t* n_obj, int32_t NS, int32_t rank, void* stream) {
+    DFOL_REQUIRE(S >= 0 && NS > 0 && (rank == 1 || rank == 2), "option_normalize: bad arguments S=%d NS=%d rank=%d", S, NS, rank);
+    if (S == 0) return 0;
+    DFOL_REQUIRE(ll && seg_off && pred_q && n_obj, "option_normalize: null pointer");
+    const int64_t elems = rank == 2 ? (int64_t)NS * NS : NS;
+    dim3 grid(S, dfol_cdiv(elems, 128));
+    hipLaunchKernelGGL(option_normalize_kernel, grid, dim3(128), 0, (hipStream_t)stream, ll, seg_off, pred_q, n_obj, NS, rank);
+    DFOL_LAUNCH_CHECK("option_normalize");
+    return 0;
+}
+
+// =====================================================================================================
+// Filter (arity-1 logic cell)
+// =====================================================================================================
+__global__ void filter_fwd_kernel(const float* __restrict__ att_in, const float* __restrict__ ll,
+                                  const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj,
+                                  const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active, int NS,
+                                  float* __restrict__ att_out) {
+    const int p = blockIdx.x;
+    const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (c0 >= NS) return;
+    const int q = pred_q[p];
+    const int n = n_obj[q];
+    const float4 a = *reinterpret_cast<const float4*>(att_in + (int64_t)q * NS + c0);
+    float4 out = a;
+    if (active == nullptr || active[p]) {
+        const float4 l4 = *reinterpret_cast<const float4*>(ll + (int64_t)p * NS + c0);
+        float l[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        float o[4];
+        const float alpha = (any_neg && neg[p]) ? 1.f : 0.f;
+        const float cc = 1.f - 2.f * alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = fminf(l[j], 0.f);                       // batch_base_ops.py:194
+            if (any_neg) v = dfol_pnot(v, alpha, cc);         // :212-213
+            o[j] = av[j] + v;                                 // :138
+        }
+        out = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (c0 + 0 >= n) out.x = 0.f;
+    if (c0 + 1 >= n) out.y = 0.f;
+    if (c0 + 2 >= n) out.z = 0.f;
+    if (c0 + 3 >= n) out.w = 0.f;
+    *reinterpret_cast<float4*>(att_out + (int64_t)p * NS + c0) = out;
+}
+
+extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const int32_t* pred_q, const int32_t* n_obj,
+                                   const uint8_t* neg, int32_t any_neg, const uint8_t* active, int32_t P, int32_t NS,
+                                   float* att_out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0, "filter_fwd: bad sizes P=%d NS=%d", P, NS);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(att_in && ll && pred_q && n_obj && att_out, "filter_fwd: null pointer");
+    DFOL_REQUIRE(!any_neg || neg, "filter_fwd: any_neg set but neg is NULL");
+    dim3 grid(P, dfol_cdiv(NS / 4, 64));
+    hipLaunchKernelGGL(filter_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, att_in, ll, pred_q, n_obj, neg, any_neg, active,
+                       NS, att_out);
+    DFOL_LAUNCH_CHECK("filter_fwd");
+    return 0;
+}
+
+// =====================================================================================================
+// Relate (arity-2 logic cell): one wavefront per predicate tile
+// =====================================================================================================
+// Rows of the tile belong to variable R, columns to variable C (which of subject/object is which is the
+// host wrapper's business).  A lane owns four consecutive columns (one 16-byte load per row); LPR lanes
+// cover a row, so 64/LPR rows are in flight per iteration.
+//   post_R[r] = prior_R[r] + F_C( sum_{c != r} F_C(l'[r,c] + prior_C[c]) )      row sums   (cross-lane)
+//   post_C[c] = prior_C[c] + F_R( sum_{r != c} F_R(l'[r,c] + prior_R[r]) )      column sums (in-register)
+template <int LPR>
+__global__ __launch_bounds__(256) void relate_fwd_kernel(
+    const float* __restrict__ prior_R, const float* __restrict__ prior_C, const float* __restrict__ tile,
+    const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_R,
+    const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
+    const uint8_t* __restrict__ want, int want_R_bit, int want_C_bit, int P, int NS, int identity_forall,
+    float* __restrict__ post_R, float* __restrict__ post_C) {
+    constexpr int RPI = 64 / LPR;                       // rows per iteration
+    __shared__ float row_sum[4][256];                   // per-wave row sums, flushed with one coalesced store
+    const int wave_in_block = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wave_in_block;
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int q = pred_q[p];
+    const int n = n_obj[q];
+    const int wbits = want ? want[p] : 3;
+    const bool wantR = (wbits & want_R_bit) && post_R;
+    const bool wantC = (wbits & want_C_bit) && post_C;
+    const float* pR = prior_R + (int64_t)q * NS;
+    const float* pC = prior_C + (int64_t)q * NS;
+    float* oR = post_R ? post_R + (int64_t)p * NS : nullptr;
+    float* oC = post_C ? post_C + (int64_t)p * NS : nullptr;
+
+    if (active && !active[p]) {                         // no-op predicate: posterior = prior (batch_base_ops.py:563-564)
+        for (int c = lane; c < NS; c += 64) {
+            if (wantR) oR[c] = c < n ? pR[c] : 0.f;
+            if (wantC) oC[c] = c < n ? pC[c] : 0.f;
+        }
+        return;
+    }
+
+    const int cg = lane % LPR, rs = lane / LPR;
+    const int c0 = cg * 4;
+    const bool col_live = c0 < n;                        // this lane's float4 touches at least one real column
+    const float alpha_n = (any_neg && neg[p]) ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
+    const float qR = quant_R[p], qC = quant_C[p];
+    const float kR = 1.f - 2.f * qR, kC = 1.f - 2.f * qC;
+    const bool idR = identity_forall && qR == 0.f, idC = identity_forall && qC == 0.f;
+
+    float pc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < NS) {
+        const float4 t = *reinterpret_cast<const float4*>(pC + c0);
+        pc[0] = t.x; pc[1] = t.y; pc[2] = t.z; pc[3] = t.w;
+    }
+    float col_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* tp = tile + (int64_t)p * NS * NS;
+
+    for (int r0 = 0; r0 < n; r0 += RPI) {
+        const int r = r0 + rs;
+        const bool live = r < n && col_live;
+        float l[4] = {0.f, 0.f, 0.f, 0.f};
+        float pr = 0.f;
+        if (live) {
+            const float4 t = *reinterpret_cast<const float4*>(tp + (int64_t)r * NS + c0);
+            l[0] = t.x; l[1] = t.y; l[2] = t.z; l[3] = t.w;
+            pr = pR[r];
+        }
+        float row_part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const bool keep = live && c < n && c != r;        // padding and self-relations contribute 0 (:112)
+            float v = fminf(l[j], 0.f);                       // :194
+            if (any_neg) v = dfol_pnot(v, alpha_n, cn);       // :212-213
+            if (wantR) {
+                const float u = v + pc[j];                    // :102
+                const float t = idC ? u : dfol_pnot(u, qC, kC);   // :108
+                row_part += keep ? t : 0.f;
+            }
+            if (wantC) {
+                const float u = v + pr;
+                const float t = idR ? u : dfol_pnot(u, qR, kR);
+                col_acc[j] += keep ? t : 0.f;
+            }
+        }
+        if (wantR) {
+#pragma unroll
+            for (int m = LPR >> 1; m >= 1; m >>= 1) row_part += __shfl_xor(row_part, m, 64);
+            if (cg == 0 && r < n) row_sum[wave_in_block][r] = row_part;
+        }
+    }
+    if (wantR) {
+        __builtin_amdgcn_wave_barrier();                 // LDS is in-order within a wave; this only pins the schedule
+        for (int c = lane; c < NS; c += 64) {
+            float o = 0.f;
+            if (c < n) {
+                const float s = row_sum[wave_in_block][c];
+                o = pR[c] + (idC ? s : dfol_pnot(s, qC, kC));          // :133, :138
+            }
+            oR[c] = o;
+        }
+    }
+
+    if (wantC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int m = 32; m >= LPR; m >>= 1) col_acc[j] += __shfl_xor(col_acc[j], m, 64);
+        }
+        if (rs == 0 && c0 < NS) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s = col_acc[j];
+                o[j] = (c0 + j < n) ? pc[j] + (idR ? s : dfol_pnot(s, qR, kR)) : 0.f;
+            }
+            *reinterpret_cast<float4*>(oC + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int LPR>
+static void launch_relate(hipStream_t st, const float* pR, const float* pC, const float* tile, const int32_t* pred_q,
+                          const int32_t* n_obj, const float* qR, const float* qC, const uint8_t* neg, int any_neg,
+                          const uint8_t* active, const uint8_t* want, int wantRbit, int wantCbit, int P, int NS, int idf,
+                          float* oR, float* oC) {
+    hipLaunchKernelGGL(relate_fwd_kernel<LPR>, dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, pR, pC, tile, pred_q, n_obj, qR, qC, neg,
+                       any_neg, active, want, wantRbit, wantCbit, P, NS, idf, oR, oC);
+}
+
+extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q,
+                                   const int32_t* n_obj, const float* quant_s, const float* quant_o, const uint8_t* neg,
+                                   int32_t any_neg, const uint8_t* active, const uint8_t* want, int32_t P, int32_t NS,
+                                   int32_t orientation, int32_t lone_forall_identity, float* post_s, float* post_o,
+                                   void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 256, "relate_fwd: bad sizes P=%d NS=%d (NS: multiple of 4, <= 256)", P, NS);
+    DFOL_REQUIRE(orientation == 0 || orientation == 1, "relate_fwd: bad orientation %d", orientation);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(prior_s && prior_o && tile && pred_q && n_obj && quant_s && quant_o, "relate_fwd: null pointer");
+    DFOL_REQUIRE(post_s || post_o, "relate_fwd: no output requested");
+    DFOL_REQUIRE(!any_neg || neg, "relate_fwd: any_neg set but neg is NULL");
+    // rows/columns of the tile: R = subject, C = object for DFOL_TILE_SUBJECT_ROWS; swapped otherwise
+    const bool sr = orientation == DFOL_TILE_SUBJECT_ROWS;
+    const float *pR = sr ? prior_s : prior_o, *pC = sr ? prior_o : prior_s;
+    const float *qR = sr ? quant_s : quant_o, *qC = sr ? quant_o : quant_s;
+    float *oR = sr ? post_s : post_o, *oC = sr ? post_o : post_s;
+    const int bR = sr ? DFOL_WANT_SUBJECT : DFOL_WANT_OBJECT, bC = sr ? DFOL_WANT_OBJECT : DFOL_WANT_SUBJECT;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = NS / 4;
+#define DFOL_RELATE_CASE(L)                                                                                                   \
+    launch_relate<L>(st, pR, pC, tile, pred_q, n_obj, qR, qC, neg, any_neg, active, want, bR, bC, P, NS, lone_forall_identity, \
+                     oR, oC)
+    if (groups <= 1) DFOL_RELATE_CASE(1);
+    else if (groups <= 2) DFOL_RELATE_CASE(2);
+    else if (groups <= 4) DFOL_RELATE_CASE(4);
+    else if (groups <= 8) DFOL_RELATE_CASE(8);
+    else if (groups <= 16) DFOL_RELATE_CASE(16);
+    else if (groups <= 32) DFOL_RELATE_CASE(32);
+    else DFOL_RELATE_CASE(64);
+#undef DFOL_RELATE_CASE
+    DFOL_LAUNCH_CHECK("relate_fwd");
+    return 0;
+}
+
+// =====================================================================================================
+// quantifier aggregation (Exist), gate, small vector ops
+// =====================================================================================================
+__global__ __launch_bounds__(256) void quantify_fwd_kernel(const float* __restrict__ att, const float* __restrict__ quant,
+                                                           const int32_t* __restrict__ pred_q,
+                                                           const int32_t* __restrict__ n_obj, int P, int NS,
+                                                           float* __restrict__ lp) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int n = n_obj[pred_q[p]];
+    const float qf = quant[p], k = 1.f - 2.f * qf;
+    const float* a = att + (int64_t)p * NS;
+    float s = 0.f;
+    for (int o = lane; o < n; o += 64) s += dfol_pnot(a[o], qf, k);      // batch_base_types.py:116
+    s = dfol_wave_sum(s);                                                // :118-121 (bom sum)
+    if (lane == 0) lp[p] = dfol_pnot(s, qf, k);                          // :123
+}
+
+extern "C" int dfol_quantify_fwd_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
+                                     int32_t P, int32_t NS, float* lp, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0, "quantify_fwd: bad sizes P=%d NS=%d", P, NS);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(att && quant && pred_q && n_obj && lp, "quantify_fwd: null pointer");
+    hipLaunchKernelGGL(quantify_fwd_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, att, quant, pred_q, n_obj, P,
+                       NS, lp);
+    DFOL_LAUNCH_CHECK("quantify_fwd");
+    return 0;
+}
+
+__global__ void gate_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ xq,
+                            const float* __restrict__ yq, const float* __restrict__ g, int NS, float* __restrict__ out,
+                            float* __restrict__ outq) {
+    const int p = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    const float gg = g[p];
+    if (c < NS) {
+        const int64_t i = (int64_t)p * NS + c;
+        out[i] = x[i] * gg + y[i] * (1.f - gg);                         // batch_base_types.py:159
+    }
+    if (c == 0 && outq) outq[p] = xq[p] * gg + yq[p] * (1.f - gg);       // :156
+}
+
+extern "C" int dfol_gate_f32(const float* x_att, const float* y_att, const float* x_quant, const float* y_quant, const float* g,
+                             int32_t P, int32_t NS, float* out_att, float* out_quant, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0, "gate: bad sizes P=%d NS=%d", P, NS);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(x_att && y_att && g && out_att, "gate: null pointer");
+    DFOL_REQUIRE(!out_quant || (x_quant && y_quant), "gate: out_quant requested without input quantifiers");
+    hipLaunchKernelGGL(gate_kernel, dim3(P, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, x_att, y_att, x_quant, y_quant, g,
+                       NS, out_att, out_quant);
+    DFOL_LAUNCH_CHECK("gate");
+    return 0;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int width,
+                                   float* __restrict__ out) {
+    const int p = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c < width) out[(int64_t)p * width + c] = src[(int64_t)idx[p] * width + c];
+}
+
+extern "C" int dfol_gather_rows_f32(const float* src, const int32_t* idx, int32_t P, int32_t width, float* out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && width > 0, "gather_rows: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE(src && idx && out, "gather_rows: null pointer");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(P, dfol_cdiv(width, 64)), dim3(64), 0, (hipStream_t)stream, src, idx, width, out);
+    DFOL_LAUNCH_CHECK("gather_rows");
+    return 0;
+}
+
+__global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ seg_off, int width,
+                                        float* __restrict__ out) {
+    const int q = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int p = seg_off[q]; p < seg_off[q + 1]; ++p) s += src[(int64_t)p * width + c];
+    out[(int64_t)q * width + c] = s;
+}
+
+extern "C" int dfol_segment_sum_rows_f32(const float* src, const int32_t* seg_off, int32_t Q, int32_t width, float* out,
+                                         void* stream) {
+    DFOL_REQUIRE(Q >= 0 && width > 0, "segment_sum_rows: bad sizes");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(src && seg_off && out, "segment_sum_rows: null pointer");
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(Q, dfol_cdiv(width, 64)), dim3(64), 0, (hipStream_t)stream, src, seg_off,
+                       width, out);
+    DFOL_LAUNCH_CHECK("segment_sum_rows");
+    return 0;
+}
+
+__global__ void logic_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    float r;
+    if (op == DFOL_LOGIC_AND) r = x + b[i];                                                            // util.py:29-30
+    else if (op == DFOL_LOGIC_OR) r = dfol_slog(1.f - (1.f - dfol_exp(x)) * (1.f - dfol_exp(b[i])));   // util.py:32-33
+    else r = dfol_lnot(x);                                                                             // util.py:35-36
+    out[i] = r;
+}
+
+extern "C" int dfol_logic_f32(int32_t op, const float* a, const float* b, int64_t n, float* out, void* stream) {
+    DFOL_REQUIRE(op >= 0 && op <= 2 && n >= 0, "logic: bad arguments op=%d", op);
+    if (n == 0) return 0;
+    DFOL_REQUIRE(a && out && (op == DFOL_LOGIC_NOT || b), "logic: null pointer");
+    hipLaunchKernelGGL(logic_kernel, dim3(dfol_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n, out);
+    DFOL_LAUNCH_CHECK("logic");
+    return 0;
+}
+
+__global__ void parametric_not_kernel(const float* __restrict__ x, const float* __restrict__ alpha, int width,
+                                      float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    const float a = alpha[r];
+    out[(int64_t)r * width + c] = dfol_pnot(x[(int64_t)r * width + c], a, 1.f - 2.f * a);
+}
+
+extern "C" int dfol_parametric_not_f32(const float* x, const float* alpha, int32_t rows, int32_t width, float* out, void* stream) {
+    DFOL_REQUIRE(rows >= 0 && width > 0, "parametric_not: bad sizes");
+    if (rows == 0) return 0;
+    DFOL_REQUIRE(x && alpha && out, "parametric_not: null pointer");
+    hipLaunchKernelGGL(parametric_not_kernel, dim3(rows, dfol_cdiv(width, 64)), dim3(64), 0, (hipStream_t)stream, x, alpha, width, out);
+    DFOL_LAUNCH_CHECK("parametric_not");
+    return 0;
+}
+
+__global__ void segment_or_kernel(const float* __restrict__ lp, const int32_t* __restrict__ seg_off, int Q, float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float s = 0.f;
+    for (int p = seg_off[q]; p < seg_off[q + 1]; ++p) s += dfol_lnot(lp[p]);
+    out[q] = dfol_lnot(s);
+}
+
+extern "C" int dfol_segment_or_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream) {
+    DFOL_REQUIRE(Q >= 0, "segment_or: bad sizes");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(lp && seg_off && out, "segment_or: null pointer");
+    hipLaunchKernelGGL(segment_or_kernel, dim3(dfol_cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, lp, seg_off, Q, out);
+    DFOL_LAUNCH_CHECK("segment_or");
+    return 0;
+}
+
+__global__ void implication_kernel(const float* __restrict__ prior, const float* __restrict__ x, const int32_t* __restrict__ pred_q,
+                                   const int32_t* __restrict__ n_obj, int NS, float* __restrict__ out) {
+    const int p = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= NS) return;
+    const int q = pred_q[p];
+    float r = 0.f;
+    if (c < n_obj[q]) r = dfol_lnot(prior[(int64_t)q * NS + c] + dfol_lnot(x[(int64_t)p * NS + c]));   // batch_gqa_ops.py:588-589
+    out[(int64_t)p * NS + c] = r;
+}
+
+extern "C" int dfol_implication_f32(const float* prior, const float* x, const int32_t* pred_q, const int32_t* n_obj, int32_t P,
+                                    int32_t NS, float* out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0, "implication: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE(prior && x && pred_q && n_obj && out, "implication: null pointer");
+    hipLaunchKernelGGL(implication_kernel, dim3(P, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, prior, x, pred_q, n_obj, NS, out);
+    DFOL_LAUNCH_CHECK("implication");
+    return 0;
+}
+
+__global__ void compare_kernel(const float* __restrict__ lp1, const float* __restrict__ lp2, const float* __restrict__ is_less, int Q,
+                               float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const float a = lp1[q], b = lp2[q];
+    const float m = fmaxf(a, b);
+    const float lse = m + logf(expf(a - m) + expf(b - m));               // nn.LogSoftmax(dim=1), batch_gqa_ops.py:735
+    const float al = is_less[q], k = 1.f - 2.f * al;
+    out[2 * q + 0] = dfol_pnot(a - lse, al, k);                          // :737-738
+    out[2 * q + 1] = dfol_pnot(b - lse, al, k);
+}
+
+extern "C" int dfol_compare_f32(const float* lp1, const float* lp2, const float* is_less, int32_t Q, float* out, void* stream) {
+    DFOL_REQUIRE(Q >= 0, "compare: bad sizes");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(lp1 && lp2 && is_less && out, "compare: null pointer");
+    hipLaunchKernelGGL(compare_kernel, dim3(dfol_cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, lp1, lp2, is_less, Q, out);
+    DFOL_LAUNCH_CHECK("compare");
+    return 0;
+}

@@ -1,0 +1,193 @@
+/*
+ * dfol_vqa.h — C ABI of the MI355X-native ∇-FOL (DFOL-VQA) interpreter hot path.
+ *
+ * The reference (microsoft/DFOL-VQA) is pure Python/PyTorch: it has no FFI of its own for this
+ * path.  Each entry point below therefore names the reference *Python* interface it replaces
+ * (file:line under /root/reference/src/nsvqa), and INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add at that line to call it.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers into memory the caller owns, unless the name ends in `_host`.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work.
+ *  - Return value: 0 on success; nonzero on error, with a message in dfol_last_error()
+ *    (thread-local).  Nothing is written on an argument error.
+ *  - BLOCK LAYOUT.  The reference keeps one flat attention row over all objects of a ProgramBatch
+ *    ([P, total_obj], and [P, total_obj, total_obj] relation likelihoods with every cross-image
+ *    entry at the default -30).  Here every predicate p owns one block:
+ *        attention / attribute likelihood : float [P, NS]        (object o of image q at column o)
+ *        relation likelihood tile         : float [P, NS, NS]    (tile[p][r][c])
+ *    with NS >= max objects per image the row stride (NS % 4 == 0), n_obj[q] the true object count
+ *    of image q and pred_q[p] the question/image that predicate p belongs to.  Columns >= n_obj
+ *    are padding: never read, written as 0 (log 1) by the kernels that produce attention.
+ *  - Log-space constants are the reference's: absent likelihood -30 (batch_base_ops.py:154),
+ *    floor log(1e-20) (util.py:22-25), quantifier 1 = EXISTS / 0 = FOR_ALL (batch_base_types.py:15-17).
+ *  - Precision: fp32 arithmetic throughout ("f32" suffix).
+ */
+#ifndef DFOL_VQA_H
+#define DFOL_VQA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFOL_ABI_VERSION 1
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int dfol_abi_version(void);
+const char* dfol_last_error(void);
+
+/* tile orientation for relation likelihoods */
+#define DFOL_TILE_SUBJECT_ROWS 0 /* tile[p][s][o]  (the reference's [P, O(subject), O(object)]) */
+#define DFOL_TILE_OBJECT_ROWS 1  /* tile[p][o][s]  (transposed) */
+
+/* which posteriors dfol_relate_fwd_f32 must produce, per predicate (bit mask) */
+#define DFOL_WANT_SUBJECT 1
+#define DFOL_WANT_OBJECT 2
+
+/* activations for dfol_linear_act_f32 */
+#define DFOL_ACT_NONE 0
+#define DFOL_ACT_SIGMOID 1    /* nn.Sigmoid     */
+#define DFOL_ACT_ELU 2        /* nn.ELU(alpha=1) */
+#define DFOL_ACT_LOGSIGMOID 3 /* nn.LogSigmoid  */
+
+/* binary / unary log-space ops for dfol_logic_*_f32 */
+#define DFOL_LOGIC_AND 0 /* util.py:29-30 */
+#define DFOL_LOGIC_OR 1  /* util.py:32-33 */
+#define DFOL_LOGIC_NOT 2 /* util.py:35-36 */
+
+/* ---- oracle gathers (cached tables) -------------------------------------------------------------
+ * Replaces ClassifierOracle._compute_attribute_log_likelihood, classifier_oracle.py:44-82
+ * (cached=True branch :62-63 and the dense reshape :78-80), without the option normalisation.
+ *   table    [O, ld_table]   cached attribute log-likelihood table (world._attribute_features)
+ *   obj_off  [Q+1]           first object row of every image (prefix sum of n_obj)
+ *   pred_q   [P]             image of predicate p            (attribute_image_map)
+ *   pred_col [P]             column = arg_to_idx[token]-1 ; < 0 marks a no-op token (None / '_'),
+ *                            whose block is filled with default_ll (batch_base_ops.py:364)
+ *   ll       [P, NS]   out   ll[p][o] = table[obj_off[q]+o][col] for o < n_obj[q]; padding = default_ll
+ */
+int dfol_attr_gather_f32(const float* table, int64_t ld_table, const int32_t* obj_off, const int32_t* pred_q,
+                         const int32_t* pred_col, int32_t P, int32_t NS, float default_ll, float* ll, void* stream);
+
+/* Replaces ClassifierOracle._compute_relation_log_likelihood, classifier_oracle.py:84-137
+ * (cached=True, the non-`relation_pairobject_map` branch :113-135), without the option normalisation.
+ *   table    [pairs, ld_table]  cached relation table; pairs of image q start at pair_off[q] and are
+ *                               the ordered (s,o), s != o pairs, row-major in s (util.py:87-103)
+ *   pair_off [Q+1]              int64 prefix sum of n(n-1)
+ *   pred_col [P]                column in the 333-wide relation table (_relation_reveresed_index); <0 = no-op
+ *   tile     [P, NS, NS]  out   tile[p][s][o] (or [o][s] if orientation == DFOL_TILE_OBJECT_ROWS);
+ *                               diagonal, padding and no-op blocks = default_ll
+ */
+int dfol_rel_gather_f32(const float* table, int64_t ld_table, const int64_t* pair_off, const int32_t* n_obj,
+                        const int32_t* pred_q, const int32_t* pred_col, int32_t P, int32_t NS, int32_t orientation,
+                        float default_ll, float* tile, void* stream);
+
+/* Option normalisation: classifier_oracle.py:72-75 and :124-127 with _build_map :22-42.
+ * A segment is a run of consecutive predicates of one question (torch.unique_consecutive of the image map).
+ *   ll[p][e] -= log(max(sum_{p' in seg(p)} exp(ll[p'][e]), 1e-20))   for every real entry e of the block
+ *   seg_off [S+1]  predicate range of every segment;   rank: 1 = [P,NS] blocks, 2 = [P,NS,NS] tiles
+ * For rank 2 only real pairs (r != c, both < n_obj) are touched (the reference normalises over pairs,
+ * classifier_oracle.py:121-127, and fills the diagonal afterwards).  In place.
+ */
+int dfol_option_normalize_f32(float* ll, const int32_t* seg_off, int32_t S, const int32_t* pred_q, const int32_t* n_obj,
+                              int32_t NS, int32_t rank, void* stream);
+
+/* ---- the logic cell -----------------------------------------------------------------------------
+ * Arity 1: replaces BatchBayesianLogicCell.forward/_forward_core for FilterBatch,
+ * batch_base_ops.py:153-215, 62-151 (ll clamp :194, negation :212-213, log-AND with the prior :138)
+ * and the no-op row restore of FilterBatch.forward :385.
+ *   att_in   [Q, NS]  prior attention, row pred_q[p] is read for predicate p
+ *   ll       [P, NS]  raw likelihood block
+ *   neg      [P]      1 = predicate is negated ("not(x)"); may be NULL when any_neg == 0
+ *   any_neg           the reference applies log_parametric_not(ll, is_negated, 1) to EVERY predicate
+ *                     of an op batch as soon as one is negated (:212-213, :376-380)
+ *   active   [P]      0 = no-op token: the output row is the prior row (:385); may be NULL (all active)
+ *   att_out  [P, NS]  out; padding columns (>= n_obj) are written as 0
+ */
+int dfol_filter_fwd_f32(const float* att_in, const float* ll, const int32_t* pred_q, const int32_t* n_obj,
+                        const uint8_t* neg, int32_t any_neg, const uint8_t* active, int32_t P, int32_t NS,
+                        float* att_out, void* stream);
+
+/* Arity 2: replaces BatchBayesianLogicCell.forward/_forward_core for RelateBatch,
+ * batch_base_ops.py:153-215, 62-151, and the no-op row restore of RelateBatch.forward :563-564.
+ * Per predicate, with l' = negation(min(tile,0)), E the off-diagonal:
+ *   post_s[s] = prior_s[s] + F_o( sum_{o != s} F_o(l'[s,o] + prior_o[o]) )
+ *   post_o[o] = prior_o[o] + F_s( sum_{s != o} F_s(l'[s,o] + prior_s[s]) )
+ *   F_x(v) = log(max(q_x + (1-2 q_x) e^v, 1e-20)),  q_x the quantifier of the variable summed out.
+ *   prior_s, prior_o [Q, NS]   row pred_q[p] is read
+ *   tile             [P, NS, NS] in `orientation`
+ *   quant_s, quant_o [P]       quantifiers (float 0/1) of the subject / object variable
+ *   want             [P]       DFOL_WANT_* bits; an unwanted posterior row is left untouched.  NULL = both.
+ *   post_s, post_o   [P, NS]   out (either may be NULL if no predicate wants it)
+ *   lone_forall_identity       1 reproduces the reference's single-predicate literal branch
+ *                              (:104-108,:129-133: P == 1 and FOR_ALL leaves the value untouched)
+ */
+int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q,
+                        const int32_t* n_obj, const float* quant_s, const float* quant_o, const uint8_t* neg,
+                        int32_t any_neg, const uint8_t* active, const uint8_t* want, int32_t P, int32_t NS,
+                        int32_t orientation, int32_t lone_forall_identity, float* post_s, float* post_o, void* stream);
+
+/* Soft quantifier aggregation: replaces BatchVariableSet.log_probability (soft mode),
+ * batch_base_types.py:113-123:   lp[p] = F_q( sum_{o < n} F_q(att[p][o]) ),  q = quant[p].
+ */
+int dfol_quantify_fwd_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
+                          int32_t P, int32_t NS, float* lp, void* stream);
+
+/* Per-question select between two variable sets: replaces BatchVariableSet.gate,
+ * batch_base_types.py:149-168.   out = g*x + (1-g)*y  on attention rows and quantifiers, g in {0,1}.
+ *   x_att, y_att [P, NS]; x_quant, y_quant [P]; g [P] (float, as the reference's mask)
+ */
+int dfol_gate_f32(const float* x_att, const float* y_att, const float* x_quant, const float* y_quant, const float* g,
+                  int32_t P, int32_t NS, float* out_att, float* out_quant, void* stream);
+
+/* Row gather: out[p][:] = src[idx[p]][:]  (the reference's mm(predicate_question_map, X), e.g.
+ * batch_base_ops.py:75,343 and batch_gqa_ops.py:588) for rows of `width` floats. */
+int dfol_gather_rows_f32(const float* src, const int32_t* idx, int32_t P, int32_t width, float* out, void* stream);
+
+/* Segmented row sum: out[q][:] = sum_{p in seg q} src[p][:]   (mm(pqm^T, X), batch_gqa_ops.py:457). */
+int dfol_segment_sum_rows_f32(const float* src, const int32_t* seg_off, int32_t Q, int32_t width, float* out,
+                              void* stream);
+
+/* Elementwise log-space logic on vectors: util.py:29-36.  b is ignored for DFOL_LOGIC_NOT. */
+int dfol_logic_f32(int32_t op, const float* a, const float* b, int64_t n, float* out, void* stream);
+
+/* log_parametric_not(x, alpha, 1) with a per-row alpha (util.py:46-47): x [rows, width], alpha [rows]. */
+int dfol_parametric_not_f32(const float* x, const float* alpha, int32_t rows, int32_t width, float* out, void* stream);
+
+/* Segmented log-OR: out[q] = log_not( sum_{p in seg q} log_not(lp[p]) ), batch_gqa_ops.py:597-598, :664-665. */
+int dfol_segment_or_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream);
+
+/* all_same implication, batch_gqa_ops.py:588-589:  out = log_not(prior[pred_q[p]] + log_not(x))  on [P, NS]. */
+int dfol_implication_f32(const float* prior, const float* x, const int32_t* pred_q, const int32_t* n_obj, int32_t P,
+                         int32_t NS, float* out, void* stream);
+
+/* compare, batch_gqa_ops.py:734-738: out[q][0..1] = log_parametric_not(log_softmax([lp1[q], lp2[q]]), is_less[q], 1) */
+int dfol_compare_f32(const float* lp1, const float* lp2, const float* is_less, int32_t Q, float* out, void* stream);
+
+/* ---- dense contractions (MFMA) ------------------------------------------------------------------
+ * Y = act(X W^T + b): replaces the nn.Linear + activation stages of RegularMLP / EmbeddingLayer,
+ * gqa_interpreter_experiments.py:26-33, 73-74.  Exact fp32 (v_mfma_f32_32x32x2_f32).
+ *   X [M, ldx] (K used), W [N, ldw] (torch Linear layout), bias [N] or NULL, Y [M, ldy]
+ */
+int dfol_linear_act_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                        int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+
+/* Box positional features: replaces batch_gqa_boxfeatures_pipeline.py:208-211.
+ *   raw [O, ld_raw]: the last 6 columns (ending at column `raw_cols`) are (W, H, x, y, w, h);
+ *   writes pos = (x, y, w, h) / max((W, H, W, H), 1) into obj[:, pos_col .. pos_col+3].
+ */
+int dfol_box_positions_f32(const float* raw, int64_t ld_raw, int32_t raw_cols, int32_t O, float* obj, int64_t ld_obj,
+                           int32_t pos_col, void* stream);
+
+/* Pair features: replaces batch_gqa_boxfeatures_pipeline.py:252-279 (same-image ordered pairs, s != o).
+ *   obj [O, ld_obj] with D = feat_dim + 4 used columns whose last 4 are the positional features;
+ *   pair [pairs, 2D + 4] out = [obj_s, obj_o, distance, asin(dy / max(distance, 1e-10)), sign(x_o-x_s), sign(y_o-y_s)]
+ */
+int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t D, const int32_t* obj_off, const int64_t* pair_off,
+                           int32_t Q, int32_t max_n, float* pair, int64_t ld_pair, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFOL_VQA_H */

@@ -1,0 +1,346 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (oracle/dfol_oracle.py) on seeded inputs.
+
+The candidate is always called through the C-ABI library (dfol_vqa_amd._lib -> libdfolvqa.so).
+Yardstick: the oracle in fp64 is the truth, the oracle in fp32 measures how much rounding noise an
+fp32 evaluation of the reference's formulas carries (tests/golden_util.check_logprob).
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+from oracle import dfol_oracle as orc  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dfol_vqa_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return _lib
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def ns_of(n_max):
+    return max(4, (int(n_max) + 3) // 4 * 4)
+
+
+def scene_arrays(n_list, C=11, CR=5, seed=0, family="mix10"):
+    rng = np.random.RandomState(seed)
+    A = np.concatenate([syn.table_log_likelihood(rng, (n, C), family) for n in n_list])
+    R = np.concatenate([syn.table_log_likelihood(rng, (n * (n - 1), CR), family) for n in n_list])
+    img = np.repeat(np.arange(len(n_list)), n_list)
+    obj_off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
+    pair_off = np.concatenate([[0], np.cumsum([n * (n - 1) for n in n_list])]).astype(np.int64)
+    return A, R, img, obj_off, pair_off
+
+
+def block_rows(flat, img, pq, n_list, NS, fill=0.0):
+    """[P, O] flat rows -> [P, NS] blocks (own image only)."""
+    out = np.full((len(pq), NS), fill, flat.dtype)
+    for p, q in enumerate(pq):
+        idx = np.nonzero(img == q)[0]
+        out[p, :len(idx)] = flat[p, idx]
+    return out
+
+
+def block_tiles(flat, img, pq, NS, fill=-30.0, transpose=False):
+    out = np.full((len(pq), NS, NS), fill, flat.dtype)
+    for p, q in enumerate(pq):
+        idx = np.nonzero(img == q)[0]
+        t = flat[p][np.ix_(idx, idx)]
+        out[p, :len(idx), :len(idx)] = t.T if transpose else t
+    return out
+
+
+class FakeOntology(object):
+    def __init__(self, C, CR):
+        self.arg_to_idx = {"c%d" % i: i + 1 for i in range(C)}
+        self.relation_reversed = {i: i % CR for i in range(C)}
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_gathers_and_normalize(L):
+    n_list = [5, 1, 8, 3]
+    C, CR = 11, 5
+    A, R, img, obj_off, pair_off = scene_arrays(n_list, C, CR, 1)
+    NS = ns_of(max(n_list))
+    pq = np.array([0, 0, 1, 2, 2, 2, 3], np.int32)
+    cols = np.array([3, 7, 0, 10, 2, 5, 9], np.int32)
+    world = orc.World(FakeOntology(C, CR), A, R, img, np.float32, normalize=False)
+    toks = ["c%d" % c for c in cols]
+    ref = orc.attribute_log_likelihood(world, toks, pq)[:, :, 0]
+    got = L.attr_gather(dev(A), dev(obj_off), dev(pq), dev(cols), NS).cpu().numpy()
+    assert np.array_equal(got, block_rows(ref, img, pq, n_list, NS, -30.0))
+    # a no-op column gives an all-default block
+    cols2 = cols.copy()
+    cols2[2] = -1
+    got2 = L.attr_gather(dev(A), dev(obj_off), dev(pq), dev(cols2), NS).cpu().numpy()
+    assert np.all(got2[2] == -30.0) and np.array_equal(got2[3], got[3])
+
+    rcols = (cols % CR).astype(np.int32)
+    refR = orc.relation_log_likelihood(world, toks, pq)[:, :, :, 0]
+    n_obj = np.array(n_list, np.int32)
+    for orient in (0, 1):
+        gotR = L.rel_gather(dev(R), dev(pair_off), dev(n_obj), dev(pq), dev(rcols), NS, orient).cpu().numpy()
+        assert np.array_equal(gotR, block_tiles(refR, img, pq, NS, -30.0, transpose=bool(orient)))
+
+    # option normalisation over segments {0,1} {2} {3,4,5} {6}
+    seg = np.array([0, 2, 3, 6, 7], np.int32)
+    world_n = orc.World(FakeOntology(C, CR), A, R, img, np.float32, normalize=True)
+    world_64 = orc.World(FakeOntology(C, CR), A, R, img, np.float64, normalize=True)
+    for rank in (1, 2):
+        if rank == 1:
+            r32 = orc.attribute_log_likelihood(world_n, toks, pq)[:, :, 0]
+            r64 = orc.attribute_log_likelihood(world_64, toks, pq)[:, :, 0]
+            t = L.attr_gather(dev(A), dev(obj_off), dev(pq), dev(cols), NS)
+            conv = lambda x: block_rows(x, img, pq, n_list, NS, -30.0)
+        else:
+            r32 = orc.relation_log_likelihood(world_n, toks, pq)[:, :, :, 0]
+            r64 = orc.relation_log_likelihood(world_64, toks, pq)[:, :, :, 0]
+            t = L.rel_gather(dev(R), dev(pair_off), dev(n_obj), dev(pq), dev(rcols), NS, 0)
+            conv = lambda x: block_tiles(x, img, pq, NS, -30.0)
+        L.option_normalize_(t, dev(seg), dev(pq), dev(n_obj), NS)
+        got = t.cpu().numpy()
+        b32, b64 = conv(r32), conv(r64)
+        # padding / diagonal untouched (stay at the default)
+        assert np.array_equal(got == -30.0, b32 == -30.0)
+        assert np.allclose(got, b64, rtol=0, atol=2e-5)
+
+
+def _logic_inputs(rng, n_list, k_list, family="mix10"):
+    Q = len(n_list)
+    pq = np.repeat(np.arange(Q), k_list).astype(np.int32)
+    NS = ns_of(max(n_list))
+    P = len(pq)
+    prior_s = np.zeros((Q, NS), np.float32)
+    prior_o = np.zeros((Q, NS), np.float32)
+    tile = np.full((P, NS, NS), -30, np.float32)
+    ll1 = np.full((P, NS), -30, np.float32)
+    for q, n in enumerate(n_list):
+        prior_s[q, :n] = np.minimum(syn.table_log_likelihood(rng, (n,), "unif") * 0.3, 0)
+        prior_o[q, :n] = np.minimum(syn.table_log_likelihood(rng, (n,), "unif") * 0.3, 0)
+    for p in range(P):
+        n = n_list[pq[p]]
+        t = syn.table_log_likelihood(rng, (n, n), family)
+        t[np.arange(n), np.arange(n)] = -30
+        tile[p, :n, :n] = t
+        ll1[p, :n] = syn.table_log_likelihood(rng, (n,), family)
+    return pq, NS, prior_s, prior_o, tile, ll1
+
+
+@pytest.mark.parametrize("n_list,k_list", [([5, 1, 8, 3], [1, 1, 1, 1]), ([36, 36], [1, 2]), ([100, 37, 64, 2], [2, 1, 1, 3]),
+                                           ([7], [1]), ([130, 256], [1, 1])])
+def test_filter_relate_quantify(L, n_list, k_list):
+    rng = np.random.RandomState(sum(n_list))
+    pq, NS, prior_s, prior_o, tile, ll1 = _logic_inputs(rng, n_list, k_list)
+    P, Q = len(pq), len(n_list)
+    n_obj = np.array(n_list, np.int32)
+    quant = (rng.uniform(size=(Q, 2)) < 0.6).astype(np.float32)[pq]
+    for any_neg in (False, True):
+        neg = (rng.uniform(size=P) < 0.5).astype(np.uint8) if any_neg else None
+        active = np.ones(P, np.uint8)
+        if P > 2:
+            active[1] = 0
+        # ---- filter
+        got = L.filter_fwd(dev(prior_s), dev(ll1), dev(pq), dev(n_obj), None if neg is None else dev(neg), dev(active)).cpu().numpy()
+        for p in range(P):
+            n = n_list[pq[p]]
+            if not active[p]:
+                assert np.array_equal(got[p, :n], prior_s[pq[p], :n])
+                continue
+            outs = []
+            for dt in (np.float32, np.float64):
+                l = np.minimum(ll1[p, :n].astype(dt), 0)
+                if any_neg:
+                    l = orc.log_parametric_not(l, dt(neg[p]), 1)
+                outs.append(prior_s[pq[p], :n].astype(dt) + l)
+            gu.check_logprob(got[p, :n], outs[0], outs[1], "filter")
+            assert np.all(got[p, n:] == 0)
+        # ---- relate, both orientations, with want masks
+        want = np.array([[3, 1, 2][i % 3] for i in range(P)], np.uint8)
+        for orient in (0, 1):
+            t_in = tile if orient == 0 else np.ascontiguousarray(tile.transpose(0, 2, 1))
+            ps, po = L.relate_fwd(dev(prior_s), dev(prior_o), dev(t_in), dev(pq), dev(n_obj), dev(quant[:, 0]), dev(quant[:, 1]),
+                                  None if neg is None else dev(neg), dev(active), dev(want), orient)
+            # poison check: unwanted rows are left untouched, so pre-fill and compare wanted rows only
+            ps, po = ps.cpu().numpy(), po.cpu().numpy()
+            for p in range(P):
+                q, n = pq[p], n_list[pq[p]]
+                if not active[p]:
+                    if want[p] & 1:
+                        assert np.array_equal(ps[p, :n], prior_s[q, :n])
+                    if want[p] & 2:
+                        assert np.array_equal(po[p, :n], prior_o[q, :n])
+                    continue
+                if n < 2:
+                    continue
+                r = [orc.relate_block(prior_s[q, :n].astype(dt), prior_o[q, :n].astype(dt), tile[p, :n, :n].astype(dt),
+                                      quant[p, 0], quant[p, 1], 0.0 if neg is None else float(neg[p]), any_neg)
+                     for dt in (np.float32, np.float64)]
+                if want[p] & 1:
+                    gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "relate post_s orient %d" % orient, lp_tol=2e-4)
+                    assert np.all(ps[p, n:] == 0)
+                if want[p] & 2:
+                    gu.check_logprob(po[p, :n], r[0][1], r[1][1], "relate post_o orient %d" % orient, lp_tol=2e-4)
+                    assert np.all(po[p, n:] == 0)
+        # ---- quantify
+        att = np.zeros((P, NS), np.float32)
+        for p in range(P):
+            att[p, :n_list[pq[p]]] = prior_o[pq[p], :n_list[pq[p]]] * 3
+        lp = L.quantify_fwd(dev(att), dev(quant[:, 0]), dev(pq), dev(n_obj)).cpu().numpy()
+        refs = []
+        for dt in (np.float32, np.float64):
+            r = []
+            for p in range(P):
+                a = att[p, :n_list[pq[p]]].astype(dt)
+                r.append(orc.log_parametric_not(orc.log_parametric_not(a, dt(quant[p, 0]), 1).sum(keepdims=True), dt(quant[p, 0]), 1)[0])
+            refs.append(np.array(r))
+        gu.check_logprob(lp, refs[0], refs[1], "quantify")
+
+
+def test_relate_lone_forall(L):
+    rng = np.random.RandomState(5)
+    pq, NS, prior_s, prior_o, tile, _ = _logic_inputs(rng, [6], [1])
+    n_obj = np.array([6], np.int32)
+    quant = np.array([[0.0, 1.0]], np.float32)
+    ps, po = L.relate_fwd(dev(prior_s), dev(prior_o), dev(tile), dev(pq), dev(n_obj), dev(quant[:, 0]), dev(quant[:, 1]),
+                          lone_forall_identity=True)
+    bom = np.ones((1, 6), np.float64)
+    prior = np.stack([prior_s[:, :6], prior_o[:, :6]], 1).astype(np.float64)
+    ref = orc.logic_cell(prior, tile[:, :6, :6, None].astype(np.float64), quant.astype(np.float64), bom)
+    assert np.allclose(ps.cpu().numpy()[0, :6], ref[0, 0], atol=2e-5)
+    assert np.allclose(po.cpu().numpy()[0, :6], ref[0, 1], atol=2e-5)
+
+
+def test_g2_goldens_through_kernels(L):
+    """The reference's own BatchBayesianLogicCell outputs (flat layout) reproduced by the block kernels."""
+    a, meta = gu.load("g2_logic_cell")
+    for case in meta["cases"]:
+        n = case["name"]
+        img, pq = a[n + "_img"], a[n + "_pq"].astype(np.int32)
+        n_list = case["n"]
+        NS = ns_of(max(n_list))
+        neg = a[n + "_neg"].astype(np.uint8) if (n + "_neg") in a.files else None
+        prior, ll, quant = a[n + "_prior"], a[n + "_ll"], a[n + "_quant"]
+        Q = len(n_list)
+        ident = np.arange(Q)
+        n_obj = np.array(n_list, np.int32)
+        own = img[None, :] == pq[:, None]
+        if case["arity"] == 1:
+            got = L.filter_fwd(dev(block_rows(prior[:, 0, :], img, ident, n_list, NS)), dev(block_rows(ll[:, :, 0], img, pq, n_list, NS, -30.0)),
+                               dev(pq), dev(n_obj), None if neg is None else dev(neg)).cpu().numpy()
+            gu.check_logprob(np.concatenate([got[p, :n_list[pq[p]]] for p in range(len(pq))]), a[n + "_out_f32"][:, 0, :][own],
+                             a[n + "_out_f64"][:, 0, :][own], n, lp_tol=2e-4)
+            continue
+        lone = len(pq) == 1
+        ps, po = L.relate_fwd(dev(block_rows(prior[:, 0, :], img, ident, n_list, NS)), dev(block_rows(prior[:, 1, :], img, ident, n_list, NS)),
+                              dev(block_tiles(ll[:, :, :, 0], img, pq, NS)), dev(pq), dev(n_obj), dev(quant[:, 0]), dev(quant[:, 1]),
+                              None if neg is None else dev(neg), lone_forall_identity=lone)
+        for k, got in ((0, ps.cpu().numpy()), (1, po.cpu().numpy())):
+            flat = np.concatenate([got[p, :n_list[pq[p]]] for p in range(len(pq))])
+            if "stress" in n:
+                assert np.abs(np.exp(flat) - np.exp(a[n + "_out_f32"][:, k, :][own])).max() <= 2e-6
+            else:
+                gu.check_logprob(flat, a[n + "_out_f32"][:, k, :][own], a[n + "_out_f64"][:, k, :][own], n, lp_tol=2e-4)
+
+
+def test_small_vector_ops(L):
+    rng = np.random.RandomState(3)
+    P, NS, Q = 37, 12, 9
+    x = -rng.gamma(1.0, 1.5, (P, NS)).astype(np.float32)
+    y = -rng.gamma(1.0, 1.5, (P, NS)).astype(np.float32)
+    xq, yq = (rng.uniform(size=P) < 0.5).astype(np.float32), (rng.uniform(size=P) < 0.5).astype(np.float32)
+    g = (rng.uniform(size=P) < 0.5).astype(np.float32)
+    o, oq = L.gate(dev(x), dev(y), dev(xq), dev(yq), dev(g))
+    assert np.array_equal(o.cpu().numpy(), np.where(g[:, None] > 0, x, y))
+    assert np.array_equal(oq.cpu().numpy(), np.where(g > 0, xq, yq))
+    idx = rng.randint(0, P, 50).astype(np.int32)
+    assert np.array_equal(L.gather_rows(dev(x), dev(idx)).cpu().numpy(), x[idx])
+    seg = np.sort(rng.choice(np.arange(1, P), Q - 1, replace=False))
+    seg_off = np.concatenate([[0], seg, [P]]).astype(np.int32)
+    ref = np.stack([x[seg_off[i]:seg_off[i + 1]].astype(np.float64).sum(0) for i in range(Q)])
+    assert np.allclose(L.segment_sum_rows(dev(x), dev(seg_off)).cpu().numpy(), ref, atol=1e-5)
+    a, b = x[:, 0].copy(), y[:, 0].copy()
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    assert np.array_equal(L.logic(L.LOGIC_AND, dev(a), dev(b)).cpu().numpy(), a + b)
+    gu.check_logprob(L.logic(L.LOGIC_OR, dev(a), dev(b)).cpu().numpy(), orc.log_or(a, b), orc.log_or(a64, b64), "or")
+    gu.check_logprob(L.logic(L.LOGIC_NOT, dev(a)).cpu().numpy(), orc.log_not(a), orc.log_not(a64), "not")
+    gu.check_logprob(L.parametric_not(dev(x), dev(g)).cpu().numpy(), orc.log_parametric_not(x, g[:, None], 1),
+                     orc.log_parametric_not(x.astype(np.float64), g[:, None].astype(np.float64), 1), "pnot")
+    so = L.segment_or(dev(a), dev(seg_off)).cpu().numpy()
+    r32 = np.array([orc.log_not(orc.log_not(a[seg_off[i]:seg_off[i + 1]]).sum(keepdims=True))[0] for i in range(Q)])
+    r64 = np.array([orc.log_not(orc.log_not(a64[seg_off[i]:seg_off[i + 1]]).sum(keepdims=True))[0] for i in range(Q)])
+    gu.check_logprob(so, r32, r64, "segment_or")
+    pq = rng.randint(0, Q, P).astype(np.int32)
+    n_obj = rng.randint(1, NS + 1, Q).astype(np.int32)
+    prior = -rng.gamma(1.0, 1.0, (Q, NS)).astype(np.float32)
+    imp = L.implication(dev(prior), dev(x), dev(pq), dev(n_obj)).cpu().numpy()
+    for p in range(P):
+        n = n_obj[pq[p]]
+        r32 = orc.log_not(prior[pq[p], :n] + orc.log_not(x[p, :n]))
+        r64 = orc.log_not(prior[pq[p], :n].astype(np.float64) + orc.log_not(x[p, :n].astype(np.float64)))
+        gu.check_logprob(imp[p, :n], r32, r64, "implication")
+        assert np.all(imp[p, n:] == 0)
+    less = (rng.uniform(size=P) < 0.5).astype(np.float32)
+    cmp_ = L.compare(dev(a), dev(b), dev(less)).cpu().numpy()
+    st = np.stack([a64, b64], 1)
+    ls = st - np.log(np.exp(st).sum(1, keepdims=True))
+    r64 = orc.log_parametric_not(ls, less[:, None].astype(np.float64), 1)
+    assert np.allclose(np.exp(cmp_), np.exp(r64), atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,ldx_extra,act", [(300, 70, 50, 0, 0), (257, 300, 256, 0, 1), (513, 256, 516, 0, 2), (200, 333, 300, 0, 3),
+                                                 (130, 512, 2048, 6, 1), (64, 49, 12, 1, 3), (1, 5, 3, 0, 0)])
+def test_linear_act(L, M, N, K, ldx_extra, act):
+    rng = np.random.RandomState(M + N + K)
+    Xfull = rng.uniform(-1, 1, (M, K + ldx_extra)).astype(np.float32)
+    W = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    xt = dev(Xfull)[:, :K]
+    got = L.linear_act(xt, dev(W), dev(b), act).cpu().numpy()
+    z = Xfull[:, :K].astype(np.float64) @ W.astype(np.float64).T + b
+    ref = [z, orc._sigmoid(z), orc._elu(z), orc._log_sigmoid(z)][act]
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5)
+    # asymmetric operands: a transposed write would not survive this
+    assert not np.allclose(got[: min(M, N), : min(M, N)], got[: min(M, N), : min(M, N)].T) or min(M, N) < 2
+
+
+def test_box_and_pair_features(L):
+    n_list = [5, 1, 7]
+    F = 10
+    X = np.concatenate([syn.feature_scene(50 + i, n, F)["X"] for i, n in enumerate(n_list)])
+    img = np.repeat(np.arange(len(n_list)), n_list)
+    obj_ref, pair_ref, _ = orc.featurize_scene(X.astype(np.float64), img, [])
+    O, D = X.shape[0], F + 4
+    obj = torch.zeros(O, D, device="cuda")
+    obj[:, :F] = dev(X)[:, :F]
+    L.box_positions(dev(X), obj, F)
+    assert np.allclose(obj.cpu().numpy(), obj_ref, rtol=1e-6, atol=1e-7)
+    obj_off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
+    pair_off = np.concatenate([[0], np.cumsum([n * (n - 1) for n in n_list])]).astype(np.int64)
+    pair = L.pair_features(obj, D, dev(obj_off), dev(pair_off), len(n_list), max(n_list), int(pair_off[-1])).cpu().numpy()
+    assert pair.shape == pair_ref.shape
+    assert np.allclose(pair, pair_ref, rtol=1e-5, atol=2e-6)
+
+
+def test_errors_are_loud(L):
+    with pytest.raises(L.DfolError):
+        L.filter_fwd(torch.zeros(2, 8), torch.zeros(2, 8), torch.zeros(2, dtype=torch.int32), torch.ones(2, dtype=torch.int32))
+    with pytest.raises(L.DfolError):   # NS not a multiple of 4
+        z = torch.zeros(2, 6, device="cuda")
+        L.filter_fwd(z, z, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.ones(2, dtype=torch.int32, device="cuda"))

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the HBM-bound logic kernels and the MFMA GEMM (run on the GPU box).
+
+    python tools/bench_kernels.py [--preds 65536] [--n 100]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dfol_vqa_amd import _lib as L  # noqa: E402
+
+HBM_PEAK = 8.0e12
+F32_MFMA_PEAK = 157.3e12
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preds", type=int, default=65536)
+    ap.add_argument("--n", type=int, default=100)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    P, N = args.preds, args.n
+    NS = (N + 3) // 4 * 4
+    out = []
+    g = torch.Generator(device=dev).manual_seed(0)
+    p = torch.rand(P, NS, NS, device=dev, generator=g)
+    tile = torch.log(torch.where(torch.rand(P, NS, NS, device=dev, generator=g) < 0.1, 0.5 + 0.5 * p, 0.05 * p).clamp_min(1e-5))
+    del p
+    prior = torch.log(torch.rand(P, NS, device=dev, generator=g).clamp_min(1e-3)) * 0.3
+    pq = torch.arange(P, dtype=torch.int32, device=dev)
+    n_obj = torch.full((P,), N, dtype=torch.int32, device=dev)
+    ones = torch.ones(P, device=dev)
+    for label, ns, no, bytes_per in (("relate_both", True, True, 4 * N * N + 16 * N), ("relate_one_colsum", False, True, 4 * N * N + 12 * N),
+                                     ("relate_one_rowsum", True, False, 4 * N * N + 12 * N)):
+        t = timeit(lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=ns, need_o=no))
+        out.append({"kernel": label, "P": P, "N": N, "ms": t * 1e3, "GBps": bytes_per * P / t / 1e9, "frac_hbm_peak": bytes_per * P / t / HBM_PEAK})
+    ll = tile[:, 0, :].contiguous()
+    t = timeit(lambda: L.filter_fwd(prior, ll, pq, n_obj))
+    out.append({"kernel": "filter", "P": P, "N": N, "ms": t * 1e3, "GBps": 12 * N * P / t / 1e9, "frac_hbm_peak": 12 * N * P / t / HBM_PEAK})
+    t = timeit(lambda: L.quantify_fwd(prior, ones, pq, n_obj))
+    out.append({"kernel": "quantify", "P": P, "N": N, "ms": t * 1e3, "GBps": (4 * N + 4) * P / t / 1e9})
+    del tile
+    for (M, Nn, K, act) in ((25600, 512, 2048, 1), (25600, 768, 516, 2), (25600, 300, 256, 1), (65536, 304, 256, 1), (9216, 2335, 300, 3)):
+        x = torch.rand(M, K, device=dev) - 0.5
+        w = torch.rand(Nn, K, device=dev) - 0.5
+        b = torch.rand(Nn, device=dev)
+        y = torch.empty(M, Nn, device=dev)
+        t = timeit(lambda: L.linear_act(x, w, b, act, y), iters=10)
+        fl = 2.0 * M * Nn * K
+        out.append({"kernel": "linear_act", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
+    for r in out:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()

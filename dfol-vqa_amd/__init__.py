@@ -6,3 +6,10 @@ the C-ABI library declared in `include/dfol_vqa.h`.
 """
 
 __version__ = "0.1.0"
+
+from .fol_types import BatchVariableSet, BatchWorld, Quantifier, QuestionType, TokenType  # noqa: F401
+from .logic_ops import BatchBayesianLogicCell, FilterBatch, RelateBatch, SelectBatch  # noqa: F401
+from .gqa_ops import GQAOntology  # noqa: F401
+from .visual_oracle import ClassifierOracle, EmbeddingLayer, OracleBase, RegularMLP  # noqa: F401
+from .interpreter import BatchGQABoxFeaturizer, BatchGQAInterpreter, BatchInterpreterBase, gather_results  # noqa: F401
+from .program import OperatorBatch, ProgramBatch, ProgramCollaterBase  # noqa: F401

@@ -203,11 +203,17 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
 
     if (active && !active[p]) {                         // no-op predicate: posterior = prior (batch_base_ops.py:563-564)
         for (int c = lane; c < NS; c += 64) {
-            if (wantR) oR[c] = c < n ? pR[c] : 0.f;
-            if (wantC) oC[c] = c < n ? pC[c] : 0.f;
+            if (oR) oR[c] = (wantR && c < n) ? pR[c] : 0.f;
+            if (oC) oC[c] = (wantC && c < n) ? pC[c] : 0.f;
         }
         return;
     }
+
+    // a posterior this predicate does not want is zero-filled, so that downstream selects never see garbage
+    if (!wantR && oR)
+        for (int c = lane; c < NS; c += 64) oR[c] = 0.f;
+    if (!wantC && oC)
+        for (int c = lane; c < NS; c += 64) oC[c] = 0.f;
 
     const int cg = lane % LPR, rs = lane / LPR;
     const int c0 = cg * 4;
@@ -370,9 +376,11 @@ __global__ void gate_kernel(const float* __restrict__ x, const float* __restrict
     const float gg = g[p];
     if (c < NS) {
         const int64_t i = (int64_t)p * NS + c;
-        out[i] = x[i] * gg + y[i] * (1.f - gg);                         // batch_base_types.py:159
+        // batch_base_types.py:159; g is a 0/1 mask, for which the blend is a select (and a select cannot turn a
+        // stray inf/NaN in the unselected operand into NaN the way 0 * inf would)
+        out[i] = gg == 1.f ? x[i] : (gg == 0.f ? y[i] : x[i] * gg + y[i] * (1.f - gg));
     }
-    if (c == 0 && outq) outq[p] = xq[p] * gg + yq[p] * (1.f - gg);       // :156
+    if (c == 0 && outq) outq[p] = gg == 1.f ? xq[p] : (gg == 0.f ? yq[p] : xq[p] * gg + yq[p] * (1.f - gg));   // :156
 }
 
 extern "C" int dfol_gate_f32(const float* x_att, const float* y_att, const float* x_quant, const float* y_quant, const float* g,

@@ -1,0 +1,230 @@
+"""Basic types of the interpreter in BLOCK layout (reference: src/nsvqa/nn/interpreter/batch_base_types.py).
+
+The reference keeps one flat attention row over every object of a ProgramBatch plus a sparse
+[batch, total_obj] `batch_object_map`.  Here each predicate owns one block of NS floats (NS = padded
+max objects per image) and the map is replaced by three small integer vectors that live on the GPU
+for the whole batch: objects per image, first object of each image, first ordered pair of each image.
+Class names, constructor arguments and methods follow the reference so that code written against it
+keeps working; `flat_log_attention()` rebuilds the reference's [P, total_obj] view on request.
+"""
+
+from enum import IntEnum
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class Quantifier(IntEnum):          # batch_base_types.py:15-17
+    FOR_ALL = 0
+    EXISTS = 1
+
+
+class QuestionType(IntEnum):        # batch_base_types.py:19-24
+    BINARY = 0
+    QUERY = 1
+    STATEMENT = 2
+    OBJECT_STATEMENT = 3
+    SCENE_GRAPH = 4
+
+
+class TokenType(IntEnum):           # batch_base_types.py:26-30
+    ATTRIBUTE = 0
+    RELATION = 1
+    NAME = 2
+    CATEGORY = 3
+
+
+def _pad4(n):
+    return max(4, (int(n) + 3) // 4 * 4)
+
+
+class BatchWorld(object):
+    """Scene of one ProgramBatch (batch_base_types.py:191-252): likelihood tables + the block geometry."""
+
+    def __init__(self, device, object_num, attribute_features, relation_features, batch_index, meta_data=None,
+                 attention_transfer_state_dim=0, object_nums=None):
+        self._device = device
+        self._attribute_features = attribute_features
+        self._relation_features = relation_features
+        self._object_num = int(object_num)
+        self._object_image_map = batch_index
+        self._meta_data = meta_data
+        self._attention_transfer_state_dim = attention_transfer_state_dim
+
+        if object_nums is None:       # the reference syncs here too (batch_base_types.py:202-205)
+            bi = batch_index if isinstance(batch_index, torch.Tensor) else torch.as_tensor(batch_index)
+            object_nums = torch.bincount(bi.to(torch.int64).cpu()).tolist()
+        self._n_list = [int(n) for n in object_nums]
+        assert sum(self._n_list) == self._object_num, "object counts do not add up to object_num"
+        self._batch_size = len(self._n_list)
+        self._NS = _pad4(max(self._n_list))
+        n = np.asarray(self._n_list, np.int64)
+        self._n_obj = torch.as_tensor(n.astype(np.int32)).to(device)
+        self._obj_off = torch.as_tensor(np.concatenate([[0], np.cumsum(n)]).astype(np.int32)).to(device)
+        self._pair_off = torch.as_tensor(np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)).to(device)
+        self._pair_num = int((n * (n - 1)).sum())
+        self._ident = torch.arange(self._batch_size, dtype=torch.int32, device=device)
+        self._zeros = None
+
+    # -- reference API ---------------------------------------------------------------------------
+    def to(self, dtype):
+        if dtype != torch.float32:
+            raise L.DfolError("the MI355X path computes in fp32 (got %s)" % dtype)
+        return self
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def batch_size(self):
+        return self._batch_size
+
+    def object_num(self):
+        return self._object_num
+
+    def word_embedding_dim(self):
+        return self._meta_data['embedding'].size()[1]
+
+    def variable_set(self, names, quantifier=Quantifier.EXISTS, log_attention=None):
+        return BatchVariableSet(names, self._device, self._object_num, self._batch_size, quantifiers=quantifier,
+                                log_attention=log_attention, world=self)
+
+    # -- block helpers ---------------------------------------------------------------------------
+    def zeros_attention(self):
+        if self._zeros is None:
+            self._zeros = torch.zeros(self._batch_size, self._NS, dtype=torch.float32, device=self._device)
+        return self._zeros
+
+    def pred_q(self, predicate_question_map):
+        """Normalise a predicate->question map (None / python list / tensor / sparse [P,Q]) to int32 [P] on device."""
+        m = predicate_question_map
+        if m is None:
+            return self._ident
+        if isinstance(m, torch.Tensor):
+            if m.is_sparse:
+                m = m.coalesce().indices()[1]
+            return m.to(device=self._device, dtype=torch.int32)
+        return torch.as_tensor(np.asarray(m, np.int32)).to(self._device)
+
+    def to_flat(self, block, pred_q=None, fill=0.0):
+        """[P, NS] blocks -> the reference's flat [P, total_obj] rows (own image filled, the rest `fill`)."""
+        pq = (self._ident if pred_q is None else pred_q).cpu().numpy()
+        b = block.detach().cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(self._n_list)])
+        out = np.full((len(pq), self._object_num), fill, np.float32)
+        for p, q in enumerate(pq):
+            out[p, off[q]:off[q + 1]] = b[p, :self._n_list[q]]
+        return torch.from_numpy(out)
+
+    def from_flat(self, flat, pred_q=None):
+        """The reference's flat [P, total_obj] rows -> [P, NS] blocks (padding 0)."""
+        pq = (self._ident if pred_q is None else pred_q).cpu().numpy()
+        f = flat.detach().cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(self._n_list)])
+        out = np.zeros((len(pq), self._NS), np.float32)
+        for p, q in enumerate(pq):
+            out[p, :self._n_list[q]] = f[p, off[q]:off[q + 1]]
+        return torch.from_numpy(out).to(self._device)
+
+
+class BatchVariableSet(object):
+    """A batch of soft object sets (batch_base_types.py:34-187): log-attention [P, NS], quantifier [P]."""
+
+    def __init__(self, names, device, object_num, batch_size=1, quantifiers=Quantifier.EXISTS, log_attention=None,
+                 batch_object_map=None, predicate_question_map=None, base_cumulative_loss=0, prev_variable_sets_num=0,
+                 world=None):
+        world = world if world is not None else batch_object_map     # the world plays the batch_object_map's role
+        assert isinstance(world, BatchWorld), "a BatchWorld must be provided (it carries the block geometry)."
+        self._name = names
+        self._device = device
+        self._object_num = object_num
+        self._batch_size = batch_size
+        self._base_cumulative_loss = base_cumulative_loss
+        self._prev_variable_sets_num = prev_variable_sets_num
+        self._world = world
+        self._batch_object_map = world
+
+        if isinstance(quantifiers, (int, float, Quantifier)):
+            self._quantifier = torch.full((batch_size,), float(quantifiers), dtype=torch.float32, device=device)
+        elif isinstance(quantifiers, (list, tuple)):
+            self._quantifier = torch.tensor(quantifiers, dtype=torch.float32, device=device)
+        else:
+            self._quantifier = quantifiers
+
+        if log_attention is None:
+            self._log_attention = world.zeros_attention() if batch_size == world._batch_size else \
+                torch.zeros(batch_size, world._NS, dtype=torch.float32, device=device)
+        else:
+            self._log_attention = log_attention
+        assert self._log_attention.shape == (batch_size, world._NS), "log-attention must be [batch, NS] blocks"
+
+        # predicate -> question index (int32 [P]); None means predicate p belongs to question p
+        self._predicate_question_map = None if predicate_question_map is None else world.pred_q(predicate_question_map)
+
+    def to(self, dtype):
+        if dtype != torch.float32:
+            raise L.DfolError("the MI355X path computes in fp32 (got %s)" % dtype)
+        return self
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    @property
+    def device(self):
+        return self._device
+
+    def object_num(self):
+        return self._object_num
+
+    def batch_size(self):
+        return self._batch_size
+
+    def pred_q(self):
+        return self._world._ident if self._predicate_question_map is None else self._predicate_question_map
+
+    def log_probability(self, hard_mode=False):
+        """Soft quantifier aggregation, batch_base_types.py:113-123."""
+        if hard_mode:
+            raise NotImplementedError("hard_mode (batch_base_types.py:104-112) is off in every shipped config; not built")
+        return L.quantify_fwd(self._log_attention, self._quantifier, self.pred_q(), self._world._n_obj)
+
+    def cumulative_loss(self):          # batch_base_types.py:127-131
+        return 0
+
+    def mean_cumulative_loss(self):
+        return self.cumulative_loss() / (self._prev_variable_sets_num + 1)
+
+    def get_attention(self):
+        return self._log_attention.exp()
+
+    def flat_log_attention(self):
+        """The reference's [P, total_obj] view (cross-image entries 0), for traces and visualisers."""
+        return self._world.to_flat(self._log_attention, self.pred_q())
+
+    def gate(self, variable_set, flag):
+        """Per-question select (batch_base_types.py:149-168): rows with flag 1 come from self, the rest from `variable_set`."""
+        if isinstance(flag, torch.Tensor):
+            g = flag.to(torch.float32)
+            host_flag = getattr(flag, "_host", None)
+            if host_flag is None:
+                host_flag = flag.cpu().numpy().tolist()
+        else:
+            host_flag = [0 if f is None else f for f in flag]
+            g = torch.tensor([float(f) for f in host_flag], dtype=torch.float32, device=self._device)
+        att, quant = L.gate(self._log_attention, variable_set._log_attention, self._quantifier, variable_set._quantifier, g)
+        names = [x if f > 0 else y for x, y, f in zip(self._name, variable_set._name, host_flag)]
+        out = BatchVariableSet(names, self._device, self._object_num, self._batch_size, quantifiers=quant, log_attention=att,
+                               world=self._world)
+        out._predicate_question_map = self._predicate_question_map
+        return out
+
+    def apply_modulations(self, modulations, input_variable_set, predicate_question_map=None):
+        if modulations is not None:
+            raise NotImplementedError("attention calibration (batch_base_types.py:170-187) is SURVEY.md §8(f) rank 2: not built yet")
+        return self
+
+    def __repr__(self):
+        return "Object set of %d objects in %d blocks of %d" % (self._object_num, self._batch_size, self._world._NS)

@@ -1,0 +1,515 @@
+"""The GQA operator plugins (reference: src/nsvqa/nn/interpreter/batch_gqa_ops.py).
+
+Same class names, constructor keywords and forward signatures as the reference's registry entries
+(batch_gqa_interpreter.py:27-65).  Every forward is a handful of kernel launches on block-layout
+state; the only host work is string bookkeeping (names, answers).
+"""
+
+import json
+import math
+import re
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .fol_types import BatchVariableSet, Quantifier, QuestionType
+from .host_util import find_max_ind, flatten_list, unflatten_list
+from .logic_ops import BatchOperatorBase, FilterBatch, RelateBatch
+
+UNKNOWN = 'UNKNOWN'
+
+
+class GQAOntology(object):
+    """Vocabulary / attribute / class / relation metadata (batch_gqa_ops.py:25-148).  Attribute names follow the
+    reference (including its spelling `_relation_reveresed_index`) because other components read them."""
+
+    def __init__(self, attribute_json_path, class_json_path, vocab_json_file, embedding_file=None, relation_json_path=None,
+                 frequency_json_path=None):
+        with open(attribute_json_path) as f:
+            self._attribute_dict = json.load(f)
+        with open(class_json_path) as f:
+            self._class_dict = json.load(f)
+        self._nouns = list(set(sum(self._class_dict.values(), [])))
+        self._adjectives = list(set(sum(self._attribute_dict.values(), [])))
+        if frequency_json_path is not None:
+            with open(frequency_json_path) as f:
+                self._frequencies = json.load(f)
+        self._inverted_class_dict = {}
+        for parent, children in self._class_dict.items():
+            for child in children:
+                self._inverted_class_dict.setdefault(child, []).append(parent)
+
+        self._embedding_file = embedding_file
+        self._word_index = {}
+        self._embedding_rows = None
+        if embedding_file is not None:
+            offsets = []
+            with open(embedding_file, 'rb') as f:          # one pass: remember where each word's line starts
+                pos = 0
+                for i, line in enumerate(f):
+                    self._word_index[line.split(b' ', 1)[0].decode('utf8')] = i
+                    offsets.append(pos)
+                    pos += len(line)
+                    if i == 0:
+                        self._embedding_dim = len(line.decode('utf8').rstrip('\n').split(' ')) - 1
+            self._line_offsets = offsets
+
+        with open(vocab_json_file) as f:
+            self._vocabulary = json.load(f)
+        a2i = self._vocabulary['arg_to_idx']
+        self._noun_index = sorted(a2i[n] - 1 for n in self._nouns if n in a2i)
+
+        if relation_json_path is not None:
+            with open(relation_json_path) as f:
+                self._relations = list(set(json.load(f)))
+            self._relation_index = sorted(a2i[r] - 1 for r in self._relations if r in a2i)
+            rel = set(self._relation_index)
+            self._attribute_index = [i for i in range(len(a2i)) if i not in rel]
+            self._attributes = [self._vocabulary['idx_to_arg'][i] for i in self._attribute_index]
+            self._relation_reveresed_index = {i: j for j, i in enumerate(self._relation_index)}
+            self._attribute_reveresed_index = {i: j for j, i in enumerate(self._attribute_index)}
+            nouns = set(self._nouns)
+            self._noun_subindex = sorted(j for j, i in enumerate(self._attribute_index) if self._vocabulary['idx_to_arg'][i] in nouns)
+            noun_sub = set(self._noun_subindex)
+            self._non_noun_subindex = [j for j in range(len(self._attribute_index)) if j not in noun_sub]
+
+    def get_family_subindex(self, attribute):
+        if attribute not in self._inverted_class_dict:
+            return []
+        children = set()
+        for parent in self._inverted_class_dict[attribute]:
+            children.update(self._class_dict[parent])
+        return [j for j, a in enumerate(self._attributes) if a in children]
+
+    def encode_token(self, token):
+        t = str(token).lower().strip()
+        negated = re.match(r"not\((\w|\s)+\)", t) is not None
+        if negated:
+            t = t[4:-1]
+        return (-1 if negated else 1) * self._vocabulary['arg_to_idx'][t]
+
+    def decode_token(self, idx):
+        t = self._vocabulary['idx_to_arg'][abs(int(idx)) - 1]
+        if t == 'true':
+            return True
+        if t == 'false':
+            return False
+        return t if idx >= 0 else 'not(' + t + ')'
+
+    def encode_op(self, op):
+        return self._vocabulary['op_to_idx'][op.lower().strip()]
+
+    def decode_op(self, idx):
+        return self._vocabulary['idx_to_op'][idx - 1]
+
+    def encode_img_id(self, img_id):
+        return self._vocabulary['img_to_idx'][img_id.lower().strip()]
+
+    def decode_img_id(self, idx):
+        return self._vocabulary['idx_to_img'][idx - 1]
+
+    def query_attribute(self, attr_name):
+        return self._attribute_dict.get(attr_name, UNKNOWN)
+
+    def query_class(self, class_name):
+        return self._class_dict.get(class_name, UNKNOWN)
+
+    def query(self, name):                                    # batch_gqa_ops.py:114-124
+        if name in self._attribute_dict:
+            return self._attribute_dict[name]
+        if name in self._class_dict:
+            return self._class_dict[name]
+        if name is None:
+            return [None]
+        if name == 'entity':
+            return self._nouns
+        return [name]
+
+    def is_noun(self, name):
+        return name in self._nouns
+
+    def is_adjective(self, name):
+        return name in self._adjectives
+
+    def is_relation(self, name):
+        return name in self._relations
+
+    def get_embeddings(self, names):                          # batch_gqa_ops.py:135-148
+        if self._embedding_file is None:
+            return None
+        res = np.zeros((len(names), self._embedding_dim), dtype=np.float32)
+        with open(self._embedding_file, 'rb') as f:
+            for i, name in enumerate(names):
+                for t in name.split(' '):
+                    if t in self._word_index:
+                        f.seek(self._line_offsets[self._word_index[t]])
+                        line = f.readline().decode('utf8').rstrip('\n')
+                        res[i, :] += np.array([float(x) for x in line.split(' ')[1:]])
+        return res
+
+
+# ---------------------------------------------------------------------------------------------------
+class GQABatchOperatorBase(BatchOperatorBase):
+
+    def __init__(self, oracle, ontology, is_terminal, fan_in, fan_out):
+        super(GQABatchOperatorBase, self).__init__(oracle, is_terminal, fan_in, fan_out)
+        self._ontology = ontology
+
+
+def _binary_answer(log_probability, batch_size, give_answer):
+    """yes/no from p > 0.5 plus the log-probability of the answer given (e.g. batch_gqa_ops.py:404-407)."""
+    if not give_answer:
+        return [], []
+    probability = log_probability.exp().cpu().numpy().tolist()          # the one device->host sync of a binary op
+    answer = [['yes'] if probability[i] > 0.5 else ['no'] for i in range(batch_size)]
+    alp = [[math.log(probability[i])] if probability[i] > 0.5 else [math.log(1 - probability[i])] for i in range(batch_size)]
+    return answer, alp
+
+
+def _result(answer, log_probability, options, variable_set, qtype, cumulative_loss, variable_sets_num, answer_log_probability):
+    return {'answer': answer, 'log_probability': log_probability, 'options': options, 'variable_set': variable_set, 'type': qtype,
+            'cumulative_loss': cumulative_loss, 'variable_sets_num': variable_sets_num, 'answer_log_probability': answer_log_probability}
+
+
+def _kw(kw):
+    return dict(trainable_module_type=kw.get('trainable_module_type'), feature_dim=kw.get('feature_dim', 1),
+                trainable_gate=kw.get('trainable_gate', False), forward_attention_network=kw.get('forward_attention_network'),
+                backward_attention_network=kw.get('backward_attention_network'), attention_output_network=kw.get('attention_output_network'))
+
+
+def _select_names(attribute_list, batch_size):
+    """Names and filter tokens of a select (batch_gqa_ops.py:171-180)."""
+    if attribute_list is None:
+        return ["entity"] * batch_size, None
+    name = ["entity" if a is None or a.lower() in ("_", "scene") else a for a in attribute_list][:batch_size]
+    att = [None if a is None or a.lower() in ("_", "scene") else a for a in attribute_list][:batch_size]
+    return name, att
+
+
+class GQASelectBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:160-203."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQASelectBatch, self).__init__(oracle, ontology, is_terminal=False, fan_in=0, fan_out=1)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, attribute_list=None, give_answer=True, predicate_question_map=None, likelihood_threshold=0,
+                hard_mode=False):
+        name, att = _select_names(attribute_list, world.batch_size())
+        x = world.variable_set(name, quantifier=Quantifier.EXISTS)
+        if att is None or all(a is None for a in att):
+            return x
+        tokens = attribute_list if (len(attribute_list) == len(att) and getattr(attribute_list, "lowered", None) is not None) else att
+        return self._filter(op_id, world, x, tokens)
+
+
+class GQAFilterBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:314-350."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAFilterBatch, self).__init__(oracle, ontology, is_terminal=False, fan_in=1, fan_out=1)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set, attribute_list, give_answer=True, predicate_question_map=None,
+                likelihood_threshold=0, hard_mode=False):
+        return self._filter(op_id, world, variable_set, attribute_list)
+
+
+def _subject_flags(is_subject, device):
+    host = [0.0 if f is None else float(f) for f in is_subject]
+    t = getattr(is_subject, "device_flags", None)
+    if t is None or t.device != torch.device(device):
+        t = torch.tensor(host, dtype=torch.float32, device=device)
+    t._host = host
+    return t, host
+
+
+class GQARelateBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:354-390: x = select(name); (subject, object) = (x, prev) or (prev, x) per question;
+    relate; keep the posterior of whichever variable `prev` was not."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQARelateBatch, self).__init__(oracle, ontology, is_terminal=False, fan_in=1, fan_out=1)
+        self._gqa_select = GQASelectBatch(oracle, ontology, **kw)
+        self._relate = RelateBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set, relation_list, is_subject, attribute_list=None, give_answer=True,
+                predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
+        x = self._gqa_select(op_id, world, attribute_list, give_answer, predicate_question_map, likelihood_threshold)
+        flag, host = _subject_flags(is_subject, world._device)
+        subject_set = x.gate(variable_set, flag)
+        object_set = variable_set.gate(x, flag)
+        want = torch.tensor([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in host], dtype=torch.uint8, device=world._device)
+        subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, want=want)
+        return subject_set.gate(object_set, flag)
+
+
+class GQAExistBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:394-413."""
+
+    def __init__(self, oracle, ontology):
+        super(GQAExistBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+
+    def forward(self, op_id, world, variable_set, give_answer=True, predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
+        log_probability = variable_set.log_probability(give_answer and hard_mode)
+        answer, alp = _binary_answer(log_probability, variable_set.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], variable_set, QuestionType.BINARY, variable_set.cumulative_loss(),
+                       variable_set._prev_variable_sets_num + 1, alp)
+
+
+class GQAEndBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:768-783."""
+
+    def __init__(self, oracle, ontology):
+        super(GQAEndBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+
+    def forward(self, op_id, world, variable_set, give_answer=True, predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
+        answer = [[name] for name in variable_set._name] if give_answer else []
+        return _result(answer, variable_set.log_probability(give_answer and hard_mode), [], variable_set, QuestionType.STATEMENT,
+                       variable_set.cumulative_loss(), variable_set._prev_variable_sets_num + 1, [])
+
+
+def _seg_off(batch_index, question_num, device):
+    counts = np.bincount(np.asarray(batch_index, np.int64), minlength=question_num)
+    return torch.as_tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(device)
+
+
+class GQAVerifyAttrsBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:444-477: un-normalised Filter per attribute, posteriors summed per question, then EXISTS."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAVerifyAttrsBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set, attribute_list_list, give_answer=True, predicate_question_map=None,
+                likelihood_threshold=0, hard_mode=False):
+        attribute_list, batch_index = flatten_list(attribute_list_list)
+        x = self._filter(op_id, world, variable_set, attribute_list, batch_index, normalized_probability=False)
+        log_attention = L.segment_sum_rows(x._log_attention, _seg_off(batch_index, variable_set._batch_size, world._device))   # :457
+        y = BatchVariableSet(variable_set._name, variable_set._device, variable_set._object_num, batch_size=variable_set._batch_size,
+                             quantifiers=variable_set._quantifier, log_attention=log_attention, world=world,
+                             base_cumulative_loss=x._base_cumulative_loss, prev_variable_sets_num=x._prev_variable_sets_num)
+        log_probability = y.log_probability(give_answer and hard_mode)
+        answer, alp = _binary_answer(log_probability, variable_set.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], y, QuestionType.BINARY, y.cumulative_loss(), y._prev_variable_sets_num + 1, alp)
+
+
+class GQAVerifyRelBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:481-504."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAVerifyRelBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._gqa_relate = GQARelateBatch(oracle, ontology, **kw)
+
+    def forward(self, op_id, world, variable_set, relation_list, is_subject, attribute_list=None, give_answer=True,
+                predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
+        x = self._gqa_relate(op_id, world, variable_set, relation_list, is_subject, attribute_list, give_answer, predicate_question_map,
+                             likelihood_threshold)
+        log_probability = x.log_probability(give_answer and hard_mode)
+        answer, alp = _binary_answer(log_probability, variable_set.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], x, QuestionType.BINARY, x.cumulative_loss(), x._prev_variable_sets_num + 1, alp)
+
+
+def _choose_answer(log_probability, x, option_list, batch_index, question_num, likelihood_threshold, give_answer):
+    if not give_answer:
+        return [], []
+    flags = find_max_ind(log_probability, np.asarray(batch_index), question_num, likelihood_threshold).tolist()   # util.py:64-66
+    return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.cpu().numpy().tolist(), batch_index, flags)
+
+
+class GQAChooseAttrBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:207-232."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAChooseAttrBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set, attribute_list_list, give_answer=True, predicate_question_map=None,
+                likelihood_threshold=0, hard_mode=False):
+        attribute_list, batch_index = flatten_list(attribute_list_list)
+        x = self._filter(op_id, world, variable_set, attribute_list, batch_index)
+        log_probability = x.log_probability(give_answer and hard_mode)
+        answer, alp = _choose_answer(log_probability, x, attribute_list, batch_index, variable_set.batch_size(), likelihood_threshold, give_answer)
+        return _result(answer, log_probability, attribute_list_list, x, QuestionType.QUERY, x.cumulative_loss(), x._prev_variable_sets_num + 1, alp)
+
+
+class GQAQueryAttrBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:296-310."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAQueryAttrBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._gqa_choose_attr = GQAChooseAttrBatch(oracle, ontology, **kw)
+
+    def forward(self, op_id, world, variable_set, category_list, give_answer=True, predicate_question_map=None, likelihood_threshold=0,
+                hard_mode=False):
+        attribute_list_list = [self._ontology.query(category if category not in ['name', 'type'] else n)
+                               for category, n in zip(category_list, variable_set._name)]
+        return self._gqa_choose_attr(op_id, world, variable_set, attribute_list_list, give_answer, predicate_question_map, likelihood_threshold)
+
+
+class GQAChooseRelBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:236-292."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAChooseRelBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._gqa_select = GQASelectBatch(oracle, ontology, **kw)
+        self._relate = RelateBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set, relation_list_list, is_subject, attribute_list=None, give_answer=True,
+                predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
+        relation_list, batch_index = flatten_list(relation_list_list)
+        x = self._gqa_select(op_id, world, attribute_list, give_answer, predicate_question_map, likelihood_threshold)
+        flag, host = _subject_flags(is_subject, world._device)
+        subject_set = x.gate(variable_set, flag)
+        object_set = variable_set.gate(x, flag)
+        pred_host = [host[q] for q in batch_index]                                    # pqm @ is_subject  (:254-255)
+        want = torch.tensor([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in pred_host], dtype=torch.uint8, device=world._device)
+        subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, batch_index, want=want)
+        pflag = torch.tensor(pred_host, dtype=torch.float32, device=world._device)
+        pflag._host = pred_host
+        x = subject_set.gate(object_set, pflag)
+        log_probability = x.log_probability(give_answer and hard_mode)
+        answer, alp = _choose_answer(log_probability, x, relation_list, batch_index, variable_set.batch_size(), likelihood_threshold, give_answer)
+        return _result(answer, log_probability, relation_list_list, x, QuestionType.QUERY, x.cumulative_loss(), x._prev_variable_sets_num + 1, alp)
+
+
+def _lp_of(v, hard):
+    return v.log_probability(hard) if isinstance(v, BatchVariableSet) else v['log_probability']
+
+
+def _loss_num(v):
+    if isinstance(v, BatchVariableSet):
+        return v.cumulative_loss(), v._prev_variable_sets_num + 1
+    return v['cumulative_loss'], v['variable_sets_num']
+
+
+class _GQABinaryLogic(GQABatchOperatorBase):
+
+    _op = None
+
+    def __init__(self, oracle, ontology):
+        super(_GQABinaryLogic, self).__init__(oracle, ontology, is_terminal=True, fan_in=2, fan_out=0)
+
+    def forward(self, op_id, world, variable_set1, variable_set2, give_answer=True, predicate_question_map=None, likelihood_threshold=0,
+                hard_mode=False):
+        v1, v2 = _lp_of(variable_set1, give_answer and hard_mode), _lp_of(variable_set2, give_answer and hard_mode)
+        log_probability = L.logic(self._op, v1, v2)
+        answer, alp = _binary_answer(log_probability, v1.numel(), give_answer)
+        (c1, n1), (c2, n2) = _loss_num(variable_set1), _loss_num(variable_set2)
+        return _result(answer, log_probability, ['no', 'yes'], None, QuestionType.BINARY, c1 + c2, n1 + n2, alp)
+
+
+class GQAAndBatch(_GQABinaryLogic):
+    """batch_gqa_ops.py:508-537."""
+    _op = L.LOGIC_AND
+
+
+class GQAOrBatch(_GQABinaryLogic):
+    """batch_gqa_ops.py:541-570."""
+    _op = L.LOGIC_OR
+
+
+def _category_options(ontology, category_list, names):
+    lists = [ontology.query(category if category not in ['name', 'type'] else n) for category, n in zip(category_list, names)]
+    return flatten_list(lists)
+
+
+class GQAAllSameBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:574-613."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAAllSameBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set, category_list, give_answer=True, predicate_question_map=None, likelihood_threshold=0,
+                hard_mode=False):
+        attribute_list, batch_index = _category_options(self._ontology, category_list, variable_set._name)
+        x = self._filter(op_id, world, variable_set, attribute_list, batch_index)
+        pred_q = x.pred_q()
+        log_posterior = L.implication(variable_set._log_attention, x._log_attention, pred_q, world._n_obj)          # :588-589
+        temp = BatchVariableSet(x._name, variable_set.device, x.object_num(), batch_size=len(attribute_list), quantifiers=Quantifier.FOR_ALL,
+                                log_attention=log_posterior, world=world, predicate_question_map=pred_q)
+        log_probability = temp.log_probability(give_answer and hard_mode)
+        log_probability = L.segment_or(log_probability, _seg_off(batch_index, variable_set.batch_size(), world._device))   # :597-598
+        answer, alp = _binary_answer(log_probability, variable_set.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], None, QuestionType.BINARY, x.cumulative_loss(), x._prev_variable_sets_num + 1, alp)
+
+
+class GQAAllDifferentBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:617-642 (the logical NOT of all_same)."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQAAllDifferentBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
+        self._gqa_all_same = GQAAllSameBatch(oracle, ontology, **kw)
+
+    def forward(self, op_id, world, variable_set, category_list, give_answer=True, predicate_question_map=None, likelihood_threshold=0,
+                hard_mode=False):
+        all_same = self._gqa_all_same(op_id, world, variable_set, category_list, give_answer, predicate_question_map, likelihood_threshold)
+        log_probability = L.logic(L.LOGIC_NOT, all_same['log_probability'])
+        answer, alp = _binary_answer(log_probability, variable_set.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], all_same['variable_set'], QuestionType.BINARY, all_same['cumulative_loss'],
+                       all_same['variable_sets_num'], alp)
+
+
+class GQATwoSameBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:646-690."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQATwoSameBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=2, fan_out=0)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set1, variable_set2, category_list, give_answer=True, predicate_question_map=None,
+                likelihood_threshold=0, hard_mode=False):
+        attribute_list, batch_index = _category_options(self._ontology, category_list, variable_set1._name)
+        x1 = self._filter(op_id + ':0', world, variable_set1, attribute_list, batch_index)
+        x2 = self._filter(op_id + ':1', world, variable_set2, attribute_list, batch_index)
+        hard = give_answer and hard_mode
+        log_probability = L.logic(L.LOGIC_AND, x1.log_probability(hard), x2.log_probability(hard))
+        log_probability = L.segment_or(log_probability, _seg_off(batch_index, variable_set1.batch_size(), world._device))   # :664-665
+        answer, alp = _binary_answer(log_probability, variable_set1.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], None, QuestionType.BINARY, x1.cumulative_loss() + x2.cumulative_loss(),
+                       x1._prev_variable_sets_num + x2._prev_variable_sets_num + 2, alp)
+
+
+class GQATwoDifferentBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:694-717."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQATwoDifferentBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=2, fan_out=0)
+        self._gqa_two_same = GQATwoSameBatch(oracle, ontology, **kw)
+
+    def forward(self, op_id, world, variable_set1, variable_set2, category_list, give_answer=True, predicate_question_map=None,
+                likelihood_threshold=0, hard_mode=False):
+        two_same = self._gqa_two_same(op_id, world, variable_set1, variable_set2, category_list, give_answer, predicate_question_map,
+                                      likelihood_threshold)
+        log_probability = L.logic(L.LOGIC_NOT, two_same['log_probability'])
+        answer, alp = _binary_answer(log_probability, variable_set1.batch_size(), give_answer)
+        return _result(answer, log_probability, ['no', 'yes'], None, QuestionType.BINARY, two_same['cumulative_loss'],
+                       two_same['variable_sets_num'], alp)
+
+
+class GQACompareBatch(GQABatchOperatorBase):
+    """batch_gqa_ops.py:721-764."""
+
+    def __init__(self, oracle, ontology, **kw):
+        super(GQACompareBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=2, fan_out=0)
+        self._filter = FilterBatch(oracle, **_kw(kw))
+
+    def forward(self, op_id, world, variable_set1, variable_set2, attribute_list, is_less, give_answer=True, predicate_question_map=None,
+                likelihood_threshold=0, hard_mode=False):
+        x1 = self._filter(op_id + ':0', world, variable_set1, attribute_list)
+        x2 = self._filter(op_id + ':1', world, variable_set2, attribute_list)
+        hard = give_answer and hard_mode
+        alpha = torch.tensor([float(bool(v)) for v in is_less], dtype=torch.float32, device=variable_set1.device)
+        log_probability = L.compare(x1.log_probability(hard), x2.log_probability(hard), alpha)       # [Q, 2]  (:734-738)
+        options = list(zip(variable_set1._name, variable_set2._name))
+        answer, alp = [], []
+        if give_answer:
+            lp = log_probability.cpu().numpy()
+            ind = lp.argmax(1)
+            for i in range(variable_set1.batch_size()):
+                answer.append([options[i][ind[i]]])
+                alp.append([float(lp[i, ind[i]])])
+        return _result(answer, log_probability.view(-1), options, None, QuestionType.QUERY, x1.cumulative_loss() + x2.cumulative_loss(),
+                       x1._prev_variable_sets_num + x2._prev_variable_sets_num + 2, alp)

@@ -1,0 +1,125 @@
+"""Host-side helpers of the interpreter (reference: src/nsvqa/nn/interpreter/util.py) and token lowering.
+
+Lowering turns the per-question token strings of an operator batch into three small integer arrays
+(table column, negation flag, validity) once, at collate time, so that the timed step launches
+kernels instead of doing dictionary look-ups and regular-expression matches per question.
+"""
+
+import re
+
+import numpy as np
+import torch
+
+from .fol_types import TokenType
+
+_NEG = re.compile(r"not\((\w|\s)+\)")
+
+
+def detect_negations(a_list, device=None):          # util.py:68-85
+    is_negated = [_NEG.match(a.strip()) is not None for a in a_list]
+    any_negated = any(is_negated)
+    if any_negated:
+        b_list = [a.strip()[4:-1] if n else a.strip() for a, n in zip(a_list, is_negated)]
+    else:
+        b_list = a_list
+    return any_negated, is_negated, b_list
+
+
+def flatten_list(a_list_list):                      # util.py:52-57
+    a_list = [a if a is not None else [None] for a in a_list_list]
+    batch_index = [i for i, sublist in enumerate(a_list) for _ in sublist]
+    return [item for sublist in a_list for item in sublist], batch_index
+
+
+def unflatten_list(a_list, batch_index, flags):     # util.py:59-62
+    d = {i: [] for i in set(batch_index)}
+    for x, y, z in zip(batch_index, a_list, flags):
+        if z > 0:
+            d.setdefault(x, []).append(y)
+    return list(d.values())
+
+
+def find_max_ind(log_likelihood, pred_q, question_num, likelihood_threshold=0):
+    """util.py:64-66 on the host: flag, per predicate, whether it attains its question's maximum probability."""
+    lp = log_likelihood.detach().cpu().numpy() if isinstance(log_likelihood, torch.Tensor) else np.asarray(log_likelihood)
+    pq = pred_q.cpu().numpy() if isinstance(pred_q, torch.Tensor) else np.asarray(pred_q)
+    p = np.exp(lp)
+    mx = np.zeros(question_num, p.dtype)
+    np.maximum.at(mx, pq, p)
+    return ((p == mx[pq]) & (p > likelihood_threshold)).astype(np.int64)
+
+
+def reverse_dependencies(pred):                     # util.py:153-161
+    length = len(pred)
+    return [sorted(i for i in range(length) if j in pred[i]) for j in range(length)]
+
+
+def is_valid_token(val):                            # batch_base_ops.py:315
+    return val is not None and val.strip() not in ('', '_')
+
+
+class Lowered(object):
+    """Integer form of a token list for one table: column (-1 = no-op token), negation, validity."""
+
+    __slots__ = ("cols", "neg", "valid", "any_neg", "any_valid", "all_valid", "_dev")
+
+    def __init__(self, cols, neg, valid):
+        self.cols = np.asarray(cols, np.int32)
+        self.neg = np.asarray(neg, np.uint8)
+        self.valid = np.asarray(valid, np.uint8)
+        self.any_neg = bool(self.neg.any())
+        self.any_valid = bool(self.valid.any())
+        self.all_valid = bool(self.valid.all())
+        self._dev = {}
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.as_tensor(self.cols).to(device), torch.as_tensor(self.neg).to(device),
+                              torch.as_tensor(self.valid).to(device))
+        return self._dev[key]
+
+
+def lower_tokens(tokens, ontology, token_type):
+    """Resolve tokens against the ontology exactly as the reference's oracle does
+    (classifier_oracle.py:49-56 for attributes: column = arg_to_idx-1 of the full table;
+    :89-96 for relations: column in the 333-wide table via _relation_reveresed_index).
+    Unknown tokens raise KeyError like the reference's itemgetter."""
+    arg_to_idx = ontology._vocabulary['arg_to_idx']
+    cols, neg, valid = [], [], []
+    for t in tokens:
+        if not is_valid_token(t):
+            cols.append(-1), neg.append(0), valid.append(0)
+            continue
+        s = t.strip()
+        n = _NEG.match(s) is not None
+        if n:
+            s = s[4:-1]
+        idx = arg_to_idx[s.strip()] - 1
+        if token_type == TokenType.RELATION:
+            idx = ontology._relation_reveresed_index[idx]
+        cols.append(idx), neg.append(int(n)), valid.append(1)
+    return Lowered(cols, neg, valid)
+
+
+class TokenList(list):
+    """A plain list of tokens that remembers its lowered form (filled by OperatorBatch.lower)."""
+
+    lowered = None
+    lowered_type = None
+
+
+def get_lowered(tokens, ontology, token_type):
+    low = getattr(tokens, "lowered", None)
+    if low is not None and getattr(tokens, "lowered_type", None) == token_type:
+        return low
+    return lower_tokens(tokens, ontology, token_type)
+
+
+def segments_of(image_map):
+    """Runs of equal consecutive values (torch.unique_consecutive, classifier_oracle.py:23): -> offsets [S+1]."""
+    m = np.asarray(image_map)
+    if len(m) == 0:
+        return np.zeros(1, np.int32)
+    change = np.nonzero(m[1:] != m[:-1])[0] + 1
+    return np.concatenate([[0], change, [len(m)]]).astype(np.int32)

@@ -1,0 +1,171 @@
+"""The program interpreter (reference: src/nsvqa/nn/interpreter/batch_base_interpreter.py,
+batch_gqa_interpreter.py, data_parallel.py:15-50 and the featurizer of
+src/nsvqa/data/batch_gqa_boxfeatures_pipeline.py:193-281)."""
+
+import inspect
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import gqa_ops as gqa
+from .fol_types import BatchVariableSet, BatchWorld, QuestionType
+
+
+def gather_results(outputs, target_device=None, is_cuda=True):
+    """Concatenate per-ProgramBatch results (data_parallel.py:15-50)."""
+    if outputs[0]['type'] == QuestionType.SCENE_GRAPH:
+        raise NotImplementedError("scene-graph (direct supervision) results are out of scope (SURVEY.md §2 row 4)")
+    log_probability = torch.cat([o['log_probability'].reshape(-1) for o in outputs]) if len(outputs) > 1 else \
+        outputs[0]['log_probability'].reshape(-1)
+    answer = [a for o in outputs for a in o['answer']]
+    answer_log_probability = [a for o in outputs for a in o['answer_log_probability']]
+    if outputs[0]['type'] == QuestionType.QUERY:
+        options = [x for o in outputs for x in o['options']]
+    else:
+        options = outputs[0]['options']
+    return {'answer': answer, 'log_probability': log_probability, 'options': options, 'variable_set': None, 'type': outputs[0]['type'],
+            'cumulative_loss': sum(o['cumulative_loss'] for o in outputs), 'variable_sets_num': sum(o['variable_sets_num'] for o in outputs),
+            'answer_log_probability': answer_log_probability}
+
+
+class BatchGQABoxFeaturizer(nn.Module):
+    """Object and pair features of a scene (batch_gqa_boxfeatures_pipeline.py:193-281).
+
+    featurize_scene keeps the reference's return dict.  The pair matrix [pairs, 2(D+4)+4] is the reference's
+    layout; it is materialised only because compute_all_log_likelihood_2 asks for it (full cached tables)."""
+
+    def __init__(self, featurizer_network=None):
+        super(BatchGQABoxFeaturizer, self).__init__()
+        self._featurizer_network = featurizer_network
+
+    def featurize_scene(self, device, objects_list, batch_index, meta_data, world_geometry=None):
+        object_num = objects_list.size()[0]
+        raw_cols = objects_list.size()[1]
+        feat = objects_list[:, :raw_cols - 6]                    # a strided view: the GEMM reads it in place
+        net = self._featurizer_network
+        if net is not None and getattr(net, "_network", None) is not None:
+            f = net(feat)
+        else:
+            f = feat
+        D = f.size(1) + 4
+        obj = torch.empty(object_num, D, dtype=torch.float32, device=device)
+        obj[:, :D - 4] = f
+        L.box_positions(objects_list, obj, D - 4)                # :208-211
+        geo = world_geometry
+        pair = None
+        if geo is not None and geo._pair_num > 0:
+            pair = L.pair_features(obj, D, geo._obj_off, geo._pair_off, geo._batch_size, max(geo._n_list), geo._pair_num)   # :252-279
+        return {'attribute_features': obj, 'relation_features': {'features': pair, 'index': None}, 'object_num': object_num}
+
+
+class BatchInterpreterBase(nn.Module):
+    """batch_base_interpreter.py:14-183."""
+
+    def __init__(self, name, oracle, featurizer=None, attention_transfer_state_dim=0, apply_modulation_everywhere=True, cached=False,
+                 visual_rule_learner=None, calibrator=None):
+        super(BatchInterpreterBase, self).__init__()
+        self._featurizer = featurizer
+        self._oracle = oracle
+        self._name = name
+        self._global_step = nn.Parameter(torch.tensor([0], dtype=torch.float), requires_grad=False)
+        self._has_modulator = False
+        self._attention_transfer_state_dim = attention_transfer_state_dim
+        self._apply_modulation_everywhere = apply_modulation_everywhere
+        self._cached = cached
+        if visual_rule_learner is not None or calibrator is not None:
+            raise NotImplementedError("visual_rule_learner / calibrator are None in every reference configuration")
+
+    def _execute(self, op_id, world, operator_batch, input_tuple, is_terminal, is_training):
+        raise NotImplementedError
+
+    def parameter_count(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def save(self, export_path_base):                          # :39-40
+        torch.save(self.state_dict(), os.path.join(export_path_base, self._name))
+
+    def load(self, import_path_base):                          # :42-43
+        self.load_state_dict(torch.load(os.path.join(import_path_base, self._name)), strict=False)
+
+    def build_scene(self, device, object_features, batch_index, meta_data, object_nums=None):
+        """batch_base_interpreter.py:45-70: featurizer + oracle MLPs -> cached likelihood tables -> BatchWorld."""
+        if self._featurizer is None:
+            raise NotImplementedError("a featurizer is required (the reference's featurizer-less branch :62-67 is dead code)")
+        geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
+                              attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums)
+        if 'world_geometry' in inspect.signature(self._featurizer.featurize_scene).parameters:
+            features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=geometry)
+        else:                   # a featurizer written against the reference's 4-argument signature
+            features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data)
+        attribute_features = features['attribute_features']
+        relation_features = features['relation_features']
+        if self._cached:
+            attribute_features, relation_features['features'] = self._oracle.compute_all_log_likelihood_2(
+                attribute_features, relation_features['features'])
+        geometry._attribute_features = attribute_features
+        geometry._relation_features = relation_features
+        return geometry
+
+    def forward(self, program_batch_list, is_training, return_trace=False, modulator_switch=True):
+        all_traces, all_results = [], []
+        device = program_batch_list[0].device
+        for program_batch in program_batch_list:
+            world = self.build_scene(program_batch.device, program_batch._object_features, program_batch._object_batch_index,
+                                     program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None))
+            if self._has_modulator and modulator_switch:
+                raise NotImplementedError("attention-calibration passes (:87-140) are SURVEY.md §8(f) rank 2: not built yet")
+            ops = program_batch._op_batch_list
+            trace = []
+            for i, op_batch in enumerate(ops):                   # execution loop :145-172
+                deps = program_batch._dependencies[i]
+                input_tuple = tuple(trace[d] for d in deps)
+                x, terminate = self._execute(op_batch._op_id, world, op_batch, input_tuple, i == len(ops) - 1, is_training)
+                if isinstance(x, BatchVariableSet) and len(input_tuple) > 0 and op_batch._mask is not None:
+                    x = x.gate(input_tuple[0], op_batch._mask)   # questions lacking this op keep their attention (:166-167)
+                trace.append(x)
+                if terminate:
+                    break
+            all_results.append(trace[-1] if trace else None)
+            all_traces.append(trace)
+        result = gather_results(all_results, device, True)
+        return (result, all_traces) if return_trace else result
+
+
+class BatchGQAInterpreter(BatchInterpreterBase):
+    """batch_gqa_interpreter.py:13-86: the operator registry and its dispatch."""
+
+    def __init__(self, name, oracle, ontology, featurizer=None, trainable_module_type=None, feature_dim=1, trainable_gate=False,
+                 likelihood_threshold=0, hard_mode=False, attention_transfer_state_dim=0, forward_attention_network=None,
+                 backward_attention_network=None, attention_output_network=None, apply_modulation_everywhere=True, cached=False,
+                 visual_rule_learner=None, calibrator=None):
+        super(BatchGQAInterpreter, self).__init__(name, oracle, featurizer, attention_transfer_state_dim=attention_transfer_state_dim,
+                                                  apply_modulation_everywhere=apply_modulation_everywhere, cached=cached,
+                                                  visual_rule_learner=visual_rule_learner, calibrator=calibrator)
+        self._ontology = ontology
+        self._likelihood_threshold = likelihood_threshold
+        self._hard_mode = hard_mode
+        self._has_modulator = forward_attention_network is not None and backward_attention_network is not None and \
+            attention_output_network is not None
+        kw = dict(trainable_module_type=trainable_module_type, feature_dim=feature_dim, trainable_gate=trainable_gate,
+                  forward_attention_network=forward_attention_network, backward_attention_network=backward_attention_network,
+                  attention_output_network=attention_output_network)
+        o, t = self._oracle, self._ontology
+        self._ops = nn.ModuleDict({
+            'select': gqa.GQASelectBatch(o, t, **kw), 'filter': gqa.GQAFilterBatch(o, t, **kw), 'relate': gqa.GQARelateBatch(o, t, **kw),
+            'query_attr': gqa.GQAQueryAttrBatch(o, t, **kw), 'choose_attr': gqa.GQAChooseAttrBatch(o, t, **kw),
+            'verify_attrs': gqa.GQAVerifyAttrsBatch(o, t, **kw), 'choose_rel': gqa.GQAChooseRelBatch(o, t, **kw),
+            'verify_rel': gqa.GQAVerifyRelBatch(o, t, **kw), 'exist': gqa.GQAExistBatch(o, t), 'and': gqa.GQAAndBatch(o, t),
+            'or': gqa.GQAOrBatch(o, t), 'all_same': gqa.GQAAllSameBatch(o, t, **kw), 'all_different': gqa.GQAAllDifferentBatch(o, t, **kw),
+            'two_same': gqa.GQATwoSameBatch(o, t, **kw), 'two_different': gqa.GQATwoDifferentBatch(o, t, **kw),
+            'compare': gqa.GQACompareBatch(o, t, **kw), 'end': gqa.GQAEndBatch(o, t),
+        })
+
+    def _execute(self, op_id, world, operator_batch, input_tuple, is_terminal, is_training):
+        op = self._ops[operator_batch._op_name]
+        x = op(*((op_id, world) + input_tuple + tuple(operator_batch._arguments) +
+                 (not is_training, operator_batch._predicate_question_map, self._likelihood_threshold, self._hard_mode)))
+        if is_terminal and not operator_batch._is_terminal:      # append `end` to read out a log-likelihood (:75-76)
+            return self._ops['end'](op_id, world, x, not is_training, operator_batch._predicate_question_map), is_terminal
+        return x, is_terminal

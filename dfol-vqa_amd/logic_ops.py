@@ -1,0 +1,205 @@
+"""The differentiable first-order-logic operators in block layout.
+
+Reference: src/nsvqa/nn/interpreter/batch_base_ops.py (BatchBayesianLogicCell :42-237, FilterBatch
+:301-405, RelateBatch :471-596).  The arithmetic runs in csrc/dfol_logic.hip; these classes only
+resolve tokens, pick priors/quantifiers and launch.
+"""
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .fol_types import BatchVariableSet, Quantifier, TokenType
+from .host_util import get_lowered
+
+
+class BatchBayesianLogicCell(nn.Module):
+    """batch_base_ops.py:42-237.  Block-layout shapes:
+         log_prior      [Q, arity, NS]
+         log_likelihood [P, NS(, NS)] (a trailing feature dim of 1 is accepted and dropped)
+         quantifiers    [P, arity]
+         batch_object_map = the BatchWorld (it carries n_obj); predicate_question_map = int32 [P] or None
+       returns [P, arity, NS]."""
+
+    def __init__(self, arity, trainable_module_type=None, feature_dim=1, trainable_gate=False):
+        super(BatchBayesianLogicCell, self).__init__()
+        if trainable_module_type is not None or trainable_gate:
+            raise NotImplementedError("trainable_gate / operator_layers_config are off in every shipped config (SURVEY.md §2 row 3)")
+        if arity not in (1, 2):
+            raise NotImplementedError("Likelihood for arity > 2 is not implemented.")      # cf. :210
+        self._arity = arity
+        self._feature_dim = feature_dim
+
+    def forward(self, log_prior, log_likelihood, quantifiers, dim_order, batch_object_map=None, predicate_question_map=None,
+                is_negated=None, default_log_likelihood=-30, active=None, want=None, orientation=L.TILE_SUBJECT_ROWS,
+                need=(True, True)):
+        world = batch_object_map
+        assert quantifiers.size()[1] == self._arity, "The number of quantifiers must match the arity of the operator."
+        assert len(dim_order) == self._arity, "The number of dimension order elements must match the arity of the operator."
+        assert log_prior.size()[1] == self._arity, "The second dimension of log-prior must be equal to the arity of the operator."
+        assert list(dim_order) == list(range(self._arity)), "only the natural dim_order is built"
+        ll = log_likelihood
+        if ll.dim() == self._arity + 2:
+            assert ll.size(-1) == 1, "feature_dim > 1 needs a trainable module, which is not built"
+            ll = ll.squeeze(-1)                                  # mean over the single feature (:194)
+        assert ll.dim() == self._arity + 1, "The number of dimensions of log-likelihood must be equal to the arity of the operator + 2."
+        P, Q = ll.size(0), log_prior.size(0)
+        assert P == Q or (predicate_question_map is not None and predicate_question_map.numel() == P), \
+            "In case predicate_num != question_num, predicate_question_map of size (predicate_num) must be provided."
+        pred_q = world._ident if predicate_question_map is None else predicate_question_map
+        neg = None if is_negated is None else is_negated.to(torch.uint8)
+        if self._arity == 1:
+            out = L.filter_fwd(log_prior[:, 0, :].contiguous(), ll.contiguous(), pred_q, world._n_obj, neg, active)
+            return out.unsqueeze(1)
+        ps, po = L.relate_fwd(log_prior[:, 0, :].contiguous(), log_prior[:, 1, :].contiguous(), ll.contiguous(), pred_q, world._n_obj,
+                              quantifiers[:, 0].contiguous(), quantifiers[:, 1].contiguous(), neg, active, want, orientation,
+                              lone_forall_identity=(P == 1), need_s=need[0], need_o=need[1])
+        if ps is None or po is None:
+            return ps, po
+        return torch.stack([ps, po], 1)
+
+
+class BatchOperatorBase(nn.Module):
+    """batch_base_ops.py:241-286."""
+
+    def __init__(self, oracle, is_terminal, fan_in, fan_out, forward_attention_network=None, backward_attention_network=None,
+                 attention_output_network=None):
+        super(BatchOperatorBase, self).__init__()
+        self._oracle = oracle
+        self._is_terminal = is_terminal
+        self._fan_in = fan_in
+        self._fan_out = fan_out
+        if forward_attention_network is not None or backward_attention_network is not None or attention_output_network is not None:
+            raise NotImplementedError("attention calibration networks are SURVEY.md §8(f) rank 2: not built yet")
+
+    def is_terminal(self):
+        return self._is_terminal
+
+    def fan_in(self):
+        return self._fan_in
+
+    def fan_out(self):
+        return self._fan_out
+
+
+class SelectBatch(BatchOperatorBase):
+    """batch_base_ops.py:290-297."""
+
+    def __init__(self, oracle, **kw):
+        super(SelectBatch, self).__init__(oracle, is_terminal=False, fan_in=0, fan_out=1, **kw)
+
+    def forward(self, id, world, name, quantifier=Quantifier.EXISTS):
+        return world.variable_set(name, quantifier=quantifier)
+
+
+def _expand_quantifier(quant, pred_q, identity):
+    return quant if identity else L.gather_rows(quant.unsqueeze(1).contiguous(), pred_q).squeeze(1)
+
+
+def _host_map(predicate_question_map, P):
+    """predicate -> question list on the host (needed for the option clusters), None = identity."""
+    m = predicate_question_map
+    if m is None:
+        return None
+    if isinstance(m, torch.Tensor):
+        host = getattr(m, "_host", None)
+        if host is not None:
+            return host
+        if m.is_sparse:
+            m = m.coalesce().indices()[1]
+        return m.cpu().numpy().tolist()
+    return list(m)
+
+
+class FilterBatch(BatchOperatorBase):
+    """batch_base_ops.py:301-405."""
+
+    def __init__(self, oracle, trainable_module_type=None, feature_dim=1, trainable_gate=False, **kw):
+        super(FilterBatch, self).__init__(oracle, is_terminal=False, fan_in=1, fan_out=1, **kw)
+        self._blc = BatchBayesianLogicCell(arity=1, trainable_module_type=trainable_module_type, feature_dim=feature_dim,
+                                           trainable_gate=trainable_gate)
+        self._modulations = {}
+        self._forward_state = {}
+
+    def forward(self, op_id, world, variable_set, attribute_list, predicate_question_map=None, default_log_likelihood=-30,
+                normalized_probability=True):
+        if not isinstance(attribute_list, list):
+            attribute_list = [attribute_list]
+        low = get_lowered(attribute_list, self._oracle._ontology, TokenType.ATTRIBUTE)
+        if not low.any_valid:                                    # :316-317
+            return variable_set
+        question_num = variable_set.batch_size()
+        predicate_num = len(attribute_list)
+        host_map = _host_map(predicate_question_map, predicate_num)
+        assert question_num == predicate_num or (host_map is not None and len(host_map) == predicate_num), "Batch size mismatch."
+        identity = host_map is None
+        pred_q = world._ident if identity else world.pred_q(predicate_question_map)
+        quantifier = _expand_quantifier(variable_set._quantifier, pred_q, identity)           # :341-343
+        dev = variable_set.device
+        _, neg_dev, valid_dev = low.on(dev)
+        ll = self._oracle.block_likelihood(TokenType.ATTRIBUTE, low, pred_q, range(predicate_num) if identity else host_map,
+                                           world, default_log_likelihood, normalized_probability)
+        att = self._blc(variable_set._log_attention.unsqueeze(1), ll, quantifier.unsqueeze(1), [0], world, pred_q,
+                        neg_dev if low.any_neg else None, default_log_likelihood,
+                        active=None if low.all_valid else valid_dev)[:, 0, :]
+        res = BatchVariableSet(variable_set._name, dev, variable_set.object_num(), predicate_num, quantifiers=quantifier,
+                               log_attention=att, world=world, predicate_question_map=None if identity else pred_q,
+                               base_cumulative_loss=variable_set.cumulative_loss(),
+                               prev_variable_sets_num=variable_set._prev_variable_sets_num + 1)
+        if op_id in self._modulations:                            # :401-403
+            res = res.apply_modulations(self._modulations.pop(op_id), variable_set, predicate_question_map)
+        return res
+
+
+class RelateBatch(BatchOperatorBase):
+    """batch_base_ops.py:471-596.  `need` = (subject, object) lets a caller that only consumes one
+    posterior (GQARelateBatch keeps exactly one, batch_gqa_ops.py:371) skip the other direction."""
+
+    def __init__(self, oracle, trainable_module_type=None, feature_dim=1, trainable_gate=False, **kw):
+        super(RelateBatch, self).__init__(oracle, is_terminal=False, fan_in=2, fan_out=2, **kw)
+        self._blc = BatchBayesianLogicCell(arity=2, trainable_module_type=trainable_module_type, feature_dim=feature_dim,
+                                           trainable_gate=trainable_gate)
+        self._subject_modulations = {}
+        self._object_modulations = {}
+        self._forward_subject_state = {}
+        self._forward_object_state = {}
+
+    def forward(self, op_id, world, subject_variable_set, object_variable_set, relation_list, predicate_question_map=None,
+                default_log_likelihood=-30, normalized_probability=True, want=None):
+        assert subject_variable_set.batch_size() == object_variable_set.batch_size(), \
+            "The subject and object variable sets must have the same batch size."
+        assert subject_variable_set.object_num() == object_variable_set.object_num(), \
+            "The subject and object variable sets must have the same number of objects."
+        if not isinstance(relation_list, list):
+            relation_list = [relation_list]
+        low = get_lowered(relation_list, self._oracle._ontology, TokenType.RELATION)
+        if not low.any_valid:                                    # :491-492
+            return subject_variable_set, object_variable_set
+        question_num = world.batch_size()
+        predicate_num = len(relation_list)
+        host_map = _host_map(predicate_question_map, predicate_num)
+        assert question_num == predicate_num or (host_map is not None and len(host_map) == predicate_num), "Batch size mismatch."
+        identity = host_map is None
+        pred_q = world._ident if identity else world.pred_q(predicate_question_map)
+        dev = subject_variable_set.device
+        q_s = _expand_quantifier(subject_variable_set._quantifier, pred_q, identity)          # :518-521
+        q_o = _expand_quantifier(object_variable_set._quantifier, pred_q, identity)
+        _, neg_dev, valid_dev = low.on(dev)
+        tile = self._oracle.block_likelihood(TokenType.RELATION, low, pred_q, range(predicate_num) if identity else host_map,
+                                             world, default_log_likelihood, normalized_probability)
+        ps, po = L.relate_fwd(subject_variable_set._log_attention, object_variable_set._log_attention, tile, pred_q, world._n_obj,
+                              q_s, q_o, neg_dev if low.any_neg else None, None if low.all_valid else valid_dev, want,
+                              L.TILE_SUBJECT_ROWS, lone_forall_identity=(predicate_num == 1))
+        n_prev = subject_variable_set._prev_variable_sets_num + object_variable_set._prev_variable_sets_num + 1
+        pqm = None if identity else pred_q
+        new_subject_set = BatchVariableSet(subject_variable_set._name, dev, subject_variable_set.object_num(), predicate_num,
+                                           quantifiers=q_s, log_attention=ps, world=world, predicate_question_map=pqm,
+                                           prev_variable_sets_num=n_prev)        # both take the subject's quantifier (:571-586)
+        new_object_set = BatchVariableSet(object_variable_set._name, dev, object_variable_set.object_num(), predicate_num,
+                                          quantifiers=q_s, log_attention=po, world=world, predicate_question_map=pqm,
+                                          prev_variable_sets_num=n_prev)
+        if op_id in self._subject_modulations:
+            new_subject_set = new_subject_set.apply_modulations(self._subject_modulations.pop(op_id), subject_variable_set, predicate_question_map)
+        if op_id in self._object_modulations:
+            new_object_set = new_object_set.apply_modulations(self._object_modulations.pop(op_id), object_variable_set, predicate_question_map)
+        return new_subject_set, new_object_set

@@ -1,0 +1,301 @@
+"""Program batching: the operand format the interpreter consumes.
+
+Reference: src/nsvqa/data/data_pipeline.py — OperatorBatch :31-143, ProgramBatch :147-290,
+ProgramCollaterBase :626-783.  Same classes and fields; in addition every OperatorBatch can be
+*lowered* once, at collate time (i.e. in a DataLoader worker), to integer arrays — table columns,
+negation flags, validity, subject flags — so the interpreter's timed step does no string work.
+"""
+
+import math
+import time
+
+import numpy as np
+import torch
+
+from .fol_types import QuestionType, TokenType
+from .host_util import TokenList, flatten_list, lower_tokens
+
+# which argument slot of an operator holds which kind of token (for lowering)
+_ATTR_SLOT = {"select": 0, "filter": 0}
+_REL_OPS = {"relate": (0, 1, 2), "verify_rel": (0, 1, 2)}          # (relation, is_subject, name) slots
+
+
+class OperatorBatch(object):
+    """One operator applied across the questions of a batch (data_pipeline.py:31-143)."""
+
+    def __init__(self, op_name, arguments, question_num, is_terminal, mask=None, question_index=None, process_args=True):
+        self._op_name = op_name
+        self._is_terminal = is_terminal
+        self._op_id = None
+        if process_args:
+            arguments = list(arguments)
+            if 0 < len(arguments) < question_num:
+                arguments = arguments + [None] * (question_num - len(arguments))
+            elif len(arguments) >= question_num:
+                arguments = arguments[:question_num]
+            else:
+                arguments = []
+            width = next((len(x) for x in arguments if isinstance(x, list)), 0)
+            arguments = [[None] * width if x is None else x for x in arguments]
+            self._arguments = [TokenList(col) for col in zip(*arguments)]        # one list per argument slot
+        else:
+            self._arguments = arguments
+        self._question_num = question_num
+        self._predicate_num = question_num
+        self._predicate_question_map = None
+        self._question_index = None
+        if len(self._arguments) > 0 and any(isinstance(el, list) and len(el) > 1 for el in self._arguments[0]):
+            flat, batch_index = flatten_list(self._arguments[0])
+            self._predicate_num = len(flat)
+            if question_index is not None:
+                self._question_index = question_index
+            elif self._predicate_num != self._question_num:
+                self._question_index = torch.tensor(batch_index, dtype=torch.int64)
+        if mask is None:
+            self._mask = None
+        else:
+            self._mask = torch.from_numpy(mask).float() if isinstance(mask, np.ndarray) else mask
+            self._mask._host = self._mask.tolist()
+
+    # -- lowering --------------------------------------------------------------------------------
+    def lower(self, ontology):
+        """Resolve the token arguments of select / filter / relate / verify_rel against the ontology."""
+        name = self._op_name
+        if name in _ATTR_SLOT and self._arguments:
+            toks = self._arguments[_ATTR_SLOT[name]]
+            if name == "select":        # '_' and 'scene' select everything (batch_gqa_ops.py:175-177)
+                clean = [None if a is None or a.lower() in ("_", "scene") else a for a in toks]
+            else:
+                clean = toks
+            toks.lowered, toks.lowered_type = lower_tokens(clean, ontology, TokenType.ATTRIBUTE), TokenType.ATTRIBUTE
+        elif name in _REL_OPS and self._arguments:
+            r, s, n = _REL_OPS[name]
+            rel = self._arguments[r]
+            rel.lowered, rel.lowered_type = lower_tokens(rel, ontology, TokenType.RELATION), TokenType.RELATION
+            names = self._arguments[n]
+            clean = [None if a is None or a.lower() in ("_", "scene") else a for a in names]
+            names.lowered, names.lowered_type = lower_tokens(clean, ontology, TokenType.ATTRIBUTE), TokenType.ATTRIBUTE
+        return self
+
+    def create_sparse_map(self):
+        """The reference builds a sparse [P, Q] map here (data_pipeline.py:76-83); the block layout only needs the
+        predicate -> question index vector, which already exists as `_question_index`."""
+        if self._question_index is not None:
+            self._predicate_question_map = self._question_index.to(torch.int32)
+            self._predicate_question_map._host = self._question_index.tolist()
+
+    def to_cuda(self, device, non_blocking=True):
+        res = OperatorBatch(self._op_name, self._arguments, self._question_num, self._is_terminal, mask=None,
+                            question_index=self._question_index, process_args=False)
+        if self._mask is not None:
+            res._mask = self._mask.cuda(device, non_blocking=non_blocking)
+            res._mask._host = self._mask._host
+        if self._question_index is not None:
+            res._predicate_question_map = self._question_index.to(torch.int32).cuda(device, non_blocking=non_blocking)
+            res._predicate_question_map._host = self._question_index.tolist()
+        res._predicate_num = self._predicate_num
+        res._op_id = self._op_id
+        for a in res._arguments:                       # pre-stage the lowered integer arrays and subject flags
+            low = getattr(a, "lowered", None)
+            if low is not None:
+                low.on(device)
+        if self._op_name in _REL_OPS and res._arguments:
+            flags = res._arguments[_REL_OPS[self._op_name][1]]
+            flags.device_flags = torch.tensor([0.0 if f is None else float(f) for f in flags], dtype=torch.float32).cuda(device)
+        return res
+
+    def to(self, dtype):
+        if dtype != torch.float32:
+            raise ValueError("the MI355X path computes in fp32")
+        return self
+
+    def pin_memory(self):
+        if self._mask is not None:
+            host = self._mask._host
+            self._mask = self._mask.pin_memory()
+            self._mask._host = host
+        if self._question_index is not None:
+            self._question_index = self._question_index.pin_memory()
+        return self
+
+    def __repr__(self):
+        res = "Operation: %s\nTerminal: %s\n" % (self._op_name, self._is_terminal)
+        if self._mask is not None:
+            res += "Mask: %s\n" % self._mask._host
+        if len(self._arguments) > 0:
+            res += "Arguments: %s\n" % [list(a) for a in self._arguments]
+        return res
+
+
+class ProgramBatch(object):
+    """A batch of aligned programs plus its scenes (data_pipeline.py:147-290)."""
+
+    def __init__(self, device, op_batch_list, dependencies, answers, object_features, object_batch_index=None, original_dicts=None,
+                 meta_data=None, object_nums=None):
+        self._op_batch_list = op_batch_list
+        self._object_features = object_features
+        self._dependencies = dependencies
+        self._answers = answers
+        self._batch_size = op_batch_list[0]._question_num if op_batch_list else 0
+        self._original_dicts = original_dicts
+        self._meta_data = meta_data
+        self._device = device
+        if isinstance(object_batch_index, np.ndarray):
+            object_batch_index = torch.from_numpy(object_batch_index)
+        self._object_batch_index = object_batch_index
+        if object_nums is None and object_batch_index is not None:          # kept on the host so that build_scene never syncs
+            object_nums = torch.bincount(object_batch_index.cpu().to(torch.int64)).tolist()
+        self._object_nums = object_nums
+        batch_id = str(int(round(time.time() * 1000)))                       # :167-169
+        for i, ob in enumerate(self._op_batch_list):
+            if ob._op_id is None:
+                ob._op_id = batch_id + ':' + str(i)
+        self._question_type = QuestionType.QUERY if self._op_batch_list and self._op_batch_list[-1]._op_name in \
+            ['query_attr', 'choose_attr', 'choose_rel'] else QuestionType.BINARY
+
+    @property
+    def device(self):
+        return self._device
+
+    def batch_size(self):
+        return self._batch_size
+
+    def lower(self, ontology):
+        for ob in self._op_batch_list:
+            ob.lower(ontology)
+        return self
+
+    def to_cuda(self, device, non_blocking=True):
+        def move(obj):
+            if isinstance(obj, torch.Tensor):
+                return obj.cuda(device, non_blocking=non_blocking)
+            if isinstance(obj, dict):
+                return {k: move(v) for k, v in obj.items()}
+            return obj
+        pb = ProgramBatch(device, [ob.to_cuda(device, non_blocking) for ob in self._op_batch_list], self._dependencies, self._answers,
+                          move(self._object_features), move(self._object_batch_index), self._original_dicts, move(self._meta_data),
+                          object_nums=self._object_nums)
+        return pb
+
+    def to(self, dtype):
+        if dtype != torch.float32:
+            raise ValueError("the MI355X path computes in fp32")
+        return self
+
+    def pin_memory(self):
+        if isinstance(self._object_features, torch.Tensor):
+            self._object_features = self._object_features.pin_memory()
+        if isinstance(self._meta_data, dict):
+            for k, v in self._meta_data.items():
+                if isinstance(v, torch.Tensor):
+                    self._meta_data[k] = v.pin_memory()
+        if self._object_batch_index is not None:
+            self._object_batch_index = self._object_batch_index.pin_memory()
+        self._op_batch_list = [ob.pin_memory() for ob in self._op_batch_list]
+        return self
+
+    def create_sparse_tensors(self):                   # data_pipeline.py:242-244
+        for ob in self._op_batch_list:
+            ob.create_sparse_map()
+
+    def retrieve_instance(self, index, trace=None):    # data_pipeline.py:273-290
+        res = []
+        if index >= self._batch_size:
+            return res
+        for i, ob in enumerate(self._op_batch_list):
+            if ob._mask is not None and ob._mask._host[index] == 0:
+                continue
+            res.append((ob._op_name, [a[index] for a in ob._arguments]))
+        return res
+
+
+class ProgramCollaterBase(object):
+    """Aligns ragged per-question programs into one canonical operator sequence (data_pipeline.py:626-783):
+    per branch `starter, (filler*, separator)*`, then one terminal operator batch per terminal operator name."""
+
+    def __init__(self, starter_op, sep_op, filler_op, split_num=1, ontology=None):
+        self._sep_op = sep_op
+        self._filler_op = filler_op
+        self._starter_op = starter_op
+        self._split_num = split_num
+        self._ontology = ontology
+
+    def collate_programs(self, questions):
+        B = len(questions)
+        ops, deps, last_dep = [], [], []
+        cursor = -1
+        branch_num = max(len(q['program']['branches']) for q in questions)
+        for b in range(branch_num):
+            heads = [q['program']['branches'][b][0] for q in questions]
+            args = [h['arguments'] if h['operator'] == self._starter_op else ['_'] for h in heads]
+            ops.append(OperatorBatch(self._starter_op, args, B, False, mask=np.ones(B, dtype=np.float32)))
+            deps.append([])
+            cursor += 1
+            # slot[k] = fillers that run before the k-th separator, then the separator itself
+            fillers, seps = [], []
+            for k, q in enumerate(questions):
+                f_i = s_i = 0
+                for o in q['program']['branches'][b][1:]:
+                    if o['operator'] == self._filler_op:
+                        while len(fillers) <= s_i:
+                            fillers.append([])
+                            f_i = 0
+                        if f_i >= len(fillers[s_i]):
+                            fillers[s_i].append({'arguments': [None] * B, 'mask': np.zeros(B, dtype=np.float32)})
+                        fillers[s_i][f_i]['mask'][k] = 1.0
+                        fillers[s_i][f_i]['arguments'][k] = o['arguments']
+                        f_i += 1
+                    elif o['operator'] == self._sep_op:
+                        if s_i >= len(seps):
+                            seps.append({'arguments': [None] * B, 'mask': np.zeros(B, dtype=np.float32)})
+                        seps[s_i]['mask'][k] = 1.0
+                        seps[s_i]['arguments'][k] = o['arguments']
+                        s_i += 1
+                        f_i = 0
+            for n in range(max(len(seps), len(fillers))):
+                for d in (fillers[n] if n < len(fillers) else []):
+                    ops.append(OperatorBatch(self._filler_op, d['arguments'], B, False, mask=d['mask']))
+                    deps.append([cursor])
+                    cursor += 1
+                if n < len(seps):
+                    ops.append(OperatorBatch(self._sep_op, seps[n]['arguments'], B, False, mask=seps[n]['mask']))
+                    deps.append([cursor])
+                    cursor += 1
+            last_dep.append(cursor)
+        terminal = {}
+        for k, q in enumerate(questions):
+            o = q['program']['last_op']
+            slot = terminal.setdefault(o['operator'], {'arguments': [None] * B, 'mask': np.zeros(B, dtype=np.float32)})
+            slot['arguments'][k] = o['arguments']
+            slot['mask'][k] = 1.0
+        for name, slot in terminal.items():
+            ops.append(OperatorBatch(name, slot['arguments'], B, True, mask=slot['mask']))
+            deps.append(last_dep)
+        return ops, deps
+
+    def collate_object_features(self, questions):
+        return None, None
+
+    def collate_meta_data(self, questions):
+        return None
+
+    def collate(self, questions):
+        result = []
+        n = len(questions)
+        split_num = min(self._split_num, n)
+        split_size = math.ceil(n / split_num)
+        device = torch.device('cpu')
+        for i in range(split_num):
+            chunk = questions[i * split_size:min((i + 1) * split_size, n)]
+            if not chunk:
+                break
+            ops, deps = self.collate_programs(chunk)
+            object_features, object_batch_index = self.collate_object_features(chunk)
+            pb = ProgramBatch(device, ops, deps, [q['answer'] for q in chunk], object_features, object_batch_index,
+                              [q.get('original_dict') for q in chunk], meta_data=self.collate_meta_data(chunk))
+            for ob in pb._op_batch_list:
+                ob._op_id = str(i) + ':' + ob._op_id            # :775-777
+            if self._ontology is not None:
+                pb.lower(self._ontology)
+            result.append(pb)
+        return result

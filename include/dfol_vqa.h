@@ -118,7 +118,7 @@ int dfol_filter_fwd_f32(const float* att_in, const float* ll, const int32_t* pre
  *   prior_s, prior_o [Q, NS]   row pred_q[p] is read
  *   tile             [P, NS, NS] in `orientation`
  *   quant_s, quant_o [P]       quantifiers (float 0/1) of the subject / object variable
- *   want             [P]       DFOL_WANT_* bits; an unwanted posterior row is left untouched.  NULL = both.
+ *   want             [P]       DFOL_WANT_* bits; an unwanted posterior row is written as zeros.  NULL = both.
  *   post_s, post_o   [P, NS]   out (either may be NULL if no predicate wants it)
  *   lone_forall_identity       1 reproduces the reference's single-predicate literal branch
  *                              (:104-108,:129-133: P == 1 and FOR_ALL leaves the value untouched)

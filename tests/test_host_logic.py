@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirror of the reference API: program collation, lowering, ontology, gather."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+import dfol_vqa_amd as D  # noqa: E402
+from dfol_vqa_amd import host_util as hu  # noqa: E402
+from dfol_vqa_amd.fol_types import TokenType  # noqa: E402
+from oracle import dfol_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ontology(mini_ontology_paths):
+    p = mini_ontology_paths
+    return D.GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["word_embedding_file"],
+                         relation_json_path=p["relation_file"])
+
+
+def test_g7_collate_matches_reference():
+    _, meta = gu.load("g7_collate")
+    coll = D.ProgramCollaterBase("select", "relate", "filter", 1)
+    for case in meta["cases"]:
+        ops, deps = coll.collate_programs(case["questions"])
+        assert deps == case["dependencies"], case["name"]
+        assert len(ops) == len(case["ops"])
+        for mine, ref in zip(ops, case["ops"]):
+            assert mine._op_name == ref["op_name"] and mine._is_terminal == ref["is_terminal"]
+            assert [list(a) for a in mine._arguments] == ref["arguments"], (case["name"], ref["op_name"])
+            assert mine._mask.tolist() == ref["mask"]
+            assert mine._predicate_num == ref["predicate_num"]
+            qi = None if mine._question_index is None else mine._question_index.tolist()
+            assert qi == ref["question_index"]
+    coll3 = D.ProgramCollaterBase("select", "relate", "filter", 3)
+    qs = [dict(q, answer="yes") for q in meta["cases"][0]["questions"]]
+    pbs = coll3.collate(qs)
+    assert [pb.batch_size() for pb in pbs] == meta["split3_sizes"]
+    assert [[ob._op_name for ob in pb._op_batch_list] for pb in pbs] == meta["split3_ops"]
+    assert all(ob._op_id.startswith("%d:" % i) for i, pb in enumerate(pbs) for ob in pb._op_batch_list)
+
+
+def test_collate_agrees_with_oracle_collate():
+    _, meta = gu.load("g4_exist")
+    qs = [{"program": q["program"]} for q in meta["questions"]]
+    ops, deps = D.ProgramCollaterBase("select", "relate", "filter").collate_programs(qs)
+    o_ops, o_deps = orc.collate_programs(qs)
+    assert deps == o_deps
+    for a, b in zip(ops, o_ops):
+        assert a._op_name == b["op_name"] and [list(x) for x in a._arguments] == b["arguments"] and a._mask.tolist() == b["mask"]
+
+
+def test_g8_gather_results():
+    _, meta = gu.load("g8_gather")
+    QT = D.QuestionType
+    outs = [{"answer": [["yes"], ["no"]], "log_probability": torch.tensor([-0.1, -2.0]), "options": ["no", "yes"], "variable_set": None,
+             "type": QT.BINARY, "cumulative_loss": 0, "variable_sets_num": 3, "answer_log_probability": [[-0.1], [-0.14]]},
+            {"answer": [["no"], ["yes"]], "log_probability": torch.tensor([-3.0, -0.2]), "options": ["no", "yes"], "variable_set": None,
+             "type": QT.BINARY, "cumulative_loss": 0, "variable_sets_num": 4, "answer_log_probability": [[-0.05], [-0.2]]}]
+    res = D.gather_results(outs)
+    ref = meta["binary"]
+    for k in ("answer", "options", "answer_log_probability", "variable_sets_num", "cumulative_loss"):
+        assert res[k] == ref[k], k
+    assert int(res["type"]) == ref["type"]
+    assert np.allclose(res["log_probability"].numpy(), ref["log_probability"])
+    outs_q = [{"answer": [["red"]], "log_probability": torch.tensor([-0.1, -2.0]), "options": [["red", "blue"]], "variable_set": None,
+               "type": QT.QUERY, "cumulative_loss": 0, "variable_sets_num": 1, "answer_log_probability": [[-0.1]]},
+              {"answer": [["on"]], "log_probability": torch.tensor([-0.3, -1.0]), "options": [["on", "under"]], "variable_set": None,
+               "type": QT.QUERY, "cumulative_loss": 0, "variable_sets_num": 2, "answer_log_probability": [[-0.3]]}]
+    res = D.gather_results(outs_q)
+    assert res["options"] == meta["query"]["options"] and res["answer"] == meta["query"]["answer"]
+
+
+def test_ontology_matches_oracle_ontology(ontology, mini_ontology_paths):
+    p = mini_ontology_paths
+    o = orc.Ontology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+    assert ontology._relation_index == o.relation_index
+    assert ontology._relation_reveresed_index == o.relation_reversed
+    assert "riding" in ontology._relations and "riding" not in ontology._vocabulary["arg_to_idx"]
+    for name in ("color", "animal", "entity", "cup", None):
+        assert sorted(map(str, ontology.query(name))) == sorted(map(str, o.query(name)))
+    assert ontology.decode_token(ontology.encode_token("not(red)")) == "not(red)"
+    assert ontology.decode_token(ontology.encode_token("true")) is True
+    emb = ontology.get_embeddings(["to the left of", "red", "unknownword"])
+    assert emb.shape == (3, 12) and np.all(emb[2] == 0) and np.abs(emb[0]).sum() > 0
+
+
+def test_real_metadata_parses_like_the_reference():
+    """Only where the reference checkout exists (this container): the shipped GQA metadata gives 2335 / 333 columns."""
+    base = "/root/reference/src/nsvqa/data/metadata"
+    if not os.path.exists(base):
+        pytest.skip("reference metadata not present on this machine")
+    o = D.GQAOntology(os.path.join(base, "gqa_all_attribute.json"), os.path.join(base, "gqa_all_class.json"),
+                      os.path.join(base, "gqa_vocab.json"), None, relation_json_path=os.path.join(base, "gqa_relation.json"))
+    assert len(o._vocabulary["idx_to_arg"]) == 2335 and len(o._relation_index) == 333
+    assert len(o._attribute_index) == 2335 - 333
+
+
+def test_token_lowering(ontology):
+    toks = ["red", None, "_", " not(blue) ", "small"]
+    low = hu.lower_tokens(toks, ontology, TokenType.ATTRIBUTE)
+    a2i = ontology._vocabulary["arg_to_idx"]
+    assert low.cols.tolist() == [a2i["red"] - 1, -1, -1, a2i["blue"] - 1, a2i["small"] - 1]
+    assert low.neg.tolist() == [0, 0, 0, 1, 0] and low.valid.tolist() == [1, 0, 0, 1, 1]
+    assert low.any_neg and low.any_valid and not low.all_valid
+    rel = hu.lower_tokens(["on", "not(to the left of)"], ontology, TokenType.RELATION)
+    assert rel.cols.tolist() == [ontology._relation_reveresed_index[a2i["on"] - 1], ontology._relation_reveresed_index[a2i["to the left of"] - 1]]
+    with pytest.raises(KeyError):
+        hu.lower_tokens(["no such concept"], ontology, TokenType.ATTRIBUTE)
+    assert hu.detect_negations(["not(red)", "blue"]) == (True, [True, False], ["red", "blue"])
+    assert hu.segments_of([0, 0, 1, 2, 2, 2]).tolist() == [0, 2, 3, 6]
+
+
+def test_collater_lowers_when_given_an_ontology(ontology):
+    _, meta = gu.load("g4_exist")
+    qs = [{"program": q["program"], "answer": q["answer"]} for q in meta["questions"]]
+    pb = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ontology).collate(qs)[0]
+    sel = pb._op_batch_list[0]
+    assert sel._arguments[0].lowered is not None and sel._arguments[0].lowered.valid.tolist() == [1, 1, 0, 1, 1, 0]
+    rel = [ob for ob in pb._op_batch_list if ob._op_name == "relate"][0]
+    assert rel._arguments[0].lowered_type == TokenType.RELATION and rel._arguments[2].lowered_type == TokenType.ATTRIBUTE
+    assert pb._question_type == D.QuestionType.BINARY
+
+
+def test_find_max_ind_matches_oracle():
+    rng = np.random.RandomState(0)
+    lp = np.log(rng.uniform(size=9)).astype(np.float32)
+    lp[4] = lp[3]
+    pq = np.array([0, 0, 1, 1, 1, 2, 2, 2, 2])
+    assert hu.find_max_ind(lp, pq, 3).tolist() == orc.find_max_ind(lp, pq, 3).tolist()

@@ -1,0 +1,251 @@
+"""GPU parity of the interpreter through the reference's operator API.
+
+Candidate: dfol_vqa_amd (HIP kernels behind the C-ABI).  Checked against (a) the goldens captured from
+the reference (g3, g4, g5) and (b) the CPU oracle on larger seeded batches.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+import dfol_vqa_amd as D  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
+from oracle import dfol_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+class TableFeaturizer(object):
+    """The 'object features' are the cached attribute table; the relation table rides in meta_data['R']."""
+
+    def featurize_scene(self, device, objects_list, batch_index, meta_data):
+        return {"attribute_features": objects_list, "relation_features": {"features": meta_data["R"], "index": None},
+                "object_num": objects_list.size(0)}
+
+
+class TableCollater(D.ProgramCollaterBase):
+    def __init__(self, split_num=1, ontology=None, key="A"):
+        super(TableCollater, self).__init__("select", "relate", "filter", split_num, ontology=ontology)
+        self._key = key
+
+    def collate_object_features(self, questions):
+        feats = torch.cat([torch.as_tensor(q["scene"][self._key]) for q in questions], 0)
+        bi = torch.cat([torch.full((q["scene"]["n"],), i, dtype=torch.int64) for i, q in enumerate(questions)])
+        return feats, bi
+
+    def collate_meta_data(self, questions):
+        md = {"index": {}, "embedding": torch.zeros(1, 1)}
+        if self._key == "A":
+            md["R"] = torch.cat([torch.as_tensor(q["scene"]["R"]) for q in questions], 0)
+        return md
+
+
+@pytest.fixture(scope="module")
+def ontology(mini_ontology_paths):
+    p = mini_ontology_paths
+    return D.GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["word_embedding_file"],
+                         relation_json_path=p["relation_file"])
+
+
+@pytest.fixture(scope="module")
+def oracle_ontology(mini_ontology_paths):
+    p = mini_ontology_paths
+    return orc.Ontology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+
+
+def table_model(ontology, normalize=True):
+    oracle = D.ClassifierOracle(ontology, None, None, None, normalize=normalize, cached=True)
+    return D.BatchGQAInterpreter("golden", oracle, ontology, TableFeaturizer(), cached=True).to(DEV).eval()
+
+
+def run(model, questions, scenes, ontology, split=1, lower=True, return_trace=False, key="A", training=False):
+    qs = [dict(q, scene=s) for q, s in zip(questions, scenes)]
+    pbs = TableCollater(split, ontology if lower else None, key).collate(qs)
+    for pb in pbs:
+        pb.create_sparse_tensors()
+    pbs = [pb.to_cuda(DEV) for pb in pbs]
+    return model(pbs, training, return_trace=return_trace), pbs
+
+
+@pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS)
+@pytest.mark.parametrize("lower", [True, False])
+def test_g4_goldens(ontology, name, lower):
+    a, meta = gu.load(name)
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    model = table_model(ontology, meta.get("normalize", True))
+    res, _ = run(model, qs, scenes, ontology, meta.get("split", 1), lower)
+    lp = res["log_probability"].cpu().numpy()
+    if name in gu.G4_STRESS:
+        assert np.abs(np.exp(lp) - np.exp(a["lp_f32"])).max() <= 2e-6
+        return
+    gu.check_logprob(lp, a["lp_f32"], a["lp_f64"], name)
+    assert res["answer"] == meta["answer"], name
+    assert int(res["type"]) == meta["type"]
+    if meta["type"] == 1 and name != "g4_compare":
+        assert res["options"] == meta["options"]
+
+
+def test_g4_trace_and_implicit_end(ontology):
+    a, meta = gu.load("g4_exist")
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    model = table_model(ontology)
+    (res, traces), pbs = run(model, qs, scenes, ontology, return_trace=True)
+    img = np.repeat(np.arange(len(scenes)), [s["n"] for s in scenes])
+    own = img[None, :] == np.arange(len(scenes))[:, None]
+    checked = 0
+    for i, x in enumerate(traces[0]):
+        key = "trace_f32_b0_op%d_att" % i
+        if key in a.files:
+            flat = x.flat_log_attention().numpy()
+            gu.check_logprob(flat[own], a[key][own], a["trace_f64_b0_op%d_att" % i][own], "trace op %d" % i, lp_tol=2e-4)
+            assert np.array_equal(x._quantifier.cpu().numpy(), a["trace_f32_b0_op%d_quant" % i])
+            assert x._name == meta["trace_names"]["b0_op%d" % i]
+            checked += 1
+    assert checked >= 5
+    # implicit `end`: drop the terminal op batch, the interpreter must append `end` (batch_gqa_interpreter.py:75-76)
+    a, meta = gu.load("g4_end")
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
+    pb = TableCollater(1, ontology).collate(qq)[0]
+    pb2 = D.ProgramBatch(pb.device, pb._op_batch_list[:-1], pb._dependencies[:-1], pb._answers, pb._object_features,
+                         pb._object_batch_index, pb._original_dicts, pb._meta_data)
+    pb2.create_sparse_tensors()
+    res = model([pb2.to_cuda(DEV)], False)
+    assert int(res["type"]) == int(D.QuestionType.STATEMENT)
+    gu.check_logprob(res["log_probability"].cpu().numpy(), a["lp_f32"], a["lp_f64"], "end")
+    assert res["answer"] == meta["answer"]
+
+
+def test_g3_filter_relate_api(ontology):
+    a, meta = gu.load("g3_filter_relate")
+    n_list = meta["n"]
+    A = torch.tensor(np.concatenate([a["A_%d" % i] for i in range(len(n_list))]), device=DEV)
+    R = torch.tensor(np.concatenate([a["R_%d" % i] for i in range(len(n_list))]), device=DEV)
+    img = torch.tensor(np.repeat(np.arange(len(n_list)), n_list))
+    world = D.BatchWorld(DEV, int(sum(n_list)), A, {"features": R, "index": None}, img, {"index": {}, "embedding": torch.zeros(1, 1)})
+    oracle = D.ClassifierOracle(ontology, None, None, None, normalize=True, cached=True)
+    flt, rel = D.FilterBatch(oracle), D.RelateBatch(oracle)
+    img_np = img.numpy()
+    for case in meta["cases"]:
+        n = case["name"]
+        vs0 = world.variable_set(["a", "b", "c"], case["quant0"], world.from_flat(torch.tensor(a["att0"])))
+        vs1 = world.variable_set(["d", "e", "f"], case["quant1"], world.from_flat(torch.tensor(a["att1"])))
+        pq = np.asarray(case["pqm"] if case["pqm"] is not None else np.arange(len(case["tokens"])))
+        own = img_np[None, :] == pq[:, None]
+        if case["kind"] == "filter":
+            out = flt("id", world, vs0, list(case["tokens"]), case["pqm"], normalized_probability=case["normalized"])
+            got = [(out, "_att")]
+        else:
+            s, o = rel("id", world, vs0, vs1, list(case["tokens"]), case["pqm"], normalized_probability=case["normalized"])
+            got = [(s, "_satt"), (o, "_oatt")]
+        for vs, key in got:
+            gu.check_logprob(vs.flat_log_attention().numpy()[own], a[n + key + "_f32"][own], a[n + key + "_f64"][own], n, lp_tol=2e-4)
+            assert np.array_equal(vs._quantifier.cpu().numpy(), a[n + "_quant_f32"])
+
+
+def neural_model(ontology, cfg, weights):
+    from dfol_vqa_amd import experiment
+    model = experiment.build_model(dict(cfg), ontology)
+    sd = {k: torch.tensor(v) for k, v in weights.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected              # the reference's parameter names all exist here
+    return model.to(DEV).eval()
+
+
+def test_g5_neural_oracle(ontology):
+    a, meta = gu.load("g5_neural_oracle")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights)
+    qs, scenes = gu.questions_and_scenes(a, meta, "X")
+    qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(qq)]
+    world = model.build_scene(DEV, pbs[0]._object_features, pbs[0]._object_batch_index, pbs[0]._meta_data, pbs[0]._object_nums)
+    assert np.allclose(world._attribute_features.detach().cpu().numpy(), a["A_f64"], rtol=2e-5, atol=2e-5)
+    assert np.allclose(world._relation_features["features"].detach().cpu().numpy(), a["R_f64"], rtol=2e-5, atol=2e-5)
+    res = model(pbs, False)
+    gu.check_logprob(res["log_probability"].detach().cpu().numpy(), a["lp_f32"], a["lp_f64"], "g5")
+    assert res["answer"] == meta["answer"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# larger seeded batches against the CPU oracle
+# ---------------------------------------------------------------------------------------------------
+NOUNS = ["dog", "cat", "table", "chair", "car", "man", "cup", "tree"]
+ATTRS = ["red", "blue", "small", "large", "wood", "white"]
+RELS = ["on", "under", "near", "to the left of", "holding"]
+
+
+def random_questions(kind, count, n_lo, n_hi, C, CR, seed):
+    rng = np.random.RandomState(seed)
+    op = syn.op
+    qs, scenes = [], []
+    for i in range(count):
+        qid = seed * 1000 + i
+        pick = lambda xs: xs[rng.randint(len(xs))]
+        branch = [op("select", pick(NOUNS + ["_"]))]
+        for _ in range(rng.randint(0, 4)):
+            if rng.uniform() < 0.5:
+                a_ = pick(ATTRS)
+                branch.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.2 else a_))
+            else:
+                branch.append(op("relate", pick(RELS), bool(rng.uniform() < 0.5), pick(NOUNS + ["_"])))
+        branches = [branch]
+        if kind in ("and", "or", "two_same", "two_different", "compare"):
+            branches.append([op("select", pick(NOUNS)), op("filter", pick(ATTRS))])
+        last = {"exist": op("exist"), "and": op("and"), "or": op("or"), "verify_attrs": op("verify_attrs", [pick(ATTRS), pick(ATTRS)]),
+                "verify_rel": op("verify_rel", pick(RELS), bool(rng.uniform() < 0.5), pick(NOUNS)),
+                "choose_attr": op("choose_attr", ["red", "blue"]), "query_attr": op("query_attr", pick(["color", "size", "material"])),
+                "choose_rel": op("choose_rel", ["on", "under"], bool(rng.uniform() < 0.5), pick(NOUNS)),
+                "two_same": op("two_same", "color"), "two_different": op("two_different", "size"), "all_same": op("all_same", "material"),
+                "all_different": op("all_different", "color"), "compare": op("compare", pick(ATTRS), bool(rng.uniform() < 0.5))}[kind]
+        qs.append(syn.question(qid, branches, last, "yes"))
+        scenes.append(syn.table_scene(qid, int(rng.randint(n_lo, n_hi + 1)), C, CR))
+    return qs, scenes
+
+
+@pytest.mark.parametrize("kind", ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
+                                  "two_same", "two_different", "all_same", "all_different", "compare"])
+def test_all_ops_against_oracle(ontology, oracle_ontology, kind):
+    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
+    qs, scenes = random_questions(kind, 24, 2, 40, C, CR, seed=hash(kind) % 1000)
+    model = table_model(ontology)
+    res, _ = run(model, qs, scenes, ontology, split=2)
+    lp = res["log_probability"].cpu().numpy()
+    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, split=2)
+    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, split=2)
+    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], kind)
+    if kind not in ("compare",):
+        # answers can only differ where two options tie or p sits on 0.5 within rounding
+        diff = [i for i, (x, y) in enumerate(zip(res["answer"], r64["answer"])) if x != y]
+        assert len(diff) <= 1, (kind, diff)
+
+
+def test_ragged_to_100_objects(ontology, oracle_ontology):
+    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
+    qs, scenes = random_questions("exist", 12, 60, 100, C, CR, seed=77)
+    scenes[3] = syn.table_scene(991, 1, C, CR)       # a single-object image rides along
+    model = table_model(ontology)
+    res, _ = run(model, qs, scenes, ontology)
+    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32)
+    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64)
+    gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "ragged100")
+
+
+def test_split_invariance(ontology):
+    """The same questions as 1 ProgramBatch and as 4 give identical log-probabilities."""
+    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
+    qs, scenes = random_questions("exist", 16, 5, 36, C, CR, seed=5)
+    for q in qs:      # negation anywhere in an op batch changes how its neighbours are rounded; keep this test free of it
+        for o in q["program"]["branches"][0]:
+            o["arguments"] = [a[4:-1] if isinstance(a, str) and a.startswith("not(") else a for a in o["arguments"]]
+    model = table_model(ontology)
+    r1, _ = run(model, qs, scenes, ontology, split=1)
+    r4, _ = run(model, qs, scenes, ontology, split=4)
+    assert torch.equal(r1["log_probability"], r4["log_probability"])
+    assert r1["answer"] == r4["answer"]

@@ -335,7 +335,12 @@ def test_box_and_pair_features(L):
     pair_off = np.concatenate([[0], np.cumsum([n * (n - 1) for n in n_list])]).astype(np.int64)
     pair = L.pair_features(obj, D, dev(obj_off), dev(pair_off), len(n_list), max(n_list), int(pair_off[-1])).cpu().numpy()
     assert pair.shape == pair_ref.shape
-    assert np.allclose(pair, pair_ref, rtol=1e-5, atol=2e-6)
+    ang = 2 * D + 1                                   # asin is ill-conditioned at +-1: compare its sine there
+    rest = np.ones(pair.shape[1], bool)
+    rest[ang] = False
+    assert np.allclose(pair[:, rest], pair_ref[:, rest], rtol=1e-5, atol=2e-6)
+    assert np.allclose(np.sin(pair[:, ang]), np.sin(pair_ref[:, ang]), atol=2e-6)
+    assert np.allclose(pair[:, ang], pair_ref[:, ang], atol=2e-3)
 
 
 def test_errors_are_loud(L):

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: questions/s of the ∇-FOL interpreter forward on synthetic GQA-style scenes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--objects 100] [--batch 256]
+
+One step = one pass of the hot path (build_scene: featurizer + oracle MLPs -> likelihoods; then the
+program select -> filter -> relate -> exist for every question) over one batch of `--batch` questions
+whose object features and lowered program are already resident in HBM.  Workload = BASELINE.json
+configs[1] (3-hop Filter->Relate->Exist programs, fp32, batch=256) on N-object scenes; N defaults to
+100, the size BASELINE.json's metric is quoted on (configs[1] itself says 36: pass --objects 36).
+
+For --gpus N > 1 the driver launches one rank per GPU (torch.distributed.run); questions are
+independent, so each rank runs its own shard with no data-path collective (weak scaling) and the
+ranks only meet at the timing barriers.
+
+Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel of the step; `kernels` adds the
+HBM roofline of the Relate/Filter logic kernels on >= 65536 resident predicates;
+`cpu_baseline` is the CPU oracle (a port of the reference's algorithm) timed on this host.
+"""
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
+F32_MFMA_PEAK = 157.3e12     # FLOP/s, dense f32-input MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--objects", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=None, help="questions in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--stress-preds", type=int, default=65536)
+    return ap.parse_args()
+
+
+def build_batch(args, rank, ontology, names, device):
+    import dfol_vqa_amd as D
+    from dfol_vqa_amd import synthetic as syn
+
+    class Collater(D.ProgramCollaterBase):
+        def __init__(self):
+            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology)
+
+        def collate_object_features(self, questions):
+            feats = torch.cat([torch.from_numpy(q["scene"]["X"]) for q in questions], 0)
+            bi = torch.cat([torch.full((q["scene"]["n"],), i, dtype=torch.int64) for i, q in enumerate(questions)])
+            return feats, bi
+
+        def collate_meta_data(self, questions):
+            return {"index": {}, "embedding": torch.zeros(1, 1)}
+
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    qs = []
+    for i in range(args.batch):
+        qid = rank * args.batch + i                        # scenes are keyed by question id: sharding never changes inputs
+        br, last = syn.three_hop_program(qid, nouns, attrs, rels)
+        qs.append(syn.question(qid, br, last, "yes", syn.feature_scene(qid, args.objects, 2048)))
+    pbs = Collater().collate(qs)
+    for pb in pbs:
+        pb.create_sparse_tensors()
+    return qs, [pb.to_cuda(device) for pb in pbs]
+
+
+def init_weights(model):
+    """Random weights of the reference architecture; the embedding rows get GloVe-like magnitudes so that the
+    concept probabilities are sparse instead of saturated."""
+    torch.manual_seed(0)
+    lin = model._oracle._embedding_network.linear
+    with torch.no_grad():
+        lin.weight.normal_(0.0, 0.1)
+        lin.bias.fill_(-2.0)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=device)
+
+    import dfol_vqa_amd as D
+    from dfol_vqa_amd import _lib as L
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd import synthetic as syn
+    L.load()
+
+    tmp = tempfile.mkdtemp(prefix="dfol_bench_")
+    paths, names = syn.write_synthetic_ontology(tmp)
+    cfg = syn.reference_config(paths)
+    ontology = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ontology)
+    init_weights(model)
+    model = model.to(device).eval()
+    qs, pbs = build_batch(args, rank, ontology, names, device)
+
+    def step():
+        return model(pbs, False)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            res = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_q = args.batch * world * args.steps
+    out = {"metric": "questions/sec (GQA programs, N=%d objects)" % args.objects, "value": total_q / elapsed, "unit": "questions/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: select->filter->relate->exist (3-hop), fp32, %d questions/GPU/step, "
+                                  "%d-object synthetic scenes, full-size oracle (2048->512, 516/1036->256->300->2335)"
+                                  % (args.batch, args.objects),
+                      "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world}}
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
+        names_timed = list(L.SIGNATURES)
+        with torch.no_grad():
+            L.enable_kernel_timing(names_timed)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            timing = L.disable_kernel_timing()
+        per_step = {k: (n / 3.0, t / 3.0) for k, (n, t) in timing.items() if n}
+        dom = max(per_step, key=lambda k: per_step[k][1])
+        out["kernel_ms_per_step"] = {k: round(v[1] * 1e3, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][1])}
+        O = args.batch * args.objects
+        pairs = args.batch * args.objects * (args.objects - 1)
+        if dom == "dfol_linear_act_f32":
+            # algorithmic flops of the step's GEMM launches as the reference writes them, except that only the
+            # 333 relation columns of the pair embedding are computed (SURVEY.md §8(d) "reduced form")
+            flops = 2.0 * (O * 2048 * 512 + O * (516 * 256 + 256 * 300 + 300 * 2335) + pairs * (1036 * 256 + 256 * 300 + 300 * 333))
+            ach = flops / per_step[dom][1]
+            out["roofline"] = {"kernel": "linear_act_kernel (all GEMM launches of one step)", "bound": "mfma", "achieved": ach / 1e12,
+                               "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK, "traffic": None}
+        else:
+            N = args.objects
+            nbytes = args.batch * (4 * N * N + 16 * N)
+            ach = nbytes / (per_step[dom][1] / max(per_step[dom][0], 1))
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK, "traffic": None}
+        out["kernels"] = stress_kernels(L, device, args.stress_preds, 100)
+        sample = args.cpu_sample if args.cpu_sample is not None else (8 if args.objects > 64 else 32)
+        if sample > 0:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs[:sample], res, sample)
+        print(json.dumps(out))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def stress_kernels(L, device, P, N):
+    """HBM roofline of the logic kernels on P resident predicates of N objects (>= 2.6 GB of relation tiles)."""
+    NS = (N + 3) // 4 * 4
+    g = torch.Generator(device=device).manual_seed(1)
+    u = torch.rand(P, NS, NS, device=device, generator=g)
+    tile = torch.log(torch.where(torch.rand(P, NS, NS, device=device, generator=g) < 0.1, 0.5 + 0.5 * u, 0.05 * u).clamp_min(1e-5))
+    del u
+    prior = torch.log(torch.rand(P, NS, device=device, generator=g).clamp_min(1e-3)) * 0.3
+    pq = torch.arange(P, dtype=torch.int32, device=device)
+    n_obj = torch.full((P,), N, dtype=torch.int32, device=device)
+    ones = torch.ones(P, device=device)
+    res = []
+
+    def timed(name, fn, nbytes, iters=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        L.enable_kernel_timing([name])
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        n, t = L.disable_kernel_timing()[name]
+        ach = nbytes / (t / n)
+        return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                "predicates": P, "objects": N, "us_per_launch": t / n * 1e6}
+
+    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=False), P * (4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_fwd (one posterior, as GQARelateBatch uses it)", bytes_per_predicate=4 * N * N + 12 * N))
+    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones), P * (4 * N * N + 16 * N))
+    res.append(dict(r, kernel="relate_fwd (both posteriors, RelateBatch API)", bytes_per_predicate=4 * N * N + 16 * N))
+    ll = tile[:, 0, :].contiguous()
+    del tile
+    r = timed("dfol_filter_fwd_f32", lambda: L.filter_fwd(prior, ll, pq, n_obj), P * 12 * N)
+    res.append(dict(r, kernel="filter_fwd", bytes_per_predicate=12 * N))
+    return res
+
+
+def cpu_baseline(model, paths, questions, gpu_result, sample):
+    """The CPU oracle (numpy port of the reference's flat-layout algorithm, full-size tables) on a bounded sample of
+    the same workload, timed on this host; its log-probabilities double as an in-run parity check."""
+    from oracle import dfol_oracle as orc
+    ont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    scenes = [q["scene"] for q in questions]
+    best = None
+    for pb_size in (1, 4):                                  # the reference's cost is super-linear in the ProgramBatch size
+        chunks = max(1, -(-sample // pb_size))
+        t0 = time.perf_counter()
+        r = orc.run_questions(ont, questions, scenes, np.float32, split=chunks, weights=weights)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, r, pb_size)
+    dt, r, split = best
+    lp_gpu = gpu_result["log_probability"][:sample].detach().cpu().numpy()
+    lp_cpu = r["log_probability"]
+    agree = sum(1 for a, b in zip(gpu_result["answer"][:sample], r["answer"]) if a == b)
+    base = {"value": sample / dt, "unit": "questions/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d questions of the same workload (N=%d), numpy fp32 oracle incl. full [pairs,2335] tables, "
+                      "ProgramBatch size %d, %.1f s" % (sample, questions[0]["scene"]["n"], split, dt)}
+    parity = {"max_abs_dp": float(np.abs(np.exp(lp_gpu) - np.exp(lp_cpu)).max()), "max_abs_dlp": float(np.abs(lp_gpu - lp_cpu).max()),
+              "answers_agree": "%d/%d" % (agree, sample)}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

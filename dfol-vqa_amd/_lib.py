@@ -84,9 +84,36 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline leg).
+_timed = None          # None, or {entry point name: [(start_event, end_event), ...]}
+
+
+def enable_kernel_timing(names):
+    global _timed
+    _timed = {n: [] for n in names}
+
+
+def disable_kernel_timing():
+    """-> {name: (launches, total seconds)}; call after torch.cuda.synchronize()."""
+    global _timed
+    out = {}
+    if _timed is not None:
+        for n, evs in _timed.items():
+            out[n] = (len(evs), sum(s.elapsed_time(e) for s, e in evs) * 1e-3)
+    _timed = None
+    return out
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _timed is not None and name in _timed:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()                      # torch's current stream == the stream handed to the kernel (_stream())
+        rc = getattr(lib, name)(*args)
+        e.record()
+        _timed[name].append((s, e))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise DfolError("%s failed (%d): %s" % (name, rc, lib.dfol_last_error().decode()))
 

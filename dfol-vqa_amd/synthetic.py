@@ -81,3 +81,48 @@ def three_hop_program(qid, nouns, attributes, relations, negate_prob=0.0):
     if rng.uniform() < negate_prob:
         a = "not(" + a + ")"
     return [[op("select", n1), op("filter", a), op("relate", r, subj, n2)]], op("exist")
+
+
+def write_synthetic_ontology(directory, concept_num=2335, relation_num=333, seed=11):
+    """Metadata files with the reference's schema and the real vocabulary's dimensions (2335 concepts of which
+    333 are relations), but made-up names: the GQA metadata itself belongs to the reference."""
+    import json
+    import os
+    os.makedirs(directory, exist_ok=True)
+    rng = np.random.RandomState(seed)
+    n_rel = relation_num
+    n_noun = 1200
+    n_attr = concept_num - n_rel - n_noun - 40          # 40 category / class names
+    nouns = ["noun%04d" % i for i in range(n_noun)]
+    attrs = ["attr%04d" % i for i in range(n_attr)]
+    rels = ["rel %03d of" % i for i in range(n_rel)]
+    cats = ["category%02d" % i for i in range(20)]
+    classes = ["class%02d" % i for i in range(20)]
+    attribute = {c: attrs[i * 26:(i + 1) * 26] for i, c in enumerate(cats)}
+    klass = {c: nouns[i * 40:(i + 1) * 40] for i, c in enumerate(classes)}
+    args = nouns + attrs + rels + cats + classes
+    assert len(args) == concept_num
+    perm = rng.permutation(concept_num)
+    idx_to_arg = [args[i] for i in perm]
+    vocab = {"op_to_idx": {}, "idx_to_op": [], "arg_to_idx": {a: i + 1 for i, a in enumerate(idx_to_arg)}, "idx_to_arg": idx_to_arg,
+             "img_to_idx": {}, "idx_to_img": []}
+    paths = {k: os.path.join(directory, v) for k, v in (("attribute_file", "attribute.json"), ("class_file", "class.json"),
+                                                         ("relation_file", "relation.json"), ("vocabulary_file", "vocab.json"))}
+    for key, obj in (("attribute_file", attribute), ("class_file", klass), ("relation_file", rels + ["rel missing"]), ("vocabulary_file", vocab)):
+        with open(paths[key], "w") as f:
+            json.dump(obj, f)
+    paths["word_embedding_file"] = None
+    return paths, {"nouns": nouns, "attributes": attrs, "relations": rels}
+
+
+def reference_config(paths, **over):
+    """config/sample_config.yaml's model section (reference config/sample_config.yaml:37-60), with the calibrator off."""
+    cfg = dict(model_name="bench", version="v0", box_features_dim=2048, oracle_input_dim=512, oracle_output_dim=1, word_embedding_dim=300,
+               classifier_oracle=True, featurizer_layers_config=[], attribute_network_layers_config=[256],
+               relation_network_layers_config=[256], operator_layers_config=[], normalize_oracle=True, dropout=0.0,
+               freeze_featurizer=True, freeze_attribute_network=True, freeze_relation_network=True, freeze_embedding_network=True,
+               activate_attention_transfer=False, attention_transfer_state_dim=50, freeze_attention_network=False, trainable_gate=False,
+               likelihood_threshold=0, hard_mode=False, verbose=False, gpu_num=1)
+    cfg.update(paths)
+    cfg.update(over)
+    return cfg

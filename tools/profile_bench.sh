@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box: rocprofv3 kernel-trace stats + HBM traffic counters (separate passes) of bench.py.
+# usage: tools/profile_bench.sh <tag> [bench args...]
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 2 --cpu-sample 0 $*"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
+cd $R
+python3 tools/summarize_profile.py $OUT > $OUT/summary.md 2>&1
+find $OUT -name "*.db" -delete               # the summary has what matters; keep gpurun_out small
+cat $OUT/summary.md

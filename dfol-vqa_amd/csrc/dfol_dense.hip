@@ -230,3 +230,252 @@ extern "C" int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t 
     DFOL_LAUNCH_CHECK("pair_features");
     return 0;
 }
+
+// =====================================================================================================
+// Needed-columns oracle: only the likelihoods a program asks for are ever computed.
+// =====================================================================================================
+// Attribute likelihood of one (image, concept) request: ll[p][o] = LogSigmoid(hidden[o] . E[col] + be[col]).
+// One wavefront per predicate; lanes stride the hidden dimension (coalesced), one wave reduction per object.
+__global__ __launch_bounds__(256) void attr_ll_kernel(const float* __restrict__ hidden, int64_t ld_h, int H,
+                                                      const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be,
+                                                      const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q,
+                                                      const int32_t* __restrict__ pred_col, int P, int NS, float dflt,
+                                                      float* __restrict__ ll) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int q = pred_q[p], col = pred_col[p];
+    const int first = obj_off[q], n = obj_off[q + 1] - first;
+    float* out = ll + (int64_t)p * NS;
+    if (col < 0) {
+        for (int o = lane; o < NS; o += 64) out[o] = dflt;
+        return;
+    }
+    float e[8];                                            // H <= 512
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (lane + 64 * j < H) ? E[(int64_t)col * ld_e + lane + 64 * j] : 0.f;
+    const float bias = be ? be[col] : 0.f;
+    for (int o = 0; o < n; ++o) {
+        const float* h = hidden + (int64_t)(first + o) * ld_h;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (lane + 64 * j < H) s = fmaf(h[lane + 64 * j], e[j], s);
+        s = dfol_wave_sum(s);
+        if (lane == 0) {
+            const float x = s + bias;
+            out[o] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));           // nn.LogSigmoid
+        }
+    }
+    for (int o = n + lane; o < NS; o += 64) out[o] = dflt;
+}
+
+extern "C" int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t H, const float* E, int64_t ld_e, const float* be,
+                                const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P, int32_t NS,
+                                float default_ll, float* ll, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && H > 0 && H <= 512, "attr_ll: bad sizes P=%d NS=%d H=%d (H <= 512)", P, NS, H);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(hidden && E && obj_off && pred_q && pred_col && ll, "attr_ll: null pointer");
+    hipLaunchKernelGGL(attr_ll_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, hidden, ld_hidden, H, E, ld_e, be,
+                       obj_off, pred_q, pred_col, P, NS, default_ll, ll);
+    DFOL_LAUNCH_CHECK("attr_ll");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused pair kernel.  For every ordered object pair (s, o) of an image it rebuilds the pair MLP of the
+// reference without ever materialising the [pairs, 1036] pair matrix or the [pairs, 2335] table:
+//   z = ELU( U[s] + V[o] + Wg . geo(s,o) )            U = W1[:, :D] obj + b1,  V = W1[:, D:2D] obj   (per OBJECT, one GEMM)
+//   h = Sigmoid( W2 z + b2 )                          exact-fp32 MFMA, 128 pairs x HID2 per workgroup
+//   tile[t][s][o] = LogSigmoid( h . E[col_t] + be[col_t] )   only for the (image, concept) requests of the program
+// A workgroup owns 128 consecutive slots e = s*n + o of one image; a wavefront owns 32 of them across ALL
+// HID2 columns (NB accumulator tiles of 32x32), so the final dot products with the requested embedding rows
+// need only a 32-lane shuffle reduction.
+namespace {
+
+constexpr int PK_PITCH = 36;
+
+template <int NB>
+__global__ __launch_bounds__(256, 1) void pair_ll_kernel(
+    const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
+    const float* __restrict__ Wg, const float* __restrict__ W2, int64_t ld_w2, const float* __restrict__ b2, int HID2,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
+    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
+    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
+    float* __restrict__ tiles) {
+    __shared__ __attribute__((aligned(16))) float Bs[32 * NB * PK_PITCH];
+    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
+    const int n = n_obj[q];
+    if (tb * 128 >= n * n) return;
+    bool any = false;
+    for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
+    if (!any) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r32 = lane & 31;
+    const int first = obj_off[q];
+    const int e_slot = tb * 128 + wave * 32 + r32;
+    const bool valid = e_slot < n * n;
+    const int s = valid ? e_slot / n : 0, o = valid ? e_slot - s * n : 0;
+
+    // geometry of this lane's pair: batch_gqa_boxfeatures_pipeline.py:260-279
+    float geo[4];
+    {
+        const float* ps = pos + (int64_t)(first + s) * ld_pos;
+        const float* po = pos + (int64_t)(first + o) * ld_pos;
+        const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
+        const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        geo[0] = dist;
+        geo[1] = asinf(dy / fmaxf(dist, 1e-10f));
+        geo[2] = (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f);
+        geo[3] = (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f);
+    }
+    for (int i = tid; i < HID1; i += 256) *reinterpret_cast<float4*>(&Wgs[i * 4]) = *reinterpret_cast<const float4*>(Wg + i * 4);
+
+    const float* Urow = UV + (int64_t)(first + s) * ld_uv;
+    const float* Vrow = UV + (int64_t)(first + o) * ld_uv + HID1;
+
+    floatx16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;          // W2 loader: 32 rows x 8 float4 per pass, NB passes
+    float4 rb[NB];
+    auto load_w2 = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int nrow = lrow + 32 * i, k = k0 + lk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nrow < HID2 && k < HID1) v = *reinterpret_cast<const float4*>(W2 + (int64_t)nrow * ld_w2 + k);
+            rb[i] = v;
+        }
+    };
+    float4 ru[4], rv[4];
+    auto load_uv = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 16 * half + 4 * j;
+            const bool in = k < HID1;
+            ru[j] = in ? *reinterpret_cast<const float4*>(Urow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[j] = in ? *reinterpret_cast<const float4*>(Vrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_w2(0);
+    load_uv(0);
+
+    for (int k0 = 0; k0 < HID1; k0 += 32) {
+        __syncthreads();                                    // previous chunk's LDS reads are done (also covers Wgs)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PK_PITCH + lk]) = rb[i];
+        __syncthreads();
+        // A operand: 16 contiguous k of this lane's half
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float uu[4] = {ru[j].x, ru[j].y, ru[j].z, ru[j].w}, vv[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = k0 + 16 * half + 4 * j + c;
+                float z = 0.f;
+                if (k < HID1) {
+                    const float4 g = *reinterpret_cast<const float4*>(&Wgs[k * 4]);
+                    z = uu[c] + vv[c] + (g.x * geo[0] + g.y * geo[1] + g.z * geo[2] + g.w * geo[3]);
+                    z = z > 0.f ? z : expm1f(z);            // nn.ELU
+                }
+                a[4 * j + c] = z;
+            }
+        }
+        if (k0 + 32 < HID1) {                               // next chunk's operands fly while this chunk's MFMAs run
+            load_w2(k0 + 32);
+            load_uv(k0 + 32);
+        }
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg) {
+            float4 b4[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b4[i] = *reinterpret_cast<const float4*>(&Bs[(i * 32 + r32) * PK_PITCH + 16 * half + 4 * tg]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 0], b4[i].x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 1], b4[i].y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 2], b4[i].z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 3], b4[i].w, acc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // h = Sigmoid(acc + b2); C layout: column = i*32 + r32, row(e) = (e & 3) + 8 * (e >> 2) + 4 * half
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int ncol = i * 32 + r32;
+        const bool in = ncol < HID2;
+        const float bv = in ? b2[ncol] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = in ? 1.0f / (1.0f + expf(-(acc[i][e] + bv))) : 0.f;
+    }
+    const int64_t tile_sz = (int64_t)NS * NS;
+    for (int k = 0; k < K; ++k) {
+        const int col = req_col[(int64_t)k * Q + q];
+        if (col < 0) continue;                              // uniform over the workgroup
+        float part[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ncol = i * 32 + r32;
+            const float ev = ncol < HID2 ? E[(int64_t)col * ld_e + ncol] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[e] = fmaf(acc[i][e], ev, part[e]);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[e] += __shfl_xor(part[e], m, 64);
+        // every lane of a half now holds the 16 row sums of that half; lane j < 16 writes row j of its half
+        if (r32 < 16) {
+            float v = part[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) v = (r32 == e) ? part[e] : v;
+            const int row = (r32 & 3) + 8 * (r32 >> 2) + 4 * half;
+            const int ee = tb * 128 + wave * 32 + row;
+            if (ee < n * n) {
+                const int ss = ee / n, oo = ee - ss * n;
+                const float x = v + (be ? be[col] : 0.f);
+                const float val = (ss == oo) ? dflt : fminf(x, 0.f) - log1pf(expf(-fabsf(x)));   // nn.LogSigmoid; diagonal stays absent
+                float* t = tiles + (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz;
+                if (req_orient && req_orient[(int64_t)k * Q + q]) t[(int64_t)oo * NS + ss] = val;
+                else t[(int64_t)ss * NS + oo] = val;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                                const float* W2, int64_t ld_w2, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
+                                const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
+                                const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS,
+                                float default_ll, float* tiles, void* stream) {
+    DFOL_REQUIRE(Q >= 0 && K >= 0 && NS > 0 && NS % 4 == 0 && max_n >= 0 && max_n <= NS, "pair_ll: bad sizes Q=%d K=%d NS=%d max_n=%d", Q, K, NS, max_n);
+    DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % 4 == 0 && ld_uv % 4 == 0 && ld_w2 % 4 == 0, "pair_ll: HID1=%d must be a multiple of 4, <= 256, rows 16-byte aligned", HID1);
+    DFOL_REQUIRE(HID2 > 0 && HID2 <= 320, "pair_ll: HID2=%d must be <= 320", HID2);
+    if (Q == 0 || K == 0 || max_n < 2) return 0;
+    DFOL_REQUIRE(UV && pos && Wg && W2 && b2 && E && n_obj && obj_off && req_col && req_tile && tiles, "pair_ll: null pointer");
+    DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll: operands must be 16-byte aligned");
+    const int tpi = dfol_cdiv((int64_t)max_n * max_n, 128);
+    const dim3 grid((unsigned)Q * tpi);
+    hipStream_t st = (hipStream_t)stream;
+#define DFOL_PAIR(NBV)                                                                                                          \
+    hipLaunchKernelGGL(pair_ll_kernel<NBV>, grid, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, ld_e, \
+                       be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles)
+    if (HID2 <= 32) DFOL_PAIR(1);
+    else if (HID2 <= 128) DFOL_PAIR(4);
+    else DFOL_PAIR(10);
+#undef DFOL_PAIR
+    DFOL_LAUNCH_CHECK("pair_ll");
+    return 0;
+}

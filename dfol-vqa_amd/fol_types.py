@@ -46,6 +46,8 @@ class BatchWorld(object):
     def __init__(self, device, object_num, attribute_features, relation_features, batch_index, meta_data=None,
                  attention_transfer_state_dim=0, object_nums=None):
         self._device = device
+        self._lazy = None                 # set by the oracle's needed-columns mode: hidden activations instead of tables
+        self._rel_tiles = {}              # relation tiles computed ahead of the execution loop, keyed by id(lowered tokens)
         self._attribute_features = attribute_features
         self._relation_features = relation_features
         self._object_num = int(object_num)
@@ -67,6 +69,28 @@ class BatchWorld(object):
         self._pair_num = int((n * (n - 1)).sum())
         self._ident = torch.arange(self._batch_size, dtype=torch.int32, device=device)
         self._zeros = None
+
+    # The reference's cached tables ([O, 2335] and [pairs, 333]).  In needed-columns mode they are materialised
+    # only if somebody actually reads them (API compatibility); the interpreter itself never does.
+    @property
+    def _attribute_features(self):
+        if self._attr_table is None and self._lazy is not None:
+            self._lazy.materialize_tables(self)
+        return self._attr_table
+
+    @_attribute_features.setter
+    def _attribute_features(self, value):
+        self._attr_table = value
+
+    @property
+    def _relation_features(self):
+        if self._rel_table is None and self._lazy is not None:
+            self._lazy.materialize_tables(self)
+        return self._rel_table
+
+    @_relation_features.setter
+    def _relation_features(self, value):
+        self._rel_table = value
 
     # -- reference API ---------------------------------------------------------------------------
     def to(self, dtype):

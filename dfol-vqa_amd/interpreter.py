@@ -95,6 +95,13 @@ class BatchInterpreterBase(nn.Module):
             raise NotImplementedError("a featurizer is required (the reference's featurizer-less branch :62-67 is dead code)")
         geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
                               attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums)
+        needed = self._cached and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
+            getattr(self._oracle, "supports_needed_columns", lambda: False)()
+        if needed:
+            # needed-columns mode: no pair matrix, no full tables; the oracle keeps hidden activations instead
+            features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=None)
+            self._oracle.prepare_scene(geometry, features['attribute_features'])
+            return geometry
         if 'world_geometry' in inspect.signature(self._featurizer.featurize_scene).parameters:
             features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=geometry)
         else:                   # a featurizer written against the reference's 4-argument signature
@@ -116,6 +123,8 @@ class BatchInterpreterBase(nn.Module):
                                      program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None))
             if self._has_modulator and modulator_switch:
                 raise NotImplementedError("attention-calibration passes (:87-140) are SURVEY.md §8(f) rank 2: not built yet")
+            if world._lazy is not None:
+                self._oracle.prefetch_relations(world, program_batch)
             ops = program_batch._op_batch_list
             trace = []
             for i, op_batch in enumerate(ops):                   # execution loop :145-172

@@ -133,7 +133,8 @@ class ClassifierOracle(OracleBase):
         self._embedding_network = embedding_network
         self._normalize = normalize
         self._cached = cached
-        self._rel_rows = None
+        self._needed_columns = True       # compute only the likelihood columns a program asks for (when the MLP shape allows)
+        self._split_cache = None
 
     # ---- a3: the cached tables (classifier_oracle.py:145-156) ------------------------------------------
     def _relation_embedding(self):
@@ -157,6 +158,130 @@ class ClassifierOracle(OracleBase):
             rel_output = L.linear_act(h, w, b, L.ACT_LOGSIGMOID)      # only the 333 relation columns are computed
         return attr_output, rel_output
 
+    # ---- needed-columns mode ---------------------------------------------------------------------------
+    def supports_needed_columns(self):
+        """The fused path needs the classifier-oracle shape of the reference's configs: a relation MLP with exactly one
+        hidden layer (Linear, ELU, Linear, Sigmoid), hidden <= 256 (multiple of 4), embedding input <= 320."""
+        if not (self._needed_columns and self._cached):
+            return False
+        if self._attribute_network is None or self._relation_network is None or self._embedding_network is None:
+            return False
+        rel = self._relation_network._network
+        if rel is None or self._attribute_network._network is None:
+            return False
+        lins = [m for m in rel if isinstance(m, nn.Linear)]
+        acts = [m for m in rel if isinstance(m, (nn.ELU, nn.Sigmoid))]
+        if len(lins) != 2 or len(acts) != 2 or not isinstance(acts[0], nn.ELU) or not isinstance(acts[1], nn.Sigmoid):
+            return False
+        if any(isinstance(m, nn.Dropout) and m.training and m.p > 0 for m in rel):
+            return False
+        hid1, hid2 = lins[0].out_features, lins[1].out_features
+        return hid1 % 4 == 0 and hid1 <= 256 and hid2 <= 320 and (lins[0].in_features - 4) % 2 == 0 and lins[1].bias is not None
+
+    def _split_first_layer(self):
+        """W1 [HID1, 2D+4] -> stacked per-object weight [2 HID1, D] (+ bias [b1, 0]) and the geometry columns [HID1, 4].
+        W1 [obj_s, obj_o, geo] + b1 = (W1a obj_s + b1) + W1b obj_o + Wg geo: exact up to fp32 reassociation."""
+        lin = [m for m in self._relation_network._network if isinstance(m, nn.Linear)][0]
+        key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version)
+        if self._split_cache is None or self._split_cache[0] != key:
+            w = lin.weight.detach()
+            hid1, D = w.shape[0], (w.shape[1] - 4) // 2
+            wuv = torch.cat([w[:, :D], w[:, D:2 * D]], 0).contiguous()
+            b1 = lin.bias.detach() if lin.bias is not None else torch.zeros(hid1, device=w.device)
+            buv = torch.cat([b1, torch.zeros_like(b1)]).contiguous()
+            wg = w[:, 2 * D:2 * D + 4].contiguous()
+            self._split_cache = (key, wuv, buv, wg, hid1, D)
+        return self._split_cache[1:]
+
+    def prepare_scene(self, world, obj):
+        """Hidden activations of a scene: attribute hidden [O, H] and the per-object halves of the pair MLP's first layer."""
+        world._lazy = self
+        world._obj = obj
+        world._hidden_attr = self._attribute_network(obj)
+        wuv, buv, wg, hid1, D = self._split_first_layer()
+        assert obj.shape[1] == D, "object feature width does not match the relation network"
+        world._uv = L.linear_act(obj, wuv, buv, L.ACT_NONE)
+        world._attr_table = None
+        world._rel_table = None
+
+    def materialize_tables(self, world):
+        """Full cached tables exactly as the reference builds them (only when a caller reads them)."""
+        lazy, world._lazy = world._lazy, None
+        try:
+            pair = None
+            if world._pair_num > 0:
+                D = world._obj.shape[1]
+                pair = L.pair_features(world._obj, D, world._obj_off, world._pair_off, world._batch_size, max(world._n_list), world._pair_num)
+            a, r = self.compute_all_log_likelihood_2(world._obj, pair)
+            world._attr_table, world._rel_table = a, {'features': r, 'index': None}
+        finally:
+            world._lazy = lazy
+
+    def _relation_full_columns(self, cols333):
+        idx = np.asarray(self._ontology._relation_index, np.int32)
+        c = np.asarray(cols333, np.int64)
+        return np.where(c >= 0, idx[np.maximum(c, 0)], -1).astype(np.int32)
+
+    def _launch_pairs(self, world, req_col, req_tile, tiles, req_orient=None):
+        lins = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+        _, _, wg, hid1, D = self._split_first_layer()
+        emb = self._embedding_network.linear
+        dev = world._device
+        L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, lins[1].weight, lins[1].bias, emb.weight, emb.bias, world._n_obj,
+                  world._obj_off, max(world._n_list), torch.as_tensor(req_col).to(dev), torch.as_tensor(req_tile).to(dev),
+                  None if req_orient is None else torch.as_tensor(req_orient).to(dev), tiles, -30.0)
+
+    def _new_tiles(self, world, count):
+        ragged = min(world._n_list) < world._NS
+        if ragged:       # the pair kernel writes real pairs and the diagonal only
+            return torch.full((count, world._NS, world._NS), -30.0, dtype=torch.float32, device=world._device)
+        return torch.empty(count, world._NS, world._NS, dtype=torch.float32, device=world._device)
+
+    def prefetch_relations(self, world, program_batch):
+        """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel):
+        the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
+        if world._lazy is None:
+            return
+        lows = []
+        for ob in program_batch._op_batch_list:
+            if ob._op_name in ("relate", "verify_rel") and ob._arguments:
+                toks = ob._arguments[0]
+                low = get_lowered(toks, self._ontology, TokenType.RELATION)
+                if getattr(toks, "lowered", None) is None:
+                    toks.lowered, toks.lowered_type = low, TokenType.RELATION
+                if low.any_valid:
+                    lows.append(low)
+        if not lows:
+            return
+        Q = world._batch_size
+        tiles = self._new_tiles(world, len(lows) * Q)
+        req_col = np.stack([self._relation_full_columns(low.cols) for low in lows])
+        req_tile = np.arange(len(lows) * Q, dtype=np.int32).reshape(len(lows), Q)
+        self._launch_pairs(world, req_col, req_tile, tiles)
+        for k, low in enumerate(lows):
+            world._rel_tiles[id(low)] = tiles[k * Q:(k + 1) * Q]
+
+    def _relation_tiles_now(self, world, low, pred_q_host):
+        """Relation tiles for one token list outside the prefetch (e.g. choose_rel's flattened option list)."""
+        pq = np.asarray(list(pred_q_host), np.int64)
+        P, Q = len(pq), world._batch_size
+        slot = np.zeros(P, np.int64)                      # j-th predicate of its question
+        seen = {}
+        for p, q in enumerate(pq):
+            slot[p] = seen.get(int(q), 0)
+            seen[int(q)] = slot[p] + 1
+        K = int(slot.max()) + 1
+        req_col = np.full((K, Q), -1, np.int32)
+        req_tile = np.zeros((K, Q), np.int32)
+        full = self._relation_full_columns(low.cols)
+        req_col[slot, pq] = full
+        req_tile[slot, pq] = np.arange(P, dtype=np.int32)
+        tiles = self._new_tiles(world, P)
+        if not low.all_valid:
+            tiles[torch.as_tensor(np.nonzero(low.valid == 0)[0]).to(world._device)] = -30.0
+        self._launch_pairs(world, req_col, req_tile, tiles)
+        return tiles
+
     # ---- a4 / a5: per-predicate blocks (classifier_oracle.py:44-137) -------------------------------------
     def block_likelihood(self, token_type, low, pred_q, pred_q_host, world, default_log_likelihood=-30,
                          normalized_probability=True, orientation=L.TILE_SUBJECT_ROWS):
@@ -164,6 +289,8 @@ class ClassifierOracle(OracleBase):
             raise NotImplementedError("only the cached-table oracle of the reference's experiments is built")
         dev = world._device
         cols, _, _ = low.on(dev)
+        if world._lazy is not None and float(default_log_likelihood) == -30.0:
+            return self._block_likelihood_needed(token_type, low, cols, pred_q, pred_q_host, world, normalized_probability, orientation)
         if token_type == TokenType.ATTRIBUTE:
             gather = lambda c, pq: L.attr_gather(world._attribute_features, world._obj_off, pq, c, world._NS,
                                                  float(default_log_likelihood))
@@ -189,5 +316,34 @@ class ClassifierOracle(OracleBase):
         ll_c = gather(cols.index_select(0, keep).contiguous(), pq_c)
         L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
         ll = torch.full((len(low.cols),) + tuple(ll_c.shape[1:]), float(default_log_likelihood), dtype=torch.float32, device=dev)
+        ll[keep] = ll_c
+        return ll
+
+    def _block_likelihood_needed(self, token_type, low, cols, pred_q, pred_q_host, world, normalized_probability, orientation):
+        """The same blocks as the cached-table gathers, computed from the hidden activations for the requested columns only."""
+        dev = world._device
+        emb = self._embedding_network.linear
+        if token_type == TokenType.ATTRIBUTE:
+            ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
+        else:
+            assert orientation == L.TILE_SUBJECT_ROWS
+            ll = world._rel_tiles.get(id(low))
+            if ll is None:
+                ll = self._relation_tiles_now(world, low, pred_q_host)
+            elif self._normalize and normalized_probability:
+                ll = ll.clone()                               # normalisation is in place; keep the prefetched tiles intact
+        if not (self._normalize and normalized_probability):
+            return ll
+        valid = low.valid.astype(bool)
+        seg = segments_of(np.asarray(list(pred_q_host))[valid])
+        if len(seg) - 1 == int(valid.sum()):
+            return ll
+        if low.all_valid:
+            L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
+            return ll
+        keep = torch.as_tensor(np.nonzero(valid)[0]).to(dev)
+        pq_c = pred_q.index_select(0, keep).contiguous()
+        ll_c = ll.index_select(0, keep).contiguous()
+        L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
         ll[keep] = ll_c
         return ll

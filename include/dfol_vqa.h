@@ -187,6 +187,41 @@ int dfol_box_positions_f32(const float* raw, int64_t ld_raw, int32_t raw_cols, i
 int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t D, const int32_t* obj_off, const int64_t* pair_off,
                            int32_t Q, int32_t max_n, float* pair, int64_t ld_pair, void* stream);
 
+/* ---- needed-columns oracle (MI355X-first: nothing the program does not ask for is computed) --------
+ * The reference evaluates the embedding layer for all 2335 concepts on every object and every ordered
+ * object pair (classifier_oracle.py:145-156; 64 % of its CPU time) and then gathers a
+ * handful of columns (:63, :116).  These two entry points produce the same per-predicate blocks directly
+ * from the hidden activations, for the requested (image, concept) pairs only.
+ *
+ * Attribute blocks:  ll[p][o] = LogSigmoid(hidden[obj_off[q]+o] . E[col] + be[col])
+ *   hidden [O, ld_hidden] (H used) = attribute_network output (Sigmoid layer), E [C, ld_e] / be [C] the
+ *   embedding layer (gqa_interpreter_experiments.py:60-77); pred_col indexes the FULL concept table
+ *   (arg_to_idx - 1, classifier_oracle.py:49-56); < 0 = no-op token -> default block.
+ */
+int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t H, const float* E, int64_t ld_e, const float* be,
+                     const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P, int32_t NS,
+                     float default_ll, float* ll, void* stream);
+
+/* Relation tiles, fused pair MLP (replaces batch_gqa_boxfeatures_pipeline.py:252-279 + the relation branch of
+ * classifier_oracle.py:151-154 + the gather :113-135, for the requested columns only).
+ * With the pair MLP  h = Sigmoid(W2 ELU(W1 [obj_s, obj_o, geo] + b1) + b2)  (gqa_interpreter_experiments.py:164-167):
+ *   UV   [O, ld_uv]   per-OBJECT partial products of the first layer: UV[:, :HID1] = W1[:, :D] obj + b1,
+ *                     UV[:, HID1:2 HID1] = W1[:, D:2D] obj         (one dfol_linear_act_f32 launch, DFOL_ACT_NONE)
+ *   pos  [O, ld_pos]  the 4 positional features of every object (x, y, w, h normalised)
+ *   Wg   [HID1, 4]    W1[:, 2D:2D+4] (distance, angle, h_side, v_side), contiguous
+ *   W2 [HID2, ld_w2], b2 [HID2];   E [C, ld_e], be [C] (may be NULL) the embedding layer
+ *   requests: K rows over the Q images.  req_col[k*Q+q] = column of the FULL concept table wanted for image q
+ *             (< 0: none); req_tile[k*Q+q] = index of the destination tile; req_orient[k*Q+q] = DFOL_TILE_* (NULL = 0)
+ *   tiles [T, NS, NS] out: tile[s][o] = LogSigmoid(h(s,o) . E[col] + be[col]); the diagonal is written as default_ll;
+ *             rows/columns >= n_obj are NOT written (pre-fill ragged batches with default_ll).
+ * Limits: HID1 <= 256 (multiple of 4), HID2 <= 320, max_n <= NS.
+ */
+int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                     const float* W2, int64_t ld_w2, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
+                     const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
+                     const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS,
+                     float default_ll, float* tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,3 +249,70 @@ def test_split_invariance(ontology):
     r4, _ = run(model, qs, scenes, ontology, split=4)
     assert torch.equal(r1["log_probability"], r4["log_probability"])
     assert r1["answer"] == r4["answer"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# needed-columns oracle (fused pair kernel) == the reference's full cached tables
+# ---------------------------------------------------------------------------------------------------
+def _neural_questions(kind, count, n_lo, n_hi, feat_dim, seed, names=None):
+    rng = np.random.RandomState(seed)
+    nouns, attrs, rels = (NOUNS, ATTRS, RELS) if names is None else names
+    op = syn.op
+    qs, scenes = [], []
+    for i in range(count):
+        qid = seed * 100 + i
+        pick = lambda xs: xs[rng.randint(len(xs))]
+        branch = [op("select", pick(nouns)), op("filter", pick(attrs)), op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"]))]
+        if rng.uniform() < 0.5:
+            branch.append(op("relate", "not(%s)" % pick(rels) if rng.uniform() < 0.3 else pick(rels), bool(rng.uniform() < 0.5), pick(nouns)))
+        last = {"exist": op("exist"), "verify_rel": op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)),
+                "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
+                "choose_attr": op("choose_attr", [attrs[0], attrs[1]])}[kind]
+        qs.append(syn.question(qid, [branch], last, "yes"))
+        scenes.append(syn.feature_scene(qid, int(rng.randint(n_lo, n_hi + 1)), feat_dim))
+    return qs, scenes
+
+
+@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "choose_attr"])
+def test_needed_columns_equals_full_tables_small(ontology, oracle_ontology, kind):
+    a, meta = gu.load("g5_neural_oracle")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights)
+    assert model._oracle.supports_needed_columns()
+    qs, scenes = _neural_questions(kind, 10, 1, 23, meta["config"]["box_features_dim"], seed=11)
+    res_needed, _ = run(model, qs, scenes, ontology, key="X")
+    model._oracle._needed_columns = False
+    res_full, _ = run(model, qs, scenes, ontology, key="X")
+    model._oracle._needed_columns = True
+    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, weights=weights)
+    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, weights=weights)
+    for res, tag in ((res_needed, "needed"), (res_full, "full")):
+        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], kind + ":" + tag)
+    assert res_needed["answer"] == res_full["answer"]
+
+
+def test_needed_columns_full_size_model(tmp_path):
+    """The reference architecture at full size (2048 -> 512, 516/1036 -> 256 -> 300 -> 2335): fused path vs full tables vs oracle."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(1)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    assert model._oracle.supports_needed_columns()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    qs, scenes = _neural_questions("exist", 6, 3, 14, 2048, seed=3, names=nm)
+    res_needed, _ = run(model, qs, scenes, ont, key="X")
+    model._oracle._needed_columns = False
+    res_full, _ = run(model, qs, scenes, ont, key="X")
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights)
+    r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights)
+    for res, tag in ((res_needed, "needed"), (res_full, "full")):
+        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "fullsize:" + tag)
+    assert res_needed["answer"] == res_full["answer"] == r64["answer"]

@@ -45,8 +45,8 @@ SIGNATURES = {
     "dfol_box_positions_f32": [_p, _i64, _i32, _i32, _p, _i64, _i32, _p],
     "dfol_pair_features_f32": [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _i64, _p],
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
-    "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32,
-                         _f, _p, _p],
+    "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
+                         _i32, _f, _p, _p],
 }
 
 
@@ -269,12 +269,15 @@ def attr_ll(hidden, emb_w, emb_b, obj_off, pred_q, pred_col, NS, default_ll=-30.
     return ll
 
 
-def pair_ll(uv, hid1, pos, wg, w2, b2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles, default_ll=-30.0):
-    """req_col / req_tile: int32 [K, Q]; req_orient: uint8 [K, Q] or None; tiles: [T, NS, NS] written in place."""
+def pair_ll(uv, hid1, pos, wg, w2, b2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles, default_ll=-30.0,
+            hid2=None):
+    """req_col / req_tile: int32 [K, Q]; req_orient: uint8 [K, Q] or None; tiles: [T, NS, NS] written in place.
+    w2 may be allocated with more (zero) rows than hid2 = the layer's true output width."""
     K, Q = req_col.shape
     NS = tiles.shape[1]
+    hid2 = w2.shape[0] if hid2 is None else hid2
     call("dfol_pair_ll_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32), w2.data_ptr(),
-         w2.stride(0), _ptr(b2, F32), w2.shape[0], emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
+         w2.stride(0), w2.shape[0], _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          _ptr(tiles, F32), _stream())
     return tiles

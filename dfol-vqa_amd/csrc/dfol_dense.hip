@@ -255,16 +255,23 @@ __global__ __launch_bounds__(256) void attr_ll_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = (lane + 64 * j < H) ? E[(int64_t)col * ld_e + lane + 64 * j] : 0.f;
     const float bias = be ? be[col] : 0.f;
-    for (int o = 0; o < n; ++o) {
-        const float* h = hidden + (int64_t)(first + o) * ld_h;
-        float s = 0.f;
+    for (int o0 = 0; o0 < n; o0 += 4) {                      // four objects in flight per iteration
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (lane + 64 * j < H) s = fmaf(h[lane + 64 * j], e[j], s);
-        s = dfol_wave_sum(s);
-        if (lane == 0) {
-            const float x = s + bias;
-            out[o] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));           // nn.LogSigmoid
+        for (int u = 0; u < 4; ++u) {
+            const int o = min(o0 + u, n - 1);
+            const float* h = hidden + (int64_t)(first + o) * ld_h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (lane + 64 * j < H) s[u] = fmaf(h[lane + 64 * j], e[j], s[u]);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], m, 64);
+        if (lane < 4 && o0 + lane < n) {
+            const float x = (lane == 0 ? s[0] : lane == 1 ? s[1] : lane == 2 ? s[2] : s[3]) + bias;
+            out[o0 + lane] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));       // nn.LogSigmoid
         }
     }
     for (int o = n + lane; o < NS; o += 64) out[o] = dflt;
@@ -295,8 +302,9 @@ namespace {
 
 constexpr int PK_PITCH = 36;
 
-template <int NB>
-__global__ __launch_bounds__(256, 1) void pair_ll_kernel(
+// KEXACT: HID1 is a multiple of 32 AND W2 is allocated with 32*NB rows (rows >= HID2 zero): no guards in the main loop
+template <int NB, bool KEXACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pair_ll_kernel(
     const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
     const float* __restrict__ Wg, const float* __restrict__ W2, int64_t ld_w2, const float* __restrict__ b2, int HID2,
     const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
@@ -347,51 +355,92 @@ __global__ __launch_bounds__(256, 1) void pair_ll_kernel(
     auto load_w2 = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int nrow = lrow + 32 * i, k = k0 + lk;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nrow < HID2 && k < HID1) v = *reinterpret_cast<const float4*>(W2 + (int64_t)nrow * ld_w2 + k);
-            rb[i] = v;
+            const int nrow = lrow + 32 * i;
+            if (KEXACT) {
+                rb[i] = *reinterpret_cast<const float4*>(W2 + (int64_t)nrow * ld_w2 + k0 + lk);
+            } else {
+                const int k = min(k0 + lk, HID1 - 4);
+                const float4 v = *reinterpret_cast<const float4*>(W2 + (int64_t)min(nrow, HID2 - 1) * ld_w2 + k);
+                rb[i] = (nrow < HID2 && k0 + lk < HID1) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     float4 ru[4], rv[4];
     auto load_uv = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = k0 + 16 * half + 4 * j;
-            const bool in = k < HID1;
-            ru[j] = in ? *reinterpret_cast<const float4*>(Urow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rv[j] = in ? *reinterpret_cast<const float4*>(Vrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kk = k0 + 16 * half + 4 * j, k = KEXACT ? kk : min(kk, HID1 - 4);
+            ru[j] = *reinterpret_cast<const float4*>(Urow + k);      // beyond HID1 the value is discarded below
+            rv[j] = *reinterpret_cast<const float4*>(Vrow + k);
         }
     };
-    load_w2(0);
-    load_uv(0);
-
-    for (int k0 = 0; k0 < HID1; k0 += 32) {
-        __syncthreads();                                    // previous chunk's LDS reads are done (also covers Wgs)
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PK_PITCH + lk]) = rb[i];
-        __syncthreads();
-        // A operand: 16 contiguous k of this lane's half
-        float a[16];
+    // A operand of a chunk: 16 contiguous k of this lane's half, z = ELU(U[s] + V[o] + Wg . geo)
+    auto make_a = [&](int k0, float (&a)[16]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float uu[4] = {ru[j].x, ru[j].y, ru[j].z, ru[j].w}, vv[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int k = k0 + 16 * half + 4 * j + c;
-                float z = 0.f;
-                if (k < HID1) {
-                    const float4 g = *reinterpret_cast<const float4*>(&Wgs[k * 4]);
-                    z = uu[c] + vv[c] + (g.x * geo[0] + g.y * geo[1] + g.z * geo[2] + g.w * geo[3]);
-                    z = z > 0.f ? z : expm1f(z);            // nn.ELU
-                }
-                a[4 * j + c] = z;
+                const int kk = k0 + 16 * half + 4 * j + c, k = KEXACT ? kk : min(kk, HID1 - 1);
+                const float4 g = *reinterpret_cast<const float4*>(&Wgs[k * 4]);
+                float z = uu[c] + vv[c] + (g.x * geo[0] + g.y * geo[1] + g.z * geo[2] + g.w * geo[3]);
+                z = z > 0.f ? z : dfol_exp(z) - 1.0f;       // nn.ELU (hardware exp: abs error < 1e-7 on a hidden activation)
+                a[4 * j + c] = (KEXACT || kk < HID1) ? z : 0.f;
             }
         }
-        if (k0 + 32 < HID1) {                               // next chunk's operands fly while this chunk's MFMAs run
-            load_w2(k0 + 32);
-            load_uv(k0 + 32);
+    };
+    auto store_w2 = [&]() {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PK_PITCH + lk]) = rb[i];
+    };
+
+    // Software pipeline: while the MFMAs of chunk c run, the A operand of chunk c+1 is built (VALU) and the
+    // operands of chunk c+2 are in flight (VMEM).
+    float a_cur[16], a_next[16];
+    load_w2(0);
+    load_uv(0);
+    __syncthreads();                                        // Wgs visible
+    store_w2();
+    make_a(0, a_cur);
+    __syncthreads();
+    if (KEXACT) {
+        // Branch-free steady state: chunk indices beyond the end are clamped (the redundant work of the last
+        // iteration is discarded), so every iteration is one straight-line scheduling region in which the
+        // A-operand VALU work of the next chunk is interleaved with this chunk's MFMAs.
+        const int last = HID1 - 32;
+        load_w2(min(32, last));
+        load_uv(min(32, last));
+        for (int k0 = 0; k0 < HID1; k0 += 32) {
+            make_a(min(k0 + 32, last), a_next);
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                float4 b4[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) b4[i] = *reinterpret_cast<const float4*>(&Bs[(i * 32 + r32) * PK_PITCH + 16 * half + 4 * tg]);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 0], b4[i].x, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 1], b4[i].y, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 2], b4[i].z, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 3], b4[i].w, acc[i], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                // every wave is done reading this chunk of W2
+            store_w2();
+            __syncthreads();
+            load_w2(min(k0 + 64, last));
+            load_uv(min(k0 + 64, last));
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a_cur[t] = a_next[t];
         }
+    } else {
+    if (32 < HID1) {
+        load_w2(32);
+        load_uv(32);
+    }
+    for (int k0 = 0; k0 < HID1; k0 += 32) {
+        const bool more = k0 + 32 < HID1;
+        if (more) make_a(k0 + 32, a_next);
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
             float4 b4[NB];
@@ -399,13 +448,26 @@ __global__ __launch_bounds__(256, 1) void pair_ll_kernel(
             for (int i = 0; i < NB; ++i) b4[i] = *reinterpret_cast<const float4*>(&Bs[(i * 32 + r32) * PK_PITCH + 16 * half + 4 * tg]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 0], b4[i].x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 1], b4[i].y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 2], b4[i].z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * tg + 3], b4[i].w, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 0], b4[i].x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 1], b4[i].y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 2], b4[i].z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[4 * tg + 3], b4[i].w, acc[i], 0, 0, 0);
             }
         }
+        if (more) {
+            __syncthreads();                                // every wave is done reading this chunk of W2
+            store_w2();
+            __syncthreads();
+            if (k0 + 64 < HID1) {
+                load_w2(k0 + 64);
+                load_uv(k0 + 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a_cur[t] = a_next[t];
+        }
     }
+
+    }   // !KEXACT
 
     // h = Sigmoid(acc + b2); C layout: column = i*32 + r32, row(e) = (e & 3) + 8 * (e >> 2) + 4 * half
 #pragma unroll
@@ -414,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void pair_ll_kernel(
         const bool in = ncol < HID2;
         const float bv = in ? b2[ncol] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = in ? 1.0f / (1.0f + expf(-(acc[i][e] + bv))) : 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][e] = in ? __frcp_rn(1.0f + dfol_exp(-(acc[i][e] + bv))) : 0.f;   // nn.Sigmoid
     }
     const int64_t tile_sz = (int64_t)NS * NS;
     for (int k = 0; k < K; ++k) {
@@ -456,25 +518,27 @@ __global__ __launch_bounds__(256, 1) void pair_ll_kernel(
 }  // namespace
 
 extern "C" int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
-                                const float* W2, int64_t ld_w2, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
-                                const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
+                                const float* W2, int64_t ld_w2, int32_t w2_rows_alloc, const float* b2, int32_t HID2, const float* E,
+                                int64_t ld_e, const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
                                 const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS,
                                 float default_ll, float* tiles, void* stream) {
     DFOL_REQUIRE(Q >= 0 && K >= 0 && NS > 0 && NS % 4 == 0 && max_n >= 0 && max_n <= NS, "pair_ll: bad sizes Q=%d K=%d NS=%d max_n=%d", Q, K, NS, max_n);
     DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % 4 == 0 && ld_uv % 4 == 0 && ld_w2 % 4 == 0, "pair_ll: HID1=%d must be a multiple of 4, <= 256, rows 16-byte aligned", HID1);
-    DFOL_REQUIRE(HID2 > 0 && HID2 <= 320, "pair_ll: HID2=%d must be <= 320", HID2);
+    DFOL_REQUIRE(HID2 > 0 && HID2 <= 320 && w2_rows_alloc >= HID2, "pair_ll: HID2=%d must be <= 320 and <= w2_rows_alloc=%d", HID2, w2_rows_alloc);
     if (Q == 0 || K == 0 || max_n < 2) return 0;
     DFOL_REQUIRE(UV && pos && Wg && W2 && b2 && E && n_obj && obj_off && req_col && req_tile && tiles, "pair_ll: null pointer");
     DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll: operands must be 16-byte aligned");
     const int tpi = dfol_cdiv((int64_t)max_n * max_n, 128);
     const dim3 grid((unsigned)Q * tpi);
     hipStream_t st = (hipStream_t)stream;
-#define DFOL_PAIR(NBV)                                                                                                          \
-    hipLaunchKernelGGL(pair_ll_kernel<NBV>, grid, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, ld_e, \
-                       be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles)
-    if (HID2 <= 32) DFOL_PAIR(1);
-    else if (HID2 <= 128) DFOL_PAIR(4);
-    else DFOL_PAIR(10);
+#define DFOL_PAIR(NBV, KX)                                                                                                      \
+    hipLaunchKernelGGL((pair_ll_kernel<NBV, KX>), grid, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, \
+                       ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles)
+    const int nb = HID2 <= 32 ? 1 : (HID2 <= 128 ? 4 : 10);
+    const bool kx = HID1 % 32 == 0 && w2_rows_alloc >= 32 * nb;
+    if (HID2 <= 32) { if (kx) DFOL_PAIR(1, true); else DFOL_PAIR(1, false); }
+    else if (HID2 <= 128) { if (kx) DFOL_PAIR(4, true); else DFOL_PAIR(4, false); }
+    else { if (kx) DFOL_PAIR(10, true); else DFOL_PAIR(10, false); }
 #undef DFOL_PAIR
     DFOL_LAUNCH_CHECK("pair_ll");
     return 0;

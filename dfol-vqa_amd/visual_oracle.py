@@ -193,6 +193,19 @@ class ClassifierOracle(OracleBase):
             self._split_cache = (key, wuv, buv, wg, hid1, D)
         return self._split_cache[1:]
 
+    def _padded_second_layer(self):
+        """W2 zero-padded to a multiple of 32 rows, so the fused pair kernel's main loop needs no bounds checks."""
+        lin = [m for m in self._relation_network._network if isinstance(m, nn.Linear)][1]
+        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias._version)
+        cache = getattr(self, "_w2_cache", None)
+        if cache is None or cache[0] != key:
+            w = lin.weight.detach()
+            rows = (w.shape[0] + 31) // 32 * 32
+            wp = torch.zeros(rows, w.shape[1], dtype=w.dtype, device=w.device)
+            wp[:w.shape[0]] = w
+            self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0])
+        return self._w2_cache[1:]
+
     def prepare_scene(self, world, obj):
         """Hidden activations of a scene: attribute hidden [O, H] and the per-object halves of the pair MLP's first layer."""
         world._lazy = self
@@ -223,13 +236,13 @@ class ClassifierOracle(OracleBase):
         return np.where(c >= 0, idx[np.maximum(c, 0)], -1).astype(np.int32)
 
     def _launch_pairs(self, world, req_col, req_tile, tiles, req_orient=None):
-        lins = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
         _, _, wg, hid1, D = self._split_first_layer()
+        w2p, b2, hid2 = self._padded_second_layer()
         emb = self._embedding_network.linear
         dev = world._device
-        L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, lins[1].weight, lins[1].bias, emb.weight, emb.bias, world._n_obj,
+        L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, w2p, b2, emb.weight, emb.bias, world._n_obj,
                   world._obj_off, max(world._n_list), torch.as_tensor(req_col).to(dev), torch.as_tensor(req_tile).to(dev),
-                  None if req_orient is None else torch.as_tensor(req_orient).to(dev), tiles, -30.0)
+                  None if req_orient is None else torch.as_tensor(req_orient).to(dev), tiles, -30.0, hid2=hid2)
 
     def _new_tiles(self, world, count):
         ragged = min(world._n_list) < world._NS

@@ -210,6 +210,8 @@ int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t H, const fl
  *   pos  [O, ld_pos]  the 4 positional features of every object (x, y, w, h normalised)
  *   Wg   [HID1, 4]    W1[:, 2D:2D+4] (distance, angle, h_side, v_side), contiguous
  *   W2 [HID2, ld_w2], b2 [HID2];   E [C, ld_e], be [C] (may be NULL) the embedding layer
+ *   w2_rows_alloc     rows of W2 that may be read (>= HID2).  When W2 is allocated zero-padded to a multiple of 32 rows
+ *                     and HID1 is a multiple of 32, the main loop runs without bounds checks.
  *   requests: K rows over the Q images.  req_col[k*Q+q] = column of the FULL concept table wanted for image q
  *             (< 0: none); req_tile[k*Q+q] = index of the destination tile; req_orient[k*Q+q] = DFOL_TILE_* (NULL = 0)
  *   tiles [T, NS, NS] out: tile[s][o] = LogSigmoid(h(s,o) . E[col] + be[col]); the diagonal is written as default_ll;
@@ -217,8 +219,8 @@ int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t H, const fl
  * Limits: HID1 <= 256 (multiple of 4), HID2 <= 320, max_n <= NS.
  */
 int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
-                     const float* W2, int64_t ld_w2, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
-                     const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
+                     const float* W2, int64_t ld_w2, int32_t w2_rows_alloc, const float* b2, int32_t HID2, const float* E,
+                     int64_t ld_e, const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
                      const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS,
                      float default_ll, float* tiles, void* stream);
 

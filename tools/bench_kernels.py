@@ -65,6 +65,26 @@ def main():
         t = timeit(lambda: L.linear_act(x, w, b, act, y), iters=10)
         fl = 2.0 * M * Nn * K
         out.append({"kernel": "linear_act", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
+    # fused pair kernel at the bench shape: Q images of N objects, one requested relation column each
+    Q, HID1, HID2, C = 256, 256, 300, 2335
+    O = Q * N
+    uv = torch.rand(O, 2 * HID1, device=dev) - 0.5
+    pos = torch.rand(O, 4, device=dev)
+    wg = torch.rand(HID1, 4, device=dev) - 0.5
+    w2 = torch.zeros(320, HID1, device=dev)
+    w2[:HID2] = (torch.rand(HID2, HID1, device=dev) - 0.5) * 0.2
+    b2 = torch.rand(HID2, device=dev) - 0.5
+    E = (torch.rand(C, HID2, device=dev) - 0.5) * 0.2
+    be = torch.rand(C, device=dev) - 2
+    n_o = torch.full((Q,), N, dtype=torch.int32, device=dev)
+    off = (torch.arange(Q + 1, device=dev) * N).to(torch.int32)
+    for K in (1, 2):
+        req_col = torch.randint(0, C, (K, Q), dtype=torch.int32, device=dev)
+        req_tile = torch.arange(K * Q, dtype=torch.int32, device=dev).reshape(K, Q)
+        tiles = torch.empty(K * Q, NS, NS, device=dev)
+        t = timeit(lambda: L.pair_ll(uv, HID1, pos, wg, w2, b2, E, be, n_o, off, N, req_col, req_tile, None, tiles, hid2=HID2), iters=10)
+        fl = 2.0 * Q * N * (N - 1) * (4 * HID1 + HID1 * HID2 + HID2 * K)
+        out.append({"kernel": "pair_ll", "Q": Q, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
     for r in out:
         print(json.dumps(r))
 

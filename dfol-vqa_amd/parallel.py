@@ -1,0 +1,81 @@
+"""Data parallelism: one process per GPU, questions sharded across ranks.
+
+Reference: src/nsvqa/nn/interpreter/data_parallel.py (ProgramDataParallel: one Python thread per GPU, parameters
+broadcast each forward, gradients reduced to device 0, log-probabilities gathered).  Questions and their scenes are
+independent, so inference needs no exchange at all except gathering the answers; training needs exactly one
+all-reduce (sum) of the flat fp32 gradient bucket per step (RCCL over xGMI on MI355X: backend "nccl"; "gloo" on CPU).
+"""
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(costs, world_size):
+    """Contiguous shards of a question list, balanced by cost (use sum of N^2 per question for ragged scenes).
+    Contiguity keeps the reference's question order when results are concatenated (data_parallel.py:59-80)."""
+    costs = np.asarray(costs, np.float64)
+    n = len(costs)
+    if n == 0:
+        return [(0, 0)] * world_size
+    cum = np.concatenate([[0.0], np.cumsum(costs)])
+    total = cum[-1]
+    bounds, start = [], 0
+    for r in range(world_size):
+        if r == world_size - 1:
+            end = n
+        else:
+            target = total * (r + 1) / world_size
+            end = int(np.searchsorted(cum, target, side="left"))          # first prefix whose cost reaches the target
+            if end > start + 1 and abs(cum[end - 1] - target) < abs(cum[min(end, n)] - target):
+                end -= 1                                                   # the shorter prefix is closer
+            end = min(max(end, start), n)
+        bounds.append((start, end))
+        start = end
+    return bounds
+
+
+def shard_questions(questions, rank, world_size, costs=None):
+    if costs is None:
+        costs = [float(q["scene"]["n"]) ** 2 if isinstance(q, dict) and "scene" in q else 1.0 for q in questions]
+    s, e = shard_bounds(costs, world_size)[rank]
+    return questions[s:e]
+
+
+def gather_results(result, group=None):
+    """All ranks receive the concatenation (in rank order) of every rank's result dict
+    (the distributed counterpart of data_parallel.gather_results :15-50)."""
+    world = dist.get_world_size(group)
+    payload = {"answer": result["answer"], "options": result["options"], "answer_log_probability": result["answer_log_probability"],
+               "log_probability": result["log_probability"].detach().cpu().numpy(), "type": int(result["type"]),
+               "variable_sets_num": result["variable_sets_num"], "cumulative_loss": result["cumulative_loss"]}
+    parts = [None] * world
+    dist.all_gather_object(parts, payload, group=group)
+    query = parts[0]["type"] == 1
+    return {"answer": [a for p in parts for a in p["answer"]],
+            "log_probability": torch.from_numpy(np.concatenate([p["log_probability"] for p in parts])),
+            "options": [o for p in parts for o in p["options"]] if query else parts[0]["options"],
+            "variable_set": None, "type": result["type"],
+            "cumulative_loss": sum(p["cumulative_loss"] for p in parts), "variable_sets_num": sum(p["variable_sets_num"] for p in parts),
+            "answer_log_probability": [a for p in parts for a in p["answer_log_probability"]]}
+
+
+def allreduce_gradients(parameters, group=None):
+    """One all-reduce (sum) of ONE flat fp32 bucket holding every trainable gradient (9.2 MB in the oracle phase,
+    0.59 MB in the calibrator phase).  With the loss divided by the GLOBAL batch size on every rank
+    (trainer.py:433-436) the summed gradient equals the single-process gradient; every rank then applies the same
+    clip + Adam step and parameters stay identical without any broadcast."""
+    params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return 0
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    offset = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
+        offset += n
+    return flat.numel() * 4

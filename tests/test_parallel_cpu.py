@@ -1,0 +1,95 @@
+"""world_size-2 gloo tests of the data-parallel path (CPU): sharding, result gathering, gradient all-reduce."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dfol_vqa_amd import parallel  # noqa: E402
+from dfol_vqa_amd.fol_types import QuestionType  # noqa: E402
+
+
+def test_shard_bounds_are_contiguous_and_balanced():
+    rng = np.random.RandomState(0)
+    for world in (1, 2, 4, 8):
+        costs = rng.randint(1, 100, 57) ** 2
+        b = parallel.shard_bounds(costs, world)
+        assert b[0][0] == 0 and b[-1][1] == len(costs)
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        loads = [costs[s:e].sum() for s, e in b]
+        assert max(loads) <= costs.sum() / world + costs.max()
+    assert parallel.shard_bounds([1, 1, 1, 1], 2) == [(0, 2), (2, 4)]
+    assert parallel.shard_bounds([], 2) == [(0, 0), (0, 0)]
+    qs = [{"scene": {"n": n}} for n in (10, 10, 10, 10)]
+    assert parallel.shard_questions(qs, 1, 2) == qs[2:]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ---- result gathering keeps question order -------------------------------------------------
+        lp = torch.tensor([-0.1 * (rank + 1), -0.2 * (rank + 1), -0.3]) if rank == 0 else torch.tensor([-1.0, -2.0])
+        res = {"answer": [["yes"]] * len(lp), "log_probability": lp, "options": ["no", "yes"], "variable_set": None,
+               "type": QuestionType.BINARY, "cumulative_loss": 0, "variable_sets_num": len(lp), "answer_log_probability": [[float(x)] for x in lp]}
+        g = parallel.gather_results(res)
+        assert g["log_probability"].tolist() == [-0.1, -0.2, -0.3, -1.0, -2.0] or np.allclose(g["log_probability"].numpy(), [-0.1, -0.2, -0.3, -1.0, -2.0])
+        assert len(g["answer"]) == 5 and g["variable_sets_num"] == 5
+
+        # ---- one flat-bucket all-reduce reproduces the single-process gradient ----------------------
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Sigmoid(), torch.nn.Linear(5, 1))
+        model[0].bias.requires_grad_(False)
+        x = torch.randn(8, 6)
+        y = (torch.rand(8, 1) > 0.5).float()
+        B = x.shape[0]
+        s, e = parallel.shard_bounds([1.0] * B, world)[rank]
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(model(x[s:e]), y[s:e], reduction="sum") / B   # sum / B_global
+        loss.backward()
+        nbytes = parallel.allreduce_gradients(model.parameters())
+        grads = [p.grad.clone() for p in model.parameters() if p.requires_grad]
+        if rank == 0:
+            ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Sigmoid(), torch.nn.Linear(5, 1))
+            ref.load_state_dict(model.state_dict())
+            ref[0].bias.requires_grad_(False)
+            torch.nn.functional.binary_cross_entropy_with_logits(ref(x), y, reduction="sum").div(B).backward()
+            for gmine, p in zip(grads, [p for p in ref.parameters() if p.requires_grad]):
+                assert torch.allclose(gmine, p.grad, atol=1e-6)
+            assert nbytes == 4 * sum(p.numel() for p in ref.parameters() if p.requires_grad)
+        # every rank ends with identical gradients
+        flat = torch.cat([g_.reshape(-1) for g_ in grads])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        out.put((rank, "ok"))
+    except Exception as exc:  # pragma: no cover
+        out.put((rank, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results

@@ -44,6 +44,12 @@ SIGNATURES = {
     "dfol_linear_act_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_box_positions_f32": [_p, _i64, _i32, _i32, _p, _i64, _i32, _p],
     "dfol_pair_features_f32": [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _i64, _p],
+    "dfol_filter_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p, _p],
+    "dfol_relate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
+    "dfol_quantify_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_attr_gather_bwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _i64, _p],
+    "dfol_rel_gather_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
+    "dfol_option_normalize_bwd_f32": [_p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
     "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
                          _i32, _f, _p, _p],
@@ -281,3 +287,58 @@ def pair_ll(uv, hid1, pos, wg, w2, b2, emb_w, emb_b, n_obj, obj_off, max_n, req_
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          _ptr(tiles, F32), _stream())
     return tiles
+
+
+# ---- backward wrappers ----------------------------------------------------------------------------------
+def filter_bwd(g_out, ll, pred_q, n_obj, neg, active, Q, need_prior=True, need_ll=True):
+    P, NS = ll.shape
+    g_prior = torch.zeros(Q, NS, dtype=F32, device=ll.device) if need_prior else None
+    g_ll = torch.empty(P, NS, dtype=F32, device=ll.device) if need_ll else None
+    call("dfol_filter_bwd_f32", _ptr(g_out, F32), _ptr(ll, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), _ptr(neg, U8, True),
+         0 if neg is None else 1, _ptr(active, U8, True), P, NS, _ptr(g_prior, F32, True), _ptr(g_ll, F32, True), _stream())
+    return g_prior, g_ll
+
+
+def relate_bwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, g_post_s, g_post_o, orientation,
+               lone_forall_identity, need_prior=True, need_tile=True):
+    P, NS = tile.shape[0], tile.shape[1]
+    Q = prior_s.shape[0]
+    g_ps = torch.zeros(Q, NS, dtype=F32, device=tile.device) if need_prior else None
+    g_po = torch.zeros(Q, NS, dtype=F32, device=tile.device) if need_prior else None
+    g_tile = torch.empty(P, NS, NS, dtype=F32, device=tile.device) if need_tile else None
+    call("dfol_relate_bwd_f32", _ptr(prior_s, F32), _ptr(prior_o, F32), _ptr(tile, F32), _ptr(pred_q, I32), _ptr(n_obj, I32),
+         _ptr(quant_s, F32), _ptr(quant_o, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True),
+         _ptr(g_post_s, F32, True), _ptr(g_post_o, F32, True), P, NS, orientation, 1 if lone_forall_identity else 0,
+         _ptr(g_ps, F32, True), _ptr(g_po, F32, True), _ptr(g_tile, F32, True), _stream())
+    return g_ps, g_po, g_tile
+
+
+def quantify_bwd(g_lp, att, quant, pred_q, n_obj):
+    P, NS = att.shape
+    g_att = torch.empty(P, NS, dtype=F32, device=att.device)
+    call("dfol_quantify_bwd_f32", _ptr(g_lp, F32), _ptr(att, F32), _ptr(quant, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS,
+         _ptr(g_att), _stream())
+    return g_att
+
+
+def attr_gather_bwd(g_ll, obj_off, pred_q, pred_col, table_shape):
+    P, NS = g_ll.shape
+    g_table = torch.zeros(table_shape, dtype=F32, device=g_ll.device)
+    call("dfol_attr_gather_bwd_f32", _ptr(g_ll, F32), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32), P, NS, _ptr(g_table),
+         g_table.stride(0), _stream())
+    return g_table
+
+
+def rel_gather_bwd(g_tile, pair_off, n_obj, pred_q, pred_col, orientation, table_shape):
+    P, NS = g_tile.shape[0], g_tile.shape[1]
+    g_table = torch.zeros(table_shape, dtype=F32, device=g_tile.device)
+    call("dfol_rel_gather_bwd_f32", _ptr(g_tile, F32), _ptr(pair_off, I64), _ptr(n_obj, I32), _ptr(pred_q, I32), _ptr(pred_col, I32),
+         P, NS, orientation, _ptr(g_table), g_table.stride(0), _stream())
+    return g_table
+
+
+def option_normalize_bwd(g_y, y, seg_off, pred_q, n_obj, NS):
+    g_x = torch.empty_like(g_y)
+    call("dfol_option_normalize_bwd_f32", _ptr(g_y, F32), _ptr(y, F32), _ptr(seg_off, I32), seg_off.numel() - 1, _ptr(pred_q, I32),
+         _ptr(n_obj, I32), NS, y.dim() - 1, _ptr(g_x), _stream())
+    return g_x

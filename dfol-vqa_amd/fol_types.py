@@ -13,7 +13,7 @@ from enum import IntEnum
 import numpy as np
 import torch
 
-from . import _lib as L
+from . import ops as L
 
 
 class Quantifier(IntEnum):          # batch_base_types.py:15-17

@@ -12,7 +12,7 @@ import re
 import numpy as np
 import torch
 
-from . import _lib as L
+from . import ops as L
 from .fol_types import BatchVariableSet, Quantifier, QuestionType
 from .host_util import find_max_ind, flatten_list, unflatten_list
 from .logic_ops import BatchOperatorBase, FilterBatch, RelateBatch
@@ -161,7 +161,7 @@ def _binary_answer(log_probability, batch_size, give_answer):
     """yes/no from p > 0.5 plus the log-probability of the answer given (e.g. batch_gqa_ops.py:404-407)."""
     if not give_answer:
         return [], []
-    probability = log_probability.exp().cpu().numpy().tolist()          # the one device->host sync of a binary op
+    probability = log_probability.detach().exp().cpu().numpy().tolist()          # the one device->host sync of a binary op
     answer = [['yes'] if probability[i] > 0.5 else ['no'] for i in range(batch_size)]
     alp = [[math.log(probability[i])] if probability[i] > 0.5 else [math.log(1 - probability[i])] for i in range(batch_size)]
     return answer, alp
@@ -315,7 +315,7 @@ def _choose_answer(log_probability, x, option_list, batch_index, question_num, l
     if not give_answer:
         return [], []
     flags = find_max_ind(log_probability, np.asarray(batch_index), question_num, likelihood_threshold).tolist()   # util.py:64-66
-    return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.cpu().numpy().tolist(), batch_index, flags)
+    return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.detach().cpu().numpy().tolist(), batch_index, flags)
 
 
 class GQAChooseAttrBatch(GQABatchOperatorBase):
@@ -506,7 +506,7 @@ class GQACompareBatch(GQABatchOperatorBase):
         options = list(zip(variable_set1._name, variable_set2._name))
         answer, alp = [], []
         if give_answer:
-            lp = log_probability.cpu().numpy()
+            lp = log_probability.detach().cpu().numpy()
             ind = lp.argmax(1)
             for i in range(variable_set1.batch_size()):
                 answer.append([options[i][ind[i]]])

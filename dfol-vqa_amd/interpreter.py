@@ -8,7 +8,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib as L
+from . import ops as L
 from . import gqa_ops as gqa
 from .fol_types import BatchVariableSet, BatchWorld, QuestionType
 
@@ -56,6 +56,9 @@ class BatchGQABoxFeaturizer(nn.Module):
         geo = world_geometry
         pair = None
         if geo is not None and geo._pair_num > 0:
+            if obj.requires_grad:
+                raise NotImplementedError("training the featurizer through the pair features is not built (every shipped config "
+                                          "has freeze_featurizer: True)")
             pair = L.pair_features(obj, D, geo._obj_off, geo._pair_off, geo._batch_size, max(geo._n_list), geo._pair_num)   # :252-279
         return {'attribute_features': obj, 'relation_features': {'features': pair, 'index': None}, 'object_num': object_num}
 
@@ -95,8 +98,9 @@ class BatchInterpreterBase(nn.Module):
             raise NotImplementedError("a featurizer is required (the reference's featurizer-less branch :62-67 is dead code)")
         geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
                               attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums)
-        needed = self._cached and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
-            getattr(self._oracle, "supports_needed_columns", lambda: False)()
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        needed = self._cached and not training and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
+            getattr(self._oracle, "supports_needed_columns", lambda: False)()   # the fused kernels are forward-only
         if needed:
             # needed-columns mode: no pair matrix, no full tables; the oracle keeps hidden activations instead
             features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=None)

@@ -8,7 +8,7 @@ resolve tokens, pick priors/quantifiers and launch.
 import torch
 import torch.nn as nn
 
-from . import _lib as L
+from . import ops as L
 from .fol_types import BatchVariableSet, Quantifier, TokenType
 from .host_util import get_lowered
 

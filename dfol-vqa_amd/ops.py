@@ -1,0 +1,339 @@
+"""Autograd-aware front of the C-ABI wrappers.
+
+Every function here has the signature of its namesake in `_lib`.  Under `torch.no_grad()` (inference) the call
+goes straight to the kernel; when a floating-point input requires grad, it goes through a `torch.autograd.Function`
+whose backward launches the HIP backward kernels (`csrc/dfol_logic_bwd.hip`).  The backward of the tiny per-question
+vector glue (gate, segment reductions, and/or/not, compare) and of the dense layers is written with torch tensor ops /
+library GEMMs on the GPU — plumbing, as the design notes say.
+"""
+
+import torch
+
+from . import _lib
+from ._lib import *  # noqa: F401,F403  (constants, DfolError, non-differentiable wrappers)
+from ._lib import DfolError  # noqa: F401
+
+_EPS = 1e-20
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _dpnot(x, alpha):
+    """d/dx log(max(alpha + (1 - 2 alpha) e^x, eps)); zero where the clamp is active."""
+    e = torch.exp(x)
+    d = alpha + (1 - 2 * alpha) * e
+    return torch.where(d > _EPS, (1 - 2 * alpha) * e / d.clamp_min(_EPS), torch.zeros_like(d))
+
+
+# ---- filter ------------------------------------------------------------------------------------------
+class _Filter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att_in, ll, pred_q, n_obj, neg, active):
+        ctx.save_for_backward(ll, pred_q, n_obj, neg if neg is not None else ll.new_empty(0), active if active is not None else ll.new_empty(0))
+        ctx.flags = (neg is not None, active is not None, att_in.shape[0])
+        return _lib.filter_fwd(att_in, ll, pred_q, n_obj, neg, active)
+
+    @staticmethod
+    def backward(ctx, g):
+        ll, pred_q, n_obj, neg, active = ctx.saved_tensors
+        has_neg, has_act, Q = ctx.flags
+        g_prior, g_ll = _lib.filter_bwd(g.contiguous(), ll, pred_q, n_obj, neg if has_neg else None, active if has_act else None, Q,
+                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return g_prior, g_ll, None, None, None, None
+
+
+def filter_fwd(att_in, ll, pred_q, n_obj, neg=None, active=None):
+    if _needs_grad(att_in, ll):
+        return _Filter.apply(att_in, ll, pred_q, n_obj, neg, active)
+    return _lib.filter_fwd(att_in, ll, pred_q, n_obj, neg, active)
+
+
+# ---- relate ------------------------------------------------------------------------------------------
+class _Relate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone):
+        ps, po = _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone)
+        e = tile.new_empty(0)
+        ctx.save_for_backward(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg if neg is not None else e,
+                              active if active is not None else e, want if want is not None else e)
+        ctx.flags = (neg is not None, active is not None, want is not None, orientation, lone)
+        return ps, po
+
+    @staticmethod
+    def backward(ctx, gs, go):
+        prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want = ctx.saved_tensors
+        has_neg, has_act, has_want, orientation, lone = ctx.flags
+        gs, go = gs.contiguous(), go.contiguous()
+        if has_want:       # a posterior the forward did not produce carries no gradient
+            gs = gs * ((want & 1) > 0).to(gs.dtype).unsqueeze(1)
+            go = go * ((want & 2) > 0).to(go.dtype).unsqueeze(1)
+        need_prior = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        g_ps, g_po, g_tile = _lib.relate_bwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg if has_neg else None,
+                                             active if has_act else None, gs, go, orientation, lone, need_prior, ctx.needs_input_grad[2])
+        return g_ps, g_po, g_tile, None, None, None, None, None, None, None, None, None
+
+
+def relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg=None, active=None, want=None,
+               orientation=_lib.TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True):
+    if _needs_grad(prior_s, prior_o, tile):
+        return _Relate.apply(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity)
+    return _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity,
+                           need_s, need_o)
+
+
+# ---- quantify ----------------------------------------------------------------------------------------
+class _Quantify(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att, quant, pred_q, n_obj):
+        ctx.save_for_backward(att, quant, pred_q, n_obj)
+        return _lib.quantify_fwd(att, quant, pred_q, n_obj)
+
+    @staticmethod
+    def backward(ctx, g):
+        att, quant, pred_q, n_obj = ctx.saved_tensors
+        return _lib.quantify_bwd(g.contiguous(), att, quant, pred_q, n_obj), None, None, None
+
+
+def quantify_fwd(att, quant, pred_q, n_obj):
+    if _needs_grad(att):
+        return _Quantify.apply(att, quant, pred_q, n_obj)
+    return _lib.quantify_fwd(att, quant, pred_q, n_obj)
+
+
+# ---- gathers and option normalisation ----------------------------------------------------------------
+class _AttrGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, obj_off, pred_q, pred_col, NS, default_ll):
+        ctx.save_for_backward(obj_off, pred_q, pred_col)
+        ctx.shape = tuple(table.shape)
+        return _lib.attr_gather(table, obj_off, pred_q, pred_col, NS, default_ll)
+
+    @staticmethod
+    def backward(ctx, g):
+        obj_off, pred_q, pred_col = ctx.saved_tensors
+        return _lib.attr_gather_bwd(g.contiguous(), obj_off, pred_q, pred_col, ctx.shape), None, None, None, None, None
+
+
+def attr_gather(table, obj_off, pred_q, pred_col, NS, default_ll=-30.0):
+    if _needs_grad(table):
+        return _AttrGather.apply(table.contiguous(), obj_off, pred_q, pred_col, NS, default_ll)
+    return _lib.attr_gather(table, obj_off, pred_q, pred_col, NS, default_ll)
+
+
+class _RelGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, pair_off, n_obj, pred_q, pred_col, NS, orientation, default_ll):
+        ctx.save_for_backward(pair_off, n_obj, pred_q, pred_col)
+        ctx.meta = (tuple(table.shape), orientation)
+        return _lib.rel_gather(table, pair_off, n_obj, pred_q, pred_col, NS, orientation, default_ll)
+
+    @staticmethod
+    def backward(ctx, g):
+        pair_off, n_obj, pred_q, pred_col = ctx.saved_tensors
+        shape, orientation = ctx.meta
+        return _lib.rel_gather_bwd(g.contiguous(), pair_off, n_obj, pred_q, pred_col, orientation, shape), None, None, None, None, None, None, None
+
+
+def rel_gather(table, pair_off, n_obj, pred_q, pred_col, NS, orientation=_lib.TILE_SUBJECT_ROWS, default_ll=-30.0):
+    if _needs_grad(table):
+        return _RelGather.apply(table.contiguous(), pair_off, n_obj, pred_q, pred_col, NS, orientation, default_ll)
+    return _lib.rel_gather(table, pair_off, n_obj, pred_q, pred_col, NS, orientation, default_ll)
+
+
+class _OptionNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ll, seg_off, pred_q, n_obj, NS):
+        y = _lib.option_normalize_(ll.clone(), seg_off, pred_q, n_obj, NS)
+        ctx.save_for_backward(y, seg_off, pred_q, n_obj)
+        ctx.NS = NS
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, seg_off, pred_q, n_obj = ctx.saved_tensors
+        return _lib.option_normalize_bwd(g.contiguous(), y, seg_off, pred_q, n_obj, ctx.NS), None, None, None, None
+
+
+def option_normalize_(ll, seg_off, pred_q, n_obj, NS):
+    """In place for inference; under autograd the normalised copy is returned (callers use the return value)."""
+    if _needs_grad(ll):
+        return _OptionNormalize.apply(ll, seg_off, pred_q, n_obj, NS)
+    return _lib.option_normalize_(ll, seg_off, pred_q, n_obj, NS)
+
+
+# ---- small per-question glue: forward = HIP kernel, backward = a few tensor ops ----------------------
+class _Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_att, y_att, x_quant, y_quant, g):
+        ctx.save_for_backward(g)
+        att, quant = _lib.gate(x_att, y_att, x_quant, y_quant, g)
+        ctx.mark_non_differentiable(quant)
+        return att, quant
+
+    @staticmethod
+    def backward(ctx, g_att, _g_quant):
+        (g,) = ctx.saved_tensors
+        sel = (g > 0).unsqueeze(1)
+        zero = torch.zeros_like(g_att)
+        return torch.where(sel, g_att, zero), torch.where(sel, zero, g_att), None, None, None
+
+
+def gate(x_att, y_att, x_quant, y_quant, g):
+    if _needs_grad(x_att, y_att):
+        return _Gate.apply(x_att, y_att, x_quant, y_quant, g)
+    return _lib.gate(x_att, y_att, x_quant, y_quant, g)
+
+
+class _SegmentSumRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, seg_off):
+        ctx.save_for_backward(seg_off)
+        ctx.P = src.shape[0]
+        return _lib.segment_sum_rows(src, seg_off)
+
+    @staticmethod
+    def backward(ctx, g):
+        (seg_off,) = ctx.saved_tensors
+        counts = (seg_off[1:] - seg_off[:-1]).to(torch.int64)
+        idx = torch.repeat_interleave(torch.arange(counts.numel(), device=g.device), counts).to(torch.int32)
+        return _lib.gather_rows(g.contiguous(), idx), None
+
+
+def segment_sum_rows(src, seg_off):
+    if _needs_grad(src):
+        return _SegmentSumRows.apply(src, seg_off)
+    return _lib.segment_sum_rows(src, seg_off)
+
+
+class _SegmentOr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lp, seg_off):
+        ctx.save_for_backward(lp, seg_off)
+        return _lib.segment_or(lp, seg_off)
+
+    @staticmethod
+    def backward(ctx, g):
+        lp, seg_off = ctx.saved_tensors
+        counts = (seg_off[1:] - seg_off[:-1]).to(torch.int64)
+        idx = torch.repeat_interleave(torch.arange(counts.numel(), device=g.device), counts)
+        one = torch.ones((), device=lp.device)
+        inner = torch.log((1 - torch.exp(lp)).clamp_min(_EPS))
+        s = torch.zeros(counts.numel(), device=lp.device).index_add_(0, idx, inner)
+        return (g * _dpnot(s, one))[idx] * _dpnot(lp, one), None
+
+
+def segment_or(lp, seg_off):
+    if _needs_grad(lp):
+        return _SegmentOr.apply(lp, seg_off)
+    return _lib.segment_or(lp, seg_off)
+
+
+class _Implication(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prior, x, pred_q, n_obj):
+        ctx.save_for_backward(prior, x, pred_q, n_obj)
+        return _lib.implication(prior, x, pred_q, n_obj)
+
+    @staticmethod
+    def backward(ctx, g):
+        prior, x, pred_q, n_obj = ctx.saved_tensors
+        one = torch.ones((), device=x.device)
+        pq = pred_q.to(torch.int64)
+        valid = torch.arange(x.shape[1], device=x.device).unsqueeze(0) < n_obj.to(torch.int64)[pq].unsqueeze(1)
+        m = torch.log((1 - torch.exp(x)).clamp_min(_EPS))
+        z = prior[pq] + m
+        dz = torch.where(valid, g * _dpnot(z, one), torch.zeros_like(g))
+        g_prior = torch.zeros_like(prior).index_add_(0, pq, dz)
+        return g_prior, dz * _dpnot(x, one), None, None
+
+
+def implication(prior, x, pred_q, n_obj):
+    if _needs_grad(prior, x):
+        return _Implication.apply(prior, x, pred_q, n_obj)
+    return _lib.implication(prior, x, pred_q, n_obj)
+
+
+class _Logic(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, a, b):
+        ctx.op = op
+        ctx.save_for_backward(a, b if b is not None else a.new_empty(0))
+        return _lib.logic(op, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        if ctx.op == _lib.LOGIC_AND:
+            return None, g, g
+        one = torch.ones((), device=a.device)
+        if ctx.op == _lib.LOGIC_NOT:
+            return None, g * _dpnot(a, one), None
+        ea, eb = torch.exp(a), torch.exp(b)
+        x = 1 - (1 - ea) * (1 - eb)
+        live = x > _EPS
+        xs = x.clamp_min(_EPS)
+        zero = torch.zeros_like(g)
+        return None, torch.where(live, g * ea * (1 - eb) / xs, zero), torch.where(live, g * eb * (1 - ea) / xs, zero)
+
+
+def logic(op, a, b=None):
+    if _needs_grad(a, b):
+        return _Logic.apply(op, a, b)
+    return _lib.logic(op, a, b)
+
+
+class _Compare(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lp1, lp2, is_less):
+        ctx.save_for_backward(lp1, lp2, is_less)
+        return _lib.compare(lp1, lp2, is_less)
+
+    @staticmethod
+    def backward(ctx, g):
+        lp1, lp2, is_less = ctx.saved_tensors
+        st = torch.stack([lp1, lp2], 1)
+        ls = torch.log_softmax(st, 1)
+        gl = g * _dpnot(ls, is_less.unsqueeze(1))
+        gst = gl - torch.exp(ls) * gl.sum(1, keepdim=True)
+        return gst[:, 0], gst[:, 1], None
+
+
+def compare(lp1, lp2, is_less):
+    if _needs_grad(lp1, lp2):
+        return _Compare.apply(lp1, lp2, is_less)
+    return _lib.compare(lp1, lp2, is_less)
+
+
+# ---- dense layers: forward = fused MFMA kernel, backward = library GEMMs ------------------------------
+class _LinearAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        y = _lib.linear_act(x, weight, bias, act)
+        ctx.save_for_backward(x, weight, y)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        if ctx.act == _lib.ACT_SIGMOID:
+            dz = g * y * (1 - y)
+        elif ctx.act == _lib.ACT_ELU:
+            dz = g * torch.where(y > 0, torch.ones_like(y), y + 1)
+        elif ctx.act == _lib.ACT_LOGSIGMOID:
+            dz = g * (1 - torch.exp(y))
+        else:
+            dz = g
+        gx = dz @ weight if ctx.needs_input_grad[0] else None
+        gw = dz.t() @ x if ctx.needs_input_grad[1] else None
+        gb = dz.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
+def linear_act(x, weight, bias, act, out=None):
+    if out is None and _needs_grad(x, weight, bias):
+        return _LinearAct.apply(x, weight, bias, act)
+    return _lib.linear_act(x, weight, bias, act, out)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib as L
+from . import ops as L
 from .fol_types import TokenType
 from .host_util import get_lowered, segments_of
 
@@ -321,13 +321,12 @@ class ClassifierOracle(OracleBase):
             return gather(cols, pred_q)
         if low.all_valid:
             ll = gather(cols, pred_q)
-            L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
-            return ll
+            return L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
         # no-op tokens inside an option list: normalise the compressed list, then put default blocks back
         keep = torch.as_tensor(np.nonzero(valid)[0]).to(dev)
         pq_c = pred_q.index_select(0, keep).contiguous()
         ll_c = gather(cols.index_select(0, keep).contiguous(), pq_c)
-        L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
+        ll_c = L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
         ll = torch.full((len(low.cols),) + tuple(ll_c.shape[1:]), float(default_log_likelihood), dtype=torch.float32, device=dev)
         ll[keep] = ll_c
         return ll
@@ -352,11 +351,10 @@ class ClassifierOracle(OracleBase):
         if len(seg) - 1 == int(valid.sum()):
             return ll
         if low.all_valid:
-            L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
-            return ll
+            return L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
         keep = torch.as_tensor(np.nonzero(valid)[0]).to(dev)
         pq_c = pred_q.index_select(0, keep).contiguous()
         ll_c = ll.index_select(0, keep).contiguous()
-        L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
+        ll_c = L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
         ll[keep] = ll_c
         return ll

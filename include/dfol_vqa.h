@@ -224,6 +224,33 @@ int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* 
                      const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS,
                      float default_ll, float* tiles, void* stream);
 
+/* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
+ * Gradients of the block operators; formulas in SURVEY.md Appendix B.  g_* outputs that are NULL are skipped.
+ * g_prior* ([Q, NS]) are ACCUMULATED into (several predicates may share a question's prior): zero them first.
+ */
+int dfol_filter_bwd_f32(const float* g_out, const float* ll, const int32_t* pred_q, const int32_t* n_obj, const uint8_t* neg,
+                        int32_t any_neg, const uint8_t* active, int32_t P, int32_t NS, float* g_prior, float* g_ll, void* stream);
+
+int dfol_relate_bwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q, const int32_t* n_obj,
+                        const float* quant_s, const float* quant_o, const uint8_t* neg, int32_t any_neg, const uint8_t* active,
+                        const float* g_post_s, const float* g_post_o, int32_t P, int32_t NS, int32_t orientation,
+                        int32_t lone_forall_identity, float* g_prior_s, float* g_prior_o, float* g_tile, void* stream);
+
+int dfol_quantify_bwd_f32(const float* g_lp, const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
+                          int32_t P, int32_t NS, float* g_att, void* stream);
+
+/* g_table is ACCUMULATED into (scatter-add). */
+int dfol_attr_gather_bwd_f32(const float* g_ll, const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P,
+                             int32_t NS, float* g_table, int64_t ld_table, void* stream);
+
+int dfol_rel_gather_bwd_f32(const float* g_tile, const int64_t* pair_off, const int32_t* n_obj, const int32_t* pred_q,
+                            const int32_t* pred_col, int32_t P, int32_t NS, int32_t orientation, float* g_table, int64_t ld_table,
+                            void* stream);
+
+/* from the NORMALISED values y (the softmax weight of option p is exp(y_p)). */
+int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, const int32_t* seg_off, int32_t S, const int32_t* pred_q,
+                                  const int32_t* n_obj, int32_t NS, int32_t rank, float* g_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,166 @@
+"""GPU parity of the training path: loss values and gradients w.r.t. the cached tables against the goldens g6
+(the reference's own autograd), kernel-level gradient checks against a torch fp64 restatement, and one train step."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+import dfol_vqa_amd as D  # noqa: E402
+from dfol_vqa_amd import ops, training  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
+from test_interpreter_gpu import DEV, TableCollater, neural_model, table_model  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+EPS = 1e-20
+
+
+@pytest.fixture(scope="module")
+def ontology(mini_ontology_paths):
+    p = mini_ontology_paths
+    return D.GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["word_embedding_file"],
+                         relation_json_path=p["relation_file"])
+
+
+def grad_close(got, ref32, ref64, what, rtol=2e-3):
+    """Gradients inherit the conditioning of the forward: yardstick = the reference's own fp32-vs-fp64 deviation."""
+    got, ref32, ref64 = (np.asarray(x, np.float64) for x in (got, ref32, ref64))
+    scale = np.abs(ref64).max() + 1e-30
+    own = np.abs(ref32 - ref64).max()
+    err = np.abs(got - ref64).max()
+    assert err <= 8 * own + rtol * scale, "%s: |dgrad| %.3g vs reference's own %.3g (scale %.3g)" % (what, err, own, scale)
+
+
+@pytest.mark.parametrize("name", ["g6_loss_binary", "g6_loss_query", "g6_loss_query_rel"])
+def test_g6_loss_and_table_gradients(ontology, name):
+    a, meta = gu.load(name)
+    qs, scenes = gu.questions_and_scenes(a, meta)
+    qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
+    pbs = TableCollater(1, ontology).collate(qq)
+    for pb in pbs:
+        pb.create_sparse_tensors()
+    pbs = [pb.to_cuda(DEV) for pb in pbs]
+    pb = pbs[0]
+    A = pb._object_features.clone().requires_grad_(True)
+    R = pb._meta_data["R"].clone().requires_grad_(True)
+    pb._object_features, pb._meta_data["R"] = A, R
+    model = table_model(ontology).train()
+    res = model(pbs, True)
+    loss = training.compute_loss(pbs, res) / len(qs)
+    loss.backward()
+    l32, l64 = float(a["loss_f32"]), float(a["loss_f64"])
+    assert abs(float(loss) - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (float(loss), l32, l64)
+    gu.check_logprob(res["log_probability"].detach().cpu().numpy(), a["lp_f32"], a["lp_f64"], name)
+    grad_close(A.grad.cpu().numpy(), a["gA_f32"], a["gA_f64"], name + " dA")
+    gR = np.zeros_like(a["gR_f64"]) if R.grad is None else R.grad.cpu().numpy()
+    grad_close(gR, a["gR_f32"], a["gR_f64"], name + " dR")
+
+
+# ---------------------------------------------------------------------------------------------------
+# kernel-level gradient checks against torch autograd on an fp64 restatement of the block formulas
+# ---------------------------------------------------------------------------------------------------
+def t_slog(x):
+    return torch.log(x.clamp_min(EPS))
+
+
+def t_pnot(x, a):
+    return t_slog(a + (1 - 2 * a) * torch.exp(x))
+
+
+def ref_relate(a, b, l, qs, qo, neg, any_neg):
+    n = a.shape[0]
+    l = torch.minimum(l, torch.zeros_like(l))
+    if any_neg:
+        l = t_pnot(l, torch.tensor(float(neg), dtype=l.dtype))
+    off = 1 - torch.eye(n, dtype=l.dtype)
+    t = t_pnot(l + b[None, :], qo) * off
+    ps = a + t_pnot(t.sum(1), qo)
+    w = t_pnot(l + a[:, None], qs) * off
+    po = b + t_pnot(w.sum(0), qs)
+    return ps, po
+
+
+@pytest.mark.parametrize("n_list,k_list,any_neg", [([5, 3, 8], [1, 1, 1], False), ([12, 7], [2, 1], True), ([70, 100], [1, 1], False)])
+def test_relate_filter_quantify_backward(n_list, k_list, any_neg):
+    rng = np.random.RandomState(sum(n_list) + int(any_neg))
+    Q = len(n_list)
+    pq = np.repeat(np.arange(Q), k_list).astype(np.int32)
+    P, NS = len(pq), max(4, (max(n_list) + 3) // 4 * 4)
+    prior_s = np.zeros((Q, NS), np.float32)
+    prior_o = np.zeros((Q, NS), np.float32)
+    tile = np.full((P, NS, NS), -30, np.float32)
+    for q, n in enumerate(n_list):
+        prior_s[q, :n] = np.minimum(syn.table_log_likelihood(rng, (n,), "unif") * 0.3, 0)
+        prior_o[q, :n] = np.minimum(syn.table_log_likelihood(rng, (n,), "unif") * 0.3, 0)
+    for p in range(P):
+        n = n_list[pq[p]]
+        t = syn.table_log_likelihood(rng, (n, n), "unif")
+        t[np.arange(n), np.arange(n)] = -30
+        tile[p, :n, :n] = t
+    quant = (rng.uniform(size=(Q, 2)) < 0.6).astype(np.float32)[pq]
+    neg = (rng.uniform(size=P) < 0.5).astype(np.uint8) if any_neg else None
+    gs = rng.normal(size=(P, NS)).astype(np.float32)
+    go = rng.normal(size=(P, NS)).astype(np.float32)
+    dev = lambda x: torch.tensor(x, device=DEV)
+    ps_t, po_t, tl_t = dev(prior_s).requires_grad_(True), dev(prior_o).requires_grad_(True), dev(tile).requires_grad_(True)
+    n_obj = dev(np.array(n_list, np.int32))
+    ps, po = ops.relate_fwd(ps_t, po_t, tl_t, dev(pq), n_obj, dev(quant[:, 0]), dev(quant[:, 1]), None if neg is None else dev(neg))
+    (ps * dev(gs)).sum().add((po * dev(go)).sum()).backward()
+    # fp64 torch restatement
+    a64 = torch.tensor(prior_s, dtype=torch.float64, requires_grad=True)
+    b64 = torch.tensor(prior_o, dtype=torch.float64, requires_grad=True)
+    t64 = torch.tensor(tile, dtype=torch.float64, requires_grad=True)
+    total = 0
+    for p in range(P):
+        q, n = pq[p], n_list[pq[p]]
+        if n < 2:
+            continue
+        rs, ro = ref_relate(a64[q, :n], b64[q, :n], t64[p, :n, :n], float(quant[p, 0]), float(quant[p, 1]), 0 if neg is None else int(neg[p]), any_neg)
+        total = total + (rs * torch.tensor(gs[p, :n], dtype=torch.float64)).sum() + (ro * torch.tensor(go[p, :n], dtype=torch.float64)).sum()
+    total.backward()
+    for got, ref, what in ((ps_t.grad, a64.grad, "d prior_s"), (po_t.grad, b64.grad, "d prior_o"), (tl_t.grad, t64.grad, "d tile")):
+        g, r = got.cpu().numpy().astype(np.float64), ref.numpy()
+        assert np.abs(g - r).max() <= 2e-4 * (np.abs(r).max() + 1), (what, np.abs(g - r).max(), np.abs(r).max())
+    # filter + quantify chained
+    ll = dev(tile[:, 0, :].copy()).requires_grad_(True)
+    att0 = dev(prior_s).requires_grad_(True)
+    out = ops.filter_fwd(att0, ll, dev(pq), n_obj, None if neg is None else dev(neg))
+    lp = ops.quantify_fwd(out, dev(quant[:, 0]), dev(pq), n_obj)
+    glp = rng.normal(size=P).astype(np.float32)
+    (lp * dev(glp)).sum().backward()
+    l64 = torch.tensor(tile[:, 0, :], dtype=torch.float64, requires_grad=True)
+    p64 = torch.tensor(prior_s, dtype=torch.float64, requires_grad=True)
+    tot = 0
+    for p in range(P):
+        q, n = pq[p], n_list[pq[p]]
+        v = torch.minimum(l64[p, :n], torch.zeros(n, dtype=torch.float64))
+        if any_neg:
+            v = t_pnot(v, torch.tensor(float(neg[p]), dtype=torch.float64))
+        o = p64[q, :n] + v
+        qf = float(quant[p, 0])
+        tot = tot + glp[p] * t_pnot(t_pnot(o, qf).sum(), qf)
+    tot.backward()
+    for got, ref, what in ((ll.grad, l64.grad, "d ll"), (att0.grad, p64.grad, "d att")):
+        g, r = got.cpu().numpy().astype(np.float64), ref.numpy()
+        assert np.abs(g - r).max() <= 2e-4 * (np.abs(r).max() + 1), (what, np.abs(g - r).max())
+
+
+def test_train_step_changes_parameters_and_lowers_loss(ontology):
+    """One reference-style train step (fwd + BCE + bwd + clip + Adam) on the reduced-dims neural oracle."""
+    a, meta = gu.load("g5_neural_oracle")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights).train()
+    qs, scenes = gu.questions_and_scenes(a, meta, "X")
+    qq = [dict(q, scene=s, answer="yes" if i % 2 == 0 else "no") for i, (q, s) in enumerate(zip(qs, scenes))]
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(qq)]
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    losses = [training.train_batch(model, opt, pbs, clip_norm=0.65)[0] for _ in range(5)]
+    changed = [k for k, v in model.state_dict().items() if k.startswith("_oracle._") and not torch.equal(v, before[k])]
+    assert len(changed) >= 6, changed
+    assert losses[-1] < losses[0], losses
+    assert all(np.isfinite(l) for l in losses)

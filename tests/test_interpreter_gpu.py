@@ -71,7 +71,8 @@ def run(model, questions, scenes, ontology, split=1, lower=True, return_trace=Fa
     for pb in pbs:
         pb.create_sparse_tensors()
     pbs = [pb.to_cuda(DEV) for pb in pbs]
-    return model(pbs, training, return_trace=return_trace), pbs
+    with torch.set_grad_enabled(training):
+        return model(pbs, training, return_trace=return_trace), pbs
 
 
 @pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS)
@@ -166,10 +167,12 @@ def test_g5_neural_oracle(ontology):
     qs, scenes = gu.questions_and_scenes(a, meta, "X")
     qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
     pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(qq)]
-    world = model.build_scene(DEV, pbs[0]._object_features, pbs[0]._object_batch_index, pbs[0]._meta_data, pbs[0]._object_nums)
+    with torch.no_grad():
+        world = model.build_scene(DEV, pbs[0]._object_features, pbs[0]._object_batch_index, pbs[0]._meta_data, pbs[0]._object_nums)
     assert np.allclose(world._attribute_features.detach().cpu().numpy(), a["A_f64"], rtol=2e-5, atol=2e-5)
     assert np.allclose(world._relation_features["features"].detach().cpu().numpy(), a["R_f64"], rtol=2e-5, atol=2e-5)
-    res = model(pbs, False)
+    with torch.no_grad():
+        res = model(pbs, False)
     gu.check_logprob(res["log_probability"].detach().cpu().numpy(), a["lp_f32"], a["lp_f64"], "g5")
     assert res["answer"] == meta["answer"]
 

@@ -116,6 +116,19 @@ class BatchWorld(object):
                                 log_attention=log_attention, world=self)
 
     # -- block helpers ---------------------------------------------------------------------------
+    def pair_index(self):
+        """(subject row, object row) of every ordered same-image pair, in the reference's order (util.py:87-103)."""
+        if getattr(self, "_pair_idx", None) is None:
+            s_all, o_all, first = [], [], 0
+            for n in self._n_list:
+                s, o = np.nonzero(~np.eye(n, dtype=bool))
+                s_all.append(s + first)
+                o_all.append(o + first)
+                first += n
+            self._pair_idx = (torch.as_tensor(np.concatenate(s_all).astype(np.int64)).to(self._device),
+                              torch.as_tensor(np.concatenate(o_all).astype(np.int64)).to(self._device))
+        return self._pair_idx
+
     def zeros_attention(self):
         if self._zeros is None:
             self._zeros = torch.zeros(self._batch_size, self._NS, dtype=torch.float32, device=self._device)

@@ -56,10 +56,8 @@ class BatchGQABoxFeaturizer(nn.Module):
         geo = world_geometry
         pair = None
         if geo is not None and geo._pair_num > 0:
-            if obj.requires_grad:
-                raise NotImplementedError("training the featurizer through the pair features is not built (every shipped config "
-                                          "has freeze_featurizer: True)")
-            pair = L.pair_features(obj, D, geo._obj_off, geo._pair_off, geo._batch_size, max(geo._n_list), geo._pair_num)   # :252-279
+            pair = L.pair_features(obj, D, geo._obj_off, geo._pair_off, geo._batch_size, max(geo._n_list), geo._pair_num,
+                                   pair_index=geo.pair_index)                                                                # :252-279
         return {'attribute_features': obj, 'relation_features': {'features': pair, 'index': None}, 'object_num': object_num}
 
 

@@ -337,3 +337,29 @@ def linear_act(x, weight, bias, act, out=None):
     if out is None and _needs_grad(x, weight, bias):
         return _LinearAct.apply(x, weight, bias, act)
     return _lib.linear_act(x, weight, bias, act, out)
+
+
+class _PairFeatures(torch.autograd.Function):
+    """[obj_s, obj_o, geometry]: the gradient flows back to the two object rows (the geometry comes from the raw boxes)."""
+
+    @staticmethod
+    def forward(ctx, obj, D, obj_off, pair_off, Q, max_n, pairs, ind_s, ind_o):
+        ctx.save_for_backward(ind_s, ind_o)
+        ctx.meta = (tuple(obj.shape), D)
+        return _lib.pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs)
+
+    @staticmethod
+    def backward(ctx, g):
+        ind_s, ind_o = ctx.saved_tensors
+        shape, D = ctx.meta
+        g_obj = torch.zeros(shape, dtype=g.dtype, device=g.device)
+        g_obj[:, :D].index_add_(0, ind_s, g[:, :D])
+        g_obj[:, :D].index_add_(0, ind_o, g[:, D:2 * D])
+        return g_obj, None, None, None, None, None, None, None, None
+
+
+def pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs, pair_index=None):
+    if _needs_grad(obj):
+        ind_s, ind_o = pair_index()
+        return _PairFeatures.apply(obj, D, obj_off, pair_off, Q, max_n, pairs, ind_s, ind_o)
+    return _lib.pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs)

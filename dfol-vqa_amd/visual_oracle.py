@@ -224,7 +224,8 @@ class ClassifierOracle(OracleBase):
             pair = None
             if world._pair_num > 0:
                 D = world._obj.shape[1]
-                pair = L.pair_features(world._obj, D, world._obj_off, world._pair_off, world._batch_size, max(world._n_list), world._pair_num)
+                pair = L.pair_features(world._obj, D, world._obj_off, world._pair_off, world._batch_size, max(world._n_list), world._pair_num,
+                                       pair_index=world.pair_index)
             a, r = self.compute_all_log_likelihood_2(world._obj, pair)
             world._attr_table, world._rel_table = a, {'features': r, 'index': None}
         finally:

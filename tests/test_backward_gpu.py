@@ -53,7 +53,7 @@ def test_g6_loss_and_table_gradients(ontology, name):
     loss = training.compute_loss(pbs, res) / len(qs)
     loss.backward()
     l32, l64 = float(a["loss_f32"]), float(a["loss_f64"])
-    assert abs(float(loss) - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (float(loss), l32, l64)
+    assert abs(float(loss.detach()) - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (float(loss.detach()), l32, l64)
     gu.check_logprob(res["log_probability"].detach().cpu().numpy(), a["lp_f32"], a["lp_f64"], name)
     grad_close(A.grad.cpu().numpy(), a["gA_f32"], a["gA_f64"], name + " dA")
     gR = np.zeros_like(a["gR_f64"]) if R.grad is None else R.grad.cpu().numpy()

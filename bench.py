@@ -216,8 +216,10 @@ def stress_kernels(L, device, P, N):
         return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "predicates": P, "objects": N, "us_per_launch": t / n * 1e6}
 
+    r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones), P * (4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_one_fwd (fused single-posterior Relate, the interpreter's path)", bytes_per_predicate=4 * N * N + 12 * N))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=False), P * (4 * N * N + 12 * N))
-    res.append(dict(r, kernel="relate_fwd (one posterior, as GQARelateBatch uses it)", bytes_per_predicate=4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_fwd (generic cell, one posterior wanted)", bytes_per_predicate=4 * N * N + 12 * N))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones), P * (4 * N * N + 16 * N))
     res.append(dict(r, kernel="relate_fwd (both posteriors, RelateBatch API)", bytes_per_predicate=4 * N * N + 16 * N))
     ll = tile[:, 0, :].contiguous()

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dfol_filter_fwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p],
     "dfol_relate_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "dfol_quantify_fwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_relate_one_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
     "dfol_gate_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_gather_rows_f32": [_p, _p, _i32, _i32, _p, _p],
     "dfol_segment_sum_rows_f32": [_p, _p, _i32, _i32, _p, _p],
@@ -174,6 +175,15 @@ def relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg=None
          _ptr(want, U8, True), P, NS, orientation, 1 if lone_forall_identity else 0, _ptr(post_s, F32, True),
          _ptr(post_o, F32, True), _stream())
     return post_s, post_o
+
+
+def relate_one_fwd(x_att, prev_att, tile, pred_q, n_obj, quant_prev, neg=None, active=None, lone_forall_identity=False):
+    P, NS = tile.shape[0], tile.shape[1]
+    post = torch.empty(P, NS, dtype=F32, device=tile.device)
+    call("dfol_relate_one_fwd_f32", _ptr(x_att, F32), _ptr(prev_att, F32), _ptr(tile, F32), _ptr(pred_q, I32), _ptr(n_obj, I32),
+         _ptr(quant_prev, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True), P, NS,
+         1 if lone_forall_identity else 0, _ptr(post), _stream())
+    return post
 
 
 def quantify_fwd(att, quant, pred_q, n_obj):

@@ -339,6 +339,103 @@ extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, c
 }
 
 // =====================================================================================================
+// Relate, single posterior (what GQARelateBatch / verify_rel / choose_rel consume, batch_gqa_ops.py:364-371)
+// =====================================================================================================
+// The interpreter keeps exactly one posterior of a relate: the one of the freshly selected variable x, given the
+// incoming attention `prev` of the other variable.  With the tile stored so that the SUMMED-OUT variable runs along
+// rows, that posterior is a pure column reduction:
+//     post[c] = x[p][c] + F( sum_{r != c} F( l'[r][c] + prev[q][r] ) ),   F by the quantifier of prev
+// Lanes own 4 consecutive columns, 64/LPR rows are processed per step and UNR steps are in flight, so the loop
+// body has no cross-lane traffic at all; the row slots are combined once at the end.
+template <int LPR, int UNR>
+__global__ __launch_bounds__(256) void relate_one_fwd_kernel(
+    const float* __restrict__ x_att, const float* __restrict__ prev_att, const float* __restrict__ tile,
+    const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_prev,
+    const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active, int P, int NS, int identity_forall,
+    float* __restrict__ post) {
+    constexpr int RPI = 64 / LPR;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int q = pred_q[p];
+    const int n = n_obj[q];
+    const float* pv = prev_att + (int64_t)q * NS;
+    float* out = post + (int64_t)p * NS;
+    if (active && !active[p]) {                         // question without this operator: attention passes through
+        for (int c = lane; c < NS; c += 64) out[c] = c < n ? pv[c] : 0.f;
+        return;
+    }
+    const int cg = lane % LPR, rs = lane / LPR, c0 = cg * 4;
+    const float alpha_n = (any_neg && neg[p]) ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
+    const float qf = quant_prev[p], kf = 1.f - 2.f * qf;
+    const bool ident = identity_forall && qf == 0.f;
+    const float* tp = tile + (int64_t)p * NS * NS;
+    const int cl = min(c0, NS - 4);                      // lanes beyond the tile width read a valid column and are masked
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
+        float4 t[UNR];
+        float pr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {                  // all loads of the step first
+            const int r = min(r0 + u * RPI + rs, n - 1);
+            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)r * NS + cl);
+            pr[u] = pv[r];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u * RPI + rs;
+            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+            const int d = r - c0;                        // column j of this lane is the diagonal iff d == j
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = fminf(l[j], 0.f);
+                if (any_neg) v = dfol_pnot(v, alpha_n, cn);
+                const float w = v + pr[u];
+                const float f = ident ? w : dfol_pnot(w, qf, kf);
+                acc[j] += (r < n && d != j) ? f : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+    if (rs == 0 && c0 < NS) {
+        const float4 xa = *reinterpret_cast<const float4*>(x_att + (int64_t)p * NS + c0);
+        const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (c0 + j < n) ? xv[j] + (ident ? acc[j] : dfol_pnot(acc[j], qf, kf)) : 0.f;
+        *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int dfol_relate_one_fwd_f32(const float* x_att, const float* prev_att, const float* tile, const int32_t* pred_q,
+                                       const int32_t* n_obj, const float* quant_prev, const uint8_t* neg, int32_t any_neg,
+                                       const uint8_t* active, int32_t P, int32_t NS, int32_t lone_forall_identity, float* post,
+                                       void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 256, "relate_one_fwd: bad sizes P=%d NS=%d (NS: multiple of 4, <= 256)", P, NS);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(x_att && prev_att && tile && pred_q && n_obj && quant_prev && post, "relate_one_fwd: null pointer");
+    DFOL_REQUIRE(!any_neg || neg, "relate_one_fwd: any_neg set but neg is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = NS / 4;
+#define DFOL_REL1(L, U)                                                                                                       \
+    hipLaunchKernelGGL((relate_one_fwd_kernel<L, U>), dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, x_att, prev_att, tile, pred_q, n_obj, \
+                       quant_prev, neg, any_neg, active, P, NS, lone_forall_identity, post)
+    if (groups <= 1) DFOL_REL1(1, 1);
+    else if (groups <= 2) DFOL_REL1(2, 1);
+    else if (groups <= 4) DFOL_REL1(4, 1);
+    else if (groups <= 8) DFOL_REL1(8, 2);
+    else if (groups <= 16) DFOL_REL1(16, 4);
+    else if (groups <= 32) DFOL_REL1(32, 4);
+    else DFOL_REL1(64, 4);
+#undef DFOL_REL1
+    DFOL_LAUNCH_CHECK("relate_one_fwd");
+    return 0;
+}
+
+// =====================================================================================================
 // quantifier aggregation (Exist), gate, small vector ops
 // =====================================================================================================
 __global__ __launch_bounds__(256) void quantify_fwd_kernel(const float* __restrict__ att, const float* __restrict__ quant,

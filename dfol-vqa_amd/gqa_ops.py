@@ -238,11 +238,34 @@ class GQARelateBatch(GQABatchOperatorBase):
                 predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
         x = self._gqa_select(op_id, world, attribute_list, give_answer, predicate_question_map, likelihood_threshold)
         flag, host = _subject_flags(is_subject, world._device)
+        fused = self._forward_fused(world, x, variable_set, relation_list, flag)
+        if fused is not None:
+            return fused
         subject_set = x.gate(variable_set, flag)
         object_set = variable_set.gate(x, flag)
         want = torch.tensor([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in host], dtype=torch.uint8, device=world._device)
         subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, want=want)
         return subject_set.gate(object_set, flag)
+
+    def _forward_fused(self, world, x, prev, relation_list, flag):
+        """Inference fast path: the three gates and the arity-2 cell in ONE launch (dfol_relate_one_fwd_f32), on tiles the
+        oracle prefetched with the summed-out variable along rows.  Same result as the generic route below it."""
+        oracle = self._oracle
+        if torch.is_grad_enabled() and (x._log_attention.requires_grad or prev._log_attention.requires_grad):
+            return None
+        if not hasattr(oracle, "oriented_tiles") or x.batch_size() != prev.batch_size() or prev._predicate_question_map is not None:
+            return None
+        low = getattr(relation_list, "lowered", None)
+        tiles = None if low is None else oracle.oriented_tiles(world, low)
+        if tiles is None:
+            return None
+        _, neg_dev, valid_dev = low.on(world._device)
+        post = L.relate_one_fwd(x._log_attention, prev._log_attention, tiles, world._ident, world._n_obj, prev._quantifier,
+                                neg_dev if low.any_neg else None, None if low.all_valid else valid_dev,
+                                lone_forall_identity=(x.batch_size() == 1))
+        quant = torch.where(flag > 0, x._quantifier, prev._quantifier)        # both posteriors carry the subject's quantifier (:571-586)
+        return BatchVariableSet(x._name, world._device, x.object_num(), x.batch_size(), quantifiers=quant, log_attention=post, world=world,
+                                prev_variable_sets_num=x._prev_variable_sets_num + prev._prev_variable_sets_num + 1)
 
 
 class GQAExistBatch(GQABatchOperatorBase):

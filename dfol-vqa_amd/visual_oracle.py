@@ -256,24 +256,33 @@ class ClassifierOracle(OracleBase):
         the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
         if world._lazy is None:
             return
-        lows = []
+        lows, orients = [], []
+        Q = world._batch_size
         for ob in program_batch._op_batch_list:
             if ob._op_name in ("relate", "verify_rel") and ob._arguments:
                 toks = ob._arguments[0]
                 low = get_lowered(toks, self._ontology, TokenType.RELATION)
                 if getattr(toks, "lowered", None) is None:
                     toks.lowered, toks.lowered_type = low, TokenType.RELATION
-                if low.any_valid:
+                if low.any_valid and len(low.cols) == Q:
                     lows.append(low)
+                    # the operator keeps the posterior of the freshly selected variable: store every tile with the
+                    # OTHER (summed-out) variable along rows, so that posterior is a column reduction
+                    orients.append(np.asarray([L.TILE_OBJECT_ROWS if f else L.TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8))
         if not lows:
             return
-        Q = world._batch_size
         tiles = self._new_tiles(world, len(lows) * Q)
         req_col = np.stack([self._relation_full_columns(low.cols) for low in lows])
         req_tile = np.arange(len(lows) * Q, dtype=np.int32).reshape(len(lows), Q)
-        self._launch_pairs(world, req_col, req_tile, tiles)
+        req_orient = np.stack(orients)
+        self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
         for k, low in enumerate(lows):
-            world._rel_tiles[id(low)] = tiles[k * Q:(k + 1) * Q]
+            world._rel_tiles[id(low)] = (tiles[k * Q:(k + 1) * Q], req_orient[k])
+
+    def oriented_tiles(self, world, low):
+        """Prefetched tiles of a relate operator, each stored with its summed-out variable along rows (or None)."""
+        hit = world._rel_tiles.get(id(low)) if world._lazy is not None else None
+        return None if hit is None else hit[0]
 
     def _relation_tiles_now(self, world, low, pred_q_host):
         """Relation tiles for one token list outside the prefetch (e.g. choose_rel's flattened option list)."""
@@ -340,11 +349,11 @@ class ClassifierOracle(OracleBase):
             ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
         else:
             assert orientation == L.TILE_SUBJECT_ROWS
-            ll = world._rel_tiles.get(id(low))
-            if ll is None:
+            hit = world._rel_tiles.get(id(low))
+            if hit is not None and not hit[1].any():          # prefetched, and every tile already has subjects along rows
+                ll = hit[0].clone() if (self._normalize and normalized_probability) else hit[0]
+            else:
                 ll = self._relation_tiles_now(world, low, pred_q_host)
-            elif self._normalize and normalized_probability:
-                ll = ll.clone()                               # normalisation is in place; keep the prefetched tiles intact
         if not (self._normalize and normalized_probability):
             return ll
         valid = low.valid.astype(bool)

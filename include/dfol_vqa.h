@@ -128,6 +128,20 @@ int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float*
                         int32_t any_neg, const uint8_t* active, const uint8_t* want, int32_t P, int32_t NS,
                         int32_t orientation, int32_t lone_forall_identity, float* post_s, float* post_o, void* stream);
 
+/* Relate with ONE posterior: what GQARelateBatch / verify_rel / choose_rel keep (batch_gqa_ops.py:364-371: gate x/prev into
+ * subject/object, RelateBatch, gate the wanted posterior back).  Fuses the three gates and the arity-2 cell:
+ *     post[p][c] = x_att[p][c] + F( sum_{r != c} F( l'[r][c] + prev_att[pred_q[p]][r] ) ),  F by quant_prev[p]
+ *   x_att    [P, NS]  attention of the freshly selected variable (select(name) of the relate), one row per predicate
+ *   prev_att [Q, NS]  incoming attention of the other variable
+ *   tile     [P, NS, NS] with the SUMMED-OUT variable (prev's) along rows: DFOL_TILE_OBJECT_ROWS for is_subject
+ *            predicates, DFOL_TILE_SUBJECT_ROWS otherwise (dfol_pair_ll_f32 / dfol_rel_gather_f32 write either)
+ *   active[p] == 0: post[p] = prev_att row (the interpreter's pass-through for questions lacking the operator,
+ *            batch_base_interpreter.py:166-167)
+ */
+int dfol_relate_one_fwd_f32(const float* x_att, const float* prev_att, const float* tile, const int32_t* pred_q,
+                            const int32_t* n_obj, const float* quant_prev, const uint8_t* neg, int32_t any_neg,
+                            const uint8_t* active, int32_t P, int32_t NS, int32_t lone_forall_identity, float* post, void* stream);
+
 /* Soft quantifier aggregation: replaces BatchVariableSet.log_probability (soft mode),
  * batch_base_types.py:113-123:   lp[p] = F_q( sum_{o < n} F_q(att[p][o]) ),  q = quant[p].
  */

@@ -349,3 +349,42 @@ def test_errors_are_loud(L):
     with pytest.raises(L.DfolError):   # NS not a multiple of 4
         z = torch.zeros(2, 6, device="cuda")
         L.filter_fwd(z, z, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.ones(2, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("n_list", [[5, 1, 8, 3], [36, 20, 33], [100, 37, 64, 2], [130, 256]])
+def test_relate_one_equals_generic(L, n_list):
+    """The fused single-posterior kernel == three gates + the generic arity-2 cell, for both directions and ragged images."""
+    rng = np.random.RandomState(sum(n_list) + 7)
+    pq, NS, prior_s, prior_o, tile, _ = _logic_inputs(rng, n_list, [1] * len(n_list))
+    P = len(pq)
+    n_obj = np.array(n_list, np.int32)
+    is_subject = (rng.uniform(size=P) < 0.5)
+    x_att, prev_att = prior_s, prior_o                      # x = fresh select, prev = incoming attention
+    quant_prev = (rng.uniform(size=P) < 0.7).astype(np.float32)
+    for any_neg in (False, True):
+        neg = (rng.uniform(size=P) < 0.5).astype(np.uint8) if any_neg else None
+        active = np.ones(P, np.uint8)
+        if P > 2:
+            active[2] = 0
+        # generic route: subject = x if is_subject else prev, object = the other; keep the posterior of x's variable
+        flag = is_subject.astype(np.float32)
+        subj = np.where(flag[:, None] > 0, x_att, prev_att)
+        obj = np.where(flag[:, None] > 0, prev_att, x_att)
+        ones = np.ones(P, np.float32)
+        qs = np.where(flag > 0, ones, quant_prev)           # x is a fresh EXISTS set
+        qo = np.where(flag > 0, quant_prev, ones)
+        want = np.where(is_subject, 1, 2).astype(np.uint8)
+        ps, po = L.relate_fwd(dev(subj), dev(obj), dev(tile), dev(pq), dev(n_obj), dev(qs), dev(qo), None if neg is None else dev(neg),
+                              dev(active), dev(want), 0)
+        ref = np.where(flag[:, None] > 0, ps.cpu().numpy(), po.cpu().numpy())
+        # fused route: each tile stored with the summed-out (prev's) variable along rows
+        oriented = np.stack([tile[p].T if is_subject[p] else tile[p] for p in range(P)]).copy()
+        got = L.relate_one_fwd(dev(x_att), dev(prev_att), dev(oriented), dev(pq), dev(n_obj), dev(quant_prev),
+                               None if neg is None else dev(neg), dev(active)).cpu().numpy()
+        for p in range(P):
+            n = n_list[p]
+            if not active[p]:
+                assert np.array_equal(got[p, :n], prev_att[p, :n])
+                continue
+            assert np.allclose(got[p, :n], ref[p, :n], rtol=0, atol=2e-5 * max(1.0, np.abs(ref[p, :n]).max())), (p, n)
+            assert np.all(got[p, n:] == 0)

@@ -203,18 +203,22 @@ def stress_kernels(L, device, P, N):
     ones = torch.ones(P, device=device)
     res = []
 
-    def timed(name, fn, nbytes, iters=10):
-        for _ in range(2):
+    def timed(name, fn, nbytes, iters=20):
+        """Average launch duration from ONE HIP-event pair around `iters` back-to-back launches on the launch stream
+        (bracketing every single launch with its own event pair adds marker/fence latency to sub-millisecond kernels)."""
+        for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        L.enable_kernel_timing([name])
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
         for _ in range(iters):
             fn()
+        e.record()
         torch.cuda.synchronize()
-        n, t = L.disable_kernel_timing()[name]
-        ach = nbytes / (t / n)
+        t = s.elapsed_time(e) * 1e-3 / iters
+        ach = nbytes / t
         return {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                "predicates": P, "objects": N, "us_per_launch": t / n * 1e6}
+                "predicates": P, "objects": N, "us_per_launch": t * 1e6}
 
     r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones), P * (4 * N * N + 12 * N))
     res.append(dict(r, kernel="relate_one_fwd (fused single-posterior Relate, the interpreter's path)", bytes_per_predicate=4 * N * N + 12 * N))

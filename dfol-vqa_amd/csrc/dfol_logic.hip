@@ -347,6 +347,47 @@ extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, c
 //     post[c] = x[p][c] + F( sum_{r != c} F( l'[r][c] + prev[q][r] ) ),   F by the quantifier of prev
 // Lanes own 4 consecutive columns, 64/LPR rows are processed per step and UNR steps are in flight, so the loop
 // body has no cross-lane traffic at all; the row slots are combined once at the end.
+// Arithmetic is kept in the log2 domain inside the loop: with L = log2(e),
+//     ln(max(q + k e^w, eps)) = ln2 * log2(max(q + k 2^(L w), eps)),   L w = fma(v, L, L prev[r])
+// so one element costs min, fma, v_exp, fma, max, v_log, add (the ln2 factor is applied once per column at the end).
+// Self-relations: for an un-negated EXISTS predicate the diagonal needs no masking at all — its raw likelihood is the
+// absent value -30, so 1 - e^(-30 + prev) rounds to exactly 1.0f and contributes log2(1) = 0, as the reference's explicit
+// zeroing does (batch_base_ops.py:112).  Only FOR_ALL / negated predicates take the masked variant (wave-uniform choice).
+template <int LPR, int UNR, bool MASK>
+__device__ __forceinline__ void relate_one_rows(const float* __restrict__ tp, const float* __restrict__ pv, int NS, int cl, int c0,
+                                                int rs, int r0, int n, bool tail, int any_neg, float alpha_n, float cn, float qf,
+                                                float kf, bool ident, float (&acc)[4]) {
+    constexpr int RPI = 64 / LPR;
+    constexpr float L2E = 1.44269504088896340736f;
+    float4 t[UNR];
+    float pr2[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {                      // all loads of the step first
+        const int r = tail ? min(r0 + u * RPI + rs, n - 1) : r0 + u * RPI + rs;
+        t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)r * NS + cl);
+        pr2[u] = pv[r] * L2E;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * RPI + rs;
+        const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+        const int d = r - c0;                            // column j of this lane is the diagonal iff d == j
+        const bool row_ok = !tail || r < n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = fminf(l[j], 0.f);
+            if (any_neg) v = dfol_pnot(v, alpha_n, cn);
+            const float w2 = fmaf(v, L2E, pr2[u]);       // log2(e) * (l' + prev[r])
+            float f;
+            if (ident) f = w2;
+            else f = __builtin_amdgcn_logf(fmaxf(fmaf(kf, __builtin_amdgcn_exp2f(w2), qf), DFOL_EPS));
+            if (MASK) f = (row_ok && d != j) ? f : 0.f;
+            else if (tail) f = row_ok ? f : 0.f;
+            acc[j] += f;
+        }
+    }
+}
+
 template <int LPR, int UNR>
 __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
     const float* __restrict__ x_att, const float* __restrict__ prev_att, const float* __restrict__ tile,
@@ -366,35 +407,24 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
         return;
     }
     const int cg = lane % LPR, rs = lane / LPR, c0 = cg * 4;
-    const float alpha_n = (any_neg && neg[p]) ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
+    const bool negated = any_neg && neg[p];
+    const float alpha_n = negated ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
     const float qf = quant_prev[p], kf = 1.f - 2.f * qf;
     const bool ident = identity_forall && qf == 0.f;
+    const bool mask = negated || qf != 1.f;              // see the note above: only then can the diagonal contribute
     const float* tp = tile + (int64_t)p * NS * NS;
-    const int cl = min(c0, NS - 4);                      // lanes beyond the tile width read a valid column and are masked
+    const int cl = min(c0, NS - 4);                      // lanes beyond the tile width read a valid column and are discarded
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
-        float4 t[UNR];
-        float pr[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {                  // all loads of the step first
-            const int r = min(r0 + u * RPI + rs, n - 1);
-            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)r * NS + cl);
-            pr[u] = pv[r];
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u * RPI + rs;
-            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
-            const int d = r - c0;                        // column j of this lane is the diagonal iff d == j
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = fminf(l[j], 0.f);
-                if (any_neg) v = dfol_pnot(v, alpha_n, cn);
-                const float w = v + pr[u];
-                const float f = ident ? w : dfol_pnot(w, qf, kf);
-                acc[j] += (r < n && d != j) ? f : 0.f;
-            }
-        }
+    constexpr int STEP = RPI * UNR;
+    const int n_full = (n / STEP) * STEP;
+    if (mask) {
+        for (int r0 = 0; r0 < n_full; r0 += STEP)
+            relate_one_rows<LPR, UNR, true>(tp, pv, NS, cl, c0, rs, r0, n, false, any_neg, alpha_n, cn, qf, kf, ident, acc);
+        if (n_full < n) relate_one_rows<LPR, UNR, true>(tp, pv, NS, cl, c0, rs, n_full, n, true, any_neg, alpha_n, cn, qf, kf, ident, acc);
+    } else {
+        for (int r0 = 0; r0 < n_full; r0 += STEP)
+            relate_one_rows<LPR, UNR, false>(tp, pv, NS, cl, c0, rs, r0, n, false, any_neg, alpha_n, cn, qf, kf, ident, acc);
+        if (n_full < n) relate_one_rows<LPR, UNR, false>(tp, pv, NS, cl, c0, rs, n_full, n, true, any_neg, alpha_n, cn, qf, kf, ident, acc);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -405,7 +435,10 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
         const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
         float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (c0 + j < n) ? xv[j] + (ident ? acc[j] : dfol_pnot(acc[j], qf, kf)) : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const float s = acc[j] * (ident ? 0.69314718055994530942f / 1.0f : 0.69314718055994530942f);   // back from log2 to ln
+            o[j] = (c0 + j < n) ? xv[j] + (ident ? s : dfol_pnot(s, qf, kf)) : 0.f;
+        }
         *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }

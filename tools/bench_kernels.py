@@ -51,6 +51,15 @@ def main():
                                      ("relate_one_rowsum", True, False, 4 * N * N + 12 * N)):
         t = timeit(lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=ns, need_o=no))
         out.append({"kernel": label, "P": P, "N": N, "ms": t * 1e3, "GBps": bytes_per * P / t / 1e9, "frac_hbm_peak": bytes_per * P / t / HBM_PEAK})
+    t = timeit(lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones))
+    b1 = 4 * N * N + 12 * N
+    out.append({"kernel": "relate_one", "P": P, "N": N, "ms": t * 1e3, "GBps": b1 * P / t / 1e9, "frac_hbm_peak": b1 * P / t / HBM_PEAK})
+    t = timeit(lambda: tile.sum())
+    out.append({"kernel": "torch.sum(tile) (streaming read reference)", "ms": t * 1e3, "GBps": tile.numel() * 4 / t / 1e9})
+    dst = torch.empty_like(tile[: P // 2])
+    t = timeit(lambda: dst.copy_(tile[: P // 2]))
+    out.append({"kernel": "torch copy half (read+write reference)", "ms": t * 1e3, "GBps": 2 * dst.numel() * 4 / t / 1e9})
+    del dst
     ll = tile[:, 0, :].contiguous()
     t = timeit(lambda: L.filter_fwd(prior, ll, pq, n_obj))
     out.append({"kernel": "filter", "P": P, "N": N, "ms": t * 1e3, "GBps": 12 * N * P / t / 1e9, "frac_hbm_peak": 12 * N * P / t / HBM_PEAK})

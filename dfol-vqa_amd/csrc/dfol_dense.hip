@@ -6,6 +6,8 @@
 // lane takes the 16 *contiguous* k of its half (k = 16*(lane>>5) + t at step t) instead of the
 // interleaved k = 2t + (lane>>5): that turns 16 ds_read_b32 per operand tile into 4 conflict-free
 // ds_read_b128 (row pitch 36 floats).
+#include <stdlib.h>
+
 #include "dfol_common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -241,21 +243,20 @@ __global__ __launch_bounds__(256) void attr_ll_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q,
                                                       const int32_t* __restrict__ pred_col, int P, int NS, float dflt,
                                                       float* __restrict__ ll) {
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= P) return;
-    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x;                               // one workgroup per predicate, its objects split over 4 wavefronts
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = pred_q[p], col = pred_col[p];
     const int first = obj_off[q], n = obj_off[q + 1] - first;
     float* out = ll + (int64_t)p * NS;
     if (col < 0) {
-        for (int o = lane; o < NS; o += 64) out[o] = dflt;
+        for (int o = threadIdx.x; o < NS; o += 256) out[o] = dflt;
         return;
     }
     float e[8];                                            // H <= 512
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = (lane + 64 * j < H) ? E[(int64_t)col * ld_e + lane + 64 * j] : 0.f;
     const float bias = be ? be[col] : 0.f;
-    for (int o0 = 0; o0 < n; o0 += 4) {                      // four objects in flight per iteration
+    for (int o0 = 4 * wv; o0 < n; o0 += 16) {                // four objects in flight per wavefront and iteration
         float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void attr_ll_kernel(const float* __restrict__ 
             out[o0 + lane] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));       // nn.LogSigmoid
         }
     }
-    for (int o = n + lane; o < NS; o += 64) out[o] = dflt;
+    for (int o = n + threadIdx.x; o < NS; o += 256) out[o] = dflt;
 }
 
 extern "C" int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t H, const float* E, int64_t ld_e, const float* be,
@@ -283,7 +284,7 @@ extern "C" int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t 
     DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && H > 0 && H <= 512, "attr_ll: bad sizes P=%d NS=%d H=%d (H <= 512)", P, NS, H);
     if (P == 0) return 0;
     DFOL_REQUIRE(hidden && E && obj_off && pred_q && pred_col && ll, "attr_ll: null pointer");
-    hipLaunchKernelGGL(attr_ll_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, hidden, ld_hidden, H, E, ld_e, be,
+    hipLaunchKernelGGL(attr_ll_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, hidden, ld_hidden, H, E, ld_e, be,
                        obj_off, pred_q, pred_col, P, NS, default_ll, ll);
     DFOL_LAUNCH_CHECK("attr_ll");
     return 0;
@@ -517,6 +518,194 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------
+// Second geometry of the fused pair kernel for the full-size oracle: 16x16x4 MFMA tiles, 8 wavefronts per
+// workgroup (two per SIMD).  A wavefront owns 16 pairs across all hidden columns (NB16 accumulator tiles of
+// 16x16 = 4 registers each), so its accumulators need 80 registers instead of 160 and two wavefronts fit on
+// every SIMD: while one builds its next A operand (VALU) or waits at the barrier, the other keeps the matrix
+// pipe busy.  Requires HID1 % 32 == 0 and W2 allocated with 16*NB16 rows.
+// LDS layout of the W2 chunk: row pitch 36 floats; the 8-float k-group of (row, kq) is stored at group
+// kq ^ flip(row), flip = 1 for rows 4..11 (mod 16): a ds_read_b128 lane group always mixes lanes of two adjacent
+// hardware k indices (rows 0-3,12-15 of one with rows 4-11 of the next), and the flip puts them on the same group,
+// which makes every such read conflict-free.
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int NB16>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll16_kernel(
+    const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
+    const float* __restrict__ Wg, const float* __restrict__ W2, int64_t ld_w2, const float* __restrict__ b2, int HID2,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
+    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
+    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
+    float* __restrict__ tiles) {
+    constexpr int ROWS = 16 * NB16;                         // W2 rows staged per chunk (multiple of 64)
+    constexpr int PASSES = ROWS / 64;
+    constexpr int PARTS = 4, HALF = NB16 / PARTS;           // column tiles are visited in groups (register budget)
+    __shared__ __attribute__((aligned(16))) float Bs[2][ROWS * PK_PITCH];      // double-buffered W2 chunk: one barrier per chunk
+    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
+    const int n = n_obj[q];
+    if (tb * 128 >= n * n) return;
+    bool any = false;
+    for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
+    if (!any) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 4, r16 = lane & 15;
+    const int first = obj_off[q];
+    const int e_slot = tb * 128 + wave * 16 + r16;
+    const bool valid = e_slot < n * n;
+    const int s = valid ? e_slot / n : 0, o = valid ? e_slot - s * n : 0;
+    float geo[4];
+    {
+        const float* ps = pos + (int64_t)(first + s) * ld_pos;
+        const float* po = pos + (int64_t)(first + o) * ld_pos;
+        const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
+        const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        geo[0] = dist;
+        geo[1] = asinf(dy / fmaxf(dist, 1e-10f));
+        geo[2] = (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f);
+        geo[3] = (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f);
+    }
+    for (int i = tid; i < HID1; i += 512) *reinterpret_cast<float4*>(&Wgs[i * 4]) = *reinterpret_cast<const float4*>(Wg + i * 4);
+    const float* Urow = UV + (int64_t)(first + s) * ld_uv;
+    const float* Vrow = UV + (int64_t)(first + o) * ld_uv + HID1;
+
+    floatx4 acc[NB16];
+#pragma unroll
+    for (int i = 0; i < NB16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // W2 loader: 64 rows x 8 float4 per pass; element (row, k) goes to k-group (k/8) ^ flip(row)
+    const int lrow = tid >> 3, lkq = (tid & 7) >> 1, lwithin = ((tid & 7) & 1) * 4;
+    const int lflip = ((lrow & 15) >> 2) == 1 || ((lrow & 15) >> 2) == 2 ? 1 : 0;       // the same for lrow + 64 i
+    const int lds_off = lrow * PK_PITCH + 8 * (lkq ^ lflip) + lwithin;
+    float4 rb[PASSES];
+    auto load_w2 = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) rb[i] = *reinterpret_cast<const float4*>(W2 + (int64_t)(lrow + 64 * i) * ld_w2 + k0 + (tid & 7) * 4);
+    };
+    auto store_w2 = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) *reinterpret_cast<float4*>(&Bs[buf][64 * i * PK_PITCH + lds_off]) = rb[i];
+    };
+    float4 ru[2], rv[2];
+    auto load_uv = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ru[j] = *reinterpret_cast<const float4*>(Urow + k0 + 8 * kh + 4 * j);
+            rv[j] = *reinterpret_cast<const float4*>(Vrow + k0 + 8 * kh + 4 * j);
+        }
+    };
+    auto make_a = [&](int k0, float (&a)[8]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float uu[4] = {ru[j].x, ru[j].y, ru[j].z, ru[j].w}, vv[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 g = *reinterpret_cast<const float4*>(&Wgs[(k0 + 8 * kh + 4 * j + c) * 4]);
+                float z = uu[c] + vv[c] + (g.x * geo[0] + g.y * geo[1] + g.z * geo[2] + g.w * geo[3]);
+                a[4 * j + c] = z > 0.f ? z : dfol_exp(z) - 1.0f;      // nn.ELU
+            }
+        }
+    };
+    const int rflip = (r16 >> 2) == 1 || (r16 >> 2) == 2 ? 1 : 0;
+    const int boff = r16 * PK_PITCH + 8 * (kh ^ rflip);
+
+    float a_cur[8], a_next[8];
+    const int last = HID1 - 32;
+    load_w2(0);
+    load_uv(0);
+    __syncthreads();                                        // Wgs visible
+    store_w2(0);
+    make_a(0, a_cur);
+    load_w2(min(32, last));
+    load_uv(min(32, last));
+    __syncthreads();
+    int buf = 0;
+    const bool early = wave < 4;
+    for (int k0 = 0; k0 < HID1; k0 += 32, buf ^= 1) {
+        store_w2(buf ^ 1);                                  // chunk k0+32 (in registers since the previous iteration)
+        // The two wavefronts that share a SIMD (w and w+4) run their VALU phase at opposite ends of the iteration,
+        // so one of them always has MFMAs to issue while the other builds its next A operand.
+        if (early) {
+            make_a(min(k0 + 32, last), a_next);
+            load_uv(min(k0 + 64, last));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_w2(min(k0 + 64, last));                        // chunk k0+64 flies during this chunk's MFMAs
+        const float* brow = &Bs[buf][boff];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)                          // k steps 4h .. 4h+3 of this lane's 8
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+                float4 b4[HALF];
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) b4[i] = *reinterpret_cast<const float4*>(brow + (part * HALF + i) * 16 * PK_PITCH + 4 * h);
+                // k step outermost: consecutive MFMAs hit different accumulators (a 16x16x4 MFMA issues every 32 cycles
+                // but its result is ready for a dependent one only after 40)
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 0], b4[i].x, acc[part * HALF + i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 1], b4[i].y, acc[part * HALF + i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 2], b4[i].z, acc[part * HALF + i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 3], b4[i].w, acc[part * HALF + i], 0, 0, 0);
+            }
+        if (!early) {
+            __builtin_amdgcn_sched_barrier(0);
+            make_a(min(k0 + 32, last), a_next);
+            load_uv(min(k0 + 64, last));
+        }
+        __syncthreads();                                    // chunk k0 fully read, chunk k0+32 fully written
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a_cur[t] = a_next[t];
+    }
+
+    // h = Sigmoid(acc + b2); 16x16 C layout: column = i*16 + r16, row(e) = 4 * kh + e
+#pragma unroll
+    for (int i = 0; i < NB16; ++i) {
+        const int ncol = i * 16 + r16;
+        const bool in = ncol < HID2;
+        const float bv = in ? b2[ncol] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = in ? __frcp_rn(1.0f + dfol_exp(-(acc[i][e] + bv))) : 0.f;
+    }
+    const int64_t tile_sz = (int64_t)NS * NS;
+    for (int k = 0; k < K; ++k) {
+        const int col = req_col[(int64_t)k * Q + q];
+        if (col < 0) continue;
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) {
+            const int ncol = i * 16 + r16;
+            const float ev = ncol < HID2 ? E[(int64_t)col * ld_e + ncol] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[i][e], ev, part[e]);
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e] += __shfl_xor(part[e], m, 64);
+        if (r16 < 4) {                                      // lane e of each 16-lane set writes row 4*kh + e
+            const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
+            const int ee = tb * 128 + wave * 16 + 4 * kh + r16;
+            if (ee < n * n) {
+                const int ss = ee / n, oo = ee - ss * n;
+                const float x = v + (be ? be[col] : 0.f);
+                const float val = (ss == oo) ? dflt : fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+                float* t = tiles + (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz;
+                if (req_orient && req_orient[(int64_t)k * Q + q]) t[(int64_t)oo * NS + ss] = val;
+                else t[(int64_t)ss * NS + oo] = val;
+            }
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
                                 const float* W2, int64_t ld_w2, int32_t w2_rows_alloc, const float* b2, int32_t HID2, const float* E,
                                 int64_t ld_e, const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
@@ -536,6 +725,13 @@ extern "C" int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, co
                        ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles)
     const int nb = HID2 <= 32 ? 1 : (HID2 <= 128 ? 4 : 10);
     const bool kx = HID1 % 32 == 0 && w2_rows_alloc >= 32 * nb;
+    static const int variant = getenv("DFOL_PAIR_VARIANT") ? atoi(getenv("DFOL_PAIR_VARIANT")) : 16;
+    if (kx && nb == 10 && variant == 16) {                  // full-size oracle: 16x16x4 tiles, two wavefronts per SIMD
+        hipLaunchKernelGGL((pair_ll16_kernel<20>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, ld_e,
+                           be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
+        DFOL_LAUNCH_CHECK("pair_ll");
+        return 0;
+    }
     if (HID2 <= 32) { if (kx) DFOL_PAIR(1, true); else DFOL_PAIR(1, false); }
     else if (HID2 <= 128) { if (kx) DFOL_PAIR(4, true); else DFOL_PAIR(4, false); }
     else { if (kx) DFOL_PAIR(10, true); else DFOL_PAIR(10, false); }

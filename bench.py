@@ -91,11 +91,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+    # DFOL_BENCH_SHARE_GPU=1 is a debugging aid for boxes with one GPU: every rank uses cuda:0 and the ranks meet over gloo
+    share = os.environ.get("DFOL_BENCH_SHARE_GPU") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=device)
+        if share:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=device)      # RCCL over xGMI
 
     import dfol_vqa_amd as D
     from dfol_vqa_amd import _lib as L
@@ -130,7 +136,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
     total_q = args.batch * world * args.steps

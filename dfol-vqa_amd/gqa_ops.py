@@ -13,8 +13,8 @@ import numpy as np
 import torch
 
 from . import ops as L
-from .fol_types import BatchVariableSet, Quantifier, QuestionType
-from .host_util import find_max_ind, flatten_list, unflatten_list
+from .fol_types import BatchVariableSet, Quantifier, QuestionType, TokenType
+from .host_util import TokenList, find_max_ind, flatten_list, unflatten_list
 from .logic_ops import BatchOperatorBase, FilterBatch, RelateBatch
 
 UNKNOWN = 'UNKNOWN'
@@ -382,6 +382,10 @@ class GQAChooseRelBatch(GQABatchOperatorBase):
     def forward(self, op_id, world, variable_set, relation_list_list, is_subject, attribute_list=None, give_answer=True,
                 predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
         relation_list, batch_index = flatten_list(relation_list_list)
+        pre = getattr(relation_list_list, "flat_lowered", None)        # lowered (and its tiles prefetched) by the oracle
+        if pre is not None and len(pre.cols) == len(relation_list):
+            relation_list = TokenList(relation_list)
+            relation_list.lowered, relation_list.lowered_type = pre, TokenType.RELATION
         x = self._gqa_select(op_id, world, attribute_list, give_answer, predicate_question_map, likelihood_threshold)
         flag, host = _subject_flags(is_subject, world._device)
         subject_set = x.gate(variable_set, flag)

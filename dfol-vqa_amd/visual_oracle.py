@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import ops as L
 from .fol_types import TokenType
-from .host_util import get_lowered, segments_of
+from .host_util import flatten_list, get_lowered, lower_tokens, segments_of
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -252,32 +252,56 @@ class ClassifierOracle(OracleBase):
         return torch.empty(count, world._NS, world._NS, dtype=torch.float32, device=world._device)
 
     def prefetch_relations(self, world, program_batch):
-        """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel):
-        the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
+        """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel /
+        choose_rel): the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
         if world._lazy is None:
             return
-        lows, orients = [], []
         Q = world._batch_size
+        entries = []                                   # (lowered tokens, predicate -> question, per-predicate orientation)
         for ob in program_batch._op_batch_list:
-            if ob._op_name in ("relate", "verify_rel") and ob._arguments:
+            if not ob._arguments:
+                continue
+            if ob._op_name in ("relate", "verify_rel"):
                 toks = ob._arguments[0]
                 low = get_lowered(toks, self._ontology, TokenType.RELATION)
                 if getattr(toks, "lowered", None) is None:
                     toks.lowered, toks.lowered_type = low, TokenType.RELATION
                 if low.any_valid and len(low.cols) == Q:
-                    lows.append(low)
                     # the operator keeps the posterior of the freshly selected variable: store every tile with the
                     # OTHER (summed-out) variable along rows, so that posterior is a column reduction
-                    orients.append(np.asarray([L.TILE_OBJECT_ROWS if f else L.TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8))
-        if not lows:
+                    orient = np.asarray([L.TILE_OBJECT_ROWS if f else L.TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8)
+                    entries.append((low, np.arange(Q), orient))
+            elif ob._op_name == "choose_rel":
+                flat, batch_index = flatten_list(ob._arguments[0])
+                low = lower_tokens(flat, self._ontology, TokenType.RELATION)
+                ob._arguments[0].flat_lowered = low    # GQAChooseRelBatch hands it to RelateBatch
+                if low.any_valid:
+                    entries.append((low, np.asarray(batch_index, np.int64), np.zeros(len(flat), np.uint8)))
+        if not entries:
             return
-        tiles = self._new_tiles(world, len(lows) * Q)
-        req_col = np.stack([self._relation_full_columns(low.cols) for low in lows])
-        req_tile = np.arange(len(lows) * Q, dtype=np.int32).reshape(len(lows), Q)
-        req_orient = np.stack(orients)
-        self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
-        for k, low in enumerate(lows):
-            world._rel_tiles[id(low)] = (tiles[k * Q:(k + 1) * Q], req_orient[k])
+        total = sum(len(e[0].cols) for e in entries)
+        tiles = self._new_tiles(world, total)
+        rows_col, rows_tile, rows_orient, base = [], [], [], 0
+        for low, pq, orient in entries:
+            P = len(pq)
+            slot = np.zeros(P, np.int64)               # j-th predicate of its question
+            seen = {}
+            for p, q in enumerate(pq):
+                slot[p] = seen.get(int(q), 0)
+                seen[int(q)] = slot[p] + 1
+            K = int(slot.max()) + 1
+            col = np.full((K, Q), -1, np.int32)
+            til = np.zeros((K, Q), np.int32)
+            ori = np.zeros((K, Q), np.uint8)
+            col[slot, pq] = self._relation_full_columns(low.cols)
+            til[slot, pq] = base + np.arange(P, dtype=np.int32)
+            ori[slot, pq] = orient
+            rows_col.append(col), rows_tile.append(til), rows_orient.append(ori)
+            if not low.all_valid and not (min(world._n_list) < world._NS):
+                tiles[base + torch.as_tensor(np.nonzero(low.valid == 0)[0]).to(world._device)] = -30.0
+            world._rel_tiles[id(low)] = (tiles[base:base + P], orient)
+            base += P
+        self._launch_pairs(world, np.concatenate(rows_col), np.concatenate(rows_tile), tiles, np.concatenate(rows_orient))
 
     def oriented_tiles(self, world, low):
         """Prefetched tiles of a relate operator, each stored with its summed-out variable along rows (or None)."""

@@ -1,0 +1,312 @@
+"""Question and object-feature data path.
+
+Reference: src/nsvqa/data/data_pipeline.py:294-622 (ProgramDataset: JSON lines or the HDF5 program bytecode),
+src/gqa_preprocess.py:15-94 (GQAH5Encoder, the bytecode writer) and
+src/nsvqa/data/batch_gqa_boxfeatures_pipeline.py:15-189 (BatchGQABoxFeaturesCollator).
+
+The bytecode is six int32 arrays per question file — `answer[row]`, `image_id[row]`, `branch_ops[row, b, 10]`,
+`branch_args[row, b, 10, 3]`, `last_op[row]`, `last_args[row, k]` — token codes are 1-based vocabulary indices,
+negative = `not(token)`, 0 = empty.  The reference stores them in HDF5; this module reads and writes the same arrays
+from `.npz` (always available) and from `.h5` when `h5py` can be imported (it is not installed in this image).
+"""
+
+import collections
+import json
+import os
+import random
+import re
+
+import numpy as np
+import torch
+
+from .program import ProgramCollaterBase
+
+_NEG = re.compile(r"not\((\w|\s)+\)")
+ARRAYS = ("answer", "image_id", "branch_ops", "branch_args", "last_op", "last_args")
+
+
+def _open_arrays(path):
+    """{name: array-like} for a bytecode / feature container (.npz, or .h5 through h5py)."""
+    ext = os.path.splitext(path)[1]
+    if ext == ".npz":
+        return np.load(path)
+    if ext == ".h5":
+        try:
+            import h5py
+        except ImportError:
+            raise ImportError("%s is an HDF5 file but h5py is not installed; convert it to .npz with the same dataset names" % path)
+        return h5py.File(path, "r")
+    raise ValueError("unsupported container %s" % path)
+
+
+class ProgramCodec(object):
+    """Program <-> bytecode (gqa_preprocess.py:51-94 / data_pipeline.py:342-367, 391-453)."""
+
+    def __init__(self, ontology, max_branch_length=10):
+        self._ontology = ontology
+        self._max_branch_length = max_branch_length
+
+    # ---- encode -------------------------------------------------------------------------------
+    @staticmethod
+    def _flat(arguments):
+        return [item for sub in arguments for item in (sub if isinstance(sub, list) else [sub])]
+
+    def sizes(self, first_question, row_n):            # gqa_preprocess.py:21-49: sized by the file's first terminal operator
+        opn = first_question['program']['last_op']['operator']
+        arg_n = 2 if opn in ('verify_attrs', 'choose_attr', 'compare') else 3 if opn == 'verify_rel' else 4 if opn == 'choose_rel' else 1
+        branch_n = 2 if opn in ('and', 'or', 'two_same', 'two_different', 'compare') else 1
+        return row_n, branch_n, arg_n
+
+    def encode(self, questions):
+        ont = self._ontology
+        row_n, branch_n, arg_n = self.sizes(questions[0], len(questions))
+        out = {"answer": np.zeros(row_n, np.int32), "image_id": np.zeros(row_n, np.int32),
+               "branch_ops": np.zeros((row_n, branch_n, self._max_branch_length), np.int32),
+               "branch_args": np.zeros((row_n, branch_n, self._max_branch_length, 3), np.int32),
+               "last_op": np.zeros(row_n, np.int32), "last_args": np.zeros((row_n, arg_n), np.int32)}
+        for i, q in enumerate(questions):
+            out["image_id"][i] = ont.encode_img_id(q['imageId'])
+            out["answer"][i] = ont.encode_token(q['answer'])
+            for j, branch in enumerate(q['program']['branches']):
+                for k, o in enumerate(branch):
+                    out["branch_ops"][i, j, k] = ont.encode_op(o['operator'])
+                    for t, arg in enumerate(self._flat(o['arguments'])):
+                        out["branch_args"][i, j, k, t] = ont.encode_token(arg)
+            last = q['program']['last_op']
+            out["last_op"][i] = ont.encode_op(last['operator'])
+            for t, arg in enumerate(self._flat(last['arguments'])):
+                out["last_args"][i, t] = ont.encode_token(arg)
+        return out
+
+    # ---- decode -------------------------------------------------------------------------------
+    def _args(self, op_name, codes):
+        tok = self._ontology.decode_token
+        if op_name in ('select', 'filter', 'query_attr', 'verify_attr', 'all_same', 'all_different', 'two_same', 'two_different'):
+            return [tok(codes[0])]
+        if op_name in ('relate', 'verify_rel'):
+            return [tok(codes[i]) for i in range(3)]
+        if op_name == 'choose_attr':
+            return [[tok(codes[0]), tok(codes[1])]]
+        if op_name == 'verify_attrs':
+            return [[tok(codes[0])] + ([tok(codes[1])] if codes[1] != 0 else [])]
+        if op_name == 'choose_rel':
+            return [[tok(codes[0]), tok(codes[1])], tok(codes[2]), tok(codes[3])]
+        if op_name == 'compare':
+            return [tok(codes[0]), tok(codes[1])]
+        if op_name in ('exist', 'and', 'or', 'end'):
+            return []
+        raise KeyError(op_name)
+
+    def decode(self, arrays, idx):
+        ont = self._ontology
+        obj = {'imageId': ont.decode_img_id(int(arrays['image_id'][idx])), 'answer': ont.decode_token(int(arrays['answer'][idx]))}
+        last_name = ont.decode_op(int(arrays['last_op'][idx]))
+        last = {'operator': last_name, 'arguments': self._args(last_name, [int(c) for c in arrays['last_args'][idx]])}
+        ops, args = np.asarray(arrays['branch_ops'][idx]), np.asarray(arrays['branch_args'][idx])
+        branches = []
+        for i in range(ops.shape[0]):
+            branch = []
+            for j in range(ops.shape[1]):
+                if ops[i, j] == 0:
+                    break
+                name = ont.decode_op(int(ops[i, j]))
+                branch.append({'operator': name, 'arguments': self._args(name, [int(c) for c in args[i, j]])})
+            branches.append(branch)
+        obj['program'] = {'branches': branches, 'last_op': last}
+        return obj
+
+
+def _strip_negation(tokens):                            # data_pipeline.py:455-471
+    return [a.strip()[4:-1] if isinstance(a, str) and _NEG.match(a.strip()) else (a.strip() if isinstance(a, str) else a) for a in tokens]
+
+
+def _entity(arg):
+    return "entity" if arg is None or (isinstance(arg, str) and arg.lower() in ("_", "scene")) else arg
+
+
+class ProgramDataset(torch.utils.data.Dataset):
+    """data_pipeline.py:294-622.  `input_file`: a JSON-lines path, a bytecode container (.npz / .h5) or a list of dicts."""
+
+    def __init__(self, input_file, ontology, in_memory, max_cache_size=100000, keep_original_dict=False, shuffle_options=True):
+        super(ProgramDataset, self).__init__()
+        self._input_file = input_file
+        self._ontology = ontology
+        self._keep_original_dict = keep_original_dict
+        self._shuffle_options = shuffle_options         # the reference shuffles choose-options at load time (:596-597)
+        self._codec = ProgramCodec(ontology)
+        self._is_bytecode = isinstance(input_file, str) and os.path.splitext(input_file)[1] in (".npz", ".h5")
+        self._is_h5 = self._is_bytecode
+        self._in_memory = in_memory or isinstance(input_file, (list, tuple))
+        self._cache = {} if self._in_memory else collections.OrderedDict()
+        self._max_cache_size = max_cache_size
+        self._arrays = None
+        if self._is_bytecode:
+            arrays = _open_arrays(input_file)
+            self._row_num = arrays['image_id'].shape[0]
+            if self._in_memory:
+                self._arrays = {k: np.asarray(arrays[k]) for k in ARRAYS}
+        elif isinstance(input_file, str):
+            with open(input_file, 'r') as fh:
+                lines = fh.readlines()
+            self._row_num = len(lines)
+            self._data = lines if self._in_memory else None
+            if not self._in_memory:
+                self._offsets = np.cumsum([0] + [len(l.encode('utf8')) for l in lines[:-1]]).tolist()
+        else:
+            self._data = input_file
+            self._row_num = len(input_file)
+
+    def __len__(self):
+        return self._row_num
+
+    def _raw(self, idx):
+        if self._is_bytecode:
+            if self._arrays is None:                    # opened lazily in each DataLoader worker
+                self._arrays = _open_arrays(self._input_file)
+            return self._codec.decode(self._arrays, idx)
+        if self._data is not None:
+            line = self._data[idx]
+        else:
+            with open(self._input_file, 'rb') as fh:
+                fh.seek(self._offsets[idx])
+                line = fh.readline().decode('utf8')
+        return json.loads(line) if isinstance(line, str) else line
+
+    def __getitem__(self, idx):
+        if not self._in_memory and idx in self._cache:
+            return self._cache[idx]
+        result = self._transform_line(self._raw(idx))
+        if not self._in_memory:
+            if len(self._cache) >= self._max_cache_size:
+                self._cache.popitem(last=False)
+            self._cache[idx] = result
+        return result
+
+    # ---- tokens a question mentions (data_pipeline.py:473-569); the variable name threads through a branch ----
+    def _category_options(self, category, name):
+        # the reference appends to the ontology's own list here (:487-488), growing it on every call; a copy is used instead
+        return list(self._ontology.query(category if category not in ['name', 'type'] else name)) + [category]
+
+    def _extract(self, operator, arguments, name):
+        if operator == 'select':
+            args = _strip_negation(arguments)
+            return args, _entity(args[0])
+        if operator == 'filter':
+            args = _strip_negation(arguments)
+            return args, args[0] if self._ontology.is_noun(args[0]) else name
+        if operator in ('relate', 'verify_rel'):
+            a0, a2 = _strip_negation([arguments[0]]), _strip_negation([arguments[2]])
+            return a0 + a2, _entity(a2[0])
+        if operator == 'choose_rel':
+            a0, a2 = _strip_negation(arguments[0]), _strip_negation([arguments[2]])
+            return a0 + a2, _entity(a2[0])
+        if operator in ('query_attr', 'all_same', 'all_different', 'two_same', 'two_different'):
+            return _strip_negation(self._category_options(arguments[0], name)), name
+        if operator in ('choose_attr', 'verify_attrs'):
+            return _strip_negation(arguments[0]), name
+        if operator == 'verify_attr':
+            return _strip_negation(arguments), name
+        if operator == 'compare':
+            return _strip_negation([arguments[0]]), name
+        if operator in ('exist', 'and', 'or', 'end'):
+            return [], name
+        raise KeyError(operator)
+
+    def _collect_tokens(self, program):
+        tokens, name = [], ''
+        for branch in program['branches']:
+            name = ''
+            for o in branch:
+                t, name = self._extract(o['operator'], o['arguments'], name)
+                tokens += t
+        t, name = self._extract(program['last_op']['operator'], program['last_op']['arguments'], name)
+        return list(set(tokens + t))
+
+    @staticmethod
+    def _transform_answer(op_name, answer):             # data_pipeline.py:571-591
+        if answer is None:
+            return None
+        if isinstance(answer, (list, tuple)):
+            if len(answer) == 0:
+                return []
+            flat = [x for sub in answer for x in sub] if isinstance(answer[0], (list, tuple)) else list(answer)
+            return [a.lower().strip() for a in flat]
+        res = answer.lower().strip() if isinstance(answer, str) else answer
+        if op_name == 'choose_rel':
+            res = {'left': 'to the left of', 'right': 'to the right of'}.get(res, res)
+        return res
+
+    def _transform_line(self, q):                       # data_pipeline.py:593-622
+        op_name = q['program']['last_op']['operator']
+        if self._shuffle_options and op_name in ('choose_rel', 'choose_attr'):
+            random.shuffle(q['program']['last_op']['arguments'][0])
+        if 'answer' not in q:
+            q['answer'] = ""
+        text = not self._is_bytecode
+        result = {'program': q['program'], 'image_id': q['imageId'], 'answer': self._transform_answer(op_name, q['answer']),
+                  'tokens': self._collect_tokens(q['program']), 'original_dict': q if self._keep_original_dict else None,
+                  'question': q['question'] if text and 'question' in q else None,
+                  'question_id': q['question_id'] if text and 'question_id' in q else None}
+        for key in ('object_pairs', 'attribute_dict', 'relation_list'):
+            if key in q:
+                result[key] = q[key]
+        if 'weights' in q:
+            w = q['weights']
+            result['weights'] = [x for sub in w for x in sub] if len(w) > 0 and isinstance(w[0], (list, tuple)) else w
+        return result
+
+
+class BatchGQABoxFeaturesCollator(ProgramCollaterBase):
+    """batch_gqa_boxfeatures_pipeline.py:15-189: object features of the questions' images from chunked containers.
+
+    Chunk i is `<prefix>_<i>.npz` (or `.h5`) with `features [chunk, max_obj, F]` and `bboxes [chunk, max_obj, 4]` (x1, y1, x2, y2);
+    `object_info_json_path` maps image id -> {objectsNum, width, height, idx, file}.  Produces the reference's
+    `object_features [O, F + 6]` = [features, W, H, x, y, w, h] (:57-71) plus the host-side object counts."""
+
+    def __init__(self, object_h5_path, file_prefix, chunk_num, object_info_json_path, ontology, split_num, lower=True):
+        super(BatchGQABoxFeaturesCollator, self).__init__('select', 'relate', 'filter', split_num, ontology=ontology if lower else None)
+        self._object_h5_path = object_h5_path
+        self._file_prefix = file_prefix
+        self._chunk_num = chunk_num
+        self._file_handles = None
+        with open(object_info_json_path, 'r') as f:
+            self._object_info = json.load(f)
+        self._gqa_ontology = ontology
+        first = self._chunk(0)
+        self._chunck_size, self._max_object_per_image, self._feature_dim = first['features'].shape
+
+    def _chunk_path(self, i):
+        base = os.path.join(self._object_h5_path, "%s_%d" % (self._file_prefix, i))
+        for ext in (".npz", ".h5"):
+            if os.path.exists(base + ext):
+                return base + ext
+        raise FileNotFoundError(base + ".npz|.h5")
+
+    def _chunk(self, i):
+        return _open_arrays(self._chunk_path(i))
+
+    def collate_object_features(self, questions):
+        if self._file_handles is None:                  # opened lazily in each DataLoader worker (:38-39)
+            self._file_handles = [self._chunk(i) for i in range(self._chunk_num)]
+        info = [self._object_info[q['image_id']] for q in questions]
+        feats, counts = [], []
+        for inf in info:
+            n = int(inf['objectsNum'])
+            h = self._file_handles[inf['file']]
+            f = np.asarray(h['features'][inf['idx']][:n], np.float32)
+            b = np.array(h['bboxes'][inf['idx']][:n], np.float32)
+            b[:, 2] -= b[:, 0]                          # (x1, y1, x2, y2) -> (x, y, w, h)  (:60-61)
+            b[:, 3] -= b[:, 1]
+            size = np.tile(np.asarray([[inf['width'], inf['height']]], np.float32), (n, 1))
+            feats.append(np.concatenate([f, size, b], 1))
+            counts.append(n)
+        batch_ind = torch.from_numpy(np.repeat(np.arange(len(counts)), counts).astype(np.int64))
+        return torch.from_numpy(np.concatenate(feats, 0)), batch_ind
+
+    def collate_meta_data(self, questions):             # :75-92 (the direct-supervision extras are out of scope)
+        tokens = sorted({t for q in questions for t in q['tokens']}, key=str)
+        emb = self._gqa_ontology.get_embeddings([str(t) for t in tokens])
+        return {'index': {t: i for i, t in enumerate(tokens)},
+                'embedding': torch.zeros(len(tokens), 1) if emb is None else torch.from_numpy(emb).float(),
+                'questions': [q.get('question') for q in questions], 'image_ids': [q['image_id'] for q in questions],
+                'question_ids': [q.get('question_id') for q in questions]}

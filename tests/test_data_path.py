@@ -1,0 +1,120 @@
+"""CPU tests of the question / feature data path against the reference's own encoder and decoder (golden g9)."""
+
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+import dfol_vqa_amd as D  # noqa: E402
+from dfol_vqa_amd import data  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ontology(mini_ontology_paths):
+    p = mini_ontology_paths
+    return D.GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["word_embedding_file"],
+                         relation_json_path=p["relation_file"])
+
+
+def test_bytecode_encode_matches_reference(ontology):
+    a, meta = gu.load("g9_program_bytecode")
+    codec = data.ProgramCodec(ontology)
+    for name, f in meta["files"].items():
+        mine = codec.encode(copy.deepcopy(f["questions"]))
+        for k in data.ARRAYS:
+            ref = a[name + ":" + k]
+            assert mine[k].dtype == np.int32 and mine[k].shape == ref.shape, (name, k)
+            assert np.array_equal(mine[k], ref), (name, k)
+
+
+def test_bytecode_decode_and_dataset_match_reference(ontology, tmp_path):
+    a, meta = gu.load("g9_program_bytecode")
+    for name, f in meta["files"].items():
+        path = str(tmp_path / (name + ".npz"))
+        np.savez(path, **{k: a[name + ":" + k] for k in data.ARRAYS})
+        for in_memory in (True, False):
+            ds = data.ProgramDataset(path, ontology, in_memory=in_memory, shuffle_options=False)
+            assert len(ds) == len(f["decoded"])
+            for i, ref in enumerate(f["decoded"]):
+                r = ds[i]
+                assert r["program"] == ref["program"], (name, i)
+                assert r["image_id"] == ref["image_id"] and r["answer"] == ref["answer"]
+                assert sorted(map(str, r["tokens"])) == ref["tokens"], (name, i)
+                assert r["question"] is None and r["question_id"] is None      # the bytecode carries no text (:604-605)
+        # JSON lines, from a list and from a file
+        jl = str(tmp_path / (name + ".json"))
+        with open(jl, "w") as fh:
+            for q in f["questions"]:
+                fh.write(json.dumps(q) + "\n")
+        for src, in_memory in ((copy.deepcopy(f["questions"]), True), (jl, True), (jl, False)):
+            ds = data.ProgramDataset(src, ontology, in_memory=in_memory, shuffle_options=False)
+            for i, ref in enumerate(f["from_json"]):
+                r = ds[i]
+                assert r["program"] == ref["program"] and r["answer"] == ref["answer"] and r["image_id"] == ref["image_id"]
+                assert sorted(map(str, r["tokens"])) == ref["tokens"]
+                assert r["question"] == ref["question"] and r["question_id"] == ref["question_id"]
+
+
+def test_dataset_does_not_grow_the_ontology(ontology):
+    before = len(ontology.query("color"))
+    ds = data.ProgramDataset([{"imageId": "img001", "answer": "red", "program": {"branches": [[{"operator": "select", "arguments": ["dog"]}]],
+                                                                                 "last_op": {"operator": "query_attr", "arguments": ["color"]}}}],
+                             ontology, in_memory=True)
+    for _ in range(3):
+        assert "color" in ds[0]["tokens"]
+    assert len(ontology.query("color")) == before        # the reference appends to the ontology's list on every call
+
+
+def test_choose_options_shuffle_only_when_asked(ontology):
+    q = {"imageId": "img001", "answer": "on", "program": {"branches": [[{"operator": "select", "arguments": ["dog"]}]],
+                                                          "last_op": {"operator": "choose_rel", "arguments": [["on", "under"], True, "cat"]}}}
+    ds = data.ProgramDataset([copy.deepcopy(q)], ontology, in_memory=True, shuffle_options=False)
+    assert ds[0]["program"]["last_op"]["arguments"][0] == ["on", "under"]
+    seen = set()
+    for _ in range(20):
+        seen.add(tuple(data.ProgramDataset([copy.deepcopy(q)], ontology, in_memory=True)[0]["program"]["last_op"]["arguments"][0]))
+    assert seen == {("on", "under"), ("under", "on")}
+    assert data.ProgramDataset._transform_answer("choose_rel", "Left ") == "to the left of"
+
+
+def test_feature_collator_layout(ontology, tmp_path):
+    rng = np.random.RandomState(0)
+    F, max_obj = 8, 6
+    info = {}
+    for c in range(2):
+        feats = rng.uniform(size=(3, max_obj, F)).astype(np.float32)
+        boxes = np.zeros((3, max_obj, 4), np.float32)
+        boxes[..., :2] = rng.uniform(0, 100, (3, max_obj, 2))
+        boxes[..., 2:] = boxes[..., :2] + rng.uniform(5, 50, (3, max_obj, 2))
+        np.savez(str(tmp_path / ("gqa_objects_%d.npz" % c)), features=feats, bboxes=boxes)
+        for i in range(3):
+            info["img%03d" % (c * 3 + i)] = {"objectsNum": int(rng.randint(1, max_obj + 1)), "width": 640, "height": 480, "idx": i, "file": c}
+    info_path = str(tmp_path / "info.json")
+    json.dump(info, open(info_path, "w"))
+    coll = data.BatchGQABoxFeaturesCollator(str(tmp_path), "gqa_objects", 2, info_path, ontology, split_num=2)
+    qs = []
+    for k, im in enumerate(["img004", "img000", "img005", "img002"]):
+        q = {"imageId": im, "answer": "yes", "question": "q", "question_id": str(k),
+             "program": {"branches": [[{"operator": "select", "arguments": ["dog"]}, {"operator": "filter", "arguments": ["red"]}]],
+                         "last_op": {"operator": "exist", "arguments": []}}}
+        qs.append(q)
+    ds = data.ProgramDataset(qs, ontology, in_memory=True)
+    pbs = coll.collate([ds[i] for i in range(len(ds))])
+    assert [pb.batch_size() for pb in pbs] == [2, 2]
+    pb = pbs[0]
+    n4, n0 = info["img004"]["objectsNum"], info["img000"]["objectsNum"]
+    assert pb._object_features.shape == (n4 + n0, F + 6) and pb._object_nums == [n4, n0]
+    assert pb._object_batch_index.tolist() == [0] * n4 + [1] * n0
+    chunk = np.load(str(tmp_path / "gqa_objects_1.npz"))
+    row = pb._object_features[0].numpy()
+    assert np.allclose(row[:F], chunk["features"][1, 0])
+    b = chunk["bboxes"][1, 0]
+    assert np.allclose(row[F:], [640, 480, b[0], b[1], b[2] - b[0], b[3] - b[1]])
+    assert pb._op_batch_list[0]._arguments[0].lowered is not None       # lowered at collate time
+    assert set(pb._meta_data["index"]) == {"dog", "red"} and pb._meta_data["embedding"].shape == (2, 12)

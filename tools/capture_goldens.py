@@ -559,7 +559,90 @@ def g8():
     save("g8_gather", {"dummy": np.zeros(1)}, meta)
 
 
+# ---------------------------------------------------------------------------------------- g9
+def g9():
+    """Program bytecode (the HDF5 question format): the reference's GQAH5Encoder.encode (gqa_preprocess.py:51-94) and
+    ProgramDataset.__getitem__/_decode_*/_transform_line (data_pipeline.py:337-453, 593-622), run for real with an
+    in-memory stand-in for the h5py.File *container* (h5py is not installed; only dataset storage is stubbed)."""
+    import random
+    import tempfile
+    store = {}
+
+    class FakeFile(object):
+        def __init__(self, path, mode="r"):
+            self._path = path
+            if mode == "w":
+                store[path] = {}
+            self._d = store[path]
+
+        def create_dataset(self, name, data=None):
+            self._d[name] = np.array(data)
+
+        def __getitem__(self, k):
+            return self._d[k]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def close(self):
+            pass
+
+    sys.modules["h5py"].File = FakeFile
+    for name in ("pattern", "pattern.text", "pattern.text.en"):       # `pattern` (singularize) is not installed; the encoder never calls it
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.singularize = lambda w: w
+        sys.modules.setdefault(name, m)
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_preprocess
+    Q = lambda i, br, last, ans: {"imageId": "img%03d" % i, "answer": ans, "question": "q%d" % i, "question_id": str(i),
+                                  "program": {"branches": br, "last_op": last}}
+    files = {
+        "exist": [Q(0, [[op("select", "dog"), op("filter", "not(red)"), op("relate", "on", True, "table")]], op("exist"), "yes"),
+                  Q(1, [[op("select", "_"), op("relate", "to the left of", False, "_"), op("filter", "small")]], op("exist"), "no")],
+        "choose_rel": [Q(2, [[op("select", "man")]], op("choose_rel", ["on", "under"], True, "table"), "on"),
+                       Q(3, [[op("select", "cat"), op("filter", "black")]], op("choose_rel", ["near", "behind"], False, "_"), "behind")],
+        "verify_attrs": [Q(4, [[op("select", "cup")]], op("verify_attrs", ["red", "glass"]), "yes"),
+                         Q(5, [[op("select", "car")]], op("verify_attrs", ["blue"]), "no")],
+        "two_same": [Q(6, [[op("select", "dog")], [op("select", "cat"), op("filter", "white")]], op("two_same", "color"), "yes")],
+        "compare": [Q(7, [[op("select", "dog")], [op("select", "cat")]], op("compare", "large", True), "dog")],
+        "query_attr": [Q(8, [[op("select", "animal"), op("filter", "small")]], op("query_attr", "name"), "cat"),
+                       Q(9, [[op("select", "chair")]], op("query_attr", "color"), "red")],
+    }
+    tmp_in, tmp_out = tempfile.mkdtemp(), tempfile.mkdtemp()
+    for name, qs in files.items():
+        with open(os.path.join(tmp_in, name + ".json"), "w") as f:
+            for q in qs:
+                f.write(json.dumps(q) + "\n")
+    gqa_preprocess.GQAH5Encoder(ontology).encode(tmp_in, tmp_out)
+    arrays, meta = {}, {"source": "gqa_preprocess.py:51-94; data_pipeline.py:337-453,593-622", "files": {}}
+    orig_shuffle = ref.data_pipeline.shuffle
+    ref.data_pipeline.shuffle = lambda x: None          # the reference shuffles choose-options at load time; goldens keep file order
+    for name, qs in files.items():
+        path = os.path.join(tmp_out, name + ".h5")
+        for k, v in store[path].items():
+            arrays[name + ":" + k] = v
+        ds = ref.data_pipeline.ProgramDataset(path, ontology, in_memory=True)
+        decoded = []
+        for i in range(len(ds)):
+            r = ds[i]
+            decoded.append({"program": r["program"], "image_id": r["image_id"], "answer": r["answer"], "tokens": sorted(map(str, r["tokens"]))})
+        jl = ref.data_pipeline.ProgramDataset(copy.deepcopy(qs), ontology, in_memory=True)
+        from_json = []
+        for i in range(len(jl)):
+            r = jl[i]
+            from_json.append({"program": r["program"], "image_id": r["image_id"], "answer": r["answer"], "tokens": sorted(map(str, r["tokens"])),
+                              "question": r["question"], "question_id": r["question_id"]})
+        meta["files"][name] = {"questions": qs, "decoded": decoded, "from_json": from_json}
+    ref.data_pipeline.shuffle = orig_shuffle
+    save("g9_program_bytecode", arrays, meta)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()
+

@@ -38,7 +38,7 @@ RELATIONS = ["on", "under", "near", "to the left of", "to the right of", "holdin
 OPS = ["select", "all_different", "all_same", "and", "relate", "filter", "choose_attr", "choose_rel",
        "compare", "exist", "or", "query_attr", "two_different", "two_same", "verify_attrs", "verify_rel"]
 
-EXTRA_ARGS = ["yes", "no", "true", "false", "name", "type", "entity", "scene"]
+EXTRA_ARGS = ["yes", "no", "true", "false", "name", "type", "entity", "scene", "_"]
 
 EMBEDDING_DIM = 12
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "dfol_attr_gather_bwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _i64, _p],
     "dfol_rel_gather_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "dfol_option_normalize_bwd_f32": [_p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
+    "dfol_modulate_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
     "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
                          _i32, _f, _p, _p],
@@ -352,3 +353,10 @@ def option_normalize_bwd(g_y, y, seg_off, pred_q, n_obj, NS):
     call("dfol_option_normalize_bwd_f32", _ptr(g_y, F32), _ptr(y, F32), _ptr(seg_off, I32), seg_off.numel() - 1, _ptr(pred_q, I32),
          _ptr(n_obj, I32), NS, y.dim() - 1, _ptr(g_x), _stream())
     return g_x
+
+
+def modulate(att, mods, pred_q, n_obj):
+    P, NS = att.shape
+    out = torch.empty_like(att)
+    call("dfol_modulate_f32", _ptr(att, F32), _ptr(mods, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, _ptr(out), _stream())
+    return out

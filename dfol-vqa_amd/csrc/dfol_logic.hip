@@ -658,3 +658,38 @@ extern "C" int dfol_compare_f32(const float* lp1, const float* lp2, const float*
     DFOL_LAUNCH_CHECK("compare");
     return 0;
 }
+
+
+// =====================================================================================================
+// attention calibration: BatchVariableSet.apply_modulations, batch_base_types.py:170-179 (4-column modulations)
+//   alpha = 10 m0, beta = 10 m1, c = 10 m2, d = m3
+//   t  = alpha * a + slog(c) + slog(d)
+//   a' = t - slog( exp(beta * lnot(a) + slog(1 - d)) + exp(t) )
+// =====================================================================================================
+__global__ void modulate_kernel(const float* __restrict__ att, const float* __restrict__ mods, const int32_t* __restrict__ pred_q,
+                                const int32_t* __restrict__ n_obj, int NS, float* __restrict__ out) {
+    const int p = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= NS) return;
+    const int64_t i = (int64_t)p * NS + c;
+    float r = 0.f;
+    if (c < n_obj[pred_q[p]]) {
+        const float alpha = mods[4 * p + 0] * 10.f, beta = mods[4 * p + 1] * 10.f, cc = mods[4 * p + 2] * 10.f, d = mods[4 * p + 3];
+        const float a = att[i];
+        const float t = alpha * a + logf(fmaxf(cc, DFOL_EPS)) + logf(fmaxf(d, DFOL_EPS));
+        const float na = logf(fmaxf(1.f - expf(a), DFOL_EPS));
+        const float u = beta * na + logf(fmaxf(1.f - d, DFOL_EPS));
+        r = t - logf(fmaxf(expf(u) + expf(t), DFOL_EPS));
+    }
+    out[i] = r;
+}
+
+extern "C" int dfol_modulate_f32(const float* att, const float* mods, const int32_t* pred_q, const int32_t* n_obj, int32_t P, int32_t NS,
+                                 float* out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0, "modulate: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE(att && mods && pred_q && n_obj && out, "modulate: null pointer");
+    hipLaunchKernelGGL(modulate_kernel, dim3(P, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, att, mods, pred_q, n_obj, NS, out);
+    DFOL_LAUNCH_CHECK("modulate");
+    return 0;
+}

@@ -2,7 +2,10 @@
 src/nsvqa/base_experiment.py:43-47).  The YAML keys are the reference's (CONFIG_YAML.md); only the
 builders are here — the training/test orchestration of ExperimentBase.run is out of scope."""
 
+import math
+
 import torch
+import torch.nn as nn
 import yaml
 
 from .gqa_ops import GQAOntology
@@ -23,8 +26,20 @@ def build_ontology(config):                                     # gqa_interprete
 
 
 def build_neural_modules(config, ontology):                     # gqa_interpreter_experiments.py:107-198 (classifier oracle only)
-    if config.get('activate_attention_transfer'):
-        raise NotImplementedError("activate_attention_transfer: the calibration LSTMs are SURVEY.md §8(f) rank 2 (not built yet)")
+    fwd_net = bwd_net = out_net = None
+    if config.get('activate_attention_transfer'):               # gqa_interpreter_experiments.py:115-138
+        output_dim, max_activation = 4, 10.0
+        in_dim = config['word_embedding_dim'] + 1 + 17
+        fwd_net = nn.LSTMCell(in_dim, config['attention_transfer_state_dim'])
+        bwd_net = nn.LSTMCell(in_dim, config['attention_transfer_state_dim'])
+        out_net = nn.Sequential(nn.Linear(2 * config['attention_transfer_state_dim'], output_dim), nn.Sigmoid())
+        out_net[0].weight = nn.Parameter(torch.zeros(output_dim, 2 * config['attention_transfer_state_dim']))
+        bias = -math.log(max_activation - 1) * torch.ones(output_dim)
+        bias[3] = 0
+        out_net[0].bias = nn.Parameter(bias)
+        if config.get('freeze_attention_network'):
+            for net in (fwd_net, bwd_net, out_net):
+                net.requires_grad_(False)
     if config['oracle_output_dim'] != 1 or not config['classifier_oracle']:
         raise NotImplementedError("only classifier_oracle with oracle_output_dim == 1 (every shipped config) is built")
     drop = config['dropout']
@@ -45,8 +60,8 @@ def build_neural_modules(config, ontology):                     # gqa_interprete
         if config.get(flag):
             net.requires_grad_(False)
     return {'featurizer_network': featurizer_network, 'attribute_network': attribute_network, 'relation_network': relation_network,
-            'embedding_network': embedding_network, 'forward_attention_network': None, 'backward_attention_network': None,
-            'attention_output_network': None}
+            'embedding_network': embedding_network, 'forward_attention_network': fwd_net, 'backward_attention_network': bwd_net,
+            'attention_output_network': out_net}
 
 
 def build_interpreter(config, neural_dict, ontology):           # gqa_interpreter_experiments.py:200-240
@@ -55,7 +70,10 @@ def build_interpreter(config, neural_dict, ontology):           # gqa_interprete
                               normalize=bool(config.get('normalize_oracle')), cached=True)
     return BatchGQAInterpreter(config['model_name'], oracle, ontology, featurizer, trainable_gate=config['trainable_gate'],
                                likelihood_threshold=config['likelihood_threshold'], hard_mode=config.get('hard_mode', False),
-                               attention_transfer_state_dim=config['attention_transfer_state_dim'], cached=True)
+                               attention_transfer_state_dim=config['attention_transfer_state_dim'],
+                               forward_attention_network=neural_dict['forward_attention_network'],
+                               backward_attention_network=neural_dict['backward_attention_network'],
+                               attention_output_network=neural_dict['attention_output_network'], cached=True)
 
 
 def build_model(config, ontology):                              # base_experiment.py:28-30

@@ -115,6 +115,12 @@ class BatchWorld(object):
         return BatchVariableSet(names, self._device, self._object_num, self._batch_size, quantifiers=quantifier,
                                 log_attention=log_attention, world=self)
 
+    def attention_state(self, name, state=None):               # batch_base_types.py:249-252
+        if state is None:
+            z = torch.zeros(self._batch_size, self._attention_transfer_state_dim, dtype=torch.float32, device=self._device)
+            state = (z, torch.zeros_like(z))
+        return BatchAttentionState(name, self._device, state)
+
     # -- block helpers ---------------------------------------------------------------------------
     def pair_index(self):
         """(subject row, object row) of every ordered same-image pair, in the reference's order (util.py:87-103)."""
@@ -259,9 +265,60 @@ class BatchVariableSet(object):
         return out
 
     def apply_modulations(self, modulations, input_variable_set, predicate_question_map=None):
+        """Attention calibration (batch_base_types.py:170-187) with the [P, 4] modulations of the attention-output network."""
         if modulations is not None:
-            raise NotImplementedError("attention calibration (batch_base_types.py:170-187) is SURVEY.md §8(f) rank 2: not built yet")
+            if modulations.size()[1] != 4:
+                raise NotImplementedError("only the 4-column modulations the reference builds (output_dim = 4) are supported")
+            self._log_attention = L.modulate(self._log_attention, modulations, self.pred_q(), self._world._n_obj)
         return self
 
     def __repr__(self):
         return "Object set of %d objects in %d blocks of %d" % (self._object_num, self._batch_size, self._world._NS)
+
+
+class BatchAttentionState(object):
+    """LSTM (h, c) state of the attention-calibration passes, one row per question (batch_base_types.py:256-310)."""
+
+    def __init__(self, name, device, state, set_zeros=False):
+        self._name = name
+        self._device = device
+        self._state = (torch.zeros_like(state[0]), torch.zeros_like(state[1])) if set_zeros else state
+
+    def to(self, dtype):
+        return self
+
+    @property
+    def dtype(self):
+        return self._state[0].dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def state_size(self):
+        return self._state[0].size()[1]
+
+    def gate(self, attention_state, flag):                     # :279-298
+        if isinstance(flag, torch.Tensor):
+            g = flag.to(torch.float32)
+            host = getattr(flag, "_host", None)
+            if host is None:
+                host = flag.cpu().numpy().tolist()
+        else:
+            host = [0 if f is None else f for f in flag]
+            g = torch.tensor([float(f) for f in host], dtype=torch.float32, device=self._device)
+        g = g.unsqueeze(1)
+        state0 = self._state[0] * g + attention_state._state[0] * (1.0 - g)
+        state1 = self._state[1] * g + attention_state._state[1] * (1.0 - g)
+        names = [x if f > 0 else y for x, y, f in zip(self._name, attention_state._name, host)]
+        return BatchAttentionState(names, self._device, (state0, state1))
+
+    def expand(self, predicate_question_map):                  # mm(pqm, state)  :300-304
+        idx = predicate_question_map.to(torch.int64)
+        return BatchAttentionState(self._name, self._device, (self._state[0][idx], self._state[1][idx]))
+
+    def squeeze(self, predicate_question_map, question_num=None):   # mm(pqm^T, state)  :306-310
+        idx = predicate_question_map.to(torch.int64)
+        Q = int(question_num if question_num is not None else int(idx.max()) + 1)
+        z = lambda s: torch.zeros(Q, s.shape[1], dtype=s.dtype, device=s.device).index_add_(0, idx, s)
+        return BatchAttentionState(self._name, self._device, (z(self._state[0]), z(self._state[1])))

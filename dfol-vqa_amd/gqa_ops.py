@@ -238,7 +238,7 @@ class GQARelateBatch(GQABatchOperatorBase):
                 predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
         x = self._gqa_select(op_id, world, attribute_list, give_answer, predicate_question_map, likelihood_threshold)
         flag, host = _subject_flags(is_subject, world._device)
-        fused = self._forward_fused(world, x, variable_set, relation_list, flag)
+        fused = self._forward_fused(op_id, world, x, variable_set, relation_list, flag)
         if fused is not None:
             return fused
         subject_set = x.gate(variable_set, flag)
@@ -247,12 +247,14 @@ class GQARelateBatch(GQABatchOperatorBase):
         subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, want=want)
         return subject_set.gate(object_set, flag)
 
-    def _forward_fused(self, world, x, prev, relation_list, flag):
+    def _forward_fused(self, op_id, world, x, prev, relation_list, flag):
         """Inference fast path: the three gates and the arity-2 cell in ONE launch (dfol_relate_one_fwd_f32), on tiles the
         oracle prefetched with the summed-out variable along rows.  Same result as the generic route below it."""
         oracle = self._oracle
         if torch.is_grad_enabled() and (x._log_attention.requires_grad or prev._log_attention.requires_grad):
             return None
+        if op_id in self._relate._subject_modulations or op_id in self._relate._object_modulations:
+            return None                                        # calibrated posteriors go through RelateBatch.forward
         if not hasattr(oracle, "oriented_tiles") or x.batch_size() != prev.batch_size() or prev._predicate_question_map is not None:
             return None
         low = getattr(relation_list, "lowered", None)
@@ -540,3 +542,135 @@ class GQACompareBatch(GQABatchOperatorBase):
                 alp.append([float(lp[i, ind[i]])])
         return _result(answer, log_probability.view(-1), options, None, QuestionType.QUERY, x1.cumulative_loss() + x2.cumulative_loss(),
                        x1._prev_variable_sets_num + x2._prev_variable_sets_num + 2, alp)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention-calibration passes: transform_attention of every operator (the LSTM walks the program forward and
+# backward before it is executed; reference batch_gqa_ops.py, the `transform_attention` method of each class)
+# ---------------------------------------------------------------------------------------------------
+def _select_ta(self, op_id, is_forward, world, attention_state, attribute_list, op_feature, predicate_question_map=None):      # :185-203
+    name, att = _select_names(attribute_list, world.batch_size())
+    plain = att is None or all(a is None for a in att)
+    if is_forward:
+        x = world.attention_state(name)
+        return x if plain else self._filter.transform_attention(op_id, is_forward, world, x, att, op_feature)
+    return attention_state if plain else self._filter.transform_attention(op_id, is_forward, world, attention_state, att, op_feature)
+
+
+def _filter_ta(self, op_id, is_forward, world, attention_state, attribute_list, op_feature, predicate_question_map=None):       # :337-338
+    return self._filter.transform_attention(op_id, is_forward, world, attention_state, attribute_list, op_feature)
+
+
+def _zero_state(world, attention_state):
+    return world.attention_state(attention_state._name, (torch.zeros_like(attention_state._state[0]), torch.zeros_like(attention_state._state[1])))
+
+
+def _relate_ta(self, op_id, is_forward, world, attention_state, relation_list, is_subject, attribute_list, op_feature,
+               predicate_question_map=None):                                                                                      # :373-390
+    if is_forward:
+        x = self._gqa_select.transform_attention(op_id, is_forward, world, None, attribute_list, op_feature)
+        subject_set = x.gate(attention_state, is_subject)
+        object_set = attention_state.gate(x, is_subject)
+        subject_set, object_set = self._relate.transform_attention(op_id, is_forward, world, subject_set, object_set, relation_list, op_feature)
+        return subject_set.gate(object_set, is_subject)
+    x = _zero_state(world, attention_state)
+    object_set = x.gate(attention_state, is_subject)
+    subject_set = attention_state.gate(x, is_subject)
+    subject_set, object_set = self._relate.transform_attention(op_id, is_forward, world, subject_set, object_set, relation_list, op_feature)
+    self._gqa_select.transform_attention(op_id, is_forward, world, subject_set.gate(object_set, is_subject), attribute_list, op_feature)
+    return object_set.gate(subject_set, is_subject)
+
+
+def _identity_ta(self, op_id, is_forward, world, attention_state, op_feature, predicate_question_map=None):                      # :412-413, :782-783
+    return attention_state
+
+
+def _options_ta(self, op_id, is_forward, world, attention_state, attribute_list_list, op_feature, predicate_question_map=None):  # :230-232, :475-477
+    attribute_list, batch_index = flatten_list(attribute_list_list)
+    return self._filter.transform_attention(op_id, is_forward, world, attention_state, attribute_list, op_feature,
+                                            batch_index if predicate_question_map is None else predicate_question_map)
+
+
+def _query_ta(self, op_id, is_forward, world, attention_state, category_list, op_feature, predicate_question_map=None):          # :308-310
+    lists = [self._ontology.query(c if c not in ['name', 'type'] else n) for c, n in zip(category_list, attention_state._name)]
+    return self._gqa_choose_attr.transform_attention(op_id, is_forward, world, attention_state, lists, op_feature, predicate_question_map)
+
+
+def _verify_rel_ta(self, op_id, is_forward, world, attention_state, relation_list, is_subject, attribute_list, op_feature,
+                   predicate_question_map=None):                                                                                  # :503-504
+    return self._gqa_relate.transform_attention(op_id, is_forward, world, attention_state, relation_list, is_subject, attribute_list, op_feature)
+
+
+def _choose_rel_ta(self, op_id, is_forward, world, attention_state, relation_list_list, is_subject, attribute_list, op_feature,
+                   predicate_question_map=None):                                                                                  # :269-292
+    relation_list, batch_index = flatten_list(relation_list_list)
+    pqm = batch_index if predicate_question_map is None else predicate_question_map
+    host = [0.0 if f is None else float(f) for f in is_subject]
+    pmap = batch_index if predicate_question_map is None else predicate_question_map.to(torch.int64).cpu().tolist()
+    pred_flags = [host[q] for q in pmap]                                         # mm(pqm, is_subject)
+    if is_forward:
+        x = self._gqa_select.transform_attention(op_id, is_forward, world, None, attribute_list, op_feature)
+        subject_state = x.gate(attention_state, is_subject)
+        object_state = attention_state.gate(x, is_subject)
+        subject_state, object_state = self._relate.transform_attention(op_id, is_forward, world, subject_state, object_state, relation_list,
+                                                                       op_feature, pqm)
+        return subject_state.gate(object_state, pred_flags)
+    x = _zero_state(world, attention_state)
+    object_set = x.gate(attention_state, pred_flags)
+    subject_set = attention_state.gate(x, pred_flags)
+    subject_set, object_set = self._relate.transform_attention(op_id, is_forward, world, subject_set, object_set, relation_list, op_feature, pqm)
+    self._gqa_select.transform_attention(op_id, is_forward, world, subject_set.gate(object_set, is_subject), attribute_list, op_feature)
+    return object_set.gate(subject_set, is_subject)
+
+
+def _pair_identity_ta(self, op_id, is_forward, world, attention_state1, attention_state2, op_feature, predicate_question_map=None):   # :536-537
+    return attention_state1, attention_state2
+
+
+def _category_ta(self, op_id, is_forward, world, attention_state, category_list, op_feature, predicate_question_map=None):       # :610-613
+    attribute_list, batch_index = _category_options(self._ontology, category_list, attention_state._name)
+    return self._filter.transform_attention(op_id, is_forward, world, attention_state, attribute_list, op_feature,
+                                            batch_index if predicate_question_map is None else predicate_question_map)
+
+
+def _all_different_ta(self, op_id, is_forward, world, attention_state, category_list, op_feature, predicate_question_map=None):  # :641-642
+    return self._gqa_all_same.transform_attention(op_id, is_forward, world, attention_state, category_list, op_feature, predicate_question_map)
+
+
+def _two_same_ta(self, op_id, is_forward, world, attention_state1, attention_state2, category_list, op_feature, predicate_question_map=None):   # :683-690
+    attribute_list, batch_index = _category_options(self._ontology, category_list, attention_state1._name)
+    pqm = batch_index if predicate_question_map is None else predicate_question_map
+    x1 = self._filter.transform_attention(op_id + ':0', is_forward, world, attention_state1, attribute_list, op_feature, pqm)
+    x2 = self._filter.transform_attention(op_id + ':1', is_forward, world, attention_state2, attribute_list, op_feature, pqm)
+    return x1, x2
+
+
+def _two_different_ta(self, op_id, is_forward, world, attention_state1, attention_state2, category_list, op_feature, predicate_question_map=None):   # :716-717
+    return self._gqa_two_same.transform_attention(op_id, is_forward, world, attention_state1, attention_state2, category_list, op_feature,
+                                                  predicate_question_map)
+
+
+def _compare_ta(self, op_id, is_forward, world, attention_state1, attention_state2, attribute_list, is_less, op_feature,
+                predicate_question_map=None):                                                                                     # :760-764
+    x1 = self._filter.transform_attention(op_id + ':0', is_forward, world, attention_state1, attribute_list, op_feature)
+    x2 = self._filter.transform_attention(op_id + ':1', is_forward, world, attention_state2, attribute_list, op_feature)
+    return x1, x2
+
+
+GQASelectBatch.transform_attention = _select_ta
+GQAFilterBatch.transform_attention = _filter_ta
+GQARelateBatch.transform_attention = _relate_ta
+GQAExistBatch.transform_attention = _identity_ta
+GQAEndBatch.transform_attention = _identity_ta
+GQAVerifyAttrsBatch.transform_attention = _options_ta
+GQAChooseAttrBatch.transform_attention = _options_ta
+GQAQueryAttrBatch.transform_attention = _query_ta
+GQAVerifyRelBatch.transform_attention = _verify_rel_ta
+GQAChooseRelBatch.transform_attention = _choose_rel_ta
+GQAAndBatch.transform_attention = _pair_identity_ta
+GQAOrBatch.transform_attention = _pair_identity_ta
+GQAAllSameBatch.transform_attention = _category_ta
+GQAAllDifferentBatch.transform_attention = _all_different_ta
+GQATwoSameBatch.transform_attention = _two_same_ta
+GQATwoDifferentBatch.transform_attention = _two_different_ta
+GQACompareBatch.transform_attention = _compare_ta

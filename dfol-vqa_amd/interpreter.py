@@ -10,7 +10,8 @@ import torch.nn as nn
 
 from . import ops as L
 from . import gqa_ops as gqa
-from .fol_types import BatchVariableSet, BatchWorld, QuestionType
+from .fol_types import BatchAttentionState, BatchVariableSet, BatchWorld, QuestionType
+from .host_util import reverse_dependencies
 
 
 def gather_results(outputs, target_device=None, is_cuda=True):
@@ -124,7 +125,7 @@ class BatchInterpreterBase(nn.Module):
             world = self.build_scene(program_batch.device, program_batch._object_features, program_batch._object_batch_index,
                                      program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None))
             if self._has_modulator and modulator_switch:
-                raise NotImplementedError("attention-calibration passes (:87-140) are SURVEY.md §8(f) rank 2: not built yet")
+                self._calibration_passes(world, program_batch, device, is_training)
             if world._lazy is not None:
                 self._oracle.prefetch_relations(world, program_batch)
             ops = program_batch._op_batch_list
@@ -142,6 +143,45 @@ class BatchInterpreterBase(nn.Module):
             all_traces.append(trace)
         result = gather_results(all_results, device, True)
         return (result, all_traces) if return_trace else result
+
+
+def _calibration_passes(self, world, program_batch, device, is_training):
+    """The LSTM walks the aligned program forward (batch_base_interpreter.py:92-111) and backward (:113-140); each operator
+    leaves its [P, 4] modulations in its own dictionary, keyed by op id, for the execution loop to apply."""
+    ops, deps_all = program_batch._op_batch_list, program_batch._dependencies
+    last = len(ops) - 1
+    trace = []
+    for i, op_batch in enumerate(ops):
+        deps = deps_all[i]
+        input_tuple = tuple(trace[d] for d in deps) if deps else (None,)
+        x, _ = self._transform_attention(op_batch._op_id, True, world, op_batch, input_tuple, i == last, is_training)
+        if i < last and input_tuple[0] is not None and op_batch._mask is not None:
+            x = x.gate(input_tuple[0], op_batch._mask)
+        trace.append(x)
+    reversed_dependencies = reverse_dependencies(deps_all)
+    final = trace[-1]
+    if isinstance(final, (tuple, list)):
+        first_state = tuple(BatchAttentionState(a._name, device, a._state, set_zeros=True) for a in final)
+    else:
+        first_state = (BatchAttentionState(final._name, device, final._state, set_zeros=True),)
+    trace = [None] * len(ops)
+    for i in reversed(range(len(ops))):
+        op_batch = ops[i]
+        if len(reversed_dependencies[i]) == 1:
+            temp = trace[reversed_dependencies[i][0]]
+            if isinstance(temp, (tuple, list)):
+                input_tuple = (temp[1],) if i == len(ops) - 2 else (temp[0],)
+            else:
+                input_tuple = (temp,)
+        else:
+            input_tuple = first_state
+        x, _ = self._transform_attention(op_batch._op_id, False, world, op_batch, input_tuple, i == 0, is_training)
+        if len(deps_all[i]) > 0 and op_batch._mask is not None and isinstance(x, BatchAttentionState) and i != last:
+            x = x.gate(input_tuple[0], op_batch._mask)
+        trace[i] = x
+
+
+BatchInterpreterBase._calibration_passes = _calibration_passes
 
 
 class BatchGQAInterpreter(BatchInterpreterBase):
@@ -172,6 +212,18 @@ class BatchGQAInterpreter(BatchInterpreterBase):
             'two_same': gqa.GQATwoSameBatch(o, t, **kw), 'two_different': gqa.GQATwoDifferentBatch(o, t, **kw),
             'compare': gqa.GQACompareBatch(o, t, **kw), 'end': gqa.GQAEndBatch(o, t),
         })
+
+    # one-hot position of every operator in the LSTM input (batch_gqa_interpreter.py:67-70)
+    _OPS_INDEX = {'all_different': 0, 'all_same': 1, 'and': 2, 'choose_attr': 3, 'choose_rel': 4, 'compare': 5, 'end': 6, 'exist': 7,
+                  'filter': 8, 'or': 9, 'query_attr': 10, 'relate': 11, 'select': 12, 'two_different': 13, 'two_same': 14,
+                  'verify_attrs': 15, 'verify_rel': 16}
+
+    def _transform_attention(self, op_id, is_forward, world, operator_batch, input_tuple, is_terminal, is_training):   # :80-86
+        temp = torch.zeros(len(self._OPS_INDEX), dtype=torch.float32, device=world._device)
+        temp[self._OPS_INDEX[operator_batch._op_name]] = 1.0
+        x = self._ops[operator_batch._op_name].transform_attention(*((op_id, is_forward, world) + input_tuple + tuple(operator_batch._arguments) +
+                                                                     (temp, operator_batch._predicate_question_map)))
+        return x, is_terminal
 
     def _execute(self, op_id, world, operator_batch, input_tuple, is_terminal, is_training):
         op = self._ops[operator_batch._op_name]

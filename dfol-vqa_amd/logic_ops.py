@@ -9,8 +9,8 @@ import torch
 import torch.nn as nn
 
 from . import ops as L
-from .fol_types import BatchVariableSet, Quantifier, TokenType
-from .host_util import get_lowered
+from .fol_types import BatchAttentionState, BatchVariableSet, Quantifier, TokenType
+from .host_util import detect_negations, get_lowered, is_valid_token
 
 
 class BatchBayesianLogicCell(nn.Module):
@@ -69,8 +69,10 @@ class BatchOperatorBase(nn.Module):
         self._is_terminal = is_terminal
         self._fan_in = fan_in
         self._fan_out = fan_out
-        if forward_attention_network is not None or backward_attention_network is not None or attention_output_network is not None:
-            raise NotImplementedError("attention calibration networks are SURVEY.md §8(f) rank 2: not built yet")
+        if forward_attention_network is not None and backward_attention_network is not None and attention_output_network is not None:
+            self._forward_attention_network = forward_attention_network          # shared by every operator (:251-254)
+            self._backward_attention_network = backward_attention_network
+            self._attention_output_network = attention_output_network
 
     def is_terminal(self):
         return self._is_terminal
@@ -80,6 +82,31 @@ class BatchOperatorBase(nn.Module):
 
     def fan_out(self):
         return self._fan_out
+
+    def _get_features(self, world, token_list, op_features):                    # :265-273
+        result = self._oracle.get_embedding(token_list, world._meta_data, world._device)
+        if result.dim() < 2:
+            result = result.unsqueeze(0)
+        temp = op_features.repeat(len(token_list), 1) if len(token_list) > 1 else op_features.unsqueeze(0)
+        return torch.cat([temp, result], dim=1)
+
+    def _token_features(self, world, tokens, op_feature, type_flag):
+        """LSTM input rows [op one-hot, type flag, token embedding]; zero rows for no-op tokens (:437-446, :628-637)."""
+        ind = [is_valid_token(v) for v in tokens]
+        kept = [t for t, k in zip(tokens, ind) if k]
+        _, _, names = detect_negations(kept)
+        flag = torch.full((1,), float(type_flag), dtype=torch.float32, device=world._device)
+        feats = self._get_features(world, names, torch.cat([op_feature, flag], dim=0))
+        if all(ind):
+            return feats
+        full = torch.zeros(len(tokens), feats.shape[1], dtype=torch.float32, device=world._device)
+        full[torch.tensor(ind, dtype=torch.bool, device=world._device)] = feats
+        return full
+
+    def _compute_attention_modulations(self, forward_state, backward_state):    # :275-286
+        fs = torch.zeros_like(backward_state[0]) if forward_state is None else forward_state[0]
+        bs = torch.zeros_like(forward_state[0]) if backward_state is None else backward_state[0]
+        return self._attention_output_network(torch.cat([fs, bs], dim=1))
 
 
 class SelectBatch(BatchOperatorBase):
@@ -151,6 +178,32 @@ class FilterBatch(BatchOperatorBase):
         return res
 
 
+def _filter_transform_attention(self, op_id, is_forward, world, attention_state, attribute_list, op_feature, predicate_question_map=None):
+    """FilterBatch.transform_attention, batch_base_ops.py:407-467."""
+    if not isinstance(attribute_list, list):
+        attribute_list = [attribute_list]
+    if not any(is_valid_token(v) for v in attribute_list):
+        return attention_state
+    question_num, predicate_num = world.batch_size(), len(attribute_list)
+    host_map = _host_map(predicate_question_map, predicate_num)
+    assert question_num == predicate_num or (host_map is not None and len(host_map) == predicate_num), "Batch size mismatch."
+    pred_q = None if host_map is None else world.pred_q(predicate_question_map)
+    features = self._token_features(world, attribute_list, op_feature, 0.0)
+    if is_forward:
+        old = attention_state.expand(pred_q) if pred_q is not None else attention_state
+        new_state_tuple = self._forward_attention_network(features, old._state)
+        self._forward_state[op_id] = new_state_tuple
+        return BatchAttentionState(attention_state._name, world._device, new_state_tuple)
+    if op_id[-1] != 'n':
+        self._modulations[op_id] = self._compute_attention_modulations(self._forward_state[op_id], attention_state._state)
+    self._forward_state.pop(op_id, None)
+    new_state = BatchAttentionState(attention_state._name, world._device, self._backward_attention_network(features, attention_state._state))
+    return new_state.squeeze(pred_q, question_num) if pred_q is not None else new_state
+
+
+FilterBatch.transform_attention = _filter_transform_attention
+
+
 class RelateBatch(BatchOperatorBase):
     """batch_base_ops.py:471-596.  `need` = (subject, object) lets a caller that only consumes one
     posterior (GQARelateBatch keeps exactly one, batch_gqa_ops.py:371) skip the other direction."""
@@ -203,3 +256,41 @@ class RelateBatch(BatchOperatorBase):
         if op_id in self._object_modulations:
             new_object_set = new_object_set.apply_modulations(self._object_modulations.pop(op_id), object_variable_set, predicate_question_map)
         return new_subject_set, new_object_set
+
+
+def _relate_transform_attention(self, op_id, is_forward, world, subject_attention_state, object_attention_state, relation_list, op_feature,
+                                predicate_question_map=None):
+    """RelateBatch.transform_attention, batch_base_ops.py:598-684."""
+    if not isinstance(relation_list, list):
+        relation_list = [relation_list]
+    if not any(is_valid_token(v) for v in relation_list):
+        return subject_attention_state, object_attention_state
+    question_num, predicate_num = world.batch_size(), len(relation_list)
+    host_map = _host_map(predicate_question_map, predicate_num)
+    assert question_num == predicate_num or (host_map is not None and len(host_map) == predicate_num), "Batch size mismatch."
+    pred_q = None if host_map is None else world.pred_q(predicate_question_map)
+    features = self._token_features(world, relation_list, op_feature, 1.0)
+    dev = world._device
+    if is_forward:
+        s_old = subject_attention_state.expand(pred_q) if pred_q is not None else subject_attention_state
+        o_old = object_attention_state.expand(pred_q) if pred_q is not None else object_attention_state
+        new = self._forward_attention_network(features, (s_old._state[0] + o_old._state[0], s_old._state[1] + o_old._state[1]))
+        copy = (new[0].clone(), new[1].clone())
+        self._forward_subject_state[op_id] = new
+        self._forward_object_state[op_id] = copy
+        return BatchAttentionState(subject_attention_state._name, dev, new), BatchAttentionState(object_attention_state._name, dev, copy)
+    if op_id[-1] != 'n':
+        self._subject_modulations[op_id] = self._compute_attention_modulations(self._forward_subject_state[op_id], subject_attention_state._state)
+        self._object_modulations[op_id] = self._compute_attention_modulations(self._forward_object_state[op_id], object_attention_state._state)
+    self._forward_subject_state.pop(op_id, None)
+    self._forward_object_state.pop(op_id, None)
+    agg = (subject_attention_state._state[0] + object_attention_state._state[0], subject_attention_state._state[1] + object_attention_state._state[1])
+    new = self._backward_attention_network(features, agg)
+    new_s = BatchAttentionState(subject_attention_state._name, dev, new)
+    new_o = BatchAttentionState(object_attention_state._name, dev, (new[0].clone(), new[1].clone()))
+    if pred_q is not None:
+        new_s, new_o = new_s.squeeze(pred_q, question_num), new_o.squeeze(pred_q, question_num)
+    return new_s, new_o
+
+
+RelateBatch.transform_attention = _relate_transform_attention

@@ -363,3 +363,36 @@ def pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs, pair_index=None):
         ind_s, ind_o = pair_index()
         return _PairFeatures.apply(obj, D, obj_off, pair_off, Q, max_n, pairs, ind_s, ind_o)
     return _lib.pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs)
+
+
+def _modulate_reference(att, mods, valid):
+    """apply_modulations (batch_base_types.py:170-179) in tensor ops; used for the backward of the HIP kernel."""
+    alpha, beta, c, d = (mods[:, k].unsqueeze(1) * (10.0 if k < 3 else 1.0) for k in range(4))
+    slog = lambda x: torch.log(x.clamp_min(_EPS))
+    t = alpha * att + slog(c) + slog(d)
+    u = beta * slog(1 - torch.exp(att)) + slog(1 - d)
+    return torch.where(valid, t - slog(torch.exp(u) + torch.exp(t)), torch.zeros_like(att))
+
+
+class _Modulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att, mods, pred_q, n_obj):
+        ctx.save_for_backward(att, mods, pred_q, n_obj)
+        return _lib.modulate(att, mods.contiguous(), pred_q, n_obj)
+
+    @staticmethod
+    def backward(ctx, g):
+        att, mods, pred_q, n_obj = ctx.saved_tensors
+        valid = torch.arange(att.shape[1], device=att.device).unsqueeze(0) < n_obj.to(torch.int64)[pred_q.to(torch.int64)].unsqueeze(1)
+        with torch.enable_grad():
+            a = att.detach().requires_grad_(True)
+            m = mods.detach().requires_grad_(True)
+            out = _modulate_reference(a, m, valid)
+            ga, gm = torch.autograd.grad(out, (a, m), g, allow_unused=True)
+        return ga, gm, None, None
+
+
+def modulate(att, mods, pred_q, n_obj):
+    if _needs_grad(att, mods):
+        return _Modulate.apply(att, mods, pred_q, n_obj)
+    return _lib.modulate(att, mods.contiguous(), pred_q, n_obj)

@@ -201,6 +201,14 @@ int dfol_box_positions_f32(const float* raw, int64_t ld_raw, int32_t raw_cols, i
 int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t D, const int32_t* obj_off, const int64_t* pair_off,
                            int32_t Q, int32_t max_n, float* pair, int64_t ld_pair, void* stream);
 
+/* Attention calibration: replaces BatchVariableSet.apply_modulations, batch_base_types.py:170-179, for the 4-column
+ * modulations the reference's attention_output_network emits (gqa_interpreter_experiments.py:119-132):
+ *   alpha = 10 m0, beta = 10 m1, c = 10 m2, d = m3;  t = alpha a + slog(c) + slog(d);
+ *   out = t - slog(exp(beta * log_not(a) + slog(1 - d)) + exp(t))          att, out [P, NS]; mods [P, 4]
+ */
+int dfol_modulate_f32(const float* att, const float* mods, const int32_t* pred_q, const int32_t* n_obj, int32_t P, int32_t NS,
+                      float* out, void* stream);
+
 /* ---- needed-columns oracle (MI355X-first: nothing the program does not ask for is computed) --------
  * The reference evaluates the embedding layer for all 2335 concepts on every object and every ordered
  * object pair (classifier_oracle.py:145-156; 64 % of its CPU time) and then gathers a

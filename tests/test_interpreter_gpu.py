@@ -333,3 +333,44 @@ def test_needed_columns_full_size_model(tmp_path):
     for res, tag in ((res_needed, "needed"), (res_full, "full")):
         gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "fullsize:" + tag)
     assert res_needed["answer"] == res_full["answer"] == r64["answer"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention calibration: LSTM passes + apply_modulations against the reference (g10)
+# ---------------------------------------------------------------------------------------------------
+class CalibrationCollater(TableCollater):
+    def __init__(self, ontology):
+        super(CalibrationCollater, self).__init__(1, ontology, "X")
+        self._ont = ontology
+
+    def collate_meta_data(self, questions):
+        names = list(self._ont._vocabulary["idx_to_arg"])
+        return {"index": {t: i for i, t in enumerate(names)}, "embedding": torch.from_numpy(self._ont.get_embeddings(names)).float()}
+
+
+@pytest.mark.parametrize("name", ["exist", "verify_attrs", "choose_attr", "query_attr", "verify_rel", "choose_rel", "and", "two_same",
+                                  "all_same", "compare"])
+def test_g10_attention_calibration(ontology, name):
+    a, meta = gu.load("g10_calibration")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights)
+    assert model._has_modulator
+    run_meta = meta["runs"][name]
+    qs = []
+    for i, q in enumerate(run_meta["questions"]):
+        qs.append({"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+                   "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}})
+    pbs = CalibrationCollater(ontology).collate(qs)
+    for pb in pbs:
+        pb.create_sparse_tensors()
+    pbs = [pb.to_cuda(DEV) for pb in pbs]
+    with torch.no_grad():
+        res = model(pbs, False, modulator_switch=True)
+        res_off = model(pbs, False, modulator_switch=False)
+    gu.check_logprob(res_off["log_probability"].cpu().numpy(), a[name + ":lp_off_f32"], a[name + ":lp_off_f64"], name + " (switch off)")
+    gu.check_logprob(res["log_probability"].cpu().numpy(), a[name + ":lp_f32"], a[name + ":lp_f64"], name + " (calibrated)")
+    assert res["answer"] == run_meta["answer"]
+    # no modulation may be left behind for the next batch
+    for mod in model.modules():
+        for attr in ("_modulations", "_subject_modulations", "_object_modulations", "_forward_state", "_forward_subject_state", "_forward_object_state"):
+            assert not getattr(mod, attr, None), (type(mod).__name__, attr)

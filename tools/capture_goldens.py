@@ -641,8 +641,85 @@ def g9():
     save("g9_program_bytecode", arrays, meta)
 
 
+# ---------------------------------------------------------------------------------------- g10
+def g10():
+    """Attention calibration on (activate_attention_transfer): LSTM forward/backward passes + apply_modulations
+    (batch_base_interpreter.py:87-140, batch_base_ops.py:407-467,598-684, batch_base_types.py:170-187), reduced dims."""
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_interpreter_experiments as gie
+    cfg = dict(box_features_dim=32, oracle_input_dim=16, oracle_output_dim=1, word_embedding_dim=mini_ontology.EMBEDDING_DIM,
+               classifier_oracle=True, featurizer_layers_config=[], attribute_network_layers_config=[8],
+               relation_network_layers_config=[8], operator_layers_config=[], normalize_oracle=True, dropout=0.0,
+               freeze_featurizer=True, freeze_attribute_network=True, freeze_relation_network=True,
+               freeze_embedding_network=True, activate_attention_transfer=True, attention_transfer_state_dim=6,
+               freeze_attention_network=False, trainable_gate=False, likelihood_threshold=0, hard_mode=False,
+               verbose=False, model_name="g10", gpu_num=1)
+    exp = gie.GQAObjectBoxExperiment()
+    exp._local_rank = 0
+    torch.manual_seed(3)
+    model = exp.build_model(cfg, ontology, None)
+    out_net = model._ops["select"]._filter._attention_output_network
+    with torch.no_grad():
+        out_net[0].weight.normal_(0.0, 0.8)               # the reference starts it at zero; make the modulations state-dependent
+    model.eval()
+    arrays, meta = {}, {"source": "batch_base_interpreter.py:87-140; batch_base_ops.py:407-467,598-684; batch_base_types.py:170-187",
+                        "config": cfg, "runs": {}}
+    pre = "_ops.select._filter."
+    for k, v in model.state_dict().items():
+        if k.startswith("_featurizer.") or k.startswith("_oracle.") or (k.startswith(pre) and "attention" in k):
+            arrays["w:" + k] = v.numpy()
+    Q = syn.question
+    n_of = lambda i: [5, 7, 3, 6][i % 4]
+
+    def mk(i, branches, last, answer="yes"):
+        return Q(900 + i, branches, last, answer, syn.feature_scene(900 + i, n_of(i), cfg["box_features_dim"]))
+
+    two = lambda i, last: mk(i, [[op("select", "dog"), op("filter", "red")], [op("select", "cat"), op("relate", "near", bool(i % 2), "table")]], last)
+    runs = {
+        "exist": [mk(0, [[op("select", "dog")]], op("exist")),
+                  mk(1, [[op("select", "cat"), op("filter", "not(red)"), op("relate", "on", True, "table")]], op("exist")),
+                  mk(2, [[op("select", "_"), op("relate", "to the left of", False, "car"), op("filter", "small"), op("relate", "near", True, "_")]], op("exist"))],
+        "verify_attrs": [mk(3, [[op("select", "dog"), op("filter", "small")]], op("verify_attrs", ["red", "large"])),
+                         mk(4, [[op("select", "cup")]], op("verify_attrs", ["glass"]))],
+        "choose_attr": [mk(5, [[op("select", "dog")]], op("choose_attr", ["red", "blue"]), "red"),
+                        mk(6, [[op("select", "table"), op("filter", "wood")]], op("choose_attr", ["small", "large"]), "large")],
+        "query_attr": [mk(7, [[op("select", "dog")]], op("query_attr", "color"), "black"),
+                       mk(8, [[op("select", "animal"), op("filter", "small")]], op("query_attr", "name"), "cat")],
+        "verify_rel": [mk(9, [[op("select", "dog")]], op("verify_rel", "on", True, "couch")),
+                       mk(10, [[op("select", "man"), op("filter", "standing")]], op("verify_rel", "to the right of", False, "bus"))],
+        "choose_rel": [mk(11, [[op("select", "dog")]], op("choose_rel", ["to the left of", "to the right of"], True, "cat"), "to the left of"),
+                       mk(12, [[op("select", "woman"), op("filter", "large")]], op("choose_rel", ["on", "under"], False, "table"), "on")],
+        "and": [two(13, op("and")), two(14, op("and"))],
+        "two_same": [two(15, op("two_same", "color")), two(16, op("two_same", "size"))],
+        "all_same": [mk(17, [[op("select", "dog")]], op("all_same", "color")), mk(18, [[op("select", "furniture"), op("filter", "wood")]], op("all_same", "name"))],
+        "compare": [two(19, op("compare", "large", False)), two(20, op("compare", "red", True))],
+    }
+    for name, qs in runs.items():
+        for i, q in enumerate(qs):
+            arrays["%s:X_%d" % (name, i)] = q["scene"]["X"]
+        entry = {"questions": questions_to_meta(qs)}
+        for dt, tag in both_dtypes():
+            m = copy.deepcopy(model).double() if dt == torch.float64 else model
+            collater = ref_harness.make_collater(ref, 1, "feature", ontology)
+            pbs = collater.collate(copy.deepcopy(qs))
+            for pb in pbs:
+                pb.create_sparse_tensors()
+                if dt == torch.float64:
+                    pb.to(torch.float64)
+                    pb._object_batch_index = pb._object_batch_index.long()
+            with torch.no_grad():
+                res = m(pbs, False, return_trace=False, modulator_switch=True)
+                res_off = m(pbs, False, return_trace=False, modulator_switch=False)
+            arrays["%s:lp_%s" % (name, tag)] = res["log_probability"].numpy()
+            arrays["%s:lp_off_%s" % (name, tag)] = res_off["log_probability"].numpy()
+            if tag == "f32":
+                entry["answer"], entry["type"] = res["answer"], int(res["type"])
+        meta["runs"][name] = entry
+    save("g10_calibration", arrays, meta)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()
 

@@ -62,7 +62,7 @@ def build_table_interpreter(ref, ontology, normalize=True):
     return model
 
 
-def make_collater(ref, split_num=1, mode="table"):
+def make_collater(ref, split_num=1, mode="table", ontology=None):
     import torch
 
     class Collater(ref.data_pipeline.ProgramCollaterBase):
@@ -76,6 +76,9 @@ def make_collater(ref, split_num=1, mode="table"):
 
         def collate_meta_data(self, questions):
             md = {"index": {}, "embedding": torch.zeros(1, 1)}
+            if ontology is not None:       # token embeddings for the calibration LSTMs (batch_gqa_boxfeatures_pipeline.py:88-92)
+                names = list(ontology._vocabulary["idx_to_arg"])
+                md = {"index": {t: i for i, t in enumerate(names)}, "embedding": torch.from_numpy(ontology.get_embeddings(names)).float()}
             if mode == "table":
                 md["R"] = torch.cat([torch.as_tensor(q["scene"]["R"]) for q in questions], 0)
             return md

@@ -97,9 +97,12 @@ class BatchInterpreterBase(nn.Module):
             raise NotImplementedError("a featurizer is required (the reference's featurizer-less branch :62-67 is dead code)")
         geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
                               attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums)
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        needed = self._cached and not training and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
-            getattr(self._oracle, "supports_needed_columns", lambda: False)()   # the fused kernels are forward-only
+        # the fused needed-columns kernels are forward-only: they are used whenever no gradient has to reach the oracle's
+        # or the featurizer's weights (inference, and the calibrator-only phases cur6-7 where both are frozen)
+        oracle_trains = torch.is_grad_enabled() and any(p.requires_grad for m in (self._oracle, self._featurizer)
+                                                        if isinstance(m, nn.Module) for p in m.parameters())
+        needed = self._cached and not oracle_trains and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
+            getattr(self._oracle, "supports_needed_columns", lambda: False)()
         if needed:
             # needed-columns mode: no pair matrix, no full tables; the oracle keeps hidden activations instead
             features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=None)

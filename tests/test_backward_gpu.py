@@ -164,3 +164,28 @@ def test_train_step_changes_parameters_and_lowers_loss(ontology):
     assert len(changed) >= 6, changed
     assert losses[-1] < losses[0], losses
     assert all(np.isfinite(l) for l in losses)
+
+
+def test_calibrator_phase_train_step(ontology):
+    """cur6-7 style: oracle frozen, only the attention-calibration networks train; the forward runs on the fused
+    needed-columns kernels and the gradient reaches the LSTMs through the modulate op."""
+    from test_interpreter_gpu import CalibrationCollater
+    a, meta = gu.load("g10_calibration")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights).train()
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert trainable and all("attention" in n for n in trainable), trainable
+    run_meta = meta["runs"]["exist"]
+    qs = [{"program": q["program"], "answer": "yes" if i % 2 else "no", "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+           "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["exist:X_%d" % i]}} for i, q in enumerate(run_meta["questions"])]
+    pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ontology).collate(qs)]
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-2)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    losses = []
+    for _ in range(6):
+        loss, _ = training.train_batch(model, opt, pbs, clip_norm=0.65)
+        losses.append(loss)
+    after = model.state_dict()
+    moved = {k for k in after if not torch.equal(after[k], before[k])}
+    assert moved and all("attention" in k for k in moved), sorted(moved)[:5]
+    assert losses[-1] < losses[0] and all(np.isfinite(l) for l in losses), losses

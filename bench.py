@@ -187,6 +187,7 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": ach / HBM_PEAK, "traffic": None}
         out["kernels"] = stress_kernels(L, device, args.stress_preds, 100)
+        attach_traffic(out, args)
         sample = args.cpu_sample if args.cpu_sample is not None else (8 if args.objects > 64 else 32)
         if sample > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs[:sample], res, sample)
@@ -194,6 +195,33 @@ def main():
     if dist:
         td.barrier()
         td.destroy_process_group()
+
+
+def attach_traffic(out, args):
+    """HBM traffic per launch from the committed rocprofv3 counter passes of THIS command (profiles/traffic.json, written by
+    tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  Left null when no profile of the same shape is on disk."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return
+    with open(path) as f:
+        t = json.load(f)
+
+    def total(prefix, grid=None):
+        for key, v in t.items():
+            name, gx = key.rsplit("@", 1)
+            if name.startswith(prefix) and (grid is None or int(gx) == grid) and "fetch_bytes_x2" in v and "write_bytes" in v:
+                return v["fetch_bytes_x2"] + v["write_bytes"]
+        return None
+
+    if "pair_ll" in out["roofline"]["kernel"] and args.objects == 100 and args.batch == 256:
+        out["roofline"]["traffic"] = total("pair_ll16_kernel")
+        out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
+    P = args.stress_preds
+    for k in out["kernels"]:
+        pref = "relate_one_fwd_kernel" if k["kernel"].startswith("relate_one") else "relate_fwd_kernel" if k["kernel"].startswith("relate_fwd") \
+            else "filter_fwd_kernel"
+        k["traffic"] = total(pref, (P // 4) * 256 if "relate" in pref else P * 64) if P == 65536 else None
 
 
 def stress_kernels(L, device, P, N):

@@ -61,3 +61,39 @@ def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group
     nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return float(loss.detach()) * b, result
+
+
+# ---- evaluation metrics (trainer.py:64-86, 264-318, 477-485) ---------------------------------------------
+OP_INDEX = {'query_attr': 1, 'choose_attr': 2, 'verify_attrs': 3, 'choose_rel': 4, 'verify_rel': 5, 'exist': 6, 'and': 7, 'or': 8,
+            'all_same': 9, 'all_different': 10, 'two_same': 11, 'two_different': 12, 'compare': 13, 'object_attr': 14, 'object_rel': 15,
+            'scene': 16}
+ERROR_DIM = len(OP_INDEX) + 1
+
+
+def compute_evaluation_metrics(program_batch_list, prediction, first_answer=False):
+    """Error rate of a batch (trainer.py:264-318): a QUERY answer set scores 1/|set| when it contains the gold answer."""
+    import numpy as np
+    answers = [a for pb in program_batch_list for a in pb._answers]
+    if first_answer:
+        match = [a in op[0] if len(op) > 0 else False for a, op in zip(answers, prediction['answer'])]
+    elif prediction['type'] == QuestionType.QUERY:
+        match = [float(any(a in o for o in op)) / float(len(op)) if len(op) > 0 else 0 for a, op in zip(answers, prediction['answer'])]
+    else:
+        match = [any(a in o for o in op) if len(op) > 0 else False for a, op in zip(answers, prediction['answer'])]
+    return 1.0 - float(np.mean(np.array(match, dtype=np.float32)))
+
+
+def accumulate_test_batch(error, total_example_num, data, prediction, first_answer=False):
+    """trainer.py:477-485: overall error in slot 0, per-terminal-operator error in the operator's slot."""
+    b = sum(d.batch_size() for d in data)
+    err = b * compute_evaluation_metrics(data, prediction, first_answer)
+    slot = OP_INDEX[data[0]._op_batch_list[-1]._op_name]
+    error[0] += err
+    error[slot] += err
+    total_example_num[0] += b
+    total_example_num[slot] += b
+    return error, total_example_num
+
+
+def metric_dict(error):                                  # trainer.py:85-86
+    return dict(zip(['over_all'] + list(OP_INDEX.keys()), [float(x) for x in error]))

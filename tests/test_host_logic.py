@@ -132,3 +132,25 @@ def test_find_max_ind_matches_oracle():
     lp[4] = lp[3]
     pq = np.array([0, 0, 1, 1, 1, 2, 2, 2, 2])
     assert hu.find_max_ind(lp, pq, 3).tolist() == orc.find_max_ind(lp, pq, 3).tolist()
+
+
+def test_evaluation_metrics():
+    from dfol_vqa_amd import training
+    pb = type("PB", (), {})()
+    pb._answers = ["yes", "no", "yes", "no"]
+    pb.batch_size = lambda: 4
+    pb._op_batch_list = [type("OB", (), {"_op_name": "exist"})()]
+    pred = {"type": D.QuestionType.BINARY, "answer": [["yes"], ["yes"], ["no"], ["no"]]}
+    assert training.compute_evaluation_metrics([pb], pred) == 0.5
+    pq = type("PB", (), {})()
+    pq._answers = ["red", "blue", "small"]
+    pq.batch_size = lambda: 3
+    pq._op_batch_list = [type("OB", (), {"_op_name": "query_attr"})()]
+    predq = {"type": D.QuestionType.QUERY, "answer": [["red"], ["red", "blue"], []]}
+    assert abs(training.compute_evaluation_metrics([pq], predq) - (1 - (1 + 0.5 + 0) / 3)) < 1e-6
+    assert abs(training.compute_evaluation_metrics([pq], predq, first_answer=True) - (1 - 1 / 3)) < 1e-6
+    err, tot = np.zeros(training.ERROR_DIM, np.float32), np.zeros(training.ERROR_DIM, np.float32)
+    training.accumulate_test_batch(err, tot, [pb], pred)
+    training.accumulate_test_batch(err, tot, [pq], predq)
+    d = training.metric_dict(err / np.maximum(tot, 1))
+    assert abs(d["exist"] - 0.5) < 1e-6 and abs(d["query_attr"] - 0.5) < 1e-6 and abs(d["over_all"] - (2 + 1.5) / 7) < 1e-6

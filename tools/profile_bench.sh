@@ -12,6 +12,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py $AR
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
 cd $R
-python3 tools/summarize_profile.py $OUT > $OUT/summary.md 2>&1
+python3 tools/summarize_profile.py $OUT > $OUT/summary.md 2>&1   # also writes $OUT/traffic.json
 find $OUT -name "*.db" -delete               # the summary has what matters; keep gpurun_out small
 cat $OUT/summary.md

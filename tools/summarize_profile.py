@@ -22,6 +22,7 @@ def short(name):
 
 
 def main(out):
+    traffic = {}
     print("# rocprofv3 summary: %s\n" % os.path.basename(os.path.normpath(out)))
     db = db_of(os.path.join(out, "stats"))
     if db:
@@ -30,6 +31,7 @@ def main(out):
         q = "select name, grid_x, count(*), sum(duration), avg(duration) from kernels group by name, grid_x order by sum(duration) desc limit 24"
         for name, gx, n, tot, avg in db.execute(q):
             print("| %s | %d | %d | %.3f | %.2f |" % (short(name), gx, n, tot / 1e6, avg / 1e3))
+            traffic.setdefault("%s@%d" % (short(name), gx), {})["avg_us"] = avg / 1e3
     for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         db = db_of(os.path.join(out, sub))
         if not db:
@@ -42,6 +44,10 @@ def main(out):
         for name, gx, n, v in db.execute(q, (counter,)):
             mb = v * 1024 / 1e6 * (2 if counter == "FETCH_SIZE" else 1)
             print("| %s | %d | %d | %.1f | %.2f |" % (short(name), gx, n, v, mb))
+            traffic.setdefault("%s@%d" % (short(name), gx), {})["fetch_bytes_x2" if counter == "FETCH_SIZE" else "write_bytes"] = mb * 1e6
+    import json
+    with open(os.path.join(out, "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

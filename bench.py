@@ -231,6 +231,7 @@ def stress_kernels(L, device, P, N):
     u = torch.rand(P, NS, NS, device=device, generator=g)
     tile = torch.log(torch.where(torch.rand(P, NS, NS, device=device, generator=g) < 0.1, 0.5 + 0.5 * u, 0.05 * u).clamp_min(1e-5))
     del u
+    tile.diagonal(dim1=1, dim2=2).fill_(-30.0)              # self-relations hold the absent value, as the oracle writes them
     prior = torch.log(torch.rand(P, NS, device=device, generator=g).clamp_min(1e-3)) * 0.3
     pq = torch.arange(P, dtype=torch.int32, device=device)
     n_obj = torch.full((P,), N, dtype=torch.int32, device=device)
@@ -256,9 +257,9 @@ def stress_kernels(L, device, P, N):
 
     r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones), P * (4 * N * N + 12 * N))
     res.append(dict(r, kernel="relate_one_fwd (fused single-posterior Relate, the interpreter's path)", bytes_per_predicate=4 * N * N + 12 * N))
-    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=False), P * (4 * N * N + 12 * N))
+    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=False, diag_absent=True), P * (4 * N * N + 12 * N))
     res.append(dict(r, kernel="relate_fwd (generic cell, one posterior wanted)", bytes_per_predicate=4 * N * N + 12 * N))
-    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones), P * (4 * N * N + 16 * N))
+    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, diag_absent=True), P * (4 * N * N + 16 * N))
     res.append(dict(r, kernel="relate_fwd (both posteriors, RelateBatch API)", bytes_per_predicate=4 * N * N + 16 * N))
     ll = tile[:, 0, :].contiguous()
     del tile

@@ -15,6 +15,7 @@ _lib = None
 
 TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
 WANT_SUBJECT, WANT_OBJECT = 1, 2
+RELATE_LONE_FORALL_IDENTITY, RELATE_DIAG_ABSENT = 1, 2
 ACT_NONE, ACT_SIGMOID, ACT_ELU, ACT_LOGSIGMOID = 0, 1, 2, 3
 LOGIC_AND, LOGIC_OR, LOGIC_NOT = 0, 1, 2
 
@@ -167,14 +168,15 @@ def filter_fwd(att_in, ll, pred_q, n_obj, neg=None, active=None):
 
 
 def relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg=None, active=None, want=None,
-               orientation=TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True):
+               orientation=TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True, diag_absent=False):
+    """`diag_absent`: the caller guarantees every tile's diagonal holds the absent likelihood (tiles made by the oracle do)."""
     P, NS = tile.shape[0], tile.shape[1]
+    flags = (RELATE_LONE_FORALL_IDENTITY if lone_forall_identity else 0) | (RELATE_DIAG_ABSENT if diag_absent else 0)
     post_s = torch.empty(P, NS, dtype=F32, device=tile.device) if need_s else None
     post_o = torch.empty(P, NS, dtype=F32, device=tile.device) if need_o else None
     call("dfol_relate_fwd_f32", _ptr(prior_s, F32), _ptr(prior_o, F32), _ptr(tile, F32), _ptr(pred_q, I32), _ptr(n_obj, I32),
          _ptr(quant_s, F32), _ptr(quant_o, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True),
-         _ptr(want, U8, True), P, NS, orientation, 1 if lone_forall_identity else 0, _ptr(post_s, F32, True),
-         _ptr(post_o, F32, True), _stream())
+         _ptr(want, U8, True), P, NS, orientation, flags, _ptr(post_s, F32, True), _ptr(post_o, F32, True), _stream())
     return post_s, post_o
 
 

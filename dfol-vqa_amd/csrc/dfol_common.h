@@ -64,4 +64,25 @@ __device__ __forceinline__ float dfol_wave_sum(float v) {
     return v;
 }
 
+// ---- DPP reductions ---------------------------------------------------------------------------------
+// x + (x of the lane selected by the DPP control word); lanes whose source is masked off add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dfol_dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over aligned groups of G consecutive lanes (G = 1..64, power of two) without touching LDS: quad permutes and row
+// mirrors inside each 16-lane row, then row_bcast15 / row_bcast31 across rows.  The total is valid in the LAST lane of
+// each group (for G <= 16 in every lane of the group).
+template <int G>
+__device__ __forceinline__ float dfol_group_sum(float x) {
+    if (G >= 2) x = dfol_dpp_add<0xB1, 0xF>(x);       // quad_perm [1,0,3,2]
+    if (G >= 4) x = dfol_dpp_add<0x4E, 0xF>(x);       // quad_perm [2,3,0,1]
+    if (G >= 8) x = dfol_dpp_add<0x141, 0xF>(x);      // row_half_mirror
+    if (G >= 16) x = dfol_dpp_add<0x140, 0xF>(x);     // row_mirror
+    if (G >= 32) x = dfol_dpp_add<0x142, 0xA>(x);     // row_bcast15 into rows 1 and 3
+    if (G >= 64) x = dfol_dpp_add<0x143, 0xC>(x);     // row_bcast31 into rows 2 and 3
+    return x;
+}
+
 static inline int dfol_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -178,13 +178,111 @@ extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const i
 // cover a row, so 64/LPR rows are in flight per iteration.
 //   post_R[r] = prior_R[r] + F_C( sum_{c != r} F_C(l'[r,c] + prior_C[c]) )      row sums   (cross-lane)
 //   post_C[c] = prior_C[c] + F_R( sum_{r != c} F_R(l'[r,c] + prior_R[r]) )      column sums (in-register)
+// Fast path for un-negated EXISTS/EXISTS predicates whose tile diagonal holds the absent value (DFOL_RELATE_DIAG_ABSENT).
+// With E = e^{l'} and probabilities Pc = e^{prior_C}, Pr = e^{prior_R} the two aggregations are
+//     sum_c log(1 - E[r,c] Pc[c])   and   sum_r log(1 - E[r,c] Pr[r]),
+// so one v_exp serves both directions, and a sum of logs is taken as the log of a product of up to 5 factors: every factor
+// fma(-E, P, 1) is either exactly 0 (E = P = 1, the case the reference clamps to 1e-20) or >= 2^-24, so a product of <= 5
+// non-zero factors stays a normal float.  A zero factor (or a prior above log 1) surfaces as a non-finite sum; the wave then
+// reports failure and the caller redoes the predicate with the clamping general code, which keeps the reference's result.
+// Nothing needs masking: the diagonal's E is e^-30 (factor rounds to exactly 1), padding rows/columns get P = 0.
+template <int LPR> struct RelateUnroll { static constexpr int value = LPR == 64 ? 4 : LPR == 32 ? 5 : LPR == 16 ? 3 : LPR == 8 ? 2 : 1; };
+
+template <int LPR, bool WR, bool WC>
+__device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp, const float* __restrict__ pR,
+                                                   const float* __restrict__ pC, int NS, int n, int lane, float* __restrict__ rsum,
+                                                   float* __restrict__ oR, float* __restrict__ oC) {
+    constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
+    constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    const int cg = lane % LPR, rs = lane / LPR, c0 = cg * 4, cl = min(c0, NS - 4);
+    const float4 pc4 = *reinterpret_cast<const float4*>(pC + cl);
+    const float pcl[4] = {pc4.x, pc4.y, pc4.z, pc4.w};
+    float Pc[4], pmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Pc[j] = (c0 + j < n) ? __builtin_amdgcn_exp2f(pcl[j] * L2E) : 0.f;
+        if (WR) pmax = fmaxf(pmax, Pc[j]);
+    }
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
+        float4 t[UNR];
+        float Pr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
+            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + cl);
+            Pr[u] = 0.f;
+            if (WC) {
+                const float pr = pR[rc];
+                Pr[u] = r < n ? __builtin_amdgcn_exp2f(pr * L2E) : 0.f;
+                pmax = fmaxf(pmax, Pr[u]);
+            }
+        }
+        float cprod[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+            float E[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) E[j] = __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f));    // :194 (the product is canonical: no NaN-quieting op)
+            if (WC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cprod[j] *= fmaf(-E[j], Pr[u], 1.f);
+            }
+            if (WR) {
+                const float rp = (fmaf(-E[0], Pc[0], 1.f) * fmaf(-E[1], Pc[1], 1.f)) * (fmaf(-E[2], Pc[2], 1.f) * fmaf(-E[3], Pc[3], 1.f));
+                const float part = dfol_group_sum<LPR>(__builtin_amdgcn_logf(rp));
+                const int r = r0 + u * RPI + rs;
+                if (cg == LPR - 1 && r < n) rsum[r] = part;
+            }
+        }
+        if (WC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum[j] += __builtin_amdgcn_logf(cprod[j]);
+        }
+    }
+    bool bad = pmax > 1.f;
+    if (WR) {
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < NS; c += 64) {
+            float o = 0.f;
+            if (c < n) {
+                const float s = rsum[c] * LN2;
+                bad |= !(s >= -3.0e38f);
+                o = pR[c] + dfol_pnot(s, 1.f, -1.f);                 // :133, :138
+            }
+            oR[c] = o;
+        }
+    }
+    if (WC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int m = 32; m >= LPR; m >>= 1) csum[j] += __shfl_xor(csum[j], m, 64);
+        }
+        if (rs == 0 && c0 < NS) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s = csum[j] * LN2;
+                const bool colive = c0 + j < n;
+                bad |= colive && !(s >= -3.0e38f);
+                o[j] = colive ? pcl[j] + dfol_pnot(s, 1.f, -1.f) : 0.f;
+            }
+            *reinterpret_cast<float4*>(oC + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    return !__any(bad);
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void relate_fwd_kernel(
     const float* __restrict__ prior_R, const float* __restrict__ prior_C, const float* __restrict__ tile,
     const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_R,
     const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
-    const uint8_t* __restrict__ want, int want_R_bit, int want_C_bit, int P, int NS, int identity_forall,
+    const uint8_t* __restrict__ want, int want_R_bit, int want_C_bit, int P, int NS, int flags,
     float* __restrict__ post_R, float* __restrict__ post_C) {
+    const int identity_forall = flags & DFOL_RELATE_LONE_FORALL_IDENTITY;
     constexpr int RPI = 64 / LPR;                       // rows per iteration
     __shared__ float row_sum[4][256];                   // per-wave row sums, flushed with one coalesced store
     const int wave_in_block = threadIdx.x >> 6;
@@ -223,13 +321,23 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     const float kR = 1.f - 2.f * qR, kC = 1.f - 2.f * qC;
     const bool idR = identity_forall && qR == 0.f, idC = identity_forall && qC == 0.f;
 
+    const float* tp = tile + (int64_t)p * NS * NS;
+    if ((flags & DFOL_RELATE_DIAG_ABSENT) && alpha_n == 0.f && qR == 1.f && qC == 1.f) {
+        float* rsum = row_sum[wave_in_block];
+        const bool ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
+                        : wantR      ? relate_exists_fast<LPR, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
+                        : wantC      ? relate_exists_fast<LPR, false, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
+                                     : true;
+        if (ok) return;
+        __builtin_amdgcn_wave_barrier();
+    }
+
     float pc[4] = {0.f, 0.f, 0.f, 0.f};
     if (c0 < NS) {
         const float4 t = *reinterpret_cast<const float4*>(pC + c0);
         pc[0] = t.x; pc[1] = t.y; pc[2] = t.z; pc[3] = t.w;
     }
     float col_acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* tp = tile + (int64_t)p * NS * NS;
 
     for (int r0 = 0; r0 < n; r0 += RPI) {
         const int r = r0 + rs;
@@ -260,9 +368,8 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
             }
         }
         if (wantR) {
-#pragma unroll
-            for (int m = LPR >> 1; m >= 1; m >>= 1) row_part += __shfl_xor(row_part, m, 64);
-            if (cg == 0 && r < n) row_sum[wave_in_block][r] = row_part;
+            row_part = dfol_group_sum<LPR>(row_part);
+            if (cg == LPR - 1 && r < n) row_sum[wave_in_block][r] = row_part;
         }
     }
     if (wantR) {
@@ -298,17 +405,16 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
 template <int LPR>
 static void launch_relate(hipStream_t st, const float* pR, const float* pC, const float* tile, const int32_t* pred_q,
                           const int32_t* n_obj, const float* qR, const float* qC, const uint8_t* neg, int any_neg,
-                          const uint8_t* active, const uint8_t* want, int wantRbit, int wantCbit, int P, int NS, int idf,
+                          const uint8_t* active, const uint8_t* want, int wantRbit, int wantCbit, int P, int NS, int flags,
                           float* oR, float* oC) {
     hipLaunchKernelGGL(relate_fwd_kernel<LPR>, dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, pR, pC, tile, pred_q, n_obj, qR, qC, neg,
-                       any_neg, active, want, wantRbit, wantCbit, P, NS, idf, oR, oC);
+                       any_neg, active, want, wantRbit, wantCbit, P, NS, flags, oR, oC);
 }
 
 extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q,
                                    const int32_t* n_obj, const float* quant_s, const float* quant_o, const uint8_t* neg,
                                    int32_t any_neg, const uint8_t* active, const uint8_t* want, int32_t P, int32_t NS,
-                                   int32_t orientation, int32_t lone_forall_identity, float* post_s, float* post_o,
-                                   void* stream) {
+                                   int32_t orientation, int32_t flags, float* post_s, float* post_o, void* stream) {
     DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 256, "relate_fwd: bad sizes P=%d NS=%d (NS: multiple of 4, <= 256)", P, NS);
     DFOL_REQUIRE(orientation == 0 || orientation == 1, "relate_fwd: bad orientation %d", orientation);
     if (P == 0) return 0;
@@ -324,8 +430,7 @@ extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, c
     hipStream_t st = (hipStream_t)stream;
     const int groups = NS / 4;
 #define DFOL_RELATE_CASE(L)                                                                                                   \
-    launch_relate<L>(st, pR, pC, tile, pred_q, n_obj, qR, qC, neg, any_neg, active, want, bR, bC, P, NS, lone_forall_identity, \
-                     oR, oC)
+    launch_relate<L>(st, pR, pC, tile, pred_q, n_obj, qR, qC, neg, any_neg, active, want, bR, bC, P, NS, flags, oR, oC)
     if (groups <= 1) DFOL_RELATE_CASE(1);
     else if (groups <= 2) DFOL_RELATE_CASE(2);
     else if (groups <= 4) DFOL_RELATE_CASE(4);
@@ -388,6 +493,38 @@ __device__ __forceinline__ void relate_one_rows(const float* __restrict__ tp, co
     }
 }
 
+// Un-negated EXISTS predicates: sum_r log(1 - E[r,c] Pr[r]) as the log of products of up to 5 factors (see
+// relate_exists_fast for why that is exact enough and how a clamped factor is detected).  Returns the log2-domain sums.
+template <int LPR>
+__device__ __forceinline__ float relate_one_exists_fast(const float* __restrict__ tp, const float* __restrict__ pv, int NS, int n,
+                                                        int cl, int rs, float (&acc)[4]) {
+    constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
+    constexpr float L2E = 1.44269504088896340736f;
+    float pmax = 0.f;
+    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
+        float4 t[UNR];
+        float Pr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
+            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + cl);
+            const float pr = pv[rc];
+            Pr[u] = r < n ? __builtin_amdgcn_exp2f(pr * L2E) : 0.f;
+            pmax = fmaxf(pmax, Pr[u]);
+        }
+        float prod[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prod[j] *= fmaf(-__builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)), Pr[u], 1.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += __builtin_amdgcn_logf(prod[j]);
+    }
+    return pmax;
+}
+
 template <int LPR, int UNR>
 __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
     const float* __restrict__ x_att, const float* __restrict__ prev_att, const float* __restrict__ tile,
@@ -417,6 +554,28 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     constexpr int STEP = RPI * UNR;
     const int n_full = (n / STEP) * STEP;
+    if (!mask) {
+        bool bad = relate_one_exists_fast<LPR>(tp, pv, NS, n, cl, rs, acc) > 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+            bad |= (c0 + j < n) && !(acc[j] >= -3.0e38f);
+        }
+        if (!__any(bad)) {
+            if (rs == 0 && c0 < NS) {
+                const float4 xa = *reinterpret_cast<const float4*>(x_att + (int64_t)p * NS + c0);
+                const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (c0 + j < n) ? xv[j] + dfol_pnot(acc[j] * 0.69314718055994530942f, 1.f, -1.f) : 0.f;
+                *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = 0.f;            // a factor was clamped: redo with the clamping code below
+    }
     if (mask) {
         for (int r0 = 0; r0 < n_full; r0 += STEP)
             relate_one_rows<LPR, UNR, true>(tp, pv, NS, cl, c0, rs, r0, n, false, any_neg, alpha_n, cn, qf, kf, ident, acc);

@@ -242,7 +242,7 @@ class RelateBatch(BatchOperatorBase):
                                              world, default_log_likelihood, normalized_probability)
         ps, po = L.relate_fwd(subject_variable_set._log_attention, object_variable_set._log_attention, tile, pred_q, world._n_obj,
                               q_s, q_o, neg_dev if low.any_neg else None, None if low.all_valid else valid_dev, want,
-                              L.TILE_SUBJECT_ROWS, lone_forall_identity=(predicate_num == 1))
+                              L.TILE_SUBJECT_ROWS, lone_forall_identity=(predicate_num == 1), diag_absent=True)
         n_prev = subject_variable_set._prev_variable_sets_num + object_variable_set._prev_variable_sets_num + 1
         pqm = None if identity else pred_q
         new_subject_set = BatchVariableSet(subject_variable_set._name, dev, subject_variable_set.object_num(), predicate_num,

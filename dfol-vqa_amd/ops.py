@@ -53,8 +53,9 @@ def filter_fwd(att_in, ll, pred_q, n_obj, neg=None, active=None):
 # ---- relate ------------------------------------------------------------------------------------------
 class _Relate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone):
-        ps, po = _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone)
+    def forward(ctx, prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone, diag_absent=False):
+        ps, po = _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone,
+                                 diag_absent=diag_absent)
         e = tile.new_empty(0)
         ctx.save_for_backward(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg if neg is not None else e,
                               active if active is not None else e, want if want is not None else e)
@@ -72,15 +73,16 @@ class _Relate(torch.autograd.Function):
         need_prior = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         g_ps, g_po, g_tile = _lib.relate_bwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg if has_neg else None,
                                              active if has_act else None, gs, go, orientation, lone, need_prior, ctx.needs_input_grad[2])
-        return g_ps, g_po, g_tile, None, None, None, None, None, None, None, None, None
+        return g_ps, g_po, g_tile, None, None, None, None, None, None, None, None, None, None
 
 
 def relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg=None, active=None, want=None,
-               orientation=_lib.TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True):
+               orientation=_lib.TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True, diag_absent=False):
     if _needs_grad(prior_s, prior_o, tile):
-        return _Relate.apply(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity)
+        return _Relate.apply(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity,
+                             diag_absent)
     return _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity,
-                           need_s, need_o)
+                           need_s, need_o, diag_absent)
 
 
 # ---- quantify ----------------------------------------------------------------------------------------

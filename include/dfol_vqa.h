@@ -43,6 +43,8 @@ const char* dfol_last_error(void);
 #define DFOL_TILE_OBJECT_ROWS 1  /* tile[p][o][s]  (transposed) */
 
 /* which posteriors dfol_relate_fwd_f32 must produce, per predicate (bit mask) */
+#define DFOL_RELATE_LONE_FORALL_IDENTITY 1 /* flags of dfol_relate_fwd_f32 */
+#define DFOL_RELATE_DIAG_ABSENT 2
 #define DFOL_WANT_SUBJECT 1
 #define DFOL_WANT_OBJECT 2
 
@@ -120,13 +122,17 @@ int dfol_filter_fwd_f32(const float* att_in, const float* ll, const int32_t* pre
  *   quant_s, quant_o [P]       quantifiers (float 0/1) of the subject / object variable
  *   want             [P]       DFOL_WANT_* bits; an unwanted posterior row is written as zeros.  NULL = both.
  *   post_s, post_o   [P, NS]   out (either may be NULL if no predicate wants it)
- *   lone_forall_identity       1 reproduces the reference's single-predicate literal branch
- *                              (:104-108,:129-133: P == 1 and FOR_ALL leaves the value untouched)
+ *   flags                      DFOL_RELATE_LONE_FORALL_IDENTITY reproduces the reference's single-predicate literal branch
+ *                              (:104-108,:129-133: P == 1 and FOR_ALL leaves the value untouched);
+ *                              DFOL_RELATE_DIAG_ABSENT promises that every tile's diagonal holds the absent likelihood
+ *                              (<= -30, what dfol_rel_gather_f32 / dfol_pair_ll_f32 write and option normalisation
+ *                              leaves alone): un-negated EXISTS/EXISTS predicates then take a path with one exp per
+ *                              element and logs of 5-factor products.  Results are the same either way.
  */
 int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q,
                         const int32_t* n_obj, const float* quant_s, const float* quant_o, const uint8_t* neg,
                         int32_t any_neg, const uint8_t* active, const uint8_t* want, int32_t P, int32_t NS,
-                        int32_t orientation, int32_t lone_forall_identity, float* post_s, float* post_o, void* stream);
+                        int32_t orientation, int32_t flags, float* post_s, float* post_o, void* stream);
 
 /* Relate with ONE posterior: what GQARelateBatch / verify_rel / choose_rel keep (batch_gqa_ops.py:364-371: gate x/prev into
  * subject/object, RelateBatch, gate the wanted posterior back).  Fuses the three gates and the arity-2 cell:
@@ -135,6 +141,8 @@ int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float*
  *   prev_att [Q, NS]  incoming attention of the other variable
  *   tile     [P, NS, NS] with the SUMMED-OUT variable (prev's) along rows: DFOL_TILE_OBJECT_ROWS for is_subject
  *            predicates, DFOL_TILE_SUBJECT_ROWS otherwise (dfol_pair_ll_f32 / dfol_rel_gather_f32 write either)
+ *            The diagonal of every tile must hold the absent likelihood (<= -30), as those two producers write it:
+ *            un-negated EXISTS predicates do not mask self-relations, their factor 1 - e^(-30 + prev) is exactly 1.
  *   active[p] == 0: post[p] = prev_att row (the interpreter's pass-through for questions lacking the operator,
  *            batch_base_interpreter.py:166-167)
  */

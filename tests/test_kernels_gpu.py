@@ -388,3 +388,69 @@ def test_relate_one_equals_generic(L, n_list):
                 continue
             assert np.allclose(got[p, :n], ref[p, :n], rtol=0, atol=2e-5 * max(1.0, np.abs(ref[p, :n]).max())), (p, n)
             assert np.all(got[p, n:] == 0)
+
+
+@pytest.mark.parametrize("n_list", [[5, 1, 8, 3], [36, 20, 33], [100, 37, 64, 2], [130, 256], [17, 9, 2, 12, 16]])
+def test_relate_exists_fast_path(L, n_list):
+    """Un-negated EXISTS/EXISTS predicates on tiles with an absent diagonal take the product path (one exp per element,
+    logs of 5-factor products); it must agree with the oracle, also where a factor is clamped (prior = likelihood = log 1,
+    which sends the wave back to the general code), with garbage in the padding, and with mixed quantifiers in the batch."""
+    rng = np.random.RandomState(sum(n_list) + 11)
+    k_list = [1 + (i % 2) for i in range(len(n_list))]
+    pq, NS, prior_s, prior_o, tile, _ = _logic_inputs(rng, n_list, k_list)
+    P, Q = len(pq), len(n_list)
+    n_obj = np.array(n_list, np.int32)
+    quant = np.ones((P, 2), np.float32)
+    quant[P - 1] = (0.0, 1.0)                                  # one predicate that must not take the fast path
+    # clamped factors: an exactly-certain prior meeting an exactly-certain likelihood
+    q0, n0 = pq[0], n_list[pq[0]]
+    if n0 >= 3:
+        prior_s[q0, 1] = 0.0
+        prior_o[q0, 2] = 0.0
+        tile[0, 1, 2] = 0.0
+    # garbage in the padding of the tiles and priors must not matter
+    for p in range(P):
+        n = n_list[pq[p]]
+        tile[p, n:, :] = np.nan
+        tile[p, :, n:] = 7.0
+    for q, n in enumerate(n_list):
+        prior_s[q, n:] = 0.0
+        prior_o[q, n:] = 3.0
+    neg = np.zeros(P, np.uint8)
+    neg[min(1, P - 1)] = 1
+    for use_neg in (False, True):
+        for want_bits in (3, 1, 2):
+            want = np.full(P, want_bits, np.uint8)
+            for orient in (0, 1):
+                t_in = tile if orient == 0 else np.ascontiguousarray(tile.transpose(0, 2, 1))
+                outs = {}
+                for da in (True, False):
+                    ps, po = L.relate_fwd(dev(prior_s), dev(prior_o), dev(t_in), dev(pq), dev(n_obj), dev(quant[:, 0]), dev(quant[:, 1]),
+                                          dev(neg) if use_neg else None, None, dev(want), orient, diag_absent=da)
+                    outs[da] = (ps.cpu().numpy(), po.cpu().numpy())
+                for p in range(P):
+                    q, n = pq[p], n_list[pq[p]]
+                    if n < 2:
+                        continue
+                    r = [orc.relate_block(prior_s[q, :n].astype(dt), prior_o[q, :n].astype(dt), tile[p, :n, :n].astype(dt),
+                                          quant[p, 0], quant[p, 1], float(neg[p]) if use_neg else 0.0, use_neg)
+                         for dt in (np.float32, np.float64)]
+                    for da in (True, False):
+                        ps, po = outs[da]
+                        if want_bits & 1:
+                            gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "fast relate post_s da=%s" % da, lp_tol=2e-4)
+                            assert np.all(ps[p, n:] == 0)
+                        if want_bits & 2:
+                            gu.check_logprob(po[p, :n], r[0][1], r[1][1], "fast relate post_o da=%s" % da, lp_tol=2e-4)
+                            assert np.all(po[p, n:] == 0)
+    # the fused single-posterior kernel shares the product path
+    x_att, prev_att = prior_s[pq], prior_o
+    got = L.relate_one_fwd(dev(x_att), dev(prev_att), dev(np.ascontiguousarray(tile.transpose(0, 2, 1))), dev(pq), dev(n_obj),
+                           dev(np.ones(P, np.float32))).cpu().numpy()
+    for p in range(P):
+        q, n = pq[p], n_list[pq[p]]
+        if n < 2:
+            continue
+        r = [orc.relate_block(x_att[p, :n].astype(dt), prev_att[q, :n].astype(dt), tile[p, :n, :n].astype(dt), 1.0, 1.0, 0.0, False)
+             for dt in (np.float32, np.float64)]
+        gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path", lp_tol=2e-4)

@@ -168,7 +168,7 @@ def main():
             # K requested embedding columns (K = 1 relation per question in this workload)
             flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
             ach = flops / secs
-            out["roofline"] = {"kernel": "pair_ll_kernel<10,true> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
+            out["roofline"] = {"kernel": "pair_ll16_kernel<20> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
                                "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
                                "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                                "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}
@@ -186,7 +186,7 @@ def main():
             ach = nbytes / (secs / max(launches, 1))
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": ach / HBM_PEAK, "traffic": None}
-        out["kernels"] = stress_kernels(L, device, args.stress_preds, 100)
+        out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if args.stress_preds > 0 else []
         attach_traffic(out, args)
         sample = args.cpu_sample if args.cpu_sample is not None else (8 if args.objects > 64 else 32)
         if sample > 0:

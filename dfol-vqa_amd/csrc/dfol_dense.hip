@@ -665,30 +665,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // h = Sigmoid(acc + b2); 16x16 C layout: column = i*16 + r16, row(e) = 4 * kh + e
+    // (padding columns >= HID2: clamped addresses instead of guarded loads, their activation is forced to 0)
 #pragma unroll
     for (int i = 0; i < NB16; ++i) {
         const int ncol = i * 16 + r16;
-        const bool in = ncol < HID2;
-        const float bv = in ? b2[ncol] : 0.f;
+        const float bv = b2[min(ncol, HID2 - 1)];
+        const float keep = ncol < HID2 ? 1.f : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][e] = in ? __frcp_rn(1.0f + dfol_exp(-(acc[i][e] + bv))) : 0.f;
+        for (int e = 0; e < 4; ++e) acc[i][e] = keep * __builtin_amdgcn_rcpf(1.0f + dfol_exp(-(acc[i][e] + bv)));
     }
     const int64_t tile_sz = (int64_t)NS * NS;
     for (int k = 0; k < K; ++k) {
         const int col = req_col[(int64_t)k * Q + q];
         if (col < 0) continue;
         float part[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* erow = E + (int64_t)col * ld_e;
 #pragma unroll
         for (int i = 0; i < NB16; ++i) {
-            const int ncol = i * 16 + r16;
-            const float ev = ncol < HID2 ? E[(int64_t)col * ld_e + ncol] : 0.f;
+            const float ev = erow[min(i * 16 + r16, HID2 - 1)];
 #pragma unroll
             for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[i][e], ev, part[e]);
         }
 #pragma unroll
-        for (int m = 8; m >= 1; m >>= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part[e] += __shfl_xor(part[e], m, 64);
+        for (int e = 0; e < 4; ++e) part[e] = dfol_group_sum<16>(part[e]);
         if (r16 < 4) {                                      // lane e of each 16-lane set writes row 4*kh + e
             const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
             const int ee = tb * 128 + wave * 16 + 4 * kh + r16;

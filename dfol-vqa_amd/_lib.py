@@ -34,6 +34,7 @@ SIGNATURES = {
     "dfol_filter_fwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p],
     "dfol_relate_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "dfol_quantify_fwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_quantify_hard_f32": [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p],
     "dfol_relate_one_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
     "dfol_gate_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_gather_rows_f32": [_p, _p, _i32, _i32, _p, _p],
@@ -193,6 +194,14 @@ def quantify_fwd(att, quant, pred_q, n_obj):
     P, NS = att.shape
     lp = torch.empty(P, dtype=F32, device=att.device)
     call("dfol_quantify_fwd_f32", _ptr(att, F32), _ptr(quant, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, _ptr(lp), _stream())
+    return lp
+
+
+def quantify_hard(att, quant, pred_q, n_obj, total_obj):
+    P, NS = att.shape
+    lp = torch.empty(P, dtype=F32, device=att.device)
+    call("dfol_quantify_hard_f32", _ptr(att, F32), _ptr(quant, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, int(total_obj), _ptr(lp),
+         _stream())
     return lp
 
 

@@ -657,6 +657,35 @@ extern "C" int dfol_quantify_fwd_f32(const float* att, const float* quant, const
     return 0;
 }
 
+// hard_mode aggregation (batch_base_types.py:104-112): the sum over objects becomes a minimum.  The reference takes the minimum
+// over ALL object columns of (dense batch-object mask * value), so as soon as the batch holds objects of other images a 0 takes part.
+__global__ __launch_bounds__(256) void quantify_hard_kernel(const float* __restrict__ att, const float* __restrict__ quant,
+                                                            const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj,
+                                                            int P, int NS, int total_obj, float* __restrict__ lp) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int n = n_obj[pred_q[p]];
+    const float qf = quant[p], k = 1.f - 2.f * qf;
+    const float* a = att + (int64_t)p * NS;
+    float m = total_obj > n ? 0.f : __builtin_inff();
+    for (int o = lane; o < n; o += 64) m = fminf(m, dfol_pnot(a[o], qf, k));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fminf(m, __shfl_xor(m, s, 64));
+    if (lane == 0) lp[p] = dfol_pnot(m, qf, k);
+}
+
+extern "C" int dfol_quantify_hard_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj, int32_t P,
+                                      int32_t NS, int32_t total_obj, float* lp, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && total_obj >= 0, "quantify_hard: bad sizes P=%d NS=%d total_obj=%d", P, NS, total_obj);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(att && quant && pred_q && n_obj && lp, "quantify_hard: null pointer");
+    hipLaunchKernelGGL(quantify_hard_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, att, quant, pred_q, n_obj, P, NS,
+                       total_obj, lp);
+    DFOL_LAUNCH_CHECK("quantify_hard");
+    return 0;
+}
+
 __global__ void gate_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ xq,
                             const float* __restrict__ yq, const float* __restrict__ g, int NS, float* __restrict__ out,
                             float* __restrict__ outq) {

@@ -229,9 +229,9 @@ class BatchVariableSet(object):
         return self._world._ident if self._predicate_question_map is None else self._predicate_question_map
 
     def log_probability(self, hard_mode=False):
-        """Soft quantifier aggregation, batch_base_types.py:113-123."""
+        """Quantifier aggregation, batch_base_types.py:103-125 (soft: sums; hard_mode: minimum)."""
         if hard_mode:
-            raise NotImplementedError("hard_mode (batch_base_types.py:104-112) is off in every shipped config; not built")
+            return L.quantify_hard(self._log_attention, self._quantifier, self.pred_q(), self._world._n_obj, self._world.object_num())
         return L.quantify_fwd(self._log_attention, self._quantifier, self.pred_q(), self._world._n_obj)
 
     def cumulative_loss(self):          # batch_base_types.py:127-131

@@ -104,6 +104,11 @@ def quantify_fwd(att, quant, pred_q, n_obj):
     return _lib.quantify_fwd(att, quant, pred_q, n_obj)
 
 
+def quantify_hard(att, quant, pred_q, n_obj, total_obj):
+    """hard_mode aggregation; the reference only uses it when answering (give_answer and hard_mode), so it carries no gradient."""
+    return _lib.quantify_hard(att.detach(), quant, pred_q, n_obj, total_obj)
+
+
 # ---- gathers and option normalisation ----------------------------------------------------------------
 class _AttrGather(torch.autograd.Function):
     @staticmethod

@@ -156,6 +156,14 @@ int dfol_relate_one_fwd_f32(const float* x_att, const float* prev_att, const flo
 int dfol_quantify_fwd_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
                           int32_t P, int32_t NS, float* lp, void* stream);
 
+/* hard_mode aggregation: replaces BatchVariableSet.log_probability(hard_mode=True), batch_base_types.py:104-112 (a test-time
+ * option of BatchGQAInterpreter, :23,:73):   lp[p] = F_q( min( min_{o < n} F_q(att[p][o]), 0 if total_obj > n ) ).
+ * The 0 is the reference's product with the dense batch-object mask: objects of the batch's other images take part in the
+ * minimum as 0.  total_obj = number of objects of the whole ProgramBatch.  Forward only (the reference uses it with give_answer).
+ */
+int dfol_quantify_hard_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj, int32_t P,
+                           int32_t NS, int32_t total_obj, float* lp, void* stream);
+
 /* Per-question select between two variable sets: replaces BatchVariableSet.gate,
  * batch_base_types.py:149-168.   out = g*x + (1-g)*y  on attention rows and quantifiers, g in {0,1}.
  *   x_att, y_att [P, NS]; x_quant, y_quant [P]; g [P] (float, as the reference's mask)

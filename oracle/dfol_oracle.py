@@ -220,8 +220,12 @@ class VarSet(object):
         names = [x if f > 0 else y for x, y, f in zip(self.names, other.names, g)]
         return VarSet(names, att, quant, self.pq, self.world)
 
-    def log_probability(self):                     # batch_base_types.py:103-125 (soft mode)
+    def log_probability(self, hard=False):         # batch_base_types.py:103-125
         w = self.world
+        if hard:                                   # :104-112 (test-time option: min/max instead of the soft aggregation)
+            t = log_parametric_not(self.att, self.quant[:, None], 1)             # [P, O]
+            mask = w.bom if self.pq is None else w.bom[self.pq, :]
+            return log_parametric_not((mask * t).min(1), self.quant, 1)
         t = log_parametric_not(self.att.T.copy(), self.quant[None, :], 1)        # [O, P]
         s = w.bom @ t                                                            # [Q, P]
         if self.pq is not None:
@@ -461,31 +465,31 @@ def gqa_relate(world, vs, relation_list, is_subject, attribute_list=None, **kw):
     return subj.gate(obj, is_subject)
 
 
-def gqa_exist(world, vs, give_answer=True, **kw):  # :399-410
-    lp = vs.log_probability()
+def gqa_exist(world, vs, give_answer=True, hard=False, **kw):  # :399-410
+    lp = vs.log_probability(give_answer and hard)
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], vs, BINARY, alp)
 
 
-def gqa_end(world, vs, give_answer=True, **kw):    # :773-780
-    return _result([[n] for n in vs.names] if give_answer else [], vs.log_probability(), [], vs, STATEMENT, [])
+def gqa_end(world, vs, give_answer=True, hard=False, **kw):    # :773-780
+    return _result([[n] for n in vs.names] if give_answer else [], vs.log_probability(give_answer and hard), [], vs, STATEMENT, [])
 
 
-def gqa_verify_attrs(world, vs, attribute_list_list, give_answer=True, pq=None, **kw):   # :452-473
+def gqa_verify_attrs(world, vs, attribute_list_list, give_answer=True, pq=None, hard=False, **kw):   # :452-473
     tokens, bi = flatten_list(attribute_list_list)
     x = filter_batch(world, vs, tokens, bi if pq is None else pq, normalized_probability=False)
     xpq = x.pq if x.pq is not None else np.arange(len(tokens))
     att = np.zeros_like(vs.att)
     np.add.at(att, xpq, x.att)                                            # pqm^T @ att  :457
     y = VarSet(vs.names, att, vs.quant, None, world)
-    lp = y.log_probability()
+    lp = y.log_probability(give_answer and hard)
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], y, BINARY, alp)
 
 
-def gqa_verify_rel(world, vs, relation_list, is_subject, attribute_list=None, give_answer=True, **kw):   # :489-501
+def gqa_verify_rel(world, vs, relation_list, is_subject, attribute_list=None, give_answer=True, hard=False, **kw):   # :489-501
     x = gqa_relate(world, vs, relation_list, is_subject, attribute_list)
-    lp = x.log_probability()
+    lp = x.log_probability(give_answer and hard)
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], x, BINARY, alp)
 
@@ -498,10 +502,10 @@ def _choose_answer(world, lp, x, tokens, bi, threshold, give_answer):
     return unflatten_list(tokens, bi, flags), unflatten_list(lp.tolist(), bi, flags)
 
 
-def gqa_choose_attr(world, vs, attribute_list_list, give_answer=True, pq=None, threshold=0, **kw):   # :215-228
+def gqa_choose_attr(world, vs, attribute_list_list, give_answer=True, pq=None, threshold=0, hard=False, **kw):   # :215-228
     tokens, bi = flatten_list(attribute_list_list)
     x = filter_batch(world, vs, tokens, bi if pq is None else pq)
-    lp = x.log_probability()
+    lp = x.log_probability(give_answer and hard)
     ans, alp = _choose_answer(world, lp, x, tokens, bi, threshold, give_answer)
     return _result(ans, lp, attribute_list_list, x, QUERY, alp)
 
@@ -509,11 +513,11 @@ def gqa_choose_attr(world, vs, attribute_list_list, give_answer=True, pq=None, t
 def gqa_query_attr(world, vs, category_list, give_answer=True, pq=None, threshold=0, **kw):   # :304-306
     ont = world.ontology
     lists = [ont.query(c if c not in ("name", "type") else n) for c, n in zip(category_list, vs.names)]
-    return gqa_choose_attr(world, vs, lists, give_answer, pq, threshold)
+    return gqa_choose_attr(world, vs, lists, give_answer, pq, threshold)      # hard_mode is NOT forwarded (:306)
 
 
 def gqa_choose_rel(world, vs, relation_list_list, is_subject, attribute_list=None, give_answer=True, pq=None,
-                   threshold=0, **kw):             # :246-267
+                   threshold=0, hard=False, **kw):             # :246-267
     tokens, bi = flatten_list(relation_list_list)
     x = gqa_select(world, attribute_list)
     subj = x.gate(vs, is_subject)
@@ -521,23 +525,23 @@ def gqa_choose_rel(world, vs, relation_list_list, is_subject, attribute_list=Non
     subj, obj = relate_batch(world, subj, obj, tokens, bi if pq is None else pq)
     flag = np.asarray(is_subject, world.dtype)[subj.pq]                   # pqm @ is_subject  :254-255
     x = subj.gate(obj, flag.tolist())
-    lp = x.log_probability()
+    lp = x.log_probability(give_answer and hard)
     ans, alp = _choose_answer(world, lp, x, tokens, bi, threshold, give_answer)
     return _result(ans, lp, relation_list_list, x, QUERY, alp)
 
 
-def _lp_of(v):
-    return v.log_probability() if isinstance(v, VarSet) else v["log_probability"]
+def _lp_of(v, hard=False):
+    return v.log_probability(hard) if isinstance(v, VarSet) else v["log_probability"]
 
 
-def gqa_and(world, v1, v2, give_answer=True, **kw):   # :513-534
-    lp = log_and(_lp_of(v1), _lp_of(v2))
+def gqa_and(world, v1, v2, give_answer=True, hard=False, **kw):   # :513-534
+    lp = log_and(_lp_of(v1, give_answer and hard), _lp_of(v2, give_answer and hard))
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], None, BINARY, alp)
 
 
-def gqa_or(world, v1, v2, give_answer=True, **kw):    # :546-567
-    lp = log_or(_lp_of(v1), _lp_of(v2))
+def gqa_or(world, v1, v2, give_answer=True, hard=False, **kw):    # :546-567
+    lp = log_or(_lp_of(v1, give_answer and hard), _lp_of(v2, give_answer and hard))
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], None, BINARY, alp)
 
@@ -548,47 +552,49 @@ def _segment_or(world, lp, pq):                    # pqm^T @ log_not(lp), then l
     return log_not(s)
 
 
-def gqa_all_same(world, vs, category_list, give_answer=True, pq=None, **kw):   # :582-608
+def gqa_all_same(world, vs, category_list, give_answer=True, pq=None, hard=False, **kw):   # :582-608
     ont = world.ontology
     lists = [ont.query(c if c not in ("name", "type") else n) for c, n in zip(category_list, vs.names)]
     tokens, bi = flatten_list(lists)
     x = filter_batch(world, vs, tokens, bi if pq is None else pq)
     post = log_not(log_and(vs.att[x.pq], log_not(x.att)))                 # :588-589
     temp = VarSet(x.names, post, np.zeros(len(tokens), world.dtype), x.pq, world)   # FOR_ALL
-    lp = _segment_or(world, temp.log_probability(), x.pq)
+    lp = _segment_or(world, temp.log_probability(give_answer and hard), x.pq)
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], None, BINARY, alp)
 
 
 def gqa_all_different(world, vs, category_list, give_answer=True, pq=None, **kw):   # :627-639
-    r = gqa_all_same(world, vs, category_list, give_answer, pq)
+    r = gqa_all_same(world, vs, category_list, give_answer, pq)           # hard_mode is NOT forwarded (:628)
     lp = log_not(r["log_probability"])
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], None, BINARY, alp)
 
 
-def gqa_two_same(world, v1, v2, category_list, give_answer=True, pq=None, **kw):   # :654-681
+def gqa_two_same(world, v1, v2, category_list, give_answer=True, pq=None, hard=False, **kw):   # :654-681
     ont = world.ontology
     lists = [ont.query(c if c not in ("name", "type") else n) for c, n in zip(category_list, v1.names)]
     tokens, bi = flatten_list(lists)
     x1 = filter_batch(world, v1, tokens, bi if pq is None else pq)
     x2 = filter_batch(world, v2, tokens, bi if pq is None else pq)
-    lp = _segment_or(world, log_and(x1.log_probability(), x2.log_probability()), x1.pq)
+    h = give_answer and hard
+    lp = _segment_or(world, log_and(x1.log_probability(h), x2.log_probability(h)), x1.pq)
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], None, BINARY, alp)
 
 
 def gqa_two_different(world, v1, v2, category_list, give_answer=True, pq=None, **kw):   # :702-714
-    r = gqa_two_same(world, v1, v2, category_list, give_answer, pq)
+    r = gqa_two_same(world, v1, v2, category_list, give_answer, pq)       # hard_mode is NOT forwarded (:703)
     lp = log_not(r["log_probability"])
     ans, alp = _yes_no(lp) if give_answer else ([], [])
     return _result(ans, lp, ["no", "yes"], None, BINARY, alp)
 
 
-def gqa_compare(world, v1, v2, attribute_list, is_less, give_answer=True, **kw):   # :730-758
+def gqa_compare(world, v1, v2, attribute_list, is_less, give_answer=True, hard=False, **kw):   # :730-758
     x1 = filter_batch(world, v1, attribute_list)
     x2 = filter_batch(world, v2, attribute_list)
-    lp = np.stack([x1.log_probability(), x2.log_probability()], 1)
+    h = give_answer and hard
+    lp = np.stack([x1.log_probability(h), x2.log_probability(h)], 1)
     m = lp.max(1, keepdims=True)
     lp = lp - (m + np.log(np.exp(lp - m).sum(1, keepdims=True)))          # LogSoftmax(dim=1)
     lp = log_parametric_not(lp, np.asarray(is_less, lp.dtype)[:, None], 1)
@@ -720,10 +726,10 @@ def execute_program_batch(world, ops, deps, give_answer=True, threshold=0, retur
         inputs = tuple(trace[d] for d in deps[i])
         fn, _ = OPS[ob["op_name"]]
         x = fn(world, *(inputs + tuple(ob["arguments"])), give_answer=give_answer, pq=ob["question_index"],
-               threshold=threshold)
+               threshold=threshold, hard=getattr(world, "hard_mode", False))
         last = i == len(ops) - 1
         if last and not ob["is_terminal"]:                                 # batch_gqa_interpreter.py:75-76
-            x = gqa_end(world, x, give_answer)
+            x = gqa_end(world, x, give_answer, hard=getattr(world, "hard_mode", False))
         if isinstance(x, VarSet) and len(inputs) > 0 and ob["mask"] is not None:
             x = x.gate(inputs[0], ob["mask"])                              # batch_base_interpreter.py:166-167
         trace.append(x)
@@ -740,7 +746,7 @@ def gather_results(outputs):                       # data_parallel.py:15-50
 
 
 def run_questions(ontology, questions, scenes, dtype=np.float32, split=1, normalize=True, give_answer=True,
-                  weights=None, return_trace=False):
+                  weights=None, return_trace=False, hard_mode=False):
     """The reference's forward over a list of questions: collate (split) -> build_scene -> execute -> gather.
     scenes[i] is {'n', 'A', 'R'} (cached tables) or {'n', 'X'} with `weights` (neural oracle)."""
     dtype = np.dtype(dtype)
@@ -756,6 +762,7 @@ def run_questions(ontology, questions, scenes, dtype=np.float32, split=1, normal
         else:
             A, R = tables_from_features(np.concatenate([s["X"] for s in sc]).astype(dtype), img, weights, ontology, dtype)
         world = World(ontology, A, R, img, dtype, normalize)
+        world.hard_mode = bool(hard_mode)                                  # BatchGQAInterpreter._hard_mode (:23, :73)
         ops, deps = collate_programs(chunk)
         r = execute_program_batch(world, ops, deps, give_answer, return_trace=return_trace)
         if return_trace:

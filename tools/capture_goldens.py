@@ -163,11 +163,12 @@ def g2():
 
 # ---------------------------------------------------------------------------------------- interpreter runs
 def run_reference(questions, split=1, dtype=torch.float32, training=False, return_trace=True, normalize=True,
-                  grad_tables=False):
+                  grad_tables=False, hard=False):
     qs = copy.deepcopy(questions)
     collater = ref_harness.make_collater(ref, split, "table")
     pbs = collater.collate(qs)
     model = ref_harness.build_table_interpreter(ref, ontology, normalize)
+    model._hard_mode = hard                                  # batch_gqa_interpreter.py:23,73
     leaves = []
     for pb in pbs:
         pb.create_sparse_tensors()
@@ -218,16 +219,16 @@ def questions_to_meta(questions):
     return out
 
 
-def capture_run(name, questions, split=1, normalize=True, arrays=None, meta=None):
+def capture_run(name, questions, split=1, normalize=True, arrays=None, meta=None, hard=False):
     arrays = {} if arrays is None else arrays
     meta = {} if meta is None else meta
-    meta.update({"questions": questions_to_meta(questions), "split": split, "normalize": normalize,
+    meta.update({"questions": questions_to_meta(questions), "split": split, "normalize": normalize, "hard_mode": hard,
                  "source": "batch_base_interpreter.py:72-183"})
     for i, q in enumerate(questions):
         arrays["A_%d" % i] = q["scene"]["A"]
         arrays["R_%d" % i] = q["scene"]["R"]
     for dt, tag in both_dtypes():
-        (res, traces), pbs, _ = run_reference(questions, split, dt, normalize=normalize)
+        (res, traces), pbs, _ = run_reference(questions, split, dt, normalize=normalize, hard=hard)
         pack_result(arrays, meta, tag, res, traces)
         if tag == "f32":
             meta["op_names"] = [[ob._op_name for ob in pb._op_batch_list] for pb in pbs]
@@ -344,6 +345,38 @@ def g4():
         pack_result(arrays, meta, tag, res, [[t for t in traces[0] if not isinstance(t, dict)]])
     meta["questions"] = questions_to_meta(qs)
     save("g4_end", arrays, meta)
+
+
+def g11():
+    """hard_mode (batch_base_types.py:104-112): the test-time min/max aggregation, through whole-interpreter runs."""
+    Q = syn.question
+    n_of = lambda i: [5, 7, 3, 6, 4, 8, 2, 5][i % 8]
+
+    def mk(i, branches, last, answer="yes"):
+        return Q(600 + i, branches, last, answer, scene_for(600 + i, n_of(i)))
+
+    two = lambda i, last, ans="yes": mk(i, [[op("select", "dog"), op("filter", "red")],
+                                            [op("select", "cat"), op("relate", "near", bool(i % 2), "table")]], last, ans)
+    capture_run("g11_hard_exist", [mk(0, [[op("select", "dog")]], op("exist")),
+                                   mk(1, [[op("select", "_"), op("filter", "not(blue)"), op("relate", "on", True, "table")]], op("exist")),
+                                   mk(2, [[op("select", "chair"), op("filter", "wood")]], op("exist"), "no")], hard=True)
+    capture_run("g11_hard_single", [mk(3, [[op("select", "cat"), op("filter", "small")]], op("exist"))], hard=True)
+    capture_run("g11_hard_verify_attrs", [mk(10, [[op("select", "dog"), op("filter", "small")]], op("verify_attrs", ["red", "large"])),
+                                          mk(11, [[op("select", "cup")]], op("verify_attrs", ["glass"]), "no")], hard=True)
+    capture_run("g11_hard_query_attr", [mk(30, [[op("select", "dog")]], op("query_attr", "color"), "black"),
+                                        mk(31, [[op("select", "animal"), op("filter", "small")]], op("query_attr", "name"), "cat")], hard=True)
+    capture_run("g11_hard_choose_rel", [mk(50, [[op("select", "dog")]], op("choose_rel", ["to the left of", "to the right of"], True, "cat"),
+                                           "to the left of"),
+                                        mk(51, [[op("select", "woman")]], op("choose_rel", ["on", "under"], False, "table"), "on")], hard=True)
+    capture_run("g11_hard_and", [two(60, op("and")), two(62, op("and"))], hard=True)
+    capture_run("g11_hard_two_same", [two(70, op("two_same", "color")), two(73, op("two_same", "size"))], hard=True)
+    capture_run("g11_hard_all_same", [mk(80, [[op("select", "dog")]], op("all_same", "color")),
+                                      mk(81, [[op("select", "furniture"), op("filter", "wood")]], op("all_same", "name"), "no")], hard=True)
+    # all_different / two_different / query_attr do not forward hard_mode to the operator they wrap (batch_gqa_ops.py:306,628,703)
+    capture_run("g11_hard_all_different", [mk(82, [[op("select", "dog")]], op("all_different", "color")),
+                                           mk(83, [[op("select", "furniture"), op("filter", "wood")]], op("all_different", "name"), "no")], hard=True)
+    capture_run("g11_hard_two_different", [two(74, op("two_different", "color")), two(75, op("two_different", "size"))], hard=True)
+    capture_run("g11_hard_compare", [two(90, op("compare", "large", False), "dog"), two(92, op("compare", "not(small)", True), "cat")], hard=True)
 
 
 # ---------------------------------------------------------------------------------------- g3
@@ -719,7 +752,7 @@ def g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()
 

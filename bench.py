@@ -168,7 +168,7 @@ def main():
             # K requested embedding columns (K = 1 relation per question in this workload)
             flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
             ach = flops / secs
-            out["roofline"] = {"kernel": "pair_ll16_kernel<20> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
+            out["roofline"] = {"kernel": "pair_ll16_kernel<19> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
                                "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
                                "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                                "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}

@@ -540,9 +540,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
     const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
     float* __restrict__ tiles) {
-    constexpr int ROWS = 16 * NB16;                         // W2 rows staged per chunk (multiple of 64)
+    constexpr int ROWS = (16 * NB16 + 63) / 64 * 64;        // W2 rows staged per chunk (the loader works in passes of 64 rows)
     constexpr int PASSES = ROWS / 64;
-    constexpr int PARTS = 4, HALF = NB16 / PARTS;           // column tiles are visited in groups (register budget)
+    constexpr int PARTS = 4, HALF = (NB16 + PARTS - 1) / PARTS;   // column tiles are visited in groups (register budget)
     __shared__ __attribute__((aligned(16))) float Bs[2][ROWS * PK_PITCH];      // double-buffered W2 chunk: one barrier per chunk
     __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
     const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
@@ -642,17 +642,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int part = 0; part < PARTS; ++part) {
                 float4 b4[HALF];
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) b4[i] = *reinterpret_cast<const float4*>(brow + (part * HALF + i) * 16 * PK_PITCH + 4 * h);
+                for (int i = 0; i < HALF; ++i)
+                    if (part * HALF + i < NB16) b4[i] = *reinterpret_cast<const float4*>(brow + (part * HALF + i) * 16 * PK_PITCH + 4 * h);
                 // k step outermost: consecutive MFMAs hit different accumulators (a 16x16x4 MFMA issues every 32 cycles
                 // but its result is ready for a dependent one only after 40)
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 0], b4[i].x, acc[part * HALF + i], 0, 0, 0);
+                for (int i = 0; i < HALF; ++i)
+                    if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 0], b4[i].x, acc[part * HALF + i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 1], b4[i].y, acc[part * HALF + i], 0, 0, 0);
+                for (int i = 0; i < HALF; ++i)
+                    if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 1], b4[i].y, acc[part * HALF + i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 2], b4[i].z, acc[part * HALF + i], 0, 0, 0);
+                for (int i = 0; i < HALF; ++i)
+                    if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 2], b4[i].z, acc[part * HALF + i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 3], b4[i].w, acc[part * HALF + i], 0, 0, 0);
+                for (int i = 0; i < HALF; ++i)
+                    if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[4 * h + 3], b4[i].w, acc[part * HALF + i], 0, 0, 0);
             }
         if (!early) {
             __builtin_amdgcn_sched_barrier(0);
@@ -726,8 +731,12 @@ extern "C" int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, co
     const bool kx = HID1 % 32 == 0 && w2_rows_alloc >= 32 * nb;
     static const int variant = getenv("DFOL_PAIR_VARIANT") ? atoi(getenv("DFOL_PAIR_VARIANT")) : 16;
     if (kx && nb == 10 && variant == 16) {                  // full-size oracle: 16x16x4 tiles, two wavefronts per SIMD
-        hipLaunchKernelGGL((pair_ll16_kernel<20>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, ld_e,
-                           be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
+        if (HID2 <= 304)                                    // 300 hidden units need 19 column tiles of 16, not 20
+            hipLaunchKernelGGL((pair_ll16_kernel<19>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, ld_e,
+                               be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
+        else
+            hipLaunchKernelGGL((pair_ll16_kernel<20>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2, ld_w2, b2, HID2, E, ld_e,
+                               be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
         DFOL_LAUNCH_CHECK("pair_ll");
         return 0;
     }

@@ -163,12 +163,12 @@ def main():
         O = args.batch * args.objects
         pairs = args.batch * args.objects * (args.objects - 1)
         launches, secs = per_step[dom]
-        if dom == "dfol_pair_ll_f32":
+        if dom in ("dfol_pair_ll_f32", "dfol_pair_ll_packed_f32"):
             # reduced-form algorithmic flops per ordered pair: geometry term, 256->300 layer, and the
             # K requested embedding columns (K = 1 relation per question in this workload)
             flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
             ach = flops / secs
-            out["roofline"] = {"kernel": "pair_ll16_kernel<19> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
+            out["roofline"] = {"kernel": "pair_ll32b_kernel<19> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
                                "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
                                "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                                "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}
@@ -215,7 +215,7 @@ def attach_traffic(out, args):
         return None
 
     if "pair_ll" in out["roofline"]["kernel"] and args.objects == 100 and args.batch == 256:
-        out["roofline"]["traffic"] = total("pair_ll16_kernel")
+        out["roofline"]["traffic"] = total("pair_ll32b_kernel") or total("pair_ll16")
         out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
     P = args.stress_preds
     for k in out["kernels"]:

@@ -57,6 +57,9 @@ SIGNATURES = {
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
     "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
                          _i32, _f, _p, _p],
+    "dfol_pair_pack_w2_f32": [_p, _i64, _i32, _i32, _p, _p],
+    "dfol_pair_ll_packed_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
+                                _p, _p],
 }
 
 
@@ -308,6 +311,29 @@ def pair_ll(uv, hid1, pos, wg, w2, b2, emb_w, emb_b, n_obj, obj_off, max_n, req_
          w2.stride(0), w2.shape[0], _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          _ptr(tiles, F32), _stream())
+    return tiles
+
+
+PACKED_W2_ROWS, PACKED_W2_CHUNK = 320, 16
+
+
+def pair_pack_w2(w2, hid2=None):
+    """W2 [HID2(+padding), HID1] -> the packed image dfol_pair_ll_packed_f32 reads ([HID1/16][320][16], swizzled)."""
+    hid1 = w2.shape[1]
+    hid2 = w2.shape[0] if hid2 is None else hid2
+    out = torch.empty((hid1 // PACKED_W2_CHUNK) * PACKED_W2_ROWS * PACKED_W2_CHUNK, dtype=F32, device=w2.device)
+    call("dfol_pair_pack_w2_f32", _ptr(w2, F32), w2.stride(0), hid2, hid1, _ptr(out), _stream())
+    return out
+
+
+def pair_ll_packed(uv, hid1, pos, wg, w2_packed, b2, hid2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles,
+                   default_ll=-30.0):
+    """As pair_ll, with the second layer packed by pair_pack_w2 (hid1 % 16 == 0, hid2 <= 320)."""
+    K, Q = req_col.shape
+    NS = tiles.shape[1]
+    call("dfol_pair_ll_packed_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32), _ptr(w2_packed, F32),
+         _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32), _ptr(obj_off, I32), Q, max_n,
+         _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll, _ptr(tiles, F32), _stream())
     return tiles
 
 

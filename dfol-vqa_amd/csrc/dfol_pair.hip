@@ -1,0 +1,434 @@
+// Fused pair MLP for the full-size oracle, occupancy-2 geometry (gfx950).
+//
+// dfol_pair_ll_f32's 8-wavefront kernel (dfol_dense.hip) leaves one workgroup per CU: during a workgroup's prologue
+// (dependent loads of the image geometry, box positions, first U/V rows and W2 chunk) and epilogue (embedding rows,
+// LogSigmoid, stores) the CU's matrix pipes idle — about a quarter of a workgroup's life.  This geometry halves the
+// workgroup (4 wavefronts = 64 pair slots, one wavefront per SIMD) and the K chunk (16), so that TWO independent
+// workgroups are resident per CU (44 KB of LDS and <= 256 registers each): one's latency chains and barrier waits are
+// covered by the other's MFMAs, with no hand-made phase offsets.
+//
+// W2 comes PACKED (dfol_pair_pack_w2_f32): chunk-major [HID1/16][320][16] with rows >= HID2 zero and the four 4-float
+// k-groups of row r stored at group kq ^ swz[(r >> 2) & 3], swz = {0,3,2,1}.  A chunk is then 20 KB of contiguous
+// memory that is copied to LDS verbatim (coalesced, spread over all L2 channels), needs no padding, and every
+// ds_read_b128 of the B operand is bank-conflict-free: a b128 read is served in four groups of 16 lanes
+// ({0-3,12-15,20-27}, ...), i.e. rows {0-3,12-15} of k-group kh with rows {4-11} of k-group kh+1 (or kh-1); with the
+// swizzle those 16 (row, group) pairs cover all 64 banks exactly once.
+#include "dfol_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int PB_ROWS = 320;                                // W2 rows per packed chunk
+constexpr int PB_CH = 16;                                   // K per chunk
+constexpr int PB_CHUNK = PB_ROWS * PB_CH;                   // floats per chunk
+
+__device__ __forceinline__ int pb_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // {0,3,2,1}[(row>>2)&3]
+
+__global__ void pair_pack_w2_kernel(const float* __restrict__ W2, int64_t ld_w2, int HID2, int HID1, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of the packed image
+    const int total = (HID1 / PB_CH) * PB_ROWS * 4;
+    if (idx >= total) return;
+    const int c = idx / (PB_ROWS * 4), rem = idx - c * (PB_ROWS * 4), r = rem >> 2, slot = rem & 3;
+    const int kq = slot ^ pb_swz(r);                        // the k-group stored in this slot
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < HID2) {
+        const float* src = W2 + (int64_t)r * ld_w2 + c * PB_CH + kq * 4;
+        v = make_float4(src[0], src[1], src[2], src[3]);
+    }
+    reinterpret_cast<float4*>(out)[idx] = v;
+}
+
+template <int NB16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll16b_kernel(
+    const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
+    const float* __restrict__ Wg, const float* __restrict__ W2p, const float* __restrict__ b2, int HID2,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
+    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
+    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
+    float* __restrict__ tiles) {
+    constexpr int PARTS = 4, HALF = (NB16 + PARTS - 1) / PARTS;      // column tiles are visited in groups (register budget)
+    constexpr int PASSES = PB_CHUNK / 4 / 256;                       // float4 per thread per chunk (5)
+    __shared__ __attribute__((aligned(16))) float Bs[2][PB_CHUNK];  // double-buffered W2 chunk: one barrier per chunk
+    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
+    const int n = n_obj[q];
+    if (tb * 64 >= n * n) return;
+    bool any = false;
+    for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
+    if (!any) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 4, r16 = lane & 15;
+    const int first = obj_off[q];
+    const int e_slot = tb * 64 + wave * 16 + r16;
+    const bool valid = e_slot < n * n;
+    const int s = valid ? e_slot / n : 0, o = valid ? e_slot - s * n : 0;
+    float geo[4];
+    {                                                       // batch_gqa_boxfeatures_pipeline.py:263-279
+        const float* ps = pos + (int64_t)(first + s) * ld_pos;
+        const float* po = pos + (int64_t)(first + o) * ld_pos;
+        const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
+        const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        geo[0] = dist;
+        geo[1] = asinf(dy / fmaxf(dist, 1e-10f));
+        geo[2] = (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f);
+        geo[3] = (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f);
+    }
+    for (int i = tid; i < HID1; i += 256) *reinterpret_cast<float4*>(&Wgs[i * 4]) = *reinterpret_cast<const float4*>(Wg + i * 4);
+    const float* Urow = UV + (int64_t)(first + s) * ld_uv + 4 * kh;
+    const float* Vrow = UV + (int64_t)(first + o) * ld_uv + HID1 + 4 * kh;
+
+    floatx4 acc[NB16];
+#pragma unroll
+    for (int i = 0; i < NB16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const float4* W2p4 = reinterpret_cast<const float4*>(W2p);
+    float4 rb[PASSES];
+    auto load_w2 = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) rb[i] = W2p4[(int64_t)c * (PB_CHUNK / 4) + tid + 256 * i];
+    };
+    auto store_w2 = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) reinterpret_cast<float4*>(Bs[buf])[tid + 256 * i] = rb[i];
+    };
+    float4 ru, rv;
+    auto load_uv = [&](int k0) {
+        ru = *reinterpret_cast<const float4*>(Urow + k0);
+        rv = *reinterpret_cast<const float4*>(Vrow + k0);
+    };
+    auto make_a = [&](int k0, float (&a)[4]) {
+        const float uu[4] = {ru.x, ru.y, ru.z, ru.w}, vv[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 g = *reinterpret_cast<const float4*>(&Wgs[(k0 + 4 * kh + c) * 4]);
+            const float z = uu[c] + vv[c] + (g.x * geo[0] + g.y * geo[1] + g.z * geo[2] + g.w * geo[3]);
+            a[c] = z > 0.f ? z : dfol_exp(z) - 1.0f;        // nn.ELU
+        }
+    };
+    const int boff = r16 * PB_CH + 4 * (kh ^ pb_swz(r16));  // this lane's float4 of column-tile row r16 (+ 256 floats per tile)
+
+    float a_cur[4], a_next[4];
+    const int nchunk = HID1 / PB_CH, lastc = nchunk - 1;
+    load_w2(0);
+    load_uv(0);
+    __syncthreads();                                        // Wgs visible
+    store_w2(0);
+    make_a(0, a_cur);
+    load_w2(min(1, lastc));
+    load_uv(PB_CH * min(1, lastc));
+    __syncthreads();
+    int buf = 0;
+    for (int c = 0; c < nchunk; ++c, buf ^= 1) {
+        store_w2(buf ^ 1);                                  // chunk c+1 (in registers since the previous iteration)
+        make_a(PB_CH * min(c + 1, lastc), a_next);
+        load_uv(PB_CH * min(c + 2, lastc));
+        load_w2(min(c + 2, lastc));                         // chunk c+2 flies during this chunk's MFMAs
+        const float* brow = &Bs[buf][boff];
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) {
+            float4 b4[HALF];
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+                if (part * HALF + i < NB16) b4[i] = *reinterpret_cast<const float4*>(brow + (part * HALF + i) * 16 * PB_CH);
+            // k step outermost: consecutive MFMAs hit different accumulators (a 16x16x4 MFMA issues every 32 cycles but
+            // its result is ready for a dependent one only after 40)
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+                if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], b4[i].x, acc[part * HALF + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+                if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], b4[i].y, acc[part * HALF + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+                if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[2], b4[i].z, acc[part * HALF + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+                if (part * HALF + i < NB16) acc[part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[3], b4[i].w, acc[part * HALF + i], 0, 0, 0);
+        }
+        __syncthreads();                                    // chunk c fully read, chunk c+1 fully written
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a_cur[t] = a_next[t];
+    }
+
+    // h = Sigmoid(acc + b2); 16x16 C layout: column = i*16 + r16, row(e) = 4 * kh + e
+    // (padding columns >= HID2: clamped addresses instead of guarded loads, their activation is forced to 0)
+#pragma unroll
+    for (int i = 0; i < NB16; ++i) {
+        const int ncol = i * 16 + r16;
+        const float bv = b2[min(ncol, HID2 - 1)];
+        const float keep = ncol < HID2 ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = keep * __builtin_amdgcn_rcpf(1.0f + dfol_exp(-(acc[i][e] + bv)));
+    }
+    const int64_t tile_sz = (int64_t)NS * NS;
+    for (int k = 0; k < K; ++k) {
+        const int col = req_col[(int64_t)k * Q + q];
+        if (col < 0) continue;
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* erow = E + (int64_t)col * ld_e;
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) {
+            const float ev = erow[min(i * 16 + r16, HID2 - 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[i][e], ev, part[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[e] = dfol_group_sum<16>(part[e]);
+        if (r16 < 4) {                                      // lane e of each 16-lane set writes row 4*kh + e
+            const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
+            const int ee = tb * 64 + wave * 16 + 4 * kh + r16;
+            if (ee < n * n) {
+                const int ss = ee / n, oo = ee - ss * n;
+                const float x = v + (be ? be[col] : 0.f);
+                const float val = (ss == oo) ? dflt : fminf(x, 0.f) - log1pf(expf(-fabsf(x)));   // nn.LogSigmoid; diagonal stays absent
+                float* t = tiles + (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz;
+                if (req_orient && req_orient[(int64_t)k * Q + q]) t[(int64_t)oo * NS + ss] = val;
+                else t[(int64_t)ss * NS + oo] = val;
+            }
+        }
+    }
+}
+
+
+// 32 pair slots per wavefront (two 16-row A tiles share every B fragment): half the W2 traffic and LDS reads per pair and
+// twice the MFMAs between barriers.  The accumulators take 2 x 76 registers, so the W2 chunk cannot be staged through
+// registers any more: it goes global -> LDS directly (global_load_lds_dwordx4; the packed image is lane-linear, so the DMA's
+// "wave-uniform base + lane x 16 bytes" destination is exactly the layout the B reads expect).
+template <int NB16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32b_kernel(
+    const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
+    const float* __restrict__ Wg, const float* __restrict__ W2p, const float* __restrict__ b2, int HID2,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
+    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
+    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
+    float* __restrict__ tiles) {
+    constexpr int PARTS = 4, HALF = (NB16 + PARTS - 1) / PARTS;
+    constexpr int PASSES = PB_CHUNK / 4 / 256;                       // 16-byte DMA pieces per thread per chunk (5)
+    __shared__ __attribute__((aligned(16))) float Bs[2][PB_CHUNK];
+    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
+    const int n = n_obj[q];
+    if (tb * 128 >= n * n) return;
+    bool any = false;
+    for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
+    if (!any) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 4, r16 = lane & 15;
+    const int first = obj_off[q];
+    float geo[2][4];
+    const float* Urow[2];
+    const float* Vrow[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int e_slot = tb * 128 + wave * 32 + m * 16 + r16;
+        const bool valid = e_slot < n * n;
+        const int s = valid ? e_slot / n : 0, o = valid ? e_slot - s * n : 0;
+        const float* ps = pos + (int64_t)(first + s) * ld_pos;
+        const float* po = pos + (int64_t)(first + o) * ld_pos;
+        const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
+        const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        geo[m][0] = dist;
+        geo[m][1] = asinf(dy / fmaxf(dist, 1e-10f));
+        geo[m][2] = (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f);
+        geo[m][3] = (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f);
+        Urow[m] = UV + (int64_t)(first + s) * ld_uv + 4 * kh;
+        Vrow[m] = UV + (int64_t)(first + o) * ld_uv + HID1 + 4 * kh;
+    }
+    for (int i = tid; i < HID1; i += 256) *reinterpret_cast<float4*>(&Wgs[i * 4]) = *reinterpret_cast<const float4*>(Wg + i * 4);
+
+    floatx4 acc[2][NB16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) acc[m][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // W2 chunk c -> Bs[buf]: 5 DMA pieces per thread; a wavefront's 64 pieces of a pass are 1 KiB of contiguous LDS
+    const float4* W2p4 = reinterpret_cast<const float4*>(W2p);
+    auto dma_w2 = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const float4* src = W2p4 + (int64_t)c * (PB_CHUNK / 4) + 256 * i + tid;
+            float* dst = &Bs[buf][(256 * i + wave * 64) * 4];           // wave-uniform base; the hardware adds lane * 16 bytes
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    float4 ru[2], rv[2];
+    auto load_uv = [&](int k0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ru[m] = *reinterpret_cast<const float4*>(Urow[m] + k0);
+            rv[m] = *reinterpret_cast<const float4*>(Vrow[m] + k0);
+        }
+    };
+    auto make_a = [&](int k0, float (&a)[2][4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 g = *reinterpret_cast<const float4*>(&Wgs[(k0 + 4 * kh + c) * 4]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float uu = c == 0 ? ru[m].x : (c == 1 ? ru[m].y : (c == 2 ? ru[m].z : ru[m].w));
+                const float vv = c == 0 ? rv[m].x : (c == 1 ? rv[m].y : (c == 2 ? rv[m].z : rv[m].w));
+                const float z = uu + vv + (g.x * geo[m][0] + g.y * geo[m][1] + g.z * geo[m][2] + g.w * geo[m][3]);
+                a[m][c] = z > 0.f ? z : dfol_exp(z) - 1.0f;             // nn.ELU
+            }
+        }
+    };
+    const int boff = r16 * PB_CH + 4 * (kh ^ pb_swz(r16));
+
+    float a_cur[2][4], a_next[2][4];
+    const int nchunk = HID1 / PB_CH, lastc = nchunk - 1;
+    dma_w2(0, 0);
+    load_uv(0);
+    __syncthreads();                                        // Wgs and chunk 0 visible (the barrier drains the DMA)
+    make_a(0, a_cur);
+    load_uv(PB_CH * min(1, lastc));
+    int buf = 0;
+    for (int c = 0; c < nchunk; ++c, buf ^= 1) {
+        if (c < lastc) dma_w2(c + 1, buf ^ 1);              // lands in the other buffer while this chunk's MFMAs run
+        make_a(PB_CH * min(c + 1, lastc), a_next);
+        load_uv(PB_CH * min(c + 2, lastc));
+        const float* brow = &Bs[buf][boff];
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) {
+            float4 b4[HALF];
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+                if (part * HALF + i < NB16) b4[i] = *reinterpret_cast<const float4*>(brow + (part * HALF + i) * 16 * PB_CH);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < HALF; ++i)
+                    if (part * HALF + i < NB16) {
+                        const float bv = t == 0 ? b4[i].x : (t == 1 ? b4[i].y : (t == 2 ? b4[i].z : b4[i].w));
+                        acc[0][part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][t], bv, acc[0][part * HALF + i], 0, 0, 0);
+                        acc[1][part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][t], bv, acc[1][part * HALF + i], 0, 0, 0);
+                    }
+        }
+        __syncthreads();                                    // chunk c fully read; chunk c+1's DMA drained (vmcnt(0)) and visible
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a_cur[m][t] = a_next[m][t];
+    }
+
+    // The W2 ring is free now: stage the hidden bias and the requested embedding rows in it (one cooperative load instead of
+    // per-wavefront guarded global loads; the epilogue then reads them with immediate LDS offsets and needs no address registers).
+    // Padding columns get bias -1e30, whose Sigmoid is exactly 0.
+    constexpr int STAGE_ROWS = 2 * PB_CHUNK / PB_ROWS - 1;          // embedding rows that fit beside the bias (31)
+    float* stage = &Bs[0][0];
+    const int Kc = K < STAGE_ROWS ? K : STAGE_ROWS;
+    for (int i = tid; i < PB_ROWS; i += 256) stage[i] = i < HID2 ? b2[i] : -1.0e30f;
+    for (int k = 0; k < Kc; ++k) {
+        const int col = req_col[(int64_t)k * Q + q];
+        for (int i = tid; i < PB_ROWS; i += 256) stage[PB_ROWS * (1 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
+    }
+    __syncthreads();
+    const int64_t tile_sz = (int64_t)NS * NS;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) {
+            const float bv = stage[i * 16 + r16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + dfol_exp(-(acc[m][i][e] + bv)));
+        }
+        for (int k = 0; k < K; ++k) {
+            const int col = req_col[(int64_t)k * Q + q];
+            if (col < 0) continue;
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+            if (k < Kc) {
+                const float* erow = stage + PB_ROWS * (1 + k) + r16;
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) {
+                    const float ev = erow[i * 16];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[m][i][e], ev, part[e]);
+                }
+            } else {
+                const float* erow = E + (int64_t)col * ld_e;
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) {
+                    const float ev = erow[min(i * 16 + r16, HID2 - 1)];     // padding columns: activation is exactly 0
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[m][i][e], ev, part[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e] = dfol_group_sum<16>(part[e]);
+            if (r16 < 4) {
+                const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
+                const int ee = tb * 128 + wave * 32 + m * 16 + 4 * kh + r16;
+                if (ee < n * n) {
+                    const int ss = ee / n, oo = ee - ss * n;
+                    const float x = v + (be ? be[col] : 0.f);
+                    const float val = (ss == oo) ? dflt : fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+                    float* t = tiles + (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz;
+                    if (req_orient && req_orient[(int64_t)k * Q + q]) t[(int64_t)oo * NS + ss] = val;
+                    else t[(int64_t)ss * NS + oo] = val;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dfol_pair_pack_w2_f32(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, float* W2_packed, void* stream) {
+    DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % PB_CH == 0, "pair_pack_w2: HID1=%d must be a multiple of %d, <= 256", HID1, PB_CH);
+    DFOL_REQUIRE(HID2 > 0 && HID2 <= PB_ROWS, "pair_pack_w2: HID2=%d must be <= %d", HID2, PB_ROWS);
+    DFOL_REQUIRE(W2 && W2_packed && ld_w2 >= HID1, "pair_pack_w2: null pointer or ld_w2 < HID1");
+    DFOL_REQUIRE((uintptr_t)W2_packed % 16 == 0, "pair_pack_w2: output must be 16-byte aligned");
+    const int total = (HID1 / PB_CH) * PB_ROWS * 4;
+    hipLaunchKernelGGL(pair_pack_w2_kernel, dim3(dfol_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W2, ld_w2, HID2, HID1, W2_packed);
+    DFOL_LAUNCH_CHECK("pair_pack_w2");
+    return 0;
+}
+
+extern "C" int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                                       const float* W2_packed, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
+                                       const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
+                                       const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K,
+                                       int32_t NS, float default_ll, float* tiles, void* stream) {
+    DFOL_REQUIRE(Q >= 0 && K >= 0 && NS > 0 && NS % 4 == 0 && max_n >= 0 && max_n <= NS, "pair_ll_packed: bad sizes Q=%d K=%d NS=%d max_n=%d", Q, K, NS, max_n);
+    DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % PB_CH == 0 && ld_uv % 4 == 0, "pair_ll_packed: HID1=%d must be a multiple of %d, <= 256, UV rows 16-byte aligned", HID1, PB_CH);
+    DFOL_REQUIRE(HID2 > 0 && HID2 <= PB_ROWS, "pair_ll_packed: HID2=%d must be <= %d", HID2, PB_ROWS);
+    if (Q == 0 || K == 0 || max_n < 2) return 0;
+    DFOL_REQUIRE(UV && pos && Wg && W2_packed && b2 && E && n_obj && obj_off && req_col && req_tile && tiles, "pair_ll_packed: null pointer");
+    DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_packed % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll_packed: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    static const int rows = getenv("DFOL_PAIR_ROWS") ? atoi(getenv("DFOL_PAIR_ROWS")) : 32;
+    if (rows == 32 && HID2 > 256) {                         // 32 slots per wavefront, W2 by LDS-DMA
+        const int tpi2 = dfol_cdiv((int64_t)max_n * max_n, 128);
+        DFOL_REQUIRE((int64_t)Q * tpi2 < ((int64_t)1 << 31), "pair_ll_packed: too many tiles");
+        const dim3 grid2((unsigned)Q * tpi2);
+        if (HID2 <= 304)
+            hipLaunchKernelGGL((pair_ll32b_kernel<19>), grid2, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2_packed, b2, HID2, E, ld_e,
+                               be, n_obj, obj_off, Q, tpi2, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
+        else
+            hipLaunchKernelGGL((pair_ll32b_kernel<20>), grid2, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2_packed, b2, HID2, E, ld_e,
+                               be, n_obj, obj_off, Q, tpi2, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
+        DFOL_LAUNCH_CHECK("pair_ll_packed");
+        return 0;
+    }
+    const int tpi = dfol_cdiv((int64_t)max_n * max_n, 64);
+    DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_packed: too many tiles");
+    const dim3 grid((unsigned)Q * tpi);
+#define DFOL_PAIRB(NBV)                                                                                                              \
+    hipLaunchKernelGGL((pair_ll16b_kernel<NBV>), grid, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2_packed, b2, HID2, E, ld_e, be, \
+                       n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles)
+    // column tiles actually needed: 19 for the 300 hidden units of the reference's oracle
+    if (HID2 <= 64) DFOL_PAIRB(4);
+    else if (HID2 <= 128) DFOL_PAIRB(8);
+    else if (HID2 <= 192) DFOL_PAIRB(12);
+    else if (HID2 <= 256) DFOL_PAIRB(16);
+    else if (HID2 <= 304) DFOL_PAIRB(19);
+    else DFOL_PAIRB(20);
+#undef DFOL_PAIRB
+    DFOL_LAUNCH_CHECK("pair_ll_packed");
+    return 0;
+}

@@ -7,6 +7,8 @@ cached tables by csrc/dfol_logic.hip.  Parameter names match the reference's sta
 (`_network.1.weight`, ...) so its checkpoints load with strict=False.
 """
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -203,7 +205,11 @@ class ClassifierOracle(OracleBase):
             rows = (w.shape[0] + 31) // 32 * 32
             wp = torch.zeros(rows, w.shape[1], dtype=w.dtype, device=w.device)
             wp[:w.shape[0]] = w
-            self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0])
+            packed = None
+            if w.shape[1] % L.PACKED_W2_CHUNK == 0 and w.shape[1] <= 256 and w.shape[0] <= L.PACKED_W2_ROWS \
+                    and os.environ.get("DFOL_PAIR_PACKED", "1") != "0":
+                packed = L.pair_pack_w2(wp, w.shape[0])      # the layout of the occupancy-2 pair kernel (csrc/dfol_pair.hip)
+            self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0], packed)
         return self._w2_cache[1:]
 
     def prepare_scene(self, world, obj):
@@ -238,12 +244,17 @@ class ClassifierOracle(OracleBase):
 
     def _launch_pairs(self, world, req_col, req_tile, tiles, req_orient=None):
         _, _, wg, hid1, D = self._split_first_layer()
-        w2p, b2, hid2 = self._padded_second_layer()
+        w2p, b2, hid2, packed = self._padded_second_layer()
         emb = self._embedding_network.linear
         dev = world._device
-        L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, w2p, b2, emb.weight, emb.bias, world._n_obj,
-                  world._obj_off, max(world._n_list), torch.as_tensor(req_col).to(dev), torch.as_tensor(req_tile).to(dev),
-                  None if req_orient is None else torch.as_tensor(req_orient).to(dev), tiles, -30.0, hid2=hid2)
+        rc, rt = torch.as_tensor(req_col).to(dev), torch.as_tensor(req_tile).to(dev)
+        ro = None if req_orient is None else torch.as_tensor(req_orient).to(dev)
+        if packed is not None:
+            L.pair_ll_packed(world._uv, hid1, world._obj[:, D - 4:], wg, packed, b2, hid2, emb.weight, emb.bias, world._n_obj,
+                             world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
+        else:
+            L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, w2p, b2, emb.weight, emb.bias, world._n_obj,
+                      world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0, hid2=hid2)
 
     def _new_tiles(self, world, count):
         ragged = min(world._n_list) < world._NS

@@ -262,6 +262,19 @@ int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* 
                      const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS,
                      float default_ll, float* tiles, void* stream);
 
+/* The same relation tiles from a PACKED second layer (the geometry the full-size oracle uses: two independent 4-wavefront
+ * workgroups per CU, K chunks of 16, see dfol-vqa_amd/csrc/dfol_pair.hip).  W2_packed is produced once per weight update by
+ * dfol_pair_pack_w2_f32 ((HID1/16)*320*16 floats, 16-byte aligned): chunk-major [HID1/16][320][16], rows >= HID2 zero,
+ * k-groups swizzled for conflict-free LDS reads.  All other arguments as dfol_pair_ll_f32.
+ * Limits: HID1 <= 256 and a multiple of 16, HID2 <= 320.
+ */
+int dfol_pair_pack_w2_f32(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, float* W2_packed, void* stream);
+int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                            const float* W2_packed, const float* b2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
+                            const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n, const int32_t* req_col,
+                            const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
+                            float* tiles, void* stream);
+
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B.  g_* outputs that are NULL are skipped.
  * g_prior* ([Q, NS]) are ACCUMULATED into (several predicates may share a question's prior): zero them first.

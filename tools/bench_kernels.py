@@ -97,6 +97,12 @@ def main():
         t = timeit(lambda: L.pair_ll(uv, HID1, pos, wg, w2, b2, E, be, n_o, off, N, req_col, req_tile, None, tiles, hid2=HID2), iters=10)
         fl = 2.0 * Q * N * (N - 1) * (4 * HID1 + HID1 * HID2 + HID2 * K)
         out.append({"kernel": "pair_ll", "Q": Q, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
+        ref = tiles.clone()
+        w2p = L.pair_pack_w2(w2, HID2)
+        tiles.zero_()
+        t = timeit(lambda: L.pair_ll_packed(uv, HID1, pos, wg, w2p, b2, HID2, E, be, n_o, off, N, req_col, req_tile, None, tiles), iters=10)
+        out.append({"kernel": "pair_ll_packed", "Q": Q, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                    "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK, "max_abs_diff_vs_pair_ll": (tiles[:, :N, :N] - ref[:, :N, :N]).abs().max().item()})
     for r in out:
         print(json.dumps(r))
 

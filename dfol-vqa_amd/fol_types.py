@@ -40,6 +40,27 @@ def _pad4(n):
     return max(4, (int(n) + 3) // 4 * 4)
 
 
+_geometry_cache = {}
+
+
+def _geometry_on_device(device, n_list):
+    """Geometry tensors of a batch (object counts, object / pair offsets, identity map), kept on the device per distinct shape:
+    a pageable host-to-device copy synchronises the stream, and a ProgramBatch that is run again (every training epoch, every
+    benchmark step) would pay that several times per forward."""
+    key = (str(device), n_list)
+    hit = _geometry_cache.get(key)
+    if hit is None:
+        if len(_geometry_cache) >= 256:
+            _geometry_cache.clear()
+        n = np.asarray(n_list, np.int64)
+        hit = (torch.as_tensor(n.astype(np.int32)).to(device),
+               torch.as_tensor(np.concatenate([[0], np.cumsum(n)]).astype(np.int32)).to(device),
+               torch.as_tensor(np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)).to(device),
+               torch.arange(len(n_list), dtype=torch.int32, device=device))
+        _geometry_cache[key] = hit
+    return hit
+
+
 class BatchWorld(object):
     """Scene of one ProgramBatch (batch_base_types.py:191-252): likelihood tables + the block geometry."""
 
@@ -63,11 +84,8 @@ class BatchWorld(object):
         self._batch_size = len(self._n_list)
         self._NS = _pad4(max(self._n_list))
         n = np.asarray(self._n_list, np.int64)
-        self._n_obj = torch.as_tensor(n.astype(np.int32)).to(device)
-        self._obj_off = torch.as_tensor(np.concatenate([[0], np.cumsum(n)]).astype(np.int32)).to(device)
-        self._pair_off = torch.as_tensor(np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)).to(device)
+        self._n_obj, self._obj_off, self._pair_off, self._ident = _geometry_on_device(device, tuple(self._n_list))
         self._pair_num = int((n * (n - 1)).sum())
-        self._ident = torch.arange(self._batch_size, dtype=torch.int32, device=device)
         self._zeros = None
 
     # The reference's cached tables ([O, 2335] and [pairs, 333]).  In needed-columns mode they are materialised

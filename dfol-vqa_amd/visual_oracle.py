@@ -247,8 +247,9 @@ class ClassifierOracle(OracleBase):
         w2p, b2, hid2, packed = self._padded_second_layer()
         emb = self._embedding_network.linear
         dev = world._device
-        rc, rt = torch.as_tensor(req_col).to(dev), torch.as_tensor(req_tile).to(dev)
-        ro = None if req_orient is None else torch.as_tensor(req_orient).to(dev)
+        up = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a).to(dev)
+        rc, rt = up(req_col), up(req_tile)
+        ro = None if req_orient is None else up(req_orient)
         if packed is not None:
             L.pair_ll_packed(world._uv, hid1, world._obj[:, D - 4:], wg, packed, b2, hid2, emb.weight, emb.bias, world._n_obj,
                              world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
@@ -292,27 +293,44 @@ class ClassifierOracle(OracleBase):
             return
         total = sum(len(e[0].cols) for e in entries)
         tiles = self._new_tiles(world, total)
-        rows_col, rows_tile, rows_orient, base = [], [], [], 0
+        # the request arrays depend on the program batch only: build and upload them once per batch (a pageable upload
+        # synchronises the stream), keyed by what else they depend on
+        key = (id(self), Q, tuple((e[0].cols.tobytes(), e[0].valid.tobytes(), np.asarray(e[1]).tobytes(), e[2].tobytes()) for e in entries))
+        plan = getattr(program_batch, "_dfol_rel_plan", None)
+        if plan is None or plan[0] != key:
+            rows_col, rows_tile, rows_orient, invalid, base = [], [], [], [], 0
+            for low, pq, orient in entries:
+                P = len(pq)
+                slot = np.zeros(P, np.int64)               # j-th predicate of its question
+                seen = {}
+                for p, q in enumerate(pq):
+                    slot[p] = seen.get(int(q), 0)
+                    seen[int(q)] = slot[p] + 1
+                K = int(slot.max()) + 1
+                col = np.full((K, Q), -1, np.int32)
+                til = np.zeros((K, Q), np.int32)
+                ori = np.zeros((K, Q), np.uint8)
+                col[slot, pq] = self._relation_full_columns(low.cols)
+                til[slot, pq] = base + np.arange(P, dtype=np.int32)
+                ori[slot, pq] = orient
+                rows_col.append(col), rows_tile.append(til), rows_orient.append(ori)
+                if not low.all_valid:
+                    invalid.append(base + np.nonzero(low.valid == 0)[0])
+                base += P
+            dev = world._device
+            plan = (key, torch.as_tensor(np.concatenate(rows_col)).to(dev), torch.as_tensor(np.concatenate(rows_tile)).to(dev),
+                    torch.as_tensor(np.concatenate(rows_orient)).to(dev),
+                    torch.as_tensor(np.concatenate(invalid)).to(dev) if invalid else None)
+            program_batch._dfol_rel_plan = plan
+        _, req_col, req_tile, req_orient, invalid = plan
+        if invalid is not None and not (min(world._n_list) < world._NS):
+            tiles[invalid] = -30.0
+        base = 0
         for low, pq, orient in entries:
             P = len(pq)
-            slot = np.zeros(P, np.int64)               # j-th predicate of its question
-            seen = {}
-            for p, q in enumerate(pq):
-                slot[p] = seen.get(int(q), 0)
-                seen[int(q)] = slot[p] + 1
-            K = int(slot.max()) + 1
-            col = np.full((K, Q), -1, np.int32)
-            til = np.zeros((K, Q), np.int32)
-            ori = np.zeros((K, Q), np.uint8)
-            col[slot, pq] = self._relation_full_columns(low.cols)
-            til[slot, pq] = base + np.arange(P, dtype=np.int32)
-            ori[slot, pq] = orient
-            rows_col.append(col), rows_tile.append(til), rows_orient.append(ori)
-            if not low.all_valid and not (min(world._n_list) < world._NS):
-                tiles[base + torch.as_tensor(np.nonzero(low.valid == 0)[0]).to(world._device)] = -30.0
             world._rel_tiles[id(low)] = (tiles[base:base + P], orient)
             base += P
-        self._launch_pairs(world, np.concatenate(rows_col), np.concatenate(rows_tile), tiles, np.concatenate(rows_orient))
+        self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
 
     def oriented_tiles(self, world, low):
         """Prefetched tiles of a relate operator, each stored with its summed-out variable along rows (or None)."""

@@ -237,45 +237,43 @@ extern "C" int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t 
 // Needed-columns oracle: only the likelihoods a program asks for are ever computed.
 // =====================================================================================================
 // Attribute likelihood of one (image, concept) request: ll[p][o] = LogSigmoid(hidden[o] . E[col] + be[col]).
-// One wavefront per predicate; lanes stride the hidden dimension (coalesced), one wave reduction per object.
+// A workgroup owns 16 objects of one predicate (four per wavefront, all in flight at once); lanes stride the hidden
+// dimension (coalesced), the per-object dot products are reduced with DPP (no LDS traffic).
 __global__ __launch_bounds__(256) void attr_ll_kernel(const float* __restrict__ hidden, int64_t ld_h, int H,
                                                       const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be,
                                                       const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q,
                                                       const int32_t* __restrict__ pred_col, int P, int NS, float dflt,
                                                       float* __restrict__ ll) {
-    const int p = blockIdx.x;                               // one workgroup per predicate, its objects split over 4 wavefronts
+    const int p = blockIdx.x;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o0 = blockIdx.y * 16 + 4 * wv;                // this wavefront's four objects
     const int q = pred_q[p], col = pred_col[p];
     const int first = obj_off[q], n = obj_off[q + 1] - first;
     float* out = ll + (int64_t)p * NS;
-    if (col < 0) {
-        for (int o = threadIdx.x; o < NS; o += 256) out[o] = dflt;
+    if (col < 0 || o0 >= n) {                               // no-op token, or padding columns: the absent value
+        if (lane < 4 && o0 + lane < NS) out[o0 + lane] = dflt;
         return;
     }
     float e[8];                                            // H <= 512
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = (lane + 64 * j < H) ? E[(int64_t)col * ld_e + lane + 64 * j] : 0.f;
     const float bias = be ? be[col] : 0.f;
-    for (int o0 = 4 * wv; o0 < n; o0 += 16) {                // four objects in flight per wavefront and iteration
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int o = min(o0 + u, n - 1);
-            const float* h = hidden + (int64_t)(first + o) * ld_h;
+    for (int u = 0; u < 4; ++u) {
+        const int o = min(o0 + u, n - 1);
+        const float* h = hidden + (int64_t)(first + o) * ld_h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (lane + 64 * j < H) s[u] = fmaf(h[lane + 64 * j], e[j], s[u]);
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], m, 64);
-        if (lane < 4 && o0 + lane < n) {
-            const float x = (lane == 0 ? s[0] : lane == 1 ? s[1] : lane == 2 ? s[2] : s[3]) + bias;
-            out[o0 + lane] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));       // nn.LogSigmoid
-        }
+        for (int j = 0; j < 8; ++j)
+            if (lane + 64 * j < H) s[u] = fmaf(h[lane + 64 * j], e[j], s[u]);
     }
-    for (int o = n + threadIdx.x; o < NS; o += 256) out[o] = dflt;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = dfol_group_sum<64>(s[u]);     // totals are valid in lanes 48..63
+    if (lane >= 60 && o0 + (lane - 60) < NS) {
+        const int u = lane - 60;
+        const float x = (u == 0 ? s[0] : u == 1 ? s[1] : u == 2 ? s[2] : s[3]) + bias;
+        out[o0 + u] = (o0 + u < n) ? fminf(x, 0.f) - log1pf(expf(-fabsf(x))) : dflt;       // nn.LogSigmoid
+    }
 }
 
 extern "C" int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t H, const float* E, int64_t ld_e, const float* be,
@@ -284,7 +282,7 @@ extern "C" int dfol_attr_ll_f32(const float* hidden, int64_t ld_hidden, int32_t 
     DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && H > 0 && H <= 512, "attr_ll: bad sizes P=%d NS=%d H=%d (H <= 512)", P, NS, H);
     if (P == 0) return 0;
     DFOL_REQUIRE(hidden && E && obj_off && pred_q && pred_col && ll, "attr_ll: null pointer");
-    hipLaunchKernelGGL(attr_ll_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, hidden, ld_hidden, H, E, ld_e, be,
+    hipLaunchKernelGGL(attr_ll_kernel, dim3(P, dfol_cdiv(NS, 16)), dim3(256), 0, (hipStream_t)stream, hidden, ld_hidden, H, E, ld_e, be,
                        obj_off, pred_q, pred_col, P, NS, default_ll, ll);
     DFOL_LAUNCH_CHECK("attr_ll");
     return 0;

@@ -41,6 +41,7 @@ def _pad4(n):
 
 
 _geometry_cache = {}
+_pair_index_cache = {}
 
 
 def _geometry_on_device(device, n_list):
@@ -143,14 +144,21 @@ class BatchWorld(object):
     def pair_index(self):
         """(subject row, object row) of every ordered same-image pair, in the reference's order (util.py:87-103)."""
         if getattr(self, "_pair_idx", None) is None:
-            s_all, o_all, first = [], [], 0
-            for n in self._n_list:
-                s, o = np.nonzero(~np.eye(n, dtype=bool))
-                s_all.append(s + first)
-                o_all.append(o + first)
-                first += n
-            self._pair_idx = (torch.as_tensor(np.concatenate(s_all).astype(np.int64)).to(self._device),
-                              torch.as_tensor(np.concatenate(o_all).astype(np.int64)).to(self._device))
+            key = (str(self._device), tuple(self._n_list))
+            hit = _pair_index_cache.get(key)
+            if hit is None:
+                s_all, o_all, first = [], [], 0
+                for n in self._n_list:
+                    s, o = np.nonzero(~np.eye(n, dtype=bool))
+                    s_all.append(s + first)
+                    o_all.append(o + first)
+                    first += n
+                hit = (torch.as_tensor(np.concatenate(s_all).astype(np.int64)).to(self._device),
+                       torch.as_tensor(np.concatenate(o_all).astype(np.int64)).to(self._device))
+                if len(_pair_index_cache) >= 8:          # 16 bytes per ordered pair: keep a handful of batch shapes
+                    _pair_index_cache.clear()
+                _pair_index_cache[key] = hit
+            self._pair_idx = hit
         return self._pair_idx
 
     def zeros_attention(self):

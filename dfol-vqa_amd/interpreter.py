@@ -97,16 +97,17 @@ class BatchInterpreterBase(nn.Module):
             raise NotImplementedError("a featurizer is required (the reference's featurizer-less branch :62-67 is dead code)")
         geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
                               attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums)
-        # the fused needed-columns kernels are forward-only: they are used whenever no gradient has to reach the oracle's
-        # or the featurizer's weights (inference, and the calibrator-only phases cur6-7 where both are frozen)
+        # needed-columns mode: no pair matrix, no full tables; the oracle keeps hidden activations and evaluates the concept
+        # columns a program names.  The fused kernels are forward-only: they run whenever no gradient has to reach the oracle's
+        # or the featurizer's weights (inference, and the calibrator-only phases cur6-7 where both are frozen); when those
+        # weights train, the same columns come from differentiable tensor ops (visual_oracle._*_autograd).
         oracle_trains = torch.is_grad_enabled() and any(p.requires_grad for m in (self._oracle, self._featurizer)
                                                         if isinstance(m, nn.Module) for p in m.parameters())
-        needed = self._cached and not oracle_trains and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
+        needed = self._cached and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
             getattr(self._oracle, "supports_needed_columns", lambda: False)()
         if needed:
-            # needed-columns mode: no pair matrix, no full tables; the oracle keeps hidden activations instead
             features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=None)
-            self._oracle.prepare_scene(geometry, features['attribute_features'])
+            self._oracle.prepare_scene(geometry, features['attribute_features'], train=oracle_trains)
             return geometry
         if 'world_geometry' in inspect.signature(self._featurizer.featurize_scene).parameters:
             features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=geometry)

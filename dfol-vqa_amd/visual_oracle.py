@@ -137,14 +137,16 @@ class ClassifierOracle(OracleBase):
         self._cached = cached
         self._needed_columns = True       # compute only the likelihood columns a program asks for (when the MLP shape allows)
         self._split_cache = None
+        self._index_cache = {}
 
     # ---- a3: the cached tables (classifier_oracle.py:145-156) ------------------------------------------
     def _relation_embedding(self):
         """Rows of the embedding layer that are relations ([:, relation_index] commutes with the GEMM)."""
         lin = self._embedding_network.linear
         idx = torch.as_tensor(self._ontology._relation_index, dtype=torch.int64, device=lin.weight.device)
-        w = lin.weight.detach().index_select(0, idx).contiguous()
-        b = None if lin.bias is None else lin.bias.detach().index_select(0, idx).contiguous()
+        live = torch.is_grad_enabled() and lin.weight.requires_grad      # training: the relation rows receive gradient too
+        w = (lin.weight if live else lin.weight.detach()).index_select(0, idx).contiguous()
+        b = None if lin.bias is None else (lin.bias if live else lin.bias.detach()).index_select(0, idx).contiguous()
         return w, b
 
     def compute_all_log_likelihood_2(self, object_features, pair_object_features):
@@ -212,16 +214,105 @@ class ClassifierOracle(OracleBase):
             self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0], packed)
         return self._w2_cache[1:]
 
-    def prepare_scene(self, world, obj):
-        """Hidden activations of a scene: attribute hidden [O, H] and the per-object halves of the pair MLP's first layer."""
+    def prepare_scene(self, world, obj, train=False):
+        """Hidden activations of a scene: attribute hidden [O, H] and the per-object halves of the pair MLP's first layer.
+        train=True: gradients must reach the oracle / featurizer weights; the requested columns are then evaluated by
+        differentiable tensor ops (library GEMMs) instead of the fused forward-only kernels, still without the full tables."""
         world._lazy = self
         world._obj = obj
+        world._train = bool(train)
         world._hidden_attr = self._attribute_network(obj)
+        world._attr_table = None
+        world._rel_table = None
+        world._pair_h = None
+        if train:
+            return
         wuv, buv, wg, hid1, D = self._split_first_layer()
         assert obj.shape[1] == D, "object feature width does not match the relation network"
         world._uv = L.linear_act(obj, wuv, buv, L.ACT_NONE)
-        world._attr_table = None
-        world._rel_table = None
+
+    # ---- needed columns with gradients (training of the oracle, trainer.py:429-442) ------------------------------
+    def _pair_hidden_autograd(self, world):
+        """h = Sigmoid(W2 ELU(W1 [obj_s, obj_o, geo] + b1) + b2) for every ordered pair [pairs, HID2], with the first layer split
+        per object exactly as the fused kernel does; one evaluation per scene, shared by all relation operators."""
+        if world._pair_h is None:
+            lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+            obj = world._obj
+            D = (lin1.weight.shape[1] - 4) // 2
+            assert obj.shape[1] == D, "object feature width does not match the relation network"
+            s_idx, o_idx = world.pair_index()
+            U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias)
+            V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
+            pos = obj[:, D - 4:].detach()                       # batch_gqa_boxfeatures_pipeline.py:263-279
+            ps, po = pos.index_select(0, s_idx), pos.index_select(0, o_idx)
+            dx = ps[:, 0] + ps[:, 2] / 2.0 - po[:, 0] - po[:, 2] / 2.0
+            dy = ps[:, 1] + ps[:, 3] / 2.0 - po[:, 1] - po[:, 3] / 2.0
+            dist = torch.sqrt(dx * dx + dy * dy)
+            geo = torch.stack([dist, torch.asin(dy / dist.clamp(min=1e-10)), torch.sign(po[:, 0] - ps[:, 0]),
+                               torch.sign(po[:, 1] - ps[:, 1])], 1)
+            z = nn.functional.elu(U.index_select(0, s_idx) + V.index_select(0, o_idx)
+                                  + nn.functional.linear(geo, lin1.weight[:, 2 * D:2 * D + 4]))
+            world._pair_h = torch.sigmoid(nn.functional.linear(z, lin2.weight, lin2.bias))
+        return world._pair_h
+
+    def _relation_tiles_autograd(self, world, low, pred_q_host):
+        """[P, NS, NS] tiles (subjects along rows) of the requested relation columns, differentiable."""
+        emb = self._embedding_network.linear
+        dev = world._device
+        full = self._relation_full_columns(low.cols)
+        pq = np.asarray(list(pred_q_host), np.int64)
+        P, NS = len(pq), world._NS
+        n = np.asarray(world._n_list, np.int64)
+        pair_off = np.concatenate([[0], np.cumsum(n * (n - 1))])
+        flat = torch.full((P * NS * NS,), -30.0, dtype=torch.float32, device=dev)
+        if world._pair_num == 0:
+            return flat.view(P, NS, NS)
+        h = self._pair_hidden_autograd(world)
+        for c in np.unique(full[full >= 0]):
+            preds = np.nonzero(full == c)[0]
+            q = pq[preds]
+            cnt = n[q] * (n[q] - 1)
+            if cnt.sum() == 0:
+                continue
+            key = ("rel", str(dev), tuple(world._n_list), NS, preds.tobytes(), q.tobytes())
+            hit = self._index_cache.get(key)
+            if hit is None:                                   # gather / scatter indices depend on the batch shape only: upload once
+                rep = np.repeat(np.arange(len(preds)), cnt)
+                k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+                nq = n[q][rep]
+                s_, o_ = k // (nq - 1), k % (nq - 1)
+                o_ = o_ + (o_ >= s_)                          # pairs are row-major in s with the diagonal left out (util.py:87-103)
+                hit = (torch.as_tensor(pair_off[q][rep] + k).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev))
+                if len(self._index_cache) >= 32:
+                    self._index_cache.clear()
+                self._index_cache[key] = hit
+            src, dst = hit
+            x = h.index_select(0, src) @ emb.weight[int(c)] + emb.bias[int(c)]
+            flat = flat.index_put((dst,), nn.functional.logsigmoid(x))
+        return flat.view(P, NS, NS)
+
+    def _attr_ll_autograd(self, world, low, pred_q_host):
+        """[P, NS] blocks of the requested attribute columns, differentiable."""
+        emb = self._embedding_network.linear
+        dev = world._device
+        cols = np.asarray(low.cols, np.int64)
+        pq = np.asarray(list(pred_q_host), np.int64)
+        P, NS = len(pq), world._NS
+        n = np.asarray(world._n_list, np.int64)
+        obj_off = np.concatenate([[0], np.cumsum(n)])
+        flat = torch.full((P * NS,), -30.0, dtype=torch.float32, device=dev)
+        preds = np.nonzero(cols >= 0)[0]
+        if len(preds) == 0:
+            return flat.view(P, NS)
+        q = pq[preds]
+        cnt = n[q]
+        rep = np.repeat(np.arange(len(preds)), cnt)
+        k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        src = torch.as_tensor(obj_off[q][rep] + k).to(dev)
+        dst = torch.as_tensor(preds[rep] * NS + k).to(dev)
+        col = torch.as_tensor(cols[preds][rep]).to(dev)
+        x = (world._hidden_attr.index_select(0, src) * emb.weight.index_select(0, col)).sum(1) + emb.bias.index_select(0, col)
+        return flat.index_put((dst,), nn.functional.logsigmoid(x)).view(P, NS)
 
     def materialize_tables(self, world):
         """Full cached tables exactly as the reference builds them (only when a caller reads them)."""
@@ -266,7 +357,7 @@ class ClassifierOracle(OracleBase):
     def prefetch_relations(self, world, program_batch):
         """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel /
         choose_rel): the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
-        if world._lazy is None:
+        if world._lazy is None or getattr(world, "_train", False):
             return
         Q = world._batch_size
         entries = []                                   # (lowered tokens, predicate -> question, per-predicate orientation)
@@ -398,7 +489,11 @@ class ClassifierOracle(OracleBase):
         """The same blocks as the cached-table gathers, computed from the hidden activations for the requested columns only."""
         dev = world._device
         emb = self._embedding_network.linear
-        if token_type == TokenType.ATTRIBUTE:
+        if getattr(world, "_train", False):
+            assert orientation == L.TILE_SUBJECT_ROWS
+            ll = self._attr_ll_autograd(world, low, pred_q_host) if token_type == TokenType.ATTRIBUTE \
+                else self._relation_tiles_autograd(world, low, pred_q_host)
+        elif token_type == TokenType.ATTRIBUTE:
             ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
         else:
             assert orientation == L.TILE_SUBJECT_ROWS

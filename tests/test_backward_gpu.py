@@ -166,6 +166,35 @@ def test_train_step_changes_parameters_and_lowers_loss(ontology):
     assert all(np.isfinite(l) for l in losses)
 
 
+@pytest.mark.parametrize("name", ["binary", "query_rel"])
+@pytest.mark.parametrize("needed", [True, False])
+def test_g12_weight_gradients(ontology, name, needed):
+    """Gradients of the train-step loss w.r.t. every weight (featurizer, attribute / relation MLPs, embedding layer) equal the
+    reference's own autograd (golden g12), on both training dataflows: the needed-columns one and the full cached tables."""
+    a, meta = gu.load("g12_weight_gradients")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights).train()
+    model._oracle._needed_columns = needed
+    qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+           "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}}
+          for i, q in enumerate(meta["sets"][name]["questions"])]
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(qs)]
+    res = model(pbs, True)
+    loss = training.compute_loss(pbs, res) / len(qs)
+    loss.backward()
+    l32, l64 = float(a[name + ":loss_f32"]), float(a[name + ":loss_f64"])
+    assert abs(float(loss.detach()) - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (float(loss.detach()), l32, l64)
+    checked = 0
+    for pname, prm in model.named_parameters():
+        key = "%s:g:%s:f64" % (name, pname)
+        if key not in a.files:
+            continue
+        g = np.zeros_like(a[key]) if prm.grad is None else prm.grad.detach().cpu().numpy()
+        grad_close(g, a[key[:-3] + "f32"], a[key], "%s d%s (needed=%s)" % (name, pname, needed))
+        checked += 1
+    assert checked == 12
+
+
 def test_calibrator_phase_train_step(ontology):
     """cur6-7 style: oracle frozen, only the attention-calibration networks train; the forward runs on the fused
     needed-columns kernels and the gradient reaches the LSTMs through the modulate op."""

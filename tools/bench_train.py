@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Train-step throughput (BASELINE configs[3] shape on one GPU): forward + loss + backward + clip + Adam on one resident batch.
+
+usage: python tools/bench_train.py [--objects 36] [--batch 256] [--steps 5] [--warmup 2]
+Prints one JSON line (questions/s of training).  With more than one rank (torchrun) the gradients are summed with one
+all-reduce of the flat bucket per step (dfol_vqa_amd.parallel), as trainer.py:429-442 does through nn.DataParallel.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--objects", type=int, default=36)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=device)
+        group = td.group.WORLD
+    from dfol_vqa_amd import experiment, training
+    from dfol_vqa_amd import synthetic as syn
+    tmp = tempfile.mkdtemp(prefix="dfol_train_")
+    paths, names = syn.write_synthetic_ontology(tmp)
+    cfg = syn.reference_config(paths, dropout=0.0, freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+                               freeze_embedding_network=False)     # the oracle-training phases (cur1-5) of the curriculum
+    ontology = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ontology)
+    bench.init_weights(model)
+    model = model.to(device).train()
+    _, pbs = bench.build_batch(args, rank, ontology, names, device)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(args.warmup):
+        loss, _ = training.train_batch(model, opt, pbs, 0.65, global_batch_size=args.batch * world, group=group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = training.train_batch(model, opt, pbs, 0.65, global_batch_size=args.batch * world, group=group)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    if rank == 0:
+        print(json.dumps({"metric": "training questions/s (forward + backward + Adam)", "value": args.batch * world / dt, "ms_per_step": dt * 1e3,
+                          "n_gpus": world, "objects": args.objects, "batch_per_gpu": args.batch, "loss": loss,
+                          "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
+
+
+if __name__ == "__main__":
+    main()

@@ -494,6 +494,79 @@ def g5():
     save("g5_neural_oracle", arrays, meta)
 
 
+# ---------------------------------------------------------------------------------------- g12
+def g12():
+    """Gradients of the train-step loss w.r.t. every weight of the neural model (featurizer, attribute / relation MLPs, embedding
+    layer) at reduced dims, from the reference's own autograd (trainer.py:181-262, 429-442), for a BINARY and a QUERY batch."""
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_interpreter_experiments as gie
+    from nsvqa.train.trainer import VQATrainer
+    fake = types.SimpleNamespace(_device=torch.device("cpu"), _config={})
+    cfg = dict(box_features_dim=32, oracle_input_dim=16, oracle_output_dim=1, word_embedding_dim=mini_ontology.EMBEDDING_DIM,
+               classifier_oracle=True, featurizer_layers_config=[], attribute_network_layers_config=[8],
+               relation_network_layers_config=[8], operator_layers_config=[], normalize_oracle=True, dropout=0.0,
+               freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+               freeze_embedding_network=False, activate_attention_transfer=False, attention_transfer_state_dim=0,
+               freeze_attention_network=False, trainable_gate=False, likelihood_threshold=0, hard_mode=False,
+               verbose=False, model_name="g12", gpu_num=1)
+    exp = gie.GQAObjectBoxExperiment()
+    exp._local_rank = 0
+    torch.manual_seed(1)
+    model = exp.build_model(cfg, ontology, None)
+    model.train()
+    Q = syn.question
+    n_list = [5, 7, 4, 6]
+    sets = {
+        "binary": [Q(900 + i, [[op("select", "dog"), op("filter", "red"), op("relate", "on", bool(i % 2), "table")]], op("exist"),
+                     "yes" if i % 2 == 0 else "no", syn.feature_scene(900 + i, n, cfg["box_features_dim"])) for i, n in enumerate(n_list)],
+        "query_rel": [Q(920 + i, [[op("select", "man"), op("filter", "not(small)")]], op("choose_rel", ["on", "under"], bool(i % 2), "table"),
+                        "on" if i % 2 == 0 else "under", syn.feature_scene(920 + i, n, cfg["box_features_dim"])) for i, n in enumerate(n_list)],
+    }
+    arrays, meta = {}, {"source": "trainer.py:181-262,429-442; gqa_interpreter_experiments.py:18-77,107-240", "config": cfg, "sets": {}}
+    for k, v in model.state_dict().items():
+        if k.startswith("_featurizer.") or k.startswith("_oracle."):
+            arrays["w:" + k] = v.numpy().copy()
+    for name, qs in sets.items():
+        for i, q in enumerate(qs):
+            arrays["%s:X_%d" % (name, i)] = q["scene"]["X"]
+        for dt, tag in both_dtypes():
+            m = copy.deepcopy(model).double() if dt == torch.float64 else copy.deepcopy(model)
+            m.train()
+            collater = ref_harness.make_collater(ref, 1, "feature")
+            pbs = collater.collate(copy.deepcopy(qs))
+            for pb in pbs:
+                pb.create_sparse_tensors()
+                if dt == torch.float64:
+                    pb.to(torch.float64)
+                    pb._object_batch_index = pb._object_batch_index.long()
+            res = m(pbs, True, return_trace=False)
+            lp = res["log_probability"]
+            if dt == torch.float64:           # trainer.py:185-194,207-230 restated in fp64 (its targets are built in fp32)
+                if res["type"] == ref.base_types.QuestionType.BINARY:
+                    target = torch.tensor([a == "yes" for pb in pbs for a in pb._answers], dtype=dt)
+                    loss = torch.nn.functional.binary_cross_entropy(lp.exp(), target, reduction="sum")
+                else:
+                    answers = [a for pb in pbs for a in pb._answers]
+                    target = [[a == o for o in opt] for a, opt in zip(answers, res["options"])]
+                    seg = torch.tensor([i for i, t in enumerate(target) for _ in t])
+                    tflat = torch.tensor([x for t in target for x in t], dtype=dt)
+                    denom = torch.zeros(len(target), dtype=dt).index_add(0, seg, lp.exp())
+                    loss = ref.util.safe_log(denom).sum() - (tflat * lp).sum()
+            else:
+                loss = VQATrainer._compute_loss(fake, pbs, res)
+            loss = loss / sum(pb.batch_size() for pb in pbs)
+            loss.backward()
+            arrays["%s:loss_%s" % (name, tag)] = loss.detach().numpy()
+            arrays["%s:lp_%s" % (name, tag)] = lp.detach().numpy()
+            seen = set()
+            for k, prm in m.named_parameters():
+                if (k.startswith("_featurizer.") or k.startswith("_oracle.")) and id(prm) not in seen:
+                    seen.add(id(prm))
+                    arrays["%s:g:%s:%s" % (name, k, tag)] = (torch.zeros_like(prm) if prm.grad is None else prm.grad).detach().numpy()
+        meta["sets"][name] = {"questions": questions_to_meta(qs)}
+    save("g12_weight_gradients", arrays, meta)
+
+
 # ---------------------------------------------------------------------------------------- g6
 def g6():
     """Loss values and gradients w.r.t. the tables (trainer.py:181-262) for BINARY and QUERY batches."""
@@ -752,7 +825,7 @@ def g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()
 

@@ -346,6 +346,49 @@ def test_needed_columns_full_size_model(tmp_path):
     assert res_needed["answer"] == res_full["answer"] == r64["answer"]
 
 
+@pytest.mark.parametrize("n_list,hops", [([100, 37, 64, 9], 1), ([256, 130], 4)])
+def test_full_size_model_large_scenes(tmp_path, n_list, hops):
+    """Full-size oracle on N = 100 (ragged, several pair tiles per image) and on BASELINE configs[4]'s shape: 256-object scenes and
+    8-hop open programs select -> (filter -> relate) x 4 -> query_attr.  Fused needed-columns path == full cached tables == oracle."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(2)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nouns, attrs, rels = names["nouns"][:6], names["attributes"][:5], names["relations"][:4]
+    rng = np.random.RandomState(len(n_list) + hops)
+    pick = lambda xs: xs[rng.randint(len(xs))]
+    qs, scenes = [], []
+    for i, n in enumerate(n_list):
+        branch = [syn.op("select", pick(nouns))]
+        for _ in range(hops):
+            branch += [syn.op("filter", pick(attrs)), syn.op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"]))]
+        last = syn.op("query_attr", "category%02d" % (i % 3)) if hops > 1 else syn.op("exist")     # 26 options per question
+        qs.append(syn.question(4000 + i, [branch], last, "yes"))
+        scenes.append(syn.feature_scene(4000 + i, n, 2048))
+    res_needed, _ = run(model, qs, scenes, ont, key="X")
+    model._oracle._needed_columns = False
+    res_full, _ = run(model, qs, scenes, ont, key="X")
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights)
+    r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights)
+    # eight hops of 256-object aggregations: the fp32 oracle itself is 6e-2 off its fp64 run on this batch, and an output both runs
+    # happen to agree on is not thereby well-conditioned along the way; the 1e-4 bar is kept for the 3-hop case
+    tol = 1e-4 if hops == 1 else 5e-4
+    for res, tag in ((res_needed, "needed"), (res_full, "full")):
+        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "large:" + tag, lp_tol=tol)
+    d = (res_needed["log_probability"] - res_full["log_probability"]).abs().max().item()
+    assert d <= (2e-4 if hops == 1 else 1e-3), d
+    dp = (res_needed["log_probability"].exp() - res_full["log_probability"].exp()).abs().max().item()
+    assert dp <= 1e-5, dp
+
+
 # ---------------------------------------------------------------------------------------------------
 # attention calibration (SURVEY.md §8(f) rank 2): LSTM passes + apply_modulations against the reference (g10)
 # ---------------------------------------------------------------------------------------------------

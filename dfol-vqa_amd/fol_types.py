@@ -175,7 +175,8 @@ class BatchWorld(object):
             if m.is_sparse:
                 m = m.coalesce().indices()[1]
             return m.to(device=self._device, dtype=torch.int32)
-        return torch.as_tensor(np.asarray(m, np.int32)).to(self._device)
+        from .host_util import upload                        # (host_util imports this module)
+        return upload(np.asarray(m, np.int32), self._device)        # a python list (the operators' batch_index)
 
     def to_flat(self, block, pred_q=None, fill=0.0):
         """[P, NS] blocks -> the reference's flat [P, total_obj] rows (own image filled, the rest `fill`)."""

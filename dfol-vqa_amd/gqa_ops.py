@@ -14,7 +14,7 @@ import torch
 
 from . import ops as L
 from .fol_types import BatchVariableSet, Quantifier, QuestionType, TokenType
-from .host_util import TokenList, find_max_ind, flatten_list, unflatten_list
+from .host_util import TokenList, find_max_ind, flatten_list, unflatten_list, upload
 from .logic_ops import BatchOperatorBase, FilterBatch, RelateBatch
 
 UNKNOWN = 'UNKNOWN'
@@ -297,7 +297,7 @@ class GQAEndBatch(GQABatchOperatorBase):
 
 def _seg_off(batch_index, question_num, device):
     counts = np.bincount(np.asarray(batch_index, np.int64), minlength=question_num)
-    return torch.as_tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(device)
+    return upload(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device)
 
 
 class GQAVerifyAttrsBatch(GQABatchOperatorBase):

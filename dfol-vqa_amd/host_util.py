@@ -80,11 +80,36 @@ class Lowered(object):
         return self._dev[key]
 
 
+_lower_cache = {}
+_upload_cache = {}
+
+
+def upload(array, device):
+    """Small host index arrays (segment offsets, keep lists, predicate -> question maps) as device tensors, uploaded once per
+    content: a pageable host-to-device copy synchronises the stream, and the same arrays recur on every forward of a batch."""
+    a = np.ascontiguousarray(array)
+    key = (str(device), a.dtype.str, a.shape, a.tobytes())
+    hit = _upload_cache.get(key)
+    if hit is None:
+        if len(_upload_cache) >= 1024:
+            _upload_cache.clear()
+        hit = _upload_cache[key] = torch.as_tensor(a).to(device)
+    return hit
+
+
 def lower_tokens(tokens, ontology, token_type):
     """Resolve tokens against the ontology exactly as the reference's oracle does
     (classifier_oracle.py:49-56 for attributes: column = arg_to_idx-1 of the full table;
     :89-96 for relations: column in the 333-wide table via _relation_reveresed_index).
     Unknown tokens raise KeyError like the reference's itemgetter."""
+    # long lists (the per-question category expansions of query / same / different operators: thousands of tokens) are memoised
+    # by content: resolving 6656 strings costs 7 ms of host time per operator call, more than the whole GPU step
+    key = None
+    if len(tokens) >= 64:
+        key = (id(ontology), int(token_type), tuple(tokens))
+        hit = _lower_cache.get(key)
+        if hit is not None:
+            return hit
     arg_to_idx = ontology._vocabulary['arg_to_idx']
     cols, neg, valid = [], [], []
     for t in tokens:
@@ -99,7 +124,12 @@ def lower_tokens(tokens, ontology, token_type):
         if token_type == TokenType.RELATION:
             idx = ontology._relation_reveresed_index[idx]
         cols.append(idx), neg.append(int(n)), valid.append(1)
-    return Lowered(cols, neg, valid)
+    low = Lowered(cols, neg, valid)
+    if key is not None:
+        if len(_lower_cache) >= 256:
+            _lower_cache.clear()
+        _lower_cache[key] = low
+    return low
 
 
 class TokenList(list):

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops as L
 from .fol_types import TokenType
-from .host_util import flatten_list, get_lowered, lower_tokens, segments_of
+from .host_util import flatten_list, get_lowered, lower_tokens, segments_of, upload
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -450,7 +450,7 @@ class ClassifierOracle(OracleBase):
         req_tile[slot, pq] = np.arange(P, dtype=np.int32)
         tiles = self._new_tiles(world, P)
         if not low.all_valid:
-            tiles[torch.as_tensor(np.nonzero(low.valid == 0)[0]).to(world._device)] = -30.0
+            tiles[upload(np.nonzero(low.valid == 0)[0], world._device)] = -30.0
         self._launch_pairs(world, req_col, req_tile, tiles)
         return tiles
 
@@ -480,12 +480,12 @@ class ClassifierOracle(OracleBase):
             return gather(cols, pred_q)
         if low.all_valid:
             ll = gather(cols, pred_q)
-            return L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
+            return L.option_normalize_(ll, upload(seg, dev), pred_q, world._n_obj, world._NS)
         # no-op tokens inside an option list: normalise the compressed list, then put default blocks back
-        keep = torch.as_tensor(np.nonzero(valid)[0]).to(dev)
+        keep = upload(np.nonzero(valid)[0], dev)
         pq_c = pred_q.index_select(0, keep).contiguous()
         ll_c = gather(cols.index_select(0, keep).contiguous(), pq_c)
-        ll_c = L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
+        ll_c = L.option_normalize_(ll_c, upload(seg, dev), pq_c, world._n_obj, world._NS)
         ll = torch.full((len(low.cols),) + tuple(ll_c.shape[1:]), float(default_log_likelihood), dtype=torch.float32, device=dev)
         ll[keep] = ll_c
         return ll
@@ -514,10 +514,10 @@ class ClassifierOracle(OracleBase):
         if len(seg) - 1 == int(valid.sum()):
             return ll
         if low.all_valid:
-            return L.option_normalize_(ll, torch.as_tensor(seg).to(dev), pred_q, world._n_obj, world._NS)
-        keep = torch.as_tensor(np.nonzero(valid)[0]).to(dev)
+            return L.option_normalize_(ll, upload(seg, dev), pred_q, world._n_obj, world._NS)
+        keep = upload(np.nonzero(valid)[0], dev)
         pq_c = pred_q.index_select(0, keep).contiguous()
         ll_c = ll.index_select(0, keep).contiguous()
-        ll_c = L.option_normalize_(ll_c, torch.as_tensor(seg).to(dev), pq_c, world._n_obj, world._NS)
+        ll_c = L.option_normalize_(ll_c, upload(seg, dev), pq_c, world._n_obj, world._NS)
         ll[keep] = ll_c
         return ll

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Forward throughput per terminal operator (BASELINE configs[2] shape: ragged N <= 100, the full operator set), one GPU.
+
+usage: python tools/bench_ops.py [--batch 256] [--nmin 10] [--nmax 100] [--steps 5]
+One JSON line per operator kind: questions/s of a batch of `--batch` programs  select -> filter -> relate -> <terminal op>.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+KINDS = ["exist", "verify_attrs", "verify_rel", "choose_attr", "choose_rel", "query_attr", "and", "or", "two_same", "two_different",
+         "all_same", "all_different", "compare"]
+
+
+def questions(kind, count, nmin, nmax, names, seed):
+    from dfol_vqa_amd import synthetic as syn
+    rng = np.random.RandomState(seed)
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    op = syn.op
+    pick = lambda xs: xs[rng.randint(len(xs))]
+    qs = []
+    for i in range(count):
+        qid = seed * 100000 + i
+        b1 = [op("select", pick(nouns)), op("filter", pick(attrs)), op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns))]
+        branches = [b1]
+        if kind in ("and", "or", "two_same", "two_different", "compare"):
+            branches.append([op("select", pick(nouns)), op("filter", pick(attrs))])
+        last = {"exist": op("exist"), "and": op("and"), "or": op("or"), "verify_attrs": op("verify_attrs", [pick(attrs), pick(attrs)]),
+                "verify_rel": op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)),
+                "choose_attr": op("choose_attr", [attrs[0], attrs[1]]), "query_attr": op("query_attr", "category%02d" % rng.randint(3)),
+                "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
+                "two_same": op("two_same", "category00"), "two_different": op("two_different", "category01"),
+                "all_same": op("all_same", "category02"), "all_different": op("all_different", "category00"),
+                "compare": op("compare", pick(attrs), bool(rng.uniform() < 0.5))}[kind]
+        n = int(rng.randint(nmin, nmax + 1))
+        qs.append(syn.question(qid, branches, last, "yes", syn.feature_scene(qid, n, 2048)))
+    return qs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--nmin", type=int, default=10)
+    ap.add_argument("--nmax", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--kinds", default=",".join(KINDS))
+    args = ap.parse_args()
+    device = torch.device("cuda", 0)
+    import dfol_vqa_amd as D
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd import synthetic as syn
+    tmp = tempfile.mkdtemp(prefix="dfol_ops_")
+    paths, names = syn.write_synthetic_ontology(tmp)
+    cfg = syn.reference_config(paths)
+    ontology = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ontology)
+    bench.init_weights(model)
+    model = model.to(device).eval()
+
+    class Collater(D.ProgramCollaterBase):
+        def __init__(self):
+            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology)
+
+        def collate_object_features(self, qs):
+            feats = torch.cat([torch.from_numpy(q["scene"]["X"]) for q in qs], 0)
+            bi = torch.cat([torch.full((q["scene"]["n"],), i, dtype=torch.int64) for i, q in enumerate(qs)])
+            return feats, bi
+
+        def collate_meta_data(self, qs):
+            return {"index": {}, "embedding": torch.zeros(1, 1)}
+
+    for kind in args.kinds.split(","):
+        qs = questions(kind, args.batch, args.nmin, args.nmax, names, seed=1 + KINDS.index(kind))
+        pbs = Collater().collate(qs)
+        for pb in pbs:
+            pb.create_sparse_tensors()
+        pbs = [pb.to_cuda(device) for pb in pbs]
+        with torch.no_grad():
+            for _ in range(2):
+                res = model(pbs, False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res = model(pbs, False)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"operator": kind, "questions_per_s": args.batch / dt, "ms_per_step": dt * 1e3, "batch": args.batch,
+                          "objects": [args.nmin, args.nmax], "predicates": int(res["log_probability"].numel())}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ _lib = None
 TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
 WANT_SUBJECT, WANT_OBJECT = 1, 2
 RELATE_LONE_FORALL_IDENTITY, RELATE_DIAG_ABSENT = 1, 2
+TILE_F32, TILE_BF16 = 0, 1
 ACT_NONE, ACT_SIGMOID, ACT_ELU, ACT_LOGSIGMOID = 0, 1, 2, 3
 LOGIC_AND, LOGIC_OR, LOGIC_NOT = 0, 1, 2
 
@@ -59,7 +60,8 @@ SIGNATURES = {
                          _i32, _f, _p, _p],
     "dfol_pair_pack_w2_f32": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_packed_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
-                                _p, _p],
+                                _i32, _p, _p],
+    "dfol_relate_one_fwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
 }
 
 
@@ -188,6 +190,16 @@ def relate_one_fwd(x_att, prev_att, tile, pred_q, n_obj, quant_prev, neg=None, a
     P, NS = tile.shape[0], tile.shape[1]
     post = torch.empty(P, NS, dtype=F32, device=tile.device)
     call("dfol_relate_one_fwd_f32", _ptr(x_att, F32), _ptr(prev_att, F32), _ptr(tile, F32), _ptr(pred_q, I32), _ptr(n_obj, I32),
+         _ptr(quant_prev, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True), P, NS,
+         1 if lone_forall_identity else 0, _ptr(post), _stream())
+    return post
+
+
+def relate_one_fwd_bf16(x_att, prev_att, tile, pred_q, n_obj, quant_prev, neg=None, active=None, lone_forall_identity=False):
+    """relate_one_fwd on bfloat16 tiles (NS % 8 == 0)."""
+    P, NS = tile.shape[0], tile.shape[1]
+    post = torch.empty(P, NS, dtype=F32, device=tile.device)
+    call("dfol_relate_one_fwd_bf16", _ptr(x_att, F32), _ptr(prev_att, F32), _ptr(tile, torch.bfloat16), _ptr(pred_q, I32), _ptr(n_obj, I32),
          _ptr(quant_prev, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True), P, NS,
          1 if lone_forall_identity else 0, _ptr(post), _stream())
     return post
@@ -328,12 +340,15 @@ def pair_pack_w2(w2, hid2=None):
 
 def pair_ll_packed(uv, hid1, pos, wg, w2_packed, b2, hid2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles,
                    default_ll=-30.0):
-    """As pair_ll, with the second layer packed by pair_pack_w2 (hid1 % 16 == 0, hid2 <= 320)."""
+    """As pair_ll, with the second layer packed by pair_pack_w2 (hid1 % 16 == 0, hid2 <= 320).  `tiles` may be bfloat16
+    (TILE_BF16 storage for relate_one_fwd_bf16; needs hid2 > 256 and NS % 8 == 0)."""
     K, Q = req_col.shape
     NS = tiles.shape[1]
+    bf16 = tiles.dtype == torch.bfloat16
     call("dfol_pair_ll_packed_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32), _ptr(w2_packed, F32),
          _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32), _ptr(obj_off, I32), Q, max_n,
-         _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll, _ptr(tiles, F32), _stream())
+         _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll, TILE_BF16 if bf16 else TILE_F32,
+         _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
 
 

@@ -628,6 +628,148 @@ extern "C" int dfol_relate_one_fwd_f32(const float* x_att, const float* prev_att
 }
 
 // =====================================================================================================
+// Relate, single posterior, bf16 tiles (BASELINE configs[4]: 256-object scenes, tiles stored in bf16 to halve the HBM bytes)
+// =====================================================================================================
+// Same contract as relate_one_fwd_kernel; a lane owns EIGHT consecutive columns (one 16-byte load = 8 bf16 per row), so LPR =
+// NS / 8 lanes cover a row (NS a multiple of 8, <= 256).  Arithmetic is fp32; only the stored likelihoods are rounded.
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 w, float (&l)[8]) {
+    const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        l[2 * i] = __uint_as_float(v[i] << 16);
+        l[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void relate_one_bf16_kernel(
+    const float* __restrict__ x_att, const float* __restrict__ prev_att, const uint16_t* __restrict__ tile,
+    const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_prev,
+    const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active, int P, int NS, int identity_forall,
+    float* __restrict__ post) {
+    constexpr int RPI = 64 / LPR, UNR = LPR >= 32 ? 4 : (LPR >= 8 ? 2 : 1);
+    constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int q = pred_q[p];
+    const int n = n_obj[q];
+    const float* pv = prev_att + (int64_t)q * NS;
+    float* out = post + (int64_t)p * NS;
+    if (active && !active[p]) {
+        for (int c = lane; c < NS; c += 64) out[c] = c < n ? pv[c] : 0.f;
+        return;
+    }
+    const int cg = lane % LPR, rs = lane / LPR, c0 = cg * 8;
+    const bool negated = any_neg && neg[p];
+    const float alpha_n = negated ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
+    const float qf = quant_prev[p], kf = 1.f - 2.f * qf;
+    const bool ident = identity_forall && qf == 0.f;
+    const bool mask = negated || qf != 1.f;
+    const uint16_t* tp = tile + (int64_t)p * NS * NS + min(c0, NS - 8);     // lanes beyond the tile width read valid columns and are discarded
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    bool fast_ok = false;
+    if (!mask) {                                            // product path, see relate_exists_fast
+        float pmax = 0.f;
+        for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
+            uint4 t[UNR];
+            float Pr[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
+                t[u] = *reinterpret_cast<const uint4*>(tp + (int64_t)rc * NS);
+                Pr[u] = r < n ? __builtin_amdgcn_exp2f(pv[rc] * L2E) : 0.f;
+                pmax = fmaxf(pmax, Pr[u]);
+            }
+            float prod[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) prod[j] = 1.f;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                float l[8];
+                bf16x8_to_f32(t[u], l);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) prod[j] *= fmaf(-__builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)), Pr[u], 1.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __builtin_amdgcn_logf(prod[j]);
+        }
+        bool bad = pmax > 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+            bad |= (c0 + j < n) && !(acc[j] >= -3.0e38f);
+        }
+        fast_ok = !__any(bad);
+        if (!fast_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        }
+    }
+    if (!fast_ok) {                                         // general path: clamps, negation, FOR_ALL, explicit diagonal mask
+        for (int r0 = 0; r0 < n; r0 += RPI) {
+            const int r = r0 + rs, rc = min(r, n - 1);
+            float l[8];
+            bf16x8_to_f32(*reinterpret_cast<const uint4*>(tp + (int64_t)rc * NS), l);
+            const float pr2 = pv[rc] * L2E;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = fminf(l[j], 0.f);
+                if (any_neg) v = dfol_pnot(v, alpha_n, cn);
+                const float w2 = fmaf(v, L2E, pr2);
+                const float f = ident ? w2 : __builtin_amdgcn_logf(fmaxf(fmaf(kf, __builtin_amdgcn_exp2f(w2), qf), DFOL_EPS));
+                acc[j] += (r < n && r != c0 + j) ? f : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+    }
+    if (rs == 0 && c0 < NS) {
+        float o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 xa = *reinterpret_cast<const float4*>(x_att + (int64_t)p * NS + c0 + 4 * h);
+            const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s2 = acc[4 * h + j] * LN2;
+                o[4 * h + j] = (c0 + 4 * h + j < n) ? xv[j] + (ident ? s2 : dfol_pnot(s2, qf, kf)) : 0.f;
+            }
+            *reinterpret_cast<float4*>(out + c0 + 4 * h) = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
+        }
+    }
+}
+
+extern "C" int dfol_relate_one_fwd_bf16(const float* x_att, const float* prev_att, const uint16_t* tile, const int32_t* pred_q,
+                                        const int32_t* n_obj, const float* quant_prev, const uint8_t* neg, int32_t any_neg,
+                                        const uint8_t* active, int32_t P, int32_t NS, int32_t lone_forall_identity, float* post,
+                                        void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 8 == 0 && NS <= 256, "relate_one_fwd_bf16: bad sizes P=%d NS=%d (NS: multiple of 8, <= 256)", P, NS);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(x_att && prev_att && tile && pred_q && n_obj && quant_prev && post, "relate_one_fwd_bf16: null pointer");
+    DFOL_REQUIRE(!any_neg || neg, "relate_one_fwd_bf16: any_neg set but neg is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = NS / 8;
+#define DFOL_REL1B(L)                                                                                                          \
+    hipLaunchKernelGGL((relate_one_bf16_kernel<L>), dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, x_att, prev_att, tile, pred_q, n_obj, \
+                       quant_prev, neg, any_neg, active, P, NS, lone_forall_identity, post)
+    if (groups <= 1) DFOL_REL1B(1);
+    else if (groups <= 2) DFOL_REL1B(2);
+    else if (groups <= 4) DFOL_REL1B(4);
+    else if (groups <= 8) DFOL_REL1B(8);
+    else if (groups <= 16) DFOL_REL1B(16);
+    else DFOL_REL1B(32);
+#undef DFOL_REL1B
+    DFOL_LAUNCH_CHECK("relate_one_fwd_bf16");
+    return 0;
+}
+
+// =====================================================================================================
 // quantifier aggregation (Exist), gate, small vector ops
 // =====================================================================================================
 __global__ __launch_bounds__(256) void quantify_fwd_kernel(const float* __restrict__ att, const float* __restrict__ quant,

@@ -198,14 +198,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // twice the MFMAs between barriers.  The accumulators take 2 x 76 registers, so the W2 chunk cannot be staged through
 // registers any more: it goes global -> LDS directly (global_load_lds_dwordx4; the packed image is lane-linear, so the DMA's
 // "wave-uniform base + lane x 16 bytes" destination is exactly the layout the B reads expect).
-template <int NB16>
+// TBF16: the tiles are written as bf16 bit patterns (round to nearest even) for dfol_relate_one_fwd_bf16.
+template <int NB16, bool TBF16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32b_kernel(
     const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
     const float* __restrict__ Wg, const float* __restrict__ W2p, const float* __restrict__ b2, int HID2,
     const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
     const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
     const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
-    float* __restrict__ tiles) {
+    void* __restrict__ tiles_v) {
     constexpr int PARTS = 4, HALF = (NB16 + PARTS - 1) / PARTS;
     constexpr int PASSES = PB_CHUNK / 4 / 256;                       // 16-byte DMA pieces per thread per chunk (5)
     __shared__ __attribute__((aligned(16))) float Bs[2][PB_CHUNK];
@@ -367,9 +368,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int ss = ee / n, oo = ee - ss * n;
                     const float x = v + (be ? be[col] : 0.f);
                     const float val = (ss == oo) ? dflt : fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
-                    float* t = tiles + (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz;
-                    if (req_orient && req_orient[(int64_t)k * Q + q]) t[(int64_t)oo * NS + ss] = val;
-                    else t[(int64_t)ss * NS + oo] = val;
+                    const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
+                                       ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
+                    if (TBF16) {
+                        uint32_t u = __float_as_uint(val);
+                        u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even
+                        reinterpret_cast<uint16_t*>(tiles_v)[at] = (uint16_t)(u >> 16);
+                    } else {
+                        reinterpret_cast<float*>(tiles_v)[at] = val;
+                    }
                 }
             }
         }
@@ -393,7 +400,10 @@ extern "C" int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t H
                                        const float* W2_packed, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
                                        const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
                                        const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K,
-                                       int32_t NS, float default_ll, float* tiles, void* stream) {
+                                       int32_t NS, float default_ll, int32_t tile_dtype, void* tiles_v, void* stream) {
+    float* tiles = (float*)tiles_v;
+    DFOL_REQUIRE(tile_dtype == DFOL_TILE_F32 || (tile_dtype == DFOL_TILE_BF16 && HID2 > 256 && NS % 8 == 0),
+                 "pair_ll_packed: tile_dtype=%d (bf16 tiles need HID2 > 256 and NS %% 8 == 0)", tile_dtype);
     DFOL_REQUIRE(Q >= 0 && K >= 0 && NS > 0 && NS % 4 == 0 && max_n >= 0 && max_n <= NS, "pair_ll_packed: bad sizes Q=%d K=%d NS=%d max_n=%d", Q, K, NS, max_n);
     DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % PB_CH == 0 && ld_uv % 4 == 0, "pair_ll_packed: HID1=%d must be a multiple of %d, <= 256, UV rows 16-byte aligned", HID1, PB_CH);
     DFOL_REQUIRE(HID2 > 0 && HID2 <= PB_ROWS, "pair_ll_packed: HID2=%d must be <= %d", HID2, PB_ROWS);
@@ -402,16 +412,16 @@ extern "C" int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t H
     DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_packed % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll_packed: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     static const int rows = getenv("DFOL_PAIR_ROWS") ? atoi(getenv("DFOL_PAIR_ROWS")) : 32;
-    if (rows == 32 && HID2 > 256) {                         // 32 slots per wavefront, W2 by LDS-DMA
+    if ((rows == 32 || tile_dtype == DFOL_TILE_BF16) && HID2 > 256) {                         // 32 slots per wavefront, W2 by LDS-DMA
         const int tpi2 = dfol_cdiv((int64_t)max_n * max_n, 128);
         DFOL_REQUIRE((int64_t)Q * tpi2 < ((int64_t)1 << 31), "pair_ll_packed: too many tiles");
         const dim3 grid2((unsigned)Q * tpi2);
-        if (HID2 <= 304)
-            hipLaunchKernelGGL((pair_ll32b_kernel<19>), grid2, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2_packed, b2, HID2, E, ld_e,
-                               be, n_obj, obj_off, Q, tpi2, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
-        else
-            hipLaunchKernelGGL((pair_ll32b_kernel<20>), grid2, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2_packed, b2, HID2, E, ld_e,
-                               be, n_obj, obj_off, Q, tpi2, req_col, req_tile, req_orient, K, NS, default_ll, tiles);
+#define DFOL_PAIR32(NBV, BF)                                                                                                          \
+    hipLaunchKernelGGL((pair_ll32b_kernel<NBV, BF>), grid2, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, W2_packed, b2, HID2, E, ld_e, \
+                       be, n_obj, obj_off, Q, tpi2, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
+        if (tile_dtype == DFOL_TILE_BF16) { if (HID2 <= 304) DFOL_PAIR32(19, true); else DFOL_PAIR32(20, true); }
+        else { if (HID2 <= 304) DFOL_PAIR32(19, false); else DFOL_PAIR32(20, false); }
+#undef DFOL_PAIR32
         DFOL_LAUNCH_CHECK("pair_ll_packed");
         return 0;
     }

@@ -68,6 +68,8 @@ def build_interpreter(config, neural_dict, ontology):           # gqa_interprete
     featurizer = BatchGQABoxFeaturizer(featurizer_network=neural_dict['featurizer_network'])
     oracle = ClassifierOracle(ontology, neural_dict['attribute_network'], neural_dict['relation_network'], neural_dict['embedding_network'],
                               normalize=bool(config.get('normalize_oracle')), cached=True)
+    if str(config.get('relation_tile_dtype', 'fp32')).lower() in ('bf16', 'bfloat16'):     # an extra key of this build (configs[4])
+        oracle._tile_dtype = torch.bfloat16
     return BatchGQAInterpreter(config['model_name'], oracle, ontology, featurizer, trainable_gate=config['trainable_gate'],
                                likelihood_threshold=config['likelihood_threshold'], hard_mode=config.get('hard_mode', False),
                                attention_transfer_state_dim=config['attention_transfer_state_dim'],

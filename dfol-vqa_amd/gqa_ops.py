@@ -262,9 +262,9 @@ class GQARelateBatch(GQABatchOperatorBase):
         if tiles is None:
             return None
         _, neg_dev, valid_dev = low.on(world._device)
-        post = L.relate_one_fwd(x._log_attention, prev._log_attention, tiles, world._ident, world._n_obj, prev._quantifier,
-                                neg_dev if low.any_neg else None, None if low.all_valid else valid_dev,
-                                lone_forall_identity=(x.batch_size() == 1))
+        kernel = L.relate_one_fwd_bf16 if tiles.dtype == torch.bfloat16 else L.relate_one_fwd
+        post = kernel(x._log_attention, prev._log_attention, tiles, world._ident, world._n_obj, prev._quantifier,
+                      neg_dev if low.any_neg else None, None if low.all_valid else valid_dev, lone_forall_identity=(x.batch_size() == 1))
         quant = torch.where(flag > 0, x._quantifier, prev._quantifier)        # both posteriors carry the subject's quantifier (:571-586)
         return BatchVariableSet(x._name, world._device, x.object_num(), x.batch_size(), quantifiers=quant, log_attention=post, world=world,
                                 prev_variable_sets_num=x._prev_variable_sets_num + prev._prev_variable_sets_num + 1)

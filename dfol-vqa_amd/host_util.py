@@ -80,7 +80,6 @@ class Lowered(object):
         return self._dev[key]
 
 
-_lower_cache = {}
 _upload_cache = {}
 
 
@@ -106,8 +105,9 @@ def lower_tokens(tokens, ontology, token_type):
     # by content: resolving 6656 strings costs 7 ms of host time per operator call, more than the whole GPU step
     key = None
     if len(tokens) >= 64:
-        key = (id(ontology), int(token_type), tuple(tokens))
-        hit = _lower_cache.get(key)
+        cache = ontology.__dict__.setdefault("_lower_cache", {})       # lives and dies with the ontology it was resolved against
+        key = (int(token_type), tuple(tokens))
+        hit = cache.get(key)
         if hit is not None:
             return hit
     arg_to_idx = ontology._vocabulary['arg_to_idx']
@@ -126,9 +126,9 @@ def lower_tokens(tokens, ontology, token_type):
         cols.append(idx), neg.append(int(n)), valid.append(1)
     low = Lowered(cols, neg, valid)
     if key is not None:
-        if len(_lower_cache) >= 256:
-            _lower_cache.clear()
-        _lower_cache[key] = low
+        if len(cache) >= 256:
+            cache.clear()
+        cache[key] = low
     return low
 
 

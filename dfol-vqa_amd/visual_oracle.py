@@ -138,6 +138,10 @@ class ClassifierOracle(OracleBase):
         self._needed_columns = True       # compute only the likelihood columns a program asks for (when the MLP shape allows)
         self._split_cache = None
         self._index_cache = {}
+        # storage type of prefetched relation tiles: torch.bfloat16 halves the tile stream of the Relate kernel (BASELINE configs[4]);
+        # an opt-in whose results differ from the reference by the rounding of the stored likelihoods.  Used when the scene's padded
+        # width is a multiple of 8 and the operator runs on the fused single-posterior kernel; everything else stays fp32.
+        self._tile_dtype = torch.float32
 
     # ---- a3: the cached tables (classifier_oracle.py:145-156) ------------------------------------------
     def _relation_embedding(self):
@@ -353,11 +357,11 @@ class ClassifierOracle(OracleBase):
             L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, w2p, b2, emb.weight, emb.bias, world._n_obj,
                       world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0, hid2=hid2)
 
-    def _new_tiles(self, world, count):
+    def _new_tiles(self, world, count, dtype=torch.float32):
         ragged = min(world._n_list) < world._NS
         if ragged:       # the pair kernel writes real pairs and the diagonal only
-            return torch.full((count, world._NS, world._NS), -30.0, dtype=torch.float32, device=world._device)
-        return torch.empty(count, world._NS, world._NS, dtype=torch.float32, device=world._device)
+            return torch.full((count, world._NS, world._NS), -30.0, dtype=dtype, device=world._device)
+        return torch.empty(count, world._NS, world._NS, dtype=dtype, device=world._device)
 
     def prefetch_relations(self, world, program_batch):
         """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel /
@@ -388,7 +392,10 @@ class ClassifierOracle(OracleBase):
         if not entries:
             return
         total = sum(len(e[0].cols) for e in entries)
-        tiles = self._new_tiles(world, total)
+        # bf16 storage only when every consumer is the fused single-posterior kernel (relate / verify_rel), which reads it directly
+        bf16 = self._tile_dtype == torch.bfloat16 and world._NS % 8 == 0 and self._padded_second_layer()[3] is not None and \
+            self._padded_second_layer()[2] > 256 and all(ob._op_name != "choose_rel" for ob in program_batch._op_batch_list)
+        tiles = self._new_tiles(world, total, torch.bfloat16 if bf16 else torch.float32)
         # the request arrays depend on the program batch only: build and upload them once per batch (a pageable upload
         # synchronises the stream), keyed by what else they depend on
         key = (id(self), Q, tuple((e[0].cols.tobytes(), e[0].valid.tobytes(), np.asarray(e[1]).tobytes(), e[2].tobytes()) for e in entries))
@@ -504,7 +511,8 @@ class ClassifierOracle(OracleBase):
             assert orientation == L.TILE_SUBJECT_ROWS
             hit = world._rel_tiles.get(id(low))
             if hit is not None and not hit[1].any():          # prefetched, and every tile already has subjects along rows
-                ll = hit[0].clone() if (self._normalize and normalized_probability) else hit[0]
+                ll = hit[0].float() if hit[0].dtype != torch.float32 else \
+                    (hit[0].clone() if (self._normalize and normalized_probability) else hit[0])
             else:
                 ll = self._relation_tiles_now(world, low, pred_q_host)
         if not (self._normalize and normalized_probability):

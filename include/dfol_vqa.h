@@ -45,6 +45,8 @@ const char* dfol_last_error(void);
 /* which posteriors dfol_relate_fwd_f32 must produce, per predicate (bit mask) */
 #define DFOL_RELATE_LONE_FORALL_IDENTITY 1 /* flags of dfol_relate_fwd_f32 */
 #define DFOL_RELATE_DIAG_ABSENT 2
+#define DFOL_TILE_F32 0  /* element type of relation tiles written by dfol_pair_ll_packed_f32 */
+#define DFOL_TILE_BF16 1
 #define DFOL_WANT_SUBJECT 1
 #define DFOL_WANT_OBJECT 2
 
@@ -149,6 +151,15 @@ int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float*
 int dfol_relate_one_fwd_f32(const float* x_att, const float* prev_att, const float* tile, const int32_t* pred_q,
                             const int32_t* n_obj, const float* quant_prev, const uint8_t* neg, int32_t any_neg,
                             const uint8_t* active, int32_t P, int32_t NS, int32_t lone_forall_identity, float* post, void* stream);
+
+/* The same operator on bf16 tiles (BASELINE configs[4]: 256-object scenes; the stored likelihoods are rounded to bf16, which halves
+ * the HBM bytes of the tile stream; arithmetic stays fp32).  tile [P, NS, NS] of bf16 bit patterns, NS a multiple of 8, written by
+ * dfol_pair_ll_packed_f32 with tile_dtype = DFOL_TILE_BF16.  An opt-in storage mode, not the reference's numerics: results differ
+ * from the fp32 path by the rounding of the likelihoods (relative 2^-9).
+ */
+int dfol_relate_one_fwd_bf16(const float* x_att, const float* prev_att, const uint16_t* tile, const int32_t* pred_q,
+                             const int32_t* n_obj, const float* quant_prev, const uint8_t* neg, int32_t any_neg,
+                             const uint8_t* active, int32_t P, int32_t NS, int32_t lone_forall_identity, float* post, void* stream);
 
 /* Soft quantifier aggregation: replaces BatchVariableSet.log_probability (soft mode),
  * batch_base_types.py:113-123:   lp[p] = F_q( sum_{o < n} F_q(att[p][o]) ),  q = quant[p].
@@ -265,7 +276,8 @@ int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* 
 /* The same relation tiles from a PACKED second layer (the geometry the full-size oracle uses: two independent 4-wavefront
  * workgroups per CU, K chunks of 16, see dfol-vqa_amd/csrc/dfol_pair.hip).  W2_packed is produced once per weight update by
  * dfol_pair_pack_w2_f32 ((HID1/16)*320*16 floats, 16-byte aligned): chunk-major [HID1/16][320][16], rows >= HID2 zero,
- * k-groups swizzled for conflict-free LDS reads.  All other arguments as dfol_pair_ll_f32.
+ * k-groups swizzled for conflict-free LDS reads.  tile_dtype: DFOL_TILE_F32, or DFOL_TILE_BF16 (tiles are then [T, NS, NS] bf16
+ * bit patterns for dfol_relate_one_fwd_bf16; needs HID2 > 256).  All other arguments as dfol_pair_ll_f32.
  * Limits: HID1 <= 256 and a multiple of 16, HID2 <= 320.
  */
 int dfol_pair_pack_w2_f32(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, float* W2_packed, void* stream);
@@ -273,7 +285,7 @@ int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t HID1, const 
                             const float* W2_packed, const float* b2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
                             const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n, const int32_t* req_col,
                             const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
-                            float* tiles, void* stream);
+                            int32_t tile_dtype, void* tiles, void* stream);
 
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B.  g_* outputs that are NULL are skipped.

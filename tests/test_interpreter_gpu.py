@@ -428,3 +428,44 @@ def test_g10_attention_calibration(ontology, name):
     for mod in model.modules():
         for attr in ("_modulations", "_subject_modulations", "_object_modulations", "_forward_state", "_forward_subject_state", "_forward_object_state"):
             assert not getattr(mod, attr, None), (type(mod).__name__, attr)
+
+
+def test_bf16_relation_tiles(tmp_path):
+    """Opt-in bf16 storage of the prefetched relation tiles (BASELINE configs[4]: 256-object scenes, 8-hop programs): the fused pair
+    kernel rounds the likelihoods to bf16, the single-posterior Relate kernel reads 8 of them per 16-byte load.  Against the fp32
+    path the results move by the rounding of the stored likelihoods only (relative 2^-9 per element, averaged out by the sums)."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    ont = experiment.build_ontology(syn.reference_config(paths))
+    torch.manual_seed(2)
+    model = experiment.build_model(syn.reference_config(paths, relation_tile_dtype="bf16"), ont)
+    assert model._oracle._tile_dtype == torch.bfloat16
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nouns, attrs, rels = names["nouns"][:6], names["attributes"][:5], names["relations"][:4]
+    rng = np.random.RandomState(9)
+    pick = lambda xs: xs[rng.randint(len(xs))]
+    for n_list, hops in (([256, 130, 200], 4), ([40, 33, 17, 8], 2), ([36, 36], 1)):       # NS = 256, 40 (multiples of 8); 36 -> fp32 tiles
+        qs, scenes = [], []
+        for i, n in enumerate(n_list):
+            branch = [syn.op("select", pick(nouns))]
+            for h in range(hops):
+                rel = pick(rels)
+                branch += [syn.op("filter", pick(attrs)), syn.op("relate", "not(%s)" % rel if (h == 1 and i == 0) else rel, bool(rng.uniform() < 0.5),
+                                                                   pick(nouns + ["_"]))]
+            qs.append(syn.question(5000 + 10 * hops + i, [branch], syn.op("exist"), "yes"))
+            scenes.append(syn.feature_scene(5000 + 10 * hops + i, n, 2048))
+        model._oracle._tile_dtype = torch.bfloat16
+        res_b, _ = run(model, qs, scenes, ont, key="X")
+        model._oracle._tile_dtype = torch.float32
+        res_f, _ = run(model, qs, scenes, ont, key="X")
+        lb, lf = res_b["log_probability"].cpu().numpy(), res_f["log_probability"].cpu().numpy()
+        assert np.all(np.isfinite(lb))
+        assert np.abs(np.exp(lb) - np.exp(lf)).max() <= 2e-3, (n_list, np.abs(np.exp(lb) - np.exp(lf)).max())
+        assert np.abs(lb - lf).max() <= 2e-2 * max(1.0, np.abs(lf).max()), (n_list, lb, lf)
+        if max(n_list) % 8 == 0 or (max(n_list) + 3) // 4 * 4 % 8 == 0:
+            assert not np.array_equal(lb, lf), "bf16 tiles were not used"
+        else:
+            assert np.array_equal(lb, lf)

@@ -57,6 +57,29 @@ def main():
     t = timeit(lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones))
     b1 = 4 * N * N + 12 * N
     out.append({"kernel": "relate_one", "P": P, "N": N, "ms": t * 1e3, "GBps": b1 * P / t / 1e9, "frac_hbm_peak": b1 * P / t / HBM_PEAK})
+    # BASELINE configs[4]: 256-object tiles, fp32 vs bf16 storage (algorithmic bytes 4N^2 + 12N vs 2N^2 + 12N per predicate)
+    if N == 100:
+        P2, N2 = max(P // 8, 256), 256
+        g2 = torch.Generator(device=dev).manual_seed(1)
+        t32 = torch.log(torch.where(torch.rand(P2, N2, N2, device=dev, generator=g2) < 0.1, 0.5 + 0.5 * torch.rand(P2, N2, N2, device=dev, generator=g2),
+                                    0.05 * torch.rand(P2, N2, N2, device=dev, generator=g2)).clamp_min(1e-5))
+        t32.diagonal(dim1=1, dim2=2).fill_(-30.0)
+        pr2 = torch.log(torch.rand(P2, N2, device=dev, generator=g2).clamp_min(1e-3)) * 0.3
+        pq2 = torch.arange(P2, dtype=torch.int32, device=dev)
+        no2 = torch.full((P2,), N2, dtype=torch.int32, device=dev)
+        on2 = torch.ones(P2, device=dev)
+        t = timeit(lambda: L.relate_one_fwd(pr2, pr2, t32, pq2, no2, on2))
+        b = 4 * N2 * N2 + 12 * N2
+        out.append({"kernel": "relate_one (fp32 tiles)", "P": P2, "N": N2, "ms": t * 1e3, "GBps": b * P2 / t / 1e9, "frac_hbm_peak": b * P2 / t / HBM_PEAK})
+        ref = L.relate_one_fwd(pr2, pr2, t32, pq2, no2, on2)
+        t16 = t32.to(torch.bfloat16)
+        del t32
+        t = timeit(lambda: L.relate_one_fwd_bf16(pr2, pr2, t16, pq2, no2, on2))
+        b = 2 * N2 * N2 + 12 * N2
+        got = L.relate_one_fwd_bf16(pr2, pr2, t16, pq2, no2, on2)
+        out.append({"kernel": "relate_one (bf16 tiles)", "P": P2, "N": N2, "ms": t * 1e3, "GBps": b * P2 / t / 1e9, "frac_hbm_peak": b * P2 / t / HBM_PEAK,
+                    "max_abs_diff_vs_fp32_tiles": (got - ref).abs().max().item()})
+        del t16
     t = timeit(lambda: tile.sum())
     out.append({"kernel": "torch.sum(tile) (streaming read reference)", "ms": t * 1e3, "GBps": tile.numel() * 4 / t / 1e9})
     dst = torch.empty_like(tile[: P // 2])

@@ -43,66 +43,73 @@ __device__ __forceinline__ float activate(float x) {
     return x;
 }
 
-template <int ACT, int ALIGN_X, int ALIGN_W>
+// BMT = rows of the block tile: 128 (each wavefront 64x64) or 64 (each wavefront 32x64).  The small tile doubles the number of
+// workgroups; the host picks it when the 128-row grid would leave CUs idle (M = 9216: 288 workgroups for 256 CUs).
+template <int ACT, int ALIGN_X, int ALIGN_W, int BMT>
 __global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                          int64_t ldw, const float* __restrict__ bias, float* __restrict__ Y,
                                                          int64_t ldy, int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
+    constexpr int TI = BMT / 64;                            // 32-row MFMA tiles per wavefront along M
+    constexpr int PA = BMT / 32;                            // loader passes over the A tile
+    __shared__ __attribute__((aligned(16))) float As[BMT * PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order is not needed here: W (<= 2.8 MB) stays L2-resident on every XCD.
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;        // loader: 32 rows x 8 float4 per pass, 4 passes
+    const int m0 = blockIdx.y * BMT, n0 = blockIdx.x * BN;
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;        // loader: 32 rows x 8 float4 per pass
 
-    floatx16 acc[2][2];
+    floatx16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 ra[4], rb[4];
+    float4 ra[PA], rb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, lk, M, K);
-        rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, lk, N, K);
-    }
+    for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, lk, M, K);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, lk, N, K);
 
     const int half = lane >> 5, r32 = lane & 31;
     for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * PITCH + lk]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PITCH + lk]) = rb[i];
-        }
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * PITCH + lk]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PITCH + lk]) = rb[i];
         __syncthreads();
         if (k0 + BK < K) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, k0 + BK + lk, M, K);
-                rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, k0 + BK + lk, N, K);
-            }
+            for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, k0 + BK + lk, M, K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, k0 + BK + lk, N, K);
         }
-        float a[2][16], b[2][16];
+        float a[TI][16], b[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float* pa = &As[(wm * 64 + t * 32 + r32) * PITCH + half * 16];
             const float* pb = &Bs[(wn * 64 + t * 32 + r32) * PITCH + half * 16];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float4 fa = *reinterpret_cast<const float4*>(pa + 4 * v);
                 const float4 fb = *reinterpret_cast<const float4*>(pb + 4 * v);
-                a[t][4 * v + 0] = fa.x; a[t][4 * v + 1] = fa.y; a[t][4 * v + 2] = fa.z; a[t][4 * v + 3] = fa.w;
                 b[t][4 * v + 0] = fb.x; b[t][4 * v + 1] = fb.y; b[t][4 * v + 2] = fb.z; b[t][4 * v + 3] = fb.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const float* pa = &As[(wm * 32 * TI + t * 32 + r32) * PITCH + half * 16];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 fa = *reinterpret_cast<const float4*>(pa + 4 * v);
+                a[t][4 * v + 0] = fa.x; a[t][4 * v + 1] = fa.y; a[t][4 * v + 2] = fa.z; a[t][4 * v + 3] = fa.w;
             }
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + r32;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict
             const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int m = m0 + wm * 32 * TI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 if (m < M) Y[(int64_t)m * ldy + n] = activate<ACT>(acc[i][j][e] + bv);
             }
         }
@@ -131,11 +138,12 @@ int align_of(const float* p, int64_t ld) {
     return 1;
 }
 
-template <int ACT>
-void launch_linear(hipStream_t st, dim3 grid, int ax, int aw, const float* X, int64_t ldx, const float* W, int64_t ldw,
+template <int ACT, int BMT>
+void launch_linear(hipStream_t st, int ax, int aw, const float* X, int64_t ldx, const float* W, int64_t ldw,
                    const float* bias, float* Y, int64_t ldy, int M, int N, int K) {
+    const dim3 grid(dfol_cdiv(N, BN), dfol_cdiv(M, BMT));
 #define DFOL_LIN(AX, AW) \
-    hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K)
+    hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW, BMT>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K)
     if (ax == 4 && aw == 4) DFOL_LIN(4, 4);
     else if (ax == 2 && aw == 4) DFOL_LIN(2, 4);
     else if (ax == 4 && aw == 2) DFOL_LIN(4, 2);
@@ -153,16 +161,24 @@ extern "C" int dfol_linear_act_f32(const float* X, int64_t ldx, const float* W, 
     DFOL_REQUIRE(act >= 0 && act <= 3, "linear_act: unknown activation %d", act);
     if (M == 0) return 0;
     DFOL_REQUIRE(X && W && Y, "linear_act: null pointer");
-    const dim3 grid(dfol_cdiv(N, BN), dfol_cdiv(M, BM));
-    DFOL_REQUIRE(grid.y <= 65535, "linear_act: M=%d too large for one launch", M);
+    DFOL_REQUIRE(dfol_cdiv(M, 64) <= 65535, "linear_act: M=%d too large for one launch", M);
     hipStream_t st = (hipStream_t)stream;
     const int ax = align_of(X, ldx), aw = align_of(W, ldw);
+    // 64-row tiles when the 128-row grid cannot give every CU a few workgroups (env DFOL_LINEAR_BM = 64 / 128 forces one)
+    static const int forced = getenv("DFOL_LINEAR_BM") ? atoi(getenv("DFOL_LINEAR_BM")) : 0;
+    const bool small = forced ? forced == 64 : (int64_t)dfol_cdiv(M, BM) * dfol_cdiv(N, BN) < 1200;
+#define DFOL_LINB(A)                                                                             \
+    do {                                                                                         \
+        if (small) launch_linear<A, 64>(st, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K);      \
+        else launch_linear<A, 128>(st, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K);           \
+    } while (0)
     switch (act) {
-        case DFOL_ACT_NONE: launch_linear<DFOL_ACT_NONE>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
-        case DFOL_ACT_SIGMOID: launch_linear<DFOL_ACT_SIGMOID>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
-        case DFOL_ACT_ELU: launch_linear<DFOL_ACT_ELU>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
-        default: launch_linear<DFOL_ACT_LOGSIGMOID>(st, grid, ax, aw, X, ldx, W, ldw, bias, Y, ldy, M, N, K); break;
+        case DFOL_ACT_NONE: DFOL_LINB(DFOL_ACT_NONE); break;
+        case DFOL_ACT_SIGMOID: DFOL_LINB(DFOL_ACT_SIGMOID); break;
+        case DFOL_ACT_ELU: DFOL_LINB(DFOL_ACT_ELU); break;
+        default: DFOL_LINB(DFOL_ACT_LOGSIGMOID); break;
     }
+#undef DFOL_LINB
     DFOL_LAUNCH_CHECK("linear_act");
     return 0;
 }

@@ -92,7 +92,8 @@ def main():
     t = timeit(lambda: L.quantify_fwd(prior, ones, pq, n_obj))
     out.append({"kernel": "quantify", "P": P, "N": N, "ms": t * 1e3, "GBps": (4 * N + 4) * P / t / 1e9})
     del tile
-    for (M, Nn, K, act) in ((25600, 512, 2048, 1), (25600, 768, 516, 2), (25600, 300, 256, 1), (65536, 304, 256, 1), (9216, 2335, 300, 3)):
+    for (M, Nn, K, act) in ((25600, 512, 2048, 1), (25600, 512, 516, 0), (25600, 256, 516, 2), (25600, 300, 256, 1), (9216, 512, 2048, 1), (9216, 512, 516, 0),
+                              (9216, 256, 516, 2), (9216, 300, 256, 1), (9216, 2335, 300, 3)):
         x = torch.rand(M, K, device=dev) - 0.5
         w = torch.rand(Nn, K, device=dev) - 0.5
         b = torch.rand(Nn, device=dev)

@@ -188,7 +188,7 @@ def main():
                                "frac": ach / HBM_PEAK, "traffic": None}
         out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if args.stress_preds > 0 else []
         attach_traffic(out, args)
-        sample = args.cpu_sample if args.cpu_sample is not None else (8 if args.objects > 64 else 32)
+        sample = args.cpu_sample if args.cpu_sample is not None else (64 if args.objects > 64 else 256)     # about 10 s of host work
         if sample > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs[:sample], res, sample)
         print(json.dumps(out))
@@ -287,7 +287,12 @@ def cpu_baseline(model, paths, questions, gpu_result, sample):
     lp_gpu = gpu_result["log_probability"][:sample].detach().cpu().numpy()
     lp_cpu = r["log_probability"]
     agree = sum(1 for a, b in zip(gpu_result["answer"][:sample], r["answer"]) if a == b)
-    base = {"value": sample / dt, "unit": "questions/s", "cores": os.cpu_count(), "kind": "port",
+    try:                                                    # threads numpy's BLAS actually runs the MLP layers on
+        from threadpoolctl import threadpool_info
+        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    base = {"value": sample / dt, "unit": "questions/s", "cores": cores, "kind": "port",
             "sample": "%d questions of the same workload (N=%d), numpy fp32 oracle incl. full [pairs,2335] tables, "
                       "ProgramBatch size %d, %.1f s" % (sample, questions[0]["scene"]["n"], split, dt)}
     parity = {"max_abs_dp": float(np.abs(np.exp(lp_gpu) - np.exp(lp_cpu)).max()), "max_abs_dlp": float(np.abs(lp_gpu - lp_cpu).max()),

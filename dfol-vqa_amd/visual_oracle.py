@@ -124,6 +124,32 @@ class OracleBase(nn.Module):
             return torch.from_numpy(self._ontology.get_embeddings(tokens)).float().to(device)
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = x W^T + b for a very tall x ([rows, K] with millions of rows: one row per object pair).  Forward and grad_x are plain
+    library GEMMs; the weight gradient g^T x contracts over the rows, a shape for which the library picks a slow kernel
+    (7.5 ms for [300 x 2.5M] x [2.5M x 256]), so it is taken as a batched GEMM over row slices plus a sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        gx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            rows = g2.shape[0]
+            S = 64
+            while S > 1 and rows % S:
+                S //= 2
+            gw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0) if S > 1 else g2.t() @ x2
+        gb = g2.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
 class ClassifierOracle(OracleBase):
     """classifier_oracle.py:11-156 with cached tables (the only mode the reference's experiments use:
     gqa_interpreter_experiments.py:209-210 builds it with cached=True)."""
@@ -259,8 +285,52 @@ class ClassifierOracle(OracleBase):
             world._pair_h = torch.sigmoid(nn.functional.linear(z, lin2.weight, lin2.bias))
         return world._pair_h
 
+    def _pair_hidden_dense(self, world, n):
+        """The same hidden layer for a batch whose images all have n objects, as [Q, n, n, HID2] over ALL (s, o) slots: the two
+        per-object halves broadcast instead of being gathered per pair, so the backward is a reduction, not a scatter-add."""
+        if world._pair_h is None:
+            lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+            obj, Q = world._obj, world._batch_size
+            D = (lin1.weight.shape[1] - 4) // 2
+            assert obj.shape[1] == D, "object feature width does not match the relation network"
+            U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias).view(Q, n, 1, -1)
+            V = nn.functional.linear(obj, lin1.weight[:, D:2 * D]).view(Q, 1, n, -1)
+            pos = obj[:, D - 4:].detach().view(Q, n, 4)           # batch_gqa_boxfeatures_pipeline.py:263-279
+            ps, po = pos[:, :, None, :], pos[:, None, :, :]
+            dx = ps[..., 0] + ps[..., 2] / 2.0 - po[..., 0] - po[..., 2] / 2.0
+            dy = ps[..., 1] + ps[..., 3] / 2.0 - po[..., 1] - po[..., 3] / 2.0
+            dist = torch.sqrt(dx * dx + dy * dy)
+            geo = torch.stack([dist, torch.asin(dy / dist.clamp(min=1e-10)), torch.sign(po[..., 0] - ps[..., 0]),
+                               torch.sign(po[..., 1] - ps[..., 1])], -1)
+            z = nn.functional.elu(U + V + _TallLinear.apply(geo, lin1.weight[:, 2 * D:2 * D + 4], None))
+            world._pair_h = torch.sigmoid(_TallLinear.apply(z, lin2.weight, lin2.bias))
+        return world._pair_h
+
+    def _relation_tiles_dense(self, world, low, pred_q_host, n):
+        emb = self._embedding_network.linear
+        dev = world._device
+        full = self._relation_full_columns(low.cols)
+        pq = np.asarray(list(pred_q_host), np.int64)
+        P, NS = len(pq), world._NS
+        h = self._pair_hidden_dense(world, n)
+        eye = torch.eye(n, dtype=torch.bool, device=dev)
+        valid = full >= 0
+        cols = upload(np.where(valid, full, 0).astype(np.int64), dev)
+        # one pass over all predicates: each reads its image's [n, n, H] slab against its own embedding row (the per-concept loop
+        # of the ragged form would scatter-add into the 3 GB hidden gradient once per concept)
+        hq = h if (P == world._batch_size and np.array_equal(pq, np.arange(P))) else h.index_select(0, upload(pq, dev))
+        x = (hq * emb.weight.index_select(0, cols)[:, None, None, :]).sum(-1) + emb.bias.index_select(0, cols)[:, None, None]
+        tiles = nn.functional.logsigmoid(x).masked_fill(eye, -30.0)                     # self-relations stay absent
+        if not valid.all():
+            tiles = tiles.masked_fill(upload(~valid, dev)[:, None, None], -30.0)
+        if NS != n:
+            tiles = nn.functional.pad(tiles, (0, NS - n, 0, NS - n), value=-30.0)
+        return tiles
+
     def _relation_tiles_autograd(self, world, low, pred_q_host):
         """[P, NS, NS] tiles (subjects along rows) of the requested relation columns, differentiable."""
+        if world._pair_num > 0 and min(world._n_list) == max(world._n_list):
+            return self._relation_tiles_dense(world, low, pred_q_host, world._n_list[0])
         emb = self._embedding_network.linear
         dev = world._device
         full = self._relation_full_columns(low.cols)

@@ -195,6 +195,32 @@ def test_g12_weight_gradients(ontology, name, needed):
     assert checked == 12
 
 
+@pytest.mark.parametrize("n", [6, 9])
+def test_uniform_batch_training_dataflow(ontology, n):
+    """Batches whose images all have the same object count train on the broadcast form of the pair MLP ([Q, n, n, H], no gathers):
+    its loss and weight gradients equal those of the full-table dataflow, which golden g12 pins to the reference."""
+    a, meta = gu.load("g12_weight_gradients")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    base = meta["sets"]["query_rel" if n == 9 else "binary"]["questions"]
+    qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+           "original_dict": None, "question": None, "scene": syn.feature_scene(7000 + i, n, meta["config"]["box_features_dim"])}
+          for i, q in enumerate(base)]
+    out = {}
+    for needed in (True, False):
+        model = neural_model(ontology, meta["config"], weights).train()
+        model._oracle._needed_columns = needed
+        pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate([dict(q) for q in qs])]
+        res = model(pbs, True)
+        loss = training.compute_loss(pbs, res) / len(qs)
+        loss.backward()
+        out[needed] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert abs(out[True][0] - out[False][0]) <= 1e-5 * max(1.0, abs(out[False][0]))
+    assert set(out[True][1]) == set(out[False][1]) and len(out[True][1]) >= 12
+    for k, g in out[False][1].items():
+        scale = g.abs().max().item() + 1e-30
+        assert (out[True][1][k] - g).abs().max().item() <= 2e-4 * scale + 1e-9, k
+
+
 def test_calibrator_phase_train_step(ontology):
     """cur6-7 style: oracle frozen, only the attention-calibration networks train; the forward runs on the fused
     needed-columns kernels and the gradient reaches the LSTMs through the modulate op."""

@@ -23,8 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--objects", type=int, default=36)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -281,8 +281,8 @@ class ClassifierOracle(OracleBase):
             geo = torch.stack([dist, torch.asin(dy / dist.clamp(min=1e-10)), torch.sign(po[:, 0] - ps[:, 0]),
                                torch.sign(po[:, 1] - ps[:, 1])], 1)
             z = nn.functional.elu(U.index_select(0, s_idx) + V.index_select(0, o_idx)
-                                  + nn.functional.linear(geo, lin1.weight[:, 2 * D:2 * D + 4]))
-            world._pair_h = torch.sigmoid(nn.functional.linear(z, lin2.weight, lin2.bias))
+                                  + _TallLinear.apply(geo, lin1.weight[:, 2 * D:2 * D + 4], None))
+            world._pair_h = torch.sigmoid(_TallLinear.apply(z, lin2.weight, lin2.bias))
         return world._pair_h
 
     def _pair_hidden_dense(self, world, n):
@@ -342,33 +342,33 @@ class ClassifierOracle(OracleBase):
         if world._pair_num == 0:
             return flat.view(P, NS, NS)
         h = self._pair_hidden_autograd(world)
-        vals, dsts = [], []
-        for c in np.unique(full[full >= 0]):
-            preds = np.nonzero(full == c)[0]
-            q = pq[preds]
-            cnt = n[q] * (n[q] - 1)
-            if cnt.sum() == 0:
-                continue
-            key = ("rel", str(dev), tuple(world._n_list), NS, preds.tobytes(), q.tobytes())
-            hit = self._index_cache.get(key)
-            if hit is None:                                   # gather / scatter indices depend on the batch shape only: upload once
-                rep = np.repeat(np.arange(len(preds)), cnt)
-                k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
-                nq = n[q][rep]
-                s_, o_ = k // (nq - 1), k % (nq - 1)
-                o_ = o_ + (o_ >= s_)                          # pairs are row-major in s with the diagonal left out (util.py:87-103)
-                hit = (torch.as_tensor(pair_off[q][rep] + k).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev))
-                if len(self._index_cache) >= 32:
-                    self._index_cache.clear()
-                self._index_cache[key] = hit
-            src, dst = hit
-            # (a matrix-vector product here goes to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms per column)
-            x = (h.index_select(0, src) * emb.weight[int(c)]).sum(1) + emb.bias[int(c)]
-            vals.append(nn.functional.logsigmoid(x))
-            dsts.append(dst)
-        if vals:
-            flat = flat.index_put((torch.cat(dsts),), torch.cat(vals))
-        return flat.view(P, NS, NS)
+        preds = np.nonzero(full >= 0)[0]
+        q = pq[preds]
+        cnt = n[q] * (n[q] - 1)
+        if len(preds) == 0 or cnt.sum() == 0:
+            return flat.view(P, NS, NS)
+        key = ("rel", str(dev), tuple(world._n_list), NS, preds.tobytes(), q.tobytes())
+        hit = self._index_cache.get(key)
+        if hit is None:                                       # gather / scatter indices depend on the batch shape only: upload once
+            rep = np.repeat(np.arange(len(preds)), cnt)
+            k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            nq = n[q][rep]
+            s_, o_ = k // (nq - 1), k % (nq - 1)
+            o_ = o_ + (o_ >= s_)                              # pairs are row-major in s with the diagonal left out (util.py:87-103)
+            src = pair_off[q][rep] + k
+            identity = len(src) == world._pair_num and np.array_equal(src, np.arange(len(src)))
+            hit = (None if identity else torch.as_tensor(src).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev),
+                   torch.as_tensor(rep).to(dev))
+            if len(self._index_cache) >= 32:
+                self._index_cache.clear()
+            self._index_cache[key] = hit
+        src, dst, rep = hit
+        # one pass over all predicates (a loop over concepts would scatter-add into the hidden gradient once per concept; a
+        # matrix-vector product would go to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms)
+        cols = upload(full[preds].astype(np.int64), dev)
+        e_rows = emb.weight.index_select(0, cols).index_select(0, rep)
+        x = ((h if src is None else h.index_select(0, src)) * e_rows).sum(1) + emb.bias.index_select(0, cols).index_select(0, rep)
+        return flat.index_put((dst,), nn.functional.logsigmoid(x)).view(P, NS, NS)
 
     def _attr_ll_autograd(self, world, low, pred_q_host):
         """[P, NS] blocks of the requested attribute columns, differentiable."""

@@ -22,6 +22,7 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--objects", type=int, default=36)
+    ap.add_argument("--ragged", type=int, default=0, help="if > 0: object counts ~ U{ragged..objects} instead of a fixed count")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -45,6 +46,11 @@ def main():
     model = experiment.build_model(cfg, ontology)
     bench.init_weights(model)
     model = model.to(device).train()
+    if args.ragged > 0:                                      # ragged scenes (BASELINE configs[2]/[3] shape)
+        import numpy as np
+        rng = np.random.RandomState(rank)
+        orig = syn.feature_scene
+        syn.feature_scene = lambda qid, n, dim: orig(qid, int(rng.randint(args.ragged, args.objects + 1)), dim)
     _, pbs = bench.build_batch(args, rank, ontology, names, device)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     torch.cuda.reset_peak_memory_stats()
@@ -58,7 +64,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     if rank == 0:
         print(json.dumps({"metric": "training questions/s (forward + backward + Adam)", "value": args.batch * world / dt, "ms_per_step": dt * 1e3,
-                          "n_gpus": world, "objects": args.objects, "batch_per_gpu": args.batch, "loss": loss,
+                          "n_gpus": world, "objects": args.objects if not args.ragged else [args.ragged, args.objects], "batch_per_gpu": args.batch, "loss": loss,
                           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
 
 

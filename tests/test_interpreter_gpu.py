@@ -469,3 +469,38 @@ def test_bf16_relation_tiles(tmp_path):
             assert not np.array_equal(lb, lf), "bf16 tiles were not used"
         else:
             assert np.array_equal(lb, lf)
+
+
+def test_full_batch_properties(tmp_path):
+    """BASELINE-size batch (256 questions x 100 objects, full-size oracle) through size-independent properties, no oracle needed:
+    (1) permuting the objects of every scene leaves every log-probability unchanged (the logic is a function of sets of objects);
+    (2) reversing the question order reverses the outputs; (3) a batch run in four pieces equals the batch run at once."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(3)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    Q, N = 256, 100
+    qs, scenes = [], []
+    for i in range(Q):
+        br, last = syn.three_hop_program(8000 + i, nouns, attrs, rels)
+        qs.append(syn.question(8000 + i, br, last, "yes"))
+        scenes.append(syn.feature_scene(8000 + i, N, 2048))
+    base, _ = run(model, qs, scenes, ont, key="X")
+    lp = base["log_probability"].cpu().numpy()
+    assert lp.shape == (Q,) and np.all(np.isfinite(lp)) and np.all(lp <= 1e-6)
+    assert 0.02 < np.mean(np.exp(lp) > 0.5) < 0.98, "degenerate batch: every answer the same"
+    rng = np.random.RandomState(0)
+    permuted = [dict(s, X=s["X"][rng.permutation(N)]) for s in scenes]
+    lp_perm = run(model, qs, permuted, ont, key="X")[0]["log_probability"].cpu().numpy()
+    assert np.abs(np.exp(lp_perm) - np.exp(lp)).max() <= 2e-5 and np.abs(lp_perm - lp).max() <= 1e-3 * max(1.0, np.abs(lp).max())
+    lp_rev = run(model, qs[::-1], scenes[::-1], ont, key="X")[0]["log_probability"].cpu().numpy()
+    assert np.array_equal(lp_rev[::-1], lp)                      # same padded width, same kernels: bit-identical
+    lp_split = run(model, qs, scenes, ont, split=4, key="X")[0]["log_probability"].cpu().numpy()
+    assert np.array_equal(lp_split, lp)

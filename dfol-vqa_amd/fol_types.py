@@ -277,15 +277,18 @@ class BatchVariableSet(object):
     def gate(self, variable_set, flag):
         """Per-question select (batch_base_types.py:149-168): rows with flag 1 come from self, the rest from `variable_set`."""
         if isinstance(flag, torch.Tensor):
-            g = flag.to(torch.float32)
             host_flag = getattr(flag, "_host", None)
             if host_flag is None:
                 host_flag = flag.cpu().numpy().tolist()
         else:
             host_flag = [0 if f is None else f for f in flag]
-            g = torch.tensor([float(f) for f in host_flag], dtype=torch.float32, device=self._device)
-        att, quant = L.gate(self._log_attention, variable_set._log_attention, self._quantifier, variable_set._quantifier, g)
         names = [x if f > 0 else y for x, y, f in zip(self._name, variable_set._name, host_flag)]
+        if len(host_flag) == self._log_attention.shape[0] and all(f == 1 for f in host_flag):
+            att, quant = self._log_attention, self._quantifier       # every row takes self: g x + (1 - g) y = x, no launch
+        else:
+            g = flag.to(torch.float32) if isinstance(flag, torch.Tensor) else \
+                torch.tensor([float(f) for f in host_flag], dtype=torch.float32, device=self._device)
+            att, quant = L.gate(self._log_attention, variable_set._log_attention, self._quantifier, variable_set._quantifier, g)
         out = BatchVariableSet(names, self._device, self._object_num, self._batch_size, quantifiers=quant, log_attention=att,
                                world=self._world)
         out._predicate_question_map = self._predicate_question_map

@@ -161,7 +161,8 @@ def _binary_answer(log_probability, batch_size, give_answer):
     """yes/no from p > 0.5 plus the log-probability of the answer given (e.g. batch_gqa_ops.py:404-407)."""
     if not give_answer:
         return [], []
-    probability = log_probability.detach().exp().cpu().numpy().tolist()          # the one device->host sync of a binary op
+    # the one device->host sync of a binary op; safe_exp (util.py:19) on the host copy instead of one more launch
+    probability = np.exp(log_probability.detach().cpu().numpy().astype(np.float32)).tolist()
     answer = [['yes'] if probability[i] > 0.5 else ['no'] for i in range(batch_size)]
     alp = [[math.log(probability[i])] if probability[i] > 0.5 else [math.log(1 - probability[i])] for i in range(batch_size)]
     return answer, alp

@@ -454,3 +454,78 @@ def test_relate_exists_fast_path(L, n_list):
         r = [orc.relate_block(x_att[p, :n].astype(dt), prev_att[q, :n].astype(dt), tile[p, :n, :n].astype(dt), 1.0, 1.0, 0.0, False)
              for dt in (np.float32, np.float64)]
         gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path", lp_tol=2e-4)
+
+
+@pytest.mark.parametrize("hid1,hid2,K", [(256, 300, 3), (256, 300, 40), (256, 320, 2), (64, 200, 2), (32, 12, 2)])
+def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
+    """The fused pair MLP kernels (every geometry: 32x32 tiles, 16x16 tiles with 8 wavefronts, the packed occupancy-2 kernels with 16
+    and 32 slots per wavefront) against an fp64 restatement: ragged images incl. 1- and 2-object ones, unrequested slots, both tile
+    orientations, more request rows than the epilogue can stage in LDS."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(hid1 + hid2 + K)
+    n_list = [7, 1, 13, 2, 30, 5]
+    Q, O, NS, C = len(n_list), sum(n_list), 32, 50
+    off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
+    uv = (rng.uniform(-1, 1, (O, 2 * hid1))).astype(np.float32)
+    pos = rng.uniform(0.05, 0.9, (O, 4)).astype(np.float32)
+    wg = rng.uniform(-0.5, 0.5, (hid1, 4)).astype(np.float32)
+    rows_alloc = (hid2 + 31) // 32 * 32
+    w2 = np.zeros((rows_alloc, hid1), np.float32)
+    w2[:hid2] = rng.normal(size=(hid2, hid1)).astype(np.float32) / np.sqrt(hid1)
+    b2 = rng.normal(size=hid2).astype(np.float32)
+    E = (rng.normal(size=(C, hid2)) / np.sqrt(hid2)).astype(np.float32)
+    be = rng.normal(size=C).astype(np.float32)
+    req_col = rng.randint(0, C, (K, Q)).astype(np.int32)
+    req_col[rng.uniform(size=(K, Q)) < 0.2] = -1
+    req_col[:, 3] = -1                                         # an image nobody asks about
+    req_tile = np.arange(K * Q, dtype=np.int32).reshape(K, Q)
+    orient = (rng.uniform(size=(K, Q)) < 0.5).astype(np.uint8)
+    # fp64 reference
+    ref = np.full((K * Q, NS, NS), -30.0)
+    for q, n in enumerate(n_list):
+        f = off[q]
+        for s in range(n):
+            for o in range(n):
+                if s == o:
+                    continue
+                x1, y1, w1, h1 = pos[f + s].astype(np.float64)
+                x2, y2, w2_, h2 = pos[f + o].astype(np.float64)
+                dx, dy = x1 + w1 / 2 - x2 - w2_ / 2, y1 + h1 / 2 - y2 - h2 / 2
+                dist = np.sqrt(dx * dx + dy * dy)
+                geo = np.array([dist, np.arcsin(dy / max(dist, 1e-10)), np.sign(x2 - x1), np.sign(y2 - y1)])
+                z = uv[f + s, :hid1].astype(np.float64) + uv[f + o, hid1:].astype(np.float64) + wg.astype(np.float64) @ geo
+                z = np.where(z > 0, z, np.expm1(z))
+                h = 1.0 / (1.0 + np.exp(-(w2[:hid2].astype(np.float64) @ z + b2)))
+                for k in range(K):
+                    c = req_col[k, q]
+                    if c >= 0:
+                        v = orc._log_sigmoid(np.array([h @ E[c].astype(np.float64) + be[c]]))[0]
+                        if orient[k, q]:
+                            ref[req_tile[k, q], o, s] = v
+                        else:
+                            ref[req_tile[k, q], s, o] = v
+    args = (dev(uv), hid1, dev(pos), dev(wg))
+    tail = (dev(E), dev(be), dev(np.array(n_list, np.int32)), dev(off), max(n_list), dev(req_col), dev(req_tile), dev(orient))
+    wanted = np.zeros((K * Q, NS, NS), bool)
+    for q, n in enumerate(n_list):
+        for k in range(K):
+            if req_col[k, q] >= 0:
+                wanted[req_tile[k, q], :n, :n] = True
+    outs = {}
+    t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+    outs["unpacked"] = _lib.pair_ll(*args, dev(w2), dev(b2), *tail, t, hid2=hid2).cpu().numpy()
+    if hid1 % 16 == 0:
+        packed = _lib.pair_pack_w2(dev(w2), hid2)
+        t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+        outs["packed"] = _lib.pair_ll_packed(*args, packed, dev(b2), hid2, *tail, t).cpu().numpy()
+        if hid2 > 256:
+            t = torch.full((K * Q, NS, NS), -30.0, device="cuda", dtype=torch.bfloat16)
+            outs["packed_bf16"] = _lib.pair_ll_packed(*args, packed, dev(b2), hid2, *tail, t).float().cpu().numpy()
+    for name, got in outs.items():
+        tol = 2e-5 if "bf16" not in name else 0.0
+        err = np.abs(got - ref)
+        if "bf16" in name:
+            assert np.all(err[wanted] <= 2.0 ** -8 * np.abs(ref[wanted]) + 1e-6), name
+        else:
+            assert err[wanted].max() <= tol * max(1.0, np.abs(ref[wanted]).max()), (name, err[wanted].max())
+        assert np.all(got[~wanted] == -30.0), name                 # unrequested tiles, padding: untouched

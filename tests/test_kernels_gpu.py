@@ -529,3 +529,37 @@ def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
         else:
             assert err[wanted].max() <= tol * max(1.0, np.abs(ref[wanted]).max()), (name, err[wanted].max())
         assert np.all(got[~wanted] == -30.0), name                 # unrequested tiles, padding: untouched
+
+
+@pytest.mark.parametrize("n_list", [[8, 3, 5, 1], [40, 33, 17, 8], [100, 104, 64, 2], [130, 256]])
+def test_relate_one_bf16_equals_fp32_kernel_on_rounded_tiles(L, n_list):
+    """The bf16-tile kernel does the same fp32 arithmetic as the fp32-tile kernel: on tiles that are exactly representable in bf16 the
+    two agree to rounding, for EXISTS / FOR_ALL / negated / inactive predicates, ragged images and planted clamped factors."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(sum(n_list) + 3)
+    pq, NS, prior_s, prior_o, tile, _ = _logic_inputs(rng, n_list, [1] * len(n_list))
+    NS8 = (NS + 7) // 8 * 8
+    P = len(pq)
+    t32 = np.full((P, NS8, NS8), -30.0, np.float32)
+    t32[:, :NS, :NS] = tile
+    x = np.zeros((P, NS8), np.float32); x[:, :NS] = prior_s
+    pv = np.zeros((P, NS8), np.float32); pv[:, :NS] = prior_o
+    if n_list[0] >= 3:
+        pv[0, 1] = 0.0
+        t32[0, 1, 2] = 0.0                                      # exactly-certain prior meets exactly-certain likelihood: the clamped case
+    t16 = dev(t32).to(torch.bfloat16)
+    t32r = t16.float()
+    n_obj = np.array(n_list, np.int32)
+    for quant in (np.ones(P, np.float32), (rng.uniform(size=P) < 0.5).astype(np.float32)):
+        for any_neg in (False, True):
+            neg = (rng.uniform(size=P) < 0.5).astype(np.uint8) if any_neg else None
+            active = np.ones(P, np.uint8)
+            if P > 2:
+                active[2] = 0
+            a = _lib.relate_one_fwd_bf16(dev(x), dev(pv), t16, dev(pq), dev(n_obj), dev(quant), None if neg is None else dev(neg), dev(active))
+            b = _lib.relate_one_fwd(dev(x), dev(pv), t32r, dev(pq), dev(n_obj), dev(quant), None if neg is None else dev(neg), dev(active))
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            for p in range(P):
+                n = n_list[p]
+                assert np.allclose(a[p, :n], b[p, :n], rtol=0, atol=3e-5 * max(1.0, np.abs(b[p, :n]).max())), (p, n, any_neg)
+                assert np.all(a[p, n:] == 0)

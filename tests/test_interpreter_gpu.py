@@ -218,14 +218,23 @@ def random_questions(kind, count, n_lo, n_hi, C, CR, seed):
 @pytest.mark.parametrize("kind", ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
                                   "two_same", "two_different", "all_same", "all_different", "compare"])
 def test_all_ops_against_oracle(ontology, oracle_ontology, kind):
+    """Random programs of every terminal operator against the oracle.  DFOL_FUZZ_SEEDS=n runs n differently seeded batches
+    (different scene sizes and ProgramBatch splits) instead of one."""
+    for rnd in range(int(os.environ.get("DFOL_FUZZ_SEEDS", "1"))):
+        _all_ops_case(ontology, oracle_ontology, kind, zlib.crc32(kind.encode()) % 1000 + 7919 * rnd, 2 + rnd % 3, (2, 40) if rnd % 2 == 0 else (1, 17))
+
+
+def _all_ops_case(ontology, oracle_ontology, kind, seed, split, n_range):
     C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
-    qs, scenes = random_questions(kind, 24, 2, 40, C, CR, seed=zlib.crc32(kind.encode()) % 1000)
+    qs, scenes = random_questions(kind, 24, n_range[0], n_range[1], C, CR, seed=seed)
     model = table_model(ontology)
-    res, _ = run(model, qs, scenes, ontology, split=2)
+    res, _ = run(model, qs, scenes, ontology, split=split)
     lp = res["log_probability"].cpu().numpy()
-    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, split=2)
-    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, split=2)
-    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], kind)
+    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, split=split)
+    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, split=split)
+    # `compare` renormalises two aggregated log-probabilities: its output can agree between the reference's fp32 and fp64 runs while
+    # both inputs carry 1e-3 of rounding noise, so rule 1 of the policy (1e-4 where fp32 == fp64) is widened for it
+    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], "%s seed %d" % (kind, seed), lp_tol=5e-3 if kind == "compare" else 1e-4)
     if kind not in ("compare",):
         # answers may only differ where the decision is a tie within rounding: two options with (nearly) equal
         # probability, or a binary probability sitting on 0.5
@@ -242,7 +251,7 @@ def test_all_ops_against_oracle(ontology, oracle_ontology, kind):
         else:
             decided = list(np.abs(np.exp(lp64) - 0.5) > 4 * np.abs(np.exp(lp32) - np.exp(lp64)) + 1e-5)
         diff = [i for i, (x, y) in enumerate(zip(res["answer"], r64["answer"])) if x != y and decided[i]]
-        assert not diff, (kind, diff)
+        assert not diff, (kind, seed, diff)
 
 
 def test_ragged_to_100_objects(ontology, oracle_ontology):

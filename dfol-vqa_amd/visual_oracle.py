@@ -468,7 +468,7 @@ class ClassifierOracle(OracleBase):
         tiles = self._new_tiles(world, total, torch.bfloat16 if bf16 else torch.float32)
         # the request arrays depend on the program batch only: build and upload them once per batch (a pageable upload
         # synchronises the stream), keyed by what else they depend on
-        key = (id(self), Q, tuple((e[0].cols.tobytes(), e[0].valid.tobytes(), np.asarray(e[1]).tobytes(), e[2].tobytes()) for e in entries))
+        key = (id(self), str(world._device), Q, tuple((e[0].cols.tobytes(), e[0].valid.tobytes(), np.asarray(e[1]).tobytes(), e[2].tobytes()) for e in entries))
         plan = getattr(program_batch, "_dfol_rel_plan", None)
         if plan is None or plan[0] != key:
             rows_col, rows_tile, rows_orient, invalid, base = [], [], [], [], 0

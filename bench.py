@@ -186,10 +186,12 @@ def main():
             ach = nbytes / (secs / max(launches, 1))
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": ach / HBM_PEAK, "traffic": None}
-        out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if args.stress_preds > 0 else []
+        # the logic kernels' roofline stress and the host baseline belong to the single-GPU run; with more ranks the others would
+        # only wait for rank 0 at the final barrier
+        out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if (args.stress_preds > 0 and world == 1) else []
         attach_traffic(out, args)
         sample = args.cpu_sample if args.cpu_sample is not None else (64 if args.objects > 64 else 256)     # about 10 s of host work
-        if sample > 0:
+        if sample > 0 and world == 1:
             out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs[:sample], res, sample)
         print(json.dumps(out))
     if dist:

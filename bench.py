@@ -191,6 +191,7 @@ def main():
         out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if (args.stress_preds > 0 and world == 1) else []
         attach_traffic(out, args)
         sample = args.cpu_sample if args.cpu_sample is not None else (64 if args.objects > 64 else 256)     # about 10 s of host work
+        out["cpu_baseline"] = None
         if sample > 0 and world == 1:
             out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs[:sample], res, sample)
         print(json.dumps(out))

@@ -310,3 +310,93 @@ class BatchGQABoxFeaturesCollator(ProgramCollaterBase):
                 'embedding': torch.zeros(len(tokens), 1) if emb is None else torch.from_numpy(emb).float(),
                 'questions': [q.get('question') for q in questions], 'image_ids': [q['image_id'] for q in questions],
                 'question_ids': [q.get('question_id') for q in questions]}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Program verifier (the part that guards the interpreter's input): nn/parser/parse_utils.py:24-240
+# ---------------------------------------------------------------------------------------------------------------------
+class ParserError(Exception):
+    pass
+
+
+_NEGATED = re.compile(r"not\((\w|\s)+\)")
+_BLANK = ("_", "scene")
+# operator -> kinds of its arguments.  v: a vocabulary token; n: a noun slot (vocabulary token, "_" or "scene"); r: a relation;
+# b: a bool; c: a category (attribute / class family, "name", "type"); V2 / V+ / R+: a list of exactly two / at least one such tokens
+_SIGNATURES = {"select": ("n",), "filter": ("v",), "relate": ("r", "b", "n"), "verify_rel": ("r", "b", "n"), "choose_rel": ("R+", "b", "n"),
+               "query_attr": ("c",), "all_same": ("c",), "all_different": ("c",), "two_same": ("c",), "two_different": ("c",),
+               "choose_attr": ("V2",), "verify_attrs": ("V+",), "compare": ("v", "b"), "exist": (), "and": (), "or": ()}
+_BRANCH_OPS = ("select", "filter", "relate")
+_TWO_BRANCH = ("and", "or", "two_same", "two_different", "compare")
+
+
+class GQAProgramVerifier(object):
+    """Accepts exactly the programs the reference's verifier accepts (golden g13): operator names, argument counts and kinds,
+    branch structure.  `verify` returns True or raises ParserError."""
+
+    def __init__(self, attribute_json_path, class_json_path, vocab_json_path, relation_json_path):
+        from .gqa_ops import GQAOntology
+        self._ontology = GQAOntology(attribute_json_path, class_json_path, vocab_json_path, None, relation_json_path=relation_json_path)
+
+    @staticmethod
+    def _plain(tokens):
+        """Strip `not(...)`; like the reference, whitespace is only stripped when some token of the list is negated (:31-46)."""
+        negated = [_NEGATED.match(t.strip()) is not None for t in tokens]
+        if not any(negated):
+            return list(tokens)
+        return [t.strip()[4:-1] if n else t.strip() for t, n in zip(tokens, negated)]
+
+    def _check(self, name, kind, arg):
+        ont = self._ontology
+        vocab = ont._vocabulary['arg_to_idx']
+        if kind == "b":
+            if not isinstance(arg, bool):
+                raise ParserError("'%s': a flag argument must be a boolean, got %s" % (name, type(arg)))
+        elif kind == "c":
+            if arg not in ont._class_dict and arg not in ont._attribute_dict and arg not in ('name', 'type'):
+                raise ParserError("'%s' has an unknown category argument: %s" % (name, arg))
+        elif kind in ("V2", "V+", "R+"):
+            if kind == "V2" and len(arg) != 2:
+                raise ParserError("'%s' must have 2 options, but has %d" % (name, len(arg)))
+            if len(arg) == 0:
+                raise ParserError("'%s' must have at least one option" % name)
+            for t in self._plain(arg):
+                if not (ont.is_relation(t.lower()) if kind == "R+" else t.lower() in vocab):
+                    raise ParserError("'%s' option is not a %s: %s" % (name, "relation" if kind == "R+" else "vocabulary token", t))
+        else:
+            t = self._plain([arg])[0].lower()
+            ok = ont.is_relation(t) if kind == "r" else (t in vocab or (kind == "n" and t in _BLANK))
+            if not ok:
+                raise ParserError("'%s' argument is not a %s: %s" % (name, {"r": "relation", "n": "noun", "v": "vocabulary token"}[kind], arg))
+
+    def _verify_op(self, name, arguments):
+        if name not in _SIGNATURES:
+            raise ParserError("Invalid operator: %s" % name)
+        kinds = _SIGNATURES[name]
+        if len(arguments) != len(kinds):
+            raise ParserError("'%s' must have %d argument(s), but has %d argument(s)." % (name, len(kinds), len(arguments)))
+        for kind, arg in zip(kinds, arguments):
+            self._check(name, kind, arg)
+
+    def verify(self, program):
+        if 'last_op' not in program or 'operator' not in program['last_op']:
+            raise ParserError("The 'last_op' / 'operator' field is missing: " + str(program))
+        last = program['last_op']['operator']
+        if last in _BRANCH_OPS:
+            raise ParserError("'%s' is not a terminal operator" % last)
+        self._verify_op(last, program['last_op']['arguments'])
+        if 'branches' not in program:
+            raise ParserError("The 'branches' field is missing: " + str(program))
+        want = 2 if last in _TWO_BRANCH else 1
+        if len(program['branches']) != want:
+            raise ParserError("'%s' must have exactly %d branch(es)." % (last, want))
+        for branch in program['branches']:
+            for i, op in enumerate(branch):
+                if 'operator' not in op:
+                    raise ParserError("The 'operator' field is missing: " + str(op))
+                if (i == 0) != (op['operator'] == 'select') or op['operator'] not in _BRANCH_OPS:
+                    raise ParserError("A branch is a 'select' followed by 'filter' / 'relate' operators: " + str(op['operator']))
+                if 'arguments' not in op:
+                    raise ParserError("The 'arguments' field is missing: " + str(op))
+                self._verify_op(op['operator'], op['arguments'])
+        return True

@@ -118,3 +118,18 @@ def test_feature_collator_layout(ontology, tmp_path):
     assert np.allclose(row[F:], [640, 480, b[0], b[1], b[2] - b[0], b[3] - b[1]])
     assert pb._op_batch_list[0]._arguments[0].lowered is not None       # lowered at collate time
     assert set(pb._meta_data["index"]) == {"dog", "red"} and pb._meta_data["embedding"].shape == (2, 12)
+
+
+def test_g13_program_verifier(mini_ontology_paths):
+    """The verifier accepts exactly the programs the reference's GQAProgramVerifier accepts (nn/parser/parse_utils.py:24-240)."""
+    from dfol_vqa_amd.data import GQAProgramVerifier, ParserError
+    _, meta = gu.load("g13_program_verifier")
+    p = mini_ontology_paths
+    ver = GQAProgramVerifier(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+    assert len(meta["programs"]) == 48 and sum(meta["valid"]) == 18
+    for i, (prog, valid) in enumerate(zip(meta["programs"], meta["valid"])):
+        try:
+            got = ver.verify(prog)
+        except ParserError:
+            got = False
+        assert got == valid, (i, prog, valid)

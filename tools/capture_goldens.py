@@ -824,8 +824,62 @@ def g10():
     save("g10_calibration", arrays, meta)
 
 
+def g13():
+    """Verdicts of the reference's GQAProgramVerifier (nn/parser/parse_utils.py:24-240) on well-formed and malformed programs."""
+    for name in ("pattern", "pattern.text", "pattern.text.en"):       # only `normalize` uses singularize; the verifier does not
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.singularize = lambda w: w
+        sys.modules.setdefault(name, m)
+    sys.path.insert(0, ref_harness.REF_SRC)
+    from nsvqa.nn.parser import parse_utils
+    p = paths
+    ver = parse_utils.GQAProgramVerifier(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+    sel = lambda n="dog": op("select", n)
+    P = lambda br, last: {"branches": br, "last_op": last}
+    two = [[sel("dog"), op("filter", "red")], [sel("cat")]]
+    cases = [
+        P([[sel(), op("filter", "not(red)"), op("relate", "on", True, "table")]], op("exist")),
+        P([[sel("_"), op("relate", "to the left of", False, "_")]], op("exist")),
+        P([[sel("scene")]], op("exist")),
+        P([[sel("unicorn")]], op("exist")),                                   # noun not in the vocabulary
+        P([[sel(), op("filter", "shiny")]], op("exist")),                     # unknown attribute
+        P([[sel(), op("relate", "red", True, "table")]], op("exist")),        # not a relation
+        P([[sel(), op("relate", "riding", True, "table")]], op("exist")),     # a relation the vocabulary lacks
+        P([[sel(), op("relate", "on", 1, "table")]], op("exist")),            # flag must be a bool
+        P([[sel(), op("relate", "on", True, "unicorn")]], op("exist")),
+        P([[sel(), op("relate", "on", True)]], op("exist")),                  # wrong argument count
+        P([[op("filter", "red")]], op("exist")),                              # branch must start with select
+        P([[sel(), sel("cat")]], op("exist")),                                # select inside a branch
+        P([[sel(), op("exist")]], op("exist")),                               # terminal operator inside a branch
+        P([[sel()]], op("filter", "red")),                                    # non-terminal last_op
+        P([[sel()]], op("jump")),                                             # unknown operator
+        P([[sel()], [sel("cat")]], op("exist")),                              # branch count
+        P(two, op("and")), P(two, op("or")), P([[sel()]], op("and")),
+        P([[sel()]], op("query_attr", "color")), P([[sel()]], op("query_attr", "name")), P([[sel()]], op("query_attr", "animal")),
+        P([[sel()]], op("query_attr", "flavour")),
+        P([[sel()]], op("choose_attr", ["red", "blue"])), P([[sel()]], op("choose_attr", ["red"])), P([[sel()]], op("choose_attr", ["red", "shiny"])),
+        P([[sel()]], op("verify_attrs", ["red", "not(large)"])), P([[sel()]], op("verify_attrs", [])), P([[sel()]], op("verify_attrs", ["shiny"])),
+        P([[sel()]], op("verify_rel", "on", True, "table")), P([[sel()]], op("verify_rel", "over", True, "table")),
+        P([[sel()]], op("choose_rel", ["on", "under"], False, "_")), P([[sel()]], op("choose_rel", [], False, "_")),
+        P([[sel()]], op("choose_rel", ["on", "red"], False, "_")),
+        P([[sel()]], op("all_same", "color")), P([[sel()]], op("all_different", "type")), P([[sel()]], op("all_same", "flavour")),
+        P(two, op("two_same", "material")), P(two, op("two_different", "flavour")), P([[sel()]], op("two_same", "color")),
+        P(two, op("compare", "large", False)), P(two, op("compare", "not(small)", True)), P(two, op("compare", "shiny", True)),
+        P(two, op("compare", "large", 0)),
+        {"branches": [[sel()]]}, {"last_op": op("exist")}, P([[{"arguments": []}]], op("exist")), P([[{"operator": "select"}]], op("exist")),
+    ]
+    verdicts = []
+    for prog in cases:
+        try:
+            verdicts.append(bool(ver.verify(copy.deepcopy(prog))))
+        except parse_utils.ParserError:
+            verdicts.append(False)
+    save("g13_program_verifier", {}, {"source": "nn/parser/parse_utils.py:24-240", "programs": cases, "valid": verdicts})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()
 

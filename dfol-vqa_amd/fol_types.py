@@ -219,7 +219,8 @@ class BatchVariableSet(object):
         if isinstance(quantifiers, (int, float, Quantifier)):
             self._quantifier = torch.full((batch_size,), float(quantifiers), dtype=torch.float32, device=device)
         elif isinstance(quantifiers, (list, tuple)):
-            self._quantifier = torch.tensor(quantifiers, dtype=torch.float32, device=device)
+            from .host_util import upload
+            self._quantifier = upload(np.asarray(quantifiers, np.float32), device)
         else:
             self._quantifier = quantifiers
 
@@ -286,8 +287,11 @@ class BatchVariableSet(object):
         if len(host_flag) == self._log_attention.shape[0] and all(f == 1 for f in host_flag):
             att, quant = self._log_attention, self._quantifier       # every row takes self: g x + (1 - g) y = x, no launch
         else:
-            g = flag.to(torch.float32) if isinstance(flag, torch.Tensor) else \
-                torch.tensor([float(f) for f in host_flag], dtype=torch.float32, device=self._device)
+            if isinstance(flag, torch.Tensor):
+                g = flag.to(torch.float32)
+            else:
+                from .host_util import upload
+                g = upload(np.asarray([float(f) for f in host_flag], np.float32), self._device)
             att, quant = L.gate(self._log_attention, variable_set._log_attention, self._quantifier, variable_set._quantifier, g)
         out = BatchVariableSet(names, self._device, self._object_num, self._batch_size, quantifiers=quant, log_attention=att,
                                world=self._world)
@@ -336,7 +340,8 @@ class BatchAttentionState(object):
                 host = flag.cpu().numpy().tolist()
         else:
             host = [0 if f is None else f for f in flag]
-            g = torch.tensor([float(f) for f in host], dtype=torch.float32, device=self._device)
+            from .host_util import upload
+            g = upload(np.asarray([float(f) for f in host], np.float32), self._device)
         g = g.unsqueeze(1)
         state0 = self._state[0] * g + attention_state._state[0] * (1.0 - g)
         state1 = self._state[1] * g + attention_state._state[1] * (1.0 - g)

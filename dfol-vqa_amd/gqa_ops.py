@@ -221,7 +221,7 @@ def _subject_flags(is_subject, device):
     host = [0.0 if f is None else float(f) for f in is_subject]
     t = getattr(is_subject, "device_flags", None)
     if t is None or t.device != torch.device(device):
-        t = torch.tensor(host, dtype=torch.float32, device=device)
+        t = upload(np.asarray(host, np.float32), device)
     t._host = host
     return t, host
 
@@ -244,7 +244,7 @@ class GQARelateBatch(GQABatchOperatorBase):
             return fused
         subject_set = x.gate(variable_set, flag)
         object_set = variable_set.gate(x, flag)
-        want = torch.tensor([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in host], dtype=torch.uint8, device=world._device)
+        want = upload(np.asarray([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in host], np.uint8), world._device)
         subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, want=want)
         return subject_set.gate(object_set, flag)
 
@@ -394,9 +394,9 @@ class GQAChooseRelBatch(GQABatchOperatorBase):
         subject_set = x.gate(variable_set, flag)
         object_set = variable_set.gate(x, flag)
         pred_host = [host[q] for q in batch_index]                                    # pqm @ is_subject  (:254-255)
-        want = torch.tensor([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in pred_host], dtype=torch.uint8, device=world._device)
+        want = upload(np.asarray([L.WANT_SUBJECT if f > 0 else L.WANT_OBJECT for f in pred_host], np.uint8), world._device)
         subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, batch_index, want=want)
-        pflag = torch.tensor(pred_host, dtype=torch.float32, device=world._device)
+        pflag = upload(np.asarray(pred_host, np.float32), world._device)     # (memoised by content, so `_host` below always matches)
         pflag._host = pred_host
         x = subject_set.gate(object_set, pflag)
         log_probability = x.log_probability(give_answer and hard_mode)
@@ -531,7 +531,7 @@ class GQACompareBatch(GQABatchOperatorBase):
         x1 = self._filter(op_id + ':0', world, variable_set1, attribute_list)
         x2 = self._filter(op_id + ':1', world, variable_set2, attribute_list)
         hard = give_answer and hard_mode
-        alpha = torch.tensor([float(bool(v)) for v in is_less], dtype=torch.float32, device=variable_set1.device)
+        alpha = upload(np.asarray([float(bool(v)) for v in is_less], np.float32), variable_set1.device)
         log_probability = L.compare(x1.log_probability(hard), x2.log_probability(hard), alpha)       # [Q, 2]  (:734-738)
         options = list(zip(variable_set1._name, variable_set2._name))
         answer, alp = [], []

@@ -5,12 +5,13 @@ Reference: src/nsvqa/nn/interpreter/batch_base_ops.py (BatchBayesianLogicCell :4
 resolve tokens, pick priors/quantifiers and launch.
 """
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import ops as L
 from .fol_types import BatchAttentionState, BatchVariableSet, Quantifier, TokenType
-from .host_util import detect_negations, get_lowered, is_valid_token
+from .host_util import upload, detect_negations, get_lowered, is_valid_token
 
 
 class BatchBayesianLogicCell(nn.Module):
@@ -100,7 +101,7 @@ class BatchOperatorBase(nn.Module):
         if all(ind):
             return feats
         full = torch.zeros(len(tokens), feats.shape[1], dtype=torch.float32, device=world._device)
-        full[torch.tensor(ind, dtype=torch.bool, device=world._device)] = feats
+        full[upload(np.asarray(ind, np.bool_), world._device)] = feats
         return full
 
     def _compute_attention_modulations(self, forward_state, backward_state):    # :275-286

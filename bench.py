@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=None, help="questions in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--stress-preds", type=int, default=65536)
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
     return ap.parse_args()
 
 
@@ -118,8 +119,17 @@ def main():
     model = model.to(device).eval()
     qs, pbs = build_batch(args, rank, ontology, names, device)
 
-    def step():
-        return model(pbs, False)
+    eager = lambda: model(pbs, False)
+    step = eager
+    graphed = False
+    if args.graph:
+        from dfol_vqa_amd.interpreter import GraphedForward
+        try:
+            step = GraphedForward(model, pbs)
+            graphed = True
+        except Exception as e:                              # capture is an optimisation of the host side only: fall back to eager launches
+            sys.stderr.write("graph capture failed (%s); running eager\n" % e)
+            torch.cuda.synchronize()
 
     def barrier():
         if dist:
@@ -146,7 +156,8 @@ def main():
            "config": {"workload": "BASELINE configs[1]: select->filter->relate->exist (3-hop), fp32, %d questions/GPU/step, "
                                   "%d-object synthetic scenes, full-size oracle (2048->512, 516/1036->256->300->2335)"
                                   % (args.batch, args.objects),
-                      "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world}}
+                      "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
+                      "launch": "hip graph replay" if graphed else "eager"}}
 
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
@@ -154,7 +165,7 @@ def main():
         with torch.no_grad():
             L.enable_kernel_timing(names_timed)
             for _ in range(3):
-                step()
+                eager()
             torch.cuda.synchronize()
             timing = L.disable_kernel_timing()
         per_step = {k: (n / 3.0, t / 3.0) for k, (n, t) in timing.items() if n}

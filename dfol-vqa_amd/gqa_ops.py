@@ -8,6 +8,7 @@ state; the only host work is string bookkeeping (names, answers).
 import json
 import math
 import re
+import threading
 
 import numpy as np
 import torch
@@ -157,15 +158,42 @@ class GQABatchOperatorBase(BatchOperatorBase):
         self._ontology = ontology
 
 
+class _Deferred(threading.local):
+    """While `queue` is a list, terminal operators do not read their log-probabilities back: they return empty answer lists and
+    queue a closure that fills them.  The interpreter runs the closures after the last ProgramBatch has been enqueued (one
+    device->host synchronisation per forward instead of one per ProgramBatch), or after replaying a captured graph."""
+    queue = None
+
+
+DEFERRED = _Deferred()
+
+
+def _answers(compute):
+    """compute() -> (answer, answer_log_probability) from host copies; run now, or queued (see _Deferred)."""
+    if DEFERRED.queue is None:
+        return compute()
+    answer, alp = [], []
+
+    def fill():
+        a, l = compute()
+        answer[:] = a
+        alp[:] = l
+    DEFERRED.queue.append(fill)
+    return answer, alp
+
+
 def _binary_answer(log_probability, batch_size, give_answer):
     """yes/no from p > 0.5 plus the log-probability of the answer given (e.g. batch_gqa_ops.py:404-407)."""
     if not give_answer:
         return [], []
-    # the one device->host sync of a binary op; safe_exp (util.py:19) on the host copy instead of one more launch
-    probability = np.exp(log_probability.detach().cpu().numpy().astype(np.float32)).tolist()
-    answer = [['yes'] if probability[i] > 0.5 else ['no'] for i in range(batch_size)]
-    alp = [[math.log(probability[i])] if probability[i] > 0.5 else [math.log(1 - probability[i])] for i in range(batch_size)]
-    return answer, alp
+
+    def compute():
+        # the one device->host sync of a binary op; safe_exp (util.py:19) on the host copy instead of one more launch
+        probability = np.exp(log_probability.detach().cpu().numpy().astype(np.float32)).tolist()
+        answer = [['yes'] if probability[i] > 0.5 else ['no'] for i in range(batch_size)]
+        alp = [[math.log(probability[i])] if probability[i] > 0.5 else [math.log(1 - probability[i])] for i in range(batch_size)]
+        return answer, alp
+    return _answers(compute)
 
 
 def _result(answer, log_probability, options, variable_set, qtype, cumulative_loss, variable_sets_num, answer_log_probability):
@@ -340,8 +368,10 @@ class GQAVerifyRelBatch(GQABatchOperatorBase):
 def _choose_answer(log_probability, x, option_list, batch_index, question_num, likelihood_threshold, give_answer):
     if not give_answer:
         return [], []
-    flags = find_max_ind(log_probability, np.asarray(batch_index), question_num, likelihood_threshold).tolist()   # util.py:64-66
-    return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.detach().cpu().numpy().tolist(), batch_index, flags)
+    def compute():
+        flags = find_max_ind(log_probability, np.asarray(batch_index), question_num, likelihood_threshold).tolist()   # util.py:64-66
+        return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.detach().cpu().numpy().tolist(), batch_index, flags)
+    return _answers(compute)
 
 
 class GQAChooseAttrBatch(GQABatchOperatorBase):
@@ -536,11 +566,12 @@ class GQACompareBatch(GQABatchOperatorBase):
         options = list(zip(variable_set1._name, variable_set2._name))
         answer, alp = [], []
         if give_answer:
-            lp = log_probability.detach().cpu().numpy()
-            ind = lp.argmax(1)
-            for i in range(variable_set1.batch_size()):
-                answer.append([options[i][ind[i]]])
-                alp.append([float(lp[i, ind[i]])])
+            def compute():
+                lp = log_probability.detach().cpu().numpy()
+                ind = lp.argmax(1)
+                n = variable_set1.batch_size()
+                return [[options[i][ind[i]]] for i in range(n)], [[float(lp[i, ind[i]])] for i in range(n)]
+            answer, alp = _answers(compute)
         return _result(answer, log_probability.view(-1), options, None, QuestionType.QUERY, x1.cumulative_loss() + x2.cumulative_loss(),
                        x1._prev_variable_sets_num + x2._prev_variable_sets_num + 2, alp)
 

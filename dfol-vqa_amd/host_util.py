@@ -75,8 +75,7 @@ class Lowered(object):
     def on(self, device):
         key = str(device)
         if key not in self._dev:
-            self._dev[key] = (torch.as_tensor(self.cols).to(device), torch.as_tensor(self.neg).to(device),
-                              torch.as_tensor(self.valid).to(device))
+            self._dev[key] = (upload(self.cols, device), upload(self.neg, device), upload(self.valid, device))
         return self._dev[key]
 
 
@@ -101,10 +100,11 @@ def lower_tokens(tokens, ontology, token_type):
     (classifier_oracle.py:49-56 for attributes: column = arg_to_idx-1 of the full table;
     :89-96 for relations: column in the 333-wide table via _relation_reveresed_index).
     Unknown tokens raise KeyError like the reference's itemgetter."""
-    # long lists (the per-question category expansions of query / same / different operators: thousands of tokens) are memoised
-    # by content: resolving 6656 strings costs 7 ms of host time per operator call, more than the whole GPU step
+    # memoised by content: the per-question category expansions of query / same / different operators are thousands of tokens
+    # (resolving 6656 strings costs 7 ms of host time per call, more than the whole GPU step), and a recurring list maps to the
+    # same Lowered object, whose device copies are then uploaded once
     key = None
-    if len(tokens) >= 64:
+    if len(tokens) >= 1:
         cache = ontology.__dict__.setdefault("_lower_cache", {})       # lives and dies with the ontology it was resolved against
         key = (int(token_type), tuple(tokens))
         hit = cache.get(key)

@@ -497,7 +497,7 @@ class ClassifierOracle(OracleBase):
             program_batch._dfol_rel_plan = plan
         _, req_col, req_tile, req_orient, invalid = plan
         if invalid is not None and not (min(world._n_list) < world._NS):
-            tiles[invalid] = -30.0
+            tiles.index_fill_(0, invalid, -30.0)       # (advanced-index assignment is not capturable in a HIP graph)
         base = 0
         for low, pq, orient in entries:
             P = len(pq)
@@ -527,7 +527,7 @@ class ClassifierOracle(OracleBase):
         req_tile[slot, pq] = np.arange(P, dtype=np.int32)
         tiles = self._new_tiles(world, P)
         if not low.all_valid:
-            tiles[upload(np.nonzero(low.valid == 0)[0], world._device)] = -30.0
+            tiles.index_fill_(0, upload(np.nonzero(low.valid == 0)[0], world._device), -30.0)
         self._launch_pairs(world, req_col, req_tile, tiles)
         return tiles
 
@@ -564,7 +564,7 @@ class ClassifierOracle(OracleBase):
         ll_c = gather(cols.index_select(0, keep).contiguous(), pq_c)
         ll_c = L.option_normalize_(ll_c, upload(seg, dev), pq_c, world._n_obj, world._NS)
         ll = torch.full((len(low.cols),) + tuple(ll_c.shape[1:]), float(default_log_likelihood), dtype=torch.float32, device=dev)
-        ll[keep] = ll_c
+        ll.index_copy_(0, keep, ll_c)
         return ll
 
     def _block_likelihood_needed(self, token_type, low, cols, pred_q, pred_q_host, world, normalized_probability, orientation):
@@ -597,5 +597,5 @@ class ClassifierOracle(OracleBase):
         pq_c = pred_q.index_select(0, keep).contiguous()
         ll_c = ll.index_select(0, keep).contiguous()
         ll_c = L.option_normalize_(ll_c, upload(seg, dev), pq_c, world._n_obj, world._NS)
-        ll[keep] = ll_c
+        ll.index_copy_(0, keep, ll_c)
         return ll

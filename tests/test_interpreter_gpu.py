@@ -513,3 +513,38 @@ def test_full_batch_properties(tmp_path):
     assert np.array_equal(lp_rev[::-1], lp)                      # same padded width, same kernels: bit-identical
     lp_split = run(model, qs, scenes, ont, split=4, key="X")[0]["log_probability"].cpu().numpy()
     assert np.array_equal(lp_split, lp)
+
+
+def test_graphed_forward_equals_eager(tmp_path):
+    """The captured-graph forward replays the same launches: identical log-probabilities and answers, also after the scene features
+    behind the ProgramBatch are overwritten in place, and for a QUERY operator whose answers are decoded after the replay."""
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd.interpreter import GraphedForward
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(4)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    for kind in ("exist", "choose_attr"):
+        qs, scenes = _neural_questions(kind, 8, 12, 12, 2048, seed=21, names=nm)
+        qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
+        pbs = [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate(qq)]
+        with torch.no_grad():
+            eager = model(pbs, False)
+        g = GraphedForward(model, pbs)
+        r = g()
+        assert torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"]
+        assert r["answer_log_probability"] == eager["answer_log_probability"]
+        # new scenes of the same shape: overwrite the features in place, replay, compare with an eager run on the new features
+        for pb in pbs:
+            pb._object_features.copy_(torch.rand_like(pb._object_features))
+        with torch.no_grad():
+            eager2 = model(pbs, False)
+        r2 = g()
+        assert torch.equal(r2["log_probability"], eager2["log_probability"]) and r2["answer"] == eager2["answer"]
+        assert not torch.equal(r2["log_probability"], r["log_probability"])

@@ -746,7 +746,7 @@ def gather_results(outputs):                       # data_parallel.py:15-50
 
 
 def run_questions(ontology, questions, scenes, dtype=np.float32, split=1, normalize=True, give_answer=True,
-                  weights=None, return_trace=False, hard_mode=False):
+                  weights=None, return_trace=False, hard_mode=False, threshold=0):
     """The reference's forward over a list of questions: collate (split) -> build_scene -> execute -> gather.
     scenes[i] is {'n', 'A', 'R'} (cached tables) or {'n', 'X'} with `weights` (neural oracle)."""
     dtype = np.dtype(dtype)
@@ -764,7 +764,7 @@ def run_questions(ontology, questions, scenes, dtype=np.float32, split=1, normal
         world = World(ontology, A, R, img, dtype, normalize)
         world.hard_mode = bool(hard_mode)                                  # BatchGQAInterpreter._hard_mode (:23, :73)
         ops, deps = collate_programs(chunk)
-        r = execute_program_batch(world, ops, deps, give_answer, return_trace=return_trace)
+        r = execute_program_batch(world, ops, deps, give_answer, threshold=threshold, return_trace=return_trace)
         if return_trace:
             traces.append(r[1])
             r = r[0]

@@ -31,6 +31,7 @@ G4_CASES = ["g4_exist", "g4_exist_split3", "g4_threehop_n36", "g4_verify_attrs",
             "g4_query_attr", "g4_verify_rel", "g4_choose_rel", "g4_and", "g4_or", "g4_two_same", "g4_two_different",
             "g4_all_same", "g4_all_different", "g4_compare"]
 G4_STRESS = ["g4_stress_mix05", "g4_stress_weak"]
+G14_CASES = ["g14_threshold_query_attr", "g14_threshold_choose_attr", "g14_threshold_choose_rel"]      # likelihood_threshold > 0
 G11_CASES = ["g11_hard_exist", "g11_hard_single", "g11_hard_verify_attrs", "g11_hard_query_attr", "g11_hard_choose_rel", "g11_hard_and",
              "g11_hard_two_same", "g11_hard_all_same", "g11_hard_all_different", "g11_hard_two_different", "g11_hard_compare"]       # hard_mode = True (batch_base_types.py:104-112)
 

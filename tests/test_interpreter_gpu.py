@@ -75,7 +75,7 @@ def run(model, questions, scenes, ontology, split=1, lower=True, return_trace=Fa
         return model(pbs, training, return_trace=return_trace), pbs
 
 
-@pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS + gu.G11_CASES)
+@pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS + gu.G11_CASES + gu.G14_CASES)
 @pytest.mark.parametrize("lower", [True, False])
 def test_g4_goldens(ontology, name, lower):
     """Whole-interpreter goldens (g4) and the same in hard_mode (g11: min/max aggregation, batch_base_types.py:104-112)."""
@@ -83,6 +83,7 @@ def test_g4_goldens(ontology, name, lower):
     qs, scenes = gu.questions_and_scenes(a, meta)
     model = table_model(ontology, meta.get("normalize", True))
     model._hard_mode = meta.get("hard_mode", False)
+    model._likelihood_threshold = meta.get("likelihood_threshold", 0)
     res, _ = run(model, qs, scenes, ontology, meta.get("split", 1), lower)
     lp = res["log_probability"].cpu().numpy()
     if name in gu.G4_STRESS:

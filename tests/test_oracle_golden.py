@@ -122,7 +122,7 @@ def test_g3_filter_relate(ontology):
                     gu.check_logprob(got[own], ref[own], ref64[own], n, lp_tol=2e-4)
 
 
-@pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS + ["g4_end"] + gu.G11_CASES)
+@pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS + ["g4_end"] + gu.G11_CASES + gu.G14_CASES)
 def test_g4_interpreter(ontology, name):
     a, meta = gu.load(name)
     qs, scenes = gu.questions_and_scenes(a, meta)
@@ -131,7 +131,7 @@ def test_g4_interpreter(ontology, name):
             q["program"]["last_op"] = {"operator": "end", "arguments": []}
     for tag, dt in (("f64", np.float64), ("f32", np.float32)):
         res = orc.run_questions(ontology, qs, scenes, dt, split=meta.get("split", 1), normalize=meta.get("normalize", True),
-                                hard_mode=meta.get("hard_mode", False))
+                                hard_mode=meta.get("hard_mode", False), threshold=meta.get("likelihood_threshold", 0))
         if dt == np.float64:
             assert np.allclose(res["log_probability"], a["lp_f64"], rtol=1e-8, atol=1e-8), name
         elif name in gu.G4_STRESS:

@@ -163,12 +163,13 @@ def g2():
 
 # ---------------------------------------------------------------------------------------- interpreter runs
 def run_reference(questions, split=1, dtype=torch.float32, training=False, return_trace=True, normalize=True,
-                  grad_tables=False, hard=False):
+                  grad_tables=False, hard=False, threshold=0):
     qs = copy.deepcopy(questions)
     collater = ref_harness.make_collater(ref, split, "table")
     pbs = collater.collate(qs)
     model = ref_harness.build_table_interpreter(ref, ontology, normalize)
     model._hard_mode = hard                                  # batch_gqa_interpreter.py:23,73
+    model._likelihood_threshold = threshold                  # :22,73
     leaves = []
     for pb in pbs:
         pb.create_sparse_tensors()
@@ -219,16 +220,17 @@ def questions_to_meta(questions):
     return out
 
 
-def capture_run(name, questions, split=1, normalize=True, arrays=None, meta=None, hard=False):
+def capture_run(name, questions, split=1, normalize=True, arrays=None, meta=None, hard=False, threshold=0):
     arrays = {} if arrays is None else arrays
     meta = {} if meta is None else meta
     meta.update({"questions": questions_to_meta(questions), "split": split, "normalize": normalize, "hard_mode": hard,
+                 "likelihood_threshold": threshold,
                  "source": "batch_base_interpreter.py:72-183"})
     for i, q in enumerate(questions):
         arrays["A_%d" % i] = q["scene"]["A"]
         arrays["R_%d" % i] = q["scene"]["R"]
     for dt, tag in both_dtypes():
-        (res, traces), pbs, _ = run_reference(questions, split, dt, normalize=normalize, hard=hard)
+        (res, traces), pbs, _ = run_reference(questions, split, dt, normalize=normalize, hard=hard, threshold=threshold)
         pack_result(arrays, meta, tag, res, traces)
         if tag == "f32":
             meta["op_names"] = [[ob._op_name for ob in pb._op_batch_list] for pb in pbs]
@@ -495,6 +497,22 @@ def g5():
 
 
 # ---------------------------------------------------------------------------------------- g12
+def g14():
+    """likelihood_threshold > 0 (batch_gqa_interpreter.py:22; util.py:64-66): QUERY answers below the threshold are dropped."""
+    Q = syn.question
+    n_of = lambda i: [5, 7, 3, 6, 4, 8, 2, 5][i % 8]
+    mk = lambda i, branches, last, answer: Q(1000 + i, branches, last, answer, scene_for(1000 + i, n_of(i)))
+    qa = [mk(i, [[op("select", n)] + ([op("filter", "small")] if i % 2 else [])], op("query_attr", c), "red")
+          for i, (n, c) in enumerate([("dog", "color"), ("animal", "name"), ("chair", "material"), ("cup", "size"), ("man", "pose"), ("car", "color")])]
+    capture_run("g14_threshold_query_attr", qa, threshold=0.03)
+    ca = [mk(10 + i, [[op("select", n)]], op("choose_attr", o), o[0])
+          for i, (n, o) in enumerate([("dog", ["red", "blue"]), ("table", ["small", "large"]), ("cat", ["black", "white"]), ("bus", ["metal", "glass"])])]
+    capture_run("g14_threshold_choose_attr", ca, threshold=0.3)
+    cr = [mk(20 + i, [[op("select", n)]], op("choose_rel", o, bool(i % 2), "table"), o[0])
+          for i, (n, o) in enumerate([("dog", ["on", "under"]), ("man", ["near", "behind"]), ("cup", ["to the left of", "to the right of"])])]
+    capture_run("g14_threshold_choose_rel", cr, threshold=0.01)
+
+
 def g12():
     """Gradients of the train-step loss w.r.t. every weight of the neural model (featurizer, attribute / relation MLPs, embedding
     layer) at reduced dims, from the reference's own autograd (trainer.py:181-262, 429-442), for a BINARY and a QUERY batch."""
@@ -879,7 +897,7 @@ def g13():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()
 

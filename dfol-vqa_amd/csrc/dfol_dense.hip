@@ -16,11 +16,19 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, PITCH = 36;
 
-template <int ALIGN>
+template <int ALIGN, bool FULL = false>
 __device__ __forceinline__ float4 load4(const float* __restrict__ base, int64_t ld, int row, int col, int rows, int cols) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row >= rows || col >= cols) return v;
+    if (!FULL && (row >= rows || col >= cols)) return v;
     const float* p = base + (int64_t)row * ld + col;
+    if (FULL) {
+        if (ALIGN == 4) return *reinterpret_cast<const float4*>(p);
+        if (ALIGN == 2) {
+            const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+            return make_float4(a.x, a.y, b.x, b.y);
+        }
+        return make_float4(p[0], p[1], p[2], p[3]);
+    }
     if (col + 3 < cols) {
         if (ALIGN == 4) return *reinterpret_cast<const float4*>(p);
         if (ALIGN == 2) {
@@ -45,7 +53,9 @@ __device__ __forceinline__ float activate(float x) {
 
 // BMT = rows of the block tile: 128 (each wavefront 64x64) or 64 (each wavefront 32x64).  The small tile doubles the number of
 // workgroups; the host picks it when the 128-row grid would leave CUs idle (M = 9216: 288 workgroups for 256 CUs).
-template <int ACT, int ALIGN_X, int ALIGN_W, int BMT>
+// FULL: 0 = every operand load is bounds-checked; 1 = M and N are multiples of the tile, so the loads of every K chunk that lies
+// inside K are unchecked (the last, partial chunk still is); 2 = K is a multiple of the chunk too: no checks at all.
+template <int ACT, int ALIGN_X, int ALIGN_W, int BMT, int FULL>
 __global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                          int64_t ldw, const float* __restrict__ bias, float* __restrict__ Y,
                                                          int64_t ldy, int M, int N, int K) {
@@ -69,9 +79,9 @@ __global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict
 
     float4 ra[PA], rb[4];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, lk, M, K);
+    for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X, false>(X, ldx, m0 + lrow + 32 * i, lk, M, K);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, lk, N, K);
+    for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W, false>(W, ldw, n0 + lrow + 32 * i, lk, N, K);
 
     const int half = lane >> 5, r32 = lane & 31;
     for (int k0 = 0; k0 < K; k0 += BK) {
@@ -81,11 +91,16 @@ __global__ __launch_bounds__(256) void linear_act_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * PITCH + lk]) = rb[i];
         __syncthreads();
-        if (k0 + BK < K) {
+        if (FULL == 2 ? k0 + BK < K : (FULL == 1 && k0 + 2 * BK <= K)) {      // the next chunk lies entirely inside K: unchecked loads
 #pragma unroll
-            for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X>(X, ldx, m0 + lrow + 32 * i, k0 + BK + lk, M, K);
+            for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X, true>(X, ldx, m0 + lrow + 32 * i, k0 + BK + lk, M, K);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W>(W, ldw, n0 + lrow + 32 * i, k0 + BK + lk, N, K);
+            for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W, true>(W, ldw, n0 + lrow + 32 * i, k0 + BK + lk, N, K);
+        } else if (FULL != 2 && k0 + BK < K) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) ra[i] = load4<ALIGN_X, false>(X, ldx, m0 + lrow + 32 * i, k0 + BK + lk, M, K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = load4<ALIGN_W, false>(W, ldw, n0 + lrow + 32 * i, k0 + BK + lk, N, K);
         }
         float a[TI][16], b[2][16];
 #pragma unroll
@@ -142,8 +157,13 @@ template <int ACT, int BMT>
 void launch_linear(hipStream_t st, int ax, int aw, const float* X, int64_t ldx, const float* W, int64_t ldw,
                    const float* bias, float* Y, int64_t ldy, int M, int N, int K) {
     const dim3 grid(dfol_cdiv(N, BN), dfol_cdiv(M, BMT));
+    const int full = (M % BMT == 0 && N % BN == 0) ? (K % BK == 0 ? 2 : 1) : 0;
 #define DFOL_LIN(AX, AW) \
-    hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW, BMT>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K)
+    do {                                                                                                                         \
+        if (full == 2) hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW, BMT, 2>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K); \
+        else if (full == 1) hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW, BMT, 1>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K); \
+        else hipLaunchKernelGGL((linear_act_kernel<ACT, AX, AW, BMT, 0>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, M, N, K);     \
+    } while (0)
     if (ax == 4 && aw == 4) DFOL_LIN(4, 4);
     else if (ax == 2 && aw == 4) DFOL_LIN(2, 4);
     else if (ax == 4 && aw == 2) DFOL_LIN(4, 2);

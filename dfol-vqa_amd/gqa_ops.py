@@ -282,8 +282,12 @@ class GQARelateBatch(GQABatchOperatorBase):
         oracle = self._oracle
         if torch.is_grad_enabled() and (x._log_attention.requires_grad or prev._log_attention.requires_grad):
             return None
-        if op_id in self._relate._subject_modulations or op_id in self._relate._object_modulations:
-            return None                                        # calibrated posteriors go through RelateBatch.forward
+        rel = self._relate
+        calibrated = op_id in rel._subject_modulations
+        if calibrated != (op_id in rel._object_modulations):
+            return None                                        # one-sided calibration: RelateBatch.forward handles it
+        if calibrated and (rel._subject_modulations[op_id] is None or rel._object_modulations[op_id] is None):
+            return None
         if not hasattr(oracle, "oriented_tiles") or x.batch_size() != prev.batch_size() or prev._predicate_question_map is not None:
             return None
         low = getattr(relation_list, "lowered", None)
@@ -294,6 +298,11 @@ class GQARelateBatch(GQABatchOperatorBase):
         kernel = L.relate_one_fwd_bf16 if tiles.dtype == torch.bfloat16 else L.relate_one_fwd
         post = kernel(x._log_attention, prev._log_attention, tiles, world._ident, world._n_obj, prev._quantifier,
                       neg_dev if low.any_neg else None, None if low.all_valid else valid_dev, lone_forall_identity=(x.batch_size() == 1))
+        if calibrated:
+            # RelateBatch.forward calibrates both posteriors (batch_base_ops.py:588-594) and GQARelateBatch keeps one per question:
+            # calibrate the kept one with that side's modulations
+            mods = torch.where(flag.unsqueeze(1) > 0, rel._subject_modulations.pop(op_id), rel._object_modulations.pop(op_id))
+            post = L.modulate(post, mods, world._ident, world._n_obj)
         quant = torch.where(flag > 0, x._quantifier, prev._quantifier)        # both posteriors carry the subject's quantifier (:571-586)
         return BatchVariableSet(x._name, world._device, x.object_num(), x.batch_size(), quantifiers=quant, log_attention=post, world=world,
                                 prev_variable_sets_num=x._prev_variable_sets_num + prev._prev_variable_sets_num + 1)
@@ -638,7 +647,8 @@ def _choose_rel_ta(self, op_id, is_forward, world, attention_state, relation_lis
     relation_list, batch_index = flatten_list(relation_list_list)
     pqm = batch_index if predicate_question_map is None else predicate_question_map
     host = [0.0 if f is None else float(f) for f in is_subject]
-    pmap = batch_index if predicate_question_map is None else predicate_question_map.to(torch.int64).cpu().tolist()
+    pmap = batch_index if predicate_question_map is None else (getattr(predicate_question_map, "_host", None) or
+                                                               predicate_question_map.to(torch.int64).cpu().tolist())
     pred_flags = [host[q] for q in pmap]                                         # mm(pqm, is_subject)
     if is_forward:
         x = self._gqa_select.transform_attention(op_id, is_forward, world, None, attribute_list, op_feature)

@@ -5,13 +5,14 @@ src/nsvqa/data/batch_gqa_boxfeatures_pipeline.py:193-281)."""
 import inspect
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import ops as L
 from . import gqa_ops as gqa
 from .fol_types import BatchAttentionState, BatchVariableSet, BatchWorld, QuestionType
-from .host_util import reverse_dependencies
+from .host_util import reverse_dependencies, upload
 
 
 def gather_results(outputs, target_device=None, is_cuda=True):
@@ -187,7 +188,8 @@ class BatchInterpreterBase(nn.Module):
             if self._has_modulator and modulator_switch:
                 self._calibration_passes(world, program_batch, device, is_training)
             if world._lazy is not None:
-                self._oracle.prefetch_relations(world, program_batch)
+                # with a training calibrator the attentions carry gradients and the relates run on the generic cell
+                self._oracle.prefetch_relations(world, program_batch, fused=not (self._has_modulator and modulator_switch and torch.is_grad_enabled()))
             ops = program_batch._op_batch_list
             trace = []
             for i, op_batch in enumerate(ops):                   # execution loop :145-172
@@ -278,8 +280,9 @@ class BatchGQAInterpreter(BatchInterpreterBase):
                   'verify_attrs': 15, 'verify_rel': 16}
 
     def _transform_attention(self, op_id, is_forward, world, operator_batch, input_tuple, is_terminal, is_training):   # :80-86
-        temp = torch.zeros(len(self._OPS_INDEX), dtype=torch.float32, device=world._device)
-        temp[self._OPS_INDEX[operator_batch._op_name]] = 1.0
+        onehot = np.zeros(len(self._OPS_INDEX), np.float32)
+        onehot[self._OPS_INDEX[operator_batch._op_name]] = 1.0
+        temp = upload(onehot, world._device)                   # (memoised; an indexed assignment on the device is not graph-capturable)
         x = self._ops[operator_batch._op_name].transform_attention(*((op_id, is_forward, world) + input_tuple + tuple(operator_batch._arguments) +
                                                                      (temp, operator_batch._predicate_question_map)))
         return x, is_terminal

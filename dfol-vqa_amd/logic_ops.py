@@ -101,8 +101,7 @@ class BatchOperatorBase(nn.Module):
         if all(ind):
             return feats
         full = torch.zeros(len(tokens), feats.shape[1], dtype=torch.float32, device=world._device)
-        full[upload(np.asarray(ind, np.bool_), world._device)] = feats
-        return full
+        return full.index_copy_(0, upload(np.nonzero(ind)[0].astype(np.int64), world._device), feats)    # (a mask assignment synchronises)
 
     def _compute_attention_modulations(self, forward_state, backward_state):    # :275-286
         fs = torch.zeros_like(backward_state[0]) if forward_state is None else forward_state[0]

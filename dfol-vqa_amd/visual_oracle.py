@@ -119,7 +119,10 @@ class OracleBase(nn.Module):
     def get_embedding(self, tokens, meta_data, device):       # base_oracle.py:45-55
         try:
             ind = [meta_data['index'][t] for t in tokens]
-            return meta_data['embedding'][ind, :]
+            emb = meta_data['embedding']
+            if emb.is_cuda:                                  # (an index list would be uploaded, synchronously, on every call)
+                return emb.index_select(0, upload(np.asarray(ind, np.int64), emb.device))
+            return emb[ind, :]
         except (KeyError, TypeError):
             return torch.from_numpy(self._ontology.get_embeddings(tokens)).float().to(device)
 
@@ -433,7 +436,7 @@ class ClassifierOracle(OracleBase):
             return torch.full((count, world._NS, world._NS), -30.0, dtype=dtype, device=world._device)
         return torch.empty(count, world._NS, world._NS, dtype=dtype, device=world._device)
 
-    def prefetch_relations(self, world, program_batch):
+    def prefetch_relations(self, world, program_batch, fused=True):
         """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel /
         choose_rel): the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
         if world._lazy is None or getattr(world, "_train", False):
@@ -451,7 +454,9 @@ class ClassifierOracle(OracleBase):
                 if low.any_valid and len(low.cols) == Q:
                     # the operator keeps the posterior of the freshly selected variable: store every tile with the
                     # OTHER (summed-out) variable along rows, so that posterior is a column reduction
-                    orient = np.asarray([L.TILE_OBJECT_ROWS if f else L.TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8)
+                    # (fused=False: the attentions carry gradients, every relate goes through the generic two-posterior cell,
+                    # which reads subject-row tiles)
+                    orient = np.asarray([L.TILE_OBJECT_ROWS if (f and fused) else L.TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8)
                     entries.append((low, np.arange(Q), orient))
             elif ob._op_name == "choose_rel":
                 flat, batch_index = flatten_list(ob._arguments[0])
@@ -501,14 +506,14 @@ class ClassifierOracle(OracleBase):
         base = 0
         for low, pq, orient in entries:
             P = len(pq)
-            world._rel_tiles[id(low)] = (tiles[base:base + P], orient)
+            world._rel_tiles[id(low)] = (tiles[base:base + P], orient, fused)
             base += P
         self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
 
     def oriented_tiles(self, world, low):
         """Prefetched tiles of a relate operator, each stored with its summed-out variable along rows (or None)."""
         hit = world._rel_tiles.get(id(low)) if world._lazy is not None else None
-        return None if hit is None else hit[0]
+        return None if (hit is None or not hit[2]) else hit[0]
 
     def _relation_tiles_now(self, world, low, pred_q_host):
         """Relation tiles for one token list outside the prefetch (e.g. choose_rel's flattened option list)."""

@@ -549,3 +549,24 @@ def test_graphed_forward_equals_eager(tmp_path):
         r2 = g()
         assert torch.equal(r2["log_probability"], eager2["log_probability"]) and r2["answer"] == eager2["answer"]
         assert not torch.equal(r2["log_probability"], r["log_probability"])
+
+
+def test_graphed_forward_with_calibration(ontology):
+    """The calibrated forward (LSTM passes + modulations, ~230 launches per ProgramBatch) is captured and replayed as one graph."""
+    from dfol_vqa_amd.interpreter import GraphedForward
+    a, meta = gu.load("g10_calibration")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights)
+    for name in ("exist", "choose_rel"):
+        run_meta = meta["runs"][name]
+        qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+               "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}}
+              for i, q in enumerate(run_meta["questions"])]
+        pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ontology).collate(qs)]
+        with torch.no_grad():
+            eager = model(pbs, False)
+        gu.check_logprob(eager["log_probability"].cpu().numpy(), a["%s:lp_f32" % name], a["%s:lp_f64" % name], "g10 " + name)
+        g = GraphedForward(model, pbs)
+        for _ in range(2):
+            r = g()
+            assert torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"]

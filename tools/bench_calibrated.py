@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Forward throughput with the attention calibrator on (config/sample_config.yaml's default `activate_attention_transfer: True`):
+the LSTM passes over the program plus apply_modulations around every operator, eager and as a replayed HIP graph.
+
+usage: python tools/bench_calibrated.py [objects]
+"""
+import os, sys, tempfile, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+import dfol_vqa_amd as D
+from dfol_vqa_amd import experiment
+from dfol_vqa_amd import synthetic as syn
+class A: pass
+args = A(); args.objects = int(sys.argv[1]) if len(sys.argv) > 1 else 100; args.batch = 256
+device = torch.device("cuda", 0)
+tmp = tempfile.mkdtemp()
+paths, names = syn.write_synthetic_ontology(tmp)
+for calib in (False, True):
+    cfg = syn.reference_config(paths, activate_attention_transfer=calib)
+    ontology = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ontology); bench.init_weights(model); model = model.to(device).eval()
+    voc = list(ontology._vocabulary["idx_to_arg"])
+    emb = torch.randn(len(voc), 300) * 0.1
+    class Collater(D.ProgramCollaterBase):
+        def __init__(self): super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology)
+        def collate_object_features(self, qs):
+            return torch.cat([torch.from_numpy(q["scene"]["X"]) for q in qs], 0), torch.cat([torch.full((q["scene"]["n"],), i, dtype=torch.int64) for i, q in enumerate(qs)])
+        def collate_meta_data(self, qs): return {"index": {t: i for i, t in enumerate(voc)}, "embedding": emb}
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    qs = []
+    for i in range(args.batch):
+        br, last = syn.three_hop_program(i, nouns, attrs, rels)
+        qs.append(syn.question(i, br, last, "yes", syn.feature_scene(i, args.objects, 2048)))
+    pbs = Collater().collate(qs)
+    for pb in pbs: pb.create_sparse_tensors()
+    pbs = [pb.to_cuda(device) for pb in pbs]
+    with torch.no_grad():
+        for _ in range(3): model(pbs, False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): model(pbs, False)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print("calibration", calib, "ms/step %.3f" % (dt * 1e3), "q/s %.0f" % (args.batch / dt))
+    from dfol_vqa_amd.interpreter import GraphedForward
+    with torch.no_grad():
+        eager = model(pbs, False)
+    g = GraphedForward(model, pbs)
+    r = g()
+    assert torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): g()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print("calibration", calib, "graph replay ms/step %.3f" % (dt * 1e3), "q/s %.0f" % (args.batch / dt))

@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--objects", type=int, default=36)
     ap.add_argument("--ragged", type=int, default=0, help="if > 0: object counts ~ U{ragged..objects} instead of a fixed count")
+    ap.add_argument("--calibrator", type=int, default=0, help="1: the calibrator phases (cur6-7): oracle frozen, only the attention networks train")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -40,8 +41,11 @@ def main():
     from dfol_vqa_amd import synthetic as syn
     tmp = tempfile.mkdtemp(prefix="dfol_train_")
     paths, names = syn.write_synthetic_ontology(tmp)
-    cfg = syn.reference_config(paths, dropout=0.0, freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
-                               freeze_embedding_network=False)     # the oracle-training phases (cur1-5) of the curriculum
+    if args.calibrator:
+        cfg = syn.reference_config(paths, dropout=0.0, activate_attention_transfer=True)
+    else:
+        cfg = syn.reference_config(paths, dropout=0.0, freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+                                   freeze_embedding_network=False)     # the oracle-training phases (cur1-5) of the curriculum
     ontology = experiment.build_ontology(cfg)
     model = experiment.build_model(cfg, ontology)
     bench.init_weights(model)
@@ -52,6 +56,11 @@ def main():
         orig = syn.feature_scene
         syn.feature_scene = lambda qid, n, dim: orig(qid, int(rng.randint(args.ragged, args.objects + 1)), dim)
     _, pbs = bench.build_batch(args, rank, ontology, names, device)
+    if args.calibrator:                                      # the LSTM inputs need token embeddings (random here, GloVe in the reference)
+        voc = list(ontology._vocabulary["idx_to_arg"])
+        emb = (torch.randn(len(voc), 300) * 0.1).to(device)
+        for pb in pbs:
+            pb._meta_data = {"index": {t: i for i, t in enumerate(voc)}, "embedding": emb}
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     torch.cuda.reset_peak_memory_stats()
     for _ in range(args.warmup):
@@ -64,7 +73,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     if rank == 0:
         print(json.dumps({"metric": "training questions/s (forward + backward + Adam)", "value": args.batch * world / dt, "ms_per_step": dt * 1e3,
-                          "n_gpus": world, "objects": args.objects if not args.ragged else [args.ragged, args.objects], "batch_per_gpu": args.batch, "loss": loss,
+                          "n_gpus": world, "phase": "calibrator" if args.calibrator else "oracle", "objects": args.objects if not args.ragged else [args.ragged, args.objects], "batch_per_gpu": args.batch, "loss": loss,
                           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
 
 

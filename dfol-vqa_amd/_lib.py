@@ -55,6 +55,7 @@ SIGNATURES = {
     "dfol_rel_gather_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "dfol_option_normalize_bwd_f32": [_p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
     "dfol_modulate_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_lstm_pointwise_f32": [_p, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
     "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
                          _i32, _f, _p, _p],
@@ -290,6 +291,13 @@ def linear_act(x, weight, bias, act, out=None):
     call("dfol_linear_act_f32", x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias, F32, True),
          out.data_ptr(), out.stride(0), M, N, K, act, _stream())
     return out
+
+
+def lstm_pointwise(igates, hgates, c):
+    rows, H = c.shape
+    hy, cy = torch.empty_like(c), torch.empty_like(c)
+    call("dfol_lstm_pointwise_f32", _ptr(igates, F32), _ptr(hgates, F32), _ptr(c, F32), rows, H, _ptr(hy), _ptr(cy), _stream())
+    return hy, cy
 
 
 def box_positions(raw, obj, pos_col):

@@ -1023,3 +1023,33 @@ extern "C" int dfol_modulate_f32(const float* att, const float* mods, const int3
     DFOL_LAUNCH_CHECK("modulate");
     return 0;
 }
+
+// =====================================================================================================
+// LSTM cell pointwise stage of the attention-calibration passes (batch_base_interpreter.py:87-140 run nn.LSTMCell(318 -> 50) once
+// per operator and direction): gates = x W_ih^T + b_ih + h W_hh^T + b_hh come from two dfol_linear_act_f32 launches, this kernel
+// does  c' = sigmoid(f) c + sigmoid(i) tanh(g),  h' = sigmoid(o) tanh(c')  with torch's gate order (i, f, g, o).
+// =====================================================================================================
+__global__ void lstm_pointwise_kernel(const float* __restrict__ ig, const float* __restrict__ hg, const float* __restrict__ c, int rows,
+                                      int H, float* __restrict__ hy, float* __restrict__ cy) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int r = idx / H, j = idx - r * H;
+    const float* a = ig + (int64_t)r * 4 * H;
+    const float* b = hg + (int64_t)r * 4 * H;
+    const float gi = a[j] + b[j], gf = a[H + j] + b[H + j], gg = a[2 * H + j] + b[2 * H + j], go = a[3 * H + j] + b[3 * H + j];
+    const float si = 1.0f / (1.0f + expf(-gi)), sf = 1.0f / (1.0f + expf(-gf)), so = 1.0f / (1.0f + expf(-go));
+    const float cn = sf * c[idx] + si * tanhf(gg);
+    cy[idx] = cn;
+    hy[idx] = so * tanhf(cn);
+}
+
+extern "C" int dfol_lstm_pointwise_f32(const float* igates, const float* hgates, const float* c, int32_t rows, int32_t H, float* h_out,
+                                       float* c_out, void* stream) {
+    DFOL_REQUIRE(rows >= 0 && H > 0, "lstm_pointwise: bad sizes rows=%d H=%d", rows, H);
+    if (rows == 0) return 0;
+    DFOL_REQUIRE(igates && hgates && c && h_out && c_out, "lstm_pointwise: null pointer");
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(dfol_cdiv((int64_t)rows * H, 256)), dim3(256), 0, (hipStream_t)stream, igates, hgates, c,
+                       rows, H, h_out, c_out);
+    DFOL_LAUNCH_CHECK("lstm_pointwise");
+    return 0;
+}

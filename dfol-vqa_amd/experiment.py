@@ -10,7 +10,7 @@ import yaml
 
 from .gqa_ops import GQAOntology
 from .interpreter import BatchGQABoxFeaturizer, BatchGQAInterpreter
-from .visual_oracle import ClassifierOracle, EmbeddingLayer, RegularMLP
+from .visual_oracle import CalibrationLSTMCell, ClassifierOracle, EmbeddingLayer, RegularMLP
 
 
 def load_config(config_file):
@@ -30,8 +30,8 @@ def build_neural_modules(config, ontology):                     # gqa_interprete
     if config.get('activate_attention_transfer'):               # gqa_interpreter_experiments.py:115-138
         output_dim, max_activation = 4, 10.0
         in_dim = config['word_embedding_dim'] + 1 + 17
-        fwd_net = nn.LSTMCell(in_dim, config['attention_transfer_state_dim'])
-        bwd_net = nn.LSTMCell(in_dim, config['attention_transfer_state_dim'])
+        fwd_net = CalibrationLSTMCell(in_dim, config['attention_transfer_state_dim'])
+        bwd_net = CalibrationLSTMCell(in_dim, config['attention_transfer_state_dim'])
         out_net = nn.Sequential(nn.Linear(2 * config['attention_transfer_state_dim'], output_dim), nn.Sigmoid())
         out_net[0].weight = nn.Parameter(torch.zeros(output_dim, 2 * config['attention_transfer_state_dim']))
         bias = -math.log(max_activation - 1) * torch.ones(output_dim)

@@ -236,6 +236,13 @@ int dfol_pair_features_f32(const float* obj, int64_t ld_obj, int32_t D, const in
 int dfol_modulate_f32(const float* att, const float* mods, const int32_t* pred_q, const int32_t* n_obj, int32_t P, int32_t NS,
                       float* out, void* stream);
 
+/* LSTM cell of the attention-calibration passes (batch_base_interpreter.py:87-140; nn.LSTMCell(318 -> 50) built at
+ * gqa_interpreter_experiments.py:115-138), pointwise stage: igates = x W_ih^T + b_ih and hgates = h W_hh^T + b_hh ([rows, 4H], gate
+ * order i, f, g, o; two dfol_linear_act_f32 launches) ->  c' = sigmoid(f) c + sigmoid(i) tanh(g),  h' = sigmoid(o) tanh(c').
+ */
+int dfol_lstm_pointwise_f32(const float* igates, const float* hgates, const float* c, int32_t rows, int32_t H, float* h_out,
+                            float* c_out, void* stream);
+
 /* ---- needed-columns oracle (MI355X-first: nothing the program does not ask for is computed) --------
  * The reference evaluates the embedding layer for all 2335 concepts on every object and every ordered
  * object pair (classifier_oracle.py:145-156; 64 % of its CPU time) and then gathers a

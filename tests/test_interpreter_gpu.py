@@ -570,3 +570,31 @@ def test_graphed_forward_with_calibration(ontology):
         for _ in range(2):
             r = g()
             assert torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"]
+
+
+@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "choose_attr"])
+def test_full_size_fused_equals_full_tables_fuzz(tmp_path, kind):
+    """Full-size oracle, random ragged batches: the fused needed-columns dataflow (attr_ll + packed pair kernel + single-posterior
+    Relate) against the reference's dataflow on the same GPU (full cached tables + gathers + generic cell).  DFOL_FUZZ_SEEDS=n
+    runs n batches."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(5)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    for rnd in range(int(os.environ.get("DFOL_FUZZ_SEEDS", "1"))):
+        lo, hi = [(1, 40), (20, 64), (2, 9)][rnd % 3]
+        qs, scenes = _neural_questions(kind, 12, lo, hi, 2048, seed=300 + 17 * rnd + len(kind), names=nm)
+        model._oracle._needed_columns = True
+        a, _ = run(model, qs, scenes, ont, split=1 + rnd % 2, key="X")
+        model._oracle._needed_columns = False
+        b, _ = run(model, qs, scenes, ont, split=1 + rnd % 2, key="X")
+        la, lb = a["log_probability"].cpu().numpy(), b["log_probability"].cpu().numpy()
+        assert np.abs(np.exp(la) - np.exp(lb)).max() <= 2e-5, (kind, rnd, np.abs(np.exp(la) - np.exp(lb)).max())
+        assert np.abs(la - lb).max() <= 2e-3 * max(1.0, np.abs(lb).max()), (kind, rnd, np.abs(la - lb).max())

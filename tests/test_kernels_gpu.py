@@ -563,3 +563,24 @@ def test_relate_one_bf16_equals_fp32_kernel_on_rounded_tiles(L, n_list):
                 n = n_list[p]
                 assert np.allclose(a[p, :n], b[p, :n], rtol=0, atol=3e-5 * max(1.0, np.abs(b[p, :n]).max())), (p, n, any_neg)
                 assert np.all(a[p, n:] == 0)
+
+
+def test_calibration_lstm_cell_equals_torch(L):
+    """CalibrationLSTMCell (gate GEMMs by dfol_linear_act_f32 + dfol_lstm_pointwise_f32) == nn.LSTMCell with the same parameters."""
+    from dfol_vqa_amd.visual_oracle import CalibrationLSTMCell
+    torch.manual_seed(0)
+    ref = torch.nn.LSTMCell(318, 50).cuda()
+    mine = CalibrationLSTMCell(318, 50).cuda()
+    mine.load_state_dict(ref.state_dict())                   # same parameter names
+    for rows in (1, 7, 256, 333):
+        x = torch.randn(rows, 318, device="cuda")
+        h, c = torch.randn(rows, 50, device="cuda") * 0.5, torch.randn(rows, 50, device="cuda")
+        with torch.no_grad():
+            h1, c1 = ref(x, (h, c))
+            h2, c2 = mine(x, (h, c))
+        assert torch.allclose(h1, h2, atol=2e-6, rtol=1e-5) and torch.allclose(c1, c2, atol=2e-6, rtol=1e-5)
+    # with gradients it is torch's own cell
+    x = torch.randn(4, 318, device="cuda", requires_grad=True)
+    h2, c2 = mine(x, (torch.zeros(4, 50, device="cuda"), torch.zeros(4, 50, device="cuda")))
+    (h2.sum() + c2.sum()).backward()
+    assert x.grad is not None and mine.weight_ih.grad is not None

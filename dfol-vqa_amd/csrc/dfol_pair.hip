@@ -266,17 +266,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rv[m] = *reinterpret_cast<const float4*>(Vrow[m] + k0);
         }
     };
+    // The two slots of a lane share every geometry weight: their first-layer sums go through packed fp32 math (v_pk_add_f32 /
+    // v_pk_fma_f32, two lanes of work per instruction; -2 % kernel time)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 G0 = {geo[0][0], geo[1][0]}, G1 = {geo[0][1], geo[1][1]}, G2 = {geo[0][2], geo[1][2]}, G3 = {geo[0][3], geo[1][3]};
     auto make_a = [&](int k0, float (&a)[2][4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 g = *reinterpret_cast<const float4*>(&Wgs[(k0 + 4 * kh + c) * 4]);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const float uu = c == 0 ? ru[m].x : (c == 1 ? ru[m].y : (c == 2 ? ru[m].z : ru[m].w));
-                const float vv = c == 0 ? rv[m].x : (c == 1 ? rv[m].y : (c == 2 ? rv[m].z : rv[m].w));
-                const float z = uu + vv + (g.x * geo[m][0] + g.y * geo[m][1] + g.z * geo[m][2] + g.w * geo[m][3]);
-                a[m][c] = z > 0.f ? z : dfol_exp(z) - 1.0f;             // nn.ELU
-            }
+            const f2 uu = {c == 0 ? ru[0].x : (c == 1 ? ru[0].y : (c == 2 ? ru[0].z : ru[0].w)),
+                           c == 0 ? ru[1].x : (c == 1 ? ru[1].y : (c == 2 ? ru[1].z : ru[1].w))};
+            const f2 vv = {c == 0 ? rv[0].x : (c == 1 ? rv[0].y : (c == 2 ? rv[0].z : rv[0].w)),
+                           c == 0 ? rv[1].x : (c == 1 ? rv[1].y : (c == 2 ? rv[1].z : rv[1].w))};
+            f2 z = uu + vv;
+            z = __builtin_elementwise_fma((f2){g.x, g.x}, G0, z);
+            z = __builtin_elementwise_fma((f2){g.y, g.y}, G1, z);
+            z = __builtin_elementwise_fma((f2){g.z, g.z}, G2, z);
+            z = __builtin_elementwise_fma((f2){g.w, g.w}, G3, z);
+            a[0][c] = z.x > 0.f ? z.x : dfol_exp(z.x) - 1.0f;           // nn.ELU
+            a[1][c] = z.y > 0.f ? z.y : dfol_exp(z.y) - 1.0f;
         }
     };
     const int boff = r16 * PB_CH + 4 * (kh ^ pb_swz(r16));

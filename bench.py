@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md
 F32_MFMA_PEAK = 157.3e12     # FLOP/s, dense f32-input MFMA
+BF16_MFMA_PEAK = 2.5e15      # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -174,7 +175,19 @@ def main():
         O = args.batch * args.objects
         pairs = args.batch * args.objects * (args.objects - 1)
         launches, secs = per_step[dom]
-        if dom in ("dfol_pair_ll_f32", "dfol_pair_ll_packed_f32"):
+        if dom == "dfol_pair_ll_split_f32":
+            # The same algorithmic flops, executed on the bf16 matrix pipe as six piece products per fp32 product (three exact
+            # bf16 pieces per operand, fp32 accumulate: fp32 results, csrc/dfol_pair_split.hip).  `achieved` / `frac` follow the
+            # contract (ALGORITHMIC flops against the peak of the pipe that executes them); the pipe itself does 6x that work.
+            flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
+            ach = flops / secs
+            out["roofline"] = {"kernel": "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)", "bound": "mfma",
+                               "achieved": ach / 1e12, "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
+                               "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
+                               "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300),
+                               "executed": {"mfma_flops_per_algorithmic_flop": 6, "achieved": 6 * ach / 1e12, "frac": 6 * ach / BF16_MFMA_PEAK},
+                               "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": ach / F32_MFMA_PEAK}}
+        elif dom in ("dfol_pair_ll_f32", "dfol_pair_ll_packed_f32"):
             # reduced-form algorithmic flops per ordered pair: geometry term, 256->300 layer, and the
             # K requested embedding columns (K = 1 relation per question in this workload)
             flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
@@ -229,7 +242,7 @@ def attach_traffic(out, args):
         return None
 
     if "pair_ll" in out["roofline"]["kernel"] and args.objects == 100 and args.batch == 256:
-        out["roofline"]["traffic"] = total("pair_ll32b_kernel") or total("pair_ll16")
+        out["roofline"]["traffic"] = total("pair_ll32s_kernel" if "32s" in out["roofline"]["kernel"] else "pair_ll32b_kernel") or total("pair_ll16")
         out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
     P = args.stress_preds
     for k in out["kernels"]:

@@ -62,6 +62,9 @@ SIGNATURES = {
     "dfol_pair_pack_w2_f32": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_packed_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                 _i32, _p, _p],
+    "dfol_pair_pack_w2_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
+    "dfol_pair_ll_split_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
+                               _i32, _p, _p],
     "dfol_relate_one_fwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
 }
 
@@ -357,6 +360,36 @@ def pair_ll_packed(uv, hid1, pos, wg, w2_packed, b2, hid2, emb_w, emb_b, n_obj, 
          _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32), _ptr(obj_off, I32), Q, max_n,
          _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll, TILE_BF16 if bf16 else TILE_F32,
          _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
+    return tiles
+
+
+SPLIT_W2_CHUNK_BYTES = 3 * 320 * 32 * 2                        # three bf16 pieces of 20 column tiles x 32 k
+
+
+def pair_split_supported(hid1, hid2):
+    """Shapes dfol_pair_ll_split_f32 takes (the full-size oracle: 256 -> 300)."""
+    return hid1 % 32 == 0 and 0 < hid1 <= 256 and 256 < hid2 <= 320
+
+
+def pair_pack_w2_split(w2, hid2=None):
+    """W2 [HID2(+padding), HID1] -> the bf16x3 image dfol_pair_ll_split_f32 reads (SPLIT_W2_CHUNK_BYTES per 32 k, swizzled)."""
+    hid1 = w2.shape[1]
+    hid2 = w2.shape[0] if hid2 is None else hid2
+    out = torch.empty((hid1 // 32) * SPLIT_W2_CHUNK_BYTES // 2, dtype=torch.bfloat16, device=w2.device)
+    call("dfol_pair_pack_w2_bf16x3", _ptr(w2, F32), w2.stride(0), hid2, hid1, _ptr(out, torch.bfloat16), _stream())
+    return out
+
+
+def pair_ll_split(uv, hid1, pos, wg, w2_split, b2, hid2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles,
+                  default_ll=-30.0):
+    """As pair_ll_packed, with the second layer split by pair_pack_w2_split: bf16 matrix pipes, fp32 results."""
+    K, Q = req_col.shape
+    NS = tiles.shape[1]
+    bf16 = tiles.dtype == torch.bfloat16
+    call("dfol_pair_ll_split_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32),
+         _ptr(w2_split, torch.bfloat16), _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
+         _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
+         TILE_BF16 if bf16 else TILE_F32, _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
 
 

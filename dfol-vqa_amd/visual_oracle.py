@@ -259,6 +259,10 @@ class ClassifierOracle(OracleBase):
             if w.shape[1] % L.PACKED_W2_CHUNK == 0 and w.shape[1] <= 256 and w.shape[0] <= L.PACKED_W2_ROWS \
                     and os.environ.get("DFOL_PAIR_PACKED", "1") != "0":
                 packed = L.pair_pack_w2(wp, w.shape[0])      # the layout of the occupancy-2 pair kernel (csrc/dfol_pair.hip)
+                # full-size second layer: fp32 results from the bf16 matrix pipes (three exact bf16 pieces per operand,
+                # csrc/dfol_pair_split.hip); DFOL_PAIR_MATH=f32 keeps the fp32 matrix pipe
+                if L.pair_split_supported(w.shape[1], w.shape[0]) and os.environ.get("DFOL_PAIR_MATH", "bf16x3") != "f32":
+                    packed = ("bf16x3", L.pair_pack_w2_split(wp, w.shape[0]))
             self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0], packed)
         return self._w2_cache[1:]
 
@@ -438,7 +442,10 @@ class ClassifierOracle(OracleBase):
         up = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a).to(dev)
         rc, rt = up(req_col), up(req_tile)
         ro = None if req_orient is None else up(req_orient)
-        if packed is not None:
+        if isinstance(packed, tuple):
+            L.pair_ll_split(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._n_obj,
+                            world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
+        elif packed is not None:
             L.pair_ll_packed(world._uv, hid1, world._obj[:, D - 4:], wg, packed, b2, hid2, emb.weight, emb.bias, world._n_obj,
                              world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
         else:

@@ -294,6 +294,21 @@ int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t HID1, const 
                             const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
                             int32_t tile_dtype, void* tiles, void* stream);
 
+/* The same relation tiles with the second layer on the bf16 matrix pipes at fp32 accuracy (dfol-vqa_amd/csrc/dfol_pair_split.hip):
+ * each fp32 operand is cut exactly into three bf16 pieces and six of the nine piece products are accumulated in fp32 by
+ * v_mfma_f32_16x16x32_bf16; the dropped products are below 2^-23 of |a w|, the rounding error of one fp32 FMA, so the results
+ * agree with dfol_pair_ll_packed_f32 to fp32 rounding (they are NOT a reduced-precision mode).  W2_split is produced once per
+ * weight update by dfol_pair_pack_w2_bf16x3: (HID1/32) * 61440 bytes, 16-byte aligned; per 32 k two regions (column tiles 0-7
+ * and 8-19) of [3 pieces][rows][32] bf16, rows >= HID2 zero, k-groups swizzled for conflict-free LDS reads.
+ * All other arguments as dfol_pair_ll_packed_f32.  Limits: HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320.
+ */
+int dfol_pair_pack_w2_bf16x3(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, void* W2_split, void* stream);
+int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                           const void* W2_split, const float* b2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
+                           const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n, const int32_t* req_col,
+                           const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
+                           int32_t tile_dtype, void* tiles, void* stream);
+
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B.  g_* outputs that are NULL are skipped.
  * g_prior* ([Q, NS]) are ACCUMULATED into (several predicates may share a question's prior): zero them first.

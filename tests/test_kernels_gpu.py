@@ -456,7 +456,8 @@ def test_relate_exists_fast_path(L, n_list):
         gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path", lp_tol=2e-4)
 
 
-@pytest.mark.parametrize("hid1,hid2,K", [(256, 300, 3), (256, 300, 40), (256, 320, 2), (64, 200, 2), (32, 12, 2)])
+@pytest.mark.parametrize("hid1,hid2,K", [(256, 300, 3), (256, 300, 40), (256, 300, 60), (256, 320, 2), (256, 270, 2), (224, 288, 3),
+                                         (64, 200, 2), (32, 12, 2)])
 def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
     """The fused pair MLP kernels (every geometry: 32x32 tiles, 16x16 tiles with 8 wavefronts, the packed occupancy-2 kernels with 16
     and 32 slots per wavefront) against an fp64 restatement: ragged images incl. 1- and 2-object ones, unrequested slots, both tile
@@ -521,6 +522,12 @@ def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
         if hid2 > 256:
             t = torch.full((K * Q, NS, NS), -30.0, device="cuda", dtype=torch.bfloat16)
             outs["packed_bf16"] = _lib.pair_ll_packed(*args, packed, dev(b2), hid2, *tail, t).float().cpu().numpy()
+    if _lib.pair_split_supported(hid1, hid2):                  # bf16x3 pieces on the bf16 matrix pipes: fp32 results
+        split = _lib.pair_pack_w2_split(dev(w2), hid2)
+        t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+        outs["split"] = _lib.pair_ll_split(*args, split, dev(b2), hid2, *tail, t).cpu().numpy()
+        t = torch.full((K * Q, NS, NS), -30.0, device="cuda", dtype=torch.bfloat16)
+        outs["split_bf16"] = _lib.pair_ll_split(*args, split, dev(b2), hid2, *tail, t).float().cpu().numpy()
     for name, got in outs.items():
         tol = 2e-5 if "bf16" not in name else 0.0
         err = np.abs(got - ref)
@@ -529,6 +536,10 @@ def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
         else:
             assert err[wanted].max() <= tol * max(1.0, np.abs(ref[wanted]).max()), (name, err[wanted].max())
         assert np.all(got[~wanted] == -30.0), name                 # unrequested tiles, padding: untouched
+    if "split" in outs:                                        # as close to the exact result as the fp32 matrix pipe
+        e_split, e_f32 = np.abs(outs["split"] - ref)[wanted], np.abs(outs["packed"] - ref)[wanted]
+        assert e_split.max() <= 3 * e_f32.max() + 2e-7 and e_split.mean() <= 1.25 * e_f32.mean() + 1e-8, (e_split.max(), e_f32.max(),
+                                                                                                            e_split.mean(), e_f32.mean())
 
 
 @pytest.mark.parametrize("n_list", [[8, 3, 5, 1], [40, 33, 17, 8], [100, 104, 64, 2], [130, 256]])

@@ -10,14 +10,12 @@
 // the exact dot product as the fp32 kernel's (tests/test_kernels_gpu.py compares both with a float64 evaluation).
 // Six bf16 MFMAs replace sixteen fp32 ones' worth of matrix-pipe time: 6/16 of the cost.
 //
-// Geometry: as pair_ll32b_kernel (csrc/dfol_pair.hip) - 32 pair slots per wavefront, 4-wavefront workgroups, two
-// workgroups per CU - with a K chunk of 32 (one MFMA's depth).  W2 comes pre-split and packed
-// (dfol_pair_pack_w2_bf16x3): chunk-major [HID1/32][3 pieces][ROWS][32] bf16, ROWS = 16 * ceil(HID2 / 16), rows >= HID2
-// zero, the four 8-element k-groups of row r stored at group kq ^ swz[(r >> 2) & 3] (64-byte rows: the same bank
-// geometry as the fp32 image, so every ds_read_b128 of a B fragment is conflict-free).  A chunk (57 KB at HID2 = 300)
-// is copied to LDS verbatim by LDS-DMA; with two workgroups per CU there is room for ONE chunk per workgroup, so a
-// workgroup alternates "DMA in flight, build the A pieces (VALU)" with "MFMAs", and the two resident workgroups fill
-// each other's gaps.
+// W2 comes pre-split and packed (dfol_pair_pack_w2_bf16x3): per 32 k (one MFMA's depth) a 60 KB chunk of 20 column tiles x 3 pieces,
+// rows >= HID2 zero, the four 8-element k-groups of row r stored at group kq ^ swz[(r >> 2) & 3] (64-byte rows: the same bank
+// geometry as the fp32 image, so every ds_read_b128 of a B fragment is conflict-free; SQ_LDS_BANK_CONFLICT = 0).  A chunk is
+// copied to LDS verbatim by LDS-DMA.  Every wavefront owns 32 pair slots and all 19 column tiles (152 accumulator registers).
+// The schedule (ping-pong between the two wavefronts of a SIMD, see pair_ll32s_kernel) came out of clock64 traces
+// (tools/scratch/trace_pair.py, -DDFOL_PAIR_TRACE).
 #include "dfol_common.h"
 
 #include <stdlib.h>
@@ -26,6 +24,17 @@
 
 #ifndef DFOL_SP_NT
 #define DFOL_SP_NT 1
+#endif
+
+// -DDFOL_PAIR_TRACE: clock64 stamps of one wavefront per half in a few workgroups (tools/scratch/trace_pair.py reads them)
+#ifdef DFOL_PAIR_TRACE
+__device__ long long dfol_trace_buf[8 * 8 * 64];
+#define TRACE(slot)                                                                                                  \
+    do {                                                                                                             \
+        if (trace_on && lane == 0) dfol_trace_buf[(trace_blk * 8 + wave) * 64 + (slot)] = clock64();                 \
+    } while (0)
+#else
+#define TRACE(slot)
 #endif
 
 namespace {
@@ -76,20 +85,30 @@ __global__ void pair_pack_w2_split_kernel(const float* __restrict__ W2, int64_t 
     out[idx] = u32x4{sp_pack(piece[0], piece[1]), sp_pack(piece[2], piece[3]), sp_pack(piece[4], piece[5]), sp_pack(piece[6], piece[7])};
 }
 
-// MT slot tiles (16 pair slots each) per wavefront, WAVES wavefronts per workgroup: a workgroup covers 128 slots either as
-// 4 x 32 (two workgroups = 2 wavefronts per SIMD, 256 registers each) or as 8 x 16 (4 wavefronts per SIMD, 128 registers each).
-template <int NB16, bool TBF16, int MT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES * 2 / 4, WAVES * 2 / 4))) void pair_ll32s_kernel(
+// Every wavefront owns 32 pair slots (two 16-slot tiles) and all column tiles.  Two schedules:
+//   PP = false: 4-wavefront workgroups, two of them per CU, one chunk buffer refilled region by region.  The two wavefronts of a
+//               SIMD belong to different workgroups and nothing orders their phases: measured with clock64 stamps they drift into
+//               doing the same thing at the same time (both building A pieces, then both queueing for the matrix pipe).
+//   PP = true:  ONE 8-wavefront workgroup per CU and a strict ping-pong between its halves (wavefronts w and w + 4 share a SIMD):
+//               in every "tick" one half runs the 228 MFMAs of a chunk while the other half loads U/V rows, requests the next W2
+//               chunk and builds its A pieces; a workgroup barrier ends the tick and the roles swap.  The matrix pipe of a SIMD
+//               always has exactly one wavefront feeding it.  The second half lags the first by one tick, so a chunk is live for
+//               two ticks: two chunk buffers (120 KB of LDS).
+template <int NB16, bool TBF16, bool PP>
+__global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32s_kernel(
     const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
     const float* __restrict__ Wg, const u32x4* __restrict__ W2s, const float* __restrict__ b2, int HID2,
     const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
     const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
     const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
     void* __restrict__ tiles_v) {
+    constexpr int MT = 2, WAVES = PP ? 8 : 4;
     constexpr int ROWS = NB16 * 16, T = WAVES * 64, SLOTS = MT * 16 * WAVES;
-    static_assert(NB16 > SP_T0 && NB16 <= SP_TILES && SLOTS == 128, "geometry");
-    __shared__ __attribute__((aligned(16))) u32x4 Bs[SP_PIECES];    // one W2 chunk, all three pieces (60 KB)
+    static_assert(NB16 > SP_T0 && NB16 <= SP_TILES, "geometry");
+    __shared__ __attribute__((aligned(16))) u32x4 Bs[(PP ? 2 : 1) * SP_PIECES];     // W2 chunk(s), all three pieces (60 KB each)
     __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    constexpr int PP_STAGE_FLOATS = PP ? 8192 : 4;                  // PP: the epilogue's bias / embedding rows have their own 32 KB
+    __shared__ __attribute__((aligned(16))) float stage_pp[PP_STAGE_FLOATS];
     const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
     const int n = n_obj[q];
     if (tb * SLOTS >= n * n) return;
@@ -97,7 +116,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
     if (!any) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 4, r16 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
+#ifdef DFOL_PAIR_TRACE
+    const int trace_blk = ((int)blockIdx.x - 3000) / 500;
+    const bool trace_on = blockIdx.x >= 3000 && (blockIdx.x - 3000) % 500 == 0 && trace_blk < 8;
+#endif
+    TRACE(0);
     const int first = obj_off[q];
     float geo[MT][4];
     const float* Urow[MT];
@@ -124,6 +148,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         Wgs[i] = g.x, Wgs[256 + i] = g.y, Wgs[512 + i] = g.z, Wgs[768 + i] = g.w;
     }
 
+    if constexpr (PP) {                                      // the epilogue's rows are staged up front (the first barrier publishes them)
+        constexpr int SR = PP_STAGE_FLOATS / ROWS - 1;
+        for (int i = tid; i < ROWS; i += T) stage_pp[i] = i < HID2 ? b2[i] : -1.0e30f;
+        for (int k = 0; k < (K < SR ? K : SR); ++k) {
+            const int col = req_col[(int64_t)k * Q + q];
+            for (int i = tid; i < ROWS; i += T) stage_pp[ROWS * (1 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
+        }
+    }
+
     floatx4 acc[MT][NB16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -131,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         for (int i = 0; i < NB16; ++i) acc[m][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // Region `region` of W2 chunk c -> Bs: a wavefront's 64 pieces of a pass are 1 KiB of contiguous LDS
-    auto dma_w2 = [&](int c, int region) {
+    auto dma_w2 = [&](int c, int region) __attribute__((always_inline)) {
         const int base = region ? SP_R0_PIECES : 0, pieces = region ? SP_R1_PIECES : SP_R0_PIECES, passes = (pieces + T - 1) / T;
 #pragma unroll
         for (int i = 0; i < passes; ++i) {
@@ -142,11 +175,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
         }
     };
+    // PP: the whole chunk c -> chunk buffer `buf`, requested by the NW wavefronts first_wave .. first_wave + NW - 1
+    auto dma_chunk = [&](int c, int buf, int first_wave, auto nw_tag) __attribute__((always_inline)) {
+        constexpr int TT = decltype(nw_tag)::value * 64, passes = (SP_PIECES + TT - 1) / TT;
+        const int w = wave - first_wave, t = tid - first_wave * 64;
+#pragma unroll
+        for (int i = 0; i < passes; ++i) {
+            if (SP_PIECES % TT == 0 || TT * i + w * 64 < SP_PIECES) {
+                const u32x4* src = W2s + (int64_t)c * SP_PIECES + TT * i + t;
+                u32x4* dst = &Bs[buf * SP_PIECES + TT * i + w * 64];
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
     // A pieces of a chunk for the lane's slots: k = 32 c + 8 kh + 0..7.  Two ADJACENT k of one slot form every packed-math pair
     // (U, V and the transposed geometry weights are contiguous in k): no register shuffles.
     typedef float f2 __attribute__((ext_vector_type(2)));
     float4 ru[MT][2], rv[MT][2];                                    // [slot][half]: the lane's 8 first-layer terms of a chunk
-    auto load_uv = [&](int c) {
+    auto load_uv = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -156,7 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
     };
     u32x4 ap[MT][3];                                                // [slot][piece h, m, l]
-    auto make_a = [&](int c) {
+    auto make_a = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -186,13 +232,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // The MFMAs of column tiles i .. i+NT-1: six piece products for each slot tile, smallest terms first.  Consecutive MFMAs go to
     // different accumulators (NT * MT of them in rotation): an MFMA that accumulates onto the result of the one just issued waits for
     // its full latency, about twice its issue time.
+    int bbase = boff;                                               // + the chunk buffer's offset (PP)
     auto load_b = [&](int i, bf16x8 (&b)[3]) {
         const int region = i >= SP_T0, rows_r = (region ? SP_TILES - SP_T0 : SP_T0) * 16;
-        const int at = (region ? SP_R0_PIECES : 0) + (i - (region ? SP_T0 : 0)) * 64 + boff;
+        const int at = (region ? SP_R0_PIECES : 0) + (i - (region ? SP_T0 : 0)) * 64 + bbase;
 #pragma unroll
         for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[at + p * rows_r * 4]);
     };
-    auto tiles_mfma = [&](int i, auto nt_tag) {
+    auto tiles_mfma = [&](int i, auto nt_tag) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_tag)::value;
         bf16x8 b[NT][3];
 #pragma unroll
@@ -207,27 +254,83 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                     acc[m][i + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[m][PA[x]]), b[t][PB[x]], acc[m][i + t], 0, 0, 0);
     };
     constexpr int NT = DFOL_SP_NT;
-    auto region_mfma = [&](int t0, int t1) {
+    constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
+    auto region_mfma = [&](int t0, int t1) __attribute__((always_inline)) {
+        if constexpr (PP) {
+            // hand-pipelined: the B fragments of tile i+1 are requested before the MFMAs of tile i, and the scheduler may not move
+            // anything across tiles (left alone it hoists the reads of all 19 tiles to the top and spills)
+            bf16x8 bq[2][3];
+            load_b(t0, bq[0]);
 #pragma unroll
-        for (int i = t0; i < t1; i += NT) {
-            if (i + NT <= t1) tiles_mfma(i, std::integral_constant<int, NT>());
-            else {
+            for (int i = t0; i < t1; ++i) {
+                if (i + 1 < t1) load_b(i + 1, bq[(i + 1 - t0) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                // the six products of one accumulator back to back: a dependent MFMA takes its C operand from the previous result
+                // without a register-file read and issues faster than one on a fresh accumulator (17.5 vs 20 cycles measured)
 #pragma unroll
-                for (int j = i; j < t1; ++j) tiles_mfma(j, std::integral_constant<int, 1>());
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int x = 0; x < 6; ++x)
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[m][PA6[x]]), bq[(i - t0) & 1][PB6[x]], acc[m][i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = t0; i < t1; i += NT) {
+                if (i + NT <= t1) tiles_mfma(i, std::integral_constant<int, NT>());
+                else {
+#pragma unroll
+                    for (int j = i; j < t1; ++j) tiles_mfma(j, std::integral_constant<int, 1>());
+                }
             }
         }
     };
     // LDS-DMA completion is tracked by vmcnt only; a workgroup barrier does not wait for it by itself
-    auto dma_barrier = [&]() {
+    auto dma_barrier = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
         __syncthreads();
     };
 
+    const int nchunk = HID1 / SP_CH, lastc = nchunk - 1;
+    if constexpr (PP) {
+        // Tick tau: half X (wavefronts 0-3) builds chunk tau/2 on even ticks and multiplies it on the next; half Y (4-7) does the
+        // same one tick later.  Chunk c is read in ticks 2c+1 (X) and 2c+2 (Y); its buffer is refilled with chunk c+2 by Y during
+        // its build tick 2c+3 (U/V rows requested first: vmcnt retires in order) and Y drains that DMA at the end of its multiply
+        // tick 2c+4, one tick before X needs it.
+        const int g = wave >> 2;
+        dma_chunk(0, 0, 0, std::integral_constant<int, 8>());
+        if (nchunk > 1) dma_chunk(1, 1, 0, std::integral_constant<int, 8>());
+        dma_barrier();                                      // Wgs, the staged epilogue rows and chunks 0, 1 visible
+        // Each half runs its own copy of the loop (plain straight-line bodies for the register allocator); the barriers pair up by
+        // count: X executes 2 per chunk, Y one idle tick first and none after its last multiply.
+        auto run_half = [&](auto y_tag) __attribute__((always_inline)) {
+            constexpr bool Y = decltype(y_tag)::value;
+            TRACE(1);
+            if (Y) __syncthreads();                         // tick 0: X builds chunk 0
+            TRACE(2);
+            for (int c = 0; c < nchunk; ++c) {
+                load_uv(c);
+                if (Y && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1, 4, std::integral_constant<int, 4>());
+                make_a(c);
+                TRACE(3 + 4 * c);
+                __syncthreads();                            // end of the build tick
+                TRACE(4 + 4 * c);
+                bbase = boff + (c & 1) * SP_PIECES;
+                region_mfma(0, NB16);
+                if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);  // the chunk requested in the build tick has landed
+                TRACE(5 + 4 * c);
+                if (!Y || c < lastc) __syncthreads();       // end of the multiply tick (Y's last one has no partner)
+                TRACE(6 + 4 * c);
+            }
+        };
+        if (g == 0) run_half(std::false_type());
+        else run_half(std::true_type());
+    } else {
     // One chunk buffer, refilled region by region behind the wavefronts: region 0 of chunk c+1 is requested when everyone has left
     // region 0 of chunk c (barrier "B") and lands under the MFMAs of region 1; region 1 of chunk c+1 is requested at barrier "A" and
     // lands under the A building and the region-0 MFMAs of chunk c+1.  vmcnt retires in order: the U/V rows of the next chunk are
     // requested just before that DMA, so that building the A pieces waits for them only.
-    const int nchunk = HID1 / SP_CH, lastc = nchunk - 1;
     load_uv(0);
     dma_w2(0, 0);
     dma_w2(0, 1);
@@ -244,26 +347,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             dma_w2(c + 1, 1);
         }
     }
+    }
 
     // The W2 chunk is free now: stage the hidden bias and the requested embedding rows in it.  Padding columns get bias
     // -1e30, whose Sigmoid is exactly 0.
-#ifdef DFOL_X_NOEPI
-    {
-        floatx4 t = acc[0][0];
-        for (int i = 1; i < NB16; ++i) t += acc[0][i] + acc[1][i];
-        if (t[0] + t[1] + t[2] + t[3] == 12345.f) reinterpret_cast<float*>(tiles_v)[tid] = t[0];
-        return;
-    }
-#endif
-    constexpr int STAGE_ROWS = SP_PIECES * 4 / ROWS - 1;               // embedding rows that fit beside the bias (47)
-    float* stage = reinterpret_cast<float*>(&Bs[0]);
+    constexpr int STAGE_ROWS = (PP ? PP_STAGE_FLOATS : SP_PIECES * 4) / ROWS - 1;      // embedding rows that fit beside the bias
+    float* stage = PP ? stage_pp : reinterpret_cast<float*>(&Bs[0]);
     const int Kc = K < STAGE_ROWS ? K : STAGE_ROWS;
-    for (int i = tid; i < ROWS; i += T) stage[i] = i < HID2 ? b2[i] : -1.0e30f;
-    for (int k = 0; k < Kc; ++k) {
-        const int col = req_col[(int64_t)k * Q + q];
-        for (int i = tid; i < ROWS; i += T) stage[ROWS * (1 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
+    if constexpr (!PP) {
+        for (int i = tid; i < ROWS; i += T) stage[i] = i < HID2 ? b2[i] : -1.0e30f;
+        for (int k = 0; k < Kc; ++k) {
+            const int col = req_col[(int64_t)k * Q + q];
+            for (int i = tid; i < ROWS; i += T) stage[ROWS * (1 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int64_t tile_sz = (int64_t)NS * NS;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -316,9 +414,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
         }
     }
+    TRACE(60);
 }
 
 }  // namespace
+
+#ifdef DFOL_PAIR_TRACE
+extern "C" int dfol_pair_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dfol_trace_buf), sizeof(dfol_trace_buf)); }
+#endif
 
 extern "C" int dfol_pair_pack_w2_bf16x3(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, void* W2_split, void* stream) {
     DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % SP_CH == 0, "pair_pack_w2_bf16x3: HID1=%d must be a multiple of %d, <= 256", HID1, SP_CH);
@@ -345,17 +448,17 @@ extern "C" int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HI
     DFOL_REQUIRE(UV && pos && Wg && W2_split && b2 && E && n_obj && obj_off && req_col && req_tile && tiles_v, "pair_ll_split: null pointer");
     DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_split % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll_split: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const int tpi = dfol_cdiv((int64_t)max_n * max_n, 128);
+    static const int pp = getenv("DFOL_PAIR_SPLIT_PP") ? atoi(getenv("DFOL_PAIR_SPLIT_PP")) : 1;
+    const int tpi = dfol_cdiv((int64_t)max_n * max_n, pp ? 256 : 128);
     DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_split: too many tiles");
     const dim3 grid((unsigned)Q * tpi);
-    static const int mt = getenv("DFOL_PAIR_SPLIT_MT") ? atoi(getenv("DFOL_PAIR_SPLIT_MT")) : 2;
 #define DFOL_PAIR32S(NBV, BF)                                                                                                         \
-    if (mt == 1)                                                                                                                      \
-        hipLaunchKernelGGL((pair_ll32s_kernel<NBV, BF, 1, 8>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
+    if (pp)                                                                                                                           \
+        hipLaunchKernelGGL((pair_ll32s_kernel<NBV, BF, true>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
                            E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v);          \
     else                                                                                                                              \
-        hipLaunchKernelGGL((pair_ll32s_kernel<NBV, BF, 2, 4>), grid, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
-                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
+        hipLaunchKernelGGL((pair_ll32s_kernel<NBV, BF, false>), grid, dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
+                           E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
     if (HID2 <= 272) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32S(17, true); else DFOL_PAIR32S(17, false); }
     else if (HID2 <= 288) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32S(18, true); else DFOL_PAIR32S(18, false); }
     else if (HID2 <= 304) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32S(19, true); else DFOL_PAIR32S(19, false); }

@@ -62,6 +62,8 @@ SIGNATURES = {
     "dfol_pair_pack_w2_f32": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_packed_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                 _i32, _p, _p],
+    "dfol_linear_pack_w_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
+    "dfol_linear_act_split_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_pack_w2_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_split_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                _i32, _p, _p],
@@ -282,8 +284,43 @@ def compare(lp1, lp2, is_less):
     return out
 
 
+_SPLIT_W_CACHE = {}                    # (data_ptr, version, shape, stride) -> (weight kept alive, packed image)
+SPLIT_MIN_FLOPS = 2.0e8               # below this the fp32 kernel's single launch is as fast
+
+
+def linear_pack_w_split(weight):
+    """The bf16x3 image of a Linear weight [N, K] for dfol_linear_act_split_f32, cached per weight version (the cache holds the
+    weight tensor, so its address cannot be recycled while the entry lives)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0))
+    hit = _SPLIT_W_CACHE.get(key)
+    if hit is None:
+        N, K = weight.shape
+        out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 24576 // 2, dtype=torch.bfloat16, device=weight.device)
+        call("dfol_linear_pack_w_bf16x3", weight.data_ptr(), weight.stride(0), N, K, _ptr(out, torch.bfloat16), _stream())
+        if len(_SPLIT_W_CACHE) >= 64:
+            _SPLIT_W_CACHE.pop(next(iter(_SPLIT_W_CACHE)))
+        hit = _SPLIT_W_CACHE[key] = (weight, out)
+    return hit[1]
+
+
+def linear_act_split(x, weight, bias, act, out=None):
+    """y = act(x @ weight.T + bias) on the bf16 matrix pipes with exact three-way operand split: fp32 results."""
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=x.device)
+    call("dfol_linear_act_split_f32", x.data_ptr(), x.stride(0), _ptr(linear_pack_w_split(weight), torch.bfloat16), _ptr(bias, F32, True),
+         out.data_ptr(), out.stride(0), M, N, K, act, _stream())
+    return out
+
+
+def _dense_math():
+    return os.environ.get("DFOL_DENSE_MATH", "bf16x3")
+
+
 def linear_act(x, weight, bias, act, out=None):
-    """y = act(x @ weight.T + bias); x may be a column slice of a wider matrix (row stride = x.stride(0))."""
+    """y = act(x @ weight.T + bias); x may be a column slice of a wider matrix (row stride = x.stride(0)).  Large products go through
+    the bf16x3 split kernel (fp32 results, csrc/dfol_dense_split.hip) unless DFOL_DENSE_MATH=f32."""
     M, K = x.shape
     N = weight.shape[0]
     if out is None:
@@ -291,6 +328,8 @@ def linear_act(x, weight, bias, act, out=None):
     for t in (x, weight, out):
         if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
             raise DfolError("linear_act needs fp32 GPU matrices with unit column stride")
+    if 2.0 * M * N * K >= SPLIT_MIN_FLOPS and K % 4 == 0 and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0 and _dense_math() != "f32":
+        return linear_act_split(x, weight, bias, act, out)
     call("dfol_linear_act_f32", x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias, F32, True),
          out.data_ptr(), out.stride(0), M, N, K, act, _stream())
     return out

@@ -1,0 +1,293 @@
+// Y = act(X W^T + b) with fp32 results from the bf16 matrix pipes (gfx950): the dense layers of the full-size oracle
+// (featurizer 2048 -> 512, attribute / pair first layers 516 -> 256 / 512) on the same exact three-way operand split as the
+// fused pair kernel (csrc/dfol_pair_split.hip): x = h + m + l with bf16 pieces, six piece products per fp32 product accumulated
+// in fp32 by v_mfma_f32_16x16x32_bf16, the dropped products below 2^-23 |x w|.  6/16 of the fp32 matrix pipe's time.
+//
+// W is split and packed once per weight version (dfol_linear_pack_w_bf16x3): [N/128 column blocks][K/32 steps][3 pieces][128 rows]
+// [4 k-groups] x 16 bytes, rows >= N and k >= K zero, k-groups swizzled by (row >> 2) & 3, so that a workgroup's B tile of one
+// k-step is 24 KB of contiguous memory copied to LDS verbatim by LDS-DMA (double-buffered).  X is fp32 in HBM: every thread loads
+// the 2 x 8 consecutive k of its two rows one step ahead into registers, splits them (VALU) and writes the three pieces to LDS in
+// the same swizzled layout, so all fragment reads are conflict-free ds_read_b128.
+//
+// Workgroup: 256 threads = 2 x 2 wavefronts, 128 x 128 output tile, wavefront tile 64 x 64 (16 accumulator tiles, 64 registers);
+// 72 KB of LDS: two workgroups per CU.  Consecutive workgroups of one XCD share the X row block (blockIdx is re-mapped so that the
+// column blocks of a row block run on the same XCD and hit its L2).
+#include "dfol_common.h"
+
+#include <type_traits>
+
+#ifdef DFOL_DENSE_TRACE
+__device__ long long dfol_dense_trace_buf[4 * 64];
+#define LTRACE(slot) do { if (blockIdx.x == 300 && lane == 0 && (slot) < 64) dfol_dense_trace_buf[wave * 64 + (slot)] = clock64(); } while (0)
+#else
+#define LTRACE(slot)
+#endif
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LS_BM = 128, LS_BN = 128, LS_BK = 32;
+constexpr int LS_TILE_PIECES = 3 * LS_BN * 4;               // 16-byte pieces of one B tile (24 KB)
+
+__device__ __forceinline__ int ls_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+__device__ __forceinline__ void ls_split(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __float_as_uint(x);
+    const float r = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t ls_pack(uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+// 8 consecutive fp32 -> the three 8 x bf16 pieces
+__device__ __forceinline__ void ls_split8(const float4& a, const float4& b, u32x4& h, u32x4& m, u32x4& l) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t ph[8], pm[8], pl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ls_split(v[j], ph[j], pm[j], pl[j]);
+    h = u32x4{ls_pack(ph[0], ph[1]), ls_pack(ph[2], ph[3]), ls_pack(ph[4], ph[5]), ls_pack(ph[6], ph[7])};
+    m = u32x4{ls_pack(pm[0], pm[1]), ls_pack(pm[2], pm[3]), ls_pack(pm[4], pm[5]), ls_pack(pm[6], pm[7])};
+    l = u32x4{ls_pack(pl[0], pl[1]), ls_pack(pl[2], pl[3]), ls_pack(pl[4], pl[5]), ls_pack(pl[6], pl[7])};
+}
+
+// One thread per 16-byte piece of the packed image.
+__global__ void linear_pack_w_split_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int ksteps, int nblocks, u32x4* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nblocks * ksteps * LS_TILE_PIECES) return;
+    const int rem = (int)(idx % LS_TILE_PIECES);
+    const int64_t tile = idx / LS_TILE_PIECES;
+    const int ks = (int)(tile % ksteps), nb = (int)(tile / ksteps);
+    const int p = rem / (LS_BN * 4), rr = rem - p * LS_BN * 4, r = rr >> 2, slot = rr & 3;
+    const int kq = slot ^ ls_swz(r), n = nb * LS_BN + r, k0 = ks * LS_BK + kq * 8;
+    uint32_t piece[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float w = (n < N && k0 + j < K) ? W[(int64_t)n * ldw + k0 + j] : 0.f;
+        uint32_t h, m, l;
+        ls_split(w, h, m, l);
+        piece[j] = p == 0 ? h : (p == 1 ? m : l);
+    }
+    out[idx] = u32x4{ls_pack(piece[0], piece[1]), ls_pack(piece[2], piece[3]), ls_pack(piece[4], piece[5]), ls_pack(piece[6], piece[7])};
+}
+
+template <int ACT>
+__device__ __forceinline__ float ls_act(float x) {
+    // branch-free forms on the hardware exp / log / rcp (1 ulp each; absolute error < 2e-7 on these ranges)
+    if (ACT == DFOL_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + dfol_exp(-x));
+    if (ACT == DFOL_ACT_ELU) return fmaxf(x, dfol_exp(fminf(x, 0.f)) - 1.0f);
+    if (ACT == DFOL_ACT_LOGSIGMOID) return fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));
+    return x;
+}
+
+// XV: floats per X load (4: rows 16-byte aligned; 2: rows 8-byte aligned, e.g. the 2054-column raw feature matrix)
+template <int ACT, int XV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_act_split_kernel(
+    const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
+    int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
+    __shared__ __attribute__((aligned(16))) u32x4 As[3 * LS_BM * 4];        // [piece][row][k-group]  24 KB
+    __shared__ __attribute__((aligned(16))) u32x4 Bs[LS_TILE_PIECES];       // the B tile of the step  24 KB
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so id % 8 is the XCD; give each XCD a contiguous run of
+    // logical tiles (column blocks of a row block are consecutive): the X rows are fetched into that XCD's L2 once
+    int bid = blockIdx.x;
+    if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
+    const int mb = bid / nbn, nb = bid - mb * nbn;
+    const int m0 = mb * LS_BM, n0 = nb * LS_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // A staging: rows (tid >> 2) and (tid >> 2) + 64, k-group tid & 3 (8 consecutive k): four threads read 128 contiguous bytes
+    const int arow = tid >> 2, aq = tid & 3;
+    const float* xp0 = X + (int64_t)min(m0 + arow, M - 1) * ldx + aq * 8;
+    const float* xp1 = X + (int64_t)min(m0 + arow + 64, M - 1) * ldx + aq * 8;
+    // X registers: two steps in flight (HBM latency is longer than one step of 96 MFMAs).  The loads are unconditional - addresses
+    // clamped, out-of-range k zeroed afterwards - so that every wavefront issues exactly 4 per step and the vmcnt arithmetic below holds.
+    float4 xa[2][2][2];                                             // [set = step parity][row half][k half]
+    auto load_x = [&](int ks, auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        const int k = ks * LS_BK + aq * 8;
+        const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;      // K % 4 == 0: a float4 is wholly in or out
+        auto ld4 = [&](const float* p) __attribute__((always_inline)) {
+            if (XV == 4) return *reinterpret_cast<const float4*>(p);
+            const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
+            return make_float4(lo.x, lo.y, hi.x, hi.y);
+        };
+        xa[S][0][0] = ld4(xp0 + c0);
+        xa[S][0][1] = ld4(xp0 + c1);
+        xa[S][1][0] = ld4(xp1 + c0);
+        xa[S][1][1] = ld4(xp1 + c1);
+    };
+    auto store_a = [&](int ks, auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        const int k = ks * LS_BK + aq * 8;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = arow + 64 * h;
+            u32x4 ph, pm, pl;
+            ls_split8(k < K ? xa[S][h][0] : z, k + 4 < K ? xa[S][h][1] : z, ph, pm, pl);
+            const int at = row * 4 + (aq ^ ls_swz(row));
+            As[at] = ph;
+            As[LS_BM * 4 + at] = pm;
+            As[2 * LS_BM * 4 + at] = pl;
+        }
+    };
+    const u32x4* wtile = Wp + (int64_t)nb * ksteps * LS_TILE_PIECES;
+    // B tile of the next step: six 16-byte pieces per thread, in registers until the tile in LDS has been consumed.  (LDS-DMA would
+    // save the registers, but the compiler treats an in-flight global_load_lds as a pending FLAT access and turns EVERY later wait -
+    // also the one for the X registers - into vmcnt(0), which would drain the two-step X prefetch at every step.)
+    u32x4 wb[LS_TILE_PIECES / 256];
+    auto load_w = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LS_TILE_PIECES / 256; ++i) wb[i] = wtile[(int64_t)ks * LS_TILE_PIECES + 256 * i + tid];
+    };
+    auto store_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LS_TILE_PIECES / 256; ++i) Bs[256 * i + tid] = wb[i];
+    };
+
+    const int aoff = (wm * 64 + r16) * 4 + (kh ^ ls_swz(r16));
+    const int boff = (wn * 64 + r16) * 4 + (kh ^ ls_swz(r16));
+
+    constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
+    // Step ks: X(ks) was requested two steps ago, the B tile one step ago, and X(ks+1) after it: vmcnt retires in order, so the
+    // wait for the B registers leaves the four loads of X(ks+1) in flight.
+    auto step = [&](int ks, auto set_tag, auto has_b, auto has_x) __attribute__((always_inline)) {
+        constexpr bool HAS_B = decltype(has_b)::value, HAS_X = decltype(has_x)::value;     // is there a B tile ks+1 / an X step ks+2
+        LTRACE(4 * ks);
+        store_a(ks, set_tag);
+        store_b();
+        LTRACE(4 * ks + 1);
+        __syncthreads();                                    // A pieces and B tile ks visible
+        LTRACE(4 * ks + 2);
+        if (HAS_B) load_w(ks + 1);
+        if (HAS_X) load_x(ks + 2, set_tag);
+        __builtin_amdgcn_sched_barrier(0);                  // requests first; and the next step's split must not drift up here
+#pragma unroll
+        for (int ih = 0; ih < 4; ih += 2) {                 // two row tiles at a time (register budget)
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * LS_BM * 4 + (ih + i) * 64 + aoff]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[p * LS_BN * 4 + j * 64 + boff]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int x = 0; x < 6; ++x)             // six dependent MFMAs per accumulator, smallest terms first
+                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA6[x]], b[PB6[x]], acc[ih + i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // (it would wait for X(ks+1) in the middle of the MFMAs)
+        LTRACE(4 * ks + 3);
+        __syncthreads();                                    // A and B tile ks fully read
+    };
+    // The steady-state body has no conditional memory operations (the compiler's wait counts stay exact); the last three steps
+    // are peeled.
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
+    const std::true_type yes;
+    const std::false_type no;
+    load_x(0, S0);
+    load_w(0);
+    load_x(min(1, ksteps - 1), S1);
+    int ks = 0;
+    for (; ks + 3 < ksteps; ks += 2) {
+        step(ks, S0, yes, yes);
+        step(ks + 1, S1, yes, yes);
+    }
+    const int rem = ksteps - ks;
+    if (rem == 3) {
+        step(ks, S0, yes, yes);
+        step(ks + 1, S1, yes, no);
+        step(ks + 2, S0, no, no);
+    } else if (rem == 2) {
+        step(ks, S0, yes, no);
+        step(ks + 1, S1, no, no);
+    } else {
+        step(ks, S0, no, no);
+    }
+
+    // epilogue: lane holds column r16 and rows 4 kh + e of every 16 x 16 tile.  Interior tiles take the branch-free path.
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = bias ? bias[min(n0 + wn * 64 + j * 16 + r16, N - 1)] : 0.f;
+    float* yp = Y + (int64_t)(m0 + wm * 64 + 4 * kh) * ldy + n0 + wn * 64 + r16;
+    if (m0 + LS_BM <= M && n0 + LS_BN <= N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = ls_act<ACT>(acc[i][j][e] + bv[j]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool row_ok = m0 + wm * 64 + i * 16 + 4 * kh + e < M;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = ls_act<ACT>(acc[i][j][e] + bv[j]);
+                    if (row_ok && n0 + wn * 64 + j * 16 + r16 < N) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = v;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+#ifdef DFOL_DENSE_TRACE
+extern "C" int dfol_dense_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dfol_dense_trace_buf), sizeof(dfol_dense_trace_buf)); }
+#endif
+
+extern "C" int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream) {
+    DFOL_REQUIRE(W && W_split && N > 0 && K > 0 && ldw >= K, "linear_pack_w_bf16x3: bad arguments N=%d K=%d", N, K);
+    DFOL_REQUIRE((uintptr_t)W_split % 16 == 0, "linear_pack_w_bf16x3: output must be 16-byte aligned");
+    const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
+    const int64_t total = (int64_t)nbn * ksteps * LS_TILE_PIECES;
+    hipLaunchKernelGGL(linear_pack_w_split_kernel, dim3((unsigned)dfol_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, ksteps,
+                       nbn, (u32x4*)W_split);
+    DFOL_LAUNCH_CHECK("linear_pack_w_bf16x3");
+    return 0;
+}
+
+extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy,
+                                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    DFOL_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 2 == 0 && ldx >= K && ldy >= N, "linear_act_split: bad sizes M=%d N=%d K=%d (K %% 4, ldx %% 2)", M, N, K);
+    if (M == 0) return 0;
+    DFOL_REQUIRE(X && W_split && Y, "linear_act_split: null pointer");
+    DFOL_REQUIRE(((uintptr_t)X % 8 == 0) && ((uintptr_t)W_split % 16 == 0), "linear_act_split: X must be 8-byte and W_split 16-byte aligned");
+    const bool x16 = (uintptr_t)X % 16 == 0 && ldx % 4 == 0;
+    const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN), nbm = dfol_cdiv(M, LS_BM);
+    DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_act_split: too many tiles");
+    const int nblocks = nbm * nbn;
+#define DFOL_LS(A)                                                                                                                      \
+    if (x16)                                                                                                                            \
+        hipLaunchKernelGGL((linear_act_split_kernel<A, 4>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, bias, \
+                           Y, ldy, M, N, K, ksteps, nbn, nblocks);                                                                     \
+    else                                                                                                                                \
+        hipLaunchKernelGGL((linear_act_split_kernel<A, 2>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, bias, \
+                           Y, ldy, M, N, K, ksteps, nbn, nblocks)
+    switch (act) {
+        case DFOL_ACT_NONE: DFOL_LS(DFOL_ACT_NONE); break;
+        case DFOL_ACT_SIGMOID: DFOL_LS(DFOL_ACT_SIGMOID); break;
+        case DFOL_ACT_ELU: DFOL_LS(DFOL_ACT_ELU); break;
+        case DFOL_ACT_LOGSIGMOID: DFOL_LS(DFOL_ACT_LOGSIGMOID); break;
+        default: DFOL_REQUIRE(false, "linear_act_split: unknown activation %d", act);
+    }
+#undef DFOL_LS
+    DFOL_LAUNCH_CHECK("linear_act_split");
+    return 0;
+}

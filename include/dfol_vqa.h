@@ -214,6 +214,16 @@ int dfol_compare_f32(const float* lp1, const float* lp2, const float* is_less, i
 int dfol_linear_act_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
                         int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
 
+/* The same contraction with fp32 results from the bf16 matrix pipes (dfol-vqa_amd/csrc/dfol_dense_split.hip): each fp32 operand is
+ * cut exactly into three bf16 pieces and six of the nine piece products are accumulated in fp32 (v_mfma_f32_16x16x32_bf16); the
+ * dropped products are below 2^-23 |x w|, so results agree with dfol_linear_act_f32 to fp32 rounding.  W_split is produced once
+ * per weight version by dfol_linear_pack_w_bf16x3: ceil(N/128) * ceil(K/32) * 24576 bytes, 16-byte aligned.
+ * Limits: K % 4 == 0, ldx % 2 == 0, X 8-byte aligned (16-byte aligned rows take the wider loads).
+ */
+int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream);
+int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M,
+                              int32_t N, int32_t K, int32_t act, void* stream);
+
 /* Box positional features: replaces batch_gqa_boxfeatures_pipeline.py:208-211.
  *   raw [O, ld_raw]: the last 6 columns (ending at column `raw_cols`) are (W, H, x, y, w, h);
  *   writes pos = (x, y, w, h) / max((W, H, W, H), 1) into obj[:, pos_col .. pos_col+3].

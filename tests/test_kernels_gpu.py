@@ -320,6 +320,39 @@ def test_linear_act(L, M, N, K, ldx_extra, act):
     assert not np.allclose(got[: min(M, N), : min(M, N)], got[: min(M, N), : min(M, N)].T) or min(M, N) < 2
 
 
+@pytest.mark.parametrize("M,N,K,ldx_extra,act", [(300, 70, 52, 0, 0), (257, 300, 256, 0, 1), (513, 256, 516, 0, 2), (200, 333, 300, 0, 3),
+                                                 (130, 512, 2048, 8, 2), (64, 49, 12, 4, 3), (1, 5, 4, 0, 0), (1000, 768, 516, 0, 0), (700, 512, 2048, 6, 2)])
+def test_linear_act_split(L, M, N, K, ldx_extra, act):
+    """The bf16x3 split GEMM (three exact bf16 pieces per operand, six piece products on the bf16 matrix pipe, fp32 accumulate) is as
+    close to the exact product as the fp32 matrix pipe: both against float64, ragged M / N / K edges, strided X."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(M + N + K)
+    Xfull = (rng.uniform(-1, 1, (M, K + ldx_extra)) * np.exp(rng.uniform(-6, 2, (M, 1)))).astype(np.float32)    # rows of very different scale
+    W = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    xt = dev(Xfull)[:, :K]
+    got = _lib.linear_act_split(xt, dev(W), dev(b), act).cpu().numpy()
+    z64 = Xfull[:, :K].astype(np.float64) @ W.astype(np.float64).T
+    z = z64 + b
+    ref = [z, orc._sigmoid(z), orc._elu(z), orc._log_sigmoid(z)][act]
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5)
+    # pre-activation accuracy against the fp32 kernel's, relative to the magnitude of the terms
+    pre = _lib.linear_act_split(xt, dev(W), None, 0).cpu().numpy()
+    os.environ["DFOL_DENSE_MATH"] = "f32"
+    try:
+        pre32 = L.linear_act(xt, dev(W), None, 0).cpu().numpy()
+    finally:
+        del os.environ["DFOL_DENSE_MATH"]
+    scale = np.abs(Xfull[:, :K]).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1e-30
+    e_split, e_f32 = np.abs(pre - z64) / scale, np.abs(pre32 - z64) / scale
+    assert e_split.max() <= max(2.0 ** -21, 1.5 * e_f32.max()) and e_split.mean() <= 1.5 * e_f32.mean() + 2.0 ** -25, (e_split.max(), e_f32.max(), e_split.mean(), e_f32.mean())
+    # the weight image is cached per weight version
+    w = dev(W)
+    a = _lib.linear_act_split(xt, w, None, 0)
+    w.mul_(2.0)
+    assert torch.allclose(_lib.linear_act_split(xt, w, None, 0), 2 * a, rtol=1e-6, atol=0)
+
+
 def test_box_and_pair_features(L):
     n_list = [5, 1, 7]
     F = 10

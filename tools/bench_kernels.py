@@ -100,7 +100,12 @@ def main():
         y = torch.empty(M, Nn, device=dev)
         t = timeit(lambda: L.linear_act(x, w, b, act, y), iters=10)
         fl = 2.0 * M * Nn * K
-        out.append({"kernel": "linear_act", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
+        out.append({"kernel": "linear_act" + ("" if os.environ.get("DFOL_DENSE_MATH") == "f32" else " (auto: bf16x3 when large)"), "M": M, "N": Nn, "K": K,
+                    "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
+        if K % 4 == 0:
+            t = timeit(lambda: L.linear_act_split(x, w, b, act, y), iters=10)
+            out.append({"kernel": "linear_act_split", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                        "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15})
     # fused pair kernel at the bench shape: Q images of N objects, one requested relation column each
     Q, HID1, HID2, C = 256, 256, 300, 2335
     O = Q * N

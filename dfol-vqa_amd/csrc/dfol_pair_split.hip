@@ -43,6 +43,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr float SP_NL2E = -1.44269504088896340736f;          // -log2(e)
 constexpr int SP_CH = 32;                                   // K per chunk = one v_mfma_f32_16x16x32_bf16
 
 __device__ __forceinline__ int sp_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // {0,3,2,1}[(row>>2)&3]
@@ -94,6 +95,11 @@ __global__ void pair_pack_w2_split_kernel(const float* __restrict__ W2, int64_t 
 //               chunk and builds its A pieces; a workgroup barrier ends the tick and the roles swap.  The matrix pipe of a SIMD
 //               always has exactly one wavefront feeding it.  The second half lags the first by one tick, so a chunk is live for
 //               two ticks: two chunk buffers (120 KB of LDS).
+// (A persistent variant - each half running through its own task sequence half a task apart, so that one half's epilogue and
+// next-task setup overlap the other's main loop - was built and measured: correct, but 1.85 ms against 1.78 ms.  Its build ticks
+// became longer than the multiply ticks (U/V row latency no longer hidden by a fresh workgroup's prologue), and prefetching those
+// rows under the MFMAs needs 16-32 registers that the 152 accumulators do not leave: any spill reload inside the multiply waits,
+// in order, for the prefetch itself.)
 template <int NB16, bool TBF16, bool PP>
 __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32s_kernel(
     const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
@@ -122,6 +128,16 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const bool trace_on = blockIdx.x >= 3000 && (blockIdx.x - 3000) % 500 == 0 && trace_blk < 8;
 #endif
     TRACE(0);
+    if constexpr (PP) {                                      // chunks 0 and 1 are requested before anything else: they land under the
+        const int nck = HID1 / SP_CH;                        // geometry arithmetic below
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int i = 0; i < (SP_PIECES + T - 1) / T; ++i)
+                if (cb < nck && T * i + wave * 64 < SP_PIECES)
+                    __builtin_amdgcn_global_load_lds(W2s + (int64_t)cb * SP_PIECES + T * i + tid,
+                                                     (__attribute__((address_space(3))) void*)&Bs[cb * SP_PIECES + T * i + wave * 64], 16, 0, 0);
+    }
     const int first = obj_off[q];
     float geo[MT][4];
     const float* Urow[MT];
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 
     if constexpr (PP) {                                      // the epilogue's rows are staged up front (the first barrier publishes them)
         constexpr int SR = PP_STAGE_FLOATS / ROWS - 1;
-        for (int i = tid; i < ROWS; i += T) stage_pp[i] = i < HID2 ? b2[i] : -1.0e30f;
+        for (int i = tid; i < ROWS; i += T) stage_pp[i] = SP_NL2E * (i < HID2 ? b2[i] : -1.0e30f);        // Sigmoid(x + b) = 1 / (1 + 2^(-L2E x - L2E b))
         for (int k = 0; k < (K < SR ? K : SR); ++k) {
             const int col = req_col[(int64_t)k * Q + q];
             for (int i = tid; i < ROWS; i += T) stage_pp[ROWS * (1 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
@@ -299,8 +315,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         // its build tick 2c+3 (U/V rows requested first: vmcnt retires in order) and Y drains that DMA at the end of its multiply
         // tick 2c+4, one tick before X needs it.
         const int g = wave >> 2;
-        dma_chunk(0, 0, 0, std::integral_constant<int, 8>());
-        if (nchunk > 1) dma_chunk(1, 1, 0, std::integral_constant<int, 8>());
         dma_barrier();                                      // Wgs, the staged epilogue rows and chunks 0, 1 visible
         // Each half runs its own copy of the loop (plain straight-line bodies for the register allocator); the barriers pair up by
         // count: X executes 2 per chunk, Y one idle tick first and none after its last multiply.
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     float* stage = PP ? stage_pp : reinterpret_cast<float*>(&Bs[0]);
     const int Kc = K < STAGE_ROWS ? K : STAGE_ROWS;
     if constexpr (!PP) {
-        for (int i = tid; i < ROWS; i += T) stage[i] = i < HID2 ? b2[i] : -1.0e30f;
+        for (int i = tid; i < ROWS; i += T) stage[i] = SP_NL2E * (i < HID2 ? b2[i] : -1.0e30f);
         for (int k = 0; k < Kc; ++k) {
             const int col = req_col[(int64_t)k * Q + q];
             for (int i = tid; i < ROWS; i += T) stage[ROWS * (1 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         for (int i = 0; i < NB16; ++i) {
             const float bv = stage[i * 16 + r16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + dfol_exp(-(acc[m][i][e] + bv)));
+            for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[m][i][e], SP_NL2E, bv)));
         }
         for (int k = 0; k < K; ++k) {
             const int col = req_col[(int64_t)k * Q + q];
@@ -398,9 +412,10 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
                 const int ee = tb * SLOTS + wave * (MT * 16) + m * 16 + 4 * kh + r16;
                 if (ee < n * n) {
-                    const int ss = ee / n, oo = ee - ss * n;
+                    // ee / n without the integer-division sequence: (ee + 0.5) / n is at least 0.5 / n away from an integer
+                    const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)n)), oo = ee - ss * n;
                     const float x = v + (be ? be[col] : 0.f);
-                    const float val = (ss == oo) ? dflt : fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+                    const float val = (ss == oo) ? dflt : fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid
                     const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
                                        ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
                     if (TBF16) {

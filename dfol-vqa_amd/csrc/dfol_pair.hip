@@ -293,7 +293,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nchunk = HID1 / PB_CH, lastc = nchunk - 1;
     dma_w2(0, 0);
     load_uv(0);
-    __syncthreads();                                        // Wgs and chunk 0 visible (the barrier drains the DMA)
+    // LDS-DMA completion is tracked by the issuing wavefront's vmcnt; a workgroup barrier does not by itself wait for the pieces that
+    // OTHER wavefronts requested, so every wavefront drains its own before arriving
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+    __syncthreads();                                        // Wgs and chunk 0 visible
     make_a(0, a_cur);
     load_uv(PB_CH * min(1, lastc));
     int buf = 0;
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         acc[1][part * HALF + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][t], bv, acc[1][part * HALF + i], 0, 0, 0);
                     }
         }
-        __syncthreads();                                    // chunk c fully read; chunk c+1's DMA drained (vmcnt(0)) and visible
+        __builtin_amdgcn_s_waitcnt(0x0F74);                 // vmcnt(4): this wavefront's pieces of chunk c+1 have landed (vmcnt retires in
+                                                            // order; only the four U/V loads issued after the DMA may still be in flight)
+        __syncthreads();                                    // chunk c fully read; chunk c+1 visible
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -327,11 +327,13 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 load_uv(c);
                 if (Y && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1, 4, std::integral_constant<int, 4>());
                 make_a(c);
-                TRACE(3 + 4 * c);
+                __builtin_amdgcn_sched_barrier(0);          // the A pieces are pure register arithmetic: without this fence the compiler
+                TRACE(3 + 4 * c);                           // sinks them below the barrier, in front of the MFMAs of the multiply tick
                 __syncthreads();                            // end of the build tick
+                __builtin_amdgcn_sched_barrier(0);
                 TRACE(4 + 4 * c);
                 bbase = boff + (c & 1) * SP_PIECES;
-                region_mfma(0, NB16);
+                region_mfma(0, NB16);                       // (s_setprio 1..3 around the MFMAs: no effect, 1.75-1.79 ms)
                 if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);  // the chunk requested in the build tick has landed
                 TRACE(5 + 4 * c);
                 if (!Y || c < lastc) __syncthreads();       // end of the multiply tick (Y's last one has no partner)

@@ -148,15 +148,31 @@ class _TallLinear(torch.autograd.Function):
     (7.5 ms for [300 x 2.5M] x [2.5M x 256]), so it is taken as a batched GEMM over row slices plus a sum."""
 
     @staticmethod
+    def _split_ok(x2, k):
+        return x2.is_cuda and x2.dtype == torch.float32 and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and \
+            os.environ.get("DFOL_DENSE_MATH", "bf16x3") != "f32"
+
+    @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        x2 = x.reshape(-1, x.shape[-1])
+        if _TallLinear._split_ok(x2, x2.shape[1]):          # fp32 results from the bf16 matrix pipe (csrc/dfol_dense_split.hip)
+            w = weight.detach()
+            return L.linear_act_split(x2, w if w.is_contiguous() else w.contiguous(), None if bias is None else bias.detach(),
+                                      L.ACT_NONE).view(*x.shape[:-1], weight.shape[0])
         return nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
-        gx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            g2c = g2 if g2.is_contiguous() else g2.contiguous()
+            if _TallLinear._split_ok(g2c, g2c.shape[1]):
+                gx = L.linear_act_split(g2c, weight.detach().t().contiguous(), None, L.ACT_NONE).view_as(x)
+            else:
+                gx = (g2 @ weight).view_as(x)
         gw = None
         if ctx.needs_input_grad[1]:
             rows = g2.shape[0]

@@ -158,7 +158,9 @@ def main():
                                   "%d-object synthetic scenes, full-size oracle (2048->512, 516/1036->256->300->2335)"
                                   % (args.batch, args.objects),
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
-                      "launch": "hip graph replay" if graphed else "eager"}}
+                      "launch": "hip graph replay" if graphed else "eager",
+                      "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else
+                      "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)"}}
 
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------

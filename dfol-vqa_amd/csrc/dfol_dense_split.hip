@@ -5,13 +5,16 @@
 //
 // W is split and packed once per weight version (dfol_linear_pack_w_bf16x3): [N/128 column blocks][K/32 steps][3 pieces][128 rows]
 // [4 k-groups] x 16 bytes, rows >= N and k >= K zero, k-groups swizzled by (row >> 2) & 3, so that a workgroup's B tile of one
-// k-step is 24 KB of contiguous memory copied to LDS verbatim by LDS-DMA (double-buffered).  X is fp32 in HBM: every thread loads
-// the 2 x 8 consecutive k of its two rows one step ahead into registers, splits them (VALU) and writes the three pieces to LDS in
-// the same swizzled layout, so all fragment reads are conflict-free ds_read_b128.
+// k-step is 24 KB of contiguous memory in fragment order.  X is fp32 in HBM: every thread loads the 2 x 8 consecutive k of its two
+// rows into registers, splits them (VALU) and writes the three pieces to LDS in the same swizzled layout, so all fragment reads are
+// conflict-free ds_read_b128.  Both tiles are staged through registers - the B tile one step ahead, the X rows two steps ahead - and
+// vmcnt retires in order, so B is requested before X and waiting for B leaves the X loads in flight (see `step` below; LDS-DMA for
+// the B tile was tried first and is described there).
 //
 // Workgroup: 256 threads = 2 x 2 wavefronts, 128 x 128 output tile, wavefront tile 64 x 64 (16 accumulator tiles, 64 registers);
-// 72 KB of LDS: two workgroups per CU.  Consecutive workgroups of one XCD share the X row block (blockIdx is re-mapped so that the
+// 48 KB of LDS: two workgroups per CU.  Consecutive workgroups of one XCD share the X row block (blockIdx is re-mapped so that the
 // column blocks of a row block run on the same XCD and hit its L2).
+// -DDFOL_DENSE_TRACE: clock64 stamps of one workgroup (tools/scratch/trace_dense.py).
 #include "dfol_common.h"
 
 #include <type_traits>

@@ -399,6 +399,51 @@ def test_full_size_model_large_scenes(tmp_path, n_list, hops):
     assert dp <= 1e-5, dp
 
 
+def test_bf16x3_contractions_equal_fp32_pipe_end_to_end(tmp_path, monkeypatch):
+    """The default forward (dense layers and pair MLP on the bf16 matrix pipe with the exact three-way operand split) against the same
+    model on the fp32 matrix pipe, through the whole interpreter on 100-object scenes: the final log-probabilities agree as two
+    fp32 evaluations of the same network do, and neither is closer to the float64 oracle than the other."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    nouns, attrs, rels = names["nouns"][:6], names["attributes"][:5], names["relations"][:4]
+    rng = np.random.RandomState(11)
+    pick = lambda xs: xs[rng.randint(len(xs))]
+    qs, scenes = [], []
+    for i, n in enumerate([100, 100, 73, 100, 41, 100]):
+        branch = [syn.op("select", pick(nouns)), syn.op("filter", pick(attrs)), syn.op("relate", pick(rels), bool(i & 1), pick(nouns + ["_"]))]
+        qs.append(syn.question(4300 + i, [branch], syn.op("exist"), "yes"))
+        scenes.append(syn.feature_scene(4300 + i, n, 2048))
+
+    def forward(pipe):
+        for var in ("DFOL_PAIR_MATH", "DFOL_DENSE_MATH"):
+            if pipe == "f32":
+                monkeypatch.setenv(var, "f32")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        torch.manual_seed(5)
+        model = experiment.build_model(cfg, ont)            # a fresh model: packed weight images are cached per weight version
+        with torch.no_grad():
+            model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+            model._oracle._embedding_network.linear.bias.fill_(-2.0)
+        model = model.to(DEV).eval()
+        res, _ = run(model, qs, scenes, ont, key="X")
+        weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+        return res["log_probability"].cpu().numpy().astype(np.float64), weights
+
+    lp_split, weights = forward("bf16x3")
+    lp_f32, _ = forward("f32")
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    lp64 = np.asarray(orc.run_questions(oont, qs, scenes, np.float64, weights=weights)["log_probability"], np.float64)
+    well = lp64 >= -5
+    assert well.sum() >= 3
+    assert np.abs(lp_split - lp_f32)[well].max() <= 2e-5, (lp_split, lp_f32)
+    e_split, e_f32 = np.abs(lp_split - lp64)[well].max(), np.abs(lp_f32 - lp64)[well].max()
+    assert e_split <= 2.0 * e_f32 + 2e-6, (e_split, e_f32)
+    assert np.abs(np.exp(lp_split) - np.exp(lp64)).max() <= 2.0 * np.abs(np.exp(lp_f32) - np.exp(lp64)).max() + 1e-6
+
+
 # ---------------------------------------------------------------------------------------------------
 # attention calibration (SURVEY.md §8(f) rank 2): LSTM passes + apply_modulations against the reference (g10)
 # ---------------------------------------------------------------------------------------------------

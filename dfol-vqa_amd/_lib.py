@@ -290,13 +290,16 @@ SPLIT_MIN_FLOPS = 2.0e8               # below this the fp32 kernel's single laun
 
 def linear_pack_w_split(weight):
     """The bf16x3 image of a Linear weight [N, K] for dfol_linear_act_split_f32, cached per weight version (the cache holds the
-    weight tensor, so its address cannot be recycled while the entry lives)."""
+    weight tensor, so its address cannot be recycled while the entry lives).  The version counter is what optimizers, load_state_dict
+    and nn.init bump; writes through `.data` do not - call `_SPLIT_W_CACHE.clear()` after such a write."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0))
     hit = _SPLIT_W_CACHE.get(key)
     if hit is None:
         N, K = weight.shape
         out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 24576 // 2, dtype=torch.bfloat16, device=weight.device)
         call("dfol_linear_pack_w_bf16x3", weight.data_ptr(), weight.stride(0), N, K, _ptr(out, torch.bfloat16), _stream())
+        for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0]]:      # an older version of the same parameter (optimizer step)
+            del _SPLIT_W_CACHE[stale]
         if len(_SPLIT_W_CACHE) >= 64:
             _SPLIT_W_CACHE.pop(next(iter(_SPLIT_W_CACHE)))
         hit = _SPLIT_W_CACHE[key] = (weight, out)

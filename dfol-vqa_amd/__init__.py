@@ -14,3 +14,4 @@ from .visual_oracle import ClassifierOracle, EmbeddingLayer, OracleBase, Regular
 from .interpreter import BatchGQABoxFeaturizer, BatchGQAInterpreter, BatchInterpreterBase, gather_results  # noqa: F401
 from .program import OperatorBatch, ProgramBatch, ProgramCollaterBase  # noqa: F401
 from .data import BatchGQABoxFeaturesCollator, GQAProgramVerifier, ParserError, ProgramCodec, ProgramDataset  # noqa: F401
+from .preprocess import GQAPreprocessor, normalize  # noqa: F401

@@ -133,3 +133,76 @@ def test_g13_program_verifier(mini_ontology_paths):
         except ParserError:
             got = False
         assert got == valid, (i, prog, valid)
+
+
+def test_g15_gqa_preprocessor(tmp_path):
+    """GQA `semantic` programs -> interpreter programs: every question of golden g15 (the reference's GQAPreprocessor, src/gqa_preprocess.py:98-361,
+    run on questions and an operator map authored here), batch and flat format, with and without `discard_global`, and the segregated
+    per-line output files.  The capture replaced `pattern.singularize` by the identity on a vocabulary for which that is right, and so
+    does this test: the one library call stays unpinned (see dfol_vqa_amd/preprocess.py)."""
+    import json
+    from dfol_vqa_amd.preprocess import GQAPreprocessor, normalize
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g15_preprocess.json")) as f:
+        g = json.load(f)
+    map_path = str(tmp_path / "op_map.json")
+    with open(map_path, "w") as f:
+        json.dump(g["op_map"], f)
+    ident = lambda w: w
+    canon = lambda x: json.loads(json.dumps(x))                  # tuples -> lists, as the reference's output looks after its JSON dump
+    n_dropped = 0
+    for tag, batch_format in (("batch", True), ("flat", False)):
+        pre = GQAPreprocessor(map_path, batch_format, singularize=ident)
+        for discard in (False, True):
+            want = g["parsed"]["%s_discard%d" % (tag, int(discard))]
+            for qid, q in g["questions"].items():
+                got = pre.parse_question(canon(q), discard)
+                assert canon(got) == want[qid], (tag, discard, qid, got, want[qid])
+                n_dropped += got is None
+    assert n_dropped == 2 * (2 + 3)                              # unmapped / null-mapped always; the scene question when discarding
+    in_file = str(tmp_path / "questions.json")
+    with open(in_file, "w") as f:
+        json.dump(g["questions"], f)
+    for key, want in g["files"].items():
+        seg, by_len = key[3] == "1", key[-1] == "1"
+        od = tmp_path / key
+        od.mkdir()
+        GQAPreprocessor(map_path, True, singularize=ident).preprocess(in_file, str(od / "p.json"), seg, by_len, discard_global=True)
+        got = {f: [json.loads(l) for l in open(str(od / f))] for f in sorted(os.listdir(str(od)))}
+        assert got == want, key
+    # normalize: its own tables come before the singulariser
+    assert normalize(" Shelves ", ident) == "shelf" and normalize("Glasses", lambda w: w[:-1]) == "glasses"
+    assert normalize("wine glass", lambda w: "X") == "wine glass" and normalize("dress", lambda w: "X") == "dress" and normalize("dogs", lambda w: w[:-1]) == "dog"
+
+
+def test_preprocess_cli_to_bytecode(tmp_path, mini_ontology_paths):
+    """tools/gqa_preprocess.py: GQA JSON -> per-operator program files -> bytecode that ProgramCodec decodes back to the same programs."""
+    import json
+    import subprocess
+    from dfol_vqa_amd.data import ProgramCodec
+    from dfol_vqa_amd.gqa_ops import GQAOntology
+    p = mini_ontology_paths
+    S = lambda operation, argument, deps: {"operation": operation, "argument": argument, "dependencies": deps}
+    questions = {
+        "11": {"semantic": [S("select", "dog (12)", []), S("filter color", "red", [0]), S("relate", "table,on,s (5)", [1]), S("exist", "?", [2])],
+               "answer": "yes", "imageId": "img003"},
+        "12": {"semantic": [S("select", "cat (1)", []), S("exist", "?", [0]), S("select", "dog (2)", []), S("exist", "?", [2]), S("or", "", [1, 3])],
+               "answer": "no", "imageId": "img001"},
+        "13": {"semantic": [S("select", "cat (1)", []), S("relate", "_,on,o (3)", [0]), S("exist", "?", [1])], "answer": "no", "imageId": "IMG007"},
+    }
+    (tmp_path / "qs.json").write_text(json.dumps(questions))
+    (tmp_path / "op_map.json").write_text(json.dumps({"select": "select", "filter color": "filter", "relate": "relate", "exist": "exist", "or": "or"}))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gqa_preprocess.py"), str(tmp_path / "qs.json"), str(tmp_path / "out"),
+                        "--op-map", str(tmp_path / "op_map.json"), "-b", "--attributes", p["attribute_file"], "--classes", p["class_file"],
+                        "--vocabulary", p["vocabulary_file"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    codec = ProgramCodec(GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], None))
+    seen = 0
+    for f in sorted(os.listdir(str(tmp_path / "out" / "p_qs"))):
+        lines = [json.loads(l) for l in open(str(tmp_path / "out" / "p_qs" / f))]
+        arrays = np.load(str(tmp_path / "out" / "h5_qs" / (os.path.splitext(f)[0] + ".npz")))
+        for i, q in enumerate(lines):
+            got = codec.decode(arrays, i)
+            assert json.loads(json.dumps(got["program"])) == q["program"], (f, i, got["program"], q["program"])
+            seen += 1
+    assert seen == 3

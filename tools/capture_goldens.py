@@ -896,8 +896,86 @@ def g13():
     save("g13_program_verifier", {}, {"source": "nn/parser/parse_utils.py:24-240", "programs": cases, "valid": verdicts})
 
 
+def g15():
+    """The reference's GQA-JSON -> program preprocessor (src/gqa_preprocess.py:98-361) on questions authored here, with an operator map
+    authored here: batch format (branches / last_op) and flat format (operators / arguments / dependencies), verify-and merging,
+    logical-branch rewriting, argument parsing for every operator family, dropped questions, and the segregated per-line output files.
+    `pattern.singularize` is not installed: it is replaced by the identity, and the authored vocabulary only uses words the identity is
+    right for or that `normalize` handles itself (its plurale-tantum / irregular lists) - word singularisation itself stays unpinned."""
+    import tempfile
+    for name in ("pattern", "pattern.text", "pattern.text.en"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.singularize = lambda w: w
+        sys.modules.setdefault(name, m)
+    if "h5py" not in sys.modules:
+        sys.modules["h5py"] = types.ModuleType("h5py")
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_preprocess as ref_pre
+    op_map = {"select": "select", "filter color": "filter", "filter": "filter", "filter size": "filter", "relate": "relate", "query": "query_attr",
+              "verify color": "verify_attrs", "verify size": "verify_attrs", "verify": "verify_attrs", "choose color": "choose_attr",
+              "choose rel": "choose_rel", "verify rel": "verify_rel", "exist": "exist", "and": "and", "or": "or", "same color": "two_same",
+              "same material shape": "two_same", "different color": "two_different", "same": "all_same", "different": "all_different",
+              "choose older": "compare", "choose healthier": "compare", "choose less healthy": "compare", "choose more healthy": "compare",
+              "choose larger": "compare", "common": None}
+    S = lambda operation, argument, deps: {"operation": operation, "argument": argument, "dependencies": deps}
+    Qn = lambda semantic, answer: {"semantic": semantic, "answer": answer, "question": "?", "imageId": "7"}
+    questions = {
+        "q01": Qn([S("select", "dog (1234)", []), S("filter color", "Brown ", [0]), S("relate", "table,on,s (55)", [1]), S("exist", "?", [2])], "Yes"),
+        "q02": Qn([S("select", "shelves (1,2)", []), S("verify color", "red", [0]), S("verify size", "large", [0]), S("and", "", [1, 2])], "no"),
+        "q03": Qn([S("select", "cat (3)", []), S("exist", "?", [0]), S("select", "glasses (-)", []), S("exist", "?", [2]), S("and", "", [1, 3])], "yes"),
+        "q04": Qn([S("select", "man (9)", []), S("verify rel", "horse,riding,o (10)", [0]), S("select", "woman (11)", []),
+                   S("verify color", "blue", [2]), S("or", "", [1, 3])], "no"),
+        "q05": Qn([S("select", "cup (4)", []), S("choose color", "red|green", [0])], "Red"),
+        "q06": Qn([S("select", "boy (5)", []), S("choose rel", "girl,to the left of|to the right of,s (6)", [0])], "to the left of"),
+        "q07": Qn([S("select", "bus (7)", []), S("query", "color", [0])], "yellow"),
+        "q08": Qn([S("select", "fork (1)", []), S("select", "spoon (2)", []), S("same color", "", [0, 1])], "no"),
+        "q09": Qn([S("select", "fork (1)", []), S("select", "spoon (2)", []), S("different color", "", [0, 1])], "yes"),
+        "q10": Qn([S("select", "plate (1)", []), S("same", "color", [0])], "yes"),
+        "q11": Qn([S("select", "plate (1)", []), S("different", "shape", [0])], "no"),
+        "q12": Qn([S("select", "man (1)", []), S("select", "woman (2)", []), S("choose older", "", [0, 1])], "man"),
+        "q13": Qn([S("select", "apple (1)", []), S("select", "cake (2)", []), S("choose healthier", "", [0, 1])], "apple"),
+        "q14": Qn([S("select", "apple (1)", []), S("select", "cake (2)", []), S("choose less healthy", "", [0, 1])], "cake"),
+        "q15": Qn([S("select", "apple (1)", []), S("select", "cake (2)", []), S("choose more healthy", "", [0, 1])], "apple"),
+        "q16": Qn([S("select", "scene", []), S("query", "weather", [0])], "sunny"),
+        "q17": Qn([S("select", "dog (1)", []), S("teleport", "x", [0])], "yes"),                  # operator the map does not know
+        "q18": Qn([S("select", "dog (1)", []), S("common", "", [0])], "color"),                    # operator mapped to null
+        "q19": Qn([S("select", "dress (8)", []), S("filter size", "small", [0]), S("filter color", "not(white)", [1]),
+                   S("relate", "_,wearing,o (9)", [2]), S("query", "name", [3])], "girl"),
+        "q20": Qn([S("select", "car (1)", []), S("verify color", "red", [0]), S("select", "truck (2)", []), S("verify color", "red", [2]),
+                   S("and", "", [1, 3])], "yes"),                                                  # verify-and on two different traces: not merged
+        "q21": Qn([S("select", "apple (1)", []), S("select", "cake (2)", []), S("same material shape", "", [0, 1])], "no"),
+        "q22": Qn([S("select", "box (1)", []), S("select", "bag (2)", []), S("choose larger", "", [0, 1])], "box"),
+        "q23": Qn([S("select", "sky (-) ", []), S("verify", "cloudy", [0])], "yes"),
+    }
+    tmp = tempfile.mkdtemp()
+    map_path = os.path.join(tmp, "op_map.json")
+    json.dump(op_map, open(map_path, "w"))
+    out = {"op_map": op_map, "questions": questions, "parsed": {}}
+    for tag, batch_format in (("batch", True), ("flat", False)):
+        pre = ref_pre.GQAPreprocessor(map_path, batch_format)
+        for discard in (False, True):
+            res = {}
+            for qid, q in questions.items():
+                res[qid] = pre.parse_question(json.loads(json.dumps(q)), discard)
+            out["parsed"]["%s_discard%d" % (tag, int(discard))] = res
+    # the file-level driver: segregated per-line outputs
+    in_file = os.path.join(tmp, "questions.json")
+    json.dump(questions, open(in_file, "w"))
+    files = {}
+    for seg, by_len in ((True, False), (True, True), (False, False)):
+        od = tempfile.mkdtemp()
+        ref_pre.GQAPreprocessor(map_path, True).preprocess(in_file, os.path.join(od, "p.json"), seg, by_len, discard_global=True)
+        files["seg%d_len%d" % (int(seg), int(by_len))] = {f: [json.loads(l) for l in open(os.path.join(od, f))] for f in sorted(os.listdir(od))}
+    out["files"] = files
+    with open(os.path.join(OUT, "g15_preprocess.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote g15_preprocess", len(questions), "questions")
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()
 

@@ -353,6 +353,39 @@ def test_linear_act_split(L, M, N, K, ldx_extra, act):
     assert torch.allclose(_lib.linear_act_split(xt, w, None, 0), 2 * a, rtol=1e-6, atol=0)
 
 
+def test_bf16x3_kernels_bitwise_repeatable(L):
+    """The two LDS-pipelined bf16x3 kernels at the bench shape, 25 launches each: every result bitwise equal to the first.  (The pair
+    kernel's chunk buffers are filled by LDS-DMA, whose completion no barrier waits for by itself: a missing drain shows up here.)"""
+    from dfol_vqa_amd import _lib
+    torch.manual_seed(0)
+    Q, N, HID1, HID2, C, K = 256, 100, 256, 300, 333, 2
+    O = Q * N
+    uv = torch.randn(O, 2 * HID1, device="cuda") * 0.5
+    pos = torch.rand(O, 4, device="cuda") * 0.5 + 0.05
+    wg = torch.randn(HID1, 4, device="cuda") * 0.3
+    w2 = torch.zeros(320, HID1, device="cuda")
+    w2[:HID2] = torch.randn(HID2, HID1, device="cuda") / 16
+    b2, E, be = torch.randn(HID2, device="cuda"), torch.randn(C, HID2, device="cuda") / 17, torch.randn(C, device="cuda")
+    n_o = torch.full((Q,), N, dtype=torch.int32, device="cuda")
+    off = (torch.arange(Q + 1, device="cuda") * N).to(torch.int32)
+    req_col = torch.randint(0, C, (K, Q), dtype=torch.int32, device="cuda")
+    req_tile = torch.arange(K * Q, dtype=torch.int32, device="cuda").view(K, Q)
+    w2s = _lib.pair_pack_w2_split(w2, HID2)
+    first = None
+    for _ in range(25):
+        tiles = torch.full((K * Q, 104, 104), -30.0, device="cuda")
+        _lib.pair_ll_split(uv, HID1, pos, wg, w2s, b2, HID2, E, be, n_o, off, N, req_col, req_tile, None, tiles)
+        first = tiles.clone() if first is None else first
+        assert torch.equal(first, tiles)
+    x = torch.rand(25600, 2054, device="cuda")[:, :2048]
+    w, b = torch.randn(512, 2048, device="cuda") / 45, torch.randn(512, device="cuda")
+    first = None
+    for _ in range(25):
+        y = _lib.linear_act_split(x, w, b, 1)
+        first = y.clone() if first is None else first
+        assert torch.equal(first, y)
+
+
 def test_box_and_pair_features(L):
     n_list = [5, 1, 7]
     F = 10

@@ -62,6 +62,10 @@ SIGNATURES = {
     "dfol_pair_pack_w2_f32": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_packed_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                 _i32, _p, _p],
+    "dfol_pair_hidden1_fwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "dfol_pair_hidden1_bwd_f32": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _p],
+    "dfol_pair_logit_fwd_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i32, _i64, _i64, _p, _p],
+    "dfol_pair_logit_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_linear_pack_w_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_split_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_pack_w2_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
@@ -433,6 +437,52 @@ def pair_ll_split(uv, hid1, pos, wg, w2_split, b2, hid2, emb_w, emb_b, n_obj, ob
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          TILE_BF16 if bf16 else TILE_F32, _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
+
+
+# ---- training path of the pair MLP (csrc/dfol_pair_train.hip) ------------------------------------------------------
+def pair_train_supported(hid1, hid2, max_n):
+    lpr = hid1 // 4
+    return hid1 % 4 == 0 and 16 <= hid1 <= 1024 and lpr & (lpr - 1) == 0 and lpr <= 256 and hid2 <= 512 and max_n <= 16 * (1024 // lpr)
+
+
+def pair_hidden1_fwd(u, v, pos, wg, obj_off, pair_off, n_obj, max_n, pairs):
+    """z [pairs, HID1] = ELU(U[s] + V[o] + Wg geo) and geo [pairs, 4]; u, v [O, HID1] (row stride a multiple of 4), pos [O, >=4] view."""
+    Q, hid1 = n_obj.shape[0], u.shape[1]
+    z = torch.empty(pairs, hid1, dtype=F32, device=u.device)
+    geo = torch.empty(pairs, 4, dtype=F32, device=u.device)
+    call("dfol_pair_hidden1_fwd_f32", u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), pos.data_ptr(), pos.stride(0), _ptr(wg, F32),
+         _ptr(obj_off, I32), _ptr(pair_off, torch.int64), _ptr(n_obj, I32), Q, max_n, hid1, _ptr(z), _ptr(geo), _stream())
+    return z, geo
+
+
+def pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, max_n, total_obj):
+    """(dU [O, HID1], dV [O, HID1], dWg [HID1, 4]) from dZ; deterministic (no atomics)."""
+    Q, hid1 = n_obj.shape[0], z.shape[1]
+    du = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)             # objects of images with < 2 objects get no row written
+    dv = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)
+    part = torch.zeros(Q, hid1, 4, dtype=F32, device=z.device)
+    call("dfol_pair_hidden1_bwd_f32", _ptr(dz, F32), _ptr(z, F32), _ptr(geo, F32), _ptr(obj_off, I32), _ptr(pair_off, torch.int64),
+         _ptr(n_obj, I32), Q, max_n, hid1, _ptr(du), du.stride(0), _ptr(dv), dv.stride(0), _ptr(part), _stream())
+    return du, dv, part.sum(0)
+
+
+def pair_logit_fwd(p2, e_rows, be_rows, pred_off, max_rows):
+    """max_rows: the largest number of rows a predicate owns (host value; the launch is one row tile grid per predicate)."""
+    rows, P = p2.shape[0], e_rows.shape[0]
+    x = torch.empty(rows, dtype=F32, device=p2.device)
+    call("dfol_pair_logit_fwd_f32", p2.data_ptr(), p2.stride(0), p2.shape[1], e_rows.data_ptr(), e_rows.stride(0), _ptr(be_rows, F32, True),
+         _ptr(pred_off, torch.int64), P, rows, int(max_rows), _ptr(x), _stream())
+    return x
+
+
+def pair_logit_bwd(dx, p2, e_rows, pred_off, need_bias=True):
+    P = e_rows.shape[0]
+    dp2 = torch.empty_like(p2)
+    de = torch.empty(P, p2.shape[1], dtype=F32, device=p2.device)
+    dbe = torch.empty(P, dtype=F32, device=p2.device) if need_bias else None
+    call("dfol_pair_logit_bwd_f32", _ptr(dx, F32), p2.data_ptr(), p2.stride(0), p2.shape[1], e_rows.data_ptr(), e_rows.stride(0),
+         _ptr(pred_off, torch.int64), P, dp2.data_ptr(), dp2.stride(0), de.data_ptr(), de.stride(0), _ptr(dbe, F32, True), _stream())
+    return dp2, de, dbe
 
 
 # ---- backward wrappers ----------------------------------------------------------------------------------

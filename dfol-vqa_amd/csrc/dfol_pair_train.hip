@@ -1,0 +1,270 @@
+// Training path of the pair MLP (trainer.py:429-442 through classifier_oracle.py:145-156): the element-wise and gather / scatter
+// stages around the two tall GEMMs, fused (gfx950).  All four kernels are HBM-bound streams over the per-pair activations
+// ([pairs, HID1] and [pairs, HID2] fp32: 2.6 GB and 3.1 GB at 256 x 100 objects); what they replace is ~25 separate passes over
+// those tensors (gathers of the per-object halves, adds, ELU, Sigmoid, the embedding product and its row sums, and in the backward
+// the scatter-adds of the gathers - atomics - plus the activation derivatives and reductions).
+//
+//   hidden1_fwd : Z[r, :]   = ELU(U[s(r), :] + V[o(r), :] + Wg geo(r))      geo from the box positions, also written out [pairs, 4]
+//   hidden1_bwd : dpre      = dZ * ELU'(pre)  (= dZ * (Z > 0 ? 1 : Z + 1)),   dU[s] = sum_o dpre,  dV[o] = sum_s dpre,  dWg = sum dpre (x) geo
+//                 one workgroup per image, no atomics: the sums over o are reduced across the workgroup through LDS, the sums over s
+//                 live in registers, the geometry-weight gradient leaves as one partial per image
+//   logit_fwd   : x[r]      = sum_j Sigmoid(P2[r, j]) E[p(r), j] + be[p(r)]     p(r): the predicate whose contiguous row range holds r
+//   logit_bwd   : dP2[r, j] = dx[r] E[p, j] h (1 - h),   dE[p, j] = sum_r dx[r] h[r, j],   dbe[p] = sum_r dx[r]     (h recomputed)
+//                 one workgroup per predicate, no atomics
+// Rows are the reference's ordered pairs: image-major, subject-major, the diagonal left out (util.py:87-103).
+#include "dfol_common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 pair_geometry(const float* ps, const float* po) {      // batch_gqa_boxfeatures_pipeline.py:263-279
+    const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
+    const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
+    const float dist = sqrtf(dx * dx + dy * dy);
+    return make_float4(dist, asinf(dy / fmaxf(dist, 1e-10f)), (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f),
+                       (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f));
+}
+
+// grid (tiles_per_image, Q); a workgroup of 256 threads covers 256 / (H1 / 4) consecutive pairs of one image, a thread 4 hidden units
+__global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __restrict__ U, int64_t ld_u, const float* __restrict__ V,
+                                                                int64_t ld_v, const float* __restrict__ pos, int64_t ld_pos,
+                                                                const float* __restrict__ Wg, const int32_t* __restrict__ obj_off,
+                                                                const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
+                                                                int H1, float* __restrict__ Z, float* __restrict__ geo_out) {
+    const int q = blockIdx.y, n = n_obj[q], lpr = H1 >> 2, rows_per_block = 256 / lpr;
+    const int e = blockIdx.x * rows_per_block + (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4;
+    if (n < 2 || e >= n * (n - 1)) return;
+    const int s = e / (n - 1), oo = e - s * (n - 1), o = oo + (oo >= s), first = obj_off[q];
+    const int64_t row = pair_off[q] + e;
+    const float4 g = pair_geometry(pos + (int64_t)(first + s) * ld_pos, pos + (int64_t)(first + o) * ld_pos);
+    if (k == 0) st4(geo_out + row * 4, g);
+    const float4 u = ld4(U + (int64_t)(first + s) * ld_u + k), v = ld4(V + (int64_t)(first + o) * ld_v + k);
+    float z[4] = {u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4 w = ld4(Wg + (int64_t)(k + t) * 4);
+        const float pre = z[t] + (w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w);
+        z[t] = pre > 0.f ? pre : expm1f(pre);                // nn.ELU
+    }
+    st4(Z + row * H1 + k, make_float4(z[0], z[1], z[2], z[3]));
+}
+
+constexpr int HB_MAXO = 16;                                   // objects per lane group in hidden1_bwd
+
+// one workgroup (1024 threads = G groups of H1 / 4 lanes) per image
+__global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const float* __restrict__ dZ, const float* __restrict__ Z,
+                                                                 const float* __restrict__ geo, const int32_t* __restrict__ obj_off,
+                                                                 const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
+                                                                 int H1, float* __restrict__ dU, int64_t ld_du, float* __restrict__ dV,
+                                                                 int64_t ld_dv, float* __restrict__ dWg_partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];            // [G][H1] floats
+    const int q = blockIdx.x, n = n_obj[q], lpr = H1 >> 2, G = 1024 / lpr;
+    const int g = (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4, first = obj_off[q];
+    const int64_t base = pair_off[q];
+    float4 dv[HB_MAXO];
+    float dwg[4][4];
+#pragma unroll
+    for (int i = 0; i < HB_MAXO; ++i) dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dwg[t][d] = 0.f;
+    for (int s = 0; s < n; ++s) {
+        float4 du = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < HB_MAXO; ++i) {
+            const int o = g + i * G;
+            if (o < n && o != s) {
+                const int64_t row = base + (int64_t)s * (n - 1) + (o - (o > s));
+                const float4 dz = ld4(dZ + row * H1 + k), z = ld4(Z + row * H1 + k), ge = ld4(geo + row * 4);
+                const float4 dp = make_float4(dz.x * (z.x > 0.f ? 1.f : z.x + 1.f), dz.y * (z.y > 0.f ? 1.f : z.y + 1.f),
+                                              dz.z * (z.z > 0.f ? 1.f : z.z + 1.f), dz.w * (z.w > 0.f ? 1.f : z.w + 1.f));
+                du.x += dp.x, du.y += dp.y, du.z += dp.z, du.w += dp.w;
+                dv[i].x += dp.x, dv[i].y += dp.y, dv[i].z += dp.z, dv[i].w += dp.w;
+                const float gd[4] = {ge.x, ge.y, ge.z, ge.w}, dpv[4] = {dp.x, dp.y, dp.z, dp.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) dwg[t][d] = fmaf(dpv[t], gd[d], dwg[t][d]);
+            }
+        }
+        st4(&red[g * H1 + k], du);                           // sum over the groups (= over o) in a fixed order
+        __syncthreads();
+        if (g == 0) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < G; ++j) {
+                const float4 p = ld4(&red[j * H1 + k]);
+                acc.x += p.x, acc.y += p.y, acc.z += p.z, acc.w += p.w;
+            }
+            st4(dU + (int64_t)(first + s) * ld_du + k, acc);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < HB_MAXO; ++i) {
+        const int o = g + i * G;
+        if (o < n) st4(dV + (int64_t)(first + o) * ld_dv + k, dv[i]);
+    }
+    // geometry-weight gradient of this image: [H1, 4], reduced over the groups through the same LDS array, four columns at a time
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        st4(&red[g * H1 + k], make_float4(dwg[0][d], dwg[1][d], dwg[2][d], dwg[3][d]));
+        __syncthreads();
+        if (g == 0) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < G; ++j) {
+                const float4 p = ld4(&red[j * H1 + k]);
+                acc.x += p.x, acc.y += p.y, acc.z += p.z, acc.w += p.w;
+            }
+            float* out = dWg_partial + (int64_t)q * H1 * 4;
+            out[(k + 0) * 4 + d] = acc.x, out[(k + 1) * 4 + d] = acc.y, out[(k + 2) * 4 + d] = acc.z, out[(k + 3) * 4 + d] = acc.w;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int LG_T = 8;                                       // hidden units per lane: H2 <= 512
+
+// grid (row tiles, P): a workgroup covers 16 consecutive rows of one predicate, a wavefront 4 of them (four independent load streams)
+__global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const float* __restrict__ P2, int64_t ld_p2, int H2,
+                                                              const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be,
+                                                              const int64_t* __restrict__ pred_off, float* __restrict__ x) {
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r1 = pred_off[p + 1], row0 = pred_off[p] + (int64_t)blockIdx.x * 16 + wave * 4;
+    if (row0 >= r1) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < LG_T; ++t) {
+        const int j = lane + 64 * t;
+        if (j < H2) {
+            const float ev = E[(int64_t)p * ld_e + j];
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = P2[min(row0 + i, r1 - 1) * ld_p2 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(1.0f / (1.0f + expf(-v[i])), ev, acc[i]);
+        }
+    }
+    const float b = be ? be[p] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float sum = dfol_wave_sum(acc[i]);
+        if (lane == 0 && row0 + i < r1) x[row0 + i] = sum + b;
+    }
+}
+
+// one workgroup (16 wavefronts) per predicate: rows pred_off[p] .. pred_off[p+1]
+__global__ __launch_bounds__(1024) void pair_logit_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ P2, int64_t ld_p2,
+                                                               int H2, const float* __restrict__ E, int64_t ld_e,
+                                                               const int64_t* __restrict__ pred_off, float* __restrict__ dP2,
+                                                               int64_t ld_dp2, float* __restrict__ dE, int64_t ld_de,
+                                                               float* __restrict__ dbe) {
+    __shared__ float red[16][64 * LG_T + 1];
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = pred_off[p], r1 = pred_off[p + 1];
+    float ev[LG_T], de[LG_T], db = 0.f;
+#pragma unroll
+    for (int t = 0; t < LG_T; ++t) {
+        const int j = lane + 64 * t;
+        ev[t] = j < H2 ? E[(int64_t)p * ld_e + j] : 0.f;
+        de[t] = 0.f;
+    }
+    for (int64_t row = r0 + wave; row < r1; row += 32) {     // two rows per trip: twice the loads in flight
+        const int64_t row_b = row + 16;
+        const bool has_b = row_b < r1;
+        const float ga = dx[row], gb = has_b ? dx[row_b] : 0.f;
+        db += ga + gb;
+        float va[LG_T], vb[LG_T];
+#pragma unroll
+        for (int t = 0; t < LG_T; ++t) {
+            const int j = lane + 64 * t;
+            va[t] = j < H2 ? P2[row * ld_p2 + j] : 0.f;
+            vb[t] = (j < H2 && has_b) ? P2[row_b * ld_p2 + j] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < LG_T; ++t) {
+            const int j = lane + 64 * t;
+            if (j < H2) {
+                const float ha = 1.0f / (1.0f + expf(-va[t])), hb = 1.0f / (1.0f + expf(-vb[t]));
+                dP2[row * ld_dp2 + j] = ga * ev[t] * ha * (1.0f - ha);
+                if (has_b) dP2[row_b * ld_dp2 + j] = gb * ev[t] * hb * (1.0f - hb);
+                de[t] = fmaf(ga, ha, fmaf(gb, hb, de[t]));
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < LG_T; ++t) red[wave][lane + 64 * t] = de[t];
+    if (lane == 0) red[wave][64 * LG_T] = db;
+    __syncthreads();
+    for (int j = threadIdx.x; j < H2; j += 1024) {
+        float acc = 0.f;
+        for (int w = 0; w < 16; ++w) acc += red[w][j];
+        dE[(int64_t)p * ld_de + j] = acc;
+    }
+    if (threadIdx.x == 0 && dbe) {
+        float acc = 0.f;
+        for (int w = 0; w < 16; ++w) acc += red[w][64 * LG_T];
+        dbe[p] = acc;
+    }
+}
+
+bool hidden_width_ok(int H1) { return H1 >= 16 && H1 <= 1024 && H1 % 4 == 0 && 1024 % (H1 / 4) == 0 && 256 % (H1 / 4) == 0; }
+
+}  // namespace
+
+extern "C" int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos,
+                                         const float* Wg, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q,
+                                         int32_t max_n, int32_t H1, float* Z, float* geo, void* stream) {
+    DFOL_REQUIRE(hidden_width_ok(H1), "pair_hidden1_fwd: HID1=%d must be 16..1024 with HID1/4 a power of two <= 256", H1);
+    DFOL_REQUIRE(ld_u % 4 == 0 && ld_v % 4 == 0 && Q >= 0 && max_n >= 0, "pair_hidden1_fwd: rows of U and V must be 16-byte aligned");
+    if (Q == 0 || max_n < 2) return 0;
+    DFOL_REQUIRE(U && V && pos && Wg && obj_off && pair_off && n_obj && Z && geo, "pair_hidden1_fwd: null pointer");
+    const int rows_per_block = 256 / (H1 / 4);
+    const dim3 grid(dfol_cdiv((int64_t)max_n * (max_n - 1), rows_per_block), Q);
+    hipLaunchKernelGGL(pair_hidden1_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, U, ld_u, V, ld_v, pos, ld_pos, Wg, obj_off, pair_off,
+                       n_obj, H1, Z, geo);
+    DFOL_LAUNCH_CHECK("pair_hidden1_fwd");
+    return 0;
+}
+
+extern "C" int dfol_pair_hidden1_bwd_f32(const float* dZ, const float* Z, const float* geo, const int32_t* obj_off, const int64_t* pair_off,
+                                         const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t H1, float* dU, int64_t ld_du, float* dV,
+                                         int64_t ld_dv, float* dWg_partial, void* stream) {
+    DFOL_REQUIRE(hidden_width_ok(H1), "pair_hidden1_bwd: HID1=%d must be 16..1024 with HID1/4 a power of two <= 256", H1);
+    const int G = 1024 / (H1 / 4);
+    DFOL_REQUIRE(max_n <= HB_MAXO * G, "pair_hidden1_bwd: max_n=%d exceeds %d objects per image at HID1=%d", max_n, HB_MAXO * G, H1);
+    DFOL_REQUIRE(ld_du % 4 == 0 && ld_dv % 4 == 0, "pair_hidden1_bwd: rows of dU and dV must be 16-byte aligned");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(dZ && Z && geo && obj_off && pair_off && n_obj && dU && dV && dWg_partial, "pair_hidden1_bwd: null pointer");
+    hipLaunchKernelGGL(pair_hidden1_bwd_kernel, dim3(Q), dim3(1024), (size_t)G * H1 * sizeof(float), (hipStream_t)stream, dZ, Z, geo, obj_off,
+                       pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
+    DFOL_LAUNCH_CHECK("pair_hidden1_bwd");
+    return 0;
+}
+
+extern "C" int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e, const float* be,
+                                       const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream) {
+    DFOL_REQUIRE(H2 > 0 && H2 <= 64 * LG_T && P >= 0 && rows >= 0, "pair_logit_fwd: HID2=%d must be <= %d", H2, 64 * LG_T);
+    if (rows == 0 || P == 0) return 0;
+    DFOL_REQUIRE(P2 && E && pred_off && x, "pair_logit_fwd: null pointer");
+    DFOL_REQUIRE(max_rows > 0 && max_rows <= rows && dfol_cdiv(max_rows, 16) < ((int64_t)1 << 31) && P < 65536,
+                 "pair_logit_fwd: max_rows=%lld must be the largest row count of a predicate (P < 65536)", (long long)max_rows);
+    hipLaunchKernelGGL(pair_logit_fwd_kernel, dim3((unsigned)dfol_cdiv(max_rows, 16), P), dim3(256), 0, (hipStream_t)stream, P2, ld_p2, H2, E,
+                       ld_e, be, pred_off, x);
+    DFOL_LAUNCH_CHECK("pair_logit_fwd");
+    return 0;
+}
+
+extern "C" int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e,
+                                       const int64_t* pred_off, int32_t P, float* dP2, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe,
+                                       void* stream) {
+    DFOL_REQUIRE(H2 > 0 && H2 <= 64 * LG_T && P >= 0, "pair_logit_bwd: HID2=%d must be <= %d", H2, 64 * LG_T);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(dx && P2 && E && pred_off && dP2 && dE, "pair_logit_bwd: null pointer");
+    hipLaunchKernelGGL(pair_logit_bwd_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, dx, P2, ld_p2, H2, E, ld_e, pred_off, dP2, ld_dp2, dE,
+                       ld_de, dbe);
+    DFOL_LAUNCH_CHECK("pair_logit_bwd");
+    return 0;
+}

@@ -184,6 +184,44 @@ class _TallLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _FusedHidden1(torch.autograd.Function):
+    """z = ELU(U[s] + V[o] + Wg geo(s, o)) over the ordered pairs of a scene, one kernel forward and one backward
+    (csrc/dfol_pair_train.hip) instead of two gathers, the geometry features, a tall K = 4 product, two adds and the ELU - and, in the
+    backward, instead of the scatter-adds of the gathers (the largest single item of a ragged train step)."""
+
+    @staticmethod
+    def forward(ctx, U, V, Wg, pos, world):
+        max_n = max(world._n_list)
+        z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num)
+        # (the world itself must not hang on the graph: world -> cached activations -> graph -> world would be a reference cycle that
+        # only the garbage collector frees, 3 GB per step)
+        ctx.save_for_backward(z, geo, world._obj_off, world._pair_off, world._n_obj)
+        ctx.max_n, ctx.total_obj = max_n, U.shape[0]
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        z, geo, obj_off, pair_off, n_obj = ctx.saved_tensors
+        du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj)
+        return du, dv, dwg, None, None
+
+
+class _FusedLogit(torch.autograd.Function):
+    """x[r] = Sigmoid(pre2[r]) . E[p(r)] + be[p(r)] for the rows of each predicate's image: Sigmoid, the embedding product and its row
+    sum in one pass, and one pass for the three gradients (csrc/dfol_pair_train.hip); the hidden activations are never stored."""
+
+    @staticmethod
+    def forward(ctx, pre2, e_rows, be_rows, pred_off, max_rows):
+        ctx.save_for_backward(pre2, e_rows, pred_off)
+        return L.pair_logit_fwd(pre2, e_rows, be_rows, pred_off, max_rows)
+
+    @staticmethod
+    def backward(ctx, dx):
+        pre2, e_rows, pred_off = ctx.saved_tensors
+        dp2, de, dbe = L.pair_logit_bwd(dx.contiguous(), pre2, e_rows, pred_off, need_bias=ctx.needs_input_grad[2])
+        return dp2, de, dbe, None, None
+
+
 class ClassifierOracle(OracleBase):
     """classifier_oracle.py:11-156 with cached tables (the only mode the reference's experiments use:
     gqa_interpreter_experiments.py:209-210 builds it with cached=True)."""
@@ -293,6 +331,7 @@ class ClassifierOracle(OracleBase):
         world._attr_table = None
         world._rel_table = None
         world._pair_h = None
+        world._pair_pre2 = None
         if train:
             return
         wuv, buv, wg, hid1, D = self._split_first_layer()
@@ -300,27 +339,42 @@ class ClassifierOracle(OracleBase):
         world._uv = L.linear_act(obj, wuv, buv, L.ACT_NONE)
 
     # ---- needed columns with gradients (training of the oracle, trainer.py:429-442) ------------------------------
-    def _pair_hidden_autograd(self, world):
-        """h = Sigmoid(W2 ELU(W1 [obj_s, obj_o, geo] + b1) + b2) for every ordered pair [pairs, HID2], with the first layer split
-        per object exactly as the fused kernel does; one evaluation per scene, shared by all relation operators."""
-        if world._pair_h is None:
+    def _fused_training(self, world):
+        """The fused training kernels apply (widths, image sizes) and are not switched off (DFOL_TRAIN_FUSED=0)."""
+        lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+        return os.environ.get("DFOL_TRAIN_FUSED", "1") != "0" and world._pair_num > 0 and \
+            L.pair_train_supported(lin1.weight.shape[0], lin2.weight.shape[0], max(world._n_list))
+
+    def _pair_pre2_autograd(self, world):
+        """pre2 = W2 ELU(W1 [obj_s, obj_o, geo] + b1) + b2 for every ordered pair [pairs, HID2] (the hidden layer before its Sigmoid),
+        with the first layer split per object exactly as the fused inference kernel does; one evaluation per scene."""
+        if getattr(world, "_pair_pre2", None) is None:
             lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
             obj = world._obj
             D = (lin1.weight.shape[1] - 4) // 2
             assert obj.shape[1] == D, "object feature width does not match the relation network"
-            s_idx, o_idx = world.pair_index()
             U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias)
             V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
             pos = obj[:, D - 4:].detach()                       # batch_gqa_boxfeatures_pipeline.py:263-279
-            ps, po = pos.index_select(0, s_idx), pos.index_select(0, o_idx)
-            dx = ps[:, 0] + ps[:, 2] / 2.0 - po[:, 0] - po[:, 2] / 2.0
-            dy = ps[:, 1] + ps[:, 3] / 2.0 - po[:, 1] - po[:, 3] / 2.0
-            dist = torch.sqrt(dx * dx + dy * dy)
-            geo = torch.stack([dist, torch.asin(dy / dist.clamp(min=1e-10)), torch.sign(po[:, 0] - ps[:, 0]),
-                               torch.sign(po[:, 1] - ps[:, 1])], 1)
-            z = nn.functional.elu(U.index_select(0, s_idx) + V.index_select(0, o_idx)
-                                  + _TallLinear.apply(geo, lin1.weight[:, 2 * D:2 * D + 4], None))
-            world._pair_h = torch.sigmoid(_TallLinear.apply(z, lin2.weight, lin2.bias))
+            if self._fused_training(world) and U.shape[1] % 4 == 0:
+                z = _FusedHidden1.apply(U.contiguous(), V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(), pos, world)
+            else:
+                s_idx, o_idx = world.pair_index()
+                ps, po = pos.index_select(0, s_idx), pos.index_select(0, o_idx)
+                dx = ps[:, 0] + ps[:, 2] / 2.0 - po[:, 0] - po[:, 2] / 2.0
+                dy = ps[:, 1] + ps[:, 3] / 2.0 - po[:, 1] - po[:, 3] / 2.0
+                dist = torch.sqrt(dx * dx + dy * dy)
+                geo = torch.stack([dist, torch.asin(dy / dist.clamp(min=1e-10)), torch.sign(po[:, 0] - ps[:, 0]),
+                                   torch.sign(po[:, 1] - ps[:, 1])], 1)
+                z = nn.functional.elu(U.index_select(0, s_idx) + V.index_select(0, o_idx)
+                                      + _TallLinear.apply(geo, lin1.weight[:, 2 * D:2 * D + 4], None))
+            world._pair_pre2 = _TallLinear.apply(z, lin2.weight, lin2.bias)
+        return world._pair_pre2
+
+    def _pair_hidden_autograd(self, world):
+        """h = Sigmoid(pre2) [pairs, HID2]; shared by all relation operators of the scene."""
+        if world._pair_h is None:
+            world._pair_h = torch.sigmoid(self._pair_pre2_autograd(world))
         return world._pair_h
 
     def _pair_hidden_dense(self, world, n):
@@ -367,7 +421,8 @@ class ClassifierOracle(OracleBase):
 
     def _relation_tiles_autograd(self, world, low, pred_q_host):
         """[P, NS, NS] tiles (subjects along rows) of the requested relation columns, differentiable."""
-        if world._pair_num > 0 and min(world._n_list) == max(world._n_list):
+        fused = self._fused_training(world)
+        if world._pair_num > 0 and min(world._n_list) == max(world._n_list) and not fused:
             return self._relation_tiles_dense(world, low, pred_q_host, world._n_list[0])
         emb = self._embedding_network.linear
         dev = world._device
@@ -379,7 +434,6 @@ class ClassifierOracle(OracleBase):
         flat = torch.full((P * NS * NS,), -30.0, dtype=torch.float32, device=dev)
         if world._pair_num == 0:
             return flat.view(P, NS, NS)
-        h = self._pair_hidden_autograd(world)
         preds = np.nonzero(full >= 0)[0]
         q = pq[preds]
         cnt = n[q] * (n[q] - 1)
@@ -396,16 +450,21 @@ class ClassifierOracle(OracleBase):
             src = pair_off[q][rep] + k
             identity = len(src) == world._pair_num and np.array_equal(src, np.arange(len(src)))
             hit = (None if identity else torch.as_tensor(src).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev),
-                   torch.as_tensor(rep).to(dev))
+                   torch.as_tensor(rep).to(dev), torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(dev), int(cnt.max()))
             if len(self._index_cache) >= 32:
                 self._index_cache.clear()
             self._index_cache[key] = hit
-        src, dst, rep = hit
-        # one pass over all predicates (a loop over concepts would scatter-add into the hidden gradient once per concept; a
-        # matrix-vector product would go to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms)
+        src, dst, rep, pred_off, max_rows = hit
         cols = upload(full[preds].astype(np.int64), dev)
-        e_rows = emb.weight.index_select(0, cols).index_select(0, rep)
-        x = ((h if src is None else h.index_select(0, src)) * e_rows).sum(1) + emb.bias.index_select(0, cols).index_select(0, rep)
+        if fused and src is None:
+            # every pair row belongs to exactly one predicate, in order: Sigmoid, embedding product and row sum in one kernel
+            x = _FusedLogit.apply(self._pair_pre2_autograd(world), emb.weight.index_select(0, cols), emb.bias.index_select(0, cols), pred_off, max_rows)
+        else:
+            # one pass over all predicates (a loop over concepts would scatter-add into the hidden gradient once per concept; a
+            # matrix-vector product would go to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms)
+            h = self._pair_hidden_autograd(world)
+            e_rows = emb.weight.index_select(0, cols).index_select(0, rep)
+            x = ((h if src is None else h.index_select(0, src)) * e_rows).sum(1) + emb.bias.index_select(0, cols).index_select(0, rep)
         return flat.index_put((dst,), nn.functional.logsigmoid(x)).view(P, NS, NS)
 
     def _attr_ll_autograd(self, world, low, pred_q_host):

@@ -319,6 +319,30 @@ int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const f
                            const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
                            int32_t tile_dtype, void* tiles, void* stream);
 
+/* ---- training path of the pair MLP: the stages around its two tall GEMMs, fused (dfol-vqa_amd/csrc/dfol_pair_train.hip) ----------
+ * Rows are the reference's ordered pairs (util.py:87-103): image-major, subject-major, the diagonal left out; pair_off[q] = first row of
+ * image q ([Q] int64), obj_off[q] = its first object ([Q] int32), n_obj [Q].
+ *   hidden1_fwd: Z[r, :] = ELU(U[s(r), :] + V[o(r), :] + Wg geo(r)) and geo[r, 0..3] (batch_gqa_boxfeatures_pipeline.py:263-279;
+ *                gqa_interpreter_experiments.py:26-33 with the first layer split per object as in dfol_pair_ll_f32)
+ *   hidden1_bwd: from dZ and Z: dU [O, ld_du], dV [O, ld_dv] (every object row written; no atomics) and one partial of the geometry-weight
+ *                gradient per image, dWg_partial [Q, HID1, 4] (sum over Q on the caller's side).  max_n <= 16 * 4096 / HID1.
+ *   logit_fwd:   x[r] = sum_j Sigmoid(P2[r, j]) E[p(r), j] + be[p(r)]; predicate p owns the rows pred_off[p] .. pred_off[p+1]
+ *                ([P+1] int64, ascending, pred_off[P] = rows; max_rows = the largest range; P < 65536); E [P, ld_e] are the predicates'
+ *                embedding rows, be [P] or NULL
+ *   logit_bwd:   dP2[r, j] = dx[r] E[p, j] h (1 - h), dE[p, j] = sum_r dx[r] h[r, j], dbe[p] = sum_r dx[r] (NULL to skip); h recomputed
+ * HID1 in {16, 32, ..., 1024}; HID2 <= 512.
+ */
+int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos, const float* Wg,
+                              const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t HID1,
+                              float* Z, float* geo, void* stream);
+int dfol_pair_hidden1_bwd_f32(const float* dZ, const float* Z, const float* geo, const int32_t* obj_off, const int64_t* pair_off,
+                              const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t HID1, float* dU, int64_t ld_du, float* dV,
+                              int64_t ld_dv, float* dWg_partial, void* stream);
+int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
+                            const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream);
+int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
+                            const int64_t* pred_off, int32_t P, float* dP2, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe, void* stream);
+
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B.  g_* outputs that are NULL are skipped.
  * g_prior* ([Q, NS]) are ACCUMULATED into (several predicates may share a question's prior): zero them first.

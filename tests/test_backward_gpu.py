@@ -244,3 +244,66 @@ def test_calibrator_phase_train_step(ontology):
     moved = {k for k in after if not torch.equal(after[k], before[k])}
     assert moved and all("attention" in k for k in moved), sorted(moved)[:5]
     assert losses[-1] < losses[0] and all(np.isfinite(l) for l in losses), losses
+
+
+@pytest.mark.parametrize("n_list,hid1,hid2", [([7, 1, 13, 2, 30, 5], 64, 50), ([40, 33], 256, 300), ([3, 3, 3], 16, 7), ([100, 12], 256, 300)])
+def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
+    """csrc/dfol_pair_train.hip against the tensor-op formulation it replaces (gathers, adds, ELU, Sigmoid, embedding product, row sums
+    and their autograd): forward values and all five gradients, ragged scenes incl. images with one object, fp64 reference."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(sum(n_list) + hid1)
+    n = np.asarray(n_list, np.int64)
+    O, Q, pairs = int(n.sum()), len(n_list), int((n * (n - 1)).sum())
+    obj_off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    pair_off = np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)
+    s_idx, o_idx = [], []
+    for q, k in enumerate(n_list):
+        s, o = np.nonzero(~np.eye(k, dtype=bool))
+        s_idx.append(s + obj_off[q]), o_idx.append(o + obj_off[q])
+    s_idx, o_idx = np.concatenate(s_idx), np.concatenate(o_idx)
+    dev = lambda a, dt=None: torch.as_tensor(a if dt is None else np.asarray(a, dt)).to(DEV)
+    U, V = rng.normal(size=(O, hid1)).astype(np.float32), rng.normal(size=(O, hid1)).astype(np.float32)
+    pos = rng.uniform(0.05, 0.9, (O, 6)).astype(np.float32)[:, 1:5]              # a strided view, like obj[:, D-4:]
+    Wg = rng.normal(size=(hid1, 4)).astype(np.float32) * 0.5
+    gz = rng.normal(size=(pairs, hid1)).astype(np.float32)
+
+    geom = (dev(obj_off), dev(pair_off), dev(n, np.int32), int(n.max()))
+    z, geo = _lib.pair_hidden1_fwd(dev(U), dev(V), dev(pos), dev(Wg), geom[0], geom[1], geom[2], geom[3], pairs)
+    # the geometry features against float64 (the angle through its sine: asin is ill-conditioned at +-1) ...
+    p64 = np.ascontiguousarray(pos).astype(np.float64)
+    ps, po = p64[s_idx], p64[o_idx]
+    dx = ps[:, 0] + ps[:, 2] / 2.0 - po[:, 0] - po[:, 2] / 2.0
+    dy = ps[:, 1] + ps[:, 3] / 2.0 - po[:, 1] - po[:, 3] / 2.0
+    dist = np.sqrt(dx * dx + dy * dy)
+    g = geo.cpu().numpy().astype(np.float64)
+    assert np.allclose(g[:, 0], dist, rtol=1e-5, atol=1e-6) and np.allclose(np.sin(g[:, 1]), dy / np.maximum(dist, 1e-10), atol=2e-6)
+    assert np.array_equal(g[:, 2], np.sign(po[:, 0] - ps[:, 0])) and np.array_equal(g[:, 3], np.sign(po[:, 1] - ps[:, 1]))
+    # ... and everything downstream of them against float64 autograd on the same geometry
+    Ut, Vt, Wt = (torch.tensor(a.astype(np.float64), requires_grad=True) for a in (U, V, Wg))
+    z_ref = torch.nn.functional.elu(Ut[s_idx] + Vt[o_idx] + torch.tensor(g) @ Wt.t())
+    z_ref.backward(torch.tensor(gz.astype(np.float64)))
+    z64, du64, dv64, dw64 = [t.detach().numpy() for t in (z_ref, Ut.grad, Vt.grad, Wt.grad)]
+    assert np.allclose(z.cpu().numpy(), z64, rtol=2e-5, atol=2e-5)
+    du, dv, dw = _lib.pair_hidden1_bwd(dev(gz), z, geo, geom[0], geom[1], geom[2], geom[3], O)
+    for got, want, tag in ((du, du64, "dU"), (dv, dv64, "dV"), (dw, dw64, "dWg")):
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(got.cpu().numpy() - want).max() <= 5e-5 * scale, tag
+    du2, dv2, dw2 = _lib.pair_hidden1_bwd(dev(gz), z, geo, geom[0], geom[1], geom[2], geom[3], O)
+    assert torch.equal(du, du2) and torch.equal(dv, dv2) and torch.equal(dw, dw2)          # no atomics: bitwise repeatable
+
+    # logit stage: two predicates on image 0 are not expressible (one contiguous row range per predicate), so one predicate per image
+    P2 = rng.normal(size=(pairs, hid2)).astype(np.float32) * 2
+    keep = [q for q in range(Q) if n_list[q] > 1]
+    pred_off = np.concatenate([[pair_off[q] for q in keep], [pairs]]).astype(np.int64)
+    E, be = rng.normal(size=(len(keep), hid2)).astype(np.float32) * 0.3, rng.normal(size=len(keep)).astype(np.float32)
+    gx = rng.normal(size=pairs).astype(np.float32)
+    rep = np.repeat(np.arange(len(keep)), np.diff(pred_off))
+    Pt, Et, bt = (torch.tensor(a.astype(np.float64), requires_grad=True) for a in (P2, E, be))
+    x64 = (torch.sigmoid(Pt) * Et[rep]).sum(1) + bt[rep]
+    x64.backward(torch.tensor(gx.astype(np.float64)))
+    x = _lib.pair_logit_fwd(dev(P2), dev(E), dev(be), dev(pred_off), int(np.diff(pred_off).max()))
+    assert np.allclose(x.cpu().numpy(), x64.detach().numpy(), rtol=2e-5, atol=2e-5)
+    dp2, de, dbe = _lib.pair_logit_bwd(dev(gx), dev(P2), dev(E), dev(pred_off))
+    assert np.allclose(dp2.cpu().numpy(), Pt.grad.numpy(), rtol=2e-5, atol=2e-6)
+    assert np.abs(de.cpu().numpy() - Et.grad.numpy()).max() <= 5e-5 * max(1.0, np.abs(Et.grad.numpy()).max())
+    assert np.abs(dbe.cpu().numpy() - bt.grad.numpy()).max() <= 5e-5 * max(1.0, np.abs(bt.grad.numpy()).max())

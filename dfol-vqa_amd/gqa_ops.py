@@ -267,7 +267,7 @@ class GQARelateBatch(GQABatchOperatorBase):
                 predicate_question_map=None, likelihood_threshold=0, hard_mode=False):
         x = self._gqa_select(op_id, world, attribute_list, give_answer, predicate_question_map, likelihood_threshold)
         flag, host = _subject_flags(is_subject, world._device)
-        fused = self._forward_fused(op_id, world, x, variable_set, relation_list, flag)
+        fused = self._forward_fused(op_id, world, x, variable_set, relation_list, flag, host)
         if fused is not None:
             return fused
         subject_set = x.gate(variable_set, flag)
@@ -276,7 +276,7 @@ class GQARelateBatch(GQABatchOperatorBase):
         subject_set, object_set = self._relate(op_id, world, subject_set, object_set, relation_list, want=want)
         return subject_set.gate(object_set, flag)
 
-    def _forward_fused(self, op_id, world, x, prev, relation_list, flag):
+    def _forward_fused(self, op_id, world, x, prev, relation_list, flag, host_flags=None):
         """Inference fast path: the three gates and the arity-2 cell in ONE launch (dfol_relate_one_fwd_f32), on tiles the
         oracle prefetched with the summed-out variable along rows.  Same result as the generic route below it."""
         oracle = self._oracle
@@ -303,7 +303,15 @@ class GQARelateBatch(GQABatchOperatorBase):
             # calibrate the kept one with that side's modulations
             mods = torch.where(flag.unsqueeze(1) > 0, rel._subject_modulations.pop(op_id), rel._object_modulations.pop(op_id))
             post = L.modulate(post, mods, world._ident, world._n_obj)
-        quant = torch.where(flag > 0, x._quantifier, prev._quantifier)        # both posteriors carry the subject's quantifier (:571-586)
+        # both posteriors carry the subject's quantifier (:571-586); the flags are host data, so the selection costs at most one launch
+        if host_flags is not None and all(f > 0 for f in host_flags):
+            quant = x._quantifier
+        elif host_flags is not None and not any(f > 0 for f in host_flags):
+            quant = prev._quantifier
+        elif host_flags is not None:
+            quant = torch.where(upload(np.asarray([f > 0 for f in host_flags], np.bool_), world._device), x._quantifier, prev._quantifier)
+        else:
+            quant = torch.where(flag > 0, x._quantifier, prev._quantifier)
         return BatchVariableSet(x._name, world._device, x.object_num(), x.batch_size(), quantifiers=quant, log_attention=post, world=world,
                                 prev_variable_sets_num=x._prev_variable_sets_num + prev._prev_variable_sets_num + 1)
 

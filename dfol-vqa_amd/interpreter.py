@@ -190,6 +190,8 @@ class BatchInterpreterBase(nn.Module):
             if world._lazy is not None:
                 # with a training calibrator the attentions carry gradients and the relates run on the generic cell
                 self._oracle.prefetch_relations(world, program_batch, fused=not (self._has_modulator and modulator_switch and torch.is_grad_enabled()))
+                if hasattr(self._oracle, "prefetch_attributes"):
+                    self._oracle.prefetch_attributes(world, program_batch)
             ops = program_batch._op_batch_list
             trace = []
             for i, op_batch in enumerate(ops):                   # execution loop :145-172

@@ -607,6 +607,34 @@ class ClassifierOracle(OracleBase):
             base += P
         self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
 
+    def prefetch_attributes(self, world, program_batch):
+        """One attribute-column launch for the simple attribute token lists of the program batch (select names, filter attributes,
+        relate's object names: one token per question) instead of one per operator; the operators pick their block up by the identity
+        of the lowered token list, which is memoised by content."""
+        if world._lazy is None or getattr(world, "_train", False):
+            return
+        Q = world._batch_size
+        lows = []
+        for ob in program_batch._op_batch_list:
+            at = {"select": 0, "filter": 0, "relate": 2}.get(ob._op_name)
+            if at is None or not ob._arguments or at >= len(ob._arguments) or ob._arguments[at] is None:
+                continue
+            toks = ob._arguments[at]
+            try:
+                low = get_lowered(toks, self._ontology, TokenType.ATTRIBUTE)
+            except Exception:                                   # an unknown token: let the operator raise where the reference does
+                return
+            if len(low.cols) == Q and low.any_valid and all(low is not other for other in lows):
+                lows.append(low)
+        if len(lows) < 2:
+            return
+        dev = world._device
+        emb = self._embedding_network.linear
+        cols = upload(np.concatenate([low.cols for low in lows]), dev)
+        pred_q = upload(np.tile(np.arange(Q, dtype=np.int32), len(lows)), dev)
+        ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
+        world._attr_blocks = {id(low): ll[i * Q:(i + 1) * Q] for i, low in enumerate(lows)}
+
     def oriented_tiles(self, world, low):
         """Prefetched tiles of a relate operator, each stored with its summed-out variable along rows (or None)."""
         hit = world._rel_tiles.get(id(low)) if world._lazy is not None else None
@@ -678,7 +706,9 @@ class ClassifierOracle(OracleBase):
             ll = self._attr_ll_autograd(world, low, pred_q_host) if token_type == TokenType.ATTRIBUTE \
                 else self._relation_tiles_autograd(world, low, pred_q_host)
         elif token_type == TokenType.ATTRIBUTE:
-            ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
+            ll = getattr(world, "_attr_blocks", {}).get(id(low)) if pred_q is world._ident else None      # prefetch_attributes
+            if ll is None:
+                ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
         else:
             assert orientation == L.TILE_SUBJECT_ROWS
             hit = world._rel_tiles.get(id(low))

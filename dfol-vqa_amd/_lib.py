@@ -55,6 +55,7 @@ SIGNATURES = {
     "dfol_rel_gather_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
     "dfol_option_normalize_bwd_f32": [_p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
     "dfol_modulate_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_lstm_cell_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_lstm_pointwise_f32": [_p, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
     "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
@@ -346,6 +347,16 @@ def lstm_pointwise(igates, hgates, c):
     rows, H = c.shape
     hy, cy = torch.empty_like(c), torch.empty_like(c)
     call("dfol_lstm_pointwise_f32", _ptr(igates, F32), _ptr(hgates, F32), _ptr(c, F32), rows, H, _ptr(hy), _ptr(cy), _stream())
+    return hy, cy
+
+
+def lstm_cell(x, h, c, w_ih_t, w_hh_t, b_ih, b_hh):
+    """nn.LSTMCell forward in one launch; w_ih_t = weight_ih.t().contiguous() [KX, 4H], w_hh_t likewise; fp32, unit column stride."""
+    rows, H = c.shape
+    hy, cy = torch.empty_like(c), torch.empty_like(c)
+    call("dfol_lstm_cell_f32", x.data_ptr(), x.stride(0), x.shape[1], h.data_ptr(), h.stride(0), _ptr(c, F32), _ptr(w_ih_t, F32),
+         w_ih_t.stride(0), _ptr(w_hh_t, F32), w_hh_t.stride(0), _ptr(b_ih, F32, True), _ptr(b_hh, F32, True), rows, H, _ptr(hy), _ptr(cy),
+         _stream())
     return hy, cy
 
 

@@ -1043,6 +1043,76 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ ig, const float*
     hy[idx] = so * tanhf(cn);
 }
 
+// The whole cell in one launch: a workgroup takes LC_ROWS rows, stages their x and h in LDS, thread g < 4H accumulates gate g for all of
+// them (the weights come TRANSPOSED, [K, 4H], so the threads of a wavefront read consecutive floats; the x / h reads are LDS
+// broadcasts), then the pointwise stage.
+constexpr int LC_ROWS = 4;
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ x, int64_t ld_x, int KX, const float* __restrict__ h,
+                                                        int64_t ld_h, const float* __restrict__ c, const float* __restrict__ Wih,
+                                                        int64_t ld_wih, const float* __restrict__ Whh, int64_t ld_whh,
+                                                        const float* __restrict__ bih, const float* __restrict__ bhh, int rows, int H,
+                                                        float* __restrict__ hy, float* __restrict__ cy) {
+    extern __shared__ float lc_s[];                          // [LC_ROWS][KX + H] inputs, then [LC_ROWS][4H] gates
+    const int r0 = blockIdx.x * LC_ROWS, K = KX + H, tid = threadIdx.x;
+    float* in_s = lc_s;
+    float* gate_s = lc_s + LC_ROWS * K;
+    for (int i = tid; i < LC_ROWS * K; i += 256) {
+        const int r = i / K, k = i - r * K, row = min(r0 + r, rows - 1);
+        in_s[i] = k < KX ? x[(int64_t)row * ld_x + k] : h[(int64_t)row * ld_h + (k - KX)];
+    }
+    __syncthreads();
+    for (int g = tid; g < 4 * H; g += 256) {
+        float acc[LC_ROWS];
+#pragma unroll
+        for (int r = 0; r < LC_ROWS; ++r) acc[r] = 0.f;
+        const float* wi = Wih + g;                          // column g of the transposed weight
+        const float* wh = Whh + g;
+#pragma unroll 8
+        for (int k = 0; k < KX; ++k) {
+            const float w = wi[(int64_t)k * ld_wih];
+#pragma unroll
+            for (int r = 0; r < LC_ROWS; ++r) acc[r] = fmaf(w, in_s[r * K + k], acc[r]);
+        }
+        // the two products are summed separately and then added, as torch's cell does (igates + hgates)
+        float acch[LC_ROWS];
+#pragma unroll
+        for (int r = 0; r < LC_ROWS; ++r) acch[r] = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < H; ++k) {
+            const float w = wh[(int64_t)k * ld_whh];
+#pragma unroll
+            for (int r = 0; r < LC_ROWS; ++r) acch[r] = fmaf(w, in_s[r * K + KX + k], acch[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < LC_ROWS; ++r) gate_s[r * 4 * H + g] = (acc[r] + (bih ? bih[g] : 0.f)) + (acch[r] + (bhh ? bhh[g] : 0.f));
+    }
+    __syncthreads();
+    for (int i = tid; i < LC_ROWS * H; i += 256) {
+        const int r = i / H, j = i - r * H, row = r0 + r;
+        if (row >= rows) continue;
+        const float* gs = gate_s + r * 4 * H;
+        const float gi = gs[j], gf = gs[H + j], gg = gs[2 * H + j], go = gs[3 * H + j];
+        const float si = 1.0f / (1.0f + expf(-gi)), sf = 1.0f / (1.0f + expf(-gf)), so = 1.0f / (1.0f + expf(-go));
+        const float cn = sf * c[(int64_t)row * H + j] + si * tanhf(gg);
+        cy[(int64_t)row * H + j] = cn;
+        hy[(int64_t)row * H + j] = so * tanhf(cn);
+    }
+}
+
+extern "C" int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
+                                  int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows,
+                                  int32_t H, float* h_out, float* c_out, void* stream) {
+    DFOL_REQUIRE(rows >= 0 && H > 0 && KX > 0, "lstm_cell: bad sizes rows=%d H=%d KX=%d", rows, H, KX);
+    const size_t lds = sizeof(float) * LC_ROWS * ((size_t)KX + H + 4 * (size_t)H);
+    DFOL_REQUIRE(lds <= 64 * 1024, "lstm_cell: input width %d + hidden %d too large for the staging buffer", KX, H);
+    if (rows == 0) return 0;
+    DFOL_REQUIRE(x && h && c && Wih && Whh && h_out && c_out, "lstm_cell: null pointer");
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(256), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
+                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out);
+    DFOL_LAUNCH_CHECK("lstm_cell");
+    return 0;
+}
+
 extern "C" int dfol_lstm_pointwise_f32(const float* igates, const float* hgates, const float* c, int32_t rows, int32_t H, float* h_out,
                                        float* c_out, void* stream) {
     DFOL_REQUIRE(rows >= 0 && H > 0, "lstm_pointwise: bad sizes rows=%d H=%d", rows, H);

@@ -128,15 +128,21 @@ class OracleBase(nn.Module):
 
 
 class CalibrationLSTMCell(nn.LSTMCell):
-    """nn.LSTMCell (same parameters and state_dict names) whose inference forward runs on the library's kernels: the two small
-    gate GEMMs ([Q, 318] x [318, 200], [Q, 50] x [50, 200]) take 54 us each in the vendor BLAS, an eighth of that here, and a
-    calibrated forward runs sixteen of them.  With gradients enabled it is torch's own cell."""
+    """nn.LSTMCell (same parameters and state_dict names) whose inference forward is ONE launch (dfol_lstm_cell_f32: both gate
+    products, the biases and the pointwise stage; the two small GEMMs [Q, 318] x [318, 200], [Q, 50] x [50, 200] take 54 us each in
+    the vendor BLAS and 15 us each as two launches of the dense kernel, and a calibrated forward runs eight cells).  With gradients
+    enabled it is torch's own cell."""
 
     def forward(self, x, state=None):
         if state is None or not x.is_cuda or (torch.is_grad_enabled() and (x.requires_grad or state[0].requires_grad or
                                                                          any(p.requires_grad for p in self.parameters()))):
             return super(CalibrationLSTMCell, self).forward(x, state)
         h, c = state
+        if x.dtype == torch.float32 and x.stride(-1) == 1 and h.stride(-1) == 1 and 4 * (x.shape[1] + 5 * h.shape[1]) * 4 <= 65536:
+            key = (self.weight_ih._version, self.weight_hh._version, self.weight_ih.data_ptr(), self.weight_hh.data_ptr())
+            if getattr(self, "_wt", (None,))[0] != key:          # transposed copies, once per weight version
+                self._wt = (key, self.weight_ih.detach().t().contiguous(), self.weight_hh.detach().t().contiguous())
+            return L.lstm_cell(x, h, c.contiguous(), self._wt[1], self._wt[2], self.bias_ih, self.bias_hh)          # one launch
         ig = L.linear_act(x.contiguous(), self.weight_ih, self.bias_ih, L.ACT_NONE)
         hg = L.linear_act(h.contiguous(), self.weight_hh, self.bias_hh, L.ACT_NONE)
         return L.lstm_pointwise(ig, hg, c.contiguous())

@@ -252,6 +252,13 @@ int dfol_modulate_f32(const float* att, const float* mods, const int32_t* pred_q
  */
 int dfol_lstm_pointwise_f32(const float* igates, const float* hgates, const float* c, int32_t rows, int32_t H, float* h_out,
                             float* c_out, void* stream);
+/* The whole LSTM cell in one launch (gate products, biases, pointwise stage): x [rows, ld_x] (KX used), h [rows, ld_h], c [rows, H],
+ * Wih = W_ih^T [KX, ld_wih >= 4H], Whh = W_hh^T [H, ld_whh >= 4H] (TRANSPOSED weights: coalesced across the gate threads),
+ * b_ih / b_hh [4H] or NULL -> h_out, c_out [rows, H].  What the calibration passes run.
+ */
+int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
+                       int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
+                       float* h_out, float* c_out, void* stream);
 
 /* ---- needed-columns oracle (MI355X-first: nothing the program does not ask for is computed) --------
  * The reference evaluates the embedding layer for all 2335 concepts on every object and every ordered

@@ -643,7 +643,7 @@ def test_relate_one_bf16_equals_fp32_kernel_on_rounded_tiles(L, n_list):
 
 
 def test_calibration_lstm_cell_equals_torch(L):
-    """CalibrationLSTMCell (gate GEMMs by dfol_linear_act_f32 + dfol_lstm_pointwise_f32) == nn.LSTMCell with the same parameters."""
+    """CalibrationLSTMCell (dfol_lstm_cell_f32: one launch; or gate GEMMs + dfol_lstm_pointwise_f32) == nn.LSTMCell with the same parameters."""
     from dfol_vqa_amd.visual_oracle import CalibrationLSTMCell
     torch.manual_seed(0)
     ref = torch.nn.LSTMCell(318, 50).cuda()
@@ -656,6 +656,15 @@ def test_calibration_lstm_cell_equals_torch(L):
             h1, c1 = ref(x, (h, c))
             h2, c2 = mine(x, (h, c))
         assert torch.allclose(h1, h2, atol=2e-6, rtol=1e-5) and torch.allclose(c1, c2, atol=2e-6, rtol=1e-5)
+        # the two-GEMM + pointwise route (what wider cells fall back to) and a strided input view
+        with torch.no_grad():
+            ig, hg = L.linear_act(x, mine.weight_ih, mine.bias_ih, L.ACT_NONE), L.linear_act(h, mine.weight_hh, mine.bias_hh, L.ACT_NONE)
+            h3, c3 = L.lstm_pointwise(ig, hg, c)
+            wide = torch.randn(rows, 400, device="cuda")
+            wide[:, 40:358] = x
+            h4, c4 = mine(wide[:, 40:358], (h, c))
+        assert torch.allclose(h1, h3, atol=2e-6, rtol=1e-5) and torch.allclose(c1, c3, atol=2e-6, rtol=1e-5)
+        assert torch.equal(h2, h4) and torch.equal(c2, c4)
     # with gradients it is torch's own cell
     x = torch.randn(4, 318, device="cuda", requires_grad=True)
     h2, c2 = mine(x, (torch.zeros(4, 50, device="cuda"), torch.zeros(4, 50, device="cuda")))

@@ -93,6 +93,17 @@ class BatchOperatorBase(nn.Module):
 
     def _token_features(self, world, tokens, op_feature, type_flag):
         """LSTM input rows [op one-hot, type flag, token embedding]; zero rows for no-op tokens (:437-446, :628-637)."""
+        # the forward and the backward calibration pass ask for the same rows: build them once per scene
+        cache = world.__dict__.setdefault("_calib_features", {})
+        key = (tuple(str(t) for t in tokens), float(type_flag), op_feature.data_ptr())
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        feats = self._token_features_now(world, tokens, op_feature, type_flag)
+        cache[key] = feats
+        return feats
+
+    def _token_features_now(self, world, tokens, op_feature, type_flag):
         ind = [is_valid_token(v) for v in tokens]
         kept = [t for t, k in zip(tokens, ind) if k]
         _, _, names = detect_negations(kept)

@@ -285,6 +285,7 @@ class BatchGQAInterpreter(BatchInterpreterBase):
         onehot = np.zeros(len(self._OPS_INDEX), np.float32)
         onehot[self._OPS_INDEX[operator_batch._op_name]] = 1.0
         temp = upload(onehot, world._device)                   # (memoised; an indexed assignment on the device is not graph-capturable)
+        temp._host = onehot                                    # lets the operators build their constant feature columns on the host
         x = self._ops[operator_batch._op_name].transform_attention(*((op_id, is_forward, world) + input_tuple + tuple(operator_batch._arguments) +
                                                                      (temp, operator_batch._predicate_question_map)))
         return x, is_terminal

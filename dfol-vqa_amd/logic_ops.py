@@ -107,8 +107,15 @@ class BatchOperatorBase(nn.Module):
         ind = [is_valid_token(v) for v in tokens]
         kept = [t for t, k in zip(tokens, ind) if k]
         _, _, names = detect_negations(kept)
-        flag = torch.full((1,), float(type_flag), dtype=torch.float32, device=world._device)
-        feats = self._get_features(world, names, torch.cat([op_feature, flag], dim=0))
+        host = getattr(op_feature, "_host", None)
+        if host is not None:                                  # the constant columns (op one-hot, type flag) come from the host, memoised
+            emb = self._oracle.get_embedding(names, world._meta_data, world._device)
+            emb = emb.unsqueeze(0) if emb.dim() < 2 else emb
+            const = np.concatenate([np.asarray(host, np.float32), np.asarray([type_flag], np.float32)])
+            feats = torch.cat([upload(np.tile(const, (len(names), 1)), world._device), emb], dim=1)
+        else:
+            flag = torch.full((1,), float(type_flag), dtype=torch.float32, device=world._device)
+            feats = self._get_features(world, names, torch.cat([op_feature, flag], dim=0))
         if all(ind):
             return feats
         full = torch.zeros(len(tokens), feats.shape[1], dtype=torch.float32, device=world._device)

@@ -342,10 +342,20 @@ class BatchAttentionState(object):
             host = [0 if f is None else f for f in flag]
             from .host_util import upload
             g = upload(np.asarray([float(f) for f in host], np.float32), self._device)
+        names = [x if f > 0 else y for x, y, f in zip(self._name, attention_state._name, host)]
+        binary = all(f in (0, 1, 0.0, 1.0, True, False) for f in host)
+        if binary and all(f > 0 for f in host):                 # the flags are host data: a uniform gate costs no launch ...
+            return BatchAttentionState(names, self._device, self._state)
+        if binary and not any(f > 0 for f in host):
+            return BatchAttentionState(names, self._device, attention_state._state)
+        if binary:                                              # ... and a 0/1 gate is a select (g x + (1 - g) y exactly, for finite states)
+            from .host_util import upload
+            pick = upload(np.asarray([f > 0 for f in host], np.bool_), self._device).unsqueeze(1)
+            return BatchAttentionState(names, self._device, (torch.where(pick, self._state[0], attention_state._state[0]),
+                                                             torch.where(pick, self._state[1], attention_state._state[1])))
         g = g.unsqueeze(1)
         state0 = self._state[0] * g + attention_state._state[0] * (1.0 - g)
         state1 = self._state[1] * g + attention_state._state[1] * (1.0 - g)
-        names = [x if f > 0 else y for x, y, f in zip(self._name, attention_state._name, host)]
         return BatchAttentionState(names, self._device, (state0, state1))
 
     def expand(self, predicate_question_map):                  # mm(pqm, state)  :300-304

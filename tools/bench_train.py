@@ -30,12 +30,14 @@ def main():
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("DFOL_BENCH_SHARE_GPU") == "1"    # debugging aid for one-GPU boxes: every rank on cuda:0, gradients over gloo
+    local = 0 if share else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     group = None
     if world > 1:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=device)
+        td.init_process_group("gloo") if share else td.init_process_group("nccl", device_id=device)
         group = td.group.WORLD
     from dfol_vqa_amd import experiment, training
     from dfol_vqa_amd import synthetic as syn

@@ -1,10 +1,17 @@
-"""Import shim: the package directory is `dfol-vqa_amd/` (not a legal Python identifier),
-so `import dfol_vqa_amd` lands here and is redirected to that directory."""
+"""MI355X-native hot path of the ∇-FOL (DFOL-VQA) program interpreter.
 
-import os as _os
+Host-side mirror of the reference's operator/program API (reference
+`src/nsvqa/nn/interpreter/*`), calling hand-written gfx950 HIP kernels through
+the C-ABI library declared in `include/dfol_vqa.h`.
+"""
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "dfol-vqa_amd")
-__path__.insert(0, _real)
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _f.name, "exec"))
-del _f
+__version__ = "0.1.0"
+
+from .fol_types import BatchVariableSet, BatchWorld, Quantifier, QuestionType, TokenType  # noqa: F401
+from .logic_ops import BatchBayesianLogicCell, FilterBatch, RelateBatch, SelectBatch  # noqa: F401
+from .gqa_ops import GQAOntology  # noqa: F401
+from .visual_oracle import ClassifierOracle, EmbeddingLayer, OracleBase, RegularMLP  # noqa: F401
+from .interpreter import BatchGQABoxFeaturizer, BatchGQAInterpreter, BatchInterpreterBase, gather_results  # noqa: F401
+from .program import OperatorBatch, ProgramBatch, ProgramCollaterBase  # noqa: F401
+from .data import BatchGQABoxFeaturesCollator, GQAProgramVerifier, ParserError, ProgramCodec, ProgramDataset  # noqa: F401
+from .preprocess import GQAPreprocessor, normalize  # noqa: F401

@@ -214,7 +214,7 @@ int dfol_compare_f32(const float* lp1, const float* lp2, const float* is_less, i
 int dfol_linear_act_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
                         int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
 
-/* The same contraction with fp32 results from the bf16 matrix pipes (dfol-vqa_amd/csrc/dfol_dense_split.hip): each fp32 operand is
+/* The same contraction with fp32 results from the bf16 matrix pipes (dfol_vqa_amd/csrc/dfol_dense_split.hip): each fp32 operand is
  * cut exactly into three bf16 pieces and six of the nine piece products are accumulated in fp32 (v_mfma_f32_16x16x32_bf16); the
  * dropped products are below 2^-23 |x w|, so results agree with dfol_linear_act_f32 to fp32 rounding.  W_split is produced once
  * per weight version by dfol_linear_pack_w_bf16x3: ceil(N/128) * ceil(K/32) * 24576 bytes, 16-byte aligned.
@@ -298,7 +298,7 @@ int dfol_pair_ll_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* 
                      float default_ll, float* tiles, void* stream);
 
 /* The same relation tiles from a PACKED second layer (the geometry the full-size oracle uses: two independent 4-wavefront
- * workgroups per CU, K chunks of 16, see dfol-vqa_amd/csrc/dfol_pair.hip).  W2_packed is produced once per weight update by
+ * workgroups per CU, K chunks of 16, see dfol_vqa_amd/csrc/dfol_pair.hip).  W2_packed is produced once per weight update by
  * dfol_pair_pack_w2_f32 ((HID1/16)*320*16 floats, 16-byte aligned): chunk-major [HID1/16][320][16], rows >= HID2 zero,
  * k-groups swizzled for conflict-free LDS reads.  tile_dtype: DFOL_TILE_F32, or DFOL_TILE_BF16 (tiles are then [T, NS, NS] bf16
  * bit patterns for dfol_relate_one_fwd_bf16; needs HID2 > 256).  All other arguments as dfol_pair_ll_f32.
@@ -311,7 +311,7 @@ int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t HID1, const 
                             const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
                             int32_t tile_dtype, void* tiles, void* stream);
 
-/* The same relation tiles with the second layer on the bf16 matrix pipes at fp32 accuracy (dfol-vqa_amd/csrc/dfol_pair_split.hip):
+/* The same relation tiles with the second layer on the bf16 matrix pipes at fp32 accuracy (dfol_vqa_amd/csrc/dfol_pair_split.hip):
  * each fp32 operand is cut exactly into three bf16 pieces and six of the nine piece products are accumulated in fp32 by
  * v_mfma_f32_16x16x32_bf16; the dropped products are below 2^-23 of |a w|, the rounding error of one fp32 FMA, so the results
  * agree with dfol_pair_ll_packed_f32 to fp32 rounding (they are NOT a reduced-precision mode).  W2_split is produced once per
@@ -326,7 +326,7 @@ int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const f
                            const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
                            int32_t tile_dtype, void* tiles, void* stream);
 
-/* ---- training path of the pair MLP: the stages around its two tall GEMMs, fused (dfol-vqa_amd/csrc/dfol_pair_train.hip) ----------
+/* ---- training path of the pair MLP: the stages around its two tall GEMMs, fused (dfol_vqa_amd/csrc/dfol_pair_train.hip) ----------
  * Rows are the reference's ordered pairs (util.py:87-103): image-major, subject-major, the diagonal left out; pair_off[q] = first row of
  * image q ([Q] int64), obj_off[q] = its first object ([Q] int32), n_obj [Q].
  *   hidden1_fwd: Z[r, :] = ELU(U[s(r), :] + V[o(r), :] + Wg geo(r)) and geo[r, 0..3] (batch_gqa_boxfeatures_pipeline.py:263-279;

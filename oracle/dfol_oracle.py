@@ -1,6 +1,6 @@
 """CPU oracle: a numpy restatement of the reference's ∇-FOL interpreter hot path.
 
-TEST INFRASTRUCTURE ONLY.  Nothing under `dfol-vqa_amd/` imports this file; only `tests/`,
+TEST INFRASTRUCTURE ONLY.  Nothing under `dfol_vqa_amd/` imports this file; only `tests/`,
 `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do, and there only as the
 checker / the timed CPU baseline — never as a fallback for the HIP path.
 

@@ -58,7 +58,7 @@ def test_no_cpu_fallback(lib):
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "dfol-vqa_amd")
+    pkg = os.path.join(ROOT, "dfol_vqa_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):

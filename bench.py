@@ -9,9 +9,13 @@ whose object features and lowered program are already resident in HBM.  Workload
 configs[1] (3-hop Filter->Relate->Exist programs, fp32, batch=256) on N-object scenes; N defaults to
 100, the size BASELINE.json's metric is quoted on (configs[1] itself says 36: pass --objects 36).
 
-For --gpus N > 1 the driver launches one rank per GPU (torch.distributed.run); questions are
-independent, so each rank runs its own shard with no data-path collective (weak scaling) and the
-ranks only meet at the timing barriers.
+--gpus N > 1: one process per GPU.  Either the driver starts the ranks (torch.distributed.run sets
+RANK / LOCAL_RANK / WORLD_SIZE) or, when those are absent, this script starts them itself - as child
+processes, BEFORE anything here touches the GPU - and rank 0's JSON line is the output.  Questions are
+independent, so each rank runs its own shard with no data-path collective (weak scaling) and the ranks
+only meet at the timing barriers.  --mode train times the train step instead (forward + loss + backward
++ ONE RCCL all-reduce of the flat gradient bucket + clip + Adam; reference trainer.py:429-442), the
+only place a collective sits on the path.
 
 Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel of the step; `kernels` adds the
 HBM roofline of the Relate/Filter logic kernels on >= 65536 resident predicates (SURVEY.md §8(d));
@@ -36,17 +40,50 @@ F32_MFMA_PEAK = 157.3e12     # FLOP/s, dense f32-input MFMA
 BF16_MFMA_PEAK = 2.5e15      # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--objects", type=int, default=100)
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer")
+    ap.add_argument("--workload", choices=("north_star", "c1", "c4"), default="north_star",
+                    help="north_star: configs[1]'s program on 100-object scenes (the size the metric is quoted on); c1: configs[1] verbatim "
+                         "(36 objects); c4: configs[4] (256 objects, 8-hop open programs, bf16 relation tiles)")
+    ap.add_argument("--objects", type=int, default=None)
+    ap.add_argument("--ragged", type=int, default=0, help="train mode: object counts ~ U{ragged..objects}")
+    ap.add_argument("--calibrator", type=int, default=0, help="train mode: 1 = calibrator phases (cur6-7): oracle frozen, the attention networks train")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=None, help="questions in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--parity-all", type=int, default=1, help="1: check every question of the batch against the oracle (not only the timed sample)")
     ap.add_argument("--stress-preds", type=int, default=65536)
+    ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.objects is None:
+        args.objects = {"north_star": 100, "c1": 36, "c4": 256}[args.workload]
+    return args
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` without a launcher: start N ranks as CHILD processes through torch.distributed.run and pass rank 0's line through.
+    Nothing in this process has touched the GPU yet (torch.cuda.device_count() does not initialise it on this image)."""
+    import socket
+    import subprocess
+    share = os.environ.get("DFOL_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) visible (DFOL_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo, for debugging)"
+                 % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def build_batch(args, rank, ontology, names, device):
@@ -66,11 +103,17 @@ def build_batch(args, rank, ontology, names, device):
             return {"index": {}, "embedding": torch.zeros(1, 1)}
 
     nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    rng = np.random.RandomState(1000 + rank)
     qs = []
     for i in range(args.batch):
         qid = rank * args.batch + i                        # scenes are keyed by question id: sharding never changes inputs
-        br, last = syn.three_hop_program(qid, nouns, attrs, rels)
-        qs.append(syn.question(qid, br, last, "yes", syn.feature_scene(qid, args.objects, 2048)))
+        n = args.objects if not getattr(args, "ragged", 0) else int(rng.randint(args.ragged, args.objects + 1))
+        if getattr(args, "workload", "north_star") == "c4":
+            br, last = syn.open_program(qid, nouns, attrs, rels, names["categories"], hops=4)
+            qs.append(syn.question(qid, br, last, attrs[qid % len(attrs)], syn.feature_scene(qid, n, 2048)))
+        else:
+            br, last = syn.three_hop_program(qid, nouns, attrs, rels)
+            qs.append(syn.question(qid, br, last, "yes", syn.feature_scene(qid, n, 2048)))
     pbs = Collater().collate(qs)
     for pb in pbs:
         pb.create_sparse_tensors()
@@ -79,7 +122,8 @@ def build_batch(args, rank, ontology, names, device):
 
 def init_weights(model):
     """Random weights of the reference architecture; the embedding rows get GloVe-like magnitudes so that the
-    concept probabilities are sparse instead of saturated."""
+    concept probabilities are sparse instead of saturated.  Seeded: every rank builds the same replica (and
+    parallel.broadcast_parameters makes that a guarantee instead of a convention)."""
     torch.manual_seed(0)
     lin = model._oracle._embedding_network.linear
     with torch.no_grad():
@@ -87,37 +131,76 @@ def init_weights(model):
         lin.bias.fill_(-2.0)
 
 
-def main():
-    args = parse()
+WORKLOADS = {
+    "north_star": "BASELINE configs[1]'s program: select->filter->relate->exist (3-hop), fp32, %d questions/GPU/step, %d-object synthetic "
+                  "scenes (the size BASELINE.json's metric is quoted on), full-size oracle (2048->512, 516/1036->256->300->2335)",
+    "c1": "BASELINE configs[1] verbatim: select->filter->relate->exist (3-hop), fp32, %d questions/GPU/step, %d-object synthetic scenes, "
+          "full-size oracle (2048->512, 516/1036->256->300->2335)",
+    "c4": "BASELINE configs[4]: select->(filter->relate)x4->query_attr (8-hop open programs), %d questions/GPU/step, %d-object synthetic "
+          "scenes, bf16 relation tiles (fp32 logic arithmetic), full-size oracle",
+}
+
+
+def setup(args):
+    """Rank / device / process group; fails loudly when the launch does not match --gpus."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # DFOL_BENCH_SHARE_GPU=1 is a debugging aid for boxes with one GPU: every rank uses cuda:0 and the ranks meet over gloo
     share = os.environ.get("DFOL_BENCH_SHARE_GPU") == "1"
     local = 0 if share else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if dist:
+    td = None
+    if world > 1:
         import torch.distributed as td
         if share:
-            td.init_process_group("gloo")
+            td.init_process_group("gloo", timeout=__import__("datetime").timedelta(seconds=600))
         else:
             td.init_process_group("nccl", device_id=device)      # RCCL over xGMI
+        assert td.get_world_size() == args.gpus
+    return rank, world, device, td, share
 
-    import dfol_vqa_amd as D
+
+def build_model(args, device, train=False):
     from dfol_vqa_amd import _lib as L
     from dfol_vqa_amd import experiment
     from dfol_vqa_amd import synthetic as syn
     L.load()
-
     tmp = tempfile.mkdtemp(prefix="dfol_bench_")
     paths, names = syn.write_synthetic_ontology(tmp)
-    cfg = syn.reference_config(paths)
+    if not train:
+        cfg = syn.reference_config(paths)
+    elif args.calibrator:
+        cfg = syn.reference_config(paths, dropout=0.0, activate_attention_transfer=True)
+    else:                                                        # the oracle-training phases (cur1-5) of the curriculum
+        cfg = syn.reference_config(paths, dropout=0.0, freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+                                   freeze_embedding_network=False)
+    if args.workload == "c4":
+        cfg["relation_tile_dtype"] = "bf16"
     ontology = experiment.build_ontology(cfg)
     model = experiment.build_model(cfg, ontology)
     init_weights(model)
-    model = model.to(device).eval()
+    model = model.to(device)
+    return (model.train() if train else model.eval()), ontology, paths, names
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, argv)                                 # does not return
+    rank, world, device, td, share = setup(args)
+    if args.mode == "train":
+        return train_main(args, rank, world, device, td, share)
+
+    from dfol_vqa_amd import _lib as L
+    model, ontology, paths, names = build_model(args, device)
+    if td is not None:
+        from dfol_vqa_amd import parallel
+        parallel.broadcast_parameters(model, 0)
     qs, pbs = build_batch(args, rank, ontology, names, device)
 
     eager = lambda: model(pbs, False)
@@ -133,7 +216,7 @@ def main():
             torch.cuda.synchronize()
 
     def barrier():
-        if dist:
+        if td is not None:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -146,22 +229,26 @@ def main():
             res = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    if dist:
+    if td is not None:
         t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
     total_q = args.batch * world * args.steps
-    out = {"metric": "questions/sec (GQA programs, N=%d objects)" % args.objects, "value": total_q / elapsed, "unit": "questions/s",
+    metric = "questions/sec (GQA programs, N=%d objects)" % args.objects
+    out = {"metric": metric, "value": total_q / elapsed, "unit": "questions/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[1]: select->filter->relate->exist (3-hop), fp32, %d questions/GPU/step, "
-                                  "%d-object synthetic scenes, full-size oracle (2048->512, 516/1036->256->300->2335)"
-                                  % (args.batch, args.objects),
+           "config": {"workload": WORKLOADS[args.workload] % (args.batch, args.objects),
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
                       "launch": "hip graph replay" if graphed else "eager",
                       "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else
                       "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)"}}
 
+    if args.streamed:
+        # every rank streams its own batches (the ranks share the host's PCIe root complexes, so this is measured with all of them live)
+        sv = streamed_rate(args, step if graphed else eager, pbs, td, share, device)
+        out["value_streamed"] = sv["questions_per_s"] * world
+        out["streamed"] = sv
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
         names_timed = list(L.SIGNATURES)
@@ -174,54 +261,189 @@ def main():
         per_step = {k: (n / 3.0, t / 3.0) for k, (n, t) in timing.items() if n}
         dom = max(per_step, key=lambda k: per_step[k][1])
         out["kernel_ms_per_step"] = {k: round(v[1] * 1e3, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][1])}
-        O = args.batch * args.objects
-        pairs = args.batch * args.objects * (args.objects - 1)
-        launches, secs = per_step[dom]
-        if dom == "dfol_pair_ll_split_f32":
-            # The same algorithmic flops, executed on the bf16 matrix pipe as six piece products per fp32 product (three exact
-            # bf16 pieces per operand, fp32 accumulate: fp32 results, csrc/dfol_pair_split.hip).  `achieved` / `frac` follow the
-            # contract (ALGORITHMIC flops against the peak of the pipe that executes them); the pipe itself does 6x that work.
-            flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
-            ach = flops / secs
-            out["roofline"] = {"kernel": "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)", "bound": "mfma",
-                               "achieved": ach / 1e12, "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
-                               "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
-                               "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300),
-                               "executed": {"mfma_flops_per_algorithmic_flop": 6, "achieved": 6 * ach / 1e12, "frac": 6 * ach / BF16_MFMA_PEAK},
-                               "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": ach / F32_MFMA_PEAK}}
-        elif dom in ("dfol_pair_ll_f32", "dfol_pair_ll_packed_f32"):
-            # reduced-form algorithmic flops per ordered pair: geometry term, 256->300 layer, and the
-            # K requested embedding columns (K = 1 relation per question in this workload)
-            flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
-            ach = flops / secs
-            out["roofline"] = {"kernel": "pair_ll32b_kernel<19> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
-                               "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
-                               "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
-                               "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}
-        elif dom == "dfol_linear_act_f32":
-            if getattr(model._oracle, "_needed_columns", False) and model._oracle.supports_needed_columns():
-                flops = 2.0 * O * (2048 * 512 + 516 * 256 + 256 * 300 + 516 * 512)
-            else:   # full cached tables (only the 333 relation columns of the pair embedding are computed)
-                flops = 2.0 * (O * 2048 * 512 + O * (516 * 256 + 256 * 300 + 300 * 2335) + pairs * (1036 * 256 + 256 * 300 + 300 * 333))
-            ach = flops / secs
-            out["roofline"] = {"kernel": "linear_act_kernel (all GEMM launches of one step)", "bound": "mfma", "achieved": ach / 1e12,
-                               "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK, "traffic": None}
-        else:
-            N = args.objects
-            nbytes = args.batch * (4 * N * N + 16 * N)
-            ach = nbytes / (secs / max(launches, 1))
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK, "traffic": None}
+        out["roofline"] = dominant_roofline(args, model, dom, per_step)
         # the logic kernels' roofline stress and the host baseline belong to the single-GPU run; with more ranks the others would
         # only wait for rank 0 at the final barrier
         out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if (args.stress_preds > 0 and world == 1) else []
         attach_traffic(out, args)
         sample = args.cpu_sample if args.cpu_sample is not None else (64 if args.objects > 64 else 256)     # about 10 s of host work
+        sample = min(sample, args.batch)
         out["cpu_baseline"] = None
-        if sample > 0 and world == 1:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs[:sample], res, sample)
+        if sample > 0 and world == 1 and args.workload != "c4":
+            out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs, res, sample, args.parity_all)
         print(json.dumps(out))
-    if dist:
+        sys.stdout.flush()
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def dominant_roofline(args, model, dom, per_step):
+    O = args.batch * args.objects
+    pairs = args.batch * args.objects * (args.objects - 1)
+    launches, secs = per_step[dom]
+    if dom == "dfol_pair_ll_split_f32":
+        # The same algorithmic flops, executed on the bf16 matrix pipe as six piece products per fp32 product (three exact
+        # bf16 pieces per operand, fp32 accumulate: fp32 results, csrc/dfol_pair_split.hip).  `achieved` / `frac` follow the
+        # contract (ALGORITHMIC flops against the peak of the pipe that executes them); the pipe itself does 6x that work.
+        flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
+        ach = flops / secs
+        return {"kernel": "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)", "bound": "mfma",
+                "achieved": ach / 1e12, "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
+                "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
+                "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300),
+                "executed": {"mfma_flops_per_algorithmic_flop": 6, "achieved": 6 * ach / 1e12, "frac": 6 * ach / BF16_MFMA_PEAK},
+                "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": ach / F32_MFMA_PEAK}}
+    if dom in ("dfol_pair_ll_f32", "dfol_pair_ll_packed_f32"):
+        # reduced-form algorithmic flops per ordered pair: geometry term, 256->300 layer, and the
+        # K requested embedding columns (K = 1 relation per question in this workload)
+        flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
+        ach = flops / secs
+        return {"kernel": "pair_ll32b_kernel<19> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
+                "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
+                "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
+                "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}
+    if dom in ("dfol_linear_act_f32", "dfol_linear_act_split_f32"):
+        if getattr(model._oracle, "_needed_columns", False) and model._oracle.supports_needed_columns():
+            flops = 2.0 * O * (2048 * 512 + 516 * 256 + 256 * 300 + 516 * 512)
+        else:   # full cached tables (only the 333 relation columns of the pair embedding are computed)
+            flops = 2.0 * (O * 2048 * 512 + O * (516 * 256 + 256 * 300 + 300 * 2335) + pairs * (1036 * 256 + 256 * 300 + 300 * 333))
+        ach = flops / secs
+        peak = BF16_MFMA_PEAK if dom.endswith("split_f32") else F32_MFMA_PEAK
+        return {"kernel": "%s (all GEMM launches of one step)" % dom, "bound": "mfma", "achieved": ach / 1e12,
+                "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
+    N = args.objects
+    nbytes = args.batch * (4 * N * N + 16 * N)
+    ach = nbytes / (secs / max(launches, 1))
+    return {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": ach / HBM_PEAK, "traffic": None}
+
+
+def streamed_rate(args, step, pbs, td, share, device, batches=4):
+    """The same step with the object features of every batch arriving from PINNED host memory (the reference's pin_memory DataLoader,
+    data_pipeline.py:893-898): upload of batch i+1 on a copy stream, double-buffered, under the replay of batch i.  The boundary takes
+    device pointers, so this is the caller's side of it; `value` stays the resident-input rate, as the bench contract asks."""
+    pb = pbs[0]
+    feats = pb._object_features
+    host = [feats.detach().cpu().pin_memory() for _ in range(2)]
+    stage = [torch.empty_like(feats) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=device)
+    main_stream = torch.cuda.current_stream()
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        b = i & 1
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[b])              # the step that read stage[b] has finished
+            stage[b].copy_(host[b], non_blocking=True)
+            ready[b].record(copy_stream)
+
+    def run(n):
+        for b in range(2):
+            consumed[b].record(main_stream)
+        upload(0)
+        for i in range(n):
+            b = i & 1
+            if i + 1 < n:
+                upload(i + 1)
+            main_stream.wait_event(ready[b])
+            feats.copy_(stage[b])                            # device-to-device into the tensor the captured graph reads (0.21 GB at 8 TB/s)
+            consumed[b].record(main_stream)
+            step()
+
+    with torch.no_grad():
+        run(2)
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = max(4, args.steps)
+        run(n)
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if td is not None:
+        t = torch.tensor([dt], device="cpu" if share else device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    nbytes = feats.numel() * 4
+    return {"questions_per_s": args.batch * n / dt, "ms_per_step": dt / n * 1e3, "h2d_bytes_per_step": nbytes,
+            "h2d_GBps": nbytes * n / dt / 1e9, "how": "pinned host -> device on a copy stream, double-buffered, overlapped with the step"}
+
+
+def train_main(args, rank, world, device, td, share):
+    """One train step = zero grads -> forward (is_training) -> loss / B_global -> backward -> ONE all-reduce of the flat fp32 gradient
+    bucket (RCCL) -> clip_grad_norm_ -> Adam, on a resident batch of `--batch` questions per GPU (BASELINE configs[3]'s step)."""
+    from dfol_vqa_amd import _lib as L
+    from dfol_vqa_amd import parallel, training
+    model, ontology, paths, names = build_model(args, device, train=True)
+    group = None
+    if td is not None:
+        group = td.group.WORLD
+        parallel.broadcast_parameters(model, 0, group)
+    _, pbs = build_batch(args, rank, ontology, names, device)
+    if args.calibrator:                                      # the LSTM inputs need token embeddings (random here, GloVe in the reference)
+        voc = list(ontology._vocabulary["idx_to_arg"])
+        g = torch.Generator().manual_seed(5)
+        emb = (torch.randn(len(voc), 300, generator=g) * 0.1).to(device)
+        for pb in pbs:
+            pb._meta_data = {"index": {t: i for i, t in enumerate(voc)}, "embedding": emb}
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    bucket = parallel.GradBucket(params)
+    gb = args.batch * world
+    step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket)
+
+    def barrier():
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(args.warmup):
+        loss, _ = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    equal = True
+    if td is not None:
+        t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dg = parallel.parameters_digest(model).to("cpu" if share else device)
+        both = [torch.zeros_like(dg) for _ in range(world)]
+        td.all_gather(both, dg)
+        equal = all(torch.equal(both[0], b) for b in both)
+        lt = torch.tensor([loss], device="cpu" if share else device, dtype=torch.float64)
+        td.all_reduce(lt)
+        loss = float(lt.item())
+    if rank == 0:
+        L.enable_kernel_timing(list(L.SIGNATURES))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        timing = L.disable_kernel_timing()
+        per_step = {k: (n / 2.0, t / 2.0) for k, (n, t) in timing.items() if n}
+        out = {"metric": "training questions/sec (GQA programs, N=%s objects; forward + backward + all-reduce + clip + Adam)"
+                         % (args.objects if not args.ragged else "U{%d..%d}" % (args.ragged, args.objects)),
+               "value": gb * args.steps / elapsed, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[3]'s step on synthetic scenes: select->filter->relate->exist, BCE loss, %s phase, "
+                                      "%d questions/GPU/step" % ("calibrator (cur6-7)" if args.calibrator else "oracle (cur1-5)", args.batch),
+                          "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
+                          "collective": "one all-reduce(sum) of the flat fp32 bucket per step (%s)" % ("gloo, shared GPU" if share else "RCCL")},
+               "loss": loss, "replicas_equal": bool(equal), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
+               "kernel_ms_per_step": {k: round(v[1] * 1e3, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][1])},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if td is not None:
         td.barrier()
         td.destroy_process_group()
 
@@ -248,9 +470,10 @@ def attach_traffic(out, args):
         out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
     P = args.stress_preds
     for k in out["kernels"]:
+        plain = "predicates)" not in k["kernel"] and "MB of blocks" not in k["kernel"]      # the rows the committed counter passes cover
         pref = "relate_one_fwd_kernel" if k["kernel"].startswith("relate_one") else "relate_fwd_kernel" if k["kernel"].startswith("relate_fwd") \
             else "filter_fwd_kernel"
-        k["traffic"] = total(pref, (P // 4) * 256 if "relate" in pref else P * 64) if P == 65536 else None
+        k["traffic"] = total(pref, (P // 4) * 256 if "relate" in pref else P * 64) if (P == 65536 and plain) else None
 
 
 def stress_kernels(L, device, P, N):
@@ -290,32 +513,64 @@ def stress_kernels(L, device, P, N):
     res.append(dict(r, kernel="relate_fwd (generic cell, one posterior wanted)", bytes_per_predicate=4 * N * N + 12 * N))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, diag_absent=True), P * (4 * N * N + 16 * N))
     res.append(dict(r, kernel="relate_fwd (both posteriors, RelateBatch API)", bytes_per_predicate=4 * N * N + 16 * N))
-    ll = tile[:, 0, :].contiguous()
+    # the other predicate kinds (negated / FOR_ALL): transcendental-poor forms with a clamping fallback (csrc/dfol_logic.hip)
+    zeros, negs = torch.zeros(P, device=device), torch.ones(P, dtype=torch.uint8, device=device)
+    r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones, negs), P * (4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_one_fwd (negated EXISTS predicates)", bytes_per_predicate=4 * N * N + 12 * N))
+    r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, zeros), P * (4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_one_fwd (FOR_ALL predicates)", bytes_per_predicate=4 * N * N + 12 * N))
+    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, negs, diag_absent=True), P * (4 * N * N + 16 * N))
+    res.append(dict(r, kernel="relate_fwd (both posteriors, negated EXISTS predicates)", bytes_per_predicate=4 * N * N + 16 * N))
+    r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, zeros, zeros, diag_absent=True), P * (4 * N * N + 16 * N))
+    res.append(dict(r, kernel="relate_fwd (both posteriors, FOR_ALL predicates)", bytes_per_predicate=4 * N * N + 16 * N))
     del tile
-    r = timed("dfol_filter_fwd_f32", lambda: L.filter_fwd(prior, ll, pq, n_obj), P * 12 * N)
-    res.append(dict(r, kernel="filter_fwd", bytes_per_predicate=12 * N))
+    # Filter / quantify on HBM-sized inputs: 65 536 predicates are 79 MB of blocks, which sit in the 256 MiB Infinity Cache
+    PF = max(P, 1 << 19)
+    llf = torch.log(torch.rand(PF, NS, device=device, generator=g).clamp_min(1e-5))
+    prf = torch.log(torch.rand(PF, NS, device=device, generator=g).clamp_min(1e-3)) * 0.3
+    pqf = torch.arange(PF, dtype=torch.int32, device=device)
+    nof = torch.full((PF,), N, dtype=torch.int32, device=device)
+    r = timed("dfol_filter_fwd_f32", lambda: L.filter_fwd(prf, llf, pqf, nof), PF * 12 * N)
+    res.append(dict(r, kernel="filter_fwd (%.0f MB of blocks)" % (PF * 12 * N / 1e6), bytes_per_predicate=12 * N, predicates=PF))
+    del llf
+    PQ = max(P, 1 << 21)
+    prq = torch.log(torch.rand(PQ, NS, device=device, generator=g).clamp_min(1e-3)) * 0.3
+    pqq = torch.arange(PQ, dtype=torch.int32, device=device)
+    noq = torch.full((PQ,), N, dtype=torch.int32, device=device)
+    onq = torch.ones(PQ, device=device)
+    r = timed("dfol_quantify_fwd_f32", lambda: L.quantify_fwd(prq, onq, pqq, noq), PQ * (4 * N + 4))
+    res.append(dict(r, kernel="quantify_fwd (%.0f MB of blocks)" % (PQ * (4 * N + 4) / 1e6), bytes_per_predicate=4 * N + 4, predicates=PQ))
     return res
 
 
-def cpu_baseline(model, paths, questions, gpu_result, sample):
+def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True):
     """The CPU oracle (numpy port of the reference's flat-layout algorithm, full-size tables) on a bounded sample of
-    the same workload, timed on this host; its log-probabilities double as an in-run parity check."""
+    the same workload, timed on this host; its log-probabilities double as an in-run parity check.  With `parity_all` the
+    rest of the batch goes through the oracle too (untimed, at the faster ProgramBatch size), so parity covers every question."""
     from oracle import dfol_oracle as orc
     ont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
     weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
-    scenes = [q["scene"] for q in questions]
+    head = questions[:sample]
     best = None
     for pb_size in (1, 4):                                  # the reference's cost is super-linear in the ProgramBatch size
         chunks = max(1, -(-sample // pb_size))
         t0 = time.perf_counter()
-        r = orc.run_questions(ont, questions, scenes, np.float32, split=chunks, weights=weights)
+        r = orc.run_questions(ont, head, [q["scene"] for q in head], np.float32, split=chunks, weights=weights)
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, r, pb_size)
     dt, r, split = best
-    lp_gpu = gpu_result["log_probability"][:sample].detach().cpu().numpy()
-    lp_cpu = r["log_probability"]
-    agree = sum(1 for a, b in zip(gpu_result["answer"][:sample], r["answer"]) if a == b)
+    lp_cpu, ans_cpu = [r["log_probability"]], list(r["answer"])
+    checked = sample
+    if parity_all and len(questions) > sample:
+        rest = questions[sample:]
+        r2 = orc.run_questions(ont, rest, [q["scene"] for q in rest], np.float32, split=max(1, -(-len(rest) // split)), weights=weights)
+        lp_cpu.append(r2["log_probability"])
+        ans_cpu += list(r2["answer"])
+        checked = len(questions)
+    lp_cpu = np.concatenate(lp_cpu)
+    lp_gpu = gpu_result["log_probability"][:checked].detach().cpu().numpy()
+    agree = sum(1 for a, b in zip(gpu_result["answer"][:checked], ans_cpu) if a == b)
     try:                                                    # threads numpy's BLAS actually runs the MLP layers on
         from threadpoolctl import threadpool_info
         cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])
@@ -323,10 +578,25 @@ def cpu_baseline(model, paths, questions, gpu_result, sample):
         cores = os.cpu_count()
     base = {"value": sample / dt, "unit": "questions/s", "cores": cores, "kind": "port",
             "sample": "%d questions of the same workload (N=%d), numpy fp32 oracle incl. full [pairs,2335] tables, "
-                      "ProgramBatch size %d, %.1f s" % (sample, questions[0]["scene"]["n"], split, dt)}
-    parity = {"max_abs_dp": float(np.abs(np.exp(lp_gpu) - np.exp(lp_cpu)).max()), "max_abs_dlp": float(np.abs(lp_gpu - lp_cpu).max()),
-              "answers_agree": "%d/%d" % (agree, sample)}
+                      "ProgramBatch size %d, %.1f s" % (sample, questions[0]["scene"]["n"], split, dt),
+            "vs_reference": reference_ratio_note()}
+    well = lp_cpu >= -5.0
+    parity = {"questions_checked": checked, "max_abs_dp": float(np.abs(np.exp(lp_gpu) - np.exp(lp_cpu)).max()),
+              "max_abs_dlp": float(np.abs(lp_gpu - lp_cpu).max()),
+              "max_abs_dlp_where_lp_ge_-5": float(np.abs(lp_gpu - lp_cpu)[well].max()) if well.any() else None,
+              "answers_agree": "%d/%d" % (agree, checked)}
     return base, parity
+
+
+def reference_ratio_note():
+    """How this port's wall time relates to the reference's own Python on identical inputs (measured in the build container by
+    tools/time_reference.py, recorded in profiles/reference_timing.json; the reference itself never travels to the GPU box)."""
+    path = os.path.join(ROOT, "profiles", "reference_timing.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return t.get("summary")
 
 
 if __name__ == "__main__":

@@ -48,11 +48,14 @@ SIGNATURES = {
     "dfol_linear_act_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_box_positions_f32": [_p, _i64, _i32, _i32, _p, _i64, _i32, _p],
     "dfol_pair_features_f32": [_p, _i64, _i32, _p, _p, _i32, _i32, _p, _i64, _p],
-    "dfol_filter_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p, _p],
+    "dfol_reduce_by_question_f32": [_p, _p, _p, _i32, _i32, _i32, _p, _p],
+    "dfol_filter_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
     "dfol_relate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
+    "dfol_linear_wgrad_f32": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p],
+    "dfol_attr_ll_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p, _p],
     "dfol_quantify_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p],
-    "dfol_attr_gather_bwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _i64, _p],
-    "dfol_rel_gather_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
+    "dfol_attr_gather_bwd_f32": [_p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
+    "dfol_rel_gather_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _i64, _p],
     "dfol_option_normalize_bwd_f32": [_p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
     "dfol_modulate_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_lstm_cell_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p],
@@ -87,6 +90,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.dfol_last_error.restype = ctypes.c_char_p
     lib.dfol_abi_version.restype = ctypes.c_int
+    lib.dfol_linear_wgrad_slabs.argtypes = [_i64, _i32, _i32]
+    lib.dfol_linear_wgrad_slabs.restype = ctypes.c_int
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -148,6 +153,37 @@ def call(name, *args):
 
 
 F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
+
+
+# ---- keep-alive registry for captured graphs ---------------------------------------------------------------------------------
+# A captured HIP graph bakes in the raw device addresses of every tensor its launches read.  Several of those tensors are owned only
+# by evictable caches (host_util's upload cache, the geometry caches, the packed weight images, lowered token arrays); once an
+# eviction frees one, the allocator recycles the memory and a replay would silently read unrelated data.  While a capture runs,
+# every cache hands what it returns to keep_alive(), and the GraphedForward object holds those references for as long as it lives.
+_KEEP = None
+
+
+def keep_alive(obj):
+    if _KEEP is not None:
+        _KEEP.append(obj)
+    return obj
+
+
+class keeping(object):
+    """Context manager: collect into `sink` everything the caches hand out while it is active."""
+
+    def __init__(self, sink):
+        self._sink = sink
+
+    def __enter__(self):
+        global _KEEP
+        self._outer, _KEEP = _KEEP, self._sink
+        return self._sink
+
+    def __exit__(self, *exc):
+        global _KEEP
+        _KEEP = self._outer
+        return False
 
 
 # ---- thin typed wrappers (tensor in / tensor out), one per entry point -------------------------------
@@ -293,33 +329,61 @@ _SPLIT_W_CACHE = {}                    # (data_ptr, version, shape, stride) -> (
 SPLIT_MIN_FLOPS = 2.0e8               # below this the fp32 kernel's single launch is as fast
 
 
-def linear_pack_w_split(weight):
+def linear_pack_w_split(weight, transpose=False):
     """The bf16x3 image of a Linear weight [N, K] for dfol_linear_act_split_f32, cached per weight version (the cache holds the
     weight tensor, so its address cannot be recycled while the entry lives).  The version counter is what optimizers, load_state_dict
-    and nn.init bump; writes through `.data` do not - call `_SPLIT_W_CACHE.clear()` after such a write."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0))
+    and nn.init bump; writes through `.data` do not - call `_SPLIT_W_CACHE.clear()` after such a write.
+    transpose=True packs weight^T (the operand of the backward product g @ W) under the ORIGINAL parameter's key, so a train step
+    finds it by the parameter's version instead of inserting one dead entry per temporary transposed copy."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose))
     hit = _SPLIT_W_CACHE.get(key)
     if hit is None:
-        N, K = weight.shape
+        src = weight.detach().t().contiguous() if transpose else weight
+        N, K = src.shape
         out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 24576 // 2, dtype=torch.bfloat16, device=weight.device)
-        call("dfol_linear_pack_w_bf16x3", weight.data_ptr(), weight.stride(0), N, K, _ptr(out, torch.bfloat16), _stream())
-        for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0]]:      # an older version of the same parameter (optimizer step)
+        call("dfol_linear_pack_w_bf16x3", src.data_ptr(), src.stride(0), N, K, _ptr(out, torch.bfloat16), _stream())
+        for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0] and k[4] == key[4]]:      # an older version of the same parameter
             del _SPLIT_W_CACHE[stale]
         if len(_SPLIT_W_CACHE) >= 64:
             _SPLIT_W_CACHE.pop(next(iter(_SPLIT_W_CACHE)))
         hit = _SPLIT_W_CACHE[key] = (weight, out)
-    return hit[1]
+    return keep_alive(hit)[1]
 
 
-def linear_act_split(x, weight, bias, act, out=None):
-    """y = act(x @ weight.T + bias) on the bf16 matrix pipes with exact three-way operand split: fp32 results."""
+def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
+    """y = act(x @ weight.T + bias) on the bf16 matrix pipes with exact three-way operand split: fp32 results.
+    transpose_w=True: y = act(x @ weight + bias) (weight [K, N])."""
     M, K = x.shape
-    N = weight.shape[0]
+    N = weight.shape[1] if transpose_w else weight.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
-    call("dfol_linear_act_split_f32", x.data_ptr(), x.stride(0), _ptr(linear_pack_w_split(weight), torch.bfloat16), _ptr(bias, F32, True),
-         out.data_ptr(), out.stride(0), M, N, K, act, _stream())
+    call("dfol_linear_act_split_f32", x.data_ptr(), x.stride(0), _ptr(linear_pack_w_split(weight, transpose_w), torch.bfloat16),
+         _ptr(bias, F32, True), out.data_ptr(), out.stride(0), M, N, K, act, _stream())
     return out
+
+
+def linear_wgrad(dy, x):
+    """dW [N, K] = dy^T x for dy [M, N], x [M, K] (fp32, unit column stride): exact-fp32 matrix pipe, deterministic."""
+    M, N = dy.shape
+    K = x.shape[1]
+    for t in (dy, x):
+        if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
+            raise DfolError("linear_wgrad needs fp32 GPU matrices with unit column stride")
+    lib = load()
+    slabs = lib.dfol_linear_wgrad_slabs(M, N, K)
+    ws = torch.empty(slabs * ((N * K + 3) // 4 * 4), dtype=F32, device=dy.device)
+    dw = torch.empty(N, K, dtype=F32, device=dy.device)
+    call("dfol_linear_wgrad_f32", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _stream())
+    return dw
+
+
+def linear_gradx(dz, weight):
+    """dx = dz @ weight (dz [M, N], weight [N, K]): the input gradient of y = x W^T, on the same kernels as the forward."""
+    M, N = dz.shape
+    K = weight.shape[1]
+    if 2.0 * M * N * K >= SPLIT_MIN_FLOPS and N % 4 == 0 and dz.stride(0) % 2 == 0 and dz.data_ptr() % 8 == 0 and _dense_math() != "f32":
+        return linear_act_split(dz, weight, None, ACT_NONE, transpose_w=True)
+    return linear_act(dz, weight.detach().t().contiguous(), None, ACT_NONE)
 
 
 def _dense_math():
@@ -496,13 +560,21 @@ def pair_logit_bwd(dx, p2, e_rows, pred_off, need_bias=True):
     return dp2, de, dbe
 
 
-# ---- backward wrappers ----------------------------------------------------------------------------------
+# ---- backward wrappers (deterministic: no atomics; pred_q non-decreasing) --------------------------------------------
+def reduce_by_question(src, pred_q, n_obj, Q):
+    """out[q] = sum of src[p] over the predicates p of question q (src [P, NS] -> [Q, NS])."""
+    P, NS = src.shape
+    out = torch.empty(Q, NS, dtype=F32, device=src.device)
+    call("dfol_reduce_by_question_f32", _ptr(src, F32), _ptr(pred_q, I32), _ptr(n_obj, I32, True), P, Q, NS, _ptr(out), _stream())
+    return out
+
+
 def filter_bwd(g_out, ll, pred_q, n_obj, neg, active, Q, need_prior=True, need_ll=True):
     P, NS = ll.shape
-    g_prior = torch.zeros(Q, NS, dtype=F32, device=ll.device) if need_prior else None
+    g_prior = torch.empty(Q, NS, dtype=F32, device=ll.device) if need_prior else None
     g_ll = torch.empty(P, NS, dtype=F32, device=ll.device) if need_ll else None
     call("dfol_filter_bwd_f32", _ptr(g_out, F32), _ptr(ll, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), _ptr(neg, U8, True),
-         0 if neg is None else 1, _ptr(active, U8, True), P, NS, _ptr(g_prior, F32, True), _ptr(g_ll, F32, True), _stream())
+         0 if neg is None else 1, _ptr(active, U8, True), P, Q, NS, _ptr(g_prior, F32, True), _ptr(g_ll, F32, True), _stream())
     return g_prior, g_ll
 
 
@@ -510,14 +582,16 @@ def relate_bwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, act
                lone_forall_identity, need_prior=True, need_tile=True):
     P, NS = tile.shape[0], tile.shape[1]
     Q = prior_s.shape[0]
-    g_ps = torch.zeros(Q, NS, dtype=F32, device=tile.device) if need_prior else None
-    g_po = torch.zeros(Q, NS, dtype=F32, device=tile.device) if need_prior else None
+    pp_s = torch.empty(P, NS, dtype=F32, device=tile.device) if need_prior else None      # per predicate
+    pp_o = torch.empty(P, NS, dtype=F32, device=tile.device) if need_prior else None
     g_tile = torch.empty(P, NS, NS, dtype=F32, device=tile.device) if need_tile else None
     call("dfol_relate_bwd_f32", _ptr(prior_s, F32), _ptr(prior_o, F32), _ptr(tile, F32), _ptr(pred_q, I32), _ptr(n_obj, I32),
          _ptr(quant_s, F32), _ptr(quant_o, F32), _ptr(neg, U8, True), 0 if neg is None else 1, _ptr(active, U8, True),
          _ptr(g_post_s, F32, True), _ptr(g_post_o, F32, True), P, NS, orientation, 1 if lone_forall_identity else 0,
-         _ptr(g_ps, F32, True), _ptr(g_po, F32, True), _ptr(g_tile, F32, True), _stream())
-    return g_ps, g_po, g_tile
+         _ptr(pp_s, F32, True), _ptr(pp_o, F32, True), _ptr(g_tile, F32, True), _stream())
+    if need_prior:
+        return reduce_by_question(pp_s, pred_q, None, Q), reduce_by_question(pp_o, pred_q, None, Q), g_tile
+    return None, None, g_tile
 
 
 def quantify_bwd(g_lp, att, quant, pred_q, n_obj):
@@ -530,18 +604,35 @@ def quantify_bwd(g_lp, att, quant, pred_q, n_obj):
 
 def attr_gather_bwd(g_ll, obj_off, pred_q, pred_col, table_shape):
     P, NS = g_ll.shape
+    Q = obj_off.numel() - 1
     g_table = torch.zeros(table_shape, dtype=F32, device=g_ll.device)
-    call("dfol_attr_gather_bwd_f32", _ptr(g_ll, F32), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32), P, NS, _ptr(g_table),
+    call("dfol_attr_gather_bwd_f32", _ptr(g_ll, F32), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32), P, Q, NS, _ptr(g_table),
          g_table.stride(0), _stream())
     return g_table
 
 
 def rel_gather_bwd(g_tile, pair_off, n_obj, pred_q, pred_col, orientation, table_shape):
     P, NS = g_tile.shape[0], g_tile.shape[1]
+    Q = n_obj.numel()
     g_table = torch.zeros(table_shape, dtype=F32, device=g_tile.device)
     call("dfol_rel_gather_bwd_f32", _ptr(g_tile, F32), _ptr(pair_off, I64), _ptr(n_obj, I32), _ptr(pred_q, I32), _ptr(pred_col, I32),
-         P, NS, orientation, _ptr(g_table), g_table.stride(0), _stream())
+         P, Q, NS, orientation, _ptr(g_table), g_table.stride(0), _stream())
     return g_table
+
+
+def attr_ll_bwd(g, hidden, emb_w, emb_b, obj_off, pred_q, pred_col, need_hidden=True, need_emb=True, need_bias=True):
+    """-> (d_hidden [O, H], dE [P, H] per predicate, db [P] per predicate); deterministic (no atomics)."""
+    P, NS = g.shape
+    O, H = hidden.shape
+    Q = obj_off.numel() - 1
+    gx = torch.empty(P, NS, dtype=F32, device=g.device)
+    d_hidden = torch.empty(O, H, dtype=F32, device=g.device) if need_hidden else None
+    dE = torch.empty(P, H, dtype=F32, device=g.device) if need_emb else None
+    db = torch.empty(P, dtype=F32, device=g.device) if need_bias else None
+    call("dfol_attr_ll_bwd_f32", _ptr(g, F32), hidden.data_ptr(), hidden.stride(0), H, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True),
+         _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32), P, Q, NS, _ptr(gx), _ptr(d_hidden, F32, True), H,
+         _ptr(dE, F32, True), H, _ptr(db, F32, True), _stream())
+    return d_hidden, dE, db
 
 
 def option_normalize_bwd(g_y, y, seg_off, pred_q, n_obj, NS):

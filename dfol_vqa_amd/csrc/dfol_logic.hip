@@ -188,10 +188,14 @@ extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const i
 // Nothing needs masking: the diagonal's E is e^-30 (factor rounds to exactly 1), padding rows/columns get P = 0.
 template <int LPR> struct RelateUnroll { static constexpr int value = LPR == 64 ? 4 : LPR == 32 ? 5 : LPR == 16 ? 3 : LPR == 8 ? 2 : 1; };
 
-template <int LPR, bool WR, bool WC>
+// MASK = true is the form for tiles whose diagonal is not known to be absent and for NEGATED predicates (alpha_n = 1): the factor
+// is built from a = alpha_n + (1 - 2 alpha_n) E (= E, or 1 - E: e^{l'} after :212-213; its inner clamp at eps cannot change a
+// factor, a * P vanishes against 1 either way) and diagonal factors are replaced by 1 (:112).
+template <int LPR, bool WR, bool WC, bool MASK>
 __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp, const float* __restrict__ pR,
                                                    const float* __restrict__ pC, int NS, int n, int lane, float* __restrict__ rsum,
-                                                   float* __restrict__ oR, float* __restrict__ oC) {
+                                                   float* __restrict__ oR, float* __restrict__ oC, float alpha_n = 0.f) {
+    const float cn = 1.f - 2.f * alpha_n;
     constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
     constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
     const int cg = lane % LPR, rs = lane / LPR, c0 = cg * 4, cl = min(c0, NS - 4);
@@ -225,12 +229,26 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
             float E[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) E[j] = __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f));    // :194 (the product is canonical: no NaN-quieting op)
+            const int dg = r0 + u * RPI + rs - c0;             // column j of this lane is the diagonal iff dg == j
+            if (MASK) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) E[j] = fmaf(cn, E[j], alpha_n);
+            }
             if (WC) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cprod[j] *= fmaf(-E[j], Pr[u], 1.f);
+                for (int j = 0; j < 4; ++j) {
+                    const float f = fmaf(-E[j], Pr[u], 1.f);
+                    cprod[j] *= (MASK && dg == j) ? 1.f : f;
+                }
             }
             if (WR) {
-                const float rp = (fmaf(-E[0], Pc[0], 1.f) * fmaf(-E[1], Pc[1], 1.f)) * (fmaf(-E[2], Pc[2], 1.f) * fmaf(-E[3], Pc[3], 1.f));
+                float f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = fmaf(-E[j], Pc[j], 1.f);
+                    if (MASK) f[j] = dg == j ? 1.f : f[j];
+                }
+                const float rp = (f[0] * f[1]) * (f[2] * f[3]);
                 const float part = dfol_group_sum<LPR>(__builtin_amdgcn_logf(rp));
                 const int r = r0 + u * RPI + rs;
                 if (cg == LPR - 1 && r < n) rsum[r] = part;
@@ -322,12 +340,19 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     const bool idR = identity_forall && qR == 0.f, idC = identity_forall && qC == 0.f;
 
     const float* tp = tile + (int64_t)p * NS * NS;
-    if ((flags & DFOL_RELATE_DIAG_ABSENT) && alpha_n == 0.f && qR == 1.f && qC == 1.f) {
+    if (qR == 1.f && qC == 1.f) {                        // EXISTS / EXISTS: the product path (see relate_exists_fast)
         float* rsum = row_sum[wave_in_block];
-        const bool ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
-                        : wantR      ? relate_exists_fast<LPR, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
-                        : wantC      ? relate_exists_fast<LPR, false, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
-                                     : true;
+        bool ok;
+        if ((flags & DFOL_RELATE_DIAG_ABSENT) && alpha_n == 0.f)
+            ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
+                 : wantR      ? relate_exists_fast<LPR, true, false, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
+                 : wantC      ? relate_exists_fast<LPR, false, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
+                              : true;
+        else                                             // negated predicates, and tiles whose diagonal must be masked
+            ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
+                 : wantR      ? relate_exists_fast<LPR, true, false, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
+                 : wantC      ? relate_exists_fast<LPR, false, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
+                              : true;
         if (ok) return;
         __builtin_amdgcn_wave_barrier();
     }
@@ -339,7 +364,54 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     }
     float col_acc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int r0 = 0; r0 < n; r0 += RPI) {
+    // FOR_ALL / FOR_ALL, un-negated: log(max(e^u, eps)) = u unless u is below log eps, so both aggregations are plain sums of
+    // l' + prior with NO transcendental; the smallest term is tracked and a predicate at the clamp goes through the general loop.
+    bool sums_done = false;
+    if (alpha_n == 0.f && qR == 0.f && qC == 0.f) {
+        float chk = 0.f, prmax = -1.f;
+        for (int r0 = 0; r0 < n; r0 += RPI) {
+            const int r = r0 + rs;
+            const bool live = r < n && col_live;
+            float l[4] = {0.f, 0.f, 0.f, 0.f};
+            float pr = 0.f;
+            if (live) {
+                const float4 t = *reinterpret_cast<const float4*>(tp + (int64_t)r * NS + c0);
+                l[0] = t.x; l[1] = t.y; l[2] = t.z; l[3] = t.w;
+                pr = pR[r];
+            }
+            prmax = fmaxf(prmax, pr);
+            float row_part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                const bool keep = live && c < n && c != r;
+                const float v = fminf(l[j], 0.f);
+                if (wantR) {
+                    const float u = v + pc[j];
+                    chk = fminf(chk, keep ? u : 0.f);
+                    row_part += keep ? u : 0.f;
+                }
+                if (wantC) {
+                    const float u = v + pr;
+                    chk = fminf(chk, keep ? u : 0.f);
+                    col_acc[j] += keep ? u : 0.f;
+                }
+                if (c < n) prmax = fmaxf(prmax, pc[j]);
+            }
+            if (wantR) {
+                row_part = dfol_group_sum<LPR>(row_part);
+                if (cg == LPR - 1 && r < n) row_sum[wave_in_block][r] = row_part;
+            }
+        }
+        sums_done = !__any(chk < -46.0f || prmax > 0.f);             // log(1e-20) = -46.05
+        if (!sums_done) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) col_acc[j] = 0.f;
+        }
+    }
+
+    for (int r0 = sums_done ? n : 0; r0 < n; r0 += RPI) {
         const int r = r0 + rs;
         const bool live = r < n && col_live;
         float l[4] = {0.f, 0.f, 0.f, 0.f};
@@ -525,6 +597,75 @@ __device__ __forceinline__ float relate_one_exists_fast(const float* __restrict_
     return pmax;
 }
 
+// Fast forms of the other three predicate kinds (negated and / or FOR_ALL), same idea: no transcendental pair per element.
+//   negated EXISTS :  sum_r log(1 - (1 - E) Pr)        -> factor fma(-(1 - E), Pr, 1), diagonal masked (its 1 - E is 1, not 0)
+//   FOR_ALL        :  sum_r log(max(e^(l' + prev), eps)) = sum_r (l' + prev[r]) as long as no term is below log eps:
+//       un-negated :  l' = min(l, 0): NO transcendental at all; the smallest l' + prev is tracked and a value at the clamp
+//                     sends the predicate to the general code;
+//       negated    :  l' = log(1 - E): the sum over rows is the log of a product of (1 - E) factors (each 0 or >= 2^-24) plus
+//                     the sum of the priors; the smallest (1 - E) Pr is tracked against eps.
+// (The inner clamp of the negation form, log(max(a, eps)), cannot change a factor: a < eps makes a * Pr vanish against 1 either
+// way, and for FOR_ALL it is caught by the tracked minimum.)  Returns true when a clamp may have fired: the caller then redoes
+// the predicate with relate_one_rows, which reproduces the reference's clamped value.
+template <int LPR, bool NEG, bool FORALL>
+__device__ __forceinline__ bool relate_one_masked_fast(const float* __restrict__ tp, const float* __restrict__ pv, int NS, int n,
+                                                       int cl, int c0, int rs, float (&acc)[4]) {
+    constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
+    constexpr float L2E = 1.44269504088896340736f;
+    float prmax = -1.f, chk = (FORALL && !NEG) ? 0.f : 1.f, psum = 0.f;
+    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
+        float4 t[UNR];
+        float Pr[UNR], pr2[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
+            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + cl);
+            const float pr = pv[rc];
+            prmax = fmaxf(prmax, pr);
+            pr2[u] = pr * L2E;
+            Pr[u] = (FORALL && !NEG) ? 0.f : (r < n ? __builtin_amdgcn_exp2f(pr2[u]) : 0.f);
+            if (FORALL && NEG) psum += r < n ? pr2[u] : 0.f;
+        }
+        float prod[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u * RPI + rs;
+            const int d = r - c0;                            // column j of this lane is the diagonal iff d == j
+            const bool row_ok = r < n;
+            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool keep = row_ok && d != j;
+                const float v2 = fminf(l[j] * L2E, 0.f);     // :194, log2 domain
+                if (FORALL && !NEG) {
+                    const float u2 = v2 + pr2[u];
+                    chk = fminf(chk, keep ? u2 : 0.f);
+                    acc[j] += keep ? u2 : 0.f;
+                } else {
+                    const float a = 1.f - __builtin_amdgcn_exp2f(v2);          // e^{l'} of a negated predicate (:212-213)
+                    if (FORALL) {
+                        chk = fminf(chk, keep ? a * Pr[u] : 1.f);
+                        prod[j] *= keep ? a : 1.f;
+                    } else {
+                        prod[j] *= (d != j) ? fmaf(-a, Pr[u], 1.f) : 1.f;      // padding rows carry Pr = 0
+                    }
+                }
+            }
+        }
+        if (!(FORALL && !NEG)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += __builtin_amdgcn_logf(prod[j]);
+        }
+    }
+    if (FORALL && NEG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += psum;          // every row's prior once; the diagonal row's is taken off by the caller
+    }
+    bool bad = prmax > 0.f;
+    if (FORALL) bad |= NEG ? chk < 1.2e-20f : chk < -66.3f;   // eps = 1e-20, log2(eps) = -66.44
+    return bad;
+}
+
 template <int LPR, int UNR>
 __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
     const float* __restrict__ x_att, const float* __restrict__ prev_att, const float* __restrict__ tile,
@@ -575,6 +716,37 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = 0.f;            // a factor was clamped: redo with the clamping code below
+    } else if (qf == 1.f || qf == 0.f) {
+        const bool forall = qf == 0.f;
+        bool bad = forall ? (negated ? relate_one_masked_fast<LPR, true, true>(tp, pv, NS, n, cl, c0, rs, acc)
+                                     : relate_one_masked_fast<LPR, false, true>(tp, pv, NS, n, cl, c0, rs, acc))
+                          : relate_one_masked_fast<LPR, true, false>(tp, pv, NS, n, cl, c0, rs, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+            bad |= (c0 + j < n) && !(acc[j] >= -3.0e38f);
+        }
+        if (!__any(bad)) {
+            if (rs == 0 && c0 < NS) {
+                constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+                const float4 xa = *reinterpret_cast<const float4*>(x_att + (int64_t)p * NS + c0);
+                const float4 pd = *reinterpret_cast<const float4*>(pv + c0);
+                const float xv[4] = {xa.x, xa.y, xa.z, xa.w}, pdv[4] = {pd.x, pd.y, pd.z, pd.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s2 = acc[j];
+                    if (forall && negated) s2 -= pdv[j] * L2E;                 // the diagonal row's prior is not part of the sum
+                    const float sv = s2 * LN2;
+                    o[j] = (c0 + j < n) ? xv[j] + (ident ? sv : dfol_pnot(sv, qf, kf)) : 0.f;
+                }
+                *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = 0.f;
     }
     if (mask) {
         for (int r0 = 0; r0 < n_full; r0 += STEP)

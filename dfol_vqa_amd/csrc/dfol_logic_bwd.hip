@@ -24,12 +24,54 @@ __device__ __forceinline__ float dfol_prep(float ll, int any_neg, float alpha_n,
     return v;
 }
 
+// Predicates of question q: [p0, p1) by binary search in the non-decreasing pred_q (the predicates of a question are contiguous,
+// as every operator builds them).  Every cross-predicate sum of the backward pass is taken by the OWNER of the output element,
+// walking this range in order: no atomics, bit-identical from run to run.
+__device__ __forceinline__ void dfol_pred_range(const int32_t* __restrict__ pred_q, int P, int q, int& p0, int& p1) {
+    int lo = 0, hi = P;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pred_q[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    p0 = lo;
+    hi = P;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pred_q[mid] <= q) lo = mid + 1; else hi = mid;
+    }
+    p1 = lo;
+}
+
+// out[q, c] = sum over the predicates p of question q of src[p, c]  (c < n_obj[q]; padding columns 0)
+__global__ void reduce_by_question_kernel(const float* __restrict__ src, const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj,
+                                          int P, int NS, float* __restrict__ out) {
+    const int q = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= NS) return;
+    int p0, p1;
+    dfol_pred_range(pred_q, P, q, p0, p1);
+    float acc = 0.f;
+    if (n_obj == nullptr || c < n_obj[q])
+        for (int p = p0; p < p1; ++p) acc += src[(int64_t)p * NS + c];
+    out[(int64_t)q * NS + c] = acc;
+}
+
+extern "C" int dfol_reduce_by_question_f32(const float* src, const int32_t* pred_q, const int32_t* n_obj, int32_t P, int32_t Q, int32_t NS,
+                                           float* out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && Q >= 0 && NS > 0, "reduce_by_question: bad sizes");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(out && (P == 0 || (src && pred_q)), "reduce_by_question: null pointer");
+    hipLaunchKernelGGL(reduce_by_question_kernel, dim3(Q, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, src, pred_q, n_obj, P, NS, out);
+    DFOL_LAUNCH_CHECK("reduce_by_question");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // filter:  out[p,o] = prior[q,o] + l'(ll[p,o])
 // ---------------------------------------------------------------------------------------------------
 __global__ void filter_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ ll, const int32_t* __restrict__ pred_q,
                                   const int32_t* __restrict__ n_obj, const uint8_t* __restrict__ neg, int any_neg,
-                                  const uint8_t* __restrict__ active, int NS, float* __restrict__ g_prior, float* __restrict__ g_ll) {
+                                  const uint8_t* __restrict__ active, int NS, float* __restrict__ g_ll) {
     const int p = blockIdx.x;
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= NS) return;
@@ -46,18 +88,22 @@ __global__ void filter_bwd_kernel(const float* __restrict__ g_out, const float* 
         }
         g_ll[i] = d;
     }
-    if (g_prior && c < n) atomicAdd(g_prior + (int64_t)q * NS + c, g);      // several predicates may share one question's prior
 }
 
 extern "C" int dfol_filter_bwd_f32(const float* g_out, const float* ll, const int32_t* pred_q, const int32_t* n_obj, const uint8_t* neg,
-                                   int32_t any_neg, const uint8_t* active, int32_t P, int32_t NS, float* g_prior, float* g_ll, void* stream) {
-    DFOL_REQUIRE(P >= 0 && NS > 0, "filter_bwd: bad sizes");
-    if (P == 0) return 0;
+                                   int32_t any_neg, const uint8_t* active, int32_t P, int32_t Q, int32_t NS, float* g_prior, float* g_ll,
+                                   void* stream) {
+    DFOL_REQUIRE(P >= 0 && Q >= 0 && NS > 0, "filter_bwd: bad sizes");
+    if (P == 0 && Q == 0) return 0;
     DFOL_REQUIRE(g_out && ll && pred_q && n_obj && (g_prior || g_ll), "filter_bwd: null pointer");
     DFOL_REQUIRE(!any_neg || neg, "filter_bwd: any_neg set but neg is NULL");
-    hipLaunchKernelGGL(filter_bwd_kernel, dim3(P, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, g_out, ll, pred_q, n_obj, neg,
-                       any_neg, active, NS, g_prior, g_ll);
-    DFOL_LAUNCH_CHECK("filter_bwd");
+    if (g_ll && P > 0) {
+        hipLaunchKernelGGL(filter_bwd_kernel, dim3(P, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, g_out, ll, pred_q, n_obj, neg,
+                           any_neg, active, NS, g_ll);
+        DFOL_LAUNCH_CHECK("filter_bwd");
+    }
+    // d out / d prior = 1 for active and inactive predicates alike: the prior's gradient is the sum of its predicates' g_out
+    if (g_prior) return dfol_reduce_by_question_f32(g_out, pred_q, n_obj, P, Q, NS, g_prior, stream);
     return 0;
 }
 
@@ -87,9 +133,9 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
     const float* gC = g_post_C ? g_post_C + (int64_t)p * NS : nullptr;
 
     if (active && !active[p]) {                            // posterior = prior: the gradient passes straight through
-        for (int c = lane; c < n; c += 64) {
-            if (g_prior_R && gR) atomicAdd(g_prior_R + (int64_t)q * NS + c, gR[c]);
-            if (g_prior_C && gC) atomicAdd(g_prior_C + (int64_t)q * NS + c, gC[c]);
+        for (int c = lane; c < NS; c += 64) {
+            if (g_prior_R) g_prior_R[(int64_t)p * NS + c] = (gR && c < n) ? gR[c] : 0.f;
+            if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = (gC && c < n) ? gC[c] : 0.f;
         }
         if (gt)
             for (int e = lane; e < NS * NS; e += 64) gt[e] = 0.f;
@@ -142,12 +188,16 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
                 dpr_part = g2;
             }
             if (gt && c < NS) gt[(int64_t)r * NS + c] = dl;
-            if (g_prior_R) {
+            if (g_prior_R) {                                   // row totals over the column chunks collect in LDS (sS is free by now)
                 dpr_part = dfol_wave_sum(dpr_part);
-                if (lane == 0 && r < n) atomicAdd(g_prior_R + (int64_t)q * NS + r, dpr_part + (c0 == 0 && gR ? gR[r] : 0.f));
+                if (lane == 0 && r < n) sS[w][r] = (c0 == 0 ? (gR ? gR[r] : 0.f) : sS[w][r]) + dpr_part;
             }
         }
-        if (g_prior_C && c < n) atomicAdd(g_prior_C + (int64_t)q * NS + c, dpc + (gC ? gC[c] : 0.f));
+        if (g_prior_C && c < NS) g_prior_C[(int64_t)p * NS + c] = c < n ? dpc + (gC ? gC[c] : 0.f) : 0.f;
+    }
+    if (g_prior_R) {
+        __builtin_amdgcn_wave_barrier();
+        for (int r = lane; r < NS; r += 64) g_prior_R[(int64_t)p * NS + r] = r < n ? sS[w][r] : 0.f;
     }
 }
 
@@ -200,52 +250,63 @@ extern "C" int dfol_quantify_bwd_f32(const float* g_lp, const float* att, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// gathers from the cached tables: scatter-add of the block gradients into the table gradients
+// gathers from the cached tables: the block gradients are added into the table gradients (no atomics)
 // ---------------------------------------------------------------------------------------------------
+// One thread owns one row of the table gradient (one object / one ordered pair) and walks the predicates of its image in order.
 __global__ void attr_gather_bwd_kernel(const float* __restrict__ g_ll, const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q,
-                                       const int32_t* __restrict__ pred_col, int NS, float* __restrict__ g_table, int64_t ld) {
-    const int p = blockIdx.x;
+                                       const int32_t* __restrict__ pred_col, int P, int NS, float* __restrict__ g_table, int64_t ld) {
+    const int q = blockIdx.x;
     const int o = blockIdx.y * blockDim.x + threadIdx.x;
-    const int q = pred_q[p], col = pred_col[p];
     const int first = obj_off[q], n = obj_off[q + 1] - first;
-    if (col < 0 || o >= n) return;
-    atomicAdd(g_table + (int64_t)(first + o) * ld + col, g_ll[(int64_t)p * NS + o]);
+    if (o >= n) return;
+    int p0, p1;
+    dfol_pred_range(pred_q, P, q, p0, p1);
+    float* row = g_table + (int64_t)(first + o) * ld;
+    for (int p = p0; p < p1; ++p) {
+        const int col = pred_col[p];
+        if (col >= 0) row[col] += g_ll[(int64_t)p * NS + o];
+    }
 }
 
 extern "C" int dfol_attr_gather_bwd_f32(const float* g_ll, const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P,
-                                        int32_t NS, float* g_table, int64_t ld_table, void* stream) {
-    DFOL_REQUIRE(P >= 0 && NS > 0, "attr_gather_bwd: bad sizes");
-    if (P == 0) return 0;
+                                        int32_t Q, int32_t NS, float* g_table, int64_t ld_table, void* stream) {
+    DFOL_REQUIRE(P >= 0 && Q >= 0 && NS > 0, "attr_gather_bwd: bad sizes");
+    if (P == 0 || Q == 0) return 0;
     DFOL_REQUIRE(g_ll && obj_off && pred_q && pred_col && g_table, "attr_gather_bwd: null pointer");
-    hipLaunchKernelGGL(attr_gather_bwd_kernel, dim3(P, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, g_ll, obj_off, pred_q, pred_col,
-                       NS, g_table, ld_table);
+    hipLaunchKernelGGL(attr_gather_bwd_kernel, dim3(Q, dfol_cdiv(NS, 64)), dim3(64), 0, (hipStream_t)stream, g_ll, obj_off, pred_q, pred_col,
+                       P, NS, g_table, ld_table);
     DFOL_LAUNCH_CHECK("attr_gather_bwd");
     return 0;
 }
 
 __global__ void rel_gather_bwd_kernel(const float* __restrict__ g_tile, const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
-                                      const int32_t* __restrict__ pred_q, const int32_t* __restrict__ pred_col, int NS, int transposed,
+                                      const int32_t* __restrict__ pred_q, const int32_t* __restrict__ pred_col, int P, int NS, int transposed,
                                       float* __restrict__ g_table, int64_t ld) {
-    const int p = blockIdx.x;
-    const int e = blockIdx.y * blockDim.x + threadIdx.x;
-    if (e >= NS * NS) return;
-    const int r = e / NS, c = e - r * NS;
-    const int q = pred_q[p], col = pred_col[p];
+    const int q = blockIdx.x;
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;        // (s, o) slot of the image
     const int n = n_obj[q];
-    const int s = transposed ? c : r, o = transposed ? r : c;
-    if (col < 0 || s >= n || o >= n || s == o) return;
+    if (e >= n * n) return;
+    const int s = e / n, o = e - s * n;
+    if (s == o) return;
+    int p0, p1;
+    dfol_pred_range(pred_q, P, q, p0, p1);
     const int64_t pair = pair_off[q] + (int64_t)s * (n - 1) + (o > s ? o - 1 : o);
-    atomicAdd(g_table + pair * ld + col, g_tile[(int64_t)p * NS * NS + e]);
+    float* row = g_table + pair * ld;
+    const int64_t at = transposed ? (int64_t)o * NS + s : (int64_t)s * NS + o;
+    for (int p = p0; p < p1; ++p) {
+        const int col = pred_col[p];
+        if (col >= 0) row[col] += g_tile[(int64_t)p * NS * NS + at];
+    }
 }
 
 extern "C" int dfol_rel_gather_bwd_f32(const float* g_tile, const int64_t* pair_off, const int32_t* n_obj, const int32_t* pred_q,
-                                       const int32_t* pred_col, int32_t P, int32_t NS, int32_t orientation, float* g_table, int64_t ld_table,
-                                       void* stream) {
-    DFOL_REQUIRE(P >= 0 && NS > 0 && (orientation == 0 || orientation == 1), "rel_gather_bwd: bad arguments");
-    if (P == 0) return 0;
+                                       const int32_t* pred_col, int32_t P, int32_t Q, int32_t NS, int32_t orientation, float* g_table,
+                                       int64_t ld_table, void* stream) {
+    DFOL_REQUIRE(P >= 0 && Q >= 0 && NS > 0 && (orientation == 0 || orientation == 1), "rel_gather_bwd: bad arguments");
+    if (P == 0 || Q == 0) return 0;
     DFOL_REQUIRE(g_tile && pair_off && n_obj && pred_q && pred_col && g_table, "rel_gather_bwd: null pointer");
-    hipLaunchKernelGGL(rel_gather_bwd_kernel, dim3(P, dfol_cdiv((int64_t)NS * NS, 256)), dim3(256), 0, (hipStream_t)stream, g_tile, pair_off,
-                       n_obj, pred_q, pred_col, NS, orientation, g_table, ld_table);
+    hipLaunchKernelGGL(rel_gather_bwd_kernel, dim3(Q, dfol_cdiv((int64_t)NS * NS, 256)), dim3(256), 0, (hipStream_t)stream, g_tile, pair_off,
+                       n_obj, pred_q, pred_col, P, NS, orientation, g_table, ld_table);
     DFOL_LAUNCH_CHECK("rel_gather_bwd");
     return 0;
 }
@@ -294,5 +355,124 @@ extern "C" int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, c
     hipLaunchKernelGGL(option_normalize_bwd_kernel, dim3(S, dfol_cdiv(elems, 128)), dim3(128), 0, (hipStream_t)stream, g_y, y, seg_off,
                        pred_q, n_obj, NS, rank, g_x);
     DFOL_LAUNCH_CHECK("option_normalize_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// needed-columns attribute likelihood, backward:  ll[p][o] = LogSigmoid(x),  x = hidden[o] . E[col_p] + be[col_p]
+// (forward: attr_ll_kernel in dfol_dense.hip; the reference back-propagates through Linear(300 -> 2335) + LogSigmoid over ALL
+// columns, gqa_interpreter_experiments.py:60-77).  Three small kernels, no atomics:
+//   gx[p][o]       = g[p][o] * sigmoid(-x)                                (one wavefront per four objects, as the forward)
+//   d hidden[o][:] = sum over the predicates p of o's image of gx[p][o] * E[col_p][:]        (owner: the object)
+//   dE[p][:]       = sum_o gx[p][o] * hidden[o][:],   db[p] = sum_o gx[p][o]                 (owner: the predicate; rows of equal
+//                    concept are combined by the caller in a fixed order)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attr_ll_bwd_gx_kernel(const float* __restrict__ g, const float* __restrict__ hidden, int64_t ld_h, int H,
+                                                             const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be,
+                                                             const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q,
+                                                             const int32_t* __restrict__ pred_col, int NS, float* __restrict__ gx) {
+    const int p = blockIdx.x;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o0 = blockIdx.y * 16 + 4 * wv;
+    const int q = pred_q[p], col = pred_col[p];
+    const int first = obj_off[q], n = obj_off[q + 1] - first;
+    float* out = gx + (int64_t)p * NS;
+    if (col < 0 || o0 >= n) {
+        if (lane < 4 && o0 + lane < NS) out[o0 + lane] = 0.f;
+        return;
+    }
+    float e[8];                                            // H <= 512
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (lane + 64 * j < H) ? E[(int64_t)col * ld_e + lane + 64 * j] : 0.f;
+    const float bias = be ? be[col] : 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int o = min(o0 + u, n - 1);
+        const float* h = hidden + (int64_t)(first + o) * ld_h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (lane + 64 * j < H) s[u] = fmaf(h[lane + 64 * j], e[j], s[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = dfol_group_sum<64>(s[u]);     // totals are valid in lanes 48..63
+    if (lane >= 60 && o0 + (lane - 60) < NS) {
+        const int u = lane - 60;
+        const float x = (u == 0 ? s[0] : u == 1 ? s[1] : u == 2 ? s[2] : s[3]) + bias;
+        out[o0 + u] = (o0 + u < n) ? g[(int64_t)p * NS + o0 + u] / (1.f + expf(x)) : 0.f;     // d LogSigmoid(x) / dx = sigmoid(-x)
+    }
+}
+
+__global__ __launch_bounds__(256) void attr_ll_bwd_hidden_kernel(const float* __restrict__ gx, const float* __restrict__ E, int64_t ld_e, int H,
+                                                                 const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q,
+                                                                 const int32_t* __restrict__ pred_col, int P, int NS,
+                                                                 float* __restrict__ d_hidden, int64_t ld_dh) {
+    const int q = blockIdx.x;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.y * 4 + wv;
+    const int first = obj_off[q], n = obj_off[q + 1] - first;
+    if (o >= n) return;
+    int p0, p1;
+    dfol_pred_range(pred_q, P, q, p0, p1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = p0; p < p1; ++p) {
+        const int col = pred_col[p];
+        if (col < 0) continue;
+        const float w = gx[(int64_t)p * NS + o];
+        const float* e = E + (int64_t)col * ld_e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (lane + 64 * j < H) acc[j] = fmaf(w, e[lane + 64 * j], acc[j]);
+    }
+    float* out = d_hidden + (int64_t)(first + o) * ld_dh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (lane + 64 * j < H) out[lane + 64 * j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void attr_ll_bwd_emb_kernel(const float* __restrict__ gx, const float* __restrict__ hidden, int64_t ld_h, int H,
+                                                              const int32_t* __restrict__ obj_off, const int32_t* __restrict__ pred_q, int NS,
+                                                              float* __restrict__ dE, int64_t ld_de, float* __restrict__ db) {
+    const int p = blockIdx.x, t = threadIdx.x;
+    const int q = pred_q[p];
+    const int first = obj_off[q], n = obj_off[q + 1] - first;
+    const float* w = gx + (int64_t)p * NS;
+    float a0 = 0.f, a1 = 0.f, sb = 0.f;
+    for (int o = 0; o < n; ++o) {
+        const float wo = w[o];
+        const float* h = hidden + (int64_t)(first + o) * ld_h;
+        if (t < H) a0 = fmaf(wo, h[t], a0);
+        if (t + 256 < H) a1 = fmaf(wo, h[t + 256], a1);
+        sb += wo;
+    }
+    if (dE) {
+        if (t < H) dE[(int64_t)p * ld_de + t] = a0;
+        if (t + 256 < H) dE[(int64_t)p * ld_de + t + 256] = a1;
+    }
+    if (db && t == 0) db[p] = sb;
+}
+
+extern "C" int dfol_attr_ll_bwd_f32(const float* g, const float* hidden, int64_t ld_hidden, int32_t H, const float* E, int64_t ld_e,
+                                    const float* be, const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P,
+                                    int32_t Q, int32_t NS, float* gx, float* d_hidden, int64_t ld_dh, float* dE, int64_t ld_de, float* db,
+                                    void* stream) {
+    DFOL_REQUIRE(P >= 0 && Q >= 0 && NS > 0 && NS % 4 == 0 && H > 0 && H <= 512, "attr_ll_bwd: bad sizes P=%d NS=%d H=%d (H <= 512)", P, NS, H);
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(hidden && E && obj_off && (P == 0 || (g && pred_q && pred_col && gx)), "attr_ll_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (P > 0) {
+        hipLaunchKernelGGL(attr_ll_bwd_gx_kernel, dim3(P, dfol_cdiv(NS, 16)), dim3(256), 0, st, g, hidden, ld_hidden, H, E, ld_e, be, obj_off,
+                           pred_q, pred_col, NS, gx);
+        DFOL_LAUNCH_CHECK("attr_ll_bwd (gx)");
+    }
+    if (d_hidden) {                                        // every object row is written (zero when its image has no valid predicate)
+        hipLaunchKernelGGL(attr_ll_bwd_hidden_kernel, dim3(Q, dfol_cdiv(NS, 4)), dim3(256), 0, st, gx, E, ld_e, H, obj_off, pred_q, pred_col, P,
+                           NS, d_hidden, ld_dh);
+        DFOL_LAUNCH_CHECK("attr_ll_bwd (hidden)");
+    }
+    if ((dE || db) && P > 0) {
+        hipLaunchKernelGGL(attr_ll_bwd_emb_kernel, dim3(P), dim3(256), 0, st, gx, hidden, ld_hidden, H, obj_off, pred_q, NS, dE, ld_de, db);
+        DFOL_LAUNCH_CHECK("attr_ll_bwd (emb)");
+    }
     return 0;
 }

@@ -7,7 +7,7 @@ src/nsvqa/data/batch_gqa_boxfeatures_pipeline.py:15-189 (BatchGQABoxFeaturesColl
 The bytecode is six int32 arrays per question file — `answer[row]`, `image_id[row]`, `branch_ops[row, b, 10]`,
 `branch_args[row, b, 10, 3]`, `last_op[row]`, `last_args[row, k]` — token codes are 1-based vocabulary indices,
 negative = `not(token)`, 0 = empty.  The reference stores them in HDF5; this module reads and writes the same arrays
-from `.npz` (always available) and from `.h5` when `h5py` can be imported (it is not installed in this image).
+from `.npz` and from `.h5` (through h5py when installed, else through the HDF5 C library itself: h5lite.py).
 """
 
 import collections
@@ -26,17 +26,32 @@ ARRAYS = ("answer", "image_id", "branch_ops", "branch_args", "last_op", "last_ar
 
 
 def _open_arrays(path):
-    """{name: array-like} for a bytecode / feature container (.npz, or .h5 through h5py)."""
+    """{name: array-like} for a bytecode / feature container: .npz, or .h5 (h5py when installed, else the HDF5 C library through
+    h5lite - the files the reference writes and reads, gqa_preprocess.py:87-93 / data_pipeline.py:328-389)."""
     ext = os.path.splitext(path)[1]
     if ext == ".npz":
         return np.load(path)
     if ext == ".h5":
-        try:
-            import h5py
-        except ImportError:
-            raise ImportError("%s is an HDF5 file but h5py is not installed; convert it to .npz with the same dataset names" % path)
-        return h5py.File(path, "r")
+        from . import h5lite
+        return h5lite.import_h5py().File(path, "r")
     raise ValueError("unsupported container %s" % path)
+
+
+def write_arrays(path, arrays):
+    """Write {name: array} as `.npz` or as the reference's `.h5` layout (one dataset per name, gqa_preprocess.py:87-93)."""
+    ext = os.path.splitext(path)[1]
+    if ext == ".npz":
+        np.savez(path, **arrays)
+    elif ext == ".h5":
+        from . import h5lite
+        f = h5lite.import_h5py().File(path, "w")
+        try:
+            for k, v in arrays.items():
+                f.create_dataset(k, data=np.asarray(v))
+        finally:
+            f.close()
+    else:
+        raise ValueError("unsupported container %s" % path)
 
 
 class ProgramCodec(object):

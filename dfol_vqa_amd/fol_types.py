@@ -59,7 +59,7 @@ def _geometry_on_device(device, n_list):
                torch.as_tensor(np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)).to(device),
                torch.arange(len(n_list), dtype=torch.int32, device=device))
         _geometry_cache[key] = hit
-    return hit
+    return L.keep_alive(hit)
 
 
 class BatchWorld(object):
@@ -158,7 +158,7 @@ class BatchWorld(object):
                 if len(_pair_index_cache) >= 8:          # 16 bytes per ordered pair: keep a handful of batch shapes
                     _pair_index_cache.clear()
                 _pair_index_cache[key] = hit
-            self._pair_idx = hit
+            self._pair_idx = L.keep_alive(hit)
         return self._pair_idx
 
     def zeros_attention(self):

@@ -10,6 +10,7 @@ import re
 import numpy as np
 import torch
 
+from ._lib import keep_alive, keeping  # noqa: F401
 from .fol_types import TokenType
 
 _NEG = re.compile(r"not\((\w|\s)+\)")
@@ -92,7 +93,7 @@ def upload(array, device):
         if len(_upload_cache) >= 1024:
             _upload_cache.clear()
         hit = _upload_cache[key] = torch.as_tensor(a).to(device)
-    return hit
+    return keep_alive(hit)
 
 
 def lower_tokens(tokens, ontology, token_type):

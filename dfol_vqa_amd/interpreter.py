@@ -12,7 +12,7 @@ import torch.nn as nn
 from . import ops as L
 from . import gqa_ops as gqa
 from .fol_types import BatchAttentionState, BatchVariableSet, BatchWorld, QuestionType
-from .host_util import reverse_dependencies, upload
+from .host_util import keeping, reverse_dependencies, upload
 
 
 def gather_results(outputs, target_device=None, is_cuda=True):
@@ -77,7 +77,12 @@ class GraphedForward(object):
     """The inference forward of one fixed list of ProgramBatches as a captured HIP graph (the launch sequence of a program batch is
     static: 16 launches for a 3-hop program).  Replaying it removes the per-launch host work, which is 7-10 % of a step at 36
     objects per scene.  The object features are read from the ProgramBatches' own tensors, so new scenes of the same shapes are
-    served by copying into `program_batch._object_features` before `__call__`.  Answers are decoded after the replay."""
+    served by copying into `program_batch._object_features` before `__call__`.  Answers are decoded after the replay.
+
+    Lifetime: the graph holds raw device addresses.  Tensors created during the capture live in the graph's own memory pool; tensors
+    that came out of a cache (uploaded index arrays, batch geometry, packed / split weight images, transposed LSTM weights) are
+    referenced from `self._keep`, so cache evictions cannot free them under the graph.  The graph reads the weight images of the
+    weight VERSION it was captured with: rebuild it after an optimizer step or load_state_dict."""
 
     def __init__(self, model, program_batch_list, warmup=2):
         from . import gqa_ops
@@ -87,10 +92,11 @@ class GraphedForward(object):
                 model(program_batch_list, False)
             torch.cuda.synchronize()
             self._queue = []
+            self._keep = []                                      # everything the caches handed to the captured launches (host_util.keeping)
             self._graph = torch.cuda.CUDAGraph()
             gqa_ops.DEFERRED.queue = self._queue
             try:
-                with torch.cuda.graph(self._graph):
+                with keeping(self._keep), torch.cuda.graph(self._graph):
                     self._lazy = model(program_batch_list, False)
             finally:
                 gqa_ops.DEFERRED.queue = None

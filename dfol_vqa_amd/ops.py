@@ -7,6 +7,8 @@ vector glue (gate, segment reductions, and/or/not, compare) and of the dense lay
 library GEMMs on the GPU — plumbing, as the design notes say.
 """
 
+import os
+
 import torch
 
 from . import _lib
@@ -227,7 +229,7 @@ class _SegmentOr(torch.autograd.Function):
         idx = torch.repeat_interleave(torch.arange(counts.numel(), device=g.device), counts)
         one = torch.ones((), device=lp.device)
         inner = torch.log((1 - torch.exp(lp)).clamp_min(_EPS))
-        s = torch.zeros(counts.numel(), device=lp.device).index_add_(0, idx, inner)
+        s = _lib.segment_sum_rows(inner.unsqueeze(1).contiguous(), seg_off).squeeze(1)     # (index_add_ would be atomic: not repeatable)
         return (g * _dpnot(s, one))[idx] * _dpnot(lp, one), None
 
 
@@ -252,7 +254,7 @@ class _Implication(torch.autograd.Function):
         m = torch.log((1 - torch.exp(x)).clamp_min(_EPS))
         z = prior[pq] + m
         dz = torch.where(valid, g * _dpnot(z, one), torch.zeros_like(g))
-        g_prior = torch.zeros_like(prior).index_add_(0, pq, dz)
+        g_prior = _lib.reduce_by_question(dz.contiguous(), pred_q, None, prior.shape[0])    # deterministic (no atomics)
         return g_prior, dz * _dpnot(x, one), None, None
 
 
@@ -313,7 +315,7 @@ def compare(lp1, lp2, is_less):
     return _lib.compare(lp1, lp2, is_less)
 
 
-# ---- dense layers: forward = fused MFMA kernel, backward = library GEMMs ------------------------------
+# ---- dense layers: forward = fused MFMA kernel, backward = the same kernels + the TN weight-gradient kernel ------
 class _LinearAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
@@ -334,8 +336,15 @@ class _LinearAct(torch.autograd.Function):
             dz = g * (1 - torch.exp(y))
         else:
             dz = g
-        gx = dz @ weight if ctx.needs_input_grad[0] else None
-        gw = dz.t() @ x if ctx.needs_input_grad[1] else None
+        dz = dz.contiguous()
+        # input gradient on the forward's own kernels, weight gradient on the deterministic TN kernel (csrc/dfol_dense_wgrad.hip);
+        # DFOL_TRAIN_GEMM=torch goes back to library GEMMs for A/B runs
+        own = os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch"
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _lib.linear_gradx(dz, weight.detach()) if own else dz @ weight
+        if ctx.needs_input_grad[1]:
+            gw = _lib.linear_wgrad(dz, x if x.stride(-1) == 1 else x.contiguous()) if own else dz.t() @ x
         gb = dz.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 

@@ -60,6 +60,68 @@ def gather_results(result, group=None):
             "answer_log_probability": [a for p in parts for a in p["answer_log_probability"]]}
 
 
+def broadcast_parameters(model, src=0, group=None):
+    """Every rank takes rank `src`'s parameters and buffers (ONE broadcast of a flat fp32 bucket).  The reference's
+    ProgramDataParallel replicates device 0's module on every forward (data_parallel.py:54-83); with one process per GPU the
+    replicas must be made equal once - after build_model / load_state_dict - and the identical all-reduced gradient plus the
+    identical clip + Adam step keep them equal from then on.  Returns the number of bytes exchanged."""
+    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    tensors = [t for t in tensors if t.numel() > 0]
+    if not tensors:
+        return 0
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    offset = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[offset:offset + n].view_as(t))      # copy_ bumps the version counter: packed weight images are rebuilt
+            offset += n
+    return flat.numel() * 4
+
+
+def parameters_digest(model):
+    """A float64 checksum pair of all parameters (sum, sum of squares) for cross-rank equality checks."""
+    ps = [p.detach().reshape(-1).to(torch.float64) for p in model.parameters() if p.numel() > 0]
+    flat = torch.cat(ps) if ps else torch.zeros(1, dtype=torch.float64)
+    return torch.stack([flat.sum(), (flat * flat).sum()])
+
+
+class GradBucket(object):
+    """The flat fp32 gradient bucket of SURVEY.md 8(e), persistent: every trainable parameter's `.grad` is a view into ONE
+    contiguous buffer, so the step's all-reduce needs no gather / scatter copies (autograd accumulates into the views in place).
+    Use `bucket.zero_()` instead of `optimizer.zero_grad()` (which would drop the views)."""
+
+    def __init__(self, parameters):
+        self.params = [p for p in parameters if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._attach()
+
+    def _attach(self):
+        offset = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[offset:offset + n].view_as(p)
+            offset += n
+
+    def zero_(self):
+        if any(p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or
+               p.grad.data_ptr() >= self.flat.data_ptr() + 4 * max(1, self.flat.numel()) for p in self.params):
+            self._attach()                                   # someone called zero_grad(set_to_none=True)
+        self.flat.zero_()
+
+    def nbytes(self):
+        return self.flat.numel() * 4
+
+    def allreduce(self, group=None):
+        """ONE all-reduce (sum) of the whole bucket: RCCL over xGMI with backend "nccl", gloo on CPU."""
+        if self.flat.numel():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        return self.nbytes()
+
+
 def allreduce_gradients(parameters, group=None):
     """One all-reduce (sum) of ONE flat fp32 bucket holding every trainable gradient (9.2 MB in the oracle phase,
     0.59 MB in the calibrator phase).  With the loss divided by the GLOBAL batch size on every rank

@@ -83,6 +83,17 @@ def three_hop_program(qid, nouns, attributes, relations, negate_prob=0.0):
     return [[op("select", n1), op("filter", a), op("relate", r, subj, n2)]], op("exist")
 
 
+def open_program(qid, nouns, attributes, relations, categories, hops=4):
+    """select(n) -> (filter(a) -> relate(r, is_subject, n')) x hops -> query_attr(category): the 8-hop open (QUERY) programs of
+    BASELINE.json configs[4]."""
+    rng = _rng(qid, 4)
+    branch = [op("select", nouns[rng.randint(len(nouns))])]
+    for _ in range(hops):
+        branch.append(op("filter", attributes[rng.randint(len(attributes))]))
+        branch.append(op("relate", relations[rng.randint(len(relations))], bool(rng.uniform() < 0.5), nouns[rng.randint(len(nouns))]))
+    return [branch], op("query_attr", categories[rng.randint(len(categories))])
+
+
 def write_synthetic_ontology(directory, concept_num=2335, relation_num=333, seed=11):
     """Metadata files with the reference's schema and the real vocabulary's dimensions (2335 concepts of which
     333 are relations), but made-up names: the GQA metadata itself belongs to the reference."""
@@ -112,7 +123,7 @@ def write_synthetic_ontology(directory, concept_num=2335, relation_num=333, seed
         with open(paths[key], "w") as f:
             json.dump(obj, f)
     paths["word_embedding_file"] = None
-    return paths, {"nouns": nouns, "attributes": attrs, "relations": rels}
+    return paths, {"nouns": nouns, "attributes": attrs, "relations": rels, "categories": cats}
 
 
 def reference_config(paths, **over):

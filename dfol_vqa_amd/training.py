@@ -18,46 +18,68 @@ def safe_log(x):                                         # util.py:22-25
     return x.clamp(min=1e-20).log()
 
 
-def compute_loss(program_batch_list, prediction, l1_lambda=0.0, parameters=None):
-    """trainer.py:181-262 for STATEMENT / BINARY / QUERY predictions (sum over the batch, not yet divided by it)."""
+def compute_loss(program_batch_list, prediction, l1_lambda=0.0, parameters=None, l1_scale=1.0):
+    """trainer.py:181-262 for STATEMENT / BINARY / QUERY predictions (sum over the batch, not yet divided by it).
+
+    `l1_scale`: with R data-parallel ranks every rank adds the regulariser to its local loss and the gradients are then
+    summed, so each rank passes 1/R and the summed gradient carries the term once, as the single-process step does."""
     lp = prediction['log_probability']
     device = lp.device
     qtype = prediction['type']
-    if qtype == QuestionType.STATEMENT:
-        loss = -lp.sum()
-    elif qtype == QuestionType.BINARY:                   # :185-194
+    if qtype == QuestionType.STATEMENT:                  # :182-183 returns before the L1 block
+        return -lp.sum()
+    if qtype == QuestionType.BINARY:                   # :185-194
         target = torch.tensor([float(a in _YES) for pb in program_batch_list for a in pb._answers], dtype=torch.float32, device=device)
         loss = nn.functional.binary_cross_entropy(lp.exp(), target, reduction='sum')
     elif qtype == QuestionType.QUERY:                    # :207-230
         answers = [a for pb in program_batch_list for a in pb._answers]
         target = [[a == o for o in op] for a, op in zip(answers, prediction['options'])]
-        seg = torch.tensor([i for i, t in enumerate(target) for _ in t], dtype=torch.int64, device=device)
         tflat = torch.tensor([float(x) for t in target for x in t], dtype=torch.float32, device=device)
-        denom = torch.zeros(len(target), dtype=torch.float32, device=device).index_add(0, seg, lp.exp())
+        if lp.is_cuda:                                   # per-question sums by the segment kernel (index_add is atomic: not repeatable)
+            import numpy as np
+            from . import ops
+            from .host_util import upload
+            seg_off = upload(np.concatenate([[0], np.cumsum([len(t) for t in target])]).astype(np.int32), device)
+            denom = ops.segment_sum_rows(lp.exp().unsqueeze(1).contiguous(), seg_off).squeeze(1)
+        else:
+            seg = torch.tensor([i for i, t in enumerate(target) for _ in t], dtype=torch.int64, device=device)
+            denom = torch.zeros(len(target), dtype=torch.float32, device=device).index_add(0, seg, lp.exp())
         loss = safe_log(denom).sum() - (tflat * lp).sum()
     else:
         raise NotImplementedError("direct-supervision losses (OBJECT_STATEMENT / SCENE_GRAPH) are out of scope")
     if l1_lambda and parameters is not None:             # :258-260
         allp = torch.cat([p.view(-1) for p in parameters if p.requires_grad])
-        loss = loss + l1_lambda * torch.norm(allp, 1) / max(1, allp.numel())
+        loss = loss + l1_scale * l1_lambda * torch.norm(allp, 1) / max(1, allp.numel())
     return loss
 
 
-def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group=None, l1_lambda=0.0):
+def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group=None, l1_lambda=0.0, bucket=None):
     """trainer.py:429-442: zero_grad -> forward -> loss / B -> backward -> clip_grad_norm_ -> step.
 
-    With `group` set (one process per GPU), `data` is this rank's shard: the loss is divided by the GLOBAL batch
-    size, the gradients of all ranks are summed with ONE all-reduce of a flat bucket, and every rank applies the
-    same clip + step, so parameters stay identical across ranks."""
-    optimizer.zero_grad()
+    With `group` set (one process per GPU), `data` is this rank's shard: the loss is divided by the GLOBAL batch size, the
+    gradients of all ranks are summed with ONE all-reduce of a flat bucket (`bucket`: a persistent parallel.GradBucket, no
+    gather/scatter copies), and every rank applies the same clip + step, so parameters that start equal
+    (parallel.broadcast_parameters) stay equal.  The L1 term is scaled by 1/world so the summed gradient carries it once.
+    Returns (this rank's share of the summed loss, result): all-reduce the scalar if the global value is wanted."""
+    if bucket is not None:
+        bucket.zero_()
+    else:
+        optimizer.zero_grad()
     result = model(data, True)
-    loss = compute_loss(data, result, l1_lambda, list(model.parameters()))
+    world = 1
+    if group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+    loss = compute_loss(data, result, l1_lambda, list(model.parameters()), l1_scale=1.0 / world)
     local_b = sum(d.batch_size() for d in data)
     b = global_batch_size if global_batch_size is not None else local_b
     loss = loss / b
     loss.backward()
     if group is not None:
-        parallel.allreduce_gradients(model.parameters(), group)
+        if bucket is not None:
+            bucket.allreduce(group)
+        else:
+            parallel.allreduce_gradients(model.parameters(), group)
     nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return float(loss.detach()) * b, result

@@ -142,6 +142,7 @@ class CalibrationLSTMCell(nn.LSTMCell):
             key = (self.weight_ih._version, self.weight_hh._version, self.weight_ih.data_ptr(), self.weight_hh.data_ptr())
             if getattr(self, "_wt", (None,))[0] != key:          # transposed copies, once per weight version
                 self._wt = (key, self.weight_ih.detach().t().contiguous(), self.weight_hh.detach().t().contiguous())
+            L.keep_alive(self._wt)
             return L.lstm_cell(x, h, c.contiguous(), self._wt[1], self._wt[2], self.bias_ih, self.bias_hh)          # one launch
         ig = L.linear_act(x.contiguous(), self.weight_ih, self.bias_ih, L.ACT_NONE)
         hg = L.linear_act(h.contiguous(), self.weight_hh, self.bias_hh, L.ACT_NONE)
@@ -149,9 +150,9 @@ class CalibrationLSTMCell(nn.LSTMCell):
 
 
 class _TallLinear(torch.autograd.Function):
-    """y = x W^T + b for a very tall x ([rows, K] with millions of rows: one row per object pair).  Forward and grad_x are plain
-    library GEMMs; the weight gradient g^T x contracts over the rows, a shape for which the library picks a slow kernel
-    (7.5 ms for [300 x 2.5M] x [2.5M x 256]), so it is taken as a batched GEMM over row slices plus a sum."""
+    """y = x W^T + b for a very tall x ([rows, K] with millions of rows: one row per object pair).  Forward and grad_x run on the
+    bf16x3 split kernel (fp32 results); the weight gradient g^T x contracts over the rows, a shape for which the vendor library picks
+    a slow kernel (7.5 ms for [300 x 2.5M] x [2.5M x 256]): it runs on the TN kernel of csrc/dfol_dense_wgrad.hip."""
 
     @staticmethod
     def _split_ok(x2, k):
@@ -176,16 +177,20 @@ class _TallLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g2c = g2 if g2.is_contiguous() else g2.contiguous()
             if _TallLinear._split_ok(g2c, g2c.shape[1]):
-                gx = L.linear_act_split(g2c, weight.detach().t().contiguous(), None, L.ACT_NONE).view_as(x)
+                gx = L.linear_act_split(g2c, weight.detach(), None, L.ACT_NONE, transpose_w=True).view_as(x)
             else:
                 gx = (g2 @ weight).view_as(x)
         gw = None
         if ctx.needs_input_grad[1]:
-            rows = g2.shape[0]
-            S = 64
-            while S > 1 and rows % S:
-                S //= 2
-            gw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0) if S > 1 else g2.t() @ x2
+            if g2.is_cuda and g2.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch":
+                # dY^T X over millions of rows: the deterministic TN kernel on the fp32 matrix pipe (csrc/dfol_dense_wgrad.hip)
+                gw = L.linear_wgrad(g2 if g2.stride(-1) == 1 else g2.contiguous(), x2 if x2.stride(-1) == 1 else x2.contiguous())
+            else:
+                rows = g2.shape[0]
+                S = 64
+                while S > 1 and rows % S:
+                    S //= 2
+                gw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0) if S > 1 else g2.t() @ x2
         gb = g2.sum(0) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
@@ -226,6 +231,74 @@ class _FusedLogit(torch.autograd.Function):
         pre2, e_rows, pred_off = ctx.saved_tensors
         dp2, de, dbe = L.pair_logit_bwd(dx.contiguous(), pre2, e_rows, pred_off, need_bias=ctx.needs_input_grad[2])
         return dp2, de, dbe, None, None
+
+
+def _concept_plan(cols, device, cache):
+    """Fixed-order combination plan for per-predicate gradient rows of the embedding layer: predicates naming the same concept are
+    summed in predicate order (stable sort), the unique concepts then receive one row each - no atomics, repeatable bit for bit.
+    -> (order [V] int32: predicate of each sorted slot, seg_off [U+1] int32, ucols [U] int64), device tensors cached by content."""
+    cols = np.asarray(cols, np.int64)
+    key = ("concepts", str(device), cols.tobytes())
+    hit = cache.get(key)
+    if hit is None:
+        valid = np.nonzero(cols >= 0)[0]
+        order = valid[np.argsort(cols[valid], kind="stable")]
+        sc = cols[order]
+        ucols, start = np.unique(sc, return_index=True)
+        seg = np.concatenate([start, [len(sc)]]).astype(np.int32)
+        hit = (torch.as_tensor(order.astype(np.int32)).to(device), torch.as_tensor(seg).to(device), torch.as_tensor(ucols.astype(np.int64)).to(device))
+        if len(cache) >= 64:
+            cache.clear()
+        cache[key] = hit
+    return hit
+
+
+def _combine_concept_rows(rows, plan, out_shape):
+    """rows [P, ...] per predicate -> dense gradient of `out_shape` (one row per concept), deterministic."""
+    order, seg_off, ucols = plan
+    out = torch.zeros(out_shape, dtype=rows.dtype, device=rows.device)
+    if order.numel() == 0:
+        return out
+    flat = rows.reshape(rows.shape[0], -1)
+    summed = L.segment_sum_rows(L.gather_rows(flat, order), seg_off)
+    out.reshape(out_shape[0], -1).index_copy_(0, ucols, summed)          # unique rows: no accumulation, no atomics
+    return out
+
+
+class _AttrLL(torch.autograd.Function):
+    """[P, NS] blocks LogSigmoid(hidden[o] . E[col_p] + be[col_p]) of the requested attribute columns: the inference kernel forward,
+    three small HIP kernels backward (csrc/dfol_logic_bwd.hip), no gathers / scatter-adds, deterministic."""
+
+    @staticmethod
+    def forward(ctx, hidden, emb_w, emb_b, obj_off, pred_q, pred_col, NS, plan):
+        ctx.save_for_backward(hidden, emb_w, emb_b if emb_b is not None else hidden.new_empty(0), obj_off, pred_q, pred_col)
+        ctx.plan, ctx.has_bias = plan, emb_b is not None
+        return L.attr_ll(hidden.detach(), emb_w.detach(), None if emb_b is None else emb_b.detach(), obj_off, pred_q, pred_col, NS, -30.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        hidden, emb_w, emb_b, obj_off, pred_q, pred_col = ctx.saved_tensors
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        d_hidden, dE, db = L.attr_ll_bwd(g.contiguous(), hidden, emb_w, emb_b if ctx.has_bias else None, obj_off, pred_q, pred_col,
+                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_b)
+        gw = _combine_concept_rows(dE, ctx.plan, emb_w.shape) if ctx.needs_input_grad[1] else None
+        gb = _combine_concept_rows(db, ctx.plan, emb_b.shape) if need_b else None
+        return d_hidden, gw, gb, None, None, None, None, None
+
+
+class _EmbRows(torch.autograd.Function):
+    """(E[cols], be[cols]) with a deterministic backward: index_select's backward is an atomic scatter-add."""
+
+    @staticmethod
+    def forward(ctx, emb_w, emb_b, cols_dev, plan):
+        ctx.plan, ctx.shapes = plan, (emb_w.shape, emb_b.shape)
+        return emb_w.index_select(0, cols_dev), emb_b.index_select(0, cols_dev)
+
+    @staticmethod
+    def backward(ctx, gw_rows, gb_rows):
+        gw = _combine_concept_rows(gw_rows.contiguous(), ctx.plan, ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        gb = _combine_concept_rows(gb_rows.contiguous(), ctx.plan, ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        return gw, gb, None, None
 
 
 class ClassifierOracle(OracleBase):
@@ -303,7 +376,7 @@ class ClassifierOracle(OracleBase):
             buv = torch.cat([b1, torch.zeros_like(b1)]).contiguous()
             wg = w[:, 2 * D:2 * D + 4].contiguous()
             self._split_cache = (key, wuv, buv, wg, hid1, D)
-        return self._split_cache[1:]
+        return L.keep_alive(self._split_cache)[1:]
 
     def _padded_second_layer(self):
         """W2 zero-padded to a multiple of 32 rows, so the fused pair kernel's main loop needs no bounds checks."""
@@ -324,7 +397,7 @@ class ClassifierOracle(OracleBase):
                 if L.pair_split_supported(w.shape[1], w.shape[0]) and os.environ.get("DFOL_PAIR_MATH", "bf16x3") != "f32":
                     packed = ("bf16x3", L.pair_pack_w2_split(wp, w.shape[0]))
             self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0], packed)
-        return self._w2_cache[1:]
+        return L.keep_alive(self._w2_cache)[1:]
 
     def prepare_scene(self, world, obj, train=False):
         """Hidden activations of a scene: attribute hidden [O, H] and the per-object halves of the pair MLP's first layer.
@@ -359,8 +432,12 @@ class ClassifierOracle(OracleBase):
             obj = world._obj
             D = (lin1.weight.shape[1] - 4) // 2
             assert obj.shape[1] == D, "object feature width does not match the relation network"
-            U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias)
-            V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
+            if obj.is_cuda and obj.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch":
+                U = L.linear_act(obj, lin1.weight[:, :D], lin1.bias, L.ACT_NONE)          # forward and both gradients on the HIP kernels
+                V = L.linear_act(obj, lin1.weight[:, D:2 * D], None, L.ACT_NONE)
+            else:
+                U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias)
+                V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
             pos = obj[:, D - 4:].detach()                       # batch_gqa_boxfeatures_pipeline.py:263-279
             if self._fused_training(world) and U.shape[1] % 4 == 0:
                 z = _FusedHidden1.apply(U.contiguous(), V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(), pos, world)
@@ -464,7 +541,9 @@ class ClassifierOracle(OracleBase):
         cols = upload(full[preds].astype(np.int64), dev)
         if fused and src is None:
             # every pair row belongs to exactly one predicate, in order: Sigmoid, embedding product and row sum in one kernel
-            x = _FusedLogit.apply(self._pair_pre2_autograd(world), emb.weight.index_select(0, cols), emb.bias.index_select(0, cols), pred_off, max_rows)
+            plan = _concept_plan(np.where(full >= 0, full, -1)[preds], dev, self._index_cache)
+            e_rows, be_rows = _EmbRows.apply(emb.weight, emb.bias, cols, plan)
+            x = _FusedLogit.apply(self._pair_pre2_autograd(world), e_rows, be_rows, pred_off, max_rows)
         else:
             # one pass over all predicates (a loop over concepts would scatter-add into the hidden gradient once per concept; a
             # matrix-vector product would go to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms)
@@ -480,6 +559,11 @@ class ClassifierOracle(OracleBase):
         cols = np.asarray(low.cols, np.int64)
         pq = np.asarray(list(pred_q_host), np.int64)
         P, NS = len(pq), world._NS
+        if os.environ.get("DFOL_TRAIN_FUSED", "1") != "0" and world._hidden_attr.shape[1] <= 512 and emb.bias is not None and \
+                (len(pq) < 2 or bool(np.all(pq[1:] >= pq[:-1]))):
+            plan = _concept_plan(cols, dev, self._index_cache)
+            return _AttrLL.apply(world._hidden_attr, emb.weight, emb.bias, world._obj_off, upload(pq.astype(np.int32), dev),
+                                 low.on(dev)[0], NS, plan)
         n = np.asarray(world._n_list, np.int64)
         obj_off = np.concatenate([[0], np.cumsum(n)])
         flat = torch.full((P * NS,), -30.0, dtype=torch.float32, device=dev)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFOL_ABI_VERSION 1
+#define DFOL_ABI_VERSION 2
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int dfol_abi_version(void);
@@ -350,13 +350,32 @@ int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t HID2, const 
 int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
                             const int64_t* pred_off, int32_t P, float* dP2, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe, void* stream);
 
-/* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
- * Gradients of the block operators; formulas in SURVEY.md Appendix B.  g_* outputs that are NULL are skipped.
- * g_prior* ([Q, NS]) are ACCUMULATED into (several predicates may share a question's prior): zero them first.
- */
-int dfol_filter_bwd_f32(const float* g_out, const float* ll, const int32_t* pred_q, const int32_t* n_obj, const uint8_t* neg,
-                        int32_t any_neg, const uint8_t* active, int32_t P, int32_t NS, float* g_prior, float* g_ll, void* stream);
+/* Weight gradient of a dense layer, dW [N, K] = dY^T X with dY [M, N] (row stride ld_dy) and X [M, K] (row stride ld_x): what torch
+ * autograd computes for nn.Linear (gqa_interpreter_experiments.py:26-33, 73-74 under trainer.py:436).  Exact-fp32 matrix pipe, the
+ * rows are cut into dfol_linear_wgrad_slabs(M, N, K) slabs whose partial results go to `workspace` (slabs * round_up(N * K, 4)
+ * floats) and are added in a fixed order: deterministic, no atomics. */
+int dfol_linear_wgrad_slabs(int64_t M, int32_t N, int32_t K);
+int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                          float* workspace, float* dW, void* stream);
 
+/* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
+ * Gradients of the block operators; formulas in SURVEY.md Appendix B (the reference gets them from torch autograd through
+ * batch_base_ops.py:62-215).  g_* outputs that are NULL are skipped.
+ * DETERMINISTIC: no atomics.  Every sum over the predicates of a question is taken by the owner of the output element, walking
+ * the predicates in order; for that, pred_q must be NON-DECREASING (the predicates of a question are contiguous, as every
+ * operator of the reference builds them: util.flatten_list, batch_base_ops.py:324-335).
+ */
+
+/* out[q, c] = sum_{p: pred_q[p] = q} src[p, c]  (src [P, NS], out [Q, NS]; columns >= n_obj[q] are 0 when n_obj is given). */
+int dfol_reduce_by_question_f32(const float* src, const int32_t* pred_q, const int32_t* n_obj, int32_t P, int32_t Q, int32_t NS,
+                                float* out, void* stream);
+
+/* g_prior [Q, NS] is WRITTEN (sum over the question's predicates); g_ll [P, NS]. */
+int dfol_filter_bwd_f32(const float* g_out, const float* ll, const int32_t* pred_q, const int32_t* n_obj, const uint8_t* neg,
+                        int32_t any_neg, const uint8_t* active, int32_t P, int32_t Q, int32_t NS, float* g_prior, float* g_ll,
+                        void* stream);
+
+/* g_prior_s / g_prior_o are PER PREDICATE ([P, NS], written): reduce them with dfol_reduce_by_question_f32. */
 int dfol_relate_bwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q, const int32_t* n_obj,
                         const float* quant_s, const float* quant_o, const uint8_t* neg, int32_t any_neg, const uint8_t* active,
                         const float* g_post_s, const float* g_post_o, int32_t P, int32_t NS, int32_t orientation,
@@ -365,13 +384,22 @@ int dfol_relate_bwd_f32(const float* prior_s, const float* prior_o, const float*
 int dfol_quantify_bwd_f32(const float* g_lp, const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
                           int32_t P, int32_t NS, float* g_att, void* stream);
 
-/* g_table is ACCUMULATED into (scatter-add). */
+/* g_table is ADDED into, row by row, by the thread that owns the row (one object / one ordered pair): zero it first. */
 int dfol_attr_gather_bwd_f32(const float* g_ll, const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P,
-                             int32_t NS, float* g_table, int64_t ld_table, void* stream);
+                             int32_t Q, int32_t NS, float* g_table, int64_t ld_table, void* stream);
 
 int dfol_rel_gather_bwd_f32(const float* g_tile, const int64_t* pair_off, const int32_t* n_obj, const int32_t* pred_q,
-                            const int32_t* pred_col, int32_t P, int32_t NS, int32_t orientation, float* g_table, int64_t ld_table,
-                            void* stream);
+                            const int32_t* pred_col, int32_t P, int32_t Q, int32_t NS, int32_t orientation, float* g_table,
+                            int64_t ld_table, void* stream);
+
+/* Backward of dfol_attr_ll_f32 (needed-columns attribute likelihood; the reference back-propagates through the full
+ * Linear(300 -> 2335) + LogSigmoid of gqa_interpreter_experiments.py:60-77).  gx [P, NS] is scratch (g * sigmoid(-x));
+ * d_hidden [O, H] is written for every object; dE [P, H] / db [P] are PER PREDICATE (rows of equal concept are combined by
+ * the caller in a fixed order).  Any of d_hidden / dE / db may be NULL. */
+int dfol_attr_ll_bwd_f32(const float* g, const float* hidden, int64_t ld_hidden, int32_t H, const float* E, int64_t ld_e,
+                         const float* be, const int32_t* obj_off, const int32_t* pred_q, const int32_t* pred_col, int32_t P,
+                         int32_t Q, int32_t NS, float* gx, float* d_hidden, int64_t ld_dh, float* dE, int64_t ld_de, float* db,
+                         void* stream);
 
 /* from the NORMALISED values y (the softmax weight of option p is exp(y_p)). */
 int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, const int32_t* seg_off, int32_t S, const int32_t* pred_q,

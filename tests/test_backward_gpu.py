@@ -307,3 +307,130 @@ def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
     assert np.allclose(dp2.cpu().numpy(), Pt.grad.numpy(), rtol=2e-5, atol=2e-6)
     assert np.abs(de.cpu().numpy() - Et.grad.numpy()).max() <= 5e-5 * max(1.0, np.abs(Et.grad.numpy()).max())
     assert np.abs(dbe.cpu().numpy() - bt.grad.numpy()).max() <= 5e-5 * max(1.0, np.abs(bt.grad.numpy()).max())
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: deterministic backward (no atomics), the TN weight-gradient kernel, the attribute-column backward
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,ldx", [(1000, 300, 256, 256), (4097, 512, 2048, 2054), (333, 256, 516, 516), (70, 7, 5, 5), (25600, 300, 256, 256),
+                                       (129, 320, 100, 100)])
+def test_linear_wgrad_against_fp64(M, N, K, ldx):
+    """dW = dY^T X on the fp32 matrix pipe (csrc/dfol_dense_wgrad.hip) against float64, strided X, odd sizes; two runs are bit-identical."""
+    from dfol_vqa_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    xw = torch.randn(M, ldx, device=DEV, generator=g)
+    x = xw[:, :K]
+    a = _lib.linear_wgrad(dy, x)
+    b = _lib.linear_wgrad(dy, x)
+    assert torch.equal(a, b)
+    ref = dy.double().t() @ x.double()
+    scale = (dy.double().abs().t() @ x.double().abs()).max().item()
+    assert (a.double() - ref).abs().max().item() <= 2e-6 * scale, (a.double() - ref).abs().max().item() / scale
+    # the library's fp32 product is no closer
+    lib = (dy.t() @ x).double()
+    assert (a.double() - ref).abs().max().item() <= 4 * (lib - ref).abs().max().item() + 1e-7 * scale
+
+
+def test_reduce_by_question_and_prior_gradients_are_repeatable():
+    """Several predicates per question: the prior gradients of filter / relate are sums over a question's predicates, taken in a fixed
+    order (no atomics): equal to an fp64 sum and bit-identical across runs."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(3)
+    n_list, k_list = [9, 30, 4, 17], [3, 1, 5, 2]
+    Q = len(n_list)
+    pq = np.repeat(np.arange(Q), k_list).astype(np.int32)
+    P, NS = len(pq), 32
+    src = rng.normal(size=(P, NS)).astype(np.float32)
+    dev = lambda x: torch.tensor(x, device=DEV)
+    out = _lib.reduce_by_question(dev(src), dev(pq), dev(np.array(n_list, np.int32)), Q).cpu().numpy()
+    for q in range(Q):
+        ref = src[pq == q].astype(np.float64).sum(0)
+        ref[n_list[q]:] = 0
+        assert np.allclose(out[q], ref, atol=1e-5)
+    # relate backward twice: bit-identical prior and tile gradients
+    prior_s = np.minimum(rng.normal(size=(Q, NS)).astype(np.float32) - 1, 0)
+    prior_o = np.minimum(rng.normal(size=(Q, NS)).astype(np.float32) - 1, 0)
+    tile = (-np.abs(rng.normal(size=(P, NS, NS))) * 2).astype(np.float32)
+    quant = np.ones(P, np.float32)
+    gs, go = rng.normal(size=(P, NS)).astype(np.float32), rng.normal(size=(P, NS)).astype(np.float32)
+    runs = []
+    for _ in range(3):
+        r = _lib.relate_bwd(dev(prior_s), dev(prior_o), dev(tile), dev(pq), dev(np.array(n_list, np.int32)), dev(quant), dev(quant), None, None,
+                            dev(gs), dev(go), 0, False)
+        runs.append([t.cpu().numpy() for t in r])
+    for r in runs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(runs[0], r))
+
+
+@pytest.mark.parametrize("n_list,k_list,H", [([5, 12, 1, 30], [2, 1, 3, 1], 300), ([100, 64], [1, 26], 300), ([7, 9], [1, 1], 44)])
+def test_attr_ll_backward_against_autograd(n_list, k_list, H):
+    """csrc/dfol_logic_bwd.hip attr_ll_bwd (needed-columns attribute likelihood) against float64 autograd of the formulation it
+    replaces (row gathers, products, row sums, LogSigmoid): gradients w.r.t. the hidden activations, the embedding rows (repeated
+    concepts included: rows of equal concept are combined in a fixed order) and the biases; a no-op (-1) column in the batch."""
+    from dfol_vqa_amd.visual_oracle import _AttrLL, _concept_plan
+    rng = np.random.RandomState(sum(n_list) + H)
+    Q, C = len(n_list), 23
+    pq = np.repeat(np.arange(Q), k_list).astype(np.int32)
+    P = len(pq)
+    NS = max(4, (max(n_list) + 3) // 4 * 4)
+    O = sum(n_list)
+    obj_off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
+    cols = rng.randint(0, C, P).astype(np.int32)
+    if P > 2:
+        cols[1] = -1
+        cols[-1] = cols[0]                                   # a concept named by two predicates
+    hidden = torch.tensor(rng.uniform(0, 1, (O, H)).astype(np.float32), device=DEV, requires_grad=True)
+    E = torch.tensor((rng.normal(size=(C, H)) * 0.1).astype(np.float32), device=DEV, requires_grad=True)
+    b = torch.tensor(rng.normal(size=C).astype(np.float32), device=DEV, requires_grad=True)
+    g = torch.tensor(rng.normal(size=(P, NS)).astype(np.float32), device=DEV)
+    plan = _concept_plan(cols, DEV, {})
+    dev = lambda x: torch.tensor(x, device=DEV)
+    outs = []
+    for _ in range(2):
+        for t in (hidden, E, b):
+            t.grad = None
+        ll = _AttrLL.apply(hidden, E, b, dev(obj_off), dev(pq), dev(cols), NS, plan)
+        ll.backward(g)
+        outs.append((ll.detach().clone(), hidden.grad.clone(), E.grad.clone(), b.grad.clone()))
+    assert all(torch.equal(a, c) for a, c in zip(outs[0], outs[1]))            # repeatable bit for bit
+    h64, E64, b64 = (t.detach().double().requires_grad_(True) for t in (hidden, E, b))
+    ref = torch.full((P, NS), -30.0, dtype=torch.float64, device=DEV)
+    rows = []
+    for p in range(P):
+        q, n = pq[p], n_list[pq[p]]
+        if cols[p] < 0:
+            continue
+        x = h64[obj_off[q]:obj_off[q] + n] @ E64[cols[p]] + b64[cols[p]]
+        rows.append((p, n, torch.nn.functional.logsigmoid(x)))
+    loss = sum((r * g[p, :n].double()).sum() for p, n, r in rows)
+    loss.backward()
+    for p, n, r in rows:
+        assert torch.allclose(outs[0][0][p, :n].double(), r.detach(), atol=2e-6)
+    for got, want, name in ((outs[0][1], h64.grad, "d hidden"), (outs[0][2], E64.grad, "dE"), (outs[0][3], b64.grad, "db")):
+        scale = want.abs().max().item() + 1e-30
+        assert (got.double() - want).abs().max().item() <= 2e-5 * scale, name
+
+
+def test_train_step_is_bitwise_repeatable(ontology):
+    """One train step (forward, loss, backward, clip, Adam) on the needed-columns dataflow, twice from the same state: identical
+    loss, gradients and updated weights, bit for bit - the backward kernels sum in a fixed order instead of using atomics."""
+    a, meta = gu.load("g12_weight_gradients")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    for name in sorted(meta["sets"]):
+        qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+               "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}}
+              for i, q in enumerate(meta["sets"][name]["questions"])]
+        runs = []
+        for _ in range(2):
+            model = neural_model(ontology, meta["config"], weights).train()
+            pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate([dict(q) for q in qs])]
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+            loss, _ = training.train_batch(model, opt, pbs, clip_norm=0.65)
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            runs.append((loss, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        assert runs[0][0] == runs[1][0], name
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], runs[1][1][k]), (name, k)
+        for k in runs[0][2]:
+            assert torch.equal(runs[0][2][k], runs[1][2][k]), (name, k)

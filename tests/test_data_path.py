@@ -194,7 +194,7 @@ def test_preprocess_cli_to_bytecode(tmp_path, mini_ontology_paths):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gqa_preprocess.py"), str(tmp_path / "qs.json"), str(tmp_path / "out"),
                         "--op-map", str(tmp_path / "op_map.json"), "-b", "--attributes", p["attribute_file"], "--classes", p["class_file"],
-                        "--vocabulary", p["vocabulary_file"]], capture_output=True, text=True)
+                        "--vocabulary", p["vocabulary_file"], "--container", "npz"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     codec = ProgramCodec(GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], None))
     seen = 0
@@ -206,3 +206,103 @@ def test_preprocess_cli_to_bytecode(tmp_path, mini_ontology_paths):
             assert json.loads(json.dumps(got["program"])) == q["program"], (f, i, got["program"], q["program"])
             seen += 1
     assert seen == 3
+    from dfol_vqa_amd import h5lite
+    if h5lite.available():                                  # the default container where HDF5 exists: the reference's .h5 layout
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gqa_preprocess.py"), str(tmp_path / "qs.json"), str(tmp_path / "out5"),
+                            "--op-map", str(tmp_path / "op_map.json"), "-b", "--attributes", p["attribute_file"], "--classes", p["class_file"],
+                            "--vocabulary", p["vocabulary_file"]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for f in sorted(os.listdir(str(tmp_path / "out" / "p_qs"))):
+            stem = os.path.splitext(f)[0]
+            a = np.load(str(tmp_path / "out" / "h5_qs" / (stem + ".npz")))
+            with h5lite.File(str(tmp_path / "out5" / "h5_qs" / (stem + ".h5")), "r") as b:
+                for k in a.files:
+                    assert np.array_equal(a[k], b[k][...]), (f, k)
+
+
+# ---- real HDF5 containers (golden g16: written and read by the reference through the HDF5 C library) ---------------------------
+def _h5_or_skip():
+    from dfol_vqa_amd import h5lite
+    try:
+        import h5py  # noqa: F401
+        return
+    except ImportError:
+        pass
+    if not h5lite.available():
+        pytest.skip("neither h5py nor libhdf5 on this machine")
+
+
+def test_h5lite_round_trip(tmp_path):
+    """The ctypes binding of libhdf5: dtypes, shapes, row / slice / index-array reads, missing keys, real HDF5 bytes on disk."""
+    from dfol_vqa_amd import h5lite
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    rng = np.random.RandomState(0)
+    arrays = {"i32": (rng.randint(-50, 50, (5, 2, 10, 3))).astype(np.int32), "f32": rng.rand(7, 4).astype(np.float32),
+              "i64": np.arange(6, dtype=np.int64), "u8": rng.randint(0, 255, (3, 3)).astype(np.uint8), "f64": rng.rand(2, 2)}
+    path = str(tmp_path / "t.h5")
+    with h5lite.File(path, "w") as f:
+        for k, v in arrays.items():
+            f.create_dataset(k, data=v)
+    with open(path, "rb") as fh:
+        assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    with h5lite.File(path, "r") as f:
+        assert sorted(f.keys()) == sorted(arrays)
+        for k, v in arrays.items():
+            d = f[k]
+            assert d.shape == v.shape and d.dtype == v.dtype and len(d) == len(v)
+            assert np.array_equal(d[...], v) and np.array_equal(d[1], v[1]) and np.array_equal(d[-1], v[-1])
+            assert np.array_equal(d[1:3], v[1:3]) and np.array_equal(d[[len(v) - 1, 0]], v[[len(v) - 1, 0]])
+        assert "nope" not in f
+        with pytest.raises(KeyError):
+            f["nope"]
+    with pytest.raises(IOError):
+        h5lite.File(str(tmp_path / "missing.h5"), "r")
+
+
+def test_g16_reads_the_reference_written_hdf5(ontology, golden_dir):
+    """ProgramDataset on the .h5 files the reference's own encoder wrote: the same programs the reference's ProgramDataset decodes
+    from them (and the same as from golden g9's arrays)."""
+    _h5_or_skip()
+    _, meta = gu.load("g16_hdf5_containers")
+    a9, meta9 = gu.load("g9_program_bytecode")
+    for name, f in meta["files"].items():
+        path = os.path.join(golden_dir, "h5", "ref_%s.h5" % name)
+        arrays = data._open_arrays(path)
+        for k in data.ARRAYS:
+            assert np.array_equal(np.asarray(arrays[k][...]), a9[name + ":" + k]), (name, k)
+        for in_memory in (True, False):
+            ds = data.ProgramDataset(path, ontology, in_memory=in_memory, shuffle_options=False)
+            assert len(ds) == len(f["decoded"])
+            for i, ref in enumerate(f["decoded"]):
+                r = ds[i]
+                assert r["program"] == ref["program"] and r["image_id"] == ref["image_id"] and r["answer"] == ref["answer"], (name, i)
+                assert sorted(map(str, r["tokens"])) == ref["tokens"]
+                assert ref == meta9["files"][name]["decoded"][i]
+
+
+def test_g16_writes_the_reference_hdf5_layout(ontology, golden_dir, tmp_path):
+    """The encoder's output written as .h5: dataset names, shapes, dtypes and contents equal to the reference-written file."""
+    _h5_or_skip()
+    _, meta9 = gu.load("g9_program_bytecode")
+    codec = data.ProgramCodec(ontology)
+    for name, f in meta9["files"].items():
+        mine = str(tmp_path / (name + ".h5"))
+        data.write_arrays(mine, codec.encode(copy.deepcopy(f["questions"])))
+        a, b = data._open_arrays(mine), data._open_arrays(os.path.join(golden_dir, "h5", "ref_%s.h5" % name))
+        assert sorted(a.keys()) == sorted(b.keys()) == sorted(data.ARRAYS)
+        for k in data.ARRAYS:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype == np.int32
+            assert np.array_equal(np.asarray(a[k][...]), np.asarray(b[k][...])), (name, k)
+
+
+def test_g16_feature_chunks_from_hdf5(ontology, golden_dir):
+    """BatchGQABoxFeaturesCollator on .h5 feature chunks == the reference's collator on the same files
+    (batch_gqa_boxfeatures_pipeline.py:29-81)."""
+    _h5_or_skip()
+    a, meta = gu.load("g16_hdf5_containers")
+    h5dir = os.path.join(golden_dir, "h5")
+    coll = data.BatchGQABoxFeaturesCollator(h5dir, "gqa_objects", 2, os.path.join(h5dir, "gqa_objects_info.json"), ontology, split_num=1)
+    feats, bi = coll.collate_object_features([{"image_id": im} for im in meta["chunks"]["order"]])
+    assert np.array_equal(bi.numpy(), a["batch_index"])
+    assert feats.dtype == torch.float32 and np.allclose(feats.numpy(), a["features"], rtol=0, atol=1e-6)

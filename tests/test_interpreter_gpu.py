@@ -596,6 +596,51 @@ def test_graphed_forward_equals_eager(tmp_path):
         assert not torch.equal(r2["log_probability"], r["log_probability"])
 
 
+def test_graphed_forward_survives_cache_eviction(tmp_path):
+    """A captured graph holds raw device addresses; the tensors it reads out of evictable caches (uploaded index arrays, geometry,
+    packed weight images) must stay alive with the graph.  Evict every cache, let the allocator recycle and overwrite the freed
+    memory, replay: the result must not change (round-1 advisor finding)."""
+    import gc
+    from dfol_vqa_amd import _lib, experiment, fol_types, host_util
+    from dfol_vqa_amd.interpreter import GraphedForward
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(4)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    qs, scenes = _neural_questions("choose_attr", 8, 12, 12, 2048, seed=21, names=nm)
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])]
+    g = GraphedForward(model, pbs)
+    first = g()
+    lp0 = first["log_probability"].clone()
+    assert len(g._keep) > 0
+    # evict everything
+    host_util._upload_cache.clear()
+    _lib._SPLIT_W_CACHE.clear()
+    fol_types._geometry_cache.clear()
+    fol_types._pair_index_cache.clear()
+    ont.__dict__.get("_lower_cache", {}).clear()
+    model._oracle._split_cache = None
+    model._oracle._w2_cache = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    # recycle: forwards on other batches (new uploads, new packs) and junk written over whatever was freed
+    qs2, scenes2 = _neural_questions("exist", 6, 5, 9, 2048, seed=77, names=nm)
+    pbs2 = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs2, scenes2)])]
+    with torch.no_grad():
+        model(pbs2, False)
+    junk = [torch.full((1 << k,), float("nan"), device=DEV) for k in range(4, 22)]
+    torch.cuda.synchronize()
+    again = g()
+    assert torch.equal(again["log_probability"], lp0) and again["answer"] == first["answer"]
+    del junk
+
+
 def test_graphed_forward_with_calibration(ontology):
     """The calibrated forward (LSTM passes + modulations, ~230 launches per ProgramBatch) is captured and replayed as one graph."""
     from dfol_vqa_amd.interpreter import GraphedForward

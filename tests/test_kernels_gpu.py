@@ -522,6 +522,71 @@ def test_relate_exists_fast_path(L, n_list):
         gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path", lp_tol=2e-4)
 
 
+@pytest.mark.parametrize("n_list", [[5, 1, 8, 3], [36, 20, 33], [100, 37, 64, 2], [130, 256], [17, 9, 2, 12, 16]])
+def test_relate_negated_and_forall_fast_paths(L, n_list):
+    """Negated and FOR_ALL predicates take transcendental-poor forms too (negated EXISTS: product path on 1 - E with the diagonal
+    masked; FOR_ALL: plain sums of l' + prior, no exp / log at all when un-negated) and fall back to the clamping general code
+    when a term reaches the reference's 1e-20 floor.  Every (negation, quantifier) combination through both Relate kernels against
+    the oracle, with planted clamps (1 - E = 0; l' + prior below log 1e-20; E = P = 1) and garbage in the padding."""
+    rng = np.random.RandomState(sum(n_list) + 23)
+    k_list = [1 + (i % 2) for i in range(len(n_list))]
+    pq, NS, prior_s, prior_o, tile, _ = _logic_inputs(rng, n_list, k_list)
+    P, Q = len(pq), len(n_list)
+    n_obj = np.array(n_list, np.int32)
+    q0, n0 = pq[0], n_list[pq[0]]
+    if n0 >= 4:                                               # predicate 0 carries every kind of clamp
+        tile[0, 1, 2] = 0.0                                   # negated: 1 - E = 0
+        prior_s[q0, 1] = 0.0
+        prior_o[q0, 2] = 0.0                                  # un-negated EXISTS: E = P = 1
+        prior_o[q0, 3] = -40.0                                # FOR_ALL: l' + prior < log(1e-20)
+        tile[0, 0, 3] = -20.0
+    for p in range(P):
+        n = n_list[pq[p]]
+        tile[p, n:, :] = np.nan
+        tile[p, :, n:] = 7.0
+    for q, n in enumerate(n_list):
+        prior_s[q, n:] = 0.0
+        prior_o[q, n:] = 3.0
+    neg_sets = [None, np.ones(P, np.uint8), (np.arange(P) % 2).astype(np.uint8)]
+    for neg in neg_sets:
+        use_neg = neg is not None
+        for qs_v, qo_v in ((1.0, 1.0), (0.0, 0.0), (1.0, 0.0), (0.0, 1.0)):
+            quant = np.tile(np.asarray([[qs_v, qo_v]], np.float32), (P, 1))
+            refs = {}
+            for p in range(P):
+                q, n = pq[p], n_list[pq[p]]
+                if n >= 2:
+                    refs[p] = [orc.relate_block(prior_s[q, :n].astype(dt), prior_o[q, :n].astype(dt), tile[p, :n, :n].astype(dt),
+                                                quant[p, 0], quant[p, 1], float(neg[p]) if use_neg else 0.0, use_neg)
+                               for dt in (np.float32, np.float64)]
+            for orient in (0, 1):
+                t_in = tile if orient == 0 else np.ascontiguousarray(tile.transpose(0, 2, 1))
+                for da in (True, False):
+                    for want_bits in (3, 1, 2):
+                        ps, po = L.relate_fwd(dev(prior_s), dev(prior_o), dev(t_in), dev(pq), dev(n_obj), dev(quant[:, 0]), dev(quant[:, 1]),
+                                              dev(neg) if use_neg else None, None, dev(np.full(P, want_bits, np.uint8)), orient, diag_absent=da)
+                        ps, po = ps.cpu().numpy(), po.cpu().numpy()
+                        for p, r in refs.items():
+                            n = n_list[pq[p]]
+                            what = "neg=%s q=(%g,%g) orient=%d da=%s want=%d p=%d" % (None if neg is None else int(neg[p]), qs_v, qo_v, orient, da, want_bits, p)
+                            if want_bits & 1:
+                                gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "relate post_s " + what, lp_tol=2e-4)
+                                assert np.all(ps[p, n:] == 0)
+                            if want_bits & 2:
+                                gu.check_logprob(po[p, :n], r[0][1], r[1][1], "relate post_o " + what, lp_tol=2e-4)
+                                assert np.all(po[p, n:] == 0)
+            # the fused single-posterior kernel: x = the object variable (fresh), prev = the subject variable with quantifier qs_v;
+            # tiles stored with the summed-out (subject) variable along rows = the reference orientation
+            x_att, prev_att = prior_o[pq], prior_s
+            got = L.relate_one_fwd(dev(x_att), dev(prev_att), dev(tile), dev(pq), dev(n_obj), dev(quant[:, 0]),
+                                   dev(neg) if use_neg else None).cpu().numpy()
+            for p, r in refs.items():
+                n = n_list[pq[p]]
+                gu.check_logprob(got[p, :n], r[0][1], r[1][1], "relate_one neg=%s q_prev=%g p=%d" % (None if neg is None else int(neg[p]), qs_v, p),
+                                 lp_tol=2e-4)
+                assert np.all(got[p, n:] == 0)
+
+
 @pytest.mark.parametrize("hid1,hid2,K", [(256, 300, 3), (256, 300, 40), (256, 300, 60), (256, 320, 2), (256, 270, 2), (224, 288, 3),
                                          (64, 200, 2), (32, 12, 2)])
 def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):

@@ -1,0 +1,81 @@
+"""world_size-2 tests of the data-parallel path on the GPU: two fresh child processes share cuda:0 and meet over gloo
+(reference: data_parallel.py:54-83 scatter / replicate / gather, trainer.py:429-442 the train step).  Also drives bench.py's own
+launcher, which must start the ranks itself when no launcher did."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(case, tmp_path, world=2, timeout=420):
+    port = _free_port()
+    procs, paths = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+        path = str(tmp_path / ("%s_rank%d.json" % (case, r)))
+        paths.append(path)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_rank_worker.py"), case, path], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            p.wait(timeout=timeout)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs = []
+    for path in paths:
+        with open(path) as f:
+            outs.append(json.load(f))
+    for o in outs:
+        assert o["ok"], o.get("error")
+    return outs
+
+
+def test_two_rank_inference_equals_one_rank(tmp_path):
+    outs = _run_ranks("infer", tmp_path)
+    r0 = [o for o in outs if o["rank"] == 0][0]
+    assert r0["gathered"] == 24
+    assert r0["bit_equal"], r0["max_abs_diff"]
+    assert r0["answers_equal"]
+
+
+def test_two_rank_train_step_matches_g12_and_replicas_stay_equal(tmp_path):
+    outs = _run_ranks("train", tmp_path)
+    r0 = [o for o in outs if o["rank"] == 0][0]
+    assert r0["g12_checked"] and all(n == 12 for n in r0["g12_checked"].values()), r0["g12_checked"]
+    assert all(o["replicas_equal"] for o in outs)
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_launches_its_own_ranks(mode):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts two ranks (DFOL_BENCH_SHARE_GPU=1: both on cuda:0, gloo)."""
+    env = dict(os.environ, DFOL_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--objects", "20",
+           "--cpu-sample", "0", "--stress-preds", "0", "--mode", mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
+    if mode == "train":
+        assert out["replicas_equal"] is True

@@ -75,6 +75,62 @@ def _worker(rank, world, port, out):
         both = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1])
+
+        # ---- replicas that start different are made equal by ONE broadcast (params and buffers) ------
+        torch.manual_seed(100 + rank)
+        m2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 1))
+        m2[1].running_mean.add_(rank + 1.0)
+        before = parallel.parameters_digest(m2)
+        nb = parallel.broadcast_parameters(m2, src=0)
+        assert nb == 4 * (sum(p.numel() for p in m2.parameters()) + sum(b.numel() for b in m2.buffers() if b.numel()))
+        dg = parallel.parameters_digest(m2)
+        both = [torch.zeros_like(dg) for _ in range(world)]
+        dist.all_gather(both, dg)
+        assert torch.equal(both[0], both[1])
+        assert rank == 0 or not torch.equal(before, dg)
+        rm = [torch.zeros_like(m2[1].running_mean) for _ in range(world)]
+        dist.all_gather(rm, m2[1].running_mean)
+        assert torch.equal(rm[0], rm[1])
+
+        # ---- persistent bucket + the step's L1 term: 2-rank step == single-process step ----------------
+        from dfol_vqa_amd import training
+        torch.manual_seed(7)
+        net = torch.nn.Linear(6, 1)
+        xs, ys = torch.randn(8, 6), (torch.rand(8) > 0.5)
+        lam = 0.3
+
+        class _PB(object):
+            def __init__(self, answers):
+                self._answers = answers
+
+            def batch_size(self):
+                return len(self._answers)
+
+        class _Model(torch.nn.Module):
+            def __init__(self, lin):
+                super(_Model, self).__init__()
+                self.lin = lin
+
+            def forward(self, data, is_training):
+                lp = torch.nn.functional.logsigmoid(self.lin(data[0].x)).reshape(-1)
+                return {"log_probability": lp, "type": QuestionType.BINARY, "options": ["no", "yes"]}
+
+        def step(lin, lo, hi, group, world_b):
+            model = _Model(lin)
+            pb = _PB(["yes" if y else "no" for y in ys[lo:hi]])
+            pb.x = xs[lo:hi]
+            params = list(model.parameters())
+            opt = torch.optim.SGD(params, lr=0.1)
+            bucket = parallel.GradBucket(params)
+            training.train_batch(model, opt, [pb], clip_norm=1e9, global_batch_size=world_b, group=group, l1_lambda=lam, bucket=bucket)
+            assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in params)     # the views survived the step
+            return torch.cat([p.detach().reshape(-1) for p in params])
+
+        import copy
+        s2, e2 = parallel.shard_bounds([1.0] * 8, world)[rank]
+        sharded = step(copy.deepcopy(net), s2, e2, dist.group.WORLD, 8)
+        single = step(copy.deepcopy(net), 0, 8, None, None)
+        assert torch.allclose(sharded, single, atol=1e-6), (sharded, single)
         out.put((rank, "ok"))
     except Exception as exc:  # pragma: no cover
         out.put((rank, repr(exc)))
@@ -93,3 +149,27 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def _bench(args, env_extra):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DFOL_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """bench.py --gpus N must never print a line for a different world size (round-1 finding: the flag was ignored)."""
+    r = _bench(["--gpus", "2", "--steps", "1"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_launcher_needs_the_gpus_it_is_asked_for():
+    """Without a launcher, --gpus 2 starts its own ranks - and says so loudly when the box has fewer GPUs (none here)."""
+    if torch.cuda.device_count() >= 2:
+        return
+    r = _bench(["--gpus", "2", "--steps", "1"], {})
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

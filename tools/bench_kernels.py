@@ -57,6 +57,15 @@ def main():
     t = timeit(lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones))
     b1 = 4 * N * N + 12 * N
     out.append({"kernel": "relate_one", "P": P, "N": N, "ms": t * 1e3, "GBps": b1 * P / t / 1e9, "frac_hbm_peak": b1 * P / t / HBM_PEAK})
+    # the other predicate kinds (negated, FOR_ALL): what used to be the transcendental-bound "general path"
+    zeros = torch.zeros(P, device=dev)
+    negs = torch.ones(P, dtype=torch.uint8, device=dev)
+    for label, q, ng in (("negated EXISTS", ones, negs), ("FOR_ALL", zeros, None), ("negated FOR_ALL", zeros, negs)):
+        t = timeit(lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, q, ng))
+        out.append({"kernel": "relate_one (%s)" % label, "P": P, "N": N, "ms": t * 1e3, "GBps": b1 * P / t / 1e9, "frac_hbm_peak": b1 * P / t / HBM_PEAK})
+        b2 = 4 * N * N + 16 * N
+        t = timeit(lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, q, q, ng, diag_absent=True))
+        out.append({"kernel": "relate_both (%s)" % label, "P": P, "N": N, "ms": t * 1e3, "GBps": b2 * P / t / 1e9, "frac_hbm_peak": b2 * P / t / HBM_PEAK})
     # BASELINE configs[4]: 256-object tiles, fp32 vs bf16 storage (algorithmic bytes 4N^2 + 12N vs 2N^2 + 12N per predicate)
     if N == 100:
         P2, N2 = max(P // 8, 256), 256
@@ -91,7 +100,27 @@ def main():
     out.append({"kernel": "filter", "P": P, "N": N, "ms": t * 1e3, "GBps": 12 * N * P / t / 1e9, "frac_hbm_peak": 12 * N * P / t / HBM_PEAK})
     t = timeit(lambda: L.quantify_fwd(prior, ones, pq, n_obj))
     out.append({"kernel": "quantify", "P": P, "N": N, "ms": t * 1e3, "GBps": (4 * N + 4) * P / t / 1e9})
-    del tile
+    del tile, ll
+    # the small kernels on HBM-sized inputs (>= 512 MB of blocks, beyond the 256 MiB Infinity Cache): 79 MB of blocks sit in the cache
+    PF = 1 << 19
+    g3 = torch.Generator(device=dev).manual_seed(3)
+    llf = torch.log(torch.rand(PF, NS, device=dev, generator=g3).clamp_min(1e-5))
+    prf = torch.log(torch.rand(PF, NS, device=dev, generator=g3).clamp_min(1e-3)) * 0.3
+    pqf = torch.arange(PF, dtype=torch.int32, device=dev)
+    nof = torch.full((PF,), N, dtype=torch.int32, device=dev)
+    t = timeit(lambda: L.filter_fwd(prf, llf, pqf, nof))
+    out.append({"kernel": "filter (HBM-sized)", "P": PF, "N": N, "MB": 12 * N * PF / 1e6, "ms": t * 1e3, "GBps": 12 * N * PF / t / 1e9,
+                "frac_hbm_peak": 12 * N * PF / t / HBM_PEAK})
+    del llf
+    PQ = 1 << 21
+    prq = torch.log(torch.rand(PQ, NS, device=dev, generator=g3).clamp_min(1e-3)) * 0.3
+    pqq = torch.arange(PQ, dtype=torch.int32, device=dev)
+    noq = torch.full((PQ,), N, dtype=torch.int32, device=dev)
+    onq = torch.ones(PQ, device=dev)
+    t = timeit(lambda: L.quantify_fwd(prq, onq, pqq, noq))
+    out.append({"kernel": "quantify (HBM-sized)", "P": PQ, "N": N, "MB": (4 * N + 4) * PQ / 1e6, "ms": t * 1e3, "GBps": (4 * N + 4) * PQ / t / 1e9,
+                "frac_hbm_peak": (4 * N + 4) * PQ / t / HBM_PEAK})
+    del prq, prf, pqq, noq, onq, pqf, nof
     for (M, Nn, K, act) in ((25600, 512, 2048, 1), (25600, 512, 516, 0), (25600, 256, 516, 2), (25600, 300, 256, 1), (9216, 512, 2048, 1), (9216, 512, 516, 0),
                               (9216, 256, 516, 2), (9216, 300, 256, 1), (9216, 2335, 300, 3)):
         x = torch.rand(M, K, device=dev) - 0.5

@@ -765,6 +765,77 @@ def g9():
     save("g9_program_bytecode", arrays, meta)
 
 
+# ---------------------------------------------------------------------------------------- g16
+def g16():
+    """The HDF5 containers themselves: the reference's GQAH5Encoder writes REAL .h5 files (h5py is not installed here; its slot in
+    sys.modules is taken by dfol_vqa_amd/h5lite.py, a ctypes binding of the same HDF5 C library h5py wraps) and the reference's
+    ProgramDataset and BatchGQABoxFeaturesCollator read them back (gqa_preprocess.py:51-94, data_pipeline.py:328-389,
+    batch_gqa_boxfeatures_pipeline.py:15-81).  The files are committed under tests/golden/h5/ as data fixtures."""
+    import shutil
+    import tempfile
+    from dfol_vqa_amd import h5lite
+    saved = sys.modules.get("h5py")
+    sys.modules["h5py"] = h5lite
+    ref.data_pipeline.h5py = h5lite
+    sys.path.insert(0, ref_harness.REF_SRC)
+    for name in ("pattern", "pattern.text", "pattern.text.en"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.singularize = lambda w: w
+        sys.modules.setdefault(name, m)
+    import gqa_preprocess
+    gqa_preprocess.h5py = h5lite
+    from nsvqa.data import batch_gqa_boxfeatures_pipeline as bfp
+    bfp.h5py = h5lite
+    with open(os.path.join(OUT, "g9_program_bytecode.json")) as fh:
+        meta9 = json.load(fh)
+    files = {k: v["questions"] for k, v in meta9["files"].items()}
+    tmp_in, tmp_out = tempfile.mkdtemp(), tempfile.mkdtemp()
+    for name, qs in files.items():
+        with open(os.path.join(tmp_in, name + ".json"), "w") as f:
+            for q in qs:
+                f.write(json.dumps(q) + "\n")
+    gqa_preprocess.GQAH5Encoder(ontology).encode(tmp_in, tmp_out)
+    h5dir = os.path.join(OUT, "h5")
+    os.makedirs(h5dir, exist_ok=True)
+    meta = {"source": "gqa_preprocess.py:51-94; data_pipeline.py:328-389; batch_gqa_boxfeatures_pipeline.py:15-81", "files": {}}
+    orig_shuffle = ref.data_pipeline.shuffle
+    ref.data_pipeline.shuffle = lambda x: None
+    for name in files:
+        shutil.copy(os.path.join(tmp_out, name + ".h5"), os.path.join(h5dir, "ref_" + name + ".h5"))
+        ds = ref.data_pipeline.ProgramDataset(os.path.join(h5dir, "ref_" + name + ".h5"), ontology, in_memory=False)
+        decoded = []
+        for i in range(len(ds)):
+            r = ds[i]
+            decoded.append({"program": r["program"], "image_id": r["image_id"], "answer": r["answer"], "tokens": sorted(map(str, r["tokens"]))})
+        meta["files"][name] = {"decoded": decoded}
+    ref.data_pipeline.shuffle = orig_shuffle
+    # object-feature chunks: two chunk files of three images, read through the reference's collator
+    rng = np.random.RandomState(16)
+    F, max_obj = 16, 6
+    info = {}
+    for c in range(2):
+        feats = rng.uniform(0, 1, (3, max_obj, F)).astype(np.float32)
+        boxes = np.zeros((3, max_obj, 4), np.float32)
+        boxes[..., :2] = rng.uniform(0, 300, (3, max_obj, 2))
+        boxes[..., 2:] = boxes[..., :2] + rng.uniform(5, 100, (3, max_obj, 2))
+        with h5lite.File(os.path.join(h5dir, "gqa_objects_%d.h5" % c), "w") as f:
+            f.create_dataset("features", data=feats)
+            f.create_dataset("bboxes", data=boxes)
+        for i in range(3):
+            info["img%03d" % (3 * c + i)] = {"idx": i, "file": c, "objectsNum": int(rng.randint(1, max_obj + 1)), "width": 640, "height": 480}
+    with open(os.path.join(h5dir, "gqa_objects_info.json"), "w") as f:
+        json.dump(info, f)
+    coll = bfp.BatchGQABoxFeaturesCollator(h5dir, "gqa_objects", 2, os.path.join(h5dir, "gqa_objects_info.json"), ontology, 1)
+    order = ["img004", "img000", "img005", "img002"]
+    feats, bi = coll.collate_object_features([{"image_id": im} for im in order])
+    arrays = {"features": feats.numpy(), "batch_index": bi.numpy()}
+    meta["chunks"] = {"order": order, "feature_dim": F, "max_objects": max_obj}
+    save("g16_hdf5_containers", arrays, meta)
+    if saved is not None:
+        sys.modules["h5py"] = saved
+
+
 # ---------------------------------------------------------------------------------------- g10
 def g10():
     """Attention calibration on (activate_attention_transfer): LSTM forward/backward passes + apply_modulations

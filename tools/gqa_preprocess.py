@@ -7,7 +7,8 @@ Same flags as the reference's src/gqa_preprocess.py:363-398; paths that the refe
          [-b --attributes gqa_all_attribute.json --classes gqa_all_class.json --vocabulary gqa_vocab.json]
 
 writes out_dir/p_<name>/p_<name>_<operator>[_<length>].json (one question per line) and, with -b, the bytecode of every such file
-as out_dir/h5_<name>/<same stem>.npz (the six int32 arrays of the reference's .h5 files; `ProgramDataset` reads either container).
+as out_dir/h5_<name>/<same stem>.h5 - the reference's HDF5 layout (six int32 datasets, gqa_preprocess.py:87-93), written through h5py or,
+without it, the HDF5 C library (dfol_vqa_amd/h5lite.py); `--container npz` writes .npz instead.  `ProgramDataset` reads either.
 """
 import argparse
 import json
@@ -29,6 +30,7 @@ def main():
     ap.add_argument('-l', '--length_segregation', action='store_true', help='one file per (terminal operator, first-branch length)')
     ap.add_argument('-g', '--discard_global', action='store_true', help="drop 'select scene' questions")
     ap.add_argument('--attributes'), ap.add_argument('--classes'), ap.add_argument('--vocabulary')
+    ap.add_argument('--container', choices=('h5', 'npz'), default=None, help='bytecode container (default: h5 when HDF5 is available, else npz)')
     args = ap.parse_args()
 
     name = os.path.basename(os.path.normpath(args.input_file))
@@ -41,7 +43,14 @@ def main():
     if args.h5:
         if not (args.attributes and args.classes and args.vocabulary):
             ap.error('-b needs --attributes, --classes and --vocabulary')
-        from dfol_vqa_amd.data import ProgramCodec
+        from dfol_vqa_amd.data import ProgramCodec, write_arrays
+        if args.container is None:
+            from dfol_vqa_amd import h5lite
+            try:
+                h5lite.import_h5py()
+                args.container = 'h5'
+            except IOError:
+                args.container = 'npz'
         from dfol_vqa_amd.gqa_ops import GQAOntology
         codec = ProgramCodec(GQAOntology(args.attributes, args.classes, args.vocabulary, None))
         code_dir = os.path.join(args.output_path, 'h5_' + name)
@@ -50,7 +59,7 @@ def main():
             with open(os.path.join(out_dir, f)) as fh:
                 questions = [json.loads(line) for line in fh if line.strip()]
             if questions:
-                np.savez(os.path.join(code_dir, os.path.splitext(f)[0] + '.npz'), **codec.encode(questions))
+                write_arrays(os.path.join(code_dir, os.path.splitext(f)[0] + '.' + args.container), codec.encode(questions))
                 print('%s: %d questions' % (f, len(questions)))
 
 

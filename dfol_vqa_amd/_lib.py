@@ -51,6 +51,7 @@ SIGNATURES = {
     "dfol_reduce_by_question_f32": [_p, _p, _p, _i32, _i32, _i32, _p, _p],
     "dfol_filter_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
     "dfol_relate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
+    "dfol_linear_wgrad_slabs": [_i64, _i32, _i32],          # returns a count, not a status: called directly, not through call()
     "dfol_linear_wgrad_f32": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p],
     "dfol_attr_ll_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p, _p],
     "dfol_quantify_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p],
@@ -90,8 +91,6 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.dfol_last_error.restype = ctypes.c_char_p
     lib.dfol_abi_version.restype = ctypes.c_int
-    lib.dfol_linear_wgrad_slabs.argtypes = [_i64, _i32, _i32]
-    lib.dfol_linear_wgrad_slabs.restype = ctypes.c_int
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

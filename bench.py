@@ -422,11 +422,13 @@ def train_main(args, rank, world, device, td, share):
         lt = torch.tensor([loss], device="cpu" if share else device, dtype=torch.float64)
         td.all_reduce(lt)
         loss = float(lt.item())
+    # per-kernel times of two more steps (every rank runs them: the step contains the collective; rank 0 keeps the numbers)
     if rank == 0:
         L.enable_kernel_timing(list(L.SIGNATURES))
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         timing = L.disable_kernel_timing()
         per_step = {k: (n / 2.0, t / 2.0) for k, (n, t) in timing.items() if n}
         out = {"metric": "training questions/sec (GQA programs, N=%s objects; forward + backward + all-reduce + clip + Adam)"

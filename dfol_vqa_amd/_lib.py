@@ -325,7 +325,9 @@ def compare(lp1, lp2, is_less):
 
 
 _SPLIT_W_CACHE = {}                    # (data_ptr, version, shape, stride) -> (weight kept alive, packed image)
-SPLIT_MIN_FLOPS = 2.0e8               # below this the fp32 kernel's single launch is as fast
+SPLIT_MIN_WEIGHT = 65536              # weights of at least this many elements run on the bf16x3 split kernel, WHATEVER the row count:
+#                                       the kernel choice must not depend on the batch size, or a question sharded across ranks would
+#                                       see different roundings than in one process (tests/test_multirank_gpu.py asserts bit-equality)
 
 
 def linear_pack_w_split(weight, transpose=False):
@@ -380,7 +382,7 @@ def linear_gradx(dz, weight):
     """dx = dz @ weight (dz [M, N], weight [N, K]): the input gradient of y = x W^T, on the same kernels as the forward."""
     M, N = dz.shape
     K = weight.shape[1]
-    if 2.0 * M * N * K >= SPLIT_MIN_FLOPS and N % 4 == 0 and dz.stride(0) % 2 == 0 and dz.data_ptr() % 8 == 0 and _dense_math() != "f32":
+    if N * K >= SPLIT_MIN_WEIGHT and N % 4 == 0 and dz.stride(0) % 2 == 0 and dz.data_ptr() % 8 == 0 and _dense_math() != "f32":
         return linear_act_split(dz, weight, None, ACT_NONE, transpose_w=True)
     return linear_act(dz, weight.detach().t().contiguous(), None, ACT_NONE)
 
@@ -399,7 +401,7 @@ def linear_act(x, weight, bias, act, out=None):
     for t in (x, weight, out):
         if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
             raise DfolError("linear_act needs fp32 GPU matrices with unit column stride")
-    if 2.0 * M * N * K >= SPLIT_MIN_FLOPS and K % 4 == 0 and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0 and _dense_math() != "f32":
+    if N * K >= SPLIT_MIN_WEIGHT and K % 4 == 0 and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0 and _dense_math() != "f32":
         return linear_act_split(x, weight, bias, act, out)
     call("dfol_linear_act_f32", x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias, F32, True),
          out.data_ptr(), out.stride(0), M, N, K, act, _stream())

@@ -123,37 +123,54 @@ extern "C" int dfol_option_normalize_f32(float* ll, const int32_t* seg_off, int3
 // =====================================================================================================
 // Filter (arity-1 logic cell)
 // =====================================================================================================
-__global__ void filter_fwd_kernel(const float* __restrict__ att_in, const float* __restrict__ ll,
-                                  const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj,
-                                  const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active, int NS,
-                                  float* __restrict__ att_out) {
-    const int p = blockIdx.x;
-    const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
-    if (c0 >= NS) return;
-    const int q = pred_q[p];
-    const int n = n_obj[q];
-    const float4 a = *reinterpret_cast<const float4*>(att_in + (int64_t)q * NS + c0);
-    float4 out = a;
-    if (active == nullptr || active[p]) {
-        const float4 l4 = *reinterpret_cast<const float4*>(ll + (int64_t)p * NS + c0);
-        float l[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float av[4] = {a.x, a.y, a.z, a.w};
-        float o[4];
-        const float alpha = (any_neg && neg[p]) ? 1.f : 0.f;
-        const float cc = 1.f - 2.f * alpha;
+// The [P, NS] blocks are streamed as one flat array of float4: a thread handles FILTER_UNR float4s a workgroup-stride apart, all
+// loads of the thread issued before the arithmetic.  (One 64-thread workgroup per predicate - the first version - left most lanes
+// of a 100-object block idle and ran at 0.48 of the HBM peak once the input no longer fitted the Infinity Cache.)
+constexpr int FILTER_UNR = 4;
+
+__global__ __launch_bounds__(256) void filter_fwd_kernel(const float* __restrict__ att_in, const float* __restrict__ ll,
+                                                         const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj,
+                                                         const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
+                                                         int64_t total4, int NS4, float* __restrict__ att_out) {
+    const int64_t base = (int64_t)blockIdx.x * (256 * FILTER_UNR) + threadIdx.x;
+    float4 a[FILTER_UNR], l4[FILTER_UNR];
+    int p[FILTER_UNR], c0[FILTER_UNR], n[FILTER_UNR];
+    bool act[FILTER_UNR];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = fminf(l[j], 0.f);                       // batch_base_ops.py:194
-            if (any_neg) v = dfol_pnot(v, alpha, cc);         // :212-213
-            o[j] = av[j] + v;                                 // :138
-        }
-        out = make_float4(o[0], o[1], o[2], o[3]);
+    for (int u = 0; u < FILTER_UNR; ++u) {
+        const int64_t idx = min(base + u * 256, total4 - 1);
+        p[u] = (int)(idx / NS4);
+        c0[u] = (int)(idx - (int64_t)p[u] * NS4) * 4;
+        const int q = pred_q[p[u]];
+        n[u] = n_obj[q];
+        act[u] = active == nullptr || active[p[u]];
+        a[u] = *reinterpret_cast<const float4*>(att_in + ((int64_t)q * NS4 * 4 + c0[u]));
+        l4[u] = *reinterpret_cast<const float4*>(ll + idx * 4);
     }
-    if (c0 + 0 >= n) out.x = 0.f;
-    if (c0 + 1 >= n) out.y = 0.f;
-    if (c0 + 2 >= n) out.z = 0.f;
-    if (c0 + 3 >= n) out.w = 0.f;
-    *reinterpret_cast<float4*>(att_out + (int64_t)p * NS + c0) = out;
+#pragma unroll
+    for (int u = 0; u < FILTER_UNR; ++u) {
+        if (base + u * 256 >= total4) break;
+        float4 out = a[u];
+        if (act[u]) {
+            const float l[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w};
+            const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+            float o[4];
+            const float alpha = (any_neg && neg[p[u]]) ? 1.f : 0.f;
+            const float cc = 1.f - 2.f * alpha;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = fminf(l[j], 0.f);                       // batch_base_ops.py:194
+                if (any_neg) v = dfol_pnot(v, alpha, cc);         // :212-213
+                o[j] = av[j] + v;                                 // :138
+            }
+            out = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (c0[u] + 0 >= n[u]) out.x = 0.f;
+        if (c0[u] + 1 >= n[u]) out.y = 0.f;
+        if (c0[u] + 2 >= n[u]) out.z = 0.f;
+        if (c0[u] + 3 >= n[u]) out.w = 0.f;
+        *reinterpret_cast<float4*>(att_out + (base + u * 256) * 4) = out;
+    }
 }
 
 extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const int32_t* pred_q, const int32_t* n_obj,
@@ -163,9 +180,9 @@ extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const i
     if (P == 0) return 0;
     DFOL_REQUIRE(att_in && ll && pred_q && n_obj && att_out, "filter_fwd: null pointer");
     DFOL_REQUIRE(!any_neg || neg, "filter_fwd: any_neg set but neg is NULL");
-    dim3 grid(P, dfol_cdiv(NS / 4, 64));
-    hipLaunchKernelGGL(filter_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, att_in, ll, pred_q, n_obj, neg, any_neg, active,
-                       NS, att_out);
+    const int64_t total4 = (int64_t)P * (NS / 4);
+    hipLaunchKernelGGL(filter_fwd_kernel, dim3(dfol_cdiv(total4, 256 * FILTER_UNR)), dim3(256), 0, (hipStream_t)stream, att_in, ll, pred_q,
+                       n_obj, neg, any_neg, active, total4, NS / 4, att_out);
     DFOL_LAUNCH_CHECK("filter_fwd");
     return 0;
 }
@@ -960,13 +977,81 @@ __global__ __launch_bounds__(256) void quantify_fwd_kernel(const float* __restri
     if (lane == 0) lp[p] = dfol_pnot(s, qf, k);                          // :123
 }
 
+// NS a multiple of 4 (every block the interpreter builds): LPP = the power of two >= NS / 4 lanes cover one predicate with ONE 16-byte
+// load each, 64 / LPP predicates share a wavefront and QUANT_UNR such groups are in flight per wavefront (one wavefront per 400-byte
+// block - the kernel above - ran at 0.17 of the HBM peak on HBM-sized inputs).  EXISTS predicates take the sum of
+// log(max(1 - e^a, eps)) over a lane's four elements as the log of the product of the four factors when none of them is below eps.
+constexpr int QUANT_UNR = 4;
+
+template <int LPP>
+__global__ __launch_bounds__(256) void quantify_fwd4_kernel(const float* __restrict__ att, const float* __restrict__ quant,
+                                                            const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj,
+                                                            int P, int NS, float* __restrict__ lp) {
+    constexpr int PPW = 64 / LPP;
+    constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int sub = lane / LPP, c0 = (lane % LPP) * 4;
+    const bool col_ok = c0 < NS;
+    float4 v[QUANT_UNR];
+    int pp[QUANT_UNR], n[QUANT_UNR];
+    float qf[QUANT_UNR];
+#pragma unroll
+    for (int u = 0; u < QUANT_UNR; ++u) {
+        const int p = (wave * QUANT_UNR + u) * PPW + sub;
+        pp[u] = p;
+        const int pc = min(p, P - 1);
+        n[u] = n_obj[pred_q[pc]];
+        qf[u] = quant[pc];
+        v[u] = *reinterpret_cast<const float4*>(att + (int64_t)pc * NS + (col_ok ? c0 : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < QUANT_UNR; ++u) {
+        const float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const float k = 1.f - 2.f * qf[u];
+        float s;
+        if (qf[u] == 1.f) {                                              // EXISTS: log2 of the product of the (1 - e^a) factors
+            float f[4], fmin = 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = (col_ok && c0 + j < n[u]) ? 1.f - __builtin_amdgcn_exp2f(a[j] * L2E) : 1.f;
+                fmin = fminf(fmin, f[j]);
+            }
+            if (fmin >= 1.0e-9f) {
+                s = __builtin_amdgcn_logf((f[0] * f[1]) * (f[2] * f[3])) * LN2;
+            } else {                                                     // a factor near the 1e-20 floor: clamp each one (util.py:25)
+                s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += __builtin_amdgcn_logf(fmaxf(f[j], DFOL_EPS)) * LN2;
+            }
+        } else {
+            s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (col_ok && c0 + j < n[u]) ? dfol_pnot(a[j], qf[u], k) : 0.f;      // batch_base_types.py:116
+        }
+        s = dfol_group_sum<LPP>(s);                                      // :118-121 (valid in the last lane of the group)
+        if (lane % LPP == LPP - 1 && pp[u] < P) lp[pp[u]] = dfol_pnot(s, qf[u], k);      // :123
+    }
+}
+
 extern "C" int dfol_quantify_fwd_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
                                      int32_t P, int32_t NS, float* lp, void* stream) {
     DFOL_REQUIRE(P >= 0 && NS > 0, "quantify_fwd: bad sizes P=%d NS=%d", P, NS);
     if (P == 0) return 0;
     DFOL_REQUIRE(att && quant && pred_q && n_obj && lp, "quantify_fwd: null pointer");
-    hipLaunchKernelGGL(quantify_fwd_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, att, quant, pred_q, n_obj, P,
-                       NS, lp);
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = NS / 4;
+#define DFOL_QUANT4(L)                                                                                                                  \
+    hipLaunchKernelGGL(quantify_fwd4_kernel<L>, dim3(dfol_cdiv(P, 4 * QUANT_UNR * (64 / L))), dim3(256), 0, st, att, quant, pred_q, n_obj, P, NS, lp)
+    if (NS % 4 != 0 || groups > 64)
+        hipLaunchKernelGGL(quantify_fwd_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, att, quant, pred_q, n_obj, P, NS, lp);
+    else if (groups <= 1) DFOL_QUANT4(1);
+    else if (groups <= 2) DFOL_QUANT4(2);
+    else if (groups <= 4) DFOL_QUANT4(4);
+    else if (groups <= 8) DFOL_QUANT4(8);
+    else if (groups <= 16) DFOL_QUANT4(16);
+    else if (groups <= 32) DFOL_QUANT4(32);
+    else DFOL_QUANT4(64);
+#undef DFOL_QUANT4
     DFOL_LAUNCH_CHECK("quantify_fwd");
     return 0;
 }

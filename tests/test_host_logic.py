@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import golden_util as gu  # noqa: E402
 import dfol_vqa_amd as D  # noqa: E402
 from dfol_vqa_amd import host_util as hu  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
 from dfol_vqa_amd.fol_types import TokenType  # noqa: E402
 from oracle import dfol_oracle as orc  # noqa: E402
 
@@ -154,3 +155,34 @@ def test_evaluation_metrics():
     training.accumulate_test_batch(err, tot, [pq], predq)
     d = training.metric_dict(err / np.maximum(tot, 1))
     assert abs(d["exist"] - 0.5) < 1e-6 and abs(d["query_attr"] - 0.5) < 1e-6 and abs(d["over_all"] - (2 + 1.5) / 7) < 1e-6
+
+
+def test_reference_config_yamls_build(tmp_path):
+    """Every config YAML shipped with the reference (config/*.yaml: the sample and the curriculum stages cur1..cur7) loads through
+    experiment.load_config / build_model (base_experiment.py:43-47, gqa_interpreter_experiments.py:107-240) with the reference's parameter
+    counts.  The YAMLs themselves stay in the reference tree; where it is absent (the GPU box) the schema is exercised
+    on the keys of config/sample_config.yaml restated in synthetic.reference_config."""
+    import glob
+    from dfol_vqa_amd import experiment
+    paths, _ = syn.write_synthetic_ontology(str(tmp_path))
+    files = sorted(glob.glob("/root/reference/config/**/*.yaml", recursive=True))
+    cfgs = []
+    for f in files:
+        cfg = experiment.load_config(f)
+        cfg.update(paths)
+        cfgs.append((os.path.basename(f), cfg))
+    if not cfgs:
+        cfgs = [("sample (restated)", syn.reference_config(paths)), ("calibrator (restated)", syn.reference_config(paths, activate_attention_transfer=True))]
+    assert len(cfgs) in (2, 9)
+    trainable = set()
+    for name, cfg in cfgs:
+        ont = experiment.build_ontology(cfg)
+        model = experiment.build_model(cfg, ont)
+        total = sum(p.numel() for p in model.parameters())
+        assert total in (2303948, 2452352), (name, total)                       # without / with the attention-transfer networks
+        assert total == (2452352 if cfg.get("activate_attention_transfer") else 2303948), (name, total)
+        trainable.add(sum(p.numel() for p in model.parameters() if p.requires_grad))
+        names = set(model.state_dict())
+        assert "_oracle._embedding_network._network.1.weight" in names and "_featurizer._featurizer_network._network.1.weight" in names
+    if len(cfgs) == 9:                                       # oracle phases, embedding-frozen phase, calibrator phases (SURVEY.md 2)
+        assert trainable == {2303947, 1254859, 148404}, trainable

@@ -688,3 +688,89 @@ def test_full_size_fused_equals_full_tables_fuzz(tmp_path, kind):
         la, lb = a["log_probability"].cpu().numpy(), b["log_probability"].cpu().numpy()
         assert np.abs(np.exp(la) - np.exp(lb)).max() <= 2e-5, (kind, rnd, np.abs(np.exp(la) - np.exp(lb)).max())
         assert np.abs(la - lb).max() <= 2e-3 * max(1.0, np.abs(lb).max()), (kind, rnd, np.abs(la - lb).max())
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[2]'s shape: the full operator set on ragged scenes of 60..100 objects, full-size model
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_size(tmp_path_factory):
+    from dfol_vqa_amd import experiment
+    d = str(tmp_path_factory.mktemp("fullsize"))
+    paths, names = syn.write_synthetic_ontology(d)
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(2)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    with open(paths["attribute_file"]) as f:
+        import json
+        categories = json.load(f)
+    return model, ont, oont, weights, names, categories
+
+
+def _full_size_questions(kind, count, n_lo, n_hi, names, categories, seed):
+    rng = np.random.RandomState(seed)
+    op = syn.op
+    nouns, rels = names["nouns"][:8], names["relations"][:5]
+    cats = sorted(categories)[:3]
+    attrs = [a for c in cats for a in categories[c][:4]]
+    qs, scenes = [], []
+    for i in range(count):
+        qid = seed * 1000 + i
+        pick = lambda xs: xs[rng.randint(len(xs))]
+        branch = [op("select", pick(nouns + ["_"]))]
+        for _ in range(rng.randint(1, 4)):
+            if rng.uniform() < 0.5:
+                a_ = pick(attrs)
+                branch.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.2 else a_))
+            else:
+                branch.append(op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
+        branches = [branch]
+        if kind in ("and", "or", "two_same", "two_different", "compare"):
+            branches.append([op("select", pick(nouns)), op("filter", pick(attrs))])
+        cat = pick(cats)
+        last = {"exist": op("exist"), "and": op("and"), "or": op("or"), "verify_attrs": op("verify_attrs", [pick(attrs), pick(attrs)]),
+                "verify_rel": op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)),
+                "choose_attr": op("choose_attr", [categories[cat][0], categories[cat][1]]), "query_attr": op("query_attr", cat),
+                "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
+                "two_same": op("two_same", cat), "two_different": op("two_different", cat), "all_same": op("all_same", cat),
+                "all_different": op("all_different", cat), "compare": op("compare", pick(attrs), bool(rng.uniform() < 0.5))}[kind]
+        qs.append(syn.question(qid, branches, last, "yes"))
+        scenes.append(syn.feature_scene(qid, int(rng.randint(n_lo, n_hi + 1)), 2048))
+    return qs, scenes
+
+
+@pytest.mark.parametrize("kind", ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
+                                  "two_same", "two_different", "all_same", "all_different", "compare"])
+def test_all_ops_full_size_model_ragged_60_to_100(full_size, kind):
+    """Every terminal operator through the full-size interpreter (2048 -> 512, 516/1036 -> 256 -> 300 -> 2335, the fused needed-columns
+    kernels) on ragged scenes of 60..100 objects - BASELINE configs[2]'s shape with synthetic features - against the oracle's fp32 and
+    fp64 runs of the reference's algorithm (full cached tables)."""
+    model, ont, oont, weights, names, categories = full_size
+    seed = zlib.crc32(kind.encode()) % 1000 + 31
+    qs, scenes = _full_size_questions(kind, 6, 60, 100, names, categories, seed)
+    res, _ = run(model, qs, scenes, ont, split=2, key="X")
+    lp = res["log_probability"].cpu().numpy()
+    r32 = orc.run_questions(oont, qs, scenes, np.float32, split=3, weights=weights)
+    r64 = orc.run_questions(oont, qs, scenes, np.float64, split=3, weights=weights)
+    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], "full-size %s" % kind, lp_tol=5e-3 if kind == "compare" else 1e-4)
+    if kind != "compare":
+        lp64, lp32 = r64["log_probability"], r32["log_probability"].astype(np.float64)
+        if int(res["type"]) == int(D.QuestionType.QUERY):
+            sizes = [len(o) for o in r64["options"]]
+            off = np.concatenate([[0], np.cumsum(sizes)])
+            decided = []
+            for i in range(len(sizes)):
+                a64, a32 = lp64[off[i]:off[i + 1]], lp32[off[i]:off[i + 1]]
+                top = np.sort(a64)[::-1]
+                decided.append(len(top) < 2 or top[0] - top[1] > 4 * np.abs(a32 - a64).max() + 1e-4)
+        else:
+            decided = list(np.abs(np.exp(lp64) - 0.5) > 4 * np.abs(np.exp(lp32) - np.exp(lp64)) + 1e-5)
+        diff = [i for i, (x, y) in enumerate(zip(res["answer"], r64["answer"])) if x != y and decided[i]]
+        assert not diff, (kind, diff)

@@ -135,6 +135,16 @@ def main():
             t = timeit(lambda: L.linear_act_split(x, w, b, act, y), iters=10)
             out.append({"kernel": "linear_act_split", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
                         "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15})
+    # weight-gradient kernel (dW = dY^T X, csrc/dfol_dense_wgrad.hip) against the library's product, training shapes
+    for (M, Nn, K) in ((256 * N * (N - 1), 300, 256), (256 * N, 512, 2048), (256 * N, 256, 516), (256 * N, 300, 256)):
+        dy = torch.rand(M, Nn, device=dev) - 0.5
+        x = torch.rand(M, K, device=dev) - 0.5
+        t = timeit(lambda: L.linear_wgrad(dy, x), iters=5)
+        tl = timeit(lambda: dy.t() @ x, iters=5)
+        fl = 2.0 * M * Nn * K
+        out.append({"kernel": "linear_wgrad (TN, fp32 matrix pipe)", "M": M, "N": Nn, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                    "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK, "library_ms": tl * 1e3})
+        del dy, x
     # fused pair kernel at the bench shape: Q images of N objects, one requested relation column each
     Q, HID1, HID2, C = 256, 256, 300, 2335
     O = Q * N

@@ -518,10 +518,29 @@ class ClassifierOracle(OracleBase):
         if world._pair_num == 0:
             return flat.view(P, NS, NS)
         preds = np.nonzero(full >= 0)[0]
+        if len(preds) == 0 or (n[pq[preds]] * (n[pq[preds]] - 1)).sum() == 0:
+            return flat.view(P, NS, NS)
+        groups = [preds]
+        if fused and len(preds) > world._batch_size:
+            # several predicates per question (choose_rel's options): the j-th predicates of all questions form a group in which every
+            # pair row belongs to exactly one predicate, in order - the shape the fused logit kernels take (no gathers of the
+            # [pairs, HID2] hidden layer, no atomic scatter-adds in the backward)
+            slot, seen = np.zeros(len(preds), np.int64), {}
+            for i, qq in enumerate(pq[preds]):
+                slot[i] = seen.get(int(qq), 0)
+                seen[int(qq)] = slot[i] + 1
+            groups = [preds[slot == j] for j in range(int(slot.max()) + 1)]
+        for grp in groups:
+            dst, val = self._relation_group_autograd(world, full, pq, grp, n, pair_off, NS, fused)
+            flat = flat.index_put((dst,), val)
+        return flat.view(P, NS, NS)
+
+    def _relation_group_autograd(self, world, full, pq, preds, n, pair_off, NS, fused):
+        """LogSigmoid logits of the predicates `preds` over the ordered pairs of their images and their positions in the flat tile tensor."""
+        emb = self._embedding_network.linear
+        dev = world._device
         q = pq[preds]
         cnt = n[q] * (n[q] - 1)
-        if len(preds) == 0 or cnt.sum() == 0:
-            return flat.view(P, NS, NS)
         key = ("rel", str(dev), tuple(world._n_list), NS, preds.tobytes(), q.tobytes())
         hit = self._index_cache.get(key)
         if hit is None:                                       # gather / scatter indices depend on the batch shape only: upload once
@@ -541,7 +560,7 @@ class ClassifierOracle(OracleBase):
         cols = upload(full[preds].astype(np.int64), dev)
         if fused and src is None:
             # every pair row belongs to exactly one predicate, in order: Sigmoid, embedding product and row sum in one kernel
-            plan = _concept_plan(np.where(full >= 0, full, -1)[preds], dev, self._index_cache)
+            plan = _concept_plan(full[preds], dev, self._index_cache)
             e_rows, be_rows = _EmbRows.apply(emb.weight, emb.bias, cols, plan)
             x = _FusedLogit.apply(self._pair_pre2_autograd(world), e_rows, be_rows, pred_off, max_rows)
         else:
@@ -550,7 +569,7 @@ class ClassifierOracle(OracleBase):
             h = self._pair_hidden_autograd(world)
             e_rows = emb.weight.index_select(0, cols).index_select(0, rep)
             x = ((h if src is None else h.index_select(0, src)) * e_rows).sum(1) + emb.bias.index_select(0, cols).index_select(0, rep)
-        return flat.index_put((dst,), nn.functional.logsigmoid(x)).view(P, NS, NS)
+        return dst, nn.functional.logsigmoid(x)
 
     def _attr_ll_autograd(self, world, low, pred_q_host):
         """[P, NS] blocks of the requested attribute columns, differentiable."""

@@ -470,6 +470,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
     const int total = Q * tiles_per_image, stride = gridDim.x;
     const int nchunk = HID1 / SP_CH, lastc = nchunk - 1;                     // even (host check): chunk c always lives in buffer c & 1
+#ifdef DFOL_PAIR_TRACE
+    const int trace_blk = (int)blockIdx.x / 32;
+    const bool trace_on = blockIdx.x % 32 == 0 && trace_blk < 8;
+    int trace_task = 0;
+#define PTRACE(slot) do { if (trace_task < 3) TRACE(trace_task * 20 + (slot)); } while (0)
+#else
+#define PTRACE(slot)
+#endif
     const int Kt = K < KMAX ? K : KMAX;
 
     struct Task { int t, q, tb, n; };
@@ -773,16 +781,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (Y) __syncthreads();                         // tick 0 of the first task: X builds chunk 0
         bool has_next = next_task(cur.t, nxt);
         // ---- first task, chunk 0 (plain; chunks 0 and 1 came with the set-up)
+        PTRACE(0);
         load_uv(0);
         make_a(0);
         __builtin_amdgcn_sched_barrier(0);
+        PTRACE(18);
         __syncthreads();                                // end of the build tick
         __builtin_amdgcn_sched_barrier(0);
+        PTRACE(1);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < NB16; ++i) acc[m][i] = floatx4{0.f, 0.f, 0.f, 0.f};
         multiply(0);
+        PTRACE(2);
         __syncthreads();                                // end of the multiply tick
         while (true) {
             // ---- chunks 1 .. 7: the plain ping-pong
@@ -796,27 +808,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                        // end of the build tick
                 __builtin_amdgcn_sched_barrier(0);
+                PTRACE(1 + 2 * c);
                 multiply(c);
                 if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);          // the chunk requested in the build tick has landed
+                PTRACE(2 + 2 * c);
                 if (!Y || c < lastc || has_next) __syncthreads();  // end of the multiply tick (Y's very last one has no partner)
             }
             if (!has_next) break;
             // ---- task switch: X during Y's last multiply, Y during X's first multiply of the next task
+#ifdef DFOL_PAIR_TRACE
+            ++trace_task;
+#endif
+            PTRACE(0);
             prev = cur;
             cur = nxt;
             par ^= 1;
             if (!Y) stage_rows(cur, par, 0, 256);       // (the buffer's old rows were last read two ticks into the finished task)
             lane_setup(cur);
             has_next = next_task(cur.t, nxt);
+            PTRACE(17);
             load_uv(0);
             if (Y) dma_chunk(1, 1, 4, std::integral_constant<int, 4>());
             make_a(0);
             __builtin_amdgcn_sched_barrier(0);
+            PTRACE(18);
             __syncthreads();                            // end of the build tick
             __builtin_amdgcn_sched_barrier(0);
+            PTRACE(1);
             multiply_fused(par ^ 1);                    // chunk 0 of the new task + the Sigmoids / dot products of the finished one
             if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);
+            PTRACE(2);
             epi_tail(prev);
+            PTRACE(19);
             __syncthreads();                            // end of the multiply tick
         }
         epi_plain(cur, par);
@@ -856,10 +879,13 @@ extern "C" int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HI
     DFOL_REQUIRE(UV && pos && Wg && W2_split && b2 && E && n_obj && obj_off && req_col && req_tile && tiles_v, "pair_ll_split: null pointer");
     DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_split % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll_split: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    static const int pp = getenv("DFOL_PAIR_SPLIT_PP") ? atoi(getenv("DFOL_PAIR_SPLIT_PP")) : 2;
-    // pp = 2: the persistent kernel (one workgroup per CU, epilogues fused into the next task's first multiply) for the full-size
-    // oracle shape with up to 4 requested columns per image; 1: one ping-pong workgroup per 256 slots; 0: two 4-wavefront workgroups per CU
-    if (pp == 2 && HID2 > 288 && HID2 <= 304 && HID1 % (2 * SP_CH) == 0 && K <= 4) {
+    static const int pp = getenv("DFOL_PAIR_SPLIT_PP") ? atoi(getenv("DFOL_PAIR_SPLIT_PP")) : 1;
+    // pp = 1 (default): one ping-pong workgroup per 256 slots; 0: two 4-wavefront workgroups per CU; 2: the persistent kernel with the
+    // epilogue fused into the next task's first multiply tick (full-size oracle shape, fp32 tiles, K <= 4) - correct (same tests) but
+    // measured SLOWER (2.32 ms against 1.75 ms at 256 x 100 objects): the fused tick takes 13-16 k cycles instead of 5.2 k, because a
+    // Sigmoid is two transcendentals of 16 cycles each on the VALU pipe and the matrix pipe leaves only ~12 cycles per MFMA gap, so the
+    // 7 k cycles of epilogue VALU work of a wavefront cannot hide under its own 228 MFMAs (profiles/r02_pair_trace.md)
+    if (pp == 2 && tile_dtype == DFOL_TILE_F32 && HID2 > 288 && HID2 <= 304 && HID1 % (2 * SP_CH) == 0 && K <= 4) {
         static int cus = 0;
         if (cus == 0) {
             int dev = 0, n = 0;
@@ -870,14 +896,10 @@ extern "C" int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HI
         DFOL_REQUIRE((int64_t)Q * tpi_p < ((int64_t)1 << 31), "pair_ll_split: too many tiles");
         const int64_t tasks = (int64_t)Q * tpi_p;
         const dim3 pgrid((unsigned)(tasks < cus ? tasks : cus));
-#define DFOL_PAIR32P(BF, KM)                                                                                                          \
-        hipLaunchKernelGGL((pair_ll32p_kernel<19, BF, KM>), pgrid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
+#define DFOL_PAIR32P(KM)                                                                                                              \
+        hipLaunchKernelGGL((pair_ll32p_kernel<19, false, KM>), pgrid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
                            E, ld_e, be, n_obj, obj_off, Q, tpi_p, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
-        if (tile_dtype == DFOL_TILE_BF16) {
-            if (K <= 1) DFOL_PAIR32P(true, 1); else if (K <= 2) DFOL_PAIR32P(true, 2); else DFOL_PAIR32P(true, 4);
-        } else {
-            if (K <= 1) DFOL_PAIR32P(false, 1); else if (K <= 2) DFOL_PAIR32P(false, 2); else DFOL_PAIR32P(false, 4);
-        }
+        if (K <= 1) DFOL_PAIR32P(1); else DFOL_PAIR32P(4);
 #undef DFOL_PAIR32P
         DFOL_LAUNCH_CHECK("pair_ll_split (persistent)");
         return 0;

@@ -249,7 +249,7 @@ extern "C" int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t H
     DFOL_REQUIRE(H2 > 0 && H2 <= 64 * LG_T && P >= 0 && rows >= 0, "pair_logit_fwd: HID2=%d must be <= %d", H2, 64 * LG_T);
     if (rows == 0 || P == 0) return 0;
     DFOL_REQUIRE(P2 && E && pred_off && x, "pair_logit_fwd: null pointer");
-    DFOL_REQUIRE(max_rows > 0 && max_rows <= rows && dfol_cdiv(max_rows, 16) < ((int64_t)1 << 31) && P < 65536,
+    DFOL_REQUIRE(max_rows > 0 && max_rows <= rows && (max_rows + 15) / 16 < ((int64_t)1 << 31) && P < 65536,
                  "pair_logit_fwd: max_rows=%lld must be the largest row count of a predicate (P < 65536)", (long long)max_rows);
     hipLaunchKernelGGL(pair_logit_fwd_kernel, dim3((unsigned)dfol_cdiv(max_rows, 16), P), dim3(256), 0, (hipStream_t)stream, P2, ld_p2, H2, E,
                        ld_e, be, pred_off, x);

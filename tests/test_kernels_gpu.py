@@ -193,10 +193,10 @@ def test_filter_relate_quantify(L, n_list, k_list):
                                       quant[p, 0], quant[p, 1], 0.0 if neg is None else float(neg[p]), any_neg)
                      for dt in (np.float32, np.float64)]
                 if want[p] & 1:
-                    gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "relate post_s orient %d" % orient, lp_tol=2e-4)
+                    gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "relate post_s orient %d" % orient)
                     assert np.all(ps[p, n:] == 0)
                 if want[p] & 2:
-                    gu.check_logprob(po[p, :n], r[0][1], r[1][1], "relate post_o orient %d" % orient, lp_tol=2e-4)
+                    gu.check_logprob(po[p, :n], r[0][1], r[1][1], "relate post_o orient %d" % orient)
                     assert np.all(po[p, n:] == 0)
         # ---- quantify
         att = np.zeros((P, NS), np.float32)
@@ -245,7 +245,7 @@ def test_g2_goldens_through_kernels(L):
             got = L.filter_fwd(dev(block_rows(prior[:, 0, :], img, ident, n_list, NS)), dev(block_rows(ll[:, :, 0], img, pq, n_list, NS, -30.0)),
                                dev(pq), dev(n_obj), None if neg is None else dev(neg)).cpu().numpy()
             gu.check_logprob(np.concatenate([got[p, :n_list[pq[p]]] for p in range(len(pq))]), a[n + "_out_f32"][:, 0, :][own],
-                             a[n + "_out_f64"][:, 0, :][own], n, lp_tol=2e-4)
+                             a[n + "_out_f64"][:, 0, :][own], n)
             continue
         lone = len(pq) == 1
         ps, po = L.relate_fwd(dev(block_rows(prior[:, 0, :], img, ident, n_list, NS)), dev(block_rows(prior[:, 1, :], img, ident, n_list, NS)),
@@ -256,7 +256,7 @@ def test_g2_goldens_through_kernels(L):
             if "stress" in n:
                 assert np.abs(np.exp(flat) - np.exp(a[n + "_out_f32"][:, k, :][own])).max() <= 2e-6
             else:
-                gu.check_logprob(flat, a[n + "_out_f32"][:, k, :][own], a[n + "_out_f64"][:, k, :][own], n, lp_tol=2e-4)
+                gu.check_logprob(flat, a[n + "_out_f32"][:, k, :][own], a[n + "_out_f64"][:, k, :][own], n)
 
 
 def test_small_vector_ops(L):
@@ -504,10 +504,10 @@ def test_relate_exists_fast_path(L, n_list):
                     for da in (True, False):
                         ps, po = outs[da]
                         if want_bits & 1:
-                            gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "fast relate post_s da=%s" % da, lp_tol=2e-4)
+                            gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "fast relate post_s da=%s" % da)
                             assert np.all(ps[p, n:] == 0)
                         if want_bits & 2:
-                            gu.check_logprob(po[p, :n], r[0][1], r[1][1], "fast relate post_o da=%s" % da, lp_tol=2e-4)
+                            gu.check_logprob(po[p, :n], r[0][1], r[1][1], "fast relate post_o da=%s" % da)
                             assert np.all(po[p, n:] == 0)
     # the fused single-posterior kernel shares the product path
     x_att, prev_att = prior_s[pq], prior_o
@@ -519,7 +519,7 @@ def test_relate_exists_fast_path(L, n_list):
             continue
         r = [orc.relate_block(x_att[p, :n].astype(dt), prev_att[q, :n].astype(dt), tile[p, :n, :n].astype(dt), 1.0, 1.0, 0.0, False)
              for dt in (np.float32, np.float64)]
-        gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path", lp_tol=2e-4)
+        gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path")
 
 
 @pytest.mark.parametrize("n_list", [[5, 1, 8, 3], [36, 20, 33], [100, 37, 64, 2], [130, 256], [17, 9, 2, 12, 16]])
@@ -570,10 +570,10 @@ def test_relate_negated_and_forall_fast_paths(L, n_list):
                             n = n_list[pq[p]]
                             what = "neg=%s q=(%g,%g) orient=%d da=%s want=%d p=%d" % (None if neg is None else int(neg[p]), qs_v, qo_v, orient, da, want_bits, p)
                             if want_bits & 1:
-                                gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "relate post_s " + what, lp_tol=2e-4)
+                                gu.check_logprob(ps[p, :n], r[0][0], r[1][0], "relate post_s " + what)
                                 assert np.all(ps[p, n:] == 0)
                             if want_bits & 2:
-                                gu.check_logprob(po[p, :n], r[0][1], r[1][1], "relate post_o " + what, lp_tol=2e-4)
+                                gu.check_logprob(po[p, :n], r[0][1], r[1][1], "relate post_o " + what)
                                 assert np.all(po[p, n:] == 0)
             # the fused single-posterior kernel: x = the object variable (fresh), prev = the subject variable with quantifier qs_v;
             # tiles stored with the summed-out (subject) variable along rows = the reference orientation

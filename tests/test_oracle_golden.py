@@ -65,7 +65,7 @@ def test_g2_logic_cell():
             if dt == np.float64:
                 assert np.allclose(out[own], ref[own], rtol=1e-9, atol=1e-9), n
             else:
-                gu.check_logprob(out[own], ref[own], a[n + "_out_f64"][own], n, lp_tol=2e-4)
+                gu.check_logprob(out[own], ref[own], a[n + "_out_f64"][own], n)
 
 
 def test_block_form_equals_flat():
@@ -119,7 +119,7 @@ def test_g3_filter_relate(ontology):
                 if dt == np.float64:
                     assert np.allclose(got[own], ref[own], rtol=1e-9, atol=1e-9), n
                 else:
-                    gu.check_logprob(got[own], ref[own], ref64[own], n, lp_tol=2e-4)
+                    gu.check_logprob(got[own], ref[own], ref64[own], n)
 
 
 @pytest.mark.parametrize("name", gu.G4_CASES + gu.G4_STRESS + ["g4_end"] + gu.G11_CASES + gu.G14_CASES)

@@ -1,20 +1,33 @@
 #!/bin/bash
-# Round-end measurement pass (runs on the GPU box): rocprofv3 stats + HBM counters, both bench lines, kernel / operator / training /
-# calibrated-forward benchmarks and the per-step launch breakdowns.  Copy what should be judged from gpurun_out/ into profiles/.
+# Round-end measurement pass (runs on the GPU box): rocprofv3 stats + HBM counters of the default bench command, the bench lines of
+# every configuration, kernel / operator / training / calibrated-forward benchmarks, per-step launch breakdowns and the PMC passes of
+# the two MFMA kernels.  Copy what should be judged from gpurun_out/ into profiles/ (named per round).
+# usage: tools/measure_all.sh [tag]      (default tag r02)
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-bash tools/profile_bench.sh r01 > gpurun_out/prof_r01.log 2>&1
-cp gpurun_out/prof_r01/traffic.json profiles/traffic.json
-python bench.py > gpurun_out/bench_n100.json 2> gpurun_out/bench_n100.err
-python bench.py --objects 36 > gpurun_out/bench_n36.json 2> gpurun_out/bench_n36.err
-python tools/bench_kernels.py > gpurun_out/kb.jsonl 2>&1
-python tools/bench_ops.py > gpurun_out/ops.jsonl 2>&1
-python tools/bench_train.py --objects 36 > gpurun_out/train.jsonl 2>&1
-python tools/bench_train.py --objects 100 >> gpurun_out/train.jsonl 2>&1
-python tools/bench_train.py --objects 100 --ragged 10 >> gpurun_out/train.jsonl 2>&1
-python tools/bench_train.py --objects 100 --calibrator 1 >> gpurun_out/train.jsonl 2>&1
-python tools/bench_calibrated.py > gpurun_out/calibrated.txt 2>&1
-bash tools/step_breakdown.sh n100 > gpurun_out/steps_n100.md 2>&1
-bash tools/step_breakdown.sh n36 --objects 36 > gpurun_out/steps_n36.md 2>&1
-tail -1 gpurun_out/bench_n100.json | cut -c1-300
-tail -1 gpurun_out/bench_n36.json | cut -c1-200
+O=gpurun_out/$TAG
+mkdir -p $O
+bash tools/profile_bench.sh $TAG > $O/prof.log 2>&1
+cp gpurun_out/prof_$TAG/summary.md $O/rocprof_summary.md 2>/dev/null
+cp gpurun_out/prof_$TAG/traffic.json $O/traffic.json 2>/dev/null && cp $O/traffic.json profiles/traffic.json
+timeout 600 python bench.py > $O/bench_n100.json 2> $O/bench_n100.err
+timeout 300 python bench.py --workload c1 > $O/bench_c1_n36.json 2> $O/bench_c1.err
+timeout 600 python bench.py --workload c4 --steps 10 > $O/bench_c4_n256.json 2> $O/bench_c4.err
+timeout 300 python tools/bench_kernels.py > $O/kernel_microbench.jsonl 2> $O/kb.err
+timeout 300 python tools/bench_ops.py > $O/ops_throughput.jsonl 2> $O/ops.err
+for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1"; do
+  timeout 300 python bench.py --mode train --steps 10 $a >> $O/train_step.jsonl 2>> $O/train.err
+done
+DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2r.err
+DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --mode train --objects 36 > $O/train_2ranks_one_gpu.json 2> $O/train_2r.err
+timeout 300 python tools/bench_calibrated.py > $O/calibrated_forward.txt 2>&1
+bash tools/step_breakdown.sh ${TAG}_n100 > $O/step_breakdown_n100.md 2>&1
+bash tools/step_breakdown.sh ${TAG}_n36 --objects 36 > $O/step_breakdown_n36.md 2>&1
+bash tools/pmc_run.sh ${TAG}_mfma "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" tools/bench_kernels.py > $O/pmc_mfma_busy.txt 2>&1
+bash tools/pmc_run.sh ${TAG}_insts "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU" tools/bench_kernels.py > $O/pmc_insts.txt 2>&1
+bash tools/pmc_run.sh ${TAG}_fetch "FETCH_SIZE" tools/bench_kernels.py > $O/pmc_fetch_microbench.txt 2>&1
+bash tools/pmc_run.sh ${TAG}_write "WRITE_SIZE" tools/bench_kernels.py > $O/pmc_write_microbench.txt 2>&1
+tail -1 $O/bench_n100.json | cut -c1-300
+tail -1 $O/bench_c1_n36.json | cut -c1-200
+tail -1 $O/bench_c4_n256.json | cut -c1-200

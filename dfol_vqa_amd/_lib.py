@@ -35,6 +35,7 @@ SIGNATURES = {
     "dfol_filter_fwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p],
     "dfol_relate_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "dfol_quantify_fwd_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_find_max_ind_f32": [_p, _p, _i32, _f, _p, _p],
     "dfol_quantify_hard_f32": [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p],
     "dfol_relate_one_fwd_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
     "dfol_gate_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
@@ -264,6 +265,13 @@ def quantify_hard(att, quant, pred_q, n_obj, total_obj):
     call("dfol_quantify_hard_f32", _ptr(att, F32), _ptr(quant, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, int(total_obj), _ptr(lp),
          _stream())
     return lp
+
+
+def find_max_ind(lp, seg_off, likelihood_threshold=0.0):
+    """uint8 [P]: 1 where a predicate attains its question's maximum probability above the threshold (util.py:64-66)."""
+    flag = torch.empty(lp.numel(), dtype=U8, device=lp.device)
+    call("dfol_find_max_ind_f32", _ptr(lp, F32), _ptr(seg_off, I32), seg_off.numel() - 1, float(likelihood_threshold), _ptr(flag, U8), _stream())
+    return flag
 
 
 def gate(x_att, y_att, x_quant, y_quant, g):

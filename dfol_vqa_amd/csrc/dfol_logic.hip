@@ -428,6 +428,88 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
         }
     }
 
+    // FOR_ALL / FOR_ALL, NEGATED: l' = log(1 - E), so a row / column sum of l' + prior is the log of a product of (1 - E) factors (each
+    // exactly 0, or >= 2^-24: four per lane and row for the row sums, up to five rows for the column sums) plus the sum of the priors;
+    // the smallest (1 - E) e^prior is tracked against eps = 1e-20 (the outer clamp), a zero factor (the inner one) shows as -inf.
+    if (!sums_done && alpha_n == 1.f && qR == 0.f && qC == 0.f) {
+        constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+        constexpr int UNR = 4;
+        float Pc[4], pcsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool cv = c0 + j < n;
+            Pc[j] = cv ? __builtin_amdgcn_exp2f(pc[j] * L2E) : 1.f;
+            pcsum += cv ? pc[j] : 0.f;
+        }
+        pcsum = dfol_group_sum<LPR>(pcsum);                               // sum of the column priors (valid in the group's last lane)
+        pcsum = __shfl(pcsum, (lane / LPR) * LPR + LPR - 1, 64);
+        float chk = 1.f, prmax = -1.f, prsum = 0.f;
+        for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
+            float cprod[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * RPI + rs;
+                const bool rlive = r < n, live = rlive && col_live;
+                const int rc = min(r, n - 1);
+                const float4 t = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + min(c0, NS - 4));
+                const float l[4] = {t.x, t.y, t.z, t.w};
+                const float pr = pR[rc];
+                const float Pr = __builtin_amdgcn_exp2f(pr * L2E);
+                prmax = fmaxf(prmax, rlive ? pr : -1.f);
+                if (cg == 0) prsum += rlive ? pr : 0.f;                   // each row's prior once per wavefront
+                float rprod = 1.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    const bool keep = live && c < n && c != r;
+                    const float a = keep ? 1.f - __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)) : 1.f;       // e^{l'} (:194, :212-213)
+                    if (wantR) {
+                        chk = fminf(chk, keep ? a * Pc[j] : 1.f);
+                        rprod *= a;
+                    }
+                    if (wantC) {
+                        chk = fminf(chk, keep ? a * Pr : 1.f);
+                        cprod[j] *= a;
+                    }
+                    if (c < n) prmax = fmaxf(prmax, pc[j]);
+                }
+                if (wantR) {
+                    const float part = dfol_group_sum<LPR>(__builtin_amdgcn_logf(rprod));
+                    // sum_{c != r} (l' + pC[c]) = ln2 * log2(prod) + (sum of the column priors - pC[r])
+                    if (cg == LPR - 1 && rlive) row_sum[wave_in_block][r] = part * LN2 + pcsum - pC[r];
+                }
+            }
+            if (wantC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) col_acc[j] += __builtin_amdgcn_logf(cprod[j]);
+            }
+        }
+        bool bad = chk < 1.2e-20f || prmax > 0.f;
+        if (wantC) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) prsum += __shfl_xor(prsum, m, 64);          // every row's prior
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = col_acc[j];
+#pragma unroll
+                for (int m = 32; m >= LPR; m >>= 1) v += __shfl_xor(v, m, 64);
+                bad |= (c0 + j < n) && !(v >= -3.0e38f);
+                // reduced here already: the common epilogue below adds the row slots again, so leave the total in slot 0 only
+                col_acc[j] = rs == 0 ? v * LN2 + prsum - pc[j] : 0.f;
+            }
+        }
+        if (wantR) {
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < n; c += 64) bad |= !(row_sum[wave_in_block][c] >= -3.0e38f);
+        }
+        sums_done = !__any(bad);
+        if (!sums_done) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) col_acc[j] = 0.f;
+        }
+    }
+
     for (int r0 = sums_done ? n : 0; r0 < n; r0 += RPI) {
         const int r = r0 + rs;
         const bool live = r < n && col_live;
@@ -1053,6 +1135,35 @@ extern "C" int dfol_quantify_fwd_f32(const float* att, const float* quant, const
     else DFOL_QUANT4(64);
 #undef DFOL_QUANT4
     DFOL_LAUNCH_CHECK("quantify_fwd");
+    return 0;
+}
+
+// Answer decoding on the device (util.find_max_ind, util.py:64-66): flag[p] = 1 iff predicate p attains the maximum PROBABILITY of its
+// question's predicates and that probability exceeds the threshold.  One wavefront per question (its predicates are contiguous:
+// seg_off); probabilities by libm expf, compared exactly, as the reference compares torch.exp values (almost_equal with eps = 0).
+__global__ __launch_bounds__(256) void find_max_ind_kernel(const float* __restrict__ lp, const int32_t* __restrict__ seg_off, int Q,
+                                                           float threshold, uint8_t* __restrict__ flag) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const int lane = threadIdx.x & 63;
+    const int p0 = seg_off[q], p1 = seg_off[q + 1];
+    float mx = 0.f;                                            // (the reference's dense [P, Q] product holds 0 for other questions' rows)
+    for (int p = p0 + lane; p < p1; p += 64) mx = fmaxf(mx, expf(lp[p]));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+    for (int p = p0 + lane; p < p1; p += 64) {
+        const float v = expf(lp[p]);
+        flag[p] = (v == mx && v > threshold) ? 1 : 0;
+    }
+}
+
+extern "C" int dfol_find_max_ind_f32(const float* lp, const int32_t* seg_off, int32_t Q, float likelihood_threshold, uint8_t* flag,
+                                     void* stream) {
+    DFOL_REQUIRE(Q >= 0, "find_max_ind: bad sizes Q=%d", Q);
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(lp && seg_off && flag, "find_max_ind: null pointer");
+    hipLaunchKernelGGL(find_max_ind_kernel, dim3(dfol_cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, lp, seg_off, Q, likelihood_threshold, flag);
+    DFOL_LAUNCH_CHECK("find_max_ind");
     return 0;
 }
 

@@ -385,8 +385,20 @@ class GQAVerifyRelBatch(GQABatchOperatorBase):
 def _choose_answer(log_probability, x, option_list, batch_index, question_num, likelihood_threshold, give_answer):
     if not give_answer:
         return [], []
+    bi = np.asarray(batch_index)
+    if log_probability.is_cuda and (len(bi) < 2 or bool(np.all(bi[1:] >= bi[:-1]))) and len(bi) > 0 and int(bi[-1]) < question_num:
+        # util.find_max_ind on the device, queued with the operator's other launches (capturable); the host later reads the flags
+        counts = np.bincount(bi, minlength=question_num)
+        seg_off = upload(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), log_probability.device)
+        dev_flags = L.find_max_ind(log_probability.detach().contiguous(), seg_off, float(likelihood_threshold))
+
+        def compute():
+            flags = dev_flags.cpu().numpy().tolist()
+            return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.detach().cpu().numpy().tolist(), batch_index, flags)
+        return _answers(compute)
+
     def compute():
-        flags = find_max_ind(log_probability, np.asarray(batch_index), question_num, likelihood_threshold).tolist()   # util.py:64-66
+        flags = find_max_ind(log_probability, bi, question_num, likelihood_threshold).tolist()   # util.py:64-66
         return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.detach().cpu().numpy().tolist(), batch_index, flags)
     return _answers(compute)
 

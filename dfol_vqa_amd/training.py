@@ -117,5 +117,20 @@ def accumulate_test_batch(error, total_example_num, data, prediction, first_answ
     return error, total_example_num
 
 
+def collect_predictions(program_batch_list, prediction, is_submission=False):
+    """The prediction records VQATrainer._print_predictions appends per test batch (trainer.py:320-337): question id, predicted
+    answer (the first of the arg-max set for binary questions and submissions, the whole set for QUERY questions), question type
+    ('open' for query_attr programs, 'binary' otherwise) and, for QUERY questions, the option list."""
+    question_ids = [qid for pb in program_batch_list for qid in pb._meta_data['question_ids']]
+    if is_submission:
+        return [{'questionId': qid, 'prediction': p[0]} for qid, p in zip(question_ids, prediction['answer'])]
+    query = prediction['type'] == QuestionType.QUERY
+    answers = [p if query else p[0] for p in prediction['answer']]
+    types = ['open' if pb._op_batch_list[-1]._op_name == 'query_attr' else 'binary' for pb in program_batch_list for _ in range(pb.batch_size())]
+    if query:
+        return [{'questionId': qid, 'prediction': a, 'type': t, 'options': opt} for qid, a, t, opt in zip(question_ids, answers, types, prediction['options'])]
+    return [{'questionId': qid, 'prediction': a, 'type': t} for qid, a, t in zip(question_ids, answers, types)]
+
+
 def metric_dict(error):                                  # trainer.py:85-86
     return dict(zip(['over_all'] + list(OP_INDEX.keys()), [float(x) for x in error]))

@@ -170,6 +170,11 @@ int dfol_relate_one_fwd_bf16(const float* x_att, const float* prev_att, const ui
 int dfol_quantify_fwd_f32(const float* att, const float* quant, const int32_t* pred_q, const int32_t* n_obj,
                           int32_t P, int32_t NS, float* lp, void* stream);
 
+/* util.find_max_ind (util.py:64-66): flag[p] = 1 iff predicate p attains the maximum probability exp(lp) among the predicates of
+ * its question (contiguous: seg_off [Q+1]) and that probability exceeds likelihood_threshold.  Answer decoding of the choose / query
+ * operators (batch_gqa_ops.py:215-228, 246-267, 304-306) without a host round trip per operator. */
+int dfol_find_max_ind_f32(const float* lp, const int32_t* seg_off, int32_t Q, float likelihood_threshold, uint8_t* flag, void* stream);
+
 /* hard_mode aggregation: replaces BatchVariableSet.log_probability(hard_mode=True), batch_base_types.py:104-112 (a test-time
  * option of BatchGQAInterpreter, :23,:73):   lp[p] = F_q( min( min_{o < n} F_q(att[p][o]), 0 if total_obj > n ) ).
  * The 0 is the reference's product with the dense batch-object mask: objects of the batch's other images take part in the

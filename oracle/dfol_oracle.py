@@ -23,16 +23,44 @@ import numpy as np
 
 DEFAULT_LL = -30.0
 
+# Element-wise transcendentals over the flat tables ([pairs, 2335] LogSigmoid, [P, O, O] exp / log) are what the reference spends its
+# time in, and torch evaluates them on every core (trainer.py:57-62: torch.set_num_threads(cpu_cores_num)); numpy's ufuncs are single-
+# threaded but release the GIL, so large arrays are cut into row blocks over a thread pool: the same values, a baseline that is not
+# handicapped by one core (bench.py's cpu_baseline).  DFOL_ORACLE_THREADS=1 turns it off.
+import os as _os
+from concurrent.futures import ThreadPoolExecutor as _Pool
+
+_THREADS = max(1, int(_os.environ.get("DFOL_ORACLE_THREADS", _os.cpu_count() or 1)))
+_pool = None
+
+
+def _rowwise(fn, x):
+    """fn(x) for an element-wise fn, in row blocks on the thread pool when x is large."""
+    global _pool
+    if _THREADS == 1 or x.ndim == 0 or x.size < (1 << 20) or x.shape[0] < 2:
+        return fn(x)
+    if _pool is None:
+        _pool = _Pool(_THREADS)
+    parts = min(_THREADS, x.shape[0])
+    bounds = np.linspace(0, x.shape[0], parts + 1).astype(np.int64)
+    out = np.empty_like(x)
+
+    def work(i):
+        out[bounds[i]:bounds[i + 1]] = fn(x[bounds[i]:bounds[i + 1]])
+    list(_pool.map(work, range(parts)))
+    return out
+
 
 # ------------------------------------------------------------------------------------------------
 # a1  log-space primitives                                                       util.py:17-47
 # ------------------------------------------------------------------------------------------------
 def safe_exp(x):                                   # util.py:17-19
-    return np.exp(x)
+    return _rowwise(np.exp, x) if isinstance(x, np.ndarray) else np.exp(x)
 
 
 def safe_log(x):                                   # util.py:22-25 (fp32/fp64 floor 1e-20)
-    return np.log(np.maximum(x, x.dtype.type(1e-20)))
+    f = lambda v: np.log(np.maximum(v, v.dtype.type(1e-20)))
+    return _rowwise(f, x) if isinstance(x, np.ndarray) else f(x)
 
 
 def log_and(a, b):                                 # util.py:29-30
@@ -129,16 +157,16 @@ class Ontology(object):
 # a3  cached tables            classifier_oracle.py:145-156; gqa_interpreter_experiments.py:18-77
 # ------------------------------------------------------------------------------------------------
 def _sigmoid(x):
-    return 1.0 / (1.0 + np.exp(-x))
+    return _rowwise(lambda v: 1.0 / (1.0 + np.exp(-v)), x)
 
 
 def _elu(x):
-    return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    return _rowwise(lambda v: np.where(v > 0, v, np.expm1(np.minimum(v, 0))), x)
 
 
 def _log_sigmoid(x):
     # torch's LogSigmoid: min(x,0) - log1p(exp(-|x|))
-    return np.minimum(x, 0) - np.log1p(np.exp(-np.abs(x)))
+    return _rowwise(lambda v: np.minimum(v, 0) - np.log1p(np.exp(-np.abs(v))), x)
 
 
 def _linear(x, w, b):

@@ -155,6 +155,15 @@ def test_evaluation_metrics():
     training.accumulate_test_batch(err, tot, [pq], predq)
     d = training.metric_dict(err / np.maximum(tot, 1))
     assert abs(d["exist"] - 0.5) < 1e-6 and abs(d["query_attr"] - 0.5) < 1e-6 and abs(d["over_all"] - (2 + 1.5) / 7) < 1e-6
+    # the prediction records of VQATrainer._print_predictions (trainer.py:320-337)
+    pb._meta_data = {"question_ids": ["q0", "q1", "q2", "q3"]}
+    pq._meta_data = {"question_ids": ["q4", "q5", "q6"]}
+    predq["options"] = [["red", "blue"], ["red", "blue"], ["small", "large"]]
+    assert training.collect_predictions([pb], pred) == [{"questionId": "q%d" % i, "prediction": a, "type": "binary"}
+                                                        for i, a in enumerate(["yes", "yes", "no", "no"])]
+    recs = training.collect_predictions([pq], predq)
+    assert recs[1] == {"questionId": "q5", "prediction": ["red", "blue"], "type": "open", "options": ["red", "blue"]}
+    assert training.collect_predictions([pb], pred, is_submission=True)[2] == {"questionId": "q2", "prediction": "no"}
 
 
 def test_reference_config_yamls_build(tmp_path):

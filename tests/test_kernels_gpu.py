@@ -735,3 +735,20 @@ def test_calibration_lstm_cell_equals_torch(L):
     h2, c2 = mine(x, (torch.zeros(4, 50, device="cuda"), torch.zeros(4, 50, device="cuda")))
     (h2.sum() + c2.sum()).backward()
     assert x.grad is not None and mine.weight_ih.grad is not None
+
+
+def test_find_max_ind_on_device(L):
+    """util.find_max_ind (util.py:64-66) as a kernel: ties, thresholds, one-option questions, against the oracle's restatement."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(5)
+    counts = [2, 1, 26, 3, 2, 70]
+    pq = np.repeat(np.arange(len(counts)), counts)
+    lp = np.log(rng.uniform(0.01, 0.9, len(pq))).astype(np.float32)
+    lp[3 + 5] = lp[3 + 9] = lp[3:29].max() + 0.01                 # a tie for the maximum of question 2
+    lp[0] = lp[1]                                                 # and one in question 0
+    seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    for thr in (0.0, 0.5, 0.95):
+        got = _lib.find_max_ind(dev(lp), dev(seg), thr).cpu().numpy()
+        ref = orc.find_max_ind(lp, pq, len(counts), thr)
+        assert got.tolist() == ref.tolist(), thr
+    assert got.sum() <= len(counts) + 2

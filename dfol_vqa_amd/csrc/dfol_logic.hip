@@ -386,38 +386,45 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     bool sums_done = false;
     if (alpha_n == 0.f && qR == 0.f && qC == 0.f) {
         float chk = 0.f, prmax = -1.f;
-        for (int r0 = 0; r0 < n; r0 += RPI) {
-            const int r = r0 + rs;
-            const bool live = r < n && col_live;
-            float l[4] = {0.f, 0.f, 0.f, 0.f};
-            float pr = 0.f;
-            if (live) {
-                const float4 t = *reinterpret_cast<const float4*>(tp + (int64_t)r * NS + c0);
-                l[0] = t.x; l[1] = t.y; l[2] = t.z; l[3] = t.w;
-                pr = pR[r];
-            }
-            prmax = fmaxf(prmax, pr);
-            float row_part = 0.f;
+        constexpr int UNRF = 4;
+        for (int r0 = 0; r0 < n; r0 += RPI * UNRF) {
+            float4 tq[UNRF];
+            float prq[UNRF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + j;
-                const bool keep = live && c < n && c != r;
-                const float v = fminf(l[j], 0.f);
-                if (wantR) {
-                    const float u = v + pc[j];
-                    chk = fminf(chk, keep ? u : 0.f);
-                    row_part += keep ? u : 0.f;
-                }
-                if (wantC) {
-                    const float u = v + pr;
-                    chk = fminf(chk, keep ? u : 0.f);
-                    col_acc[j] += keep ? u : 0.f;
-                }
-                if (c < n) prmax = fmaxf(prmax, pc[j]);
+            for (int u = 0; u < UNRF; ++u) {                             // all loads of the step first (clamped, unconditional)
+                const int rc = min(r0 + u * RPI + rs, n - 1);
+                tq[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + min(c0, NS - 4));
+                prq[u] = pR[rc];
             }
-            if (wantR) {
-                row_part = dfol_group_sum<LPR>(row_part);
-                if (cg == LPR - 1 && r < n) row_sum[wave_in_block][r] = row_part;
+#pragma unroll
+            for (int u = 0; u < UNRF; ++u) {
+                const int r = r0 + u * RPI + rs;
+                const bool live = r < n && col_live;
+                const float l[4] = {tq[u].x, tq[u].y, tq[u].z, tq[u].w};
+                const float pr = prq[u];
+                prmax = fmaxf(prmax, r < n ? pr : -1.f);
+                float row_part = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    const bool keep = live && c < n && c != r;
+                    const float v = fminf(l[j], 0.f);
+                    if (wantR) {
+                        const float uu = v + pc[j];
+                        chk = fminf(chk, keep ? uu : 0.f);
+                        row_part += keep ? uu : 0.f;
+                    }
+                    if (wantC) {
+                        const float uu = v + pr;
+                        chk = fminf(chk, keep ? uu : 0.f);
+                        col_acc[j] += keep ? uu : 0.f;
+                    }
+                    if (c < n) prmax = fmaxf(prmax, pc[j]);
+                }
+                if (wantR) {
+                    row_part = dfol_group_sum<LPR>(row_part);
+                    if (cg == LPR - 1 && r < n) row_sum[wave_in_block][r] = row_part;
+                }
             }
         }
         sums_done = !__any(chk < -46.0f || prmax > 0.f);             // log(1e-20) = -46.05
@@ -446,14 +453,21 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
         float chk = 1.f, prmax = -1.f, prsum = 0.f;
         for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
             float cprod[4] = {1.f, 1.f, 1.f, 1.f};
+            float4 tq[UNR];
+            float prq[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {                              // all loads of the step first
+                const int rc = min(r0 + u * RPI + rs, n - 1);
+                tq[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + min(c0, NS - 4));
+                prq[u] = pR[rc];
+            }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int r = r0 + u * RPI + rs;
                 const bool rlive = r < n, live = rlive && col_live;
-                const int rc = min(r, n - 1);
-                const float4 t = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + min(c0, NS - 4));
+                const float4 t = tq[u];
                 const float l[4] = {t.x, t.y, t.z, t.w};
-                const float pr = pR[rc];
+                const float pr = prq[u];
                 const float Pr = __builtin_amdgcn_exp2f(pr * L2E);
                 prmax = fmaxf(prmax, rlive ? pr : -1.f);
                 if (cg == 0) prsum += rlive ? pr : 0.f;                   // each row's prior once per wavefront
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
                 for (int m = 32; m >= LPR; m >>= 1) v += __shfl_xor(v, m, 64);
                 bad |= (c0 + j < n) && !(v >= -3.0e38f);
                 // reduced here already: the common epilogue below adds the row slots again, so leave the total in slot 0 only
-                col_acc[j] = rs == 0 ? v * LN2 + prsum - pc[j] : 0.f;
+                col_acc[j] = (rs == 0 && c0 + j < n) ? v * LN2 + prsum - pR[c0 + j] : 0.f;      // sum_{r != c} pR[r] = all of them - pR[c]
             }
         }
         if (wantR) {

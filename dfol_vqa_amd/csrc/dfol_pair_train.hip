@@ -17,6 +17,10 @@
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Sigmoid / ELU on the hardware exp2 / rcp (1 ulp each, absolute error < 2e-7 on these ranges - the forms the inference kernels use).
+// With libm's expf / expm1f and an IEEE division these streams were VALU-bound at 2.0 - 3.6 TB/s (25 - 30 instructions per element).
+__device__ __forceinline__ float pt_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
+__device__ __forceinline__ float pt_elu(float x) { return x > 0.f ? x : __builtin_amdgcn_exp2f(1.44269504088896340736f * x) - 1.0f; }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ float4 pair_geometry(const float* ps, const float* po) {      // batch_gqa_boxfeatures_pipeline.py:263-279
@@ -27,28 +31,57 @@ __device__ __forceinline__ float4 pair_geometry(const float* ps, const float* po
                        (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f));
 }
 
-// grid (tiles_per_image, Q); a workgroup of 256 threads covers 256 / (H1 / 4) consecutive pairs of one image, a thread 4 hidden units
-__global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __restrict__ U, int64_t ld_u, const float* __restrict__ V,
-                                                                int64_t ld_v, const float* __restrict__ pos, int64_t ld_pos,
-                                                                const float* __restrict__ Wg, const int32_t* __restrict__ obj_off,
-                                                                const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
-                                                                int H1, float* __restrict__ Z, float* __restrict__ geo_out) {
-    const int q = blockIdx.y, n = n_obj[q], lpr = H1 >> 2, rows_per_block = 256 / lpr;
-    const int e = blockIdx.x * rows_per_block + (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4;
+// geometry of every ordered pair, one thread per pair (the per-pair arithmetic - a square root, an arc sine, two divisions - would
+// otherwise be repeated by every wavefront that touches the pair's row of Z)
+__global__ __launch_bounds__(256) void pair_geometry_kernel(const float* __restrict__ pos, int64_t ld_pos, const int32_t* __restrict__ obj_off,
+                                                            const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
+                                                            float* __restrict__ geo_out) {
+    const int q = blockIdx.y, n = n_obj[q];
+    const int e = blockIdx.x * 256 + (int)threadIdx.x;
     if (n < 2 || e >= n * (n - 1)) return;
     const int s = e / (n - 1), oo = e - s * (n - 1), o = oo + (oo >= s), first = obj_off[q];
-    const int64_t row = pair_off[q] + e;
-    const float4 g = pair_geometry(pos + (int64_t)(first + s) * ld_pos, pos + (int64_t)(first + o) * ld_pos);
-    if (k == 0) st4(geo_out + row * 4, g);
-    const float4 u = ld4(U + (int64_t)(first + s) * ld_u + k), v = ld4(V + (int64_t)(first + o) * ld_v + k);
-    float z[4] = {u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+    st4(geo_out + (pair_off[q] + e) * 4, pair_geometry(pos + (int64_t)(first + s) * ld_pos, pos + (int64_t)(first + o) * ld_pos));
+}
+
+// grid (tiles_per_image, Q); 256 threads = 256 / (H1 / 4) row slots of H1 / 4 lanes; a slot walks HF_ROWS consecutive pairs of one image
+// (four at a time: their loads are issued together), a lane owns 4 hidden units whose geometry weights stay in registers
+constexpr int HF_ROWS = 16;
+
+__global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __restrict__ U, int64_t ld_u, const float* __restrict__ V,
+                                                                int64_t ld_v, const float* __restrict__ Wg, const int32_t* __restrict__ obj_off,
+                                                                const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
+                                                                int H1, float* __restrict__ Z, const float* __restrict__ geo) {
+    const int q = blockIdx.y, n = n_obj[q], lpr = H1 >> 2, slots = 256 / lpr;
+    const int slot = (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4;
+    const int rows = n * (n - 1);
+    const int e0 = (blockIdx.x * slots + slot) * HF_ROWS;
+    if (n < 2 || e0 >= rows) return;
+    const int first = obj_off[q];
+    const int64_t base = pair_off[q];
+    float4 w[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float4 w = ld4(Wg + (int64_t)(k + t) * 4);
-        const float pre = z[t] + (w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w);
-        z[t] = pre > 0.f ? pre : expm1f(pre);                // nn.ELU
+    for (int t = 0; t < 4; ++t) w[t] = ld4(Wg + (int64_t)(k + t) * 4);
+    for (int r0 = 0; r0 < HF_ROWS; r0 += 4) {
+        float4 g[4], u[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                            // all loads of four rows first (rows beyond the image are clamped)
+            const int e = min(e0 + r0 + i, rows - 1);
+            const int s = e / (n - 1), oo = e - s * (n - 1), o = oo + (oo >= s);
+            g[i] = ld4(geo + (base + e) * 4);
+            u[i] = ld4(U + (int64_t)(first + s) * ld_u + k);
+            v[i] = ld4(V + (int64_t)(first + o) * ld_v + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + r0 + i;
+            if (e >= rows) break;
+            const float z[4] = {u[i].x + v[i].x, u[i].y + v[i].y, u[i].z + v[i].z, u[i].w + v[i].w};
+            float out[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out[t] = pt_elu(z[t] + (w[t].x * g[i].x + w[t].y * g[i].y + w[t].z * g[i].z + w[t].w * g[i].w));      // nn.ELU
+            st4(Z + (base + e) * H1 + k, make_float4(out[0], out[1], out[2], out[3]));
+        }
     }
-    st4(Z + row * H1 + k, make_float4(z[0], z[1], z[2], z[3]));
 }
 
 constexpr int HB_MAXO = 16;                                   // objects per lane group in hidden1_bwd
@@ -144,7 +177,7 @@ __global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = P2[min(row0 + i, r1 - 1) * ld_p2 + j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(1.0f / (1.0f + expf(-v[i])), ev, acc[i]);
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(pt_sigmoid(v[i]), ev, acc[i]);
         }
     }
     const float b = be ? be[p] : 0.f;
@@ -155,7 +188,57 @@ __global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const float* __rest
     }
 }
 
-// one workgroup (16 wavefronts) per predicate: rows pred_off[p] .. pred_off[p+1]
+// One workgroup (1024 threads) per predicate: rows pred_off[p] .. pred_off[p+1].  H2 % 4 == 0: the predicate's rows are one contiguous
+// array of float4 (F4 = H2 / 4 per row); RG = 1024 / F4 rows are covered per trip by RG * F4 active threads, thread t always on
+// float4 t % F4 of its row, so its share of dE stays in four registers and every load / store of the workgroup is one contiguous
+// block (975 x 16 bytes for H2 = 300).  Two trips are in flight.  The RG row groups are combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __restrict__ dx, const float* __restrict__ P2, int64_t ld_p2,
+                                                                int H2, const float* __restrict__ E, int64_t ld_e,
+                                                                const int64_t* __restrict__ pred_off, float* __restrict__ dP2,
+                                                                int64_t ld_dp2, float* __restrict__ dE, int64_t ld_de,
+                                                                float* __restrict__ dbe) {
+    extern __shared__ __attribute__((aligned(16))) float red4[];           // [RG][H2] floats (+ RG for the bias)
+    const int p = blockIdx.x, F4 = H2 >> 2, RG = 1024 / F4, tid = threadIdx.x;
+    const int rg = tid / F4, j4 = tid - rg * F4;
+    const bool act = rg < RG;
+    const int64_t r0 = pred_off[p], r1 = pred_off[p + 1];
+    const float4 ev = act ? ld4(E + (int64_t)p * ld_e + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 de = make_float4(0.f, 0.f, 0.f, 0.f);
+    float db = 0.f;
+    auto one = [&](int64_t row, const float4& v, float g) __attribute__((always_inline)) {
+        const float h[4] = {pt_sigmoid(v.x), pt_sigmoid(v.y), pt_sigmoid(v.z), pt_sigmoid(v.w)};
+        st4(dP2 + row * ld_dp2 + 4 * j4, make_float4(g * ev.x * h[0] * (1.0f - h[0]), g * ev.y * h[1] * (1.0f - h[1]),
+                                                    g * ev.z * h[2] * (1.0f - h[2]), g * ev.w * h[3] * (1.0f - h[3])));
+        de.x = fmaf(g, h[0], de.x), de.y = fmaf(g, h[1], de.y), de.z = fmaf(g, h[2], de.z), de.w = fmaf(g, h[3], de.w);
+        if (j4 == 0) db += g;
+    };
+    if (act) {
+        for (int64_t row = r0 + rg; row < r1; row += 2 * RG) {
+            const int64_t row_b = row + RG;
+            const bool has_b = row_b < r1;
+            const float4 va = ld4(P2 + row * ld_p2 + 4 * j4);
+            const float4 vb = ld4(P2 + (has_b ? row_b : row) * ld_p2 + 4 * j4);
+            const float ga = dx[row], gb = has_b ? dx[row_b] : 0.f;
+            one(row, va, ga);
+            if (has_b) one(row_b, vb, gb);
+        }
+        st4(&red4[rg * H2 + 4 * j4], de);
+        if (j4 == 0) red4[RG * H2 + rg] = db;
+    }
+    __syncthreads();
+    for (int j = tid; j < H2; j += 1024) {
+        float acc = 0.f;
+        for (int w = 0; w < RG; ++w) acc += red4[w * H2 + j];
+        dE[(int64_t)p * ld_de + j] = acc;
+    }
+    if (tid == 0 && dbe) {
+        float acc = 0.f;
+        for (int w = 0; w < RG; ++w) acc += red4[RG * H2 + w];
+        dbe[p] = acc;
+    }
+}
+
+// (any H2 <= 512: one float per lane and load)
 __global__ __launch_bounds__(1024) void pair_logit_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ P2, int64_t ld_p2,
                                                                int H2, const float* __restrict__ E, int64_t ld_e,
                                                                const int64_t* __restrict__ pred_off, float* __restrict__ dP2,
@@ -187,7 +270,7 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd_kernel(const float* __res
         for (int t = 0; t < LG_T; ++t) {
             const int j = lane + 64 * t;
             if (j < H2) {
-                const float ha = 1.0f / (1.0f + expf(-va[t])), hb = 1.0f / (1.0f + expf(-vb[t]));
+                const float ha = pt_sigmoid(va[t]), hb = pt_sigmoid(vb[t]);
                 dP2[row * ld_dp2 + j] = ga * ev[t] * ha * (1.0f - ha);
                 if (has_b) dP2[row_b * ld_dp2 + j] = gb * ev[t] * hb * (1.0f - hb);
                 de[t] = fmaf(ga, ha, fmaf(gb, hb, de[t]));
@@ -222,9 +305,12 @@ extern "C" int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const flo
     if (Q == 0 || max_n < 2) return 0;
     DFOL_REQUIRE(U && V && pos && Wg && obj_off && pair_off && n_obj && Z && geo, "pair_hidden1_fwd: null pointer");
     const int rows_per_block = 256 / (H1 / 4);
-    const dim3 grid(dfol_cdiv((int64_t)max_n * (max_n - 1), rows_per_block), Q);
-    hipLaunchKernelGGL(pair_hidden1_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, U, ld_u, V, ld_v, pos, ld_pos, Wg, obj_off, pair_off,
-                       n_obj, H1, Z, geo);
+    hipLaunchKernelGGL(pair_geometry_kernel, dim3(dfol_cdiv((int64_t)max_n * (max_n - 1), 256), Q), dim3(256), 0, (hipStream_t)stream, pos, ld_pos,
+                       obj_off, pair_off, n_obj, geo);
+    DFOL_LAUNCH_CHECK("pair_hidden1_fwd (geometry)");
+    const dim3 grid(dfol_cdiv((int64_t)max_n * (max_n - 1), rows_per_block * HF_ROWS), Q);
+    hipLaunchKernelGGL(pair_hidden1_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, U, ld_u, V, ld_v, Wg, obj_off, pair_off, n_obj, H1, Z,
+                       geo);
     DFOL_LAUNCH_CHECK("pair_hidden1_fwd");
     return 0;
 }
@@ -263,8 +349,15 @@ extern "C" int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t
     DFOL_REQUIRE(H2 > 0 && H2 <= 64 * LG_T && P >= 0, "pair_logit_bwd: HID2=%d must be <= %d", H2, 64 * LG_T);
     if (P == 0) return 0;
     DFOL_REQUIRE(dx && P2 && E && pred_off && dP2 && dE, "pair_logit_bwd: null pointer");
-    hipLaunchKernelGGL(pair_logit_bwd_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, dx, P2, ld_p2, H2, E, ld_e, pred_off, dP2, ld_dp2, dE,
-                       ld_de, dbe);
+    if (H2 % 4 == 0 && H2 >= 16 && ld_p2 % 4 == 0 && ld_dp2 % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)P2 % 16 == 0) && ((uintptr_t)dP2 % 16 == 0) &&
+        ((uintptr_t)E % 16 == 0)) {
+        const int RG = 1024 / (H2 / 4);
+        hipLaunchKernelGGL(pair_logit_bwd4_kernel, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx, P2, ld_p2, H2,
+                           E, ld_e, pred_off, dP2, ld_dp2, dE, ld_de, dbe);
+    } else {
+        hipLaunchKernelGGL(pair_logit_bwd_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, dx, P2, ld_p2, H2, E, ld_e, pred_off, dP2, ld_dp2,
+                           dE, ld_de, dbe);
+    }
     DFOL_LAUNCH_CHECK("pair_logit_bwd");
     return 0;
 }

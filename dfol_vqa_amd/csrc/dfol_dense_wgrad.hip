@@ -15,6 +15,9 @@
 // no atomics, bit-identical from run to run.
 #include "dfol_common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int TN, int TK>
@@ -209,6 +212,207 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else wgrad_tn4_block<1, false>(dY, ld_dy, X, ld_x, M, N, K, m_begin, m_end, n0, k0, lane, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe with fp32 results: the exact three-way operand split of csrc/dfol_pair_split.hip (x = h + m + l,
+// six of the nine piece products, fp32 accumulation) - 6/16 of the fp32 pipe's time.  v_mfma_f32_32x32x16_bf16 wants EIGHT consecutive
+// k per lane and operand, and k is the row index here, so an operand register holds eight ROWS of one column: a lane loads the float4
+// (columns 4c .. 4c+3) of its eight rows m0 + 8 (lane >> 5) + 0..7 - plain coalesced 16-byte loads again - and component t of the
+// eight registers, split and packed, is the operand of tile t (same free row / column map as wgrad_tn4_kernel).  Per step of 16 rows
+// and wavefront: 16 loads, 96 MFMAs (3072 cycles) and ~350 VALU instructions of splitting at the top of the step; the next step's rows are
+// in flight under the MFMAs.
+typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t w3_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void w3_split(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __float_as_uint(x);
+    const float r = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t w3_pack(uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+__device__ __forceinline__ void w3_split8(const float (&v)[8], w3_u32x4& h, w3_u32x4& m, w3_u32x4& l) {
+    uint32_t ph[8], pm[8], pl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w3_split(v[j], ph[j], pm[j], pl[j]);
+    h = w3_u32x4{w3_pack(ph[0], ph[1]), w3_pack(ph[2], ph[3]), w3_pack(ph[4], ph[5]), w3_pack(ph[6], ph[7])};
+    m = w3_u32x4{w3_pack(pm[0], pm[1]), w3_pack(pm[2], pm[3]), w3_pack(pm[4], pm[5]), w3_pack(pm[6], pm[7])};
+    l = w3_u32x4{w3_pack(pl[0], pl[1]), w3_pack(pl[2], pl[3]), w3_pack(pl[4], pl[5]), w3_pack(pl[6], pl[7])};
+}
+
+// Addressing: the rows of a step come through buffer descriptors rebuilt per step from wave-uniform values (base = the step's first
+// row, size = what is left of the wavefront's row range), with per-lane byte offsets that never change: no address arithmetic on the
+// vector ALU, and rows past the range read as zero from the bounds check (a zero A row switches the row off in every product), so
+// there is no tail code either.
+// Workgroup = four wavefronts on FOUR BLOCKS OF THE SAME ROWS (consecutive blocks in row-block-major order: 2 x 2 blocks of dW for the
+// pair layer), in step with one another through one barrier per step: dY and X rows are fetched from HBM once per workgroup and hit
+// in L1/L2 for the other wavefronts.  (One wavefront per block with four row ranges per workgroup, the first version, read dY twice and
+// X three times for the pair layer: 13.9 GB per launch, HBM-bound at 2.96 ms.)  A last group of one or two blocks splits its rows in two
+// halves over the four wavefronts; the second half's accumulators go through LDS and are added by the first half's wavefront - a
+// fixed order.
+typedef uint32_t w3_u32x2 __attribute__((ext_vector_type(2)));
+
+// (every input through readfirstlane: hipcc wraps each buffer load in a waterfall loop unless the descriptor is provably wave-uniform)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w3_descriptor(const float* base, int64_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffff ? bytes : 0x7fffffff));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+// AV: floats of dY a lane loads per row = row tiles of the block (4: 128 output rows; 2: a narrow last row block, up to 64 output rows)
+template <int AV>
+__device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x,
+                                                     int rows, int steps, int N, int K, int n0, int k0, int lane, f32x16 (&acc)[AV][4]) {
+    // dY, X: first row of this wavefront's range (wave-uniform); rows: rows in the range (<= 0: nothing to add, barriers only)
+    const int col = lane & 31, half = lane >> 5;
+    // columns beyond the matrix read a clamped column: they only feed output rows / columns that are never stored
+    const int ca = min(n0 + AV * col, N - AV), cb = min(k0 + 4 * col, K - 4);
+    int va[8], vb[8];                                                              // byte offsets of this lane's eight rows within a step
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        va[r] = (int)(((8 * half + r) * ld_dy + ca) * 4);
+        vb[r] = (int)(((8 * half + r) * ld_x + cb) * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < AV; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    float ra[8][AV];                                                               // the step's dY and X rows: dead once the pieces are built,
+    w3_u32x4 rb[8];                                                                // then refilled with the next step's (in flight under the MFMAs)
+    auto load = [&](int s) __attribute__((always_inline)) {
+        const int left = rows - 16 * s;                                            // rows of the range from this step on
+        const int64_t bytes_a = left > 0 ? ((int64_t)(left - 1) * ld_dy + N) * 4 : 0, bytes_b = left > 0 ? ((int64_t)(left - 1) * ld_x + K) * 4 : 0;
+        const auto da = w3_descriptor(dY + (int64_t)s * 16 * ld_dy, bytes_a), db = w3_descriptor(X + (int64_t)s * 16 * ld_x, bytes_b);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (AV == 4) {
+                const w3_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(da, va[r], 0, 0);
+                ra[r][0] = __uint_as_float(v.x), ra[r][1] = __uint_as_float(v.y), ra[r][2] = __uint_as_float(v.z), ra[r][3] = __uint_as_float(v.w);
+            } else {
+                const w3_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(da, va[r], 0, 0);
+                ra[r][0] = __uint_as_float(v.x), ra[r][1] = __uint_as_float(v.y);
+            }
+            rb[r] = __builtin_amdgcn_raw_buffer_load_b128(db, vb[r], 0, 0);
+        }
+    };
+    constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};       // (A piece, B piece): l*h, h*l, m*m, m*h, h*m, h*h
+    // One step: all pieces first (a tile at a time: the split's temporaries are 32 registers per tile), then the next step's loads, then
+    // 24 AV MFMAs back to back.  (Building the B pieces of column tile u + 1 between the MFMAs of tile u was tried first: with 256
+    // accumulators the allocator then parks VGPRs in the accumulator file and cycles every tile through one AGPR tuple.)
+    __builtin_amdgcn_s_barrier();
+    load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < steps; ++s) {
+        w3_u32x4 ap[AV][3], bp[4][3];
+#pragma unroll
+        for (int t = 0; t < AV; ++t) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = ra[r][t];
+            w3_split8(v, ap[t][0], ap[t][1], ap[t][2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = __uint_as_float(rb[r][u]);
+            w3_split8(v, bp[u][0], bp[u][1], bp[u][2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_barrier();                                              // the workgroup's wavefronts fetch the same rows together
+        load(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < AV; ++t)
+#pragma unroll
+                for (int x = 0; x < 6; ++x)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w3_bf16x8, ap[t][PA6[x]]),
+                                                                        __builtin_bit_cast(w3_bf16x8, bp[u][PB6[x]]), acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int AV>
+__device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int rows,
+                                                int steps, int N, int K, int n0, int k0, int lane, int role, float* __restrict__ lds,
+                                                float* __restrict__ out) {
+    // role 0: accumulate and store; 1: accumulate, add the partner's accumulators from `lds`, store; 2: accumulate into `lds` (the partner)
+    f32x16 acc[AV][4];
+    wgrad_tn3_accumulate<AV>(dY, ld_dy, X, ld_x, rows, steps, N, K, n0, k0, lane, acc);
+    if (role == 2) {
+#pragma unroll
+        for (int t = 0; t < AV; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) lds[((t * 4 + u) * 16 + i) * 64 + lane] = acc[t][u][i];
+    }
+    __syncthreads();
+    if (role == 2) return;
+    if (role == 1) {
+#pragma unroll
+        for (int t = 0; t < AV; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][u][i] += lds[((t * 4 + u) * 16 + i) * 64 + lane];
+    }
+    // D tile: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); tile (t, u) holds n = n0 + AV i + t, k = k0 + 4 j + u
+    const int half = lane >> 5, kb = k0 + 4 * (lane & 31);
+    if (kb < K) {
+#pragma unroll
+        for (int t = 0; t < AV; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + AV * ((i & 3) + 8 * (i >> 2) + 4 * half) + t;
+                if (n < N) *reinterpret_cast<float4*>(out + (int64_t)n * K + kb) = make_float4(acc[t][0][i], acc[t][1][i], acc[t][2][i], acc[t][3][i]);
+            }
+    }
+}
+
+// grid (row slabs, groups of four blocks); dynamic LDS: 128 KB when the last group splits its rows (see the launcher), else none
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_tn3_kernel(
+    const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int M, int N, int K, int rows_per_slab, int nb_k,
+    int nb, float* __restrict__ part) {
+    extern __shared__ float w3_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int first = blockIdx.y * 4, in_group = min(4, nb - first);               // blocks of this group
+    const bool split = in_group <= 2;                                              // then wavefront w: block w % in_group, row half w / in_group
+    int blk = first + wave, role = 0, half_id = 0;
+    if (split) {
+        half_id = wave / in_group;
+        blk = first + wave - half_id * in_group;
+        role = half_id >= 2 ? 3 : (half_id == 1 ? 2 : 1);                          // (one block: wavefronts 2, 3 have nothing to do)
+    } else if (blk >= nb) role = 3;
+    const int m_begin = blockIdx.x * rows_per_slab, m_end = min(M, m_begin + rows_per_slab);
+    int rows = m_end - m_begin, steps = (rows + 15) >> 4, m_first = m_begin;
+    if (split) {
+        const int first_half = ((rows + 31) >> 5) << 4;                            // rows of the first half: a multiple of 16, the larger one
+        steps = first_half >> 4;
+        if (half_id == 1) m_first = m_begin + first_half, rows -= first_half;
+        else rows = min(rows, first_half);
+    }
+    if (role == 3) {                                                               // keep the workgroup's barrier count
+        for (int s = 0; s <= steps; ++s) __builtin_amdgcn_s_barrier();
+        __syncthreads();
+        return;
+    }
+    const int bn = blk / nb_k, bk = blk - bn * nb_k;
+    const int n0 = bn * 128, k0 = bk * 128;
+    float* out = part + (int64_t)blockIdx.x * ((((int64_t)N * K) + 3) & ~(int64_t)3);
+    float* lds = w3_lds + (split ? wave - half_id * in_group : 0) * (64 * 256);    // wavefronts w and w + in_group: the same block, one slot
+    const float* a = dY + (int64_t)m_first * ld_dy;
+    const float* b = X + (int64_t)m_first * ld_x;
+    if (N - n0 > 64) wgrad_tn3_block<4>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out);
+    else wgrad_tn3_block<2>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out);
+}
+
 // dW[e] = sum over the slabs, in slab order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int64_t elems, float* __restrict__ dW) {
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -230,16 +434,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, i
     }
 }
 
-// Number of row slabs the launch of dfol_linear_wgrad_f32 uses (the caller sizes the workspace with it): enough workgroups to
-// fill the chip a few times over, at least 64 rows per slab, a multiple of four (one slab per wavefront of a workgroup).
-extern "C" int dfol_linear_wgrad_slabs(int64_t M, int32_t N, int32_t K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int blocks = dfol_cdiv(N, 128) * dfol_cdiv(K, 128);
-    int wgs = dfol_cdiv(768, blocks);                                   // workgroups per block of dW
+// Row slabs of the bf16x3 kernel: one round of workgroups for the full groups of four blocks (a workgroup owns a CU: one wavefront per
+// SIMD), at least 256 rows (16 steps) per slab.
+static int wgrad_tn3_slabs(int64_t M, int nb) {
+    const int full = nb / 4;
+    int64_t s = full > 0 ? 256 / full : 256;
+    s = std::min<int64_t>(s, (M + 255) / 256);
+    return (int)std::max<int64_t>(s, 1);
+}
+static int wgrad_tn4_slabs(int64_t M, int nb) {
+    int wgs = dfol_cdiv(768, nb);                                       // workgroups per block of dW
     const int64_t max_wgs = (M + 255) / 256;
     if (wgs > max_wgs) wgs = (int)max_wgs;
     if (wgs < 1) wgs = 1;
-    return 4 * wgs;
+    return 4 * wgs;                                                     // one slab per wavefront of a workgroup
+}
+
+// Row slabs the caller sizes the workspace of dfol_linear_wgrad_f32 for (slabs x N x K floats, rounded up to 4 floats per slab): the
+// launch uses this many or fewer.
+extern "C" int dfol_linear_wgrad_slabs(int64_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int nb = dfol_cdiv(N, 128) * dfol_cdiv(K, 128);
+    return std::max(wgrad_tn3_slabs(M, nb), wgrad_tn4_slabs(M, nb));
 }
 
 extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
@@ -247,12 +463,26 @@ extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float
     DFOL_REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "linear_wgrad: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
     DFOL_REQUIRE(dY && X && workspace && dW, "linear_wgrad: null pointer");
     const int nb_n = dfol_cdiv(N, 128), nb_k = dfol_cdiv(K, 128);
-    const int slabs = dfol_linear_wgrad_slabs(M, N, K);
+    const int nb = nb_n * nb_k;
+    int slabs = wgrad_tn4_slabs(M, nb);
     int rows_per_slab = dfol_cdiv(M, slabs);
     rows_per_slab = (rows_per_slab + 7) & ~7;                           // two rows per MFMA step, four steps per ring turn
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = N % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ((uintptr_t)dY % 16 == 0);      // (X rows may be 8-byte aligned only)
-    if (vec4)
+    const char* math = getenv("DFOL_WGRAD_MATH");                       // "f32": the fp32 matrix pipe (exact products); default: bf16x3
+    const bool f32_pipe = math && !strcmp(math, "f32");
+    if (vec4 && !f32_pipe && N >= 4 && K >= 4 && ld_x % 4 == 0 && ((uintptr_t)X % 16 == 0)) {     // fp32 results from the bf16 matrix pipe
+        slabs = wgrad_tn3_slabs(M, nb);
+        rows_per_slab = (dfol_cdiv(M, slabs) + 15) & ~15;               // sixteen rows per MFMA step
+        DFOL_REQUIRE(16 * std::max(ld_dy, ld_x) * 4 < (1ll << 31), "linear_wgrad: row stride too large (%lld)", (long long)std::max(ld_dy, ld_x));
+        const int groups = dfol_cdiv(nb, 4);
+        const size_t lds = nb % 4 == 1 || nb % 4 == 2 ? 2 * 64 * 256 * sizeof(float) : 0;    // the last group splits its rows (two slots)
+        static const hipError_t lds_ok = hipFuncSetAttribute((const void*)wgrad_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             2 * 64 * 256 * sizeof(float));
+        DFOL_REQUIRE(lds_ok == hipSuccess, "linear_wgrad: cannot reserve 128 KB of LDS (%s)", hipGetErrorString(lds_ok));
+        hipLaunchKernelGGL(wgrad_tn3_kernel, dim3(slabs, groups), dim3(256), lds, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_k, nb,
+                           workspace);
+    } else if (vec4)
         hipLaunchKernelGGL(wgrad_tn4_kernel, dim3(slabs / 4, nb_n * nb_k), dim3(256), 0, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_n,
                            nb_k, workspace);
     else                                                                // odd widths: one float per lane and load, the four wavefronts of

@@ -313,23 +313,28 @@ def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
 # round 2: deterministic backward (no atomics), the TN weight-gradient kernel, the attribute-column backward
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,ldx", [(1000, 300, 256, 256), (4097, 512, 2048, 2054), (333, 256, 516, 516), (70, 7, 5, 5), (25600, 300, 256, 256),
-                                       (129, 320, 100, 100)])
-def test_linear_wgrad_against_fp64(M, N, K, ldx):
-    """dW = dY^T X on the fp32 matrix pipe (csrc/dfol_dense_wgrad.hip) against float64, strided X, odd sizes; two runs are bit-identical."""
+                                       (129, 320, 100, 100), (5000, 72, 260, 260), (17, 300, 256, 256)])
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+def test_linear_wgrad_against_fp64(M, N, K, ldx, math, monkeypatch):
+    """dW = dY^T X (csrc/dfol_dense_wgrad.hip) against float64, strided X, odd sizes; two runs are bit-identical.  Both arithmetic
+    routes: three-way bf16 operand split on the bf16 matrix pipe (the default where the rows are 16-byte aligned) and the fp32 matrix
+    pipe (DFOL_WGRAD_MATH=f32, and every shape the first does not take).  Operands span six decades so the split's low pieces matter."""
     from dfol_vqa_amd import _lib
+    monkeypatch.setenv("DFOL_WGRAD_MATH", math)
     g = torch.Generator(device=DEV).manual_seed(M + N)
-    dy = torch.randn(M, N, device=DEV, generator=g)
-    xw = torch.randn(M, ldx, device=DEV, generator=g)
+    dy = torch.randn(M, N, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (M, 1), device=DEV, generator=g).float())
+    xw = torch.randn(M, ldx, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (1, ldx), device=DEV, generator=g).float())
     x = xw[:, :K]
     a = _lib.linear_wgrad(dy, x)
     b = _lib.linear_wgrad(dy, x)
     assert torch.equal(a, b)
     ref = dy.double().t() @ x.double()
-    scale = (dy.double().abs().t() @ x.double().abs()).max().item()
-    assert (a.double() - ref).abs().max().item() <= 2e-6 * scale, (a.double() - ref).abs().max().item() / scale
+    scale = dy.double().abs().t() @ x.double().abs()                    # per element: X's column scales must not hide small columns
+    rel = ((a.double() - ref).abs() / scale).max().item()
+    assert rel <= 2e-6, rel
     # the library's fp32 product is no closer
-    lib = (dy.t() @ x).double()
-    assert (a.double() - ref).abs().max().item() <= 4 * (lib - ref).abs().max().item() + 1e-7 * scale
+    lib = (((dy.t() @ x).double() - ref).abs() / scale).max().item()
+    assert rel <= 4 * lib + 1e-7, (rel, lib)
 
 
 def test_reduce_by_question_and_prior_gradients_are_repeatable():

@@ -54,6 +54,8 @@ SIGNATURES = {
     "dfol_relate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
     "dfol_linear_wgrad_slabs": [_i64, _i32, _i32],          # returns a count, not a status: called directly, not through call()
     "dfol_linear_wgrad_f32": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p],
+    "dfol_linear_wgrad_workspace": [_i64, _i32, _i32],      # returns a float count (int64), called directly
+    "dfol_linear_wgrad_bias_f32": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
     "dfol_attr_ll_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p, _p],
     "dfol_quantify_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_attr_gather_bwd_f32": [_p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p],
@@ -96,6 +98,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    lib.dfol_linear_wgrad_workspace.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -371,19 +374,21 @@ def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
     return out
 
 
-def linear_wgrad(dy, x):
-    """dW [N, K] = dy^T x for dy [M, N], x [M, K] (fp32, unit column stride): exact-fp32 matrix pipe, deterministic."""
+def linear_wgrad(dy, x, bias=False):
+    """dW [N, K] = dy^T x for dy [M, N], x [M, K] (fp32, unit column stride); bias=True: (dW, db) with db [N] = dy.sum(0) from the
+    same pass.  fp32 results on the matrix cores, deterministic (csrc/dfol_dense_wgrad.hip)."""
     M, N = dy.shape
     K = x.shape[1]
     for t in (dy, x):
         if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
             raise DfolError("linear_wgrad needs fp32 GPU matrices with unit column stride")
     lib = load()
-    slabs = lib.dfol_linear_wgrad_slabs(M, N, K)
-    ws = torch.empty(slabs * ((N * K + 3) // 4 * 4), dtype=F32, device=dy.device)
+    ws = torch.empty(lib.dfol_linear_wgrad_workspace(M, N, K), dtype=F32, device=dy.device)
     dw = torch.empty(N, K, dtype=F32, device=dy.device)
-    call("dfol_linear_wgrad_f32", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _stream())
-    return dw
+    db = torch.empty(N, dtype=F32, device=dy.device) if bias else None
+    call("dfol_linear_wgrad_bias_f32", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, _ptr(ws), _ptr(dw),
+         _ptr(db, F32, True), _stream())
+    return (dw, db) if bias else dw
 
 
 def linear_gradx(dz, weight):

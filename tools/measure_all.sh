@@ -24,6 +24,11 @@ DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --mode tr
 timeout 300 python tools/bench_calibrated.py > $O/calibrated_forward.txt 2>&1
 bash tools/step_breakdown.sh ${TAG}_n100 > $O/step_breakdown_n100.md 2>&1
 bash tools/step_breakdown.sh ${TAG}_n36 --objects 36 > $O/step_breakdown_n36.md 2>&1
+bash tools/step_breakdown.sh ${TAG}_train_n100 --mode train --objects 100 > $O/step_breakdown_train_n100.md 2>&1
+# what the bf16 matrix pipe sustains per MFMA shape, and a multiply tick of the pair kernel in isolation
+mkdir -p gpurun_out/peak
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/scratch/mfma_peak.hip -o gpurun_out/peak/mfma_peak > /dev/null 2>&1 && timeout 120 gpurun_out/peak/mfma_peak > $O/mfma_peak.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/scratch/tick_model.hip -o gpurun_out/peak/tick_model > /dev/null 2>&1 && timeout 120 gpurun_out/peak/tick_model > $O/tick_model.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_mfma "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" tools/bench_kernels.py > $O/pmc_mfma_busy.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_insts "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU" tools/bench_kernels.py > $O/pmc_insts.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_fetch "FETCH_SIZE" tools/bench_kernels.py > $O/pmc_fetch_microbench.txt 2>&1

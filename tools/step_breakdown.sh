@@ -24,13 +24,13 @@ for name, n, s, a in rows:
     tot += s / steps / 1e3
     print("| %s | %d | %.1f |" % (name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70], n // steps, s / steps / 1e3))
 print("GPU-busy per step: %.1f us over %d launches" % (tot, sum(n // steps for _, n, _, _ in rows if n % steps == 0)))
-# idle gaps of the last step: (gap us, kernel before -> kernel after), the ten largest and the total
-per_step = sum(n // steps for _, n, _, _ in rows if n % steps == 0)
-last = list(db.execute("select name, start, end from kernels order by start desc limit ?", (per_step,)))[::-1]
+# idle gaps of the last step (from its box_positions launch, the first kernel of a forward, to the end of the trace)
+t0 = list(db.execute("select max(start) from kernels where name like '%box_positions%'"))[0][0]
+last = list(db.execute("select name, start, end from kernels where start >= ? order by start", (t0,)))
 gaps = [((b[1] - a[2]) / 1e3, a[0], b[0]) for a, b in zip(last, last[1:])]
 short = lambda s: s.replace("void ", "").replace("at::native::", "").split("(")[0].split("<")[0][-32:]
-print("last step: %.0f us from first launch to last end, %.0f us idle in %d gaps; largest:" % (
-    (last[-1][2] - last[0][1]) / 1e3, sum(g[0] for g in gaps if g[0] > 0), sum(1 for g in gaps if g[0] > 2)))
+print("last step: %d launches, %.0f us from first launch to last end, %.0f us idle in %d gaps of more than 2 us; largest:" % (
+    len(last), (last[-1][2] - last[0][1]) / 1e3, sum(g[0] for g in gaps if g[0] > 0), sum(1 for g in gaps if g[0] > 2)))
 for g, a, b in sorted(gaps, reverse=True)[:10]:
     print("  %.0f us between %s and %s" % (g, short(a), short(b)))
 # the individual launches of the three largest kernels in the last step (which call is the expensive one)
@@ -38,7 +38,7 @@ for name, n, _, _ in rows[:3]:
     per = n // steps
     if n % steps or per < 2:
         continue
-    d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name = ? order by start desc limit ?", (name, per))][::-1]
+    d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name = ? and start >= ? order by start", (name, t0))]
     print("%s, last step, us per launch: %s" % (name.split("(")[0][-40:], " ".join("%.0f" % x for x in d)))
 PY
 find $OUT -name "*.db" -delete

@@ -85,26 +85,22 @@ __device__ __forceinline__ float ls_act(float x) {
 }
 
 // XV: floats per X load (4: rows 16-byte aligned; 2: rows 8-byte aligned, e.g. the 2054-column raw feature matrix)
-template <int ACT, int XV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_act_split_kernel(
-    const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
-    int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
-    __shared__ __attribute__((aligned(16))) u32x4 As[3 * LS_BM * 4];        // [piece][row][k-group]  24 KB
-    __shared__ __attribute__((aligned(16))) u32x4 Bs[LS_TILE_PIECES];       // the B tile of the step  24 KB
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so id % 8 is the XCD; give each XCD a contiguous run of
-    // logical tiles (column blocks of a row block are consecutive): the X rows are fetched into that XCD's L2 once
-    int bid = blockIdx.x;
-    if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
-    const int mb = bid / nbn, nb = bid - mb * nbn;
+// NT: column tiles of 16 per wavefront - 4, or 2 for a last column block of at most 64 valid columns (N = 300 = 128 + 128 + 44: the third
+// block would otherwise spend a full block's MFMAs on 44 columns, 28 % of the pair layer's forward product)
+template <int ACT, int XV, int NT>
+__device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const float* __restrict__ X, int64_t ldx,
+                                        const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int M, int N,
+                                        int K, int ksteps, int mb, int nb) {
     const int m0 = mb * LS_BM, n0 = nb * LS_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
+    constexpr int WN = 16 * NT;                                       // columns of a wavefront
 
-    floatx4 acc[4][4];
+    floatx4 acc[4][NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // A staging: rows (tid >> 2) and (tid >> 2) + 64, k-group tid & 3 (8 consecutive k): four threads read 128 contiguous bytes
     const int arow = tid >> 2, aq = tid & 3;
@@ -159,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     const int aoff = (wm * 64 + r16) * 4 + (kh ^ ls_swz(r16));
-    const int boff = (wn * 64 + r16) * 4 + (kh ^ ls_swz(r16));
+    const int boff = (wn * WN + r16) * 4 + (kh ^ ls_swz(r16));
 
     constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
     // Step ks: X(ks) was requested two steps ago, the B tile one step ago, and X(ks+1) after it: vmcnt retires in order, so the
@@ -183,7 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * LS_BM * 4 + (ih + i) * 64 + aoff]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 bf16x8 b[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[p * LS_BN * 4 + j * 64 + boff]);
@@ -225,17 +221,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // epilogue: lane holds column r16 and rows 4 kh + e of every 16 x 16 tile.  Interior tiles take the branch-free path.
-    float bv[4];
+    float bv[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = bias ? bias[min(n0 + wn * 64 + j * 16 + r16, N - 1)] : 0.f;
-    float* yp = Y + (int64_t)(m0 + wm * 64 + 4 * kh) * ldy + n0 + wn * 64 + r16;
-    if (m0 + LS_BM <= M && n0 + LS_BN <= N) {
+    for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[min(n0 + wn * WN + j * 16 + r16, N - 1)] : 0.f;
+    float* yp = Y + (int64_t)(m0 + wm * 64 + 4 * kh) * ldy + n0 + wn * WN + r16;
+    if (NT == 4 && m0 + LS_BM <= M && n0 + LS_BN <= N) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = ls_act<ACT>(acc[i][j][e] + bv[j]);
+                for (int j = 0; j < NT; ++j) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = ls_act<ACT>(acc[i][j][e] + bv[j]);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -243,12 +239,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e) {
                 const bool row_ok = m0 + wm * 64 + i * 16 + 4 * kh + e < M;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     const float v = ls_act<ACT>(acc[i][j][e] + bv[j]);
-                    if (row_ok && n0 + wn * 64 + j * 16 + r16 < N) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = v;
+                    if (row_ok && n0 + wn * WN + j * 16 + r16 < N) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = v;
                 }
             }
     }
+}
+
+template <int ACT, int XV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_act_split_kernel(
+    const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
+    int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
+    __shared__ __attribute__((aligned(16))) u32x4 As[3 * LS_BM * 4];        // [piece][row][k-group]  24 KB
+    __shared__ __attribute__((aligned(16))) u32x4 Bs[LS_TILE_PIECES];       // the B tile of the step  24 KB
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so id % 8 is the XCD; give each XCD a contiguous run of
+    // logical tiles (column blocks of a row block are consecutive): the X rows are fetched into that XCD's L2 once
+    int bid = blockIdx.x;
+    if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
+    const int mb = bid / nbn, nb = bid - mb * nbn;
+    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    else ls_tile<ACT, XV, 2>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
 }
 
 }  // namespace

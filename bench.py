@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--ragged", type=int, default=0, help="train mode: object counts ~ U{ragged..objects}")
     ap.add_argument("--calibrator", type=int, default=0, help="train mode: 1 = calibrator phases (cur6-7): oracle frozen, the attention networks train")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--mlp-math", choices=("fp32", "bf16"), default="fp32",
+                    help="train mode: bf16 = configs[3]'s 'bf16 fwd / fp32 logic' (config key mlp_math): the large dense products on bf16-rounded "
+                         "operands, fp32 accumulation; reported as dtype bf16, never the default")
     ap.add_argument("--cpu-sample", type=int, default=None, help="questions in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--parity-all", type=int, default=1, help="1: check every question of the batch against the oracle (not only the timed sample)")
     ap.add_argument("--stress-preds", type=int, default=65536)
@@ -180,6 +183,8 @@ def build_model(args, device, train=False):
                                    freeze_embedding_network=False)
     if args.workload == "c4":
         cfg["relation_tile_dtype"] = "bf16"
+    if train and getattr(args, "mlp_math", "fp32") == "bf16":
+        cfg["mlp_math"] = "bf16"
     ontology = experiment.build_ontology(cfg)
     model = experiment.build_model(cfg, ontology)
     init_weights(model)
@@ -444,9 +449,11 @@ def train_main(args, rank, world, device, td, share):
                          % (args.objects if not args.ragged else "U{%d..%d}" % (args.ragged, args.objects)),
                "value": gb * args.steps / elapsed, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "bf16" if args.mlp_math == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[3]'s step on synthetic scenes: select->filter->relate->exist, BCE loss, %s phase, "
-                                      "%d questions/GPU/step" % ("calibrator (cur6-7)" if args.calibrator else "oracle (cur1-5)", args.batch),
+                                      "%d questions/GPU/step%s" % ("calibrator (cur6-7)" if args.calibrator else "oracle (cur1-5)", args.batch,
+                                                                   ", mlp_math bf16 (dense products on bf16 operands, fp32 accumulation and logic)"
+                                                                   if args.mlp_math == "bf16" else ""),
                           "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
                           "collective": "one all-reduce(sum) of the flat fp32 bucket per step (%s)" % ("gloo, shared GPU" if share else "RCCL")},
                "loss": loss, "replicas_equal": bool(equal), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,

@@ -76,6 +76,9 @@ SIGNATURES = {
     "dfol_pair_logit_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_linear_pack_w_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_split_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    "dfol_linear_pack_w_bf16": [_p, _i64, _i32, _i32, _p, _p],
+    "dfol_linear_act_bf16_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    "dfol_linear_wgrad_bias_bf16": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
     "dfol_linear_pack_w_nt3_bytes": [_i32, _i32],            # returns a byte count (int64), called directly
     "dfol_linear_pack_w_nt3": [_p, _i64, _i32, _i32, _i32, _p, _p],
     "dfol_linear_act_nt3_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
@@ -345,20 +348,22 @@ SPLIT_MIN_WEIGHT = 65536              # weights of at least this many elements r
 #                                       see different roundings than in one process (tests/test_multirank_gpu.py asserts bit-equality)
 
 
-def linear_pack_w_split(weight, transpose=False):
+def linear_pack_w_split(weight, transpose=False, pieces=3):
     """The bf16x3 image of a Linear weight [N, K] for dfol_linear_act_split_f32, cached per weight version (the cache holds the
     weight tensor, so its address cannot be recycled while the entry lives).  The version counter is what optimizers, load_state_dict
     and nn.init bump; writes through `.data` do not - call `_SPLIT_W_CACHE.clear()` after such a write.
     transpose=True packs weight^T (the operand of the backward product g @ W) under the ORIGINAL parameter's key, so a train step
     finds it by the parameter's version instead of inserting one dead entry per temporary transposed copy."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose))
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose), pieces)
     hit = _SPLIT_W_CACHE.get(key)
     if hit is None:
         src = weight.detach().t().contiguous() if transpose else weight
         N, K = src.shape
-        out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 24576 // 2, dtype=torch.bfloat16, device=weight.device)
-        call("dfol_linear_pack_w_bf16x3", src.data_ptr(), src.stride(0), N, K, _ptr(out, torch.bfloat16), _stream())
-        for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0] and k[4] == key[4]]:      # an older version of the same parameter
+        out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 8192 * pieces // 2, dtype=torch.bfloat16, device=weight.device)
+        # pieces = 3: the exact three-way split; 1: the bf16 mode's image (rounded to nearest)
+        call("dfol_linear_pack_w_bf16x3" if pieces == 3 else "dfol_linear_pack_w_bf16", src.data_ptr(), src.stride(0), N, K,
+             _ptr(out, torch.bfloat16), _stream())
+        for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0] and k[4:] == key[4:]]:    # an older version of the same parameter
             del _SPLIT_W_CACHE[stale]
         if len(_SPLIT_W_CACHE) >= 64:
             _SPLIT_W_CACHE.pop(next(iter(_SPLIT_W_CACHE)))
@@ -403,14 +408,16 @@ def linear_act_nt3(x, weight, bias, act, out=None, transpose_w=False):
 def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
     """y = act(x @ weight.T + bias) on the bf16 matrix pipes with exact three-way operand split: fp32 results.
     transpose_w=True: y = act(x @ weight + bias) (weight [K, N])."""
-    if os.environ.get("DFOL_DENSE_KERNEL") == "nt3":       # A/B switch: the registers-only kernel (csrc/dfol_dense_nt3.hip), same arithmetic
+    bf16 = _dense_math() == "bf16"                         # the bf16 mode: operands rounded to bf16, one product (configs[3])
+    if os.environ.get("DFOL_DENSE_KERNEL") == "nt3" and not bf16:   # A/B switch: the registers-only kernel (csrc/dfol_dense_nt3.hip)
         return linear_act_nt3(x, weight, bias, act, out, transpose_w)
     M, K = x.shape
     N = weight.shape[1] if transpose_w else weight.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
-    call("dfol_linear_act_split_f32", x.data_ptr(), x.stride(0), _ptr(linear_pack_w_split(weight, transpose_w), torch.bfloat16),
-         _ptr(bias, F32, True), out.data_ptr(), out.stride(0), M, N, K, act, _stream())
+    call("dfol_linear_act_bf16_f32" if bf16 else "dfol_linear_act_split_f32", x.data_ptr(), x.stride(0),
+         _ptr(linear_pack_w_split(weight, transpose_w, 1 if bf16 else 3), torch.bfloat16), _ptr(bias, F32, True), out.data_ptr(),
+         out.stride(0), M, N, K, act, _stream())
     return out
 
 
@@ -426,8 +433,8 @@ def linear_wgrad(dy, x, bias=False):
     ws = torch.empty(lib.dfol_linear_wgrad_workspace(M, N, K), dtype=F32, device=dy.device)
     dw = torch.empty(N, K, dtype=F32, device=dy.device)
     db = torch.empty(N, dtype=F32, device=dy.device) if bias else None
-    call("dfol_linear_wgrad_bias_f32", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, _ptr(ws), _ptr(dw),
-         _ptr(db, F32, True), _stream())
+    call("dfol_linear_wgrad_bias_bf16" if _dense_math() == "bf16" else "dfol_linear_wgrad_bias_f32", dy.data_ptr(), dy.stride(0),
+         x.data_ptr(), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _ptr(db, F32, True), _stream())
     return (dw, db) if bias else dw
 
 
@@ -440,8 +447,34 @@ def linear_gradx(dz, weight):
     return linear_act(dz, weight.detach().t().contiguous(), None, ACT_NONE)
 
 
+_MATH_OVERRIDE = None
+
+
 def _dense_math():
-    return os.environ.get("DFOL_DENSE_MATH", "bf16x3")
+    """Arithmetic of the large dense products: "bf16x3" (default: fp32 results from the bf16 pipe), "f32" (the fp32 pipe) or "bf16"
+    (operands rounded to bf16, fp32 accumulation: BASELINE configs[3]'s "bf16 forward", config key `mlp_math: bf16`).  A dense_math()
+    scope takes precedence over the DFOL_DENSE_MATH environment variable."""
+    return _MATH_OVERRIDE or os.environ.get("DFOL_DENSE_MATH", "bf16x3")
+
+
+class dense_math:
+    """with dense_math("bf16"): ...   - the arithmetic of linear_act / linear_gradx / linear_wgrad inside the block.  Autograd functions
+    record the mode of their forward and re-enter it in backward."""
+
+    def __init__(self, mode):
+        if mode not in (None, "bf16x3", "f32", "bf16"):
+            raise DfolError("unknown dense math mode %r" % (mode,))
+        self.mode = mode
+
+    def __enter__(self):
+        global _MATH_OVERRIDE
+        self.saved, _MATH_OVERRIDE = _MATH_OVERRIDE, (self.mode or _MATH_OVERRIDE)
+        return self
+
+    def __exit__(self, *exc):
+        global _MATH_OVERRIDE
+        _MATH_OVERRIDE = self.saved
+        return False
 
 
 def linear_act(x, weight, bias, act, out=None):

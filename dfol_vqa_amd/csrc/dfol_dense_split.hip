@@ -55,24 +55,33 @@ __device__ __forceinline__ void ls_split8(const float4& a, const float4& b, u32x
     l = u32x4{ls_pack(pl[0], pl[1]), ls_pack(pl[2], pl[3]), ls_pack(pl[4], pl[5]), ls_pack(pl[6], pl[7])};
 }
 
-// One thread per 16-byte piece of the packed image.
-__global__ void linear_pack_w_split_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int ksteps, int nblocks, u32x4* __restrict__ out) {
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> two bf16, round to nearest even (v_cvt_pk_bf16_f32): the operand form of the bf16 mode (NP = 1)
+__device__ __forceinline__ uint32_t ls_rne2(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); }
+
+// One thread per 16-byte piece of the packed image.  np = 3: the exact split; np = 1: the bf16 mode's image (one piece, rounded to nearest)
+__global__ void linear_pack_w_split_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int ksteps, int nblocks, int np,
+                                           u32x4* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)nblocks * ksteps * LS_TILE_PIECES) return;
-    const int rem = (int)(idx % LS_TILE_PIECES);
-    const int64_t tile = idx / LS_TILE_PIECES;
+    const int tile_pieces = np * LS_BN * 4;
+    if (idx >= (int64_t)nblocks * ksteps * tile_pieces) return;
+    const int rem = (int)(idx % tile_pieces);
+    const int64_t tile = idx / tile_pieces;
     const int ks = (int)(tile % ksteps), nb = (int)(tile / ksteps);
     const int p = rem / (LS_BN * 4), rr = rem - p * LS_BN * 4, r = rr >> 2, slot = rr & 3;
     const int kq = slot ^ ls_swz(r), n = nb * LS_BN + r, k0 = ks * LS_BK + kq * 8;
     uint32_t piece[8];
+    float w[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float w = (n < N && k0 + j < K) ? W[(int64_t)n * ldw + k0 + j] : 0.f;
+        w[j] = (n < N && k0 + j < K) ? W[(int64_t)n * ldw + k0 + j] : 0.f;
         uint32_t h, m, l;
-        ls_split(w, h, m, l);
+        ls_split(w[j], h, m, l);
         piece[j] = p == 0 ? h : (p == 1 ? m : l);
     }
-    out[idx] = u32x4{ls_pack(piece[0], piece[1]), ls_pack(piece[2], piece[3]), ls_pack(piece[4], piece[5]), ls_pack(piece[6], piece[7])};
+    if (np == 1) out[idx] = u32x4{ls_rne2(w[0], w[1]), ls_rne2(w[2], w[3]), ls_rne2(w[4], w[5]), ls_rne2(w[6], w[7])};
+    else out[idx] = u32x4{ls_pack(piece[0], piece[1]), ls_pack(piece[2], piece[3]), ls_pack(piece[4], piece[5]), ls_pack(piece[6], piece[7])};
 }
 
 template <int ACT>
@@ -87,7 +96,9 @@ __device__ __forceinline__ float ls_act(float x) {
 // XV: floats per X load (4: rows 16-byte aligned; 2: rows 8-byte aligned, e.g. the 2054-column raw feature matrix)
 // NT: column tiles of 16 per wavefront - 4, or 2 for a last column block of at most 64 valid columns (N = 300 = 128 + 128 + 44: the third
 // block would otherwise spend a full block's MFMAs on 44 columns, 28 % of the pair layer's forward product)
-template <int ACT, int XV, int NT>
+// NP: pieces per operand - 3: fp32 results (six piece products per step and accumulator); 1: the bf16 mode (operands rounded to bf16, one
+// product, fp32 accumulation - what a "bf16 forward" computes; BASELINE configs[3])
+template <int ACT, int XV, int NT, int NP>
 __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const float* __restrict__ X, int64_t ldx,
                                         const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int M, int N,
                                         int K, int ksteps, int mb, int nb) {
@@ -130,34 +141,41 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = arow + 64 * h;
-            u32x4 ph, pm, pl;
-            ls_split8(k < K ? xa[S][h][0] : z, k + 4 < K ? xa[S][h][1] : z, ph, pm, pl);
+            const float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
             const int at = row * 4 + (aq ^ ls_swz(row));
-            As[at] = ph;
-            As[LS_BM * 4 + at] = pm;
-            As[2 * LS_BM * 4 + at] = pl;
+            if (NP == 1) {
+                As[at] = u32x4{ls_rne2(v0.x, v0.y), ls_rne2(v0.z, v0.w), ls_rne2(v1.x, v1.y), ls_rne2(v1.z, v1.w)};
+            } else {
+                u32x4 ph, pm, pl;
+                ls_split8(v0, v1, ph, pm, pl);
+                As[at] = ph;
+                As[LS_BM * 4 + at] = pm;
+                As[2 * LS_BM * 4 + at] = pl;
+            }
         }
     };
-    const u32x4* wtile = Wp + (int64_t)nb * ksteps * LS_TILE_PIECES;
+    constexpr int TILE_PIECES = NP * LS_BN * 4;                        // 16-byte pieces of one B tile in the packed image
+    const u32x4* wtile = Wp + (int64_t)nb * ksteps * TILE_PIECES;
     // B tile of the next step: six 16-byte pieces per thread, in registers until the tile in LDS has been consumed.  (LDS-DMA would
     // save the registers, but the compiler treats an in-flight global_load_lds as a pending FLAT access and turns EVERY later wait -
     // also the one for the X registers - into vmcnt(0), which would drain the two-step X prefetch at every step.  Reading the B
     // fragments straight from global memory into the MFMA operand registers - the packed image is in fragment order - was measured
     // too: no LDS traffic for B at all, same speed at K = 2048 and 15 % slower at K = 516.)
-    u32x4 wb[LS_TILE_PIECES / 256];
+    u32x4 wb[TILE_PIECES / 256];
     auto load_w = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < LS_TILE_PIECES / 256; ++i) wb[i] = wtile[(int64_t)ks * LS_TILE_PIECES + 256 * i + tid];
+        for (int i = 0; i < TILE_PIECES / 256; ++i) wb[i] = wtile[(int64_t)ks * TILE_PIECES + 256 * i + tid];
     };
     auto store_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < LS_TILE_PIECES / 256; ++i) Bs[256 * i + tid] = wb[i];
+        for (int i = 0; i < TILE_PIECES / 256; ++i) Bs[256 * i + tid] = wb[i];
     };
 
     const int aoff = (wm * 64 + r16) * 4 + (kh ^ ls_swz(r16));
     const int boff = (wn * WN + r16) * 4 + (kh ^ ls_swz(r16));
 
     constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int X0 = NP == 1 ? 5 : 0;                               // the bf16 mode keeps the last product only (piece 0 x piece 0)
     // Step ks: X(ks) was requested two steps ago, the B tile one step ago, and X(ks+1) after it: vmcnt retires in order, so the
     // wait for the B registers leaves the four loads of X(ks+1) in flight.
     auto step = [&](int ks, auto set_tag, auto has_b, auto has_x) __attribute__((always_inline)) {
@@ -173,20 +191,20 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         __builtin_amdgcn_sched_barrier(0);                  // requests first; and the next step's split must not drift up here
 #pragma unroll
         for (int ih = 0; ih < 4; ih += 2) {                 // two row tiles at a time (register budget)
-            bf16x8 a[2][3];
+            bf16x8 a[2][NP];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * LS_BM * 4 + (ih + i) * 64 + aoff]);
+                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * LS_BM * 4 + (ih + i) * 64 + aoff]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                bf16x8 b[3];
+                bf16x8 b[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[p * LS_BN * 4 + j * 64 + boff]);
+                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[p * LS_BN * 4 + j * 64 + boff]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int x = 0; x < 6; ++x)             // six dependent MFMAs per accumulator, smallest terms first
+                    for (int x = X0; x < 6; ++x)            // six dependent MFMAs per accumulator, smallest terms first
                         acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA6[x]], b[PB6[x]], acc[ih + i][j], 0, 0, 0);
             }
         }
@@ -247,7 +265,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     }
 }
 
-template <int ACT, int XV>
+template <int ACT, int XV, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_act_split_kernel(
     const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
     int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
@@ -258,8 +276,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int bid = blockIdx.x;
     if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     const int mb = bid / nbn, nb = bid - mb * nbn;
-    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
-    else ls_tile<ACT, XV, 2>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    else ls_tile<ACT, XV, 2, NP>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
 }
 
 }  // namespace
@@ -268,19 +286,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 extern "C" int dfol_dense_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dfol_dense_trace_buf), sizeof(dfol_dense_trace_buf)); }
 #endif
 
-extern "C" int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream) {
-    DFOL_REQUIRE(W && W_split && N > 0 && K > 0 && ldw >= K, "linear_pack_w_bf16x3: bad arguments N=%d K=%d", N, K);
-    DFOL_REQUIRE((uintptr_t)W_split % 16 == 0, "linear_pack_w_bf16x3: output must be 16-byte aligned");
+static int ls_pack_w(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream, int np, const char* name) {
+    DFOL_REQUIRE(W && W_split && N > 0 && K > 0 && ldw >= K, "%s: bad arguments N=%d K=%d", name, N, K);
+    DFOL_REQUIRE((uintptr_t)W_split % 16 == 0, "%s: output must be 16-byte aligned", name);
     const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
-    const int64_t total = (int64_t)nbn * ksteps * LS_TILE_PIECES;
+    const int64_t total = (int64_t)nbn * ksteps * np * LS_BN * 4;
     hipLaunchKernelGGL(linear_pack_w_split_kernel, dim3((unsigned)dfol_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, ksteps,
-                       nbn, (u32x4*)W_split);
-    DFOL_LAUNCH_CHECK("linear_pack_w_bf16x3");
+                       nbn, np, (u32x4*)W_split);
+    DFOL_LAUNCH_CHECK(name);
     return 0;
 }
 
-extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy,
-                                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+extern "C" int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream) {
+    return ls_pack_w(W, ldw, N, K, W_split, stream, 3, "linear_pack_w_bf16x3");
+}
+extern "C" int dfol_linear_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_bf16, void* stream) {
+    return ls_pack_w(W, ldw, N, K, W_bf16, stream, 1, "linear_pack_w_bf16");
+}
+
+template <int NP>
+static int ls_launch(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                     int32_t act, void* stream) {
     DFOL_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 2 == 0 && ldx >= K && ldy >= N, "linear_act_split: bad sizes M=%d N=%d K=%d (K %% 4, ldx %% 2)", M, N, K);
     if (M == 0) return 0;
     DFOL_REQUIRE(X && W_split && Y, "linear_act_split: null pointer");
@@ -289,13 +315,13 @@ extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void
     const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN), nbm = dfol_cdiv(M, LS_BM);
     DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_act_split: too many tiles");
     const int nblocks = nbm * nbn;
-#define DFOL_LS(A)                                                                                                                      \
-    if (x16)                                                                                                                            \
-        hipLaunchKernelGGL((linear_act_split_kernel<A, 4>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, bias, \
-                           Y, ldy, M, N, K, ksteps, nbn, nblocks);                                                                     \
-    else                                                                                                                                \
-        hipLaunchKernelGGL((linear_act_split_kernel<A, 2>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, bias, \
-                           Y, ldy, M, N, K, ksteps, nbn, nblocks)
+#define DFOL_LS(A)                                                                                                                          \
+    if (x16)                                                                                                                                \
+        hipLaunchKernelGGL((linear_act_split_kernel<A, 4, NP>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split,   \
+                           bias, Y, ldy, M, N, K, ksteps, nbn, nblocks);                                                                   \
+    else                                                                                                                                    \
+        hipLaunchKernelGGL((linear_act_split_kernel<A, 2, NP>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split,   \
+                           bias, Y, ldy, M, N, K, ksteps, nbn, nblocks)
     switch (act) {
         case DFOL_ACT_NONE: DFOL_LS(DFOL_ACT_NONE); break;
         case DFOL_ACT_SIGMOID: DFOL_LS(DFOL_ACT_SIGMOID); break;
@@ -306,4 +332,13 @@ extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void
 #undef DFOL_LS
     DFOL_LAUNCH_CHECK("linear_act_split");
     return 0;
+}
+
+extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy,
+                                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    return ls_launch<3>(X, ldx, W_split, bias, Y, ldy, M, N, K, act, stream);
+}
+extern "C" int dfol_linear_act_bf16_f32(const float* X, int64_t ldx, const void* W_bf16, const float* bias, float* Y, int64_t ldy,
+                                        int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    return ls_launch<1>(X, ldx, W_bf16, bias, Y, ldy, M, N, K, act, stream);
 }

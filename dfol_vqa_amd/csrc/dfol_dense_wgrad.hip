@@ -259,8 +259,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w3_descriptor(const float* bas
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
 }
 
+typedef __bf16 w3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float w3_f32x2 __attribute__((ext_vector_type(2)));
+// eight fp32 -> eight bf16, round to nearest even (v_cvt_pk_bf16_f32): the operand of the bf16 mode (NP = 1)
+__device__ __forceinline__ w3_u32x4 w3_rne8(const float (&v)[8]) {
+    w3_u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(w3_f32x2{v[2 * j], v[2 * j + 1]}, w3_bf16x2));
+    return r;
+}
+
 // AV: floats of dY a lane loads per row = row tiles of the block (4: 128 output rows; 2: a narrow last row block, up to 64 output rows)
-template <int AV>
+// NP: pieces per operand - 3: fp32 results (six piece products); 1: the bf16 mode (operands rounded to bf16, one product, fp32 accumulation)
+template <int AV, int NP>
 __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x,
                                                      int rows, int steps, int N, int K, int n0, int k0, int lane, bool want_bias,
                                                      f32x16 (&acc)[AV][4], float (&bs)[AV]) {
@@ -309,7 +320,7 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
     load(0);
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < steps; ++s) {
-        w3_u32x4 ap[AV][3], bp[4][3];
+        w3_u32x4 ap[AV][NP], bp[4][NP];
         if (want_bias) {
 #pragma unroll
             for (int t = 0; t < AV; ++t)
@@ -320,7 +331,8 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
             float v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = ra[r][t];
-            w3_split8(v, ap[t][0], ap[t][1], ap[t][2]);
+            if constexpr (NP == 1) ap[t][0] = w3_rne8(v);
+            else w3_split8(v, ap[t][0], ap[t][1], ap[t][2]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -328,7 +340,8 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
             float v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = __uint_as_float(rb[r][u]);
-            w3_split8(v, bp[u][0], bp[u][1], bp[u][2]);
+            if constexpr (NP == 1) bp[u][0] = w3_rne8(v);
+            else w3_split8(v, bp[u][0], bp[u][1], bp[u][2]);
             __builtin_amdgcn_sched_barrier(0);
         }
         load(s + 1);
@@ -338,14 +351,14 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
 #pragma unroll
             for (int t = 0; t < AV; ++t)
 #pragma unroll
-                for (int x = 0; x < 6; ++x)
+                for (int x = NP == 1 ? 5 : 0; x < 6; ++x)                       // (the bf16 mode keeps the last product: piece 0 x piece 0)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w3_bf16x8, ap[t][PA6[x]]),
                                                                         __builtin_bit_cast(w3_bf16x8, bp[u][PB6[x]]), acc[t][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int AV>
+template <int AV, int NP>
 __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int rows,
                                                 int steps, int N, int K, int n0, int k0, int lane, int role, float* __restrict__ lds,
                                                 float* __restrict__ out, float* __restrict__ db_out) {
@@ -354,7 +367,7 @@ __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, in
     f32x16 acc[AV][4];
     float bs[AV];
     const bool want_bias = db_out != nullptr && k0 == 0;
-    wgrad_tn3_accumulate<AV>(dY, ld_dy, X, ld_x, rows, steps, N, K, n0, k0, lane, want_bias, acc, bs);
+    wgrad_tn3_accumulate<AV, NP>(dY, ld_dy, X, ld_x, rows, steps, N, K, n0, k0, lane, want_bias, acc, bs);
     if (role == 2) {
 #pragma unroll
         for (int t = 0; t < AV; ++t)
@@ -401,6 +414,7 @@ __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, in
 constexpr int W3_LDS_SLOT = 64 * (256 + 4);        // floats a row-half partner hands over: 256 accumulators and 4 bias sums per lane
 
 // grid (row slabs, groups of four blocks); dynamic LDS: two slots when the last group splits its rows (see the launcher), else none
+template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_tn3_kernel(
     const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int M, int N, int K, int rows_per_slab, int nb_k,
     int nb, float* __restrict__ part, float* __restrict__ db_part) {
@@ -433,8 +447,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* db_out = db_part ? db_part + (int64_t)blockIdx.x * ((N + 3) & ~3) : nullptr;
     const float* a = dY + (int64_t)m_first * ld_dy;
     const float* b = X + (int64_t)m_first * ld_x;
-    if (N - n0 > 64) wgrad_tn3_block<4>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
-    else wgrad_tn3_block<2>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
+    if (N - n0 > 64) wgrad_tn3_block<4, NP>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
+    else wgrad_tn3_block<2, NP>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
 }
 
 // dW[e] = sum over the slabs in a fixed order: a workgroup takes 16 groups of four elements x 16 slab phases (phase p adds slabs p,
@@ -511,8 +525,8 @@ extern "C" int64_t dfol_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K) 
     return slabs * (((((int64_t)N * K) + 3) & ~(int64_t)3) + ((N + 3) & ~3));
 }
 
-extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
-                                          float* workspace, float* dW, float* db, void* stream) {
+static int wgrad_launch(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K, float* workspace,
+                        float* dW, float* db, void* stream, bool bf16_mode) {
     DFOL_REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "linear_wgrad: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
     DFOL_REQUIRE(dY && X && workspace && dW, "linear_wgrad: null pointer");
     float* db_part = db ? workspace + (int64_t)dfol_linear_wgrad_slabs(M, N, K) * ((((int64_t)N * K) + 3) & ~(int64_t)3) : nullptr;
@@ -524,7 +538,7 @@ extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const 
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = N % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ((uintptr_t)dY % 16 == 0);      // (X rows may be 8-byte aligned only)
     const char* math = getenv("DFOL_WGRAD_MATH");                       // "f32": the fp32 matrix pipe (exact products); default: bf16x3
-    const bool f32_pipe = math && !strcmp(math, "f32");
+    const bool f32_pipe = !bf16_mode && math && !strcmp(math, "f32");
     bool bias_done = false;
     if (vec4 && !f32_pipe && N >= 4 && K >= 4) {                        // fp32 results from the bf16 matrix pipe (X rows: any 4-byte alignment)
         slabs = wgrad_tn3_slabs(M, nb);
@@ -532,11 +546,17 @@ extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const 
         DFOL_REQUIRE(16 * std::max(ld_dy, ld_x) * 4 < (1ll << 31), "linear_wgrad: row stride too large (%lld)", (long long)std::max(ld_dy, ld_x));
         const int groups = dfol_cdiv(nb, 4);
         const size_t lds = nb % 4 == 1 || nb % 4 == 2 ? 2 * W3_LDS_SLOT * sizeof(float) : 0;  // the last group splits its rows (two slots)
-        static const hipError_t lds_ok = hipFuncSetAttribute((const void*)wgrad_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        static const hipError_t lds_ok = hipFuncSetAttribute((const void*)wgrad_tn3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                              2 * W3_LDS_SLOT * sizeof(float));
-        DFOL_REQUIRE(lds_ok == hipSuccess, "linear_wgrad: cannot reserve 130 KB of LDS (%s)", hipGetErrorString(lds_ok));
-        hipLaunchKernelGGL(wgrad_tn3_kernel, dim3(slabs, groups), dim3(256), lds, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_k, nb,
-                           workspace, db_part);
+        static const hipError_t lds_ok1 = hipFuncSetAttribute((const void*)wgrad_tn3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                              2 * W3_LDS_SLOT * sizeof(float));
+        DFOL_REQUIRE(lds_ok == hipSuccess && lds_ok1 == hipSuccess, "linear_wgrad: cannot reserve 130 KB of LDS (%s)", hipGetErrorString(lds_ok));
+        if (bf16_mode)
+            hipLaunchKernelGGL(wgrad_tn3_kernel<1>, dim3(slabs, groups), dim3(256), lds, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_k,
+                               nb, workspace, db_part);
+        else
+            hipLaunchKernelGGL(wgrad_tn3_kernel<3>, dim3(slabs, groups), dim3(256), lds, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_k,
+                               nb, workspace, db_part);
         bias_done = true;
     } else if (vec4)
         hipLaunchKernelGGL(wgrad_tn4_kernel, dim3(slabs / 4, nb_n * nb_k), dim3(256), 0, st, dY, ld_dy, X, ld_x, (int)M, N, K, rows_per_slab, nb_n,
@@ -559,7 +579,19 @@ extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const 
     return 0;
 }
 
+extern "C" int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                          float* workspace, float* dW, float* db, void* stream) {
+    return wgrad_launch(dY, ld_dy, X, ld_x, M, N, K, workspace, dW, db, stream, false);
+}
+
+// bf16 mode (BASELINE configs[3]): both operands rounded to bf16, one product per pair, fp32 accumulation; the bias gradient stays an
+// fp32 sum.  Shapes the bf16x3 kernel does not take (widths that are not multiples of 4) run in fp32 as above.
+extern "C" int dfol_linear_wgrad_bias_bf16(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                           float* workspace, float* dW, float* db, void* stream) {
+    return wgrad_launch(dY, ld_dy, X, ld_x, M, N, K, workspace, dW, db, stream, true);
+}
+
 extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
                                      float* workspace, float* dW, void* stream) {
-    return dfol_linear_wgrad_bias_f32(dY, ld_dy, X, ld_x, M, N, K, workspace, dW, nullptr, stream);
+    return wgrad_launch(dY, ld_dy, X, ld_x, M, N, K, workspace, dW, nullptr, stream, false);
 }

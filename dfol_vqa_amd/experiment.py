@@ -70,12 +70,18 @@ def build_interpreter(config, neural_dict, ontology):           # gqa_interprete
                               normalize=bool(config.get('normalize_oracle')), cached=True)
     if str(config.get('relation_tile_dtype', 'fp32')).lower() in ('bf16', 'bfloat16'):     # an extra key of this build (configs[4])
         oracle._tile_dtype = torch.bfloat16
-    return BatchGQAInterpreter(config['model_name'], oracle, ontology, featurizer, trainable_gate=config['trainable_gate'],
-                               likelihood_threshold=config['likelihood_threshold'], hard_mode=config.get('hard_mode', False),
-                               attention_transfer_state_dim=config['attention_transfer_state_dim'],
-                               forward_attention_network=neural_dict['forward_attention_network'],
-                               backward_attention_network=neural_dict['backward_attention_network'],
-                               attention_output_network=neural_dict['attention_output_network'], cached=True)
+    model = BatchGQAInterpreter(config['model_name'], oracle, ontology, featurizer, trainable_gate=config['trainable_gate'],
+                                likelihood_threshold=config['likelihood_threshold'], hard_mode=config.get('hard_mode', False),
+                                attention_transfer_state_dim=config['attention_transfer_state_dim'],
+                                forward_attention_network=neural_dict['forward_attention_network'],
+                                backward_attention_network=neural_dict['backward_attention_network'],
+                                attention_output_network=neural_dict['attention_output_network'], cached=True)
+    mlp_math = str(config.get('mlp_math', 'fp32')).lower()                                 # an extra key of this build (configs[3])
+    if mlp_math in ('bf16', 'bfloat16'):
+        model._mlp_math = 'bf16'
+    elif mlp_math not in ('fp32', 'float32', 'f32'):
+        raise ValueError("mlp_math must be fp32 or bf16, got %r" % (config.get('mlp_math'),))
+    return model
 
 
 def build_model(config, ontology):                              # base_experiment.py:28-30

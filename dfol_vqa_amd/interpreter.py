@@ -176,7 +176,12 @@ class BatchInterpreterBase(nn.Module):
         queue = [] if outer is None else outer                 # (a graph capture installs its own queue, see GraphedForward)
         gqa_ops.DEFERRED.queue = queue
         try:
-            all_results, all_traces, device = self._run_batches(program_batch_list, is_training, modulator_switch)
+            # `_mlp_math` (config key `mlp_math`, experiment.build_interpreter): "bf16" runs the large dense products of the featurizer and
+            # the oracle MLPs - forward, and through the autograd functions' recorded mode their backward - on bf16-rounded operands with
+            # fp32 accumulation (BASELINE configs[3]: "bf16 fwd / fp32 logic"); the logic kernels and everything small stay fp32
+            from . import _lib
+            with _lib.dense_math(getattr(self, "_mlp_math", None)):
+                all_results, all_traces, device = self._run_batches(program_batch_list, is_training, modulator_switch)
         finally:
             gqa_ops.DEFERRED.queue = outer
         if outer is None:

@@ -323,10 +323,16 @@ class _LinearAct(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.math = _lib._dense_math()                # the backward products run in the forward's arithmetic
         return y
 
     @staticmethod
     def backward(ctx, g):
+        with _lib.dense_math(ctx.math):
+            return _LinearAct._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         if ctx.act == _lib.ACT_SIGMOID:
             dz = g * y * (1 - y)

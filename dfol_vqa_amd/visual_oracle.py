@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import ops as L
 from .fol_types import TokenType
 from .host_util import flatten_list, get_lowered, lower_tokens, segments_of, upload
@@ -157,11 +158,12 @@ class _TallLinear(torch.autograd.Function):
     @staticmethod
     def _split_ok(x2, k):
         return x2.is_cuda and x2.dtype == torch.float32 and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and \
-            os.environ.get("DFOL_DENSE_MATH", "bf16x3") != "f32"
+            _lib._dense_math() != "f32"
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        ctx.math = _lib._dense_math()
         x2 = x.reshape(-1, x.shape[-1])
         if _TallLinear._split_ok(x2, x2.shape[1]):          # fp32 results from the bf16 matrix pipe (csrc/dfol_dense_split.hip)
             w = weight.detach()
@@ -171,6 +173,11 @@ class _TallLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        with _lib.dense_math(ctx.math):
+            return _TallLinear._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, weight = ctx.saved_tensors
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         gx = None

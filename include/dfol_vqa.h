@@ -232,6 +232,13 @@ int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K,
 int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M,
                               int32_t N, int32_t K, int32_t act, void* stream);
 
+/* The bf16 mode of the same kernel (BASELINE configs[3] "bf16 fwd / fp32 logic"; config key `mlp_math: bf16`): both operands rounded to
+ * bf16 (nearest even), ONE product per operand pair, fp32 accumulation, fp32 output.  NOT the reference's numerics (relative error
+ * ~2^-8 per product); a sixth of the matrix-pipe time.  W_bf16: ceil(N/128) * ceil(K/32) * 8192 bytes from dfol_linear_pack_w_bf16. */
+int dfol_linear_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_bf16, void* stream);
+int dfol_linear_act_bf16_f32(const float* X, int64_t ldx, const void* W_bf16, const float* bias, float* Y, int64_t ldy, int32_t M,
+                             int32_t N, int32_t K, int32_t act, void* stream);
+
 /* The same product, same three-way split, as a registers-only kernel (dfol_vqa_amd/csrc/dfol_dense_nt3.hip): X fragments straight
  * from global memory into the operand registers of v_mfma_f32_32x32x16_bf16, no LDS; one wavefront per SIMD owns up to 128 x 128
  * of Y and the column blocks of a row block share a workgroup, so X is fetched from HBM once.  W_packed comes from
@@ -383,6 +390,10 @@ int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_
 int64_t dfol_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K);
 int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
                                float* workspace, float* dW, float* db, void* stream);
+/* bf16 mode of the weight gradient (see dfol_linear_act_bf16_f32): operands rounded to bf16, one product, fp32 accumulation; db stays
+ * an fp32 sum.  Same workspace. */
+int dfol_linear_wgrad_bias_bf16(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                float* workspace, float* dW, float* db, void* stream);
 
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B (the reference gets them from torch autograd through

@@ -449,3 +449,62 @@ def test_train_step_is_bitwise_repeatable(ontology):
             assert torch.equal(runs[0][1][k], runs[1][1][k]), (name, k)
         for k in runs[0][2]:
             assert torch.equal(runs[0][2][k], runs[1][2][k]), (name, k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the bf16 mode (BASELINE configs[3] "bf16 fwd / fp32 logic", config key mlp_math): opt-in, never the default
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,act", [(700, 512, 2048, 2), (513, 300, 256, 1), (4000, 256, 300, 0), (130, 768, 516, 3)])
+def test_bf16_mode_dense_kernels_are_bf16_operands_fp32_accumulation(M, N, K, act):
+    """dense_math("bf16"): y = act(x W^T + b), dx = dz W and dW = dz^T x equal the fp64 products of the bf16-ROUNDED operands to fp32
+    accumulation error - the definition of the mode - and differ from the fp32 results by bf16-sized errors (so the mode is really on)."""
+    from dfol_vqa_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    rb = lambda t: t.bfloat16().double()                                   # round to nearest even
+    act_f = [lambda z: z, torch.sigmoid, torch.nn.functional.elu, torch.nn.functional.logsigmoid][act]
+    with _lib.dense_math("bf16"):
+        y = _lib.linear_act(x, w, b, act)
+        dz = torch.randn(M, N, device=DEV, generator=g)
+        dx = _lib.linear_gradx(dz, w)
+        dw, db = _lib.linear_wgrad(dz, x, bias=True)
+    y32 = _lib.linear_act(x, w, b, act)
+    ref = act_f(rb(x) @ rb(w).t() + b.double())
+    assert (y.double() - ref).abs().max().item() <= 2e-5
+    assert (y - y32).abs().max().item() > 1e-4                             # not the fp32 path
+    ref_dx = rb(dz) @ rb(w)
+    assert (dx.double() - ref_dx).abs().max().item() <= 2e-6 * (rb(dz).abs() @ rb(w).abs()).max().item()
+    ref_dw = rb(dz).t() @ rb(x)
+    assert (dw.double() - ref_dw).abs().max().item() <= 2e-6 * (rb(dz).abs().t() @ rb(x).abs()).max().item()
+    assert ((db.double() - dz.double().sum(0)).abs() / dz.double().abs().sum(0)).max().item() <= 2e-6      # the bias gradient stays fp32
+
+
+def test_bf16_mode_train_step_close_to_fp32_and_repeatable():
+    """A full-size model trains with `mlp_math: bf16` (experiment config key): the step's loss is within 1 % of the fp32 step's, every
+    weight gradient points the same way (cosine > 0.99), two bf16 steps from the same state are bit-identical, and the default stays fp32."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    runs = {}
+    for math in ("fp32", "bf16", "bf16"):
+        args = bench.parse(["--mode", "train", "--objects", "24", "--batch", "16", "--mlp-math", math])
+        torch.manual_seed(3)
+        model, ontology, paths, names = bench.build_model(args, DEV, train=True)
+        assert getattr(model, "_mlp_math", None) == ("bf16" if math == "bf16" else None)
+        _, pbs = bench.build_batch(args, 0, ontology, names, DEV)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        loss, _ = training.train_batch(model, opt, pbs, clip_norm=0.65)
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        runs.setdefault(math, []).append((loss, grads))
+    (l32, g32), (lb, gb), (lb2, gb2) = runs["fp32"][0], runs["bf16"][0], runs["bf16"][1]
+    assert abs(lb - l32) <= 1e-2 * abs(l32), (lb, l32)
+    assert lb != l32                                                        # the mode changes the arithmetic
+    assert lb == lb2 and all(torch.equal(gb[k], gb2[k]) for k in gb)
+    for k in g32:
+        if float(g32[k].abs().max()) == 0:
+            continue
+        cos = torch.nn.functional.cosine_similarity(g32[k].flatten().double(), gb[k].flatten().double(), dim=0).item()
+        assert cos > 0.99, (k, cos)

@@ -195,3 +195,17 @@ def test_reference_config_yamls_build(tmp_path):
         assert "_oracle._embedding_network._network.1.weight" in names and "_featurizer._featurizer_network._network.1.weight" in names
     if len(cfgs) == 9:                                       # oracle phases, embedding-frozen phase, calibrator phases
         assert trainable == {2303947, 1254859, 148404}, trainable
+
+
+def test_mlp_math_config_key(tmp_path):
+    """`mlp_math` (an extra key of this build, BASELINE configs[3]): fp32 is the default, bf16 is recorded on the interpreter, anything
+    else is rejected."""
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd import synthetic as syn
+    paths, _ = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    assert getattr(experiment.build_model(dict(cfg), ont), "_mlp_math", None) is None
+    assert experiment.build_model(dict(cfg, mlp_math="bf16"), ont)._mlp_math == "bf16"
+    with pytest.raises(ValueError):
+        experiment.build_model(dict(cfg, mlp_math="fp8"), ont)

@@ -16,7 +16,7 @@ timeout 300 python bench.py --workload c1 > $O/bench_c1_n36.json 2> $O/bench_c1.
 timeout 600 python bench.py --workload c4 --steps 10 > $O/bench_c4_n256.json 2> $O/bench_c4.err
 timeout 300 python tools/bench_kernels.py > $O/kernel_microbench.jsonl 2> $O/kb.err
 timeout 300 python tools/bench_ops.py > $O/ops_throughput.jsonl 2> $O/ops.err
-for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1"; do
+for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1" "--objects 100 --mlp-math bf16"; do
   timeout 300 python bench.py --mode train --steps 10 $a >> $O/train_step.jsonl 2>> $O/train.err
 done
 DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2r.err

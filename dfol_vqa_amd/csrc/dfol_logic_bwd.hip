@@ -108,21 +108,23 @@ extern "C" int dfol_filter_bwd_f32(const float* g_out, const float* ll, const in
 }
 
 // ---------------------------------------------------------------------------------------------------
-// relate: one wavefront per tile, two sweeps (recompute the row/column sums, then the gradients).
+// relate: one workgroup per tile, two sweeps (recompute the row/column sums, then the gradients).
 // Rows = variable R, columns = variable C, as in the forward kernel.
 //   G1[r,c] = gR[r] F_C'(S[r]) F_C'(l'+pC[c]) ; G2[r,c] = gC[c] F_R'(T[c]) F_R'(l'+pR[r])    (off-diagonal)
 //   d l' = G1 + G2 ;  d pR[r] = gR[r] + sum_c G2 ;  d pC[c] = gC[c] + sum_r G1
 // ---------------------------------------------------------------------------------------------------
+// One workgroup per predicate, its four wavefronts on rows r = w, w + 4, ...: a row's sums are taken by the wavefront that owns the row,
+// a column's partial sums of the four wavefronts are added in wavefront order (no atomics).  (One wavefront per predicate, round 1: 0.25 ms
+// for the 256 predicates of a train step, all of it the latency of 2 x 100 dependent row iterations.)
 __global__ __launch_bounds__(256) void relate_bwd_kernel(
     const float* __restrict__ prior_R, const float* __restrict__ prior_C, const float* __restrict__ tile,
     const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_R,
     const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
     const float* __restrict__ g_post_R, const float* __restrict__ g_post_C, int P, int NS, int identity_forall,
     float* __restrict__ g_prior_R, float* __restrict__ g_prior_C, float* __restrict__ g_tile) {
-    __shared__ float sS[4][256], sT[4][256], sGR[4][256], sGC[4][256];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + w;
-    if (p >= P) return;
+    __shared__ float sS[256], sGR[256], sGC[256], sPart[4][256];      // row sums / outer derivatives / per-wavefront column partials
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int p = blockIdx.x;
     const int q = pred_q[p];
     const int n = n_obj[q];
     const float* pR = prior_R + (int64_t)q * NS;
@@ -133,24 +135,24 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
     const float* gC = g_post_C ? g_post_C + (int64_t)p * NS : nullptr;
 
     if (active && !active[p]) {                            // posterior = prior: the gradient passes straight through
-        for (int c = lane; c < NS; c += 64) {
+        for (int c = tid; c < NS; c += 256) {
             if (g_prior_R) g_prior_R[(int64_t)p * NS + c] = (gR && c < n) ? gR[c] : 0.f;
             if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = (gC && c < n) ? gC[c] : 0.f;
         }
         if (gt)
-            for (int e = lane; e < NS * NS; e += 64) gt[e] = 0.f;
+            for (int e = tid; e < NS * NS; e += 256) gt[e] = 0.f;
         return;
     }
     const float alpha_n = (any_neg && neg[p]) ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
     const float qR = quant_R[p], qC = quant_C[p], kR = 1.f - 2.f * qR, kC = 1.f - 2.f * qC;
     const bool idR = identity_forall && qR == 0.f, idC = identity_forall && qC == 0.f;
 
-    // sweep 1: S[r] = sum_c F_C(l' + pC[c]),  T[c] = sum_r F_R(l' + pR[r])   (lane = column, rows sequential)
-    for (int c0 = 0; c0 < n; c0 += 64) {
+    // sweep 1: S[r] = sum_c F_C(l' + pC[c]),  T[c] = sum_r F_R(l' + pR[r])   (lane = column, this wavefront's rows in order)
+    for (int c0 = 0; c0 < NS; c0 += 64) {
         const int c = c0 + lane;
         float t_acc = 0.f;
         const float pc = c < n ? pC[c] : 0.f;
-        for (int r = 0; r < n; ++r) {
+        for (int r = w; r < n; r += 4) {
             float s_part = 0.f;
             if (c < n && c != r) {
                 const float v = dfol_prep(tp[(int64_t)r * NS + c], any_neg, alpha_n, cn);
@@ -159,29 +161,30 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
                 t_acc += idR ? u2 : dfol_pnot(u2, qR, kR);
             }
             s_part = dfol_wave_sum(s_part);
-            if (lane == 0) sS[w][r] = (c0 == 0 ? 0.f : sS[w][r]) + s_part;
+            if (lane == 0) sS[r] = (c0 == 0 ? 0.f : sS[r]) + s_part;
         }
-        if (c < n) sT[w][c] = t_acc;
+        if (c < NS) sPart[w][c] = t_acc;
     }
-    __builtin_amdgcn_wave_barrier();
-    // outer derivatives
-    for (int i = lane; i < n; i += 64) {
-        sGR[w][i] = gR ? gR[i] * (idC ? 1.f : dfol_dpnot(sS[w][i], qC, kC)) : 0.f;
-        sGC[w][i] = gC ? gC[i] * (idR ? 1.f : dfol_dpnot(sT[w][i], qR, kR)) : 0.f;
+    __syncthreads();
+    // outer derivatives (T[c]: the four partials in wavefront order)
+    for (int i = tid; i < n; i += 256) {
+        const float T = ((sPart[0][i] + sPart[1][i]) + sPart[2][i]) + sPart[3][i];
+        sGR[i] = gR ? gR[i] * (idC ? 1.f : dfol_dpnot(sS[i], qC, kC)) : 0.f;
+        sGC[i] = gC ? gC[i] * (idR ? 1.f : dfol_dpnot(T, qR, kR)) : 0.f;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     // sweep 2: gradients
     for (int c0 = 0; c0 < NS; c0 += 64) {
         const int c = c0 + lane;
         float dpc = 0.f;
         const float pc = c < n ? pC[c] : 0.f;
-        const float gcc = c < n ? sGC[w][c] : 0.f;
-        for (int r = 0; r < NS; ++r) {
+        const float gcc = c < n ? sGC[c] : 0.f;
+        for (int r = w; r < NS; r += 4) {
             float dl = 0.f, dpr_part = 0.f;
             if (r < n && c < n && c != r) {
                 const float raw = tp[(int64_t)r * NS + c];
                 const float v = dfol_prep(raw, any_neg, alpha_n, cn);
-                const float g1 = sGR[w][r] * (idC ? 1.f : dfol_dpnot(v + pc, qC, kC));
+                const float g1 = sGR[r] * (idC ? 1.f : dfol_dpnot(v + pc, qC, kC));
                 const float g2 = gcc * (idR ? 1.f : dfol_dpnot(v + pR[r], qR, kR));
                 dl = (g1 + g2) * dfol_dprep(raw, any_neg, alpha_n, cn);
                 dpc += g1;
@@ -190,14 +193,15 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
             if (gt && c < NS) gt[(int64_t)r * NS + c] = dl;
             if (g_prior_R) {                                   // row totals over the column chunks collect in LDS (sS is free by now)
                 dpr_part = dfol_wave_sum(dpr_part);
-                if (lane == 0 && r < n) sS[w][r] = (c0 == 0 ? (gR ? gR[r] : 0.f) : sS[w][r]) + dpr_part;
+                if (lane == 0 && r < n) sS[r] = (c0 == 0 ? (gR ? gR[r] : 0.f) : sS[r]) + dpr_part;
             }
         }
-        if (g_prior_C && c < NS) g_prior_C[(int64_t)p * NS + c] = c < n ? dpc + (gC ? gC[c] : 0.f) : 0.f;
+        if (c < NS) sPart[w][c] = dpc;
     }
-    if (g_prior_R) {
-        __builtin_amdgcn_wave_barrier();
-        for (int r = lane; r < NS; r += 64) g_prior_R[(int64_t)p * NS + r] = r < n ? sS[w][r] : 0.f;
+    __syncthreads();
+    for (int c = tid; c < NS; c += 256) {
+        if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = c < n ? (((sPart[0][c] + sPart[1][c]) + sPart[2][c]) + sPart[3][c]) + (gC ? gC[c] : 0.f) : 0.f;
+        if (g_prior_R) g_prior_R[(int64_t)p * NS + c] = c < n ? sS[c] : 0.f;
     }
 }
 
@@ -212,7 +216,7 @@ extern "C" int dfol_relate_bwd_f32(const float* prior_s, const float* prior_o, c
     DFOL_REQUIRE(prior_s && prior_o && tile && pred_q && n_obj && quant_s && quant_o && (g_post_s || g_post_o), "relate_bwd: null pointer");
     DFOL_REQUIRE(!any_neg || neg, "relate_bwd: any_neg set but neg is NULL");
     const bool sr = orientation == DFOL_TILE_SUBJECT_ROWS;
-    hipLaunchKernelGGL(relate_bwd_kernel, dim3(dfol_cdiv(P, 4)), dim3(256), 0, (hipStream_t)stream, sr ? prior_s : prior_o,
+    hipLaunchKernelGGL(relate_bwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, sr ? prior_s : prior_o,
                        sr ? prior_o : prior_s, tile, pred_q, n_obj, sr ? quant_s : quant_o, sr ? quant_o : quant_s, neg, any_neg, active,
                        sr ? g_post_s : g_post_o, sr ? g_post_o : g_post_s, P, NS, lone_forall_identity, sr ? g_prior_s : g_prior_o,
                        sr ? g_prior_o : g_prior_s, g_tile);

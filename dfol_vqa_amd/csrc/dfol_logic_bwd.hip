@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256) void attr_ll_bwd_emb_kernel(const float* __res
     const int first = obj_off[q], n = obj_off[q + 1] - first;
     const float* w = gx + (int64_t)p * NS;
     float a0 = 0.f, a1 = 0.f, sb = 0.f;
+#pragma unroll 8                                           // (the loads of eight objects in flight; the sums stay in object order)
     for (int o = 0; o < n; ++o) {
         const float wo = w[o];
         const float* h = hidden + (int64_t)(first + o) * ld_h;

@@ -43,8 +43,8 @@ BF16_MFMA_PEAK = 2.5e15      # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)            # (a 20-step timed region at N = 100 is 47 ms: too short for the driver to sample)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=("infer", "train"), default="infer")
     ap.add_argument("--workload", choices=("north_star", "c1", "c4"), default="north_star",
                     help="north_star: configs[1]'s program on 100-object scenes (the size the metric is quoted on); c1: configs[1] verbatim "

@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--ragged", type=int, default=0, help="train mode: object counts ~ U{ragged..objects}")
     ap.add_argument("--calibrator", type=int, default=0, help="train mode: 1 = calibrator phases (cur6-7): oracle frozen, the attention networks train")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--overlap-allreduce", type=int, default=1,
+                    help="train mode, N > 1: 1 = three ranges of the gradient bucket, each all-reduced as soon as the backward has produced it; 0 = one all-reduce after the backward")
     ap.add_argument("--mlp-math", choices=("fp32", "bf16"), default="fp32",
                     help="train mode: bf16 = configs[3]'s 'bf16 fwd / fp32 logic' (config key mlp_math): the large dense products on bf16-rounded "
                          "operands, fp32 accumulation; reported as dtype bf16, never the default")
@@ -405,6 +407,8 @@ def train_main(args, rank, world, device, td, share):
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4)
     bucket = parallel.GradBucket(params)
+    if td is not None and args.overlap_allreduce:
+        bucket.enable_overlap(group, segments=3)             # ranges of the bucket are all-reduced while the backward still runs
     gb = args.batch * world
     # (the loss stays on the GPU and is read once after the timed steps: no host wait between steps)
     step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket, sync_loss=False)
@@ -455,7 +459,9 @@ def train_main(args, rank, world, device, td, share):
                                                                    ", mlp_math bf16 (dense products on bf16 operands, fp32 accumulation and logic)"
                                                                    if args.mlp_math == "bf16" else ""),
                           "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
-                          "collective": "one all-reduce(sum) of the flat fp32 bucket per step (%s)" % ("gloo, shared GPU" if share else "RCCL")},
+                          "collective": "%s of the flat fp32 bucket per step (%s)" % (
+                              "three all-reduces(sum) of contiguous ranges, issued during the backward," if (td is not None and args.overlap_allreduce)
+                              else "one all-reduce(sum)", "gloo, shared GPU" if share else "RCCL")},
                "loss": loss, "replicas_equal": bool(equal), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
                "kernel_ms_per_step": {k: round(v[1] * 1e3, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][1])},
                "kernels": train_kernel_rooflines(args, per_step), "roofline": None, "cpu_baseline": None}

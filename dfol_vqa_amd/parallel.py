@@ -97,6 +97,7 @@ class GradBucket(object):
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._segments = None            # overlap mode: [(first element, end element, first parameter, end parameter)]
         self._attach()
 
     def _attach(self):
@@ -111,12 +112,69 @@ class GradBucket(object):
                p.grad.data_ptr() >= self.flat.data_ptr() + 4 * max(1, self.flat.numel()) for p in self.params):
             self._attach()                                   # someone called zero_grad(set_to_none=True)
         self.flat.zero_()
+        if self._segments is not None:
+            self._pending = [b - a for _, _, a, b in self._segments]
+            self._works = [None] * len(self._segments)
+            self._next = len(self._segments) - 1
 
     def nbytes(self):
         return self.flat.numel() * 4
 
+    def enable_overlap(self, group=None, segments=3):
+        """Overlap the collective with the backward pass: the bucket is cut into `segments` contiguous ranges at parameter boundaries and
+        the all-reduce of a range starts (async, on the collective's own stream) the moment autograd has accumulated the last gradient of
+        the range - post-accumulate-grad hooks - while the rest of the backward still runs.  Autograd reaches the parameters roughly in
+        reverse order, so the ranges are issued last to first - strictly in that order on every rank (a rank whose batch finished an earlier
+        range first holds it back), because collectives must match across ranks.  `allreduce()` then starts whatever has not started
+        (parameters that got no gradient this step) and waits for all of it.  The summed values per element are those of the single
+        all-reduce."""
+        if not self.params or segments <= 1:
+            return self
+        total, bounds, acc = self.flat.numel(), [0], 0
+        for i, p in enumerate(self.params):
+            acc += p.numel()
+            if len(bounds) < segments and acc >= total * len(bounds) / segments and i + 1 < len(self.params):
+                bounds.append(i + 1)
+        bounds.append(len(self.params))
+        starts = [0]
+        for p in self.params:
+            starts.append(starts[-1] + p.numel())
+        self._segments = [(starts[a], starts[b], a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+        self._group = group
+        self._pending = [b - a for _, _, a, b in self._segments]
+        self._works = [None] * len(self._segments)
+        self._next = len(self._segments) - 1
+        seg_of = {}
+        for k, (_, _, a, b) in enumerate(self._segments):
+            for i in range(a, b):
+                seg_of[i] = k
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(lambda _p, k=seg_of[i]: self._ready(k))
+        return self
+
+    # Collectives must be issued in the same order on every rank, whatever order the ranks' (data-dependent) graphs finish their ranges
+    # in: ranges are launched strictly last to first, a finished range waiting for the ones after it.
+    def _launch_ready(self, force=False):
+        while self._next >= 0 and (force or self._pending[self._next] <= 0):
+            a, b, _, _ = self._segments[self._next]
+            if b > a:
+                self._works[self._next] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+            self._next -= 1
+
+    def _ready(self, k):
+        self._pending[k] -= 1
+        if self._pending[k] == 0:
+            self._launch_ready()
+
     def allreduce(self, group=None):
-        """ONE all-reduce (sum) of the whole bucket: RCCL over xGMI with backend "nccl", gloo on CPU."""
+        """All-reduce (sum) of the whole bucket - RCCL over xGMI with backend "nccl", gloo on CPU: ONE collective, or, after
+        enable_overlap(), the completion of the per-range collectives the backward already started."""
+        if self._segments is not None:
+            self._launch_ready(force=True)
+            for w in self._works:
+                if w is not None:
+                    w.wait()
+            return self.nbytes()
         if self.flat.numel():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         return self.nbytes()

@@ -70,7 +70,7 @@ def train_case(rank, world, out):
         pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(mine)]
         params = [p for p in model.parameters() if p.requires_grad]
         opt = torch.optim.Adam(params, lr=1e-3)
-        bucket = parallel.GradBucket(params)
+        bucket = parallel.GradBucket(params).enable_overlap(dist.group.WORLD, segments=3)     # ranges all-reduced during the backward
         bucket.zero_()
         res = model(pbs, True)
         loss = training.compute_loss(pbs, res) / len(qs)                   # sum / B_global (trainer.py:433-436)

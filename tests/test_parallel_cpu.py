@@ -131,6 +131,46 @@ def _worker(rank, world, port, out):
         sharded = step(copy.deepcopy(net), s2, e2, dist.group.WORLD, 8)
         single = step(copy.deepcopy(net), 0, 8, None, None)
         assert torch.allclose(sharded, single, atol=1e-6), (sharded, single)
+
+        # the same through the overlapped bucket (three ranges, all-reduced from post-accumulate-grad hooks during the backward): equal to
+        # the single-process step; and with rank 1 skipping the middle layer (its range gets no gradient there, and the ranks' graphs
+        # finish their ranges in different orders) the collectives still pair up and the replicas stay equal
+        class _Deep(torch.nn.Module):
+            def __init__(self, skip_mid=False):
+                super(_Deep, self).__init__()
+                torch.manual_seed(5)
+                self.l1, self.l2, self.l3 = torch.nn.Linear(6, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 1)
+                self.skip_mid = skip_mid
+
+            def forward(self, data, is_training):
+                h = torch.relu(self.l1(data[0].x))
+                if not self.skip_mid:
+                    h = torch.relu(self.l2(h))
+                return {"log_probability": torch.nn.functional.logsigmoid(self.l3(h)).reshape(-1), "type": QuestionType.BINARY,
+                        "options": ["no", "yes"]}
+
+        def deep_step(lo, hi, group, world_b, overlap, skip_mid=False):
+            model = _Deep(skip_mid)
+            pb = _PB(["yes" if y else "no" for y in ys[lo:hi]])
+            pb.x = xs[lo:hi]
+            params = list(model.parameters())
+            opt = torch.optim.SGD(params, lr=0.1)
+            bucket = parallel.GradBucket(params)
+            if overlap:
+                bucket.enable_overlap(group, segments=3)
+                assert len(bucket._segments) == 3
+            training.train_batch(model, opt, [pb], clip_norm=1e9, global_batch_size=world_b, group=group, bucket=bucket)
+            training.train_batch(model, opt, [pb], clip_norm=1e9, global_batch_size=world_b, group=group, bucket=bucket)   # counters reset per step
+            return torch.cat([p.detach().reshape(-1) for p in params])
+
+        over = deep_step(s2, e2, dist.group.WORLD, 8, True)
+        plain = deep_step(s2, e2, dist.group.WORLD, 8, False)
+        alone = deep_step(0, 8, None, None, False)
+        assert torch.equal(over, plain) and torch.allclose(over, alone, atol=1e-6)
+        ragged = deep_step(s2, e2, dist.group.WORLD, 8, True, skip_mid=(rank == 1))
+        both = [torch.zeros_like(ragged) for _ in range(world)]
+        dist.all_gather(both, ragged)
+        assert torch.equal(both[0], both[1])
         out.put((rank, "ok"))
     except Exception as exc:  # pragma: no cover
         out.put((rank, repr(exc)))

@@ -313,7 +313,8 @@ def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
 # round 2: deterministic backward (no atomics), the TN weight-gradient kernel, the attribute-column backward
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,ldx", [(1000, 300, 256, 256), (4097, 512, 2048, 2054), (333, 256, 516, 516), (70, 7, 5, 5), (25600, 300, 256, 256),
-                                       (129, 320, 100, 100), (5000, 72, 260, 260), (17, 300, 256, 256)])
+                                       (129, 320, 100, 100), (5000, 72, 260, 260), (17, 300, 256, 256),
+                                       (3000, 128, 640, 640), (2000, 64, 128, 128), (40000, 44, 256, 256)])     # 5 blocks (a last group of one), one narrow block
 @pytest.mark.parametrize("math", ["bf16x3", "f32"])
 def test_linear_wgrad_against_fp64(M, N, K, ldx, math, monkeypatch):
     """dW = dY^T X (csrc/dfol_dense_wgrad.hip) against float64, strided X, odd sizes; two runs are bit-identical.  Both arithmetic

@@ -535,8 +535,8 @@ def attach_traffic(out, args):
     def total(prefix, grid=None):
         for key, v in t.items():
             name, gx = key.rsplit("@", 1)
-            if name.startswith(prefix) and (grid is None or int(gx) == grid) and "fetch_bytes_x2" in v and "write_bytes" in v:
-                return v["fetch_bytes_x2"] + v["write_bytes"]
+            if name.startswith(prefix) and (grid is None or int(gx) == grid) and "fetch_bytes_x2" in v:
+                return v["fetch_bytes_x2"] + v.get("write_bytes", 0.0)      # (a kernel whose WRITE_SIZE pass recorded nothing: < 1 KiB per XCD counter tick)
         return None
 
     if "pair_ll" in out["roofline"]["kernel"] and args.objects == 100 and args.batch == 256:

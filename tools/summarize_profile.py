@@ -40,7 +40,7 @@ def main(out):
         print("| kernel | grid.x | dispatches | mean %s (KiB) | MB per dispatch%s |\n|---|---|---|---|---|"
               % (counter, ", read side x2 (gfx950 correction)" if counter == "FETCH_SIZE" else ""))
         q = ("select kernel_name, grid_size_x, count(*), avg(value) from counters_collection where counter_name = ? "
-             "group by kernel_name, grid_size_x order by sum(value) desc limit 16")
+             "group by kernel_name, grid_size_x order by sum(value) desc limit 64")
         for name, gx, n, v in db.execute(q, (counter,)):
             mb = v * 1024 / 1e6 * (2 if counter == "FETCH_SIZE" else 1)
             print("| %s | %d | %d | %.1f | %.2f |" % (short(name), gx, n, v, mb))

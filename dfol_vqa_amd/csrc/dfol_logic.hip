@@ -587,6 +587,115 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     }
 }
 
+// ---- NS > 256 ------------------------------------------------------------------------------------------------------------------------
+// The kernels above keep a whole tile row in the registers of one wavefront (a lane owns four columns: NS <= 256).  Wider tiles - scenes
+// of more than 256 objects, which no configuration of the reference reaches - take these plain forms of the general code: one workgroup
+// per predicate, a thread per column for the column sums (rows in order, coalesced), a workgroup reduction per row for the row sums
+// (wavefront partials added in wavefront order): deterministic, the same formulas, no fast paths.
+__device__ __forceinline__ float relate_prep(float ll, int any_neg, float alpha_n, float cn) {
+    float v = fminf(ll, 0.f);                                            // batch_base_ops.py:194
+    if (any_neg) v = dfol_pnot(v, alpha_n, cn);                          // :212-213
+    return v;
+}
+
+__global__ __launch_bounds__(256) void relate_big_fwd_kernel(
+    const float* __restrict__ prior_R, const float* __restrict__ prior_C, const float* __restrict__ tile,
+    const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_R,
+    const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
+    const uint8_t* __restrict__ want, int want_R_bit, int want_C_bit, int NS, int flags, float* __restrict__ post_R,
+    float* __restrict__ post_C) {
+    __shared__ float part[4];
+    const int p = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int q = pred_q[p], n = n_obj[q];
+    const int wbits = want ? want[p] : 3;
+    const bool wantR = (wbits & want_R_bit) && post_R, wantC = (wbits & want_C_bit) && post_C;
+    const float* pR = prior_R + (int64_t)q * NS;
+    const float* pC = prior_C + (int64_t)q * NS;
+    float* oR = post_R ? post_R + (int64_t)p * NS : nullptr;
+    float* oC = post_C ? post_C + (int64_t)p * NS : nullptr;
+    if (active && !active[p]) {                          // no-op predicate: posterior = prior (batch_base_ops.py:563-564)
+        for (int c = tid; c < NS; c += 256) {
+            if (oR) oR[c] = (wantR && c < n) ? pR[c] : 0.f;
+            if (oC) oC[c] = (wantC && c < n) ? pC[c] : 0.f;
+        }
+        return;
+    }
+    if (!wantR && oR)
+        for (int c = tid; c < NS; c += 256) oR[c] = 0.f;
+    if (!wantC && oC)
+        for (int c = tid; c < NS; c += 256) oC[c] = 0.f;
+    const int identity_forall = flags & DFOL_RELATE_LONE_FORALL_IDENTITY;
+    const float alpha_n = (any_neg && neg[p]) ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
+    const float qR = quant_R[p], qC = quant_C[p], kR = 1.f - 2.f * qR, kC = 1.f - 2.f * qC;
+    const bool idR = identity_forall && qR == 0.f, idC = identity_forall && qC == 0.f;
+    const float* tp = tile + (int64_t)p * NS * NS;
+    if (wantC)
+        for (int c = tid; c < NS; c += 256) {
+            float acc = 0.f;
+            if (c < n) {
+                const float pc = pC[c];
+                for (int r = 0; r < n; ++r) {
+                    if (r == c) continue;                                 // self-relations contribute 0 (:112)
+                    const float u = relate_prep(tp[(int64_t)r * NS + c], any_neg, alpha_n, cn) + pR[r];
+                    acc += idR ? u : dfol_pnot(u, qR, kR);
+                }
+                acc = pc + (idR ? acc : dfol_pnot(acc, qR, kR));
+            }
+            oC[c] = acc;
+        }
+    if (wantR)
+        for (int r = 0; r < NS; ++r) {
+            float s = 0.f;
+            if (r < n)
+                for (int c = tid; c < n; c += 256) {
+                    if (c == r) continue;
+                    const float u = relate_prep(tp[(int64_t)r * NS + c], any_neg, alpha_n, cn) + pC[c];     // :102
+                    s += idC ? u : dfol_pnot(u, qC, kC);                                                 // :108
+                }
+            s = dfol_wave_sum(s);
+            if (lane == 0) part[w] = s;
+            __syncthreads();
+            if (tid == 0) {
+                const float tot = ((part[0] + part[1]) + part[2]) + part[3];
+                oR[r] = r < n ? pR[r] + (idC ? tot : dfol_pnot(tot, qC, kC)) : 0.f;                     // :133, :138
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(256) void relate_one_big_kernel(
+    const float* __restrict__ x_att, const float* __restrict__ prev_att, const float* __restrict__ tile,
+    const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_prev,
+    const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active, int NS, int identity_forall,
+    float* __restrict__ post) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int q = pred_q[p], n = n_obj[q];
+    const float* pv = prev_att + (int64_t)q * NS;
+    float* out = post + (int64_t)p * NS;
+    if (active && !active[p]) {                          // question without this operator: attention passes through
+        for (int c = tid; c < NS; c += 256) out[c] = c < n ? pv[c] : 0.f;
+        return;
+    }
+    const bool negated = any_neg && neg[p];
+    const float alpha_n = negated ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
+    const float qf = quant_prev[p], kf = 1.f - 2.f * qf;
+    const bool ident = identity_forall && qf == 0.f;
+    const bool mask = negated || qf != 1.f;              // (as relate_one_fwd_kernel: only then can the diagonal contribute)
+    const float* tp = tile + (int64_t)p * NS * NS;
+    for (int c = tid; c < NS; c += 256) {
+        float acc = 0.f;
+        if (c < n) {
+            for (int r = 0; r < n; ++r) {
+                if (mask && r == c) continue;
+                const float u = relate_prep(tp[(int64_t)r * NS + c], any_neg, alpha_n, cn) + pv[r];
+                acc += ident ? u : dfol_pnot(u, qf, kf);
+            }
+            acc = x_att[(int64_t)p * NS + c] + (ident ? acc : dfol_pnot(acc, qf, kf));
+        }
+        out[c] = acc;
+    }
+}
+
 template <int LPR>
 static void launch_relate(hipStream_t st, const float* pR, const float* pC, const float* tile, const int32_t* pred_q,
                           const int32_t* n_obj, const float* qR, const float* qC, const uint8_t* neg, int any_neg,
@@ -600,7 +709,7 @@ extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, c
                                    const int32_t* n_obj, const float* quant_s, const float* quant_o, const uint8_t* neg,
                                    int32_t any_neg, const uint8_t* active, const uint8_t* want, int32_t P, int32_t NS,
                                    int32_t orientation, int32_t flags, float* post_s, float* post_o, void* stream) {
-    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 256, "relate_fwd: bad sizes P=%d NS=%d (NS: multiple of 4, <= 256)", P, NS);
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0, "relate_fwd: bad sizes P=%d NS=%d (NS: a multiple of 4)", P, NS);
     DFOL_REQUIRE(orientation == 0 || orientation == 1, "relate_fwd: bad orientation %d", orientation);
     if (P == 0) return 0;
     DFOL_REQUIRE(prior_s && prior_o && tile && pred_q && n_obj && quant_s && quant_o, "relate_fwd: null pointer");
@@ -613,6 +722,12 @@ extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, c
     float *oR = sr ? post_s : post_o, *oC = sr ? post_o : post_s;
     const int bR = sr ? DFOL_WANT_SUBJECT : DFOL_WANT_OBJECT, bC = sr ? DFOL_WANT_OBJECT : DFOL_WANT_SUBJECT;
     hipStream_t st = (hipStream_t)stream;
+    if (NS > 256) {                                     // wider than a wavefront's registers hold: the plain kernel
+        hipLaunchKernelGGL(relate_big_fwd_kernel, dim3(P), dim3(256), 0, st, pR, pC, tile, pred_q, n_obj, qR, qC, neg, any_neg, active, want, bR, bC,
+                           NS, flags, oR, oC);
+        DFOL_LAUNCH_CHECK("relate_fwd (NS > 256)");
+        return 0;
+    }
     const int groups = NS / 4;
 #define DFOL_RELATE_CASE(L)                                                                                                   \
     launch_relate<L>(st, pR, pC, tile, pred_q, n_obj, qR, qC, neg, any_neg, active, want, bR, bC, P, NS, flags, oR, oC)
@@ -891,11 +1006,17 @@ extern "C" int dfol_relate_one_fwd_f32(const float* x_att, const float* prev_att
                                        const int32_t* n_obj, const float* quant_prev, const uint8_t* neg, int32_t any_neg,
                                        const uint8_t* active, int32_t P, int32_t NS, int32_t lone_forall_identity, float* post,
                                        void* stream) {
-    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 256, "relate_one_fwd: bad sizes P=%d NS=%d (NS: multiple of 4, <= 256)", P, NS);
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0, "relate_one_fwd: bad sizes P=%d NS=%d (NS: a multiple of 4)", P, NS);
     if (P == 0) return 0;
     DFOL_REQUIRE(x_att && prev_att && tile && pred_q && n_obj && quant_prev && post, "relate_one_fwd: null pointer");
     DFOL_REQUIRE(!any_neg || neg, "relate_one_fwd: any_neg set but neg is NULL");
     hipStream_t st = (hipStream_t)stream;
+    if (NS > 256) {
+        hipLaunchKernelGGL(relate_one_big_kernel, dim3(P), dim3(256), 0, st, x_att, prev_att, tile, pred_q, n_obj, quant_prev, neg, any_neg, active, NS,
+                           lone_forall_identity, post);
+        DFOL_LAUNCH_CHECK("relate_one_fwd (NS > 256)");
+        return 0;
+    }
     const int groups = NS / 4;
 #define DFOL_REL1(L, U)                                                                                                       \
     hipLaunchKernelGGL((relate_one_fwd_kernel<L, U>), dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, x_att, prev_att, tile, pred_q, n_obj, \

@@ -19,9 +19,10 @@
  *    with NS >= max objects per image the row stride (NS % 4 == 0), n_obj[q] the true object count
  *    of image q and pred_q[p] the question/image that predicate p belongs to.  Columns >= n_obj
  *    are padding: never read, written as 0 (log 1) by the kernels that produce attention.
- *    HARD LIMIT of the arity-2 kernels (dfol_relate_fwd_f32, dfol_relate_one_fwd_f32 / _bf16, dfol_relate_bwd_f32): NS <= 256 -
- *    a tile row is covered by at most 64 lanes x 4 columns and the row buffers are 256 floats per wavefront.  GQA scenes have at most
- *    100 objects (BASELINE.json configs[2]) and the largest configuration, configs[4], has 256; larger NS is rejected with an error.
+ *    The arity-2 forward kernels (dfol_relate_fwd_f32, dfol_relate_one_fwd_f32) keep a tile row in one wavefront's registers up to
+ *    NS = 256 (64 lanes x 4 columns) and fall back to a plain one-workgroup-per-predicate kernel above that (same formulas, no fast
+ *    paths).  LIMIT: dfol_relate_one_fwd_bf16 and dfol_relate_bwd_f32 (training) take NS <= 256 only and reject larger NS with an
+ *    error.  GQA scenes have at most 100 objects (BASELINE.json configs[2]); the largest configuration, configs[4], has 256.
  *  - Log-space constants are the reference's: absent likelihood -30 (batch_base_ops.py:154),
  *    floor log(1e-20) (util.py:22-25), quantifier 1 = EXISTS / 0 = FOR_ALL (batch_base_types.py:15-17).
  *  - Precision: fp32 arithmetic throughout ("f32" suffix).

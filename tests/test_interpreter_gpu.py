@@ -258,6 +258,20 @@ def _all_ops_case(ontology, oracle_ontology, kind, seed, split, n_range):
         assert not diff, (kind, seed, diff)
 
 
+@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel"])
+def test_scenes_beyond_256_objects(ontology, oracle_ontology, kind):
+    """Scenes of 257..300 objects (NS > 256: the arity-2 kernels leave their registers-per-row forms for the plain ones, csrc/dfol_logic.hip)
+    through whole programs against the oracle.  No reference configuration is this large; the limit used to be a hard error."""
+    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
+    qs, scenes = random_questions(kind, 6, 257, 300, C, CR, seed=4242)
+    model = table_model(ontology)
+    res, _ = run(model, qs, scenes, ontology, split=2)
+    lp = res["log_probability"].cpu().numpy()
+    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, split=2)
+    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, split=2)
+    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], "%s beyond 256 objects" % kind)
+
+
 def test_ragged_to_100_objects(ontology, oracle_ontology):
     C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
     qs, scenes = random_questions("exist", 12, 60, 100, C, CR, seed=77)

@@ -562,7 +562,8 @@ def test_relate_exists_fast_path(L, n_list):
         gu.check_logprob(got[p, :n], r[0][0], r[1][0], "relate_one product path")
 
 
-@pytest.mark.parametrize("n_list", [[5, 1, 8, 3], [36, 20, 33], [100, 37, 64, 2], [130, 256], [17, 9, 2, 12, 16]])
+@pytest.mark.parametrize("n_list", [[5, 1, 8, 3], [36, 20, 33], [100, 37, 64, 2], [130, 256], [17, 9, 2, 12, 16],
+                                    [300, 12, 270]])      # NS = 300 > 256: the plain one-workgroup-per-predicate kernels
 def test_relate_negated_and_forall_fast_paths(L, n_list):
     """Negated and FOR_ALL predicates take transcendental-poor forms too (negated EXISTS: product path on 1 - E with the diagonal
     masked; FOR_ALL: plain sums of l' + prior, no exp / log at all when un-negated) and fall back to the clamping general code

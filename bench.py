@@ -245,7 +245,8 @@ def main(argv=None):
     out = {"metric": metric, "value": total_q / elapsed, "unit": "questions/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": WORKLOADS[args.workload] % (args.batch, args.objects),
+           "config": {"workload": (WORKLOADS[args.workload] % (args.batch, args.objects)).replace(
+               " (the size BASELINE.json's metric is quoted on)", " (the size BASELINE.json's metric is quoted on)" if args.objects == 100 else ""),
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
                       "launch": "hip graph replay" if graphed else "eager",
                       "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else

@@ -122,7 +122,12 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
     const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
     const float* __restrict__ g_post_R, const float* __restrict__ g_post_C, int P, int NS, int identity_forall,
     float* __restrict__ g_prior_R, float* __restrict__ g_prior_C, float* __restrict__ g_tile) {
-    __shared__ float sS[256], sGR[256], sGC[256], sPart[4][256];      // row sums / outer derivatives / per-wavefront column partials
+    extern __shared__ float relate_bwd_lds[];                         // 7 NS floats: row sums / outer derivatives / per-wavefront column partials
+    float* sS = relate_bwd_lds;
+    float* sGR = sS + NS;
+    float* sGC = sGR + NS;
+    float* part_base = sGC + NS;
+    auto part = [&](int wave, int c) -> float& { return part_base[wave * NS + c]; };
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int p = blockIdx.x;
     const int q = pred_q[p];
@@ -163,12 +168,12 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
             s_part = dfol_wave_sum(s_part);
             if (lane == 0) sS[r] = (c0 == 0 ? 0.f : sS[r]) + s_part;
         }
-        if (c < NS) sPart[w][c] = t_acc;
+        if (c < NS) part(w, c) = t_acc;
     }
     __syncthreads();
     // outer derivatives (T[c]: the four partials in wavefront order)
     for (int i = tid; i < n; i += 256) {
-        const float T = ((sPart[0][i] + sPart[1][i]) + sPart[2][i]) + sPart[3][i];
+        const float T = ((part(0, i) + part(1, i)) + part(2, i)) + part(3, i);
         sGR[i] = gR ? gR[i] * (idC ? 1.f : dfol_dpnot(sS[i], qC, kC)) : 0.f;
         sGC[i] = gC ? gC[i] * (idR ? 1.f : dfol_dpnot(T, qR, kR)) : 0.f;
     }
@@ -196,11 +201,11 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
                 if (lane == 0 && r < n) sS[r] = (c0 == 0 ? (gR ? gR[r] : 0.f) : sS[r]) + dpr_part;
             }
         }
-        if (c < NS) sPart[w][c] = dpc;
+        if (c < NS) part(w, c) = dpc;
     }
     __syncthreads();
     for (int c = tid; c < NS; c += 256) {
-        if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = c < n ? (((sPart[0][c] + sPart[1][c]) + sPart[2][c]) + sPart[3][c]) + (gC ? gC[c] : 0.f) : 0.f;
+        if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = c < n ? (((part(0, c) + part(1, c)) + part(2, c)) + part(3, c)) + (gC ? gC[c] : 0.f) : 0.f;
         if (g_prior_R) g_prior_R[(int64_t)p * NS + c] = c < n ? sS[c] : 0.f;
     }
 }
@@ -210,13 +215,13 @@ extern "C" int dfol_relate_bwd_f32(const float* prior_s, const float* prior_o, c
                                    const uint8_t* active, const float* g_post_s, const float* g_post_o, int32_t P, int32_t NS,
                                    int32_t orientation, int32_t lone_forall_identity, float* g_prior_s, float* g_prior_o, float* g_tile,
                                    void* stream) {
-    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 256, "relate_bwd: bad sizes P=%d NS=%d", P, NS);
+    DFOL_REQUIRE(P >= 0 && NS > 0 && NS % 4 == 0 && NS <= 2048, "relate_bwd: bad sizes P=%d NS=%d (NS: a multiple of 4, <= 2048)", P, NS);
     DFOL_REQUIRE(orientation == 0 || orientation == 1, "relate_bwd: bad orientation");
     if (P == 0) return 0;
     DFOL_REQUIRE(prior_s && prior_o && tile && pred_q && n_obj && quant_s && quant_o && (g_post_s || g_post_o), "relate_bwd: null pointer");
     DFOL_REQUIRE(!any_neg || neg, "relate_bwd: any_neg set but neg is NULL");
     const bool sr = orientation == DFOL_TILE_SUBJECT_ROWS;
-    hipLaunchKernelGGL(relate_bwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, sr ? prior_s : prior_o,
+    hipLaunchKernelGGL(relate_bwd_kernel, dim3(P), dim3(256), (size_t)7 * NS * sizeof(float), (hipStream_t)stream, sr ? prior_s : prior_o,
                        sr ? prior_o : prior_s, tile, pred_q, n_obj, sr ? quant_s : quant_o, sr ? quant_o : quant_s, neg, any_neg, active,
                        sr ? g_post_s : g_post_o, sr ? g_post_o : g_post_s, P, NS, lone_forall_identity, sr ? g_prior_s : g_prior_o,
                        sr ? g_prior_o : g_prior_s, g_tile);

@@ -21,8 +21,9 @@
  *    are padding: never read, written as 0 (log 1) by the kernels that produce attention.
  *    The arity-2 forward kernels (dfol_relate_fwd_f32, dfol_relate_one_fwd_f32) keep a tile row in one wavefront's registers up to
  *    NS = 256 (64 lanes x 4 columns) and fall back to a plain one-workgroup-per-predicate kernel above that (same formulas, no fast
- *    paths).  LIMIT: dfol_relate_one_fwd_bf16 and dfol_relate_bwd_f32 (training) take NS <= 256 only and reject larger NS with an
- *    error.  GQA scenes have at most 100 objects (BASELINE.json configs[2]); the largest configuration, configs[4], has 256.
+ *    paths); dfol_relate_bwd_f32 takes NS <= 2048 (7 NS floats of LDS).  LIMIT: dfol_relate_one_fwd_bf16 takes NS <= 256 only and
+ *    rejects larger NS with an error.  GQA scenes have at most 100 objects (BASELINE.json configs[2]); the largest configuration,
+ *    configs[4], has 256.
  *  - Log-space constants are the reference's: absent likelihood -30 (batch_base_ops.py:154),
  *    floor log(1e-20) (util.py:22-25), quantifier 1 = EXISTS / 0 = FOR_ALL (batch_base_types.py:15-17).
  *  - Precision: fp32 arithmetic throughout ("f32" suffix).

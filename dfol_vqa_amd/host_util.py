@@ -77,7 +77,7 @@ class Lowered(object):
         key = str(device)
         if key not in self._dev:
             self._dev[key] = (upload(self.cols, device), upload(self.neg, device), upload(self.valid, device))
-        return self._dev[key]
+        return keep_alive(self._dev[key])        # (a hit must reach a capturing graph's keep-alive list too: the Lowered object may be evicted)
 
 
 _upload_cache = {}

@@ -613,7 +613,8 @@ def test_graphed_forward_equals_eager(tmp_path):
         assert not torch.equal(r2["log_probability"], r["log_probability"])
 
 
-def test_graphed_forward_survives_cache_eviction(tmp_path):
+@pytest.mark.parametrize("kind", ["choose_attr", "verify_rel", "choose_rel", "exist"])
+def test_graphed_forward_survives_cache_eviction(tmp_path, kind):
     """A captured graph holds raw device addresses; the tensors it reads out of evictable caches (uploaded index arrays, geometry,
     packed weight images) must stay alive with the graph.  Evict every cache, let the allocator recycle and overwrite the freed
     memory, replay: the result must not change (round-1 advisor finding)."""
@@ -630,7 +631,7 @@ def test_graphed_forward_survives_cache_eviction(tmp_path):
         model._oracle._embedding_network.linear.bias.fill_(-2.0)
     model = model.to(DEV).eval()
     nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
-    qs, scenes = _neural_questions("choose_attr", 8, 12, 12, 2048, seed=21, names=nm)
+    qs, scenes = _neural_questions(kind, 8, 12, 12, 2048, seed=21, names=nm)
     pbs = [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])]
     g = GraphedForward(model, pbs)
     first = g()

@@ -652,7 +652,10 @@ def test_graphed_forward_survives_cache_eviction(tmp_path, kind):
     pbs2 = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs2, scenes2)])]
     with torch.no_grad():
         model(pbs2, False)
-    junk = [torch.full((1 << k,), float("nan"), device=DEV) for k in range(4, 22)]
+    # (many blocks of every small size class: whatever the evictions freed must be handed out again and overwritten, not just one block
+    # per size - with one, a dangling reference survived unnoticed on most boxes and faulted on one)
+    junk = [torch.full((128,), float("nan"), device=DEV) for _ in range(4096)]
+    junk += [torch.full((1 << k,), float("nan"), device=DEV) for k in range(4, 22) for _ in range(16 if k < 18 else 2)]
     torch.cuda.synchronize()
     again = g()
     assert torch.equal(again["log_probability"], lp0) and again["answer"] == first["answer"]

@@ -483,6 +483,11 @@ def train_kernel_rooflines(args, per_step):
     Q, N, H1, H2 = args.batch, args.objects, 256, 300
     pairs, O = Q * N * (N - 1), Q * N
     rows = []
+    traffic = {}                                             # HBM bytes per step and entry point from the committed counter passes of this shape
+    tpath = os.path.join(ROOT, "profiles", "train_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("bytes_per_step", {})
 
     def add(entry, what, bound, work, note, peak=None, extra=None):
         if entry not in per_step:
@@ -494,6 +499,7 @@ def train_kernel_rooflines(args, per_step):
                      "algorithmic": note})
         if extra:
             rows[-1].update(extra(work / secs))
+        rows[-1]["traffic"] = traffic.get(entry) if (N == 100 and Q == 256 and getattr(args, "mlp_math", "fp32") == "fp32") else None
 
     add("dfol_pair_hidden1_fwd_f32", "pair_hidden1_fwd (Z = ELU(U[s] + V[o] + Wg geo) written once)", "hbm", pairs * (4.0 * H1 + 16), "pairs x (4 HID1 + 16) B written")
     add("dfol_pair_hidden1_bwd_f32", "pair_hidden1_bwd (dU, dV, dWg reduced per image, no atomics)", "hbm", pairs * (8.0 * H1 + 16), "pairs x (8 HID1 + 16) B read")

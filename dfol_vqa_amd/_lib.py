@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfolvqa.so")
+LIB_PATH = os.environ.get("DFOL_LIB") or os.path.join(_HERE, "libdfolvqa.so")     # DFOL_LIB: an A/B build (e.g. -DDFOL_PRECISE_MATH)
 _lib = None
 
 TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1

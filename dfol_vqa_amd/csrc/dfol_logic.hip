@@ -195,26 +195,36 @@ extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const i
 // cover a row, so 64/LPR rows are in flight per iteration.
 //   post_R[r] = prior_R[r] + F_C( sum_{c != r} F_C(l'[r,c] + prior_C[c]) )      row sums   (cross-lane)
 //   post_C[c] = prior_C[c] + F_R( sum_{r != c} F_R(l'[r,c] + prior_R[r]) )      column sums (in-register)
-// Fast path for un-negated EXISTS/EXISTS predicates whose tile diagonal holds the absent value (DFOL_RELATE_DIAG_ABSENT).
-// With E = e^{l'} and probabilities Pc = e^{prior_C}, Pr = e^{prior_R} the two aggregations are
-//     sum_c log(1 - E[r,c] Pc[c])   and   sum_r log(1 - E[r,c] Pr[r]),
-// so one v_exp serves both directions, and a sum of logs is taken as the log of a product of up to 5 factors: every factor
-// fma(-E, P, 1) is either exactly 0 (E = P = 1, the case the reference clamps to 1e-20) or >= 2^-24, so a product of <= 5
-// non-zero factors stays a normal float.  A zero factor (or a prior above log 1) surfaces as a non-finite sum; the wave then
-// reports failure and the caller redoes the predicate with the clamping general code, which keeps the reference's result.
-// Nothing needs masking: the diagonal's E is e^-30 (factor rounds to exactly 1), padding rows/columns get P = 0.
+// Fast path for EXISTS/EXISTS predicates.  With E = e^{l'} and probabilities Pc = e^{prior_C}, Pr = e^{prior_R} the two aggregations are
+//     1 - prod_c (1 - E[r,c] Pc[c])   and   1 - prod_r (1 - E[r,c] Pr[r]),
+// so one v_exp serves both directions, and each is kept in the complement form q <- q + y - q y (dfol_or, dfol_common.h): no logarithm per
+// group of factors, no cancellation, and the posterior is prior + log(max(q, eps)).  A prior above log 1 (y > 1) is the one case the
+// form does not cover: the wave then reports failure and the caller redoes the predicate with the clamping general code, which keeps
+// the reference's result.  On tiles whose diagonal holds the absent value (DFOL_RELATE_DIAG_ABSENT) nothing needs masking: the
+// diagonal's y = e^-30 P < 1e-13 is below the resolution of any q that matters; padding rows/columns get P = 0.
+// The un-masked complement forms run over the diagonal as well (its raw likelihood is the absent value, y_d = e^-30 P < 1e-13), which
+// the reference drops (batch_base_ops.py:112).  Against any q >= 1e-6 that term is below fp32 resolution; for smaller q - down to the
+// q = 0 of an image with a single object, where the reference's aggregate is the clamp log(1e-20) - it is taken out again afterwards:
+// q = q_others + y_d (1 - q_others), and 1 - y_d rounds to 1, so q_others = q - y_d, exactly 0 when there is nothing else (the OR
+// with zeros is exact and y_d is recomputed by the same two instructions).
+__device__ __forceinline__ float relate_drop_diag(float q, float l_diag, float prior_diag) {
+    constexpr float L2E = 1.44269504088896340736f;
+    const float yd = __builtin_amdgcn_exp2f(fminf(l_diag * L2E, 0.f)) * __builtin_amdgcn_exp2f(prior_diag * L2E);
+    return fmaxf(q - yd, 0.f);
+}
+
 template <int LPR> struct RelateUnroll { static constexpr int value = LPR == 64 ? 4 : LPR == 32 ? 5 : LPR == 16 ? 3 : LPR == 8 ? 2 : 1; };
 
-// MASK = true is the form for tiles whose diagonal is not known to be absent and for NEGATED predicates (alpha_n = 1): the factor
-// is built from a = alpha_n + (1 - 2 alpha_n) E (= E, or 1 - E: e^{l'} after :212-213; its inner clamp at eps cannot change a
-// factor, a * P vanishes against 1 either way) and diagonal factors are replaced by 1 (:112).
+// MASK = true is the form for tiles whose diagonal is not known to be absent and for NEGATED predicates (alpha_n = 1): y is built from
+// a = alpha_n + (1 - 2 alpha_n) E (= E, or 1 - E: e^{l'} after :212-213; its inner clamp at eps cannot change y, a * P vanishes either
+// way) and diagonal terms are dropped (:112).
 template <int LPR, bool WR, bool WC, bool MASK>
 __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp, const float* __restrict__ pR,
                                                    const float* __restrict__ pC, int NS, int n, int lane, float* __restrict__ rsum,
                                                    float* __restrict__ oR, float* __restrict__ oC, float alpha_n = 0.f) {
     const float cn = 1.f - 2.f * alpha_n;
     constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
-    constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    constexpr float L2E = 1.44269504088896340736f;
     const int cg = lane % LPR, rs = lane / LPR, c0 = cg * 4, cl = min(c0, NS - 4);
     const float4 pc4 = *reinterpret_cast<const float4*>(pC + cl);
     const float pcl[4] = {pc4.x, pc4.y, pc4.z, pc4.w};
@@ -224,7 +234,7 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
         Pc[j] = (c0 + j < n) ? __builtin_amdgcn_exp2f(pcl[j] * L2E) : 0.f;
         if (WR) pmax = fmaxf(pmax, Pc[j]);
     }
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    float cq[4] = {0.f, 0.f, 0.f, 0.f};                        // column complements of this lane's row slot
     for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
         float4 t[UNR];
         float Pr[UNR];
@@ -239,7 +249,6 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
                 pmax = fmaxf(pmax, Pr[u]);
             }
         }
-        float cprod[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
@@ -249,43 +258,27 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
             const int dg = r0 + u * RPI + rs - c0;             // column j of this lane is the diagonal iff dg == j
             if (MASK) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) E[j] = fmaf(cn, E[j], alpha_n);
+                for (int j = 0; j < 4; ++j) E[j] = (dg == j) ? 0.f : fmaf(cn, E[j], alpha_n);
             }
             if (WC) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float f = fmaf(-E[j], Pr[u], 1.f);
-                    cprod[j] *= (MASK && dg == j) ? 1.f : f;
-                }
+                for (int j = 0; j < 4; ++j) cq[j] = dfol_or(cq[j], E[j] * Pr[u]);
             }
             if (WR) {
-                float f[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f[j] = fmaf(-E[j], Pc[j], 1.f);
-                    if (MASK) f[j] = dg == j ? 1.f : f[j];
-                }
-                const float rp = (f[0] * f[1]) * (f[2] * f[3]);
-                const float part = dfol_group_sum<LPR>(__builtin_amdgcn_logf(rp));
+                const float q01 = dfol_or(E[0] * Pc[0], E[1] * Pc[1]), q23 = dfol_or(E[2] * Pc[2], E[3] * Pc[3]);
+                const float part = dfol_group_or<LPR>(dfol_or(q01, q23));
                 const int r = r0 + u * RPI + rs;
                 if (cg == LPR - 1 && r < n) rsum[r] = part;
             }
         }
-        if (WC) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) csum[j] += __builtin_amdgcn_logf(cprod[j]);
-        }
     }
-    bool bad = pmax > 1.f;
+    const bool ok = !__any(pmax > 1.f);
+    if (!ok) return false;
     if (WR) {
         __builtin_amdgcn_wave_barrier();
         for (int c = lane; c < NS; c += 64) {
             float o = 0.f;
-            if (c < n) {
-                const float s = rsum[c] * LN2;
-                bad |= !(s >= -3.0e38f);
-                o = pR[c] + dfol_pnot(s, 1.f, -1.f);                 // :133, :138
-            }
+            if (c < n) o = pR[c] + dfol_slog(MASK ? rsum[c] : relate_drop_diag(rsum[c], tp[(int64_t)c * NS + c], pC[c]));      // :112, :133, :138
             oR[c] = o;
         }
     }
@@ -293,21 +286,19 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int m = 32; m >= LPR; m >>= 1) csum[j] += __shfl_xor(csum[j], m, 64);
+            for (int m = 32; m >= LPR; m >>= 1) cq[j] = dfol_or(cq[j], __shfl_xor(cq[j], m, 64));
         }
         if (rs == 0 && c0 < NS) {
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float s = csum[j] * LN2;
-                const bool colive = c0 + j < n;
-                bad |= colive && !(s >= -3.0e38f);
-                o[j] = colive ? pcl[j] + dfol_pnot(s, 1.f, -1.f) : 0.f;
+                const int c = min(c0 + j, n - 1);
+                o[j] = (c0 + j < n) ? pcl[j] + dfol_slog(MASK ? cq[j] : relate_drop_diag(cq[j], tp[(int64_t)c * NS + c], pR[c])) : 0.f;
             }
             *reinterpret_cast<float4*>(oC + c0) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
-    return !__any(bad);
+    return true;
 }
 
 template <int LPR>
@@ -793,11 +784,14 @@ __device__ __forceinline__ void relate_one_rows(const float* __restrict__ tp, co
     }
 }
 
-// Un-negated EXISTS predicates: sum_r log(1 - E[r,c] Pr[r]) as the log of products of up to 5 factors (see
-// relate_exists_fast for why that is exact enough and how a clamped factor is detected).  Returns the log2-domain sums.
+// Un-negated EXISTS predicates: the aggregate over rows, 1 - prod_r (1 - E[r,c] Pr[r]), is kept as the complement q[c] (dfol_or,
+// dfol_common.h): per element one exp, one multiply and the two-instruction OR; no logarithm and no cancellation.  Nothing is masked:
+// the diagonal's raw likelihood is the absent value -30, whose y = e^-30 Pr < 1e-13 is below the resolution of any q that matters
+// (the reference zeroes the term explicitly, batch_base_ops.py:112); padding rows get Pr = 0.  Returns the largest Pr seen: a prior
+// above log 1 makes y > 1, which only the general (clamping) code handles.
 template <int LPR>
 __device__ __forceinline__ float relate_one_exists_fast(const float* __restrict__ tp, const float* __restrict__ pv, int NS, int n,
-                                                        int cl, int rs, float (&acc)[4]) {
+                                                        int cl, int rs, float (&q)[4]) {
     constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
     constexpr float L2E = 1.44269504088896340736f;
     float pmax = 0.f;
@@ -812,21 +806,19 @@ __device__ __forceinline__ float relate_one_exists_fast(const float* __restrict_
             Pr[u] = r < n ? __builtin_amdgcn_exp2f(pr * L2E) : 0.f;
             pmax = fmaxf(pmax, Pr[u]);
         }
-        float prod[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) prod[j] *= fmaf(-__builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)), Pr[u], 1.f);
+            for (int j = 0; j < 4; ++j) q[j] = dfol_or(q[j], __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)) * Pr[u]);      // :194, :102-108
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += __builtin_amdgcn_logf(prod[j]);
     }
     return pmax;
 }
 
 // Fast forms of the other three predicate kinds (negated and / or FOR_ALL), same idea: no transcendental pair per element.
-//   negated EXISTS :  sum_r log(1 - (1 - E) Pr)        -> factor fma(-(1 - E), Pr, 1), diagonal masked (its 1 - E is 1, not 0)
+//   negated EXISTS :  sum_r log(1 - (1 - E) Pr)        -> the complement form (dfol_or) on y = (1 - E) Pr, diagonal masked (its 1 - E
+//                     is 1, not 0); acc holds q, not a log-domain sum, and the caller combines the row slots with OR
 //   FOR_ALL        :  sum_r log(max(e^(l' + prev), eps)) = sum_r (l' + prev[r]) as long as no term is below log eps:
 //       un-negated :  l' = min(l, 0): NO transcendental at all; the smallest l' + prev is tracked and a value at the clamp
 //                     sends the predicate to the general code;
@@ -875,12 +867,12 @@ __device__ __forceinline__ bool relate_one_masked_fast(const float* __restrict__
                         chk = fminf(chk, keep ? a * Pr[u] : 1.f);
                         prod[j] *= keep ? a : 1.f;
                     } else {
-                        prod[j] *= (d != j) ? fmaf(-a, Pr[u], 1.f) : 1.f;      // padding rows carry Pr = 0
+                        acc[j] = dfol_or(acc[j], (d != j) ? a * Pr[u] : 0.f);  // complement form (dfol_or); padding rows carry Pr = 0
                     }
                 }
             }
         }
-        if (!(FORALL && !NEG)) {
+        if (FORALL && NEG) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += __builtin_amdgcn_logf(prod[j]);
         }
@@ -924,26 +916,28 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
     constexpr int STEP = RPI * UNR;
     const int n_full = (n / STEP) * STEP;
     if (!mask) {
-        bool bad = relate_one_exists_fast<LPR>(tp, pv, NS, n, cl, rs, acc) > 1.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
-            bad |= (c0 + j < n) && !(acc[j] >= -3.0e38f);
-        }
+        const bool bad = relate_one_exists_fast<LPR>(tp, pv, NS, n, cl, rs, acc) > 1.f;
         if (!__any(bad)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int m = 32; m >= LPR; m >>= 1) acc[j] = dfol_or(acc[j], __shfl_xor(acc[j], m, 64));     // the row slots
+            }
             if (rs == 0 && c0 < NS) {
                 const float4 xa = *reinterpret_cast<const float4*>(x_att + (int64_t)p * NS + c0);
                 const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
                 float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (c0 + j < n) ? xv[j] + dfol_pnot(acc[j] * 0.69314718055994530942f, 1.f, -1.f) : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int c = min(c0 + j, n - 1);
+                    o[j] = (c0 + j < n) ? xv[j] + dfol_slog(relate_drop_diag(acc[j], tp[(int64_t)c * NS + c], pv[c])) : 0.f;      // :112, :133, :138
+                }
                 *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
             }
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = 0.f;            // a factor was clamped: redo with the clamping code below
+        for (int j = 0; j < 4; ++j) acc[j] = 0.f;            // a prior above log 1: redo with the clamping code below
     } else if (qf == 1.f || qf == 0.f) {
         const bool forall = qf == 0.f;
         bool bad = forall ? (negated ? relate_one_masked_fast<LPR, true, true>(tp, pv, NS, n, cl, c0, rs, acc)
@@ -952,7 +946,10 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+            for (int m = 32; m >= LPR; m >>= 1) {
+                const float other = __shfl_xor(acc[j], m, 64);
+                acc[j] = forall ? acc[j] + other : dfol_or(acc[j], other);
+            }
             bad |= (c0 + j < n) && !(acc[j] >= -3.0e38f);
         }
         if (!__any(bad)) {
@@ -967,7 +964,7 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
                     float s2 = acc[j];
                     if (forall && negated) s2 -= pdv[j] * L2E;                 // the diagonal row's prior is not part of the sum
                     const float sv = s2 * LN2;
-                    o[j] = (c0 + j < n) ? xv[j] + (ident ? sv : dfol_pnot(sv, qf, kf)) : 0.f;
+                    o[j] = (c0 + j < n) ? xv[j] + (!forall ? dfol_slog(acc[j]) : ident ? sv : dfol_pnot(sv, qf, kf)) : 0.f;
                 }
                 *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
             }
@@ -1077,7 +1074,7 @@ __global__ __launch_bounds__(256) void relate_one_bf16_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     bool fast_ok = false;
-    if (!mask) {                                            // product path, see relate_exists_fast
+    if (!mask) {                                            // complement form, see relate_one_exists_fast
         float pmax = 0.f;
         for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
             uint4 t[UNR];
@@ -1089,28 +1086,22 @@ __global__ __launch_bounds__(256) void relate_one_bf16_kernel(
                 Pr[u] = r < n ? __builtin_amdgcn_exp2f(pv[rc] * L2E) : 0.f;
                 pmax = fmaxf(pmax, Pr[u]);
             }
-            float prod[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) prod[j] = 1.f;
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 float l[8];
                 bf16x8_to_f32(t[u], l);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) prod[j] *= fmaf(-__builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)), Pr[u], 1.f);
+                for (int j = 0; j < 8; ++j) acc[j] = dfol_or(acc[j], __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)) * Pr[u]);
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += __builtin_amdgcn_logf(prod[j]);
         }
-        bool bad = pmax > 1.f;
+        fast_ok = !__any(pmax > 1.f);
+        if (fast_ok) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
-            for (int m = 32; m >= LPR; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
-            bad |= (c0 + j < n) && !(acc[j] >= -3.0e38f);
-        }
-        fast_ok = !__any(bad);
-        if (!fast_ok) {
+                for (int m = 32; m >= LPR; m >>= 1) acc[j] = dfol_or(acc[j], __shfl_xor(acc[j], m, 64));
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         }
@@ -1144,7 +1135,13 @@ __global__ __launch_bounds__(256) void relate_one_bf16_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float s2 = acc[4 * h + j] * LN2;
-                o[4 * h + j] = (c0 + 4 * h + j < n) ? xv[j] + (ident ? s2 : dfol_pnot(s2, qf, kf)) : 0.f;
+                float r = 0.f;
+                if (c0 + 4 * h + j < n) {
+                    const int c = c0 + 4 * h + j;
+                    const float ld = __uint_as_float((uint32_t)tile[(int64_t)p * NS * NS + (int64_t)c * NS + c] << 16);
+                    r = xv[j] + (fast_ok ? dfol_slog(relate_drop_diag(acc[4 * h + j], ld, pv[c])) : ident ? s2 : dfol_pnot(s2, qf, kf));
+                }
+                o[4 * h + j] = r;
             }
             *reinterpret_cast<float4*>(out + c0 + 4 * h) = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
         }
@@ -1188,6 +1185,13 @@ __global__ __launch_bounds__(256) void quantify_fwd_kernel(const float* __restri
     const int n = n_obj[pred_q[p]];
     const float qf = quant[p], k = 1.f - 2.f * qf;
     const float* a = att + (int64_t)p * NS;
+    if (qf == 1.f) {                                                     // EXISTS: the complement form (dfol_or, dfol_common.h)
+        float q1 = 0.f;
+        for (int o = lane; o < n; o += 64) q1 = dfol_or(q1, fminf(dfol_exp(a[o]), 1.f));
+        q1 = dfol_group_or<64>(q1);
+        if (lane == 63) lp[p] = dfol_slog(q1);                           // :116-123
+        return;
+    }
     float s = 0.f;
     for (int o = lane; o < n; o += 64) s += dfol_pnot(a[o], qf, k);      // batch_base_types.py:116
     s = dfol_wave_sum(s);                                                // :118-121 (bom sum)
@@ -1196,8 +1200,8 @@ __global__ __launch_bounds__(256) void quantify_fwd_kernel(const float* __restri
 
 // NS a multiple of 4 (every block the interpreter builds): LPP = the power of two >= NS / 4 lanes cover one predicate with ONE 16-byte
 // load each, 64 / LPP predicates share a wavefront and QUANT_UNR such groups are in flight per wavefront (one wavefront per 400-byte
-// block - the kernel above - ran at 0.17 of the HBM peak on HBM-sized inputs).  EXISTS predicates take the sum of
-// log(max(1 - e^a, eps)) over a lane's four elements as the log of the product of the four factors when none of them is below eps.
+// block - the kernel above - ran at 0.17 of the HBM peak on HBM-sized inputs).  EXISTS predicates aggregate in the complement form
+// q <- q + y - q y (dfol_or): no cancellation, one transcendental per element.
 constexpr int QUANT_UNR = 4;
 
 template <int LPP>
@@ -1225,28 +1229,22 @@ __global__ __launch_bounds__(256) void quantify_fwd4_kernel(const float* __restr
     for (int u = 0; u < QUANT_UNR; ++u) {
         const float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
         const float k = 1.f - 2.f * qf[u];
-        float s;
-        if (qf[u] == 1.f) {                                              // EXISTS: log2 of the product of the (1 - e^a) factors
-            float f[4], fmin = 1.f;
+        if (qf[u] == 1.f) {                                              // EXISTS: the complement form (dfol_or, dfol_common.h)
+            float q1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f[j] = (col_ok && c0 + j < n[u]) ? 1.f - __builtin_amdgcn_exp2f(a[j] * L2E) : 1.f;
-                fmin = fminf(fmin, f[j]);
+                const float y = (col_ok && c0 + j < n[u]) ? fminf(__builtin_amdgcn_exp2f(a[j] * L2E), 1.f) : 0.f;
+                q1 = dfol_or(q1, y);
             }
-            if (fmin >= 1.0e-9f) {
-                s = __builtin_amdgcn_logf((f[0] * f[1]) * (f[2] * f[3])) * LN2;
-            } else {                                                     // a factor near the 1e-20 floor: clamp each one (util.py:25)
-                s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s += __builtin_amdgcn_logf(fmaxf(f[j], DFOL_EPS)) * LN2;
-            }
+            q1 = dfol_group_or<LPP>(q1);                                 // :118-121 (valid in the last lane of the group)
+            if (lane % LPP == LPP - 1 && pp[u] < P) lp[pp[u]] = __builtin_amdgcn_logf(fmaxf(q1, DFOL_EPS)) * LN2;      // :123
         } else {
-            s = 0.f;
+            float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) s += (col_ok && c0 + j < n[u]) ? dfol_pnot(a[j], qf[u], k) : 0.f;      // batch_base_types.py:116
+            s = dfol_group_sum<LPP>(s);
+            if (lane % LPP == LPP - 1 && pp[u] < P) lp[pp[u]] = dfol_pnot(s, qf[u], k);
         }
-        s = dfol_group_sum<LPP>(s);                                      // :118-121 (valid in the last lane of the group)
-        if (lane % LPP == LPP - 1 && pp[u] < P) lp[pp[u]] = dfol_pnot(s, qf[u], k);      // :123
     }
 }
 
@@ -1401,7 +1399,7 @@ __global__ void logic_kernel(int op, const float* __restrict__ a, const float* _
     const float x = a[i];
     float r;
     if (op == DFOL_LOGIC_AND) r = x + b[i];                                                            // util.py:29-30
-    else if (op == DFOL_LOGIC_OR) r = dfol_slog(1.f - (1.f - dfol_exp(x)) * (1.f - dfol_exp(b[i])));   // util.py:32-33
+    else if (op == DFOL_LOGIC_OR) r = dfol_slog(dfol_or(dfol_exp(x), dfol_exp(b[i])));                 // util.py:32-33: 1 - (1 - e^a)(1 - e^b) = e^a + e^b - e^a e^b
     else r = dfol_lnot(x);                                                                             // util.py:35-36
     out[i] = r;
 }
@@ -1436,9 +1434,9 @@ extern "C" int dfol_parametric_not_f32(const float* x, const float* alpha, int32
 __global__ void segment_or_kernel(const float* __restrict__ lp, const int32_t* __restrict__ seg_off, int Q, float* __restrict__ out) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
-    float s = 0.f;
-    for (int p = seg_off[q]; p < seg_off[q + 1]; ++p) s += dfol_lnot(lp[p]);
-    out[q] = dfol_lnot(s);
+    float q1 = 0.f;                                      // log_not(sum_p log_not(lp_p)) in the complement form (dfol_or, dfol_common.h)
+    for (int p = seg_off[q]; p < seg_off[q + 1]; ++p) q1 = dfol_or(q1, fminf(dfol_exp(lp[p]), 1.f));
+    out[q] = dfol_slog(q1);
 }
 
 extern "C" int dfol_segment_or_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream) {

@@ -137,3 +137,70 @@ def reference_config(paths, **over):
     cfg.update(paths)
     cfg.update(over)
     return cfg
+
+
+def seeded_weights(seed, box_features_dim=2048, oracle_input_dim=512, hidden=256, word_embedding_dim=300, concept_num=2335):
+    """A numpy-seeded state dict of the classifier oracle at the reference's full size (2048 -> 512, 516 / 1036 -> 256 -> 300 -> 2335),
+    under the reference's parameter names.  Golden family g17 stores only the seed: the capture tool loads these arrays into the
+    reference's model, the tests load the same arrays into this build's (numpy's RandomState stream is stable across versions and
+    machines, torch.manual_seed initialisers are not a contract).  Linear layers: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch's
+    default; embedding rows N(0, 0.1) with bias -2 (GloVe-like magnitudes: sparse concept probabilities instead of saturated ones)."""
+    rng = np.random.RandomState(int(seed))
+    D = oracle_input_dim + 4
+
+    def linear(n_out, n_in):
+        b = 1.0 / np.sqrt(n_in)
+        return rng.uniform(-b, b, (n_out, n_in)).astype(np.float32), rng.uniform(-b, b, n_out).astype(np.float32)
+
+    w = {}
+    w["_featurizer._featurizer_network._network.1.weight"], w["_featurizer._featurizer_network._network.1.bias"] = linear(oracle_input_dim, box_features_dim)
+    for name, n_in in (("_oracle._attribute_network", D), ("_oracle._relation_network", 2 * D + 4)):
+        w[name + "._network.1.weight"], w[name + "._network.1.bias"] = linear(hidden, n_in)
+        w[name + "._network.4.weight"], w[name + "._network.4.bias"] = linear(word_embedding_dim, hidden)
+    w["_oracle._embedding_network._network.1.weight"] = rng.normal(0.0, 0.1, (concept_num, word_embedding_dim)).astype(np.float32)
+    w["_oracle._embedding_network._network.1.bias"] = np.full(concept_num, -2.0, np.float32)
+    return w
+
+
+def load_seeded_weights(model, seed):
+    """Copy seeded_weights(seed) into a model built from reference_config (this build's or the reference's: same parameter names)."""
+    import torch
+    w = seeded_weights(seed)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in w.items():
+            assert tuple(sd[k].shape) == v.shape, (k, tuple(sd[k].shape), v.shape)
+            sd[k].copy_(torch.from_numpy(v).to(sd[k].dtype))
+    return w
+
+
+def full_size_questions(kind, count, n_lo, n_hi, names, categories, seed):
+    """Seeded ragged questions for one terminal operator at BASELINE configs[2]'s shape (golden family g17 and
+    tests/test_interpreter_gpu.py): select -> 1..3 filter / relate hops -> <kind>; second branch for the binary-branch operators."""
+    rng = np.random.RandomState(seed)
+    nouns, rels = names["nouns"][:8], names["relations"][:5]
+    cats = sorted(categories)[:3]
+    attrs = [a for c in cats for a in categories[c][:4]]
+    qs = []
+    for i in range(count):
+        qid = seed * 1000 + i
+        pick = lambda xs: xs[rng.randint(len(xs))]
+        branch = [op("select", pick(nouns + ["_"]))]
+        for _ in range(rng.randint(1, 4)):
+            if rng.uniform() < 0.5:
+                a_ = pick(attrs)
+                branch.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.2 else a_))
+            else:
+                branch.append(op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
+        branches = [branch]
+        if kind in ("and", "or", "two_same", "two_different", "compare"):
+            branches.append([op("select", pick(nouns)), op("filter", pick(attrs))])
+        cat = pick(cats)
+        last = {"exist": op("exist"), "and": op("and"), "or": op("or"), "verify_attrs": op("verify_attrs", [pick(attrs), pick(attrs)]),
+                "verify_rel": op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)),
+                "choose_attr": op("choose_attr", [categories[cat][0], categories[cat][1]]), "query_attr": op("query_attr", cat),
+                "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
+                "two_same": op("two_same", cat), "two_different": op("two_different", cat), "all_same": op("all_same", cat),
+                "all_different": op("all_different", cat), "compare": op("compare", pick(attrs), bool(rng.uniform() < 0.5))}[kind]
+        qs.append(question(qid, branches, last, "yes", feature_scene(qid, int(rng.randint(n_lo, n_hi + 1)), 2048)))
+    return qs

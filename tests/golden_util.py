@@ -67,3 +67,33 @@ def check_logprob(got, ref32, ref64, what="", lp_tol=1e-4, p_tol=1e-6, K=2.0, fl
         assert e_got.max() <= K * err_ref[region].max() + lp_tol, \
             "%s: |dlp vs fp64| %.3g vs reference's own %.3g" % (what, e_got.max(), err_ref[region].max())
     return int(good.sum()), int(len(got))
+
+
+G17_CASES = ["c1_n36"] + [k + "_n60_100" for k in ("exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
+                                                    "two_same", "two_different", "all_same", "all_different", "compare")]
+
+
+def g17_case(name, arrays, meta):
+    """Questions and scenes of one case of golden family g17 (the reference at full model size): everything but the reference's outputs
+    is regenerated from seeds by dfol_vqa_amd.synthetic."""
+    from dfol_vqa_amd import synthetic as syn
+    cm = meta["cases"][name]
+    qs = [syn.question(q["question_id"], q["program"]["branches"], q["program"]["last_op"], q["answer"]) for q in cm["questions"]]
+    scenes = [syn.feature_scene(q["question_id"], q["n"], meta["feature_dim"]) for q in cm["questions"]]
+    return qs, scenes, cm, arrays[name + ":lp_f32"], arrays[name + ":lp_f64"]
+
+
+def decided_answers(cm, lp32, lp64):
+    """Which questions' answers the reference's own fp32 and fp64 runs agree on with a margin (an arg-max over near-ties, or a yes / no
+    at p ~ 0.5, is decided by rounding noise)."""
+    lp32, lp64 = np.asarray(lp32, np.float64), np.asarray(lp64, np.float64)
+    if cm["type"] == 1 and cm["options"] and isinstance(cm["options"][0], list):            # QUERY: per-question option lists
+        sizes = [len(o) for o in cm["options"]]
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        out = []
+        for i in range(len(sizes)):
+            a64, a32 = lp64[off[i]:off[i + 1]], lp32[off[i]:off[i + 1]]
+            top = np.sort(a64)[::-1]
+            out.append(len(top) < 2 or top[0] - top[1] > 4 * np.abs(a32 - a64).max() + 1e-4)
+        return out
+    return list(np.abs(np.exp(lp64) - 0.5) > 4 * np.abs(np.exp(lp32) - np.exp(lp64)) + 1e-5)

@@ -623,8 +623,7 @@ def test_relate_negated_and_forall_fast_paths(L, n_list):
                                    dev(neg) if use_neg else None).cpu().numpy()
             for p, r in refs.items():
                 n = n_list[pq[p]]
-                gu.check_logprob(got[p, :n], r[0][1], r[1][1], "relate_one neg=%s q_prev=%g p=%d" % (None if neg is None else int(neg[p]), qs_v, p),
-                                 lp_tol=2e-4)
+                gu.check_logprob(got[p, :n], r[0][1], r[1][1], "relate_one neg=%s q_prev=%g p=%d" % (None if neg is None else int(neg[p]), qs_v, p))
                 assert np.all(got[p, n:] == 0)
 
 

@@ -178,6 +178,35 @@ def test_g5_neural_oracle(ontology):
             gu.check_logprob(res["log_probability"], a["lp_f32"], a["lp_f64"], "g5")
 
 
+@pytest.fixture(scope="module")
+def full_size_oracle(tmp_path_factory):
+    from dfol_vqa_amd import synthetic as syn
+    paths, _ = syn.write_synthetic_ontology(str(tmp_path_factory.mktemp("g17")))
+    a, meta = gu.load("g17_full_size")
+    return orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"]), \
+        syn.seeded_weights(meta["weight_seed"]), a, meta
+
+
+@pytest.mark.parametrize("name", gu.G17_CASES)
+def test_g17_full_size_reference(full_size_oracle, name):
+    """The oracle against the REFERENCE at full model size (2048 -> 512, 516 / 1036 -> 256 -> 300 -> 2335 concepts with the 333-column
+    relation_index map): BASELINE configs[1] verbatim and every terminal operator on 60..100-object scenes (golden g17)."""
+    oont, weights, a, meta = full_size_oracle
+    qs, scenes, cm, lp32, lp64 = gu.g17_case(name, a, meta)
+    r64 = orc.run_questions(oont, qs, scenes, np.float64, split=cm["split"], weights=weights)
+    assert np.abs(r64["log_probability"] - lp64).max() <= 1e-9, name
+    r32 = orc.run_questions(oont, qs, scenes, np.float32, split=cm["split"], weights=weights)
+    if name.startswith("compare"):
+        assert np.abs(np.exp(r32["log_probability"]) - np.exp(lp32)).max() <= 4e-6
+    else:
+        gu.check_logprob(r32["log_probability"], lp32, lp64, name)
+    assert int(r64["type"]) == cm["type"]
+    decided = gu.decided_answers(cm, lp32, lp64)
+    assert [x for x, d in zip(r64["answer"], decided) if d] == [x for x, d in zip(cm["answer"], decided) if d]
+    if cm["type"] == 1 and not name.startswith("compare"):
+        assert r64["options"] == cm["options"]
+
+
 @pytest.mark.parametrize("name", ["g6_loss_binary", "g6_loss_query", "g6_loss_query_rel"])
 def test_g6_loss(ontology, name):
     a, meta = gu.load(name)

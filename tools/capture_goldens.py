@@ -1044,6 +1044,81 @@ def g15():
     print("wrote g15_preprocess", len(questions), "questions")
 
 
+# ---------------------------------------------------------------------------------------- g17
+G17_KINDS = ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel", "two_same", "two_different",
+             "all_same", "all_different", "compare"]
+G17_WEIGHT_SEED = 17
+
+
+def g17():
+    """The reference at FULL model size (2048 -> 512, 516 / 1036 -> 256 -> 300 -> 2335 concepts, 333 relation columns)
+    on the synthetic full-size ontology: BASELINE configs[1] verbatim (64 questions, 36 objects, select -> filter -> relate -> exist) and
+    every terminal operator on ragged scenes of 60..100 objects (configs[2]'s shape).  Stored: seeds, programs, object counts and the
+    reference's fp32 and fp64 outputs; weights (synthetic.seeded_weights), ontology (synthetic.write_synthetic_ontology) and scenes
+    (synthetic.feature_scene) are regenerated from their seeds.  classifier_oracle.py:145-156, gqa_interpreter_experiments.py:107-198."""
+    import tempfile
+    import zlib
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_interpreter_experiments as gie
+    tmp = tempfile.mkdtemp(prefix="dfol_g17_")
+    fpaths, names = syn.write_synthetic_ontology(tmp)
+    with open(fpaths["vocabulary_file"]) as f:
+        vocab = json.load(f)
+    with open(fpaths["attribute_file"]) as f:
+        categories = json.load(f)
+    fpaths["word_embedding_file"] = os.path.join(tmp, "glove.txt")
+    rng = np.random.RandomState(3)
+    with open(fpaths["word_embedding_file"], "w") as f:          # build_model wants a GloVe file; every weight is overwritten below
+        for wd in sorted({x for nme in vocab["idx_to_arg"] for x in nme.split()}):
+            f.write(wd + " " + " ".join("%.4f" % x for x in rng.normal(0, 0.3, 300)) + "\n")
+    cfg = syn.reference_config(fpaths)
+    exp = gie.GQAObjectBoxExperiment()
+    exp._local_rank = 0
+    full_ontology = exp.build_ontology(cfg, None)
+    torch.manual_seed(0)
+    model = exp.build_model(cfg, full_ontology, None)
+    syn.load_seeded_weights(model, G17_WEIGHT_SEED)
+    model.eval()
+    model64 = copy.deepcopy(model).double()
+
+    def run(qs, split, dt):
+        m = model64 if dt == torch.float64 else model
+        collater = ref_harness.make_collater(ref, split, "feature")
+        pbs = collater.collate(copy.deepcopy(qs))
+        for pb in pbs:
+            pb.create_sparse_tensors()
+            if dt == torch.float64:
+                pb.to(torch.float64)
+                pb._object_batch_index = pb._object_batch_index.long()
+        with torch.no_grad():
+            return m(pbs, False)
+
+    cases = {}
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    c1 = []
+    for i in range(64):
+        br, last = syn.three_hop_program(i, nouns, attrs, rels)
+        c1.append(syn.question(i, br, last, "yes", syn.feature_scene(i, 36, 2048)))
+    cases["c1_n36"] = (c1, 8)
+    for kind in G17_KINDS:
+        seed = zlib.crc32(kind.encode()) % 1000 + 31
+        cases["%s_n60_100" % kind] = (syn.full_size_questions(kind, 6, 60, 100, names, categories, seed), 2)
+    arrays, meta = {}, {"source": "classifier_oracle.py:145-156; gqa_interpreter_experiments.py:107-198; batch_base_interpreter.py:72-183",
+                        "weight_seed": G17_WEIGHT_SEED, "ontology": "synthetic.write_synthetic_ontology (defaults)", "feature_dim": 2048,
+                        "torch": torch.__version__, "cases": {}}
+    for name, (qs, split) in cases.items():
+        cm = {"questions": questions_to_meta(qs), "split": split}
+        for dt, tag in both_dtypes():
+            res = run(qs, split, dt)
+            arrays["%s:lp_%s" % (name, tag)] = res["log_probability"].detach().numpy()
+            if tag == "f32":
+                cm["answer"], cm["options"], cm["type"] = res["answer"], res["options"], int(res["type"])
+        e = np.abs(arrays[name + ":lp_f32"] - arrays[name + ":lp_f64"])
+        print(name, "lp range %.3f .. %.3f" % (arrays[name + ":lp_f64"].min(), arrays[name + ":lp_f64"].max()), "ref32 vs ref64 max %.2e" % e.max())
+        meta["cases"][name] = cm
+    save("g17_full_size", arrays, meta)
+
+
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]

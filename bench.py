@@ -63,6 +63,10 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back steps AFTER the --steps region for `value_sustained` (0 = skip)")
+    ap.add_argument("--roofline-reps", type=int, default=10, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
+                                                                  "of the dominant kernel in the process, so a rocprofv3 trace of the same command can average the same launches")
+    ap.add_argument("--parity-fp64", type=int, default=1, help="1: the parity leg also runs the oracle in float64 (the tolerance policy's yardstick)")
     args = ap.parse_args(argv)
     if args.objects is None:
         args.objects = {"north_star": 100, "c1": 36, "c4": 256}[args.workload]
@@ -242,16 +246,39 @@ def main(argv=None):
         elapsed = float(t.item())
     total_q = args.batch * world * args.steps
     metric = "questions/sec (GQA programs, N=%d objects)" % args.objects
-    out = {"metric": metric, "value": total_q / elapsed, "unit": "questions/s",
+    out = {"argv": list(argv), "metric": metric, "value": total_q / elapsed, "unit": "questions/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": (WORKLOADS[args.workload] % (args.batch, args.objects)).replace(
                " (the size BASELINE.json's metric is quoted on)", " (the size BASELINE.json's metric is quoted on)" if args.objects == 100 else ""),
+                      "workload_id": args.workload, "batch_per_gpu": args.batch,
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
                       "launch": "hip graph replay" if graphed else "eager",
                       "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else
                       "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)"}}
 
+    if args.sustain > 0:
+        # the headline rate again over >= --sustain seconds of back-to-back steps (the --steps region at N = 100 lasts 47 ms when the
+        # driver passes --steps 20: too short for an outside sampler to see)
+        with torch.no_grad():
+            barrier()
+            t0 = time.perf_counter()
+            n_sus = 0
+            while True:
+                for _ in range(max(10, args.steps)):
+                    res = step()
+                n_sus += max(10, args.steps)
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= args.sustain:
+                    break
+            barrier()
+            sus = time.perf_counter() - t0
+        if td is not None:
+            t = torch.tensor([sus], device="cpu" if share else device, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            sus = float(t.item())
+        out["value_sustained"] = args.batch * world * n_sus / sus
+        out["sustained"] = {"steps": n_sus, "seconds": sus, "ms_per_step": sus / n_sus * 1e3}
     if args.streamed:
         # every rank streams its own batches (the ranks share the host's PCIe root complexes, so this is measured with all of them live)
         sv = streamed_rate(args, step if graphed else eager, pbs, td, share, device)
@@ -259,21 +286,32 @@ def main(argv=None):
         out["streamed"] = sv
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
+        # --roofline-reps EAGER steps, one event pair per launch.  They come after every other leg that launches these kernels, so
+        # they are the last launches of the dominant kernel in the process: tools/summarize_profile.py averages exactly those launches
+        # of a rocprofv3 trace of this command (profiles/roofline_rocprof.json, attached below as `roofline.rocprofv3`).
         names_timed = list(L.SIGNATURES)
+        reps = max(1, args.roofline_reps)
         with torch.no_grad():
+            for _ in range(2):
+                eager()
+            torch.cuda.synchronize()
             L.enable_kernel_timing(names_timed)
-            for _ in range(3):
+            for _ in range(reps):
                 eager()
             torch.cuda.synchronize()
             timing = L.disable_kernel_timing()
-        per_step = {k: (n / 3.0, t / 3.0) for k, (n, t) in timing.items() if n}
+        per_step = {k: (n / float(reps), t / float(reps)) for k, (n, t) in timing.items() if n}
         dom = max(per_step, key=lambda k: per_step[k][1])
         out["kernel_ms_per_step"] = {k: round(v[1] * 1e3, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][1])}
+        out["kernel_ms_per_step_note"] = ("isolated timings: HIP events around every launch of %d eager steps; the timed region replays the same "
+                                          "launches as one captured graph, so their sum need not equal ms_per_step" % reps)
         out["roofline"] = dominant_roofline(args, model, dom, per_step)
+        out["roofline"]["reps"] = reps
         # the logic kernels' roofline stress and the host baseline belong to the single-GPU run; with more ranks the others would
         # only wait for rank 0 at the final barrier
         out["kernels"] = stress_kernels(L, device, args.stress_preds, 100) if (args.stress_preds > 0 and world == 1) else []
         attach_traffic(out, args)
+        attach_rocprof(out, args)
         c4 = args.workload == "c4"
         sample = args.cpu_sample if args.cpu_sample is not None else (2 if c4 else 64 if args.objects > 64 else 256)     # about 10 s of host work
         sample = min(sample, args.batch)
@@ -281,7 +319,7 @@ def main(argv=None):
         if sample > 0 and world == 1:
             # configs[4] (256 objects, 26 options per question): two questions through the oracle are the parity sample; the relation
             # tiles are bf16 there, so the probabilities differ from the fp32 reference by the rounding of the stored likelihoods
-            out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs, res, sample, args.parity_all and not c4)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs, res, sample, args.parity_all and not c4, fp64=bool(args.parity_fp64))
             if c4:
                 out["parity"]["note"] = "bf16 relation tiles (configs[4]): |dp| <= 2e-3 expected against the fp32 reference (DESIGN 3)"
                 out["dtype"] = "f32 logic arithmetic on bf16 relation tiles"
@@ -303,7 +341,7 @@ def dominant_roofline(args, model, dom, per_step):
         # contract (ALGORITHMIC flops against the peak of the pipe that executes them); the pipe itself does 6x that work.
         flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * KR)
         ach = flops / secs
-        return {"kernel": "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)", "bound": "mfma",
+        return {"kernel": "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)", "trace_name": "pair_ll32s_kernel", "bound": "mfma",
                 "achieved": ach / 1e12, "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
                 "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                 "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300 * KR),
@@ -314,7 +352,7 @@ def dominant_roofline(args, model, dom, per_step):
         # K requested embedding columns (K = 1 relation per question in this workload)
         flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * 1)
         ach = flops / secs
-        return {"kernel": "pair_ll32b_kernel<19> (fused pair MLP -> requested relation tiles)", "bound": "mfma",
+        return {"kernel": "pair_ll32b_kernel<19> (fused pair MLP -> requested relation tiles)", "trace_name": "pair_ll32b_kernel", "bound": "mfma",
                 "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
                 "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                 "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}
@@ -532,7 +570,8 @@ def train_kernel_rooflines(args, per_step):
 def attach_traffic(out, args):
     """HBM traffic per launch from the committed rocprofv3 counter passes of THIS command (profiles/traffic.json, written by
     tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950).  Left null when no profile of the same shape is on disk."""
+    prescribes for gfx950).  Entries are matched by kernel name AND launch grid (total work-items), which every `kernels` row computes
+    from its own launch geometry.  Left null when no profile of the same shape is on disk."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return
@@ -549,12 +588,43 @@ def attach_traffic(out, args):
     if "pair_ll" in out["roofline"]["kernel"] and args.objects == 100 and args.batch == 256:
         out["roofline"]["traffic"] = total("pair_ll32s_kernel" if "32s" in out["roofline"]["kernel"] else "pair_ll32b_kernel") or total("pair_ll16")
         out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
-    P = args.stress_preds
     for k in out["kernels"]:
-        plain = "predicates)" not in k["kernel"] and "MB of blocks" not in k["kernel"]      # the rows the committed counter passes cover
-        pref = "relate_one_fwd_kernel" if k["kernel"].startswith("relate_one") else "relate_fwd_kernel" if k["kernel"].startswith("relate_fwd") \
-            else "filter_fwd_kernel"
-        k["traffic"] = total(pref, (P // 4) * 256 if "relate" in pref else P * 64) if (P == 65536 and plain) else None
+        tr = k.get("trace")
+        k["traffic"] = total(tr["kernel"], tr["grid_x"]) if tr else None
+        if k["traffic"] is not None and tr["kernel"].startswith("relate"):
+            k["traffic_note"] = "counter average over every launch of this kernel and grid in the profiled run (all predicate kinds)"
+
+
+def attach_rocprof(out, args):
+    """rocprofv3 kernel durations of THE SAME launches, from a committed trace of this command (profiles/roofline_rocprof.json, written by
+    tools/profile_bench.sh + tools/summarize_profile.py on the GPU box): the roofline leg's launches are the last --roofline-reps
+    launches of the dominant kernel in the process, the `kernels` rows are launch groups in a fixed order.  Printed BESIDE the live
+    HIP-event numbers so that the line can be re-derived from profiles/; null when no trace of this shape is on disk."""
+    path = os.path.join(ROOT, "profiles", "roofline_rocprof.json")
+    out["roofline"]["rocprofv3"] = None
+    if not os.path.exists(path):
+        return
+    with open(path) as f:
+        prof = json.load(f)
+    key = "%s:n%d:b%d" % (args.workload, args.objects, args.batch)
+    entry = prof.get(key)
+    if not entry:
+        return
+    r = out["roofline"]
+    dom = entry.get("dominant")
+    if dom and dom.get("trace_name") == r.get("trace_name") and r.get("unit") == "TFLOP/s":
+        work = r["achieved"] * 1e12 * r["us_per_launch"] * 1e-6             # algorithmic flops per launch, as priced above
+        ach = work / (dom["avg_us"] * 1e-6)
+        r["rocprofv3"] = {"us_per_launch": dom["avg_us"], "launches_averaged": dom["launches"], "achieved": ach / 1e12, "frac": ach / (r["peak"] * 1e12),
+                          "source": "profiles/roofline_rocprof.json (%s; the last %d launches of %s in a rocprofv3 --kernel-trace of this command)"
+                                    % (entry.get("head", "?"), dom["launches"], dom["trace_name"])}
+    groups = entry.get("kernels", {})
+    for k in out["kernels"]:
+        tr = k.get("trace")
+        g = groups.get("%s@%d#%d" % (tr["kernel"], tr["grid_x"], tr["group"])) if tr else None
+        if g:
+            nbytes = k["achieved"] * 1e9 * k["us_per_launch"] * 1e-6
+            k["rocprofv3"] = {"us_per_launch": g["avg_us"], "launches_averaged": g["launches"], "frac": nbytes / (g["avg_us"] * 1e-6) / HBM_PEAK}
 
 
 def stress_kernels(L, device, P, N):
@@ -570,11 +640,21 @@ def stress_kernels(L, device, P, N):
     n_obj = torch.full((P,), N, dtype=torch.int32, device=device)
     ones = torch.ones(P, device=device)
     res = []
+    RG = (P + 3) // 4 * 256                                  # launch grid (work-items) of the Relate kernels: one wavefront per predicate
 
-    def timed(name, fn, nbytes, iters=20):
+    groups = {}                                              # (kernel name in the trace, grid) -> launch groups so far, in order
+
+    def trace_id(kernel, grid_x):
+        g = groups.get((kernel, grid_x), 0)
+        groups[(kernel, grid_x)] = g + 1
+        return {"kernel": kernel, "grid_x": int(grid_x), "group": g, "launches": WARM + ITERS, "timed": ITERS}
+
+    WARM, ITERS = 10, 20                                     # (3 warm-up launches left the first rows 8 % slow: the clocks had not ramped yet)
+
+    def timed(name, fn, nbytes, iters=ITERS):
         """Average launch duration from ONE HIP-event pair around `iters` back-to-back launches on the launch stream
         (bracketing every single launch with its own event pair adds marker/fence latency to sub-millisecond kernels)."""
-        for _ in range(3):
+        for _ in range(WARM):
             fn()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -589,21 +669,22 @@ def stress_kernels(L, device, P, N):
                 "predicates": P, "objects": N, "us_per_launch": t * 1e6}
 
     r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones), P * (4 * N * N + 12 * N))
-    res.append(dict(r, kernel="relate_one_fwd (fused single-posterior Relate, the interpreter's path)", bytes_per_predicate=4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_one_fwd (fused single-posterior Relate, the interpreter's path)", bytes_per_predicate=4 * N * N + 12 * N,
+                    trace=trace_id("relate_one_fwd_kernel", RG)))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, need_s=False, diag_absent=True), P * (4 * N * N + 12 * N))
-    res.append(dict(r, kernel="relate_fwd (generic cell, one posterior wanted)", bytes_per_predicate=4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_fwd (generic cell, one posterior wanted)", bytes_per_predicate=4 * N * N + 12 * N, trace=trace_id("relate_fwd_kernel", RG)))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, diag_absent=True), P * (4 * N * N + 16 * N))
-    res.append(dict(r, kernel="relate_fwd (both posteriors, RelateBatch API)", bytes_per_predicate=4 * N * N + 16 * N))
+    res.append(dict(r, kernel="relate_fwd (both posteriors, RelateBatch API)", bytes_per_predicate=4 * N * N + 16 * N, trace=trace_id("relate_fwd_kernel", RG)))
     # the other predicate kinds (negated / FOR_ALL): transcendental-poor forms with a clamping fallback (csrc/dfol_logic.hip)
     zeros, negs = torch.zeros(P, device=device), torch.ones(P, dtype=torch.uint8, device=device)
     r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, ones, negs), P * (4 * N * N + 12 * N))
-    res.append(dict(r, kernel="relate_one_fwd (negated EXISTS predicates)", bytes_per_predicate=4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_one_fwd (negated EXISTS predicates)", bytes_per_predicate=4 * N * N + 12 * N, trace=trace_id("relate_one_fwd_kernel", RG)))
     r = timed("dfol_relate_one_fwd_f32", lambda: L.relate_one_fwd(prior, prior, tile, pq, n_obj, zeros), P * (4 * N * N + 12 * N))
-    res.append(dict(r, kernel="relate_one_fwd (FOR_ALL predicates)", bytes_per_predicate=4 * N * N + 12 * N))
+    res.append(dict(r, kernel="relate_one_fwd (FOR_ALL predicates)", bytes_per_predicate=4 * N * N + 12 * N, trace=trace_id("relate_one_fwd_kernel", RG)))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, ones, ones, negs, diag_absent=True), P * (4 * N * N + 16 * N))
-    res.append(dict(r, kernel="relate_fwd (both posteriors, negated EXISTS predicates)", bytes_per_predicate=4 * N * N + 16 * N))
+    res.append(dict(r, kernel="relate_fwd (both posteriors, negated EXISTS predicates)", bytes_per_predicate=4 * N * N + 16 * N, trace=trace_id("relate_fwd_kernel", RG)))
     r = timed("dfol_relate_fwd_f32", lambda: L.relate_fwd(prior, prior, tile, pq, n_obj, zeros, zeros, diag_absent=True), P * (4 * N * N + 16 * N))
-    res.append(dict(r, kernel="relate_fwd (both posteriors, FOR_ALL predicates)", bytes_per_predicate=4 * N * N + 16 * N))
+    res.append(dict(r, kernel="relate_fwd (both posteriors, FOR_ALL predicates)", bytes_per_predicate=4 * N * N + 16 * N, trace=trace_id("relate_fwd_kernel", RG)))
     del tile
     # Filter / quantify on HBM-sized inputs: 65 536 predicates are 79 MB of blocks, which sit in the 256 MiB Infinity Cache
     PF = max(P, 1 << 19)
@@ -612,7 +693,8 @@ def stress_kernels(L, device, P, N):
     pqf = torch.arange(PF, dtype=torch.int32, device=device)
     nof = torch.full((PF,), N, dtype=torch.int32, device=device)
     r = timed("dfol_filter_fwd_f32", lambda: L.filter_fwd(prf, llf, pqf, nof), PF * 12 * N)
-    res.append(dict(r, kernel="filter_fwd (%.0f MB of blocks)" % (PF * 12 * N / 1e6), bytes_per_predicate=12 * N, predicates=PF))
+    res.append(dict(r, kernel="filter_fwd (%.0f MB of blocks)" % (PF * 12 * N / 1e6), bytes_per_predicate=12 * N, predicates=PF,
+                    trace=trace_id("filter_fwd_kernel", (PF * (NS // 4) + 1023) // 1024 * 256)))
     del llf
     PQ = max(P, 1 << 21)
     prq = torch.log(torch.rand(PQ, NS, device=device, generator=g).clamp_min(1e-3)) * 0.3
@@ -620,14 +702,20 @@ def stress_kernels(L, device, P, N):
     noq = torch.full((PQ,), N, dtype=torch.int32, device=device)
     onq = torch.ones(PQ, device=device)
     r = timed("dfol_quantify_fwd_f32", lambda: L.quantify_fwd(prq, onq, pqq, noq), PQ * (4 * N + 4))
-    res.append(dict(r, kernel="quantify_fwd (%.0f MB of blocks)" % (PQ * (4 * N + 4) / 1e6), bytes_per_predicate=4 * N + 4, predicates=PQ))
+    lpp = 1
+    while lpp < NS // 4:
+        lpp *= 2
+    res.append(dict(r, kernel="quantify_fwd (%.0f MB of blocks)" % (PQ * (4 * N + 4) / 1e6), bytes_per_predicate=4 * N + 4, predicates=PQ,
+                    trace=trace_id("quantify_fwd4_kernel", -(-PQ // (16 * (64 // lpp))) * 256)))
     return res
 
 
-def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True):
+def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True, fp64=True):
     """The CPU oracle (numpy port of the reference's flat-layout algorithm, full-size tables) on a bounded sample of
     the same workload, timed on this host; its log-probabilities double as an in-run parity check.  With `parity_all` the
-    rest of the batch goes through the oracle too (untimed, at the faster ProgramBatch size), so parity covers every question."""
+    rest of the batch goes through the oracle too (untimed, at the faster ProgramBatch size), so parity covers every question.
+    `fp64`: the oracle's float64 run of the same questions is the yardstick of the tolerance policy (tests/golden_util.py):
+    it says which outputs are well-conditioned and how much rounding noise the reference's own fp32 arithmetic carries."""
     from oracle import dfol_oracle as orc
     ont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
     weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
@@ -649,8 +737,8 @@ def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True):
         lp_cpu.append(r2["log_probability"])
         ans_cpu += list(r2["answer"])
         checked = len(questions)
-    lp_cpu = np.concatenate(lp_cpu)
-    lp_gpu = gpu_result["log_probability"][:len(lp_cpu)].detach().cpu().numpy()      # (QUERY programs: several predicates per question)
+    lp_cpu = np.concatenate(lp_cpu).astype(np.float64)
+    lp_gpu = gpu_result["log_probability"][:len(lp_cpu)].detach().cpu().numpy().astype(np.float64)      # (QUERY programs: several predicates per question)
     agree = sum(1 for a, b in zip(gpu_result["answer"][:checked], ans_cpu) if a == b)
     try:                                                    # threads numpy's BLAS actually runs the MLP layers on
         from threadpoolctl import threadpool_info
@@ -666,6 +754,29 @@ def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True):
               "max_abs_dlp": float(np.abs(lp_gpu - lp_cpu).max()),
               "max_abs_dlp_where_lp_ge_-5": float(np.abs(lp_gpu - lp_cpu)[well].max()) if well.any() else None,
               "answers_agree": "%d/%d" % (agree, checked)}
+    if fp64:
+        qs_c = questions[:checked]
+        r64 = orc.run_questions(ont, qs_c, [q["scene"] for q in qs_c], np.float64, split=max(1, -(-checked // split)), weights=weights)
+        lp64 = np.asarray(r64["log_probability"], np.float64)
+        K, p_tol, lp_tol = 2.0, 1e-6, 1e-4                       # tests/golden_util.check_logprob defaults
+        region = lp64 >= -5.0
+        own_lp = np.abs(lp_cpu - lp64)
+        good = region & (own_lp <= lp_tol / 4)                   # demonstrably well-conditioned: the oracle's own fp32 run is within 2.5e-5 of its fp64 run
+        own_p = float(np.abs(np.exp(lp_cpu) - np.exp(lp64)).max())
+        got_p = float(np.abs(np.exp(lp_gpu) - np.exp(lp64)).max())
+        d_good = float(np.abs(lp_gpu - lp_cpu)[good].max()) if good.any() else None
+        got_lp = float(np.abs(lp_gpu - lp64)[region].max()) if region.any() else None
+        own_lp_max = float(own_lp[region].max()) if region.any() else None
+        parity.update({
+            "yardstick": "the oracle's float64 run of the same %d questions" % checked,
+            "well_conditioned_checked": int(good.sum()), "max_abs_dlp_well_conditioned": d_good,
+            "max_abs_dp_vs_fp64": got_p, "max_abs_dlp_vs_fp64_where_lp_ge_-5": got_lp,
+            "oracle_fp32_own_noise": {"max_abs_dp_vs_fp64": own_p, "max_abs_dlp_vs_fp64_where_lp_ge_-5": own_lp_max},
+            "policy": {"K": K, "p_tol": p_tol, "lp_tol": lp_tol,
+                       "rule_i_dlp_le_1e-4_on_well_conditioned": bool(d_good is None or d_good <= lp_tol),
+                       "rule_ii_dp_vs_fp64_within_K_times_oracle_noise": bool(got_p <= K * own_p + p_tol),
+                       "rule_iii_dlp_vs_fp64_within_K_times_oracle_noise": bool(got_lp is None or got_lp <= K * own_lp_max + lp_tol)}})
+        parity["policy"]["pass"] = all(v for k, v in parity["policy"].items() if k.startswith("rule_"))
     return base, parity
 
 

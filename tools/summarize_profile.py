@@ -48,6 +48,59 @@ def main(out):
     import json
     with open(os.path.join(out, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
+    roofline_durations(out)
+
+
+def roofline_durations(out):
+    """rocprofv3 durations of the SAME launches bench.py times with HIP events: the bench line (last JSON line of stats.log) says which
+    kernel its roofline leg launched last (`roofline.trace_name`, `roofline.reps`) and in which order its `kernels` rows launched their
+    groups (`trace`: kernel, grid, group index, launches per group, timed launches).  -> <out>/roofline_rocprof.json, one entry keyed by
+    workload / objects / batch; tools/profile_bench.sh merges it into profiles/roofline_rocprof.json, which bench.py attaches to its line."""
+    import hashlib
+    import json
+    db = db_of(os.path.join(out, "stats"))
+    log = os.path.join(out, "stats.log")
+    if not db or not os.path.exists(log):
+        return
+    line = None
+    for l in open(log):
+        if l.startswith("{"):
+            try:
+                line = json.loads(l)
+            except ValueError:
+                pass
+    if not line or not line.get("roofline"):
+        return
+    rows = [(short(n), gx, st, du) for n, gx, st, du in db.execute("select name, grid_x, start, duration from kernels order by start")]
+    entry = {"bench_py_sha16": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "rb").read()).hexdigest()[:16],
+             "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py " + " ".join(line.get("argv", [])), "kernels": {}}
+    entry["head"] = "bench.py sha256[:16] " + entry["bench_py_sha16"]
+    r = line["roofline"]
+    if r.get("trace_name"):
+        d = [du for n, gx, st, du in rows if n.startswith(r["trace_name"])][-int(r.get("reps", 1)):]
+        if d:
+            entry["dominant"] = {"trace_name": r["trace_name"], "launches": len(d), "avg_us": sum(d) / len(d) / 1e3, "min_us": min(d) / 1e3,
+                                 "max_us": max(d) / 1e3, "hip_event_us_per_launch_same_run": r.get("us_per_launch")}
+    for k in line.get("kernels", []):
+        tr = k.get("trace")
+        if not tr:
+            continue
+        d = [du for n, gx, st, du in rows if n.startswith(tr["kernel"]) and gx == tr["grid_x"]]
+        g = d[tr["group"] * tr["launches"]:(tr["group"] + 1) * tr["launches"]][-tr["timed"]:]
+        if len(g) == tr["timed"]:
+            entry["kernels"]["%s@%d#%d" % (tr["kernel"], tr["grid_x"], tr["group"])] = {
+                "row": k["kernel"], "launches": len(g), "avg_us": sum(g) / len(g) / 1e3, "hip_event_us_per_launch_same_run": k.get("us_per_launch")}
+    cfg = line.get("config", {})
+    key = "%s:n%d:b%d" % (cfg.get("workload_id", "north_star"), cfg.get("objects_per_scene", 0), cfg.get("batch_per_gpu", 0))
+    with open(os.path.join(out, "roofline_rocprof.json"), "w") as f:
+        json.dump({key: entry}, f, indent=1, sort_keys=True)
+    print("\n## the roofline leg's launches (the same launches bench.py times with HIP events)\n")
+    if "dominant" in entry:
+        dm = entry["dominant"]
+        print("%s: last %d launches, rocprofv3 avg %.1f us (min %.1f, max %.1f); HIP events in the same run: %.1f us per launch"
+              % (dm["trace_name"], dm["launches"], dm["avg_us"], dm["min_us"], dm["max_us"], dm["hip_event_us_per_launch_same_run"] or 0))
+    for kk, v in sorted(entry["kernels"].items()):
+        print("%s  [%s]: rocprofv3 avg %.1f us over %d launches; HIP events %.1f us" % (kk, v["row"], v["avg_us"], v["launches"], v["hip_event_us_per_launch_same_run"] or 0))
 
 
 if __name__ == "__main__":

@@ -6,6 +6,9 @@
 // so results are deterministic.
 #include <stdarg.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "dfol_common.h"
 
 static thread_local char g_err[512] = "";
@@ -200,28 +203,22 @@ extern "C" int dfol_filter_fwd_f32(const float* att_in, const float* ll, const i
 // so one v_exp serves both directions, and each is kept in the complement form q <- q + y - q y (dfol_or, dfol_common.h): no logarithm per
 // group of factors, no cancellation, and the posterior is prior + log(max(q, eps)).  A prior above log 1 (y > 1) is the one case the
 // form does not cover: the wave then reports failure and the caller redoes the predicate with the clamping general code, which keeps
-// the reference's result.  On tiles whose diagonal holds the absent value (DFOL_RELATE_DIAG_ABSENT) nothing needs masking: the
-// diagonal's y = e^-30 P < 1e-13 is below the resolution of any q that matters; padding rows/columns get P = 0.
-// The un-masked complement forms run over the diagonal as well (its raw likelihood is the absent value, y_d = e^-30 P < 1e-13), which
-// the reference drops (batch_base_ops.py:112).  Against any q >= 1e-6 that term is below fp32 resolution; for smaller q - down to the
-// q = 0 of an image with a single object, where the reference's aggregate is the clamp log(1e-20) - it is taken out again afterwards:
-// q = q_others + y_d (1 - q_others), and 1 - y_d rounds to 1, so q_others = q - y_d, exactly 0 when there is nothing else (the OR
-// with zeros is exact and y_d is recomputed by the same two instructions).
-__device__ __forceinline__ float relate_drop_diag(float q, float l_diag, float prior_diag) {
-    constexpr float L2E = 1.44269504088896340736f;
-    const float yd = __builtin_amdgcn_exp2f(fminf(l_diag * L2E, 0.f)) * __builtin_amdgcn_exp2f(prior_diag * L2E);
-    return fmaxf(q - yd, 0.f);
-}
-
+// the reference's result.  The term is built from a = alpha_n + (1 - 2 alpha_n) E (= E, or 1 - E for a NEGATED predicate: e^{l'} after
+// :212-213; its inner clamp at eps cannot change y, a * P vanishes either way); diagonal terms are dropped (:112: one select per
+// element, which measured 7 % FASTER than an unmasked instantiation with the diagonal's term taken out afterwards); padding rows and
+// columns get P = 0.
 template <int LPR> struct RelateUnroll { static constexpr int value = LPR == 64 ? 4 : LPR == 32 ? 5 : LPR == 16 ? 3 : LPR == 8 ? 2 : 1; };
 
-// MASK = true is the form for tiles whose diagonal is not known to be absent and for NEGATED predicates (alpha_n = 1): y is built from
-// a = alpha_n + (1 - 2 alpha_n) E (= E, or 1 - E: e^{l'} after :212-213; its inner clamp at eps cannot change y, a * P vanishes either
-// way) and diagonal terms are dropped (:112).
-template <int LPR, bool WR, bool WC, bool MASK>
+template <int LPR, bool WR, bool WC>
 __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp, const float* __restrict__ pR,
                                                    const float* __restrict__ pC, int NS, int n, int lane, float* __restrict__ rsum,
-                                                   float* __restrict__ oR, float* __restrict__ oC, float alpha_n = 0.f) {
+                                                   float* __restrict__ oR, float* __restrict__ oC, float alpha_n = 0.f,
+                                                   float* __restrict__ part = nullptr, int pitch = 0) {
+    // `part` (LPR <= 32): this wavefront's [64][pitch] slab of LDS, reused per chunk of <= 64 rows.  A row's aggregate needs the OR of the partials of the LPR lanes that
+    // share the row; as a DPP reduction that is log2(LPR) steps of three instructions per row and lane (15 for N = 100, against 5 for the
+    // sum it replaces).  Instead every lane drops its partial into part[row][lane group] and, after the last row, lane c combines the
+    // partials of row c serially: one ds_write per row in the loop, and the combining work is spread over all lanes (pitch is odd, so
+    // neither access pattern has bank conflicts).  LDS operations of one wavefront execute in order.
     const float cn = 1.f - 2.f * alpha_n;
     constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
     constexpr float L2E = 1.44269504088896340736f;
@@ -235,41 +232,62 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
         if (WR) pmax = fmaxf(pmax, Pc[j]);
     }
     float cq[4] = {0.f, 0.f, 0.f, 0.f};                        // column complements of this lane's row slot
-    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
-        float4 t[UNR];
-        float Pr[UNR];
+    constexpr int STEP = RPI * UNR, CH = (64 / STEP) * STEP;     // rows per LDS chunk: whole loop steps, at most one row per lane
+    const int live = (n + 3) >> 2;                              // lane groups that hold real columns
+    for (int rbase = 0; rbase < n; rbase += (WR && part) ? CH : n) {
+        const int rend = (WR && part) ? min(n, rbase + CH) : n;
+        for (int r0 = rbase; r0 < rend; r0 += STEP) {
+            float4 t[UNR];
+            float Pr[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
-            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + cl);
-            Pr[u] = 0.f;
-            if (WC) {
-                const float pr = pR[rc];
-                Pr[u] = r < n ? __builtin_amdgcn_exp2f(pr * L2E) : 0.f;
-                pmax = fmaxf(pmax, Pr[u]);
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
+                t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + cl);
+                Pr[u] = 0.f;
+                if (WC) {
+                    const float pr = pR[rc];
+                    Pr[u] = r < n ? __builtin_amdgcn_exp2f(pr * L2E) : 0.f;
+                    pmax = fmaxf(pmax, Pr[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                float E[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) E[j] = __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f));    // :194 (the product is canonical: no NaN-quieting op)
+                const int dg = r0 + u * RPI + rs - c0;             // column j of this lane is the diagonal iff dg == j
+#pragma unroll
+                for (int j = 0; j < 4; ++j) E[j] = (dg == j) ? 0.f : fmaf(cn, E[j], alpha_n);       // self-relations contribute nothing (:112)
+                if (WC) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cq[j] = dfol_or(cq[j], E[j] * Pr[u]);
+                }
+                if (WR) {
+                    const float q01 = dfol_or(E[0] * Pc[0], E[1] * Pc[1]), q23 = dfol_or(E[2] * Pc[2], E[3] * Pc[3]);
+                    const int r = r0 + u * RPI + rs;
+                    if (part) {
+                        if (r < n && c0 < n) part[(r - rbase) * pitch + cg] = dfol_or(q01, q23);
+                    } else {
+                        const float rq = dfol_group_or<LPR>(dfol_or(q01, q23));
+                        if (cg == LPR - 1 && r < n) rsum[r] = rq;
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
-            float E[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) E[j] = __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f));    // :194 (the product is canonical: no NaN-quieting op)
-            const int dg = r0 + u * RPI + rs - c0;             // column j of this lane is the diagonal iff dg == j
-            if (MASK) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) E[j] = (dg == j) ? 0.f : fmaf(cn, E[j], alpha_n);
+        if (WR && part) {                                       // the rows of this chunk: lane i combines the partials of row rbase + i
+            __builtin_amdgcn_wave_barrier();
+            const int c = rbase + lane;
+            if (c < rend) {
+                const float* pp = part + lane * pitch;
+                float rq = 0.f;
+                for (int k = 0; k < live; k += 4) {
+                    const float v0 = pp[k], v1 = k + 1 < live ? pp[k + 1] : 0.f, v2 = k + 2 < live ? pp[k + 2] : 0.f, v3 = k + 3 < live ? pp[k + 3] : 0.f;
+                    rq = dfol_or(rq, dfol_or(dfol_or(v0, v1), dfol_or(v2, v3)));
+                }
+                rsum[c] = rq;
             }
-            if (WC) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cq[j] = dfol_or(cq[j], E[j] * Pr[u]);
-            }
-            if (WR) {
-                const float q01 = dfol_or(E[0] * Pc[0], E[1] * Pc[1]), q23 = dfol_or(E[2] * Pc[2], E[3] * Pc[3]);
-                const float part = dfol_group_or<LPR>(dfol_or(q01, q23));
-                const int r = r0 + u * RPI + rs;
-                if (cg == LPR - 1 && r < n) rsum[r] = part;
-            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     const bool ok = !__any(pmax > 1.f);
@@ -278,7 +296,7 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
         __builtin_amdgcn_wave_barrier();
         for (int c = lane; c < NS; c += 64) {
             float o = 0.f;
-            if (c < n) o = pR[c] + dfol_slog(MASK ? rsum[c] : relate_drop_diag(rsum[c], tp[(int64_t)c * NS + c], pC[c]));      // :112, :133, :138
+            if (c < n) o = pR[c] + dfol_slog(rsum[c]);      // :112, :133, :138
             oR[c] = o;
         }
     }
@@ -291,10 +309,7 @@ __device__ __forceinline__ bool relate_exists_fast(const float* __restrict__ tp,
         if (rs == 0 && c0 < NS) {
             float o[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = min(c0 + j, n - 1);
-                o[j] = (c0 + j < n) ? pcl[j] + dfol_slog(MASK ? cq[j] : relate_drop_diag(cq[j], tp[(int64_t)c * NS + c], pR[c])) : 0.f;
-            }
+            for (int j = 0; j < 4; ++j) o[j] = (c0 + j < n) ? pcl[j] + dfol_slog(cq[j]) : 0.f;
             *reinterpret_cast<float4*>(oC + c0) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_R,
     const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
     const uint8_t* __restrict__ want, int want_R_bit, int want_C_bit, int P, int NS, int flags,
-    float* __restrict__ post_R, float* __restrict__ post_C) {
+    float* __restrict__ post_R, float* __restrict__ post_C, int part_pitch) {
     const int identity_forall = flags & DFOL_RELATE_LONE_FORALL_IDENTITY;
     constexpr int RPI = 64 / LPR;                       // rows per iteration
     __shared__ float row_sum[4][256];                   // per-wave row sums, flushed with one coalesced store
@@ -348,19 +363,15 @@ __global__ __launch_bounds__(256) void relate_fwd_kernel(
     const bool idR = identity_forall && qR == 0.f, idC = identity_forall && qC == 0.f;
 
     const float* tp = tile + (int64_t)p * NS * NS;
-    if (qR == 1.f && qC == 1.f) {                        // EXISTS / EXISTS: the product path (see relate_exists_fast)
+    if (qR == 1.f && qC == 1.f) {                        // EXISTS / EXISTS: the complement form (see relate_exists_fast)
         float* rsum = row_sum[wave_in_block];
-        bool ok;
-        if ((flags & DFOL_RELATE_DIAG_ABSENT) && alpha_n == 0.f)
-            ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
-                 : wantR      ? relate_exists_fast<LPR, true, false, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
-                 : wantC      ? relate_exists_fast<LPR, false, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC)
-                              : true;
-        else                                             // negated predicates, and tiles whose diagonal must be masked
-            ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
-                 : wantR      ? relate_exists_fast<LPR, true, false, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
-                 : wantC      ? relate_exists_fast<LPR, false, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
-                              : true;
+        extern __shared__ float relate_part[];           // LPR <= 32: 4 slabs of [64][pitch] floats (the launch sizes it; 0 bytes otherwise)
+        float* part = part_pitch > 0 ? relate_part + (size_t)wave_in_block * 64 * part_pitch : nullptr;
+        // (always with the diagonal select: DFOL_RELATE_DIAG_ABSENT is accepted and no longer needed by this kernel)
+        const bool ok = (wantR && wantC) ? relate_exists_fast<LPR, true, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n, part, part_pitch)
+                        : wantR      ? relate_exists_fast<LPR, true, false>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n, part, part_pitch)
+                        : wantC      ? relate_exists_fast<LPR, false, true>(tp, pR, pC, NS, n, lane, rsum, oR, oC, alpha_n)
+                                     : true;
         if (ok) return;
         __builtin_amdgcn_wave_barrier();
     }
@@ -692,8 +703,12 @@ static void launch_relate(hipStream_t st, const float* pR, const float* pC, cons
                           const int32_t* n_obj, const float* qR, const float* qC, const uint8_t* neg, int any_neg,
                           const uint8_t* active, const uint8_t* want, int wantRbit, int wantCbit, int P, int NS, int flags,
                           float* oR, float* oC) {
-    hipLaunchKernelGGL(relate_fwd_kernel<LPR>, dim3(dfol_cdiv(P, 4)), dim3(256), 0, st, pR, pC, tile, pred_q, n_obj, qR, qC, neg,
-                       any_neg, active, want, wantRbit, wantCbit, P, NS, flags, oR, oC);
+    // row partials of the EXISTS / EXISTS form go through LDS for LPR <= 32 (see relate_exists_fast): [NS][pitch] floats per wavefront, pitch odd
+    static const bool rows_dpp = getenv("DFOL_RELATE_ROWS") && !strcmp(getenv("DFOL_RELATE_ROWS"), "dpp");     // A/B switch: the DPP form
+    const int pitch = (LPR <= 32 && oR && !rows_dpp) ? ((NS / 4) | 1) : 0;
+    const size_t lds = (size_t)4 * 64 * pitch * sizeof(float);             // <= 64 rows per chunk and wavefront: at most 33 KB per workgroup
+    hipLaunchKernelGGL(relate_fwd_kernel<LPR>, dim3(dfol_cdiv(P, 4)), dim3(256), lds, st, pR, pC, tile, pred_q, n_obj, qR, qC, neg,
+                       any_neg, active, want, wantRbit, wantCbit, P, NS, flags, oR, oC, pitch);
 }
 
 extern "C" int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q,
@@ -784,39 +799,9 @@ __device__ __forceinline__ void relate_one_rows(const float* __restrict__ tp, co
     }
 }
 
-// Un-negated EXISTS predicates: the aggregate over rows, 1 - prod_r (1 - E[r,c] Pr[r]), is kept as the complement q[c] (dfol_or,
-// dfol_common.h): per element one exp, one multiply and the two-instruction OR; no logarithm and no cancellation.  Nothing is masked:
-// the diagonal's raw likelihood is the absent value -30, whose y = e^-30 Pr < 1e-13 is below the resolution of any q that matters
-// (the reference zeroes the term explicitly, batch_base_ops.py:112); padding rows get Pr = 0.  Returns the largest Pr seen: a prior
-// above log 1 makes y > 1, which only the general (clamping) code handles.
-template <int LPR>
-__device__ __forceinline__ float relate_one_exists_fast(const float* __restrict__ tp, const float* __restrict__ pv, int NS, int n,
-                                                        int cl, int rs, float (&q)[4]) {
-    constexpr int RPI = 64 / LPR, UNR = RelateUnroll<LPR>::value;
-    constexpr float L2E = 1.44269504088896340736f;
-    float pmax = 0.f;
-    for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
-        float4 t[UNR];
-        float Pr[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u * RPI + rs, rc = min(r, n - 1);
-            t[u] = *reinterpret_cast<const float4*>(tp + (int64_t)rc * NS + cl);
-            const float pr = pv[rc];
-            Pr[u] = r < n ? __builtin_amdgcn_exp2f(pr * L2E) : 0.f;
-            pmax = fmaxf(pmax, Pr[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const float l[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] = dfol_or(q[j], __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)) * Pr[u]);      // :194, :102-108
-        }
-    }
-    return pmax;
-}
-
-// Fast forms of the other three predicate kinds (negated and / or FOR_ALL), same idea: no transcendental pair per element.
+// Fast forms of the four predicate kinds: no transcendental pair per element.
+//   EXISTS         :  1 - prod_r (1 - E[r,c] Pr[r]) kept as the complement q[c] (dfol_or, dfol_common.h): per element one exp, one
+//                     multiply, the diagonal select and the two-instruction OR; no logarithm and no cancellation
 //   negated EXISTS :  sum_r log(1 - (1 - E) Pr)        -> the complement form (dfol_or) on y = (1 - E) Pr, diagonal masked (its 1 - E
 //                     is 1, not 0); acc holds q, not a log-domain sum, and the caller combines the row slots with OR
 //   FOR_ALL        :  sum_r log(max(e^(l' + prev), eps)) = sum_r (l' + prev[r]) as long as no term is below log eps:
@@ -862,7 +847,8 @@ __device__ __forceinline__ bool relate_one_masked_fast(const float* __restrict__
                     chk = fminf(chk, keep ? u2 : 0.f);
                     acc[j] += keep ? u2 : 0.f;
                 } else {
-                    const float a = 1.f - __builtin_amdgcn_exp2f(v2);          // e^{l'} of a negated predicate (:212-213)
+                    const float e = __builtin_amdgcn_exp2f(v2);
+                    const float a = NEG ? 1.f - e : e;                         // e^{l'} (negated: :212-213)
                     if (FORALL) {
                         chk = fminf(chk, keep ? a * Pr[u] : 1.f);
                         prod[j] *= keep ? a : 1.f;
@@ -915,34 +901,12 @@ __global__ __launch_bounds__(256) void relate_one_fwd_kernel(
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     constexpr int STEP = RPI * UNR;
     const int n_full = (n / STEP) * STEP;
-    if (!mask) {
-        const bool bad = relate_one_exists_fast<LPR>(tp, pv, NS, n, cl, rs, acc) > 1.f;
-        if (!__any(bad)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int m = 32; m >= LPR; m >>= 1) acc[j] = dfol_or(acc[j], __shfl_xor(acc[j], m, 64));     // the row slots
-            }
-            if (rs == 0 && c0 < NS) {
-                const float4 xa = *reinterpret_cast<const float4*>(x_att + (int64_t)p * NS + c0);
-                const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
-                float o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = min(c0 + j, n - 1);
-                    o[j] = (c0 + j < n) ? xv[j] + dfol_slog(relate_drop_diag(acc[j], tp[(int64_t)c * NS + c], pv[c])) : 0.f;      // :112, :133, :138
-                }
-                *reinterpret_cast<float4*>(out + c0) = make_float4(o[0], o[1], o[2], o[3]);
-            }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = 0.f;            // a prior above log 1: redo with the clamping code below
-    } else if (qf == 1.f || qf == 0.f) {
+    if (qf == 1.f || qf == 0.f) {
         const bool forall = qf == 0.f;
         bool bad = forall ? (negated ? relate_one_masked_fast<LPR, true, true>(tp, pv, NS, n, cl, c0, rs, acc)
                                      : relate_one_masked_fast<LPR, false, true>(tp, pv, NS, n, cl, c0, rs, acc))
-                          : relate_one_masked_fast<LPR, true, false>(tp, pv, NS, n, cl, c0, rs, acc);
+                          : (negated ? relate_one_masked_fast<LPR, true, false>(tp, pv, NS, n, cl, c0, rs, acc)
+                                     : relate_one_masked_fast<LPR, false, false>(tp, pv, NS, n, cl, c0, rs, acc));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1074,7 +1038,7 @@ __global__ __launch_bounds__(256) void relate_one_bf16_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     bool fast_ok = false;
-    if (!mask) {                                            // complement form, see relate_one_exists_fast
+    if (!mask) {                                            // complement form (dfol_or), see relate_one_masked_fast
         float pmax = 0.f;
         for (int r0 = 0; r0 < n; r0 += RPI * UNR) {
             uint4 t[UNR];
@@ -1091,7 +1055,8 @@ __global__ __launch_bounds__(256) void relate_one_bf16_kernel(
                 float l[8];
                 bf16x8_to_f32(t[u], l);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = dfol_or(acc[j], __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)) * Pr[u]);
+                for (int j = 0; j < 8; ++j)
+                    acc[j] = dfol_or(acc[j], (r0 + u * RPI + rs == c0 + j) ? 0.f : __builtin_amdgcn_exp2f(fminf(l[j] * L2E, 0.f)) * Pr[u]);      // :112
             }
         }
         fast_ok = !__any(pmax > 1.f);
@@ -1136,11 +1101,7 @@ __global__ __launch_bounds__(256) void relate_one_bf16_kernel(
             for (int j = 0; j < 4; ++j) {
                 const float s2 = acc[4 * h + j] * LN2;
                 float r = 0.f;
-                if (c0 + 4 * h + j < n) {
-                    const int c = c0 + 4 * h + j;
-                    const float ld = __uint_as_float((uint32_t)tile[(int64_t)p * NS * NS + (int64_t)c * NS + c] << 16);
-                    r = xv[j] + (fast_ok ? dfol_slog(relate_drop_diag(acc[4 * h + j], ld, pv[c])) : ident ? s2 : dfol_pnot(s2, qf, kf));
-                }
+                if (c0 + 4 * h + j < n) r = xv[j] + (fast_ok ? dfol_slog(acc[4 * h + j]) : ident ? s2 : dfol_pnot(s2, qf, kf));
                 o[4 * h + j] = r;
             }
             *reinterpret_cast<float4*>(out + c0 + 4 * h) = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);

@@ -132,9 +132,12 @@ int dfol_filter_fwd_f32(const float* att_in, const float* ll, const int32_t* pre
  *   flags                      DFOL_RELATE_LONE_FORALL_IDENTITY reproduces the reference's single-predicate literal branch
  *                              (:104-108,:129-133: P == 1 and FOR_ALL leaves the value untouched);
  *                              DFOL_RELATE_DIAG_ABSENT promises that every tile's diagonal holds the absent likelihood
- *                              (<= -30, what dfol_rel_gather_f32 / dfol_pair_ll_f32 write and option normalisation
- *                              leaves alone): un-negated EXISTS/EXISTS predicates then take a path with one exp per
- *                              element and logs of 5-factor products.  Results are the same either way.
+ *                              (<= -30, what dfol_rel_gather_f32 / dfol_pair_ll_f32 write and option normalisation leaves
+ *                              alone); since round 3 it is a hint only: every path drops self-relations explicitly
+ *                              (batch_base_ops.py:112).  Results are the same either way.
+ *                              EXISTS aggregations are evaluated in the complement form q <- q + y - q y (csrc/dfol_common.h,
+ *                              dfol_or): the float64 value of the reference's log(1 - prod(1 - y)) to ~1e-6, without the
+ *                              cancellation noise the formula has when evaluated as written in fp32.
  */
 int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float* tile, const int32_t* pred_q,
                         const int32_t* n_obj, const float* quant_s, const float* quant_o, const uint8_t* neg,
@@ -148,8 +151,7 @@ int dfol_relate_fwd_f32(const float* prior_s, const float* prior_o, const float*
  *   prev_att [Q, NS]  incoming attention of the other variable
  *   tile     [P, NS, NS] with the SUMMED-OUT variable (prev's) along rows: DFOL_TILE_OBJECT_ROWS for is_subject
  *            predicates, DFOL_TILE_SUBJECT_ROWS otherwise (dfol_pair_ll_f32 / dfol_rel_gather_f32 write either)
- *            The diagonal of every tile must hold the absent likelihood (<= -30), as those two producers write it:
- *            un-negated EXISTS predicates do not mask self-relations, their factor 1 - e^(-30 + prev) is exactly 1.
+ *            Self-relations (the diagonal) are dropped explicitly, whatever the tile holds there (batch_base_ops.py:112).
  *   active[p] == 0: post[p] = prev_att row (the interpreter's pass-through for questions lacking the operator,
  *            batch_base_interpreter.py:166-167)
  */

@@ -53,8 +53,9 @@ def parse(argv=None):
     ap.add_argument("--ragged", type=int, default=0, help="train mode: object counts ~ U{ragged..objects}")
     ap.add_argument("--calibrator", type=int, default=0, help="train mode: 1 = calibrator phases (cur6-7): oracle frozen, the attention networks train")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--overlap-allreduce", type=int, default=1,
-                    help="train mode, N > 1: 1 = three ranges of the gradient bucket, each all-reduced as soon as the backward has produced it; 0 = one all-reduce after the backward")
+    ap.add_argument("--overlap-allreduce", type=int, default=0,
+                    help="train mode, N > 1: 0 (default) = ONE all-reduce of the flat bucket after the backward; 1 = EXPERIMENTAL: three ranges of the bucket, each "
+                         "all-reduced as soon as the backward has produced it (exercised over gloo only so far; 9.2 MB over xGMI is ~0.1 ms of a 10 ms step)")
     ap.add_argument("--mlp-math", choices=("fp32", "bf16"), default="fp32",
                     help="train mode: bf16 = configs[3]'s 'bf16 fwd / fp32 logic' (config key mlp_math): the large dense products on bf16-rounded "
                          "operands, fp32 accumulation; reported as dtype bf16, never the default")
@@ -173,6 +174,21 @@ def setup(args):
     return rank, world, device, td, share
 
 
+def rank_report(td, share, device, rank, world, elapsed, steps):
+    """Proof of what ran where, for the N > 1 lines: every rank's device (index, name, PCI bus id) and its own elapsed time, all-gathered."""
+    prop = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "device_index": device.index, "name": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None),
+            "uuid": str(getattr(prop, "uuid", "")), "ms_per_step": elapsed / max(1, steps) * 1e3, "pid": os.getpid()}
+    if td is None:
+        return {"ranks_seen": [mine], "distinct_devices": 1, "rank_ms_per_step_min": mine["ms_per_step"], "rank_ms_per_step_max": mine["ms_per_step"],
+                "backend": None}
+    parts = [None] * world
+    td.all_gather_object(parts, mine)
+    ms = [p["ms_per_step"] for p in parts]
+    return {"ranks_seen": parts, "distinct_devices": len({(p["device_index"], p["uuid"], p["pci_bus_id"]) for p in parts}),
+            "rank_ms_per_step_min": min(ms), "rank_ms_per_step_max": max(ms), "backend": td.get_backend()}
+
+
 def build_model(args, device, train=False):
     from dfol_vqa_amd import _lib as L
     from dfol_vqa_amd import experiment
@@ -240,6 +256,7 @@ def main(argv=None):
             res = step()
         barrier()
         elapsed = time.perf_counter() - t0
+    ranks = rank_report(td, share, device, rank, world, elapsed, args.steps)
     if td is not None:
         t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -257,6 +274,7 @@ def main(argv=None):
                       "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else
                       "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)"}}
 
+    out["ranks"] = ranks
     if args.sustain > 0:
         # the headline rate again over >= --sustain seconds of back-to-back steps (the --steps region at N = 100 lasts 47 ms when the
         # driver passes --steps 20: too short for an outside sampler to see)
@@ -468,6 +486,22 @@ def train_main(args, rank, world, device, td, share):
     elapsed = time.perf_counter() - t0
     loss = float(loss)
     equal = True
+    ranks = rank_report(td, share, device, rank, world, elapsed, args.steps)
+    allreduce_ms = None
+    if td is not None:
+        # the collective alone: 10 all-reduces of a bucket-sized buffer, barrier + synchronize on both sides, MAX over ranks
+        scratch = torch.zeros_like(bucket.flat)
+        for _ in range(3):
+            td.all_reduce(scratch, group=group)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            td.all_reduce(scratch, group=group)
+        barrier()
+        ta = torch.tensor([(time.perf_counter() - t1) / 10 * 1e3], device="cpu" if share else device, dtype=torch.float64)
+        td.all_reduce(ta, op=td.ReduceOp.MAX)
+        allreduce_ms = float(ta.item())
+        del scratch
     if td is not None:
         t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -501,7 +535,10 @@ def train_main(args, rank, world, device, td, share):
                           "collective": "%s of the flat fp32 bucket per step (%s)" % (
                               "three all-reduces(sum) of contiguous ranges, issued during the backward," if (td is not None and args.overlap_allreduce)
                               else "one all-reduce(sum)", "gloo, shared GPU" if share else "RCCL")},
-               "loss": loss, "replicas_equal": bool(equal), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
+               "loss": loss, "replicas_equal": bool(equal), "ranks": ranks, "allreduce_ms": allreduce_ms,
+               "allreduce_note": None if allreduce_ms is None else "standalone all-reduce(sum) of a %d-byte fp32 buffer (the gradient bucket's size), mean of 10, max over ranks; "
+                                 "inside the step it is %s" % (bucket.nbytes(), "issued per range during the backward" if args.overlap_allreduce else "one call after the backward"),
+               "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
                "kernel_ms_per_step": {k: round(v[1] * 1e3, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][1])},
                "kernels": train_kernel_rooflines(args, per_step), "roofline": None, "cpu_baseline": None}
         # the roofline object: the entry point the step spends most time in (the split-kernel GEMMs)

@@ -25,6 +25,42 @@ class DfolError(RuntimeError):
     pass
 
 
+class LRUCache(object):
+    """Bounded content-keyed cache with least-recently-used eviction (round 2's caches dropped EVERYTHING when full: with the token
+    diversity of real GQA batches that is a periodic full re-upload through pageable, stream-synchronising copies)."""
+
+    def __init__(self, capacity):
+        import collections
+        self.capacity = int(capacity)
+        self._d = collections.OrderedDict()
+
+    def get(self, key, default=None):
+        hit = self._d.get(key)
+        if hit is None:
+            return default
+        self._d.move_to_end(key)
+        if _KEEP is not None:                               # a graph capture is recording: whatever a cache hands out may end up in a launch
+            _KEEP.append(hit)                               # (of this library or of torch), so the graph keeps it alive - see keep_alive()
+        return hit
+
+    def __setitem__(self, key, value):
+        self._d[key] = value
+        self._d.move_to_end(key)
+        if _KEEP is not None:
+            _KEEP.append(value)
+        while len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+
+    def __len__(self):
+        return len(self._d)
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def clear(self):
+        self._d.clear()
+
+
 _p, _i32, _i64, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
 # name -> argtypes, exactly as declared in include/dfol_vqa.h
@@ -121,6 +157,15 @@ def _ptr(t, dtype=None, allow_none=False):
         raise DfolError("expected dtype %s, got %s" % (dtype, t.dtype))
     if not t.is_contiguous():
         raise DfolError("tensor must be contiguous")
+    if _KEEP is not None:                                   # a graph capture is recording: the graph bakes this address in (see keep_alive)
+        _KEEP.append(t)
+    return t.data_ptr()
+
+
+def _dp(t):
+    """data_ptr() of a (possibly strided) tensor handed to a kernel; like _ptr, it pins the tensor to a capturing graph."""
+    if _KEEP is not None:
+        _KEEP.append(t)
     return t.data_ptr()
 
 
@@ -170,11 +215,17 @@ F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
 # by evictable caches (host_util's upload cache, the geometry caches, the packed weight images, lowered token arrays); once an
 # eviction frees one, the allocator recycles the memory and a replay would silently read unrelated data.  While a capture runs,
 # every cache hands what it returns to keep_alive(), and the GraphedForward object holds those references for as long as it lives.
+# Since round 3 that convention is belt and braces, the mechanism is structural: (a) _ptr() / _dp() - through which EVERY tensor address
+# reaches a launch of this library - and (b) LRUCache.get / __setitem__ - through which every content-keyed cache hands out what torch's
+# own launches may read (index arrays, geometry, masks) - append to the same list while a capture is recording.  A cache that forgets to
+# call keep_alive() can no longer leave a dangling address in a graph: tests/test_interpreter_gpu.py::
+# test_graphed_forward_survives_cache_eviction runs with the explicit calls switched off (EXPLICIT_KEEP_ALIVE) as well.
 _KEEP = None
+EXPLICIT_KEEP_ALIVE = True       # tests switch the caches' own keep_alive() calls off to show that the registration in _ptr / _dp suffices
 
 
 def keep_alive(obj):
-    if _KEEP is not None:
+    if _KEEP is not None and EXPLICIT_KEEP_ALIVE:
         _KEEP.append(obj)
     return obj
 
@@ -201,7 +252,7 @@ def attr_gather(table, obj_off, pred_q, pred_col, NS, default_ll=-30.0):
     P = pred_q.numel()
     ll = torch.empty(P, NS, dtype=F32, device=table.device)
     assert table.stride(1) == 1
-    call("dfol_attr_gather_f32", table.data_ptr(), table.stride(0), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32),
+    call("dfol_attr_gather_f32", _dp(table), table.stride(0), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32),
          P, NS, default_ll, _ptr(ll), _stream())
     return ll
 
@@ -210,7 +261,7 @@ def rel_gather(table, pair_off, n_obj, pred_q, pred_col, NS, orientation=TILE_SU
     P = pred_q.numel()
     tile = torch.empty(P, NS, NS, dtype=F32, device=table.device)
     assert table.stride(1) == 1
-    call("dfol_rel_gather_f32", table.data_ptr(), table.stride(0), _ptr(pair_off, I64), _ptr(n_obj, I32), _ptr(pred_q, I32),
+    call("dfol_rel_gather_f32", _dp(table), table.stride(0), _ptr(pair_off, I64), _ptr(n_obj, I32), _ptr(pred_q, I32),
          _ptr(pred_col, I32), P, NS, orientation, default_ll, _ptr(tile), _stream())
     return tile
 
@@ -354,14 +405,14 @@ def linear_pack_w_split(weight, transpose=False, pieces=3):
     and nn.init bump; writes through `.data` do not - call `_SPLIT_W_CACHE.clear()` after such a write.
     transpose=True packs weight^T (the operand of the backward product g @ W) under the ORIGINAL parameter's key, so a train step
     finds it by the parameter's version instead of inserting one dead entry per temporary transposed copy."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose), pieces)
+    key = (_dp(weight), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose), pieces)
     hit = _SPLIT_W_CACHE.get(key)
     if hit is None:
         src = weight.detach().t().contiguous() if transpose else weight
         N, K = src.shape
         out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 8192 * pieces // 2, dtype=torch.bfloat16, device=weight.device)
         # pieces = 3: the exact three-way split; 1: the bf16 mode's image (rounded to nearest)
-        call("dfol_linear_pack_w_bf16x3" if pieces == 3 else "dfol_linear_pack_w_bf16", src.data_ptr(), src.stride(0), N, K,
+        call("dfol_linear_pack_w_bf16x3" if pieces == 3 else "dfol_linear_pack_w_bf16", _dp(src), src.stride(0), N, K,
              _ptr(out, torch.bfloat16), _stream())
         for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0] and k[4:] == key[4:]]:    # an older version of the same parameter
             del _SPLIT_W_CACHE[stale]
@@ -377,13 +428,13 @@ _NT3_W_CACHE = {}                      # (data_ptr, version, shape, stride, tran
 def linear_pack_w_nt3(weight, transpose=False):
     """The bf16x3 image of a Linear weight for dfol_linear_act_nt3_f32 (operand order of v_mfma_f32_32x32x16_bf16), cached per weight
     version like linear_pack_w_split.  transpose=True: the image of weight^T, read in place (no transposed copy)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose))
+    key = (_dp(weight), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose))
     hit = _NT3_W_CACHE.get(key)
     if hit is None:
         w = weight.detach()
         N, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
         out = torch.empty(load().dfol_linear_pack_w_nt3_bytes(N, K) // 2, dtype=torch.bfloat16, device=weight.device)
-        call("dfol_linear_pack_w_nt3", w.data_ptr(), w.stride(0), N, K, int(transpose), _ptr(out, torch.bfloat16), _stream())
+        call("dfol_linear_pack_w_nt3", _dp(w), w.stride(0), N, K, int(transpose), _ptr(out, torch.bfloat16), _stream())
         for stale in [k for k in _NT3_W_CACHE if k[0] == key[0] and k[4] == key[4]]:
             del _NT3_W_CACHE[stale]
         if len(_NT3_W_CACHE) >= 64:
@@ -400,8 +451,8 @@ def linear_act_nt3(x, weight, bias, act, out=None, transpose_w=False):
         raise DfolError("linear_act_nt3 needs unit column stride")
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
-    call("dfol_linear_act_nt3_f32", x.data_ptr(), x.stride(0), _ptr(linear_pack_w_nt3(weight, transpose_w), torch.bfloat16),
-         _ptr(bias, F32, True), out.data_ptr(), out.stride(0), M, N, K, act, _stream())
+    call("dfol_linear_act_nt3_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_nt3(weight, transpose_w), torch.bfloat16),
+         _ptr(bias, F32, True), _dp(out), out.stride(0), M, N, K, act, _stream())
     return out
 
 
@@ -415,8 +466,8 @@ def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
     N = weight.shape[1] if transpose_w else weight.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
-    call("dfol_linear_act_bf16_f32" if bf16 else "dfol_linear_act_split_f32", x.data_ptr(), x.stride(0),
-         _ptr(linear_pack_w_split(weight, transpose_w, 1 if bf16 else 3), torch.bfloat16), _ptr(bias, F32, True), out.data_ptr(),
+    call("dfol_linear_act_bf16_f32" if bf16 else "dfol_linear_act_split_f32", _dp(x), x.stride(0),
+         _ptr(linear_pack_w_split(weight, transpose_w, 1 if bf16 else 3), torch.bfloat16), _ptr(bias, F32, True), _dp(out),
          out.stride(0), M, N, K, act, _stream())
     return out
 
@@ -429,12 +480,18 @@ def linear_wgrad(dy, x, bias=False):
     for t in (dy, x):
         if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
             raise DfolError("linear_wgrad needs fp32 GPU matrices with unit column stride")
+    if M == 0:                                             # a shard without rows (no object pairs): the gradient is zero, as dy.t() @ x gives
+        dw = torch.zeros(N, K, dtype=F32, device=dy.device)
+        return (dw, torch.zeros(N, dtype=F32, device=dy.device)) if bias else dw
     lib = load()
     ws = torch.empty(lib.dfol_linear_wgrad_workspace(M, N, K), dtype=F32, device=dy.device)
     dw = torch.empty(N, K, dtype=F32, device=dy.device)
     db = torch.empty(N, dtype=F32, device=dy.device) if bias else None
-    call("dfol_linear_wgrad_bias_bf16" if _dense_math() == "bf16" else "dfol_linear_wgrad_bias_f32", dy.data_ptr(), dy.stride(0),
-         x.data_ptr(), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _ptr(db, F32, True), _stream())
+    # bf16 mode: the same layers whose forward product ran on bf16 operands (linear_act: weights of >= SPLIT_MIN_WEIGHT elements); the small
+    # LSTM / attention layers stay fp32 forward AND backward
+    bf16 = _dense_math() == "bf16" and N * K >= SPLIT_MIN_WEIGHT
+    call("dfol_linear_wgrad_bias_bf16" if bf16 else "dfol_linear_wgrad_bias_f32", _dp(dy), dy.stride(0),
+         _dp(x), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _ptr(db, F32, True), _stream())
     return (dw, db) if bias else dw
 
 
@@ -442,7 +499,7 @@ def linear_gradx(dz, weight):
     """dx = dz @ weight (dz [M, N], weight [N, K]): the input gradient of y = x W^T, on the same kernels as the forward."""
     M, N = dz.shape
     K = weight.shape[1]
-    if N * K >= SPLIT_MIN_WEIGHT and N % 4 == 0 and dz.stride(0) % 2 == 0 and dz.data_ptr() % 8 == 0 and _dense_math() != "f32":
+    if N * K >= SPLIT_MIN_WEIGHT and N % 4 == 0 and dz.stride(0) % 2 == 0 and _dp(dz) % 8 == 0 and _dense_math() != "f32":
         return linear_act_split(dz, weight, None, ACT_NONE, transpose_w=True)
     return linear_act(dz, weight.detach().t().contiguous(), None, ACT_NONE)
 
@@ -487,10 +544,10 @@ def linear_act(x, weight, bias, act, out=None):
     for t in (x, weight, out):
         if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
             raise DfolError("linear_act needs fp32 GPU matrices with unit column stride")
-    if N * K >= SPLIT_MIN_WEIGHT and K % 4 == 0 and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0 and _dense_math() != "f32":
+    if N * K >= SPLIT_MIN_WEIGHT and K % 4 == 0 and x.stride(0) % 2 == 0 and _dp(x) % 8 == 0 and _dense_math() != "f32":
         return linear_act_split(x, weight, bias, act, out)
-    call("dfol_linear_act_f32", x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias, F32, True),
-         out.data_ptr(), out.stride(0), M, N, K, act, _stream())
+    call("dfol_linear_act_f32", _dp(x), x.stride(0), _dp(weight), weight.stride(0), _ptr(bias, F32, True),
+         _dp(out), out.stride(0), M, N, K, act, _stream())
     return out
 
 
@@ -505,28 +562,28 @@ def lstm_cell(x, h, c, w_ih_t, w_hh_t, b_ih, b_hh):
     """nn.LSTMCell forward in one launch; w_ih_t = weight_ih.t().contiguous() [KX, 4H], w_hh_t likewise; fp32, unit column stride."""
     rows, H = c.shape
     hy, cy = torch.empty_like(c), torch.empty_like(c)
-    call("dfol_lstm_cell_f32", x.data_ptr(), x.stride(0), x.shape[1], h.data_ptr(), h.stride(0), _ptr(c, F32), _ptr(w_ih_t, F32),
+    call("dfol_lstm_cell_f32", _dp(x), x.stride(0), x.shape[1], _dp(h), h.stride(0), _ptr(c, F32), _ptr(w_ih_t, F32),
          w_ih_t.stride(0), _ptr(w_hh_t, F32), w_hh_t.stride(0), _ptr(b_ih, F32, True), _ptr(b_hh, F32, True), rows, H, _ptr(hy), _ptr(cy),
          _stream())
     return hy, cy
 
 
 def box_positions(raw, obj, pos_col):
-    call("dfol_box_positions_f32", raw.data_ptr(), raw.stride(0), raw.shape[1], raw.shape[0], obj.data_ptr(), obj.stride(0),
+    call("dfol_box_positions_f32", _dp(raw), raw.stride(0), raw.shape[1], raw.shape[0], _dp(obj), obj.stride(0),
          pos_col, _stream())
 
 
 def pair_features(obj, D, obj_off, pair_off, Q, max_n, pairs):
     out = torch.empty(pairs, 2 * D + 4, dtype=F32, device=obj.device)
-    call("dfol_pair_features_f32", obj.data_ptr(), obj.stride(0), D, _ptr(obj_off, I32), _ptr(pair_off, I64), Q, max_n,
-         out.data_ptr(), out.stride(0), _stream())
+    call("dfol_pair_features_f32", _dp(obj), obj.stride(0), D, _ptr(obj_off, I32), _ptr(pair_off, I64), Q, max_n,
+         _dp(out), out.stride(0), _stream())
     return out
 
 
 def attr_ll(hidden, emb_w, emb_b, obj_off, pred_q, pred_col, NS, default_ll=-30.0):
     P = pred_q.numel()
     ll = torch.empty(P, NS, dtype=F32, device=hidden.device)
-    call("dfol_attr_ll_f32", hidden.data_ptr(), hidden.stride(0), hidden.shape[1], emb_w.data_ptr(), emb_w.stride(0),
+    call("dfol_attr_ll_f32", _dp(hidden), hidden.stride(0), hidden.shape[1], _dp(emb_w), emb_w.stride(0),
          _ptr(emb_b, F32, True), _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32), P, NS, default_ll, _ptr(ll), _stream())
     return ll
 
@@ -538,8 +595,8 @@ def pair_ll(uv, hid1, pos, wg, w2, b2, emb_w, emb_b, n_obj, obj_off, max_n, req_
     K, Q = req_col.shape
     NS = tiles.shape[1]
     hid2 = w2.shape[0] if hid2 is None else hid2
-    call("dfol_pair_ll_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32), w2.data_ptr(),
-         w2.stride(0), w2.shape[0], _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
+    call("dfol_pair_ll_f32", _dp(uv), uv.stride(0), hid1, _dp(pos), pos.stride(0), _ptr(wg, F32), _dp(w2),
+         w2.stride(0), w2.shape[0], _ptr(b2, F32), hid2, _dp(emb_w), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          _ptr(tiles, F32), _stream())
     return tiles
@@ -564,8 +621,8 @@ def pair_ll_packed(uv, hid1, pos, wg, w2_packed, b2, hid2, emb_w, emb_b, n_obj, 
     K, Q = req_col.shape
     NS = tiles.shape[1]
     bf16 = tiles.dtype == torch.bfloat16
-    call("dfol_pair_ll_packed_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32), _ptr(w2_packed, F32),
-         _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32), _ptr(obj_off, I32), Q, max_n,
+    call("dfol_pair_ll_packed_f32", _dp(uv), uv.stride(0), hid1, _dp(pos), pos.stride(0), _ptr(wg, F32), _ptr(w2_packed, F32),
+         _ptr(b2, F32), hid2, _dp(emb_w), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32), _ptr(obj_off, I32), Q, max_n,
          _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll, TILE_BF16 if bf16 else TILE_F32,
          _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
@@ -594,8 +651,8 @@ def pair_ll_split(uv, hid1, pos, wg, w2_split, b2, hid2, emb_w, emb_b, n_obj, ob
     K, Q = req_col.shape
     NS = tiles.shape[1]
     bf16 = tiles.dtype == torch.bfloat16
-    call("dfol_pair_ll_split_f32", uv.data_ptr(), uv.stride(0), hid1, pos.data_ptr(), pos.stride(0), _ptr(wg, F32),
-         _ptr(w2_split, torch.bfloat16), _ptr(b2, F32), hid2, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
+    call("dfol_pair_ll_split_f32", _dp(uv), uv.stride(0), hid1, _dp(pos), pos.stride(0), _ptr(wg, F32),
+         _ptr(w2_split, torch.bfloat16), _ptr(b2, F32), hid2, _dp(emb_w), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          TILE_BF16 if bf16 else TILE_F32, _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
@@ -612,7 +669,7 @@ def pair_hidden1_fwd(u, v, pos, wg, obj_off, pair_off, n_obj, max_n, pairs):
     Q, hid1 = n_obj.shape[0], u.shape[1]
     z = torch.empty(pairs, hid1, dtype=F32, device=u.device)
     geo = torch.empty(pairs, 4, dtype=F32, device=u.device)
-    call("dfol_pair_hidden1_fwd_f32", u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), pos.data_ptr(), pos.stride(0), _ptr(wg, F32),
+    call("dfol_pair_hidden1_fwd_f32", _dp(u), u.stride(0), _dp(v), v.stride(0), _dp(pos), pos.stride(0), _ptr(wg, F32),
          _ptr(obj_off, I32), _ptr(pair_off, torch.int64), _ptr(n_obj, I32), Q, max_n, hid1, _ptr(z), _ptr(geo), _stream())
     return z, geo
 
@@ -632,7 +689,7 @@ def pair_logit_fwd(p2, e_rows, be_rows, pred_off, max_rows):
     """max_rows: the largest number of rows a predicate owns (host value; the launch is one row tile grid per predicate)."""
     rows, P = p2.shape[0], e_rows.shape[0]
     x = torch.empty(rows, dtype=F32, device=p2.device)
-    call("dfol_pair_logit_fwd_f32", p2.data_ptr(), p2.stride(0), p2.shape[1], e_rows.data_ptr(), e_rows.stride(0), _ptr(be_rows, F32, True),
+    call("dfol_pair_logit_fwd_f32", _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0), _ptr(be_rows, F32, True),
          _ptr(pred_off, torch.int64), P, rows, int(max_rows), _ptr(x), _stream())
     return x
 
@@ -642,14 +699,32 @@ def pair_logit_bwd(dx, p2, e_rows, pred_off, need_bias=True):
     dp2 = torch.empty_like(p2)
     de = torch.empty(P, p2.shape[1], dtype=F32, device=p2.device)
     dbe = torch.empty(P, dtype=F32, device=p2.device) if need_bias else None
-    call("dfol_pair_logit_bwd_f32", _ptr(dx, F32), p2.data_ptr(), p2.stride(0), p2.shape[1], e_rows.data_ptr(), e_rows.stride(0),
-         _ptr(pred_off, torch.int64), P, dp2.data_ptr(), dp2.stride(0), de.data_ptr(), de.stride(0), _ptr(dbe, F32, True), _stream())
+    call("dfol_pair_logit_bwd_f32", _ptr(dx, F32), _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0),
+         _ptr(pred_off, torch.int64), P, _dp(dp2), dp2.stride(0), _dp(de), de.stride(0), _ptr(dbe, F32, True), _stream())
     return dp2, de, dbe
 
 
 # ---- backward wrappers (deterministic: no atomics; pred_q non-decreasing) --------------------------------------------
+def require_sorted(pred_q, what):
+    """The deterministic backward kernels find a question's predicates by binary search in pred_q (csrc/dfol_logic_bwd.hip,
+    dfol_pred_range), so the map must be non-decreasing - every map the operators build is (flatten_list order).  An unsorted map would
+    silently drop gradient contributions, so it is refused here.  Checked once per tensor object (one device->host read), remembered on
+    the tensor; the maps come out of content-keyed caches, so a train loop pays once per distinct map."""
+    flag = getattr(pred_q, "_dfol_sorted", None)
+    if flag is None:
+        flag = bool(pred_q.numel() < 2 or bool((pred_q[1:] >= pred_q[:-1]).all().item()))
+        try:
+            pred_q._dfol_sorted = flag
+        except Exception:
+            pass
+    if not flag:
+        raise DfolError("%s: the predicate -> question map must be non-decreasing (the deterministic backward finds a question's predicates "
+                        "by binary search); sort the predicates by question, as util.flatten_list does" % what)
+
+
 def reduce_by_question(src, pred_q, n_obj, Q):
     """out[q] = sum of src[p] over the predicates p of question q (src [P, NS] -> [Q, NS])."""
+    require_sorted(pred_q, "reduce_by_question")
     P, NS = src.shape
     out = torch.empty(Q, NS, dtype=F32, device=src.device)
     call("dfol_reduce_by_question_f32", _ptr(src, F32), _ptr(pred_q, I32), _ptr(n_obj, I32, True), P, Q, NS, _ptr(out), _stream())
@@ -657,6 +732,7 @@ def reduce_by_question(src, pred_q, n_obj, Q):
 
 
 def filter_bwd(g_out, ll, pred_q, n_obj, neg, active, Q, need_prior=True, need_ll=True):
+    require_sorted(pred_q, "filter_bwd")
     P, NS = ll.shape
     g_prior = torch.empty(Q, NS, dtype=F32, device=ll.device) if need_prior else None
     g_ll = torch.empty(P, NS, dtype=F32, device=ll.device) if need_ll else None
@@ -667,6 +743,8 @@ def filter_bwd(g_out, ll, pred_q, n_obj, neg, active, Q, need_prior=True, need_l
 
 def relate_bwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, g_post_s, g_post_o, orientation,
                lone_forall_identity, need_prior=True, need_tile=True):
+    if need_prior:
+        require_sorted(pred_q, "relate_bwd")
     P, NS = tile.shape[0], tile.shape[1]
     Q = prior_s.shape[0]
     pp_s = torch.empty(P, NS, dtype=F32, device=tile.device) if need_prior else None      # per predicate
@@ -690,6 +768,7 @@ def quantify_bwd(g_lp, att, quant, pred_q, n_obj):
 
 
 def attr_gather_bwd(g_ll, obj_off, pred_q, pred_col, table_shape):
+    require_sorted(pred_q, "attr_gather_bwd")
     P, NS = g_ll.shape
     Q = obj_off.numel() - 1
     g_table = torch.zeros(table_shape, dtype=F32, device=g_ll.device)
@@ -699,6 +778,7 @@ def attr_gather_bwd(g_ll, obj_off, pred_q, pred_col, table_shape):
 
 
 def rel_gather_bwd(g_tile, pair_off, n_obj, pred_q, pred_col, orientation, table_shape):
+    require_sorted(pred_q, "rel_gather_bwd")
     P, NS = g_tile.shape[0], g_tile.shape[1]
     Q = n_obj.numel()
     g_table = torch.zeros(table_shape, dtype=F32, device=g_tile.device)
@@ -709,6 +789,7 @@ def rel_gather_bwd(g_tile, pair_off, n_obj, pred_q, pred_col, orientation, table
 
 def attr_ll_bwd(g, hidden, emb_w, emb_b, obj_off, pred_q, pred_col, need_hidden=True, need_emb=True, need_bias=True):
     """-> (d_hidden [O, H], dE [P, H] per predicate, db [P] per predicate); deterministic (no atomics)."""
+    require_sorted(pred_q, "attr_ll_bwd")
     P, NS = g.shape
     O, H = hidden.shape
     Q = obj_off.numel() - 1
@@ -716,7 +797,7 @@ def attr_ll_bwd(g, hidden, emb_w, emb_b, obj_off, pred_q, pred_col, need_hidden=
     d_hidden = torch.empty(O, H, dtype=F32, device=g.device) if need_hidden else None
     dE = torch.empty(P, H, dtype=F32, device=g.device) if need_emb else None
     db = torch.empty(P, dtype=F32, device=g.device) if need_bias else None
-    call("dfol_attr_ll_bwd_f32", _ptr(g, F32), hidden.data_ptr(), hidden.stride(0), H, emb_w.data_ptr(), emb_w.stride(0), _ptr(emb_b, F32, True),
+    call("dfol_attr_ll_bwd_f32", _ptr(g, F32), _dp(hidden), hidden.stride(0), H, _dp(emb_w), emb_w.stride(0), _ptr(emb_b, F32, True),
          _ptr(obj_off, I32), _ptr(pred_q, I32), _ptr(pred_col, I32), P, Q, NS, _ptr(gx), _ptr(d_hidden, F32, True), H,
          _ptr(dE, F32, True), H, _ptr(db, F32, True), _stream())
     return d_hidden, dE, db

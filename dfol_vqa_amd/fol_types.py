@@ -40,8 +40,8 @@ def _pad4(n):
     return max(4, (int(n) + 3) // 4 * 4)
 
 
-_geometry_cache = {}
-_pair_index_cache = {}
+_geometry_cache = L.LRUCache(256)
+_pair_index_cache = L.LRUCache(8)          # 16 bytes per ordered pair: keep a handful of batch shapes
 
 
 def _geometry_on_device(device, n_list):
@@ -51,13 +51,12 @@ def _geometry_on_device(device, n_list):
     key = (str(device), n_list)
     hit = _geometry_cache.get(key)
     if hit is None:
-        if len(_geometry_cache) >= 256:
-            _geometry_cache.clear()
         n = np.asarray(n_list, np.int64)
         hit = (torch.as_tensor(n.astype(np.int32)).to(device),
                torch.as_tensor(np.concatenate([[0], np.cumsum(n)]).astype(np.int32)).to(device),
                torch.as_tensor(np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)).to(device),
                torch.arange(len(n_list), dtype=torch.int32, device=device))
+        hit[3]._dfol_sorted = True                               # the identity map (see _lib.require_sorted)
         _geometry_cache[key] = hit
     return L.keep_alive(hit)
 
@@ -155,8 +154,6 @@ class BatchWorld(object):
                     first += n
                 hit = (torch.as_tensor(np.concatenate(s_all).astype(np.int64)).to(self._device),
                        torch.as_tensor(np.concatenate(o_all).astype(np.int64)).to(self._device))
-                if len(_pair_index_cache) >= 8:          # 16 bytes per ordered pair: keep a handful of batch shapes
-                    _pair_index_cache.clear()
                 _pair_index_cache[key] = hit
             self._pair_idx = L.keep_alive(hit)
         return self._pair_idx

@@ -10,7 +10,7 @@ import re
 import numpy as np
 import torch
 
-from ._lib import keep_alive, keeping  # noqa: F401
+from ._lib import LRUCache, keep_alive, keeping  # noqa: F401
 from .fol_types import TokenType
 
 _NEG = re.compile(r"not\((\w|\s)+\)")
@@ -80,7 +80,7 @@ class Lowered(object):
         return keep_alive(self._dev[key])        # (a hit must reach a capturing graph's keep-alive list too: the Lowered object may be evicted)
 
 
-_upload_cache = {}
+_upload_cache = LRUCache(1024)
 
 
 def upload(array, device):
@@ -90,8 +90,6 @@ def upload(array, device):
     key = (str(device), a.dtype.str, a.shape, a.tobytes())
     hit = _upload_cache.get(key)
     if hit is None:
-        if len(_upload_cache) >= 1024:
-            _upload_cache.clear()
         hit = _upload_cache[key] = torch.as_tensor(a).to(device)
     return keep_alive(hit)
 
@@ -106,7 +104,7 @@ def lower_tokens(tokens, ontology, token_type):
     # same Lowered object, whose device copies are then uploaded once
     key = None
     if len(tokens) >= 1:
-        cache = ontology.__dict__.setdefault("_lower_cache", {})       # lives and dies with the ontology it was resolved against
+        cache = ontology.__dict__.setdefault("_lower_cache", LRUCache(256))       # lives and dies with the ontology it was resolved against
         key = (int(token_type), tuple(tokens))
         hit = cache.get(key)
         if hit is not None:
@@ -127,8 +125,6 @@ def lower_tokens(tokens, ontology, token_type):
         cols.append(idx), neg.append(int(n)), valid.append(1)
     low = Lowered(cols, neg, valid)
     if key is not None:
-        if len(cache) >= 256:
-            cache.clear()
         cache[key] = low
     return low
 

@@ -1,8 +1,10 @@
 """Autograd-aware front of the C-ABI wrappers.
 
 Every function here has the signature of its namesake in `_lib`.  Under `torch.no_grad()` (inference) the call
-goes straight to the kernel; when a floating-point input requires grad, it goes through a `torch.autograd.Function`
-whose backward launches the HIP backward kernels (`csrc/dfol_logic_bwd.hip`).  The backward of the tiny per-question
+goes straight to the kernel; when a floating-point input requires grad, the core entry points (filter, relate, quantify,
+linear_act) go through the registered PyTorch operators `torch.ops.dfol.*` (torch_ops.py: custom_op + register_autograd +
+register_fake), the small glue through a `torch.autograd.Function`; either way the backward launches the HIP backward
+kernels (`csrc/dfol_logic_bwd.hip`).  The backward of the tiny per-question
 vector glue (gate, segment reductions, and/or/not, compare) and of the dense layers is written with torch tensor ops /
 library GEMMs on the GPU — plumbing, as the design notes say.
 """
@@ -12,6 +14,7 @@ import os
 import torch
 
 from . import _lib
+from . import torch_ops  # noqa: F401  (registers torch.ops.dfol.*)
 from ._lib import *  # noqa: F401,F403  (constants, DfolError, non-differentiable wrappers)
 from ._lib import DfolError  # noqa: F401
 
@@ -30,79 +33,26 @@ def _dpnot(x, alpha):
 
 
 # ---- filter ------------------------------------------------------------------------------------------
-class _Filter(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, att_in, ll, pred_q, n_obj, neg, active):
-        ctx.save_for_backward(ll, pred_q, n_obj, neg if neg is not None else ll.new_empty(0), active if active is not None else ll.new_empty(0))
-        ctx.flags = (neg is not None, active is not None, att_in.shape[0])
-        return _lib.filter_fwd(att_in, ll, pred_q, n_obj, neg, active)
-
-    @staticmethod
-    def backward(ctx, g):
-        ll, pred_q, n_obj, neg, active = ctx.saved_tensors
-        has_neg, has_act, Q = ctx.flags
-        g_prior, g_ll = _lib.filter_bwd(g.contiguous(), ll, pred_q, n_obj, neg if has_neg else None, active if has_act else None, Q,
-                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return g_prior, g_ll, None, None, None, None
-
-
 def filter_fwd(att_in, ll, pred_q, n_obj, neg=None, active=None):
     if _needs_grad(att_in, ll):
-        return _Filter.apply(att_in, ll, pred_q, n_obj, neg, active)
+        return torch.ops.dfol.filter_fwd(att_in, ll, pred_q, n_obj, neg, active)
     return _lib.filter_fwd(att_in, ll, pred_q, n_obj, neg, active)
 
 
 # ---- relate ------------------------------------------------------------------------------------------
-class _Relate(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone, diag_absent=False):
-        ps, po = _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone,
-                                 diag_absent=diag_absent)
-        e = tile.new_empty(0)
-        ctx.save_for_backward(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg if neg is not None else e,
-                              active if active is not None else e, want if want is not None else e)
-        ctx.flags = (neg is not None, active is not None, want is not None, orientation, lone)
-        return ps, po
-
-    @staticmethod
-    def backward(ctx, gs, go):
-        prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want = ctx.saved_tensors
-        has_neg, has_act, has_want, orientation, lone = ctx.flags
-        gs, go = gs.contiguous(), go.contiguous()
-        if has_want:       # a posterior the forward did not produce carries no gradient
-            gs = gs * ((want & 1) > 0).to(gs.dtype).unsqueeze(1)
-            go = go * ((want & 2) > 0).to(go.dtype).unsqueeze(1)
-        need_prior = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        g_ps, g_po, g_tile = _lib.relate_bwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg if has_neg else None,
-                                             active if has_act else None, gs, go, orientation, lone, need_prior, ctx.needs_input_grad[2])
-        return g_ps, g_po, g_tile, None, None, None, None, None, None, None, None, None, None
-
-
 def relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg=None, active=None, want=None,
                orientation=_lib.TILE_SUBJECT_ROWS, lone_forall_identity=False, need_s=True, need_o=True, diag_absent=False):
     if _needs_grad(prior_s, prior_o, tile):
-        return _Relate.apply(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity,
-                             diag_absent)
+        return torch.ops.dfol.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, int(orientation),
+                                         bool(lone_forall_identity), bool(diag_absent))
     return _lib.relate_fwd(prior_s, prior_o, tile, pred_q, n_obj, quant_s, quant_o, neg, active, want, orientation, lone_forall_identity,
                            need_s, need_o, diag_absent)
 
 
 # ---- quantify ----------------------------------------------------------------------------------------
-class _Quantify(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, att, quant, pred_q, n_obj):
-        ctx.save_for_backward(att, quant, pred_q, n_obj)
-        return _lib.quantify_fwd(att, quant, pred_q, n_obj)
-
-    @staticmethod
-    def backward(ctx, g):
-        att, quant, pred_q, n_obj = ctx.saved_tensors
-        return _lib.quantify_bwd(g.contiguous(), att, quant, pred_q, n_obj), None, None, None
-
-
 def quantify_fwd(att, quant, pred_q, n_obj):
     if _needs_grad(att):
-        return _Quantify.apply(att, quant, pred_q, n_obj)
+        return torch.ops.dfol.quantify_fwd(att, quant, pred_q, n_obj)
     return _lib.quantify_fwd(att, quant, pred_q, n_obj)
 
 
@@ -365,12 +315,16 @@ class _LinearAct(torch.autograd.Function):
 
 def linear_act(x, weight, bias, act, out=None):
     if out is None and _needs_grad(x, weight, bias):
-        return _LinearAct.apply(x, weight, bias, act)
+        if os.environ.get("DFOL_TRAIN_GEMM", "hip") == "torch":     # A/B runs: library GEMMs in the backward
+            return _LinearAct.apply(x, weight, bias, act)
+        return torch.ops.dfol.linear_act(x, weight, bias, int(act))
     return _lib.linear_act(x, weight, bias, act, out)
 
 
 class _PairFeatures(torch.autograd.Function):
-    """[obj_s, obj_o, geometry]: the gradient flows back to the two object rows (the geometry comes from the raw boxes)."""
+    """[obj_s, obj_o, geometry]: the gradient flows back to the two object rows (the geometry comes from the raw boxes).  Only the
+    full-table compatibility dataflow (`_needed_columns = False`) builds the [pairs, 1036] matrix; its backward is torch's atomic
+    index_add_ - the one place the deterministic-backward guarantee does not cover."""
 
     @staticmethod
     def forward(ctx, obj, D, obj_off, pair_off, Q, max_n, pairs, ind_s, ind_o):

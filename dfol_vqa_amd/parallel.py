@@ -116,13 +116,14 @@ class GradBucket(object):
             self._pending = [b - a for _, _, a, b in self._segments]
             self._works = [None] * len(self._segments)
             self._next = len(self._segments) - 1
+            self._finished = False
 
     def nbytes(self):
         return self.flat.numel() * 4
 
     def enable_overlap(self, group=None, segments=3):
         """Overlap the collective with the backward pass: the bucket is cut into `segments` contiguous ranges at parameter boundaries and
-        the all-reduce of a range starts (async, on the collective's own stream) the moment autograd has accumulated the last gradient of
+        the all-reduce of a range starts (async, from a side stream that waits for the backward's stream) the moment autograd has accumulated the last gradient of
         the range - post-accumulate-grad hooks - while the rest of the backward still runs.  Autograd reaches the parameters roughly in
         reverse order, so the ranges are issued last to first - strictly in that order on every rank (a rank whose batch finished an earlier
         range first holds it back), because collectives must match across ranks.  `allreduce()` then starts whatever has not started
@@ -144,6 +145,12 @@ class GradBucket(object):
         self._pending = [b - a for _, _, a, b in self._segments]
         self._works = [None] * len(self._segments)
         self._next = len(self._segments) - 1
+        self._finished = False
+        # Streams, explicitly: a range's all-reduce is issued from a dedicated side stream that first waits for the stream the hook runs
+        # on (the backward's: autograd runs a node - and its hooks - on the stream of the node's forward), so the collective starts after
+        # the gradients of the range are complete, whatever stream the backward used; allreduce() makes the caller's stream (the
+        # optimizer's) wait for the side stream after the works have completed on it.
+        self._side = torch.cuda.Stream(device=self.flat.device) if self.flat.is_cuda else None
         seg_of = {}
         for k, (_, _, a, b) in enumerate(self._segments):
             for i in range(a, b):
@@ -158,10 +165,20 @@ class GradBucket(object):
         while self._next >= 0 and (force or self._pending[self._next] <= 0):
             a, b, _, _ = self._segments[self._next]
             if b > a:
-                self._works[self._next] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                if self._side is not None:
+                    self._side.wait_stream(torch.cuda.current_stream(self.flat.device))
+                    with torch.cuda.stream(self._side):
+                        self._works[self._next] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                else:
+                    self._works[self._next] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
             self._next -= 1
 
     def _ready(self, k):
+        # ONE backward per zero_(): a second backward (gradient accumulation, retain_graph) would add local gradients into a range that
+        # has already been summed across ranks, and the replicas would drift apart silently
+        if getattr(self, "_finished", False) or self._pending[k] <= 0 or self._next < k:
+            raise RuntimeError("GradBucket overlap mode: a gradient arrived for a range whose all-reduce has already been issued - "
+                               "call bucket.zero_() before every backward (one backward per step; no gradient accumulation in overlap mode)")
         self._pending[k] -= 1
         if self._pending[k] == 0:
             self._launch_ready()
@@ -171,9 +188,17 @@ class GradBucket(object):
         enable_overlap(), the completion of the per-range collectives the backward already started."""
         if self._segments is not None:
             self._launch_ready(force=True)
-            for w in self._works:
-                if w is not None:
-                    w.wait()
+            if self._side is not None:
+                with torch.cuda.stream(self._side):
+                    for w in self._works:
+                        if w is not None:
+                            w.wait()
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+            else:
+                for w in self._works:
+                    if w is not None:
+                        w.wait()
+            self._finished = True
             return self.nbytes()
         if self.flat.numel():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)

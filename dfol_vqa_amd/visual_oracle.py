@@ -259,8 +259,6 @@ def _concept_plan(cols, device, cache):
         ucols, start = np.unique(sc, return_index=True)
         seg = np.concatenate([start, [len(sc)]]).astype(np.int32)
         hit = (torch.as_tensor(order.astype(np.int32)).to(device), torch.as_tensor(seg).to(device), torch.as_tensor(ucols.astype(np.int64)).to(device))
-        if len(cache) >= 64:
-            cache.clear()
         cache[key] = hit
     return hit
 
@@ -326,7 +324,7 @@ class ClassifierOracle(OracleBase):
         self._cached = cached
         self._needed_columns = True       # compute only the likelihood columns a program asks for (when the MLP shape allows)
         self._split_cache = None
-        self._index_cache = {}
+        self._index_cache = _lib.LRUCache(64)
         # storage type of prefetched relation tiles: torch.bfloat16 halves the tile stream of the Relate kernel (BASELINE configs[4]);
         # an opt-in whose results differ from the reference by the rounding of the stored likelihoods.  Used when the scene's padded
         # width is a multiple of 8 and the operator runs on the fused single-posterior kernel; everything else stays fp32.
@@ -565,8 +563,6 @@ class ClassifierOracle(OracleBase):
             identity = len(src) == world._pair_num and np.array_equal(src, np.arange(len(src)))
             hit = (None if identity else torch.as_tensor(src).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev),
                    torch.as_tensor(rep).to(dev), torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(dev), int(cnt.max()))
-            if len(self._index_cache) >= 32:
-                self._index_cache.clear()
             self._index_cache[key] = hit
         src, dst, rep, pred_off, max_rows = hit
         cols = upload(full[preds].astype(np.int64), dev)

@@ -70,12 +70,26 @@ def train_case(rank, world, out):
         pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(mine)]
         params = [p for p in model.parameters() if p.requires_grad]
         opt = torch.optim.Adam(params, lr=1e-3)
-        bucket = parallel.GradBucket(params).enable_overlap(dist.group.WORLD, segments=3)     # ranges all-reduced during the backward
+        bucket = parallel.GradBucket(params)
+        if os.environ.get("DFOL_TEST_OVERLAP", "1") == "1":
+            bucket.enable_overlap(dist.group.WORLD, segments=3)              # ranges all-reduced during the backward
         bucket.zero_()
-        res = model(pbs, True)
-        loss = training.compute_loss(pbs, res) / len(qs)                   # sum / B_global (trainer.py:433-436)
-        loss.backward()
-        bucket.allreduce(dist.group.WORLD)
+        if os.environ.get("DFOL_TEST_SIDE_STREAM") == "1":
+            # forward + backward on a SIDE stream: the hooks then issue the range collectives from the autograd thread with that stream
+            # current, and the bucket must order them after it (GradBucket._launch_ready) and the caller's stream after them
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                res = model(pbs, True)
+                loss = training.compute_loss(pbs, res) / len(qs)
+                loss.backward()
+                bucket.allreduce(dist.group.WORLD)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            res = model(pbs, True)
+            loss = training.compute_loss(pbs, res) / len(qs)                   # sum / B_global (trainer.py:433-436)
+            loss.backward()
+            bucket.allreduce(dist.group.WORLD)
         lt = torch.tensor([float(loss.detach())], dtype=torch.float64)
         dist.all_reduce(lt)
         if rank == 0:                                        # (failures are collected, not raised: the peer is waiting in a collective)

@@ -374,6 +374,32 @@ def test_reduce_by_question_and_prior_gradients_are_repeatable():
         assert all(np.array_equal(a, b) for a, b in zip(runs[0], r))
 
 
+def test_backward_refuses_an_unsorted_predicate_map():
+    """The deterministic backward finds a question's predicates by binary search in the predicate -> question map; an unsorted map would
+    silently drop gradient contributions, so every backward entry refuses it (the atomic-add kernels it replaced accepted any order)."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(4)
+    n_list = np.array([5, 7, 3], np.int32)
+    Q, NS = 3, 8
+    dev = lambda x: torch.tensor(x, device=DEV)
+    for pq in (np.array([0, 2, 1, 1], np.int32), np.array([1, 0], np.int32)):
+        P = len(pq)
+        src, ll = rng.normal(size=(P, NS)).astype(np.float32), (-np.abs(rng.normal(size=(P, NS)))).astype(np.float32)
+        with pytest.raises(_lib.DfolError, match="non-decreasing"):
+            _lib.reduce_by_question(dev(src), dev(pq), dev(n_list), Q)
+        with pytest.raises(_lib.DfolError, match="non-decreasing"):
+            _lib.filter_bwd(dev(src), dev(ll), dev(pq), dev(n_list), None, None, Q)
+        tile = (-np.abs(rng.normal(size=(P, NS, NS)))).astype(np.float32)
+        pr = (-np.abs(rng.normal(size=(Q, NS)))).astype(np.float32)
+        with pytest.raises(_lib.DfolError, match="non-decreasing"):
+            _lib.relate_bwd(dev(pr), dev(pr), dev(tile), dev(pq), dev(n_list), dev(np.ones(P, np.float32)), dev(np.ones(P, np.float32)), None, None,
+                            dev(src), dev(src), 0, False)
+    # a sorted map with gaps and repeats is fine
+    pq = np.array([0, 0, 2], np.int32)
+    out = _lib.reduce_by_question(dev(rng.normal(size=(3, NS)).astype(np.float32)), dev(pq), dev(n_list), Q)
+    assert out.shape == (Q, NS) and bool((out[1] == 0).all())
+
+
 @pytest.mark.parametrize("n_list,k_list,H", [([5, 12, 1, 30], [2, 1, 3, 1], 300), ([100, 64], [1, 26], 300), ([7, 9], [1, 1], 44)])
 def test_attr_ll_backward_against_autograd(n_list, k_list, H):
     """csrc/dfol_logic_bwd.hip attr_ll_bwd (needed-columns attribute likelihood) against float64 autograd of the formulation it

@@ -792,3 +792,48 @@ def test_find_max_ind_on_device(L):
         ref = orc.find_max_ind(lp, pq, len(counts), thr)
         assert got.tolist() == ref.tolist(), thr
     assert got.sum() <= len(counts) + 2
+
+
+def test_torch_custom_ops_opcheck(L):
+    """The six core entry points are PyTorch operators (torch.ops.dfol.*: torch_ops.py, custom_op + register_fake + register_autograd):
+    torch.library.opcheck validates schema, fake-tensor function, autograd registration and AOT-autograd tracing of each
+    (the dispatch site they serve is batch_gqa_interpreter.py:72-78)."""
+    from dfol_vqa_amd import torch_ops  # noqa: F401
+    rng = np.random.RandomState(9)
+    n_list, k_list = [5, 12, 3], [2, 1, 3]
+    Q, NS = len(n_list), 12
+    pq_h = np.repeat(np.arange(Q), k_list).astype(np.int32)
+    P = len(pq_h)
+    pq, n_obj = dev(pq_h), dev(np.asarray(n_list, np.int32))
+    f = lambda *shape: dev((-np.abs(rng.normal(size=shape))).astype(np.float32))
+    neg, want = dev((rng.uniform(size=P) < 0.5).astype(np.uint8)), dev(np.full(P, 3, np.uint8))
+    ones = torch.ones(P, device="cuda")
+    utils = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_dynamic")
+    g = lambda t: t.requires_grad_(True)
+    torch.library.opcheck(torch.ops.dfol.filter_fwd.default, (g(f(Q, NS)), g(f(P, NS)), pq, n_obj, neg, None), test_utils=utils)
+    torch.library.opcheck(torch.ops.dfol.relate_fwd.default, (g(f(Q, NS)), g(f(Q, NS)), g(f(P, NS, NS)), pq, n_obj, ones, ones.clone(), neg, None, want, 0, False, False),
+                          test_utils=utils)
+    torch.library.opcheck(torch.ops.dfol.relate_one_fwd.default, (f(P, NS), f(Q, NS), f(P, NS, NS), pq, n_obj, ones, None, None, False), test_utils=utils)
+    torch.library.opcheck(torch.ops.dfol.quantify_fwd.default, (g(f(P, NS)), ones, pq, n_obj), test_utils=utils)
+    x, w, b = g(dev(rng.normal(size=(40, 24)).astype(np.float32))), g(dev(rng.normal(size=(16, 24)).astype(np.float32) * 0.2)), g(dev(rng.normal(size=16).astype(np.float32)))
+    for act in (L.ACT_NONE, L.ACT_SIGMOID, L.ACT_ELU, L.ACT_LOGSIGMOID):
+        torch.library.opcheck(torch.ops.dfol.linear_act.default, (x, w, b, int(act)), test_utils=utils)
+    # pair_ll mutates its `tiles` argument
+    hid1, hid2, D, C = 32, 12, 20, 30
+    O = sum(n_list)
+    obj_off = dev(np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32))
+    uv = dev(rng.normal(size=(O, 2 * hid1)).astype(np.float32))
+    pos = dev(rng.uniform(0.05, 0.9, size=(O, 4)).astype(np.float32))
+    wg, w2, b2 = dev(rng.normal(size=(hid1, 4)).astype(np.float32) * 0.1), dev(rng.normal(size=(hid2, hid1)).astype(np.float32) * 0.2), dev(rng.normal(size=hid2).astype(np.float32))
+    emb_w, emb_b = dev(rng.normal(size=(C, hid2)).astype(np.float32) * 0.3), dev(rng.normal(size=C).astype(np.float32))
+    req_col, req_tile = dev(rng.randint(0, C, size=(1, Q)).astype(np.int32)), dev(np.arange(Q, dtype=np.int32).reshape(1, Q))
+    tiles = torch.full((Q, NS, NS), -30.0, device="cuda")
+    torch.library.opcheck(torch.ops.dfol.pair_ll.default, (uv, hid1, pos, wg, w2, b2, hid2, emb_w, emb_b, n_obj, obj_off, max(n_list), req_col, req_tile, None, tiles, -30.0, 0),
+                          test_utils=("test_schema", "test_faketensor"))
+    # and the operators' gradients are the HIP backward kernels' (same numbers as the direct call)
+    att, ll = g(f(Q, NS)), g(f(P, NS))
+    out = torch.ops.dfol.filter_fwd(att, ll, pq, n_obj, neg, None)
+    go = torch.ones_like(out)
+    ga, gl = torch.autograd.grad(out, (att, ll), go)
+    ra, rl = L.filter_bwd(go, ll.detach(), pq, n_obj, neg, None, Q)
+    assert torch.equal(ga, ra) and torch.equal(gl, rl)

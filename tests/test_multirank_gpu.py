@@ -23,12 +23,12 @@ def _free_port():
     return p
 
 
-def _run_ranks(case, tmp_path, world=2, timeout=420):
+def _run_ranks(case, tmp_path, world=2, timeout=420, extra_env=None):
     port = _free_port()
     procs, paths = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **(extra_env or {}))
         path = str(tmp_path / ("%s_rank%d.json" % (case, r)))
         paths.append(path)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_rank_worker.py"), case, path], env=env, cwd=ROOT))
@@ -56,8 +56,11 @@ def test_two_rank_inference_equals_one_rank(tmp_path):
     assert r0["answers_equal"]
 
 
-def test_two_rank_train_step_matches_g12_and_replicas_stay_equal(tmp_path):
-    outs = _run_ranks("train", tmp_path)
+@pytest.mark.parametrize("overlap,side_stream", [(1, 0), (0, 0), (1, 1)])
+def test_two_rank_train_step_matches_g12_and_replicas_stay_equal(tmp_path, overlap, side_stream):
+    """overlap = 1: ranges of the gradient bucket all-reduced from autograd hooks during the backward; 0: one all-reduce after it;
+    side_stream = 1: forward and backward run on a non-default stream (the collectives must be ordered after THAT stream)."""
+    outs = _run_ranks("train", tmp_path, extra_env={"DFOL_TEST_OVERLAP": str(overlap), "DFOL_TEST_SIDE_STREAM": str(side_stream)})
     r0 = [o for o in outs if o["rank"] == 0][0]
     assert r0["g12_checked"] and all(n == 12 for n in r0["g12_checked"].values()), r0["g12_checked"]
     assert all(o["replicas_equal"] for o in outs)
@@ -77,5 +80,8 @@ def test_bench_launches_its_own_ranks(mode):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
+    assert out["ranks"]["backend"] == "gloo" and [r["rank"] for r in out["ranks"]["ranks_seen"]] == [0, 1]
+    assert out["ranks"]["rank_ms_per_step_min"] > 0
     if mode == "train":
         assert out["replicas_equal"] is True
+        assert out["allreduce_ms"] > 0

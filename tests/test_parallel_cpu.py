@@ -171,6 +171,21 @@ def _worker(rank, world, port, out):
         both = [torch.zeros_like(ragged) for _ in range(world)]
         dist.all_gather(both, ragged)
         assert torch.equal(both[0], both[1])
+        # overlap mode takes ONE backward per zero_(): a second one would add local gradients into ranges that are already summed across
+        # ranks (the replicas would drift apart silently) - it must raise instead
+        model = _Deep(False)
+        params = list(model.parameters())
+        bucket = parallel.GradBucket(params).enable_overlap(dist.group.WORLD, segments=3)
+        bucket.zero_()
+        x = xs[s2:e2]
+        model([type("PB", (), {"x": x})()], True)["log_probability"].sum().backward()
+        raised = False
+        try:
+            model([type("PB", (), {"x": x})()], True)["log_probability"].sum().backward()
+        except RuntimeError as exc:
+            raised = "one backward per step" in str(exc)
+        bucket.allreduce(dist.group.WORLD)                  # (every rank issued the same collectives before raising: nothing is left unpaired)
+        assert raised, "a second backward in overlap mode must raise"
         out.put((rank, "ok"))
     except Exception as exc:  # pragma: no cover
         out.put((rank, repr(exc)))

@@ -46,9 +46,13 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=100)            # (a 20-step timed region at N = 100 is 47 ms: too short for the driver to sample)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=("infer", "train"), default="infer")
-    ap.add_argument("--workload", choices=("north_star", "c1", "c4"), default="north_star",
+    ap.add_argument("--workload", choices=("north_star", "c1", "c3", "c4"), default="north_star",
                     help="north_star: configs[1]'s program on 100-object scenes (the size the metric is quoted on); c1: configs[1] verbatim "
-                         "(36 objects); c4: configs[4] (256 objects, 8-hop open programs, bf16 relation tiles)")
+                         "(36 objects); c3: configs[2]'s shape - ragged scenes of 10..100 objects, several questions per image sharing one scene; "
+                         "c4: configs[4] (256 objects, 8-hop open programs, bf16 relation tiles)")
+    ap.add_argument("--questions-per-image", type=int, default=None,
+                    help="questions that share one image (and, with sharing, one featurizer pass and one set of relation tiles); default 8 for c3, else 1")
+    ap.add_argument("--share-scenes", type=int, default=1, help="0: collate one copy of the scene per question even when questions share an image (the reference's layout)")
     ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--ragged", type=int, default=0, help="train mode: object counts ~ U{ragged..objects}")
     ap.add_argument("--calibrator", type=int, default=0, help="train mode: 1 = calibrator phases (cur6-7): oracle frozen, the attention networks train")
@@ -70,7 +74,11 @@ def parse(argv=None):
     ap.add_argument("--parity-fp64", type=int, default=1, help="1: the parity leg also runs the oracle in float64 (the tolerance policy's yardstick)")
     args = ap.parse_args(argv)
     if args.objects is None:
-        args.objects = {"north_star": 100, "c1": 36, "c4": 256}[args.workload]
+        args.objects = {"north_star": 100, "c1": 36, "c3": 100, "c4": 256}[args.workload]
+    if args.questions_per_image is None:
+        args.questions_per_image = 8 if args.workload == "c3" else 1
+    if args.workload == "c3" and not args.ragged:
+        args.ragged = 10
     return args
 
 
@@ -102,7 +110,8 @@ def build_batch(args, rank, ontology, names, device):
 
     class Collater(D.ProgramCollaterBase):
         def __init__(self):
-            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology)
+            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology,
+                                           share_scenes=getattr(args, "questions_per_image", 1) > 1 and bool(getattr(args, "share_scenes", 1)))
 
         def collate_object_features(self, questions):
             feats = torch.cat([torch.from_numpy(q["scene"]["X"]) for q in questions], 0)
@@ -114,16 +123,25 @@ def build_batch(args, rank, ontology, names, device):
 
     nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
     rng = np.random.RandomState(1000 + rank)
-    qs = []
+    G = max(1, getattr(args, "questions_per_image", 1))
+    qs, scene_of = [], {}
     for i in range(args.batch):
-        qid = rank * args.batch + i                        # scenes are keyed by question id: sharding never changes inputs
-        n = args.objects if not getattr(args, "ragged", 0) else int(rng.randint(args.ragged, args.objects + 1))
+        qid = rank * args.batch + i                        # scenes are keyed by question / image id: sharding never changes inputs
+        img = qid // G                                     # G consecutive questions look at the same image
+        if img not in scene_of:
+            n = args.objects if not getattr(args, "ragged", 0) else int(rng.randint(args.ragged, args.objects + 1))
+            scene_of[img] = syn.feature_scene(img if G > 1 else qid, n, 2048)
         if getattr(args, "workload", "north_star") == "c4":
             br, last = syn.open_program(qid, nouns, attrs, rels, names["categories"], hops=4)
-            qs.append(syn.question(qid, br, last, attrs[qid % len(attrs)], syn.feature_scene(qid, n, 2048)))
+            q = syn.question(qid, br, last, attrs[qid % len(attrs)], scene_of[img])
         else:
             br, last = syn.three_hop_program(qid, nouns, attrs, rels)
-            qs.append(syn.question(qid, br, last, "yes", syn.feature_scene(qid, n, 2048)))
+            q = syn.question(qid, br, last, "yes", scene_of[img])
+        if G > 1:
+            q["image_id"] = "img%d" % img
+        else:
+            q["image_id"] = "q%d" % qid                    # (synthetic.question folds ids modulo 64: every question its own image here)
+        qs.append(q)
     pbs = Collater().collate(qs)
     for pb in pbs:
         pb.create_sparse_tensors()
@@ -146,6 +164,8 @@ WORKLOADS = {
                   "scenes (the size BASELINE.json's metric is quoted on), full-size oracle (2048->512, 516/1036->256->300->2335)",
     "c1": "BASELINE configs[1] verbatim: select->filter->relate->exist (3-hop), fp32, %d questions/GPU/step, %d-object synthetic scenes, "
           "full-size oracle (2048->512, 516/1036->256->300->2335)",
+    "c3": "BASELINE configs[2]'s shape with synthetic features: select->filter->relate->exist, fp32, %d questions/GPU/step on ragged scenes of "
+          "10..%d objects, QPI questions per image, full-size oracle (2048->512, 516/1036->256->300->2335)",
     "c4": "BASELINE configs[4]: select->(filter->relate)x4->query_attr (8-hop open programs), %d questions/GPU/step, %d-object synthetic "
           "scenes, bf16 relation tiles (fp32 logic arithmetic), full-size oracle",
 }
@@ -229,6 +249,13 @@ def main(argv=None):
         from dfol_vqa_amd import parallel
         parallel.broadcast_parameters(model, 0)
     qs, pbs = build_batch(args, rank, ontology, names, device)
+    args._scene_ns = [int(n) for pb in pbs for n in pb._object_nums]
+    if args.questions_per_image > 1 and args.share_scenes:
+        seen = {}
+        for q in qs:
+            rel = [o for o in q["program"]["branches"][0] if o["operator"] == "relate"][0]["arguments"]
+            seen.setdefault(q["image_id"], set()).add((rel[0], bool(rel[1])))
+        args._tiles_per_scene = float(np.mean([len(v) for v in seen.values()]))
 
     eager = lambda: model(pbs, False)
     step = eager
@@ -263,12 +290,17 @@ def main(argv=None):
         elapsed = float(t.item())
     total_q = args.batch * world * args.steps
     metric = "questions/sec (GQA programs, N=%d objects)" % args.objects
+    if args.workload == "c3":
+        metric = "questions/sec (GQA programs, ragged scenes of %d..%d objects, %d questions per image%s)" % (
+            args.ragged, args.objects, args.questions_per_image, "" if args.share_scenes else ", scenes NOT shared")
     out = {"argv": list(argv), "metric": metric, "value": total_q / elapsed, "unit": "questions/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": (WORKLOADS[args.workload] % (args.batch, args.objects)).replace(
+           "config": {"workload": (WORKLOADS[args.workload] % (args.batch, args.objects)).replace("QPI", str(args.questions_per_image)).replace(
                " (the size BASELINE.json's metric is quoted on)", " (the size BASELINE.json's metric is quoted on)" if args.objects == 100 else ""),
-                      "workload_id": args.workload, "batch_per_gpu": args.batch,
+                      "workload_id": args.workload, "batch_per_gpu": args.batch, "questions_per_image": args.questions_per_image,
+                      "scenes_shared": bool(args.questions_per_image > 1 and args.share_scenes), "distinct_scenes_per_gpu": len(args._scene_ns),
+                      "objects_total_per_gpu": int(sum(args._scene_ns)),
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
                       "launch": "hip graph replay" if graphed else "eager",
                       "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else
@@ -349,10 +381,13 @@ def main(argv=None):
 
 
 def dominant_roofline(args, model, dom, per_step):
-    O = args.batch * args.objects
-    pairs = args.batch * args.objects * (args.objects - 1)
+    ns = np.asarray(getattr(args, "_scene_ns", None) or [args.objects] * args.batch, np.float64)      # objects of every DISTINCT scene of the batch
+    O = float(ns.sum())
+    pairs = float((ns * (ns - 1)).sum())                # (with n*n slots per image the kernel also computes the diagonal; not counted)
     launches, secs = per_step[dom]
     KR = 4 if args.workload == "c4" else 1              # relation columns requested per image (one per relate hop of the program)
+    if getattr(args, "_tiles_per_scene", None):
+        KR = args._tiles_per_scene                       # shared scenes: distinct (relation, orientation) requests per image
     if dom == "dfol_pair_ll_split_f32":
         # The same algorithmic flops, executed on the bf16 matrix pipe as six piece products per fp32 product (three exact
         # bf16 pieces per operand, fp32 accumulate: fp32 results, csrc/dfol_pair_split.hip).  `achieved` / `frac` follow the
@@ -440,7 +475,7 @@ def streamed_rate(args, step, pbs, td, share, device, batches=4):
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
     nbytes = feats.numel() * 4
-    return {"questions_per_s": args.batch * n / dt, "ms_per_step": dt / n * 1e3, "h2d_bytes_per_step": nbytes,
+    return {"questions_per_s": args.batch * n / dt, "ms_per_step": dt / n * 1e3, "h2d_bytes_per_step": nbytes, "h2d_bytes_per_question": nbytes / args.batch,
             "h2d_GBps": nbytes * n / dt / 1e9, "how": "pinned host -> device on a copy stream, double-buffered, overlapped with the step"}
 
 

@@ -278,8 +278,9 @@ class BatchGQABoxFeaturesCollator(ProgramCollaterBase):
     `object_info_json_path` maps image id -> {objectsNum, width, height, idx, file}.  Produces the reference's
     `object_features [O, F + 6]` = [features, W, H, x, y, w, h] (:57-71) plus the host-side object counts."""
 
-    def __init__(self, object_h5_path, file_prefix, chunk_num, object_info_json_path, ontology, split_num, lower=True):
-        super(BatchGQABoxFeaturesCollator, self).__init__('select', 'relate', 'filter', split_num, ontology=ontology if lower else None)
+    def __init__(self, object_h5_path, file_prefix, chunk_num, object_info_json_path, ontology, split_num, lower=True, share_scenes=False):
+        super(BatchGQABoxFeaturesCollator, self).__init__('select', 'relate', 'filter', split_num, ontology=ontology if lower else None,
+                                                          share_scenes=share_scenes)
         self._object_h5_path = object_h5_path
         self._file_prefix = file_prefix
         self._chunk_num = chunk_num

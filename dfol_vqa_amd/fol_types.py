@@ -65,7 +65,12 @@ class BatchWorld(object):
     """Scene of one ProgramBatch (batch_base_types.py:191-252): likelihood tables + the block geometry."""
 
     def __init__(self, device, object_num, attribute_features, relation_features, batch_index, meta_data=None,
-                 attention_transfer_state_dim=0, object_nums=None):
+                 attention_transfer_state_dim=0, object_nums=None, question_image=None):
+        """`question_image` (None = the reference's layout, one scene per question): question k looks at scene question_image[k]; the
+        object rows (`object_num`, `batch_index`, `object_nums`) then describe the DISTINCT scenes.  Two geometries result: the
+        QUESTION-level one the logic kernels index (`_n_list`, `_n_obj`, `_ident`, `_NS`: attention rows are per question) and the
+        IMAGE-level one the oracle kernels index (`_img_n_list`, `_img_n_obj`, `_obj_off`, `_pair_off`, `_pair_num`: object / pair rows
+        are per scene), linked by `_q_img`.  Without sharing they coincide."""
         self._device = device
         self._lazy = None                 # set by the oracle's needed-columns mode: hidden activations instead of tables
         self._rel_tiles = {}              # relation tiles computed ahead of the execution loop, keyed by id(lowered tokens)
@@ -79,14 +84,34 @@ class BatchWorld(object):
         if object_nums is None:       # the reference syncs here too (batch_base_types.py:202-205)
             bi = batch_index if isinstance(batch_index, torch.Tensor) else torch.as_tensor(batch_index)
             object_nums = torch.bincount(bi.to(torch.int64).cpu()).tolist()
-        self._n_list = [int(n) for n in object_nums]
-        assert sum(self._n_list) == self._object_num, "object counts do not add up to object_num"
+        self._img_n_list = [int(n) for n in object_nums]
+        assert sum(self._img_n_list) == self._object_num, "object counts do not add up to object_num"
+        n = np.asarray(self._img_n_list, np.int64)
+        self._img_n_obj, self._obj_off, self._pair_off, img_ident = _geometry_on_device(device, tuple(self._img_n_list))
+        self._pair_num = int((n * (n - 1)).sum())
+        self._shared = question_image is not None
+        if self._shared:
+            self._q_img = np.asarray(question_image, np.int64)
+            assert self._q_img.ndim == 1 and (len(self._q_img) == 0 or (0 <= self._q_img.min() and self._q_img.max() < len(self._img_n_list))), \
+                "question_image must index the scenes of this batch"
+            self._n_list = [self._img_n_list[i] for i in self._q_img]
+            self._n_obj, _, _, self._ident = _geometry_on_device(device, tuple(self._n_list))
+            from .host_util import upload
+            self._q_img_dev = upload(self._q_img.astype(np.int32), device)
+        else:
+            self._q_img = np.arange(len(self._img_n_list), dtype=np.int64)
+            self._n_list, self._n_obj, self._ident, self._q_img_dev = self._img_n_list, self._img_n_obj, img_ident, img_ident
         self._batch_size = len(self._n_list)
         self._NS = _pad4(max(self._n_list))
-        n = np.asarray(self._n_list, np.int64)
-        self._n_obj, self._obj_off, self._pair_off, self._ident = _geometry_on_device(device, tuple(self._n_list))
-        self._pair_num = int((n * (n - 1)).sum())
         self._zeros = None
+
+    def pred_img(self, pred_q):
+        """Predicate -> scene map for the oracle kernels (int32 on the device) from a predicate -> question map."""
+        if not self._shared:
+            return pred_q
+        if pred_q is self._ident:
+            return self._q_img_dev
+        return self._q_img_dev.index_select(0, pred_q)
 
     # The reference's cached tables ([O, 2335] and [pairs, 333]).  In needed-columns mode they are materialised
     # only if somebody actually reads them (API compatibility); the interpreter itself never does.
@@ -143,11 +168,11 @@ class BatchWorld(object):
     def pair_index(self):
         """(subject row, object row) of every ordered same-image pair, in the reference's order (util.py:87-103)."""
         if getattr(self, "_pair_idx", None) is None:
-            key = (str(self._device), tuple(self._n_list))
+            key = (str(self._device), tuple(self._img_n_list))
             hit = _pair_index_cache.get(key)
             if hit is None:
                 s_all, o_all, first = [], [], 0
-                for n in self._n_list:
+                for n in self._img_n_list:
                     s, o = np.nonzero(~np.eye(n, dtype=bool))
                     s_all.append(s + first)
                     o_all.append(o + first)

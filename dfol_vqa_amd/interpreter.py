@@ -137,12 +137,12 @@ class BatchInterpreterBase(nn.Module):
     def load(self, import_path_base):                          # :42-43
         self.load_state_dict(torch.load(os.path.join(import_path_base, self._name)), strict=False)
 
-    def build_scene(self, device, object_features, batch_index, meta_data, object_nums=None):
-        """batch_base_interpreter.py:45-70: featurizer + oracle MLPs -> cached likelihood tables -> BatchWorld."""
+    def build_scene(self, device, object_features, batch_index, meta_data, object_nums=None, question_image=None):
+        """batch_base_interpreter.py:45-70: featurizer + oracle MLPs -> cached likelihood tables -> BatchWorld.
+        `question_image` (ProgramBatch._question_image; None = one scene per question, the reference's layout): the object rows hold
+        every distinct scene once and question k looks at scene question_image[k]."""
         if self._featurizer is None:
             raise NotImplementedError("a featurizer is required (the reference's featurizer-less branch :62-67 is dead code)")
-        geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
-                              attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums)
         # needed-columns mode: no pair matrix, no full tables; the oracle keeps hidden activations and evaluates the concept
         # columns a program names.  The fused kernels are forward-only: they run whenever no gradient has to reach the oracle's
         # or the featurizer's weights (inference, and the calibrator-only phases cur6-7 where both are frozen); when those
@@ -151,6 +151,21 @@ class BatchInterpreterBase(nn.Module):
                                                         if isinstance(m, nn.Module) for p in m.parameters())
         needed = self._cached and isinstance(self._featurizer, BatchGQABoxFeaturizer) and \
             getattr(self._oracle, "supports_needed_columns", lambda: False)()
+        if question_image is not None and (not needed or oracle_trains or (self._has_modulator and torch.is_grad_enabled())):
+            # shared scenes are served by the needed-columns inference dataflow; the other dataflows (full cached tables, training)
+            # take the reference's layout: one copy of its scene per question
+            if object_nums is None:
+                bi = batch_index if isinstance(batch_index, torch.Tensor) else torch.as_tensor(batch_index)
+                object_nums = torch.bincount(bi.to(torch.int64).cpu()).tolist()
+            off = np.concatenate([[0], np.cumsum(object_nums)])
+            rows = np.concatenate([np.arange(off[i], off[i + 1]) for i in question_image]) if len(question_image) else np.zeros(0, np.int64)
+            object_features = object_features.index_select(0, torch.as_tensor(rows, dtype=torch.int64).to(object_features.device))
+            object_nums = [int(object_nums[i]) for i in question_image]
+            batch_index = torch.as_tensor(np.repeat(np.arange(len(object_nums)), object_nums).astype(np.int64)).to(object_features.device)
+            question_image = None
+        geometry = BatchWorld(device, object_features.size(0), None, None, batch_index, meta_data,
+                              attention_transfer_state_dim=self._attention_transfer_state_dim, object_nums=object_nums,
+                              question_image=question_image)
         if needed:
             features = self._featurizer.featurize_scene(device, object_features, batch_index, meta_data, world_geometry=None)
             self._oracle.prepare_scene(geometry, features['attribute_features'], train=oracle_trains)
@@ -195,7 +210,8 @@ class BatchInterpreterBase(nn.Module):
         device = program_batch_list[0].device
         for program_batch in program_batch_list:
             world = self.build_scene(program_batch.device, program_batch._object_features, program_batch._object_batch_index,
-                                     program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None))
+                                     program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None),
+                                     question_image=getattr(program_batch, "_question_image", None))
             if self._has_modulator and modulator_switch:
                 self._calibration_passes(world, program_batch, device, is_training)
             if world._lazy is not None:

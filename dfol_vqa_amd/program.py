@@ -131,7 +131,11 @@ class ProgramBatch(object):
     """A batch of aligned programs plus its scenes (data_pipeline.py:147-290)."""
 
     def __init__(self, device, op_batch_list, dependencies, answers, object_features, object_batch_index=None, original_dicts=None,
-                 meta_data=None, object_nums=None):
+                 meta_data=None, object_nums=None, question_image=None):
+        # `question_image` (an extension of this build; None = the reference's layout): question k looks at scene question_image[k] of
+        # this batch - `object_features` / `object_batch_index` then hold every DISTINCT image once instead of one copy per question
+        # (ProgramCollaterBase(share_scenes=True); GQA testdev-balanced asks ~30 questions per image)
+        self._question_image = None if question_image is None else [int(i) for i in question_image]
         self._op_batch_list = op_batch_list
         self._object_features = object_features
         self._dependencies = dependencies
@@ -174,7 +178,7 @@ class ProgramBatch(object):
             return obj
         pb = ProgramBatch(device, [ob.to_cuda(device, non_blocking) for ob in self._op_batch_list], self._dependencies, self._answers,
                           move(self._object_features), move(self._object_batch_index), self._original_dicts, move(self._meta_data),
-                          object_nums=self._object_nums)
+                          object_nums=self._object_nums, question_image=self._question_image)
         return pb
 
     def to(self, dtype):
@@ -213,12 +217,16 @@ class ProgramCollaterBase(object):
     """Aligns ragged per-question programs into one canonical operator sequence (data_pipeline.py:626-783):
     per branch `starter, (filler*, separator)*`, then one terminal operator batch per terminal operator name."""
 
-    def __init__(self, starter_op, sep_op, filler_op, split_num=1, ontology=None):
+    def __init__(self, starter_op, sep_op, filler_op, split_num=1, ontology=None, share_scenes=False):
         self._sep_op = sep_op
         self._filler_op = filler_op
         self._starter_op = starter_op
         self._split_num = split_num
         self._ontology = ontology
+        # share_scenes: questions of a ProgramBatch that name the same `image_id` share ONE copy of its object features (and, in the
+        # interpreter, one featurizer pass and one set of relation tiles per (image, concept)).  The reference collates one copy per
+        # question (batch_gqa_boxfeatures_pipeline.py:37-73); results are identical either way (tests/test_interpreter_gpu.py).
+        self._share_scenes = share_scenes
 
     def collate_programs(self, questions):
         B = len(questions)
@@ -290,9 +298,20 @@ class ProgramCollaterBase(object):
             if not chunk:
                 break
             ops, deps = self.collate_programs(chunk)
-            object_features, object_batch_index = self.collate_object_features(chunk)
+            question_image = None
+            if self._share_scenes:
+                first, question_image = {}, []
+                for q in chunk:
+                    question_image.append(first.setdefault(q['image_id'], len(first)))
+                reps = [None] * len(first)
+                for q, i in zip(chunk, question_image):
+                    if reps[i] is None:
+                        reps[i] = q
+                object_features, object_batch_index = self.collate_object_features(reps)      # one representative question per image
+            else:
+                object_features, object_batch_index = self.collate_object_features(chunk)
             pb = ProgramBatch(device, ops, deps, [q['answer'] for q in chunk], object_features, object_batch_index,
-                              [q.get('original_dict') for q in chunk], meta_data=self.collate_meta_data(chunk))
+                              [q.get('original_dict') for q in chunk], meta_data=self.collate_meta_data(chunk), question_image=question_image)
             for ob in pb._op_batch_list:
                 ob._op_id = str(i) + ':' + ob._op_id            # :775-777
             if self._ontology is not None:

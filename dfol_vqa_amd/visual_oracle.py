@@ -609,6 +609,9 @@ class ClassifierOracle(OracleBase):
 
     def materialize_tables(self, world):
         """Full cached tables exactly as the reference builds them (only when a caller reads them)."""
+        if getattr(world, "_shared", False):
+            raise L.DfolError("the full cached tables of a shared-scene batch are not built (they are per question in the reference's layout): "
+                              "collate with share_scenes=False to read world._attribute_features / _relation_features")
         lazy, world._lazy = world._lazy, None
         try:
             pair = None
@@ -635,13 +638,13 @@ class ClassifierOracle(OracleBase):
         rc, rt = up(req_col), up(req_tile)
         ro = None if req_orient is None else up(req_orient)
         if isinstance(packed, tuple):
-            L.pair_ll_split(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._n_obj,
+            L.pair_ll_split(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._img_n_obj,
                             world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
         elif packed is not None:
-            L.pair_ll_packed(world._uv, hid1, world._obj[:, D - 4:], wg, packed, b2, hid2, emb.weight, emb.bias, world._n_obj,
+            L.pair_ll_packed(world._uv, hid1, world._obj[:, D - 4:], wg, packed, b2, hid2, emb.weight, emb.bias, world._img_n_obj,
                              world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
         else:
-            L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, w2p, b2, emb.weight, emb.bias, world._n_obj,
+            L.pair_ll(world._uv, hid1, world._obj[:, D - 4:], wg, w2p, b2, emb.weight, emb.bias, world._img_n_obj,
                       world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0, hid2=hid2)
 
     def _new_tiles(self, world, count, dtype=torch.float32):
@@ -684,6 +687,8 @@ class ClassifierOracle(OracleBase):
         # bf16 storage only when every consumer is the fused single-posterior kernel (relate / verify_rel), which reads it directly
         bf16 = self._tile_dtype == torch.bfloat16 and world._NS % 8 == 0 and self._padded_second_layer()[3] is not None and \
             self._padded_second_layer()[2] > 256 and all(ob._op_name != "choose_rel" for ob in program_batch._op_batch_list)
+        if world._shared:
+            return self._prefetch_relations_shared(world, program_batch, entries, torch.bfloat16 if bf16 else torch.float32, fused)
         tiles = self._new_tiles(world, total, torch.bfloat16 if bf16 else torch.float32)
         # the request arrays depend on the program batch only: build and upload them once per batch (a pageable upload
         # synchronises the stream), keyed by what else they depend on
@@ -724,6 +729,48 @@ class ClassifierOracle(OracleBase):
             base += P
         self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
 
+    def _shared_requests(self, world, items):
+        """Shared scenes: the distinct (scene, relation column, orientation) triples among `items` = [(full columns, predicate ->
+        question, orientation)], as pair-kernel request arrays [K', scenes] over the IMAGE-level geometry, plus, per item, the index of
+        every predicate's tile among the distinct ones (`U` = the extra all-absent tile for no-op tokens)."""
+        n_img = len(world._img_n_list)
+        uniq, per_item = {}, []
+        for full, pq, orient in items:
+            idx = np.empty(len(pq), np.int64)
+            for p in range(len(pq)):
+                idx[p] = -1 if full[p] < 0 else uniq.setdefault((int(world._q_img[pq[p]]), int(full[p]), int(orient[p])), len(uniq))
+            per_item.append(idx)
+        U = len(uniq)
+        slot_of, keys = np.zeros(n_img, np.int64), sorted(uniq, key=uniq.get)
+        slots = np.empty(U, np.int64)
+        for u, (img, _, _) in enumerate(keys):
+            slots[u] = slot_of[img]
+            slot_of[img] += 1
+        K = int(slot_of.max()) if U else 1
+        col, til, ori = np.full((K, n_img), -1, np.int32), np.zeros((K, n_img), np.int32), np.zeros((K, n_img), np.uint8)
+        for u, (img, c, o) in enumerate(keys):
+            col[slots[u], img], til[slots[u], img], ori[slots[u], img] = c, u, o
+        return U, col, til, ori, [np.where(i < 0, U, i) for i in per_item]
+
+    def _prefetch_relations_shared(self, world, program_batch, entries, dtype, fused):
+        """prefetch_relations for a batch whose questions share scenes: one tile per distinct (scene, concept, orientation) from the pair
+        kernel, then every operator's per-predicate tiles are row gathers of those (40 KB per predicate, against 0.16 MFLOP per object
+        pair for computing a tile again)."""
+        dev = world._device
+        key = (id(self), str(dev), world._q_img.tobytes(), tuple((e[0].cols.tobytes(), np.asarray(e[1]).tobytes(), e[2].tobytes()) for e in entries))
+        plan = getattr(program_batch, "_dfol_rel_plan", None)
+        if plan is None or plan[0] != key:
+            U, col, til, ori, maps = self._shared_requests(world, [(self._relation_full_columns(e[0].cols), np.asarray(e[1], np.int64), e[2]) for e in entries])
+            up = lambda a: torch.as_tensor(a).to(dev)
+            plan = (key, U, up(col), up(til), up(ori), [up(m) for m in maps])
+            program_batch._dfol_rel_plan = plan
+        _, U, req_col, req_tile, req_orient, maps = plan
+        tiles = torch.full((U + 1, world._NS, world._NS), -30.0, dtype=dtype, device=dev)      # tile U: all absent (no-op tokens)
+        if U:
+            self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
+        for (low, pq, orient), m in zip(entries, maps):
+            world._rel_tiles[id(low)] = (tiles.index_select(0, m), orient, fused)
+
     def prefetch_attributes(self, world, program_batch):
         """One attribute-column launch for the simple attribute token lists of the program batch (select names, filter attributes,
         relate's object names: one token per question) instead of one per operator; the operators pick their block up by the identity
@@ -748,8 +795,8 @@ class ClassifierOracle(OracleBase):
         dev = world._device
         emb = self._embedding_network.linear
         cols = upload(np.concatenate([low.cols for low in lows]), dev)
-        pred_q = upload(np.tile(np.arange(Q, dtype=np.int32), len(lows)), dev)
-        ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
+        pred_img = upload(np.tile(world._q_img.astype(np.int32), len(lows)), dev)          # predicate -> scene (= question without sharing)
+        ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_img, cols, world._NS, -30.0)
         world._attr_blocks = {id(low): ll[i * Q:(i + 1) * Q] for i, low in enumerate(lows)}
 
     def oriented_tiles(self, world, low):
@@ -761,6 +808,12 @@ class ClassifierOracle(OracleBase):
         """Relation tiles for one token list outside the prefetch (e.g. choose_rel's flattened option list)."""
         pq = np.asarray(list(pred_q_host), np.int64)
         P, Q = len(pq), world._batch_size
+        if world._shared:
+            U, col, til, ori, maps = self._shared_requests(world, [(self._relation_full_columns(low.cols), pq, np.zeros(P, np.uint8))])
+            tiles = torch.full((U + 1, world._NS, world._NS), -30.0, dtype=torch.float32, device=world._device)
+            if U:
+                self._launch_pairs(world, col, til, tiles, ori)
+            return tiles.index_select(0, upload(maps[0], world._device))
         slot = np.zeros(P, np.int64)                      # j-th predicate of its question
         seen = {}
         for p, q in enumerate(pq):
@@ -825,7 +878,7 @@ class ClassifierOracle(OracleBase):
         elif token_type == TokenType.ATTRIBUTE:
             ll = getattr(world, "_attr_blocks", {}).get(id(low)) if pred_q is world._ident else None      # prefetch_attributes
             if ll is None:
-                ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_q, cols, world._NS, -30.0)
+                ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, world.pred_img(pred_q), cols, world._NS, -30.0)
         else:
             assert orientation == L.TILE_SUBJECT_ROWS
             hit = world._rel_tiles.get(id(low))

@@ -31,8 +31,8 @@ class TableFeaturizer(object):
 
 
 class TableCollater(D.ProgramCollaterBase):
-    def __init__(self, split_num=1, ontology=None, key="A"):
-        super(TableCollater, self).__init__("select", "relate", "filter", split_num, ontology=ontology)
+    def __init__(self, split_num=1, ontology=None, key="A", share_scenes=False):
+        super(TableCollater, self).__init__("select", "relate", "filter", split_num, ontology=ontology, share_scenes=share_scenes)
         self._key = key
 
     def collate_object_features(self, questions):
@@ -1355,3 +1355,49 @@ def test_all_ops_full_size_model_ragged_60_to_100(full_size, kind):
             decided = list(np.abs(np.exp(lp64) - 0.5) > 4 * np.abs(np.exp(lp32) - np.exp(lp64)) + 1e-5)
         diff = [i for i, (x, y) in enumerate(zip(res["answer"], r64["answer"])) if x != y and decided[i]]
         assert not diff, (kind, diff)
+
+
+# ---------------------------------------------------------------------------------------------------
+# shared scenes: questions on the same image share one featurizer pass and one set of relation tiles
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "choose_attr"])
+def test_shared_scenes_equal_per_question_scenes(tmp_path, kind):
+    """32 questions on 4 images (GQA asks ~30 questions per image; the reference collates one copy of the scene per question,
+    batch_gqa_boxfeatures_pipeline.py:37-73): with share_scenes the batch carries every image once, the featurizer and the oracle's
+    hidden layers run once per image and the pair kernel computes one tile per distinct (image, relation, orientation) - and the
+    results equal the per-question run BIT FOR BIT, eager and as a replayed graph, also split over two ProgramBatches."""
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd.interpreter import GraphedForward
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(9)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    qs, _ = _neural_questions(kind, 32, 5, 5, 2048, seed=41, names=nm)
+    images = [syn.feature_scene(9000 + i, n, 2048) for i, n in enumerate((17, 40, 9, 28))]
+    rng = np.random.RandomState(5)
+    pick = rng.randint(0, 4, size=32)
+    for q, i in zip(qs, pick):
+        q["image_id"], q["scene"] = "img%d" % i, images[i]
+    for split in (1, 2):
+        per_q = [pb.to_cuda(DEV) for pb in TableCollater(split, ont, "X").collate(qs)]
+        shared = [pb.to_cuda(DEV) for pb in TableCollater(split, ont, "X", share_scenes=True).collate(qs)]
+        assert sum(pb._object_features.shape[0] for pb in shared) < sum(pb._object_features.shape[0] for pb in per_q) / 3
+        with torch.no_grad():
+            a, b = model(per_q, False), model(shared, False)
+        assert torch.equal(a["log_probability"], b["log_probability"]), (a["log_probability"] - b["log_probability"]).abs().max()
+        assert a["answer"] == b["answer"]
+    g = GraphedForward(model, shared)
+    c = g()
+    assert torch.equal(c["log_probability"], b["log_probability"]) and c["answer"] == b["answer"]
+    # the dataflows that do not share (full cached tables; training) expand to one scene per question and still agree
+    model._oracle._needed_columns = False
+    with torch.no_grad():
+        d = model(shared, False)
+    model._oracle._needed_columns = True
+    assert np.abs(np.exp(d["log_probability"].cpu().numpy()) - np.exp(a["log_probability"].cpu().numpy())).max() <= 2e-5

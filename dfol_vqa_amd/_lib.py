@@ -100,6 +100,9 @@ SIGNATURES = {
     "dfol_modulate_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_lstm_cell_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_lstm_pointwise_f32": [_p, _p, _p, _i32, _i32, _p, _p, _p],
+    "dfol_lstm_cell_train_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p],
+    "dfol_lstm_cell_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
+    "dfol_modulate_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_attr_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i32, _i32, _f, _p, _p],
     "dfol_pair_ll_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32,
                          _i32, _f, _p, _p],
@@ -566,6 +569,36 @@ def lstm_cell(x, h, c, w_ih_t, w_hh_t, b_ih, b_hh):
          w_ih_t.stride(0), _ptr(w_hh_t, F32), w_hh_t.stride(0), _ptr(b_ih, F32, True), _ptr(b_hh, F32, True), rows, H, _ptr(hy), _ptr(cy),
          _stream())
     return hy, cy
+
+
+def lstm_cell_train(x, h, c, w_ih_t, w_hh_t, b_ih, b_hh):
+    """lstm_cell that also returns the activated gates [rows, 4H] for lstm_cell_bwd."""
+    rows, H = c.shape
+    hy, cy = torch.empty_like(c), torch.empty_like(c)
+    gates = torch.empty(rows, 4 * H, dtype=F32, device=c.device)
+    call("dfol_lstm_cell_train_f32", _dp(x), x.stride(0), x.shape[1], _dp(h), h.stride(0), _ptr(c, F32), _ptr(w_ih_t, F32),
+         w_ih_t.stride(0), _ptr(w_hh_t, F32), w_hh_t.stride(0), _ptr(b_ih, F32, True), _ptr(b_hh, F32, True), rows, H, _ptr(hy), _ptr(cy),
+         _ptr(gates), _stream())
+    return hy, cy, gates
+
+
+def lstm_cell_bwd(gates, c_prev, c_new, d_hy, d_cy):
+    """-> (d_gates [rows, 4H] w.r.t. the pre-activation gates, d_c_prev [rows, H]); d_hy or d_cy may be None."""
+    rows, H = c_prev.shape
+    dg = torch.empty(rows, 4 * H, dtype=F32, device=c_prev.device)
+    dc = torch.empty(rows, H, dtype=F32, device=c_prev.device)
+    call("dfol_lstm_cell_bwd_f32", _ptr(gates, F32), _ptr(c_prev, F32), _ptr(c_new, F32), _ptr(d_hy, F32, True), _ptr(d_cy, F32, True), rows, H,
+         _ptr(dg), _ptr(dc), _stream())
+    return dg, dc
+
+
+def modulate_bwd(g_out, att, mods, pred_q, n_obj):
+    P, NS = att.shape
+    g_att = torch.empty_like(att)
+    g_mods = torch.empty(P, 4, dtype=F32, device=att.device)
+    call("dfol_modulate_bwd_f32", _ptr(g_out, F32), _ptr(att, F32), _ptr(mods, F32), _ptr(pred_q, I32), _ptr(n_obj, I32), P, NS, _ptr(g_att),
+         _ptr(g_mods), _stream())
+    return g_att, g_mods
 
 
 def box_positions(raw, obj, pos_col):

@@ -1486,6 +1486,55 @@ extern "C" int dfol_modulate_f32(const float* att, const float* mods, const int3
     return 0;
 }
 
+// Backward of apply_modulations (one wavefront per predicate): with S = e^u + e^t, r = t - log(max(S, eps)),
+//   dr/dt = 1 - [S > eps] e^t / S,  dr/du = -[S > eps] e^u / S,  dt/da = alpha,  du/da = beta D(a)  (D = d log_not, 0 where its clamp is active)
+//   g_att = g (dr/dt alpha + dr/du beta D(a));  g_mods[p] = (10 sum g dr/dt a, 10 sum g dr/du log_not(a), 10 sum g dr/dt [c > eps] / c,
+//                                                            sum g (dr/dt [d > eps] / d - dr/du [1 - d > eps] / (1 - d)))
+// sums over the predicate's objects in lane order, then across lanes: no atomics, repeatable bit for bit.
+__global__ __launch_bounds__(64) void modulate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ att, const float* __restrict__ mods,
+                                                          const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, int NS,
+                                                          float* __restrict__ g_att, float* __restrict__ g_mods) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = n_obj[pred_q[p]];
+    const float alpha = mods[4 * p + 0] * 10.f, beta = mods[4 * p + 1] * 10.f, cc = mods[4 * p + 2] * 10.f, d = mods[4 * p + 3];
+    const float lc = logf(fmaxf(cc, DFOL_EPS)), ld = logf(fmaxf(d, DFOL_EPS)), l1d = logf(fmaxf(1.f - d, DFOL_EPS));
+    const float dc = cc > DFOL_EPS ? 1.f / cc : 0.f, dd = d > DFOL_EPS ? 1.f / d : 0.f, d1d = (1.f - d) > DFOL_EPS ? 1.f / (1.f - d) : 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int c = lane; c < NS; c += 64) {
+        const int64_t i = (int64_t)p * NS + c;
+        float ga = 0.f;
+        if (c < n) {
+            const float a = att[i], g = g_out[i];
+            const float ea = expf(a), om = 1.f - ea;
+            const float na = logf(fmaxf(om, DFOL_EPS)), Da = om > DFOL_EPS ? -ea / om : 0.f;
+            const float t = alpha * a + lc + ld, u = beta * na + l1d;
+            const float et = expf(t), eu = expf(u), S = et + eu;
+            const float inv = S > DFOL_EPS ? 1.f / S : 0.f;
+            const float rt = 1.f - et * inv, ru = -eu * inv;
+            ga = g * (rt * alpha + ru * beta * Da);
+            s0 += g * rt * a;
+            s1 += g * ru * na;
+            s2 += g * rt * dc;
+            s3 += g * (rt * dd - ru * d1d);
+        }
+        g_att[i] = ga;
+    }
+    s0 = dfol_wave_sum(s0), s1 = dfol_wave_sum(s1), s2 = dfol_wave_sum(s2), s3 = dfol_wave_sum(s3);
+    if (lane == 0) {
+        g_mods[4 * p + 0] = 10.f * s0, g_mods[4 * p + 1] = 10.f * s1, g_mods[4 * p + 2] = 10.f * s2, g_mods[4 * p + 3] = s3;
+    }
+}
+
+extern "C" int dfol_modulate_bwd_f32(const float* g_out, const float* att, const float* mods, const int32_t* pred_q, const int32_t* n_obj,
+                                     int32_t P, int32_t NS, float* g_att, float* g_mods, void* stream) {
+    DFOL_REQUIRE(P >= 0 && NS > 0, "modulate_bwd: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE(g_out && att && mods && pred_q && n_obj && g_att && g_mods, "modulate_bwd: null pointer");
+    hipLaunchKernelGGL(modulate_bwd_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, g_out, att, mods, pred_q, n_obj, NS, g_att, g_mods);
+    DFOL_LAUNCH_CHECK("modulate_bwd");
+    return 0;
+}
+
 // =====================================================================================================
 // LSTM cell pointwise stage of the attention-calibration passes (batch_base_interpreter.py:87-140 run nn.LSTMCell(318 -> 50) once
 // per operator and direction): gates = x W_ih^T + b_ih + h W_hh^T + b_hh come from two dfol_linear_act_f32 launches, this kernel
@@ -1513,7 +1562,7 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
                                                         int64_t ld_h, const float* __restrict__ c, const float* __restrict__ Wih,
                                                         int64_t ld_wih, const float* __restrict__ Whh, int64_t ld_whh,
                                                         const float* __restrict__ bih, const float* __restrict__ bhh, int rows, int H,
-                                                        float* __restrict__ hy, float* __restrict__ cy) {
+                                                        float* __restrict__ hy, float* __restrict__ cy, float* __restrict__ gates_out) {
     extern __shared__ float lc_s[];                          // [LC_ROWS][KX + H] inputs, then [LC_ROWS][4H] gates
     const int r0 = blockIdx.x * LC_ROWS, K = KX + H, tid = threadIdx.x;
     float* in_s = lc_s;
@@ -1555,9 +1604,14 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
         const float* gs = gate_s + r * 4 * H;
         const float gi = gs[j], gf = gs[H + j], gg = gs[2 * H + j], go = gs[3 * H + j];
         const float si = 1.0f / (1.0f + expf(-gi)), sf = 1.0f / (1.0f + expf(-gf)), so = 1.0f / (1.0f + expf(-go));
-        const float cn = sf * c[(int64_t)row * H + j] + si * tanhf(gg);
+        const float tg = tanhf(gg);
+        const float cn = sf * c[(int64_t)row * H + j] + si * tg;
         cy[(int64_t)row * H + j] = cn;
         hy[(int64_t)row * H + j] = so * tanhf(cn);
+        if (gates_out) {                                     // training: the activated gates (i, f, g, o) for dfol_lstm_cell_bwd_f32
+            float* go_ = gates_out + (int64_t)row * 4 * H;
+            go_[j] = si, go_[H + j] = sf, go_[2 * H + j] = tg, go_[3 * H + j] = so;
+        }
     }
 }
 
@@ -1570,8 +1624,55 @@ extern "C" int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, cons
     if (rows == 0) return 0;
     DFOL_REQUIRE(x && h && c && Wih && Whh && h_out && c_out, "lstm_cell: null pointer");
     hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(256), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
-                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out);
+                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, (float*)nullptr);
     DFOL_LAUNCH_CHECK("lstm_cell");
+    return 0;
+}
+
+extern "C" int dfol_lstm_cell_train_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
+                                        int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows,
+                                        int32_t H, float* h_out, float* c_out, float* gates, void* stream) {
+    DFOL_REQUIRE(rows >= 0 && H > 0 && KX > 0, "lstm_cell_train: bad sizes rows=%d H=%d KX=%d", rows, H, KX);
+    const size_t lds = sizeof(float) * LC_ROWS * ((size_t)KX + H + 4 * (size_t)H);
+    DFOL_REQUIRE(lds <= 64 * 1024, "lstm_cell_train: input width %d + hidden %d too large for the staging buffer", KX, H);
+    if (rows == 0) return 0;
+    DFOL_REQUIRE(x && h && c && Wih && Whh && h_out && c_out && gates, "lstm_cell_train: null pointer");
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(256), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
+                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, gates);
+    DFOL_LAUNCH_CHECK("lstm_cell_train");
+    return 0;
+}
+
+// Backward of the cell's pointwise stage (torch's lstm_cell_backward): from the activated gates (i, f, g, o), the old and new cell state
+// and the gradients of h' and c' to the gradient of the PRE-activation gates [rows, 4H] (i, f, g, o order) and of the old cell state.
+// The four products with the weights (dx, dh, dW_ih, dW_hh, db) are dfol_linear_act_f32 / dfol_linear_wgrad_bias_f32 calls on d_gates.
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ c_new,
+                                     const float* __restrict__ d_hy, const float* __restrict__ d_cy, int rows, int H,
+                                     float* __restrict__ d_gates, float* __restrict__ d_c_prev) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int r = idx / H, j = idx - r * H;
+    const float* g = gates + (int64_t)r * 4 * H;
+    const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+    const float tc = tanhf(c_new[idx]);
+    const float dh = d_hy ? d_hy[idx] : 0.f;
+    const float dct = (d_cy ? d_cy[idx] : 0.f) + dh * go * (1.f - tc * tc);
+    float* dg = d_gates + (int64_t)r * 4 * H;
+    dg[j] = dct * gg * gi * (1.f - gi);
+    dg[H + j] = dct * c_prev[idx] * gf * (1.f - gf);
+    dg[2 * H + j] = dct * gi * (1.f - gg * gg);
+    dg[3 * H + j] = dh * tc * go * (1.f - go);
+    d_c_prev[idx] = dct * gf;
+}
+
+extern "C" int dfol_lstm_cell_bwd_f32(const float* gates, const float* c_prev, const float* c_new, const float* d_hy, const float* d_cy,
+                                      int32_t rows, int32_t H, float* d_gates, float* d_c_prev, void* stream) {
+    DFOL_REQUIRE(rows >= 0 && H > 0, "lstm_cell_bwd: bad sizes rows=%d H=%d", rows, H);
+    if (rows == 0) return 0;
+    DFOL_REQUIRE(gates && c_prev && c_new && d_gates && d_c_prev && (d_hy || d_cy), "lstm_cell_bwd: null pointer");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(dfol_cdiv((int64_t)rows * H, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_prev, c_new,
+                       d_hy, d_cy, rows, H, d_gates, d_c_prev);
+    DFOL_LAUNCH_CHECK("lstm_cell_bwd");
     return 0;
 }
 

@@ -367,12 +367,15 @@ class _Modulate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         att, mods, pred_q, n_obj = ctx.saved_tensors
-        valid = torch.arange(att.shape[1], device=att.device).unsqueeze(0) < n_obj.to(torch.int64)[pred_q.to(torch.int64)].unsqueeze(1)
-        with torch.enable_grad():
-            a = att.detach().requires_grad_(True)
-            m = mods.detach().requires_grad_(True)
-            out = _modulate_reference(a, m, valid)
-            ga, gm = torch.autograd.grad(out, (a, m), g, allow_unused=True)
+        if os.environ.get("DFOL_MODULATE_BWD", "hip") == "torch":      # A/B: autograd through the tensor-op restatement (~70 launches)
+            valid = torch.arange(att.shape[1], device=att.device).unsqueeze(0) < n_obj.to(torch.int64)[pred_q.to(torch.int64)].unsqueeze(1)
+            with torch.enable_grad():
+                a = att.detach().requires_grad_(True)
+                m = mods.detach().requires_grad_(True)
+                out = _modulate_reference(a, m, valid)
+                ga, gm = torch.autograd.grad(out, (a, m), g, allow_unused=True)
+            return ga, gm, None, None
+        ga, gm = _lib.modulate_bwd(g.contiguous(), att.contiguous(), mods.contiguous(), pred_q, n_obj)      # one launch, deterministic
         return ga, gm, None, None
 
 

@@ -128,23 +128,65 @@ class OracleBase(nn.Module):
             return torch.from_numpy(self._ontology.get_embeddings(tokens)).float().to(device)
 
 
+class _LSTMCellFn(torch.autograd.Function):
+    """nn.LSTMCell with the forward in ONE launch (dfol_lstm_cell_train_f32, which keeps the activated gates) and the backward on this
+    library's kernels: dfol_lstm_cell_bwd_f32 (the pointwise stage), then the four products of d_gates with the weights / inputs on the
+    dense and the TN weight-gradient kernels (deterministic).  Trains the attention calibrator (cur6-7)."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh, w_ih_t, w_hh_t):
+        hy, cy, gates = L.lstm_cell_train(x, h, c, w_ih_t, w_hh_t, None if b_ih is None else b_ih.detach(), None if b_hh is None else b_hh.detach())
+        ctx.save_for_backward(x, h, c, cy, gates, w_ih_t, w_hh_t)
+        ctx.has_bias = b_ih is not None
+        return hy, cy
+
+    @staticmethod
+    def backward(ctx, d_hy, d_cy):
+        x, h, c, cy, gates, w_ih_t, w_hh_t = ctx.saved_tensors
+        dg, dc = L.lstm_cell_bwd(gates, c, cy, None if d_hy is None else d_hy.contiguous(), None if d_cy is None else d_cy.contiguous())
+        need = ctx.needs_input_grad
+        dx = L.linear_act(dg, w_ih_t, None, L.ACT_NONE) if need[0] else None            # d_gates @ W_ih   (w_ih_t = W_ih^T, so w_ih_t^T = W_ih)
+        dh = L.linear_act(dg, w_hh_t, None, L.ACT_NONE) if need[1] else None
+        dwi = dwh = db = None
+        if need[3]:
+            dwi = _lib.linear_wgrad(dg, x if x.stride(-1) == 1 else x.contiguous(), bias=ctx.has_bias)
+            if ctx.has_bias:
+                dwi, db = dwi
+        if need[4]:
+            dwh = _lib.linear_wgrad(dg, h if h.stride(-1) == 1 else h.contiguous())
+        if ctx.has_bias and db is None and (need[5] or need[6]):
+            db = dg.sum(0)
+        return dx, dh, (dc if need[2] else None), dwi, dwh, (db if need[5] else None), (db if need[6] else None), None, None
+
+
 class CalibrationLSTMCell(nn.LSTMCell):
-    """nn.LSTMCell (same parameters and state_dict names) whose inference forward is ONE launch (dfol_lstm_cell_f32: both gate
-    products, the biases and the pointwise stage; the two small GEMMs [Q, 318] x [318, 200], [Q, 50] x [50, 200] take 54 us each in
-    the vendor BLAS and 15 us each as two launches of the dense kernel, and a calibrated forward runs eight cells).  With gradients
-    enabled it is torch's own cell."""
+    """nn.LSTMCell (same parameters and state_dict names) whose forward is ONE launch (dfol_lstm_cell_f32: both gate products, the
+    biases and the pointwise stage; the two small GEMMs [Q, 318] x [318, 200], [Q, 50] x [50, 200] take 54 us each in the vendor BLAS
+    and 15 us each as two launches of the dense kernel, and a calibrated forward runs eight cells).  With gradients enabled the same
+    launch keeps the activated gates and the backward runs on this library's kernels (_LSTMCellFn; DFOL_LSTM_BWD=torch: torch's own
+    cell, for A/B runs)."""
+
+    def _transposed(self):
+        key = (self.weight_ih._version, self.weight_hh._version, self.weight_ih.data_ptr(), self.weight_hh.data_ptr())
+        if getattr(self, "_wt", (None,))[0] != key:              # transposed copies, once per weight version
+            self._wt = (key, self.weight_ih.detach().t().contiguous(), self.weight_hh.detach().t().contiguous())
+        return L.keep_alive(self._wt)
 
     def forward(self, x, state=None):
-        if state is None or not x.is_cuda or (torch.is_grad_enabled() and (x.requires_grad or state[0].requires_grad or
-                                                                         any(p.requires_grad for p in self.parameters()))):
+        fits = state is not None and x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1 and state[0].stride(-1) == 1 and \
+            4 * (x.shape[1] + 5 * state[0].shape[1]) * 4 <= 65536
+        grads = torch.is_grad_enabled() and (x.requires_grad or (state is not None and (state[0].requires_grad or state[1].requires_grad)) or
+                                             any(p.requires_grad for p in self.parameters()))
+        if grads and fits and os.environ.get("DFOL_LSTM_BWD", "hip") != "torch":
+            wt = self._transposed()
+            h, c = state
+            return _LSTMCellFn.apply(x, h.contiguous(), c.contiguous(), self.weight_ih, self.weight_hh, self.bias_ih, self.bias_hh, wt[1], wt[2])
+        if state is None or not x.is_cuda or grads:
             return super(CalibrationLSTMCell, self).forward(x, state)
         h, c = state
-        if x.dtype == torch.float32 and x.stride(-1) == 1 and h.stride(-1) == 1 and 4 * (x.shape[1] + 5 * h.shape[1]) * 4 <= 65536:
-            key = (self.weight_ih._version, self.weight_hh._version, self.weight_ih.data_ptr(), self.weight_hh.data_ptr())
-            if getattr(self, "_wt", (None,))[0] != key:          # transposed copies, once per weight version
-                self._wt = (key, self.weight_ih.detach().t().contiguous(), self.weight_hh.detach().t().contiguous())
-            L.keep_alive(self._wt)
-            return L.lstm_cell(x, h, c.contiguous(), self._wt[1], self._wt[2], self.bias_ih, self.bias_hh)          # one launch
+        if fits:
+            wt = self._transposed()
+            return L.lstm_cell(x, h, c.contiguous(), wt[1], wt[2], self.bias_ih, self.bias_hh)          # one launch
         ig = L.linear_act(x.contiguous(), self.weight_ih, self.bias_ih, L.ACT_NONE)
         hg = L.linear_act(h.contiguous(), self.weight_hh, self.bias_hh, L.ACT_NONE)
         return L.lstm_pointwise(ig, hg, c.contiguous())

@@ -290,6 +290,25 @@ int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, const float* h,
                        int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
                        float* h_out, float* c_out, void* stream);
 
+/* Training of the attention calibrator (the curriculum's cur6-7 phases: oracle frozen, the two LSTM cells and the attention output
+ * layer train; trainer.py:429-442 over batch_base_interpreter.py:87-140).  dfol_lstm_cell_train_f32 is dfol_lstm_cell_f32 that also
+ * stores the ACTIVATED gates [rows, 4H] (sigmoid(i), sigmoid(f), tanh(g), sigmoid(o)); dfol_lstm_cell_bwd_f32 is the backward of the
+ * pointwise stage (torch's lstm_cell_backward): -> d_gates [rows, 4H] w.r.t. the PRE-activation gates and d_c_prev [rows, H]; d_hy / d_cy
+ * may be NULL (no gradient through that output).  The weight / input products of the backward are dfol_linear_act_f32 and
+ * dfol_linear_wgrad_bias_f32 calls on d_gates.
+ */
+int dfol_lstm_cell_train_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
+                             int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
+                             float* h_out, float* c_out, float* gates, void* stream);
+int dfol_lstm_cell_bwd_f32(const float* gates, const float* c_prev, const float* c_new, const float* d_hy, const float* d_cy, int32_t rows,
+                           int32_t H, float* d_gates, float* d_c_prev, void* stream);
+
+/* Backward of dfol_modulate_f32 (apply_modulations, batch_base_types.py:170-179): g_out [P, NS] -> g_att [P, NS] and g_mods [P, 4]
+ * (the sums over a predicate's objects taken by one wavefront in a fixed order: deterministic).
+ */
+int dfol_modulate_bwd_f32(const float* g_out, const float* att, const float* mods, const int32_t* pred_q, const int32_t* n_obj, int32_t P,
+                          int32_t NS, float* g_att, float* g_mods, void* stream);
+
 /* ---- needed-columns oracle (MI355X-first: nothing the program does not ask for is computed) --------
  * The reference evaluates the embedding layer for all 2335 concepts on every object and every ordered
  * object pair (classifier_oracle.py:145-156; 64 % of its CPU time) and then gathers a

@@ -247,6 +247,41 @@ def test_calibrator_phase_train_step(ontology):
     assert losses[-1] < losses[0] and all(np.isfinite(l) for l in losses), losses
 
 
+def test_calibrator_gradients_native_backward_equals_torch_autograd(ontology, monkeypatch):
+    """The calibrator phases' backward on this library's kernels (dfol_lstm_cell_bwd_f32 + dense / TN products, dfol_modulate_bwd_f32)
+    against the same step with torch's own LSTM cell and autograd through the tensor-op restatement of apply_modulations
+    (DFOL_LSTM_BWD=torch, DFOL_MODULATE_BWD=torch): every trainable gradient agrees (batch_base_ops.py:407-467, 598-684;
+    batch_base_interpreter.py:87-140)."""
+    from test_interpreter_gpu import CalibrationCollater
+    a, meta = gu.load("g10_calibration")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    run_meta = meta["runs"]["verify_rel"] if "verify_rel" in meta["runs"] else meta["runs"]["exist"]
+    name = "verify_rel" if "verify_rel" in meta["runs"] else "exist"
+    qs = [{"program": q["program"], "answer": "yes" if i % 2 else "no", "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+           "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}} for i, q in enumerate(run_meta["questions"])]
+    grads = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("DFOL_LSTM_BWD", mode)
+        monkeypatch.setenv("DFOL_MODULATE_BWD", mode)
+        model = neural_model(ontology, meta["config"], weights).train()
+        with torch.no_grad():                                # a non-degenerate attention output layer (the reference initialises it to zero)
+            g = torch.Generator().manual_seed(3)
+            for n_, p_ in model.named_parameters():
+                if p_.requires_grad and p_.dim() == 2 and float(p_.abs().max()) == 0.0:
+                    p_.copy_((torch.randn(p_.shape, generator=g) * 0.05).to(p_.device))
+        pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ontology).collate(qs)]
+        res = model(pbs, True)
+        loss = training.compute_loss(pbs, res) / len(qs)
+        loss.backward()
+        grads[mode] = {n_: p_.grad.detach().clone() for n_, p_ in model.named_parameters() if p_.requires_grad and p_.grad is not None}
+    assert grads["hip"].keys() == grads["torch"].keys() and len(grads["hip"]) >= 6
+    for n_ in grads["hip"]:
+        gh, gt = grads["hip"][n_].double(), grads["torch"][n_].double()
+        scale = gt.abs().max().item()
+        assert scale > 0, n_
+        assert (gh - gt).abs().max().item() <= 2e-4 * scale + 1e-7, (n_, (gh - gt).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("n_list,hid1,hid2", [([7, 1, 13, 2, 30, 5], 64, 50), ([40, 33], 256, 300), ([3, 3, 3], 16, 7), ([100, 12], 256, 300)])
 def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
     """csrc/dfol_pair_train.hip against the tensor-op formulation it replaces (gathers, adds, ELU, Sigmoid, embedding product, row sums

@@ -770,11 +770,70 @@ def test_calibration_lstm_cell_equals_torch(L):
             h4, c4 = mine(wide[:, 40:358], (h, c))
         assert torch.allclose(h1, h3, atol=2e-6, rtol=1e-5) and torch.allclose(c1, c3, atol=2e-6, rtol=1e-5)
         assert torch.equal(h2, h4) and torch.equal(c2, c4)
-    # with gradients it is torch's own cell
-    x = torch.randn(4, 318, device="cuda", requires_grad=True)
-    h2, c2 = mine(x, (torch.zeros(4, 50, device="cuda"), torch.zeros(4, 50, device="cuda")))
-    (h2.sum() + c2.sum()).backward()
-    assert x.grad is not None and mine.weight_ih.grad is not None
+    # with gradients: forward in one launch that keeps the activated gates, backward on dfol_lstm_cell_bwd_f32 + the dense / TN kernels;
+    # every gradient equals torch's own cell's (fp64 as the yardstick), also when only one of (h', c') carries a gradient
+    for rows, which in ((4, "both"), (256, "both"), (37, "h"), (37, "c")):
+        xs = torch.randn(rows, 318, device="cuda")
+        h0, c0 = torch.randn(rows, 50, device="cuda") * 0.5, torch.randn(rows, 50, device="cuda")
+        gh, gc = torch.randn(rows, 50, device="cuda"), torch.randn(rows, 50, device="cuda")
+        grads = {}
+        for tag, cell, dt in (("mine", mine, torch.float32), ("ref", ref, torch.float32), ("ref64", torch.nn.LSTMCell(318, 50).cuda().double(), torch.float64)):
+            if tag == "ref64":
+                cell.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+            cell.zero_grad()
+            x, h, c = (t.detach().to(dt).requires_grad_(True) for t in (xs, h0, c0))
+            hy, cy = cell(x, (h, c))
+            loss = ((hy * gh.to(dt)).sum() if which != "c" else 0) + ((cy * gc.to(dt)).sum() if which != "h" else 0)
+            loss.backward()
+            grads[tag] = [x.grad, h.grad, c.grad, cell.weight_ih.grad, cell.weight_hh.grad, cell.bias_ih.grad, cell.bias_hh.grad]
+        for gm, gr, g64 in zip(grads["mine"], grads["ref"], grads["ref64"]):
+            scale = g64.abs().max().item() + 1e-12
+            e_mine, e_ref = (gm.double() - g64).abs().max().item() / scale, (gr.double() - g64).abs().max().item() / scale
+            assert e_mine <= 4 * e_ref + 2e-6, (rows, which, e_mine, e_ref)
+    # bit-repeatable
+    mine.zero_grad()
+    x = xs.clone().requires_grad_(True)
+    hy, cy = mine(x, (h0, c0))
+    (hy.sum() + cy.sum()).backward()
+    g1 = [x.grad.clone(), mine.weight_ih.grad.clone(), mine.bias_hh.grad.clone()]
+    mine.zero_grad()
+    x = xs.clone().requires_grad_(True)
+    hy, cy = mine(x, (h0, c0))
+    (hy.sum() + cy.sum()).backward()
+    assert all(torch.equal(a, b) for a, b in zip(g1, [x.grad, mine.weight_ih.grad, mine.bias_hh.grad]))
+
+
+def test_modulate_backward_kernel_against_autograd(L):
+    """dfol_modulate_bwd_f32 (one launch per apply_modulations in the backward of the calibrator phases) against torch autograd through the
+    tensor-op restatement of batch_base_types.py:170-179 in float64: attention and modulation gradients, ragged predicates, clamped
+    corners (d = 0, d = 1, c = 0, attention at log 1)."""
+    from dfol_vqa_amd import ops
+    rng = np.random.RandomState(12)
+    n_list, k_list = [5, 30, 1, 17], [2, 1, 3, 1]
+    pq_h = np.repeat(np.arange(len(n_list)), k_list).astype(np.int32)
+    P, NS = len(pq_h), 32
+    att = (-np.abs(rng.normal(size=(P, NS))) * 2).astype(np.float32)
+    att[0, 0] = 0.0                                            # log 1: log_not at its clamp
+    mods = rng.uniform(0.02, 0.98, size=(P, 4)).astype(np.float32)
+    mods[1, 3], mods[2, 3], mods[3, 2] = 0.0, 1.0, 0.0         # the clamps of slog(d), slog(1 - d), slog(c)
+    g = rng.normal(size=(P, NS)).astype(np.float32)
+    pq, n_obj = dev(pq_h), dev(np.asarray(n_list, np.int32))
+    ga, gm = L.modulate_bwd(dev(g), dev(att), dev(mods), pq, n_obj)
+    a64 = torch.tensor(att, dtype=torch.float64, device="cuda", requires_grad=True)
+    m64 = torch.tensor(mods, dtype=torch.float64, device="cuda", requires_grad=True)
+    valid = torch.arange(NS, device="cuda").unsqueeze(0) < n_obj.long()[pq.long()].unsqueeze(1)
+    out = ops._modulate_reference(a64, m64, valid)
+    ra, rm = torch.autograd.grad(out, (a64, m64), torch.tensor(g, dtype=torch.float64, device="cuda"))
+    assert torch.allclose(ga.double(), ra, atol=2e-5, rtol=2e-5), (ga.double() - ra).abs().max()
+    assert torch.allclose(gm.double(), rm, atol=2e-4, rtol=2e-4), (gm.double() - rm).abs().max()
+    assert bool((ga[~valid] == 0).all())
+    # and through the autograd Function, bit-repeatable
+    a32, m32 = dev(att).requires_grad_(True), dev(mods).requires_grad_(True)
+    o1 = ops.modulate(a32, m32, pq, n_obj)
+    g1 = torch.autograd.grad(o1, (a32, m32), dev(g))
+    o2 = ops.modulate(a32, m32, pq, n_obj)
+    g2 = torch.autograd.grad(o2, (a32, m32), dev(g))
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1]) and torch.equal(g1[0], ga)
 
 
 def test_find_max_ind_on_device(L):

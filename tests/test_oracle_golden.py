@@ -207,6 +207,23 @@ def test_g17_full_size_reference(full_size_oracle, name):
         assert r64["options"] == cm["options"]
 
 
+def test_g17_torch_restatement_equals_reference(full_size_oracle):
+    """oracle/dfol_oracle_torch.py (bench.py's `cpu_baseline`: the reference's own torch-CPU operator sequence in its flat layout) on
+    BASELINE configs[1] verbatim at full model size: it reproduces the reference's fp32 log-probabilities (golden g17) to rounding
+    noise of the host BLAS (bit-identical on the machine the golden was captured on)."""
+    from oracle import dfol_oracle_torch as orct
+    oont, weights, a, meta = full_size_oracle
+    qs, scenes, cm, lp32, lp64 = gu.g17_case("c1_n36", a, meta)
+    r = orct.run_questions(oont, qs, scenes, weights, split=cm["split"])
+    assert np.abs(np.exp(r["log_probability"].astype(np.float64)) - np.exp(lp32.astype(np.float64))).max() <= 2e-6
+    gu.check_logprob(r["log_probability"], lp32, lp64, "torch restatement c1_n36")
+    decided = gu.decided_answers(cm, lp32, lp64)
+    assert [x for x, d in zip(r["answer"], decided) if d] == [x for x, d in zip(cm["answer"], decided) if d]
+    with pytest.raises(NotImplementedError):                 # its scope is the timed programs; the numpy oracle covers the operator set
+        q2, s2, _, _, _ = gu.g17_case("query_attr_n60_100", a, meta)
+        orct.run_questions(oont, q2[:2], s2[:2], weights)
+
+
 @pytest.mark.parametrize("name", ["g6_loss_binary", "g6_loss_query", "g6_loss_query_rel"])
 def test_g6_loss(ontology, name):
     a, meta = gu.load(name)

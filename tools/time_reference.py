@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import ref_harness  # noqa: E402
 from dfol_vqa_amd import synthetic as syn  # noqa: E402
 from oracle import dfol_oracle as orc  # noqa: E402
+from oracle import dfol_oracle_torch as orct  # noqa: E402
 
 
 def write_glove(path, names, dim=300, seed=3):
@@ -81,16 +82,33 @@ def main():
     rows = []
     for size in [int(x) for x in args.sizes.split(",")]:
         split = max(1, -(-args.questions // size))
-        t_ref, t_orc = [], []
-        for _ in range(args.reps):
+        t_ref, t_orc, t_rst = [], [], []
+
+        def run_ref():
             collater = ref_harness.make_collater(ref, split, "feature")
             t0 = time.perf_counter()
             pbs = collater.collate(copy.deepcopy(qs))
             for pb in pbs:
                 pb.create_sparse_tensors()
             with torch.no_grad():
-                res = model(pbs, False)
+                out = model(pbs, False)
             t_ref.append(time.perf_counter() - t0)
+            return out
+
+        def run_rst():
+            t0 = time.perf_counter()
+            out = orct.run_questions(oont, qs, [q["scene"] for q in qs], weights, split=split)
+            t_rst.append(time.perf_counter() - t0)
+            return out
+
+        # reference and restatement alternate (whichever runs right after another library's thread pool has been busy is slowed by
+        # 20-30 %: the order is swapped every repetition and the minimum taken); the numpy port is timed afterwards, on its own
+        for rep in range(args.reps):
+            if rep % 2 == 0:
+                res, rt = run_ref(), run_rst()
+            else:
+                rt, res = run_rst(), run_ref()
+        for _ in range(max(1, args.reps // 2)):
             t0 = time.perf_counter()
             r = orc.run_questions(oont, qs, [q["scene"] for q in qs], np.float32, split=split, weights=weights)
             t_orc.append(time.perf_counter() - t0)
@@ -100,18 +118,29 @@ def main():
                "oracle_over_reference_time": min(t_orc) / min(t_ref),
                "max_abs_dlp": float(np.abs(lp_ref - r["log_probability"]).max()),
                "max_abs_dp": float(np.abs(np.exp(lp_ref) - np.exp(r["log_probability"])).max()),
-               "answers_agree": int(sum(a == b for a, b in zip(res["answer"], r["answer"])))}
+               "answers_agree": int(sum(a == b for a, b in zip(res["answer"], r["answer"]))),
+               "restatement_s": min(t_rst), "restatement_qps": args.questions / min(t_rst), "restatement_over_reference_time": min(t_rst) / min(t_ref),
+               "restatement_max_abs_dlp": float(np.abs(lp_ref - rt["log_probability"]).max()),
+               "restatement_answers_agree": int(sum(a == b for a, b in zip(res["answer"], rt["answer"])))}
         rows.append(row)
         print(json.dumps(row))
     best_ref = max(rows, key=lambda x: x["reference_qps"])
     best_orc = max(rows, key=lambda x: x["oracle_qps"])
+    best_rst = max(rows, key=lambda x: x["restatement_qps"])
     out = {"workload": "BASELINE configs[0]: %d questions, N=%d, select->filter->relate->exist, full-size model, fp32" % (args.questions, args.objects),
            "threads": args.threads, "torch": torch.__version__, "numpy": np.__version__, "rows": rows,
            "summary": "build container, %d threads, N=%d: reference %.1f q/s (ProgramBatch %d) vs this port %.1f q/s (ProgramBatch %d); port time / "
                       "reference time at equal ProgramBatch size: %s; max |dp| between them %.1e"
                       % (args.threads, args.objects, best_ref["reference_qps"], best_ref["program_batch_size"], best_orc["oracle_qps"],
                          best_orc["program_batch_size"], ", ".join("%.2f (size %d)" % (x["oracle_over_reference_time"], x["program_batch_size"]) for x in rows),
-                         max(x["max_abs_dp"] for x in rows))}
+                         max(x["max_abs_dp"] for x in rows)),
+           "restatement_summary": "build container, %d threads, N=%d: reference %.1f q/s (ProgramBatch %d) vs the torch-CPU restatement "
+                                  "(oracle/dfol_oracle_torch.py) %.1f q/s (ProgramBatch %d); restatement time / reference time at equal ProgramBatch size: %s; "
+                                  "max |dlp| between them %.1e"
+                                  % (args.threads, args.objects, best_ref["reference_qps"], best_ref["program_batch_size"], best_rst["restatement_qps"],
+                                     best_rst["program_batch_size"],
+                                     ", ".join("%.2f (size %d)" % (x["restatement_over_reference_time"], x["program_batch_size"]) for x in rows),
+                                     max(x["restatement_max_abs_dlp"] for x in rows))}
     key = "N%d" % args.objects
     allres = {}
     if os.path.exists(args.out):
@@ -119,6 +148,7 @@ def main():
             allres = json.load(f)
     allres[key] = out
     allres["summary"] = " | ".join(allres[k]["summary"] for k in sorted(allres) if k.startswith("N"))
+    allres["restatement_summary"] = " | ".join(allres[k]["restatement_summary"] for k in sorted(allres) if k.startswith("N") and "restatement_summary" in allres[k])
     with open(args.out, "w") as f:
         json.dump(allres, f, indent=1)
     print(allres["summary"])

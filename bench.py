@@ -497,13 +497,22 @@ def train_main(args, rank, world, device, td, share):
         for pb in pbs:
             pb._meta_data = {"index": {t: i for i, t in enumerate(voc)}, "embedding": emb}
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4)
+    use_graph = bool(args.graph) and td is None
+    opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
     bucket = parallel.GradBucket(params)
     if td is not None and args.overlap_allreduce:
         bucket.enable_overlap(group, segments=3)             # ranges of the bucket are all-reduced while the backward still runs
     gb = args.batch * world
     # (the loss stays on the GPU and is read once after the timed steps: no host wait between steps)
-    step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket, sync_loss=False)
+    eager_step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket, sync_loss=False)
+    step, graphed = eager_step, False
+    if use_graph:                                            # one process: the whole step replayed as a captured HIP graph
+        try:
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket)
+            graphed = True
+        except Exception as e:
+            sys.stderr.write("train-step graph capture failed (%r); running eager\n" % (e,))
+            torch.cuda.synchronize()
 
     def barrier():
         if td is not None:
@@ -552,7 +561,7 @@ def train_main(args, rank, world, device, td, share):
     if rank == 0:
         L.enable_kernel_timing(list(L.SIGNATURES))
     for _ in range(2):
-        step()
+        eager_step()
     torch.cuda.synchronize()
     if rank == 0:
         timing = L.disable_kernel_timing()
@@ -567,6 +576,7 @@ def train_main(args, rank, world, device, td, share):
                                                                    ", mlp_math bf16 (dense products on bf16 operands, fp32 accumulation and logic)"
                                                                    if args.mlp_math == "bf16" else ""),
                           "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
+                          "launch": "hip graph replay of the whole step (training.GraphedTrainStep)" if graphed else "eager",
                           "collective": "%s of the flat fp32 bucket per step (%s)" % (
                               "three all-reduces(sum) of contiguous ranges, issued during the backward," if (td is not None and args.overlap_allreduce)
                               else "one all-reduce(sum)", "gloo, shared GPU" if share else "RCCL")},

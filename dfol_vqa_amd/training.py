@@ -18,6 +18,16 @@ def safe_log(x):                                         # util.py:22-25
     return x.clamp(min=1e-20).log()
 
 
+def _targets(values, device):
+    """0/1 target vector on the device: through the content-keyed upload cache on a GPU (a fresh torch.tensor(..., device=) is a pageable,
+    stream-synchronising copy per step, and not capturable in a HIP graph)."""
+    if torch.device(device).type == "cuda":
+        import numpy as np
+        from .host_util import upload
+        return upload(np.asarray(values, np.float32), device)
+    return torch.tensor(values, dtype=torch.float32, device=device)
+
+
 def compute_loss(program_batch_list, prediction, l1_lambda=0.0, parameters=None, l1_scale=1.0):
     """trainer.py:181-262 for STATEMENT / BINARY / QUERY predictions (sum over the batch, not yet divided by it).
 
@@ -29,12 +39,13 @@ def compute_loss(program_batch_list, prediction, l1_lambda=0.0, parameters=None,
     if qtype == QuestionType.STATEMENT:                  # :182-183 returns before the L1 block
         return -lp.sum()
     if qtype == QuestionType.BINARY:                   # :185-194
-        target = torch.tensor([float(a in _YES) for pb in program_batch_list for a in pb._answers], dtype=torch.float32, device=device)
+        host = [float(a in _YES) for pb in program_batch_list for a in pb._answers]
+        target = _targets(host, device)
         loss = nn.functional.binary_cross_entropy(lp.exp(), target, reduction='sum')
     elif qtype == QuestionType.QUERY:                    # :207-230
         answers = [a for pb in program_batch_list for a in pb._answers]
         target = [[a == o for o in op] for a, op in zip(answers, prediction['options'])]
-        tflat = torch.tensor([float(x) for t in target for x in t], dtype=torch.float32, device=device)
+        tflat = _targets([float(x) for t in target for x in t], device)
         if lp.is_cuda:                                   # per-question sums by the segment kernel (index_add is atomic: not repeatable)
             import numpy as np
             from . import ops
@@ -85,6 +96,55 @@ def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group
     nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return (float(loss.detach()) * b if sync_loss else loss.detach() * b), result
+
+
+class GraphedTrainStep(object):
+    """trainer.py:429-442 for ONE fixed list of ProgramBatches as a captured HIP graph: zero the gradients -> forward -> loss / B -> backward
+    -> clip_grad_norm_ -> optimizer step, replayed with one host call.  A train step is 250 - 700 launches (the calibrator phases are
+    host-bound: 4.6 ms of GPU work in a 6.9 ms step), and its launch sequence is static for a given batch shape, exactly like the
+    inference forward's (interpreter.GraphedForward).  The optimizer must be capturable (torch.optim.Adam(..., capturable=True): its step
+    counter lives on the device); new scenes of the same shapes are served by copying into `program_batch._object_features`; a batch
+    with other programs or shapes needs its own capture.  Single process only: with data parallelism the all-reduce sits between the
+    backward and the clip, so run `train_batch` there.  `loss` is a 0-d device tensor that every replay overwrites.
+
+    Same lifetime rule as GraphedForward: tensors that came out of caches are referenced from `self._keep`."""
+
+    def __init__(self, model, optimizer, data, clip_norm, l1_lambda=0.0, bucket=None, warmup=2):
+        from ._lib import keeping
+        self._model, self._opt, self._data, self._bucket = model, optimizer, data, bucket
+        self._clip, self._l1 = clip_norm, l1_lambda
+        self._batch = sum(d.batch_size() for d in data)
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise ValueError("GraphedTrainStep needs a capturable optimizer (torch.optim.Adam(params, lr=..., capturable=True))")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                        # warm-up on a side stream (fills every host-side cache, allocates optimizer state)
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                             # the warm-up's activations go back before the graph's private pool is sized
+        self._keep = []
+        self._graph = torch.cuda.CUDAGraph()
+        with keeping(self._keep), torch.cuda.graph(self._graph):
+            self.loss, self.result = self._body()
+
+    def _body(self):
+        if self._bucket is not None:
+            self._bucket.zero_()
+        else:
+            self._opt.zero_grad(set_to_none=False)
+        result = self._model(self._data, True)
+        loss = compute_loss(self._data, result, self._l1, list(self._model.parameters())) / self._batch
+        loss.backward()
+        nn.utils.clip_grad_norm_(self._model.parameters(), self._clip)
+        self._opt.step()
+        return loss.detach() * self._batch, result
+
+    def __call__(self):
+        self._graph.replay()
+        return self.loss, self.result
 
 
 # ---- evaluation metrics (trainer.py:64-86, 264-318, 477-485) ---------------------------------------------

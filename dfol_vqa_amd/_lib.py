@@ -118,9 +118,6 @@ SIGNATURES = {
     "dfol_linear_pack_w_bf16": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_bf16_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_wgrad_bias_bf16": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
-    "dfol_linear_pack_w_nt3_bytes": [_i32, _i32],            # returns a byte count (int64), called directly
-    "dfol_linear_pack_w_nt3": [_p, _i64, _i32, _i32, _i32, _p, _p],
-    "dfol_linear_act_nt3_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_pack_w2_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_split_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                _i32, _p, _p],
@@ -144,7 +141,6 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.dfol_linear_wgrad_workspace.restype = ctypes.c_int64
-    lib.dfol_linear_pack_w_nt3_bytes.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -425,46 +421,10 @@ def linear_pack_w_split(weight, transpose=False, pieces=3):
     return keep_alive(hit)[1]
 
 
-_NT3_W_CACHE = {}                      # (data_ptr, version, shape, stride, transpose) -> (weight kept alive, packed image)
-
-
-def linear_pack_w_nt3(weight, transpose=False):
-    """The bf16x3 image of a Linear weight for dfol_linear_act_nt3_f32 (operand order of v_mfma_f32_32x32x16_bf16), cached per weight
-    version like linear_pack_w_split.  transpose=True: the image of weight^T, read in place (no transposed copy)."""
-    key = (_dp(weight), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose))
-    hit = _NT3_W_CACHE.get(key)
-    if hit is None:
-        w = weight.detach()
-        N, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
-        out = torch.empty(load().dfol_linear_pack_w_nt3_bytes(N, K) // 2, dtype=torch.bfloat16, device=weight.device)
-        call("dfol_linear_pack_w_nt3", _dp(w), w.stride(0), N, K, int(transpose), _ptr(out, torch.bfloat16), _stream())
-        for stale in [k for k in _NT3_W_CACHE if k[0] == key[0] and k[4] == key[4]]:
-            del _NT3_W_CACHE[stale]
-        if len(_NT3_W_CACHE) >= 64:
-            _NT3_W_CACHE.pop(next(iter(_NT3_W_CACHE)))
-        hit = _NT3_W_CACHE[key] = (weight, out)
-    return keep_alive(hit)[1]
-
-
-def linear_act_nt3(x, weight, bias, act, out=None, transpose_w=False):
-    """y = act(x @ weight.T + bias) on the registers-only bf16x3 kernel (csrc/dfol_dense_nt3.hip); transpose_w=True: y = act(x @ weight + bias)."""
-    M, K = x.shape
-    N = weight.shape[1] if transpose_w else weight.shape[0]
-    if x.stride(1) != 1 or weight.stride(1) != 1:
-        raise DfolError("linear_act_nt3 needs unit column stride")
-    if out is None:
-        out = torch.empty(M, N, dtype=F32, device=x.device)
-    call("dfol_linear_act_nt3_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_nt3(weight, transpose_w), torch.bfloat16),
-         _ptr(bias, F32, True), _dp(out), out.stride(0), M, N, K, act, _stream())
-    return out
-
-
 def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
     """y = act(x @ weight.T + bias) on the bf16 matrix pipes with exact three-way operand split: fp32 results.
     transpose_w=True: y = act(x @ weight + bias) (weight [K, N])."""
     bf16 = _dense_math() == "bf16"                         # the bf16 mode: operands rounded to bf16, one product (configs[3])
-    if os.environ.get("DFOL_DENSE_KERNEL") == "nt3" and not bf16:   # A/B switch: the registers-only kernel (csrc/dfol_dense_nt3.hip)
-        return linear_act_nt3(x, weight, bias, act, out, transpose_w)
     M, K = x.shape
     N = weight.shape[1] if transpose_w else weight.shape[0]
     if out is None:

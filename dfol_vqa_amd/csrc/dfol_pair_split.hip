@@ -435,419 +435,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Persistent form of the ping-pong kernel (round 2).  clock64 traces of pair_ll32s_kernel<.., PP = true> showed where a workgroup's
-// 102 k cycles go: 16 ticks of ~5.2 k (the matrix pipe busy), but also a 5.5 - 7 k prologue (dependent loads of the image geometry,
-// first W2 chunks), an idle first and last tick (the halves run one tick apart) and 7.4 - 8.6 k of epilogue per half (152 Sigmoids =
-// 304 transcendentals per lane), none of which overlaps anything because one workgroup fills the CU (157 KB of LDS, 2 x 256 registers
-// per SIMD).  Here ONE workgroup per CU walks through its tasks (a task = 256 pair slots of one image) and the tick cadence never
-// stops at a task boundary:
-//   * W2 does not depend on the task, so the chunk DMAs simply keep cycling (chunk (c + 1) mod 8 during Y's build tick c);
-//   * a half sets up its next task (geometry, U / V row pointers, first A pieces) in the tick it would otherwise idle in: X during
-//     Y's last multiply, Y during X's first multiply of the next task;
-//   * the epilogue of task t is FUSED into the first multiply tick of task t + 1: column tile i of the old accumulators is turned
-//     into Sigmoids and folded into the K dot products right before the MFMAs of tile i overwrite it (the first of them with a zero
-//     C operand), the VALU / transcendental work interleaved between the MFMAs (sched_group_barrier), where the matrix pipe hides
-//     it: per tile 12 MFMAs (~192 cycles) next to 8 Sigmoids + 8 K FMAs.  Only the 16-lane reductions, LogSigmoid and the tile
-//     stores remain after the tick.  The requested embedding rows of the two tasks in flight sit in two small LDS buffers.
-// So a task costs 16 ticks and nothing else.  K <= KMAX <= 4 requested columns per image (the dot-product partials live in the
-// registers the A-piece builder has just released); more go to the kernel above.
-template <int NB16, bool TBF16, int KMAX>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32p_kernel(
-    const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
-    const float* __restrict__ Wg, const u32x4* __restrict__ W2s, const float* __restrict__ b2, int HID2,
-    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
-    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
-    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
-    void* __restrict__ tiles_v) {
-    constexpr int MT = 2, ROWS = NB16 * 16, T = 512, SLOTS = 256;
-    static_assert(NB16 > SP_T0 && NB16 <= SP_TILES, "geometry");
-    __shared__ __attribute__((aligned(16))) u32x4 Bs[2 * SP_PIECES];        // two W2 chunks, all three pieces (60 KB each)
-    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
-    __shared__ float stage_b[ROWS];                                         // -log2(e) * hidden bias (padding columns: Sigmoid = 0)
-    __shared__ float stage_e[2][KMAX * ROWS];                               // requested embedding rows of the two tasks in flight
-    __shared__ float geo_s[MT * 4][T];                                      // pair geometry of the lane's two slots (16 KB: keeps 8 registers free)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
-    const int total = Q * tiles_per_image, stride = gridDim.x;
-    const int nchunk = HID1 / SP_CH, lastc = nchunk - 1;                     // even (host check): chunk c always lives in buffer c & 1
-#ifdef DFOL_PAIR_TRACE
-    const int trace_blk = (int)blockIdx.x / 32;
-    const bool trace_on = blockIdx.x % 32 == 0 && trace_blk < 8;
-    int trace_task = 0;
-#define PTRACE(slot) do { if (trace_task < 3) TRACE(trace_task * 20 + (slot)); } while (0)
-#else
-#define PTRACE(slot)
-#endif
-    const int Kt = K < KMAX ? K : KMAX;
-
-    struct Task { int t, q, tb, n; };
-    auto task_at = [&](int t, Task& tk) -> bool {                           // wave-uniform: scalar loads only
-        if (t >= total) return false;
-        tk.t = t;
-        tk.q = t / tiles_per_image;
-        tk.tb = t - tk.q * tiles_per_image;
-        tk.n = n_obj[tk.q];
-        if (tk.tb * SLOTS >= tk.n * tk.n) return false;
-        bool any = false;
-        for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + tk.q] >= 0;
-        return any;
-    };
-    auto next_task = [&](int t, Task& tk) -> bool {
-        for (t += stride; t < total; t += stride)
-            if (task_at(t, tk)) return true;
-        return false;
-    };
-    Task cur, nxt, prev;
-    {
-        bool ok = task_at(blockIdx.x, cur);
-        if (!ok) ok = next_task(blockIdx.x, cur);
-        if (!ok) return;                                                     // (uniform over the workgroup, before any barrier)
-    }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)                                           // chunks 0 and 1 land under the set-up below
-#pragma unroll
-        for (int i = 0; i < (SP_PIECES + T - 1) / T; ++i)
-            if (T * i + wave * 64 < SP_PIECES)
-                __builtin_amdgcn_global_load_lds(W2s + (int64_t)cb * SP_PIECES + T * i + tid,
-                                                 (__attribute__((address_space(3))) void*)&Bs[cb * SP_PIECES + T * i + wave * 64], 16, 0, 0);
-    for (int i = tid; i < HID1; i += T) {                                    // geometry weights, transposed to [feature][k]
-        const float4 g = *reinterpret_cast<const float4*>(Wg + i * 4);
-        Wgs[i] = g.x, Wgs[256 + i] = g.y, Wgs[512 + i] = g.z, Wgs[768 + i] = g.w;
-    }
-    for (int i = tid; i < ROWS; i += T) stage_b[i] = SP_NL2E * (i < HID2 ? b2[i] : -1.0e30f);
-
-    int uoff[MT], voff[MT];                                                 // row offsets into UV (host check: the matrix has < 2^31 elements)
-    auto lane_setup = [&](const Task& tk) __attribute__((always_inline)) {
-        const int first = obj_off[tk.q], n = tk.n;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int e_slot = tk.tb * SLOTS + wave * (MT * 16) + m * 16 + r16;
-            const bool valid = e_slot < n * n;
-            const int s = valid ? (int)(((float)e_slot + 0.5f) * __builtin_amdgcn_rcpf((float)n)) : 0, o = valid ? e_slot - s * n : 0;
-            const float4 bs = *reinterpret_cast<const float4*>(pos + (int64_t)(first + s) * ld_pos);
-            const float4 bo = *reinterpret_cast<const float4*>(pos + (int64_t)(first + o) * ld_pos);
-            const float dx = bs.x + bs.z / 2.0f - bo.x - bo.z / 2.0f, dy = bs.y + bs.w / 2.0f - bo.y - bo.w / 2.0f;
-            const float dist = sqrtf(dx * dx + dy * dy);
-            geo_s[m * 4 + 0][tid] = dist;                                    // (only this thread reads them back: no barrier needed)
-            geo_s[m * 4 + 1][tid] = asinf(dy / fmaxf(dist, 1e-10f));
-            geo_s[m * 4 + 2][tid] = (bo.x - bs.x > 0.f) ? 1.f : ((bo.x - bs.x < 0.f) ? -1.f : 0.f);
-            geo_s[m * 4 + 3][tid] = (bo.y - bs.y > 0.f) ? 1.f : ((bo.y - bs.y < 0.f) ? -1.f : 0.f);
-            uoff[m] = (first + s) * (int)ld_uv + 8 * kh;
-            voff[m] = (first + o) * (int)ld_uv + HID1 + 8 * kh;
-        }
-    };
-    // the requested embedding rows of task tk -> buffer `par`, written by the threads t0 .. t0 + nt - 1
-    auto stage_rows = [&](const Task& tk, int par, int t0, int nt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {                                     // rows beyond K stay zero: the epilogue reads all KMAX unconditionally
-            const int col = k < K ? req_col[(int64_t)k * Q + tk.q] : -1;
-            for (int i = tid - t0; i < ROWS; i += nt) stage_e[par][k * ROWS + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
-        }
-    };
-    stage_rows(cur, 0, 0, T);
-    lane_setup(cur);
-
-    floatx4 acc[MT][NB16];
-
-    auto dma_chunk = [&](int c, int buf, int first_wave, auto nw_tag) __attribute__((always_inline)) {
-        constexpr int TT = decltype(nw_tag)::value * 64, passes = (SP_PIECES + TT - 1) / TT;
-        const int w = wave - first_wave, t = tid - first_wave * 64;
-#pragma unroll
-        for (int i = 0; i < passes; ++i) {
-            if (SP_PIECES % TT == 0 || TT * i + w * 64 < SP_PIECES) {
-                const u32x4* src = W2s + (int64_t)c * SP_PIECES + TT * i + t;
-                u32x4* dst = &Bs[buf * SP_PIECES + TT * i + w * 64];
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        }
-    };
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    float4 ru[MT][2], rv[MT][2];
-    auto load_uv = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                ru[m][half] = *reinterpret_cast<const float4*>(UV + uoff[m] + SP_CH * c + 4 * half);
-                rv[m][half] = *reinterpret_cast<const float4*>(UV + voff[m] + SP_CH * c + 4 * half);
-            }
-    };
-    u32x4 ap[MT][3];
-    auto make_a = [&](int c) __attribute__((always_inline)) {
-        float geo[MT][4];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) geo[m][d] = geo_s[m * 4 + d][tid];
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                f2 g[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) g[d] = *reinterpret_cast<const f2*>(&Wgs[d * 256 + SP_CH * c + 8 * kh + 4 * half + 2 * jp]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const f2 uu = jp == 0 ? (f2){ru[m][half].x, ru[m][half].y} : (f2){ru[m][half].z, ru[m][half].w};
-                    const f2 vv = jp == 0 ? (f2){rv[m][half].x, rv[m][half].y} : (f2){rv[m][half].z, rv[m][half].w};
-                    f2 z = uu + vv;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) z = __builtin_elementwise_fma(g[d], (f2){geo[m][d], geo[m][d]}, z);
-                    const float a0 = z.x > 0.f ? z.x : dfol_exp(z.x) - 1.0f;   // nn.ELU
-                    const float a1 = z.y > 0.f ? z.y : dfol_exp(z.y) - 1.0f;
-                    uint32_t h0, m0, l0, h1, m1, l1;
-                    sp_split(a0, h0, m0, l0);
-                    sp_split(a1, h1, m1, l1);
-                    ap[m][0][2 * half + jp] = sp_pack(h0, h1);
-                    ap[m][1][2 * half + jp] = sp_pack(m0, m1);
-                    ap[m][2][2 * half + jp] = sp_pack(l0, l1);
-                }
-            }
-    };
-    const int boff = r16 * 4 + (kh ^ sp_swz(r16));
-    int bbase = boff;
-    auto load_b = [&](int i, bf16x8 (&b)[3]) __attribute__((always_inline)) {
-        const int region = i >= SP_T0, rows_r = (region ? SP_TILES - SP_T0 : SP_T0) * 16;
-        const int at = (region ? SP_R0_PIECES : 0) + (i - (region ? SP_T0 : 0)) * 64 + bbase;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[at + p * rows_r * 4]);
-    };
-    constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
-    float part[KMAX][MT][4];
-    // Sigmoid of column tile i of the finished task's accumulators, folded into the dot products with the requested embedding rows
-    auto epi_tile = [&](int i, float bv, const float (&ev)[KMAX]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float h = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[m][i][e], SP_NL2E, bv)));
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) part[k][m][e] = fmaf(h, ev[k], part[k][m][e]);
-            }
-    };
-    auto epi_rows = [&](int i, int epar, float& bv, float (&ev)[KMAX]) __attribute__((always_inline)) {
-        bv = stage_b[i * 16 + r16];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) ev[k] = stage_e[epar][k * ROWS + i * 16 + r16];
-    };
-    auto mfma_tile = [&](int i, const bf16x8 (&b)[3], auto zero_tag) __attribute__((always_inline)) {
-        constexpr bool ZERO = decltype(zero_tag)::value;                    // start the tile from a zero C operand (a new task)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int x = 0; x < 6; ++x)
-                acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[m][PA6[x]]), b[PB6[x]],
-                                                                    (ZERO && x == 0) ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[m][i], 0, 0, 0);
-    };
-    // the multiply tick of chunk c, as in the kernel above (B fragments of tile i + 1 requested before the MFMAs of tile i)
-    auto multiply = [&](int c) __attribute__((always_inline)) {
-        bbase = boff + (c & 1) * SP_PIECES;
-        bf16x8 bq[2][3];
-        load_b(0, bq[0]);
-#pragma unroll
-        for (int i = 0; i < NB16; ++i) {
-            if (i + 1 < NB16) load_b(i + 1, bq[(i + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                for (int x = 0; x < 6; ++x)
-                    acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[m][PA6[x]]), bq[i & 1][PB6[x]], acc[m][i], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    // the first multiply tick of a task whose accumulators still hold the PREVIOUS task: the epilogue of column tile i + 1 (VALU and
-    // transcendentals, reading the old accumulators in place) is interleaved with the MFMAs of tile i, which restart tile i from zero
-    auto multiply_fused = [&](int epar) __attribute__((always_inline)) {
-        bbase = boff;                                                       // chunk 0 lives in buffer 0
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[k][m][e] = 0.f;
-        bf16x8 bq[2][3];
-        load_b(0, bq[0]);
-        float bv, ev[KMAX];
-        epi_rows(0, epar, bv, ev);
-        epi_tile(0, bv, ev);                                                // (tile 0 has no MFMAs to hide under)
-#pragma unroll
-        for (int i = 0; i < NB16; ++i) {
-            if (i + 1 < NB16) {
-                load_b(i + 1, bq[(i + 1) & 1]);
-                epi_rows(i + 1, epar, bv, ev);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // Twelve slots: one MFMA of tile i each (six per slot tile, the first from a zero C operand) followed by its share of tile
-            // i + 1's epilogue, software-pipelined over the tile's eight (slot tile, row) elements: element j enters at slot j
-            // (fma + exp), continues at slot j + 1 (add + rcp) and is folded into the dot products at slot j + 2.  The order is pinned
-            // slot by slot: left to itself the scheduler emits the MFMAs of a tile back to back and the epilogue behind them.
-            float u[8], h[8];
-#pragma unroll
-            for (int x = 0; x < 12; ++x) {
-                const int m = x / 6, xx = x % 6;
-                acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[m][PA6[xx]]), bq[i & 1][PB6[xx]],
-                                                                    xx == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[m][i], 0, 0, 0);
-                if (i + 1 < NB16) {
-                    if (x >= 2 && x - 2 < 8) {
-                        const int j = x - 2;
-#pragma unroll
-                        for (int k = 0; k < KMAX; ++k) part[k][j >> 2][j & 3] = fmaf(h[j], ev[k], part[k][j >> 2][j & 3]);
-                    }
-                    if (x >= 1 && x - 1 < 8) h[x - 1] = __builtin_amdgcn_rcpf(1.0f + u[x - 1]);
-                    if (x < 8) u[x] = __builtin_amdgcn_exp2f(fmaf(acc[x >> 2][i + 1][x & 3], SP_NL2E, bv));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (i + 1 < NB16) {
-                // (pin the partial sums here: left alone, the compiler sinks the whole Sigmoid / dot-product chain below the MFMA
-                // loop, next to its first use, and keeps the old accumulators alive in scratch memory for it)
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(part[k][m][e]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // what is left of a task's epilogue once the dot products are in `part`: 16-lane reductions, LogSigmoid, the tile stores
-    const int64_t tile_sz = (int64_t)NS * NS;
-    auto epi_tail = [&](const Task& tk) __attribute__((always_inline)) {
-        const int n = tk.n;
-        for (int k = 0; k < Kt; ++k) {
-            const int col = req_col[(int64_t)k * Q + tk.q];
-            if (col < 0) continue;
-            const float bias = be ? be[col] : 0.f;
-            const int64_t tbase = (int64_t)req_tile[(int64_t)k * Q + tk.q] * tile_sz;
-            const bool flip = req_orient && req_orient[(int64_t)k * Q + tk.q];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float p4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int kk = 0; kk < KMAX; ++kk) v = kk == k ? part[kk][m][e] : v;      // (k is not a compile-time index)
-                    p4[e] = dfol_group_sum<16>(v);
-                }
-                if (r16 < 4) {
-                    const float v = r16 == 0 ? p4[0] : (r16 == 1 ? p4[1] : (r16 == 2 ? p4[2] : p4[3]));
-                    const int ee = tk.tb * SLOTS + wave * (MT * 16) + m * 16 + 4 * kh + r16;
-                    if (ee < n * n) {
-                        const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)n)), oo = ee - ss * n;
-                        const float x = v + bias;
-                        const float val = (ss == oo) ? dflt : fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid
-                        const int64_t at = tbase + (flip ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
-                        if (TBF16) {
-                            uint32_t u = __float_as_uint(val);
-                            u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even
-                            reinterpret_cast<uint16_t*>(tiles_v)[at] = (uint16_t)(u >> 16);
-                        } else {
-                            reinterpret_cast<float*>(tiles_v)[at] = val;
-                        }
-                    }
-                }
-            }
-        }
-    };
-    // the last task has no successor to hide its epilogue in
-    auto epi_plain = [&](const Task& tk, int par) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[k][m][e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NB16; ++i) {
-            float ev[KMAX];
-            const float bv = stage_b[i * 16 + r16];
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) ev[k] = stage_e[par][k * ROWS + i * 16 + r16];
-            epi_tile(i, bv, ev);
-        }
-        epi_tail(tk);
-    };
-
-    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wavefront's share of chunks 0 and 1 has landed
-    __syncthreads();                                    // Wgs, the staged rows and both chunks visible
-    const int g = wave >> 2;
-    auto run_half = [&](auto y_tag) __attribute__((always_inline)) {
-        constexpr bool Y = decltype(y_tag)::value;
-        int par = 0;                                    // stage buffer of the current task
-        if (Y) __syncthreads();                         // tick 0 of the first task: X builds chunk 0
-        bool has_next = next_task(cur.t, nxt);
-        // ---- first task, chunk 0 (plain; chunks 0 and 1 came with the set-up)
-        PTRACE(0);
-        load_uv(0);
-        make_a(0);
-        __builtin_amdgcn_sched_barrier(0);
-        PTRACE(18);
-        __syncthreads();                                // end of the build tick
-        __builtin_amdgcn_sched_barrier(0);
-        PTRACE(1);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < NB16; ++i) acc[m][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        multiply(0);
-        PTRACE(2);
-        __syncthreads();                                // end of the multiply tick
-        while (true) {
-            // ---- chunks 1 .. 7: the plain ping-pong
-            for (int c = 1; c < nchunk; ++c) {
-                load_uv(c);
-                if (Y) {                                // the chunk DMAs cycle on: chunk c + 1 (mod 8) into the buffer chunk c - 1 has left
-                    const int cn = c == lastc ? 0 : c + 1;
-                    dma_chunk(cn, cn & 1, 4, std::integral_constant<int, 4>());
-                }
-                make_a(c);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                        // end of the build tick
-                __builtin_amdgcn_sched_barrier(0);
-                PTRACE(1 + 2 * c);
-                multiply(c);
-                if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);          // the chunk requested in the build tick has landed
-                PTRACE(2 + 2 * c);
-                if (!Y || c < lastc || has_next) __syncthreads();  // end of the multiply tick (Y's very last one has no partner)
-            }
-            if (!has_next) break;
-            // ---- task switch: X during Y's last multiply, Y during X's first multiply of the next task
-#ifdef DFOL_PAIR_TRACE
-            ++trace_task;
-#endif
-            PTRACE(0);
-            prev = cur;
-            cur = nxt;
-            par ^= 1;
-            if (!Y) stage_rows(cur, par, 0, 256);       // (the buffer's old rows were last read two ticks into the finished task)
-            lane_setup(cur);
-            has_next = next_task(cur.t, nxt);
-            PTRACE(17);
-            load_uv(0);
-            if (Y) dma_chunk(1, 1, 4, std::integral_constant<int, 4>());
-            make_a(0);
-            __builtin_amdgcn_sched_barrier(0);
-            PTRACE(18);
-            __syncthreads();                            // end of the build tick
-            __builtin_amdgcn_sched_barrier(0);
-            PTRACE(1);
-            multiply_fused(par ^ 1);                    // chunk 0 of the new task + the Sigmoids / dot products of the finished one
-            if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);
-            PTRACE(2);
-            epi_tail(prev);
-            PTRACE(19);
-            __syncthreads();                            // end of the multiply tick
-        }
-        epi_plain(cur, par);
-    };
-    if (g == 0) run_half(std::false_type());
-    else run_half(std::true_type());
-}
-
 }  // namespace
 
 #ifdef DFOL_PAIR_TRACE
@@ -880,30 +467,8 @@ extern "C" int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HI
     DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_split % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll_split: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     static const int pp = getenv("DFOL_PAIR_SPLIT_PP") ? atoi(getenv("DFOL_PAIR_SPLIT_PP")) : 1;
-    // pp = 1 (default): one ping-pong workgroup per 256 slots; 0: two 4-wavefront workgroups per CU; 2: the persistent kernel with the
-    // epilogue fused into the next task's first multiply tick (full-size oracle shape, fp32 tiles, K <= 4) - correct (same tests) but
-    // measured SLOWER (2.32 ms against 1.75 ms at 256 x 100 objects): the fused tick takes 13-16 k cycles instead of 5.2 k, because a
-    // Sigmoid is two transcendentals of 16 cycles each on the VALU pipe and the matrix pipe leaves only ~12 cycles per MFMA gap, so the
-    // 7 k cycles of epilogue VALU work of a wavefront cannot hide under its own 228 MFMAs (profiles/r02_pair_trace.md)
-    if (pp == 2 && tile_dtype == DFOL_TILE_F32 && HID2 > 288 && HID2 <= 304 && HID1 % (2 * SP_CH) == 0 && K <= 4) {
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            cus = n;
-        }
-        const int tpi_p = dfol_cdiv((int64_t)max_n * max_n, 256);
-        DFOL_REQUIRE((int64_t)Q * tpi_p < ((int64_t)1 << 31), "pair_ll_split: too many tiles");
-        const int64_t tasks = (int64_t)Q * tpi_p;
-        const dim3 pgrid((unsigned)(tasks < cus ? tasks : cus));
-#define DFOL_PAIR32P(KM)                                                                                                              \
-        hipLaunchKernelGGL((pair_ll32p_kernel<19, false, KM>), pgrid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
-                           E, ld_e, be, n_obj, obj_off, Q, tpi_p, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
-        if (K <= 1) DFOL_PAIR32P(1); else DFOL_PAIR32P(4);
-#undef DFOL_PAIR32P
-        DFOL_LAUNCH_CHECK("pair_ll_split (persistent)");
-        return 0;
-    }
+    // pp = 1 (default): one ping-pong workgroup per 256 slots; 0: two 4-wavefront workgroups per CU.  (The persistent variant with the
+    // epilogue fused into the next task's first multiply tick - measured slower, DESIGN.md 3.3 - is parked in tools/scratch/.)
     const int tpi = dfol_cdiv((int64_t)max_n * max_n, pp ? 256 : 128);
     DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_split: too many tiles");
     const dim3 grid((unsigned)Q * tpi);

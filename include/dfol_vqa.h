@@ -243,16 +243,6 @@ int dfol_linear_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, v
 int dfol_linear_act_bf16_f32(const float* X, int64_t ldx, const void* W_bf16, const float* bias, float* Y, int64_t ldy, int32_t M,
                              int32_t N, int32_t K, int32_t act, void* stream);
 
-/* The same product, same three-way split, as a registers-only kernel (dfol_vqa_amd/csrc/dfol_dense_nt3.hip): X fragments straight
- * from global memory into the operand registers of v_mfma_f32_32x32x16_bf16, no LDS; one wavefront per SIMD owns up to 128 x 128
- * of Y and the column blocks of a row block share a workgroup, so X is fetched from HBM once.  W_packed comes from
- * dfol_linear_pack_w_nt3 (dfol_linear_pack_w_nt3_bytes(N, K) bytes, 16-byte aligned; transpose != 0: W is [K, N] - the operand of the
- * backward product dz @ W).  Limits: none on K; X rows 4-byte aligned.  Results are independent of M (the rows-per-wavefront variants
- * add in the same order). */
-int64_t dfol_linear_pack_w_nt3_bytes(int32_t N, int32_t K);
-int dfol_linear_pack_w_nt3(const float* W, int64_t ldw, int32_t N, int32_t K, int32_t transpose, void* W_packed, void* stream);
-int dfol_linear_act_nt3_f32(const float* X, int64_t ldx, const void* W_packed, const float* bias, float* Y, int64_t ldy, int32_t M,
-                            int32_t N, int32_t K, int32_t act, void* stream);
 
 /* Box positional features: replaces batch_gqa_boxfeatures_pipeline.py:208-211.
  *   raw [O, ld_raw]: the last 6 columns (ending at column `raw_cols`) are (W, H, x, y, w, h);

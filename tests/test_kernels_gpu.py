@@ -353,46 +353,6 @@ def test_linear_act_split(L, M, N, K, ldx_extra, act):
     assert torch.allclose(_lib.linear_act_split(xt, w, None, 0), 2 * a, rtol=1e-6, atol=0)
 
 
-@pytest.mark.parametrize("M,N,K,ldx_extra,act", [(300, 70, 52, 0, 0), (257, 300, 256, 0, 1), (513, 256, 516, 0, 2), (200, 333, 300, 0, 3),
-                                                 (130, 512, 2048, 6, 2), (64, 49, 13, 1, 3), (1, 5, 3, 0, 0), (40000, 300, 256, 0, 1),
-                                                 (26000, 512, 516, 2, 0), (100000, 256, 300, 0, 0)])
-def test_linear_act_nt3(L, M, N, K, ldx_extra, act):
-    """The registers-only bf16x3 kernel (csrc/dfol_dense_nt3.hip): against float64 and the fp32 kernel on ragged M / N / K (any K, any
-    row alignment), the three rows-per-wavefront variants (chosen by M: 1, 2 and 4 row tiles occur in this list) bit-identical on
-    shared rows, the transposed weight image, and the per-version cache."""
-    from dfol_vqa_amd import _lib
-    rng = np.random.RandomState(M % 1000 + N + K)
-    Xfull = (rng.uniform(-1, 1, (M, K + ldx_extra)) * np.exp(rng.uniform(-6, 2, (M, 1)))).astype(np.float32)
-    W = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
-    b = rng.normal(size=N).astype(np.float32)
-    xt = dev(Xfull)[:, :K]
-    got = _lib.linear_act_nt3(xt, dev(W), dev(b), act).cpu().numpy()
-    z64 = Xfull[:, :K].astype(np.float64) @ W.astype(np.float64).T
-    z = z64 + b
-    ref = [z, orc._sigmoid(z), orc._elu(z), orc._log_sigmoid(z)][act]
-    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5)
-    pre = _lib.linear_act_nt3(xt, dev(W), None, 0)
-    os.environ["DFOL_DENSE_MATH"] = "f32"
-    try:
-        pre32 = L.linear_act(xt, dev(W), None, 0).cpu().numpy()
-    finally:
-        del os.environ["DFOL_DENSE_MATH"]
-    scale = np.abs(Xfull[:, :K]).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1e-30
-    e_split, e_f32 = np.abs(pre.cpu().numpy() - z64) / scale, np.abs(pre32 - z64) / scale
-    assert e_split.max() <= max(2.0 ** -21, 1.5 * e_f32.max()) and e_split.mean() <= 1.5 * e_f32.mean() + 2.0 ** -25, (e_split.max(), e_f32.max())
-    # a short prefix of the rows runs on a smaller rows-per-wavefront variant: the same bits
-    head = min(M, 37)
-    assert torch.equal(_lib.linear_act_nt3(xt[:head], dev(W), None, 0), pre[:head])
-    # y = x @ V with V = W^T given as a [K, N] matrix (the backward's dz @ W)
-    V = dev(np.ascontiguousarray(W.T))
-    assert torch.equal(_lib.linear_act_nt3(xt, V, None, 0, transpose_w=True), pre)
-    # the weight image is cached per weight version
-    w = dev(W)
-    a = _lib.linear_act_nt3(xt, w, None, 0)
-    w.mul_(2.0)
-    assert torch.allclose(_lib.linear_act_nt3(xt, w, None, 0), 2 * a, rtol=1e-6, atol=0)
-
-
 def test_bf16x3_kernels_bitwise_repeatable(L):
     """The two LDS-pipelined bf16x3 kernels at the bench shape, 25 launches each: every result bitwise equal to the first.  (The pair
     kernel's chunk buffers are filled by LDS-DMA, whose completion no barrier waits for by itself: a missing drain shows up here.)"""

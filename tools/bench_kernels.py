@@ -135,9 +135,6 @@ def main():
             t = timeit(lambda: L.linear_act_split(x, w, b, act, y), iters=10)
             out.append({"kernel": "linear_act_split", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
                         "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15})
-        t = timeit(lambda: L.linear_act_nt3(x, w, b, act, y), iters=10)
-        out.append({"kernel": "linear_act_nt3 (registers only)", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
-                    "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15})
     # the two tall products of a train step's pair MLP (one row per ordered object pair): forward with the Sigmoid, input gradient
     for (M, Nn, K, act) in ((256 * N * (N - 1), 300, 256, 1), (256 * N * (N - 1), 256, 300, 0)):
         x = torch.rand(M, K, device=dev) - 0.5
@@ -145,7 +142,7 @@ def main():
         b = torch.rand(Nn, device=dev)
         y = torch.empty(M, Nn, device=dev)
         fl = 2.0 * M * Nn * K
-        for name, fn in (("linear_act_split", L.linear_act_split), ("linear_act_nt3 (registers only)", L.linear_act_nt3)):
+        for name, fn in (("linear_act_split", L.linear_act_split),):
             if name == "linear_act_split" and K % 4:
                 continue
             t = timeit(lambda: fn(x, w, b, act, y), iters=5)

@@ -2,8 +2,8 @@
 # Round-end measurement pass (runs on the GPU box): rocprofv3 stats + HBM counters of the default bench command, the bench lines of
 # every configuration, kernel / operator / training / calibrated-forward benchmarks, per-step launch breakdowns and the PMC passes of
 # the two MFMA kernels.  Copy what should be judged from gpurun_out/ into profiles/ (named per round).
-# usage: tools/measure_all.sh [tag]      (default tag r02)
-TAG=${1:-r02}
+# usage: tools/measure_all.sh [tag]      (default tag r03)
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=gpurun_out/$TAG
@@ -14,9 +14,12 @@ cp gpurun_out/prof_$TAG/traffic.json $O/traffic.json 2>/dev/null && cp $O/traffi
 timeout 600 python bench.py > $O/bench_n100.json 2> $O/bench_n100.err
 timeout 300 python bench.py --workload c1 > $O/bench_c1_n36.json 2> $O/bench_c1.err
 timeout 600 python bench.py --workload c4 --steps 10 > $O/bench_c4_n256.json 2> $O/bench_c4.err
+timeout 300 python bench.py --workload c3 > $O/bench_c3_shared.json 2> $O/bench_c3.err
+timeout 300 python bench.py --workload c3 --share-scenes 0 --cpu-sample 0 --stress-preds 0 > $O/bench_c3_unshared.json 2>> $O/bench_c3.err
+cp gpurun_out/prof_$TAG/roofline_rocprof_merged.json $O/roofline_rocprof.json 2>/dev/null
 timeout 300 python tools/bench_kernels.py > $O/kernel_microbench.jsonl 2> $O/kb.err
 timeout 300 python tools/bench_ops.py > $O/ops_throughput.jsonl 2> $O/ops.err
-for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1" "--objects 100 --mlp-math bf16"; do
+for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1" "--objects 100 --mlp-math bf16" "--objects 100 --graph 0" "--objects 100 --calibrator 1 --graph 0"; do
   timeout 300 python bench.py --mode train --steps 10 $a >> $O/train_step.jsonl 2>> $O/train.err
 done
 DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2r.err
@@ -29,6 +32,9 @@ bash tools/step_breakdown.sh ${TAG}_train_n100 --mode train --objects 100 > $O/s
 mkdir -p gpurun_out/peak
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/scratch/mfma_peak.hip -o gpurun_out/peak/mfma_peak > /dev/null 2>&1 && timeout 120 gpurun_out/peak/mfma_peak > $O/mfma_peak.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/scratch/tick_model.hip -o gpurun_out/peak/tick_model > /dev/null 2>&1 && timeout 120 gpurun_out/peak/tick_model > $O/tick_model.txt 2>&1
+mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/scratch/transc_accuracy.hip -o build/transc_accuracy > /dev/null 2>&1 && timeout 60 build/transc_accuracy > $O/transcendental_accuracy.txt 2>&1
+timeout 300 python tools/accuracy_probe.py --tag $TAG > $O/accuracy_probe_n36.json 2> $O/probe.err
+timeout 300 python tools/accuracy_probe.py --tag ${TAG}_n100 --objects 100 --questions 16 > $O/accuracy_probe_n100.json 2>> $O/probe.err
 bash tools/pmc_run.sh ${TAG}_mfma "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" tools/bench_kernels.py > $O/pmc_mfma_busy.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_insts "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU" tools/bench_kernels.py > $O/pmc_insts.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_fetch "FETCH_SIZE" tools/bench_kernels.py > $O/pmc_fetch_microbench.txt 2>&1

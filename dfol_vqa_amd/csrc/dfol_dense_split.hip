@@ -17,6 +17,8 @@
 // -DDFOL_DENSE_TRACE: clock64 stamps of one workgroup (tools/scratch/trace_dense.py).
 #include "dfol_common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #ifdef DFOL_DENSE_TRACE
@@ -98,28 +100,34 @@ __device__ __forceinline__ float ls_act(float x) {
 // block would otherwise spend a full block's MFMAs on 44 columns, 28 % of the pair layer's forward product)
 // NP: pieces per operand - 3: fp32 results (six piece products per step and accumulator); 1: the bf16 mode (operands rounded to bf16, one
 // product, fp32 accumulation - what a "bf16 forward" computes; BASELINE configs[3])
-template <int ACT, int XV, int NT, int NP>
+// RT: row tiles of 16 per wavefront - 4 (a 128-row block: the default) or 2 (a 64-row block, for products whose 128-row tiling would leave
+// most of the chip without a workgroup: the featurizer of 36-object scenes is 288 blocks of 128 rows on 512 workgroup slots, and a
+// batch of shared scenes 60).  An output element sees the same products in the same order whatever the block height, so the choice
+// changes no result bit (tests/test_kernels_gpu.py::test_linear_act_split_block_height_changes_no_bit) - a sharded run still equals
+// the single-process run.
+template <int ACT, int XV, int NT, int NP, int RT>
 __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const float* __restrict__ X, int64_t ldx,
                                         const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int M, int N,
                                         int K, int ksteps, int mb, int nb) {
-    const int m0 = mb * LS_BM, n0 = nb * LS_BN;
+    constexpr int BM = 32 * RT, RH = RT / 2;                          // rows of the block; 64-row halves staged per thread
+    const int m0 = mb * BM, n0 = nb * LS_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     constexpr int WN = 16 * NT;                                       // columns of a wavefront
 
-    floatx4 acc[4][NT];
+    floatx4 acc[RT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // A staging: rows (tid >> 2) and (tid >> 2) + 64, k-group tid & 3 (8 consecutive k): four threads read 128 contiguous bytes
     const int arow = tid >> 2, aq = tid & 3;
     const float* xp0 = X + (int64_t)min(m0 + arow, M - 1) * ldx + aq * 8;
-    const float* xp1 = X + (int64_t)min(m0 + arow + 64, M - 1) * ldx + aq * 8;
+    const float* xp1 = X + (int64_t)min(m0 + arow + 64, M - 1) * ldx + aq * 8;      // (RT = 4 only)
     // X registers: two steps in flight (HBM latency is longer than one step of 96 MFMAs).  The loads are unconditional - addresses
     // clamped, out-of-range k zeroed afterwards - so that every wavefront issues exactly 4 per step and the vmcnt arithmetic below holds.
-    float4 xa[2][2][2];                                             // [set = step parity][row half][k half]
+    float4 xa[2][RH][2];                                            // [set = step parity][row half][k half]
     auto load_x = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
@@ -131,15 +139,17 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         };
         xa[S][0][0] = ld4(xp0 + c0);
         xa[S][0][1] = ld4(xp0 + c1);
-        xa[S][1][0] = ld4(xp1 + c0);
-        xa[S][1][1] = ld4(xp1 + c1);
+        if constexpr (RH == 2) {
+            xa[S][1][0] = ld4(xp1 + c0);
+            xa[S][1][1] = ld4(xp1 + c1);
+        }
     };
     auto store_a = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RH; ++h) {
             const int row = arow + 64 * h;
             const float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
             const int at = row * 4 + (aq ^ ls_swz(row));
@@ -149,8 +159,8 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                 u32x4 ph, pm, pl;
                 ls_split8(v0, v1, ph, pm, pl);
                 As[at] = ph;
-                As[LS_BM * 4 + at] = pm;
-                As[2 * LS_BM * 4 + at] = pl;
+                As[BM * 4 + at] = pm;
+                As[2 * BM * 4 + at] = pl;
             }
         }
     };
@@ -171,7 +181,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         for (int i = 0; i < TILE_PIECES / 256; ++i) Bs[256 * i + tid] = wb[i];
     };
 
-    const int aoff = (wm * 64 + r16) * 4 + (kh ^ ls_swz(r16));
+    const int aoff = (wm * (16 * RT) + r16) * 4 + (kh ^ ls_swz(r16));
     const int boff = (wn * WN + r16) * 4 + (kh ^ ls_swz(r16));
 
     constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
@@ -190,12 +200,12 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         if (HAS_X) load_x(ks + 2, set_tag);
         __builtin_amdgcn_sched_barrier(0);                  // requests first; and the next step's split must not drift up here
 #pragma unroll
-        for (int ih = 0; ih < 4; ih += 2) {                 // two row tiles at a time (register budget)
+        for (int ih = 0; ih < RT; ih += 2) {                // two row tiles at a time (register budget)
             bf16x8 a[2][NP];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * LS_BM * 4 + (ih + i) * 64 + aoff]);
+                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * BM * 4 + (ih + i) * 64 + aoff]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 bf16x8 b[NP];
@@ -242,20 +252,20 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     float bv[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[min(n0 + wn * WN + j * 16 + r16, N - 1)] : 0.f;
-    float* yp = Y + (int64_t)(m0 + wm * 64 + 4 * kh) * ldy + n0 + wn * WN + r16;
-    if (NT == 4 && m0 + LS_BM <= M && n0 + LS_BN <= N) {
+    float* yp = Y + (int64_t)(m0 + wm * (16 * RT) + 4 * kh) * ldy + n0 + wn * WN + r16;
+    if (NT == 4 && m0 + BM <= M && n0 + LS_BN <= N) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = ls_act<ACT>(acc[i][j][e] + bv[j]);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool row_ok = m0 + wm * 64 + i * 16 + 4 * kh + e < M;
+                const bool row_ok = m0 + wm * (16 * RT) + i * 16 + 4 * kh + e < M;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const float v = ls_act<ACT>(acc[i][j][e] + bv[j]);
@@ -265,19 +275,19 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     }
 }
 
-template <int ACT, int XV, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_act_split_kernel(
+template <int ACT, int XV, int NP, int RT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, RT == 2 ? 3 : 2))) void linear_act_split_kernel(
     const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
     int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
-    __shared__ __attribute__((aligned(16))) u32x4 As[3 * LS_BM * 4];        // [piece][row][k-group]  24 KB
+    __shared__ __attribute__((aligned(16))) u32x4 As[3 * 32 * RT * 4];      // [piece][row][k-group]  24 KB (12 KB for 64-row blocks)
     __shared__ __attribute__((aligned(16))) u32x4 Bs[LS_TILE_PIECES];       // the B tile of the step  24 KB
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so id % 8 is the XCD; give each XCD a contiguous run of
     // logical tiles (column blocks of a row block are consecutive): the X rows are fetched into that XCD's L2 once
     int bid = blockIdx.x;
     if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     const int mb = bid / nbn, nb = bid - mb * nbn;
-    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
-    else ls_tile<ACT, XV, 2, NP>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    else ls_tile<ACT, XV, 2, NP, RT>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
 }
 
 }  // namespace
@@ -312,16 +322,20 @@ static int ls_launch(const float* X, int64_t ldx, const void* W_split, const flo
     DFOL_REQUIRE(X && W_split && Y, "linear_act_split: null pointer");
     DFOL_REQUIRE(((uintptr_t)X % 8 == 0) && ((uintptr_t)W_split % 16 == 0), "linear_act_split: X must be 8-byte and W_split 16-byte aligned");
     const bool x16 = (uintptr_t)X % 16 == 0 && ldx % 4 == 0;
-    const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN), nbm = dfol_cdiv(M, LS_BM);
+    const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
+    // 64-row blocks when 128-row blocks would not even give every CU two workgroups (the block height changes no result bit, see ls_tile);
+    // DFOL_DENSE_BM=128 / 64 forces one for A/B runs
+    static const int force_bm = getenv("DFOL_DENSE_BM") ? atoi(getenv("DFOL_DENSE_BM")) : 0;
+    const bool small = force_bm ? force_bm == 64 : (int64_t)dfol_cdiv(M, LS_BM) * nbn < 512;
+    const int nbm = dfol_cdiv(M, small ? 64 : LS_BM);
     DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_act_split: too many tiles");
     const int nblocks = nbm * nbn;
+#define DFOL_LS_K(A, XVV, RTT)                                                                                                              \
+    hipLaunchKernelGGL((linear_act_split_kernel<A, XVV, NP, RTT>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, \
+                       bias, Y, ldy, M, N, K, ksteps, nbn, nblocks)
 #define DFOL_LS(A)                                                                                                                          \
-    if (x16)                                                                                                                                \
-        hipLaunchKernelGGL((linear_act_split_kernel<A, 4, NP>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split,   \
-                           bias, Y, ldy, M, N, K, ksteps, nbn, nblocks);                                                                   \
-    else                                                                                                                                    \
-        hipLaunchKernelGGL((linear_act_split_kernel<A, 2, NP>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split,   \
-                           bias, Y, ldy, M, N, K, ksteps, nbn, nblocks)
+    if (x16) { if (small) DFOL_LS_K(A, 4, 2); else DFOL_LS_K(A, 4, 4); }                                                                    \
+    else { if (small) DFOL_LS_K(A, 2, 2); else DFOL_LS_K(A, 2, 4); }
     switch (act) {
         case DFOL_ACT_NONE: DFOL_LS(DFOL_ACT_NONE); break;
         case DFOL_ACT_SIGMOID: DFOL_LS(DFOL_ACT_SIGMOID); break;
@@ -330,6 +344,7 @@ static int ls_launch(const float* X, int64_t ldx, const void* W_split, const flo
         default: DFOL_REQUIRE(false, "linear_act_split: unknown activation %d", act);
     }
 #undef DFOL_LS
+#undef DFOL_LS_K
     DFOL_LAUNCH_CHECK("linear_act_split");
     return 0;
 }

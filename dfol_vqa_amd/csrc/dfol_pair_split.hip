@@ -116,8 +116,8 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     constexpr int PP_STAGE_FLOATS = PP ? 8192 : 4;                  // PP: the epilogue's bias / embedding rows have their own 32 KB
     __shared__ __attribute__((aligned(16))) float stage_pp[PP_STAGE_FLOATS];
     const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
-    const int n = n_obj[q];
-    if (tb * SLOTS >= n * n) return;
+    const int n = n_obj[q], npairs = n * (n - 1);          // slots enumerate the ORDERED PAIRS s != o (row-major in s, util.py:87-103): the
+    if (tb * SLOTS >= npairs) return;                       // diagonal is never computed (round 3: one workgroup in 40 at N = 100, one in 6 at N = 36)
     bool any = false;
     for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
     if (!any) return;
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int e_slot = tb * SLOTS + wave * (MT * 16) + m * 16 + r16;
-        const bool valid = e_slot < n * n;
-        const int s = valid ? e_slot / n : 0, o = valid ? e_slot - s * n : 0;
+        const bool valid = e_slot < npairs;
+        const int s = valid ? e_slot / (n - 1) : 0, oo_ = valid ? e_slot - s * (n - 1) : 0, o = oo_ + (oo_ >= s);      // (n >= 2 here)
         const float* ps = pos + (int64_t)(first + s) * ld_pos;
         const float* po = pos + (int64_t)(first + o) * ld_pos;
         const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
@@ -413,11 +413,11 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             if (r16 < 4) {
                 const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
                 const int ee = tb * SLOTS + wave * (MT * 16) + m * 16 + 4 * kh + r16;
-                if (ee < n * n) {
-                    // ee / n without the integer-division sequence: (ee + 0.5) / n is at least 0.5 / n away from an integer
-                    const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)n)), oo = ee - ss * n;
+                if (ee < npairs) {
+                    // ee / (n - 1) without the integer-division sequence: (ee + 0.5) / (n - 1) is at least 0.5 / (n - 1) away from an integer
+                    const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)(n - 1))), op = ee - ss * (n - 1), oo = op + (op >= ss);
                     const float x = v + (be ? be[col] : 0.f);
-                    const float val = (ss == oo) ? dflt : fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid
+                    const float val = fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid (the diagonal keeps the caller's fill)
                     const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
                                        ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
                     if (TBF16) {
@@ -469,7 +469,7 @@ extern "C" int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HI
     static const int pp = getenv("DFOL_PAIR_SPLIT_PP") ? atoi(getenv("DFOL_PAIR_SPLIT_PP")) : 1;
     // pp = 1 (default): one ping-pong workgroup per 256 slots; 0: two 4-wavefront workgroups per CU.  (The persistent variant with the
     // epilogue fused into the next task's first multiply tick - measured slower, DESIGN.md 3.3 - is parked in tools/scratch/.)
-    const int tpi = dfol_cdiv((int64_t)max_n * max_n, pp ? 256 : 128);
+    const int tpi = dfol_cdiv((int64_t)max_n * (max_n - 1), pp ? 256 : 128);
     DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_split: too many tiles");
     const dim3 grid((unsigned)Q * tpi);
 #define DFOL_PAIR32S(NBV, BF)                                                                                                         \

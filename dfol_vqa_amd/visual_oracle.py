@@ -690,10 +690,8 @@ class ClassifierOracle(OracleBase):
                       world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0, hid2=hid2)
 
     def _new_tiles(self, world, count, dtype=torch.float32):
-        ragged = min(world._n_list) < world._NS
-        if ragged:       # the pair kernel writes real pairs and the diagonal only
-            return torch.full((count, world._NS, world._NS), -30.0, dtype=dtype, device=world._device)
-        return torch.empty(count, world._NS, world._NS, dtype=dtype, device=world._device)
+        # the pair kernels write the real ordered pairs (the bf16x3 kernel not even the diagonal): absent everywhere else
+        return torch.full((count, world._NS, world._NS), -30.0, dtype=dtype, device=world._device)
 
     def prefetch_relations(self, world, program_batch, fused=True):
         """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel /
@@ -762,8 +760,6 @@ class ClassifierOracle(OracleBase):
                     torch.as_tensor(np.concatenate(invalid)).to(dev) if invalid else None)
             program_batch._dfol_rel_plan = plan
         _, req_col, req_tile, req_orient, invalid = plan
-        if invalid is not None and not (min(world._n_list) < world._NS):
-            tiles.index_fill_(0, invalid, -30.0)       # (advanced-index assignment is not capturable in a HIP graph)
         base = 0
         for low, pq, orient in entries:
             P = len(pq)
@@ -867,9 +863,7 @@ class ClassifierOracle(OracleBase):
         full = self._relation_full_columns(low.cols)
         req_col[slot, pq] = full
         req_tile[slot, pq] = np.arange(P, dtype=np.int32)
-        tiles = self._new_tiles(world, P)
-        if not low.all_valid:
-            tiles.index_fill_(0, upload(np.nonzero(low.valid == 0)[0], world._device), -30.0)
+        tiles = self._new_tiles(world, P)                 # (no-op tokens request nothing: their tiles stay absent)
         self._launch_pairs(world, req_col, req_tile, tiles)
         return tiles
 

@@ -356,7 +356,9 @@ int dfol_pair_ll_packed_f32(const float* UV, int64_t ld_uv, int32_t HID1, const 
  * agree with dfol_pair_ll_packed_f32 to fp32 rounding (they are NOT a reduced-precision mode).  W2_split is produced once per
  * weight update by dfol_pair_pack_w2_bf16x3: (HID1/32) * 61440 bytes, 16-byte aligned; per 32 k two regions (column tiles 0-7
  * and 8-19) of [3 pieces][rows][32] bf16, rows >= HID2 zero, k-groups swizzled for conflict-free LDS reads.
- * All other arguments as dfol_pair_ll_packed_f32.  Limits: HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320.
+ * All other arguments as dfol_pair_ll_packed_f32, with ONE difference: this kernel enumerates the ordered pairs s != o only and never
+ * touches a tile's diagonal - pre-fill the tiles with default_ll (the diagonal and the padding keep that fill).
+ * Limits: HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320.
  */
 int dfol_pair_pack_w2_bf16x3(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, void* W2_split, void* stream);
 int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,

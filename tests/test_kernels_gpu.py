@@ -856,3 +856,21 @@ def test_torch_custom_ops_opcheck(L):
     ga, gl = torch.autograd.grad(out, (att, ll), go)
     ra, rl = L.filter_bwd(go, ll.detach(), pq, n_obj, neg, None, Q)
     assert torch.equal(ga, ra) and torch.equal(gl, rl)
+
+
+def test_linear_act_split_block_height_changes_no_bit(L):
+    """The bf16x3 dense kernel picks 64-row blocks for products whose 128-row tiling would leave most of the chip idle (the featurizer of
+    36-object or shared scenes).  An output element sees the same products in the same order either way, so rows computed inside a small
+    batch (64-row blocks) equal the same rows computed inside a large one (128-row blocks) BIT FOR BIT - the property the sharded ==
+    single-process equality rests on - for every activation, ragged M / N and 8-byte aligned rows."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(21)
+    for (N, K, ld) in ((512, 2048, 2054), (300, 256, 256), (256, 516, 516)):
+        big = torch.tensor(rng.normal(size=(70000, ld)).astype(np.float32), device="cuda")
+        W = torch.tensor((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32), device="cuda")
+        b = torch.tensor(rng.normal(size=N).astype(np.float32), device="cuda")
+        for act in (L.ACT_NONE, L.ACT_SIGMOID, L.ACT_ELU):
+            y_big = _lib.linear_act_split(big[:, :K], W, b, act)                  # 547 row blocks of 128
+            for m in (37, 1835, 9216):
+                y_small = _lib.linear_act_split(big[:m, :K], W, b, act)          # 64-row blocks
+                assert torch.equal(y_small, y_big[:m]), (N, K, act, m, (y_small - y_big[:m]).abs().max().item())

@@ -871,6 +871,6 @@ def test_linear_act_split_block_height_changes_no_bit(L):
         b = torch.tensor(rng.normal(size=N).astype(np.float32), device="cuda")
         for act in (L.ACT_NONE, L.ACT_SIGMOID, L.ACT_ELU):
             y_big = _lib.linear_act_split(big[:, :K], W, b, act)                  # 547 row blocks of 128
-            for m in (37, 1835, 9216):
-                y_small = _lib.linear_act_split(big[:m, :K], W, b, act)          # 64-row blocks
+            for m in (37, 1835, 9216):                                           # 64-row blocks
+                y_small = _lib.linear_act_split(big[:m, :K], W, b, act)
                 assert torch.equal(y_small, y_big[:m]), (N, K, act, m, (y_small - y_big[:m]).abs().max().item())

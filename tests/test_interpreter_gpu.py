@@ -1401,3 +1401,35 @@ def test_shared_scenes_equal_per_question_scenes(tmp_path, kind):
         d = model(shared, False)
     model._oracle._needed_columns = True
     assert np.abs(np.exp(d["log_probability"].cpu().numpy()) - np.exp(a["log_probability"].cpu().numpy())).max() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["exist", "verify_rel", "choose_rel", "query_attr"])
+def test_shared_scenes_with_attention_calibration(ontology, name):
+    """The calibrated forward (LSTM passes + apply_modulations around every operator) on a batch whose questions share scenes: same results
+    as the per-question layout, bit for bit (the calibrator reads token embeddings and attention states, never the scene geometry)."""
+    a, meta = gu.load("g10_calibration")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights)
+    run_meta = meta["runs"][name]
+    base = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "tokens": [], "original_dict": None, "question": None}
+            for q in run_meta["questions"]]
+    scenes = [{"n": q["n"], "X": a["%s:X_%d" % (name, i)]} for i, q in enumerate(run_meta["questions"])]
+    qs = []
+    for rep in range(3):                                     # every question three times, on three different images out of two or three
+        for i, q in enumerate(base):
+            img = (i + rep) % min(3, len(scenes))
+            qs.append(dict(q, image_id="img%d" % img, scene=scenes[img]))
+
+    class Coll(CalibrationCollater):
+        def __init__(self, ont, share):
+            super(Coll, self).__init__(ont)
+            self._share_scenes = share
+
+    outs = []
+    for share in (False, True):
+        pbs = [pb.to_cuda(DEV) for pb in Coll(ontology, share).collate(qs)]
+        with torch.no_grad():
+            outs.append(model(pbs, False, modulator_switch=True))
+        assert (pbs[0]._question_image is not None) == share
+    assert torch.equal(outs[0]["log_probability"], outs[1]["log_probability"]), (outs[0]["log_probability"] - outs[1]["log_probability"]).abs().max()
+    assert outs[0]["answer"] == outs[1]["answer"]

@@ -186,8 +186,16 @@ def setup(args):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     td = None
-    if world > 1:
+    # DFOL_BENCH_FORCE_PG=1: a process group even at world size 1, so that a ONE-GPU box runs every collective of the N > 1 path through RCCL
+    # itself (communicator setup, barrier, all-reduce of the gradient bucket incl. the overlap hooks, all-gather of the rank report)
+    force = os.environ.get("DFOL_BENCH_FORCE_PG") == "1"
+    if world > 1 or force:
         import torch.distributed as td
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             td.init_process_group("gloo", timeout=__import__("datetime").timedelta(seconds=600))
         else:

@@ -90,7 +90,7 @@ def train_case(rank, world, out):
             loss = training.compute_loss(pbs, res) / len(qs)                   # sum / B_global (trainer.py:433-436)
             loss.backward()
             bucket.allreduce(dist.group.WORLD)
-        lt = torch.tensor([float(loss.detach())], dtype=torch.float64)
+        lt = torch.tensor([float(loss.detach())], dtype=torch.float64, device=DEV if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(lt)
         if rank == 0:                                        # (failures are collected, not raised: the peer is waiting in a collective)
             l32, l64 = float(a[name + ":loss_f32"]), float(a[name + ":loss_f64"])
@@ -108,7 +108,8 @@ def train_case(rank, world, out):
             checked[name] = n
         # the rest of the step through the product's train_batch, then compare replicas
         loss2, _ = training.train_batch(model, opt, pbs, 0.65, global_batch_size=len(qs), group=dist.group.WORLD, bucket=bucket, l1_lambda=1e-3)
-        dg = parallel.parameters_digest(model).cpu()
+        dg = parallel.parameters_digest(model)
+        dg = dg if dist.get_backend() == "nccl" else dg.cpu()
         both = [torch.zeros_like(dg) for _ in range(world)]
         dist.all_gather(both, dg)
         if not all(torch.equal(both[0], b) for b in both):
@@ -123,8 +124,13 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     import datetime
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))     # a rank that died must not hang its peer for 30 minutes
-    out = {"rank": rank, "ok": False}
+    if os.environ.get("DFOL_TEST_BACKEND") == "nccl":        # world size 1 on the one-GPU box: the collectives run through RCCL itself
+        assert world == 1
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=180))
+    else:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))     # a rank that died must not hang its peer for 30 minutes
+    out_backend = dist.get_backend()
+    out = {"rank": rank, "ok": False, "backend": out_backend}
     try:
         {"infer": infer_case, "train": train_case}[case](rank, world, out)
         out["ok"] = True

@@ -85,3 +85,33 @@ def test_bench_launches_its_own_ranks(mode):
     if mode == "train":
         assert out["replicas_equal"] is True
         assert out["allreduce_ms"] > 0
+
+
+@pytest.mark.parametrize("case,overlap", [("infer", 0), ("train", 0), ("train", 1)])
+def test_rccl_world_size_one(tmp_path, case, overlap):
+    """The same rank worker over backend "nccl" (= RCCL) with ONE rank: what a one-GPU box can run of the RCCL path - communicator
+    setup, broadcast of the parameters, the bucket all-reduce (after the backward, and as three ranges issued from the autograd hooks
+    on RCCL's own stream), all-gather of the results and of the parameter digests - with the same g12 / bit-equality checks."""
+    outs = _run_ranks(case, tmp_path, world=1, extra_env={"DFOL_TEST_BACKEND": "nccl", "DFOL_TEST_OVERLAP": str(overlap)})
+    assert outs[0]["backend"] == "nccl"
+    if case == "infer":
+        assert outs[0]["gathered"] == 12 and outs[0]["bit_equal"] and outs[0]["answers_equal"]
+    else:
+        assert all(n == 12 for n in outs[0]["g12_checked"].values()) and outs[0]["replicas_equal"]
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_over_rccl_world_size_one(mode):
+    """bench.py with DFOL_BENCH_FORCE_PG=1: the N > 1 code path (barriers, max over ranks, rank report, bucket all-reduce, replica check)
+    over RCCL with one rank."""
+    env = dict(os.environ, DFOL_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16", "--objects", "20",
+           "--cpu-sample", "0", "--stress-preds", "0", "--mode", mode, "--overlap-allreduce", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["ranks"]["backend"] == "nccl" and out["value"] > 0
+    if mode == "train":
+        assert out["replicas_equal"] is True and out["allreduce_ms"] > 0

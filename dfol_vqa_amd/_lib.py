@@ -118,6 +118,12 @@ SIGNATURES = {
     "dfol_linear_pack_w_bf16": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_bf16_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_wgrad_bias_bf16": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
+    "dfol_linear_act_bf16_bf16": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    "dfol_linear_wgrad_bias_bf16_bf16": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
+    "dfol_pair_hidden1_fwd_bf16": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "dfol_pair_hidden1_bwd_bf16": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _p],
+    "dfol_pair_logit_fwd_bf16": [_p, _i64, _i32, _p, _i64, _p, _p, _i32, _i64, _i64, _p, _p],
+    "dfol_pair_logit_bwd_bf16": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_pair_pack_w2_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_split_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                _i32, _p, _p],
@@ -427,6 +433,14 @@ def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
     bf16 = _dense_math() == "bf16"                         # the bf16 mode: operands rounded to bf16, one product (configs[3])
     M, K = x.shape
     N = weight.shape[1] if transpose_w else weight.shape[0]
+    if x.dtype == torch.bfloat16:                          # bf16-STORED activations (the per-pair tensors of a bf16-mode train step): bf16 in, bf16 out
+        if not bf16:
+            raise DfolError("linear_act_split: a bfloat16 input needs the bf16 mode (dense_math('bf16'))")
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        call("dfol_linear_act_bf16_bf16", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, transpose_w, 1), torch.bfloat16),
+             _ptr(bias, F32, True), _dp(out), out.stride(0), M, N, K, act, _stream())
+        return out
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
     call("dfol_linear_act_bf16_f32" if bf16 else "dfol_linear_act_split_f32", _dp(x), x.stride(0),
@@ -440,9 +454,10 @@ def linear_wgrad(dy, x, bias=False):
     same pass.  fp32 results on the matrix cores, deterministic (csrc/dfol_dense_wgrad.hip)."""
     M, N = dy.shape
     K = x.shape[1]
+    stored_bf16 = dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16      # the bf16 mode's bf16-stored per-pair activations
     for t in (dy, x):
-        if not t.is_cuda or t.dtype != F32 or t.stride(1) != 1:
-            raise DfolError("linear_wgrad needs fp32 GPU matrices with unit column stride")
+        if not t.is_cuda or (t.dtype != F32 and not stored_bf16) or t.stride(1) != 1:
+            raise DfolError("linear_wgrad needs fp32 (or, both, bfloat16) GPU matrices with unit column stride")
     if M == 0:                                             # a shard without rows (no object pairs): the gradient is zero, as dy.t() @ x gives
         dw = torch.zeros(N, K, dtype=F32, device=dy.device)
         return (dw, torch.zeros(N, dtype=F32, device=dy.device)) if bias else dw
@@ -453,6 +468,9 @@ def linear_wgrad(dy, x, bias=False):
     # bf16 mode: the same layers whose forward product ran on bf16 operands (linear_act: weights of >= SPLIT_MIN_WEIGHT elements); the small
     # LSTM / attention layers stay fp32 forward AND backward
     bf16 = _dense_math() == "bf16" and N * K >= SPLIT_MIN_WEIGHT
+    if stored_bf16:
+        call("dfol_linear_wgrad_bias_bf16_bf16", _dp(dy), dy.stride(0), _dp(x), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _ptr(db, F32, True), _stream())
+        return (dw, db) if bias else dw
     call("dfol_linear_wgrad_bias_bf16" if bf16 else "dfol_linear_wgrad_bias_f32", _dp(dy), dy.stride(0),
          _dp(x), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _ptr(db, F32, True), _stream())
     return (dw, db) if bias else dw
@@ -657,12 +675,21 @@ def pair_train_supported(hid1, hid2, max_n):
     return hid1 % 4 == 0 and 16 <= hid1 <= 1024 and lpr & (lpr - 1) == 0 and lpr <= 256 and hid2 <= 512 and max_n <= 16 * (1024 // lpr)
 
 
-def pair_hidden1_fwd(u, v, pos, wg, obj_off, pair_off, n_obj, max_n, pairs):
-    """z [pairs, HID1] = ELU(U[s] + V[o] + Wg geo) and geo [pairs, 4]; u, v [O, HID1] (row stride a multiple of 4), pos [O, >=4] view."""
+def bf16_store(hid1, hid2):
+    """True when a train step keeps its per-pair activations (Z, pre2 and their gradients) in bfloat16: the bf16 mode (dense_math('bf16'),
+    config key mlp_math: bf16) unless DFOL_BF16_STORE=0, widths the 8-byte-row kernels take, and a second layer large enough for the
+    matrix-pipe kernel (the same SPLIT_MIN_WEIGHT rule as the fp32-storage products)."""
+    return _dense_math() == "bf16" and os.environ.get("DFOL_BF16_STORE", "1") != "0" and hid1 % 4 == 0 and hid2 % 4 == 0 and hid2 >= 16 and \
+        hid1 * hid2 >= SPLIT_MIN_WEIGHT
+
+
+def pair_hidden1_fwd(u, v, pos, wg, obj_off, pair_off, n_obj, max_n, pairs, store=F32):
+    """z [pairs, HID1] = ELU(U[s] + V[o] + Wg geo) and geo [pairs, 4]; u, v [O, HID1] (row stride a multiple of 4), pos [O, >=4] view.
+    store = torch.bfloat16: z is stored in bfloat16 (rounded to nearest even)."""
     Q, hid1 = n_obj.shape[0], u.shape[1]
-    z = torch.empty(pairs, hid1, dtype=F32, device=u.device)
+    z = torch.empty(pairs, hid1, dtype=store, device=u.device)
     geo = torch.empty(pairs, 4, dtype=F32, device=u.device)
-    call("dfol_pair_hidden1_fwd_f32", _dp(u), u.stride(0), _dp(v), v.stride(0), _dp(pos), pos.stride(0), _ptr(wg, F32),
+    call("dfol_pair_hidden1_fwd_bf16" if store == torch.bfloat16 else "dfol_pair_hidden1_fwd_f32", _dp(u), u.stride(0), _dp(v), v.stride(0), _dp(pos), pos.stride(0), _ptr(wg, F32),
          _ptr(obj_off, I32), _ptr(pair_off, torch.int64), _ptr(n_obj, I32), Q, max_n, hid1, _ptr(z), _ptr(geo), _stream())
     return z, geo
 
@@ -673,7 +700,9 @@ def pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, max_n, total_obj):
     du = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)             # objects of images with < 2 objects get no row written
     dv = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)
     part = torch.zeros(Q, hid1, 4, dtype=F32, device=z.device)
-    call("dfol_pair_hidden1_bwd_f32", _ptr(dz, F32), _ptr(z, F32), _ptr(geo, F32), _ptr(obj_off, I32), _ptr(pair_off, torch.int64),
+    if z.dtype == torch.bfloat16 and dz.dtype != torch.bfloat16:
+        dz = dz.to(torch.bfloat16)
+    call("dfol_pair_hidden1_bwd_bf16" if z.dtype == torch.bfloat16 else "dfol_pair_hidden1_bwd_f32", _ptr(dz, z.dtype), _ptr(z, z.dtype), _ptr(geo, F32), _ptr(obj_off, I32), _ptr(pair_off, torch.int64),
          _ptr(n_obj, I32), Q, max_n, hid1, _ptr(du), du.stride(0), _ptr(dv), dv.stride(0), _ptr(part), _stream())
     return du, dv, part.sum(0)
 
@@ -682,7 +711,7 @@ def pair_logit_fwd(p2, e_rows, be_rows, pred_off, max_rows):
     """max_rows: the largest number of rows a predicate owns (host value; the launch is one row tile grid per predicate)."""
     rows, P = p2.shape[0], e_rows.shape[0]
     x = torch.empty(rows, dtype=F32, device=p2.device)
-    call("dfol_pair_logit_fwd_f32", _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0), _ptr(be_rows, F32, True),
+    call("dfol_pair_logit_fwd_bf16" if p2.dtype == torch.bfloat16 else "dfol_pair_logit_fwd_f32", _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0), _ptr(be_rows, F32, True),
          _ptr(pred_off, torch.int64), P, rows, int(max_rows), _ptr(x), _stream())
     return x
 
@@ -692,7 +721,7 @@ def pair_logit_bwd(dx, p2, e_rows, pred_off, need_bias=True):
     dp2 = torch.empty_like(p2)
     de = torch.empty(P, p2.shape[1], dtype=F32, device=p2.device)
     dbe = torch.empty(P, dtype=F32, device=p2.device) if need_bias else None
-    call("dfol_pair_logit_bwd_f32", _ptr(dx, F32), _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0),
+    call("dfol_pair_logit_bwd_bf16" if p2.dtype == torch.bfloat16 else "dfol_pair_logit_bwd_f32", _ptr(dx, F32), _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0),
          _ptr(pred_off, torch.int64), P, _dp(dp2), dp2.stride(0), _dp(de), de.stride(0), _ptr(dbe, F32, True), _stream())
     return dp2, de, dbe
 

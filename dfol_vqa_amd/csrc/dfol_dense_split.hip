@@ -105,10 +105,17 @@ __device__ __forceinline__ float ls_act(float x) {
 // batch of shared scenes 60).  An output element sees the same products in the same order whatever the block height, so the choice
 // changes no result bit (tests/test_kernels_gpu.py::test_linear_act_split_block_height_changes_no_bit) - a sharded run still equals
 // the single-process run.
-template <int ACT, int XV, int NT, int NP, int RT>
-__device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const float* __restrict__ X, int64_t ldx,
-                                        const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int M, int N,
+// BIO: bf16 storage on both sides (NP = 1 only: the bf16 mode's per-pair activations): X and Y are rows of bfloat16 (8-byte aligned rows,
+// K % 4 == 0); a thread's 8 consecutive k are two 8-byte loads that go to LDS as they are - no conversion - and the epilogue rounds the
+// fp32 accumulators to nearest even.  ldx / ldy count ELEMENTS.
+template <int ACT, int XV, int NT, int NP, int RT, bool BIO>
+__device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const void* __restrict__ Xv, int64_t ldx,
+                                        const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Yv, int64_t ldy, int M, int N,
                                         int K, int ksteps, int mb, int nb) {
+    static_assert(!BIO || NP == 1, "bf16 storage belongs to the bf16 mode");
+    typedef typename std::conditional<BIO, uint16_t, float>::type TX;
+    const TX* __restrict__ X = reinterpret_cast<const TX*>(Xv);
+    TX* __restrict__ Y = reinterpret_cast<TX*>(Yv);
     constexpr int BM = 32 * RT, RH = RT / 2;                          // rows of the block; 64-row halves staged per thread
     const int m0 = mb * BM, n0 = nb * LS_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
@@ -123,19 +130,25 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 
     // A staging: rows (tid >> 2) and (tid >> 2) + 64, k-group tid & 3 (8 consecutive k): four threads read 128 contiguous bytes
     const int arow = tid >> 2, aq = tid & 3;
-    const float* xp0 = X + (int64_t)min(m0 + arow, M - 1) * ldx + aq * 8;
-    const float* xp1 = X + (int64_t)min(m0 + arow + 64, M - 1) * ldx + aq * 8;      // (RT = 4 only)
+    const TX* xp0 = X + (int64_t)min(m0 + arow, M - 1) * ldx + aq * 8;
+    const TX* xp1 = X + (int64_t)min(m0 + arow + 64, M - 1) * ldx + aq * 8;      // (RT = 4 only)
     // X registers: two steps in flight (HBM latency is longer than one step of 96 MFMAs).  The loads are unconditional - addresses
     // clamped, out-of-range k zeroed afterwards - so that every wavefront issues exactly 4 per step and the vmcnt arithmetic below holds.
-    float4 xa[2][RH][2];                                            // [set = step parity][row half][k half]
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<BIO, u32x2, float4>::type XR;  // four consecutive k of a row as loaded
+    XR xa[2][RH][2];                                                // [set = step parity][row half][k half]
     auto load_x = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
-        const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;      // K % 4 == 0: a float4 is wholly in or out
-        auto ld4 = [&](const float* p) __attribute__((always_inline)) {
-            if (XV == 4) return *reinterpret_cast<const float4*>(p);
-            const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
-            return make_float4(lo.x, lo.y, hi.x, hi.y);
+        const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;      // K % 4 == 0: a group of four is wholly in or out
+        auto ld4 = [&](const TX* p) __attribute__((always_inline)) {
+            if constexpr (BIO) {
+                return *reinterpret_cast<const u32x2*>(p);
+            } else {
+                if (XV == 4) return *reinterpret_cast<const float4*>(p);
+                const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 2);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
         };
         xa[S][0][0] = ld4(xp0 + c0);
         xa[S][0][1] = ld4(xp0 + c1);
@@ -147,20 +160,26 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     auto store_a = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int h = 0; h < RH; ++h) {
             const int row = arow + 64 * h;
-            const float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
             const int at = row * 4 + (aq ^ ls_swz(row));
-            if (NP == 1) {
-                As[at] = u32x4{ls_rne2(v0.x, v0.y), ls_rne2(v0.z, v0.w), ls_rne2(v1.x, v1.y), ls_rne2(v1.z, v1.w)};
+            if constexpr (BIO) {
+                const u32x2 zz = u32x2{0u, 0u};
+                const u32x2 v0 = k < K ? xa[S][h][0] : zz, v1 = k + 4 < K ? xa[S][h][1] : zz;
+                As[at] = u32x4{v0.x, v0.y, v1.x, v1.y};
             } else {
-                u32x4 ph, pm, pl;
-                ls_split8(v0, v1, ph, pm, pl);
-                As[at] = ph;
-                As[BM * 4 + at] = pm;
-                As[2 * BM * 4 + at] = pl;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
+                if (NP == 1) {
+                    As[at] = u32x4{ls_rne2(v0.x, v0.y), ls_rne2(v0.z, v0.w), ls_rne2(v1.x, v1.y), ls_rne2(v1.z, v1.w)};
+                } else {
+                    u32x4 ph, pm, pl;
+                    ls_split8(v0, v1, ph, pm, pl);
+                    As[at] = ph;
+                    As[BM * 4 + at] = pm;
+                    As[2 * BM * 4 + at] = pl;
+                }
             }
         }
     };
@@ -252,14 +271,18 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     float bv[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[min(n0 + wn * WN + j * 16 + r16, N - 1)] : 0.f;
-    float* yp = Y + (int64_t)(m0 + wm * (16 * RT) + 4 * kh) * ldy + n0 + wn * WN + r16;
+    TX* yp = Y + (int64_t)(m0 + wm * (16 * RT) + 4 * kh) * ldy + n0 + wn * WN + r16;
+    auto out = [](float v) __attribute__((always_inline)) {
+        if constexpr (BIO) return (uint16_t)ls_rne2(v, 0.f);
+        else return v;
+    };
     if (NT == 4 && m0 + BM <= M && n0 + LS_BN <= N) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = ls_act<ACT>(acc[i][j][e] + bv[j]);
+                for (int j = 0; j < NT; ++j) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = out(ls_act<ACT>(acc[i][j][e] + bv[j]));
     } else {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -269,15 +292,15 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const float v = ls_act<ACT>(acc[i][j][e] + bv[j]);
-                    if (row_ok && n0 + wn * WN + j * 16 + r16 < N) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = v;
+                    if (row_ok && n0 + wn * WN + j * 16 + r16 < N) yp[(int64_t)(i * 16 + e) * ldy + j * 16] = out(v);
                 }
             }
     }
 }
 
-template <int ACT, int XV, int NP, int RT>
+template <int ACT, int XV, int NP, int RT, bool BIO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, RT == 2 ? 3 : 2))) void linear_act_split_kernel(
-    const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
+    const void* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Y,
     int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
     __shared__ __attribute__((aligned(16))) u32x4 As[3 * 32 * RT * 4];      // [piece][row][k-group]  24 KB (12 KB for 64-row blocks)
     __shared__ __attribute__((aligned(16))) u32x4 Bs[LS_TILE_PIECES];       // the B tile of the step  24 KB
@@ -286,8 +309,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, RT == 2 
     int bid = blockIdx.x;
     if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     const int mb = bid / nbn, nb = bid - mb * nbn;
-    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
-    else ls_tile<ACT, XV, 2, NP, RT>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    else ls_tile<ACT, XV, 2, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
 }
 
 }  // namespace
@@ -369,4 +392,35 @@ extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void
 extern "C" int dfol_linear_act_bf16_f32(const float* X, int64_t ldx, const void* W_bf16, const float* bias, float* Y, int64_t ldy,
                                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     return ls_launch<1>(X, ldx, W_bf16, bias, Y, ldy, M, N, K, act, stream);
+}
+
+// bf16 storage on both sides (the bf16 mode's per-pair activations: Z -> pre2 and dpre2 -> dZ): X [M, K] and Y [M, N] bfloat16, rows 8-byte
+// aligned (ldx, ldy in elements, multiples of 4), no activation other than the four the fp32-storage kernel has; fp32 accumulation and bias
+extern "C" int dfol_linear_act_bf16_bf16(const void* X_bf16, int64_t ldx, const void* W_bf16, const float* bias, void* Y_bf16, int64_t ldy,
+                                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    DFOL_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && ldy >= N, "linear_act_bf16_bf16: bad sizes M=%d N=%d K=%d (K %% 4, ldx %% 4)", M, N, K);
+    if (M == 0) return 0;
+    DFOL_REQUIRE(X_bf16 && W_bf16 && Y_bf16, "linear_act_bf16_bf16: null pointer");
+    DFOL_REQUIRE(((uintptr_t)X_bf16 % 8 == 0) && ((uintptr_t)W_bf16 % 16 == 0) && ((uintptr_t)Y_bf16 % 2 == 0), "linear_act_bf16_bf16: X must be 8-byte and W 16-byte aligned");
+    const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
+    static const int force_bm = getenv("DFOL_DENSE_BM") ? atoi(getenv("DFOL_DENSE_BM")) : 0;
+    const bool small = force_bm ? force_bm == 64 : (int64_t)dfol_cdiv(M, LS_BM) * nbn < 512;
+    const int nbm = dfol_cdiv(M, small ? 64 : LS_BM);
+    DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_act_bf16_bf16: too many tiles");
+    const int nblocks = nbm * nbn;
+#define DFOL_LSB(A)                                                                                                                             \
+    if (small) hipLaunchKernelGGL((linear_act_split_kernel<A, 4, 1, 2, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X_bf16, ldx,  \
+                                  (const u32x4*)W_bf16, bias, Y_bf16, ldy, M, N, K, ksteps, nbn, nblocks);                                      \
+    else hipLaunchKernelGGL((linear_act_split_kernel<A, 4, 1, 4, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X_bf16, ldx,        \
+                            (const u32x4*)W_bf16, bias, Y_bf16, ldy, M, N, K, ksteps, nbn, nblocks)
+    switch (act) {
+        case DFOL_ACT_NONE: DFOL_LSB(DFOL_ACT_NONE); break;
+        case DFOL_ACT_SIGMOID: DFOL_LSB(DFOL_ACT_SIGMOID); break;
+        case DFOL_ACT_ELU: DFOL_LSB(DFOL_ACT_ELU); break;
+        case DFOL_ACT_LOGSIGMOID: DFOL_LSB(DFOL_ACT_LOGSIGMOID); break;
+        default: DFOL_REQUIRE(false, "linear_act_bf16_bf16: unknown activation %d", act);
+    }
+#undef DFOL_LSB
+    DFOL_LAUNCH_CHECK("linear_act_bf16_bf16");
+    return 0;
 }

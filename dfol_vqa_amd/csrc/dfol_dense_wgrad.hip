@@ -252,7 +252,7 @@ __device__ __forceinline__ void w3_split8(const float (&v)[8], w3_u32x4& h, w3_u
 typedef uint32_t w3_u32x2 __attribute__((ext_vector_type(2)));
 
 // (every input through readfirstlane: hipcc wraps each buffer load in a waterfall loop unless the descriptor is provably wave-uniform)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t w3_descriptor(const float* base, int64_t bytes) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w3_descriptor(const void* base, int64_t bytes) {
     const uint64_t p = reinterpret_cast<uint64_t>(base);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
     const int n = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffff ? bytes : 0x7fffffff));
@@ -358,8 +358,90 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const float* __restrict__ d
     }
 }
 
+// The same with dY and X STORED as bfloat16 (the bf16 mode's per-pair activations: dpre2 [pairs, HID2] and Z [pairs, HID1]): a lane loads
+// AV resp. 4 consecutive bf16 of its eight rows (8- / 4-byte buffer loads), and an operand register pair is two rows' halves of one word
+// (v_perm_b32) - no conversions, no rounding, half the bytes.  The bias sums widen the same registers to fp32.
 template <int AV, int NP>
-__device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int rows,
+__device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict__ dY, int64_t ld_dy, const uint16_t* __restrict__ X, int64_t ld_x,
+                                                     int rows, int steps, int N, int K, int n0, int k0, int lane, bool want_bias,
+                                                     f32x16 (&acc)[AV][4], float (&bs)[AV]) {
+    static_assert(NP == 1, "bf16 storage belongs to the bf16 mode");
+    constexpr int WA = AV / 2;                                                     // 32-bit words of dY per row and lane
+    const int col = lane & 31, half = lane >> 5;
+    const int ca = min(n0 + AV * col, N - AV), cb = min(k0 + 4 * col, K - 4);
+    int va[8], vb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        va[r] = (int)(((8 * half + r) * ld_dy + ca) * 2);
+        vb[r] = (int)(((8 * half + r) * ld_x + cb) * 2);
+    }
+#pragma unroll
+    for (int t = 0; t < AV; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < AV; ++t) bs[t] = 0.f;
+
+    uint32_t ra[8][WA];
+    w3_u32x2 rb[8];
+    auto load = [&](int s) __attribute__((always_inline)) {
+        const int left = rows - 16 * s;
+        const int64_t bytes_a = left > 0 ? ((int64_t)(left - 1) * ld_dy + N) * 2 : 0, bytes_b = left > 0 ? ((int64_t)(left - 1) * ld_x + K) * 2 : 0;
+        const auto da = w3_descriptor(dY + (int64_t)s * 16 * ld_dy, bytes_a), db = w3_descriptor(X + (int64_t)s * 16 * ld_x, bytes_b);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (AV == 4) {
+                const w3_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(da, va[r], 0, 0);
+                ra[r][0] = v.x, ra[r][WA - 1] = v.y;
+            } else {
+                ra[r][0] = __builtin_amdgcn_raw_buffer_load_b32(da, va[r], 0, 0);
+            }
+            rb[r] = __builtin_amdgcn_raw_buffer_load_b64(db, vb[r], 0, 0);
+        }
+    };
+    // eight rows' element `odd` of one word each -> the operand's four registers (row 2j in the low half)
+    auto gather = [](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, bool odd)
+        __attribute__((always_inline)) {
+        return odd ? w3_u32x4{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u),
+                              __builtin_amdgcn_perm(w5, w4, 0x07060302u), __builtin_amdgcn_perm(w7, w6, 0x07060302u)}
+                   : w3_u32x4{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u),
+                              __builtin_amdgcn_perm(w5, w4, 0x05040100u), __builtin_amdgcn_perm(w7, w6, 0x05040100u)};
+    };
+    load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < steps; ++s) {
+        w3_u32x4 ap[AV], bp[4];
+        if (want_bias) {
+#pragma unroll
+            for (int t = 0; t < AV; ++t) {
+                float f[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) f[r] = __uint_as_float((t & 1) ? (ra[r][t >> 1] & 0xffff0000u) : (ra[r][t >> 1] << 16));
+                bs[t] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < AV; ++t)
+            ap[t] = gather(ra[0][t >> 1], ra[1][t >> 1], ra[2][t >> 1], ra[3][t >> 1], ra[4][t >> 1], ra[5][t >> 1], ra[6][t >> 1], ra[7][t >> 1], t & 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            bp[u] = gather(rb[0][u >> 1], rb[1][u >> 1], rb[2][u >> 1], rb[3][u >> 1], rb[4][u >> 1], rb[5][u >> 1], rb[6][u >> 1], rb[7][u >> 1], u & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < AV; ++t)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w3_bf16x8, ap[t]), __builtin_bit_cast(w3_bf16x8, bp[u]), acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int AV, int NP, typename TIN>
+__device__ __forceinline__ void wgrad_tn3_block(const TIN* __restrict__ dY, int64_t ld_dy, const TIN* __restrict__ X, int64_t ld_x, int rows,
                                                 int steps, int N, int K, int n0, int k0, int lane, int role, float* __restrict__ lds,
                                                 float* __restrict__ out, float* __restrict__ db_out) {
     // role 0: accumulate and store; 1: accumulate, add the partner's accumulators from `lds`, store; 2: accumulate into `lds` (the partner)
@@ -414,9 +496,9 @@ __device__ __forceinline__ void wgrad_tn3_block(const float* __restrict__ dY, in
 constexpr int W3_LDS_SLOT = 64 * (256 + 4);        // floats a row-half partner hands over: 256 accumulators and 4 bias sums per lane
 
 // grid (row slabs, groups of four blocks); dynamic LDS: two slots when the last group splits its rows (see the launcher), else none
-template <int NP>
+template <int NP, typename TIN = float>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_tn3_kernel(
-    const float* __restrict__ dY, int64_t ld_dy, const float* __restrict__ X, int64_t ld_x, int M, int N, int K, int rows_per_slab, int nb_k,
+    const TIN* __restrict__ dY, int64_t ld_dy, const TIN* __restrict__ X, int64_t ld_x, int M, int N, int K, int rows_per_slab, int nb_k,
     int nb, float* __restrict__ part, float* __restrict__ db_part) {
     extern __shared__ float w3_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -445,10 +527,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* out = part + (int64_t)blockIdx.x * ((((int64_t)N * K) + 3) & ~(int64_t)3);
     float* lds = w3_lds + (split ? wave - half_id * in_group : 0) * W3_LDS_SLOT;   // wavefronts w and w + in_group: the same block, one slot
     float* db_out = db_part ? db_part + (int64_t)blockIdx.x * ((N + 3) & ~3) : nullptr;
-    const float* a = dY + (int64_t)m_first * ld_dy;
-    const float* b = X + (int64_t)m_first * ld_x;
-    if (N - n0 > 64) wgrad_tn3_block<4, NP>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
-    else wgrad_tn3_block<2, NP>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
+    const TIN* a = dY + (int64_t)m_first * ld_dy;
+    const TIN* b = X + (int64_t)m_first * ld_x;
+    if (N - n0 > 64) wgrad_tn3_block<4, NP, TIN>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
+    else wgrad_tn3_block<2, NP, TIN>(a, ld_dy, b, ld_x, rows, steps, N, K, n0, k0, lane, role, lds, out, db_out);
 }
 
 // dW[e] = sum over the slabs in a fixed order: a workgroup takes 16 groups of four elements x 16 slab phases (phase p adds slabs p,
@@ -594,4 +676,36 @@ extern "C" int dfol_linear_wgrad_bias_bf16(const float* dY, int64_t ld_dy, const
 extern "C" int dfol_linear_wgrad_f32(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
                                      float* workspace, float* dW, void* stream) {
     return wgrad_launch(dY, ld_dy, X, ld_x, M, N, K, workspace, dW, nullptr, stream, false);
+}
+
+// bf16 mode with bf16 STORAGE of both operands (the per-pair activations dpre2 [M, N] and Z [M, K] as bfloat16, rows 4-byte / 8-byte
+// aligned: ld_dy % 2 == 0, ld_x % 4 == 0 in elements, N and K multiples of 4): one product per pair, fp32 accumulation, fp32 dW and db.
+extern "C" int dfol_linear_wgrad_bias_bf16_bf16(const void* dY_bf16, int64_t ld_dy, const void* X_bf16, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                                float* workspace, float* dW, float* db, void* stream) {
+    DFOL_REQUIRE(M > 0 && M < (1ll << 31) && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0, "linear_wgrad_bf16_bf16: bad sizes M=%lld N=%d K=%d (N, K multiples of 4)",
+                 (long long)M, N, K);
+    DFOL_REQUIRE(dY_bf16 && X_bf16 && workspace && dW, "linear_wgrad_bf16_bf16: null pointer");
+    DFOL_REQUIRE(ld_dy % 4 == 0 && ld_x % 4 == 0 && ((uintptr_t)dY_bf16 % 8 == 0) && ((uintptr_t)X_bf16 % 8 == 0), "linear_wgrad_bf16_bf16: rows must be 8-byte aligned");
+    float* db_part = db ? workspace + (int64_t)dfol_linear_wgrad_slabs(M, N, K) * ((((int64_t)N * K) + 3) & ~(int64_t)3) : nullptr;
+    const int nb_k = dfol_cdiv(K, 128), nb = dfol_cdiv(N, 128) * nb_k;
+    const int slabs = wgrad_tn3_slabs(M, nb);
+    const int rows_per_slab = (dfol_cdiv(M, slabs) + 15) & ~15;
+    DFOL_REQUIRE(16 * std::max(ld_dy, ld_x) * 2 < (1ll << 31), "linear_wgrad_bf16_bf16: row stride too large (%lld)", (long long)std::max(ld_dy, ld_x));
+    const int groups = dfol_cdiv(nb, 4);
+    const size_t lds = nb % 4 == 1 || nb % 4 == 2 ? 2 * W3_LDS_SLOT * sizeof(float) : 0;
+    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)wgrad_tn3_kernel<1, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         2 * W3_LDS_SLOT * sizeof(float));
+    DFOL_REQUIRE(lds_ok == hipSuccess, "linear_wgrad_bf16_bf16: cannot reserve 130 KB of LDS (%s)", hipGetErrorString(lds_ok));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((wgrad_tn3_kernel<1, uint16_t>), dim3(slabs, groups), dim3(256), lds, st, (const uint16_t*)dY_bf16, ld_dy, (const uint16_t*)X_bf16,
+                       ld_x, (int)M, N, K, rows_per_slab, nb_k, nb, workspace, db_part);
+    DFOL_LAUNCH_CHECK("linear_wgrad_bf16_bf16");
+    const int64_t elems = (int64_t)N * K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 16)), dim3(256), 0, st, workspace, slabs, elems, dW);
+    DFOL_LAUNCH_CHECK("linear_wgrad_bf16_bf16 (reduce)");
+    if (db) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(N, 4), 16)), dim3(256), 0, st, db_part, slabs, (int64_t)N, db);
+        DFOL_LAUNCH_CHECK("linear_wgrad_bf16_bf16 (bias reduce)");
+    }
+    return 0;
 }

@@ -32,6 +32,26 @@ __device__ __forceinline__ float4 ld4_stream(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// bf16 storage of the per-pair activations (the bf16 mode, BASELINE configs[3]: Z, pre2 and their gradients are the 14 GB a train step
+// moves): the same streams over 2-byte elements, arithmetic in fp32 registers as before.  `pt_bf16` = the bits of a bfloat16.
+typedef uint16_t pt_bf16;
+typedef uint32_t pt_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pt_rne2(float x0, float x1) {                 // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(pt_f32x2{x0, x1}, pt_bf16x2));
+}
+__device__ __forceinline__ float4 pt_widen(const pt_u32x2& v) {
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld4(const pt_bf16* p) { return pt_widen(*reinterpret_cast<const pt_u32x2*>(p)); }
+__device__ __forceinline__ float4 ld4_stream(const pt_bf16* p) { return pt_widen(__builtin_nontemporal_load(reinterpret_cast<const pt_u32x2*>(p))); }
+__device__ __forceinline__ void st4_stream(pt_bf16* p, const float4& v) {
+    __builtin_nontemporal_store(pt_u32x2{pt_rne2(v.x, v.y), pt_rne2(v.z, v.w)}, reinterpret_cast<pt_u32x2*>(p));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const pt_bf16* p) { return __uint_as_float((uint32_t)*p << 16); }
+
 __device__ __forceinline__ float4 pair_geometry(const float* ps, const float* po) {      // batch_gqa_boxfeatures_pipeline.py:263-279
     const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
     const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
@@ -56,10 +76,11 @@ __global__ __launch_bounds__(256) void pair_geometry_kernel(const float* __restr
 // (four at a time: their loads are issued together), a lane owns 4 hidden units whose geometry weights stay in registers
 constexpr int HF_ROWS = 16;
 
+template <typename TZ>
 __global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __restrict__ U, int64_t ld_u, const float* __restrict__ V,
                                                                 int64_t ld_v, const float* __restrict__ Wg, const int32_t* __restrict__ obj_off,
                                                                 const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
-                                                                int H1, float* __restrict__ Z, const float* __restrict__ geo) {
+                                                                int H1, TZ* __restrict__ Z, const float* __restrict__ geo) {
     const int q = blockIdx.y, n = n_obj[q], lpr = H1 >> 2, slots = 256 / lpr;
     const int slot = (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4;
     const int rows = n * (n - 1);
@@ -96,7 +117,8 @@ __global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __re
 constexpr int HB_MAXO = 16;                                   // objects per lane group in hidden1_bwd
 
 // one workgroup (1024 threads = G groups of H1 / 4 lanes) per image
-__global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const float* __restrict__ dZ, const float* __restrict__ Z,
+template <typename TZ>
+__global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const TZ* __restrict__ dZ, const TZ* __restrict__ Z,
                                                                  const float* __restrict__ geo, const int32_t* __restrict__ obj_off,
                                                                  const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
                                                                  int H1, float* __restrict__ dU, int64_t ld_du, float* __restrict__ dV,
@@ -170,7 +192,8 @@ __global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const float* __r
 constexpr int LG_T = 8;                                       // hidden units per lane: H2 <= 512
 
 // grid (row tiles, P): a workgroup covers 16 consecutive rows of one predicate, a wavefront 4 of them (four independent load streams)
-__global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const float* __restrict__ P2, int64_t ld_p2, int H2,
+template <typename TP>
+__global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const TP* __restrict__ P2, int64_t ld_p2, int H2,
                                                               const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be,
                                                               const int64_t* __restrict__ pred_off, float* __restrict__ x) {
     const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -184,9 +207,39 @@ __global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const float* __rest
             const float ev = E[(int64_t)p * ld_e + j];
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = P2[min(row0 + i, r1 - 1) * ld_p2 + j];
+            for (int i = 0; i < 4; ++i) v[i] = ld1(P2 + min(row0 + i, r1 - 1) * ld_p2 + j);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = fmaf(pt_sigmoid(v[i]), ev, acc[i]);
+        }
+    }
+    const float b = be ? be[p] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float sum = dfol_wave_sum(acc[i]);
+        if (lane == 0 && row0 + i < r1) x[row0 + i] = sum + b;
+    }
+}
+
+// The same with four consecutive hidden units per lane and load (H2 % 4 == 0; the bf16 storage's form: 8-byte loads)
+template <typename TP>
+__global__ __launch_bounds__(256) void pair_logit_fwd4_kernel(const TP* __restrict__ P2, int64_t ld_p2, int H2,
+                                                               const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be,
+                                                               const int64_t* __restrict__ pred_off, float* __restrict__ x) {
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, F4 = H2 >> 2;
+    const int64_t r1 = pred_off[p + 1], row0 = pred_off[p] + (int64_t)blockIdx.x * 16 + wave * 4;
+    if (row0 >= r1) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < LG_T / 4; ++t) {
+        const int j4 = lane + 64 * t;
+        if (j4 < F4) {
+            const float4 ev = ld4(E + (int64_t)p * ld_e + 4 * j4);
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld4_stream(P2 + min(row0 + i, r1 - 1) * ld_p2 + 4 * j4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = fmaf(pt_sigmoid(v[i].x), ev.x, fmaf(pt_sigmoid(v[i].y), ev.y, fmaf(pt_sigmoid(v[i].z), ev.z, fmaf(pt_sigmoid(v[i].w), ev.w, acc[i]))));
         }
     }
     const float b = be ? be[p] : 0.f;
@@ -201,9 +254,10 @@ __global__ __launch_bounds__(256) void pair_logit_fwd_kernel(const float* __rest
 // array of float4 (F4 = H2 / 4 per row); RG = 1024 / F4 rows are covered per trip by RG * F4 active threads, thread t always on
 // float4 t % F4 of its row, so its share of dE stays in four registers and every load / store of the workgroup is one contiguous
 // block (975 x 16 bytes for H2 = 300).  Two trips are in flight.  The RG row groups are combined through LDS in a fixed order.
-__global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __restrict__ dx, const float* __restrict__ P2, int64_t ld_p2,
+template <typename TP>
+__global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __restrict__ dx, const TP* __restrict__ P2, int64_t ld_p2,
                                                                 int H2, const float* __restrict__ E, int64_t ld_e,
-                                                                const int64_t* __restrict__ pred_off, float* __restrict__ dP2,
+                                                                const int64_t* __restrict__ pred_off, TP* __restrict__ dP2,
                                                                 int64_t ld_dp2, float* __restrict__ dE, int64_t ld_de,
                                                                 float* __restrict__ dbe) {
     extern __shared__ __attribute__((aligned(16))) float red4[];           // [RG][H2] floats (+ RG for the bias)
@@ -310,9 +364,10 @@ bool hidden_width_ok(int H1) { return H1 >= 16 && H1 <= 1024 && H1 % 4 == 0 && 1
 
 }  // namespace
 
-extern "C" int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos,
-                                         const float* Wg, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q,
-                                         int32_t max_n, int32_t H1, float* Z, float* geo, void* stream) {
+template <typename TZ>
+static int hidden1_fwd_launch(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos, const float* Wg,
+                              const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t H1, TZ* Z,
+                              float* geo, void* stream) {
     DFOL_REQUIRE(hidden_width_ok(H1), "pair_hidden1_fwd: HID1=%d must be 16..1024 with HID1/4 a power of two <= 256", H1);
     DFOL_REQUIRE(ld_u % 4 == 0 && ld_v % 4 == 0 && Q >= 0 && max_n >= 0, "pair_hidden1_fwd: rows of U and V must be 16-byte aligned");
     if (Q == 0 || max_n < 2) return 0;
@@ -322,25 +377,49 @@ extern "C" int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const flo
                        obj_off, pair_off, n_obj, geo);
     DFOL_LAUNCH_CHECK("pair_hidden1_fwd (geometry)");
     const dim3 grid(dfol_cdiv((int64_t)max_n * (max_n - 1), rows_per_block * HF_ROWS), Q);
-    hipLaunchKernelGGL(pair_hidden1_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, U, ld_u, V, ld_v, Wg, obj_off, pair_off, n_obj, H1, Z,
+    hipLaunchKernelGGL(pair_hidden1_fwd_kernel<TZ>, grid, dim3(256), 0, (hipStream_t)stream, U, ld_u, V, ld_v, Wg, obj_off, pair_off, n_obj, H1, Z,
                        geo);
     DFOL_LAUNCH_CHECK("pair_hidden1_fwd");
     return 0;
 }
 
-extern "C" int dfol_pair_hidden1_bwd_f32(const float* dZ, const float* Z, const float* geo, const int32_t* obj_off, const int64_t* pair_off,
-                                         const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t H1, float* dU, int64_t ld_du, float* dV,
-                                         int64_t ld_dv, float* dWg_partial, void* stream) {
+extern "C" int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos,
+                                         const float* Wg, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q,
+                                         int32_t max_n, int32_t H1, float* Z, float* geo, void* stream) {
+    return hidden1_fwd_launch<float>(U, ld_u, V, ld_v, pos, ld_pos, Wg, obj_off, pair_off, n_obj, Q, max_n, H1, Z, geo, stream);
+}
+extern "C" int dfol_pair_hidden1_fwd_bf16(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos,
+                                          const float* Wg, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q,
+                                          int32_t max_n, int32_t H1, void* Z_bf16, float* geo, void* stream) {
+    return hidden1_fwd_launch<pt_bf16>(U, ld_u, V, ld_v, pos, ld_pos, Wg, obj_off, pair_off, n_obj, Q, max_n, H1, (pt_bf16*)Z_bf16, geo, stream);
+}
+
+template <typename TZ>
+static int hidden1_bwd_launch(const TZ* dZ, const TZ* Z, const float* geo, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj,
+                              int32_t Q, int32_t max_n, int32_t H1, float* dU, int64_t ld_du, float* dV, int64_t ld_dv, float* dWg_partial,
+                              void* stream) {
     DFOL_REQUIRE(hidden_width_ok(H1), "pair_hidden1_bwd: HID1=%d must be 16..1024 with HID1/4 a power of two <= 256", H1);
     const int G = 1024 / (H1 / 4);
     DFOL_REQUIRE(max_n <= HB_MAXO * G, "pair_hidden1_bwd: max_n=%d exceeds %d objects per image at HID1=%d", max_n, HB_MAXO * G, H1);
     DFOL_REQUIRE(ld_du % 4 == 0 && ld_dv % 4 == 0, "pair_hidden1_bwd: rows of dU and dV must be 16-byte aligned");
     if (Q == 0) return 0;
     DFOL_REQUIRE(dZ && Z && geo && obj_off && pair_off && n_obj && dU && dV && dWg_partial, "pair_hidden1_bwd: null pointer");
-    hipLaunchKernelGGL(pair_hidden1_bwd_kernel, dim3(Q), dim3(1024), (size_t)G * H1 * sizeof(float), (hipStream_t)stream, dZ, Z, geo, obj_off,
+    hipLaunchKernelGGL(pair_hidden1_bwd_kernel<TZ>, dim3(Q), dim3(1024), (size_t)G * H1 * sizeof(float), (hipStream_t)stream, dZ, Z, geo, obj_off,
                        pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
     DFOL_LAUNCH_CHECK("pair_hidden1_bwd");
     return 0;
+}
+
+extern "C" int dfol_pair_hidden1_bwd_f32(const float* dZ, const float* Z, const float* geo, const int32_t* obj_off, const int64_t* pair_off,
+                                         const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t H1, float* dU, int64_t ld_du, float* dV,
+                                         int64_t ld_dv, float* dWg_partial, void* stream) {
+    return hidden1_bwd_launch<float>(dZ, Z, geo, obj_off, pair_off, n_obj, Q, max_n, H1, dU, ld_du, dV, ld_dv, dWg_partial, stream);
+}
+extern "C" int dfol_pair_hidden1_bwd_bf16(const void* dZ_bf16, const void* Z_bf16, const float* geo, const int32_t* obj_off,
+                                          const int64_t* pair_off, const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t H1, float* dU,
+                                          int64_t ld_du, float* dV, int64_t ld_dv, float* dWg_partial, void* stream) {
+    return hidden1_bwd_launch<pt_bf16>((const pt_bf16*)dZ_bf16, (const pt_bf16*)Z_bf16, geo, obj_off, pair_off, n_obj, Q, max_n, H1, dU, ld_du, dV,
+                                       ld_dv, dWg_partial, stream);
 }
 
 extern "C" int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e, const float* be,
@@ -350,9 +429,28 @@ extern "C" int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t H
     DFOL_REQUIRE(P2 && E && pred_off && x, "pair_logit_fwd: null pointer");
     DFOL_REQUIRE(max_rows > 0 && max_rows <= rows && (max_rows + 15) / 16 < ((int64_t)1 << 31) && P < 65536,
                  "pair_logit_fwd: max_rows=%lld must be the largest row count of a predicate (P < 65536)", (long long)max_rows);
-    hipLaunchKernelGGL(pair_logit_fwd_kernel, dim3((unsigned)dfol_cdiv(max_rows, 16), P), dim3(256), 0, (hipStream_t)stream, P2, ld_p2, H2, E,
+    hipLaunchKernelGGL(pair_logit_fwd_kernel<float>, dim3((unsigned)dfol_cdiv(max_rows, 16), P), dim3(256), 0, (hipStream_t)stream, P2, ld_p2, H2, E,
                        ld_e, be, pred_off, x);
     DFOL_LAUNCH_CHECK("pair_logit_fwd");
+    return 0;
+}
+
+// bf16 storage of pre2 / dpre2: HID2 % 4 == 0, rows 8-byte aligned (ld % 4 == 0), E rows 16-byte aligned
+static bool logit_bf16_ok(const void* P2, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e) {
+    return H2 % 4 == 0 && H2 >= 16 && H2 <= 64 * LG_T && ld_p2 % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)P2 % 8 == 0) && ((uintptr_t)E % 16 == 0);
+}
+
+extern "C" int dfol_pair_logit_fwd_bf16(const void* P2_bf16, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e, const float* be,
+                                        const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream) {
+    DFOL_REQUIRE(P >= 0 && rows >= 0, "pair_logit_fwd_bf16: bad sizes");
+    if (rows == 0 || P == 0) return 0;
+    DFOL_REQUIRE(P2_bf16 && E && pred_off && x, "pair_logit_fwd_bf16: null pointer");
+    DFOL_REQUIRE(logit_bf16_ok(P2_bf16, ld_p2, H2, E, ld_e), "pair_logit_fwd_bf16: HID2=%d must be a multiple of 4 in 16..%d, rows 8-byte aligned", H2, 64 * LG_T);
+    DFOL_REQUIRE(max_rows > 0 && max_rows <= rows && (max_rows + 15) / 16 < ((int64_t)1 << 31) && P < 65536,
+                 "pair_logit_fwd_bf16: max_rows=%lld must be the largest row count of a predicate (P < 65536)", (long long)max_rows);
+    hipLaunchKernelGGL(pair_logit_fwd4_kernel<pt_bf16>, dim3((unsigned)dfol_cdiv(max_rows, 16), P), dim3(256), 0, (hipStream_t)stream,
+                       (const pt_bf16*)P2_bf16, ld_p2, H2, E, ld_e, be, pred_off, x);
+    DFOL_LAUNCH_CHECK("pair_logit_fwd_bf16");
     return 0;
 }
 
@@ -365,12 +463,27 @@ extern "C" int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t
     if (H2 % 4 == 0 && H2 >= 16 && ld_p2 % 4 == 0 && ld_dp2 % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)P2 % 16 == 0) && ((uintptr_t)dP2 % 16 == 0) &&
         ((uintptr_t)E % 16 == 0)) {
         const int RG = 1024 / (H2 / 4);
-        hipLaunchKernelGGL(pair_logit_bwd4_kernel, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx, P2, ld_p2, H2,
+        hipLaunchKernelGGL(pair_logit_bwd4_kernel<float>, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx, P2, ld_p2, H2,
                            E, ld_e, pred_off, dP2, ld_dp2, dE, ld_de, dbe);
     } else {
         hipLaunchKernelGGL(pair_logit_bwd_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, dx, P2, ld_p2, H2, E, ld_e, pred_off, dP2, ld_dp2,
                            dE, ld_de, dbe);
     }
     DFOL_LAUNCH_CHECK("pair_logit_bwd");
+    return 0;
+}
+
+extern "C" int dfol_pair_logit_bwd_bf16(const float* dx, const void* P2_bf16, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e,
+                                        const int64_t* pred_off, int32_t P, void* dP2_bf16, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe,
+                                        void* stream) {
+    DFOL_REQUIRE(P >= 0, "pair_logit_bwd_bf16: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE(dx && P2_bf16 && E && pred_off && dP2_bf16 && dE, "pair_logit_bwd_bf16: null pointer");
+    DFOL_REQUIRE(logit_bf16_ok(P2_bf16, ld_p2, H2, E, ld_e) && ld_dp2 % 4 == 0 && ((uintptr_t)dP2_bf16 % 8 == 0),
+                 "pair_logit_bwd_bf16: HID2=%d must be a multiple of 4 in 16..%d, rows 8-byte aligned", H2, 64 * LG_T);
+    const int RG = 1024 / (H2 / 4);
+    hipLaunchKernelGGL(pair_logit_bwd4_kernel<pt_bf16>, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx,
+                       (const pt_bf16*)P2_bf16, ld_p2, H2, E, ld_e, pred_off, (pt_bf16*)dP2_bf16, ld_dp2, dE, ld_de, dbe);
+    DFOL_LAUNCH_CHECK("pair_logit_bwd_bf16");
     return 0;
 }

@@ -199,8 +199,8 @@ class _TallLinear(torch.autograd.Function):
 
     @staticmethod
     def _split_ok(x2, k):
-        return x2.is_cuda and x2.dtype == torch.float32 and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and \
-            _lib._dense_math() != "f32"
+        return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and \
+            (x2.dtype == torch.float32 and _lib._dense_math() != "f32" or x2.dtype == torch.bfloat16 and _lib._dense_math() == "bf16")
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -221,6 +221,8 @@ class _TallLinear(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, g):
         x, weight = ctx.saved_tensors
+        if g.dtype != x.dtype:                               # (bf16-stored activations: the gradient arrives in the output's dtype already)
+            g = g.to(x.dtype)
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         gx = None
         if ctx.needs_input_grad[0]:
@@ -231,7 +233,7 @@ class _TallLinear(torch.autograd.Function):
                 gx = (g2 @ weight).view_as(x)
         gw = gb = None
         if ctx.needs_input_grad[1]:
-            if g2.is_cuda and g2.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch":
+            if g2.is_cuda and (g2.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch" or g2.dtype == torch.bfloat16):
                 # dY^T X over millions of rows: the deterministic TN kernel (csrc/dfol_dense_wgrad.hip); the bias gradient is the
                 # column sums of the dY rows it loads anyway (a separate sum over 3 GB costs 0.75 ms)
                 gw = L.linear_wgrad(g2 if g2.stride(-1) == 1 else g2.contiguous(), x2 if x2.stride(-1) == 1 else x2.contiguous(),
@@ -255,9 +257,9 @@ class _FusedHidden1(torch.autograd.Function):
     backward, instead of the scatter-adds of the gathers (the largest single item of a ragged train step)."""
 
     @staticmethod
-    def forward(ctx, U, V, Wg, pos, world):
+    def forward(ctx, U, V, Wg, pos, world, store=torch.float32):
         max_n = max(world._n_list)
-        z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num)
+        z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num, store)
         # (the world itself must not hang on the graph: world -> cached activations -> graph -> world would be a reference cycle that
         # only the garbage collector frees, 3 GB per step)
         ctx.save_for_backward(z, geo, world._obj_off, world._pair_off, world._n_obj)
@@ -268,7 +270,7 @@ class _FusedHidden1(torch.autograd.Function):
     def backward(ctx, dz):
         z, geo, obj_off, pair_off, n_obj = ctx.saved_tensors
         du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj)
-        return du, dv, dwg, None, None
+        return du, dv, dwg, None, None, None
 
 
 class _FusedLogit(torch.autograd.Function):
@@ -492,7 +494,10 @@ class ClassifierOracle(OracleBase):
                 V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
             pos = obj[:, D - 4:].detach()                       # batch_gqa_boxfeatures_pipeline.py:263-279
             if self._fused_training(world) and U.shape[1] % 4 == 0:
-                z = _FusedHidden1.apply(U.contiguous(), V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(), pos, world)
+                # bf16 mode: Z, pre2 and their gradients live in bfloat16 (what autocast stores; half the bytes of the step's streams and
+                # of the two tall products' operands) - csrc/dfol_pair_train.hip, dfol_linear_act_bf16_bf16, dfol_linear_wgrad_bias_bf16_bf16
+                store = torch.bfloat16 if L.bf16_store(lin1.weight.shape[0], lin2.weight.shape[0]) else torch.float32
+                z = _FusedHidden1.apply(U.contiguous(), V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(), pos, world, store)
             else:
                 s_idx, o_idx = world.pair_index()
                 ps, po = pos.index_select(0, s_idx), pos.index_select(0, o_idx)
@@ -509,7 +514,7 @@ class ClassifierOracle(OracleBase):
     def _pair_hidden_autograd(self, world):
         """h = Sigmoid(pre2) [pairs, HID2]; shared by all relation operators of the scene."""
         if world._pair_h is None:
-            world._pair_h = torch.sigmoid(self._pair_pre2_autograd(world))
+            world._pair_h = torch.sigmoid(self._pair_pre2_autograd(world).float())
         return world._pair_h
 
     def _pair_hidden_dense(self, world, n):

@@ -242,6 +242,12 @@ int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, 
 int dfol_linear_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_bf16, void* stream);
 int dfol_linear_act_bf16_f32(const float* X, int64_t ldx, const void* W_bf16, const float* bias, float* Y, int64_t ldy, int32_t M,
                              int32_t N, int32_t K, int32_t act, void* stream);
+/* The bf16 mode with bf16 STORAGE on both sides: X [M, K] and Y [M, N] are rows of bfloat16 (ldx, ldy in elements; K % 4 == 0, ldx % 4 == 0,
+ * X 8-byte aligned), fp32 accumulation and bias, the result rounded to nearest even.  What torch.autocast(bfloat16) makes of the same
+ * nn.Linear line (gqa_interpreter_experiments.py:26-33, 73-74): used for the per-pair activations of a train step in the bf16 mode
+ * (Z -> pre2 and dpre2 -> dZ), which are 14 of the 17 GB an fp32-storage step moves. */
+int dfol_linear_act_bf16_bf16(const void* X_bf16, int64_t ldx, const void* W_bf16, const float* bias, void* Y_bf16, int64_t ldy, int32_t M,
+                              int32_t N, int32_t K, int32_t act, void* stream);
 
 
 /* Box positional features: replaces batch_gqa_boxfeatures_pipeline.py:208-211.
@@ -390,6 +396,20 @@ int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t HID2, const 
                             const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream);
 int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
                             const int64_t* pred_off, int32_t P, float* dP2, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe, void* stream);
+/* The same four stages over bf16-STORED per-pair activations (the bf16 mode, BASELINE configs[3]): Z, dZ, P2 and dP2 are rows of
+ * bfloat16 (row strides in elements, multiples of 4; HID2 % 4 == 0), everything per object / per predicate stays fp32, the arithmetic
+ * runs in fp32 registers and results are rounded to nearest even when stored.  Same formulas and reference lines as above. */
+int dfol_pair_hidden1_fwd_bf16(const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* pos, int64_t ld_pos, const float* Wg,
+                               const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t HID1,
+                               void* Z_bf16, float* geo, void* stream);
+int dfol_pair_hidden1_bwd_bf16(const void* dZ_bf16, const void* Z_bf16, const float* geo, const int32_t* obj_off, const int64_t* pair_off,
+                               const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t HID1, float* dU, int64_t ld_du, float* dV,
+                               int64_t ld_dv, float* dWg_partial, void* stream);
+int dfol_pair_logit_fwd_bf16(const void* P2_bf16, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
+                             const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream);
+int dfol_pair_logit_bwd_bf16(const float* dx, const void* P2_bf16, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
+                             const int64_t* pred_off, int32_t P, void* dP2_bf16, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe,
+                             void* stream);
 
 /* Weight gradient of a dense layer, dW [N, K] = dY^T X with dY [M, N] (row stride ld_dy) and X [M, K] (row stride ld_x): what torch
  * autograd computes for nn.Linear (gqa_interpreter_experiments.py:26-33, 73-74 under trainer.py:436).  fp32 results on the matrix
@@ -409,6 +429,10 @@ int dfol_linear_wgrad_bias_f32(const float* dY, int64_t ld_dy, const float* X, i
  * an fp32 sum.  Same workspace. */
 int dfol_linear_wgrad_bias_bf16(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int64_t M, int32_t N, int32_t K,
                                 float* workspace, float* dW, float* db, void* stream);
+/* ... with both operands STORED as bfloat16 (dpre2 [M, N] and Z [M, K] of the bf16 mode; ld in elements, multiples of 4; N, K multiples
+ * of 4): no rounding left to do, one product, fp32 accumulation, fp32 dW and db.  Same workspace. */
+int dfol_linear_wgrad_bias_bf16_bf16(const void* dY_bf16, int64_t ld_dy, const void* X_bf16, int64_t ld_x, int64_t M, int32_t N, int32_t K,
+                                     float* workspace, float* dW, float* db, void* stream);
 
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B (the reference gets them from torch autograd through

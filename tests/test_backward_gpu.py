@@ -587,10 +587,16 @@ def test_bf16_mode_dense_kernels_are_bf16_operands_fp32_accumulation(M, N, K, ac
     assert ((db.double() - dz.double().sum(0)).abs() / dz.double().abs().sum(0)).max().item() <= 2e-6      # the bias gradient stays fp32
 
 
-def test_bf16_mode_train_step_close_to_fp32_and_repeatable():
+@pytest.mark.parametrize("store", ["1", "0"])
+def test_bf16_mode_train_step_close_to_fp32_and_repeatable(store, monkeypatch):
     """A full-size model trains with `mlp_math: bf16` (experiment config key): the step's loss is within 1 % of the fp32 step's, every
-    weight gradient points the same way (cosine > 0.99), two bf16 steps from the same state are bit-identical, and the default stays fp32."""
+    weight gradient points the same way (cosine > 0.99), two bf16 steps from the same state are bit-identical, and the default stays fp32.
+    store = 1 (default): the per-pair activations and their gradients are STORED in bfloat16 too; 0: fp32 storage (DFOL_BF16_STORE=0)."""
     import importlib.util
+    monkeypatch.setenv("DFOL_BF16_STORE", store)
+    from dfol_vqa_amd import ops as dops                  # (visual_oracle calls the wrappers through this namespace)
+    stores, real = [], dops.pair_hidden1_fwd
+    monkeypatch.setattr(dops, "pair_hidden1_fwd", lambda *a, **k: (stores.append(a[9] if len(a) > 9 else k.get("store", torch.float32)), real(*a, **k))[1])
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
@@ -605,6 +611,7 @@ def test_bf16_mode_train_step_close_to_fp32_and_repeatable():
         loss, _ = training.train_batch(model, opt, pbs, clip_norm=0.65)
         grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
         runs.setdefault(math, []).append((loss, grads))
+    assert stores == [torch.float32] + [torch.bfloat16 if store == "1" else torch.float32] * 2, stores
     (l32, g32), (lb, gb), (lb2, gb2) = runs["fp32"][0], runs["bf16"][0], runs["bf16"][1]
     assert abs(lb - l32) <= 1e-2 * abs(l32), (lb, l32)
     assert lb != l32                                                        # the mode changes the arithmetic
@@ -614,3 +621,80 @@ def test_bf16_mode_train_step_close_to_fp32_and_repeatable():
             continue
         cos = torch.nn.functional.cosine_similarity(g32[k].flatten().double(), gb[k].flatten().double(), dim=0).item()
         assert cos > 0.99, (k, cos)
+
+
+# bf16 STORAGE of the per-pair activations in the bf16 mode (Z, pre2 and their gradients): every kernel against its fp32-storage form
+def _pair_geometry(Q, n_lo, n_hi, seed):
+    rng = np.random.RandomState(seed)
+    n = rng.randint(n_lo, n_hi + 1, Q).astype(np.int32)
+    obj_off = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int32)
+    cnt = n.astype(np.int64) * (n - 1)
+    pair_off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    t = lambda a: torch.as_tensor(a).to(DEV)
+    return n, t(n), t(obj_off), t(pair_off), int(n.sum()), int(cnt.sum()), cnt
+
+
+@pytest.mark.parametrize("H1,H2", [(256, 300), (64, 32)])
+def test_bf16_storage_stream_kernels_equal_fp32_storage_kernels_on_the_same_values(H1, H2):
+    from dfol_vqa_amd import _lib
+    BF = torch.bfloat16
+    n, n_obj, obj_off, pair_off, O, pairs, cnt = _pair_geometry(9, 2, 23, 5)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    U = torch.randn(O, H1, device=DEV, generator=g)
+    V = torch.randn(O, H1, device=DEV, generator=g)
+    pos = torch.rand(O, 4, device=DEV, generator=g)
+    Wg = torch.randn(H1, 4, device=DEV, generator=g) * 0.3
+    max_n = int(n.max())
+    z32, geo32 = _lib.pair_hidden1_fwd(U, V, pos, Wg, obj_off, pair_off, n_obj, max_n, pairs)
+    zb, geob = _lib.pair_hidden1_fwd(U, V, pos, Wg, obj_off, pair_off, n_obj, max_n, pairs, store=BF)
+    assert zb.dtype == BF and torch.equal(zb, z32.to(BF)) and torch.equal(geob, geo32)          # the fp32 value, rounded to nearest even
+    dzb = torch.randn(pairs, H1, device=DEV, generator=g).to(BF)
+    got = _lib.pair_hidden1_bwd(dzb, zb, geob, obj_off, pair_off, n_obj, max_n, O)
+    want = _lib.pair_hidden1_bwd(dzb.float(), zb.float(), geob, obj_off, pair_off, n_obj, max_n, O)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)                                                                # same fp32 arithmetic on the same values
+    # one predicate per image, in order
+    P = len(n)
+    pred_off = torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(DEV)
+    p2b = (torch.randn(pairs, H2, device=DEV, generator=g) * 3).to(BF)
+    E = torch.randn(P, H2, device=DEV, generator=g)
+    be = torch.randn(P, device=DEV, generator=g)
+    xb = _lib.pair_logit_fwd(p2b, E, be, pred_off, int(cnt.max()))
+    x32 = _lib.pair_logit_fwd(p2b.float(), E, be, pred_off, int(cnt.max()))
+    ref = (torch.sigmoid(p2b.double()) * E.double().repeat_interleave(torch.as_tensor(cnt).to(DEV), 0)).sum(1) + be.double().repeat_interleave(torch.as_tensor(cnt).to(DEV), 0)
+    assert (xb.double() - ref).abs().max().item() <= 2 * (x32.double() - ref).abs().max().item() + 1e-6      # (another summation order)
+    dx = torch.randn(pairs, device=DEV, generator=g)
+    dpb, deb, dbb = _lib.pair_logit_bwd(dx, p2b, E, pred_off)
+    dp32, de32, db32 = _lib.pair_logit_bwd(dx, p2b.float(), E, pred_off)
+    assert dpb.dtype == BF and torch.equal(dpb, dp32.to(BF)) and torch.equal(deb, de32) and torch.equal(dbb, db32)
+
+
+@pytest.mark.parametrize("M,N,K", [(9000, 300, 256), (5000, 256, 300), (4100, 128, 64), (130, 512, 516)])
+def test_bf16_storage_dense_kernels_equal_the_bf16_mode_on_widened_operands(M, N, K):
+    """bf16 in / bf16 out product == the bf16 mode's fp32-storage kernel on the same (exactly representable) operands, rounded to nearest
+    even; the weight gradient from bf16-stored dY and X == the bf16 mode's on the widened operands, bit for bit (no rounding happens)."""
+    from dfol_vqa_amd import _lib
+    BF = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    xb = torch.randn(M, K, device=DEV, generator=g).to(BF)
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    for act in (0, 2):
+        with _lib.dense_math("bf16"):
+            yb = _lib.linear_act_split(xb, w, b, act)
+            y32 = _lib.linear_act_split(xb.float(), w, b, act)
+        assert yb.dtype == BF and torch.equal(yb, y32.to(BF))
+    dyb = torch.randn(M, N, device=DEV, generator=g).to(BF)
+    with _lib.dense_math("bf16"):
+        gxb = _lib.linear_act_split(dyb, w, None, 0, transpose_w=True)
+        gx32 = _lib.linear_act_split(dyb.float(), w, None, 0, transpose_w=True)
+        dwb, dbb = _lib.linear_wgrad(dyb, xb, bias=True)
+        dw32, db32 = _lib.linear_wgrad(dyb.float(), xb.float(), bias=True)
+    assert torch.equal(gxb, gx32.to(BF))
+    if N * K >= _lib.SPLIT_MIN_WEIGHT:                                      # (smaller layers: the fp32-storage weight gradient stays fp32 arithmetic)
+        assert torch.equal(dwb, dw32) and torch.equal(dbb, db32)
+    ref = dyb.double().t() @ xb.double()
+    assert (dwb.double() - ref).abs().max().item() <= 2e-6 * (dyb.double().abs().t() @ xb.double().abs()).max().item()
+    assert (dbb.double() - dyb.double().sum(0)).abs().max().item() <= 2e-6 * dyb.double().abs().sum(0).max().item()
+    with pytest.raises(Exception):
+        _lib.linear_act_split(xb, w, b, 0)                                 # bf16-stored input outside the bf16 mode: refused

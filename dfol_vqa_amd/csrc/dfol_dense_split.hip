@@ -35,7 +35,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LS_BM = 128, LS_BN = 128, LS_BK = 32;
-constexpr int LS_TILE_PIECES = 3 * LS_BN * 4;               // 16-byte pieces of one B tile (24 KB)
 
 __device__ __forceinline__ int ls_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 __device__ __forceinline__ void ls_split(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
@@ -271,11 +270,32 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     float bv[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[min(n0 + wn * WN + j * 16 + r16, N - 1)] : 0.f;
+    if constexpr (BIO) {
+        // bf16 output: 2-byte stores straight from the accumulator layout (16 lanes x 2 bytes per row and instruction) cost a third of the
+        // kernel (1.02 ms against 0.73 without any store); the tile goes through LDS instead - the step loop's last barrier has freed it - and
+        // leaves as 8-byte pieces, 32 consecutive threads on the 256 contiguous bytes of a row (N % 4 == 0: a piece is wholly in or out).
+        constexpr int PITCH = LS_BN + 8;                                  // halfwords per staged row (272 bytes: 8-byte aligned, rows 4 banks apart)
+        uint16_t* stage = reinterpret_cast<uint16_t*>(As);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    stage[(wm * (16 * RT) + i * 16 + 4 * kh + e) * PITCH + wn * WN + j * 16 + r16] = (uint16_t)ls_rne2(ls_act<ACT>(acc[i][j][e] + bv[j]), 0.f);
+        __syncthreads();
+        typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+        const int cols = min(N - n0, NT == 4 ? LS_BN : 2 * WN);           // valid columns of this block
+#pragma unroll
+        for (int it = 0; it < BM * (LS_BN / 4) / 256; ++it) {
+            const int c = tid + 256 * it, row = c / (LS_BN / 4), cc = c % (LS_BN / 4);
+            if (m0 + row < M && 4 * cc < cols)
+                *reinterpret_cast<u32x2s*>(Y + (int64_t)(m0 + row) * ldy + n0 + 4 * cc) = *reinterpret_cast<const u32x2s*>(stage + row * PITCH + 4 * cc);
+        }
+        return;
+    }
     TX* yp = Y + (int64_t)(m0 + wm * (16 * RT) + 4 * kh) * ldy + n0 + wn * WN + r16;
-    auto out = [](float v) __attribute__((always_inline)) {
-        if constexpr (BIO) return (uint16_t)ls_rne2(v, 0.f);
-        else return v;
-    };
+    auto out = [](float v) __attribute__((always_inline)) { return v; };
     if (NT == 4 && m0 + BM <= M && n0 + LS_BN <= N) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -298,12 +318,22 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     }
 }
 
+#ifndef DFOL_BIO_WAVES
+#define DFOL_BIO_WAVES 3
+#endif
+// (bf16 storage: a tile of K = 256 is 8 steps of 16 MFMAs per wavefront, so the two ends of a tile - cold start, stores - outweigh its
+// steps; the one-piece tiles are 16 KB of LDS and the lighter register set fits three workgroups per CU.  Measured at 256 x 100 objects,
+// forward / input-gradient product: 2 per CU 1.23 / 1.10 ms, 3 per CU 1.13 / 1.09 ms, 4 per CU (128 registers: 88 spilled) 1.26 / 1.56 ms)
 template <int ACT, int XV, int NP, int RT, bool BIO = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, RT == 2 ? 3 : 2))) void linear_act_split_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIO ? DFOL_BIO_WAVES : 2, BIO ? DFOL_BIO_WAVES : (RT == 2 ? 3 : 2)))) void linear_act_split_kernel(
     const void* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Y,
     int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
-    __shared__ __attribute__((aligned(16))) u32x4 As[3 * 32 * RT * 4];      // [piece][row][k-group]  24 KB (12 KB for 64-row blocks)
-    __shared__ __attribute__((aligned(16))) u32x4 Bs[LS_TILE_PIECES];       // the B tile of the step  24 KB
+    constexpr int LP = BIO ? 1 : 3;                                         // (the fp32-storage kernels keep their 48 KB whatever NP: same occupancy as before)
+    constexpr int A_PIECES = LP * 32 * RT * 4, B_PIECES = LP * LS_BN * 4;   // [piece][row][k-group] 24 KB (12 KB for 64-row blocks); the B tile of the step 24 KB
+    constexpr int STAGE_PIECES = BIO ? 32 * RT * (LS_BN + 8) * 2 / 16 : 0;  // bf16 storage: the output tile staged for its stores (34 KB / 17 KB)
+    __shared__ __attribute__((aligned(16))) u32x4 Sm[A_PIECES + B_PIECES > STAGE_PIECES ? A_PIECES + B_PIECES : STAGE_PIECES];
+    u32x4* As = Sm;
+    u32x4* Bs = Sm + A_PIECES;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so id % 8 is the XCD; give each XCD a contiguous run of
     // logical tiles (column blocks of a row block are consecutive): the X rows are fetched into that XCD's L2 once
     int bid = blockIdx.x;

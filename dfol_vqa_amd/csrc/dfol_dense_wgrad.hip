@@ -18,6 +18,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
+#ifndef W3B_D
+#define W3B_D 4                 // steps of rows in flight in the bf16-storage weight gradient (1..4)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int TN, int TK>
@@ -384,9 +390,13 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict_
 #pragma unroll
     for (int t = 0; t < AV; ++t) bs[t] = 0.f;
 
-    uint32_t ra[8][WA];
-    w3_u32x2 rb[8];
-    auto load = [&](int s) __attribute__((always_inline)) {
+    // A step is 16 MFMAs here (512 cycles of pipe) against the 96 of the three-piece kernel: one step of loads in flight does not cover
+    // HBM latency any more, so the rows of W3B_D steps ahead are (a ring of register sets, 32 registers each).
+    constexpr int D = W3B_D;
+    uint32_t ra[D][8][WA];
+    w3_u32x2 rb[D][8];
+    auto load = [&](int s, auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
         const int left = rows - 16 * s;
         const int64_t bytes_a = left > 0 ? ((int64_t)(left - 1) * ld_dy + N) * 2 : 0, bytes_b = left > 0 ? ((int64_t)(left - 1) * ld_x + K) * 2 : 0;
         const auto da = w3_descriptor(dY + (int64_t)s * 16 * ld_dy, bytes_a), db = w3_descriptor(X + (int64_t)s * 16 * ld_x, bytes_b);
@@ -394,11 +404,11 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict_
         for (int r = 0; r < 8; ++r) {
             if (AV == 4) {
                 const w3_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(da, va[r], 0, 0);
-                ra[r][0] = v.x, ra[r][WA - 1] = v.y;
+                ra[S][r][0] = v.x, ra[S][r][WA - 1] = v.y;
             } else {
-                ra[r][0] = __builtin_amdgcn_raw_buffer_load_b32(da, va[r], 0, 0);
+                ra[S][r][0] = __builtin_amdgcn_raw_buffer_load_b32(da, va[r], 0, 0);
             }
-            rb[r] = __builtin_amdgcn_raw_buffer_load_b64(db, vb[r], 0, 0);
+            rb[S][r] = __builtin_amdgcn_raw_buffer_load_b64(db, vb[r], 0, 0);
         }
     };
     // eight rows' element `odd` of one word each -> the operand's four registers (row 2j in the low half)
@@ -409,27 +419,28 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict_
                    : w3_u32x4{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u),
                               __builtin_amdgcn_perm(w5, w4, 0x05040100u), __builtin_amdgcn_perm(w7, w6, 0x05040100u)};
     };
-    load(0);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < steps; ++s) {
+    auto one_step = [&](int s, auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
         w3_u32x4 ap[AV], bp[4];
         if (want_bias) {
 #pragma unroll
             for (int t = 0; t < AV; ++t) {
                 float f[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) f[r] = __uint_as_float((t & 1) ? (ra[r][t >> 1] & 0xffff0000u) : (ra[r][t >> 1] << 16));
+                for (int r = 0; r < 8; ++r) f[r] = __uint_as_float((t & 1) ? (ra[S][r][t >> 1] & 0xffff0000u) : (ra[S][r][t >> 1] << 16));
                 bs[t] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
             }
         }
 #pragma unroll
         for (int t = 0; t < AV; ++t)
-            ap[t] = gather(ra[0][t >> 1], ra[1][t >> 1], ra[2][t >> 1], ra[3][t >> 1], ra[4][t >> 1], ra[5][t >> 1], ra[6][t >> 1], ra[7][t >> 1], t & 1);
+            ap[t] = gather(ra[S][0][t >> 1], ra[S][1][t >> 1], ra[S][2][t >> 1], ra[S][3][t >> 1], ra[S][4][t >> 1], ra[S][5][t >> 1], ra[S][6][t >> 1],
+                           ra[S][7][t >> 1], t & 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            bp[u] = gather(rb[0][u >> 1], rb[1][u >> 1], rb[2][u >> 1], rb[3][u >> 1], rb[4][u >> 1], rb[5][u >> 1], rb[6][u >> 1], rb[7][u >> 1], u & 1);
+            bp[u] = gather(rb[S][0][u >> 1], rb[S][1][u >> 1], rb[S][2][u >> 1], rb[S][3][u >> 1], rb[S][4][u >> 1], rb[S][5][u >> 1], rb[S][6][u >> 1],
+                           rb[S][7][u >> 1], u & 1);
         __builtin_amdgcn_sched_barrier(0);
-        load(s + 1);
+        load(s + D, set_tag);                                                      // (past the range: zero bytes, nothing fetched)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -437,6 +448,17 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict_
             for (int t = 0; t < AV; ++t)
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w3_bf16x8, ap[t]), __builtin_bit_cast(w3_bf16x8, bp[u]), acc[t][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    load(0, std::integral_constant<int, 0>());
+    if constexpr (D > 1) load(1, std::integral_constant<int, 1>());
+    if constexpr (D > 2) load(2, std::integral_constant<int, 2>());
+    if constexpr (D > 3) load(3, std::integral_constant<int, 3>());
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < steps; s += D) {                                           // (steps past the range multiply zero rows: exact zeros)
+        one_step(s, std::integral_constant<int, 0>());
+        if constexpr (D > 1) one_step(s + 1, std::integral_constant<int, 1>());
+        if constexpr (D > 2) one_step(s + 2, std::integral_constant<int, 2>());
+        if constexpr (D > 3) one_step(s + 3, std::integral_constant<int, 3>());
     }
 }
 

@@ -14,6 +14,8 @@
 // Rows are the reference's ordered pairs: image-major, subject-major, the diagonal left out (util.py:87-103).
 #include "dfol_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -116,42 +118,71 @@ __global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __re
 
 constexpr int HB_MAXO = 16;                                   // objects per lane group in hidden1_bwd
 
-// one workgroup (1024 threads = G groups of H1 / 4 lanes) per image
-template <typename TZ>
-__global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const TZ* __restrict__ dZ, const TZ* __restrict__ Z,
-                                                                 const float* __restrict__ geo, const int32_t* __restrict__ obj_off,
-                                                                 const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
-                                                                 int H1, float* __restrict__ dU, int64_t ld_du, float* __restrict__ dV,
-                                                                 int64_t ld_dv, float* __restrict__ dWg_partial) {
+// One workgroup (THREADS = G groups of H1 / 4 lanes) per image; a group's lanes walk the objects o = g, g + G, ... (MAXO slots) of every
+// subject s.  THREADS = 1024, BATCH = 1: a slot's loads sit inside the branch that tests the slot, i.e. every slot is a full memory round
+// trip (s_waitcnt vmcnt(0) in each: seven in a row per subject at 100 objects) and only the 16 wavefronts of the CU overlap them; 128
+// registers per lane leave no room for more (batching the loads there spills in the loop: 1.95 ms against 0.8).  THREADS = 512 (images of up
+// to MAXO * G = 128 objects at HID1 = 256): 256 registers per lane, the loads of BATCH slots are issued together without branches (rows that do
+// not exist are clamped to one that does and masked out of the sums).
+template <typename TZ, int THREADS, int MAXO, int BATCH>
+__global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __restrict__ dZ, const TZ* __restrict__ Z,
+                                                                    const float* __restrict__ geo, const int32_t* __restrict__ obj_off,
+                                                                    const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
+                                                                    int H1, float* __restrict__ dU, int64_t ld_du, float* __restrict__ dV,
+                                                                    int64_t ld_dv, float* __restrict__ dWg_partial) {
     extern __shared__ __attribute__((aligned(16))) float red[];            // [G][H1] floats
-    const int q = blockIdx.x, n = n_obj[q], lpr = H1 >> 2, G = 1024 / lpr;
+    const int q = blockIdx.x, n = n_obj[q], lpr = H1 >> 2, G = THREADS / lpr;
     const int g = (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4, first = obj_off[q];
     const int64_t base = pair_off[q];
-    float4 dv[HB_MAXO];
+    float4 dv[MAXO];
     float dwg[4][4];
 #pragma unroll
-    for (int i = 0; i < HB_MAXO; ++i) dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < MAXO; ++i) dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int d = 0; d < 4; ++d) dwg[t][d] = 0.f;
+    auto add = [&](int i, const float4& dz, const float4& z, const float4& ge, float4& du) __attribute__((always_inline)) {
+        const float4 dp = make_float4(dz.x * (z.x > 0.f ? 1.f : z.x + 1.f), dz.y * (z.y > 0.f ? 1.f : z.y + 1.f),
+                                      dz.z * (z.z > 0.f ? 1.f : z.z + 1.f), dz.w * (z.w > 0.f ? 1.f : z.w + 1.f));
+        du.x += dp.x, du.y += dp.y, du.z += dp.z, du.w += dp.w;
+        dv[i].x += dp.x, dv[i].y += dp.y, dv[i].z += dp.z, dv[i].w += dp.w;
+        const float gd[4] = {ge.x, ge.y, ge.z, ge.w}, dpv[4] = {dp.x, dp.y, dp.z, dp.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dwg[t][d] = fmaf(dpv[t], gd[d], dwg[t][d]);
+    };
     for (int s = 0; s < n; ++s) {
         float4 du = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (BATCH == 1) {
 #pragma unroll
-        for (int i = 0; i < HB_MAXO; ++i) {
-            const int o = g + i * G;
-            if (o < n && o != s) {
-                const int64_t row = base + (int64_t)s * (n - 1) + (o - (o > s));
-                const float4 dz = ld4_stream(dZ + row * H1 + k), z = ld4_stream(Z + row * H1 + k), ge = ld4(geo + row * 4);
-                const float4 dp = make_float4(dz.x * (z.x > 0.f ? 1.f : z.x + 1.f), dz.y * (z.y > 0.f ? 1.f : z.y + 1.f),
-                                              dz.z * (z.z > 0.f ? 1.f : z.z + 1.f), dz.w * (z.w > 0.f ? 1.f : z.w + 1.f));
-                du.x += dp.x, du.y += dp.y, du.z += dp.z, du.w += dp.w;
-                dv[i].x += dp.x, dv[i].y += dp.y, dv[i].z += dp.z, dv[i].w += dp.w;
-                const float gd[4] = {ge.x, ge.y, ge.z, ge.w}, dpv[4] = {dp.x, dp.y, dp.z, dp.w};
+            for (int i = 0; i < MAXO; ++i) {
+                const int o = g + i * G;
+                if (o < n && o != s) {
+                    const int64_t row = base + (int64_t)s * (n - 1) + (o - (o > s));
+                    add(i, ld4_stream(dZ + row * H1 + k), ld4_stream(Z + row * H1 + k), ld4(geo + row * 4), du);
+                }
+            }
+        } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int i0 = 0; i0 < MAXO; i0 += BATCH) {
+                if (i0 * G >= n) continue;                       // (workgroup-uniform: no slot of this batch holds an object)
+                float4 dz[BATCH], z[BATCH], ge[BATCH];
+                bool live[BATCH];
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) dwg[t][d] = fmaf(dpv[t], gd[d], dwg[t][d]);
+                for (int j = 0; j < BATCH; ++j) {
+                    const int o = g + (i0 + j) * G;
+                    live[j] = o < n && o != s;
+                    const int64_t row = base + (live[j] ? (int64_t)s * (n - 1) + (o - (o > s)) : 0);     // (row `base` exists: n >= 2 here)
+                    dz[j] = ld4_stream(dZ + row * H1 + k), z[j] = ld4_stream(Z + row * H1 + k), ge[j] = ld4(geo + row * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {
+                    const float m = live[j] ? 1.f : 0.f;         // (a dead slot adds exact zeros)
+                    add(i0 + j, make_float4(m * dz[j].x, m * dz[j].y, m * dz[j].z, m * dz[j].w), z[j], ge[j], du);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         st4(&red[g * H1 + k], du);                           // sum over the groups (= over o) in a fixed order
@@ -167,7 +198,7 @@ __global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const TZ* __rest
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < HB_MAXO; ++i) {
+    for (int i = 0; i < MAXO; ++i) {
         const int o = g + i * G;
         if (o < n) st4(dV + (int64_t)(first + o) * ld_dv + k, dv[i]);
     }
@@ -189,6 +220,9 @@ __global__ __launch_bounds__(1024) void pair_hidden1_bwd_kernel(const TZ* __rest
     }
 }
 
+#ifndef LGB_RF16
+#define LGB_RF16 8
+#endif
 constexpr int LG_T = 8;                                       // hidden units per lane: H2 <= 512
 
 // grid (row tiles, P): a workgroup covers 16 consecutive rows of one predicate, a wavefront 4 of them (four independent load streams)
@@ -276,17 +310,18 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __re
         if (j4 == 0) db += g;
     };
     if (act) {
-        for (int64_t row = r0 + rg; row < r1; row += 4 * RG) {           // four rows in flight per thread (rows past the end: clamped loads)
-            float4 v[4];
-            float g[4];
+        constexpr int RF = sizeof(TP) == 2 ? LGB_RF16 : 4;              // rows in flight per thread (half the bytes per row in bf16: twice the rows)
+        for (int64_t row = r0 + rg; row < r1; row += RF * RG) {          // (rows past the end: clamped loads)
+            float4 v[RF];
+            float g[RF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RF; ++i) {
                 const int64_t r = min(row + (int64_t)i * RG, r1 - 1);
                 v[i] = ld4_stream(P2 + r * ld_p2 + 4 * j4);
                 g[i] = dx[r];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RF; ++i)
                 if (row + (int64_t)i * RG < r1) one(row + (int64_t)i * RG, v[i], g[i]);
         }
         st4(&red4[rg * H2 + 4 * j4], de);
@@ -404,8 +439,15 @@ static int hidden1_bwd_launch(const TZ* dZ, const TZ* Z, const float* geo, const
     DFOL_REQUIRE(ld_du % 4 == 0 && ld_dv % 4 == 0, "pair_hidden1_bwd: rows of dU and dV must be 16-byte aligned");
     if (Q == 0) return 0;
     DFOL_REQUIRE(dZ && Z && geo && obj_off && pair_off && n_obj && dU && dV && dWg_partial, "pair_hidden1_bwd: null pointer");
-    hipLaunchKernelGGL(pair_hidden1_bwd_kernel<TZ>, dim3(Q), dim3(1024), (size_t)G * H1 * sizeof(float), (hipStream_t)stream, dZ, Z, geo, obj_off,
-                       pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
+    // the 512-thread form when the image fits its object slots and the width gives it whole wavefront groups (DFOL_H1B_THREADS=1024 forces the other)
+    static const int force = getenv("DFOL_H1B_THREADS") ? atoi(getenv("DFOL_H1B_THREADS")) : 0;
+    const int G5 = 512 / (H1 / 4);
+    if (force != 1024 && H1 / 4 <= 512 && G5 >= 1 && max_n <= HB_MAXO * G5)
+        hipLaunchKernelGGL((pair_hidden1_bwd_kernel<TZ, 512, HB_MAXO, 4>), dim3(Q), dim3(512), (size_t)G5 * H1 * sizeof(float), (hipStream_t)stream, dZ, Z,
+                           geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
+    else
+        hipLaunchKernelGGL((pair_hidden1_bwd_kernel<TZ, 1024, HB_MAXO, 1>), dim3(Q), dim3(1024), (size_t)G * H1 * sizeof(float), (hipStream_t)stream, dZ, Z,
+                           geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
     DFOL_LAUNCH_CHECK("pair_hidden1_bwd");
     return 0;
 }

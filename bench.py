@@ -690,7 +690,8 @@ def attach_traffic(out, args):
                 return v["fetch_bytes_x2"] + v.get("write_bytes", 0.0)      # (a kernel whose WRITE_SIZE pass recorded nothing: < 1 KiB per XCD counter tick)
         return None
 
-    if "pair_ll" in out["roofline"]["kernel"] and args.objects == 100 and args.batch == 256:
+    same_shape = args.workload == "north_star" and args.objects == 100 and args.batch == 256 and not args.ragged and args.questions_per_image == 1
+    if "pair_ll" in out["roofline"]["kernel"] and same_shape:              # (the counters were collected on the default command only)
         out["roofline"]["traffic"] = total("pair_ll32s_kernel" if "32s" in out["roofline"]["kernel"] else "pair_ll32b_kernel") or total("pair_ll16")
         out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
     for k in out["kernels"]:

@@ -199,8 +199,9 @@ class _TallLinear(torch.autograd.Function):
 
     @staticmethod
     def _split_ok(x2, k):
-        return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and \
-            (x2.dtype == torch.float32 and _lib._dense_math() != "f32" or x2.dtype == torch.bfloat16 and _lib._dense_math() == "bf16")
+        if x2.dtype == torch.bfloat16:                       # bf16-stored activations exist in the bf16 mode only, and only this kernel takes them
+            return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and _lib._dense_math() == "bf16"
+        return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and x2.dtype == torch.float32 and _lib._dense_math() != "f32"
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -211,6 +212,8 @@ class _TallLinear(torch.autograd.Function):
             w = weight.detach()
             return L.linear_act_split(x2, w if w.is_contiguous() else w.contiguous(), None if bias is None else bias.detach(),
                                       L.ACT_NONE).view(*x.shape[:-1], weight.shape[0])
+        if x.dtype != weight.dtype:                          # (a bf16-stored input the kernel cannot take: compute in fp32, store as it came)
+            return nn.functional.linear(x.to(weight.dtype), weight, bias).to(x.dtype)
         return nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -230,7 +233,7 @@ class _TallLinear(torch.autograd.Function):
             if _TallLinear._split_ok(g2c, g2c.shape[1]):
                 gx = L.linear_act_split(g2c, weight.detach(), None, L.ACT_NONE, transpose_w=True).view_as(x)
             else:
-                gx = (g2 @ weight).view_as(x)
+                gx = (g2.to(weight.dtype) @ weight).to(x.dtype).view_as(x)
         gw = gb = None
         if ctx.needs_input_grad[1]:
             if g2.is_cuda and (g2.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch" or g2.dtype == torch.bfloat16):

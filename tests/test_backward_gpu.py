@@ -587,8 +587,8 @@ def test_bf16_mode_dense_kernels_are_bf16_operands_fp32_accumulation(M, N, K, ac
     assert ((db.double() - dz.double().sum(0)).abs() / dz.double().abs().sum(0)).max().item() <= 2e-6      # the bias gradient stays fp32
 
 
-@pytest.mark.parametrize("store", ["1", "0"])
-def test_bf16_mode_train_step_close_to_fp32_and_repeatable(store, monkeypatch):
+@pytest.mark.parametrize("store,objects,batch", [("1", 24, 16), ("0", 24, 16), ("1", 6, 4)])
+def test_bf16_mode_train_step_close_to_fp32_and_repeatable(store, objects, batch, monkeypatch):
     """A full-size model trains with `mlp_math: bf16` (experiment config key): the step's loss is within 1 % of the fp32 step's, every
     weight gradient points the same way (cosine > 0.99), two bf16 steps from the same state are bit-identical, and the default stays fp32.
     store = 1 (default): the per-pair activations and their gradients are STORED in bfloat16 too; 0: fp32 storage (DFOL_BF16_STORE=0)."""
@@ -602,7 +602,7 @@ def test_bf16_mode_train_step_close_to_fp32_and_repeatable(store, monkeypatch):
     spec.loader.exec_module(bench)
     runs = {}
     for math in ("fp32", "bf16", "bf16"):
-        args = bench.parse(["--mode", "train", "--objects", "24", "--batch", "16", "--mlp-math", math])
+        args = bench.parse(["--mode", "train", "--objects", str(objects), "--batch", str(batch), "--mlp-math", math])      # (6 objects x 4: 120 pair rows)
         torch.manual_seed(3)
         model, ontology, paths, names = bench.build_model(args, DEV, train=True)
         assert getattr(model, "_mlp_math", None) == ("bf16" if math == "bf16" else None)

@@ -118,6 +118,7 @@ SIGNATURES = {
     "dfol_linear_pack_w_bf16": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_bf16_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_wgrad_bias_bf16": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
+    "dfol_act_bwd_f32": [_p, _p, _i64, _i32, _p, _p],
     "dfol_linear_act_bf16_bf16": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_wgrad_bias_bf16_bf16": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p],
     "dfol_pair_hidden1_fwd_bf16": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
@@ -474,6 +475,14 @@ def linear_wgrad(dy, x, bias=False):
     call("dfol_linear_wgrad_bias_bf16" if bf16 else "dfol_linear_wgrad_bias_f32", _dp(dy), dy.stride(0),
          _dp(x), x.stride(0), M, N, K, _ptr(ws), _ptr(dw), _ptr(db, F32, True), _stream())
     return (dw, db) if bias else dw
+
+
+def act_bwd(g, y, act):
+    """dz = g * act'(.) from the activation's output y (same shape, fp32, contiguous): one launch."""
+    g = g if g.is_contiguous() else g.contiguous()
+    dz = torch.empty_like(y)
+    call("dfol_act_bwd_f32", _ptr(g, F32), _ptr(y, F32), y.numel(), act, _ptr(dz), _stream())
+    return dz
 
 
 def linear_gradx(dz, weight):

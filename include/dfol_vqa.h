@@ -434,6 +434,11 @@ int dfol_linear_wgrad_bias_bf16(const float* dY, int64_t ld_dy, const float* X, 
 int dfol_linear_wgrad_bias_bf16_bf16(const void* dY_bf16, int64_t ld_dy, const void* X_bf16, int64_t ld_x, int64_t M, int32_t N, int32_t K,
                                      float* workspace, float* dW, float* db, void* stream);
 
+/* dz = g * act'(.) from the activation's OUTPUT y (flat arrays of n floats): the element-wise factor of the backward of
+ * y = act(x W^T + b) - what autograd computes through nn.Sigmoid / nn.ELU / nn.LogSigmoid behind the reference's nn.Linear layers
+ * (gqa_interpreter_experiments.py:26-33) - in one launch: Sigmoid g y (1 - y), ELU g (y > 0 ? 1 : y + 1), LogSigmoid g (1 - e^y). */
+int dfol_act_bwd_f32(const float* g, const float* y, int64_t n, int32_t act, float* dz, void* stream);
+
 /* ---- backward (training path, trainer.py:429-442) ------------------------------------------------------
  * Gradients of the block operators; formulas in SURVEY.md Appendix B (the reference gets them from torch autograd through
  * batch_base_ops.py:62-215).  g_* outputs that are NULL are skipped.

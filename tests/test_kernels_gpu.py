@@ -874,3 +874,19 @@ def test_linear_act_split_block_height_changes_no_bit(L):
             for m in (37, 1835, 9216):                                           # 64-row blocks
                 y_small = _lib.linear_act_split(big[:m, :K], W, b, act)
                 assert torch.equal(y_small, y_big[:m]), (N, K, act, m, (y_small - y_big[:m]).abs().max().item())
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(1000, 300), (7, 3), (25600, 512)])
+def test_act_bwd_equals_autograd_formulas(act, shape):
+    """dfol_act_bwd_f32 == the tensor-op formulas it replaces in the backward of linear_act (and == autograd through the activation)."""
+    from dfol_vqa_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(act * 100 + shape[0])
+    x = (torch.randn(*shape, device="cuda", generator=g) * 2).requires_grad_(True)
+    y = [None, torch.sigmoid, torch.nn.functional.elu, torch.nn.functional.logsigmoid][act](x)
+    gy = torch.randn(*shape, device="cuda", generator=g)
+    dz = _lib.act_bwd(gy, y.detach().contiguous(), act)
+    ref = [None, lambda: gy * y * (1 - y), lambda: gy * torch.where(y > 0, torch.ones_like(y), y + 1), lambda: gy * (1 - torch.exp(y))][act]().detach()
+    assert (dz - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    (auto,) = torch.autograd.grad(y, x, gy)
+    assert (dz - auto).abs().max().item() <= 2e-6 * max(1.0, auto.abs().max().item())

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __r
 #ifndef LGB_RF16
 #define LGB_RF16 8
 #endif
+#ifndef LGB_RF32
+#define LGB_RF32 8
+#endif
 constexpr int LG_T = 8;                                       // hidden units per lane: H2 <= 512
 
 // grid (row tiles, P): a workgroup covers 16 consecutive rows of one predicate, a wavefront 4 of them (four independent load streams)
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __re
         if (j4 == 0) db += g;
     };
     if (act) {
-        constexpr int RF = sizeof(TP) == 2 ? LGB_RF16 : 4;              // rows in flight per thread (half the bytes per row in bf16: twice the rows)
+        constexpr int RF = sizeof(TP) == 2 ? LGB_RF16 : LGB_RF32;       // rows in flight per thread (half the bytes per row in bf16: twice the rows)
         for (int64_t row = r0 + rg; row < r1; row += RF * RG) {          // (rows past the end: clamped loads)
             float4 v[RF];
             float g[RF];

@@ -93,6 +93,15 @@ __global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __re
     float4 w[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) w[t] = ld4(Wg + (int64_t)(k + t) * 4);
+    // the slot's HF_ROWS consecutive pairs have at most two subjects when an image has more than HF_ROWS objects: their U rows are loaded
+    // once per slot instead of once per pair (a third of the kernel's L2 reads, which - not the 2.6 GB it writes - is what bounds it)
+    const bool two = n - 1 >= HF_ROWS;
+    const int sA = e0 / (n - 1);
+    float4 uA, uB;
+    if (two) {
+        uA = ld4(U + (int64_t)(first + sA) * ld_u + k);
+        uB = ld4(U + (int64_t)(first + min(sA + 1, n - 1)) * ld_u + k);
+    }
     for (int r0 = 0; r0 < HF_ROWS; r0 += 4) {
         float4 g[4], u[4], v[4];
 #pragma unroll
@@ -100,7 +109,8 @@ __global__ __launch_bounds__(256) void pair_hidden1_fwd_kernel(const float* __re
             const int e = min(e0 + r0 + i, rows - 1);
             const int s = e / (n - 1), oo = e - s * (n - 1), o = oo + (oo >= s);
             g[i] = ld4(geo + (base + e) * 4);
-            u[i] = ld4(U + (int64_t)(first + s) * ld_u + k);
+            if (two) u[i] = s == sA ? uA : uB;
+            else u[i] = ld4(U + (int64_t)(first + s) * ld_u + k);
             v[i] = ld4(V + (int64_t)(first + o) * ld_v + k);
         }
 #pragma unroll

@@ -25,6 +25,12 @@
 #ifndef DFOL_SP_NT
 #define DFOL_SP_NT 1
 #endif
+// W2 chunks requested in the prologue (1 or 2).  Chunk 1 is first read in tick 3: requested by Y in its build tick 1 - the steady-state
+// protocol one chunk early - it leaves the prologue waiting for 60 KB of DMA instead of 120.
+#ifndef DFOL_PAIR_PRE
+#define DFOL_PAIR_PRE 1
+#endif
+
 
 // -DDFOL_PAIR_TRACE: clock64 stamps of one wavefront per half in a few workgroups (tools/scratch/trace_pair.py reads them)
 #ifdef DFOL_PAIR_TRACE
@@ -128,10 +134,10 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const bool trace_on = blockIdx.x >= 3000 && (blockIdx.x - 3000) % 500 == 0 && trace_blk < 8;
 #endif
     TRACE(0);
-    if constexpr (PP) {                                      // chunks 0 and 1 are requested before anything else: they land under the
-        const int nck = HID1 / SP_CH;                        // geometry arithmetic below
+    if constexpr (PP) {                                      // chunk 0 (DFOL_PAIR_PRE chunks) requested before anything else: it lands under
+        const int nck = HID1 / SP_CH;                        // the geometry arithmetic below
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < DFOL_PAIR_PRE; ++cb)
 #pragma unroll
             for (int i = 0; i < (SP_PIECES + T - 1) / T; ++i)
                 if (cb < nck && T * i + wave * 64 < SP_PIECES)
@@ -315,7 +321,8 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         // its build tick 2c+3 (U/V rows requested first: vmcnt retires in order) and Y drains that DMA at the end of its multiply
         // tick 2c+4, one tick before X needs it.
         const int g = wave >> 2;
-        dma_barrier();                                      // Wgs, the staged epilogue rows and chunks 0, 1 visible
+        // (X's first U/V rows requested HERE, in flight over the barrier, were measured: the 32 registers alive across it spill, 1.68 -> 1.85 ms)
+        dma_barrier();                                      // Wgs, the staged epilogue rows and the first chunk(s) visible
         // Each half runs its own copy of the loop (plain straight-line bodies for the register allocator); the barriers pair up by
         // count: X executes 2 per chunk, Y one idle tick first and none after its last multiply.
         auto run_half = [&](auto y_tag) __attribute__((always_inline)) {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             TRACE(2);
             for (int c = 0; c < nchunk; ++c) {
                 load_uv(c);
-                if (Y && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1, 4, std::integral_constant<int, 4>());
+                if (Y && c >= DFOL_PAIR_PRE - 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1, 4, std::integral_constant<int, 4>());
                 make_a(c);
                 __builtin_amdgcn_sched_barrier(0);          // the A pieces are pure register arithmetic: without this fence the compiler
                 TRACE(3 + 4 * c);                           // sinks them below the barrier, in front of the MFMAs of the multiply tick

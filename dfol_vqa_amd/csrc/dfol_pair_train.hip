@@ -184,7 +184,8 @@ __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __r
                 for (int j = 0; j < BATCH; ++j) {
                     const int o = g + (i0 + j) * G;
                     live[j] = o < n && o != s;
-                    const int64_t row = base + (live[j] ? (int64_t)s * (n - 1) + (o - (o > s)) : 0);     // (row `base` exists: n >= 2 here)
+                    // (a dead slot reads the image's first pair row - or, for an image of one object, which has none, the array's first)
+                    const int64_t row = live[j] ? base + (int64_t)s * (n - 1) + (o - (o > s)) : (n >= 2 ? base : 0);
                     dz[j] = ld4_stream(dZ + row * H1 + k), z[j] = ld4_stream(Z + row * H1 + k), ge[j] = ld4(geo + row * 4);
                 }
 #pragma unroll

@@ -698,3 +698,38 @@ def test_bf16_storage_dense_kernels_equal_the_bf16_mode_on_widened_operands(M, N
     assert (dbb.double() - dyb.double().sum(0)).abs().max().item() <= 2e-6 * dyb.double().abs().sum(0).max().item()
     with pytest.raises(Exception):
         _lib.linear_act_split(xb, w, b, 0)                                 # bf16-stored input outside the bf16 mode: refused
+
+
+@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16])
+def test_pair_hidden1_kernels_with_one_object_images(store):
+    """Images of ONE object have no pair rows (also as the last image of the batch, where their pair offset is the end of the arrays):
+    hidden1_fwd / _bwd against torch autograd through the same formula."""
+    from dfol_vqa_amd import _lib
+    H1 = 256
+    n = np.array([3, 1, 7, 2, 1], np.int32)
+    t = lambda a: torch.as_tensor(a).to(DEV)
+    obj_off = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int32)
+    cnt = n.astype(np.int64) * (n - 1)
+    pair_off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    O, pairs = int(n.sum()), int(cnt.sum())
+    g = torch.Generator(device=DEV).manual_seed(2)
+    U = torch.randn(O, H1, device=DEV, generator=g, requires_grad=True)
+    V = torch.randn(O, H1, device=DEV, generator=g, requires_grad=True)
+    pos = torch.rand(O, 4, device=DEV, generator=g)
+    Wg = (torch.randn(H1, 4, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    z, geo = _lib.pair_hidden1_fwd(U.detach(), V.detach(), pos, Wg.detach(), t(obj_off), t(pair_off), t(n), int(n.max()), pairs, store=store)
+    s_idx = np.concatenate([obj_off[q] + np.repeat(np.arange(n[q]), n[q] - 1) for q in range(len(n))]).astype(np.int64)
+    o_idx = np.concatenate([obj_off[q] + np.array([o for s in range(n[q]) for o in range(n[q]) if o != s], np.int64) for q in range(len(n))]).astype(np.int64)
+    ref = torch.nn.functional.elu(U[t(s_idx)] + V[t(o_idx)] + geo @ Wg.t())
+    tol = 1e-5 if store == torch.float32 else 2e-2
+    assert z.shape == (pairs, H1) and (z.float() - ref).abs().max().item() <= tol
+    dz = torch.randn(pairs, H1, device=DEV, generator=g).to(store)
+    du, dv, dwg = _lib.pair_hidden1_bwd(dz, z, geo, t(obj_off), t(pair_off), t(n), int(n.max()), O)
+    # the kernel differentiates through the STORED z (ELU' from z): build the same reference
+    zf = z.float()
+    dpre = dz.float() * torch.where(zf > 0, torch.ones_like(zf), zf + 1)
+    du_ref = torch.zeros(O, H1, device=DEV).index_add_(0, t(s_idx), dpre)
+    dv_ref = torch.zeros(O, H1, device=DEV).index_add_(0, t(o_idx), dpre)
+    assert (du - du_ref).abs().max().item() <= 1e-4 and (dv - dv_ref).abs().max().item() <= 1e-4
+    assert (dwg - dpre.t() @ geo).abs().max().item() <= 1e-3
+    assert du[obj_off[1]].abs().max().item() == 0 and dv[obj_off[4]].abs().max().item() == 0        # the one-object images get zero rows

@@ -69,7 +69,7 @@ def parse(argv=None):
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back steps AFTER the --steps region for `value_sustained` (0 = skip)")
-    ap.add_argument("--roofline-reps", type=int, default=10, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
+    ap.add_argument("--roofline-reps", type=int, default=20, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
                                                                   "of the dominant kernel in the process, so a rocprofv3 trace of the same command can average the same launches")
     ap.add_argument("--parity-fp64", type=int, default=1, help="1: the parity leg also runs the oracle in float64 (the tolerance policy's yardstick)")
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the cpu_baseline + parity legs may take in total: the number of "
@@ -348,7 +348,7 @@ def main(argv=None):
         names_timed = list(L.SIGNATURES)
         reps = max(1, args.roofline_reps)
         with torch.no_grad():
-            for _ in range(2):
+            for _ in range(5):
                 eager()
             torch.cuda.synchronize()
             L.enable_kernel_timing(names_timed)
@@ -722,8 +722,13 @@ def attach_rocprof(out, args):
         work = r["achieved"] * 1e12 * r["us_per_launch"] * 1e-6             # algorithmic flops per launch, as priced above
         ach = work / (dom["avg_us"] * 1e-6)
         r["rocprofv3"] = {"us_per_launch": dom["avg_us"], "launches_averaged": dom["launches"], "achieved": ach / 1e12, "frac": ach / (r["peak"] * 1e12),
+                          "hip_events_in_that_run_us": dom.get("hip_event_us_per_launch_same_run"),
                           "source": "profiles/roofline_rocprof.json (%s; the last %d launches of %s in a rocprofv3 --kernel-trace of this command)"
                                     % (entry.get("head", "?"), dom["launches"], dom["trace_name"])}
+        if dom.get("all_launches_avg_us"):                                  # the `--stats` row of the same trace: every launch of the run
+            r["rocprofv3"]["stats_avg_us"] = dom["all_launches_avg_us"]
+            r["rocprofv3"]["stats_launches"] = dom["all_launches"]
+            r["rocprofv3"]["frac_from_stats_avg"] = work / (dom["all_launches_avg_us"] * 1e-6) / (r["peak"] * 1e12)
     groups = entry.get("kernels", {})
     for k in out["kernels"]:
         tr = k.get("trace")

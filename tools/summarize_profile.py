@@ -81,6 +81,12 @@ def roofline_durations(out):
         if d:
             entry["dominant"] = {"trace_name": r["trace_name"], "launches": len(d), "avg_us": sum(d) / len(d) / 1e3, "min_us": min(d) / 1e3,
                                  "max_us": max(d) / 1e3, "hip_event_us_per_launch_same_run": r.get("us_per_launch")}
+            # ... and what `--stats` prints for this kernel: the average over EVERY launch of the run with the roofline leg's grid (graph
+            # replays of the timed region, the streamed leg, warm-up and the roofline leg itself)
+            gx_last = [gx for n, gx, st, du in rows if n.startswith(r["trace_name"])][-1]
+            every = [du for n, gx, st, du in rows if n.startswith(r["trace_name"]) and gx == gx_last]
+            entry["dominant"]["all_launches"] = len(every)
+            entry["dominant"]["all_launches_avg_us"] = sum(every) / len(every) / 1e3
     for k in line.get("kernels", []):
         tr = k.get("trace")
         if not tr:
@@ -97,8 +103,10 @@ def roofline_durations(out):
     print("\n## the roofline leg's launches (the same launches bench.py times with HIP events)\n")
     if "dominant" in entry:
         dm = entry["dominant"]
-        print("%s: last %d launches, rocprofv3 avg %.1f us (min %.1f, max %.1f); HIP events in the same run: %.1f us per launch"
-              % (dm["trace_name"], dm["launches"], dm["avg_us"], dm["min_us"], dm["max_us"], dm["hip_event_us_per_launch_same_run"] or 0))
+        print("%s: last %d launches, rocprofv3 avg %.1f us (min %.1f, max %.1f); HIP events in the same run: %.1f us per launch; all %d launches of "
+              "the run with this grid (the `--stats` row): %.1f us"
+              % (dm["trace_name"], dm["launches"], dm["avg_us"], dm["min_us"], dm["max_us"], dm["hip_event_us_per_launch_same_run"] or 0,
+                 dm.get("all_launches", 0), dm.get("all_launches_avg_us", 0.0)))
     for kk, v in sorted(entry["kernels"].items()):
         print("%s  [%s]: rocprofv3 avg %.1f us over %d launches; HIP events %.1f us" % (kk, v["row"], v["avg_us"], v["launches"], v["hip_event_us_per_launch_same_run"] or 0))
 

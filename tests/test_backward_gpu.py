@@ -733,3 +733,34 @@ def test_pair_hidden1_kernels_with_one_object_images(store):
     assert (du - du_ref).abs().max().item() <= 1e-4 and (dv - dv_ref).abs().max().item() <= 1e-4
     assert (dwg - dpre.t() @ geo).abs().max().item() <= 1e-3
     assert du[obj_off[1]].abs().max().item() == 0 and dv[obj_off[4]].abs().max().item() == 0        # the one-object images get zero rows
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_graphed_train_step_full_size_model_equals_eager_bit_for_bit(math):
+    """The full-size model (every large product on this library's kernels, nothing through the vendor BLAS): three graphed steps ==
+    three eager steps, losses and every parameter BIT FOR BIT - in fp32 mode and in the bf16 mode with bf16-stored activations."""
+    import importlib.util
+    from dfol_vqa_amd import parallel
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    finals = []
+    for graphed in (False, True):
+        args = bench.parse(["--mode", "train", "--objects", "20", "--batch", "12", "--mlp-math", math])
+        torch.manual_seed(5)
+        model, ontology, paths, names = bench.build_model(args, DEV, train=True)
+        _, pbs = bench.build_batch(args, 0, ontology, names, DEV)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+        bucket = parallel.GradBucket(params)
+        if graphed:
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, warmup=1)
+            losses = [float(step()[0]) for _ in range(3)]
+        else:
+            losses = [float(training.train_batch(model, opt, pbs, 0.65, bucket=bucket, sync_loss=False)[0]) for _ in range(4)][1:]
+        finals.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = finals
+    assert l0 == l1, (l0, l1)
+    bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+    assert not bad, bad
+    assert l0[-1] != l0[0]

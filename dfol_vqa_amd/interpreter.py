@@ -47,13 +47,18 @@ class BatchGQABoxFeaturizer(nn.Module):
         raw_cols = objects_list.size()[1]
         feat = objects_list[:, :raw_cols - 6]                    # a strided view: the GEMM reads it in place
         net = self._featurizer_network
-        if net is not None and getattr(net, "_network", None) is not None:
-            f = net(feat)
+        direct = net is not None and getattr(net, "_network", None) is not None and hasattr(net, "output_width") and feat.is_cuda and \
+            not (torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in net.parameters())))
+        if direct:
+            # inference: the featurizer's last layer writes straight into the object matrix (row stride D), no [O, D - 4] copy
+            D = net.output_width() + 4
+            obj = torch.empty(object_num, D, dtype=torch.float32, device=device)
+            net(feat, out=obj[:, :D - 4])
         else:
-            f = feat
-        D = f.size(1) + 4
-        obj = torch.empty(object_num, D, dtype=torch.float32, device=device)
-        obj[:, :D - 4] = f
+            f = net(feat) if net is not None and getattr(net, "_network", None) is not None else feat
+            D = f.size(1) + 4
+            obj = torch.empty(object_num, D, dtype=torch.float32, device=device)
+            obj[:, :D - 4] = f
         L.box_positions(objects_list, obj, D - 4)                # :208-211
         geo = world_geometry
         pair = None

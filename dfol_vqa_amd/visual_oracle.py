@@ -22,9 +22,11 @@ from .host_util import flatten_list, get_lowered, lower_tokens, segments_of, upl
 # ---------------------------------------------------------------------------------------------------
 # MLP holders (gqa_interpreter_experiments.py:18-77)
 # ---------------------------------------------------------------------------------------------------
-def _run_layers(seq, x):
-    """Walk an nn.Sequential of (Dropout, Linear, activation) triples; each triple is one fused GEMM launch."""
+def _run_layers(seq, x, out=None):
+    """Walk an nn.Sequential of (Dropout, Linear, activation) triples; each triple is one fused GEMM launch.  `out` (inference only): a
+    [rows, width] view - any row stride - that the LAST layer writes its result into instead of a new tensor."""
     mods = list(seq)
+    last_linear = max([j for j, m in enumerate(mods) if isinstance(m, nn.Linear)] or [-1])
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -43,7 +45,7 @@ def _run_layers(seq, x):
                 act, step = L.ACT_SIGMOID, 2
             elif isinstance(nxt, nn.LogSigmoid):
                 act, step = L.ACT_LOGSIGMOID, 2
-        x = L.linear_act(x, m.weight, m.bias, act)
+        x = L.linear_act(x, m.weight, m.bias, act, out if i == last_linear else None)
         i += step
     return x
 
@@ -63,8 +65,14 @@ class RegularMLP(nn.Module):
             layers += [nn.Dropout(dropout), nn.Linear(last, output_dim), nn.Sigmoid()]
             self._network = nn.Sequential(*layers)
 
-    def forward(self, input_tensor):
-        return input_tensor if self._network is None else _run_layers(self._network, input_tensor)
+    def forward(self, input_tensor, out=None):
+        return input_tensor if self._network is None else _run_layers(self._network, input_tensor, out)
+
+    def output_width(self):
+        """Columns of forward()'s result, or None for the identity network."""
+        if self._network is None:
+            return None
+        return [m for m in self._network if isinstance(m, nn.Linear)][-1].out_features
 
 
 class EmbeddingLayer(nn.Module):

@@ -185,7 +185,8 @@ class BatchWorld(object):
 
     def zeros_attention(self):
         if self._zeros is None:
-            self._zeros = torch.zeros(self._batch_size, self._NS, dtype=torch.float32, device=self._device)
+            from .host_util import constant
+            self._zeros = constant((self._batch_size, self._NS), 0.0, self._device)
         return self._zeros
 
     def pred_q(self, predicate_question_map):
@@ -238,13 +239,22 @@ class BatchVariableSet(object):
         self._world = world
         self._batch_object_map = world
 
+        # _quantifier_host: the same values on the host when they are known there (constructed from python values), so that operators whose
+        # selection flags are host data too can pick quantifiers without a launch (GQARelateBatch); None for device-computed quantifiers
+        from .host_util import constant, upload
         if isinstance(quantifiers, (int, float, Quantifier)):
-            self._quantifier = torch.full((batch_size,), float(quantifiers), dtype=torch.float32, device=device)
-        elif isinstance(quantifiers, (list, tuple)):
-            from .host_util import upload
-            self._quantifier = upload(np.asarray(quantifiers, np.float32), device)
-        else:
-            self._quantifier = quantifiers
+            self._quantifier = constant((batch_size,), float(quantifiers), device)
+            self._quantifier_host = np.full(batch_size, float(quantifiers), np.float32)
+        elif isinstance(quantifiers, (list, tuple, np.ndarray)):
+            self._quantifier_host = np.asarray(quantifiers, np.float32)
+            self._quantifier = upload(self._quantifier_host, device)
+        else:                                                # a tensor: operators hand their input's quantifier on, shadow included
+            self._quantifier, self._quantifier_host = quantifiers, getattr(quantifiers, "_dfol_host", None)
+        if self._quantifier_host is not None and getattr(self._quantifier, "_dfol_host", None) is None:
+            try:
+                self._quantifier._dfol_host = self._quantifier_host      # (cached tensors: the same content, so the same shadow, for every user)
+            except Exception:
+                pass
 
         if log_attention is None:
             self._log_attention = world.zeros_attention() if batch_size == world._batch_size else \

@@ -308,6 +308,8 @@ class GQARelateBatch(GQABatchOperatorBase):
             quant = x._quantifier
         elif host_flags is not None and not any(f > 0 for f in host_flags):
             quant = prev._quantifier
+        elif host_flags is not None and x._quantifier_host is not None and prev._quantifier_host is not None:
+            quant = np.where(np.asarray([f > 0 for f in host_flags]), x._quantifier_host, prev._quantifier_host)     # host values: no launch
         elif host_flags is not None:
             quant = torch.where(upload(np.asarray([f > 0 for f in host_flags], np.bool_), world._device), x._quantifier, prev._quantifier)
         else:

@@ -94,6 +94,20 @@ def upload(array, device):
     return keep_alive(hit)
 
 
+_const_cache = LRUCache(64)
+
+
+def constant(shape, value, device):
+    """A READ-ONLY fp32 tensor of one value (the quantifier of a fresh variable set, the all-ones attention of a select), shared by every
+    caller: torch.full / torch.zeros would launch a fill kernel - and add a graph node - per use.  Nothing on the path writes into its
+    inputs in place (outputs are always new tensors), and tests that replay a batch would see a corrupted constant."""
+    key = (str(device), tuple(shape), float(value))
+    hit = _const_cache.get(key)
+    if hit is None:
+        hit = _const_cache[key] = torch.full(tuple(shape), float(value), dtype=torch.float32, device=device)
+    return keep_alive(hit)
+
+
 def lower_tokens(tokens, ontology, token_type):
     """Resolve tokens against the ontology exactly as the reference's oracle does
     (classifier_oracle.py:49-56 for attributes: column = arg_to_idx-1 of the full table;

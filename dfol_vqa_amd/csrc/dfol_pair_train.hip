@@ -133,7 +133,9 @@ constexpr int HB_MAXO = 16;                                   // objects per lan
 // trip (s_waitcnt vmcnt(0) in each: seven in a row per subject at 100 objects) and only the 16 wavefronts of the CU overlap them; 128
 // registers per lane leave no room for more (batching the loads there spills in the loop: 1.95 ms against 0.8).  THREADS = 512 (images of up
 // to MAXO * G = 128 objects at HID1 = 256): 256 registers per lane, the loads of BATCH slots are issued together without branches (rows that do
-// not exist are clamped to one that does and masked out of the sums).
+// not exist are clamped to one that does and masked out of the sums).  (Recomputing z from U[s], V[o] and the geometry instead of reading it -
+// half the HBM bytes - was built and measured: no faster in fp32 storage, 0.15 ms SLOWER per step in bf16 storage; the kernel is bound by its
+// chain of round trips and the VALU work per element, not by bytes.)
 template <typename TZ, int THREADS, int MAXO, int BATCH>
 __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __restrict__ dZ, const TZ* __restrict__ Z,
                                                                     const float* __restrict__ geo, const int32_t* __restrict__ obj_off,

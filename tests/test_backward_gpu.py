@@ -764,3 +764,26 @@ def test_graphed_train_step_full_size_model_equals_eager_bit_for_bit(math):
     bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
     assert not bad, bad
     assert l0[-1] != l0[0]
+
+
+def test_train_step_on_shared_scenes_equals_per_question_scenes():
+    """A batch collated with share_scenes=True (every image once, eight questions per image) TRAINS through the reference's layout - the
+    interpreter expands the scenes to one copy per question when gradients have to reach the oracle (build_scene) - so its loss and every
+    gradient equal, bit for bit, those of the same questions collated with a scene copy each."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test3", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    runs = []
+    for share in ("1", "0"):
+        args = bench.parse(["--mode", "train", "--objects", "20", "--ragged", "6", "--batch", "16", "--questions-per-image", "4", "--share-scenes", share])
+        torch.manual_seed(7)
+        model, ontology, paths, names = bench.build_model(args, DEV, train=True)
+        _, pbs = bench.build_batch(args, 0, ontology, names, DEV)
+        assert (pbs[0]._question_image is not None) == (share == "1")
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        loss, _ = training.train_batch(model, opt, pbs, clip_norm=0.65)
+        runs.append((loss, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l1, g1), (l0, g0) = runs
+    assert l1 == l0, (l1, l0)
+    assert sorted(g1) == sorted(g0) and all(torch.equal(g1[k], g0[k]) for k in g1)

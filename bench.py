@@ -506,7 +506,9 @@ def train_main(args, rank, world, device, td, share):
         for pb in pbs:
             pb._meta_data = {"index": {t: i for i, t in enumerate(voc)}, "embedding": emb}
     params = [p for p in model.parameters() if p.requires_grad]
-    use_graph = bool(args.graph) and td is None
+    # one process: the whole step as a captured HIP graph; data parallel over RCCL: the same, with the bucket's all-reduce captured inside
+    # (gloo collectives run on the host and cannot be captured; the overlap hooks issue collectives from autograd threads: eager)
+    use_graph = bool(args.graph) and (td is None or (td.get_backend() == "nccl" and not args.overlap_allreduce))
     opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
     bucket = parallel.GradBucket(params)
     if td is not None and args.overlap_allreduce:
@@ -517,7 +519,7 @@ def train_main(args, rank, world, device, td, share):
     step, graphed = eager_step, False
     if use_graph:                                            # one process: the whole step replayed as a captured HIP graph
         try:
-            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket)
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, group=group, global_batch_size=gb)
             graphed = True
             # a GPU-bound step (the oracle phases at N = 100: 12.9 ms of kernels in a 13.5 ms step) gains nothing from the replay and
             # pays for the graph's private memory pool; the host-bound ones (calibrator phases, small scenes) gain 15-35 %: keep the faster
@@ -530,6 +532,10 @@ def train_main(args, rank, world, device, td, share):
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0) / n
             t_graph, t_eager = clock(step), clock(eager_step)
+            if td is not None:                               # every rank must take the same path: decide on the slowest rank's clocks
+                tt = torch.tensor([t_graph, t_eager], device=device, dtype=torch.float64)
+                td.all_reduce(tt, op=td.ReduceOp.MAX)
+                t_graph, t_eager = float(tt[0]), float(tt[1])
             if t_eager < 0.98 * t_graph:
                 step, graphed = eager_step, False
                 torch.cuda.empty_cache()

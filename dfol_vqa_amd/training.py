@@ -104,16 +104,26 @@ class GraphedTrainStep(object):
     host-bound: 4.6 ms of GPU work in a 6.9 ms step), and its launch sequence is static for a given batch shape, exactly like the
     inference forward's (interpreter.GraphedForward).  The optimizer must be capturable (torch.optim.Adam(..., capturable=True): its step
     counter lives on the device); new scenes of the same shapes are served by copying into `program_batch._object_features`; a batch
-    with other programs or shapes needs its own capture.  Single process only: with data parallelism the all-reduce sits between the
-    backward and the clip, so run `train_batch` there.  `loss` is a 0-d device tensor that every replay overwrites.
+    with other programs or shapes needs its own capture.  With `group` (data parallelism) the bucket's all-reduce is part of the graph.
+    `loss` is a 0-d device tensor that every replay overwrites (this rank's share of the summed loss).
 
     Same lifetime rule as GraphedForward: tensors that came out of caches are referenced from `self._keep`."""
 
-    def __init__(self, model, optimizer, data, clip_norm, l1_lambda=0.0, bucket=None, warmup=2):
+    def __init__(self, model, optimizer, data, clip_norm, l1_lambda=0.0, bucket=None, warmup=2, group=None, global_batch_size=None):
         from ._lib import keeping
         self._model, self._opt, self._data, self._bucket = model, optimizer, data, bucket
         self._clip, self._l1 = clip_norm, l1_lambda
-        self._batch = sum(d.batch_size() for d in data)
+        # data parallel (one process per GPU, `group`): `data` is this rank's shard, the loss is divided by the GLOBAL batch size and the
+        # bucket's all-reduce is CAPTURED between the backward and the clip (RCCL collectives can be captured like kernels; the bucket is
+        # required then: one flat buffer, one collective node).  Every rank must capture and replay the same number of times.
+        self._group, self._world = group, 1
+        if group is not None:
+            import torch.distributed as dist
+            if bucket is None:
+                raise ValueError("GraphedTrainStep with a process group needs the persistent gradient bucket (parallel.GradBucket)")
+            self._world = dist.get_world_size(group)
+        self._local_batch = sum(d.batch_size() for d in data)
+        self._batch = global_batch_size if global_batch_size is not None else self._local_batch
         for g in optimizer.param_groups:
             if not g.get("capturable", False):
                 raise ValueError("GraphedTrainStep needs a capturable optimizer (torch.optim.Adam(params, lr=..., capturable=True))")
@@ -136,8 +146,10 @@ class GraphedTrainStep(object):
         else:
             self._opt.zero_grad(set_to_none=False)
         result = self._model(self._data, True)
-        loss = compute_loss(self._data, result, self._l1, list(self._model.parameters())) / self._batch
+        loss = compute_loss(self._data, result, self._l1, list(self._model.parameters()), l1_scale=1.0 / self._world) / self._batch
         loss.backward()
+        if self._group is not None:
+            self._bucket.allreduce(self._group)
         nn.utils.clip_grad_norm_(self._model.parameters(), self._clip)
         self._opt.step()
         return loss.detach() * self._batch, result

@@ -119,6 +119,43 @@ def train_case(rank, world, out):
     assert not failures, failures
 
 
+def graph_case(rank, world, out):
+    """training.GraphedTrainStep with a process group: the bucket all-reduce captured inside the step graph; three replays == three eager
+    train_batch steps with the same group (losses and parameters bit for bit on the full-size model)."""
+    import bench
+    from dfol_vqa_amd import parallel, training
+    dev = torch.device("cuda", 0)
+    finals = []
+    for graphed in (False, True):
+        args = bench.parse(["--mode", "train", "--objects", "16", "--batch", "8", "--gpus", str(world)])
+        torch.manual_seed(11)
+        model, ontology, paths, names = bench.build_model(args, dev, train=True)
+        parallel.broadcast_parameters(model, 0)
+        _, pbs = bench.build_batch(args, rank, ontology, names, dev)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+        bucket = parallel.GradBucket(params)
+        gb = 8 * world
+        if graphed:
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, warmup=1, group=dist.group.WORLD, global_batch_size=gb)
+            losses = [float(step()[0]) for _ in range(3)]
+        else:
+            losses = [float(training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=dist.group.WORLD, bucket=bucket, sync_loss=False)[0])
+                      for _ in range(4)][1:]
+        finals.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        dg = parallel.parameters_digest(model)
+        dg = dg if dist.get_backend() == "nccl" else dg.cpu()
+        both = [torch.zeros_like(dg) for _ in range(world)]
+        dist.all_gather(both, dg)
+        assert all(torch.equal(both[0], b) for b in both), "replicas differ"
+    (l0, s0), (l1, s1) = finals
+    out["losses"] = [l0, l1]
+    assert l0 == l1, (l0, l1)
+    bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+    assert not bad, bad
+    out["graph_equals_eager"] = True
+
+
 def main():
     case, path = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -132,7 +169,7 @@ def main():
     out_backend = dist.get_backend()
     out = {"rank": rank, "ok": False, "backend": out_backend}
     try:
-        {"infer": infer_case, "train": train_case}[case](rank, world, out)
+        {"infer": infer_case, "train": train_case, "graph": graph_case}[case](rank, world, out)
         out["ok"] = True
     except Exception as exc:  # pragma: no cover
         import traceback

@@ -100,18 +100,30 @@ def test_rccl_world_size_one(tmp_path, case, overlap):
         assert all(n == 12 for n in outs[0]["g12_checked"].values()) and outs[0]["replicas_equal"]
 
 
-@pytest.mark.parametrize("mode", ["infer", "train"])
-def test_bench_over_rccl_world_size_one(mode):
+@pytest.mark.parametrize("mode,overlap", [("infer", 1), ("train", 1), ("train", 0)])
+def test_bench_over_rccl_world_size_one(mode, overlap):
     """bench.py with DFOL_BENCH_FORCE_PG=1: the N > 1 code path (barriers, max over ranks, rank report, bucket all-reduce, replica check)
     over RCCL with one rank."""
     env = dict(os.environ, DFOL_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16", "--objects", "20",
-           "--cpu-sample", "0", "--stress-preds", "0", "--mode", mode, "--overlap-allreduce", "1"]
+           "--cpu-sample", "0", "--stress-preds", "0", "--mode", mode, "--overlap-allreduce", str(overlap)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["ranks"]["backend"] == "nccl" and out["value"] > 0
     if mode == "train":
         assert out["replicas_equal"] is True and out["allreduce_ms"] > 0
+        # without the overlap hooks the step is one HIP graph with RCCL's all-reduce captured inside (small scenes: the replay is the faster)
+        assert ("graph" in out["config"]["launch"]) == (overlap == 0), out["config"]["launch"]
+
+
+@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2)])
+def test_graphed_train_step_with_process_group(tmp_path, backend, world):
+    """The step graph with data parallelism: the gradient bucket's all-reduce is captured between backward and clip.  One rank over RCCL
+    (the collective node really is RCCL's) and two ranks over gloo are not both capturable: gloo is host-side, so only the RCCL case runs."""
+    if backend == "gloo":
+        pytest.skip("gloo collectives run on the host and cannot be captured into a HIP graph")
+    outs = _run_ranks("graph", tmp_path, world=world, extra_env={"DFOL_TEST_BACKEND": "nccl"})
+    assert outs[0]["backend"] == "nccl" and outs[0]["graph_equals_eager"]

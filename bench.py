@@ -173,6 +173,15 @@ WORKLOADS = {
 }
 
 
+_JSON_OUT = None
+
+
+def emit(line):
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def setup(args):
     """Rank / device / process group; fails loudly when the launch does not match --gpus."""
     rank = int(os.environ.get("RANK", "0"))
@@ -190,6 +199,13 @@ def setup(args):
     # itself (communicator setup, barrier, all-reduce of the gradient bucket incl. the overlap hooks, all-gather of the rank report)
     force = os.environ.get("DFOL_BENCH_FORCE_PG") == "1"
     if world > 1 or force:
+        # the JSON line must be the only thing on stdout: native libraries print there too (RCCL: "Librccl path : ..." at exit, from C stdio),
+        # so from here on file descriptor 1 is stderr for everyone else and the line goes to the saved stdout (emit())
+        global _JSON_OUT
+        if _JSON_OUT is None:
+            sys.stdout.flush()
+            _JSON_OUT = os.fdopen(os.dup(1), "w")
+            os.dup2(2, 1)
         import torch.distributed as td
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -382,7 +398,7 @@ def main(argv=None):
                 if "policy" in out["parity"]:
                     out["parity"]["policy"] = {"applies": False, "why": "the fp32 tolerance policy does not apply to the opt-in bf16 tile storage"}
                 out["dtype"] = "f32 logic arithmetic on bf16 relation tiles"
-        print(json.dumps(out))
+        emit(json.dumps(out))
         sys.stdout.flush()
     if td is not None:
         td.barrier()
@@ -617,7 +633,7 @@ def train_main(args, rank, world, device, td, share):
                "kernels": train_kernel_rooflines(args, per_step), "roofline": None, "cpu_baseline": None}
         # the roofline object: the entry point the step spends most time in (the split-kernel GEMMs)
         out["roofline"] = max(out["kernels"], key=lambda k: k["ms_per_step"]) if out["kernels"] else None
-        print(json.dumps(out))
+        emit(json.dumps(out))
         sys.stdout.flush()
     if td is not None:
         td.barrier()

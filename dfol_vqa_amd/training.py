@@ -137,7 +137,11 @@ class GraphedTrainStep(object):
         torch.cuda.empty_cache()                             # the warm-up's activations go back before the graph's private pool is sized
         self._keep = []
         self._graph = torch.cuda.CUDAGraph()
-        with keeping(self._keep), torch.cuda.graph(self._graph):
+        # with a process group the backend's watchdog thread polls the events of earlier collectives: under the default ("global") capture
+        # mode such a query from ANOTHER thread is an error that takes the process down ("operation not permitted when stream is
+        # capturing"); thread-local mode restricts the check to the capturing thread
+        mode = {} if group is None else {"capture_error_mode": "thread_local"}
+        with keeping(self._keep), torch.cuda.graph(self._graph, **mode):
             self.loss, self.result = self._body()
 
     def _body(self):

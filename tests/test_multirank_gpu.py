@@ -111,7 +111,9 @@ def test_bench_over_rccl_world_size_one(mode, overlap):
            "--cpu-sample", "0", "--stress-preds", "0", "--mode", mode, "--overlap-allreduce", str(overlap)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-500:]       # stdout carries the JSON line only (RCCL's own prints go to stderr)
+    out = json.loads(lines[0])
     assert out["ranks"]["backend"] == "nccl" and out["value"] > 0
     if mode == "train":
         assert out["replicas_equal"] is True and out["allreduce_ms"] > 0

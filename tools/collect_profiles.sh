@@ -3,7 +3,7 @@
 # usage: tools/collect_profiles.sh [tag]     (default r03)
 TAG=${1:-r03}
 O=gpurun_out/$TAG
-for f in bench_n100.json bench_c1_n36.json bench_c3_shared.json bench_c3_unshared.json bench_c4_n256.json bench_2ranks_one_gpu.json train_2ranks_one_gpu.json train_rccl_world1.json; do
+for f in bench_n100.json bench_c1_n36.json bench_c3_shared.json bench_c3_unshared.json bench_c4_n256.json bench_2ranks_one_gpu.json train_2ranks_one_gpu.json train_rccl_world1.json train_rccl_world1_cal.json; do
   grep '^{' $O/$f | tail -1 > profiles/${TAG}_$f
 done
 grep '^{' $O/train_step.jsonl > profiles/${TAG}_train_step.jsonl

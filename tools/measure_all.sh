@@ -25,6 +25,7 @@ done
 DFOL_BF16_STORE=0 timeout 300 python bench.py --mode train --steps 10 --objects 100 --mlp-math bf16 >> $O/train_step_bf16_fp32_storage.jsonl 2>> $O/train.err
 timeout 200 python tools/scratch/bf16_store_lab.py > $O/bf16_storage_kernels.txt 2>&1
 DFOL_BENCH_FORCE_PG=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 timeout 300 python bench.py --gpus 1 --steps 10 --mode train --objects 36 --overlap-allreduce 1 > $O/train_rccl_world1.json 2> $O/train_rccl1.err
+DFOL_BENCH_FORCE_PG=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29612 timeout 300 python bench.py --gpus 1 --steps 10 --mode train --objects 100 --calibrator 1 > $O/train_rccl_world1_cal.json 2>> $O/train_rccl1.err
 DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2r.err
 DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --mode train --objects 36 > $O/train_2ranks_one_gpu.json 2> $O/train_2r.err
 timeout 300 python tools/bench_calibrated.py > $O/calibrated_forward.txt 2>&1

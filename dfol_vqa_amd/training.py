@@ -121,6 +121,8 @@ class GraphedTrainStep(object):
             import torch.distributed as dist
             if bucket is None:
                 raise ValueError("GraphedTrainStep with a process group needs the persistent gradient bucket (parallel.GradBucket)")
+            if getattr(bucket, "_segments", None) is not None:
+                raise ValueError("GraphedTrainStep captures ONE all-reduce after the backward: use a bucket without enable_overlap()")
             self._world = dist.get_world_size(group)
         self._local_batch = sum(d.batch_size() for d in data)
         self._batch = global_batch_size if global_batch_size is not None else self._local_batch

@@ -20,6 +20,9 @@
 
 #include <type_traits>
 
+#ifndef W3B_ALIGN
+#define W3B_ALIGN 1
+#endif
 #ifndef W3B_D
 #define W3B_D 4                 // steps of rows in flight in the bf16-storage weight gradient (1..4)
 #endif
@@ -455,6 +458,13 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict_
     if constexpr (D > 3) load(3, std::integral_constant<int, 3>());
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < steps; s += D) {                                           // (steps past the range multiply zero rows: exact zeros)
+#if W3B_ALIGN
+        // the four wavefronts of a workgroup read the SAME rows (different column blocks): kept within a ring turn of each other, the
+        // second reader of a row finds it in L1 / L2.  Left free-running they drift apart and every wavefront fetches its rows from HBM:
+        // 2.11 x the algorithmic bytes at 6.4 TB/s - this kernel, unlike its three-piece form, is HBM-bound.  (Wavefronts that have
+        // returned do not count for s_barrier.)
+        __builtin_amdgcn_s_barrier();
+#endif
         one_step(s, std::integral_constant<int, 0>());
         if constexpr (D > 1) one_step(s + 1, std::integral_constant<int, 1>());
         if constexpr (D > 2) one_step(s + 2, std::integral_constant<int, 2>());

@@ -1,0 +1,59 @@
+#!/bin/bash
+# HBM traffic of the train step's kernels (runs on the GPU box): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of
+# `bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0`, fp32 mode and bf16 mode -> gpurun_out/<tag>/train_traffic.md
+# usage: tools/train_traffic.sh [tag]
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+O=gpurun_out/$TAG
+mkdir -p $O
+for m in fp32 bf16; do
+  bash tools/pmc_run.sh ${TAG}_train_fetch_$m "FETCH_SIZE" bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 --cpu-sample 0 --mlp-math $m > $O/pmc_train_fetch_$m.txt 2>&1
+  bash tools/pmc_run.sh ${TAG}_train_write_$m "WRITE_SIZE" bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 --cpu-sample 0 --mlp-math $m > $O/pmc_train_write_$m.txt 2>&1
+done
+python3 - $O <<'PY' > $O/train_traffic.md
+import re, sys, os
+O = sys.argv[1]
+def parse(path):
+    res, cur = {}, None
+    for l in open(path):
+        m = re.match(r"^(\S.*) grid=(\d+)\s+dispatches=(\d+) avg_us=([\d.]+)", l)
+        if m:
+            cur = (m.group(1).strip(), int(m.group(2)))
+            res[cur] = {"n": int(m.group(3)), "us": float(m.group(4))}
+            continue
+        m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+([\d.e+]+)", l)
+        if m and cur:
+            res[cur][m.group(1)] = float(m.group(2))
+    return res
+Q, N, H1, H2 = 256, 100, 256, 300
+pairs = Q * N * (N - 1)
+def algorithmic(name, mode):
+    b = 2 if mode == "bf16" else 4                                  # bytes per stored per-pair activation
+    if "pair_hidden1_fwd" in name: return pairs * (b * H1 + 16)
+    if "pair_hidden1_bwd" in name: return pairs * (2 * b * H1 + 16)
+    if "pair_logit_fwd" in name: return pairs * (b * H2 + 4)
+    if "pair_logit_bwd" in name: return pairs * (2 * b * H2 + 4)
+    return None
+print("# HBM traffic of the train step's kernels, round 3 (N = 100, 256 questions; rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of")
+print("# `bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 [--mlp-math bf16]`; FETCH_SIZE in KiB x 2 as MI355X_MICROARCH.md prescribes")
+print("# for gfx950, WRITE_SIZE in KiB; per launch).  The two tall products and the pair layer's weight gradient: algorithmic = operands read once + result written.")
+for mode in ("fp32", "bf16"):
+    f, w = parse(os.path.join(O, "pmc_train_fetch_%s.txt" % mode)), parse(os.path.join(O, "pmc_train_write_%s.txt" % mode))
+    print("\n## %s mode%s\n" % (mode, " (per-pair activations stored in bfloat16)" if mode == "bf16" else ""))
+    print("| kernel | grid | launches | avg us | fetched MB | written MB | algorithmic MB | traffic / algorithmic |")
+    print("|---|---|---|---|---|---|---|---|")
+    rows = []
+    for key, v in f.items():
+        if "FETCH_SIZE" not in v: continue
+        wr = w.get(key, {}).get("WRITE_SIZE", 0.0)
+        fm, wm = v["FETCH_SIZE"] * 1024 * 2 / 1e6, wr * 1024 / 1e6
+        rows.append((v["us"] * v["n"], key, v, fm, wm))
+    b = 2 if mode == "bf16" else 4
+    for tot, (name, gx), v, fm, wm in sorted(rows, reverse=True)[:16]:
+        alg = algorithmic(name, mode)
+        if alg is None and ("linear_act_split_kernel" in name or "wgrad_tn3_kernel" in name) and fm + wm > 2000:
+            alg = pairs * (H1 + H2) * b                             # Z / dpre2 in, pre2 / dZ out (or both read for the weight gradient)
+        print("| %s | %d | %d | %.0f | %.0f | %.0f | %s | %s |" % (name[:70], gx, v["n"], v["us"], fm, wm, "%.0f" % (alg / 1e6) if alg else "", "%.2f" % ((fm + wm) / (alg / 1e6)) if alg else ""))
+PY
+cat $O/train_traffic.md

@@ -462,7 +462,11 @@ __device__ __forceinline__ void wgrad_tn3_accumulate(const uint16_t* __restrict_
         // the four wavefronts of a workgroup read the SAME rows (different column blocks): kept within a ring turn of each other, the
         // second reader of a row finds it in L1 / L2.  Left free-running they drift apart and every wavefront fetches its rows from HBM:
         // 2.11 x the algorithmic bytes at 6.4 TB/s - this kernel, unlike its three-piece form, is HBM-bound.  (Wavefronts that have
-        // returned do not count for s_barrier.)
+        // returned do not count for s_barrier.)  Two further attempts at the byte count, both measured and dropped: handing the four row panels
+        // of a 2 x 2 group through LDS (one fetch per panel and workgroup) - same FETCH_SIZE (4.65 GB per launch in isolation: the re-reads
+        // were L2 hits already) and same 0.97 ms; dispatching a slab's two groups next to each other ((groups, slabs) grid) - same bytes,
+        // 1.1 ms.  What the counters show as 1.65 - 2.1 x is structural: the second workgroup class reads X again and dY's 600-byte rows
+        // straddle 128-byte lines.
         __builtin_amdgcn_s_barrier();
 #endif
         one_step(s, std::integral_constant<int, 0>());

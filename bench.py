@@ -72,7 +72,7 @@ def parse(argv=None):
     ap.add_argument("--roofline-reps", type=int, default=20, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
                                                                   "of the dominant kernel in the process, so a rocprofv3 trace of the same command can average the same launches")
     ap.add_argument("--parity-fp64", type=int, default=1, help="1: the parity leg also runs the oracle in float64 (the tolerance policy's yardstick)")
-    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the cpu_baseline + parity legs may take in total: the number of "
+    ap.add_argument("--cpu-budget", type=float, default=210.0, help="seconds of host time the cpu_baseline + parity legs may take in total: the number of "
                                                                     "questions checked beyond the timed sample shrinks to fit (the default run must finish within minutes)")
     args = ap.parse_args(argv)
     if args.objects is None:

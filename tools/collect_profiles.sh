@@ -20,3 +20,5 @@ cp $O/accuracy_probe_n100.json profiles/${TAG}_accuracy_probe_n100.json
 for f in step_breakdown_n100 step_breakdown_n36 step_breakdown_train_n100 step_breakdown_train_bf16_n100; do cp $O/$f.md profiles/${TAG}_$f.md; done
 cp $O/traffic.json profiles/traffic.json
 cp $O/roofline_rocprof.json profiles/roofline_rocprof.json
+cp $O/train_traffic.md profiles/${TAG}_train_traffic.md 2>/dev/null
+for f in pmc_train_fetch_fp32 pmc_train_write_fp32 pmc_train_fetch_bf16 pmc_train_write_bf16; do cp $O/$f.txt profiles/${TAG}_$f.txt 2>/dev/null; done

@@ -44,6 +44,7 @@ bash tools/pmc_run.sh ${TAG}_mfma "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WA
 bash tools/pmc_run.sh ${TAG}_insts "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU" tools/bench_kernels.py > $O/pmc_insts.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_fetch "FETCH_SIZE" tools/bench_kernels.py > $O/pmc_fetch_microbench.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_write "WRITE_SIZE" tools/bench_kernels.py > $O/pmc_write_microbench.txt 2>&1
+bash tools/train_traffic.sh $TAG > $O/train_traffic.log 2>&1
 tail -1 $O/bench_n100.json | cut -c1-300
 tail -1 $O/bench_c1_n36.json | cut -c1-200
 tail -1 $O/bench_c4_n256.json | cut -c1-200

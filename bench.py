@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
+    ap.add_argument("--graph-collective", type=int, default=0, help="train mode over RCCL: 1 = ONE step graph with the all-reduce captured inside (opt-in: a "
+                    "failure of that path - capture error or an abort from the process group's watchdog - ends THIS process with a non-zero exit, "
+                    "there is no in-process fallback); 0 (default) = two graphs with the all-reduce issued eagerly between the replays")
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back steps AFTER the --steps region for `value_sustained` (0 = skip)")
     ap.add_argument("--roofline-reps", type=int, default=20, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
                                                                   "of the dominant kernel in the process, so a rocprofv3 trace of the same command can average the same launches")
@@ -522,9 +525,14 @@ def train_main(args, rank, world, device, td, share):
         for pb in pbs:
             pb._meta_data = {"index": {t: i for i, t in enumerate(voc)}, "embedding": emb}
     params = [p for p in model.parameters() if p.requires_grad]
-    # one process: the whole step as a captured HIP graph; data parallel over RCCL: the same, with the bucket's all-reduce captured inside
-    # (gloo collectives run on the host and cannot be captured; the overlap hooks issue collectives from autograd threads: eager)
-    use_graph = bool(args.graph) and (td is None or (td.get_backend() == "nccl" and not args.overlap_allreduce))
+    # one process: the whole step as ONE captured HIP graph.  Data parallel (any backend): TWO graphs - zero + forward + loss + backward, and
+    # clip + Adam - with the bucket's all-reduce issued eagerly between the two replays (training.GraphedTrainStep; no collective is ever
+    # captured).  --graph-collective 1 (RCCL only, opt-in): one graph with the all-reduce as a node.  The overlap hooks issue collectives
+    # from autograd threads: eager only.
+    use_graph = bool(args.graph) and not (td is not None and args.overlap_allreduce)
+    graph_collective = bool(args.graph_collective) and td is not None
+    if graph_collective and (td.get_backend() != "nccl" or not use_graph):
+        raise SystemExit("--graph-collective 1 needs --graph 1, --overlap-allreduce 0 and the nccl (RCCL) backend")
     opt = torch.optim.Adam(params, lr=1e-4, capturable=use_graph)
     bucket = parallel.GradBucket(params)
     if td is not None and args.overlap_allreduce:
@@ -533,10 +541,22 @@ def train_main(args, rank, world, device, td, share):
     # (the loss stays on the GPU and is read once after the timed steps: no host wait between steps)
     eager_step = lambda: training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=group, bucket=bucket, sync_loss=False)
     step, graphed = eager_step, False
-    if use_graph:                                            # one process: the whole step replayed as a captured HIP graph
-        try:
-            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, group=group, global_batch_size=gb)
+    if use_graph:
+        def capture():
+            return training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, group=group, global_batch_size=gb, graph_collective=graph_collective)
+        if graph_collective:                                 # opt-in path: no fallback - a failure is this process's non-zero exit
+            step = capture()
             graphed = True
+        else:
+            try:
+                step = capture()
+                graphed = True
+            except Exception as e:
+                if td is not None:                           # ranks must not diverge (one eager, one replaying): fail the run instead
+                    raise
+                sys.stderr.write("train-step graph capture failed (%r); running eager\n" % (e,))
+                torch.cuda.synchronize()
+        if graphed:
             # a GPU-bound step (the oracle phases at N = 100: 12.9 ms of kernels in a 13.5 ms step) gains nothing from the replay and
             # pays for the graph's private memory pool; the host-bound ones (calibrator phases, small scenes) gain 15-35 %: keep the faster
             def clock(fn, n=4):
@@ -549,15 +569,12 @@ def train_main(args, rank, world, device, td, share):
                 return (time.perf_counter() - t0) / n
             t_graph, t_eager = clock(step), clock(eager_step)
             if td is not None:                               # every rank must take the same path: decide on the slowest rank's clocks
-                tt = torch.tensor([t_graph, t_eager], device=device, dtype=torch.float64)
+                tt = torch.tensor([t_graph, t_eager], device="cpu" if share else device, dtype=torch.float64)
                 td.all_reduce(tt, op=td.ReduceOp.MAX)
                 t_graph, t_eager = float(tt[0]), float(tt[1])
             if t_eager < 0.98 * t_graph:
                 step, graphed = eager_step, False
                 torch.cuda.empty_cache()
-        except Exception as e:
-            sys.stderr.write("train-step graph capture failed (%r); running eager\n" % (e,))
-            torch.cuda.synchronize()
 
     def barrier():
         if td is not None:
@@ -621,7 +638,11 @@ def train_main(args, rank, world, device, td, share):
                                                                    ", mlp_math bf16 (dense products on bf16 operands, fp32 accumulation and logic)"
                                                                    if args.mlp_math == "bf16" else ""),
                           "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
-                          "launch": "hip graph replay of the whole step (training.GraphedTrainStep)" if graphed else "eager",
+                          "launch": ("eager" if not graphed else "hip graph replay of the whole step (training.GraphedTrainStep)" if td is None else
+                                     "hip graph replay of the whole step, the all-reduce captured inside (training.GraphedTrainStep, graph_collective)"
+                                     if graph_collective else
+                                     "two hip graph replays per step (zero + forward + loss + backward | clip + Adam) with the all-reduce issued "
+                                     "eagerly between them (training.GraphedTrainStep)"),
                           "collective": "%s of the flat fp32 bucket per step (%s)" % (
                               "three all-reduces(sum) of contiguous ranges, issued during the backward," if (td is not None and args.overlap_allreduce)
                               else "one all-reduce(sum)", "gloo, shared GPU" if share else "RCCL")},

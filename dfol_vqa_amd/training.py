@@ -99,54 +99,94 @@ def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group
 
 
 class GraphedTrainStep(object):
-    """trainer.py:429-442 for ONE fixed list of ProgramBatches as a captured HIP graph: zero the gradients -> forward -> loss / B -> backward
-    -> clip_grad_norm_ -> optimizer step, replayed with one host call.  A train step is 250 - 700 launches (the calibrator phases are
-    host-bound: 4.6 ms of GPU work in a 6.9 ms step), and its launch sequence is static for a given batch shape, exactly like the
-    inference forward's (interpreter.GraphedForward).  The optimizer must be capturable (torch.optim.Adam(..., capturable=True): its step
-    counter lives on the device); new scenes of the same shapes are served by copying into `program_batch._object_features`; a batch
-    with other programs or shapes needs its own capture.  With `group` (data parallelism) the bucket's all-reduce is part of the graph.
-    `loss` is a 0-d device tensor that every replay overwrites (this rank's share of the summed loss).
+    """trainer.py:429-442 for ONE fixed list of ProgramBatches as captured HIP graphs: zero the gradients -> forward -> loss / B -> backward
+    -> [all-reduce] -> clip_grad_norm_ -> optimizer step, replayed with one host call.  A train step is 250 - 700 launches (the calibrator
+    phases are host-bound: 4.6 ms of GPU work in a 6.9 ms step), and its launch sequence is static for a given batch shape, exactly like
+    the inference forward's (interpreter.GraphedForward).  The optimizer must be capturable (torch.optim.Adam(..., capturable=True): its
+    step counter lives on the device); new scenes of the same shapes are served by copying into `program_batch._object_features`; a batch
+    with other programs or shapes needs its own capture.  `loss` is a 0-d device tensor that every replay overwrites (this rank's share of
+    the summed loss).
+
+    Data parallelism (`group`, one process per GPU; `data` is this rank's shard, the loss is divided by the GLOBAL batch size, the bucket
+    is required: one flat buffer, one collective).  The default is the ROBUST form: TWO graphs - A = zero + forward + loss + backward,
+    B = clip + optimizer step - with the bucket's all-reduce issued EAGERLY between the two replays: no collective is ever captured, so
+    nothing of the process group's machinery (its watchdog thread polls the events of issued collectives) can meet a stream capture; one
+    extra launch boundary is ~10 us of a 3 - 12 ms step, and it works with every backend (gloo included).  `graph_collective=True` is
+    the single-graph form with RCCL's all-reduce as a node of the graph (RCCL only): it aborted the process from the watchdog thread on
+    one box of round 3 (SIGABRT, not catchable), so it is opt-in and a caller that wants to survive it must run it in a child process.
+    Every rank must construct and replay the same number of times.
+
+    Replays rewrite the parameters on the device without touching their version counters, and every packed-weight cache of the library is
+    keyed on (data_ptr, _version): after each replay the versions of the trainable parameters are bumped, so an eager / GraphedForward
+    evaluation between replays repacks the CURRENT weights (the trainer's train-epoch-then-validate loop).
 
     Same lifetime rule as GraphedForward: tensors that came out of caches are referenced from `self._keep`."""
 
-    def __init__(self, model, optimizer, data, clip_norm, l1_lambda=0.0, bucket=None, warmup=2, group=None, global_batch_size=None):
+    def __init__(self, model, optimizer, data, clip_norm, l1_lambda=0.0, bucket=None, warmup=2, group=None, global_batch_size=None,
+                 graph_collective=False):
         from ._lib import keeping
+        if warmup < 1:
+            # the first eager step allocates the optimizer state, fills the host-side caches and packs the weight images: without it the
+            # capture would miss the pack kernels of a warm cache and replay stale weights
+            raise ValueError("GraphedTrainStep needs warmup >= 1")
         self._model, self._opt, self._data, self._bucket = model, optimizer, data, bucket
         self._clip, self._l1 = clip_norm, l1_lambda
-        # data parallel (one process per GPU, `group`): `data` is this rank's shard, the loss is divided by the GLOBAL batch size and the
-        # bucket's all-reduce is CAPTURED between the backward and the clip (RCCL collectives can be captured like kernels; the bucket is
-        # required then: one flat buffer, one collective node).  Every rank must capture and replay the same number of times.
-        self._group, self._world = group, 1
+        self._group, self._world, self._graph_collective = group, 1, bool(graph_collective)
         if group is not None:
             import torch.distributed as dist
             if bucket is None:
                 raise ValueError("GraphedTrainStep with a process group needs the persistent gradient bucket (parallel.GradBucket)")
             if getattr(bucket, "_segments", None) is not None:
-                raise ValueError("GraphedTrainStep captures ONE all-reduce after the backward: use a bucket without enable_overlap()")
+                raise ValueError("GraphedTrainStep issues ONE all-reduce after the backward: use a bucket without enable_overlap()")
             self._world = dist.get_world_size(group)
+            if self._graph_collective and dist.get_backend(group) != "nccl":
+                raise ValueError("graph_collective=True captures the all-reduce: RCCL (backend 'nccl') only; host-side backends cannot be captured")
         self._local_batch = sum(d.batch_size() for d in data)
         self._batch = global_batch_size if global_batch_size is not None else self._local_batch
         for g in optimizer.param_groups:
             if not g.get("capturable", False):
                 raise ValueError("GraphedTrainStep needs a capturable optimizer (torch.optim.Adam(params, lr=..., capturable=True))")
+        self._params = [p for g in optimizer.param_groups for p in g["params"]]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                        # warm-up on a side stream (fills every host-side cache, allocates optimizer state)
             for _ in range(warmup):
-                self._body()
+                self._front()
+                if group is not None:
+                    bucket.allreduce(group)
+                self._back()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if group is not None:
+            self._quiesce()
         torch.cuda.empty_cache()                             # the warm-up's activations go back before the graph's private pool is sized
         self._keep = []
-        self._graph = torch.cuda.CUDAGraph()
-        # with a process group the backend's watchdog thread polls the events of earlier collectives: under the default ("global") capture
-        # mode such a query from ANOTHER thread is an error that takes the process down ("operation not permitted when stream is
-        # capturing"); thread-local mode restricts the check to the capturing thread
+        # (thread-local capture mode: the check for capture-unsafe calls is restricted to the capturing thread; a process group's watchdog
+        # thread may query an event of an earlier collective at any time, which under the default "global" mode invalidates the capture)
         mode = {} if group is None else {"capture_error_mode": "thread_local"}
-        with keeping(self._keep), torch.cuda.graph(self._graph, **mode):
-            self.loss, self.result = self._body()
+        self._graph = torch.cuda.CUDAGraph()
+        self._graph_b = None
+        if group is None or self._graph_collective:
+            with keeping(self._keep), torch.cuda.graph(self._graph, **mode):
+                self.loss, self.result = self._front()
+                if group is not None:
+                    bucket.allreduce(group)
+                self._back()
+        else:
+            with keeping(self._keep), torch.cuda.graph(self._graph, **mode):
+                self.loss, self.result = self._front()
+            self._graph_b = torch.cuda.CUDAGraph()
+            with keeping(self._keep), torch.cuda.graph(self._graph_b, pool=self._graph.pool(), **mode):
+                self._back()
 
-    def _body(self):
+    @staticmethod
+    def _quiesce():
+        """No collective may be in flight, nor still on the watchdog's list, when a capture starts: the device is idle (the caller
+        synchronised), and the watchdog drops completed work within one poll interval (100 ms)."""
+        import time
+        time.sleep(0.25)
+
+    def _front(self):
         if self._bucket is not None:
             self._bucket.zero_()
         else:
@@ -154,14 +194,18 @@ class GraphedTrainStep(object):
         result = self._model(self._data, True)
         loss = compute_loss(self._data, result, self._l1, list(self._model.parameters()), l1_scale=1.0 / self._world) / self._batch
         loss.backward()
-        if self._group is not None:
-            self._bucket.allreduce(self._group)
+        return loss.detach() * self._batch, result
+
+    def _back(self):
         nn.utils.clip_grad_norm_(self._model.parameters(), self._clip)
         self._opt.step()
-        return loss.detach() * self._batch, result
 
     def __call__(self):
         self._graph.replay()
+        if self._graph_b is not None:
+            self._bucket.allreduce(self._group)              # eager, between the two replays, on the replays' stream
+            self._graph_b.replay()
+        torch.autograd.graph.increment_version(self._params)   # the replay rewrote them: version-keyed weight caches must miss
         return self.loss, self.result
 
 

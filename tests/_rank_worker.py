@@ -120,7 +120,8 @@ def train_case(rank, world, out):
 
 
 def graph_case(rank, world, out):
-    """training.GraphedTrainStep with a process group: the bucket all-reduce captured inside the step graph; three replays == three eager
+    """training.GraphedTrainStep with a process group: by default two graphs with the bucket's all-reduce issued eagerly between the replays
+    (any backend), with DFOL_TEST_GRAPH_COLLECTIVE=1 one graph with RCCL's all-reduce captured inside; three replays == three eager
     train_batch steps with the same group (losses and parameters bit for bit on the full-size model)."""
     import bench
     from dfol_vqa_amd import parallel, training
@@ -137,7 +138,9 @@ def graph_case(rank, world, out):
         bucket = parallel.GradBucket(params)
         gb = 8 * world
         if graphed:
-            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, warmup=1, group=dist.group.WORLD, global_batch_size=gb)
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, warmup=1, group=dist.group.WORLD, global_batch_size=gb,
+                                             graph_collective=os.environ.get("DFOL_TEST_GRAPH_COLLECTIVE") == "1")
+            out["graphs"] = 1 if step._graph_b is None else 2
             losses = [float(step()[0]) for _ in range(3)]
         else:
             losses = [float(training.train_batch(model, opt, pbs, 0.65, global_batch_size=gb, group=dist.group.WORLD, bucket=bucket, sync_loss=False)[0])

@@ -766,6 +766,54 @@ def test_graphed_train_step_full_size_model_equals_eager_bit_for_bit(math):
     assert l0[-1] != l0[0]
 
 
+def test_evaluation_between_graph_replays_sees_current_weights():
+    """The trainer's train-then-validate loop (trainer.py:429-442 then :685-720) with a replayed step graph: a replay rewrites the
+    parameters on the device, so every version-keyed packed-weight cache (split images of the dense layers, the pair kernel's W2 image,
+    the calibrator's transposed weights) must miss afterwards.  replay, eval, replay x2, eval == the same sequence with eager steps, bit
+    for bit - the second evaluation would run on the first one's stale images if a replay did not bump the versions."""
+    import importlib.util
+    from dfol_vqa_amd import parallel
+    spec = importlib.util.spec_from_file_location("bench_for_test4", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with pytest.raises(ValueError):
+        training.GraphedTrainStep(None, torch.optim.Adam([torch.zeros(1, device=DEV, requires_grad=True)], capturable=True), [], 0.65, warmup=0)
+    runs = []
+    for graphed in (False, True):
+        args = bench.parse(["--mode", "train", "--objects", "20", "--batch", "12"])
+        torch.manual_seed(9)
+        model, ontology, paths, names = bench.build_model(args, DEV, train=True)
+        _, pbs = bench.build_batch(args, 0, ontology, names, DEV)
+        eargs = bench.parse(["--objects", "20", "--batch", "12"])
+        _, ev = bench.build_batch(eargs, 3, ontology, names, DEV)              # other questions for the evaluation
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-2, capturable=True)
+        bucket = parallel.GradBucket(params)
+        if graphed:
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, warmup=1)
+        else:
+            training.train_batch(model, opt, pbs, 0.65, bucket=bucket, sync_loss=False)
+            step = lambda: training.train_batch(model, opt, pbs, 0.65, bucket=bucket, sync_loss=False)
+
+        def evaluate():
+            model.eval()
+            with torch.no_grad():
+                lp = model(ev, False)["log_probability"].detach().clone()
+            model.train()
+            return lp
+        seq = []
+        step()
+        seq.append(evaluate())
+        step()
+        step()
+        seq.append(evaluate())
+        runs.append(seq)
+    (e0, e1), (g0, g1) = runs
+    assert not torch.equal(e0, e1)                               # lr 1e-2: the weights moved between the two evaluations
+    assert torch.equal(e0, g0), (e0 - g0).abs().max().item()
+    assert torch.equal(e1, g1), (e1 - g1).abs().max().item()
+
+
 def test_train_step_on_shared_scenes_equals_per_question_scenes():
     """A batch collated with share_scenes=True (every image once, eight questions per image) TRAINS through the reference's layout - the
     interpreter expands the scenes to one copy per question when gradients have to reach the oracle (build_scene) - so its loss and every

@@ -117,15 +117,28 @@ def test_bench_over_rccl_world_size_one(mode, overlap):
     assert out["ranks"]["backend"] == "nccl" and out["value"] > 0
     if mode == "train":
         assert out["replicas_equal"] is True and out["allreduce_ms"] > 0
-        # without the overlap hooks the step is one HIP graph with RCCL's all-reduce captured inside (small scenes: the replay is the faster)
+        # without the overlap hooks the step is two HIP graphs with RCCL's all-reduce issued eagerly between the replays (small scenes: the
+        # replay is the faster); never the captured-collective form unless asked for
         assert ("graph" in out["config"]["launch"]) == (overlap == 0), out["config"]["launch"]
+        assert "captured inside" not in out["config"]["launch"]
 
 
 @pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2)])
 def test_graphed_train_step_with_process_group(tmp_path, backend, world):
-    """The step graph with data parallelism: the gradient bucket's all-reduce is captured between backward and clip.  One rank over RCCL
-    (the collective node really is RCCL's) and two ranks over gloo are not both capturable: gloo is host-side, so only the RCCL case runs."""
-    if backend == "gloo":
-        pytest.skip("gloo collectives run on the host and cannot be captured into a HIP graph")
-    outs = _run_ranks("graph", tmp_path, world=world, extra_env={"DFOL_TEST_BACKEND": "nccl"})
-    assert outs[0]["backend"] == "nccl" and outs[0]["graph_equals_eager"]
+    """The step graphs with data parallelism, robust form (the default): graph A = zero + forward + loss + backward, graph B = clip + Adam,
+    the gradient bucket's all-reduce issued EAGERLY between the two replays - one rank over RCCL and two ranks over gloo (sharing
+    cuda:0): three replays == three eager steps with the same group, bit for bit, replicas equal."""
+    outs = _run_ranks("graph", tmp_path, world=world, extra_env={"DFOL_TEST_BACKEND": backend})
+    assert all(o["backend"] == backend and o["graph_equals_eager"] and o["graphs"] == 2 for o in outs)
+
+
+def test_graphed_train_step_with_captured_collective(tmp_path):
+    """The opt-in single-graph form (graph_collective=True: RCCL's all-reduce is a node of the step graph).  It ran green on some boxes and
+    was aborted by the process group's watchdog thread (SIGABRT - nothing in-process can catch it) on another in round 3, which is why it
+    is opt-in and why this test runs it in a child process: an abort of the child is reported as an expected failure of the opt-in
+    path; a child that completes must equal the eager steps bit for bit."""
+    try:
+        outs = _run_ranks("graph", tmp_path, world=1, extra_env={"DFOL_TEST_BACKEND": "nccl", "DFOL_TEST_GRAPH_COLLECTIVE": "1"})
+    except (FileNotFoundError, ValueError):                      # the child died before it could write its findings
+        pytest.xfail("the captured-collective step graph took its process down on this box (opt-in path; the default is the two-graph form)")
+    assert outs[0]["backend"] == "nccl" and outs[0]["graph_equals_eager"] and outs[0]["graphs"] == 1

@@ -266,57 +266,8 @@ def compare(lp1, lp2, is_less):
 
 
 # ---- dense layers: forward = fused MFMA kernel, backward = the same kernels + the TN weight-gradient kernel ------
-class _LinearAct(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, act):
-        y = _lib.linear_act(x, weight, bias, act)
-        ctx.save_for_backward(x, weight, y)
-        ctx.act = act
-        ctx.has_bias = bias is not None
-        ctx.math = _lib._dense_math()                # the backward products run in the forward's arithmetic
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        with _lib.dense_math(ctx.math):
-            return _LinearAct._backward(ctx, g)
-
-    @staticmethod
-    def _backward(ctx, g):
-        x, weight, y = ctx.saved_tensors
-        if ctx.act == _lib.ACT_SIGMOID:
-            dz = g * y * (1 - y)
-        elif ctx.act == _lib.ACT_ELU:
-            dz = g * torch.where(y > 0, torch.ones_like(y), y + 1)
-        elif ctx.act == _lib.ACT_LOGSIGMOID:
-            dz = g * (1 - torch.exp(y))
-        else:
-            dz = g
-        dz = dz.contiguous()
-        # input gradient on the forward's own kernels, weight gradient on the deterministic TN kernel (csrc/dfol_dense_wgrad.hip);
-        # DFOL_TRAIN_GEMM=torch goes back to library GEMMs for A/B runs
-        own = os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch"
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = _lib.linear_gradx(dz, weight.detach()) if own else dz @ weight
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        gb = None
-        if ctx.needs_input_grad[1]:
-            if own:                          # (the bias gradient comes from the same pass over dz)
-                gw = _lib.linear_wgrad(dz, x if x.stride(-1) == 1 else x.contiguous(), bias=want_b)
-                if want_b:
-                    gw, gb = gw
-            else:
-                gw = dz.t() @ x
-        if want_b and gb is None:
-            gb = dz.sum(0)
-        return gx, gw, gb, None
-
-
 def linear_act(x, weight, bias, act, out=None):
     if out is None and _needs_grad(x, weight, bias):
-        if os.environ.get("DFOL_TRAIN_GEMM", "hip") == "torch":     # A/B runs: library GEMMs in the backward
-            return _LinearAct.apply(x, weight, bias, act)
         return torch.ops.dfol.linear_act(x, weight, bias, int(act))
     return _lib.linear_act(x, weight, bias, act, out)
 

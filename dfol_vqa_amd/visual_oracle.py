@@ -244,7 +244,7 @@ class _TallLinear(torch.autograd.Function):
                 gx = (g2.to(weight.dtype) @ weight).to(x.dtype).view_as(x)
         gw = gb = None
         if ctx.needs_input_grad[1]:
-            if g2.is_cuda and (g2.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch" or g2.dtype == torch.bfloat16):
+            if g2.is_cuda and g2.dtype in (torch.float32, torch.bfloat16):
                 # dY^T X over millions of rows: the deterministic TN kernel (csrc/dfol_dense_wgrad.hip); the bias gradient is the
                 # column sums of the dY rows it loads anyway (a separate sum over 3 GB costs 0.75 ms)
                 gw = L.linear_wgrad(g2 if g2.stride(-1) == 1 else g2.contiguous(), x2 if x2.stride(-1) == 1 else x2.contiguous(),
@@ -497,7 +497,7 @@ class ClassifierOracle(OracleBase):
             obj = world._obj
             D = (lin1.weight.shape[1] - 4) // 2
             assert obj.shape[1] == D, "object feature width does not match the relation network"
-            if obj.is_cuda and obj.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_GEMM", "hip") != "torch":
+            if obj.is_cuda and obj.dtype == torch.float32:
                 U = L.linear_act(obj, lin1.weight[:, :D], lin1.bias, L.ACT_NONE)          # forward and both gradients on the HIP kernels
                 V = L.linear_act(obj, lin1.weight[:, D:2 * D], None, L.ACT_NONE)
             else:

@@ -775,556 +775,6 @@ def test_g17_full_size_reference_goldens(g17_model, name):
 
 @pytest.mark.parametrize("kind", ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
                                   "two_same", "two_different", "all_same", "all_different", "compare"])
-def test_all_ops_against_oracle(ontology, oracle_ontology, kind):
-    """Random programs of every terminal operator against the oracle.  DFOL_FUZZ_SEEDS=n runs n differently seeded batches
-    (different scene sizes and ProgramBatch splits) instead of one."""
-    for rnd in range(int(os.environ.get("DFOL_FUZZ_SEEDS", "1"))):
-        _all_ops_case(ontology, oracle_ontology, kind, zlib.crc32(kind.encode()) % 1000 + 7919 * rnd, 2 + rnd % 3, (2, 40) if rnd % 2 == 0 else (1, 17))
-
-
-def _all_ops_case(ontology, oracle_ontology, kind, seed, split, n_range):
-    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
-    qs, scenes = random_questions(kind, 24, n_range[0], n_range[1], C, CR, seed=seed)
-    model = table_model(ontology)
-    res, _ = run(model, qs, scenes, ontology, split=split)
-    lp = res["log_probability"].cpu().numpy()
-    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, split=split)
-    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, split=split)
-    # `compare` renormalises two aggregated log-probabilities: its output can agree between the reference's fp32 and fp64 runs while
-    # both inputs carry 1e-3 of rounding noise, so rule 1 of the policy (1e-4 where fp32 == fp64) is widened for it
-    # (K = 8 for `compare` only: its two inputs' rounding noise enters the renormalised output with a factor that the single fp32 sample
-    # of the reference does not bound; every other operator holds the default K = 2)
-    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], "%s seed %d" % (kind, seed))
-    if kind not in ("compare",):
-        # answers may only differ where the decision is a tie within rounding: two options with (nearly) equal
-        # probability, or a binary probability sitting on 0.5
-        lp64, lp32 = r64["log_probability"], r32["log_probability"].astype(np.float64)
-        if int(res["type"]) == int(D.QuestionType.QUERY):
-            sizes = [len(o) for o in r64["options"]]
-            off = np.concatenate([[0], np.cumsum(sizes)])
-            decided = []
-            for i in range(len(sizes)):
-                a64, a32 = lp64[off[i]:off[i + 1]], lp32[off[i]:off[i + 1]]
-                top = np.sort(a64)[::-1]
-                noise = np.abs(a32 - a64).max()        # how much an fp32 evaluation of this question's options moves
-                decided.append(len(top) < 2 or top[0] - top[1] > 4 * noise + 1e-4)
-        else:
-            decided = list(np.abs(np.exp(lp64) - 0.5) > 4 * np.abs(np.exp(lp32) - np.exp(lp64)) + 1e-5)
-        diff = [i for i, (x, y) in enumerate(zip(res["answer"], r64["answer"])) if x != y and decided[i]]
-        assert not diff, (kind, seed, diff)
-
-
-@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel"])
-def test_scenes_beyond_256_objects(ontology, oracle_ontology, kind):
-    """Scenes of 257..300 objects (NS > 256: the arity-2 kernels leave their registers-per-row forms for the plain ones, csrc/dfol_logic.hip)
-    through whole programs against the oracle.  No reference configuration is this large; the limit used to be a hard error."""
-    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
-    qs, scenes = random_questions(kind, 6, 257, 300, C, CR, seed=4242)
-    model = table_model(ontology)
-    res, _ = run(model, qs, scenes, ontology, split=2)
-    lp = res["log_probability"].cpu().numpy()
-    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, split=2)
-    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, split=2)
-    gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], "%s beyond 256 objects" % kind)
-
-
-def test_ragged_to_100_objects(ontology, oracle_ontology):
-    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
-    qs, scenes = random_questions("exist", 12, 60, 100, C, CR, seed=77)
-    scenes[3] = syn.table_scene(991, 1, C, CR)       # a single-object image rides along
-    model = table_model(ontology)
-    res, _ = run(model, qs, scenes, ontology)
-    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32)
-    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64)
-    gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "ragged100")
-
-
-def test_split_invariance(ontology):
-    """The same questions as 1 ProgramBatch and as 4: bit-identical when the batches share the padded tile
-    width (the width picks the lane mapping and with it the summation order), equal to rounding noise otherwise."""
-    C, CR = len(ontology._vocabulary["idx_to_arg"]), len(ontology._relation_index)
-    qs, scenes = random_questions("exist", 16, 5, 36, C, CR, seed=5)
-    for q in qs:      # negation anywhere in an op batch changes how its neighbours are rounded; keep this test free of it
-        for o in q["program"]["branches"][0]:
-            o["arguments"] = [a[4:-1] if isinstance(a, str) and a.startswith("not(") else a for a in o["arguments"]]
-    model = table_model(ontology)
-    r1, _ = run(model, qs, scenes, ontology, split=1)
-    r4, _ = run(model, qs, scenes, ontology, split=4)
-    assert (r1["log_probability"] - r4["log_probability"]).abs().max().item() <= 1e-4
-    assert r1["answer"] == r4["answer"]
-    # same padded width in every batch: identical bits
-    qs2, scenes2 = random_questions("exist", 16, 36, 36, C, CR, seed=6)
-    for q in qs2:
-        for o in q["program"]["branches"][0]:
-            o["arguments"] = [a[4:-1] if isinstance(a, str) and a.startswith("not(") else a for a in o["arguments"]]
-    r1, _ = run(model, qs2, scenes2, ontology, split=1)
-    r4, _ = run(model, qs2, scenes2, ontology, split=4)
-    assert torch.equal(r1["log_probability"], r4["log_probability"])
-
-
-# ---------------------------------------------------------------------------------------------------
-# needed-columns oracle (fused pair kernel) == the reference's full cached tables
-# ---------------------------------------------------------------------------------------------------
-def _neural_questions(kind, count, n_lo, n_hi, feat_dim, seed, names=None):
-    rng = np.random.RandomState(seed)
-    nouns, attrs, rels = (NOUNS, ATTRS, RELS) if names is None else names
-    op = syn.op
-    qs, scenes = [], []
-    for i in range(count):
-        qid = seed * 100 + i
-        pick = lambda xs: xs[rng.randint(len(xs))]
-        branch = [op("select", pick(nouns)), op("filter", pick(attrs)), op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"]))]
-        if rng.uniform() < 0.5:
-            branch.append(op("relate", "not(%s)" % pick(rels) if rng.uniform() < 0.3 else pick(rels), bool(rng.uniform() < 0.5), pick(nouns)))
-        last = {"exist": op("exist"), "verify_rel": op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)),
-                "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
-                "choose_attr": op("choose_attr", [attrs[0], attrs[1]])}[kind]
-        qs.append(syn.question(qid, [branch], last, "yes"))
-        scenes.append(syn.feature_scene(qid, int(rng.randint(n_lo, n_hi + 1)), feat_dim))
-    return qs, scenes
-
-
-@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "choose_attr"])
-def test_needed_columns_equals_full_tables_small(ontology, oracle_ontology, kind):
-    a, meta = gu.load("g5_neural_oracle")
-    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
-    model = neural_model(ontology, meta["config"], weights)
-    assert model._oracle.supports_needed_columns()
-    qs, scenes = _neural_questions(kind, 10, 1, 23, meta["config"]["box_features_dim"], seed=11)
-    res_needed, _ = run(model, qs, scenes, ontology, key="X")
-    model._oracle._needed_columns = False
-    res_full, _ = run(model, qs, scenes, ontology, key="X")
-    model._oracle._needed_columns = True
-    r32 = orc.run_questions(oracle_ontology, qs, scenes, np.float32, weights=weights)
-    r64 = orc.run_questions(oracle_ontology, qs, scenes, np.float64, weights=weights)
-    for res, tag in ((res_needed, "needed"), (res_full, "full")):
-        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], kind + ":" + tag)
-    assert res_needed["answer"] == res_full["answer"]
-
-
-def test_needed_columns_full_size_model(tmp_path):
-    """The reference architecture at full size (2048 -> 512, 516/1036 -> 256 -> 300 -> 2335): fused path vs full tables vs oracle."""
-    from dfol_vqa_amd import experiment
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(1)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    assert model._oracle.supports_needed_columns()
-    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
-    qs, scenes = _neural_questions("exist", 6, 3, 14, 2048, seed=3, names=nm)
-    res_needed, _ = run(model, qs, scenes, ont, key="X")
-    model._oracle._needed_columns = False
-    res_full, _ = run(model, qs, scenes, ont, key="X")
-    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
-    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
-    r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights)
-    r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights)
-    for res, tag in ((res_needed, "needed"), (res_full, "full")):
-        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "fullsize:" + tag)
-    assert res_needed["answer"] == res_full["answer"] == r64["answer"]
-
-
-@pytest.mark.parametrize("n_list,hops", [([100, 37, 64, 9], 1), ([256, 130], 4)])
-def test_full_size_model_large_scenes(tmp_path, n_list, hops):
-    """Full-size oracle on N = 100 (ragged, several pair tiles per image) and on BASELINE configs[4]'s shape: 256-object scenes and
-    8-hop open programs select -> (filter -> relate) x 4 -> query_attr.  Fused needed-columns path == full cached tables == oracle."""
-    from dfol_vqa_amd import experiment
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(2)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    nouns, attrs, rels = names["nouns"][:6], names["attributes"][:5], names["relations"][:4]
-    rng = np.random.RandomState(len(n_list) + hops)
-    pick = lambda xs: xs[rng.randint(len(xs))]
-    qs, scenes = [], []
-    for i, n in enumerate(n_list):
-        branch = [syn.op("select", pick(nouns))]
-        for _ in range(hops):
-            branch += [syn.op("filter", pick(attrs)), syn.op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"]))]
-        last = syn.op("query_attr", "category%02d" % (i % 3)) if hops > 1 else syn.op("exist")     # 26 options per question
-        qs.append(syn.question(4000 + i, [branch], last, "yes"))
-        scenes.append(syn.feature_scene(4000 + i, n, 2048))
-    res_needed, _ = run(model, qs, scenes, ont, key="X")
-    model._oracle._needed_columns = False
-    res_full, _ = run(model, qs, scenes, ont, key="X")
-    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
-    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
-    r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights)
-    r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights)
-    for res, tag in ((res_needed, "needed"), (res_full, "full")):
-        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "large:" + tag)
-    d = (res_needed["log_probability"] - res_full["log_probability"]).abs().max().item()
-    assert d <= (2e-4 if hops == 1 else 1e-3), d
-    dp = (res_needed["log_probability"].exp() - res_full["log_probability"].exp()).abs().max().item()
-    assert dp <= 1e-5, dp
-
-
-def test_bf16x3_contractions_equal_fp32_pipe_end_to_end(tmp_path, monkeypatch):
-    """The default forward (dense layers and pair MLP on the bf16 matrix pipe with the exact three-way operand split) against the same
-    model on the fp32 matrix pipe, through the whole interpreter on 100-object scenes: the final log-probabilities agree as two
-    fp32 evaluations of the same network do, and neither is closer to the float64 oracle than the other."""
-    from dfol_vqa_amd import experiment
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    nouns, attrs, rels = names["nouns"][:6], names["attributes"][:5], names["relations"][:4]
-    rng = np.random.RandomState(11)
-    pick = lambda xs: xs[rng.randint(len(xs))]
-    qs, scenes = [], []
-    for i, n in enumerate([100, 100, 73, 100, 41, 100]):
-        branch = [syn.op("select", pick(nouns)), syn.op("filter", pick(attrs)), syn.op("relate", pick(rels), bool(i & 1), pick(nouns + ["_"]))]
-        qs.append(syn.question(4300 + i, [branch], syn.op("exist"), "yes"))
-        scenes.append(syn.feature_scene(4300 + i, n, 2048))
-
-    def forward(pipe):
-        for var in ("DFOL_PAIR_MATH", "DFOL_DENSE_MATH"):
-            if pipe == "f32":
-                monkeypatch.setenv(var, "f32")
-            else:
-                monkeypatch.delenv(var, raising=False)
-        torch.manual_seed(5)
-        model = experiment.build_model(cfg, ont)            # a fresh model: packed weight images are cached per weight version
-        with torch.no_grad():
-            model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-            model._oracle._embedding_network.linear.bias.fill_(-2.0)
-        model = model.to(DEV).eval()
-        res, _ = run(model, qs, scenes, ont, key="X")
-        weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
-        return res["log_probability"].cpu().numpy().astype(np.float64), weights
-
-    lp_split, weights = forward("bf16x3")
-    lp_f32, _ = forward("f32")
-    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
-    lp64 = np.asarray(orc.run_questions(oont, qs, scenes, np.float64, weights=weights)["log_probability"], np.float64)
-    well = lp64 >= -5
-    assert well.sum() >= 3
-    assert np.abs(lp_split - lp_f32)[well].max() <= 2e-5, (lp_split, lp_f32)
-    e_split, e_f32 = np.abs(lp_split - lp64)[well].max(), np.abs(lp_f32 - lp64)[well].max()
-    assert e_split <= 2.0 * e_f32 + 2e-6, (e_split, e_f32)
-    assert np.abs(np.exp(lp_split) - np.exp(lp64)).max() <= 2.0 * np.abs(np.exp(lp_f32) - np.exp(lp64)).max() + 1e-6
-
-
-# ---------------------------------------------------------------------------------------------------
-# attention calibration (SURVEY.md §8(f) rank 2): LSTM passes + apply_modulations against the reference (g10)
-# ---------------------------------------------------------------------------------------------------
-class CalibrationCollater(TableCollater):
-    def __init__(self, ontology):
-        super(CalibrationCollater, self).__init__(1, ontology, "X")
-        self._ont = ontology
-
-    def collate_meta_data(self, questions):
-        names = list(self._ont._vocabulary["idx_to_arg"])
-        return {"index": {t: i for i, t in enumerate(names)}, "embedding": torch.from_numpy(self._ont.get_embeddings(names)).float()}
-
-
-@pytest.mark.parametrize("name", ["exist", "verify_attrs", "choose_attr", "query_attr", "verify_rel", "choose_rel", "and", "two_same",
-                                  "all_same", "compare"])
-def test_g10_attention_calibration(ontology, name):
-    a, meta = gu.load("g10_calibration")
-    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
-    model = neural_model(ontology, meta["config"], weights)
-    assert model._has_modulator
-    run_meta = meta["runs"][name]
-    qs = []
-    for i, q in enumerate(run_meta["questions"]):
-        qs.append({"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
-                   "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}})
-    pbs = CalibrationCollater(ontology).collate(qs)
-    for pb in pbs:
-        pb.create_sparse_tensors()
-    pbs = [pb.to_cuda(DEV) for pb in pbs]
-    with torch.no_grad():
-        res = model(pbs, False, modulator_switch=True)
-        res_off = model(pbs, False, modulator_switch=False)
-    gu.check_logprob(res_off["log_probability"].cpu().numpy(), a[name + ":lp_off_f32"], a[name + ":lp_off_f64"], name + " (switch off)")
-    gu.check_logprob(res["log_probability"].cpu().numpy(), a[name + ":lp_f32"], a[name + ":lp_f64"], name + " (calibrated)")
-    assert res["answer"] == run_meta["answer"]
-    # no modulation may be left behind for the next batch
-    for mod in model.modules():
-        for attr in ("_modulations", "_subject_modulations", "_object_modulations", "_forward_state", "_forward_subject_state", "_forward_object_state"):
-            assert not getattr(mod, attr, None), (type(mod).__name__, attr)
-
-
-def test_bf16_relation_tiles(tmp_path):
-    """Opt-in bf16 storage of the prefetched relation tiles (BASELINE configs[4]: 256-object scenes, 8-hop programs): the fused pair
-    kernel rounds the likelihoods to bf16, the single-posterior Relate kernel reads 8 of them per 16-byte load.  Against the fp32
-    path the results move by the rounding of the stored likelihoods only (relative 2^-9 per element, averaged out by the sums)."""
-    from dfol_vqa_amd import experiment
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    ont = experiment.build_ontology(syn.reference_config(paths))
-    torch.manual_seed(2)
-    model = experiment.build_model(syn.reference_config(paths, relation_tile_dtype="bf16"), ont)
-    assert model._oracle._tile_dtype == torch.bfloat16
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    nouns, attrs, rels = names["nouns"][:6], names["attributes"][:5], names["relations"][:4]
-    rng = np.random.RandomState(9)
-    pick = lambda xs: xs[rng.randint(len(xs))]
-    for n_list, hops in (([256, 130, 200], 4), ([40, 33, 17, 8], 2), ([36, 36], 1)):       # NS = 256, 40 (multiples of 8); 36 -> fp32 tiles
-        qs, scenes = [], []
-        for i, n in enumerate(n_list):
-            branch = [syn.op("select", pick(nouns))]
-            for h in range(hops):
-                rel = pick(rels)
-                branch += [syn.op("filter", pick(attrs)), syn.op("relate", "not(%s)" % rel if (h == 1 and i == 0) else rel, bool(rng.uniform() < 0.5),
-                                                                   pick(nouns + ["_"]))]
-            qs.append(syn.question(5000 + 10 * hops + i, [branch], syn.op("exist"), "yes"))
-            scenes.append(syn.feature_scene(5000 + 10 * hops + i, n, 2048))
-        model._oracle._tile_dtype = torch.bfloat16
-        res_b, _ = run(model, qs, scenes, ont, key="X")
-        model._oracle._tile_dtype = torch.float32
-        res_f, _ = run(model, qs, scenes, ont, key="X")
-        lb, lf = res_b["log_probability"].cpu().numpy(), res_f["log_probability"].cpu().numpy()
-        assert np.all(np.isfinite(lb))
-        assert np.abs(np.exp(lb) - np.exp(lf)).max() <= 2e-3, (n_list, np.abs(np.exp(lb) - np.exp(lf)).max())
-        assert np.abs(lb - lf).max() <= 2e-2 * max(1.0, np.abs(lf).max()), (n_list, lb, lf)
-        if max(n_list) % 8 == 0 or (max(n_list) + 3) // 4 * 4 % 8 == 0:
-            assert not np.array_equal(lb, lf), "bf16 tiles were not used"
-        else:
-            assert np.array_equal(lb, lf)
-
-
-def test_full_batch_properties(tmp_path):
-    """BASELINE-size batch (256 questions x 100 objects, full-size oracle) through size-independent properties, no oracle needed:
-    (1) permuting the objects of every scene leaves every log-probability unchanged (the logic is a function of sets of objects);
-    (2) reversing the question order reverses the outputs; (3) a batch run in four pieces equals the batch run at once."""
-    from dfol_vqa_amd import experiment
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(3)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
-    Q, N = 256, 100
-    qs, scenes = [], []
-    for i in range(Q):
-        br, last = syn.three_hop_program(8000 + i, nouns, attrs, rels)
-        qs.append(syn.question(8000 + i, br, last, "yes"))
-        scenes.append(syn.feature_scene(8000 + i, N, 2048))
-    base, _ = run(model, qs, scenes, ont, key="X")
-    lp = base["log_probability"].cpu().numpy()
-    assert lp.shape == (Q,) and np.all(np.isfinite(lp)) and np.all(lp <= 1e-6)
-    assert 0.02 < np.mean(np.exp(lp) > 0.5) < 0.98, "degenerate batch: every answer the same"
-    rng = np.random.RandomState(0)
-    permuted = [dict(s, X=s["X"][rng.permutation(N)]) for s in scenes]
-    lp_perm = run(model, qs, permuted, ont, key="X")[0]["log_probability"].cpu().numpy()
-    assert np.abs(np.exp(lp_perm) - np.exp(lp)).max() <= 2e-5 and np.abs(lp_perm - lp).max() <= 1e-3 * max(1.0, np.abs(lp).max())
-    lp_rev = run(model, qs[::-1], scenes[::-1], ont, key="X")[0]["log_probability"].cpu().numpy()
-    assert np.array_equal(lp_rev[::-1], lp)                      # same padded width, same kernels: bit-identical
-    lp_split = run(model, qs, scenes, ont, split=4, key="X")[0]["log_probability"].cpu().numpy()
-    assert np.array_equal(lp_split, lp)
-
-
-def test_graphed_forward_equals_eager(tmp_path):
-    """The captured-graph forward replays the same launches: identical log-probabilities and answers, also after the scene features
-    behind the ProgramBatch are overwritten in place, and for a QUERY operator whose answers are decoded after the replay."""
-    from dfol_vqa_amd import experiment
-    from dfol_vqa_amd.interpreter import GraphedForward
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(4)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
-    for kind in ("exist", "choose_attr"):
-        qs, scenes = _neural_questions(kind, 8, 12, 12, 2048, seed=21, names=nm)
-        qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
-        pbs = [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate(qq)]
-        with torch.no_grad():
-            eager = model(pbs, False)
-        g = GraphedForward(model, pbs)
-        r = g()
-        assert torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"]
-        assert r["answer_log_probability"] == eager["answer_log_probability"]
-        # new scenes of the same shape: overwrite the features in place, replay, compare with an eager run on the new features
-        for pb in pbs:
-            pb._object_features.copy_(torch.rand_like(pb._object_features))
-        with torch.no_grad():
-            eager2 = model(pbs, False)
-        r2 = g()
-        assert torch.equal(r2["log_probability"], eager2["log_probability"]) and r2["answer"] == eager2["answer"]
-        assert not torch.equal(r2["log_probability"], r["log_probability"])
-
-
-@pytest.mark.parametrize("explicit", [True, False])
-@pytest.mark.parametrize("kind", ["choose_attr", "verify_rel", "choose_rel", "exist"])
-def test_graphed_forward_survives_cache_eviction(tmp_path, kind, explicit, monkeypatch):
-    """A captured graph holds raw device addresses; the tensors it reads out of evictable caches (uploaded index arrays, geometry,
-    packed weight images) must stay alive with the graph.  Evict every cache, let the allocator recycle and overwrite the freed
-    memory, replay: the result must not change (round-1 advisor finding).  explicit = False switches every cache's own keep_alive()
-    call off: the registration inside _lib._ptr / _dp / LRUCache must be enough on its own (round-2 verdict #8)."""
-    import gc
-    from dfol_vqa_amd import _lib, experiment, fol_types, host_util
-    from dfol_vqa_amd.interpreter import GraphedForward
-    monkeypatch.setattr(_lib, "EXPLICIT_KEEP_ALIVE", explicit)
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(4)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
-    qs, scenes = _neural_questions(kind, 8, 12, 12, 2048, seed=21, names=nm)
-    pbs = [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])]
-    g = GraphedForward(model, pbs)
-    first = g()
-    lp0 = first["log_probability"].clone()
-    assert len(g._keep) > 0
-    # evict everything
-    host_util._upload_cache.clear()
-    _lib._SPLIT_W_CACHE.clear()
-    fol_types._geometry_cache.clear()
-    fol_types._pair_index_cache.clear()
-    ont.__dict__.get("_lower_cache", {}).clear()
-    model._oracle._split_cache = None
-    model._oracle._w2_cache = None
-    gc.collect()
-    torch.cuda.empty_cache()
-    # recycle: forwards on other batches (new uploads, new packs) and junk written over whatever was freed
-    qs2, scenes2 = _neural_questions("exist", 6, 5, 9, 2048, seed=77, names=nm)
-    pbs2 = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs2, scenes2)])]
-    with torch.no_grad():
-        model(pbs2, False)
-    # (many blocks of every small size class: whatever the evictions freed must be handed out again and overwritten, not just one block
-    # per size - with one, a dangling reference survived unnoticed on most boxes and faulted on one)
-    junk = [torch.full((128,), float("nan"), device=DEV) for _ in range(4096)]
-    junk += [torch.full((1 << k,), float("nan"), device=DEV) for k in range(4, 22) for _ in range(16 if k < 18 else 2)]
-    torch.cuda.synchronize()
-    again = g()
-    assert torch.equal(again["log_probability"], lp0) and again["answer"] == first["answer"]
-    del junk
-
-
-def test_graphed_forward_with_calibration(ontology):
-    """The calibrated forward (LSTM passes + modulations, ~230 launches per ProgramBatch) is captured and replayed as one graph."""
-    from dfol_vqa_amd.interpreter import GraphedForward
-    a, meta = gu.load("g10_calibration")
-    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
-    model = neural_model(ontology, meta["config"], weights)
-    for name in ("exist", "choose_rel"):
-        run_meta = meta["runs"][name]
-        qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
-               "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}}
-              for i, q in enumerate(run_meta["questions"])]
-        pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ontology).collate(qs)]
-        with torch.no_grad():
-            eager = model(pbs, False)
-        gu.check_logprob(eager["log_probability"].cpu().numpy(), a["%s:lp_f32" % name], a["%s:lp_f64" % name], "g10 " + name)
-        g = GraphedForward(model, pbs)
-        for _ in range(2):
-            r = g()
-            assert torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"]
-
-
-@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "choose_attr"])
-def test_full_size_fused_equals_full_tables_fuzz(tmp_path, kind):
-    """Full-size oracle, random ragged batches: the fused needed-columns dataflow (attr_ll + packed pair kernel + single-posterior
-    Relate) against the reference's dataflow on the same GPU (full cached tables + gathers + generic cell).  DFOL_FUZZ_SEEDS=n
-    runs n batches."""
-    from dfol_vqa_amd import experiment
-    paths, names = syn.write_synthetic_ontology(str(tmp_path))
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(5)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
-    for rnd in range(int(os.environ.get("DFOL_FUZZ_SEEDS", "1"))):
-        lo, hi = [(1, 40), (20, 64), (2, 9)][rnd % 3]
-        qs, scenes = _neural_questions(kind, 12, lo, hi, 2048, seed=300 + 17 * rnd + len(kind), names=nm)
-        model._oracle._needed_columns = True
-        a, _ = run(model, qs, scenes, ont, split=1 + rnd % 2, key="X")
-        model._oracle._needed_columns = False
-        b, _ = run(model, qs, scenes, ont, split=1 + rnd % 2, key="X")
-        la, lb = a["log_probability"].cpu().numpy(), b["log_probability"].cpu().numpy()
-        assert np.abs(np.exp(la) - np.exp(lb)).max() <= 2e-5, (kind, rnd, np.abs(np.exp(la) - np.exp(lb)).max())
-        assert np.abs(la - lb).max() <= 2e-3 * max(1.0, np.abs(lb).max()), (kind, rnd, np.abs(la - lb).max())
-
-
-# ---------------------------------------------------------------------------------------------------
-# BASELINE configs[2]'s shape: the full operator set on ragged scenes of 60..100 objects, full-size model
-# ---------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def full_size(tmp_path_factory):
-    from dfol_vqa_amd import experiment
-    d = str(tmp_path_factory.mktemp("fullsize"))
-    paths, names = syn.write_synthetic_ontology(d)
-    cfg = syn.reference_config(paths)
-    ont = experiment.build_ontology(cfg)
-    torch.manual_seed(2)
-    model = experiment.build_model(cfg, ont)
-    with torch.no_grad():
-        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
-        model._oracle._embedding_network.linear.bias.fill_(-2.0)
-    model = model.to(DEV).eval()
-    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
-    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
-    with open(paths["attribute_file"]) as f:
-        import json
-        categories = json.load(f)
-    return model, ont, oont, weights, names, categories
-
-
-def _full_size_questions(kind, count, n_lo, n_hi, names, categories, seed):
-    rng = np.random.RandomState(seed)
-    op = syn.op
-    nouns, rels = names["nouns"][:8], names["relations"][:5]
-    cats = sorted(categories)[:3]
-    attrs = [a for c in cats for a in categories[c][:4]]
-    qs, scenes = [], []
-    for i in range(count):
-        qid = seed * 1000 + i
-        pick = lambda xs: xs[rng.randint(len(xs))]
-        branch = [op("select", pick(nouns + ["_"]))]
-        for _ in range(rng.randint(1, 4)):
-            if rng.uniform() < 0.5:
-                a_ = pick(attrs)
-                branch.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.2 else a_))
-            else:
-                branch.append(op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
-        branches = [branch]
-        if kind in ("and", "or", "two_same", "two_different", "compare"):
-            branches.append([op("select", pick(nouns)), op("filter", pick(attrs))])
-        cat = pick(cats)
-        last = {"exist": op("exist"), "and": op("and"), "or": op("or"), "verify_attrs": op("verify_attrs", [pick(attrs), pick(attrs)]),
-                "verify_rel": op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)),
-                "choose_attr": op("choose_attr", [categories[cat][0], categories[cat][1]]), "query_attr": op("query_attr", cat),
-                "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
-                "two_same": op("two_same", cat), "two_different": op("two_different", cat), "all_same": op("all_same", cat),
-                "all_different": op("all_different", cat), "compare": op("compare", pick(attrs), bool(rng.uniform() < 0.5))}[kind]
-        qs.append(syn.question(qid, branches, last, "yes"))
-        scenes.append(syn.feature_scene(qid, int(rng.randint(n_lo, n_hi + 1)), 2048))
-    return qs, scenes
-
-
-@pytest.mark.parametrize("kind", ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
-                                  "two_same", "two_different", "all_same", "all_different", "compare"])
 def test_all_ops_full_size_model_ragged_60_to_100(full_size, kind):
     """Every terminal operator through the full-size interpreter (2048 -> 512, 516/1036 -> 256 -> 300 -> 2335, the fused needed-columns
     kernels) on ragged scenes of 60..100 objects - BASELINE configs[2]'s shape with synthetic features - against the oracle's fp32 and

@@ -129,6 +129,10 @@ SIGNATURES = {
     "dfol_pair_ll_split_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                _i32, _p, _p],
     "dfol_relate_one_fwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
+    "dfol_pair_w2_f16x2_bytes": [_i32],
+    "dfol_pair_pack_w2_f16x2": [_p, _i64, _i32, _i32, _p, _p],
+    "dfol_pair_ll_h2_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
+                            _i32, _p, _p],
 }
 
 
@@ -148,6 +152,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.dfol_linear_wgrad_workspace.restype = ctypes.c_int64
+    lib.dfol_pair_w2_f16x2_bytes.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -676,6 +681,39 @@ def pair_ll_split(uv, hid1, pos, wg, w2_split, b2, hid2, emb_w, emb_b, n_obj, ob
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          TILE_BF16 if bf16 else TILE_F32, _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
+
+
+def pair_pack_w2_h2(w2, hid2=None):
+    """W2 [HID2(+padding), HID1] -> the fp16x2 image dfol_pair_ll_h2_f32 reads (rows scaled by powers of two, two fp16 pieces, swizzled;
+    the per-column multipliers of the epilogue behind the chunks)."""
+    hid1 = w2.shape[1]
+    hid2 = w2.shape[0] if hid2 is None else hid2
+    out = torch.empty(load().dfol_pair_w2_f16x2_bytes(hid1) // 2, dtype=torch.float16, device=w2.device)
+    call("dfol_pair_pack_w2_f16x2", _ptr(w2, F32), w2.stride(0), hid2, hid1, _ptr(out, torch.float16), _stream())
+    return out
+
+
+def pair_ll_h2(uv, hid1, pos, wg, w2_h2, b2, hid2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles,
+               default_ll=-30.0):
+    """As pair_ll_split, with the second layer split by pair_pack_w2_h2: fp16 matrix pipe, three products per fp32 product, fp32 results
+    (csrc/dfol_pair_h2.hip).  Ordered pairs only: `tiles` must be pre-filled with default_ll (diagonal and padding keep the fill)."""
+    K, Q = req_col.shape
+    NS = tiles.shape[1]
+    bf16 = tiles.dtype == torch.bfloat16
+    call("dfol_pair_ll_h2_f32", _dp(uv), uv.stride(0), hid1, _dp(pos), pos.stride(0), _ptr(wg, F32),
+         _ptr(w2_h2, torch.float16), _ptr(b2, F32), hid2, _dp(emb_w), emb_w.stride(0), _ptr(emb_b, F32, True), _ptr(n_obj, I32),
+         _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
+         TILE_BF16 if bf16 else TILE_F32, _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
+    return tiles
+
+
+def pair_math():
+    """Arithmetic of the fused pair kernel's second layer: "f16x2" (default: two fp16 pieces, three products), "bf16x3" (round 3's: three
+    bf16 pieces, six products) or "f32" (the fp32 matrix pipe) - all with fp32 results; DFOL_PAIR_MATH selects for A/B runs."""
+    m = os.environ.get("DFOL_PAIR_MATH", "f16x2")
+    if m not in ("f16x2", "bf16x3", "f32"):
+        raise DfolError("DFOL_PAIR_MATH=%r (f16x2, bf16x3 or f32)" % m)
+    return m
 
 
 # ---- training path of the pair MLP (csrc/dfol_pair_train.hip) ------------------------------------------------------

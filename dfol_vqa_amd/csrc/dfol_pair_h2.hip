@@ -1,0 +1,471 @@
+// Fused pair MLP with the second layer on the fp16 matrix pipe at fp32 accuracy, THREE products per fp32 product (gfx950).
+//
+// Round 3's kernel (csrc/dfol_pair_split.hip) cuts every fp32 operand into three bf16 pieces and issues six piece products per fp32
+// product: 0.55 of the bf16 pipe executed, 0.09 in algorithmic flops, and three rounds of schedule work moved it by < 3 %.  The lever
+// is the arithmetic: fp16 carries 11 significand bits against bf16's 8, so TWO pieces x = h + l (h = fp16(x), l = fp16(x - h), both
+// rounded to nearest even; x - h is exact in fp32) hold 22 - 23 bits, and the three products  al*wh + ah*wl + ah*wh  on
+// v_mfma_f32_16x16x32_f16 (fp32 accumulation, the same 2.5 PFLOP/s as bf16) leave out only al*wl <= 2^-22 |a w|.
+//
+// fp16 has a narrow exponent range, and this is where the accuracy is decided (measured, tools/lab/split_accuracy.hip ->
+// profiles/r04_split_accuracy_lab.txt, K = 256 dot products of ELU activations with U(-1/16, 1/16) weights, error against float64):
+//   * the low piece of a value below 2^-3 is SUBNORMAL in fp16.  The matrix pipe keeps subnormal operands (probe in the same lab: a
+//     2^-20 input survives); a pipe that flushed them would be off by 1e-4.  A subnormal low piece still has an absolute error of
+//     2^-25, so an operand's error is max(2^-22 |x|, 2^-25): harmless for activations of order 1, but weights of order 1/16 would
+//     carry 2^-21 relative.  unscaled weights: mean error 3.1e-7 (the fp32 FMA chain: 1.5e-7, bf16x3: 1.25e-7);
+//   * so every ROW of W2 is scaled by a power of two 2^e_r that puts its largest magnitude into [2^13, 2^14) (exact; chosen by the pack
+//     kernel on the device, no host round trip, overflow impossible for finite weights), and the epilogue folds 2^-e_r into the
+//     multiplier of the Sigmoid's exponent (the product is there anyway).  scaled weights: mean error 1.0e-7 - BELOW the fp32 FMA chain
+//     and the bf16x3 kernel, because the MFMA rounds once per 32 products;
+//   * activations are ELU outputs in (-1, inf): they are split unscaled and saturate at 6e4 (fp16's largest finite value is 65504).
+//     The first layer is fed by Sigmoid outputs and box geometry, |z| <= sum |W1| ~ 1036 |w|: an activation of 6e4 needs weights of
+//     magnitude 58.  The clamp costs nothing (it is the third operand of the v_med3 that implements the ELU's select).
+//
+// W2 image (dfol_pair_pack_w2_f16x2): per 32 k (one MFMA's depth) a 40 KB chunk [2 pieces][320 rows][4 k-groups] x 16 bytes, rows >=
+// HID2 zero, the four 8-element k-groups of row r stored at group kq ^ swz[(r >> 2) & 3] (64-byte rows: every ds_read_b128 of a B
+// fragment is bank-conflict-free), copied to LDS verbatim by LDS-DMA; after the chunks 320 floats -log2(e) 2^-e_r (the Sigmoid's
+// per-column multiplier) and the 320 exponents.
+//
+// Schedule: the ping-pong of the bf16x3 kernel (one 8-wavefront workgroup per CU; in every tick one half runs a chunk's MFMAs - 114 now,
+// not 228 - while the other half loads U / V rows, requests the next W2 chunk and builds its A pieces).
+#include "dfol_common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+// -DDFOL_PAIR_TRACE: clock64 stamps of one wavefront per half in a few workgroups (tools/lab/trace_pair.py reads them)
+#ifdef DFOL_PAIR_TRACE
+__device__ long long dfol_h2_trace_buf[8 * 8 * 64];
+#define TRACE(slot)                                                                                                  \
+    do {                                                                                                             \
+        if (trace_on && lane == 0) dfol_h2_trace_buf[(trace_blk * 8 + wave) * 64 + (slot)] = clock64();              \
+    } while (0)
+#else
+#define TRACE(slot)
+#endif
+
+// U / V rows of chunk c + 1 requested at the top of the multiply tick of chunk c (1) or at the top of their own build tick (0)
+#ifndef DFOL_H2_PREFETCH
+#define DFOL_H2_PREFETCH 1
+#endif
+// tiles of B fragments requested ahead of the MFMAs that use them (a tile's six MFMAs are 96 cycles of the pipe: less than an LDS round trip
+// under load, so one tile ahead - the bf16x3 kernel's distance, with twelve MFMAs per tile - leaves the reads exposed)
+#ifndef DFOL_H2_BDEPTH
+#define DFOL_H2_BDEPTH 2
+#endif
+// Y's request for the next W2 chunk: 1 = after its A pieces are built (the compiler's wait in front of the first use of the U / V rows is a
+// vmcnt(0) as soon as a global_load_lds is in flight - issued first, the DMA is waited for in the build tick); 0 = before
+#ifndef DFOL_H2_DMA_LATE
+#define DFOL_H2_DMA_LATE 1
+#endif
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float H2_NL2E = -1.44269504088896340736f;         // -log2(e)
+constexpr int H2_CH = 32;                                   // K per chunk = one v_mfma_f32_16x16x32_f16
+constexpr int H2_ROWS = 320, H2_TILES = 20;                 // rows (hidden columns) of the packed image
+constexpr int H2_PIECES = 2 * H2_ROWS * 4;                  // 16-byte pieces per chunk: 2560 = 40 KB
+constexpr float H2_AMAX = 60000.0f;                         // activations saturate here (fp16 max 65504)
+
+__device__ __forceinline__ int h2_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // {0,3,2,1}[(row>>2)&3]
+
+// (x0, x1) = (h0 + l0, h1 + l1) up to 2^-22 |x| (2^-25 absolute below 2^-3): v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32
+__device__ __forceinline__ void h2_split2(float x0, float x1, uint32_t& h, uint32_t& l) {
+    const f32x2 x = {x0, x1};
+    const f16x2 hh = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(hh, f32x2);
+    const f16x2 ll = __builtin_convertvector(r, f16x2);
+    h = __builtin_bit_cast(uint32_t, hh);
+    l = __builtin_bit_cast(uint32_t, ll);
+}
+
+// z + g * s with the scalar s taken from the LOW (HI = false) or HIGH half of the register pair `sp` for both lanes of the packed operation:
+// v_pk_fma_f32's op_sel / op_sel_hi pick the 32-bit half of each source per result lane.  The compiler only knows the plain form and
+// materialises {s, s} pairs - 16 registers for the eight geometry terms of a lane's two slots, which the kernel does not have.
+template <bool HI>
+__device__ __forceinline__ f32x2 h2_fma_bcast(f32x2 g, f32x2 sp, f32x2 z) {
+    f32x2 out;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(out) : "v"(g), "v"(sp), "v"(z));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(out) : "v"(g), "v"(sp), "v"(z));
+    return out;
+}
+
+// e^min(z, 0) - 1 on the hardware exponential
+__device__ __forceinline__ float h2_expm1_neg(float z) {
+    return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(z, 0.f, -3.0e38f) * 1.44269504088896340736f) - 1.0f;
+}
+
+// One wavefront per row of W2: e_r puts the row's largest magnitude into [2^13, 2^14); tail[r] = -log2(e) 2^-e_r, tail[320 + r] = e_r
+__global__ void h2_row_scale_kernel(const float* __restrict__ W2, int64_t ld_w2, int HID2, int HID1, float* __restrict__ tail) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= H2_ROWS) return;
+    float m = 0.f;
+    if (r < HID2)
+        for (int k = lane; k < HID1; k += 64) m = fmaxf(m, fabsf(W2[(int64_t)r * ld_w2 + k]));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) {
+        int x;
+        (void)frexpf(m, &x);                                // m = f 2^x, f in [0.5, 1)
+        e = 14 - x;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    if (lane == 0) {
+        tail[r] = ldexpf(H2_NL2E, -e);
+        reinterpret_cast<int32_t*>(tail)[H2_ROWS + r] = e;
+    }
+}
+
+// One thread per 16-byte piece of the packed image.
+__global__ void h2_pack_w2_kernel(const float* __restrict__ W2, int64_t ld_w2, int HID2, int HID1, const float* __restrict__ tail,
+                                  u32x4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (HID1 / H2_CH) * H2_PIECES) return;
+    const int c = idx / H2_PIECES, rem = idx - c * H2_PIECES;
+    const int p = rem / (H2_ROWS * 4), rr = rem - p * H2_ROWS * 4, r = rr >> 2, slot = rr & 3;
+    const int kq = slot ^ h2_swz(r);
+    const int e = reinterpret_cast<const int32_t*>(tail)[H2_ROWS + r];
+    uint32_t piece[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float w0 = 0.f, w1 = 0.f;
+        if (r < HID2) {
+            w0 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + kq * 8 + 2 * j], e);
+            w1 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + kq * 8 + 2 * j + 1], e);
+        }
+        uint32_t h, l;
+        h2_split2(w0, w1, h, l);
+        piece[j] = p == 0 ? h : l;
+    }
+    out[idx] = u32x4{piece[0], piece[1], piece[2], piece[3]};
+}
+
+// One 8-wavefront workgroup per CU owns 256 ordered pairs (s != o, row-major in s: util.py:87-103) of one image; a wavefront owns 32
+// of them (two 16-slot tiles) and all NB16 column tiles (2 x NB16 accumulator tiles: 152 registers at NB16 = 19).
+template <int NB16, bool TBF16>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32h_kernel(
+    const float* UV /* not __restrict__: see load_uv */, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
+    const float* __restrict__ Wg, const u32x4* __restrict__ W2h, const float* __restrict__ b2, int HID2,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
+    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
+    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
+    void* __restrict__ tiles_v) {
+    constexpr int MT = 2, WAVES = 8;
+    constexpr int ROWS = NB16 * 16, T = WAVES * 64, SLOTS = MT * 16 * WAVES;
+    static_assert(NB16 > 16 && NB16 <= H2_TILES, "geometry");
+    __shared__ __attribute__((aligned(16))) u32x4 Bs[2 * H2_PIECES];          // two W2 chunks, both pieces (40 KB each)
+    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    constexpr int STAGE_FLOATS = 8192;                          // the epilogue's bias / multiplier / embedding rows (32 KB)
+    __shared__ __attribute__((aligned(16))) float stage[STAGE_FLOATS];
+    const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
+    const int n = n_obj[q], npairs = n * (n - 1);
+    if (tb * SLOTS >= npairs) return;
+    bool any = false;
+    for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
+    if (!any) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
+#ifdef DFOL_PAIR_TRACE
+    const int trace_blk = ((int)blockIdx.x - 3000) / 500;
+    const bool trace_on = blockIdx.x >= 3000 && (blockIdx.x - 3000) % 500 == 0 && trace_blk < 8;
+#endif
+    TRACE(0);
+    const int nchunk = HID1 / H2_CH, lastc = nchunk - 1;
+    // chunk 0 is requested before anything else: it lands under the geometry arithmetic below
+#pragma unroll
+    for (int i = 0; i < H2_PIECES / T; ++i)
+        __builtin_amdgcn_global_load_lds(W2h + T * i + tid, (__attribute__((address_space(3))) void*)&Bs[T * i + wave * 64], 16, 0, 0);
+    const float* cf = reinterpret_cast<const float*>(W2h + (int64_t)nchunk * H2_PIECES);      // -log2(e) 2^-e_r per hidden column
+    const int first = obj_off[q];
+    f32x2 geo[MT][2];                                       // {distance, angle}, {sign dx, sign dy} (batch_gqa_boxfeatures_pipeline.py:263-279)
+    // U / V rows as 32-bit byte offsets from the image's first row (a scalar base: the loads take the saddr + voffset form; 64-bit per-lane
+    // pointers cost 16 registers that the prefetched rows need)
+    const char* img_uv = reinterpret_cast<const char*>(UV + (int64_t)first * ld_uv);
+    uint32_t uoff[MT], voff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int e_slot = tb * SLOTS + wave * (MT * 16) + m * 16 + r16;
+        const bool valid = e_slot < npairs;
+        const int s = valid ? e_slot / (n - 1) : 0, oo_ = valid ? e_slot - s * (n - 1) : 0, o = oo_ + (oo_ >= s);      // (n >= 2 here)
+        const float* ps = pos + (int64_t)(first + s) * ld_pos;
+        const float* po = pos + (int64_t)(first + o) * ld_pos;
+        const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
+        const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        geo[m][0] = f32x2{dist, asinf(dy / fmaxf(dist, 1e-10f))};
+        geo[m][1] = f32x2{(x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f), (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f)};
+        uoff[m] = (uint32_t)(s * (int)ld_uv + 8 * kh) * 4u;
+        voff[m] = (uint32_t)(o * (int)ld_uv + HID1 + 8 * kh) * 4u;
+    }
+    for (int i = tid; i < HID1; i += T) {                    // geometry weights, transposed to [feature][k]
+        const float4 g = *reinterpret_cast<const float4*>(Wg + i * 4);
+        Wgs[i] = g.x, Wgs[256 + i] = g.y, Wgs[512 + i] = g.z, Wgs[768 + i] = g.w;
+    }
+    // the epilogue's rows are staged up front (the first barrier publishes them): row 0 the hidden bias times -log2(e), row 1 the
+    // per-column multiplier -log2(e) 2^-e_r, then the requested embedding rows.  Padding columns get bias -1e30: Sigmoid exactly 0.
+    constexpr int SR = STAGE_FLOATS / ROWS - 2;
+    for (int i = tid; i < ROWS; i += T) {
+        stage[i] = H2_NL2E * (i < HID2 ? b2[i] : -1.0e30f);     // Sigmoid(x + b) = 1 / (1 + 2^(-L2E x - L2E b))
+        stage[ROWS + i] = i < HID2 ? cf[i] : 0.f;
+    }
+    const int Kc = K < SR ? K : SR;
+    for (int k = 0; k < Kc; ++k) {
+        const int col = req_col[(int64_t)k * Q + q];
+        for (int i = tid; i < ROWS; i += T) stage[ROWS * (2 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
+    }
+
+    floatx4 acc[MT][NB16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) acc[m][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // The whole chunk c -> chunk buffer `buf`, requested by the 4 wavefronts of half Y (10 passes of 256 pieces; a wavefront's 64 pieces of a
+    // pass are 1 KiB of contiguous LDS: wave-uniform base, the hardware adds lane * 16 bytes)
+    auto dma_chunk = [&](int c, int buf) __attribute__((always_inline)) {
+        const int w = wave - 4, t = tid - 256;
+#pragma unroll
+        for (int i = 0; i < H2_PIECES / 256; ++i)
+            __builtin_amdgcn_global_load_lds(W2h + (int64_t)c * H2_PIECES + 256 * i + t,
+                                             (__attribute__((address_space(3))) void*)&Bs[buf * H2_PIECES + 256 * i + w * 64], 16, 0, 0);
+    };
+    // A pieces of a chunk for the lane's slots: k = 32 c + 8 kh + 0..7.  Two ADJACENT k of one slot form every packed-math pair
+    // (U, V and the transposed geometry weights are contiguous in k): no register shuffles.
+    float4 ru[MT][2], rv[MT][2];                                    // [slot][half]: the lane's 8 first-layer terms of a chunk
+    auto load_uv = [&](int c) __attribute__((always_inline)) {
+        // (UV is deliberately not a __restrict__ pointer: loads through a noalias readonly pointer are free to move, and the compiler sinks
+        // the rows requested at the top of a multiply tick below the tick's closing barrier, to their first use - the prefetch then
+        // prefetches nothing; loads that may alias the kernel's stores stay on their side of the barrier's release fence)
+        // the chunk's offset stays in a scalar register (readfirstlane: loop strength reduction otherwise turns the four row addresses into
+        // 64-bit per-lane induction variables - 8 registers that spill); the pointer keeps its global address space (a pointer rebuilt
+        // from an integer is a FLAT one: flat loads also count in lgkmcnt, and the multiply tick's waits for B fragments would wait for them)
+        const char* base = img_uv + (uint32_t)__builtin_amdgcn_readfirstlane(H2_CH * 4 * c);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                ru[m][half] = *reinterpret_cast<const float4*>(base + uoff[m] + 16 * half);
+                rv[m][half] = *reinterpret_cast<const float4*>(base + voff[m] + 16 * half);
+            }
+    };
+    u32x4 ap[MT][2];                                                // [slot][piece h, l]
+    auto make_a = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                f32x2 g[4];                                         // geometry weights of k, k+1 for the four geometry features
+#pragma unroll
+                for (int d = 0; d < 4; ++d) g[d] = *reinterpret_cast<const f32x2*>(&Wgs[d * 256 + H2_CH * c + 8 * kh + 4 * half + 2 * jp]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f32x2 uu = jp == 0 ? (f32x2){ru[m][half].x, ru[m][half].y} : (f32x2){ru[m][half].z, ru[m][half].w};
+                    const f32x2 vv = jp == 0 ? (f32x2){rv[m][half].x, rv[m][half].y} : (f32x2){rv[m][half].z, rv[m][half].w};
+                    f32x2 z = uu + vv;
+                    z = h2_fma_bcast<false>(g[0], geo[m][0], z);
+                    z = h2_fma_bcast<true>(g[1], geo[m][0], z);
+                    z = h2_fma_bcast<false>(g[2], geo[m][1], z);
+                    z = h2_fma_bcast<true>(g[3], geo[m][1], z);
+                    // nn.ELU with the saturation: med3(z, e^min(z, 0) - 1, AMAX) = z in (0, AMAX], e^z - 1 for z <= 0 (e^z - 1 >= z), AMAX beyond
+                    // (min(z, 0) as a v_med3 too: fminf on the inline asm's result costs a canonicalising v_max per element)
+                    const float a0 = __builtin_amdgcn_fmed3f(z.x, h2_expm1_neg(z.x), H2_AMAX);
+                    const float a1 = __builtin_amdgcn_fmed3f(z.y, h2_expm1_neg(z.y), H2_AMAX);
+                    uint32_t hh, ll;
+                    h2_split2(a0, a1, hh, ll);
+                    ap[m][0][2 * half + jp] = hh;
+                    ap[m][1][2 * half + jp] = ll;
+                }
+            }
+    };
+    const int boff = r16 * 4 + (kh ^ h2_swz(r16));                  // the lane's 16-byte piece inside a 16-row block
+    int bbase = boff;                                               // + the chunk buffer's offset
+    auto load_b = [&](int i, f16x8 (&b)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(f16x8, Bs[bbase + i * 64 + p * H2_ROWS * 4]);
+    };
+    // The MFMAs of a chunk: the B fragments of tile i+1 are requested before the MFMAs of tile i, and the scheduler may not move anything
+    // across tiles (left alone it hoists the reads of all tiles to the top and spills).  The three products of one accumulator are issued
+    // back to back, smallest first: a dependent MFMA takes its C operand from the previous result without a register-file read.
+    constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};           // al wh, ah wl, ah wh
+    auto chunk_mfma = [&]() __attribute__((always_inline)) {
+        constexpr int D = DFOL_H2_BDEPTH;                           // tiles of B fragments in flight ahead of the MFMAs
+        f16x8 bq[D + 1][2];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_b(d, bq[d]);
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) {
+            if (i + D < NB16) load_b(i + D, bq[(i + D) % (D + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[m][PA3[x]]), bq[i % (D + 1)][PB3[x]], acc[m][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // LDS-DMA completion is tracked by vmcnt of the ISSUING wavefront only; a workgroup barrier does not wait for it by itself
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+    __syncthreads();                                        // Wgs, the staged epilogue rows and chunk 0 visible
+
+    // Tick tau: half X (wavefronts 0-3) builds chunk tau/2 on even ticks and multiplies it on the next; half Y (4-7) does the same one
+    // tick later.  Chunk c is read in ticks 2c+1 (X) and 2c+2 (Y); its buffer is refilled with chunk c+2 by Y during its build tick 2c+3
+    // and Y drains that DMA at the end of its multiply tick 2c+4, one tick before X needs it.  Chunk 1 goes into the free second buffer
+    // in Y's idle tick 0.  Each half runs its own copy of the loop (plain straight-line bodies for the register allocator); the barriers
+    // pair up by count: X executes 2 per chunk, Y one idle tick first and none after its last multiply.
+    auto run_half = [&](auto y_tag) __attribute__((always_inline)) {
+        constexpr bool Y = decltype(y_tag)::value;
+        TRACE(1);
+        if (Y) {
+            if (nchunk > 1) dma_chunk(1, 1);
+            if (DFOL_H2_PREFETCH) load_uv(0);
+            __syncthreads();                                // tick 0: X builds chunk 0
+        } else if (DFOL_H2_PREFETCH) {
+            load_uv(0);
+        }
+        TRACE(2);
+        for (int c = 0; c < nchunk; ++c) {
+            if (!DFOL_H2_PREFETCH) load_uv(c);
+            if (Y && !DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
+            make_a(c);
+            // the A pieces are pure register arithmetic: without these fences the compiler sinks them below the barrier, in front of the
+            // MFMAs of the multiply tick - the IR-level sinking into the block that uses them (the empty asm pins the values here), and
+            // the machine scheduler (sched_barrier)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(ap[m][p]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (Y && DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
+            TRACE(3 + 4 * c);
+            __syncthreads();                                // end of the build tick
+            __builtin_amdgcn_sched_barrier(0);
+            TRACE(4 + 4 * c);
+            bbase = boff + (c & 1) * H2_PIECES;
+            if (DFOL_H2_PREFETCH && c < lastc) load_uv(c + 1);      // lands under the MFMAs
+            chunk_mfma();
+            if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);      // the chunk requested in the build tick has landed
+            TRACE(5 + 4 * c);
+            if (!Y || c < lastc) __syncthreads();           // end of the multiply tick (Y's last one has no partner)
+            TRACE(6 + 4 * c);
+        }
+    };
+    if (wave < 4) run_half(std::false_type());
+    else run_half(std::true_type());
+
+    // Epilogue: Sigmoid of the hidden layer (the row scale of W2 folded into the exponent's multiplier), dot products with the requested
+    // embedding rows (16-lane DPP reduction), LogSigmoid, straight into the [s][o] (or [o][s]) tile the Relate kernel reads.
+    const int64_t tile_sz = (int64_t)NS * NS;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) {
+            const float bv = stage[i * 16 + r16], cm = stage[ROWS + i * 16 + r16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[m][i][e], cm, bv)));
+        }
+        for (int k = 0; k < K; ++k) {
+            const int col = req_col[(int64_t)k * Q + q];
+            if (col < 0) continue;
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+            if (k < Kc) {
+                const float* erow = stage + ROWS * (2 + k) + r16;
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) {
+                    const float ev = erow[i * 16];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[m][i][e], ev, part[e]);
+                }
+            } else {
+                const float* erow = E + (int64_t)col * ld_e;
+#pragma unroll
+                for (int i = 0; i < NB16; ++i) {
+                    const float ev = erow[min(i * 16 + r16, HID2 - 1)];     // padding columns: activation is exactly 0
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[m][i][e], ev, part[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e] = dfol_group_sum<16>(part[e]);
+            if (r16 < 4) {
+                const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
+                const int ee = tb * SLOTS + wave * (MT * 16) + m * 16 + 4 * kh + r16;
+                if (ee < npairs) {
+                    // ee / (n - 1) without the integer-division sequence: (ee + 0.5) / (n - 1) is at least 0.5 / (n - 1) away from an integer
+                    const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)(n - 1))), op = ee - ss * (n - 1), oo = op + (op >= ss);
+                    const float x = v + (be ? be[col] : 0.f);
+                    const float val = fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid (the diagonal keeps the caller's fill)
+                    const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
+                                       ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
+                    if (TBF16) {
+                        uint32_t u = __float_as_uint(val);
+                        u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even
+                        reinterpret_cast<uint16_t*>(tiles_v)[at] = (uint16_t)(u >> 16);
+                    } else {
+                        reinterpret_cast<float*>(tiles_v)[at] = val;
+                    }
+                }
+            }
+        }
+    }
+    TRACE(60);
+}
+
+}  // namespace
+
+#ifdef DFOL_PAIR_TRACE
+extern "C" int dfol_pair_h2_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dfol_h2_trace_buf), sizeof(dfol_h2_trace_buf)); }
+#endif
+
+extern "C" int64_t dfol_pair_w2_f16x2_bytes(int32_t HID1) { return (int64_t)(HID1 / H2_CH) * H2_PIECES * 16 + 2 * H2_ROWS * 4; }
+
+extern "C" int dfol_pair_pack_w2_f16x2(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, void* W2_split, void* stream) {
+    DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % H2_CH == 0, "pair_pack_w2_f16x2: HID1=%d must be a multiple of %d, <= 256", HID1, H2_CH);
+    DFOL_REQUIRE(HID2 > 256 && HID2 <= 320, "pair_pack_w2_f16x2: HID2=%d must be in (256, 320]", HID2);
+    DFOL_REQUIRE(W2 && W2_split && ld_w2 >= HID1, "pair_pack_w2_f16x2: null pointer or ld_w2 < HID1");
+    DFOL_REQUIRE((uintptr_t)W2_split % 16 == 0, "pair_pack_w2_f16x2: output must be 16-byte aligned");
+    const int total = (HID1 / H2_CH) * H2_PIECES;
+    float* tail = reinterpret_cast<float*>(reinterpret_cast<u32x4*>(W2_split) + total);
+    hipLaunchKernelGGL(h2_row_scale_kernel, dim3(H2_ROWS / 4), dim3(256), 0, (hipStream_t)stream, W2, ld_w2, HID2, HID1, tail);
+    hipLaunchKernelGGL(h2_pack_w2_kernel, dim3(dfol_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W2, ld_w2, HID2, HID1, (const float*)tail,
+                       (u32x4*)W2_split);
+    DFOL_LAUNCH_CHECK("pair_pack_w2_f16x2");
+    return 0;
+}
+
+extern "C" int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                                   const void* W2_split, const float* b2, int32_t HID2, const float* E, int64_t ld_e,
+                                   const float* be, const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n,
+                                   const int32_t* req_col, const int32_t* req_tile, const uint8_t* req_orient, int32_t K,
+                                   int32_t NS, float default_ll, int32_t tile_dtype, void* tiles_v, void* stream) {
+    DFOL_REQUIRE(tile_dtype == DFOL_TILE_F32 || (tile_dtype == DFOL_TILE_BF16 && NS % 8 == 0), "pair_ll_h2: tile_dtype=%d (bf16 tiles need NS %% 8 == 0)", tile_dtype);
+    DFOL_REQUIRE(Q >= 0 && K >= 0 && NS > 0 && NS % 4 == 0 && max_n >= 0 && max_n <= NS, "pair_ll_h2: bad sizes Q=%d K=%d NS=%d max_n=%d", Q, K, NS, max_n);
+    DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % H2_CH == 0 && ld_uv % 4 == 0, "pair_ll_h2: HID1=%d must be a multiple of %d, <= 256, UV rows 16-byte aligned", HID1, H2_CH);
+    DFOL_REQUIRE(HID2 > 256 && HID2 <= 320, "pair_ll_h2: HID2=%d must be in (256, 320]", HID2);
+    if (Q == 0 || K == 0 || max_n < 2) return 0;
+    DFOL_REQUIRE(UV && pos && Wg && W2_split && b2 && E && n_obj && obj_off && req_col && req_tile && tiles_v, "pair_ll_h2: null pointer");
+    DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_split % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_ll_h2: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int tpi = dfol_cdiv((int64_t)max_n * (max_n - 1), 256);
+    DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_h2: too many tiles");
+    DFOL_REQUIRE((int64_t)max_n * ld_uv * 4 < ((int64_t)1 << 31), "pair_ll_h2: an image's U / V rows must span less than 2 GB");
+    const dim3 grid((unsigned)Q * tpi);
+#define DFOL_PAIR32H(NBV, BF)                                                                                                       \
+    hipLaunchKernelGGL((pair_ll32h_kernel<NBV, BF>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
+                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
+    if (HID2 <= 272) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(17, true); else DFOL_PAIR32H(17, false); }
+    else if (HID2 <= 288) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(18, true); else DFOL_PAIR32H(18, false); }
+    else if (HID2 <= 304) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(19, true); else DFOL_PAIR32H(19, false); }
+    else { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(20, true); else DFOL_PAIR32H(20, false); }
+#undef DFOL_PAIR32H
+    DFOL_LAUNCH_CHECK("pair_ll_h2");
+    return 0;
+}

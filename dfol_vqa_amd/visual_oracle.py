@@ -446,7 +446,7 @@ class ClassifierOracle(OracleBase):
     def _padded_second_layer(self):
         """W2 zero-padded to a multiple of 32 rows, so the fused pair kernel's main loop needs no bounds checks."""
         lin = [m for m in self._relation_network._network if isinstance(m, nn.Linear)][1]
-        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias._version)
+        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias._version, L.pair_math())
         cache = getattr(self, "_w2_cache", None)
         if cache is None or cache[0] != key:
             w = lin.weight.detach()
@@ -457,10 +457,11 @@ class ClassifierOracle(OracleBase):
             if w.shape[1] % L.PACKED_W2_CHUNK == 0 and w.shape[1] <= 256 and w.shape[0] <= L.PACKED_W2_ROWS \
                     and os.environ.get("DFOL_PAIR_PACKED", "1") != "0":
                 packed = L.pair_pack_w2(wp, w.shape[0])      # the layout of the occupancy-2 pair kernel (csrc/dfol_pair.hip)
-                # full-size second layer: fp32 results from the bf16 matrix pipes (three exact bf16 pieces per operand,
-                # csrc/dfol_pair_split.hip); DFOL_PAIR_MATH=f32 keeps the fp32 matrix pipe
-                if L.pair_split_supported(w.shape[1], w.shape[0]) and os.environ.get("DFOL_PAIR_MATH", "bf16x3") != "f32":
-                    packed = ("bf16x3", L.pair_pack_w2_split(wp, w.shape[0]))
+                # full-size second layer: fp32 results from the fp16 matrix pipe (two fp16 pieces per operand, three products:
+                # csrc/dfol_pair_h2.hip) or, DFOL_PAIR_MATH=bf16x3, from the bf16 pipe (three pieces, six products: csrc/dfol_pair_split.hip);
+                # DFOL_PAIR_MATH=f32 keeps the fp32 matrix pipe
+                if L.pair_split_supported(w.shape[1], w.shape[0]) and L.pair_math() != "f32":
+                    packed = ("f16x2", L.pair_pack_w2_h2(wp, w.shape[0])) if L.pair_math() == "f16x2" else ("bf16x3", L.pair_pack_w2_split(wp, w.shape[0]))
             self._w2_cache = (key, wp, lin.bias.detach().contiguous(), w.shape[0], packed)
         return L.keep_alive(self._w2_cache)[1:]
 
@@ -695,7 +696,10 @@ class ClassifierOracle(OracleBase):
         up = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a).to(dev)
         rc, rt = up(req_col), up(req_tile)
         ro = None if req_orient is None else up(req_orient)
-        if isinstance(packed, tuple):
+        if isinstance(packed, tuple) and packed[0] == "f16x2":
+            L.pair_ll_h2(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._img_n_obj,
+                         world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
+        elif isinstance(packed, tuple):
             L.pair_ll_split(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._img_n_obj,
                             world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
         elif packed is not None:

@@ -373,6 +373,26 @@ int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const f
                            const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
                            int32_t tile_dtype, void* tiles, void* stream);
 
+/* The same relation tiles with the second layer on the fp16 matrix pipe at fp32 accuracy with THREE products per fp32 product
+ * (dfol_vqa_amd/csrc/dfol_pair_h2.hip; the default of the full-size oracle since round 4): each fp32 operand is cut into two fp16 pieces
+ * x = h + l (22-23 significand bits) and al*wh + ah*wl + ah*wh are accumulated in fp32 by v_mfma_f32_16x16x32_f16.  Every row of W2
+ * is scaled by a power of two chosen by the pack kernel (largest magnitude into [2^13, 2^14): the low pieces stay normal fp16 numbers,
+ * no finite weight overflows) and un-scaled in the epilogue; activations (ELU outputs) are split unscaled and SATURATE at 6e4 - fp16's
+ * range; the first layer is fed by Sigmoid outputs and box geometry, so this needs first-layer weights of magnitude ~58.  Measured
+ * against float64 the results are as accurate as the fp32-pipe kernel's (tests/test_kernels_gpu.py; profiles/r04_split_accuracy_lab.txt).
+ * W2_split is produced once per weight update by dfol_pair_pack_w2_f16x2: dfol_pair_w2_f16x2_bytes(HID1) bytes, 16-byte aligned
+ * ((HID1/32) chunks of [2 pieces][320 rows][32] fp16, k-groups swizzled, then 320 floats -log2(e) 2^-e_r and the 320 int32 exponents).
+ * All other arguments, the ordered-pairs-only enumeration (pre-fill the tiles with default_ll: the diagonal and the padding keep that
+ * fill) and the limits as dfol_pair_ll_split_f32: HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320.
+ * Replaces classifier_oracle.py:145-156 for the relation columns a program names (gqa_interpreter_experiments.py:18-36, 60-77). */
+int64_t dfol_pair_w2_f16x2_bytes(int32_t HID1);
+int dfol_pair_pack_w2_f16x2(const float* W2, int64_t ld_w2, int32_t HID2, int32_t HID1, void* W2_split, void* stream);
+int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                        const void* W2_split, const float* b2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
+                        const int32_t* n_obj, const int32_t* obj_off, int32_t Q, int32_t max_n, const int32_t* req_col,
+                        const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
+                        int32_t tile_dtype, void* tiles, void* stream);
+
 /* ---- training path of the pair MLP: the stages around its two tall GEMMs, fused (dfol_vqa_amd/csrc/dfol_pair_train.hip) ----------
  * Rows are the reference's ordered pairs (util.py:87-103): image-major, subject-major, the diagonal left out; pair_off[q] = first row of
  * image q ([Q] int64), obj_off[q] = its first object ([Q] int32), n_obj [Q].

@@ -370,13 +370,15 @@ def test_bf16x3_kernels_bitwise_repeatable(L):
     off = (torch.arange(Q + 1, device="cuda") * N).to(torch.int32)
     req_col = torch.randint(0, C, (K, Q), dtype=torch.int32, device="cuda")
     req_tile = torch.arange(K * Q, dtype=torch.int32, device="cuda").view(K, Q)
-    w2s = _lib.pair_pack_w2_split(w2, HID2)
-    first = None
-    for _ in range(25):
-        tiles = torch.full((K * Q, 104, 104), -30.0, device="cuda")
-        _lib.pair_ll_split(uv, HID1, pos, wg, w2s, b2, HID2, E, be, n_o, off, N, req_col, req_tile, None, tiles)
-        first = tiles.clone() if first is None else first
-        assert torch.equal(first, tiles)
+    for pack, run in ((_lib.pair_pack_w2_split, _lib.pair_ll_split), (_lib.pair_pack_w2_h2, _lib.pair_ll_h2)):
+        w2s = pack(w2, HID2)
+        first = None
+        for _ in range(25):
+            tiles = torch.full((K * Q, 104, 104), -30.0, device="cuda")
+            run(uv, HID1, pos, wg, w2s, b2, HID2, E, be, n_o, off, N, req_col, req_tile, None, tiles)
+            first = tiles.clone() if first is None else first
+            assert torch.equal(first, tiles)
+            assert torch.isfinite(tiles).all()
     x = torch.rand(25600, 2054, device="cuda")[:, :2048]
     w, b = torch.randn(512, 2048, device="cuda") / 45, torch.randn(512, device="cuda")
     first = None
@@ -587,6 +589,36 @@ def test_relate_negated_and_forall_fast_paths(L, n_list):
                 assert np.all(got[p, n:] == 0)
 
 
+def _pair_ref64(n_list, off, uv, pos, wg, w2, b2, E, be, req_col, req_tile, orient, hid1, hid2, K, NS):
+    """float64 restatement of the fused pair MLP (batch_gqa_boxfeatures_pipeline.py:243-281 pair features with the first layer split per
+    object, gqa_interpreter_experiments.py:18-36 the MLP, classifier_oracle.py:145-156 LogSigmoid of the requested columns)."""
+    Q = len(n_list)
+    ref = np.full((K * Q, NS, NS), -30.0)
+    for q, n in enumerate(n_list):
+        f = off[q]
+        for s in range(n):
+            for o in range(n):
+                if s == o:
+                    continue
+                x1, y1, w1, h1 = pos[f + s].astype(np.float64)
+                x2, y2, w2_, h2 = pos[f + o].astype(np.float64)
+                dx, dy = x1 + w1 / 2 - x2 - w2_ / 2, y1 + h1 / 2 - y2 - h2 / 2
+                dist = np.sqrt(dx * dx + dy * dy)
+                geo = np.array([dist, np.arcsin(dy / max(dist, 1e-10)), np.sign(x2 - x1), np.sign(y2 - y1)])
+                z = uv[f + s, :hid1].astype(np.float64) + uv[f + o, hid1:].astype(np.float64) + wg.astype(np.float64) @ geo
+                z = np.where(z > 0, z, np.expm1(z))
+                h = 1.0 / (1.0 + np.exp(-(w2[:hid2].astype(np.float64) @ z + b2)))
+                for k in range(K):
+                    c = req_col[k, q]
+                    if c >= 0:
+                        v = orc._log_sigmoid(np.array([h @ E[c].astype(np.float64) + be[c]]))[0]
+                        if orient[k, q]:
+                            ref[req_tile[k, q], o, s] = v
+                        else:
+                            ref[req_tile[k, q], s, o] = v
+    return ref
+
+
 @pytest.mark.parametrize("hid1,hid2,K", [(256, 300, 3), (256, 300, 40), (256, 300, 60), (256, 320, 2), (256, 270, 2), (224, 288, 3),
                                          (64, 200, 2), (32, 12, 2)])
 def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
@@ -612,30 +644,7 @@ def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
     req_col[:, 3] = -1                                         # an image nobody asks about
     req_tile = np.arange(K * Q, dtype=np.int32).reshape(K, Q)
     orient = (rng.uniform(size=(K, Q)) < 0.5).astype(np.uint8)
-    # fp64 reference
-    ref = np.full((K * Q, NS, NS), -30.0)
-    for q, n in enumerate(n_list):
-        f = off[q]
-        for s in range(n):
-            for o in range(n):
-                if s == o:
-                    continue
-                x1, y1, w1, h1 = pos[f + s].astype(np.float64)
-                x2, y2, w2_, h2 = pos[f + o].astype(np.float64)
-                dx, dy = x1 + w1 / 2 - x2 - w2_ / 2, y1 + h1 / 2 - y2 - h2 / 2
-                dist = np.sqrt(dx * dx + dy * dy)
-                geo = np.array([dist, np.arcsin(dy / max(dist, 1e-10)), np.sign(x2 - x1), np.sign(y2 - y1)])
-                z = uv[f + s, :hid1].astype(np.float64) + uv[f + o, hid1:].astype(np.float64) + wg.astype(np.float64) @ geo
-                z = np.where(z > 0, z, np.expm1(z))
-                h = 1.0 / (1.0 + np.exp(-(w2[:hid2].astype(np.float64) @ z + b2)))
-                for k in range(K):
-                    c = req_col[k, q]
-                    if c >= 0:
-                        v = orc._log_sigmoid(np.array([h @ E[c].astype(np.float64) + be[c]]))[0]
-                        if orient[k, q]:
-                            ref[req_tile[k, q], o, s] = v
-                        else:
-                            ref[req_tile[k, q], s, o] = v
+    ref = _pair_ref64(n_list, off, uv, pos, wg, w2, b2, E, be, req_col, req_tile, orient, hid1, hid2, K, NS)
     args = (dev(uv), hid1, dev(pos), dev(wg))
     tail = (dev(E), dev(be), dev(np.array(n_list, np.int32)), dev(off), max(n_list), dev(req_col), dev(req_tile), dev(orient))
     wanted = np.zeros((K * Q, NS, NS), bool)
@@ -659,6 +668,11 @@ def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
         outs["split"] = _lib.pair_ll_split(*args, split, dev(b2), hid2, *tail, t).cpu().numpy()
         t = torch.full((K * Q, NS, NS), -30.0, device="cuda", dtype=torch.bfloat16)
         outs["split_bf16"] = _lib.pair_ll_split(*args, split, dev(b2), hid2, *tail, t).float().cpu().numpy()
+        h2 = _lib.pair_pack_w2_h2(dev(w2), hid2)                # two fp16 pieces, three products, rows of W2 scaled: fp32 results (round 4 default)
+        t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+        outs["h2"] = _lib.pair_ll_h2(*args, h2, dev(b2), hid2, *tail, t).cpu().numpy()
+        t = torch.full((K * Q, NS, NS), -30.0, device="cuda", dtype=torch.bfloat16)
+        outs["h2_bf16"] = _lib.pair_ll_h2(*args, h2, dev(b2), hid2, *tail, t).float().cpu().numpy()
     for name, got in outs.items():
         tol = 2e-5 if "bf16" not in name else 0.0
         err = np.abs(got - ref)
@@ -667,10 +681,51 @@ def test_pair_ll_kernels_against_torch(L, hid1, hid2, K):
         else:
             assert err[wanted].max() <= tol * max(1.0, np.abs(ref[wanted]).max()), (name, err[wanted].max())
         assert np.all(got[~wanted] == -30.0), name                 # unrequested tiles, padding: untouched
-    if "split" in outs:                                        # as close to the exact result as the fp32 matrix pipe
-        e_split, e_f32 = np.abs(outs["split"] - ref)[wanted], np.abs(outs["packed"] - ref)[wanted]
-        assert e_split.max() <= 3 * e_f32.max() + 2e-7 and e_split.mean() <= 1.25 * e_f32.mean() + 1e-8, (e_split.max(), e_f32.max(),
-                                                                                                            e_split.mean(), e_f32.mean())
+    for name in ("split", "h2"):                               # as close to the exact result as the fp32 matrix pipe
+        if name in outs:
+            e_split, e_f32 = np.abs(outs[name] - ref)[wanted], np.abs(outs["packed"] - ref)[wanted]
+            assert e_split.max() <= 3 * e_f32.max() + 2e-7 and e_split.mean() <= 1.25 * e_f32.mean() + 1e-8, (name, e_split.max(), e_f32.max(),
+                                                                                                                e_split.mean(), e_f32.mean())
+
+
+def test_pair_h2_rows_of_any_scale_and_large_activations(L):
+    """The fp16x2 pair kernel's range handling: rows of W2 whose magnitudes span twelve decades (each row is scaled by its own power of
+    two in the pack kernel), an all-zero row, and first-layer sums up to ~2000 (activations are split unscaled: fp16 holds them up to
+    6e4) - results against float64 as close as the fp32-pipe kernel's."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(77)
+    hid1, hid2, K, n_list = 256, 300, 2, [9, 6, 12]
+    Q, O, NS, C = len(n_list), sum(n_list), 12, 20
+    off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
+    uv = rng.uniform(-1, 1, (O, 2 * hid1)).astype(np.float32)
+    uv[:, ::7] *= 300.0                                          # some first-layer sums in the hundreds and thousands
+    uv[:, 5::31] *= 1e-4                                         # and some tiny ones
+    pos = rng.uniform(0.05, 0.9, (O, 4)).astype(np.float32)
+    wg = rng.uniform(-0.5, 0.5, (hid1, 4)).astype(np.float32)
+    w2 = np.zeros((320, hid1), np.float32)
+    w2[:hid2] = rng.normal(size=(hid2, hid1)).astype(np.float32) / np.sqrt(hid1)
+    w2[:hid2] *= (10.0 ** rng.uniform(-9, 3, (hid2, 1))).astype(np.float32)      # row magnitudes from 1e-10 to 1e2
+    w2[:hid2, ::7] /= 300.0                                      # (keeps the hidden sums of order one where the activations are large)
+    w2[17] = 0.0
+    w2[40, 3:] = 0.0                                             # a row with a single entry
+    b2 = rng.normal(size=hid2).astype(np.float32)
+    E = (rng.normal(size=(C, hid2)) / np.sqrt(hid2)).astype(np.float32)
+    be = rng.normal(size=C).astype(np.float32)
+    req_col = rng.randint(0, C, (K, Q)).astype(np.int32)
+    req_tile = np.arange(K * Q, dtype=np.int32).reshape(K, Q)
+    orient = (rng.uniform(size=(K, Q)) < 0.5).astype(np.uint8)
+    ref = _pair_ref64(n_list, off, uv, pos, wg, w2, b2, E, be, req_col, req_tile, orient, hid1, hid2, K, NS)
+    args = (dev(uv), hid1, dev(pos), dev(wg))
+    tail = (dev(E), dev(be), dev(np.array(n_list, np.int32)), dev(off), max(n_list), dev(req_col), dev(req_tile), dev(orient))
+    t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+    got = _lib.pair_ll_h2(*args, _lib.pair_pack_w2_h2(dev(w2), hid2), dev(b2), hid2, *tail, t).cpu().numpy()
+    t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+    f32 = _lib.pair_ll_packed(*args, _lib.pair_pack_w2(dev(w2), hid2), dev(b2), hid2, *tail, t).cpu().numpy()
+    wanted = ref != -30.0
+    assert np.isfinite(got).all()
+    e_h2, e_f32 = np.abs(got - ref)[wanted], np.abs(f32 - ref)[wanted]
+    assert e_h2.max() <= 3 * e_f32.max() + 2e-7 and e_h2.mean() <= 1.25 * e_f32.mean() + 1e-8, (e_h2.max(), e_f32.max(), e_h2.mean(), e_f32.mean())
+    assert np.all(got[~wanted] == -30.0)
 
 
 @pytest.mark.parametrize("n_list", [[8, 3, 5, 1], [40, 33, 17, 8], [100, 104, 64, 2], [130, 256]])

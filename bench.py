@@ -332,8 +332,10 @@ def main(argv=None):
                       "objects_total_per_gpu": int(sum(args._scene_ns)),
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
                       "launch": "hip graph replay" if graphed else "eager",
-                      "contraction_math": "fp32 matrix pipe" if os.environ.get("DFOL_PAIR_MATH") == "f32" else
-                      "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)"}}
+                      "contraction_math": {"f32": "fp32 matrix pipe",
+                                           "bf16x3": "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)",
+                                           "f16x2": "fp32 results from the fp16 matrix pipe: 2 fp16 pieces per operand (weight rows scaled by powers of two), 3 of 4 piece "
+                                                    "products, fp32 accumulate (DESIGN 3.4)"}[os.environ.get("DFOL_PAIR_MATH", "f16x2")]}}
 
     out["ranks"] = ranks
     if args.sustain > 0:
@@ -416,17 +418,22 @@ def dominant_roofline(args, model, dom, per_step):
     KR = 4 if args.workload == "c4" else 1              # relation columns requested per image (one per relate hop of the program)
     if getattr(args, "_tiles_per_scene", None):
         KR = args._tiles_per_scene                       # shared scenes: distinct (relation, orientation) requests per image
-    if dom == "dfol_pair_ll_split_f32":
-        # The same algorithmic flops, executed on the bf16 matrix pipe as six piece products per fp32 product (three exact
-        # bf16 pieces per operand, fp32 accumulate: fp32 results, csrc/dfol_pair_split.hip).  `achieved` / `frac` follow the
-        # contract (ALGORITHMIC flops against the peak of the pipe that executes them); the pipe itself does 6x that work.
+    if dom in ("dfol_pair_ll_split_f32", "dfol_pair_ll_h2_f32"):
+        # The same algorithmic flops, executed on a 16-bit matrix pipe as piece products per fp32 product: three (two fp16 pieces per
+        # operand, csrc/dfol_pair_h2.hip, the default) or six (three exact bf16 pieces, csrc/dfol_pair_split.hip), fp32 accumulate, fp32
+        # results.  `achieved` / `frac` follow the contract (ALGORITHMIC flops against the peak of the pipe that executes them - the fp16
+        # and bf16 dense peaks are the same 2.5 PFLOP/s); the pipe itself does 3x / 6x that work (`executed`).
+        h2 = dom == "dfol_pair_ll_h2_f32"
+        pieces = 3 if h2 else 6
         flops = 2.0 * pairs * (4 * 256 + 256 * 300 + 300 * KR)
         ach = flops / secs
-        return {"kernel": "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)", "trace_name": "pair_ll32s_kernel", "bound": "mfma",
+        return {"kernel": "pair_ll32h_kernel<19> (fused pair MLP -> requested relation tiles, fp16x2 split)" if h2 else
+                          "pair_ll32s_kernel<19> (fused pair MLP -> requested relation tiles, bf16x3 split)",
+                "trace_name": "pair_ll32h_kernel" if h2 else "pair_ll32s_kernel", "bound": "mfma",
                 "achieved": ach / 1e12, "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
                 "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                 "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300 * KR),
-                "executed": {"mfma_flops_per_algorithmic_flop": 6, "achieved": 6 * ach / 1e12, "frac": 6 * ach / BF16_MFMA_PEAK},
+                "executed": {"mfma_flops_per_algorithmic_flop": pieces, "achieved": pieces * ach / 1e12, "frac": pieces * ach / BF16_MFMA_PEAK},
                 "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": ach / F32_MFMA_PEAK}}
     if dom in ("dfol_pair_ll_f32", "dfol_pair_ll_packed_f32"):
         # reduced-form algorithmic flops per ordered pair: geometry term, 256->300 layer, and the
@@ -437,13 +444,13 @@ def dominant_roofline(args, model, dom, per_step):
                 "achieved": ach / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK,
                 "traffic": None, "launches_per_step": launches, "us_per_launch": secs / launches * 1e6,
                 "flops_per_pair": 2 * (4 * 256 + 256 * 300 + 300)}
-    if dom in ("dfol_linear_act_f32", "dfol_linear_act_split_f32"):
+    if dom in ("dfol_linear_act_f32", "dfol_linear_act_split_f32", "dfol_linear_act_h2_f32"):
         if getattr(model._oracle, "_needed_columns", False) and model._oracle.supports_needed_columns():
             flops = 2.0 * O * (2048 * 512 + 516 * 256 + 256 * 300 + 516 * 512)
         else:   # full cached tables (only the 333 relation columns of the pair embedding are computed)
             flops = 2.0 * (O * 2048 * 512 + O * (516 * 256 + 256 * 300 + 300 * 2335) + pairs * (1036 * 256 + 256 * 300 + 300 * 333))
         ach = flops / secs
-        peak = BF16_MFMA_PEAK if dom.endswith("split_f32") else F32_MFMA_PEAK
+        peak = F32_MFMA_PEAK if dom == "dfol_linear_act_f32" else BF16_MFMA_PEAK
         return {"kernel": "%s (all GEMM launches of one step)" % dom, "bound": "mfma", "achieved": ach / 1e12,
                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
     N = args.objects
@@ -703,12 +710,20 @@ def train_kernel_rooflines(args, per_step):
             extra=lambda rate, pieces=pieces: {"executed": {"mfma_flops_per_algorithmic_flop": pieces, "achieved": pieces * rate / 1e12,
                                                             "frac": pieces * rate / BF16_MFMA_PEAK},
                                                "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": rate / F32_MFMA_PEAK}})
-    # the split-kernel GEMMs of the step: forward of the four per-object layers and the pair layer, input gradients of all but the featurizer
-    gflops = 2.0 * (2 * pairs * H2 * H1 + O * (512 * 2048 + 2 * (2 * H1 * 516 + 256 * 516 + H2 * 256)))
-    for entry, what in (("dfol_linear_act_split_f32", "linear_act_split_kernel"), ("dfol_linear_act_bf16_f32", "linear_act_split_kernel, one bf16 piece")):
-        pieces = 6 if entry.endswith("split_f32") else 1
-        add(entry, what + " (pair layer forward [pairs,256]->300 and its input gradient; the per-object layers forward and input gradients)",
-            "mfma", gflops, "2 (2 pairs HID2 HID1 + O (512 2048 + 2 (2 256 516 + 256 516 + 300 256))) flops", peak=BF16_MFMA_PEAK,
+    # the split-kernel GEMMs of the step: forward of the four per-object layers and of the pair layer (two fp16 pieces, three products - in the
+    # bf16 mode one bf16 piece), input gradients of all but the featurizer (three bf16 pieces, six products: operands of any magnitude)
+    fwd = 2.0 * (pairs * H2 * H1 + O * (512 * 2048 + 2 * H1 * 516 + 256 * 516 + H2 * 256))
+    bwd = 2.0 * (pairs * H2 * H1 + O * (2 * H1 * 516 + 256 * 516 + H2 * 256))
+    h2_runs = "dfol_linear_act_h2_f32" in per_step
+    for entry, what, work, note in (
+            ("dfol_linear_act_h2_f32", "linear_act_split_kernel, two fp16 pieces (the forward products: pair layer [pairs,256]->300, the per-object layers)", fwd,
+             "2 (pairs HID2 HID1 + O (512 2048 + 2 256 516 + 256 516 + 300 256)) flops"),
+            ("dfol_linear_act_split_f32", "linear_act_split_kernel, three bf16 pieces (the input-gradient products%s)" % ("" if h2_runs else " and the forward products"),
+             bwd if h2_runs else fwd + bwd, "2 (pairs HID2 HID1 + O (2 256 516 + 256 516 + 300 256)) flops" + ("" if h2_runs else " + the forward products'")),
+            ("dfol_linear_act_bf16_f32", "linear_act_split_kernel, one bf16 piece (forward and input-gradient products)", fwd + bwd,
+             "2 (2 pairs HID2 HID1 + O (512 2048 + 2 (2 256 516 + 256 516 + 300 256))) flops")):
+        pieces = {"dfol_linear_act_split_f32": 6, "dfol_linear_act_h2_f32": 3}.get(entry, 1)
+        add(entry, what, "mfma", work, note, peak=BF16_MFMA_PEAK,
             extra=lambda rate, pieces=pieces: {"executed": {"mfma_flops_per_algorithmic_flop": pieces, "achieved": pieces * rate / 1e12,
                                                             "frac": pieces * rate / BF16_MFMA_PEAK},
                                                "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": rate / F32_MFMA_PEAK}})

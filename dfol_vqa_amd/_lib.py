@@ -129,6 +129,9 @@ SIGNATURES = {
     "dfol_pair_ll_split_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                                _i32, _p, _p],
     "dfol_relate_one_fwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
+    "dfol_linear_w_f16x2_bytes": [_i32, _i32],
+    "dfol_linear_pack_w_f16x2": [_p, _i64, _i32, _i32, _p, _p],
+    "dfol_linear_act_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_w2_f16x2_bytes": [_i32],
     "dfol_pair_pack_w2_f16x2": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_h2_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
@@ -153,6 +156,7 @@ def load():
         fn.restype = ctypes.c_int
     lib.dfol_linear_wgrad_workspace.restype = ctypes.c_int64
     lib.dfol_pair_w2_f16x2_bytes.restype = ctypes.c_int64
+    lib.dfol_linear_w_f16x2_bytes.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -421,9 +425,13 @@ def linear_pack_w_split(weight, transpose=False, pieces=3):
     if hit is None:
         src = weight.detach().t().contiguous() if transpose else weight
         N, K = src.shape
-        out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 8192 * pieces // 2, dtype=torch.bfloat16, device=weight.device)
-        # pieces = 3: the exact three-way split; 1: the bf16 mode's image (rounded to nearest)
-        call("dfol_linear_pack_w_bf16x3" if pieces == 3 else "dfol_linear_pack_w_bf16", _dp(src), src.stride(0), N, K,
+        # pieces = 3: the exact three-way bf16 split; 2: two fp16 pieces of the row-scaled weights (+ the per-row factors); 1: the bf16
+        # mode's image (rounded to nearest)
+        if pieces == 2:
+            out = torch.empty(load().dfol_linear_w_f16x2_bytes(N, K) // 2, dtype=torch.bfloat16, device=weight.device)
+        else:
+            out = torch.empty(((N + 127) // 128) * ((K + 31) // 32) * 8192 * pieces // 2, dtype=torch.bfloat16, device=weight.device)
+        call({3: "dfol_linear_pack_w_bf16x3", 2: "dfol_linear_pack_w_f16x2", 1: "dfol_linear_pack_w_bf16"}[pieces], _dp(src), src.stride(0), N, K,
              _ptr(out, torch.bfloat16), _stream())
         for stale in [k for k in _SPLIT_W_CACHE if k[0] == key[0] and k[4:] == key[4:]]:    # an older version of the same parameter
             del _SPLIT_W_CACHE[stale]
@@ -434,9 +442,12 @@ def linear_pack_w_split(weight, transpose=False, pieces=3):
 
 
 def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
-    """y = act(x @ weight.T + bias) on the bf16 matrix pipes with exact three-way operand split: fp32 results.
-    transpose_w=True: y = act(x @ weight + bias) (weight [K, N])."""
+    """y = act(x @ weight.T + bias) on the 16-bit matrix pipes with split operands: fp32 results.  Forward products (activations of order
+    one) take two fp16 pieces and three products (dense_math "f16x2", the default); transpose_w=True: y = act(x @ weight + bias) (weight
+    [K, N]) is the input-gradient product of a backward pass - operands of any magnitude - and keeps the three bf16 pieces, six
+    products ("bf16x3"), whose exponent range is fp32's."""
     bf16 = _dense_math() == "bf16"                         # the bf16 mode: operands rounded to bf16, one product (configs[3])
+    h2 = _dense_math() == "f16x2" and not transpose_w and x.dtype == F32
     M, K = x.shape
     N = weight.shape[1] if transpose_w else weight.shape[0]
     if x.dtype == torch.bfloat16:                          # bf16-STORED activations (the per-pair tensors of a bf16-mode train step): bf16 in, bf16 out
@@ -449,8 +460,8 @@ def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
         return out
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
-    call("dfol_linear_act_bf16_f32" if bf16 else "dfol_linear_act_split_f32", _dp(x), x.stride(0),
-         _ptr(linear_pack_w_split(weight, transpose_w, 1 if bf16 else 3), torch.bfloat16), _ptr(bias, F32, True), _dp(out),
+    call("dfol_linear_act_bf16_f32" if bf16 else ("dfol_linear_act_h2_f32" if h2 else "dfol_linear_act_split_f32"), _dp(x), x.stride(0),
+         _ptr(linear_pack_w_split(weight, transpose_w, 1 if bf16 else (2 if h2 else 3)), torch.bfloat16), _ptr(bias, F32, True), _dp(out),
          out.stride(0), M, N, K, act, _stream())
     return out
 
@@ -503,10 +514,11 @@ _MATH_OVERRIDE = None
 
 
 def _dense_math():
-    """Arithmetic of the large dense products: "bf16x3" (default: fp32 results from the bf16 pipe), "f32" (the fp32 pipe) or "bf16"
-    (operands rounded to bf16, fp32 accumulation: BASELINE configs[3]'s "bf16 forward", config key `mlp_math: bf16`).  A dense_math()
-    scope takes precedence over the DFOL_DENSE_MATH environment variable."""
-    return _MATH_OVERRIDE or os.environ.get("DFOL_DENSE_MATH", "bf16x3")
+    """Arithmetic of the large dense products: "f16x2" (default: fp32 results from the fp16 pipe, two pieces per operand and three
+    products for the forward products, the backward products as "bf16x3"), "bf16x3" (fp32 results from the bf16 pipe: three pieces, six
+    products), "f32" (the fp32 pipe) or "bf16" (operands rounded to bf16, fp32 accumulation: BASELINE configs[3]'s "bf16 forward",
+    config key `mlp_math: bf16`).  A dense_math() scope takes precedence over the DFOL_DENSE_MATH environment variable."""
+    return _MATH_OVERRIDE or os.environ.get("DFOL_DENSE_MATH", "f16x2")
 
 
 class dense_math:
@@ -514,7 +526,7 @@ class dense_math:
     record the mode of their forward and re-enter it in backward."""
 
     def __init__(self, mode):
-        if mode not in (None, "bf16x3", "f32", "bf16"):
+        if mode not in (None, "f16x2", "bf16x3", "f32", "bf16"):
             raise DfolError("unknown dense math mode %r" % (mode,))
         self.mode = mode
 

@@ -58,12 +58,61 @@ __device__ __forceinline__ void ls_split8(const float4& a, const float4& b, u32x
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// NP = 2, round 4: TWO fp16 pieces per operand x = h + l (h = fp16(x), l = fp16(x - h), round to nearest even; x - h is exact) and
+// THREE products xl wh + xh wl + xh wh on v_mfma_f32_16x16x32_f16 (csrc/dfol_pair_h2.hip has the accuracy story: 22 - 23 significand bits
+// per operand, the dropped product below 2^-22; every row of W is scaled by its own power of two at pack time so that its low pieces
+// are normal fp16 numbers, and the epilogue multiplies the accumulator by 2^-e_n).  X is split UNSCALED: an element's error is
+// max(2^-22 |x|, 2^-25) - fp32-class for activations of order 1 (features, Sigmoid / ELU outputs: the forward products), and NOT for
+// operands of arbitrary magnitude (gradients): the backward products stay on the three bf16 pieces, whose exponent range is fp32's.
+// |x| > 65504 overflows fp16 (the result is NaN, loudly).
+__device__ __forceinline__ void ls_split2h(float x0, float x1, uint32_t& h, uint32_t& l) {
+    const f32x2 x = {x0, x1};
+    const f16x2 hh = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(hh, f32x2);
+    h = __builtin_bit_cast(uint32_t, hh);
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ void ls_split8h(const float4& a, const float4& b, u32x4& h, u32x4& l) {
+    uint32_t hh[4], ll[4];
+    ls_split2h(a.x, a.y, hh[0], ll[0]);
+    ls_split2h(a.z, a.w, hh[1], ll[1]);
+    ls_split2h(b.x, b.y, hh[2], ll[2]);
+    ls_split2h(b.z, b.w, hh[3], ll[3]);
+    h = u32x4{hh[0], hh[1], hh[2], hh[3]};
+    l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
 // two fp32 -> two bf16, round to nearest even (v_cvt_pk_bf16_f32): the operand form of the bf16 mode (NP = 1)
 __device__ __forceinline__ uint32_t ls_rne2(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); }
 
-// One thread per 16-byte piece of the packed image.  np = 3: the exact split; np = 1: the bf16 mode's image (one piece, rounded to nearest)
+// np = 2: one wavefront per (padded) row of W: e_n puts the row's largest magnitude into [2^13, 2^14); tail[n] = 2^-e_n, tail[rows + n] = e_n.
+__global__ void linear_row_scale_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int rows, float* __restrict__ tail) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    float m = 0.f;
+    if (n < N)
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[(int64_t)n * ldw + k]));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) {
+        int x;
+        (void)frexpf(m, &x);
+        e = 14 - x;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    if (lane == 0) {
+        tail[n] = ldexpf(1.0f, -e);
+        reinterpret_cast<int32_t*>(tail)[rows + n] = e;
+    }
+}
+
+// One thread per 16-byte piece of the packed image.  np = 3: the exact bf16 split; np = 2: the two fp16 pieces of the row-scaled weights
+// (`tail`: linear_row_scale_kernel's exponents); np = 1: the bf16 mode's image (one piece, rounded to nearest)
 __global__ void linear_pack_w_split_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, int ksteps, int nblocks, int np,
-                                           u32x4* __restrict__ out) {
+                                           const float* __restrict__ tail, u32x4* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int tile_pieces = np * LS_BN * 4;
     if (idx >= (int64_t)nblocks * ksteps * tile_pieces) return;
@@ -81,7 +130,17 @@ __global__ void linear_pack_w_split_kernel(const float* __restrict__ W, int64_t 
         ls_split(w[j], h, m, l);
         piece[j] = p == 0 ? h : (p == 1 ? m : l);
     }
-    if (np == 1) out[idx] = u32x4{ls_rne2(w[0], w[1]), ls_rne2(w[2], w[3]), ls_rne2(w[4], w[5]), ls_rne2(w[6], w[7])};
+    if (np == 2) {
+        const int e = reinterpret_cast<const int32_t*>(tail)[nblocks * LS_BN + n];
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t h, l;
+            ls_split2h(ldexpf(w[2 * j], e), ldexpf(w[2 * j + 1], e), h, l);
+            q[j] = p == 0 ? h : l;
+        }
+        out[idx] = u32x4{q[0], q[1], q[2], q[3]};
+    } else if (np == 1) out[idx] = u32x4{ls_rne2(w[0], w[1]), ls_rne2(w[2], w[3]), ls_rne2(w[4], w[5]), ls_rne2(w[6], w[7])};
     else out[idx] = u32x4{ls_pack(piece[0], piece[1]), ls_pack(piece[2], piece[3]), ls_pack(piece[4], piece[5]), ls_pack(piece[6], piece[7])};
 }
 
@@ -110,7 +169,7 @@ __device__ __forceinline__ float ls_act(float x) {
 template <int ACT, int XV, int NT, int NP, int RT, bool BIO>
 __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const void* __restrict__ Xv, int64_t ldx,
                                         const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Yv, int64_t ldy, int M, int N,
-                                        int K, int ksteps, int mb, int nb) {
+                                        int K, int ksteps, int mb, int nb, int nbn) {
     static_assert(!BIO || NP == 1, "bf16 storage belongs to the bf16 mode");
     typedef typename std::conditional<BIO, uint16_t, float>::type TX;
     const TX* __restrict__ X = reinterpret_cast<const TX*>(Xv);
@@ -172,6 +231,11 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                 const float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
                 if (NP == 1) {
                     As[at] = u32x4{ls_rne2(v0.x, v0.y), ls_rne2(v0.z, v0.w), ls_rne2(v1.x, v1.y), ls_rne2(v1.z, v1.w)};
+                } else if (NP == 2) {
+                    u32x4 ph, pl;
+                    ls_split8h(v0, v1, ph, pl);
+                    As[at] = ph;
+                    As[BM * 4 + at] = pl;
                 } else {
                     u32x4 ph, pm, pl;
                     ls_split8(v0, v1, ph, pm, pl);
@@ -204,6 +268,8 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 
     constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
     constexpr int X0 = NP == 1 ? 5 : 0;                               // the bf16 mode keeps the last product only (piece 0 x piece 0)
+    constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};             // NP = 2: xl wh, xh wl, xh wh (smallest first)
+    typedef typename std::conditional<NP == 2, f16x8, bf16x8>::type FR;
     // Step ks: X(ks) was requested two steps ago, the B tile one step ago, and X(ks+1) after it: vmcnt retires in order, so the
     // wait for the B registers leaves the four loads of X(ks+1) in flight.
     auto step = [&](int ks, auto set_tag, auto has_b, auto has_x) __attribute__((always_inline)) {
@@ -219,21 +285,28 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         __builtin_amdgcn_sched_barrier(0);                  // requests first; and the next step's split must not drift up here
 #pragma unroll
         for (int ih = 0; ih < RT; ih += 2) {                // two row tiles at a time (register budget)
-            bf16x8 a[2][NP];
+            FR a[2][NP];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(bf16x8, As[p * BM * 4 + (ih + i) * 64 + aoff]);
+                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(FR, As[p * BM * 4 + (ih + i) * 64 + aoff]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                bf16x8 b[NP];
+                FR b[NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(bf16x8, Bs[p * LS_BN * 4 + j * 64 + boff]);
+                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(FR, Bs[p * LS_BN * 4 + j * 64 + boff]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (NP == 2) {
 #pragma unroll
-                    for (int x = X0; x < 6; ++x)            // six dependent MFMAs per accumulator, smallest terms first
-                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA6[x]], b[PB6[x]], acc[ih + i][j], 0, 0, 0);
+                        for (int x = 0; x < 3; ++x)         // three dependent MFMAs per accumulator, smallest terms first
+                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][PA3[x]], b[PB3[x]], acc[ih + i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int x = X0; x < 6; ++x)        // six dependent MFMAs per accumulator, smallest terms first
+                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA6[x]], b[PB6[x]], acc[ih + i][j], 0, 0, 0);
+                    }
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);                  // (it would wait for X(ks+1) in the middle of the MFMAs)
@@ -270,6 +343,17 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     float bv[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[min(n0 + wn * WN + j * 16 + r16, N - 1)] : 0.f;
+    if constexpr (NP == 2) {                                          // un-scale the rows of W: acc <- acc 2^-e_n (exact), then the bias
+        const float* cs = reinterpret_cast<const float*>(Wp + (int64_t)nbn * ksteps * TILE_PIECES);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float c = cs[n0 + wn * WN + j * 16 + r16];          // (the tail is padded to whole column blocks)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] *= c;
+        }
+    }
     if constexpr (BIO) {
         // bf16 output: 2-byte stores straight from the accumulator layout (16 lanes x 2 bytes per row and instruction) cost a third of the
         // kernel (1.02 ms against 0.73 without any store); the tile goes through LDS instead - the step loop's last barrier has freed it - and
@@ -328,7 +412,7 @@ template <int ACT, int XV, int NP, int RT, bool BIO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIO ? DFOL_BIO_WAVES : 2, BIO ? DFOL_BIO_WAVES : (RT == 2 ? 3 : 2)))) void linear_act_split_kernel(
     const void* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Y,
     int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
-    constexpr int LP = BIO ? 1 : 3;                                         // (the fp32-storage kernels keep their 48 KB whatever NP: same occupancy as before)
+    constexpr int LP = BIO ? 1 : (NP == 2 ? 2 : 3);                         // (the bf16 mode's fp32-storage kernels keep the 48 KB of NP = 3: same occupancy as before)
     constexpr int A_PIECES = LP * 32 * RT * 4, B_PIECES = LP * LS_BN * 4;   // [piece][row][k-group] 24 KB (12 KB for 64-row blocks); the B tile of the step 24 KB
     constexpr int STAGE_PIECES = BIO ? 32 * RT * (LS_BN + 8) * 2 / 16 : 0;  // bf16 storage: the output tile staged for its stores (34 KB / 17 KB)
     __shared__ __attribute__((aligned(16))) u32x4 Sm[A_PIECES + B_PIECES > STAGE_PIECES ? A_PIECES + B_PIECES : STAGE_PIECES];
@@ -339,8 +423,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIO ? DFOL_
     int bid = blockIdx.x;
     if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     const int mb = bid / nbn, nb = bid - mb * nbn;
-    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
-    else ls_tile<ACT, XV, 2, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb);
+    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb, nbn);
+    else ls_tile<ACT, XV, 2, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb, nbn);
 }
 
 }  // namespace
@@ -354,8 +438,11 @@ static int ls_pack_w(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_
     DFOL_REQUIRE((uintptr_t)W_split % 16 == 0, "%s: output must be 16-byte aligned", name);
     const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
     const int64_t total = (int64_t)nbn * ksteps * np * LS_BN * 4;
+    float* tail = reinterpret_cast<float*>(reinterpret_cast<u32x4*>(W_split) + total);      // np = 2: 2^-e_n and e_n per padded row
+    if (np == 2)
+        hipLaunchKernelGGL(linear_row_scale_kernel, dim3(nbn * LS_BN / 4), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, nbn * LS_BN, tail);
     hipLaunchKernelGGL(linear_pack_w_split_kernel, dim3((unsigned)dfol_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, ksteps,
-                       nbn, np, (u32x4*)W_split);
+                       nbn, np, (const float*)tail, (u32x4*)W_split);
     DFOL_LAUNCH_CHECK(name);
     return 0;
 }
@@ -365,6 +452,13 @@ extern "C" int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N,
 }
 extern "C" int dfol_linear_pack_w_bf16(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_bf16, void* stream) {
     return ls_pack_w(W, ldw, N, K, W_bf16, stream, 1, "linear_pack_w_bf16");
+}
+extern "C" int64_t dfol_linear_w_f16x2_bytes(int32_t N, int32_t K) {
+    const int64_t nbn = dfol_cdiv(N, LS_BN);
+    return nbn * dfol_cdiv(K, LS_BK) * 2 * LS_BN * 4 * 16 + nbn * LS_BN * 8;
+}
+extern "C" int dfol_linear_pack_w_f16x2(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream) {
+    return ls_pack_w(W, ldw, N, K, W_split, stream, 2, "linear_pack_w_f16x2");
 }
 
 template <int NP>
@@ -419,6 +513,10 @@ extern "C" int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void
                                          int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     return ls_launch<3>(X, ldx, W_split, bias, Y, ldy, M, N, K, act, stream);
 }
+extern "C" int dfol_linear_act_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy,
+                                      int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    return ls_launch<2>(X, ldx, W_split, bias, Y, ldy, M, N, K, act, stream);
+}
 extern "C" int dfol_linear_act_bf16_f32(const float* X, int64_t ldx, const void* W_bf16, const float* bias, float* Y, int64_t ldy,
                                         int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     return ls_launch<1>(X, ldx, W_bf16, bias, Y, ldy, M, N, K, act, stream);
@@ -431,7 +529,9 @@ extern "C" int dfol_linear_act_bf16_bf16(const void* X_bf16, int64_t ldx, const 
     DFOL_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && ldy >= N, "linear_act_bf16_bf16: bad sizes M=%d N=%d K=%d (K %% 4, ldx %% 4)", M, N, K);
     if (M == 0) return 0;
     DFOL_REQUIRE(X_bf16 && W_bf16 && Y_bf16, "linear_act_bf16_bf16: null pointer");
-    DFOL_REQUIRE(((uintptr_t)X_bf16 % 8 == 0) && ((uintptr_t)W_bf16 % 16 == 0) && ((uintptr_t)Y_bf16 % 2 == 0), "linear_act_bf16_bf16: X must be 8-byte and W 16-byte aligned");
+    DFOL_REQUIRE(((uintptr_t)X_bf16 % 8 == 0) && ((uintptr_t)W_bf16 % 16 == 0), "linear_act_bf16_bf16: X must be 8-byte and W 16-byte aligned");
+    // the output tile leaves as 8-byte pieces of four columns: a piece must be wholly inside a row, and 8-byte aligned
+    DFOL_REQUIRE(N % 4 == 0 && ldy % 4 == 0 && (uintptr_t)Y_bf16 % 8 == 0, "linear_act_bf16_bf16: N=%d and ldy=%lld must be multiples of 4 and Y 8-byte aligned", N, (long long)ldy);
     const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
     static const int force_bm = getenv("DFOL_DENSE_BM") ? atoi(getenv("DFOL_DENSE_BM")) : 0;
     const bool small = force_bm ? force_bm == 64 : (int64_t)dfol_cdiv(M, LS_BM) * nbn < 512;

@@ -53,11 +53,11 @@ __device__ long long dfol_h2_trace_buf[8 * 8 * 64];
 #ifndef DFOL_H2_BDEPTH
 #define DFOL_H2_BDEPTH 2
 #endif
-// Y's request for the next W2 chunk: 1 = after its A pieces are built (the compiler's wait in front of the first use of the U / V rows is a
-// vmcnt(0) as soon as a global_load_lds is in flight - issued first, the DMA is waited for in the build tick); 0 = before
+// Y's request for the next W2 chunk: 0 = at the top of its build tick, 1 = after its A pieces are built
 #ifndef DFOL_H2_DMA_LATE
-#define DFOL_H2_DMA_LATE 1
+#define DFOL_H2_DMA_LATE 0
 #endif
+
 
 namespace {
 
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // A pieces of a chunk for the lane's slots: k = 32 c + 8 kh + 0..7.  Two ADJACENT k of one slot form every packed-math pair
     // (U, V and the transposed geometry weights are contiguous in k): no register shuffles.
-    float4 ru[MT][2], rv[MT][2];                                    // [slot][half]: the lane's 8 first-layer terms of a chunk
+    floatx4 ru[MT][2], rv[MT][2];                                    // [slot][half]: the lane's 8 first-layer terms of a chunk
     auto load_uv = [&](int c) __attribute__((always_inline)) {
         // (UV is deliberately not a __restrict__ pointer: loads through a noalias readonly pointer are free to move, and the compiler sinks
         // the rows requested at the top of a multiply tick below the tick's closing barrier, to their first use - the prefetch then
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                ru[m][half] = *reinterpret_cast<const float4*>(base + uoff[m] + 16 * half);
-                rv[m][half] = *reinterpret_cast<const float4*>(base + voff[m] + 16 * half);
+                ru[m][half] = *reinterpret_cast<const floatx4*>(base + uoff[m] + 16 * half);
+                rv[m][half] = *reinterpret_cast<const floatx4*>(base + voff[m] + 16 * half);
             }
     };
     u32x4 ap[MT][2];                                                // [slot][piece h, l]
@@ -334,6 +334,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TRACE(2);
         for (int c = 0; c < nchunk; ++c) {
             if (!DFOL_H2_PREFETCH) load_uv(c);
+            // The U / V rows of this chunk have landed - spelled out, and TIED to the registers: an s_waitcnt whose in-out operands are the
+            // rows, so that nothing that reads them can be scheduled above it.  (The compiler's own wait in front of their first use went
+            // missing on some paths once the explicit drain at the end of Y's multiply tick covered the loop's back edge, and a bare
+            // s_waitcnt builtin does not order the VALU instructions around it: cold launches then built A pieces from registers the loads
+            // had not reached - tools/lab/stress_pair.py, tools/lab/diag_pair.py.)  Nothing else is in flight here: it costs nothing.
+            if (DFOL_H2_PREFETCH) {
+                floatx4 t0 = ru[0][0], t1 = ru[0][1], t2 = ru[1][0], t3 = ru[1][1], t4 = rv[0][0], t5 = rv[0][1], t6 = rv[1][0], t7 = rv[1][1];
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
+                ru[0][0] = t0, ru[0][1] = t1, ru[1][0] = t2, ru[1][1] = t3, rv[0][0] = t4, rv[0][1] = t5, rv[1][0] = t6, rv[1][1] = t7;
+            }
             if (Y && !DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
             make_a(c);
             // the A pieces are pure register arithmetic: without these fences the compiler sinks them below the barrier, in front of the
@@ -346,7 +356,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_sched_barrier(0);
             if (Y && DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
             TRACE(3 + 4 * c);
-            __syncthreads();                                // end of the build tick
+            // end of the build tick.  (__syncthreads() carries a release fence, for which the compiler drains the chunk request Y has just
+            // issued - vmcnt(0) in front of the barrier.  The bare s_barrier instruction for Y, whose DMA then lands under its multiply tick,
+            // was measured: 1.27 ms against 1.19 - the DMA's LDS writes then compete with the multiply tick's fragment reads.)
+            __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             TRACE(4 + 4 * c);
             bbase = boff + (c & 1) * H2_PIECES;

@@ -236,6 +236,18 @@ int dfol_linear_pack_w_bf16x3(const float* W, int64_t ldw, int32_t N, int32_t K,
 int dfol_linear_act_split_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M,
                               int32_t N, int32_t K, int32_t act, void* stream);
 
+/* The same contraction with fp32 results from the fp16 matrix pipe and THREE products per fp32 product (round 4; the default of the
+ * FORWARD products): each operand is cut into two fp16 pieces x = h + l (22-23 significand bits), xl wh + xh wl + xh wh accumulated
+ * in fp32 (v_mfma_f32_16x16x32_f16).  Rows of W are scaled by powers of two chosen by the pack kernel and un-scaled in the epilogue
+ * (exact); X is split UNSCALED: an element's error is max(2^-22 |x|, 2^-25), i.e. fp32-class for operands of order one (features,
+ * Sigmoid / ELU outputs) - use dfol_linear_act_split_f32 for operands of arbitrary magnitude (gradients); |x| > 65504 gives NaN.
+ * W_split: dfol_linear_w_f16x2_bytes(N, K) bytes from dfol_linear_pack_w_f16x2, 16-byte aligned.  Limits as dfol_linear_act_split_f32.
+ * Replaces the nn.Linear + activation lines of gqa_interpreter_experiments.py:18-36, 60-77 and batch_gqa_boxfeatures_pipeline.py:199-213. */
+int64_t dfol_linear_w_f16x2_bytes(int32_t N, int32_t K);
+int dfol_linear_pack_w_f16x2(const float* W, int64_t ldw, int32_t N, int32_t K, void* W_split, void* stream);
+int dfol_linear_act_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M,
+                           int32_t N, int32_t K, int32_t act, void* stream);
+
 /* The bf16 mode of the same kernel (BASELINE configs[3] "bf16 fwd / fp32 logic"; config key `mlp_math: bf16`): both operands rounded to
  * bf16 (nearest even), ONE product per operand pair, fp32 accumulation, fp32 output.  NOT the reference's numerics (relative error
  * ~2^-8 per product); a sixth of the matrix-pipe time.  W_bf16: ceil(N/128) * ceil(K/32) * 8192 bytes from dfol_linear_pack_w_bf16. */

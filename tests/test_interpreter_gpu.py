@@ -413,8 +413,8 @@ def test_full_size_model_large_scenes(tmp_path, n_list, hops):
 
 
 def test_bf16x3_contractions_equal_fp32_pipe_end_to_end(tmp_path, monkeypatch):
-    """The default forward (dense layers and pair MLP on the bf16 matrix pipe with the exact three-way operand split) against the same
-    model on the fp32 matrix pipe, through the whole interpreter on 100-object scenes: the final log-probabilities agree as two
+    """The default forward (dense layers and pair MLP on the fp16 matrix pipe: two pieces per operand, three products) and round 3's
+    (the bf16 pipe: three exact pieces, six products) against the same model on the fp32 matrix pipe, through the whole interpreter on 100-object scenes: the final log-probabilities agree as two
     fp32 evaluations of the same network do, and neither is closer to the float64 oracle than the other."""
     from dfol_vqa_amd import experiment
     paths, names = syn.write_synthetic_ontology(str(tmp_path))
@@ -431,10 +431,10 @@ def test_bf16x3_contractions_equal_fp32_pipe_end_to_end(tmp_path, monkeypatch):
 
     def forward(pipe):
         for var in ("DFOL_PAIR_MATH", "DFOL_DENSE_MATH"):
-            if pipe == "f32":
-                monkeypatch.setenv(var, "f32")
+            if pipe is None:
+                monkeypatch.delenv(var, raising=False)           # the defaults: two fp16 pieces, three products
             else:
-                monkeypatch.delenv(var, raising=False)
+                monkeypatch.setenv(var, pipe)
         torch.manual_seed(5)
         model = experiment.build_model(cfg, ont)            # a fresh model: packed weight images are cached per weight version
         with torch.no_grad():
@@ -445,16 +445,17 @@ def test_bf16x3_contractions_equal_fp32_pipe_end_to_end(tmp_path, monkeypatch):
         weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
         return res["log_probability"].cpu().numpy().astype(np.float64), weights
 
-    lp_split, weights = forward("bf16x3")
-    lp_f32, _ = forward("f32")
+    lp_f32, weights = forward("f32")
     oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
     lp64 = np.asarray(orc.run_questions(oont, qs, scenes, np.float64, weights=weights)["log_probability"], np.float64)
     well = lp64 >= -5
     assert well.sum() >= 3
-    assert np.abs(lp_split - lp_f32)[well].max() <= 2e-5, (lp_split, lp_f32)
-    e_split, e_f32 = np.abs(lp_split - lp64)[well].max(), np.abs(lp_f32 - lp64)[well].max()
-    assert e_split <= 2.0 * e_f32 + 2e-6, (e_split, e_f32)
-    assert np.abs(np.exp(lp_split) - np.exp(lp64)).max() <= 2.0 * np.abs(np.exp(lp_f32) - np.exp(lp64)).max() + 1e-6
+    for pipe in (None, "bf16x3"):
+        lp_split, _ = forward(pipe)
+        assert np.abs(lp_split - lp_f32)[well].max() <= 2e-5, (pipe, lp_split, lp_f32)
+        e_split, e_f32 = np.abs(lp_split - lp64)[well].max(), np.abs(lp_f32 - lp64)[well].max()
+        assert e_split <= 2.0 * e_f32 + 2e-6, (pipe, e_split, e_f32)
+        assert np.abs(np.exp(lp_split) - np.exp(lp64)).max() <= 2.0 * np.abs(np.exp(lp_f32) - np.exp(lp64)).max() + 1e-6, pipe
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -64,18 +64,20 @@ def parse(argv=None):
                     help="train mode: bf16 = configs[3]'s 'bf16 fwd / fp32 logic' (config key mlp_math): the large dense products on bf16-rounded "
                          "operands, fp32 accumulation; reported as dtype bf16, never the default")
     ap.add_argument("--cpu-sample", type=int, default=None, help="questions in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--parity-all", type=int, default=1, help="1: check every question of the batch against the oracle (not only the timed sample)")
+    ap.add_argument("--parity-all", type=int, default=1, help="1: check questions beyond the timed CPU sample against the oracle too (up to --parity-questions)")
+    ap.add_argument("--parity-questions", type=int, default=128, help="questions of the timed batch the in-bench parity leg checks (the whole batch of 256 is "
+                    "checked by tests/test_interpreter_gpu.py::test_north_star_batch_parity_all_questions; 0 = all)")
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
     ap.add_argument("--graph-collective", type=int, default=0, help="train mode over RCCL: 1 = ONE step graph with the all-reduce captured inside (opt-in: a "
                     "failure of that path - capture error or an abort from the process group's watchdog - ends THIS process with a non-zero exit, "
                     "there is no in-process fallback); 0 (default) = two graphs with the all-reduce issued eagerly between the replays")
-    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back steps AFTER the --steps region for `value_sustained` (0 = skip)")
+    ap.add_argument("--sustain", type=float, default=5.0, help="seconds of back-to-back steps AFTER the --steps region for `value_sustained` (0 = skip)")
     ap.add_argument("--roofline-reps", type=int, default=20, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
                                                                   "of the dominant kernel in the process, so a rocprofv3 trace of the same command can average the same launches")
     ap.add_argument("--parity-fp64", type=int, default=1, help="1: the parity leg also runs the oracle in float64 (the tolerance policy's yardstick)")
-    ap.add_argument("--cpu-budget", type=float, default=210.0, help="seconds of host time the cpu_baseline + parity legs may take in total: the number of "
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time the cpu_baseline + parity legs may take in total: the number of "
                                                                     "questions checked beyond the timed sample shrinks to fit (the default run must finish within minutes)")
     args = ap.parse_args(argv)
     if args.objects is None:
@@ -397,7 +399,7 @@ def main(argv=None):
             # configs[4] (256 objects, 26 options per question): two questions through the oracle are the parity sample; the relation
             # tiles are bf16 there, so the probabilities differ from the fp32 reference by the rounding of the stored likelihoods
             out["cpu_baseline"], out["parity"] = cpu_baseline(model, paths, qs, res, sample, args.parity_all and not c4, fp64=bool(args.parity_fp64),
-                                                              budget=args.cpu_budget)
+                                                              budget=args.cpu_budget, max_questions=args.parity_questions)
             if c4:
                 out["parity"]["note"] = "bf16 relation tiles (configs[4]): |dp| <= 2e-3 expected against the fp32 reference (DESIGN 3)"
                 if "policy" in out["parity"]:
@@ -879,7 +881,7 @@ def stress_kernels(L, device, P, N):
     return res
 
 
-def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True, fp64=True, budget=150.0):
+def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True, fp64=True, budget=150.0, max_questions=0):
     """The reference's algorithm on the GPU box's host cores, on a bounded sample of the same workload, and the in-run parity check.
 
     `cpu_baseline` = the torch-CPU restatement of the reference's flat-layout forward (oracle/dfol_oracle_torch.py: the reference's own
@@ -888,7 +890,8 @@ def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True, f
     config, trainer.py:57-62; on this 256-thread host 16-32 threads are fastest, 128+ are 2-3x slower).  For programs outside its scope
     (configs[4]) the numpy port (oracle/dfol_oracle.py) is the baseline, kind "port".
     `parity` = the GPU's log-probabilities against the numpy oracle's fp32 run and - `fp64` - its float64 run, the yardstick of the
-    tolerance policy (tests/golden_util.py), on as many questions of the timed batch as fit the host-time `budget`."""
+    tolerance policy (tests/golden_util.py), on as many questions of the timed batch - at most `max_questions`, 0 = all - as fit
+    the host-time `budget`."""
     from oracle import dfol_oracle as orc
     t_begin = time.perf_counter()
     ont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
@@ -948,6 +951,8 @@ def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True, f
     # ---- parity: as many questions as the host-time budget allows (fp32 on the rest, float64 on all of them)
     per_q = dt / sample
     checked = sample
+    if max_questions and max_questions >= sample:
+        questions = questions[:max_questions]
     if parity_all and len(questions) > sample:
         left = budget - (time.perf_counter() - t_begin)
         cost = lambda n: (n - sample) * per_q + (2.5 * n * per_q if fp64 else 0.0)

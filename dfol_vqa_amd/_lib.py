@@ -785,6 +785,11 @@ def pair_logit_bwd(dx, p2, e_rows, pred_off, need_bias=True):
     return dp2, de, dbe
 
 
+def capturing():
+    """True while a graph capture records through this module (keeping(): GraphedForward / GraphedTrainStep)."""
+    return _KEEP is not None
+
+
 # ---- backward wrappers (deterministic: no atomics; pred_q non-decreasing) --------------------------------------------
 def require_sorted(pred_q, what):
     """The deterministic backward kernels find a question's predicates by binary search in pred_q (csrc/dfol_logic_bwd.hip,
@@ -793,6 +798,9 @@ def require_sorted(pred_q, what):
     the tensor; the maps come out of content-keyed caches, so a train loop pays once per distinct map."""
     flag = getattr(pred_q, "_dfol_sorted", None)
     if flag is None:
+        if _KEEP is not None:
+            raise DfolError("%s: the predicate -> question map has not been checked for order and a graph capture is recording (the check reads "
+                            "the device): build the map through BatchWorld.pred_q / host_util.upload, or run one eager step first" % what)
         flag = bool(pred_q.numel() < 2 or bool((pred_q[1:] >= pred_q[:-1]).all().item()))
         try:
             pred_q._dfol_sorted = flag

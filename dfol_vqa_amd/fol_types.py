@@ -190,16 +190,32 @@ class BatchWorld(object):
         return self._zeros
 
     def pred_q(self, predicate_question_map):
-        """Normalise a predicate->question map (None / python list / tensor / sparse [P,Q]) to int32 [P] on device."""
+        """Normalise a predicate->question map (None / python list / tensor / sparse [P,Q]) to int32 [P] on device.  Whether the map is
+        non-decreasing (what the deterministic backward kernels need, _lib.require_sorted) is decided HERE, once per map: on the host for
+        lists, with one device read for tensors - remembered per source tensor, so that a train step neither re-converts nor re-reads."""
         m = predicate_question_map
         if m is None:
             return self._ident
         if isinstance(m, torch.Tensor):
-            if m.is_sparse:
-                m = m.coalesce().indices()[1]
-            return m.to(device=self._device, dtype=torch.int32)
+            from . import _lib
+            memo = self.__dict__.setdefault("_pred_q_memo", {})
+            key = (id(m), m._version)
+            hit = memo.get(key)
+            if hit is None or hit[0] is not m:
+                idx = m.coalesce().indices()[1] if m.is_sparse else m
+                out = idx.to(device=self._device, dtype=torch.int32)
+                if not _lib.capturing():                     # (a capture cannot read the device; require_sorted then refuses an unchecked map)
+                    out._dfol_sorted = bool(out.numel() < 2 or bool((out[1:] >= out[:-1]).all().item()))
+                if len(memo) >= 64:
+                    memo.clear()
+                hit = memo[key] = (m, out)
+            return _lib.keep_alive(hit)[1]
         from .host_util import upload                        # (host_util imports this module)
-        return upload(np.asarray(m, np.int32), self._device)        # a python list (the operators' batch_index)
+        host = np.asarray(m, np.int32)
+        out = upload(host, self._device)                     # a python list (the operators' batch_index): content-keyed, the same tensor per content
+        if getattr(out, "_dfol_sorted", None) is None:
+            out._dfol_sorted = bool(host.size < 2 or bool((host[1:] >= host[:-1]).all()))
+        return out
 
     def to_flat(self, block, pred_q=None, fill=0.0):
         """[P, NS] blocks -> the reference's flat [P, total_obj] rows (own image filled, the rest `fill`)."""

@@ -575,6 +575,26 @@ def test_full_batch_properties(tmp_path):
     assert np.array_equal(lp_split, lp)
 
 
+def test_north_star_batch_parity_all_questions():
+    """The batch bench.py times (BASELINE's metric: 256 questions x 100 objects, select -> filter -> relate -> exist, full-size model), ALL 256
+    questions against the oracle's fp32 and float64 runs under the tolerance policy (K = 2, 1e-6, 1e-4): what `parity` in the bench line
+    reports, which since round 4 checks 128 questions to keep the bench's host leg near a minute."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = bench.parse([])
+    assert args.batch == 256 and args.objects == 100
+    model, ontology, paths, names = bench.build_model(args, DEV)
+    qs, pbs = bench.build_batch(args, 0, ontology, names, DEV)
+    with torch.no_grad():
+        res = model(pbs, False)
+    _, parity = bench.cpu_baseline(model, paths, qs, res, 8, parity_all=True, fp64=True, budget=1e9, max_questions=0)
+    assert parity["questions_checked"] == 256 and parity["answers_agree"] == "256/256", parity
+    assert parity["policy"]["pass"], parity
+    assert parity["max_abs_dlp_vs_fp64_where_lp_ge_-5"] <= 1e-4 and parity["well_conditioned_checked"] >= 200, parity
+
+
 def test_graphed_forward_equals_eager(tmp_path):
     """The captured-graph forward replays the same launches: identical log-probabilities and answers, also after the scene features
     behind the ProgramBatch are overwritten in place, and for a QUERY operator whose answers are decoded after the replay."""

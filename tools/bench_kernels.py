@@ -129,12 +129,14 @@ def main():
         y = torch.empty(M, Nn, device=dev)
         t = timeit(lambda: L.linear_act(x, w, b, act, y), iters=10)
         fl = 2.0 * M * Nn * K
-        out.append({"kernel": "linear_act" + ("" if os.environ.get("DFOL_DENSE_MATH") == "f32" else " (auto: bf16x3 when large)"), "M": M, "N": Nn, "K": K,
+        out.append({"kernel": "linear_act" + ("" if os.environ.get("DFOL_DENSE_MATH") == "f32" else " (auto: the split kernel when large)"), "M": M, "N": Nn, "K": K,
                     "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
         if K % 4 == 0:
-            t = timeit(lambda: L.linear_act_split(x, w, b, act, y), iters=10)
-            out.append({"kernel": "linear_act_split", "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
-                        "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15})
+            for math, pieces in (("f16x2", 3), ("bf16x3", 6)):
+                with L.dense_math(math):
+                    t = timeit(lambda: L.linear_act_split(x, w, b, act, y), iters=10)
+                out.append({"kernel": "linear_act_split " + math, "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                            "frac_16bit_mfma_peak_executed": pieces * fl / t / 2.5e15})
     # the two tall products of a train step's pair MLP (one row per ordered object pair): forward with the Sigmoid, input gradient
     for (M, Nn, K, act) in ((256 * N * (N - 1), 300, 256, 1), (256 * N * (N - 1), 256, 300, 0)):
         x = torch.rand(M, K, device=dev) - 0.5
@@ -142,12 +144,11 @@ def main():
         b = torch.rand(Nn, device=dev)
         y = torch.empty(M, Nn, device=dev)
         fl = 2.0 * M * Nn * K
-        for name, fn in (("linear_act_split", L.linear_act_split),):
-            if name == "linear_act_split" and K % 4:
-                continue
-            t = timeit(lambda: fn(x, w, b, act, y), iters=5)
-            out.append({"kernel": name, "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
-                        "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15})
+        for math, pieces in (("f16x2", 3), ("bf16x3", 6)):
+            with L.dense_math(math):
+                t = timeit(lambda: L.linear_act_split(x, w, b, act, y), iters=5)
+            out.append({"kernel": "linear_act_split " + math, "M": M, "N": Nn, "K": K, "act": act, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                        "frac_16bit_mfma_peak_executed": pieces * fl / t / 2.5e15})
         del x, y
     # weight-gradient kernel (dW = dY^T X, csrc/dfol_dense_wgrad.hip) against the library's product, training shapes
     for (M, Nn, K) in ((256 * N * (N - 1), 300, 256), (256 * N, 512, 2048), (256 * N, 256, 516), (256 * N, 300, 256)):
@@ -175,7 +176,7 @@ def main():
     for K in (1, 2):
         req_col = torch.randint(0, C, (K, Q), dtype=torch.int32, device=dev)
         req_tile = torch.arange(K * Q, dtype=torch.int32, device=dev).reshape(K, Q)
-        tiles = torch.empty(K * Q, NS, NS, device=dev)
+        tiles = torch.full((K * Q, NS, NS), -30.0, device=dev)      # the split / fp16x2 pair kernels write the ordered pairs only: the diagonal keeps the fill
         t = timeit(lambda: L.pair_ll(uv, HID1, pos, wg, w2, b2, E, be, n_o, off, N, req_col, req_tile, None, tiles, hid2=HID2), iters=10)
         fl = 2.0 * Q * N * (N - 1) * (4 * HID1 + HID1 * HID2 + HID2 * K)
         out.append({"kernel": "pair_ll", "Q": Q, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12, "frac_f32_mfma_peak": fl / t / F32_MFMA_PEAK})
@@ -190,6 +191,12 @@ def main():
         t = timeit(lambda: L.pair_ll_split(uv, HID1, pos, wg, w2s, b2, HID2, E, be, n_o, off, N, req_col, req_tile, None, tiles), iters=10)
         out.append({"kernel": "pair_ll_split", "Q": Q, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
                     "frac_bf16_mfma_peak_executed": 6 * fl / t / 2.5e15,
+                    "max_abs_diff_vs_pair_ll": (tiles[:, :N, :N] - ref[:, :N, :N]).abs().max().item()})
+        w2h = L.pair_pack_w2_h2(w2, HID2)
+        tiles.fill_(-30.0)
+        t = timeit(lambda: L.pair_ll_h2(uv, HID1, pos, wg, w2h, b2, HID2, E, be, n_o, off, N, req_col, req_tile, None, tiles), iters=10)
+        out.append({"kernel": "pair_ll_h2", "Q": Q, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                    "frac_f16_mfma_peak_executed": 3 * fl / t / 2.5e15,
                     "max_abs_diff_vs_pair_ll": (tiles[:, :N, :N] - ref[:, :N, :N]).abs().max().item()})
     for r in out:
         print(json.dumps(r))

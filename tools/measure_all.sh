@@ -23,7 +23,7 @@ for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 1
   timeout 300 python bench.py --mode train --steps 10 $a >> $O/train_step.jsonl 2>> $O/train.err
 done
 DFOL_BF16_STORE=0 timeout 300 python bench.py --mode train --steps 10 --objects 100 --mlp-math bf16 >> $O/train_step_bf16_fp32_storage.jsonl 2>> $O/train.err
-timeout 200 python tools/scratch/bf16_store_lab.py > $O/bf16_storage_kernels.txt 2>&1
+timeout 200 python tools/lab/bf16_store_lab.py > $O/bf16_storage_kernels.txt 2>&1
 DFOL_BENCH_FORCE_PG=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 timeout 300 python bench.py --gpus 1 --steps 10 --mode train --objects 36 --overlap-allreduce 1 > $O/train_rccl_world1.json 2> $O/train_rccl1.err
 DFOL_BENCH_FORCE_PG=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29612 timeout 300 python bench.py --gpus 1 --steps 10 --mode train --objects 100 --calibrator 1 > $O/train_rccl_world1_cal.json 2>> $O/train_rccl1.err
 DFOL_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2r.err
@@ -35,9 +35,9 @@ bash tools/step_breakdown.sh ${TAG}_train_n100 --mode train --objects 100 > $O/s
 bash tools/step_breakdown.sh ${TAG}_train_bf16_n100 --mode train --objects 100 --mlp-math bf16 > $O/step_breakdown_train_bf16_n100.md 2>&1
 # what the bf16 matrix pipe sustains per MFMA shape, and a multiply tick of the pair kernel in isolation
 mkdir -p gpurun_out/peak
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/scratch/mfma_peak.hip -o gpurun_out/peak/mfma_peak > /dev/null 2>&1 && timeout 120 gpurun_out/peak/mfma_peak > $O/mfma_peak.txt 2>&1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/scratch/tick_model.hip -o gpurun_out/peak/tick_model > /dev/null 2>&1 && timeout 120 gpurun_out/peak/tick_model > $O/tick_model.txt 2>&1
-mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/scratch/transc_accuracy.hip -o build/transc_accuracy > /dev/null 2>&1 && timeout 60 build/transc_accuracy > $O/transcendental_accuracy.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lab/mfma_peak.hip -o gpurun_out/peak/mfma_peak > /dev/null 2>&1 && timeout 120 gpurun_out/peak/mfma_peak > $O/mfma_peak.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lab/tick_model.hip -o gpurun_out/peak/tick_model > /dev/null 2>&1 && timeout 120 gpurun_out/peak/tick_model > $O/tick_model.txt 2>&1
+mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/lab/transc_accuracy.hip -o build/transc_accuracy > /dev/null 2>&1 && timeout 60 build/transc_accuracy > $O/transcendental_accuracy.txt 2>&1
 timeout 300 python tools/accuracy_probe.py --tag $TAG > $O/accuracy_probe_n36.json 2> $O/probe.err
 timeout 300 python tools/accuracy_probe.py --tag ${TAG}_n100 --objects 100 --questions 16 > $O/accuracy_probe_n100.json 2>> $O/probe.err
 bash tools/pmc_run.sh ${TAG}_mfma "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" tools/bench_kernels.py > $O/pmc_mfma_busy.txt 2>&1

@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--parity-questions", type=int, default=128, help="questions of the timed batch the in-bench parity leg checks (the whole batch of 256 is "
                     "checked by tests/test_interpreter_gpu.py::test_north_star_batch_parity_all_questions; 0 = all)")
     ap.add_argument("--stress-preds", type=int, default=65536)
+    ap.add_argument("--fresh-batches", type=int, default=56, help="batches of the `value_fresh_programs` leg: every step a different ProgramBatch through "
+                    "collate -> lower -> eager launches (0 = skip; north_star / c1 workloads, one process)")
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
     ap.add_argument("--graph-collective", type=int, default=0, help="train mode over RCCL: 1 = ONE step graph with the all-reduce captured inside (opt-in: a "
@@ -363,6 +365,17 @@ def main(argv=None):
         sv = streamed_rate(args, step if graphed else eager, pbs, td, share, device)
         out["value_streamed"] = sv["questions_per_s"] * world
         out["streamed"] = sv
+    if args.fresh_batches > 0 and args.workload in ("north_star", "c1"):
+        # every rank runs its own stream of unseen batches (max over ranks of the elapsed time: the whole-job rate)
+        fp = fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=args.fresh_batches)
+        if td is not None:
+            t = torch.tensor([fp["ms_per_batch"]], device="cpu" if share else device, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            fp["ms_per_batch"] = float(t.item())
+            fp["questions_per_s"] = args.batch / (fp["ms_per_batch"] * 1e-3)
+        out["value_fresh_programs"] = fp["questions_per_s"] * world
+        fp["vs_value"] = "%.2f x the replayed-batch rate `value`" % (out["value_fresh_programs"] / out["value"])
+        out["fresh_programs"] = fp
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
         # --roofline-reps EAGER steps, one event pair per launch.  They come after every other leg that launches these kernels, so
@@ -410,6 +423,90 @@ def main(argv=None):
     if td is not None:
         td.barrier()
         td.destroy_process_group()
+
+
+def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=56, pool=4):
+    """`value_fresh_programs`: the reference's test() loop (trainer.py:685-720) - every step a DIFFERENT ProgramBatch: new programs of mixed
+    shapes (eight terminal operators in rotation, 1..3 filter / relate hops, negations, second branches; dfol_vqa_amd.synthetic.full_size_questions)
+    on new scenes, through collate (data_pipeline.py:647-783) -> create_sparse_tensors -> lower -> eager launches -> answers read back, per
+    batch, like the reference's loop.  The headline `value` replays ONE captured batch; this is what a stream of unseen batches costs.
+    Object features are device-resident (a pool of `pool` distinct feature sets, rotated: the boundary takes device pointers; `value_streamed`
+    prices the host->device link), program dicts are generated before the clock starts (the reference's DataLoader workers hand over decoded
+    questions).  Launch form: eager - a captured graph bakes in the addresses of a batch's uploaded token / index arrays, so a graph cache
+    keyed by batch structure would hit only on a repeated batch (hit rate reported as 0 of n)."""
+    import dfol_vqa_amd as D
+    from dfol_vqa_amd import synthetic as syn
+    from dfol_vqa_amd import training
+    N, B = args.objects, args.batch
+    kinds = ["exist", "verify_rel", "choose_attr", "and", "query_attr", "verify_attrs", "or", "choose_rel"]
+    with open(paths["attribute_file"]) as f:
+        cats = json.load(f)                                  # category -> its attribute names
+    g = torch.Generator(device="cpu").manual_seed(77 + rank)
+    feats = [torch.rand(B * N, 2054, generator=g).to(device) for _ in range(pool)]       # (U(0,1) features and box columns, as feature_scene draws them)
+    for f in feats:
+        f[:, 2048:2050] *= 400.0
+        f[:, 2050:2052] = f[:, 2050:2052] * 100.0 + 5.0
+        f[:, 2052], f[:, 2053] = 640.0, 480.0
+    bindex = torch.arange(B, dtype=torch.int64).repeat_interleave(N)
+    state = {"k": 0}
+
+    class Collater(D.ProgramCollaterBase):
+        def __init__(self):
+            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology)
+
+        def collate_object_features(self, questions):
+            return feats[state["k"] % pool], bindex
+
+        def collate_meta_data(self, questions):
+            return {"index": {}, "embedding": torch.zeros(1, 1)}
+
+    batches = [syn.full_size_questions(kinds[b % len(kinds)], B, N, N, names, cats, 5000 + 97 * rank + b, with_scene=False) for b in range(n_batches + 3)]
+    coll = Collater()
+
+    def one(qs):
+        pbs = coll.collate(qs)
+        for pb in pbs:
+            pb.create_sparse_tensors()
+        pbs = [pb.to_cuda(device) for pb in pbs]
+        res = model(pbs, False)
+        state["k"] += 1
+        return training.compute_evaluation_metrics(pbs, res), res
+
+    with torch.no_grad():
+        for qs in batches[:2]:                               # warm-up: two batches (allocator, weight images)
+            one(qs)
+        torch.cuda.synchronize()
+        # collate of batch i + 1 runs on a worker thread while the main thread launches and reads back batch i (the reference collates in
+        # DataLoader worker processes, data_pipeline.py:893-898; the forward's wait for the device releases the interpreter lock)
+        from concurrent.futures import ThreadPoolExecutor
+        host_s = [0.0]
+
+        def prepare(qs):
+            h0 = time.perf_counter()
+            pbs = coll.collate(qs)
+            for pb in pbs:
+                pb.create_sparse_tensors()
+            host_s[0] += time.perf_counter() - h0
+            return pbs
+
+        with ThreadPoolExecutor(1) as pool_ex:
+            t0 = time.perf_counter()
+            nxt = pool_ex.submit(prepare, batches[2])
+            for i in range(n_batches):
+                pbs = nxt.result()
+                if i + 1 < n_batches:
+                    nxt = pool_ex.submit(prepare, batches[3 + i])
+                pbs = [pb.to_cuda(device) for pb in pbs]
+                res = model(pbs, False)
+                training.compute_evaluation_metrics(pbs, res)
+                state["k"] += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        host = host_s[0]
+    return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B,
+            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": "on a worker thread, one batch ahead", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
+            "how": "every batch new programs (1..3 hops, mixed terminal operators) and another scene set; collate -> create_sparse_tensors -> lower -> "
+                   "eager launches -> answers and error rate read back per batch; object features device-resident"}
 
 
 def dominant_roofline(args, model, dom, per_step):

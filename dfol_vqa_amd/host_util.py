@@ -83,14 +83,47 @@ class Lowered(object):
 _upload_cache = LRUCache(1024)
 
 
+class _PinnedRing(object):
+    """Host staging for small uploads: slices of ONE pinned buffer, copied with non_blocking=True.  A pageable host-to-device copy makes the
+    host wait for the stream (~20 us each, ~60 per fresh 256-question batch); from pinned memory the copy is queued behind the stream's work
+    and the host moves on.  A slice is reused only after the ring has wrapped, and wrapping waits for the stream once."""
+
+    def __init__(self, nbytes=8 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.view = self.buf.numpy()
+        self.pos = 0
+
+    def stage(self, a):
+        n = a.nbytes
+        start = (self.pos + 15) & ~15
+        if start + n > self.buf.numel():
+            torch.cuda.synchronize()                         # every copy queued from the ring so far has been consumed
+            start = 0
+        self.view[start:start + n] = a.reshape(-1).view(np.uint8)
+        self.pos = start + n
+        return self.buf[start:start + n]
+
+
+_ring = None
+
+
 def upload(array, device):
     """Small host index arrays (segment offsets, keep lists, predicate -> question maps) as device tensors, uploaded once per
-    content: a pageable host-to-device copy synchronises the stream, and the same arrays recur on every forward of a batch."""
+    content: the same arrays recur on every forward of a batch.  New content goes through a pinned staging ring (no host wait per copy)."""
+    global _ring
     a = np.ascontiguousarray(array)
     key = (str(device), a.dtype.str, a.shape, a.tobytes())
     hit = _upload_cache.get(key)
     if hit is None:
-        hit = _upload_cache[key] = torch.as_tensor(a).to(device)
+        dev = torch.device(device)
+        if dev.type == "cuda" and a.ndim >= 1 and 0 < a.nbytes <= (1 << 20) and not torch.cuda.is_current_stream_capturing():
+            if _ring is None:
+                _ring = _PinnedRing()
+            hit = torch.empty(a.shape, dtype=torch.as_tensor(a[:0]).dtype, device=dev)
+            hit.view(torch.uint8).reshape(-1).copy_(_ring.stage(a), non_blocking=True)
+        else:
+            hit = torch.as_tensor(a).to(device)
+        _upload_cache[key] = hit
     return keep_alive(hit)
 
 
@@ -123,20 +156,28 @@ def lower_tokens(tokens, ontology, token_type):
         hit = cache.get(key)
         if hit is not None:
             return hit
+    # per-token memo (token string -> column, negation, validity): a fresh batch names the same few hundred concepts as the one before
+    # it, and resolving a token from scratch is a strip, a regex and two dictionary reads (4.5 k tokens per 256-question batch: 3.6 ms)
+    memo = ontology.__dict__.setdefault("_token_memo", {}).setdefault(int(token_type), {})
     arg_to_idx = ontology._vocabulary['arg_to_idx']
     cols, neg, valid = [], [], []
     for t in tokens:
-        if not is_valid_token(t):
-            cols.append(-1), neg.append(0), valid.append(0)
-            continue
-        s = t.strip()
-        n = _NEG.match(s) is not None
-        if n:
-            s = s[4:-1]
-        idx = arg_to_idx[s.strip()] - 1
-        if token_type == TokenType.RELATION:
-            idx = ontology._relation_reveresed_index[idx]
-        cols.append(idx), neg.append(int(n)), valid.append(1)
+        hit = memo.get(t)
+        if hit is None:
+            if not is_valid_token(t):
+                hit = (-1, 0, 0)
+            else:
+                s = t.strip()
+                n = _NEG.match(s) is not None
+                if n:
+                    s = s[4:-1]
+                idx = arg_to_idx[s.strip()] - 1              # (an unknown token raises KeyError, as the reference's itemgetter does: not memoised)
+                if token_type == TokenType.RELATION:
+                    idx = ontology._relation_reveresed_index[idx]
+                hit = (idx, int(n), 1)
+            if len(memo) < 65536:
+                memo[t] = hit
+        cols.append(hit[0]), neg.append(hit[1]), valid.append(hit[2])
     low = Lowered(cols, neg, valid)
     if key is not None:
         cache[key] = low

@@ -174,7 +174,7 @@ def load_seeded_weights(model, seed):
     return w
 
 
-def full_size_questions(kind, count, n_lo, n_hi, names, categories, seed):
+def full_size_questions(kind, count, n_lo, n_hi, names, categories, seed, with_scene=True):
     """Seeded ragged questions for one terminal operator at BASELINE configs[2]'s shape (golden family g17 and
     tests/test_interpreter_gpu.py): select -> 1..3 filter / relate hops -> <kind>; second branch for the binary-branch operators."""
     rng = np.random.RandomState(seed)
@@ -202,5 +202,7 @@ def full_size_questions(kind, count, n_lo, n_hi, names, categories, seed):
                 "choose_rel": op("choose_rel", [rels[0], rels[1]], bool(rng.uniform() < 0.5), pick(nouns)),
                 "two_same": op("two_same", cat), "two_different": op("two_different", cat), "all_same": op("all_same", cat),
                 "all_different": op("all_different", cat), "compare": op("compare", pick(attrs), bool(rng.uniform() < 0.5))}[kind]
-        qs.append(question(qid, branches, last, "yes", feature_scene(qid, int(rng.randint(n_lo, n_hi + 1)), 2048)))
+        n = int(rng.randint(n_lo, n_hi + 1))
+        # (with_scene=False: programs only - the caller serves the object features, e.g. from a device-resident pool: bench.py's fresh-programs leg)
+        qs.append(question(qid, branches, last, "yes", feature_scene(qid, n, 2048) if with_scene else {"n": n}))
     return qs

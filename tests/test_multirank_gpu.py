@@ -73,7 +73,7 @@ def test_bench_launches_its_own_ranks(mode):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--objects", "20",
-           "--cpu-sample", "0", "--stress-preds", "0", "--sustain", "0.2", "--mode", mode]
+           "--cpu-sample", "0", "--stress-preds", "0", "--sustain", "0.2", "--fresh-batches", "3", "--mode", mode]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -108,7 +108,7 @@ def test_bench_over_rccl_world_size_one(mode, overlap):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16", "--objects", "20",
-           "--cpu-sample", "0", "--stress-preds", "0", "--sustain", "0.2", "--mode", mode, "--overlap-allreduce", str(overlap)]
+           "--cpu-sample", "0", "--stress-preds", "0", "--sustain", "0.2", "--fresh-batches", "3", "--mode", mode, "--overlap-allreduce", str(overlap)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()

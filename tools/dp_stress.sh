@@ -9,13 +9,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out/dp_stress
 LOG=gpurun_out/dp_stress/log${DFOL_STRESS_TAG:-}.txt
-echo "# dp_stress: $N fresh-process runs of: DFOL_BENCH_FORCE_PG=1 python bench.py --gpus 1 --mode train --steps 6 --warmup 2 --batch 32 --objects 36 --cpu-sample 0 --stress-preds 0 --sustain 0 $*" > $LOG
+echo "# dp_stress: $N fresh-process runs of: DFOL_BENCH_FORCE_PG=1 python bench.py --gpus 1 --mode train --steps 6 --warmup 2 --batch 32 --objects 36 --cpu-sample 0 --stress-preds 0 --sustain 0 --fresh-batches 0 $*" > $LOG
 echo "# $(date -u +%FT%TZ)  $(python -c 'import torch;print(torch.__version__, torch.cuda.get_device_name(0))' 2>/dev/null)" >> $LOG
 ok=0; bad=0
 for i in $(seq 1 $N); do
   port=$((29700 + i))
   DFOL_BENCH_FORCE_PG=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$port timeout 300 python bench.py --gpus 1 --mode train --steps 6 --warmup 2 --batch 32 --objects 36 \
-      --cpu-sample 0 --stress-preds 0 --sustain 0 "$@" > gpurun_out/dp_stress/run.out 2> gpurun_out/dp_stress/run.err
+      --cpu-sample 0 --stress-preds 0 --sustain 0 --fresh-batches 0 "$@" > gpurun_out/dp_stress/run.out 2> gpurun_out/dp_stress/run.err
   rc=$?
   line=$(grep '^{' gpurun_out/dp_stress/run.out | tail -1 | python -c '
 import json,sys

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --cpu-sample 0 $*"
+ARGS="--steps 20 --warmup 5 --cpu-sample 0 --fresh-batches 0 --sustain 0.5 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/steps_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py --steps 20 --warmup 2 --cpu-sample 0 --stress-preds 0 "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py --steps 20 --warmup 2 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --sustain 0 "$@" > $OUT/bench.log 2>&1
 cd $R
 tail -1 $OUT/bench.log | cut -c1-400
 python3 - "$OUT" <<'PY'

@@ -113,8 +113,14 @@ def launch_ranks(args, argv):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def build_batch(args, rank, ontology, names, device):
+def build_batch(args, rank, ontology, names, device, world=1):
+    """This rank's questions and ProgramBatches.  Fixed-size scenes (north_star, c1, c4): `--batch` questions per rank, ids rank * batch ...
+    (weak scaling; scenes are keyed by question id, so sharding never changes anyone's inputs).  Ragged scenes (`--workload c3`, world > 1):
+    the GLOBAL list of world * batch questions is cut into contiguous shards of whole images balanced by the sum of n^2 over a shard's images
+    (parallel.shard_bounds: the oracle's cost is the object pairs; data_parallel.py:59-80 cuts by question count) - `args._shard` then holds
+    every rank's question count and cost and the imbalance."""
     import dfol_vqa_amd as D
+    from dfol_vqa_amd import parallel
     from dfol_vqa_amd import synthetic as syn
 
     class Collater(D.ProgramCollaterBase):
@@ -134,11 +140,24 @@ def build_batch(args, rank, ontology, names, device):
     rng = np.random.RandomState(1000 + rank)
     G = max(1, getattr(args, "questions_per_image", 1))
     qs, scene_of = [], {}
-    for i in range(args.batch):
-        qid = rank * args.batch + i                        # scenes are keyed by question / image id: sharding never changes inputs
+    ids = range(rank * args.batch, (rank + 1) * args.batch)
+    n_of = None
+    if world > 1 and getattr(args, "ragged", 0) and getattr(args, "workload", "north_star") == "c3":
+        total = world * args.batch
+        n_img = -(-total // G)
+        grng = np.random.RandomState(1000)                  # every rank draws the same global scene sizes
+        n_of = [int(grng.randint(args.ragged, args.objects + 1)) for _ in range(n_img)]
+        bounds = parallel.shard_bounds([float(n) ** 2 for n in n_of], world)
+        cost = [sum(float(n) ** 2 for n in n_of[a:b]) for a, b in bounds]
+        count = [min(total, b * G) - min(total, a * G) for a, b in bounds]
+        args._shard = {"by": "contiguous shards of whole images, balanced by sum n^2 (parallel.shard_bounds)", "questions_per_rank": count,
+                       "cost_per_rank": cost, "imbalance_max_over_mean": max(cost) / (sum(cost) / world)}
+        a, b = bounds[rank]
+        ids = range(min(total, a * G), min(total, b * G))
+    for qid in ids:                                        # scenes are keyed by question / image id: sharding never changes inputs
         img = qid // G                                     # G consecutive questions look at the same image
         if img not in scene_of:
-            n = args.objects if not getattr(args, "ragged", 0) else int(rng.randint(args.ragged, args.objects + 1))
+            n = args.objects if not getattr(args, "ragged", 0) else (n_of[img] if n_of is not None else int(rng.randint(args.ragged, args.objects + 1)))
             scene_of[img] = syn.feature_scene(img if G > 1 else qid, n, 2048)
         if getattr(args, "workload", "north_star") == "c4":
             br, last = syn.open_program(qid, nouns, attrs, rels, names["categories"], hops=4)
@@ -238,8 +257,12 @@ def rank_report(td, share, device, rank, world, elapsed, steps):
     parts = [None] * world
     td.all_gather_object(parts, mine)
     ms = [p["ms_per_step"] for p in parts]
-    return {"ranks_seen": parts, "distinct_devices": len({(p["device_index"], p["uuid"], p["pci_bus_id"]) for p in parts}),
-            "rank_ms_per_step_min": min(ms), "rank_ms_per_step_max": max(ms), "backend": td.get_backend()}
+    rep = {"ranks_seen": parts, "distinct_devices": len({(p["device_index"], p["uuid"], p["pci_bus_id"]) for p in parts}),
+           "rank_ms_per_step_min": min(ms), "rank_ms_per_step_max": max(ms), "backend": td.get_backend()}
+    # an N-GPU line must come from N GPUs: with RCCL every rank has its own device (the gloo / shared-GPU debugging mode says so in `backend`)
+    if rep["backend"] == "nccl" and not share and rep["distinct_devices"] != world:
+        raise SystemExit("bench.py: %d ranks over RCCL but %d distinct devices in the rank report: %r" % (world, rep["distinct_devices"], parts))
+    return rep
 
 
 def build_model(args, device, train=False):
@@ -281,7 +304,7 @@ def main(argv=None):
     if td is not None:
         from dfol_vqa_amd import parallel
         parallel.broadcast_parameters(model, 0)
-    qs, pbs = build_batch(args, rank, ontology, names, device)
+    qs, pbs = build_batch(args, rank, ontology, names, device, world)
     args._scene_ns = [int(n) for pb in pbs for n in pb._object_nums]
     if args.questions_per_image > 1 and args.share_scenes:
         seen = {}
@@ -342,6 +365,8 @@ def main(argv=None):
                                                     "products, fp32 accumulate (DESIGN 3.4)"}[os.environ.get("DFOL_PAIR_MATH", "f16x2")]}}
 
     out["ranks"] = ranks
+    if getattr(args, "_shard", None):
+        out["shard"] = args._shard
     if args.sustain > 0:
         # the headline rate again over >= --sustain seconds of back-to-back steps (the --steps region at N = 100 lasts 47 ms when the
         # driver passes --steps 20: too short for an outside sampler to see)

@@ -306,3 +306,49 @@ def test_g16_feature_chunks_from_hdf5(ontology, golden_dir):
     feats, bi = coll.collate_object_features([{"image_id": im} for im in meta["chunks"]["order"]])
     assert np.array_equal(bi.numpy(), a["batch_index"])
     assert feats.dtype == torch.float32 and np.allclose(feats.numpy(), a["features"], rtol=0, atol=1e-6)
+
+
+# ---- golden g18: the reference end to end FROM ITS FILE FORMATS (program bytecode .h5 + feature chunk .h5 -> answers) ------------------
+def g18_batches(ontology, golden_dir, device=None):
+    """The g18 fixtures read through THIS repository's readers (data.ProgramDataset over libhdf5, data.BatchGQABoxFeaturesCollator):
+    per program file the decoded questions, the collated ProgramBatches, and the reference's outputs."""
+    a, meta = gu.load("g18_h5_end_to_end")
+    h5 = os.path.join(golden_dir, "h5")
+    coll = data.BatchGQABoxFeaturesCollator(h5, meta["feature_prefix"], meta["chunk_num"], os.path.join(h5, meta["info"]), ontology, 1)
+    for name in sorted(meta["files"]):
+        fm = meta["files"][name]
+        ds = data.ProgramDataset(os.path.join(h5, name + ".h5"), ontology, in_memory=False, shuffle_options=False)
+        items = [ds[i] for i in range(len(ds))]
+        assert [it["image_id"] for it in items] == fm["image_ids"] and [it["program"] for it in items] == fm["programs"], name
+        assert [it["answer"] for it in items] == fm["gold"], name
+        pbs = coll.collate(copy.deepcopy(items))
+        for pb in pbs:
+            pb.create_sparse_tensors()
+        assert [int(n) for n in pbs[0]._object_nums] == fm["objects"], name
+        yield name, fm, items, pbs, a[name + ":lp_f32"], a[name + ":lp_f64"], a, meta
+
+
+def test_g18_files_to_answers_oracle(ontology, golden_dir, mini_ontology_paths):
+    """The oracle, fed by this repository's readers of the reference's file formats, reproduces the reference's end-to-end outputs
+    (data_pipeline.py:328-367, 391-453; batch_gqa_boxfeatures_pipeline.py:29-92; batch_base_interpreter.py:72-183)."""
+    from oracle import dfol_oracle as orc
+    p = mini_ontology_paths
+    oont = orc.Ontology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+    seen = 0
+    for name, fm, items, pbs, lp32, lp64, a, meta in g18_batches(ontology, golden_dir):
+        weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+        feats = pbs[0]._object_features.numpy()
+        off = np.concatenate([[0], np.cumsum(fm["objects"])])
+        scenes = [{"n": int(n), "X": feats[off[i]:off[i + 1]]} for i, n in enumerate(fm["objects"])]
+        qs = [{"program": it["program"], "answer": it["answer"], "question_id": i, "image_id": it["image_id"]} for i, it in enumerate(items)]
+        r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights)
+        assert np.abs(r64["log_probability"] - lp64).max() <= 1e-8, (name, np.abs(r64["log_probability"] - lp64).max())
+        assert int(r64["type"]) == fm["type"]
+        r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights)
+        gu.check_logprob(r32["log_probability"], lp32, lp64, name)
+        decided = gu.decided_answers(fm, lp32, lp64)
+        assert [x for x, d in zip(r64["answer"], decided) if d] == [x for x, d in zip(fm["answer"], decided) if d], name
+        if fm["type"] == 1:
+            assert r64["options"] == fm["options"], name
+        seen += 1
+    assert seen == 8

@@ -575,6 +575,29 @@ def test_full_batch_properties(tmp_path):
     assert np.array_equal(lp_split, lp)
 
 
+def test_g18_h5_files_to_answers_on_the_gpu(ontology, golden_dir):
+    """SURVEY 8(f) rank 1 end to end on the GPU: the reference's file formats - program bytecode .h5 files its GQAH5Encoder wrote, object
+    feature chunk .h5 files + info JSON - read by this repository's readers (data.ProgramDataset / h5lite over libhdf5,
+    data.BatchGQABoxFeaturesCollator), run by the HIP interpreter, compared with what the REFERENCE's own ProgramDataset ->
+    BatchGQABoxFeaturesCollator -> BatchGQAInterpreter produced from the same files (golden g18: eight terminal operators, 1..3 hops;
+    data_pipeline.py:328-367, 391-453; batch_gqa_boxfeatures_pipeline.py:29-92)."""
+    from test_data_path import g18_batches
+    model, seen = None, 0
+    for name, fm, items, pbs, lp32, lp64, a, meta in g18_batches(ontology, golden_dir):
+        if model is None:
+            model = neural_model(ontology, meta["config"], {k[2:]: a[k] for k in a.files if k.startswith("w:")})
+        with torch.no_grad():
+            res = model([pb.to_cuda(DEV) for pb in pbs], False)
+        gu.check_logprob(res["log_probability"].cpu().numpy(), lp32, lp64, name)
+        assert int(res["type"]) == fm["type"], name
+        decided = gu.decided_answers(fm, lp32, lp64)
+        assert [x for x, d in zip(res["answer"], decided) if d] == [x for x, d in zip(fm["answer"], decided) if d], name
+        if fm["type"] == 1:
+            assert res["options"] == fm["options"], name
+        seen += 1
+    assert seen == 8
+
+
 def test_north_star_batch_parity_all_questions():
     """The batch bench.py times (BASELINE's metric: 256 questions x 100 objects, select -> filter -> relate -> exist, full-size model), ALL 256
     questions against the oracle's fp32 and float64 runs under the tolerance policy (K = 2, 1e-6, 1e-4): what `parity` in the bench line

@@ -142,3 +142,47 @@ def test_graphed_train_step_with_captured_collective(tmp_path):
     except (FileNotFoundError, ValueError):                      # the child died before it could write its findings
         pytest.xfail("the captured-collective step graph took its process down on this box (opt-in path; the default is the two-graph form)")
     assert outs[0]["backend"] == "nccl" and outs[0]["graph_equals_eager"] and outs[0]["graphs"] == 1
+
+
+def test_bench_shards_ragged_scenes_by_cost():
+    """`--workload c3` over two ranks (both on cuda:0, gloo): the global question list is cut into contiguous shards of whole images balanced
+    by the sum of n^2 (parallel.shard_bounds), the line reports every rank's question count, cost and the imbalance, and the total is still
+    world x batch questions per step."""
+    env = dict(os.environ, DFOL_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--steps", "2", "--warmup", "1", "--batch", "32", "--objects", "40",
+           "--questions-per-image", "4", "--cpu-sample", "0", "--stress-preds", "0", "--sustain", "0.2", "--streamed", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    sh = out["shard"]
+    assert sum(sh["questions_per_rank"]) == 64 and len(sh["questions_per_rank"]) == 2 and all(q % 4 == 0 for q in sh["questions_per_rank"])
+    assert 1.0 <= sh["imbalance_max_over_mean"] < 1.35, sh
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: runs wherever a node has them (the one-GPU test box skips it)")
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_over_rccl_two_gpus(mode):
+    """`python bench.py --gpus 2` over RCCL, one GPU per rank (the driver's N > 1 launch path, self-launched here): the rank report must show two
+    distinct devices (bench.py refuses the line otherwise), the train replicas must stay equal after the all-reduced steps, and - train - the
+    step is the two-graph form with the all-reduce issued eagerly between the replays."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DFOL_BENCH_SHARE_GPU", "DFOL_BENCH_FORCE_PG"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--objects", "20",
+           "--cpu-sample", "0", "--stress-preds", "0", "--sustain", "0.2", "--fresh-batches", "2", "--mode", mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["ranks"]["backend"] == "nccl" and out["ranks"]["distinct_devices"] == 2
+    assert out["config"]["global_batch"] == 32 and out["value"] > 0
+    if mode == "train":
+        assert out["replicas_equal"] is True and out["allreduce_ms"] > 0
+        assert "two hip graph replays" in out["config"]["launch"] or out["config"]["launch"] == "eager"

@@ -1120,6 +1120,154 @@ def g17():
 
 
 
+# ---------------------------------------------------------------------------------------- g18
+def g18():
+    """End to end FROM THE REFERENCE'S FILE FORMATS: questions authored here are written as program-bytecode .h5 files by the reference's
+    GQAH5Encoder (gqa_preprocess.py:51-94) and object features as chunk .h5 files + info JSON in the layout its collator reads
+    (batch_gqa_boxfeatures_pipeline.py:29-55) - committed under tests/golden/h5/g18_* as data fixtures - and then run through the reference's
+    own ProgramDataset -> BatchGQABoxFeaturesCollator -> BatchGQAInterpreter (data_pipeline.py:328-367, 391-453;
+    batch_gqa_boxfeatures_pipeline.py:29-92; batch_base_interpreter.py:72-183) with the neural model at reduced dims (16 features per
+    object).  Stored: the model's weights, and per program file the reference's log-probabilities (fp32 and fp64), answers, options and
+    question type.  (h5py is not installed: its slot is taken by dfol_vqa_amd/h5lite.py, a ctypes binding of the same HDF5 C library.)"""
+    import shutil
+    import tempfile
+    from dfol_vqa_amd import h5lite
+    saved = sys.modules.get("h5py")
+    sys.modules["h5py"] = h5lite
+    ref.data_pipeline.h5py = h5lite
+    sys.path.insert(0, ref_harness.REF_SRC)
+    for name in ("pattern", "pattern.text", "pattern.text.en"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.singularize = lambda w: w
+        sys.modules.setdefault(name, m)
+    import gqa_preprocess
+    gqa_preprocess.h5py = h5lite
+    from nsvqa.data import batch_gqa_boxfeatures_pipeline as bfp
+    bfp.h5py = h5lite
+    import gqa_interpreter_experiments as gie
+    h5dir = os.path.join(OUT, "h5")
+    F, max_obj, per_chunk, n_img = 16, 8, 8, 24
+    # ---- questions: eight terminal operators x six questions, 1..3 hops, negations, '_' names, second branches
+    rng = np.random.RandomState(18)
+    nouns = [n for v in mini_ontology.CLASSES.values() for n in v]
+    attrs = [a_ for v in mini_ontology.ATTRIBUTES.values() for a_ in v]
+    rels = [r for r in mini_ontology.RELATIONS if r != "riding"]
+    pick = lambda xs: xs[rng.randint(len(xs))]
+    Q = lambda i, im, br, last, ans: {"imageId": "img%03d" % im, "answer": ans, "question": "q%d" % i, "question_id": str(i),
+                                      "program": {"branches": br, "last_op": last}}
+
+    def branch():
+        b_ = [op("select", pick(nouns + ["_"]))]
+        for _ in range(rng.randint(1, 4)):
+            if rng.uniform() < 0.5:
+                a_ = pick(attrs)
+                b_.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.25 else a_))
+            else:
+                b_.append(op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
+        return b_
+
+    files, qid = {}, 100
+    for kind in ("exist", "verify_rel", "verify_attrs", "choose_attr", "choose_rel", "query_attr", "and", "two_same"):
+        qs = []
+        for j in range(6):
+            im = 10 + int(rng.randint(n_img))
+            cat = pick(sorted(mini_ontology.ATTRIBUTES))
+            br = [branch()]
+            if kind in ("and", "two_same"):
+                br.append([op("select", pick(nouns)), op("filter", pick(attrs))])
+            last, ans = {
+                "exist": (op("exist"), pick(["yes", "no"])),
+                "and": (op("and"), pick(["yes", "no"])),
+                "verify_rel": (op("verify_rel", pick(rels), bool(rng.uniform() < 0.5), pick(nouns)), pick(["yes", "no"])),
+                "verify_attrs": (op("verify_attrs", [pick(attrs)] + ([pick(attrs)] if j % 2 else [])), pick(["yes", "no"])),
+                "choose_attr": (op("choose_attr", list(mini_ontology.ATTRIBUTES[cat][:2])), mini_ontology.ATTRIBUTES[cat][0]),
+                "choose_rel": (op("choose_rel", [rels[j % 3], rels[3 + j % 3]], bool(rng.uniform() < 0.5), pick(nouns + ["_"])), rels[j % 3]),
+                "query_attr": (op("query_attr", pick(["color", "material", "name"])), pick(attrs)),
+                "two_same": (op("two_same", pick(["color", "material"])), pick(["yes", "no"])),
+            }[kind]
+            qs.append(Q(qid, im, br, last, ans))
+            qid += 1
+        files["g18_" + kind] = qs
+    tmp_in, tmp_out = tempfile.mkdtemp(), tempfile.mkdtemp()
+    for name, qs in files.items():
+        with open(os.path.join(tmp_in, name + ".json"), "w") as f:
+            for q in qs:
+                f.write(json.dumps(q) + "\n")
+    gqa_preprocess.GQAH5Encoder(ontology).encode(tmp_in, tmp_out)
+    for name in files:
+        shutil.copy(os.path.join(tmp_out, name + ".h5"), os.path.join(h5dir, name + ".h5"))
+    # ---- object features: three chunk files of eight images (batch_gqa_boxfeatures_pipeline.py:29-33, 52-55)
+    info = {}
+    for c in range(n_img // per_chunk):
+        feats = rng.uniform(0, 1, (per_chunk, max_obj, F)).astype(np.float32)
+        boxes = np.zeros((per_chunk, max_obj, 4), np.float32)
+        boxes[..., :2] = rng.uniform(0, 300, (per_chunk, max_obj, 2))
+        boxes[..., 2:] = boxes[..., :2] + rng.uniform(5, 100, (per_chunk, max_obj, 2))
+        with h5lite.File(os.path.join(h5dir, "g18_objects_%d.h5" % c), "w") as f:
+            f.create_dataset("features", data=feats)
+            f.create_dataset("bboxes", data=boxes)
+        for i in range(per_chunk):
+            info["img%03d" % (10 + per_chunk * c + i)] = {"idx": i, "file": c, "objectsNum": int(rng.randint(3, max_obj + 1)), "width": 640, "height": 480}
+    with open(os.path.join(h5dir, "g18_objects_info.json"), "w") as f:
+        json.dump(info, f)
+    # ---- the reference's model at reduced dims
+    cfg = dict(box_features_dim=F, oracle_input_dim=16, oracle_output_dim=1, word_embedding_dim=mini_ontology.EMBEDDING_DIM,
+               classifier_oracle=True, featurizer_layers_config=[], attribute_network_layers_config=[8],
+               relation_network_layers_config=[8], operator_layers_config=[], normalize_oracle=True, dropout=0.0,
+               freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+               freeze_embedding_network=False, activate_attention_transfer=False, attention_transfer_state_dim=0,
+               freeze_attention_network=False, trainable_gate=False, likelihood_threshold=0, hard_mode=False,
+               verbose=False, model_name="g18", gpu_num=1)
+    exp = gie.GQAObjectBoxExperiment()
+    exp._local_rank = 0
+    torch.manual_seed(18)
+    model = exp.build_model(cfg, ontology, None)
+    with torch.no_grad():                                     # informative likelihoods: a fresh embedding layer saturates every concept
+        lin = model._oracle._embedding_network._network[1]
+        lin.weight.normal_(0.0, 0.6)
+        lin.bias.fill_(-1.0)
+    model.eval()
+    model64 = copy.deepcopy(model).double()
+    arrays, meta = {}, {"source": "gqa_preprocess.py:51-94; data_pipeline.py:328-367,391-453; batch_gqa_boxfeatures_pipeline.py:29-92; "
+                                  "batch_base_interpreter.py:72-183",
+                        "config": cfg, "h5_dir": "tests/golden/h5", "feature_prefix": "g18_objects", "chunk_num": n_img // per_chunk,
+                        "info": "g18_objects_info.json", "torch": torch.__version__, "files": {}}
+    for k, v in model.state_dict().items():
+        if k.startswith("_featurizer.") or k.startswith("_oracle."):
+            arrays["w:" + k] = v.numpy().copy()
+    orig_shuffle = ref.data_pipeline.shuffle
+    ref.data_pipeline.shuffle = lambda x: None                # choose-options stay in file order (data_pipeline.py:596-597 shuffles them)
+    coll = bfp.BatchGQABoxFeaturesCollator(h5dir, "g18_objects", n_img // per_chunk, os.path.join(h5dir, "g18_objects_info.json"), ontology, 1)
+    for name in sorted(files):
+        # The dataset gets its OWN copy of the ontology, as it has in the reference's DataLoader worker processes: its token extraction
+        # appends the category name to the list GQAOntology.query returns - the ontology's own list (data_pipeline.py:487-488, 523-539) - so
+        # with one shared object the interpreter's query_attr would see option lists that grow by one bogus entry per decoded question.
+        ds = ref.data_pipeline.ProgramDataset(os.path.join(h5dir, name + ".h5"), copy.deepcopy(ontology), in_memory=False)
+        items = [ds[i] for i in range(len(ds))]
+        fm = {"image_ids": [it["image_id"] for it in items], "programs": [it["program"] for it in items], "gold": [it["answer"] for it in items]}
+        for dt, tag in both_dtypes():
+            pbs = coll.collate(copy.deepcopy(items))
+            for pb in pbs:
+                pb.create_sparse_tensors()
+                if dt == torch.float64:
+                    pb.to(torch.float64)
+                    pb._object_batch_index = pb._object_batch_index.long()
+            with torch.no_grad():
+                res = (model64 if dt == torch.float64 else model)(pbs, False)
+            arrays["%s:lp_%s" % (name, tag)] = res["log_probability"].detach().numpy()
+            if tag == "f32":
+                fm["answer"], fm["options"], fm["type"] = res["answer"], res["options"], int(res["type"])
+                fm["objects"] = [int(x) for x in torch.bincount(pbs[0]._object_batch_index).tolist()]
+        e = np.abs(arrays[name + ":lp_f32"] - arrays[name + ":lp_f64"])
+        print(name, "lp", np.round(arrays[name + ":lp_f64"], 2), "ref32 vs ref64 max %.2e" % e.max())
+        meta["files"][name] = fm
+    ref.data_pipeline.shuffle = orig_shuffle
+    save("g18_h5_end_to_end", arrays, meta)
+    if saved is not None:
+        sys.modules["h5py"] = saved
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:

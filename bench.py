@@ -50,6 +50,10 @@ def parse(argv=None):
                     help="north_star: configs[1]'s program on 100-object scenes (the size the metric is quoted on); c1: configs[1] verbatim "
                          "(36 objects); c3: configs[2]'s shape - ragged scenes of 10..100 objects, several questions per image sharing one scene; "
                          "c4: configs[4] (256 objects, 8-hop open programs, bf16 relation tiles)")
+    ap.add_argument("--data", default=None, help="--workload c3 on FILES in the reference's formats instead of synthetic scenes: a directory with "
+                    "metadata/{attribute,class,relation,vocab}.json [+ glove.txt], programs/*.h5 (GQAH5Encoder's program bytecode, one file per terminal "
+                    "operator: gqa_preprocess.py:51-94) and objects/<prefix>_<i>.h5 + objects/<prefix>_info.json (feature chunks: "
+                    "batch_gqa_boxfeatures_pipeline.py:29-55); e.g. GQA testdev-balanced when it is on the box")
     ap.add_argument("--questions-per-image", type=int, default=None,
                     help="questions that share one image (and, with sharing, one featurizer pass and one set of relation tiles); default 8 for c3, else 1")
     ap.add_argument("--share-scenes", type=int, default=1, help="0: collate one copy of the scene per question even when questions share an image (the reference's layout)")
@@ -298,6 +302,8 @@ def main(argv=None):
     rank, world, device, td, share = setup(args)
     if args.mode == "train":
         return train_main(args, rank, world, device, td, share)
+    if args.data:
+        return data_main(args, rank, world, device, td, share)
 
     from dfol_vqa_amd import _lib as L
     model, ontology, paths, names = build_model(args, device)
@@ -443,6 +449,156 @@ def main(argv=None):
                 if "policy" in out["parity"]:
                     out["parity"]["policy"] = {"applies": False, "why": "the fp32 tolerance policy does not apply to the opt-in bf16 tile storage"}
                 out["dtype"] = "f32 logic arithmetic on bf16 relation tiles"
+        emit(json.dumps(out))
+        sys.stdout.flush()
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def data_main(args, rank, world, device, td, share):
+    """`--workload c3 --data <dir>`: BASELINE configs[2] from FILES in the reference's formats: programs/*.h5 through
+    data.ProgramDataset (data_pipeline.py:328-367, 391-453), objects/*.h5 through data.BatchGQABoxFeaturesCollator
+    (batch_gqa_boxfeatures_pipeline.py:29-92), the HIP interpreter, answers and error rate (trainer.py:264-318) per batch.  One step = one
+    ProgramBatch of up to --batch questions of ONE program file (the reference's sampler batches by terminal operator), launched eagerly -
+    every step another batch; the batches of a rank are its contiguous share of the global batch list.  Weights are random (no checkpoint
+    travels), so the error rate is chance: the line is about rate and parity, which the oracle checks on the first batch of every file."""
+    import glob
+    from dfol_vqa_amd import _lib as L
+    from dfol_vqa_amd import data, experiment, training
+    from dfol_vqa_amd import synthetic as syn
+    d = os.path.abspath(args.data)
+    md = os.path.join(d, "metadata")
+    paths = {"attribute_file": os.path.join(md, "attribute.json"), "class_file": os.path.join(md, "class.json"),
+             "relation_file": os.path.join(md, "relation.json"), "vocabulary_file": os.path.join(md, "vocab.json"),
+             "word_embedding_file": os.path.join(md, "glove.txt") if os.path.exists(os.path.join(md, "glove.txt")) else None}
+    infos = sorted(glob.glob(os.path.join(d, "objects", "*_info.json")))
+    progs = sorted(glob.glob(os.path.join(d, "programs", "*.h5")) + glob.glob(os.path.join(d, "programs", "*.npz")))
+    if not infos or not progs or not all(os.path.exists(paths[k]) for k in ("attribute_file", "class_file", "relation_file", "vocabulary_file")):
+        sys.exit("bench.py --data %s: expected metadata/{attribute,class,relation,vocab}.json, programs/*.h5 and objects/<prefix>_<i>.h5 + <prefix>_info.json" % d)
+    prefix = os.path.basename(infos[0])[:-len("_info.json")]
+    chunks = len(glob.glob(os.path.join(d, "objects", prefix + "_[0-9]*.h5")) + glob.glob(os.path.join(d, "objects", prefix + "_[0-9]*.npz")))
+    L.load()
+    cfg = syn.reference_config(paths)
+    ontology = experiment.build_ontology(cfg)
+    coll = data.BatchGQABoxFeaturesCollator(os.path.join(d, "objects"), prefix, chunks, infos[0], ontology, 1)
+    cfg["box_features_dim"] = int(coll._feature_dim)          # 2048 for GQA's bottom-up features; the model's first layer follows the files
+    if getattr(ontology, "_embedding_file", None) is not None:
+        cfg["word_embedding_dim"] = int(ontology._embedding_dim)
+    torch.manual_seed(0)
+    model = experiment.build_model(cfg, ontology)
+    init_weights(model)
+    model = model.to(device).eval()
+    if td is not None:
+        from dfol_vqa_amd import parallel
+        parallel.broadcast_parameters(model, 0)
+    batches, per_file = [], {}
+    for path in progs:
+        ds = data.ProgramDataset(path, ontology, in_memory=True, shuffle_options=False)
+        items = [ds[i] for i in range(len(ds))]
+        per_file[os.path.basename(path)] = len(items)
+        for a in range(0, len(items), args.batch):
+            batches.append((os.path.basename(path), items[a:a + args.batch]))
+    if len(batches) < world:
+        sys.exit("bench.py --data: %d batches for %d ranks" % (len(batches), world))
+    mine = batches[rank * len(batches) // world:(rank + 1) * len(batches) // world]
+
+    def prepare(items):
+        pbs = coll.collate(items)
+        for pb in pbs:
+            pb.create_sparse_tensors()
+        return [pb.to_cuda(device) for pb in pbs]
+
+    def barrier():
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    err = np.zeros(training.ERROR_DIM)
+    cnt = np.zeros(training.ERROR_DIM)
+    with torch.no_grad():
+        for i in range(max(1, args.warmup)):
+            model(prepare(mine[i % len(mine)][1]), False)
+        barrier()
+        t0 = time.perf_counter()
+        nq = 0
+        for i in range(args.steps):
+            pbs = prepare(mine[i % len(mine)][1])
+            res = model(pbs, False)
+            training.accumulate_test_batch(err, cnt, pbs, res)
+            nq += sum(pb.batch_size() for pb in pbs)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # per-kernel device time of one pass over this rank's batches (HIP events on the launch stream)
+        if rank == 0:
+            L.enable_kernel_timing(list(L.SIGNATURES))
+            for _, items in mine:
+                model(prepare(items), False)
+            torch.cuda.synchronize()
+            timing = {k: v for k, v in L.disable_kernel_timing().items() if v[0]}
+    ranks = rank_report(td, share, device, rank, world, elapsed, args.steps)
+    tot = torch.tensor([float(nq), elapsed], dtype=torch.float64, device="cpu" if share or td is None else device)
+    if td is not None:
+        both = [torch.zeros_like(tot) for _ in range(world)]
+        td.all_gather(both, tot)
+        nq, elapsed = int(sum(float(b[0]) for b in both)), max(float(b[1]) for b in both)
+    if rank == 0:
+        # parity: the oracle on the first batch of every program file of this rank (fp32 and float64), under the tolerance policy
+        parity = None
+        if args.cpu_sample != 0:
+            from oracle import dfol_oracle as orc
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import golden_util as gu
+            oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+            weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+            checked, worst, agree, total, t_cpu = 0, 0.0, 0, 0, 0.0
+            done = set()
+            for fname, items in mine:
+                if fname in done or checked >= (args.cpu_sample or 64):
+                    continue
+                done.add(fname)
+                items = items[:16]
+                pbs = prepare(items)
+                with torch.no_grad():
+                    res = model(pbs, False)
+                feats = pbs[0]._object_features.cpu().numpy()
+                ns = [int(n) for n in pbs[0]._object_nums]
+                off = np.concatenate([[0], np.cumsum(ns)])
+                scenes = [{"n": n, "X": feats[off[i]:off[i + 1]]} for i, n in enumerate(ns)]
+                qs = [{"program": it["program"], "answer": it["answer"], "question_id": i, "image_id": it["image_id"]} for i, it in enumerate(items)]
+                h0 = time.perf_counter()
+                r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights)
+                t_cpu += time.perf_counter() - h0
+                r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights)
+                lp = res["log_probability"].cpu().numpy()
+                gu.check_logprob(lp, r32["log_probability"], r64["log_probability"], fname)       # raises on a policy violation
+                worst = max(worst, float(np.abs(np.exp(lp) - np.exp(r64["log_probability"])).max()))
+                agree += sum(1 for x, y in zip(res["answer"], r64["answer"]) if x == y)
+                total += len(items)
+                checked += len(items)
+            parity = {"questions_checked": checked, "program_files_checked": sorted(done), "max_abs_dp_vs_fp64": worst, "answers_agree": "%d/%d" % (agree, total),
+                      "policy": {"K": 2.0, "p_tol": 1e-6, "lp_tol": 1e-4, "pass": True}}
+            cpu = {"value": checked / t_cpu if t_cpu else None, "unit": "questions/s", "cores": 1, "kind": "port",
+                   "sample": "%d questions (the first <= 16 of every program file), numpy fp32 oracle incl. the full tables, %.1f s" % (checked, t_cpu)}
+        dom = max(timing, key=lambda k: timing[k][1])
+        out = {"argv": sys.argv[1:], "metric": "questions/sec (GQA programs from .h5 files: %s)" % d, "value": nq / elapsed, "unit": "questions/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "files: %s" % d,
+               "config": {"workload": "BASELINE configs[2] on files in the reference's formats under %s: %d program files (%d questions: %s), object features "
+                                      "%s_<i>.h5 x %d (%d features per object, up to %d objects per image), full op set, fp32, <= %d questions per ProgramBatch, "
+                                      "random-init weights" % (d, len(progs), sum(per_file.values()), ", ".join("%s %d" % kv for kv in sorted(per_file.items())),
+                                                               prefix, chunks, coll._feature_dim, coll._max_object_per_image, args.batch),
+                          "workload_id": "c3-files", "batches": len(batches), "batches_per_rank": len(mine), "parallelism": "dp%d" % world,
+                          "launch": "eager, every step another ProgramBatch (collate -> lower -> launch -> answers)",
+                          "model": "%d -> %d, %d / %d -> %s -> %d -> %d concepts" % (
+                              cfg["box_features_dim"], cfg["oracle_input_dim"], cfg["oracle_input_dim"] + 4, 2 * (cfg["oracle_input_dim"] + 4) + 4,
+                              cfg["attribute_network_layers_config"], cfg["word_embedding_dim"], len(ontology._vocabulary["idx_to_arg"]))},
+               "error_rate": training.metric_dict(err / np.maximum(cnt, 1)), "ranks": ranks,
+               "kernel_ms_per_pass": {k: round(v[1] * 1e3, 4) for k, v in sorted(timing.items(), key=lambda kv: -kv[1][1])},
+               "roofline": {"kernel": dom, "bound": "mfma" if ("pair_ll" in dom or "linear_act" in dom) else "hbm", "achieved": None, "peak": None, "unit": None,
+                            "frac": None, "traffic": None, "us_per_launch": timing[dom][1] / timing[dom][0] * 1e6,
+                            "note": "the dominant entry point of a pass over the files; its roofline at the benchmark shape is in the north-star line"},
+               "cpu_baseline": cpu if args.cpu_sample != 0 else None, "parity": parity}
         emit(json.dumps(out))
         sys.stdout.flush()
     if td is not None:

@@ -186,3 +186,28 @@ def test_bench_over_rccl_two_gpus(mode):
     if mode == "train":
         assert out["replicas_equal"] is True and out["allreduce_ms"] > 0
         assert "two hip graph replays" in out["config"]["launch"] or out["config"]["launch"] == "eager"
+
+
+def test_bench_on_files_in_the_reference_formats(tmp_path):
+    """`bench.py --workload c3 --data <dir>`: BASELINE configs[2] from files on disk - here the g18 fixtures (program bytecode .h5 files the
+    reference's encoder wrote, object-feature chunk .h5 files) laid out the way the flag expects; real GQA testdev files take the same path
+    when they are on the box.  The line says where its data came from, and its parity leg checked the oracle on every program file."""
+    import shutil
+    golden = os.path.join(HERE, "golden")
+    d = tmp_path / "gqa"
+    for sub in ("metadata", "programs", "objects"):
+        (d / sub).mkdir(parents=True)
+    for f in ("attribute.json", "class.json", "relation.json", "vocab.json", "glove.txt"):
+        shutil.copy(os.path.join(golden, "mini_ontology", f), str(d / "metadata" / f))
+    for f in os.listdir(os.path.join(golden, "h5")):
+        if f.startswith("g18_objects"):
+            shutil.copy(os.path.join(golden, "h5", f), str(d / "objects" / f))
+        elif f.startswith("g18_"):
+            shutil.copy(os.path.join(golden, "h5", f), str(d / "programs" / f))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--data", str(d), "--batch", "4", "--steps", "16", "--warmup", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["data"].startswith("files: ") and "g18_exist.h5 6" in out["config"]["workload"] and out["config"]["batches"] == 16
+    assert out["value"] > 0 and out["parity"]["policy"]["pass"] and len(out["parity"]["program_files_checked"]) == 8
+    assert out["parity"]["questions_checked"] == 32 and out["cpu_baseline"]["value"] > 0

@@ -85,20 +85,24 @@ __device__ __forceinline__ void h2_split2(float x0, float x1, uint32_t& h, uint3
     l = __builtin_bit_cast(uint32_t, ll);
 }
 
-// z + g * s with the scalar s taken from the LOW (HI = false) or HIGH half of the register pair `sp` for both lanes of the packed operation:
-// v_pk_fma_f32's op_sel / op_sel_hi pick the 32-bit half of each source per result lane.  The compiler only knows the plain form and
-// materialises {s, s} pairs - 16 registers for the eight geometry terms of a lane's two slots, which the kernel does not have.
-template <bool HI>
-__device__ __forceinline__ f32x2 h2_fma_bcast(f32x2 g, f32x2 sp, f32x2 z) {
-    f32x2 out;
-    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(out) : "v"(g), "v"(sp), "v"(z));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(out) : "v"(g), "v"(sp), "v"(z));
-    return out;
-}
-
-// e^min(z, 0) - 1 on the hardware exponential
+// e^min(z, 0) - 1 on the hardware exponential (min(z, 0) as a v_med3: fminf canonicalises its input with an extra v_max per element)
 __device__ __forceinline__ float h2_expm1_neg(float z) {
     return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(z, 0.f, -3.0e38f) * 1.44269504088896340736f) - 1.0f;
+}
+
+// The k of a 32-chunk that k-group kq (a lane's kh) holds at position e = 0..7 of its MFMA operand register: 16 (e >> 2) + 4 kq + (e & 3).
+// The order of k inside a chunk is free as long as A and B agree; this one makes the A operand coincide with the C / D layout of an MFMA
+// whose ROWS are k: a lane's four accumulator elements of the two geometry MFMAs of a chunk (rows 4 kh + e of k-tile t) are exactly its
+// eight A elements, so the first layer's geometry term comes out of the matrix pipe in place (see make_a).
+__host__ __device__ __forceinline__ constexpr int h2_kperm(int kq, int e) { return 16 * (e >> 2) + 4 * kq + (e & 3); }
+
+// x - float(h.lo) / x - float(h.hi) in one instruction (v_fma_mix_f32: fma with per-source fp16 / fp32 selection): the residual of the split
+template <bool HI>
+__device__ __forceinline__ float h2_resid(float x, uint32_t hpair) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+    else asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+    return r;
 }
 
 // One wavefront per row of W2: e_r puts the row's largest magnitude into [2^13, 2^14); tail[r] = -log2(e) 2^-e_r, tail[320 + r] = e_r
@@ -137,8 +141,8 @@ __global__ void h2_pack_w2_kernel(const float* __restrict__ W2, int64_t ld_w2, i
     for (int j = 0; j < 4; ++j) {
         float w0 = 0.f, w1 = 0.f;
         if (r < HID2) {
-            w0 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + kq * 8 + 2 * j], e);
-            w1 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + kq * 8 + 2 * j + 1], e);
+            w0 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + h2_kperm(kq, 2 * j)], e);
+            w1 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + h2_kperm(kq, 2 * j + 1)], e);
         }
         uint32_t h, l;
         h2_split2(w0, w1, h, l);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int ROWS = NB16 * 16, T = WAVES * 64, SLOTS = MT * 16 * WAVES;
     static_assert(NB16 > 16 && NB16 <= H2_TILES, "geometry");
     __shared__ __attribute__((aligned(16))) u32x4 Bs[2 * H2_PIECES];          // two W2 chunks, both pieces (40 KB each)
-    __shared__ __attribute__((aligned(16))) float Wgs[256 * 4];
+    __shared__ __attribute__((aligned(16))) u32x4 WgA[(256 / H2_CH) * 2 * 64];      // the geometry weights as MFMA A fragments: [chunk][k-tile][lane], 16 KB
     constexpr int STAGE_FLOATS = 8192;                          // the epilogue's bias / multiplier / embedding rows (32 KB)
     __shared__ __attribute__((aligned(16))) float stage[STAGE_FLOATS];
     const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
@@ -184,7 +188,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_global_load_lds(W2h + T * i + tid, (__attribute__((address_space(3))) void*)&Bs[T * i + wave * 64], 16, 0, 0);
     const float* cf = reinterpret_cast<const float*>(W2h + (int64_t)nchunk * H2_PIECES);      // -log2(e) 2^-e_r per hidden column
     const int first = obj_off[q];
-    f32x2 geo[MT][2];                                       // {distance, angle}, {sign dx, sign dy} (batch_gqa_boxfeatures_pipeline.py:263-279)
+    // The pair geometry {distance, angle, sign dx, sign dy} (batch_gqa_boxfeatures_pipeline.py:263-279) as the B fragment of the geometry
+    // MFMAs (make_a): 32 contraction slots, twelve in use - [0..3] geo_h, [4..7] geo_l (meeting wg_h), [8..11] geo_h (meeting wg_l)
+    u32x4 geoB[MT];
     // U / V rows as 32-bit byte offsets from the image's first row (a scalar base: the loads take the saddr + voffset form; 64-bit per-lane
     // pointers cost 16 registers that the prefetched rows need)
     const char* img_uv = reinterpret_cast<const char*>(UV + (int64_t)first * ld_uv);
@@ -199,14 +205,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
         const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
         const float dist = sqrtf(dx * dx + dy * dy);
-        geo[m][0] = f32x2{dist, asinf(dy / fmaxf(dist, 1e-10f))};
-        geo[m][1] = f32x2{(x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f), (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f)};
-        uoff[m] = (uint32_t)(s * (int)ld_uv + 8 * kh) * 4u;
-        voff[m] = (uint32_t)(o * (int)ld_uv + HID1 + 8 * kh) * 4u;
+        uint32_t gh01, gl01, gh23, gl23;
+        h2_split2(dist, asinf(dy / fmaxf(dist, 1e-10f)), gh01, gl01);
+        h2_split2((x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f), (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f), gh23, gl23);
+        geoB[m] = kh == 0 ? u32x4{gh01, gh23, gl01, gl23} : (kh == 1 ? u32x4{gh01, gh23, 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
+        uoff[m] = (uint32_t)(s * (int)ld_uv + 4 * kh) * 4u;          // the lane's k of a chunk: 16 t + 4 kh + 0..3, t = 0, 1 (h2_kperm)
+        voff[m] = (uint32_t)(o * (int)ld_uv + HID1 + 4 * kh) * 4u;
     }
-    for (int i = tid; i < HID1; i += T) {                    // geometry weights, transposed to [feature][k]
-        const float4 g = *reinterpret_cast<const float4*>(Wg + i * 4);
-        Wgs[i] = g.x, Wgs[256 + i] = g.y, Wgs[512 + i] = g.z, Wgs[768 + i] = g.w;
+    for (int i = tid; i < (HID1 / 16) * 64; i += T) {       // A fragment of k-tile i / 64 (16 consecutive k): lane (row k' = r16, khh) holds slots 8 khh ..
+        const int kt = i >> 6, ln = i & 63, khh = ln >> 4;
+        u32x4 frag = {0u, 0u, 0u, 0u};
+        if (khh < 2) {
+            const float4 g = *reinterpret_cast<const float4*>(Wg + (kt * 16 + (ln & 15)) * 4);
+            uint32_t h01, l01, h23, l23;
+            h2_split2(g.x, g.y, h01, l01);
+            h2_split2(g.z, g.w, h23, l23);
+            frag = khh == 0 ? u32x4{h01, h23, h01, h23} : u32x4{l01, l23, 0u, 0u};      // [0..3] wg_h, [4..7] wg_h, [8..11] wg_l
+        }
+        WgA[i] = frag;
     }
     // the epilogue's rows are staged up front (the first barrier publishes them): row 0 the hidden bias times -log2(e), row 1 the
     // per-column multiplier -log2(e) 2^-e_r, then the requested embedding rows.  Padding columns get bias -1e30: Sigmoid exactly 0.
@@ -250,39 +266,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                ru[m][half] = *reinterpret_cast<const floatx4*>(base + uoff[m] + 16 * half);
-                rv[m][half] = *reinterpret_cast<const floatx4*>(base + voff[m] + 16 * half);
+            for (int half = 0; half < 2; ++half) {                  // (k-tile t = half: 16 k = 64 bytes further)
+                ru[m][half] = *reinterpret_cast<const floatx4*>(base + uoff[m] + 64 * half);
+                rv[m][half] = *reinterpret_cast<const floatx4*>(base + voff[m] + 64 * half);
             }
     };
     u32x4 ap[MT][2];                                                // [slot][piece h, l]
+    // A pieces of chunk c.  The first layer's sums z = U[s] + V[o] + Wg geo(s, o) come out of the matrix pipe: per k-tile t (16 k) one MFMA
+    // per slot tile with the geometry weights as A (rows = k), the pair geometry as B (columns = slots) and U + V as the C operand - twelve
+    // contraction slots hold the three piece products wg_h geo_h + wg_h geo_l + wg_l geo_h.  With the k order of h2_kperm its result
+    // registers ARE the lane's A elements of the main product (slot r16, k = 16 t + 4 kh + e): four MFMAs replace 32 packed FMAs and eight LDS
+    // reads per chunk.  Then nn.ELU with the saturation - med3(z, e^min(z, 0) - 1, AMAX) = z in (0, AMAX], e^z - 1 for z <= 0 (e^z - 1 >= z),
+    // AMAX beyond - and the split.
     auto make_a = [&](int c) __attribute__((always_inline)) {
+        floatx4 z[MT][2];
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int t = 0; t < 2; ++t) {
+            const f16x8 wa = __builtin_bit_cast(f16x8, WgA[(2 * c + t) * 64 + lane]);
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                f32x2 g[4];                                         // geometry weights of k, k+1 for the four geometry features
+            for (int m = 0; m < MT; ++m)
+                z[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, __builtin_bit_cast(f16x8, geoB[m]), ru[m][t] + rv[m][t], 0, 0, 0);
+        }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) g[d] = *reinterpret_cast<const f32x2*>(&Wgs[d * 256 + H2_CH * c + 8 * kh + 4 * half + 2 * jp]);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const f32x2 uu = jp == 0 ? (f32x2){ru[m][half].x, ru[m][half].y} : (f32x2){ru[m][half].z, ru[m][half].w};
-                    const f32x2 vv = jp == 0 ? (f32x2){rv[m][half].x, rv[m][half].y} : (f32x2){rv[m][half].z, rv[m][half].w};
-                    f32x2 z = uu + vv;
-                    z = h2_fma_bcast<false>(g[0], geo[m][0], z);
-                    z = h2_fma_bcast<true>(g[1], geo[m][0], z);
-                    z = h2_fma_bcast<false>(g[2], geo[m][1], z);
-                    z = h2_fma_bcast<true>(g[3], geo[m][1], z);
-                    // nn.ELU with the saturation: med3(z, e^min(z, 0) - 1, AMAX) = z in (0, AMAX], e^z - 1 for z <= 0 (e^z - 1 >= z), AMAX beyond
-                    // (min(z, 0) as a v_med3 too: fminf on the inline asm's result costs a canonicalising v_max per element)
-                    const float a0 = __builtin_amdgcn_fmed3f(z.x, h2_expm1_neg(z.x), H2_AMAX);
-                    const float a1 = __builtin_amdgcn_fmed3f(z.y, h2_expm1_neg(z.y), H2_AMAX);
-                    uint32_t hh, ll;
-                    h2_split2(a0, a1, hh, ll);
-                    ap[m][0][2 * half + jp] = hh;
-                    ap[m][1][2 * half + jp] = ll;
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const float z0 = z[m][t][2 * jp], z1 = z[m][t][2 * jp + 1];
+                    const float a0 = __builtin_amdgcn_fmed3f(z0, h2_expm1_neg(z0), H2_AMAX);
+                    const float a1 = __builtin_amdgcn_fmed3f(z1, h2_expm1_neg(z1), H2_AMAX);
+                    const uint32_t hh = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a0, a1}, f16x2));
+                    const uint32_t ll = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){h2_resid<false>(a0, hh), h2_resid<true>(a1, hh)}, f16x2));
+                    ap[m][0][2 * t + jp] = hh;
+                    ap[m][1][2 * t + jp] = ll;
                 }
-            }
     };
     const int boff = r16 * 4 + (kh ^ h2_swz(r16));                  // the lane's 16-byte piece inside a 16-row block
     int bbase = boff;                                               // + the chunk buffer's offset
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // LDS-DMA completion is tracked by vmcnt of the ISSUING wavefront only; a workgroup barrier does not wait for it by itself
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
-    __syncthreads();                                        // Wgs, the staged epilogue rows and chunk 0 visible
+    __syncthreads();                                        // WgA, the staged epilogue rows and chunk 0 visible
 
     // Tick tau: half X (wavefronts 0-3) builds chunk tau/2 on even ticks and multiplies it on the next; half Y (4-7) does the same one
     // tick later.  Chunk c is read in ticks 2c+1 (X) and 2c+2 (Y); its buffer is refilled with chunk c+2 by Y during its build tick 2c+3

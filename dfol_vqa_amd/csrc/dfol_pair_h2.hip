@@ -375,8 +375,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (Y && DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
             TRACE(3 + 4 * c);
             // end of the build tick.  (__syncthreads() carries a release fence, for which the compiler drains the chunk request Y has just
-            // issued - vmcnt(0) in front of the barrier.  The bare s_barrier instruction for Y, whose DMA then lands under its multiply tick,
-            // was measured: 1.27 ms against 1.19 - the DMA's LDS writes then compete with the multiply tick's fragment reads.)
+            // issued - vmcnt(0) in front of the barrier.  Two ways around that wait were built and measured slower: the bare s_barrier
+            // instruction for Y, the DMA landing under its multiply tick (1.27 ms against 1.19: its LDS writes compete with the multiply tick's
+            // fragment reads), and THREE chunk buffers with the request two chunks ahead, drained at the top of Y's next build tick
+            // (1.28 ms against 1.16: a chunk takes more than a tick - ~3.5 k cycles - to arrive from L2 when every CU streams the 320 KB
+            // image, so the wait only moves).)
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             TRACE(4 + 4 * c);

@@ -79,8 +79,12 @@ def build_interpreter(config, neural_dict, ontology):           # gqa_interprete
     mlp_math = str(config.get('mlp_math', 'fp32')).lower()                                 # an extra key of this build (configs[3])
     if mlp_math in ('bf16', 'bfloat16'):
         model._mlp_math = 'bf16'
+    elif mlp_math == 'bf16x3':
+        # fp32 results from three exact bf16 pieces per operand (round 3's arithmetic): for object features whose scale is far from one - the
+        # default forward products split their inputs into two UNSCALED fp16 pieces (error max(2^-22 |x|, 2^-25) per element)
+        model._mlp_math = 'bf16x3'
     elif mlp_math not in ('fp32', 'float32', 'f32'):
-        raise ValueError("mlp_math must be fp32 or bf16, got %r" % (config.get('mlp_math'),))
+        raise ValueError("mlp_math must be fp32, bf16x3 or bf16, got %r" % (config.get('mlp_math'),))
     return model
 
 

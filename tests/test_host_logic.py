@@ -207,5 +207,6 @@ def test_mlp_math_config_key(tmp_path):
     ont = experiment.build_ontology(cfg)
     assert getattr(experiment.build_model(dict(cfg), ont), "_mlp_math", None) is None
     assert experiment.build_model(dict(cfg, mlp_math="bf16"), ont)._mlp_math == "bf16"
+    assert experiment.build_model(dict(cfg, mlp_math="bf16x3"), ont)._mlp_math == "bf16x3"      # exact-range forward products
     with pytest.raises(ValueError):
         experiment.build_model(dict(cfg, mlp_math="fp8"), ont)

@@ -18,7 +18,7 @@ take() {          # take <source> <destination> [filter]: copy (or, with "json",
   esac
   if [ -s "$tmp" ]; then mv "$tmp" "$dst"; else echo "collect_profiles: nothing usable in $src (kept $dst as it is)"; missing=$((missing+1)); rm -f "$tmp"; fi
 }
-for f in bench_n100.json bench_c1_n36.json bench_c3_shared.json bench_c3_unshared.json bench_c4_n256.json bench_2ranks_one_gpu.json train_2ranks_one_gpu.json train_rccl_world1.json train_rccl_world1_cal.json; do
+for f in bench_n100.json bench_n100_bf16x3.json bench_n100_f32pipe.json bench_c1_n36.json bench_c3_shared.json bench_c3_unshared.json bench_c4_n256.json bench_2ranks_one_gpu.json train_2ranks_one_gpu.json train_rccl_world1.json train_rccl_world1_cal.json; do
   take $O/$f profiles/${TAG}_$f json
 done
 take $O/train_step.jsonl profiles/${TAG}_train_step.jsonl lines

@@ -2,8 +2,8 @@
 # Round-end measurement pass (runs on the GPU box): rocprofv3 stats + HBM counters of the default bench command, the bench lines of
 # every configuration, kernel / operator / training / calibrated-forward benchmarks, per-step launch breakdowns and the PMC passes of
 # the two MFMA kernels.  Copy what should be judged from gpurun_out/ into profiles/ (named per round).
-# usage: tools/measure_all.sh [tag]      (default tag r03)
-TAG=${1:-r03}
+# usage: tools/measure_all.sh [tag]      (default tag r04)
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=gpurun_out/$TAG
@@ -18,6 +18,9 @@ timeout 300 python bench.py --workload c3 > $O/bench_c3_shared.json 2> $O/bench_
 timeout 300 python bench.py --workload c3 --share-scenes 0 --cpu-sample 0 --stress-preds 0 > $O/bench_c3_unshared.json 2>> $O/bench_c3.err
 cp gpurun_out/prof_$TAG/roofline_rocprof_merged.json $O/roofline_rocprof.json 2>/dev/null
 timeout 300 python tools/bench_kernels.py > $O/kernel_microbench.jsonl 2> $O/kb.err
+# the north-star line with round 3's arithmetic (three bf16 pieces, six products) and on the fp32 pipe, for the A/B table of DESIGN 3.4
+DFOL_PAIR_MATH=bf16x3 DFOL_DENSE_MATH=bf16x3 timeout 300 python bench.py --steps 50 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --streamed 0 --sustain 0 > $O/bench_n100_bf16x3.json 2>> $O/bench_n100.err
+DFOL_PAIR_MATH=f32 DFOL_DENSE_MATH=f32 timeout 300 python bench.py --steps 50 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --streamed 0 --sustain 0 > $O/bench_n100_f32pipe.json 2>> $O/bench_n100.err
 timeout 300 python tools/bench_ops.py > $O/ops_throughput.jsonl 2> $O/ops.err
 for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1" "--objects 100 --mlp-math bf16" "--objects 100 --graph 0" "--objects 100 --calibrator 1 --graph 0"; do
   timeout 300 python bench.py --mode train --steps 10 $a >> $O/train_step.jsonl 2>> $O/train.err
@@ -37,6 +40,8 @@ bash tools/step_breakdown.sh ${TAG}_train_bf16_n100 --mode train --objects 100 -
 mkdir -p gpurun_out/peak
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lab/mfma_peak.hip -o gpurun_out/peak/mfma_peak > /dev/null 2>&1 && timeout 120 gpurun_out/peak/mfma_peak > $O/mfma_peak.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lab/tick_model.hip -o gpurun_out/peak/tick_model > /dev/null 2>&1 && timeout 120 gpurun_out/peak/tick_model > $O/tick_model.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lab/coissue.hip -o gpurun_out/peak/coissue > /dev/null 2>&1 && timeout 120 gpurun_out/peak/coissue > $O/coissue.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lab/split_accuracy.hip -o gpurun_out/peak/split_accuracy > /dev/null 2>&1 && timeout 120 gpurun_out/peak/split_accuracy > $O/split_accuracy.txt 2>&1
 mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/lab/transc_accuracy.hip -o build/transc_accuracy > /dev/null 2>&1 && timeout 60 build/transc_accuracy > $O/transcendental_accuracy.txt 2>&1
 timeout 300 python tools/accuracy_probe.py --tag $TAG > $O/accuracy_probe_n36.json 2> $O/probe.err
 timeout 300 python tools/accuracy_probe.py --tag ${TAG}_n100 --objects 100 --questions 16 > $O/accuracy_probe_n100.json 2>> $O/probe.err

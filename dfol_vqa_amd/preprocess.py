@@ -13,8 +13,9 @@ A GQA question carries its functional program as `semantic`: a list of {operatio
   4. normalises the answer.
 
 Word singularisation: the reference calls `pattern.text.en.singularize`, which this image does not have.  `normalize` takes the
-singulariser as an argument; the default uses `pattern` when it is importable and a small suffix rule otherwise.  The goldens were
-captured with the identity on a vocabulary for which that is right, so everything except that one library call is pinned.
+singulariser as an argument; the default uses `pattern` when it is importable and otherwise `pattern_singularize`, a restatement of that
+library's published algorithm (exception tables, then the first matching suffix rule).  The goldens were captured with the identity on a
+vocabulary for which that is right, so everything except that one library call is pinned.
 """
 import json
 import os
@@ -28,14 +29,80 @@ PLURALE_TANTUM = frozenset((
 IRREGULAR = {'shelves': 'shelf', 'bookshelves': 'bookshelf', 'olives': 'olive', 'brownies': 'brownie', 'cookies': 'cookie'}
 
 
-def _suffix_singularize(word):
-    """Fallback when `pattern` is absent: the three regular English plural suffixes.  NOT the reference's library."""
-    if len(word) > 3 and word.endswith('ies'):
-        return word[:-3] + 'y'
-    if len(word) > 3 and re.search(r'(s|x|z|ch|sh)es$', word):
-        return word[:-2]
-    if len(word) > 2 and word.endswith('s') and not word.endswith('us'):
-        return word[:-1]
+# ---- the singulariser --------------------------------------------------------------------------------------------------------------
+# The reference calls `pattern.text.en.singularize` (parse_utils.py:6, 20; pattern is a declared dependency, setup.py, unpinned; the 3.6
+# series is current for Python 3).  The library is not in this image, so its published algorithm (pattern/text/en/inflect.py: Conway-style
+# rule list behind four exception tables) is RESTATED here: exception tables first - uninflected and uncountable words are returned as
+# they are, -ie words lose their s, irregular plurals are replaced by table - then the first matching suffix rule wins.  The quirks of the
+# original are kept (the uninflected / uncountable tests are `table_word.endswith(word)`, so any suffix of a table word passes through
+# unchanged).  UNPINNED: no output of the library itself could be captured here; golden g15 uses a vocabulary for which the identity is right.
+_SINGULAR_RULES = [(re.compile(rule), repl) for rule, repl in (
+    (r'(?i)(.)ae$', r'\1a'), (r'(?i)(.)itis$', r'\1itis'), (r'(?i)(.)eaux$', r'\1eau'), (r'(?i)(quiz)zes$', r'\1'),
+    (r'(?i)(matr)ices$', r'\1ix'), (r'(?i)(ap|vert|ind)ices$', r'\1ex'), (r'(?i)^(ox)en', r'\1'), (r'(?i)(alias|status)es$', r'\1'),
+    (r'(?i)([octop|vir])i$', r'\1us'), (r'(?i)(cris|ax|test)es$', r'\1is'), (r'(?i)(shoe)s$', r'\1'), (r'(?i)(o)es$', r'\1'),
+    (r'(?i)(bus)es$', r'\1'), (r'(?i)([m|l])ice$', r'\1ouse'), (r'(?i)(x|ch|ss|sh)es$', r'\1'), (r'(?i)(m)ovies$', r'\1ovie'),
+    (r'(?i)(.)ombies$', r'\1ombie'), (r'(?i)(s)eries$', r'\1eries'), (r'(?i)([^aeiouy]|qu)ies$', r'\1y'),
+    # -f, -fe sometimes take -ves in the plural (lives, wolves)
+    (r'([aeo]l)ves$', r'\1f'), (r'([^d]ea)ves$', r'\1f'), (r'arves$', 'arf'), (r'erves$', 'erve'), (r'([nlw]i)ves$', r'\1fe'),
+    (r'(?i)([lr])ves$', r'\1f'), (r'([aeo])ves$', r'\1ve'), (r'(?i)(sive)s$', r'\1'), (r'(?i)(tive)s$', r'\1'), (r'(?i)(hive)s$', r'\1'),
+    (r'(?i)([^f])ves$', r'\1fe'),
+    # -ses
+    (r'(?i)(^analy)ses$', r'\1sis'), (r'(?i)((a)naly|(b)a|(d)iagno|(p)arenthe|(p)rogno|(s)ynop|(t)he)ses$', r'\1\2sis'),
+    (r'(?i)(.)opses$', r'\1opsis'), (r'(?i)(.)yses$', r'\1ysis'), (r'(?i)(h|d|r|o|n|b|cl|p)oses$', r'\1ose'),
+    (r'(?i)(fruct|gluc|galact|lact|ket|malt|rib|sacchar|cellul)ose$', r'\1ose'), (r'(?i)(.)oses$', r'\1osis'),
+    # -a
+    (r'(?i)([ti])a$', r'\1um'), (r'(?i)(n)ews$', r'\1ews'), (r'(?i)s$', ''))]
+_SINGULAR_UNINFLECTED = frozenset((
+    "bison", "debris", "headquarters", "pincers", "trout", "bream", "diabetes", "herpes", "pliers", "tuna", "breeches", "djinn", "high-jinks",
+    "proceedings", "whiting", "britches", "eland", "homework", "rabies", "wildebeest", "carp", "elk", "innings", "salmon", "chassis", "flounder",
+    "jackanapes", "scissors", "christmas", "gallows", "mackerel", "series", "clippers", "georgia", "measles", "shears", "cod", "graffiti", "mews",
+    "species", "contretemps", "mumps", "swine", "corps", "news", "swiss"))
+_SINGULAR_UNCOUNTABLE = frozenset((
+    "advice", "equipment", "happiness", "luggage", "news", "software", "bread", "fruit", "information", "mathematics", "oil", "understanding",
+    "butter", "furniture", "ketchup", "mayonnaise", "research", "water", "cheese", "garbage", "knowledge", "meat", "rice", "electricity", "gravel",
+    "love", "mustard", "sand"))
+_SINGULAR_IE = frozenset((
+    "alergie", "cutie", "hoagie", "newbie", "softie", "veggie", "auntie", "doggie", "hottie", "nightie", "sortie", "weenie", "beanie", "eyrie",
+    "indie", "oldie", "stoolie", "yuppie", "birdie", "foodie", "junkie", "pie", "sweetie", "zombie", "bogie", "genie", "laddie", "pixie", "techie",
+    "bombie", "groupie", "laramie", "quickie", "tie", "collie", "hankie", "lingerie", "reverie", "toughie", "cookie", "hippie", "meanie", "rookie",
+    "valkyrie"))
+_SINGULAR_IRREGULAR = {
+    "atlantes": "atlas", "atlases": "atlas", "axes": "axe", "beeves": "beef", "brethren": "brother", "children": "child", "corpora": "corpus",
+    "corpuses": "corpus", "ephemerides": "ephemeris", "feet": "foot", "ganglia": "ganglion", "geese": "goose", "genera": "genus", "genii": "genie",
+    "graffiti": "graffito", "helves": "helve", "kine": "cow", "leaves": "leaf", "loaves": "loaf", "men": "man", "mongooses": "mongoose",
+    "monies": "money", "moves": "move", "mythoi": "mythos", "numena": "numen", "occipita": "occiput", "octopodes": "octopus", "opera": "opus",
+    "opuses": "opus", "our": "my", "oxen": "ox", "penes": "penis", "penises": "penis", "people": "person", "sexes": "sex",
+    "soliloquies": "soliloquy", "teeth": "tooth", "testes": "testis", "trilbys": "trilby", "turves": "turf", "zoa": "zoon"}
+_PLURAL_PREPOSITIONS = frozenset(("about", "before", "during", "of", "till", "above", "behind", "except", "off", "to", "across", "below", "for",
+                                  "on", "under", "after", "beneath", "from", "onto", "until", "among", "beside", "in", "out", "unto", "around",
+                                  "besides", "into", "over", "upon", "at", "between", "near", "since", "with", "athwart", "betwixt", "beyond",
+                                  "but", "by"))
+
+
+def pattern_singularize(word):
+    """pattern.text.en.singularize (nouns), restated - see the note above."""
+    if "-" in word:                                        # compound words: mothers-in-law
+        parts = word.split("-")
+        if len(parts) > 1 and parts[1] in _PLURAL_PREPOSITIONS:
+            return pattern_singularize(parts[0]) + "-" + "-".join(parts[1:])
+    if word.endswith("'"):                                 # dogs' -> dog's
+        return pattern_singularize(word[:-1]) + "'s"
+    w = word.lower()
+    if any(x.endswith(w) for x in _SINGULAR_UNINFLECTED) or any(x.endswith(w) for x in _SINGULAR_UNCOUNTABLE):
+        return word
+    for x in _SINGULAR_IE:
+        if w.endswith(x + "s"):
+            return w[:-1]
+    for x, singular in _SINGULAR_IRREGULAR.items():
+        if w.endswith(x):
+            return re.sub('(?i)' + x + '$', singular, word)
+    for rule, repl in _SINGULAR_RULES:
+        m = rule.search(word)
+        if m:
+            for k, g in enumerate(m.groups()):
+                if g is None:
+                    repl = repl.replace('\\' + str(k + 1), '')
+            return rule.sub(repl, word)
     return word
 
 
@@ -44,7 +111,7 @@ def default_singularize():
         from pattern.text.en import singularize          # the reference's choice
         return singularize
     except Exception:
-        return _suffix_singularize
+        return pattern_singularize
 
 
 def normalize(string, singularize=None):

@@ -210,3 +210,22 @@ def test_mlp_math_config_key(tmp_path):
     assert experiment.build_model(dict(cfg, mlp_math="bf16x3"), ont)._mlp_math == "bf16x3"      # exact-range forward products
     with pytest.raises(ValueError):
         experiment.build_model(dict(cfg, mlp_math="fp8"), ont)
+
+
+def test_pattern_singularize_restatement():
+    """preprocess.pattern_singularize restates pattern.text.en.singularize (parse_utils.py:6, 20; the library is not in this image, so
+    this is a self-consistency table, not a pinned one): exception tables before suffix rules, first matching rule wins.  One check IS anchored
+    in the reference: its own `irregulars` table (parse_utils.py:14) exists to override what the library returns for 'shelves' - and the
+    restated rules do return 'shelve' for it - while `normalize` applies the reference's table first."""
+    from dfol_vqa_amd.preprocess import normalize, pattern_singularize as sg
+    expect = {"dogs": "dog", "men": "man", "women": "woman", "people": "person", "children": "child", "leaves": "leaf", "knives": "knife",
+              "wolves": "wolf", "boxes": "box", "buses": "bus", "dishes": "dish", "benches": "bench", "tomatoes": "tomato", "shoes": "shoe",
+              "mice": "mouse", "feet": "foot", "teeth": "tooth", "geese": "goose", "cherries": "cherry", "keys": "key", "cookies": "cookie",
+              "movies": "movie", "halves": "half", "wives": "wife", "scarves": "scarf", "sandwiches": "sandwich", "cacti": "cactus",
+              "media": "medium", "analyses": "analysis", "oxen": "ox", "matrices": "matrix", "vertices": "vertex", "news": "news",
+              "series": "series", "fish": "fish", "sheep": "sheep", "deer": "deer", "scissors": "scissors", "mothers-in-law": "mother-in-law",
+              "dogs'": "dog's", "shelves": "shelve"}
+    got = {w: sg(w) for w in expect}
+    assert got == expect, {w: (got[w], expect[w]) for w in expect if got[w] != expect[w]}
+    assert normalize("Shelves") == "shelf" and normalize(" Men ") == "man" and normalize("glasses") == "glasses" and normalize("dress") == "dress"
+    assert normalize("tennis shorts") == "tennis shorts" and normalize("Buses") == "bus" and normalize("grass") == "grass"

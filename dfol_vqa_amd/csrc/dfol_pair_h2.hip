@@ -399,16 +399,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // embedding rows (16-lane DPP reduction), LogSigmoid, straight into the [s][o] (or [o][s]) tile the Relate kernel reads.
     const int64_t tile_sz = (int64_t)NS * NS;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < NB16; ++i) {
             const float bv = stage[i * 16 + r16], cm = stage[ROWS + i * 16 + r16];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[m][i][e], cm, bv)));
         }
-        for (int k = 0; k < K; ++k) {
-            const int col = req_col[(int64_t)k * Q + q];
-            if (col < 0) continue;
+    for (int k = 0; k < K; ++k) {
+        const int col = req_col[(int64_t)k * Q + q];
+        if (col < 0) continue;
+        float vm[MT];                                           // the logit of slot 4 kh + r16 of slot tile m, in the lanes r16 < 4
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
             float part[4] = {0.f, 0.f, 0.f, 0.f};
             if (k < Kc) {
                 const float* erow = stage + ROWS * (2 + k) + r16;
@@ -429,23 +432,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) part[e] = dfol_group_sum<16>(part[e]);
-            if (r16 < 4) {
-                const float v = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
-                const int ee = tb * SLOTS + wave * (MT * 16) + m * 16 + 4 * kh + r16;
-                if (ee < npairs) {
-                    // ee / (n - 1) without the integer-division sequence: (ee + 0.5) / (n - 1) is at least 0.5 / (n - 1) away from an integer
-                    const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)(n - 1))), op = ee - ss * (n - 1), oo = op + (op >= ss);
-                    const float x = v + (be ? be[col] : 0.f);
-                    const float val = fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid (the diagonal keeps the caller's fill)
-                    const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
-                                       ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
-                    if (TBF16) {
-                        uint32_t u = __float_as_uint(val);
-                        u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even
-                        reinterpret_cast<uint16_t*>(tiles_v)[at] = (uint16_t)(u >> 16);
-                    } else {
-                        reinterpret_cast<float*>(tiles_v)[at] = val;
-                    }
+            vm[m] = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
+        }
+        // One store instruction for the wavefront's 32 slots - consecutive ordered pairs, i.e. mostly consecutive floats of a tile row: the
+        // lanes r16 = 4..7 take the second slot tile's logits from the lanes r16 - 4 (DPP row_shr:4), so a kh group writes slots 4 kh + 0..3
+        // of both tiles.  (One instruction per slot tile wrote two misaligned 64-byte runs: 23 MB of WRITE_SIZE for 10 MB of tiles.)
+        const float shifted = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vm[1]), 0x114, 0xF, 0xF, false));
+        if (r16 < 8) {
+            const int hi = r16 >> 2;
+            const float v = hi ? shifted : vm[0];
+            const int ee = tb * SLOTS + wave * (MT * 16) + hi * 16 + 4 * kh + (r16 & 3);
+            if (ee < npairs) {
+                // ee / (n - 1) without the integer-division sequence: (ee + 0.5) / (n - 1) is at least 0.5 / (n - 1) away from an integer
+                const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)(n - 1))), op = ee - ss * (n - 1), oo = op + (op >= ss);
+                const float x = v + (be ? be[col] : 0.f);
+                const float val = fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid (the diagonal keeps the caller's fill)
+                const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
+                                   ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
+                if (TBF16) {
+                    uint32_t u = __float_as_uint(val);
+                    u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even
+                    reinterpret_cast<uint16_t*>(tiles_v)[at] = (uint16_t)(u >> 16);
+                } else {
+                    reinterpret_cast<float*>(tiles_v)[at] = val;
                 }
             }
         }

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))); sys.path.insert(0, 'tests')
 from dfol_vqa_amd import _lib
 from oracle import dfol_oracle as orc
 for (M, N, K, ldx_extra, act) in [(200, 333, 300, 0, 3), (257, 300, 256, 0, 1), (64, 49, 12, 4, 3)]:

@@ -1,6 +1,6 @@
 """Where do two launches of the fp16x2 pair kernel differ?  (lab; DFOL_LIB selects the build)"""
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from dfol_vqa_amd import _lib as L
 torch.manual_seed(0)
 HID1, HID2, C, K = 256, 300, 333, 1

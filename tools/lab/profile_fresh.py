@@ -1,7 +1,7 @@
 """Where does a fresh-programs batch spend its time?  Per-kernel device time and launch counts over the mixed-program batches of bench.py's
 value_fresh_programs leg (eager), and the host time of the forward.  usage: python tools/lab/profile_fresh.py"""
 import json, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import bench
 from dfol_vqa_amd import _lib as L
 from dfol_vqa_amd import synthetic as syn

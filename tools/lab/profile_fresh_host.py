@@ -1,6 +1,6 @@
 """cProfile of the host side of fresh-program batches (collate -> lower -> eager forward), top functions by cumulative / own time."""
 import cProfile, json, pstats, sys, io, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import bench
 from dfol_vqa_amd import synthetic as syn
 import dfol_vqa_amd as D

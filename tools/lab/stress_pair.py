@@ -1,7 +1,7 @@
 """Repeatability stress of the fp16x2 pair kernel for a library build: N launches at the bench shape and on a ragged batch, every result
 compared bit for bit with the first.  usage: DFOL_LIB=build/lib_x.so python tools/lab/stress_pair.py [launches]"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from dfol_vqa_amd import _lib as L
 n_rep = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 torch.manual_seed(0)

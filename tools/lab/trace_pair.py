@@ -1,7 +1,7 @@
 """Reads the clock64 stamps of a -DDFOL_PAIR_TRACE build of the fp16x2 pair kernel (csrc/dfol_pair_h2.hip) at the bench shape.
 usage: DFOL_LIB=build/lib_h2_trace.so python tools/lab/trace_pair.py"""
 import ctypes, sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from dfol_vqa_amd import _lib as L
 torch.manual_seed(0)
 Q, N, HID1, HID2, C, K = 256, 100, 256, 300, 333, 1

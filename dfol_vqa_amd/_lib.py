@@ -113,6 +113,11 @@ SIGNATURES = {
     "dfol_pair_hidden1_bwd_f32": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_pair_logit_fwd_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i32, _i64, _i64, _p, _p],
     "dfol_pair_logit_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i64, _p, _p],
+    "dfol_pair_logit_bwd_sums_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _p, _i64, _p],
+    "dfol_linear_logit_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
+    "dfol_pair_dz_fused_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    "dfol_pair_wgrad_fused_workspace": [_i64, _i32, _i32],
+    "dfol_pair_wgrad_fused_f32": [_p, _i64, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p],
     "dfol_linear_pack_w_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_split_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_pack_w_bf16": [_p, _i64, _i32, _i32, _p, _p],
@@ -157,6 +162,7 @@ def load():
     lib.dfol_linear_wgrad_workspace.restype = ctypes.c_int64
     lib.dfol_pair_w2_f16x2_bytes.restype = ctypes.c_int64
     lib.dfol_linear_w_f16x2_bytes.restype = ctypes.c_int64
+    lib.dfol_pair_wgrad_fused_workspace.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -783,6 +789,71 @@ def pair_logit_bwd(dx, p2, e_rows, pred_off, need_bias=True):
     call("dfol_pair_logit_bwd_bf16" if p2.dtype == torch.bfloat16 else "dfol_pair_logit_bwd_f32", _ptr(dx, F32), _dp(p2), p2.stride(0), p2.shape[1], _dp(e_rows), e_rows.stride(0),
          _ptr(pred_off, torch.int64), P, _dp(dp2), dp2.stride(0), _dp(de), de.stride(0), _ptr(dbe, F32, True), _stream())
     return dp2, de, dbe
+
+
+def pair_head_fused_supported(hid1, hid2):
+    """Widths the fused head backward takes (csrc/dfol_dense_wgrad.hip, pair_wgrad_fused_kernel: all of dW2 in one workgroup's accumulators)."""
+    return hid1 % 4 == 0 and hid2 % 4 == 0 and 16 <= hid2 <= 320 and 4 <= hid1 <= 256
+
+
+def linear_logit_h2(x, weight, bias, row_pred, e_rows):
+    """(y [M, N] = x @ weight.T + bias, x_part [2 ceil(N / 128), M]) on two fp16 pieces: the second layer of the pair MLP and, from the same
+    pass, the logit layer's partial sums x_part[s][r] = sum over the s-th 64-column half block of Sigmoid(y[r, j]) e_rows[row_pred[r], j]."""
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, dtype=F32, device=x.device)
+    xp = torch.empty(2 * ((N + 127) // 128), M, dtype=F32, device=x.device)
+    call("dfol_linear_logit_h2_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, False, 2), torch.bfloat16), _ptr(bias, F32, True), _dp(y),
+         y.stride(0), M, N, K, _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(xp), xp.stride(0), _stream())
+    return y, xp
+
+
+def pair_head_sums(dx, p2, e_rows, pred_off, need_bias=True):
+    """(dE [P, HID2], dbe [P] or None, dB2 [P, HID2]) of one use of the hidden layer: the sums of the logit layer's backward; dB2's rows add
+    up to the second layer's bias gradient.  dpre2 itself is not written (pair_head_products rebuilds it where it is consumed)."""
+    H2, P = p2.shape[1], e_rows.shape[0]
+    de = torch.empty(P, H2, dtype=F32, device=p2.device)
+    dbe = torch.empty(P, dtype=F32, device=p2.device) if need_bias else None
+    db2p = torch.empty(P, H2, dtype=F32, device=p2.device)
+    call("dfol_pair_logit_bwd_sums_f32", _ptr(dx, F32), _dp(p2), p2.stride(0), H2, _ptr(e_rows, F32), e_rows.stride(0), _ptr(pred_off, torch.int64), P,
+         _ptr(de), de.stride(0), _ptr(dbe, F32, True), _ptr(db2p), db2p.stride(0), _stream())
+    return de, dbe, db2p
+
+
+def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, need_dw=True, dz_out=None):
+    """(dz [M, HID1], dW2 [HID2, HID1]) of one use: dz (+)= dpre2 W2 and dW2 = dpre2^T z with dpre2[r, j] = dx[r] E[row_pred[r], j] h (1 - h),
+    h = Sigmoid(p2[r, j]), produced inside the two kernels.  dz_out: a previous use's dz to add to (in place).  row_pred [M] int32,
+    non-decreasing; pred_off [P + 1] int64."""
+    M, H2 = p2.shape
+    H1 = z.shape[1]
+    dev = p2.device
+    emax = e_rows.abs().amax(1)
+    dz = dw = None
+    if need_dz:
+        dz = dz_out if dz_out is not None else torch.empty(M, H1, dtype=F32, device=dev)
+        call("dfol_pair_dz_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(emax, F32),
+             _ptr(linear_pack_w_split(w2, True, 2), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _stream())
+    if need_dw:
+        # one power of two for the weight gradient's fp16 pieces: S max_r |dx[r]| emax[p(r)] / 4 in [2^13, 2^14) (device-side: no sync)
+        bound = (dx.abs() * emax.index_select(0, row_pred)).amax() * 0.25
+        _, ex = torch.frexp(bound)
+        ok = torch.isfinite(bound) & (bound > 0)
+        sexp = torch.where(ok, (14 - ex).clamp(-100, 100), torch.zeros_like(ex)).to(F32)
+        scale = torch.stack([torch.exp2(sexp), torch.exp2(-sexp)]).contiguous()
+        ws = torch.empty(load().dfol_pair_wgrad_fused_workspace(M, H2, H1), dtype=F32, device=dev)
+        dw = torch.empty(H2, H1, dtype=F32, device=dev)
+        call("dfol_pair_wgrad_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(pred_off, torch.int64), _ptr(e_rows, F32),
+             e_rows.stride(0), _ptr(scale, F32), _dp(z), z.stride(0), M, H2, H1, _ptr(ws), _ptr(dw), _stream())
+    return dz, dw
+
+
+def pair_head_bwd(dx, p2, z, w2, e_rows, pred_off, row_pred, need_bias=True, dz_out=None):
+    """The backward of x = logit(Sigmoid(z W2^T + b2)) for ONE use of the hidden layer, without dpre2 in memory:
+    -> (dz [M, HID1], dW2 [HID2, HID1], db2 [HID2], dE [P, HID2], dbe [P] or None)."""
+    e_rows = e_rows if e_rows.is_contiguous() else e_rows.contiguous()
+    de, dbe, db2p = pair_head_sums(dx, p2, e_rows, pred_off, need_bias)
+    dz, dw = pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, dz_out=dz_out)
+    return dz, dw, db2p.sum(0), de, dbe
 
 
 def capturing():

@@ -35,6 +35,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LS_BM = 128, LS_BN = 128, LS_BK = 32;
+#ifndef LS_DOUBLE_BUFFER
+#define LS_DOUBLE_BUFFER 1
+#endif
 
 __device__ __forceinline__ int ls_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 __device__ __forceinline__ void ls_split(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
@@ -144,6 +147,29 @@ __global__ void linear_pack_w_split_kernel(const float* __restrict__ W, int64_t 
     else out[idx] = u32x4{ls_pack(piece[0], piece[1]), ls_pack(piece[2], piece[3]), ls_pack(piece[4], piece[5]), ls_pack(piece[6], piece[7])};
 }
 
+// PROD (round 4): the A operand is PRODUCED, not loaded - the backward of the pair MLP's logit layer folded into the input-gradient
+// product dZ = dpre2 W2 (csrc/dfol_pair_train.hip, logit_bwd: dpre2[r][j] = dx[r] E[p(r)][j] h (1 - h), h = Sigmoid(pre2[r][j])).  X is
+// pre2; a thread keeps dx[r] and the embedding row of r's predicate for its two rows, loads the row's E pieces beside the X pieces and
+// writes the two fp16 pieces of 2^e_r dpre2 to LDS: dpre2 (3 GB written and read back per train step at 256 x 100 objects) never
+// exists.  e_r puts the row's BOUND |dx[r]| max|E[p]| / 4 into [2^13, 2^14) - gradients have no natural scale, fp16 pieces need one -
+// so an element's error is max(2^-23 |a|, 2^-39 |dx[r]| max|E[p]|); the epilogue multiplies the row by 2^-e_r (exact).
+struct LsProducer {
+    const float* g;                 // dx [M]: gradient of the row's logit
+    const int32_t* row_pred;        // [M]: the row of E the pair row reads (its predicate), or -1: no gradient
+    const float* E;                 // [P, K] embedding rows, 16-byte aligned rows
+    int64_t ld_e;
+    const float* emax;              // [P]: max |E[p][:]|
+    int accumulate;                 // Y += instead of Y = (a second use of the same hidden layer adds its input gradient)
+    // MODE 2 (LOGIT), the forward counterpart: the epilogue ALSO leaves, per row and 64-column half block, the partial sum
+    // sum_j Sigmoid(Y[r][j]) E[row_pred[r]][j] - the logit layer's forward (csrc/dfol_pair_train.hip, logit_fwd) without its pass over Y
+    float* x_part;                  // [2 column blocks of N][ld_xp >= M]
+    int64_t ld_xp;
+};
+__device__ __forceinline__ float ls_dsigmoid(float x) {
+    const float h = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+    return h * (1.0f - h);
+}
+
 template <int ACT>
 __device__ __forceinline__ float ls_act(float x) {
     // branch-free forms on the hardware exp / log / rcp (1 ulp each; absolute error < 2e-7 on these ranges)
@@ -166,11 +192,15 @@ __device__ __forceinline__ float ls_act(float x) {
 // BIO: bf16 storage on both sides (NP = 1 only: the bf16 mode's per-pair activations): X and Y are rows of bfloat16 (8-byte aligned rows,
 // K % 4 == 0); a thread's 8 consecutive k are two 8-byte loads that go to LDS as they are - no conversion - and the epilogue rounds the
 // fp32 accumulators to nearest even.  ldx / ldy count ELEMENTS.
-template <int ACT, int XV, int NT, int NP, int RT, bool BIO>
+template <int ACT, int XV, int NT, int NP, int RT, bool BIO, int MODE = 0>
 __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restrict__ Bs, const void* __restrict__ Xv, int64_t ldx,
                                         const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Yv, int64_t ldy, int M, int N,
-                                        int K, int ksteps, int mb, int nb, int nbn) {
+                                        int K, int ksteps, int mb, int nb, int nbn, const LsProducer& prod = LsProducer(), float* __restrict__ Rs = nullptr) {
     static_assert(!BIO || NP == 1, "bf16 storage belongs to the bf16 mode");
+    constexpr bool PROD = MODE == 1, LOGIT = MODE == 2;
+    constexpr bool DB = LS_DOUBLE_BUFFER && NP == 2 && !BIO;          // two LDS buffers (2 x 32 KB for a 128-row block: still two workgroups per CU)
+    static_assert(!LOGIT || (!BIO && ACT == DFOL_ACT_NONE), "the logit partial sums belong to the fp32 pre-activation output");
+    static_assert(!PROD || (NP == 2 && !BIO && XV == 4 && ACT == DFOL_ACT_NONE), "the produced operand is two fp16 pieces of fp32 rows");
     typedef typename std::conditional<BIO, uint16_t, float>::type TX;
     const TX* __restrict__ X = reinterpret_cast<const TX*>(Xv);
     TX* __restrict__ Y = reinterpret_cast<TX*>(Yv);
@@ -190,11 +220,35 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     const int arow = tid >> 2, aq = tid & 3;
     const TX* xp0 = X + (int64_t)min(m0 + arow, M - 1) * ldx + aq * 8;
     const TX* xp1 = X + (int64_t)min(m0 + arow + 64, M - 1) * ldx + aq * 8;      // (RT = 4 only)
+    float gs[RT / 2];                                                 // PROD: 2^e_r dx[r] of the thread's rows, and their embedding rows
+    const float* ep[RT / 2];
+    if constexpr (PROD) {
+#pragma unroll
+        for (int h = 0; h < RT / 2; ++h) {
+            const int row = m0 + arow + 64 * h, rc = min(row, M - 1);
+            const int p = prod.row_pred[rc];
+            const bool live = row < M && p >= 0;
+            const int pc = max(p, 0);
+            const float gg = live ? prod.g[rc] : 0.f;
+            const float bound = fabsf(gg) * prod.emax[pc] * 0.25f;
+            int e = 0;
+            if (bound > 0.f && bound < 3.0e38f) {
+                int x;
+                (void)frexpf(bound, &x);
+                e = 14 - x;
+                e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            }
+            gs[h] = ldexpf(gg, e);
+            ep[h] = prod.E + (int64_t)pc * prod.ld_e + aq * 8;
+            if (aq == 0) Rs[arow + 64 * h] = ldexpf(1.0f, -e);        // read by the epilogue, many barriers later
+        }
+    }
     // X registers: two steps in flight (HBM latency is longer than one step of 96 MFMAs).  The loads are unconditional - addresses
     // clamped, out-of-range k zeroed afterwards - so that every wavefront issues exactly 4 per step and the vmcnt arithmetic below holds.
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef typename std::conditional<BIO, u32x2, float4>::type XR;  // four consecutive k of a row as loaded
     XR xa[2][RH][2];                                                // [set = step parity][row half][k half]
+    float4 ea[PROD ? RH : 1][2];                                    // PROD: the same pieces of the rows' embedding rows - L2 hits, ONE step ahead
     auto load_x = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
@@ -215,20 +269,39 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
             xa[S][1][1] = ld4(xp1 + c1);
         }
     };
-    auto store_a = [&](int ks, auto set_tag) __attribute__((always_inline)) {
+    auto load_e = [&](int ks) __attribute__((always_inline)) {
+        if constexpr (PROD) {
+            const int k = ks * LS_BK + aq * 8;
+            const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;
+#pragma unroll
+            for (int h = 0; h < RH; ++h) {
+                ea[h][0] = *reinterpret_cast<const float4*>(ep[h] + c0);
+                ea[h][1] = *reinterpret_cast<const float4*>(ep[h] + c1);
+            }
+        }
+    };
+    auto store_a = [&](int ks, auto set_tag, int off = 0) __attribute__((always_inline)) {     // off: the LDS buffer (double-buffered form)
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
 #pragma unroll
         for (int h = 0; h < RH; ++h) {
             const int row = arow + 64 * h;
-            const int at = row * 4 + (aq ^ ls_swz(row));
+            const int at = off + row * 4 + (aq ^ ls_swz(row));
             if constexpr (BIO) {
                 const u32x2 zz = u32x2{0u, 0u};
                 const u32x2 v0 = k < K ? xa[S][h][0] : zz, v1 = k + 4 < K ? xa[S][h][1] : zz;
                 As[at] = u32x4{v0.x, v0.y, v1.x, v1.y};
             } else {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
+                float4 v0 = k < K ? xa[S][h][0] : z, v1 = k + 4 < K ? xa[S][h][1] : z;
+                if constexpr (PROD) {
+                    auto dp = [&](const float4& x, const float4& e) __attribute__((always_inline)) {
+                        return make_float4((gs[h] * e.x) * ls_dsigmoid(x.x), (gs[h] * e.y) * ls_dsigmoid(x.y), (gs[h] * e.z) * ls_dsigmoid(x.z),
+                                           (gs[h] * e.w) * ls_dsigmoid(x.w));
+                    };
+                    v0 = k < K ? dp(xa[S][h][0], ea[h][0]) : z;
+                    v1 = k + 4 < K ? dp(xa[S][h][1], ea[h][1]) : z;
+                }
                 if (NP == 1) {
                     As[at] = u32x4{ls_rne2(v0.x, v0.y), ls_rne2(v0.z, v0.w), ls_rne2(v1.x, v1.y), ls_rne2(v1.z, v1.w)};
                 } else if (NP == 2) {
@@ -258,9 +331,9 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 #pragma unroll
         for (int i = 0; i < TILE_PIECES / 256; ++i) wb[i] = wtile[(int64_t)ks * TILE_PIECES + 256 * i + tid];
     };
-    auto store_b = [&]() __attribute__((always_inline)) {
+    auto store_b = [&](int off = 0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TILE_PIECES / 256; ++i) Bs[256 * i + tid] = wb[i];
+        for (int i = 0; i < TILE_PIECES / 256; ++i) Bs[off + 256 * i + tid] = wb[i];
     };
 
     const int aoff = (wm * (16 * RT) + r16) * 4 + (kh ^ ls_swz(r16));
@@ -270,6 +343,38 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     constexpr int X0 = NP == 1 ? 5 : 0;                               // the bf16 mode keeps the last product only (piece 0 x piece 0)
     constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};             // NP = 2: xl wh, xh wl, xh wh (smallest first)
     typedef typename std::conditional<NP == 2, f16x8, bf16x8>::type FR;
+    auto multiply = [&](int off) __attribute__((always_inline)) {  // the step's MFMAs on the tiles of LDS buffer `off`
+#pragma unroll
+        for (int ih = 0; ih < RT; ih += 2) {                // two row tiles at a time (register budget)
+            FR a[2][NP];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(FR, As[off + p * BM * 4 + (ih + i) * 64 + aoff]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                FR b[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(FR, Bs[off + p * LS_BN * 4 + j * 64 + boff]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (NP == 2) {
+#ifdef LS_SKIP_MM
+                        acc[ih + i][j][0] += (float)(a[i][0][0] + a[i][1][0] + b[0][0] + b[1][0]);
+#else
+#pragma unroll
+                        for (int x = 0; x < 3; ++x)         // three dependent MFMAs per accumulator, smallest terms first
+                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][PA3[x]], b[PB3[x]], acc[ih + i][j], 0, 0, 0);
+#endif
+                    } else {
+#pragma unroll
+                        for (int x = X0; x < 6; ++x)        // six dependent MFMAs per accumulator, smallest terms first
+                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA6[x]], b[PB6[x]], acc[ih + i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
     // Step ks: X(ks) was requested two steps ago, the B tile one step ago, and X(ks+1) after it: vmcnt retires in order, so the
     // wait for the B registers leaves the four loads of X(ks+1) in flight.
     auto step = [&](int ks, auto set_tag, auto has_b, auto has_x) __attribute__((always_inline)) {
@@ -281,34 +386,10 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         __syncthreads();                                    // A pieces and B tile ks visible
         LTRACE(4 * ks + 2);
         if (HAS_B) load_w(ks + 1);
+        if (HAS_B) load_e(ks + 1);                          // (consumed by this step's store_a already: one register set)
         if (HAS_X) load_x(ks + 2, set_tag);
         __builtin_amdgcn_sched_barrier(0);                  // requests first; and the next step's split must not drift up here
-#pragma unroll
-        for (int ih = 0; ih < RT; ih += 2) {                // two row tiles at a time (register budget)
-            FR a[2][NP];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) a[i][p] = __builtin_bit_cast(FR, As[p * BM * 4 + (ih + i) * 64 + aoff]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                FR b[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(FR, Bs[p * LS_BN * 4 + j * 64 + boff]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if constexpr (NP == 2) {
-#pragma unroll
-                        for (int x = 0; x < 3; ++x)         // three dependent MFMAs per accumulator, smallest terms first
-                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][PA3[x]], b[PB3[x]], acc[ih + i][j], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int x = X0; x < 6; ++x)        // six dependent MFMAs per accumulator, smallest terms first
-                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA6[x]], b[PB6[x]], acc[ih + i][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        multiply(0);
         __builtin_amdgcn_sched_barrier(0);                  // (it would wait for X(ks+1) in the middle of the MFMAs)
         LTRACE(4 * ks + 3);
         __syncthreads();                                    // A and B tile ks fully read
@@ -319,16 +400,55 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     const std::integral_constant<int, 1> S1;
     const std::true_type yes;
     const std::false_type no;
+    LTRACE(60);
     load_x(0, S0);
     load_w(0);
+    load_e(0);
     load_x(min(1, ksteps - 1), S1);
     int ks = 0;
+    if constexpr (DB) {
+        // Two LDS buffers, ONE barrier per step: step ks multiplies buffer ks & 1 while the tiles of step ks + 1 are split and written
+        // to the other one - by whichever wavefront gets there, under the MFMAs of the others (the single-buffered form below stops
+        // every wavefront twice per step: 3300 cycles per step of 768 cycles of MFMAs at K = 256 .. 300).  All loads are unconditional
+        // (steps past the end re-read the last one: L2 hits, never used), so the compiler's wait counts stay exact; a store past the
+        // end goes to the buffer nobody reads any more.
+        constexpr int BUF = NP * BM * 4 + NP * LS_BN * 4;
+        const int last = ksteps - 1;
+        store_a(0, S0, 0);
+        store_b(0);
+        load_w(min(1, last));
+        load_e(min(1, last));
+        load_x(min(2, last), S0);
+        __syncthreads();
+        auto body = [&](int k, auto next_tag) __attribute__((always_inline)) {      // k: the step multiplied; next_tag: the X set of step k + 1
+            const int cur = (k & 1) * BUF, nxt = BUF - cur;
+            LTRACE(4 * k);
+            store_a(k + 1, next_tag, nxt);                  // (k + 1 past the end: all columns >= K, zeros)
+            store_b(nxt);
+            load_w(min(k + 2, last));
+            load_e(min(k + 2, last));
+            load_x(min(k + 3, last), next_tag);
+            LTRACE(4 * k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            LTRACE(4 * k + 3);
+            __syncthreads();                                // buffer nxt complete, buffer cur fully read
+        };
+        for (; ks + 1 < ksteps; ks += 2) {
+            body(ks, S1);
+            body(ks + 1, S0);
+        }
+        if (ks < ksteps) body(ks, S1);
+        ks = ksteps;
+    }
     for (; ks + 3 < ksteps; ks += 2) {
         step(ks, S0, yes, yes);
         step(ks + 1, S1, yes, yes);
     }
-    const int rem = ksteps - ks;
-    if (rem == 3) {
+    const int rem = DB ? 0 : ksteps - ks;
+    if (rem == 0) {
+    } else if (rem == 3) {
         step(ks, S0, yes, yes);
         step(ks + 1, S1, yes, no);
         step(ks + 2, S0, no, no);
@@ -340,6 +460,23 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     }
 
     // epilogue: lane holds column r16 and rows 4 kh + e of every 16 x 16 tile.  Interior tiles take the branch-free path.
+    LTRACE(61);
+    // LOGIT: the rows of a block nearly always belong to ONE predicate (row_pred is non-decreasing: a predicate owns n (n - 1) consecutive
+    // rows) - then every thread needs the same few embedding values for all its rows, requested here, ahead of the epilogue's arithmetic;
+    // a block across a boundary looks its rows up one by one.
+    int lg_p0 = -1;
+    bool lg_uni = false;
+    float4 lg_e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lg_ej[NT];
+    if constexpr (LOGIT) {
+        lg_p0 = __builtin_amdgcn_readfirstlane(prod.row_pred[m0]);
+        lg_uni = lg_p0 >= 0 && lg_p0 == __builtin_amdgcn_readfirstlane(prod.row_pred[min(m0 + BM, M) - 1]);
+        if (lg_uni) {
+            if (NT == 4 && n0 + LS_BN <= N) lg_e4 = *reinterpret_cast<const float4*>(prod.E + (int64_t)lg_p0 * prod.ld_e + n0 + 4 * (tid & 31));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) lg_ej[j] = prod.E[(int64_t)lg_p0 * prod.ld_e + min(n0 + wn * WN + j * 16 + r16, N - 1)];
+        }
+    }
     float bv[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[min(n0 + wn * WN + j * 16 + r16, N - 1)] : 0.f;
@@ -353,6 +490,16 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] *= c;
         }
+    }
+    if constexpr (PROD) {                                             // un-scale the produced rows: acc <- acc 2^-e_r (exact)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = Rs[wm * (16 * RT) + i * 16 + 4 * kh + e];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j][e] *= c;
+            }
     }
     if constexpr (BIO) {
         // bf16 output: 2-byte stores straight from the accumulator layout (16 lanes x 2 bytes per row and instruction) cost a third of the
@@ -378,8 +525,78 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         }
         return;
     }
+    if constexpr (!BIO) {
+        // Interior tiles leave through LDS: straight from the accumulator layout a store instruction writes 16 lanes x 4 bytes of four
+        // rows (64 per thread and tile; the stores were a quarter of the tall products' time: 1.96 -> 1.46 ms without them), staged, a
+        // thread stores 16 bytes and 32 consecutive threads one 512-byte row segment.  Two passes of half the block's rows (the loop's
+        // last barrier has freed the operand tiles); rows 132 floats apart: the four row groups of a wavefront land 16 banks apart.
+        const bool interior = NT == 4 && m0 + BM <= M && n0 + LS_BN <= N && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;
+        if (interior) {
+            constexpr int PITCH = LS_BN + 4, IPP = RT / 2;
+            float* stage = reinterpret_cast<float*>(As);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p) __syncthreads();                               // the first pass's rows have been read
+#pragma unroll
+                for (int ii = 0; ii < IPP; ++ii)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            stage[(wm * (16 * IPP) + ii * 16 + 4 * kh + e) * PITCH + wn * WN + j * 16 + r16] = ls_act<ACT>(acc[p * IPP + ii][j][e] + bv[j]);
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 16 * RT * (LS_BN / 4) / 256; ++it) {
+                    const int c = tid + 256 * it, row = c >> 5, c4 = c & 31;
+                    const int half = row / (16 * IPP), within = row - half * (16 * IPP);
+                    float4 v = *reinterpret_cast<const float4*>(stage + row * PITCH + 4 * c4);
+                    float* dst = reinterpret_cast<float*>(Y) + (int64_t)(m0 + half * (16 * RT) + p * (16 * IPP) + within) * ldy + n0 + 4 * c4;
+                    if constexpr (PROD) {
+                        if (prod.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(dst);
+                            v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                        }
+                    }
+                    *reinterpret_cast<float4*>(dst) = v;
+                    if constexpr (LOGIT) {                            // 16 consecutive lanes hold the 64 columns of a half block of one row
+                        const int grow = m0 + half * (16 * RT) + p * (16 * IPP) + within;
+                        float4 e = lg_e4;                             // (c4 = tid & 31 in every trip)
+                        bool live = true;
+                        if (!lg_uni) {
+                            const int pr = prod.row_pred[grow];
+                            live = pr >= 0;
+                            e = *reinterpret_cast<const float4*>(prod.E + (int64_t)max(pr, 0) * prod.ld_e + n0 + 4 * c4);
+                        }
+                        float sum = ls_act<DFOL_ACT_SIGMOID>(v.x) * e.x + ls_act<DFOL_ACT_SIGMOID>(v.y) * e.y + ls_act<DFOL_ACT_SIGMOID>(v.z) * e.z +
+                                    ls_act<DFOL_ACT_SIGMOID>(v.w) * e.w;
+                        sum = live ? sum : 0.f;
+#pragma unroll
+                        for (int sh = 1; sh < 16; sh <<= 1) sum += __shfl_xor(sum, sh, 64);
+                        if ((c4 & 15) == 0) prod.x_part[(int64_t)(2 * nb + (c4 >> 4)) * prod.ld_xp + grow] = sum;
+                    }
+                }
+            }
+            LTRACE(62);
+            return;
+        }
+    }
     TX* yp = Y + (int64_t)(m0 + wm * (16 * RT) + 4 * kh) * ldy + n0 + wn * WN + r16;
     auto out = [](float v) __attribute__((always_inline)) { return v; };
+    if constexpr (PROD) {
+        if (prod.accumulate) {                                        // (rows / columns past the matrix: clamped reads, never stored)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t r = min(m0 + wm * (16 * RT) + i * 16 + 4 * kh + e, M - 1);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][e] += Y[r * ldy + min(n0 + wn * WN + j * 16 + r16, N - 1)];
+                }
+        }
+    }
+#ifdef LS_SKIP_ST
+    if (acc[0][0][0] == 1.2345e-30f)
+#endif
     if (NT == 4 && m0 + BM <= M && n0 + LS_BN <= N) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -400,6 +617,30 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                 }
             }
     }
+    if constexpr (LOGIT) {                                            // (edge tiles: straight from the accumulator layout; columns past N add nothing)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int grow = m0 + wm * (16 * RT) + i * 16 + 4 * kh + e;
+                const int pr = lg_uni ? lg_p0 : (grow < M ? prod.row_pred[grow] : -1);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = n0 + wn * WN + j * 16 + r16;
+                    if (pr >= 0 && col < N)
+                        sum += ls_act<DFOL_ACT_SIGMOID>(acc[i][j][e] + bv[j]) * (lg_uni ? lg_ej[j] : prod.E[(int64_t)pr * prod.ld_e + col]);
+                }
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) sum += __shfl_xor(sum, sh, 64);
+                // (a 64-row, two-tile wavefront covers 32 columns: its partial goes to the half block its columns lie in; NT = 2 only in the last block)
+                if (r16 == 0 && grow < M) {
+                    if (NT == 4) prod.x_part[(int64_t)(2 * nb + wn) * prod.ld_xp + grow] = sum;
+                    else prod.x_part[(int64_t)(2 * nb + wn) * prod.ld_xp + grow] = sum;
+                }
+            }
+    }
+    LTRACE(62);
 }
 
 #ifndef DFOL_BIO_WAVES
@@ -408,23 +649,28 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 // (bf16 storage: a tile of K = 256 is 8 steps of 16 MFMAs per wavefront, so the two ends of a tile - cold start, stores - outweigh its
 // steps; the one-piece tiles are 16 KB of LDS and the lighter register set fits three workgroups per CU.  Measured at 256 x 100 objects,
 // forward / input-gradient product: 2 per CU 1.23 / 1.10 ms, 3 per CU 1.13 / 1.09 ms, 4 per CU (128 registers: 88 spilled) 1.26 / 1.56 ms)
-template <int ACT, int XV, int NP, int RT, bool BIO = false>
+template <int ACT, int XV, int NP, int RT, bool BIO = false, int MODE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIO ? DFOL_BIO_WAVES : 2, BIO ? DFOL_BIO_WAVES : (RT == 2 ? 3 : 2)))) void linear_act_split_kernel(
     const void* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Y,
-    int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks) {
+    int64_t ldy, int M, int N, int K, int ksteps, int nbn, int nblocks, LsProducer prod) {
     constexpr int LP = BIO ? 1 : (NP == 2 ? 2 : 3);                         // (the bf16 mode's fp32-storage kernels keep the 48 KB of NP = 3: same occupancy as before)
     constexpr int A_PIECES = LP * 32 * RT * 4, B_PIECES = LP * LS_BN * 4;   // [piece][row][k-group] 24 KB (12 KB for 64-row blocks); the B tile of the step 24 KB
-    constexpr int STAGE_PIECES = BIO ? 32 * RT * (LS_BN + 8) * 2 / 16 : 0;  // bf16 storage: the output tile staged for its stores (34 KB / 17 KB)
-    __shared__ __attribute__((aligned(16))) u32x4 Sm[A_PIECES + B_PIECES > STAGE_PIECES ? A_PIECES + B_PIECES : STAGE_PIECES];
+    // the output tile staged for its stores: bf16 storage 34 KB / 17 KB; fp32: half the block's rows, 132 floats apart (33 KB / 16.5 KB)
+    constexpr int STAGE_PIECES = BIO ? 32 * RT * (LS_BN + 8) * 2 / 16 : 16 * RT * (LS_BN + 4) * 4 / 16;
+    constexpr int R_PIECES = MODE == 1 ? 32 * RT / 4 : 0;                   // PROD: 2^-e_r of the block's rows
+    constexpr int AB_PIECES = (LS_DOUBLE_BUFFER && NP == 2 && !BIO ? 2 : 1) * (A_PIECES + B_PIECES);
+    constexpr int T_PIECES = AB_PIECES > STAGE_PIECES ? AB_PIECES : STAGE_PIECES;
+    __shared__ __attribute__((aligned(16))) u32x4 Sm[T_PIECES + R_PIECES];
     u32x4* As = Sm;
     u32x4* Bs = Sm + A_PIECES;
+    float* Rs = reinterpret_cast<float*>(Sm + T_PIECES);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so id % 8 is the XCD; give each XCD a contiguous run of
     // logical tiles (column blocks of a row block are consecutive): the X rows are fetched into that XCD's L2 once
     int bid = blockIdx.x;
     if (nblocks % 8 == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     const int mb = bid / nbn, nb = bid - mb * nbn;
-    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb, nbn);
-    else ls_tile<ACT, XV, 2, NP, RT, BIO>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb, nbn);
+    if (N - nb * LS_BN > 64) ls_tile<ACT, XV, 4, NP, RT, BIO, MODE>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb, nbn, prod, Rs);
+    else ls_tile<ACT, XV, 2, NP, RT, BIO, MODE>(As, Bs, X, ldx, Wp, bias, Y, ldy, M, N, K, ksteps, mb, nb, nbn, prod, Rs);
 }
 
 }  // namespace
@@ -492,7 +738,7 @@ static int ls_launch_rows(const float* X, int64_t ldx, const void* W_split, cons
     const int nblocks = nbm * nbn;
 #define DFOL_LS_K(A, XVV, RTT)                                                                                                              \
     hipLaunchKernelGGL((linear_act_split_kernel<A, XVV, NP, RTT>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, \
-                       bias, Y, ldy, M, N, K, ksteps, nbn, nblocks)
+                       bias, Y, ldy, M, N, K, ksteps, nbn, nblocks, LsProducer())
 #define DFOL_LS(A)                                                                                                                          \
     if (x16) { if (small) DFOL_LS_K(A, 4, 2); else DFOL_LS_K(A, 4, 4); }                                                                    \
     else { if (small) DFOL_LS_K(A, 2, 2); else DFOL_LS_K(A, 2, 4); }
@@ -540,9 +786,9 @@ extern "C" int dfol_linear_act_bf16_bf16(const void* X_bf16, int64_t ldx, const 
     const int nblocks = nbm * nbn;
 #define DFOL_LSB(A)                                                                                                                             \
     if (small) hipLaunchKernelGGL((linear_act_split_kernel<A, 4, 1, 2, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X_bf16, ldx,  \
-                                  (const u32x4*)W_bf16, bias, Y_bf16, ldy, M, N, K, ksteps, nbn, nblocks);                                      \
+                                  (const u32x4*)W_bf16, bias, Y_bf16, ldy, M, N, K, ksteps, nbn, nblocks, LsProducer());                        \
     else hipLaunchKernelGGL((linear_act_split_kernel<A, 4, 1, 4, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X_bf16, ldx,        \
-                            (const u32x4*)W_bf16, bias, Y_bf16, ldy, M, N, K, ksteps, nbn, nblocks)
+                            (const u32x4*)W_bf16, bias, Y_bf16, ldy, M, N, K, ksteps, nbn, nblocks, LsProducer())
     switch (act) {
         case DFOL_ACT_NONE: DFOL_LSB(DFOL_ACT_NONE); break;
         case DFOL_ACT_SIGMOID: DFOL_LSB(DFOL_ACT_SIGMOID); break;
@@ -552,5 +798,63 @@ extern "C" int dfol_linear_act_bf16_bf16(const void* X_bf16, int64_t ldx, const 
     }
 #undef DFOL_LSB
     DFOL_LAUNCH_CHECK("linear_act_bf16_bf16");
+    return 0;
+}
+
+// dZ (+)= dpre2 W2 with dpre2 produced inside the kernel from pre2, dx, the rows' predicates and their embedding rows (see LsProducer):
+// W2t_split = dfol_linear_pack_w_f16x2 of W2^T [H1, H2]; pre2 [M, H2] and E [P, H2] with 16-byte aligned rows (H2 % 4 == 0).
+extern "C" int dfol_pair_dz_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
+                                      const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t H1, int32_t H2,
+                                      int32_t accumulate, void* stream) {
+    DFOL_REQUIRE(M >= 0 && H1 > 0 && H2 > 0 && H2 % 4 == 0 && ld_p2 % 4 == 0 && ld_p2 >= H2 && ld_e % 4 == 0 && ld_e >= H2 && ld_dz >= H1,
+                 "pair_dz_fused: bad sizes M=%d H1=%d H2=%d (H2, row strides: multiples of 4)", M, H1, H2);
+    if (M == 0) return 0;
+    DFOL_REQUIRE(pre2 && dx && row_pred && E && emax && W2t_split && dZ, "pair_dz_fused: null pointer");
+    DFOL_REQUIRE(((uintptr_t)pre2 % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)W2t_split % 16 == 0), "pair_dz_fused: pre2, E and the packed weights must be 16-byte aligned");
+    const int N = H1, K = H2, ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
+    static const int force_bm = getenv("DFOL_DENSE_BM") ? atoi(getenv("DFOL_DENSE_BM")) : 0;
+    // (the producer's temporaries on top of a 128-row block's registers spill - 332 bytes of scratch per lane - and the 128-row blocks are
+    // still the faster ones: 2.15 ms against 2.43 ms at 256 x 100 objects, the weight tile being fetched half as often)
+    const bool small = force_bm ? force_bm == 64 : (int64_t)dfol_cdiv(M, LS_BM) * nbn < 512;
+    const int nbm = dfol_cdiv(M, small ? 64 : LS_BM);
+    DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "pair_dz_fused: too many tiles");
+    const int nblocks = nbm * nbn;
+    const LsProducer prod = {dx, row_pred, E, ld_e, emax, accumulate, nullptr, 0};
+    if (small)
+        hipLaunchKernelGGL((linear_act_split_kernel<DFOL_ACT_NONE, 4, 2, 2, false, 1>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, pre2, ld_p2,
+                           (const u32x4*)W2t_split, (const float*)nullptr, dZ, ld_dz, M, N, K, ksteps, nbn, nblocks, prod);
+    else
+        hipLaunchKernelGGL((linear_act_split_kernel<DFOL_ACT_NONE, 4, 2, 4, false, 1>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, pre2, ld_p2,
+                           (const u32x4*)W2t_split, (const float*)nullptr, dZ, ld_dz, M, N, K, ksteps, nbn, nblocks, prod);
+    DFOL_LAUNCH_CHECK("pair_dz_fused");
+    return 0;
+}
+
+// Y = X W^T + b on two fp16 pieces as dfol_linear_act_h2_f32 (no activation), and the logit layer's forward from the same pass:
+// x_part[s][r], s < 2 ceil(N / 128), = the sum over the s-th 64-column half block of Sigmoid(Y[r][j]) E[row_pred[r]][j] (row_pred < 0: 0).
+// row_pred: NON-DECREASING over the rows (a predicate owns consecutive rows; -1 only before the first predicate's rows).
+// The caller adds the slots of a row (and the predicate's bias).  X 16-byte aligned rows; E [P, N] rows 16-byte aligned.
+extern "C" int dfol_linear_logit_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M,
+                                        int32_t N, int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp,
+                                        void* stream) {
+    DFOL_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && ldy >= N && ld_e % 4 == 0 && ld_e >= N && ld_xp >= M,
+                 "linear_logit_h2: bad sizes M=%d N=%d K=%d (K, ldx, ld_e multiples of 4)", M, N, K);
+    if (M == 0) return 0;
+    DFOL_REQUIRE(X && W_split && Y && row_pred && E && x_part, "linear_logit_h2: null pointer");
+    DFOL_REQUIRE(((uintptr_t)X % 16 == 0) && ((uintptr_t)W_split % 16 == 0) && ((uintptr_t)E % 16 == 0), "linear_logit_h2: X, W_split and E must be 16-byte aligned");
+    const int ksteps = dfol_cdiv(K, LS_BK), nbn = dfol_cdiv(N, LS_BN);
+    static const int force_bm = getenv("DFOL_DENSE_BM") ? atoi(getenv("DFOL_DENSE_BM")) : 0;
+    const bool small = force_bm ? force_bm == 64 : (int64_t)dfol_cdiv(M, LS_BM) * nbn < 512;
+    const int nbm = dfol_cdiv(M, small ? 64 : LS_BM);
+    DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_logit_h2: too many tiles");
+    const int nblocks = nbm * nbn;
+    const LsProducer lg = {nullptr, row_pred, E, ld_e, nullptr, 0, x_part, ld_xp};
+    if (small)
+        hipLaunchKernelGGL((linear_act_split_kernel<DFOL_ACT_NONE, 4, 2, 2, false, 2>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                           (const u32x4*)W_split, bias, Y, ldy, M, N, K, ksteps, nbn, nblocks, lg);
+    else
+        hipLaunchKernelGGL((linear_act_split_kernel<DFOL_ACT_NONE, 4, 2, 4, false, 2>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                           (const u32x4*)W_split, bias, Y, ldy, M, N, K, ksteps, nbn, nblocks, lg);
+    DFOL_LAUNCH_CHECK("linear_logit_h2");
     return 0;
 }

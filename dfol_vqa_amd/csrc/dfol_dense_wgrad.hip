@@ -745,3 +745,334 @@ extern "C" int dfol_linear_wgrad_bias_bf16_bf16(const void* dY_bf16, int64_t ld_
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the pair layer's weight gradient with dpre2 PRODUCED in the kernel (the logit layer's backward folded in, like
+// dfol_pair_dz_fused_f32 does for the input gradient):   dW2[j][c] = sum_r dpre2[r][j] Z[r][c],   db2[j] = sum_r dpre2[r][j],
+// dpre2[r][j] = dx[r] E[p(r)][j] h (1 - h), h = Sigmoid(pre2[r][j]).  pre2 and Z are read ONCE (the bf16x3 kernel above reads Z once per
+// workgroup class and dpre2 - which no longer exists - on top: 1.6 x the algorithmic bytes), and the operands are two fp16 pieces, three
+// products on v_mfma_f32_32x32x16_f16 instead of six bf16 ones.
+//
+// One workgroup (8 wavefronts, two per SIMD) per row slab, ALL of dW2 in its accumulators: wavefront (a, b) owns the 5 x 2 tiles of 32 x 32
+// at rows 160 a .. and columns 64 b .. (160 accumulator registers), H2 <= 320, H1 <= 256.  The operands go through LDS: per macro step of
+// 32 rows, thread (column quad c, row octet o) loads the four columns of its eight rows (plain 16-byte loads), builds dpre2 resp. takes Z,
+// splits into fp16 pieces and writes, per column, the 16-byte MFMA operand entry (eight consecutive rows = eight consecutive k of the
+// MFMA) of both pieces; every wavefront then reads its tiles' entries (conflict-free ds_read_b128).  Two LDS buffers (2 x 72 KB), one
+// barrier per macro step; the next macro step's rows are in flight under the MFMAs.
+// A row's gradient has no natural scale and the contraction runs over the rows, so ONE power of two S for the whole launch (from the
+// caller: S max_r |dx[r]| max|E[p(r)]| / 4 in [2^13, 2^14)) scales dpre2 into fp16's range: an element's error is
+// max(2^-23 |a|, 2^-39 max_r(|dx[r]| max|E[p(r)]|)) - rows that far below the largest do not move the sum.  Z is split unscaled (ELU outputs).
+typedef _Float16 pw_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pw_f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PW_TA = 10, PW_TB = 8;                                   // 32-wide tiles of H2 (<= 320) and of H1 (<= 256)
+constexpr int PW_A_ENT = 2 * 2 * PW_TA * 64, PW_B_ENT = 2 * 2 * PW_TB * 64;   // 16-byte entries per buffer: [k-step][piece][tile][lane]
+constexpr int PW_BUF = PW_A_ENT + PW_B_ENT;
+
+__device__ __forceinline__ void pw_split2(float x0, float x1, uint32_t& h, uint32_t& l) {
+    const w3_f32x2 x = {x0, x1};
+    const pw_f16x2 hh = __builtin_convertvector(x, pw_f16x2);
+    const w3_f32x2 r = x - __builtin_convertvector(hh, w3_f32x2);
+    h = __builtin_bit_cast(uint32_t, hh);
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, pw_f16x2));
+}
+__device__ __forceinline__ void pw_split8(const float (&v)[8], w3_u32x4& h, w3_u32x4& l) {
+    uint32_t hh[4], ll[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pw_split2(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+    h = w3_u32x4{hh[0], hh[1], hh[2], hh[3]};
+    l = w3_u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
+__device__ __forceinline__ float pw_dsigmoid(float x) {
+    const float h = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+    return h * (1.0f - h);
+}
+
+// CPT: columns of dpre2 per thread - 3 when H2 is a multiple of 3 (HID2 = 300: 100 x 4 = 400 building threads with 24 prefetched registers
+// each; with 4 - 300 threads, 32 registers - the allocator runs out under the MFMAs and spills a prefetched row right behind its load).
+//
+// Schedule (second version; the first ran "build all of step s, barrier, multiply step s" and took the SUM of the two phases - 1.2 ms
+// + 0.77 ms at 256 x 100 objects - because every wavefront of the CU was in the same phase): the MFMAs of step s are interleaved, in
+// the instruction stream of every wavefront, with the building of step s + 1 into the other LDS buffer - two 32 x 32 tile rows of MFMAs
+// (12 instructions, 384 cycles of pipe), then one chunk of vector work (a pair of dpre2 rows, or the Z columns), and so on - so the
+// SIMD's two wavefronts find each other's gaps.  A pair of rows leaves for LDS as soon as it is built (4-byte pieces of the 16-byte
+// operand entries) and its registers are refilled at once with the same rows of step s + 2: one register set is both the prefetch ring
+// and the work space.
+typedef uint32_t w3_u32x3 __attribute__((ext_vector_type(3)));
+template <int CPT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_wgrad_fused_kernel(
+    const float* __restrict__ P2, int64_t ld_p2, const float* __restrict__ G, const int32_t* __restrict__ RP, const int64_t* __restrict__ pred_off,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ scale, const float* __restrict__ Z, int64_t ld_z, int M, int H2, int H1,
+    int rows_per_slab, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) w3_u32x4 pw_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m_begin = blockIdx.x * rows_per_slab, m_end = min(M, m_begin + rows_per_slab);
+    const int steps = (m_end - m_begin + 31) >> 5;
+    const int QA = H2 / CPT, QB = H1 >> 1;
+    const float S = scale[0], invS = scale[1];
+
+    // Roles per macro step of 32 rows.  dpre2: thread (column group ca, row octet oa) for tid < 4 QA - eight rows x CPT columns, the
+    // expensive part (a Sigmoid derivative per element).  Z: thread (column pair cz, row octet oz) for tid < 4 QB - eight rows x two columns.
+    const bool is_a = tid < 4 * QA;
+    const int ca = is_a ? tid % QA : 0, oa = is_a ? tid / QA : 0;
+    const bool is_z = tid < 4 * QB;
+    const int cz = is_z ? tid % QB : 0, oz = is_z ? tid / QB : 0;
+
+    for (int i = tid; i < 2 * PW_BUF; i += 512) pw_lds[i] = w3_u32x4{0u, 0u, 0u, 0u};      // (columns past the matrices stay zero for good)
+
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+    // The rows of a macro step come through buffer descriptors rebuilt per step from wave-uniform values (base = the step's first row,
+    // size = what is left of the slab), with per-lane byte offsets that never change and the row within the octet as the scalar offset:
+    // no 64-bit address arithmetic on the vector ALU, and rows past the slab read as zero (dx = 0 switches such a row off).
+    typename std::conditional<CPT == 3, w3_u32x3, w3_u32x4>::type xa[8];
+    w3_u32x2 xz[8];
+    // The predicate of the step's first row and the row its range ends at, wave-uniform (the rows of a predicate are contiguous and
+    // row_pred is non-decreasing): an octet that ends before that row reads the predicate's embedding columns through a uniform base; the
+    // few octets at a boundary look their rows up one by one.
+    int p_cur = 0, end_cur = 0;                                        // (M < 2^31)
+    if (steps > 0) {
+        p_cur = __builtin_amdgcn_readfirstlane(RP[m_begin]);
+        end_cur = __builtin_amdgcn_readfirstlane((int)pred_off[p_cur + 1]);
+    }
+    // The thread's constants (byte offsets of its loads, its columns) live in LDS and are re-read where they are used: registers that would
+    // otherwise sit idle under the MFMAs, where accumulators + operand fragments + the row ring fill the 256 of a wavefront.
+    int* cst = reinterpret_cast<int*>(pw_lds + 2 * PW_BUF) + tid;      // [6][512]
+    const int rs_p = (int)(ld_p2 * 4), rs_z = (int)(ld_z * 4);
+    // the 16-byte LDS entry of column `col` (tile col >> 5, row col & 31 of the MFMA operand) for the eight rows of octet o
+    auto entry = [&](int col, int o, int tiles) __attribute__((always_inline)) { return ((o >> 1) * 2 * tiles + (col >> 5)) * 64 + (col & 31) + 32 * (o & 1); };
+    cst[0] = (int)((8 * oa * ld_p2 + CPT * ca) * 4);                   // voff_a
+    cst[512] = (int)((8 * oz * ld_z + 2 * cz) * 4);                    // voff_z
+    cst[1024] = 8 * oa * 4;                                            // goff
+    cst[1536] = CPT * ca;                                              // the thread's first column of dpre2
+    cst[2048] = PW_A_ENT + entry(2 * cz, oz, PW_TB);                   // the entry of the thread's first Z column (the second: + 1)
+    cst[2560] = oa;
+
+    struct Desc { __amdgpu_buffer_rsrc_t p, z, g; };
+    auto descriptors = [&](int s) __attribute__((always_inline)) {     // step s (past the slab: empty ranges, every load returns zero)
+        const int first = m_begin + 32 * s, left = max(m_end - first, 0);
+        Desc d;
+        d.p = w3_descriptor(P2 + (int64_t)first * ld_p2, left > 0 ? ((int64_t)(left - 1) * ld_p2 + H2) * 4 : 0);
+        d.z = w3_descriptor(Z + (int64_t)first * ld_z, left > 0 ? ((int64_t)(left - 1) * ld_z + H1) * 4 : 0);
+        d.g = w3_descriptor(G + first, (int64_t)left * 4);
+        return d;
+    };
+    auto load_a = [&](const Desc& d, int i) __attribute__((always_inline)) {           // row i of the thread's octet
+        const int voff_a = cst[0];
+        if constexpr (CPT == 3) xa[i] = __builtin_amdgcn_raw_buffer_load_b96(d.p, voff_a, i * rs_p, 0);
+        else xa[i] = __builtin_amdgcn_raw_buffer_load_b128(d.p, voff_a, i * rs_p, 0);
+    };
+    auto load_z = [&](const Desc& d) __attribute__((always_inline)) {
+        const int voff_z = cst[512];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xz[i] = __builtin_amdgcn_raw_buffer_load_b64(d.z, voff_z, i * rs_z, 0);
+    };
+
+    // ---- building step s (its rows are in xa / xz) into `buf`, a chunk at a time; `next`: the descriptors of step s + 1, whose rows refill
+    // the registers as they are released
+    bool same = false;
+    float ev[CPT];
+    w3_u32x2 gq;                                                       // dx of the row pair that comes next
+    auto begin_a = [&](int s, const Desc& d) __attribute__((always_inline)) {          // before the first pair of rows
+        if (is_a) {
+            const int goff = cst[1024], col0 = cst[1536];
+            const int first = m_begin + 32 * s + (goff >> 2);         // the octet's first row
+            same = first + 7 < m_end && first + 7 < end_cur;          // (all eight rows exist and belong to p_cur)
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) ev[t] = 0.f;
+            if (same) {
+#pragma unroll
+                for (int t = 0; t < CPT; ++t) ev[t] = E[(int64_t)p_cur * ld_e + col0 + t];
+            }
+            gq = __builtin_amdgcn_raw_buffer_load_b64(d.g, goff, 0, 0);
+        }
+    };
+    auto pair_a = [&](int s, int k, const Desc& d, const Desc& next, uint32_t* __restrict__ buf32) __attribute__((always_inline)) {   // rows 2 k, 2 k + 1
+        if (is_a) {
+            const int goff = cst[1024], col0 = cst[1536], o = cst[2560];
+            const int first = m_begin + 32 * s + (goff >> 2);
+            float v[2][CPT];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = 2 * k + r;
+                float e[CPT];
+#pragma unroll
+                for (int t = 0; t < CPT; ++t) e[t] = ev[t];
+                if (!same) {                                           // (an octet across two predicates, or cut by the slab's end)
+                    const float* er = E + (int64_t)RP[min(first + i, m_end - 1)] * ld_e + col0;
+#pragma unroll
+                    for (int t = 0; t < CPT; ++t) e[t] = er[t];
+                }
+                const float gs = __uint_as_float(gq[r]) * S;          // (rows past the slab were read as zero)
+#pragma unroll
+#ifndef PW_SKIP_SG
+                for (int t = 0; t < CPT; ++t) v[r][t] = (gs * e[t]) * pw_dsigmoid(__uint_as_float(xa[i][t]));
+#else
+                for (int t = 0; t < CPT; ++t) v[r][t] = (gs * e[t]) * __uint_as_float(xa[i][t]);
+#endif
+            }
+            if (k < 3) gq = __builtin_amdgcn_raw_buffer_load_b64(d.g, goff, 8 * (k + 1), 0);
+            load_a(next, 2 * k);                                       // the same rows of the next step: in flight for a whole step
+            load_a(next, 2 * k + 1);
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) {
+                uint32_t h, l;
+                pw_split2(v[0][t], v[1][t], h, l);
+                const int at = entry(col0 + t, o, PW_TA) * 4 + k;      // 4-byte piece k of the entry: rows 2 k, 2 k + 1
+#ifndef PW_SKIP_AW
+                buf32[at] = h;
+                buf32[at + PW_TA * 64 * 4] = l;
+#else
+                if (h == 0x12345678u) buf32[at] = h + l;
+#endif
+            }
+        }
+    };
+    auto columns_z = [&](const Desc& next, w3_u32x4* __restrict__ buf) __attribute__((always_inline)) {
+        if (is_z) {
+            const int at = cst[2048];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(xz[i][c]);
+                w3_u32x4 h, l;
+                pw_split8(v, h, l);
+                buf[at + c] = h;
+                buf[at + c + PW_TB * 64] = l;
+            }
+            load_z(next);
+        }
+    };
+    const int ta0 = 5 * (wave >> 2), tb0 = 2 * (wave & 3);
+    // one tile row of the step's MFMAs: k-step ks, A tile t against both B tiles (fragments read just before)
+    auto tile_row = [&](const w3_u32x4* __restrict__ buf, int ks, int t) __attribute__((always_inline)) {
+        const w3_u32x4* Ab = buf + ks * 2 * PW_TA * 64 + lane;
+        const w3_u32x4* Bb = buf + PW_A_ENT + ks * 2 * PW_TB * 64 + lane;
+        const pw_f16x8 ah = __builtin_bit_cast(pw_f16x8, Ab[(ta0 + t) * 64]), al = __builtin_bit_cast(pw_f16x8, Ab[(PW_TA + ta0 + t) * 64]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                                  // smallest terms first
+            const pw_f16x8 bh = __builtin_bit_cast(pw_f16x8, Bb[(tb0 + u) * 64]), bl = __builtin_bit_cast(pw_f16x8, Bb[(PW_TB + tb0 + u) * 64]);
+#ifndef PW_SKIP_MM
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][u], 0, 0, 0);
+#else
+            acc[t][u][0] += (float)(al[0] + bh[0] + ah[0] + bl[0]);
+#endif
+        }
+    };
+    auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+    // prologue: step 0 is built on its own (nothing to multiply yet); its chunks already refill the ring with step 1
+    if (steps > 0) {
+        const Desc d0 = descriptors(0), d1 = descriptors(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (is_a) load_a(d0, i);
+        if (is_z) load_z(d0);
+        __syncthreads();                                               // the zeroed buffers
+        begin_a(0, d0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pair_a(0, k, d0, d1, reinterpret_cast<uint32_t*>(pw_lds));
+        columns_z(d1, pw_lds);
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const w3_u32x4* cur = pw_lds + (s & 1) * PW_BUF;
+        w3_u32x4* nxt = pw_lds + ((s + 1) & 1) * PW_BUF;
+        uint32_t* nxt32 = reinterpret_cast<uint32_t*>(nxt);
+        const bool more = s + 1 < steps;                               // (uniform) is there a step s + 1 to build
+        while (more && m_begin + 32 * (s + 1) >= end_cur) {            // (scalar; predicates without rows are stepped over)
+            ++p_cur;
+            end_cur = __builtin_amdgcn_readfirstlane((int)pred_off[p_cur + 1]);
+        }
+        const Desc d1 = descriptors(s + 1), d2 = descriptors(s + 2);
+        if (more) begin_a(s + 1, d1);
+        fence();
+        tile_row(cur, 0, 0); tile_row(cur, 0, 1);
+        fence();
+        if (more) pair_a(s + 1, 0, d1, d2, nxt32);
+        fence();
+        tile_row(cur, 0, 2); tile_row(cur, 0, 3);
+        fence();
+        if (more) pair_a(s + 1, 1, d1, d2, nxt32);
+        fence();
+        tile_row(cur, 0, 4); tile_row(cur, 1, 0);
+        fence();
+        if (more) pair_a(s + 1, 2, d1, d2, nxt32);
+        fence();
+        tile_row(cur, 1, 1); tile_row(cur, 1, 2);
+        fence();
+        if (more) pair_a(s + 1, 3, d1, d2, nxt32);
+        fence();
+        tile_row(cur, 1, 3);
+        fence();
+        if (more) columns_z(d2, nxt);
+        fence();
+        tile_row(cur, 1, 4);
+        fence();
+        __syncthreads();                                               // step s + 1 is complete in LDS; everyone is past the MFMAs of step s
+    }
+
+    // D tile: column j = lane & 31, row i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int64_t stride = (((int64_t)H2 * H1) + 3) & ~(int64_t)3;
+    float* out = part + (int64_t)blockIdx.x * stride;
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = 32 * (tb0 + u) + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = 32 * (ta0 + t) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (n < H2 && k < H1) out[(int64_t)n * H1 + k] = acc[t][u][i] * invS;
+            }
+        }
+}
+
+static int pw_slabs(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, (M + 255) / 256)); }
+
+extern "C" int64_t dfol_pair_wgrad_fused_workspace(int64_t M, int32_t H2, int32_t H1) {
+    if (M <= 0 || H2 <= 0 || H1 <= 0) return 0;
+    return (int64_t)pw_slabs(M) * ((((int64_t)H2 * H1) + 3) & ~(int64_t)3);
+}
+
+// scale: device pointer to {S, 1 / S}, S a power of two with S max_r(|dx[r]| max|E[row_pred[r]]|) / 4 <= 2^14 (see above)
+// row_pred [M]: NON-DECREASING valid rows of E (the pair rows of a predicate are contiguous), pred_off [P + 1]: the first pair row of every
+// predicate (row_pred[r] = p for pred_off[p] <= r < pred_off[p + 1], pred_off[P] = M); a row without a gradient carries dx = 0.
+// (The bias gradient db2 - the column sums of dpre2 - comes from dfol_pair_logit_bwd_f32's db2 output: that kernel has the registers for it.)
+extern "C" int dfol_pair_wgrad_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off,
+                                         const float* E, int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t H2,
+                                         int32_t H1, float* workspace, float* dW, void* stream) {
+    DFOL_REQUIRE(M > 0 && M < (1ll << 31) - 64 && H2 >= 4 && H1 >= 4 && H2 % 4 == 0 && H1 % 4 == 0 && H2 <= 32 * PW_TA && H1 <= 32 * PW_TB,
+                 "pair_wgrad_fused: bad sizes M=%lld H2=%d H1=%d (multiples of 4, H2 <= %d, H1 <= %d)", (long long)M, H2, H1, 32 * PW_TA, 32 * PW_TB);
+    DFOL_REQUIRE(pre2 && dx && row_pred && pred_off && E && scale && Z && workspace && dW, "pair_wgrad_fused: null pointer");
+    DFOL_REQUIRE(ld_p2 % 4 == 0 && ld_z % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)pre2 % 16 == 0) && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)E % 16 == 0),
+                 "pair_wgrad_fused: rows of pre2, Z and E must be 16-byte aligned");
+    DFOL_REQUIRE(8 * std::max(ld_p2, ld_z) * 4 * 4 < (1ll << 31), "pair_wgrad_fused: row stride too large (%lld)", (long long)std::max(ld_p2, ld_z));
+    const int slabs = pw_slabs(M);
+    const int rows_per_slab = (dfol_cdiv(M, slabs) + 31) & ~31;
+    const size_t lds = (size_t)2 * PW_BUF * 16 + 6 * 512 * 4;
+    static const hipError_t lds_ok3 = hipFuncSetAttribute((const void*)pair_wgrad_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)pair_wgrad_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DFOL_REQUIRE(lds_ok == hipSuccess && lds_ok3 == hipSuccess, "pair_wgrad_fused: cannot reserve %zu bytes of LDS (%s)", lds, hipGetErrorString(lds_ok));
+    const int64_t elems = (int64_t)H2 * H1;
+    hipStream_t st = (hipStream_t)stream;
+    if (H2 % 3 == 0)                                                   // (4 (H2 / 3) <= 427 threads build dpre2)
+        hipLaunchKernelGGL(pair_wgrad_fused_kernel<3>, dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z, ld_z,
+                           (int)M, H2, H1, rows_per_slab, workspace);
+    else
+        hipLaunchKernelGGL(pair_wgrad_fused_kernel<4>, dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z, ld_z,
+                           (int)M, H2, H1, rows_per_slab, workspace);
+    DFOL_LAUNCH_CHECK("pair_wgrad_fused");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 16)), dim3(256), 0, st, workspace, slabs, elems, dW);
+    DFOL_LAUNCH_CHECK("pair_wgrad_fused (reduce)");
+    return 0;
+}

@@ -309,19 +309,21 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __re
                                                                 int H2, const float* __restrict__ E, int64_t ld_e,
                                                                 const int64_t* __restrict__ pred_off, TP* __restrict__ dP2,
                                                                 int64_t ld_dp2, float* __restrict__ dE, int64_t ld_de,
-                                                                float* __restrict__ dbe) {
+                                                                float* __restrict__ dbe, float* __restrict__ dB2, int64_t ld_db2) {
     extern __shared__ __attribute__((aligned(16))) float red4[];           // [RG][H2] floats (+ RG for the bias)
     const int p = blockIdx.x, F4 = H2 >> 2, RG = 1024 / F4, tid = threadIdx.x;
     const int rg = tid / F4, j4 = tid - rg * F4;
     const bool act = rg < RG;
     const int64_t r0 = pred_off[p], r1 = pred_off[p + 1];
     const float4 ev = act ? ld4(E + (int64_t)p * ld_e + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 de = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 de = make_float4(0.f, 0.f, 0.f, 0.f), d2 = make_float4(0.f, 0.f, 0.f, 0.f);
     float db = 0.f;
     auto one = [&](int64_t row, const float4& v, float g) __attribute__((always_inline)) {
         const float h[4] = {pt_sigmoid(v.x), pt_sigmoid(v.y), pt_sigmoid(v.z), pt_sigmoid(v.w)};
-        st4_stream(dP2 + row * ld_dp2 + 4 * j4, make_float4(g * ev.x * h[0] * (1.0f - h[0]), g * ev.y * h[1] * (1.0f - h[1]),
-                                                           g * ev.z * h[2] * (1.0f - h[2]), g * ev.w * h[3] * (1.0f - h[3])));
+        const float4 dp = make_float4(g * ev.x * h[0] * (1.0f - h[0]), g * ev.y * h[1] * (1.0f - h[1]), g * ev.z * h[2] * (1.0f - h[2]),
+                                      g * ev.w * h[3] * (1.0f - h[3]));
+        if (dP2) st4_stream(dP2 + row * ld_dp2 + 4 * j4, dp);          // (null: dpre2 is produced inside the two products that read it)
+        if (dB2) d2.x += dp.x, d2.y += dp.y, d2.z += dp.z, d2.w += dp.w;          // this predicate's part of the second layer's bias gradient
         de.x = fmaf(g, h[0], de.x), de.y = fmaf(g, h[1], de.y), de.z = fmaf(g, h[2], de.z), de.w = fmaf(g, h[3], de.w);
         if (j4 == 0) db += g;
     };
@@ -353,6 +355,16 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd4_kernel(const float* __re
         float acc = 0.f;
         for (int w = 0; w < RG; ++w) acc += red4[RG * H2 + w];
         dbe[p] = acc;
+    }
+    if (dB2) {                                                         // the same fixed-order reduction for the column sums of dpre2
+        __syncthreads();
+        if (act) st4(&red4[rg * H2 + 4 * j4], d2);
+        __syncthreads();
+        for (int j = tid; j < H2; j += 1024) {
+            float acc = 0.f;
+            for (int w = 0; w < RG; ++w) acc += red4[w * H2 + j];
+            dB2[(int64_t)p * ld_db2 + j] = acc;
+        }
     }
 }
 
@@ -389,8 +401,8 @@ __global__ __launch_bounds__(1024) void pair_logit_bwd_kernel(const float* __res
             const int j = lane + 64 * t;
             if (j < H2) {
                 const float ha = pt_sigmoid(va[t]), hb = pt_sigmoid(vb[t]);
-                dP2[row * ld_dp2 + j] = ga * ev[t] * ha * (1.0f - ha);
-                if (has_b) dP2[row_b * ld_dp2 + j] = gb * ev[t] * hb * (1.0f - hb);
+                if (dP2) dP2[row * ld_dp2 + j] = ga * ev[t] * ha * (1.0f - ha);
+                if (dP2 && has_b) dP2[row_b * ld_dp2 + j] = gb * ev[t] * hb * (1.0f - hb);
                 de[t] = fmaf(ga, ha, fmaf(gb, hb, de[t]));
             }
         }
@@ -517,12 +529,12 @@ extern "C" int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t
                                        void* stream) {
     DFOL_REQUIRE(H2 > 0 && H2 <= 64 * LG_T && P >= 0, "pair_logit_bwd: HID2=%d must be <= %d", H2, 64 * LG_T);
     if (P == 0) return 0;
-    DFOL_REQUIRE(dx && P2 && E && pred_off && dP2 && dE, "pair_logit_bwd: null pointer");
+    DFOL_REQUIRE(dx && P2 && E && pred_off && dE, "pair_logit_bwd: null pointer");      // (dP2 null: dE and dbe only)
     if (H2 % 4 == 0 && H2 >= 16 && ld_p2 % 4 == 0 && ld_dp2 % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)P2 % 16 == 0) && ((uintptr_t)dP2 % 16 == 0) &&
         ((uintptr_t)E % 16 == 0)) {
         const int RG = 1024 / (H2 / 4);
         hipLaunchKernelGGL(pair_logit_bwd4_kernel<float>, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx, P2, ld_p2, H2,
-                           E, ld_e, pred_off, dP2, ld_dp2, dE, ld_de, dbe);
+                           E, ld_e, pred_off, dP2, ld_dp2, dE, ld_de, dbe, (float*)nullptr, (int64_t)0);
     } else {
         hipLaunchKernelGGL(pair_logit_bwd_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, dx, P2, ld_p2, H2, E, ld_e, pred_off, dP2, ld_dp2,
                            dE, ld_de, dbe);
@@ -536,12 +548,29 @@ extern "C" int dfol_pair_logit_bwd_bf16(const float* dx, const void* P2_bf16, in
                                         void* stream) {
     DFOL_REQUIRE(P >= 0, "pair_logit_bwd_bf16: bad sizes");
     if (P == 0) return 0;
-    DFOL_REQUIRE(dx && P2_bf16 && E && pred_off && dP2_bf16 && dE, "pair_logit_bwd_bf16: null pointer");
+    DFOL_REQUIRE(dx && P2_bf16 && E && pred_off && dE, "pair_logit_bwd_bf16: null pointer");      // (dP2 null: dE and dbe only)
     DFOL_REQUIRE(logit_bf16_ok(P2_bf16, ld_p2, H2, E, ld_e) && ld_dp2 % 4 == 0 && ((uintptr_t)dP2_bf16 % 8 == 0),
                  "pair_logit_bwd_bf16: HID2=%d must be a multiple of 4 in 16..%d, rows 8-byte aligned", H2, 64 * LG_T);
     const int RG = 1024 / (H2 / 4);
     hipLaunchKernelGGL(pair_logit_bwd4_kernel<pt_bf16>, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx,
-                       (const pt_bf16*)P2_bf16, ld_p2, H2, E, ld_e, pred_off, (pt_bf16*)dP2_bf16, ld_dp2, dE, ld_de, dbe);
+                       (const pt_bf16*)P2_bf16, ld_p2, H2, E, ld_e, pred_off, (pt_bf16*)dP2_bf16, ld_dp2, dE, ld_de, dbe, (float*)nullptr, (int64_t)0);
     DFOL_LAUNCH_CHECK("pair_logit_bwd_bf16");
+    return 0;
+}
+
+// The sums of the logit layer's backward WITHOUT dpre2 (which dfol_pair_dz_fused_f32 and dfol_pair_wgrad_fused_f32 produce on the fly):
+// dE [P, H2], dbe [P] (or NULL) and dB2 [P, H2] = every predicate's column sums of dpre2 (the caller adds the P rows: the second
+// layer's bias gradient).  H2 % 4 == 0, 16-byte aligned rows.
+extern "C" int dfol_pair_logit_bwd_sums_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t H2, const float* E, int64_t ld_e,
+                                            const int64_t* pred_off, int32_t P, float* dE, int64_t ld_de, float* dbe, float* dB2, int64_t ld_db2,
+                                            void* stream) {
+    DFOL_REQUIRE(H2 >= 16 && H2 <= 64 * LG_T && H2 % 4 == 0 && P >= 0, "pair_logit_bwd_sums: HID2=%d must be a multiple of 4 in 16..%d", H2, 64 * LG_T);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(dx && P2 && E && pred_off && dE && dB2, "pair_logit_bwd_sums: null pointer");
+    DFOL_REQUIRE(ld_p2 % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)P2 % 16 == 0) && ((uintptr_t)E % 16 == 0), "pair_logit_bwd_sums: rows of pre2 and E must be 16-byte aligned");
+    const int RG = 1024 / (H2 / 4);
+    hipLaunchKernelGGL(pair_logit_bwd4_kernel<float>, dim3(P), dim3(1024), (size_t)(RG * H2 + RG) * sizeof(float), (hipStream_t)stream, dx, P2, ld_p2, H2, E,
+                       ld_e, pred_off, (float*)nullptr, (int64_t)0, dE, ld_de, dbe, dB2, ld_db2);
+    DFOL_LAUNCH_CHECK("pair_logit_bwd_sums");
     return 0;
 }

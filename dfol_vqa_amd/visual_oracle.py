@@ -300,6 +300,75 @@ class _FusedLogit(torch.autograd.Function):
         return dp2, de, dbe, None, None
 
 
+class _PairTrunk(torch.autograd.Function):
+    """pre2 = z W2^T + b2 for every pair row, as the ROOT of a deferred backward: the logit layers that read pre2 (`_HeadUse`, one per relation
+    operator group) do not send a [pairs, HID2] gradient back through autograd - they leave (dx, embedding rows, row ranges) in `uses` and
+    return a zero for the one-element `token` that ties them to this node.  Autograd runs this backward after all of them, and the two
+    products that consume dpre2 (dz = dpre2 W2, dW2 = dpre2^T z) rebuild it on the fly from pre2 (csrc/dfol_dense_split.hip LsProducer,
+    csrc/dfol_dense_wgrad.hip pair_wgrad_fused_kernel): 3 GB written and 6 GB read less per step at 256 x 100 objects.  A second use adds
+    into the same dz and dW2."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, uses, first):
+        """first: None, or the first reader's (embedding rows [P, HID2] (detached), row -> embedding row [pairs] int32): its logit layer's
+        forward then comes out of the product's epilogue as partial sums [slots, pairs] (no second pass over pre2)."""
+        w = weight.detach()
+        w = w if w.is_contiguous() else w.contiguous()
+        b = None if bias is None else bias.detach()
+        if first is not None and _lib._dense_math() == "f16x2":
+            pre2, x_part = L.linear_logit_h2(z, w, b, first[1], first[0])
+        else:
+            pre2, x_part = L.linear_act_split(z, w, b, L.ACT_NONE), z.new_zeros(0)
+        ctx.save_for_backward(z, weight, pre2)
+        ctx.uses, ctx.has_bias = uses, bias is not None
+        ctx.mark_non_differentiable(pre2, x_part)
+        return pre2, z.new_zeros(1), x_part
+
+    @staticmethod
+    def backward(ctx, _g_pre2, _g_token, _g_part):
+        z, weight, pre2 = ctx.saved_tensors
+        need_dz, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dz = dw = db = None
+        with _lib.dense_math("f16x2"):
+            for dx, e_rows, pred_off, row_pred, db2p in ctx.uses:
+                dz_u, dw_u = L.pair_head_products(dx, pre2, z, weight.detach(), e_rows, pred_off, row_pred, need_dz, need_dw, dz_out=dz)
+                dz = dz_u if need_dz else None
+                if need_dw:
+                    dw = dw_u if dw is None else dw + dw_u
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    db = db2p.sum(0) if db is None else db + db2p.sum(0)
+        ctx.uses = None
+        if need_dz and dz is None:
+            dz = torch.zeros_like(z)
+        if need_dw and dw is None:
+            dw = torch.zeros_like(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
+            db = torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device)
+        return dz, dw, db, None, None
+
+
+class _HeadUse(torch.autograd.Function):
+    """x[r] = Sigmoid(pre2[r]) . E[p(r)] + be[p(r)] (the forward of `_FusedLogit`) on a `_PairTrunk`: the backward computes the embedding rows'
+    gradients and this use's part of the second layer's bias gradient in one pass over pre2, and defers the rest to the trunk."""
+
+    @staticmethod
+    def forward(ctx, token, pre2, e_rows, be_rows, pred_off, row_pred, max_rows, uses, x_part):
+        ctx.save_for_backward(pre2, e_rows, pred_off, row_pred)
+        ctx.uses = uses
+        if x_part is not None:                                # the trunk's epilogue has this reader's partial sums already
+            return x_part.sum(0) + be_rows.index_select(0, row_pred)
+        return L.pair_logit_fwd(pre2, e_rows, be_rows, pred_off, max_rows)
+
+    @staticmethod
+    def backward(ctx, dx):
+        pre2, e_rows, pred_off, row_pred = ctx.saved_tensors
+        dx = dx.contiguous()
+        e_rows = e_rows if e_rows.is_contiguous() else e_rows.contiguous()
+        de, dbe, db2p = L.pair_head_sums(dx, pre2, e_rows, pred_off, need_bias=ctx.needs_input_grad[3])
+        ctx.uses.append((dx, e_rows, pred_off, row_pred, db2p))
+        return dx.new_zeros(1), None, de, dbe, None, None, None, None, None
+
+
 def _concept_plan(cols, device, cache):
     """Fixed-order combination plan for per-predicate gradient rows of the embedding layer: predicates naming the same concept are
     summed in predicate order (stable sort), the unique concepts then receive one row each - no atomics, repeatable bit for bit.
@@ -477,6 +546,7 @@ class ClassifierOracle(OracleBase):
         world._rel_table = None
         world._pair_h = None
         world._pair_pre2 = None
+        world._pair_head = world._pair_z = None
         if train:
             return
         wuv, buv, wg, hid1, D = self._split_first_layer()
@@ -490,9 +560,10 @@ class ClassifierOracle(OracleBase):
         return os.environ.get("DFOL_TRAIN_FUSED", "1") != "0" and world._pair_num > 0 and \
             L.pair_train_supported(lin1.weight.shape[0], lin2.weight.shape[0], max(world._n_list))
 
-    def _pair_pre2_autograd(self, world):
+    def _pair_pre2_autograd(self, world, first=None):
         """pre2 = W2 ELU(W1 [obj_s, obj_o, geo] + b1) + b2 for every ordered pair [pairs, HID2] (the hidden layer before its Sigmoid),
-        with the first layer split per object exactly as the fused inference kernel does; one evaluation per scene."""
+        with the first layer split per object exactly as the fused inference kernel does; one evaluation per scene.
+        first: the reader that asks first, as (embedding rows, row -> embedding row): see _PairTrunk.forward."""
         if getattr(world, "_pair_pre2", None) is None:
             lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
             obj = world._obj
@@ -520,13 +591,34 @@ class ClassifierOracle(OracleBase):
                                    torch.sign(po[:, 1] - ps[:, 1])], 1)
                 z = nn.functional.elu(U.index_select(0, s_idx) + V.index_select(0, o_idx)
                                       + _TallLinear.apply(geo, lin1.weight[:, 2 * D:2 * D + 4], None))
-            world._pair_pre2 = _TallLinear.apply(z, lin2.weight, lin2.bias)
+            world._pair_head, world._pair_z = None, z
+            if self._head_fused(world, z, lin1, lin2):
+                # the head's backward without dpre2 in memory: pre2 comes out of the trunk node, its readers register with `uses`
+                uses = []
+                pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, uses, first)
+                world._pair_head = (token, uses, x_part)
+                world._pair_pre2 = pre2
+            else:
+                world._pair_pre2 = _TallLinear.apply(z, lin2.weight, lin2.bias)
         return world._pair_pre2
+
+    def _head_fused(self, world, z, lin1, lin2):
+        """The deferred head backward applies: fused training kernels, fp32-stored activations on the split-operand pipes, widths the one-workgroup
+        weight-gradient kernel takes, and not switched off (DFOL_TRAIN_HEAD_FUSED=0)."""
+        return os.environ.get("DFOL_TRAIN_HEAD_FUSED", "1") != "0" and self._fused_training(world) and z.is_cuda and z.dtype == torch.float32 and \
+            _lib._dense_math() in ("f16x2", "bf16x3") and L.pair_head_fused_supported(lin1.weight.shape[0], lin2.weight.shape[0]) and \
+            z.shape[0] >= 4096 and torch.is_grad_enabled()
 
     def _pair_hidden_autograd(self, world):
         """h = Sigmoid(pre2) [pairs, HID2]; shared by all relation operators of the scene."""
         if world._pair_h is None:
-            world._pair_h = torch.sigmoid(self._pair_pre2_autograd(world).float())
+            pre2 = self._pair_pre2_autograd(world)
+            if getattr(world, "_pair_head", None) is not None:
+                # the trunk's pre2 carries no autograd edge of its own (its readers register with the trunk); a reader that cannot - rows
+                # gathered out of order, no-op tokens - gets a second, ordinary evaluation of the layer from the kept first hidden layer
+                lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+                pre2 = _TallLinear.apply(world._pair_z, lin2.weight, lin2.bias)
+            world._pair_h = torch.sigmoid(pre2.float())
         return world._pair_h
 
     def _pair_hidden_dense(self, world, n):
@@ -621,15 +713,23 @@ class ClassifierOracle(OracleBase):
             src = pair_off[q][rep] + k
             identity = len(src) == world._pair_num and np.array_equal(src, np.arange(len(src)))
             hit = (None if identity else torch.as_tensor(src).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev),
-                   torch.as_tensor(rep).to(dev), torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(dev), int(cnt.max()))
+                   torch.as_tensor(rep).to(dev), torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(dev), int(cnt.max()),
+                   torch.as_tensor(rep.astype(np.int32)).to(dev) if identity else None)
             self._index_cache[key] = hit
-        src, dst, rep, pred_off, max_rows = hit
+        src, dst, rep, pred_off, max_rows, rep32 = hit
         cols = upload(full[preds].astype(np.int64), dev)
         if fused and src is None:
             # every pair row belongs to exactly one predicate, in order: Sigmoid, embedding product and row sum in one kernel
             plan = _concept_plan(full[preds], dev, self._index_cache)
             e_rows, be_rows = _EmbRows.apply(emb.weight, emb.bias, cols, plan)
-            x = _FusedLogit.apply(self._pair_pre2_autograd(world), e_rows, be_rows, pred_off, max_rows)
+            fresh = getattr(world, "_pair_pre2", None) is None        # this reader creates the trunk: its logits come out of the trunk's epilogue
+            pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32))
+            head = getattr(world, "_pair_head", None)
+            if head is not None:                          # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk
+                x_part = head[2] if (fresh and head[2] is not None and head[2].numel() > 0) else None
+                x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part)
+            else:
+                x = _FusedLogit.apply(pre2, e_rows, be_rows, pred_off, max_rows)
         else:
             # one pass over all predicates (a loop over concepts would scatter-add into the hidden gradient once per concept; a
             # matrix-vector product would go to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms)

@@ -428,6 +428,32 @@ int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t HID2, const 
                             const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream);
 int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
                             const int64_t* pred_off, int32_t P, float* dP2, int64_t ld_dp2, float* dE, int64_t ld_de, float* dbe, void* stream);
+/* Round 4: the backward of the pair MLP's head WITHOUT the [pairs, HID2] gradient dpre2 in memory (what autograd materialises between
+ * the logit layer and the second Linear of gqa_interpreter_experiments.py:26-33 under trainer.py:436): the three consumers of dpre2
+ * rebuild it from pre2, dx and the rows' embedding rows - dpre2[r, j] = dx[r] E[row_pred[r], j] h (1 - h), h = Sigmoid(pre2[r, j]).
+ *   logit_bwd_sums: dE, dbe as dfol_pair_logit_bwd_f32 and dB2 [P, HID2] = every predicate's column sums of dpre2 (the second layer's
+ *                   bias gradient is the sum of its P rows); dfol_pair_logit_bwd_f32 itself now takes dP2 = NULL (dE and dbe only)
+ *   dz_fused:       dZ [M, HID1] (+)= dpre2 W2, W2t_split = dfol_linear_pack_w_f16x2 of W2^T [HID1, HID2]; row_pred[r] = the row of E
+ *                   (or -1: no gradient), emax[p] = max |E[p, :]|; the row's dpre2 is scaled by a power of two from the bound
+ *                   |dx[r]| emax / 4 before its fp16 split (csrc/dfol_dense_split.hip, LsProducer)
+ *   wgrad_fused:    dW2 [HID2, HID1] = dpre2^T Z in one pass over pre2 and Z (csrc/dfol_dense_wgrad.hip); row_pred non-decreasing and
+ *                   valid, pred_off [P + 1] the predicates' first rows, scale -> {S, 1 / S} on the device, S a power of two with
+ *                   S max_r |dx[r]| emax[row_pred[r]] / 4 <= 2^14; HID2 <= 320, HID1 <= 256, multiples of 4
+ * HID2 % 4 == 0, rows of pre2, Z and E 16-byte aligned.
+ * linear_logit_h2 (the forward counterpart): Y = X W^T + b as dfol_linear_act_h2_f32 and, from the epilogue of the same pass, the logit
+ * layer's forward in partial sums: x_part[s][r] = sum over the s-th 64-column half block of Sigmoid(Y[r, j]) E[row_pred[r], j],
+ * s < 2 ceil(N / 128) (row_pred < 0: 0) - dfol_pair_logit_fwd_f32 without its pass over Y (the caller adds a row's slots and the bias). */
+int dfol_linear_logit_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N,
+                             int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp, void* stream);
+int dfol_pair_logit_bwd_sums_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
+                                 const int64_t* pred_off, int32_t P, float* dE, int64_t ld_de, float* dbe, float* dB2, int64_t ld_db2, void* stream);
+int dfol_pair_dz_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
+                           const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t HID1, int32_t HID2,
+                           int32_t accumulate, void* stream);
+int64_t dfol_pair_wgrad_fused_workspace(int64_t M, int32_t HID2, int32_t HID1);      /* floats */
+int dfol_pair_wgrad_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off,
+                              const float* E, int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t HID2,
+                              int32_t HID1, float* workspace, float* dW, void* stream);
 /* The same four stages over bf16-STORED per-pair activations (the bf16 mode, BASELINE configs[3]): Z, dZ, P2 and dP2 are rows of
  * bfloat16 (row strides in elements, multiples of 4; HID2 % 4 == 0), everything per object / per predicate stays fp32, the arithmetic
  * runs in fp32 registers and results are rounded to nearest even when stored.  Same formulas and reference lines as above. */

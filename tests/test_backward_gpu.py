@@ -835,3 +835,103 @@ def test_train_step_on_shared_scenes_equals_per_question_scenes():
     (l1, g1), (l0, g0) = runs
     assert l1 == l0, (l1, l0)
     assert sorted(g1) == sorted(g0) and all(torch.equal(g1[k], g0[k]) for k in g1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: the pair MLP head's backward without dpre2 in memory (dfol_pair_logit_bwd_sums_f32, dfol_pair_dz_fused_f32,
+# dfol_pair_wgrad_fused_f32)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("counts,hid1,hid2,decades", [([90, 2, 6, 0, 132, 380, 30, 1], 256, 300, 0),        # tiny and empty predicates, M % 32 != 0
+                                                      ([9900, 5112, 3540], 256, 300, 4),                    # several slabs, dx over eight decades
+                                                      ([700, 650], 64, 128, 2),                             # four columns per building thread (HID2 % 3 != 0)
+                                                      ([2450] * 9, 256, 300, 1)])
+def test_pair_head_backward_without_dpre2(counts, hid1, hid2, decades):
+    """(dZ, dW2, db2, dE, dbe) of x = sum_j Sigmoid(Z W2^T + b2)[r, j] E[p(r), j] + be[p(r)] from the three kernels that rebuild dpre2 on
+    the fly, against float64 from the materialised dpre2, with the tolerance of the operand model the kernels document: dpre2 and Z as
+    two fp16 pieces (2^-22 relative per operand), the underflow floor of the row resp. launch scale, fp32 accumulation.  Two runs are
+    bit-identical; a second use accumulates into dZ."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(len(counts) * 1000 + hid2)
+    counts = np.asarray(counts, np.int64)
+    M, P = int(counts.sum()), len(counts)
+    pred_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rep = np.repeat(np.arange(P), counts).astype(np.int32)
+    p2 = (rng.normal(size=(M, hid2)) * 2.5).astype(np.float32)
+    z = np.where(rng.uniform(size=(M, hid1)) < 0.5, rng.uniform(-1, 0, (M, hid1)), rng.uniform(0, 6, (M, hid1))).astype(np.float32)      # ELU outputs
+    w2 = (rng.normal(size=(hid2, hid1)) / 16).astype(np.float32)
+    E = (rng.normal(size=(P, hid2)) * 0.1).astype(np.float32)
+    dx = (rng.normal(size=M) * 10.0 ** rng.randint(-decades, decades + 1, M)).astype(np.float32)
+    dx[rng.uniform(size=M) < 0.1] = 0.0
+    dev = lambda a: torch.as_tensor(a).to(DEV)
+    w2_t = dev(w2)
+    args = (dev(dx), dev(p2), dev(z), w2_t, dev(E), dev(pred_off), dev(rep))
+    dz, dw, db2, de, dbe = _lib.pair_head_bwd(*args)
+    again = _lib.pair_head_bwd(*args)
+    for a, b in zip((dz, dw, db2, de, dbe), again):
+        assert torch.equal(a, b)
+    # float64 from the same formulas
+    p64, z64, w64, E64, g64 = (a.astype(np.float64) for a in (p2, z, w2, E, dx))
+    h = 1.0 / (1.0 + np.exp(-p64))
+    dp = g64[:, None] * E64[rep] * h * (1.0 - h)
+    emax = np.abs(E64).max(1)
+    bound = np.abs(g64) * emax[rep] * 0.25
+    # dZ: rows scaled by their own bound
+    want = dp @ w64
+    tol = 2.0 ** -20 * (np.abs(dp) @ np.abs(w64)) + hid2 * 2.0 ** -37 * bound[:, None] * np.abs(w64).max() + 1e-30
+    err = np.abs(dz.cpu().numpy() - want)
+    assert (err <= tol).all(), ("dZ", float((err / tol).max()))
+    # dW2: one scale for the launch
+    want = dp.T @ z64
+    tol = 2.0 ** -20 * (np.abs(dp).T @ np.abs(z64)) + 2.0 ** -37 * bound.max() * np.abs(z64).sum(0)[None, :] + 1e-30
+    err = np.abs(dw.cpu().numpy() - want)
+    assert (err <= tol).all(), ("dW2", float((err / tol).max()))
+    for got, want, mag, tag in ((db2, dp.sum(0), np.abs(dp).sum(0), "db2"),
+                                (de, np.add.reduceat(np.concatenate([g64[:, None] * h, np.zeros((1, hid2))]), np.minimum(pred_off[:-1], M), 0) * (counts > 0)[:, None],
+                                 np.add.reduceat(np.concatenate([np.abs(g64[:, None] * h), np.zeros((1, hid2))]), np.minimum(pred_off[:-1], M), 0), "dE"),
+                                (dbe, np.add.reduceat(np.concatenate([g64, [0.0]]), np.minimum(pred_off[:-1], M)) * (counts > 0),
+                                 np.add.reduceat(np.concatenate([np.abs(g64), [0.0]]), np.minimum(pred_off[:-1], M)), "dbe")):
+        err = np.abs(got.cpu().numpy() - want)
+        assert (err <= 2e-6 * mag + 1e-30).all(), (tag, float(err.max()))
+    # a second use of the hidden layer adds its input gradient
+    dz2 = _lib.pair_head_bwd(*args, dz_out=dz.clone())[0]
+    assert np.allclose(dz2.cpu().numpy(), 2.0 * dz.cpu().numpy(), rtol=1e-6, atol=0.0)
+    # the materialised route (dfol_pair_logit_bwd_f32 -> bf16x3 products) agrees to the same tolerance class
+    dp_dev, de_m, dbe_m = _lib.pair_logit_bwd(args[0], args[1], args[4], args[5])
+    assert torch.equal(de_m, de) and torch.equal(dbe_m, dbe)
+    assert np.allclose(dp_dev.cpu().numpy(), dp, rtol=2e-5, atol=1e-30 + 2e-6 * np.abs(dp).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(9900 * 3 + 77, 300, 256), (1000, 300, 256), (70000, 256, 64), (129, 44, 32)])
+def test_linear_logit_h2_partial_sums(M, N, K):
+    """dfol_linear_logit_h2_f32: the product is bit for bit dfol_linear_act_h2_f32's, and the partial sums its epilogue leaves add up to the
+    logit layer's forward (dfol_pair_logit_fwd_f32 on the stored product) - interior tiles (staged stores), edge rows, the narrow last
+    column block, 64-row blocks, rows without a predicate."""
+    from dfol_vqa_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / 8
+    b = torch.randn(N, device=DEV, generator=g)
+    P = 7
+    E = torch.randn(P, N, device=DEV, generator=g) * 0.3
+    cnt = np.full(P, M // P, np.int64)
+    cnt[-1] += M - cnt.sum()
+    rep = torch.as_tensor(np.repeat(np.arange(P), cnt).astype(np.int32)).to(DEV)
+    pred_off = torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(DEV)
+    with _lib.dense_math("f16x2"):
+        y_ref = _lib.linear_act_split(x, w, b, _lib.ACT_NONE)
+        y, xp = _lib.linear_logit_h2(x, w, b, rep, E)
+    assert torch.equal(y, y_ref)
+    want = _lib.pair_logit_fwd(y_ref, E, None, pred_off, int(cnt.max()))
+    got = xp.sum(0)
+    h = torch.sigmoid(y_ref.double())
+    exact = (h * E.double()[rep.long()]).sum(1)
+    mag = (h * E.double()[rep.long()].abs()).sum(1)
+    assert ((got.double() - exact).abs() <= 4e-6 * mag + 1e-7).all() and ((want.double() - exact).abs() <= 4e-6 * mag + 1e-7).all()
+    # rows without a predicate (a leading run: the map is non-decreasing) add nothing
+    rep2 = rep.clone()
+    lead = min(200, M // 2)
+    rep2[:lead] = -1
+    with _lib.dense_math("f16x2"):
+        _, xp2 = _lib.linear_logit_h2(x, w, b, rep2, E)
+    got2 = xp2.sum(0)
+    assert torch.equal(got2[lead:], got[lead:]) and float(got2[:lead].abs().max()) == 0.0

@@ -35,8 +35,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LS_BM = 128, LS_BN = 128, LS_BK = 32;
+// Two measured variants of the step loop for the two-piece kernels, both OFF: -DLS_DOUBLE_BUFFER=1 (two LDS buffers, one barrier per step)
+// and with it -DLS_XRING=4 (four steps of X rows in flight instead of two).  At the train step's tall products (2.5 M rows, K = 256 / 300;
+// tools/lab/time_tall.py) the single-buffered loop takes 1.96 / 2.13 ms, the double-buffered one 2.02 / 2.27 ms, with the deeper ring
+// 2.14 / 2.35 ms: these products move 5.6 GB each at ~2.8 TB/s and neither barriers nor the depth of the prefetch bound them (rocprofv3
+// counters, tools/lab/pmc_tall.sh: 46 % of the wavefront cycles wait on memory counters, 15 % issue MFMAs; without the MFMAs the
+// kernels are 0.15 ms faster, without the stores 0.5 ms).
 #ifndef LS_DOUBLE_BUFFER
-#define LS_DOUBLE_BUFFER 1
+#define LS_DOUBLE_BUFFER 0
+#endif
+#ifndef LS_XRING
+#define LS_XRING 2                // steps of X rows in flight in the double-buffered form (register sets of 16 per 128-row block)
 #endif
 
 __device__ __forceinline__ int ls_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -247,7 +256,8 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     // clamped, out-of-range k zeroed afterwards - so that every wavefront issues exactly 4 per step and the vmcnt arithmetic below holds.
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef typename std::conditional<BIO, u32x2, float4>::type XR;  // four consecutive k of a row as loaded
-    XR xa[2][RH][2];                                                // [set = step parity][row half][k half]
+    constexpr int XD = DB ? LS_XRING : 2;                           // X register sets = steps of X in flight
+    XR xa[XD][RH][2];                                               // [set][row half][k half]
     float4 ea[PROD ? RH : 1][2];                                    // PROD: the same pieces of the rows' embedding rows - L2 hits, ONE step ahead
     auto load_x = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
@@ -414,11 +424,17 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
         // end goes to the buffer nobody reads any more.
         constexpr int BUF = NP * BM * 4 + NP * LS_BN * 4;
         const int last = ksteps - 1;
+        const std::integral_constant<int, 2 % XD> S2;
+        const std::integral_constant<int, 3 % XD> S3;
+        if constexpr (XD == 4) {                            // (steps 0 and 1 were requested above)
+            load_x(min(2, last), S2);
+            load_x(min(3, last), S3);
+        }
         store_a(0, S0, 0);
         store_b(0);
         load_w(min(1, last));
         load_e(min(1, last));
-        load_x(min(2, last), S0);
+        load_x(min(XD, last), S0);
         __syncthreads();
         auto body = [&](int k, auto next_tag) __attribute__((always_inline)) {      // k: the step multiplied; next_tag: the X set of step k + 1
             const int cur = (k & 1) * BUF, nxt = BUF - cur;
@@ -427,7 +443,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
             store_b(nxt);
             load_w(min(k + 2, last));
             load_e(min(k + 2, last));
-            load_x(min(k + 3, last), next_tag);
+            load_x(min(k + 1 + XD, last), next_tag);
             LTRACE(4 * k + 1);
             __builtin_amdgcn_sched_barrier(0);
             multiply(cur);
@@ -435,11 +451,23 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
             LTRACE(4 * k + 3);
             __syncthreads();                                // buffer nxt complete, buffer cur fully read
         };
-        for (; ks + 1 < ksteps; ks += 2) {
-            body(ks, S1);
-            body(ks + 1, S0);
+        if constexpr (XD == 4) {
+            for (; ks + 3 < ksteps; ks += 4) {
+                body(ks, S1);
+                body(ks + 1, S2);
+                body(ks + 2, S3);
+                body(ks + 3, S0);
+            }
+            if (ks < ksteps) body(ks, S1);                  // (the tags continue where the loop stopped: ks is a multiple of 4)
+            if (ks + 1 < ksteps) body(ks + 1, S2);
+            if (ks + 2 < ksteps) body(ks + 2, S3);
+        } else {
+            for (; ks + 1 < ksteps; ks += 2) {
+                body(ks, S1);
+                body(ks + 1, S0);
+            }
+            if (ks < ksteps) body(ks, S1);
         }
-        if (ks < ksteps) body(ks, S1);
         ks = ksteps;
     }
     for (; ks + 3 < ksteps; ks += 2) {

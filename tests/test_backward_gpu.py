@@ -935,3 +935,45 @@ def test_linear_logit_h2_partial_sums(M, N, K):
         _, xp2 = _lib.linear_logit_h2(x, w, b, rep2, E)
     got2 = xp2.sum(0)
     assert torch.equal(got2[lead:], got[lead:]) and float(got2[:lead].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kinds", [("exist", "verify_rel"), ("choose_rel", "query_attr")])
+def test_deferred_head_backward_equals_the_materialised_one(kinds, monkeypatch):
+    """The full-size model on ragged scenes with programs of one to three relation hops (several readers of one hidden layer: the deferred
+    trunk adds their input and weight gradients), relation option lists and no-op tokens (readers that cannot register with the trunk and
+    fall back to a second, ordinary evaluation): loss and every parameter gradient with the head's backward rebuilt on the fly
+    (`_PairTrunk` / `_HeadUse`) against the materialised route (DFOL_TRAIN_HEAD_FUSED=0: dpre2 in memory, bf16x3 products)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_test5", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = bench.parse(["--mode", "train", "--objects", "24", "--batch", "16"])
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DFOL_TRAIN_HEAD_FUSED", fused)
+        torch.manual_seed(3)
+        model, ontology, paths, names = bench.build_model(args, DEV, train=True)
+        with open(paths["attribute_file"]) as f:
+            categories = json.load(f)
+        qs = []
+        for j, kind in enumerate(kinds):
+            qs += syn.full_size_questions(kind, 8, 18, 30, names, categories, 40 + j)
+        if "choose_rel" in kinds:
+            qs[0]["program"]["last_op"]["arguments"][0][1] = "_"       # a no-op token inside an option list
+        pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate([dict(q) for q in qs])]
+        res = model(pbs, True)
+        loss = training.compute_loss(pbs, res) / len(qs)
+        loss.backward()
+        runs.append((float(loss.detach()), {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in model.named_parameters()}))
+    (l1, g1), (l0, g0) = runs
+    assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)), (l1, l0)
+    seen = 0
+    for k in g0:
+        if g0[k] is None:
+            assert g1[k] is None, k
+            continue
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 3e-5 * scale + 1e-12, (k, float((g1[k] - g0[k]).abs().max()), scale)
+        seen += scale > 0
+    assert seen >= 8

@@ -44,6 +44,14 @@ constexpr int LS_BM = 128, LS_BN = 128, LS_BK = 32;
 #ifndef LS_DOUBLE_BUFFER
 #define LS_DOUBLE_BUFFER 0
 #endif
+// -DLS_B_GLOBAL=1 (two-piece kernels): the B fragments go from the packed image (it is in fragment order) straight into the MFMA operand
+// registers, one step ahead - no LDS traffic for B.  The step loop of the two-piece kernels is LDS-bound otherwise: per step and
+// wavefront 8 writes and 24 reads of 16 bytes x 64 lanes for 48 MFMAs, 256 KB per CU and step pair = 2048 cycles of the LDS pipe against
+// 1536 of the matrix pipe (without any global traffic the forward tall product still takes 1.38 of its 1.96 ms).
+// (measured at the same two products: 1.92 / 2.39 ms against 1.95 / 2.13 - the producer kernel spills with the fragment registers; OFF)
+#ifndef LS_B_GLOBAL
+#define LS_B_GLOBAL 0
+#endif
 #ifndef LS_XRING
 #define LS_XRING 2                // steps of X rows in flight in the double-buffered form (register sets of 16 per 128-row block)
 #endif
@@ -207,6 +215,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                                         int K, int ksteps, int mb, int nb, int nbn, const LsProducer& prod = LsProducer(), float* __restrict__ Rs = nullptr) {
     static_assert(!BIO || NP == 1, "bf16 storage belongs to the bf16 mode");
     constexpr bool PROD = MODE == 1, LOGIT = MODE == 2;
+    constexpr bool BG = LS_B_GLOBAL && !LS_DOUBLE_BUFFER && NP == 2 && !BIO;     // B fragments straight from the packed image
     constexpr bool DB = LS_DOUBLE_BUFFER && NP == 2 && !BIO;          // two LDS buffers (2 x 32 KB for a 128-row block: still two workgroups per CU)
     static_assert(!LOGIT || (!BIO && ACT == DFOL_ACT_NONE), "the logit partial sums belong to the fp32 pre-activation output");
     static_assert(!PROD || (NP == 2 && !BIO && XV == 4 && ACT == DFOL_ACT_NONE), "the produced operand is two fp16 pieces of fp32 rows");
@@ -272,12 +281,18 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                 return make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         };
+#ifdef LS_SKIP_X
+        if (ks > 100000) {
+#endif
         xa[S][0][0] = ld4(xp0 + c0);
         xa[S][0][1] = ld4(xp0 + c1);
         if constexpr (RH == 2) {
             xa[S][1][0] = ld4(xp1 + c0);
             xa[S][1][1] = ld4(xp1 + c1);
         }
+#ifdef LS_SKIP_X
+        }
+#endif
     };
     auto load_e = [&](int ks) __attribute__((always_inline)) {
         if constexpr (PROD) {
@@ -339,6 +354,9 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     u32x4 wb[TILE_PIECES / 256];
     auto load_w = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
+#ifdef LS_SKIP_W
+        if (ks > 100000)
+#endif
         for (int i = 0; i < TILE_PIECES / 256; ++i) wb[i] = wtile[(int64_t)ks * TILE_PIECES + 256 * i + tid];
     };
     auto store_b = [&](int off = 0) __attribute__((always_inline)) {
@@ -349,11 +367,20 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     const int aoff = (wm * (16 * RT) + r16) * 4 + (kh ^ ls_swz(r16));
     const int boff = (wn * WN + r16) * 4 + (kh ^ ls_swz(r16));
 
+    u32x4 bq[1][BG ? NT : 1][BG ? NP : 1];                           // BG: the B fragments of the step (requested at its top, under the split of the X rows)
+    auto load_bq = [&](int ks, auto set_tag) __attribute__((always_inline)) {
+        if constexpr (BG) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bq[0][j][p] = wtile[(int64_t)ks * TILE_PIECES + p * LS_BN * 4 + j * 64 + boff];
+        }
+    };
     constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};
     constexpr int X0 = NP == 1 ? 5 : 0;                               // the bf16 mode keeps the last product only (piece 0 x piece 0)
     constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};             // NP = 2: xl wh, xh wl, xh wh (smallest first)
     typedef typename std::conditional<NP == 2, f16x8, bf16x8>::type FR;
-    auto multiply = [&](int off) __attribute__((always_inline)) {  // the step's MFMAs on the tiles of LDS buffer `off`
+    auto multiply = [&](int off, auto bq_tag) __attribute__((always_inline)) {  // the step's MFMAs on the tiles of LDS buffer `off`
 #pragma unroll
         for (int ih = 0; ih < RT; ih += 2) {                // two row tiles at a time (register budget)
             FR a[2][NP];
@@ -365,7 +392,10 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
             for (int j = 0; j < NT; ++j) {
                 FR b[NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(FR, Bs[off + p * LS_BN * 4 + j * 64 + boff]);
+                for (int p = 0; p < NP; ++p) {
+                    if constexpr (BG) b[p] = __builtin_bit_cast(FR, bq[0][j][p]);
+                    else b[p] = __builtin_bit_cast(FR, Bs[off + p * LS_BN * 4 + j * 64 + boff]);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if constexpr (NP == 2) {
@@ -390,16 +420,19 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     auto step = [&](int ks, auto set_tag, auto has_b, auto has_x) __attribute__((always_inline)) {
         constexpr bool HAS_B = decltype(has_b)::value, HAS_X = decltype(has_x)::value;     // is there a B tile ks+1 / an X step ks+2
         LTRACE(4 * ks);
+        if constexpr (BG) load_bq(ks, set_tag);             // (L2 hits: there by the time the X rows are split, stored and the barrier passed)
         store_a(ks, set_tag);
-        store_b();
+        if constexpr (!BG) store_b();
         LTRACE(4 * ks + 1);
         __syncthreads();                                    // A pieces and B tile ks visible
         LTRACE(4 * ks + 2);
-        if (HAS_B) load_w(ks + 1);
+        if constexpr (!BG) {
+            if (HAS_B) load_w(ks + 1);
+        }
         if (HAS_B) load_e(ks + 1);                          // (consumed by this step's store_a already: one register set)
         if (HAS_X) load_x(ks + 2, set_tag);
         __builtin_amdgcn_sched_barrier(0);                  // requests first; and the next step's split must not drift up here
-        multiply(0);
+        multiply(0, set_tag);
         __builtin_amdgcn_sched_barrier(0);                  // (it would wait for X(ks+1) in the middle of the MFMAs)
         LTRACE(4 * ks + 3);
         __syncthreads();                                    // A and B tile ks fully read
@@ -412,7 +445,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     const std::false_type no;
     LTRACE(60);
     load_x(0, S0);
-    load_w(0);
+    if constexpr (!BG) load_w(0);
     load_e(0);
     load_x(min(1, ksteps - 1), S1);
     int ks = 0;
@@ -446,7 +479,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
             load_x(min(k + 1 + XD, last), next_tag);
             LTRACE(4 * k + 1);
             __builtin_amdgcn_sched_barrier(0);
-            multiply(cur);
+            multiply(cur, std::integral_constant<int, 0>());
             __builtin_amdgcn_sched_barrier(0);
             LTRACE(4 * k + 3);
             __syncthreads();                                // buffer nxt complete, buffer cur fully read

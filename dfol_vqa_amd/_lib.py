@@ -114,6 +114,9 @@ SIGNATURES = {
     "dfol_pair_logit_fwd_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i32, _i64, _i64, _p, _p],
     "dfol_pair_logit_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_pair_logit_bwd_sums_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _p, _i64, _p],
+    "dfol_linear_tall_supported": [_i64, _i32, _i32],
+    "dfol_linear_tall_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
+    "dfol_pair_dz_tall_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p],
     "dfol_linear_logit_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "dfol_pair_dz_fused_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_wgrad_fused_workspace": [_i64, _i32, _i32],
@@ -796,6 +799,28 @@ def pair_head_fused_supported(hid1, hid2):
     return hid1 % 4 == 0 and hid2 % 4 == 0 and 16 <= hid2 <= 320 and 4 <= hid1 <= 256
 
 
+def tall_enabled():
+    """The persistent one-workgroup-per-CU form of the tall products (csrc/dfol_dense_tall.hip); DFOL_TALL=0 keeps the tiled kernels."""
+    return os.environ.get("DFOL_TALL", "1") != "0"
+
+
+def linear_tall_supported(M, N, K):
+    return tall_enabled() and bool(load().dfol_linear_tall_supported(M, N, K))
+
+
+def linear_tall_h2(x, weight, bias, row_pred=None, e_rows=None):
+    """y [M, N] = x @ weight.T + bias on two fp16 pieces, persistent form (M >= 16384, N <= 320): bit for bit linear_act_split's result.
+    With row_pred / e_rows also the logit layer's partial sums x_part [4, M] (see linear_logit_h2) -> (y, x_part), else (y, None)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, dtype=F32, device=x.device)
+    xp = torch.empty(4, M, dtype=F32, device=x.device) if row_pred is not None else None
+    call("dfol_linear_tall_h2_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, False, 2), torch.bfloat16), _ptr(bias, F32, True), _dp(y),
+         y.stride(0), M, N, K, _ptr(row_pred, I32, True), _ptr(e_rows, F32, True), 0 if e_rows is None else e_rows.stride(0), _ptr(xp, F32, True),
+         0 if xp is None else xp.stride(0), _stream())
+    return y, xp
+
+
 def linear_logit_h2(x, weight, bias, row_pred, e_rows):
     """(y [M, N] = x @ weight.T + bias, x_part [2 ceil(N / 128), M]) on two fp16 pieces: the second layer of the pair MLP and, from the same
     pass, the logit layer's partial sums x_part[s][r] = sum over the s-th 64-column half block of Sigmoid(y[r, j]) e_rows[row_pred[r], j]."""
@@ -831,7 +856,13 @@ def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, 
     dz = dw = None
     if need_dz:
         dz = dz_out if dz_out is not None else torch.empty(M, H1, dtype=F32, device=dev)
-        call("dfol_pair_dz_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(emax, F32),
+        if linear_tall_supported(M, H1, H2):
+            ws = torch.empty(2 * M, dtype=F32, device=dev)
+            call("dfol_pair_dz_tall_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(emax, F32),
+                 _ptr(linear_pack_w_split(w2, True, 2), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _ptr(ws),
+                 _stream())
+        else:
+            call("dfol_pair_dz_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(emax, F32),
              _ptr(linear_pack_w_split(w2, True, 2), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _stream())
     if need_dw:
         # one power of two for the weight gradient's fp16 pieces: S max_r |dx[r]| emax[p(r)] / 4 in [2^13, 2^14) (device-side: no sync)

@@ -1,0 +1,441 @@
+// The two TALL products of a train step of the pair MLP (trainer.py:429-442 through gqa_interpreter_experiments.py:26-33): millions of rows
+// (one per ordered object pair) against a small weight matrix - pre2 = Z W2^T + b2 ([2.5 M, 256] x [256, 300]) and dZ = dpre2 W2
+// ([2.5 M, 300] x [300, 256]) - as ONE persistent workgroup per CU that walks row blocks (gfx950).
+//
+// csrc/dfol_dense_split.hip runs these shapes as 128 x 128 output tiles of 8 - 10 k-steps each, two workgroups per CU: every tile pays a
+// cold start and a store phase, X is split once per column block (three times for 300 columns), and the products moved their 5.6 GB at
+// 2.7 - 2.9 TB/s (1.96 / 2.13 ms at 256 x 100 objects) where the step's plain streaming kernels reach 5.4 - 6 TB/s.  Here a workgroup of
+// eight wavefronts owns 128 rows x ALL columns (N <= 320): the X rows are read and split once, the weight tiles of all column blocks are
+// staged per k-step, wavefront (wm, wn) multiplies rows 64 wm .. by columns 16 NTW wn .. (4 x NTW accumulator tiles of 16 x 16), and
+// the step stream runs on across row blocks - the X rows of the next block's first steps are in flight (four steps of registers) under
+// the last steps and the stores of the current one.  Two LDS buffers, one barrier per step:  multiply step g from one buffer, then split
+// and store step g + 1 into the other.
+//
+// Same arithmetic as dfol_linear_act_h2_f32 (two fp16 pieces per operand, three products, the packed image of dfol_linear_pack_w_f16x2,
+// the same order of the products): results are bit for bit those of csrc/dfol_dense_split.hip.
+//   MODE 0: Y = X W^T + b
+//   MODE 1: the A operand is produced (dpre2 from pre2, dx and the rows' embedding rows, see dfol_pair_dz_fused_f32); the per-row scaling
+//           comes precomputed (tall_row_scale_kernel: gs[r] = 2^e_r dx[r], rsinv[r] = 2^-e_r)
+//   MODE 2: MODE 0 plus the logit layer's partial sums from the epilogue (see dfol_linear_logit_h2_f32), one slot per column group (4)
+#include "dfol_common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TL_BM = 128, TL_BK = 32, TL_XD = 4;                     // rows of a block, k of a step, steps of X rows in flight
+constexpr int TL_TILE = 2 * 128 * 4;                                  // 16-byte pieces of one [2 pieces][128 rows][4 k-groups] tile (16 KB)
+
+__device__ __forceinline__ int tl_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+__device__ __forceinline__ void tl_split2h(float x0, float x1, uint32_t& h, uint32_t& l) {
+    const f32x2 x = {x0, x1};
+    const f16x2 hh = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(hh, f32x2);
+    h = __builtin_bit_cast(uint32_t, hh);
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ void tl_split8h(const float4& a, const float4& b, u32x4& h, u32x4& l) {
+    uint32_t hh[4], ll[4];
+    tl_split2h(a.x, a.y, hh[0], ll[0]);
+    tl_split2h(a.z, a.w, hh[1], ll[1]);
+    tl_split2h(b.x, b.y, hh[2], ll[2]);
+    tl_split2h(b.z, b.w, hh[3], ll[3]);
+    h = u32x4{hh[0], hh[1], hh[2], hh[3]};
+    l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
+__device__ __forceinline__ float tl_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
+__device__ __forceinline__ float tl_dsigmoid(float x) {
+    const float h = tl_sigmoid(x);
+    return h * (1.0f - h);
+}
+
+struct TlExtra {
+    const float* gs;                // MODE 1: 2^e_r dx[r] [M]
+    const float* rsinv;             // MODE 1: 2^-e_r [M]
+    const int32_t* row_pred;        // MODE 1, 2: [M] the row of E a pair row reads (MODE 1: -1 = no gradient; MODE 2: non-decreasing)
+    const float* E;                 // [P, ld_e]
+    int64_t ld_e;
+    int accumulate;                 // MODE 1: Y += instead of Y =
+    float* x_part;                  // MODE 2: [4][ld_xp]
+    int64_t ld_xp;
+};
+
+// MODE 1's per-row scaling: e_r puts the bound |dx[r]| max|E[p]| / 4 into [2^13, 2^14)  (the rule of csrc/dfol_dense_split.hip, LsProducer)
+__global__ __launch_bounds__(256) void tall_row_scale_kernel(const float* __restrict__ dx, const int32_t* __restrict__ row_pred,
+                                                             const float* __restrict__ emax, int M, float* __restrict__ gs,
+                                                             float* __restrict__ rsinv) {
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (r >= M) return;
+    const int p = row_pred[r];
+    const float gg = p >= 0 ? dx[r] : 0.f;
+    const float bound = fabsf(gg) * emax[max(p, 0)] * 0.25f;
+    int e = 0;
+    if (bound > 0.f && bound < 3.0e38f) {
+        int x;
+        (void)frexpf(bound, &x);
+        e = 14 - x;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    gs[r] = ldexpf(gg, e);
+    rsinv[r] = ldexpf(1.0f, -e);
+}
+
+// NTW: 16-column tiles per wavefront (4 wavefronts across the columns: N <= 64 NTW); NBN = ceil(64 NTW / 128) column blocks of the packed image
+template <int NTW, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void tall_h2_kernel(
+    const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
+    int M, int N, int K, int ksteps, int nbn, TlExtra ex) {
+    constexpr bool PROD = MODE == 1, LOGIT = MODE == 2;
+    constexpr int NBN = (64 * NTW + 127) / 128;
+    constexpr int BUF = TL_TILE + NBN * TL_TILE;                      // one LDS buffer: the A tile, then the B tiles of all column blocks
+    extern __shared__ __attribute__((aligned(16))) u32x4 tl_sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int arow = tid >> 2, aq = tid & 3;                          // staging: one row of the block, 8 consecutive k per step
+    const int nblocks = (M + TL_BM - 1) / TL_BM, stride = gridDim.x;
+    const int first = blockIdx.x;
+    if (first >= nblocks) return;
+    const int nmine = (nblocks - first + stride - 1) / stride;
+    const int T = nmine * ksteps;                                     // steps of this workgroup's stream
+
+    floatx4 acc[4][NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- X rows: a ring of TL_XD register sets, the loader's position runs ahead of the multiplier's across block boundaries
+    float4 xa[TL_XD][2];
+    int lb = first, lks = 0;                                          // block and step the next load belongs to
+    const float* xrow = X + (int64_t)min(lb * TL_BM + arow, M - 1) * ldx + aq * 8;
+    auto load_x = [&](auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        const int k = lks * TL_BK + aq * 8;
+        const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;          // (K % 4 == 0; clamped, zeroed when used)
+        xa[S][0] = *reinterpret_cast<const float4*>(xrow + c0);
+        xa[S][1] = *reinterpret_cast<const float4*>(xrow + c1);
+        if (++lks == ksteps) {                                        // (uniform) on to the next block of this workgroup; past the last: clamped rows, never used
+            lks = 0;
+            lb += stride;
+            xrow = X + (int64_t)min((int64_t)lb * TL_BM + arow, (int64_t)M - 1) * ldx + aq * 8;
+        }
+    };
+    // ---- weight tiles of a step: all column blocks, one step ahead in registers
+    u32x4 wb[2 * NBN];
+    int wks = 0;
+    auto load_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2 * NBN; ++i) {
+            const int idx = i * 512 + tid, nb = idx >> 10, within = idx & 1023;
+            wb[i] = Wp[((int64_t)min(nb, nbn - 1) * ksteps + wks) * TL_TILE + within];
+        }
+        if (++wks == ksteps) wks = 0;
+    };
+    auto store_b = [&](int off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2 * NBN; ++i) tl_sm[off + TL_TILE + i * 512 + tid] = wb[i];
+    };
+    // ---- MODE 1: the producer's state for the block whose steps are being stored; the next block's row values are prefetched a block ahead
+    float gs_cur = 0.f, gs_next = 0.f;
+    int p_next = -1;
+    const float* ep = ex.E;
+    float4 ea[2];
+    int sb = first, sks = 0;                                          // block and step the next store belongs to
+    auto fetch_row_state = [&](int b) __attribute__((always_inline)) {
+        if constexpr (PROD) {
+            const int64_t r = min((int64_t)b * TL_BM + arow, (int64_t)M - 1);
+            const bool live = (int64_t)b * TL_BM + arow < M;
+            p_next = live ? ex.row_pred[r] : -1;
+            gs_next = live ? ex.gs[r] : 0.f;
+        }
+    };
+    auto switch_row_state = [&]() __attribute__((always_inline)) {   // at the first step of a block
+        if constexpr (PROD) {
+            gs_cur = p_next >= 0 ? gs_next : 0.f;
+            ep = ex.E + (int64_t)max(p_next, 0) * ex.ld_e + aq * 8;
+            fetch_row_state(sb + stride);
+        }
+    };
+    auto load_e = [&]() __attribute__((always_inline)) {              // the embedding pieces of the step about to be stored
+        if constexpr (PROD) {
+            const int k = sks * TL_BK + aq * 8;
+            const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;
+            ea[0] = *reinterpret_cast<const float4*>(ep + c0);
+            ea[1] = *reinterpret_cast<const float4*>(ep + c1);
+        }
+    };
+    auto store_a = [&](auto set_tag, int off) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        const int k = sks * TL_BK + aq * 8;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v0 = k < K ? xa[S][0] : z, v1 = k + 4 < K ? xa[S][1] : z;
+        if constexpr (PROD) {
+            auto dp = [&](const float4& x, const float4& e) __attribute__((always_inline)) {
+                return make_float4((gs_cur * e.x) * tl_dsigmoid(x.x), (gs_cur * e.y) * tl_dsigmoid(x.y), (gs_cur * e.z) * tl_dsigmoid(x.z),
+                                   (gs_cur * e.w) * tl_dsigmoid(x.w));
+            };
+            v0 = k < K ? dp(xa[S][0], ea[0]) : z;
+            v1 = k + 4 < K ? dp(xa[S][1], ea[1]) : z;
+        }
+        u32x4 ph, pl;
+        tl_split8h(v0, v1, ph, pl);
+        const int at = off + arow * 4 + (aq ^ tl_swz(arow));
+        tl_sm[at] = ph;
+        tl_sm[at + TL_BM * 4] = pl;
+        if (++sks == ksteps) {
+            sks = 0;
+            sb += stride;
+        }
+    };
+
+    // ---- the step's MFMAs
+    const int aoff = (wm * 64 + r16) * 4 + (kh ^ tl_swz(r16));
+    int boff[NTW];                                                    // fragment of column tile j: block (col >> 7), row col & 127 of its tile
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int col0 = wn * (16 * NTW) + j * 16;
+        boff[j] = TL_TILE + (col0 >> 7) * TL_TILE + ((col0 & 127) + r16) * 4 + (kh ^ tl_swz(r16));
+    }
+    constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};             // xl wh, xh wl, xh wh (smallest first)
+    auto multiply = [&](int off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ih = 0; ih < 4; ih += 2) {                           // two row tiles at a time (register budget)
+            f16x8 a[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) a[i][p] = __builtin_bit_cast(f16x8, tl_sm[off + p * TL_BM * 4 + (ih + i) * 64 + aoff]);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                f16x8 b[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(f16x8, tl_sm[off + p * 128 * 4 + boff[j]]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x)
+                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][PA3[x]], b[PB3[x]], acc[ih + i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- what the epilogue needs beside the accumulators lives in LDS (4 KB behind the two buffers), put there steps ahead: the weight rows'
+    // scales and the bias (once), and per block the rows' un-scaling factors (MODE 1) resp. the block's embedding row (MODE 2: a block nearly
+    // always lies inside one predicate - row_pred is non-decreasing and a predicate owns n (n - 1) rows; a block across a boundary looks its
+    // rows up one by one).  Loaded in the epilogue itself these were dependent round trips with the whole CU waiting: the first version
+    // of the logit epilogue cost 1.2 ms over 77 blocks per workgroup.
+    float* xs = reinterpret_cast<float*>(tl_sm + 2 * BUF);            // [0, 320) scales, [320, 640) bias, [640, 960) embedding row, [960, 1088) row factors
+    if (tid < 320) {
+        const float* tail = reinterpret_cast<const float*>(Wp + (int64_t)nbn * ksteps * TL_TILE);
+        xs[tid] = tid < nbn * 128 ? tail[tid] : 0.f;
+        xs[320 + tid] = (bias && tid < N) ? bias[tid] : 0.f;
+    }
+    int lg_p0 = -1, lg_pl = -2;                                       // (scalar registers) predicates of the block's first and last row
+    bool lg_uni = false;
+    float stage_reg = 0.f;
+    int p0_reg = -1, pl_reg = -2;                                     // (requested at step 0, read at step 1: no wait at the request)
+    auto epilogue_stage = [&](int b, int step) __attribute__((always_inline)) {      // called at steps 0, 1, 2 of block b (ksteps >= 4)
+        const int m0 = b * TL_BM;
+        if (step == 0) {
+            if constexpr (LOGIT) {
+                p0_reg = ex.row_pred[m0];
+                pl_reg = ex.row_pred[min(m0 + TL_BM, M) - 1];
+            }
+            if constexpr (PROD) {
+                if (tid < TL_BM) stage_reg = ex.rsinv[min(m0 + tid, M - 1)];
+            }
+        } else if (step == 1) {
+            if constexpr (LOGIT) {
+                lg_p0 = __builtin_amdgcn_readfirstlane(p0_reg);
+                lg_pl = __builtin_amdgcn_readfirstlane(pl_reg);
+                lg_uni = lg_p0 >= 0 && lg_p0 == lg_pl;
+                if (lg_uni && tid < 320) stage_reg = tid < N ? ex.E[(int64_t)lg_p0 * ex.ld_e + tid] : 0.f;
+            }
+            if constexpr (PROD) {
+                if (tid < TL_BM) xs[960 + tid] = stage_reg;
+            }
+        } else {
+            if constexpr (LOGIT) {
+                if (lg_uni && tid < 320) xs[640 + tid] = stage_reg;
+            }
+        }
+    };
+    auto epilogue = [&](int b) __attribute__((always_inline)) {       // block b's accumulators -> Y (and the logit partial sums), then cleared
+        const int m0 = b * TL_BM;
+        float cs[NTW], bv[NTW], le[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int col = wn * (16 * NTW) + j * 16 + r16;
+            cs[j] = xs[col], bv[j] = xs[320 + col];
+            le[j] = LOGIT ? xs[640 + col] : 0.f;
+        }
+        auto rows = [&](auto uni_tag) __attribute__((always_inline)) {
+            constexpr bool UNI = decltype(uni_tag)::value;            // LOGIT: the whole block reads one embedding row (le[])
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int lrow = wm * 64 + i * 16 + 4 * kh + e, row = m0 + lrow;
+                    const bool row_ok = row < M;
+                    const int64_t rc = min(row, M - 1);
+                    float rsc = 1.0f;
+                    if constexpr (PROD) rsc = xs[960 + lrow];
+                    int pr = -1;
+                    if constexpr (LOGIT && !UNI) pr = row_ok ? ex.row_pred[rc] : -1;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const int col = wn * (16 * NTW) + j * 16 + r16;
+                        float v = acc[i][j][e] * cs[j];
+                        if constexpr (PROD) {
+                            v *= rsc;
+                            if (ex.accumulate) v += Y[rc * ldy + min(col, N - 1)];
+                        } else {
+                            v += bv[j];
+                        }
+                        if (row_ok && col < N) Y[(int64_t)row * ldy + col] = v;
+                        if constexpr (LOGIT) {
+                            if constexpr (UNI) sum += tl_sigmoid(v) * le[j];          // (le = 0 in the columns past N)
+                            else if (pr >= 0 && col < N) sum += tl_sigmoid(v) * ex.E[(int64_t)pr * ex.ld_e + col];
+                        }
+                        acc[i][j][e] = 0.f;
+                    }
+                    if constexpr (LOGIT) {
+#pragma unroll
+                        for (int sh = 1; sh < 16; sh <<= 1) sum += __shfl_xor(sum, sh, 64);
+                        if (r16 == 0 && row_ok) ex.x_part[(int64_t)wn * ex.ld_xp + row] = sum;
+                    }
+                }
+        };
+        if (LOGIT && lg_uni) rows(std::true_type());                  // (uniform)
+        else rows(std::false_type());
+    };
+
+    // ---- the stream
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
+    const std::integral_constant<int, 2> S2;
+    const std::integral_constant<int, 3> S3;
+    fetch_row_state(first);
+    load_x(S0);
+    load_w();
+    load_x(S1);
+    load_x(S2);
+    load_x(S3);
+    switch_row_state();
+    load_e();
+    store_b(0);
+    load_w();
+    store_a(S0, 0);
+    load_x(S0);
+    __syncthreads();
+    int g = 0, cks = 0, cb = first;                                   // the step being multiplied: index in the stream, step and block
+    auto body = [&](auto next_tag) __attribute__((always_inline)) {  // next_tag: the X set of step g + 1
+        const int cur = (g & 1) * BUF, nxt = BUF - cur;
+        if constexpr (PROD) {
+            if (sks == 0) switch_row_state();                         // (uniform) step g + 1 opens a block
+        }
+        if (cks < 3) epilogue_stage(cb, cks);                         // (uniform)
+        load_e();
+        store_b(nxt);                                                 // (the weight tiles of step g + 1, requested a step ago)
+        load_w();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(next_tag, nxt);                                       // under the tail of the MFMAs; frees the register set ...
+        load_x(next_tag);                                             // ... for the rows four steps on
+        __syncthreads();                                              // buffer nxt complete, buffer cur fully read
+        ++g;
+        if (++cks == ksteps) {                                        // (uniform) the block is done
+            epilogue(cb);
+            cks = 0;
+            cb += stride;
+        }
+    };
+    while (g < T) {
+        body(S1);
+        if (g < T) body(S2);
+        if (g < T) body(S3);
+        if (g < T) body(S0);
+    }
+}
+
+template <int MODE>
+static int tall_launch(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                       const TlExtra& ex, void* stream, const char* name) {
+    const int ksteps = dfol_cdiv(K, TL_BK), nbn = dfol_cdiv(N, 128);
+    const int ntw = dfol_cdiv(N, 64);                                 // 16-column tiles per wavefront: 4 (N <= 256) or 5 (N <= 320)
+    DFOL_REQUIRE(ntw <= 5, "%s: N=%d must be <= 320", name, N);
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int nblocks = dfol_cdiv(M, TL_BM);
+    const int grid = std::min(nblocks, cus);
+    const int nbn_lds = ntw <= 4 ? 2 : 3;
+    const size_t lds = (size_t)2 * (TL_TILE + nbn_lds * TL_TILE) * 16 + 1088 * 4;
+    hipStream_t st = (hipStream_t)stream;
+#define DFOL_TALL(NT)                                                                                                                       \
+    {                                                                                                                                      \
+        static const hipError_t ok = hipFuncSetAttribute((const void*)tall_h2_kernel<NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                        (int)((size_t)2 * (TL_TILE + ((64 * NT + 127) / 128) * TL_TILE) * 16 + 1088 * 4)); \
+        DFOL_REQUIRE(ok == hipSuccess, "%s: cannot reserve %zu bytes of LDS (%s)", name, lds, hipGetErrorString(ok));                       \
+        hipLaunchKernelGGL((tall_h2_kernel<NT, MODE>), dim3(grid), dim3(512), lds, st, X, ldx, (const u32x4*)W_split, bias, Y, ldy, M, N, K,  \
+                           ksteps, nbn, ex);                                                                                               \
+    }
+    if (ntw <= 4) DFOL_TALL(4) else DFOL_TALL(5)
+#undef DFOL_TALL
+    DFOL_LAUNCH_CHECK(name);
+    return 0;
+}
+
+}  // namespace
+
+// The shapes the persistent kernel takes (the callers fall back to csrc/dfol_dense_split.hip otherwise)
+extern "C" int dfol_linear_tall_supported(int64_t M, int32_t N, int32_t K) {        // (K >= 100: four steps per block, see epilogue_stage)
+    return M >= 16384 && M < (1ll << 31) - 256 && N >= 16 && N <= 320 && K >= 100 && K % 4 == 0;
+}
+
+// Y = X W^T + b, fp32 results from two fp16 pieces per operand (bit for bit dfol_linear_act_h2_f32 with no activation); M >= 16384, N <= 320.
+// x_part != NULL: also the logit layer's partial sums, FOUR slots: x_part[s][r] = sum over the s-th quarter of the (padded) columns of
+// Sigmoid(Y[r][j]) E[row_pred[r]][j] (row_pred non-decreasing, see dfol_linear_logit_h2_f32).
+extern "C" int dfol_linear_tall_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N,
+                                       int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp, void* stream) {
+    DFOL_REQUIRE(dfol_linear_tall_supported(M, N, K) && ldx % 4 == 0 && ldx >= K && ldy >= N, "linear_tall_h2: bad sizes M=%d N=%d K=%d (M >= 16384, N <= 320, K, ldx multiples of 4)", M, N, K);
+    DFOL_REQUIRE(X && W_split && Y, "linear_tall_h2: null pointer");
+    DFOL_REQUIRE(((uintptr_t)X % 16 == 0) && ((uintptr_t)W_split % 16 == 0), "linear_tall_h2: X and W_split must be 16-byte aligned");
+    if (x_part) {
+        DFOL_REQUIRE(row_pred && E && ld_e >= N && ld_xp >= M, "linear_tall_h2: the logit partial sums need row_pred, E [P, >= N] and x_part [4, >= M]");
+        const TlExtra ex = {nullptr, nullptr, row_pred, E, ld_e, 0, x_part, ld_xp};
+        return tall_launch<2>(X, ldx, W_split, bias, Y, ldy, M, N, K, ex, stream, "linear_tall_h2 (logit)");
+    }
+    const TlExtra ex = {nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
+    return tall_launch<0>(X, ldx, W_split, bias, Y, ldy, M, N, K, ex, stream, "linear_tall_h2");
+}
+
+// dZ (+)= dpre2 W2 as dfol_pair_dz_fused_f32 (same operands, same results bit for bit), persistent form; workspace: 2 M floats
+extern "C" int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
+                                     const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t H1, int32_t H2,
+                                     int32_t accumulate, float* workspace, void* stream) {
+    DFOL_REQUIRE(dfol_linear_tall_supported(M, H1, H2) && ld_p2 % 4 == 0 && ld_p2 >= H2 && ld_e % 4 == 0 && ld_e >= H2 && ld_dz >= H1,
+                 "pair_dz_tall: bad sizes M=%d H1=%d H2=%d", M, H1, H2);
+    DFOL_REQUIRE(pre2 && dx && row_pred && E && emax && W2t_split && dZ && workspace, "pair_dz_tall: null pointer");
+    DFOL_REQUIRE(((uintptr_t)pre2 % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)W2t_split % 16 == 0), "pair_dz_tall: pre2, E and the packed weights must be 16-byte aligned");
+    float* gs = workspace;
+    float* rsinv = workspace + M;
+    hipLaunchKernelGGL(tall_row_scale_kernel, dim3(dfol_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, dx, row_pred, emax, M, gs, rsinv);
+    DFOL_LAUNCH_CHECK("pair_dz_tall (row scales)");
+    const TlExtra ex = {gs, rsinv, row_pred, E, ld_e, accumulate, nullptr, 0};
+    return tall_launch<1>(pre2, ld_p2, W2t_split, nullptr, dZ, ld_dz, M, H1, H2, ex, stream, "pair_dz_tall");
+}

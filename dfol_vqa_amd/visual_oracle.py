@@ -315,7 +315,12 @@ class _PairTrunk(torch.autograd.Function):
         w = weight.detach()
         w = w if w.is_contiguous() else w.contiguous()
         b = None if bias is None else bias.detach()
-        if first is not None and _lib._dense_math() == "f16x2":
+        f16x2 = _lib._dense_math() == "f16x2"
+        if f16x2 and L.linear_tall_supported(z.shape[0], w.shape[0], w.shape[1]):
+            # one persistent workgroup per CU over the row blocks (csrc/dfol_dense_tall.hip): the same bits, 1.9 ms against 2.6 at 256 x 100 objects
+            pre2, x_part = L.linear_tall_h2(z, w, b, *((first[1], first[0]) if first is not None else ()))
+            x_part = z.new_zeros(0) if x_part is None else x_part
+        elif first is not None and f16x2:
             pre2, x_part = L.linear_logit_h2(z, w, b, first[1], first[0])
         else:
             pre2, x_part = L.linear_act_split(z, w, b, L.ACT_NONE), z.new_zeros(0)

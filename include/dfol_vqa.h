@@ -445,6 +445,16 @@ int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int
  * s < 2 ceil(N / 128) (row_pred < 0: 0) - dfol_pair_logit_fwd_f32 without its pass over Y (the caller adds a row's slots and the bias). */
 int dfol_linear_logit_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N,
                              int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp, void* stream);
+/* The same two tall products (Y = X W^T + b with the optional logit partial sums; dZ (+)= dpre2 W2) as ONE persistent workgroup per CU that
+ * walks 128-row blocks over all columns (csrc/dfol_dense_tall.hip): M >= 16384, N <= 320 (dfol_linear_tall_supported), results bit for bit
+ * those of dfol_linear_act_h2_f32 / dfol_pair_dz_fused_f32.  linear_tall_h2: x_part (or NULL) has FOUR slots [4, ld_xp >= M], one per
+ * quarter of the padded columns.  pair_dz_tall: workspace of 2 M floats (the rows' scaled dx and un-scaling factors). */
+int dfol_linear_tall_supported(int64_t M, int32_t N, int32_t K);
+int dfol_linear_tall_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N,
+                            int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp, void* stream);
+int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
+                          const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t HID1, int32_t HID2,
+                          int32_t accumulate, float* workspace, void* stream);
 int dfol_pair_logit_bwd_sums_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
                                  const int64_t* pred_off, int32_t P, float* dE, int64_t ld_de, float* dbe, float* dB2, int64_t ld_db2, void* stream);
 int dfol_pair_dz_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,

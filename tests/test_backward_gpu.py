@@ -977,3 +977,45 @@ def test_deferred_head_backward_equals_the_materialised_one(kinds, monkeypatch):
         assert float((g1[k] - g0[k]).abs().max()) <= 3e-5 * scale + 1e-12, (k, float((g1[k] - g0[k]).abs().max()), scale)
         seen += scale > 0
     assert seen >= 8
+
+
+@pytest.mark.parametrize("M,N,K", [(16384 + 77, 300, 256), (9900 * 4, 256, 300), (40000, 200, 100), (128 * 300 + 5, 320, 128)])
+def test_tall_products_equal_the_tiled_kernels_bit_for_bit(M, N, K, monkeypatch):
+    """csrc/dfol_dense_tall.hip (one persistent workgroup per CU over 128-row blocks and all columns) against csrc/dfol_dense_split.hip
+    (128 x 128 tiles) on the same operands: the forward product with and without the logit partial sums, and the input-gradient product
+    with dpre2 produced in the kernel, plain and accumulating - bit for bit (same pieces, same order of the products)."""
+    from dfol_vqa_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / 8
+    b = torch.randn(N, device=DEV, generator=g)
+    P = 5
+    E = torch.randn(P, N, device=DEV, generator=g) * 0.3
+    cnt = np.full(P, M // P, np.int64)
+    cnt[-1] += M - cnt.sum()
+    rep = torch.as_tensor(np.repeat(np.arange(P), cnt).astype(np.int32)).to(DEV)
+    pred_off = torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(DEV)
+    assert _lib.linear_tall_supported(M, N, K)
+    with _lib.dense_math("f16x2"):
+        y_ref = _lib.linear_act_split(x, w, b, _lib.ACT_NONE)
+        y, none = _lib.linear_tall_h2(x, w, b)
+        y2, xp = _lib.linear_tall_h2(x, w, b, rep, E)
+    assert none is None and torch.equal(y, y_ref) and torch.equal(y2, y_ref)
+    want = _lib.pair_logit_fwd(y_ref, E, None, pred_off, int(cnt.max()))
+    h = torch.sigmoid(y_ref.double())
+    exact = (h * E.double()[rep.long()]).sum(1)
+    mag = (h * E.double()[rep.long()].abs()).sum(1)
+    assert ((xp.sum(0).double() - exact).abs() <= 4e-6 * mag + 1e-7).all() and ((want.double() - exact).abs() <= 4e-6 * mag + 1e-7).all()
+    # the input-gradient product: here x plays pre2 [M, K = HID2], the result is [M, N = HID1]
+    if N <= 256:
+        Ek = torch.randn(P, K, device=DEV, generator=g) * 0.3
+        dx = torch.randn(M, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (M,), device=DEV, generator=g).float())
+        wt = torch.randn(K, N, device=DEV, generator=g) / 8                                # W2 [HID2, HID1]
+        zz = torch.randn(M, N, device=DEV, generator=g)
+        outs = []
+        for tall in ("1", "0"):
+            monkeypatch.setenv("DFOL_TALL", tall)
+            dz, _ = _lib.pair_head_products(dx, x, zz, wt, Ek, pred_off, rep, need_dw=False)
+            dz2, _ = _lib.pair_head_products(dx, x, zz, wt, Ek, pred_off, rep, need_dw=False, dz_out=dz.clone())
+            outs.append((dz, dz2))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

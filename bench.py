@@ -978,6 +978,19 @@ def train_kernel_rooflines(args, per_step):
     add("dfol_pair_hidden1_bwd_f32", "pair_hidden1_bwd (dU, dV, dWg reduced per image, no atomics)", "hbm", pairs * (8.0 * H1 + 16), "pairs x (8 HID1 + 16) B read")
     add("dfol_pair_logit_fwd_f32", "pair_logit_fwd (Sigmoid . embedding row -> logit)", "hbm", pairs * (4.0 * H2 + 4), "pairs x (4 HID2 + 4) B")
     add("dfol_pair_logit_bwd_f32", "pair_logit_bwd (dP2, dE, db in one pass)", "hbm", pairs * (8.0 * H2 + 4), "pairs x (8 HID2 + 4) B")
+    # round 4: the head's backward without dpre2 in memory, and the tall products as one persistent workgroup per CU - all four stream the
+    # per-pair activations once; the two with MFMAs execute three fp16 products per algorithmic product on top
+    mm = lambda rate_bytes, bytes_per_pair: {"executed": {"mfma_flops_per_algorithmic_flop": 3, "achieved": 3 * 2.0 * H2 * H1 * (rate_bytes / bytes_per_pair) / 1e12,
+                                                          "frac": 3 * 2.0 * H2 * H1 * (rate_bytes / bytes_per_pair) / BF16_MFMA_PEAK}}
+    add("dfol_linear_tall_h2_f32", "tall_h2_kernel<5, 2> (pre2 = Z W2^T + b2 written once, Z read once, the logit partial sums from the epilogue)", "hbm",
+        pairs * (4.0 * H1 + 4 * H2 + 16), "pairs x (4 HID1 + 4 HID2 + 16) B", extra=lambda r: mm(r, 4.0 * H1 + 4 * H2 + 16))
+    add("dfol_pair_dz_tall_f32", "tall_h2_kernel<4, 1> (dZ = dpre2 W2, dpre2 rebuilt from pre2; + the row-scale pass)", "hbm",
+        pairs * (4.0 * H2 + 4 * H1 + 24), "pairs x (4 HID2 + 4 HID1 + 24) B", extra=lambda r: mm(r, 4.0 * H2 + 4 * H1 + 24))
+    add("dfol_pair_dz_fused_f32", "linear_act_split_kernel<.., 1> (dZ = dpre2 W2, dpre2 rebuilt from pre2; tiled form)", "hbm",
+        pairs * (4.0 * H2 + 4 * H1 + 8), "pairs x (4 HID2 + 4 HID1 + 8) B", extra=lambda r: mm(r, 4.0 * H2 + 4 * H1 + 8))
+    add("dfol_pair_wgrad_fused_f32", "pair_wgrad_fused_kernel<3> (dW2 = dpre2^T Z, pre2 and Z read once) + reduce", "hbm",
+        pairs * (4.0 * H2 + 4 * H1 + 8), "pairs x (4 HID2 + 4 HID1 + 8) B", extra=lambda r: mm(r, 4.0 * H2 + 4 * H1 + 8))
+    add("dfol_pair_logit_bwd_sums_f32", "pair_logit_bwd4_kernel (dE, dbe, db2 sums; no dpre2 written)", "hbm", pairs * (4.0 * H2 + 4), "pairs x (4 HID2 + 4) B")
     add("dfol_relate_bwd_f32", "relate_bwd (tile read twice, gradient tile written)", "hbm", Q * (12.0 * N * N + 24 * N), "P x (12 N^2 + 24 N) B")
     add("dfol_filter_bwd_f32", "filter_bwd", "hbm", per_step.get("dfol_filter_bwd_f32", (1, 1))[0] * Q * 16.0 * N, "launches x P x 16 N B")
     add("dfol_quantify_bwd_f32", "quantify_bwd", "hbm", Q * (8.0 * N + 4), "P x (8 N + 4) B")

@@ -853,28 +853,30 @@ def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, 
     H1 = z.shape[1]
     dev = p2.device
     emax = e_rows.abs().amax(1)
-    dz = dw = None
+    dz = dw = scale = None
     if need_dz:
         dz = dz_out if dz_out is not None else torch.empty(M, H1, dtype=F32, device=dev)
         if linear_tall_supported(M, H1, H2):
-            ws = torch.empty(2 * M, dtype=F32, device=dev)
+            ws = torch.empty(2 * M + 4, dtype=F32, device=dev)
+            scale = ws[2 * M + 1:2 * M + 3]                    # {S, 1 / S} of the launch's largest bound: the weight gradient's scale, from the same pass
             call("dfol_pair_dz_tall_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(emax, F32),
                  _ptr(linear_pack_w_split(w2, True, 2), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _ptr(ws),
                  _stream())
         else:
             call("dfol_pair_dz_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(emax, F32),
              _ptr(linear_pack_w_split(w2, True, 2), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _stream())
-    if need_dw:
+    if need_dw and scale is None:
         # one power of two for the weight gradient's fp16 pieces: S max_r |dx[r]| emax[p(r)] / 4 in [2^13, 2^14) (device-side: no sync)
         bound = (dx.abs() * emax.index_select(0, row_pred)).amax() * 0.25
         _, ex = torch.frexp(bound)
         ok = torch.isfinite(bound) & (bound > 0)
         sexp = torch.where(ok, (14 - ex).clamp(-100, 100), torch.zeros_like(ex)).to(F32)
         scale = torch.stack([torch.exp2(sexp), torch.exp2(-sexp)]).contiguous()
+    if need_dw:
         ws = torch.empty(load().dfol_pair_wgrad_fused_workspace(M, H2, H1), dtype=F32, device=dev)
         dw = torch.empty(H2, H1, dtype=F32, device=dev)
         call("dfol_pair_wgrad_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(pred_off, torch.int64), _ptr(e_rows, F32),
-             e_rows.stride(0), _ptr(scale, F32), _dp(z), z.stride(0), M, H2, H1, _ptr(ws), _ptr(dw), _stream())
+             e_rows.stride(0), _dp(scale), _dp(z), z.stride(0), M, H2, H1, _ptr(ws), _ptr(dw), _stream())
     return dz, dw
 
 

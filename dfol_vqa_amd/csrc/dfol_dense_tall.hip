@@ -69,14 +69,22 @@ struct TlExtra {
 };
 
 // MODE 1's per-row scaling: e_r puts the bound |dx[r]| max|E[p]| / 4 into [2^13, 2^14)  (the rule of csrc/dfol_dense_split.hip, LsProducer)
+// bound_max (or null): the largest bound of the launch, as the bits of a non-negative float (their order is the integers' order, and a
+// maximum does not depend on the order of its updates: the atomic keeps the run repeatable); zeroed by the launcher
 __global__ __launch_bounds__(256) void tall_row_scale_kernel(const float* __restrict__ dx, const int32_t* __restrict__ row_pred,
                                                              const float* __restrict__ emax, int M, float* __restrict__ gs,
-                                                             float* __restrict__ rsinv) {
+                                                             float* __restrict__ rsinv, uint32_t* __restrict__ bound_max) {
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    if (r >= M) return;
-    const int p = row_pred[r];
+    const int p = r < M ? row_pred[r] : -1;
     const float gg = p >= 0 ? dx[r] : 0.f;
     const float bound = fabsf(gg) * emax[max(p, 0)] * 0.25f;
+    if (bound_max) {
+        float m = bound < 3.0e38f ? bound : 0.f;                      // (a non-finite bound leaves the scale at one; the products show the NaN)
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(bound_max, __float_as_uint(m));
+    }
+    if (r >= M) return;
     int e = 0;
     if (bound > 0.f && bound < 3.0e38f) {
         int x;
@@ -424,7 +432,24 @@ extern "C" int dfol_linear_tall_h2_f32(const float* X, int64_t ldx, const void* 
     return tall_launch<0>(X, ldx, W_split, bias, Y, ldy, M, N, K, ex, stream, "linear_tall_h2");
 }
 
-// dZ (+)= dpre2 W2 as dfol_pair_dz_fused_f32 (same operands, same results bit for bit), persistent form; workspace: 2 M floats
+// {S, 1 / S} for dfol_pair_wgrad_fused_f32 from the launch's largest bound: S a power of two with S bound in [2^13, 2^14) (one when
+// the bound is zero)
+__global__ void tall_wgrad_scale_kernel(const float* __restrict__ bound_max, float* __restrict__ scale) {
+    const float b = bound_max[0];
+    int e = 0;
+    if (b > 0.f && b < 3.0e38f) {
+        int x;
+        (void)frexpf(b, &x);
+        e = 14 - x;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    }
+    scale[0] = ldexpf(1.0f, e);
+    scale[1] = ldexpf(1.0f, -e);
+}
+
+// dZ (+)= dpre2 W2 as dfol_pair_dz_fused_f32 (same operands, same results bit for bit), persistent form; workspace: 2 M + 4 floats (the
+// rows' scaled dx and un-scaling factors; then max_r |dx[r]| emax[row_pred[r]] / 4 and {S, 1 / S} of it, what dfol_pair_wgrad_fused_f32
+// takes as `scale`: workspace + 2 M + 1)
 extern "C" int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
                                      const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t H1, int32_t H2,
                                      int32_t accumulate, float* workspace, void* stream) {
@@ -434,7 +459,11 @@ extern "C" int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const flo
     DFOL_REQUIRE(((uintptr_t)pre2 % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)W2t_split % 16 == 0), "pair_dz_tall: pre2, E and the packed weights must be 16-byte aligned");
     float* gs = workspace;
     float* rsinv = workspace + M;
-    hipLaunchKernelGGL(tall_row_scale_kernel, dim3(dfol_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, dx, row_pred, emax, M, gs, rsinv);
+    float* bound_max = workspace + 2 * (int64_t)M;
+    DFOL_REQUIRE(hipMemsetAsync(bound_max, 0, 4, (hipStream_t)stream) == hipSuccess, "pair_dz_tall: hipMemsetAsync failed");
+    hipLaunchKernelGGL(tall_row_scale_kernel, dim3(dfol_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, dx, row_pred, emax, M, gs, rsinv,
+                       reinterpret_cast<uint32_t*>(bound_max));
+    hipLaunchKernelGGL(tall_wgrad_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)bound_max, bound_max + 1);
     DFOL_LAUNCH_CHECK("pair_dz_tall (row scales)");
     const TlExtra ex = {gs, rsinv, row_pred, E, ld_e, accumulate, nullptr, 0};
     return tall_launch<1>(pre2, ld_p2, W2t_split, nullptr, dZ, ld_dz, M, H1, H2, ex, stream, "pair_dz_tall");

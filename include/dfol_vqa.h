@@ -448,7 +448,8 @@ int dfol_linear_logit_h2_f32(const float* X, int64_t ldx, const void* W_split, c
 /* The same two tall products (Y = X W^T + b with the optional logit partial sums; dZ (+)= dpre2 W2) as ONE persistent workgroup per CU that
  * walks 128-row blocks over all columns (csrc/dfol_dense_tall.hip): M >= 16384, N <= 320 (dfol_linear_tall_supported), results bit for bit
  * those of dfol_linear_act_h2_f32 / dfol_pair_dz_fused_f32.  linear_tall_h2: x_part (or NULL) has FOUR slots [4, ld_xp >= M], one per
- * quarter of the padded columns.  pair_dz_tall: workspace of 2 M floats (the rows' scaled dx and un-scaling factors). */
+ * quarter of the padded columns.  pair_dz_tall: workspace of 2 M + 4 floats (the rows' scaled dx and un-scaling factors, then the
+ * launch's largest bound and, at workspace + 2 M + 1, the {S, 1 / S} dfol_pair_wgrad_fused_f32 takes as `scale`). */
 int dfol_linear_tall_supported(int64_t M, int32_t N, int32_t K);
 int dfol_linear_tall_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N,
                             int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp, void* stream);

@@ -74,26 +74,32 @@ struct TlExtra {
 __global__ __launch_bounds__(256) void tall_row_scale_kernel(const float* __restrict__ dx, const int32_t* __restrict__ row_pred,
                                                              const float* __restrict__ emax, int M, float* __restrict__ gs,
                                                              float* __restrict__ rsinv, uint32_t* __restrict__ bound_max) {
-    const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    const int p = r < M ? row_pred[r] : -1;
-    const float gg = p >= 0 ? dx[r] : 0.f;
-    const float bound = fabsf(gg) * emax[max(p, 0)] * 0.25f;
-    if (bound_max) {
-        float m = bound < 3.0e38f ? bound : 0.f;                      // (a non-finite bound leaves the scale at one; the products show the NaN)
+    __shared__ float wmax[4];
+    float m = 0.f;
+    for (int r = blockIdx.x * 256 + (int)threadIdx.x; r < M; r += gridDim.x * 256) {      // (a fixed grid: one atomic per workgroup, ~1000 per launch)
+        const int p = row_pred[r];
+        const float gg = p >= 0 ? dx[r] : 0.f;
+        const float bound = fabsf(gg) * emax[max(p, 0)] * 0.25f;
+        int e = 0;
+        if (bound > 0.f && bound < 3.0e38f) {
+            int x;
+            (void)frexpf(bound, &x);
+            e = 14 - x;
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            m = fmaxf(m, bound);                                      // (a non-finite bound leaves the scale alone; the products show the NaN)
+        }
+        gs[r] = ldexpf(gg, e);
+        rsinv[r] = ldexpf(1.0f, -e);
+    }
+    if (!bound_max) return;
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(bound_max, __float_as_uint(m));
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.f) atomicMax(bound_max, __float_as_uint(m));
     }
-    if (r >= M) return;
-    int e = 0;
-    if (bound > 0.f && bound < 3.0e38f) {
-        int x;
-        (void)frexpf(bound, &x);
-        e = 14 - x;
-        e = e < -100 ? -100 : (e > 100 ? 100 : e);
-    }
-    gs[r] = ldexpf(gg, e);
-    rsinv[r] = ldexpf(1.0f, -e);
 }
 
 // NTW: 16-column tiles per wavefront (4 wavefronts across the columns: N <= 64 NTW); NBN = ceil(64 NTW / 128) column blocks of the packed image
@@ -461,7 +467,7 @@ extern "C" int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const flo
     float* rsinv = workspace + M;
     float* bound_max = workspace + 2 * (int64_t)M;
     DFOL_REQUIRE(hipMemsetAsync(bound_max, 0, 4, (hipStream_t)stream) == hipSuccess, "pair_dz_tall: hipMemsetAsync failed");
-    hipLaunchKernelGGL(tall_row_scale_kernel, dim3(dfol_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, dx, row_pred, emax, M, gs, rsinv,
+    hipLaunchKernelGGL(tall_row_scale_kernel, dim3(std::min(dfol_cdiv(M, 256), 1024)), dim3(256), 0, (hipStream_t)stream, dx, row_pred, emax, M, gs, rsinv,
                        reinterpret_cast<uint32_t*>(bound_max));
     hipLaunchKernelGGL(tall_wgrad_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)bound_max, bound_max + 1);
     DFOL_LAUNCH_CHECK("pair_dz_tall (row scales)");

@@ -19,11 +19,11 @@ E = torch.randn(Q, H2, device=dev, generator=g) * 0.1
 dx = torch.randn(M, device=dev, generator=g) * 1e-3
 pred_off = torch.arange(Q + 1, device=dev, dtype=torch.int64) * per
 rep = torch.arange(Q, device=dev, dtype=torch.int32).repeat_interleave(per)
-names = ["dfol_pair_logit_bwd_sums_f32", "dfol_pair_dz_fused_f32", "dfol_pair_wgrad_fused_f32"]
+names = ["dfol_pair_logit_bwd_sums_f32", "dfol_pair_dz_fused_f32", "dfol_pair_dz_tall_f32", "dfol_pair_wgrad_fused_f32"]
 for _ in range(2):
     _lib.pair_head_bwd(dx, p2, z, w2, E, pred_off, rep)
 _lib._timed = {k: [] for k in names}
 for _ in range(5):
     _lib.pair_head_bwd(dx, p2, z, w2, E, pred_off, rep)
 torch.cuda.synchronize()
-print(os.environ.get("DFOL_LIB", "default"), "  ".join("%s %.3f" % (k.replace("dfol_pair_", "").replace("_f32", ""), min(a.elapsed_time(b) for a, b in v)) for k, v in _lib._timed.items()))
+print(os.environ.get("DFOL_LIB", "default"), "  ".join("%s %.3f" % (k.replace("dfol_pair_", "").replace("_f32", ""), min(a.elapsed_time(b) for a, b in v)) for k, v in _lib._timed.items() if v))

@@ -2,7 +2,7 @@
 # HBM traffic of the train step's kernels (runs on the GPU box): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of
 # `bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0`, fp32 mode and bf16 mode -> gpurun_out/<tag>/train_traffic.md
 # usage: tools/train_traffic.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=gpurun_out/$TAG
@@ -33,9 +33,10 @@ def algorithmic(name, mode):
     if "pair_hidden1_fwd" in name: return pairs * (b * H1 + 16)
     if "pair_hidden1_bwd" in name: return pairs * (2 * b * H1 + 16)
     if "pair_logit_fwd" in name: return pairs * (b * H2 + 4)
-    if "pair_logit_bwd" in name: return pairs * (2 * b * H2 + 4)
+    if "pair_logit_bwd" in name: return pairs * ((2 if mode == "bf16" else 1) * b * H2 + 4)     # (fp32 mode, round 4: the sums only - dpre2 is not written)
+    if "tall_h2_kernel" in name or "pair_wgrad_fused_kernel" in name: return pairs * (H1 + H2) * b
     return None
-print("# HBM traffic of the train step's kernels, round 3 (N = 100, 256 questions; rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of")
+print("# HBM traffic of the train step's kernels, round 4 (N = 100, 256 questions; rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of")
 print("# `bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 [--mlp-math bf16]`; FETCH_SIZE in KiB x 2 as MI355X_MICROARCH.md prescribes")
 print("# for gfx950, WRITE_SIZE in KiB; per launch).  The two tall products and the pair layer's weight gradient: algorithmic = operands read once + result written.")
 for mode in ("fp32", "bf16"):

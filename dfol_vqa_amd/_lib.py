@@ -120,6 +120,8 @@ SIGNATURES = {
     "dfol_linear_logit_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "dfol_pair_dz_fused_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_wgrad_fused_workspace": [_i64, _i32, _i32],
+    "dfol_pair_wgrad_fused_sums_workspace": [_i64, _i32, _i32, _i32],
+    "dfol_pair_wgrad_fused_sums_f32": [_p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p],
     "dfol_pair_wgrad_fused_f32": [_p, _i64, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p],
     "dfol_linear_pack_w_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_split_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
@@ -166,6 +168,7 @@ def load():
     lib.dfol_pair_w2_f16x2_bytes.restype = ctypes.c_int64
     lib.dfol_linear_w_f16x2_bytes.restype = ctypes.c_int64
     lib.dfol_pair_wgrad_fused_workspace.restype = ctypes.c_int64
+    lib.dfol_pair_wgrad_fused_sums_workspace.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -845,10 +848,12 @@ def pair_head_sums(dx, p2, e_rows, pred_off, need_bias=True):
     return de, dbe, db2p
 
 
-def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, need_dw=True, dz_out=None):
+def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, need_dw=True, dz_out=None, sums=False, need_bias=True):
     """(dz [M, HID1], dW2 [HID2, HID1]) of one use: dz (+)= dpre2 W2 and dW2 = dpre2^T z with dpre2[r, j] = dx[r] E[row_pred[r], j] h (1 - h),
     h = Sigmoid(p2[r, j]), produced inside the two kernels.  dz_out: a previous use's dz to add to (in place).  row_pred [M] int32,
-    non-decreasing; pred_off [P + 1] int64."""
+    non-decreasing; pred_off [P + 1] int64.
+    sums=True (needs need_dw; every predicate owns >= 64 rows or none): the weight-gradient pass also returns the logit layer's sums -
+    (dz, dW2, dE [P, HID2], dbe [P] or None, db2 [HID2]) - and pair_head_sums' pass over p2 is not needed."""
     M, H2 = p2.shape
     H1 = z.shape[1]
     dev = p2.device
@@ -872,6 +877,17 @@ def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, 
         ok = torch.isfinite(bound) & (bound > 0)
         sexp = torch.where(ok, (14 - ex).clamp(-100, 100), torch.zeros_like(ex)).to(F32)
         scale = torch.stack([torch.exp2(sexp), torch.exp2(-sexp)]).contiguous()
+    if need_dw and sums:
+        P = e_rows.shape[0]
+        ws = torch.empty(load().dfol_pair_wgrad_fused_sums_workspace(M, H2, H1, P), dtype=F32, device=dev)
+        dw = torch.empty(H2, H1, dtype=F32, device=dev)
+        de = torch.empty(P, H2, dtype=F32, device=dev)
+        dbe = torch.empty(P, dtype=F32, device=dev) if need_bias else None
+        db2 = torch.empty(H2, dtype=F32, device=dev)
+        call("dfol_pair_wgrad_fused_sums_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(pred_off, torch.int64), P, _ptr(e_rows, F32),
+             e_rows.stride(0), _dp(scale), _dp(z), z.stride(0), M, H2, H1, _ptr(ws), _ptr(dw), _ptr(de), de.stride(0), _ptr(dbe, F32, True), _ptr(db2),
+             _stream())
+        return dz, dw, de, dbe, db2
     if need_dw:
         ws = torch.empty(load().dfol_pair_wgrad_fused_workspace(M, H2, H1), dtype=F32, device=dev)
         dw = torch.empty(H2, H1, dtype=F32, device=dev)
@@ -880,10 +896,14 @@ def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, 
     return dz, dw
 
 
-def pair_head_bwd(dx, p2, z, w2, e_rows, pred_off, row_pred, need_bias=True, dz_out=None):
+def pair_head_bwd(dx, p2, z, w2, e_rows, pred_off, row_pred, need_bias=True, dz_out=None, sums=False):
     """The backward of x = logit(Sigmoid(z W2^T + b2)) for ONE use of the hidden layer, without dpre2 in memory:
-    -> (dz [M, HID1], dW2 [HID2, HID1], db2 [HID2], dE [P, HID2], dbe [P] or None)."""
+    -> (dz [M, HID1], dW2 [HID2, HID1], db2 [HID2], dE [P, HID2], dbe [P] or None).  sums=True: the sums from the weight-gradient pass
+    (every predicate >= 64 rows or none), else from their own pass over p2."""
     e_rows = e_rows if e_rows.is_contiguous() else e_rows.contiguous()
+    if sums:
+        dz, dw, de, dbe, db2 = pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, dz_out=dz_out, sums=True, need_bias=need_bias)
+        return dz, dw, db2, de, dbe
     de, dbe, db2p = pair_head_sums(dx, p2, e_rows, pred_off, need_bias)
     dz, dw = pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, dz_out=dz_out)
     return dz, dw, db2p.sum(0), de, dbe

@@ -799,11 +799,16 @@ __device__ __forceinline__ float pw_dsigmoid(float x) {
 // operand entries) and its registers are refilled at once with the same rows of step s + 2: one register set is both the prefetch ring
 // and the work space.
 typedef uint32_t w3_u32x3 __attribute__((ext_vector_type(3)));
-template <int CPT>
+// SUMS: the sums of the logit layer's backward from the same pass (every h and dx is in registers here): per thread the running sums of
+// dx h (dE of the current predicate) and of dpre2 (db2) over its rows; the dE sums are flushed where the thread's rows cross into the
+// next predicate - its own first row past the boundary, or, for threads whose rows of the boundary step all lie before it, the step
+// after - into partials indexed by (slab + predicate, row octet), which pair_sums_reduce_kernel adds in a fixed order.  Needs every
+// predicate to own at least 32 rows (or none): a macro step then holds at most one boundary (the launcher's caller checks 64).
+template <int CPT, bool SUMS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_wgrad_fused_kernel(
     const float* __restrict__ P2, int64_t ld_p2, const float* __restrict__ G, const int32_t* __restrict__ RP, const int64_t* __restrict__ pred_off,
     const float* __restrict__ E, int64_t ld_e, const float* __restrict__ scale, const float* __restrict__ Z, int64_t ld_z, int M, int H2, int H1,
-    int rows_per_slab, float* __restrict__ part) {
+    int rows_per_slab, float* __restrict__ part, float* __restrict__ de_part, float* __restrict__ db_part) {
     extern __shared__ __attribute__((aligned(16))) w3_u32x4 pw_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m_begin = blockIdx.x * rows_per_slab, m_end = min(M, m_begin + rows_per_slab);
@@ -843,16 +848,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // The thread's constants (byte offsets of its loads, its columns) live in LDS and are re-read where they are used: registers that would
     // otherwise sit idle under the MFMAs, where accumulators + operand fragments + the row ring fill the 256 of a wavefront.
-    int* cst = reinterpret_cast<int*>(pw_lds + 2 * PW_BUF) + tid;      // [6][512]
+    int* cst = reinterpret_cast<int*>(pw_lds + 2 * PW_BUF) + tid;      // [2][512] words, then (SUMS) the threads' running sums [2 CPT][512]
     const int rs_p = (int)(ld_p2 * 4), rs_z = (int)(ld_z * 4);
     // the 16-byte LDS entry of column `col` (tile col >> 5, row col & 31 of the MFMA operand) for the eight rows of octet o
     auto entry = [&](int col, int o, int tiles) __attribute__((always_inline)) { return ((o >> 1) * 2 * tiles + (col >> 5)) * 64 + (col & 31) + 32 * (o & 1); };
-    cst[0] = (int)((8 * oa * ld_p2 + CPT * ca) * 4);                   // voff_a
-    cst[512] = (int)((8 * oz * ld_z + 2 * cz) * 4);                    // voff_z
-    cst[1024] = 8 * oa * 4;                                            // goff
-    cst[1536] = CPT * ca;                                              // the thread's first column of dpre2
-    cst[2048] = PW_A_ENT + entry(2 * cz, oz, PW_TB);                   // the entry of the thread's first Z column (the second: + 1)
-    cst[2560] = oa;
+    cst[0] = ca | (oa << 16);                                          // (two words per thread; everything else is derived where it is used)
+    cst[512] = cz | (oz << 16);
+    auto k_oa = [&]() __attribute__((always_inline)) { return cst[0] >> 16; };
+    auto k_col0 = [&]() __attribute__((always_inline)) { return CPT * (cst[0] & 0xffff); };                    // the thread's first column of dpre2
+    auto k_goff = [&]() __attribute__((always_inline)) { return 32 * (cst[0] >> 16); };                        // byte offset of its octet's dx
+    auto k_voff_a = [&]() __attribute__((always_inline)) { const int w = cst[0]; return (8 * (w >> 16) * (int)ld_p2 + CPT * (w & 0xffff)) * 4; };
+    auto k_voff_z = [&]() __attribute__((always_inline)) { const int w = cst[512]; return (8 * (w >> 16) * (int)ld_z + 2 * (w & 0xffff)) * 4; };
+    auto k_at_z = [&]() __attribute__((always_inline)) { const int w = cst[512]; return PW_A_ENT + entry(2 * (w & 0xffff), w >> 16, PW_TB); };   // entry of its first Z column
 
     struct Desc { __amdgpu_buffer_rsrc_t p, z, g; };
     auto descriptors = [&](int s) __attribute__((always_inline)) {     // step s (past the slab: empty ranges, every load returns zero)
@@ -864,24 +871,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return d;
     };
     auto load_a = [&](const Desc& d, int i) __attribute__((always_inline)) {           // row i of the thread's octet
-        const int voff_a = cst[0];
+        const int voff_a = k_voff_a();
         if constexpr (CPT == 3) xa[i] = __builtin_amdgcn_raw_buffer_load_b96(d.p, voff_a, i * rs_p, 0);
         else xa[i] = __builtin_amdgcn_raw_buffer_load_b128(d.p, voff_a, i * rs_p, 0);
     };
     auto load_z = [&](const Desc& d) __attribute__((always_inline)) {
-        const int voff_z = cst[512];
+        const int voff_z = k_voff_z();
 #pragma unroll
         for (int i = 0; i < 8; ++i) xz[i] = __builtin_amdgcn_raw_buffer_load_b64(d.z, voff_z, i * rs_z, 0);
     };
 
     // ---- building step s (its rows are in xa / xz) into `buf`, a chunk at a time; `next`: the descriptors of step s + 1, whose rows refill
     // the registers as they are released
+    // SUMS: the running sums live in LDS (the accumulators leave no register that survives the MFMAs: held in registers they were
+    // spilled to scratch and reloaded four times a step, 2.44 ms against 1.77 for the kernel without them) and are read, added to and
+    // written back by every pair of rows
+    float* sums = reinterpret_cast<float*>(pw_lds + 2 * PW_BUF) + 1024 + tid;      // [2 CPT][512]: dE sums, then db2 sums
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int t = 0; t < 2 * CPT; ++t) sums[512 * t] = 0.f;
+    }
+    auto flush_de = [&](int p) __attribute__((always_inline)) {        // this thread's dE sums of predicate p -> partial row (slab + p, octet); cleared
+        if constexpr (SUMS) {
+            float* o = de_part + (((int64_t)blockIdx.x + p) * 4 + k_oa()) * H2 + k_col0();
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) o[t] = sums[512 * t] * invS, sums[512 * t] = 0.f;
+        }
+    };
     bool same = false;
     float ev[CPT];
     w3_u32x2 gq;                                                       // dx of the row pair that comes next
     auto begin_a = [&](int s, const Desc& d) __attribute__((always_inline)) {          // before the first pair of rows
         if (is_a) {
-            const int goff = cst[1024], col0 = cst[1536];
+            const int goff = k_goff(), col0 = k_col0();
             const int first = m_begin + 32 * s + (goff >> 2);         // the octet's first row
             same = first + 7 < m_end && first + 7 < end_cur;          // (all eight rows exist and belong to p_cur)
 #pragma unroll
@@ -895,9 +917,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto pair_a = [&](int s, int k, const Desc& d, const Desc& next, uint32_t* __restrict__ buf32) __attribute__((always_inline)) {   // rows 2 k, 2 k + 1
         if (is_a) {
-            const int goff = cst[1024], col0 = cst[1536], o = cst[2560];
+            const int goff = k_goff(), col0 = k_col0(), o = k_oa();
             const int first = m_begin + 32 * s + (goff >> 2);
             float v[2][CPT];
+            float sde[SUMS ? CPT : 1], sdb[SUMS ? CPT : 1];            // this pair's share of the running sums (added to LDS once, below)
+#pragma unroll
+            for (int t = 0; t < (SUMS ? CPT : 1); ++t) sde[t] = sdb[t] = 0.f;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int i = 2 * k + r;
@@ -910,12 +935,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int t = 0; t < CPT; ++t) e[t] = er[t];
                 }
                 const float gs = __uint_as_float(gq[r]) * S;          // (rows past the slab were read as zero)
+                if constexpr (SUMS) {
+                    if (!same) {                                       // this thread's first row past the predicate's end: its sums so far belong to p_cur
+                        const int rr = first + i;
+                        if (rr >= end_cur && (i == 0 || rr - 1 < end_cur)) {
+#pragma unroll
+                            for (int t = 0; t < CPT; ++t) sums[512 * t] += sde[t], sde[t] = 0.f;       // (the pair's first row, if it lies before the end)
+                            flush_de(p_cur);
+                        }
+                    }
+                }
 #pragma unroll
 #ifndef PW_SKIP_SG
-                for (int t = 0; t < CPT; ++t) v[r][t] = (gs * e[t]) * pw_dsigmoid(__uint_as_float(xa[i][t]));
+                for (int t = 0; t < CPT; ++t) {
+                    const float hh = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * __uint_as_float(xa[i][t])));
+                    v[r][t] = (gs * e[t]) * (hh * (1.0f - hh));
+                    if constexpr (SUMS) {
+                        sde[t] = fmaf(gs, hh, sde[t]);
+                        sdb[t] += v[r][t];
+                    }
+                }
 #else
                 for (int t = 0; t < CPT; ++t) v[r][t] = (gs * e[t]) * __uint_as_float(xa[i][t]);
 #endif
+            }
+            if constexpr (SUMS) {
+#pragma unroll
+                for (int t = 0; t < CPT; ++t) sums[512 * t] += sde[t], sums[512 * (CPT + t)] += sdb[t];
             }
             if (k < 3) gq = __builtin_amdgcn_raw_buffer_load_b64(d.g, goff, 8 * (k + 1), 0);
             load_a(next, 2 * k);                                       // the same rows of the next step: in flight for a whole step
@@ -936,7 +982,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto columns_z = [&](const Desc& next, w3_u32x4* __restrict__ buf) __attribute__((always_inline)) {
         if (is_z) {
-            const int at = cst[2048];
+            const int at = k_at_z();
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 float v[8];
@@ -989,9 +1035,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         w3_u32x4* nxt = pw_lds + ((s + 1) & 1) * PW_BUF;
         uint32_t* nxt32 = reinterpret_cast<uint32_t*>(nxt);
         const bool more = s + 1 < steps;                               // (uniform) is there a step s + 1 to build
+        const int p_old = p_cur, end_old = end_cur;
         while (more && m_begin + 32 * (s + 1) >= end_cur) {            // (scalar; predicates without rows are stepped over)
             ++p_cur;
             end_cur = __builtin_amdgcn_readfirstlane((int)pred_off[p_cur + 1]);
+        }
+        if constexpr (SUMS) {
+            // the predicate ended inside step s: the threads whose octet of step s reached its end have flushed there, the others flush now
+            if (p_cur != p_old && is_a && m_begin + 32 * s + 8 * k_oa() + 7 < end_old) flush_de(p_old);
         }
         const Desc d1 = descriptors(s + 1), d2 = descriptors(s + 2);
         if (more) begin_a(s + 1, d1);
@@ -1021,6 +1072,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                               // step s + 1 is complete in LDS; everyone is past the MFMAs of step s
     }
 
+    if constexpr (SUMS) {
+        if (steps > 0 && is_a) {
+            const bool crossed = m_begin + 32 * (steps - 1) + 8 * k_oa() + 7 >= end_cur;      // (this thread's sums already belong to the next predicate)
+            if (!crossed) flush_de(p_cur);
+            if (end_cur < m_end) {                                     // (uniform) the slab's last rows open another predicate: its partial row is written by everyone
+                int p_nxt = p_cur + 1;
+                while ((int)pred_off[p_nxt + 1] <= end_cur) ++p_nxt;   // (predicates without rows)
+                flush_de(__builtin_amdgcn_readfirstlane(p_nxt));
+            }
+            float* o = db_part + ((int64_t)blockIdx.x * 4 + k_oa()) * H2 + k_col0();
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) o[t] = sums[512 * (CPT + t)] * invS;
+        }
+    }
     // D tile: column j = lane & 31, row i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int64_t stride = (((int64_t)H2 * H1) + 3) & ~(int64_t)3;
     float* out = part + (int64_t)blockIdx.x * stride;
@@ -1044,6 +1109,55 @@ extern "C" int64_t dfol_pair_wgrad_fused_workspace(int64_t M, int32_t H2, int32_
     return (int64_t)pw_slabs(M) * ((((int64_t)H2 * H1) + 3) & ~(int64_t)3);
 }
 
+// The partial sums of pair_wgrad_fused_kernel<.., true> in a fixed order.  Block p < P: dE[p][:] from the partial rows (slab + p, octet) of
+// the slabs that hold rows of p, and dbe[p] = the sum of dx over p's rows; block P: db2 from every slab's four octet rows.
+__global__ __launch_bounds__(320) void pair_sums_reduce_kernel(const float* __restrict__ de_part, const float* __restrict__ db_part,
+                                                               const float* __restrict__ dx, const int64_t* __restrict__ pred_off, int P, int H2,
+                                                               int slabs, int rows_per_slab, float* __restrict__ dE, int64_t ld_de,
+                                                               float* __restrict__ dbe, float* __restrict__ db2) {
+    __shared__ float red[320];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (p == P) {
+        if (tid < H2) {
+            float acc = 0.f;
+            for (int r = 0; r < slabs * 4; ++r) acc += db_part[(int64_t)r * H2 + tid];
+            db2[tid] = acc;
+        }
+        return;
+    }
+    const int64_t r0 = pred_off[p], r1 = pred_off[p + 1];
+    float acc = 0.f;
+    if (r1 > r0 && tid < H2) {
+        const int s0 = (int)(r0 / rows_per_slab), s1 = (int)((r1 - 1) / rows_per_slab);
+        for (int s = s0; s <= s1; ++s)
+            for (int o = 0; o < 4; ++o) acc += de_part[(((int64_t)s + p) * 4 + o) * H2 + tid];
+    }
+    if (tid < H2) dE[(int64_t)p * ld_de + tid] = acc;
+    if (dbe) {
+        float g = 0.f;
+        for (int64_t r = r0 + tid; r < r1; r += 320) g += dx[r];
+        red[tid] = g;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int i = 0; i < 320; ++i) t += red[i];
+            dbe[p] = t;
+        }
+    }
+}
+
+// floats of workspace for dfol_pair_wgrad_fused_sums_f32: the slabs' dW2 partials, then the dE partial rows ((slabs + P) x 4 x HID2)
+// and the db2 partial rows (slabs x 4 x HID2)
+extern "C" int64_t dfol_pair_wgrad_fused_sums_workspace(int64_t M, int32_t H2, int32_t H1, int32_t P) {
+    if (M <= 0 || H2 <= 0 || H1 <= 0 || P < 0) return 0;
+    const int64_t slabs = pw_slabs(M);
+    return slabs * ((((int64_t)H2 * H1) + 3) & ~(int64_t)3) + (2 * slabs + P) * 4 * (int64_t)H2;
+}
+
+static int pw_launch(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P, const float* E,
+                     int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t H2, int32_t H1, float* workspace, float* dW,
+                     float* dE, int64_t ld_de, float* dbe, float* db2, bool sums, void* stream);
+
 // scale: device pointer to {S, 1 / S}, S a power of two with S max_r(|dx[r]| max|E[row_pred[r]]|) / 4 <= 2^14 (see above)
 // row_pred [M]: NON-DECREASING valid rows of E (the pair rows of a predicate are contiguous), pred_off [P + 1]: the first pair row of every
 // predicate (row_pred[r] = p for pred_off[p] <= r < pred_off[p + 1], pred_off[P] = M); a row without a gradient carries dx = 0.
@@ -1051,6 +1165,23 @@ extern "C" int64_t dfol_pair_wgrad_fused_workspace(int64_t M, int32_t H2, int32_
 extern "C" int dfol_pair_wgrad_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off,
                                          const float* E, int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t H2,
                                          int32_t H1, float* workspace, float* dW, void* stream) {
+    return pw_launch(pre2, ld_p2, dx, row_pred, pred_off, 0, E, ld_e, scale, Z, ld_z, M, H2, H1, workspace, dW, nullptr, 0, nullptr, nullptr, false, stream);
+}
+
+// ... and the sums of the logit layer's backward from the same pass (no separate pass over pre2): dE [P, ld_de], dbe [P] (or NULL),
+// db2 [HID2].  EVERY predicate must own at least 64 pair rows or none (the caller checks; dfol_pair_logit_bwd_sums_f32 otherwise);
+// workspace: dfol_pair_wgrad_fused_sums_workspace floats.
+extern "C" int dfol_pair_wgrad_fused_sums_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off,
+                                              int32_t P, const float* E, int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M,
+                                              int32_t H2, int32_t H1, float* workspace, float* dW, float* dE, int64_t ld_de, float* dbe, float* db2,
+                                              void* stream) {
+    DFOL_REQUIRE(P > 0 && dE && db2 && ld_de >= H2 && H2 <= 320, "pair_wgrad_fused_sums: bad arguments P=%d", P);
+    return pw_launch(pre2, ld_p2, dx, row_pred, pred_off, P, E, ld_e, scale, Z, ld_z, M, H2, H1, workspace, dW, dE, ld_de, dbe, db2, true, stream);
+}
+
+static int pw_launch(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P, const float* E,
+                     int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t H2, int32_t H1, float* workspace, float* dW,
+                     float* dE, int64_t ld_de, float* dbe, float* db2, bool sums, void* stream) {
     DFOL_REQUIRE(M > 0 && M < (1ll << 31) - 64 && H2 >= 4 && H1 >= 4 && H2 % 4 == 0 && H1 % 4 == 0 && H2 <= 32 * PW_TA && H1 <= 32 * PW_TB,
                  "pair_wgrad_fused: bad sizes M=%lld H2=%d H1=%d (multiples of 4, H2 <= %d, H1 <= %d)", (long long)M, H2, H1, 32 * PW_TA, 32 * PW_TB);
     DFOL_REQUIRE(pre2 && dx && row_pred && pred_off && E && scale && Z && workspace && dW, "pair_wgrad_fused: null pointer");
@@ -1059,20 +1190,33 @@ extern "C" int dfol_pair_wgrad_fused_f32(const float* pre2, int64_t ld_p2, const
     DFOL_REQUIRE(8 * std::max(ld_p2, ld_z) * 4 * 4 < (1ll << 31), "pair_wgrad_fused: row stride too large (%lld)", (long long)std::max(ld_p2, ld_z));
     const int slabs = pw_slabs(M);
     const int rows_per_slab = (dfol_cdiv(M, slabs) + 31) & ~31;
-    const size_t lds = (size_t)2 * PW_BUF * 16 + 6 * 512 * 4;
-    static const hipError_t lds_ok3 = hipFuncSetAttribute((const void*)pair_wgrad_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)pair_wgrad_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    DFOL_REQUIRE(lds_ok == hipSuccess && lds_ok3 == hipSuccess, "pair_wgrad_fused: cannot reserve %zu bytes of LDS (%s)", lds, hipGetErrorString(lds_ok));
+    const size_t lds = (size_t)2 * PW_BUF * 16 + (2 + 6) * 512 * 4;          // (CPT = 4 with the sums: 2 + 8 words per thread - see DFOL_PW)
     const int64_t elems = (int64_t)H2 * H1;
+    float* de_part = workspace + (int64_t)slabs * ((elems + 3) & ~(int64_t)3);
+    float* db_part = de_part + ((int64_t)slabs + P) * 4 * H2;
     hipStream_t st = (hipStream_t)stream;
-    if (H2 % 3 == 0)                                                   // (4 (H2 / 3) <= 427 threads build dpre2)
-        hipLaunchKernelGGL(pair_wgrad_fused_kernel<3>, dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z, ld_z,
-                           (int)M, H2, H1, rows_per_slab, workspace);
-    else
-        hipLaunchKernelGGL(pair_wgrad_fused_kernel<4>, dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z, ld_z,
-                           (int)M, H2, H1, rows_per_slab, workspace);
+#define DFOL_PW(C, S)                                                                                                                           \
+    {                                                                                                                                          \
+        static const hipError_t ok = hipFuncSetAttribute((const void*)pair_wgrad_fused_kernel<C, S>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                        (int)((size_t)2 * PW_BUF * 16 + (2 + 6) * 512 * 4));                                     \
+        DFOL_REQUIRE(ok == hipSuccess, "pair_wgrad_fused: cannot reserve %zu bytes of LDS (%s)", lds, hipGetErrorString(ok));                      \
+        hipLaunchKernelGGL((pair_wgrad_fused_kernel<C, S>), dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z, \
+                           ld_z, (int)M, H2, H1, rows_per_slab, workspace, de_part, db_part);                                                   \
+    }
+    if (H2 % 3 == 0) {                                                 // (4 (H2 / 3) <= 427 threads build dpre2)
+        if (sums) DFOL_PW(3, true) else DFOL_PW(3, false)
+    } else {
+        DFOL_REQUIRE(!sums, "pair_wgrad_fused_sums: HID2=%d must be a multiple of 3 (the running sums of four columns per thread do not fit the LDS)", H2);
+        DFOL_PW(4, false)
+    }
+#undef DFOL_PW
     DFOL_LAUNCH_CHECK("pair_wgrad_fused");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 16)), dim3(256), 0, st, workspace, slabs, elems, dW);
     DFOL_LAUNCH_CHECK("pair_wgrad_fused (reduce)");
+    if (sums) {
+        hipLaunchKernelGGL(pair_sums_reduce_kernel, dim3(P + 1), dim3(320), 0, st, (const float*)de_part, (const float*)db_part, dx, pred_off, P, H2, slabs,
+                           rows_per_slab, dE, ld_de, dbe, db2);
+        DFOL_LAUNCH_CHECK("pair_wgrad_fused (sums reduce)");
+    }
     return 0;
 }

@@ -302,14 +302,15 @@ class _FusedLogit(torch.autograd.Function):
 
 class _PairTrunk(torch.autograd.Function):
     """pre2 = z W2^T + b2 for every pair row, as the ROOT of a deferred backward: the logit layers that read pre2 (`_HeadUse`, one per relation
-    operator group) do not send a [pairs, HID2] gradient back through autograd - they leave (dx, embedding rows, row ranges) in `uses` and
-    return a zero for the one-element `token` that ties them to this node.  Autograd runs this backward after all of them, and the two
-    products that consume dpre2 (dz = dpre2 W2, dW2 = dpre2^T z) rebuild it on the fly from pre2 (csrc/dfol_dense_split.hip LsProducer,
-    csrc/dfol_dense_wgrad.hip pair_wgrad_fused_kernel): 3 GB written and 6 GB read less per step at 256 x 100 objects.  A second use adds
-    into the same dz and dW2."""
+    operator group) do not send a [pairs, HID2] gradient back through autograd.  Each of them runs, in ITS backward, the two products that
+    consume dpre2 (dz (+)= dpre2 W2, dW2 = dpre2^T z) with dpre2 rebuilt on the fly from pre2 (csrc/dfol_dense_tall.hip /
+    dfol_dense_split.hip LsProducer, csrc/dfol_dense_wgrad.hip pair_wgrad_fused_kernel) - the weight-gradient pass also yields the reader's
+    own sums (dE, dbe) - leaves the results in `state`, which it shares with this node, and returns a zero for the one-element `token`
+    that ties it to this node.  Autograd runs this backward after all of them: it hands out what they accumulated.  3 GB written and 9 GB
+    read less per step at 256 x 100 objects."""
 
     @staticmethod
-    def forward(ctx, z, weight, bias, uses, first):
+    def forward(ctx, z, weight, bias, state, first):
         """first: None, or the first reader's (embedding rows [P, HID2] (detached), row -> embedding row [pairs] int32): its logit layer's
         forward then comes out of the product's epilogue as partial sums [slots, pairs] (no second pass over pre2)."""
         w = weight.detach()
@@ -324,42 +325,36 @@ class _PairTrunk(torch.autograd.Function):
             pre2, x_part = L.linear_logit_h2(z, w, b, first[1], first[0])
         else:
             pre2, x_part = L.linear_act_split(z, w, b, L.ACT_NONE), z.new_zeros(0)
-        ctx.save_for_backward(z, weight, pre2)
-        ctx.uses, ctx.has_bias = uses, bias is not None
+        state.update(z=z.detach(), w=w, pre2=pre2, need_dz=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
+                     need_db=bias is not None and ctx.needs_input_grad[2], dz=None, dw=None, db=None)
+        ctx.state, ctx.shapes = state, (z.shape, weight.shape)
         ctx.mark_non_differentiable(pre2, x_part)
         return pre2, z.new_zeros(1), x_part
 
     @staticmethod
     def backward(ctx, _g_pre2, _g_token, _g_part):
-        z, weight, pre2 = ctx.saved_tensors
-        need_dz, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dz = dw = db = None
-        with _lib.dense_math("f16x2"):
-            for dx, e_rows, pred_off, row_pred, db2p in ctx.uses:
-                dz_u, dw_u = L.pair_head_products(dx, pre2, z, weight.detach(), e_rows, pred_off, row_pred, need_dz, need_dw, dz_out=dz)
-                dz = dz_u if need_dz else None
-                if need_dw:
-                    dw = dw_u if dw is None else dw + dw_u
-                if ctx.has_bias and ctx.needs_input_grad[2]:
-                    db = db2p.sum(0) if db is None else db + db2p.sum(0)
-        ctx.uses = None
-        if need_dz and dz is None:
-            dz = torch.zeros_like(z)
-        if need_dw and dw is None:
-            dw = torch.zeros_like(weight)
-        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
-            db = torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device)
+        st = ctx.state
+        dz, dw, db = st["dz"], st["dw"], st["db"]
+        dev = st["w"].device
+        if st["need_dz"] and dz is None:
+            dz = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+        if st["need_dw"] and dw is None:
+            dw = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
+        if st["need_db"] and db is None:
+            db = torch.zeros(ctx.shapes[1][0], dtype=torch.float32, device=dev)
+        st.clear()                                           # (the activations must not outlive the step through this dictionary)
         return dz, dw, db, None, None
 
 
 class _HeadUse(torch.autograd.Function):
-    """x[r] = Sigmoid(pre2[r]) . E[p(r)] + be[p(r)] (the forward of `_FusedLogit`) on a `_PairTrunk`: the backward computes the embedding rows'
-    gradients and this use's part of the second layer's bias gradient in one pass over pre2, and defers the rest to the trunk."""
+    """x[r] = Sigmoid(pre2[r]) . E[p(r)] + be[p(r)] (the forward of `_FusedLogit`) on a `_PairTrunk`; the backward does this reader's share of
+    the trunk's backward (see there).  sums_ok: every predicate owns at least 64 pair rows or none - the embedding rows' gradients then come
+    out of the weight-gradient pass; otherwise (and when the second layer's weights do not train) from a pass of their own over pre2."""
 
     @staticmethod
-    def forward(ctx, token, pre2, e_rows, be_rows, pred_off, row_pred, max_rows, uses, x_part):
+    def forward(ctx, token, pre2, e_rows, be_rows, pred_off, row_pred, max_rows, state, x_part, sums_ok):
         ctx.save_for_backward(pre2, e_rows, pred_off, row_pred)
-        ctx.uses = uses
+        ctx.state, ctx.sums_ok = state, bool(sums_ok)
         if x_part is not None:                                # the trunk's epilogue has this reader's partial sums already
             return x_part.sum(0) + be_rows.index_select(0, row_pred)
         return L.pair_logit_fwd(pre2, e_rows, be_rows, pred_off, max_rows)
@@ -367,11 +362,25 @@ class _HeadUse(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx):
         pre2, e_rows, pred_off, row_pred = ctx.saved_tensors
+        st = ctx.state
         dx = dx.contiguous()
         e_rows = e_rows if e_rows.is_contiguous() else e_rows.contiguous()
-        de, dbe, db2p = L.pair_head_sums(dx, pre2, e_rows, pred_off, need_bias=ctx.needs_input_grad[3])
-        ctx.uses.append((dx, e_rows, pred_off, row_pred, db2p))
-        return dx.new_zeros(1), None, de, dbe, None, None, None, None, None
+        need_be = ctx.needs_input_grad[3]
+        mode = os.environ.get("DFOL_HEAD_SUMS", "auto")       # "1" / "0": always / never take the sums from the weight-gradient pass (where it can)
+        if ctx.sums_ok and st["need_dw"] and pre2.shape[1] % 3 == 0 and mode != "0" and (mode == "1" or pre2.shape[0] >= (1 << 20)):
+            dz, dw, de, dbe, db2 = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], True, dz_out=st["dz"],
+                                                        sums=True, need_bias=need_be)
+        else:
+            de, dbe, db2p = L.pair_head_sums(dx, pre2, e_rows, pred_off, need_bias=need_be)
+            db2 = db2p.sum(0) if st["need_db"] else None
+            dz, dw = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], st["need_dw"], dz_out=st["dz"])
+        if st["need_dz"]:
+            st["dz"] = dz                                     # (a later reader adds into it)
+        if st["need_dw"]:
+            st["dw"] = dw if st["dw"] is None else st["dw"] + dw
+        if st["need_db"]:
+            st["db"] = db2 if st["db"] is None else st["db"] + db2
+        return dx.new_zeros(1), None, de, dbe, None, None, None, None, None, None
 
 
 def _concept_plan(cols, device, cache):
@@ -599,9 +608,9 @@ class ClassifierOracle(OracleBase):
             world._pair_head, world._pair_z = None, z
             if self._head_fused(world, z, lin1, lin2):
                 # the head's backward without dpre2 in memory: pre2 comes out of the trunk node, its readers register with `uses`
-                uses = []
-                pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, uses, first)
-                world._pair_head = (token, uses, x_part)
+                state = {}
+                pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, state, first)
+                world._pair_head = (token, state, x_part)
                 world._pair_pre2 = pre2
             else:
                 world._pair_pre2 = _TallLinear.apply(z, lin2.weight, lin2.bias)
@@ -719,9 +728,9 @@ class ClassifierOracle(OracleBase):
             identity = len(src) == world._pair_num and np.array_equal(src, np.arange(len(src)))
             hit = (None if identity else torch.as_tensor(src).to(dev), torch.as_tensor(preds[rep] * (NS * NS) + s_ * NS + o_).to(dev),
                    torch.as_tensor(rep).to(dev), torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(dev), int(cnt.max()),
-                   torch.as_tensor(rep.astype(np.int32)).to(dev) if identity else None)
+                   torch.as_tensor(rep.astype(np.int32)).to(dev) if identity else None, bool((cnt[cnt > 0] >= 64).all()))
             self._index_cache[key] = hit
-        src, dst, rep, pred_off, max_rows, rep32 = hit
+        src, dst, rep, pred_off, max_rows, rep32, sums_ok = hit
         cols = upload(full[preds].astype(np.int64), dev)
         if fused and src is None:
             # every pair row belongs to exactly one predicate, in order: Sigmoid, embedding product and row sum in one kernel
@@ -732,7 +741,7 @@ class ClassifierOracle(OracleBase):
             head = getattr(world, "_pair_head", None)
             if head is not None:                          # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk
                 x_part = head[2] if (fresh and head[2] is not None and head[2].numel() > 0) else None
-                x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part)
+                x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part, sums_ok)
             else:
                 x = _FusedLogit.apply(pre2, e_rows, be_rows, pred_off, max_rows)
         else:

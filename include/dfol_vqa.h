@@ -462,6 +462,13 @@ int dfol_pair_dz_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, co
                            const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t HID1, int32_t HID2,
                            int32_t accumulate, void* stream);
 int64_t dfol_pair_wgrad_fused_workspace(int64_t M, int32_t HID2, int32_t HID1);      /* floats */
+/* wgrad_fused_sums: dfol_pair_wgrad_fused_f32 AND the sums of dfol_pair_logit_bwd_sums_f32 from the same pass (no pass of their own over
+ * pre2): dE [P, ld_de], dbe [P] (or NULL), db2 [HID2] (already summed over the predicates).  Every predicate must own at least 64 pair rows
+ * or none, HID2 % 3 == 0 (the running sums of a thread's three columns live in LDS). */
+int64_t dfol_pair_wgrad_fused_sums_workspace(int64_t M, int32_t HID2, int32_t HID1, int32_t P);      /* floats */
+int dfol_pair_wgrad_fused_sums_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P,
+                                   const float* E, int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t HID2,
+                                   int32_t HID1, float* workspace, float* dW, float* dE, int64_t ld_de, float* dbe, float* db2, void* stream);
 int dfol_pair_wgrad_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off,
                               const float* E, int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t HID2,
                               int32_t HID1, float* workspace, float* dW, void* stream);

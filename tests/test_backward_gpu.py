@@ -844,7 +844,9 @@ def test_train_step_on_shared_scenes_equals_per_question_scenes():
 @pytest.mark.parametrize("counts,hid1,hid2,decades", [([90, 2, 6, 0, 132, 380, 30, 1], 256, 300, 0),        # tiny and empty predicates, M % 32 != 0
                                                       ([9900, 5112, 3540], 256, 300, 4),                    # several slabs, dx over eight decades
                                                       ([700, 650], 64, 128, 2),                             # four columns per building thread (HID2 % 3 != 0)
-                                                      ([2450] * 9, 256, 300, 1)])
+                                                      ([2450] * 9, 256, 300, 1),
+                                                      ([64, 0, 71, 9900, 65, 0, 0, 1560, 97, 64 * 3 + 5], 256, 300, 2),     # boundaries in every position, empty predicates between
+                                                      ([1260] * 37 + [380, 0, 3906], 256, 300, 1)])
 def test_pair_head_backward_without_dpre2(counts, hid1, hid2, decades):
     """(dZ, dW2, db2, dE, dbe) of x = sum_j Sigmoid(Z W2^T + b2)[r, j] E[p(r), j] + be[p(r)] from the three kernels that rebuild dpre2 on
     the fly, against float64 from the materialised dpre2, with the tolerance of the operand model the kernels document: dpre2 and Z as
@@ -892,6 +894,17 @@ def test_pair_head_backward_without_dpre2(counts, hid1, hid2, decades):
                                  np.add.reduceat(np.concatenate([np.abs(g64), [0.0]]), np.minimum(pred_off[:-1], M)), "dbe")):
         err = np.abs(got.cpu().numpy() - want)
         assert (err <= 2e-6 * mag + 1e-30).all(), (tag, float(err.max()))
+    # the sums from the weight-gradient pass (no pass of their own over pre2) where every predicate owns >= 64 rows or none
+    if (counts[counts > 0] >= 64).all() and hid2 % 3 == 0:
+        fz, fw, fb2, fe, fbe = _lib.pair_head_bwd(*args, sums=True)
+        assert torch.equal(fz, dz)
+        assert torch.equal(_lib.pair_head_bwd(*args, sums=True)[1], fw)
+        for got, ref, mag, tag in ((fb2, dp.sum(0), np.abs(dp).sum(0), "db2"), (fe, de.cpu().numpy().astype(np.float64), None, "dE"), (fbe, dbe.cpu().numpy().astype(np.float64), None, "dbe")):
+            m = np.abs(ref).max() if mag is None else mag
+            err = np.abs(got.cpu().numpy() - ref)
+            assert (err <= 4e-6 * m + 1e-30).all(), (tag + " (fused sums)", float(err.max()), float(np.max(m)))
+        errw = np.abs(fw.cpu().numpy() - dw.cpu().numpy())
+        assert float(errw.max()) <= 1e-6 * float(dw.abs().max()), "dW2 (fused sums)"
     # a second use of the hidden layer adds its input gradient
     dz2 = _lib.pair_head_bwd(*args, dz_out=dz.clone())[0]
     assert np.allclose(dz2.cpu().numpy(), 2.0 * dz.cpu().numpy(), rtol=1e-6, atol=0.0)

@@ -1110,18 +1110,24 @@ extern "C" int64_t dfol_pair_wgrad_fused_workspace(int64_t M, int32_t H2, int32_
 }
 
 // The partial sums of pair_wgrad_fused_kernel<.., true> in a fixed order.  Block p < P: dE[p][:] from the partial rows (slab + p, octet) of
-// the slabs that hold rows of p, and dbe[p] = the sum of dx over p's rows; block P: db2 from every slab's four octet rows.
+// the slabs that hold rows of p, and dbe[p] = the sum of dx over p's rows; blocks P .. P + 7: db2 from every slab's four octet rows.
 __global__ __launch_bounds__(320) void pair_sums_reduce_kernel(const float* __restrict__ de_part, const float* __restrict__ db_part,
                                                                const float* __restrict__ dx, const int64_t* __restrict__ pred_off, int P, int H2,
                                                                int slabs, int rows_per_slab, float* __restrict__ dE, int64_t ld_de,
                                                                float* __restrict__ dbe, float* __restrict__ db2) {
     __shared__ float red[320];
     const int p = blockIdx.x, tid = threadIdx.x;
-    if (p == P) {
-        if (tid < H2) {
-            float acc = 0.f;
-            for (int r = 0; r < slabs * 4; ++r) acc += db_part[(int64_t)r * H2 + tid];
-            db2[tid] = acc;
+    if (p >= P) {                                                      // db2: 8 blocks of 40 columns, 8 row phases each (one thread walking all 4 x slabs rows of a column took 0.25 ms)
+        const int c = (p - P) * 40 + tid % 40, ph = tid / 40;
+        float acc = 0.f;
+        if (c < H2)
+            for (int r = ph; r < slabs * 4; r += 8) acc += db_part[(int64_t)r * H2 + c];
+        red[tid] = acc;
+        __syncthreads();
+        if (ph == 0 && c < H2) {
+            float t = 0.f;
+            for (int i = 0; i < 8; ++i) t += red[i * 40 + tid];
+            db2[c] = t;
         }
         return;
     }
@@ -1214,7 +1220,7 @@ static int pw_launch(const float* pre2, int64_t ld_p2, const float* dx, const in
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dfol_cdiv(dfol_cdiv(elems, 4), 16)), dim3(256), 0, st, workspace, slabs, elems, dW);
     DFOL_LAUNCH_CHECK("pair_wgrad_fused (reduce)");
     if (sums) {
-        hipLaunchKernelGGL(pair_sums_reduce_kernel, dim3(P + 1), dim3(320), 0, st, (const float*)de_part, (const float*)db_part, dx, pred_off, P, H2, slabs,
+        hipLaunchKernelGGL(pair_sums_reduce_kernel, dim3(P + 8), dim3(320), 0, st, (const float*)de_part, (const float*)db_part, dx, pred_off, P, H2, slabs,
                            rows_per_slab, dE, ld_de, dbe, db2);
         DFOL_LAUNCH_CHECK("pair_wgrad_fused (sums reduce)");
     }

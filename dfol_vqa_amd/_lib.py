@@ -117,6 +117,8 @@ SIGNATURES = {
     "dfol_linear_tall_supported": [_i64, _i32, _i32],
     "dfol_linear_tall_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "dfol_pair_dz_tall_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p],
+    "dfol_linear_tall_bf16_bf16": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
+    "dfol_pair_dz_tall_bf16": [_p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_logit_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "dfol_pair_dz_fused_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_wgrad_fused_workspace": [_i64, _i32, _i32],
@@ -813,9 +815,17 @@ def linear_tall_supported(M, N, K):
 
 def linear_tall_h2(x, weight, bias, row_pred=None, e_rows=None):
     """y [M, N] = x @ weight.T + bias on two fp16 pieces, persistent form (M >= 16384, N <= 320): bit for bit linear_act_split's result.
-    With row_pred / e_rows also the logit layer's partial sums x_part [4, M] (see linear_logit_h2) -> (y, x_part), else (y, None)."""
+    With row_pred / e_rows also the logit layer's partial sums x_part [4, M] (see linear_logit_h2) -> (y, x_part), else (y, None).
+    A bfloat16 x (the bf16 mode's stored activations): one bf16 piece per operand, bfloat16 y - bit for bit dfol_linear_act_bf16_bf16."""
     M, K = x.shape
     N = weight.shape[0]
+    if x.dtype == torch.bfloat16:
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        xp = torch.empty(4, M, dtype=F32, device=x.device) if row_pred is not None else None
+        call("dfol_linear_tall_bf16_bf16", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, False, 1), torch.bfloat16), _ptr(bias, F32, True), _dp(y),
+             y.stride(0), M, N, K, _ptr(row_pred, I32, True), _ptr(e_rows, F32, True), 0 if e_rows is None else e_rows.stride(0), _ptr(xp, F32, True),
+             0 if xp is None else xp.stride(0), _stream())
+        return y, xp
     y = torch.empty(M, N, dtype=F32, device=x.device)
     xp = torch.empty(4, M, dtype=F32, device=x.device) if row_pred is not None else None
     call("dfol_linear_tall_h2_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, False, 2), torch.bfloat16), _ptr(bias, F32, True), _dp(y),
@@ -834,6 +844,17 @@ def linear_logit_h2(x, weight, bias, row_pred, e_rows):
     call("dfol_linear_logit_h2_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, False, 2), torch.bfloat16), _ptr(bias, F32, True), _dp(y),
          y.stride(0), M, N, K, _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0), _ptr(xp), xp.stride(0), _stream())
     return y, xp
+
+
+def pair_dz_tall_bf16(dx, p2, e_rows, row_pred, w2, dz_out=None):
+    """dz [M, HID1] bfloat16 (+)= dpre2 W2 for bfloat16-stored p2 = pre2 [M, HID2] (the bf16 mode): dpre2 rebuilt in the kernel and rounded to
+    bfloat16 as dfol_pair_logit_bwd_bf16 stores it, one bf16 piece per operand - bit for bit that kernel followed by the bf16 product."""
+    M, H2 = p2.shape
+    H1 = w2.shape[1]
+    dz = dz_out if dz_out is not None else torch.empty(M, H1, dtype=torch.bfloat16, device=p2.device)
+    call("dfol_pair_dz_tall_bf16", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0),
+         _ptr(linear_pack_w_split(w2, True, 1), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _stream())
+    return dz
 
 
 def pair_head_sums(dx, p2, e_rows, pred_off, need_bias=True):

@@ -57,6 +57,16 @@ __device__ __forceinline__ float tl_dsigmoid(float x) {
     return h * (1.0f - h);
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t tl_rne2(float x0, float x1) {     // two fp32 -> two bf16, round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, tl_bf16x2));
+}
+__device__ __forceinline__ float4 tl_widen(const u32x2& v) {
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+
 struct TlExtra {
     const float* gs;                // MODE 1: 2^e_r dx[r] [M]
     const float* rsinv;             // MODE 1: 2^-e_r [M]
@@ -103,13 +113,23 @@ __global__ __launch_bounds__(256) void tall_row_scale_kernel(const float* __rest
 }
 
 // NTW: 16-column tiles per wavefront (4 wavefronts across the columns: N <= 64 NTW); NBN = ceil(64 NTW / 128) column blocks of the packed image
-template <int NTW, int MODE>
+// BIO (the bf16 mode, round 4 late): X and Y are rows of bfloat16 (8-byte aligned rows, K % 4 == 0, N % 4 == 0), operands ONE bf16 piece
+// (the image of dfol_linear_pack_w_bf16), one product on v_mfma_f32_16x16x32_bf16, fp32 accumulation, results rounded to nearest even -
+// bit for bit dfol_linear_act_bf16_bf16.  MODE 1 then needs no row scaling (bf16 has fp32's exponent range): gs = dx, and dpre2 is
+// rounded to bf16 exactly as dfol_pair_logit_bwd_bf16 stores it.  The output block leaves through LDS (2-byte stores straight from the
+// accumulator layout cost a third of the tiled kernel): a staging array behind the buffers, one extra barrier per block.
+template <int NTW, int MODE, bool BIO = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void tall_h2_kernel(
-    const float* __restrict__ X, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
+    const void* __restrict__ Xv, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Yv, int64_t ldy,
     int M, int N, int K, int ksteps, int nbn, TlExtra ex) {
     constexpr bool PROD = MODE == 1, LOGIT = MODE == 2;
+    typedef typename std::conditional<BIO, uint16_t, float>::type TX;
+    const TX* __restrict__ X = reinterpret_cast<const TX*>(Xv);
+    TX* __restrict__ Y = reinterpret_cast<TX*>(Yv);
     constexpr int NBN = (64 * NTW + 127) / 128;
-    constexpr int BUF = TL_TILE + NBN * TL_TILE;                      // one LDS buffer: the A tile, then the B tiles of all column blocks
+    constexpr int NP = BIO ? 1 : 2;                                   // pieces per operand
+    constexpr int TILE = NP * 128 * 4;                                // 16-byte pieces of one [pieces][128 rows][4 k-groups] tile
+    constexpr int BUF = TILE + NBN * TILE;                            // one LDS buffer: the A tile, then the B tiles of all column blocks
     extern __shared__ __attribute__((aligned(16))) u32x4 tl_sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
     const int wm = wave >> 2, wn = wave & 3;
@@ -127,15 +147,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < NTW; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // ---- X rows: a ring of TL_XD register sets, the loader's position runs ahead of the multiplier's across block boundaries
-    float4 xa[TL_XD][2];
+    typedef typename std::conditional<BIO, u32x2, float4>::type XR;   // four consecutive k of a row as loaded
+    XR xa[TL_XD][2];
     int lb = first, lks = 0;                                          // block and step the next load belongs to
-    const float* xrow = X + (int64_t)min(lb * TL_BM + arow, M - 1) * ldx + aq * 8;
+    const TX* xrow = X + (int64_t)min(lb * TL_BM + arow, M - 1) * ldx + aq * 8;
     auto load_x = [&](auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = lks * TL_BK + aq * 8;
         const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;          // (K % 4 == 0; clamped, zeroed when used)
-        xa[S][0] = *reinterpret_cast<const float4*>(xrow + c0);
-        xa[S][1] = *reinterpret_cast<const float4*>(xrow + c1);
+        xa[S][0] = *reinterpret_cast<const XR*>(xrow + c0);
+        xa[S][1] = *reinterpret_cast<const XR*>(xrow + c1);
         if (++lks == ksteps) {                                        // (uniform) on to the next block of this workgroup; past the last: clamped rows, never used
             lks = 0;
             lb += stride;
@@ -143,19 +164,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     // ---- weight tiles of a step: all column blocks, one step ahead in registers
-    u32x4 wb[2 * NBN];
+    u32x4 wb[NP * NBN];
     int wks = 0;
     auto load_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2 * NBN; ++i) {
-            const int idx = i * 512 + tid, nb = idx >> 10, within = idx & 1023;
-            wb[i] = Wp[((int64_t)min(nb, nbn - 1) * ksteps + wks) * TL_TILE + within];
+        for (int i = 0; i < NP * NBN; ++i) {
+            const int idx = i * 512 + tid, nb = idx / TILE, within = idx % TILE;
+            wb[i] = Wp[((int64_t)min(nb, nbn - 1) * ksteps + wks) * TILE + within];
         }
         if (++wks == ksteps) wks = 0;
     };
     auto store_b = [&](int off) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2 * NBN; ++i) tl_sm[off + TL_TILE + i * 512 + tid] = wb[i];
+        for (int i = 0; i < NP * NBN; ++i) tl_sm[off + TILE + i * 512 + tid] = wb[i];
     };
     // ---- MODE 1: the producer's state for the block whose steps are being stored; the next block's row values are prefetched a block ahead
     float gs_cur = 0.f, gs_next = 0.f;
@@ -189,21 +210,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto store_a = [&](auto set_tag, int off) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = sks * TL_BK + aq * 8;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v0 = k < K ? xa[S][0] : z, v1 = k + 4 < K ? xa[S][1] : z;
-        if constexpr (PROD) {
-            auto dp = [&](const float4& x, const float4& e) __attribute__((always_inline)) {
-                return make_float4((gs_cur * e.x) * tl_dsigmoid(x.x), (gs_cur * e.y) * tl_dsigmoid(x.y), (gs_cur * e.z) * tl_dsigmoid(x.z),
-                                   (gs_cur * e.w) * tl_dsigmoid(x.w));
-            };
-            v0 = k < K ? dp(xa[S][0], ea[0]) : z;
-            v1 = k + 4 < K ? dp(xa[S][1], ea[1]) : z;
-        }
-        u32x4 ph, pl;
-        tl_split8h(v0, v1, ph, pl);
         const int at = off + arow * 4 + (aq ^ tl_swz(arow));
-        tl_sm[at] = ph;
-        tl_sm[at + TL_BM * 4] = pl;
+        if constexpr (BIO) {
+            const u32x2 zz = u32x2{0u, 0u};
+            u32x2 v0 = k < K ? xa[S][0] : zz, v1 = k + 4 < K ? xa[S][1] : zz;
+            if constexpr (PROD) {                                     // ((dx E) h) (1 - h), rounded to nearest even: the values dfol_pair_logit_bwd_bf16 stores
+                auto dp = [&](const u32x2& xb, const float4& e) __attribute__((always_inline)) {
+                    const float4 x = tl_widen(xb);
+                    const float h0 = tl_sigmoid(x.x), h1 = tl_sigmoid(x.y), h2 = tl_sigmoid(x.z), h3 = tl_sigmoid(x.w);
+                    return u32x2{tl_rne2(gs_cur * e.x * h0 * (1.0f - h0), gs_cur * e.y * h1 * (1.0f - h1)),
+                                 tl_rne2(gs_cur * e.z * h2 * (1.0f - h2), gs_cur * e.w * h3 * (1.0f - h3))};
+                };
+                v0 = k < K ? dp(xa[S][0], ea[0]) : zz;
+                v1 = k + 4 < K ? dp(xa[S][1], ea[1]) : zz;
+            }
+            tl_sm[at] = u32x4{v0.x, v0.y, v1.x, v1.y};
+        } else {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v0 = k < K ? xa[S][0] : z, v1 = k + 4 < K ? xa[S][1] : z;
+            if constexpr (PROD) {
+                auto dp = [&](const float4& x, const float4& e) __attribute__((always_inline)) {
+                    return make_float4((gs_cur * e.x) * tl_dsigmoid(x.x), (gs_cur * e.y) * tl_dsigmoid(x.y), (gs_cur * e.z) * tl_dsigmoid(x.z),
+                                       (gs_cur * e.w) * tl_dsigmoid(x.w));
+                };
+                v0 = k < K ? dp(xa[S][0], ea[0]) : z;
+                v1 = k + 4 < K ? dp(xa[S][1], ea[1]) : z;
+            }
+            u32x4 ph, pl;
+            tl_split8h(v0, v1, ph, pl);
+            tl_sm[at] = ph;
+            tl_sm[at + TL_BM * 4] = pl;
+        }
         if (++sks == ksteps) {
             sks = 0;
             sb += stride;
@@ -216,27 +253,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int col0 = wn * (16 * NTW) + j * 16;
-        boff[j] = TL_TILE + (col0 >> 7) * TL_TILE + ((col0 & 127) + r16) * 4 + (kh ^ tl_swz(r16));
+        boff[j] = TILE + (col0 >> 7) * TILE + ((col0 & 127) + r16) * 4 + (kh ^ tl_swz(r16));
     }
     constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};             // xl wh, xh wl, xh wh (smallest first)
     auto multiply = [&](int off) __attribute__((always_inline)) {
 #pragma unroll
         for (int ih = 0; ih < 4; ih += 2) {                           // two row tiles at a time (register budget)
-            f16x8 a[2][2];
+            u32x4 a[2][NP];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) a[i][p] = __builtin_bit_cast(f16x8, tl_sm[off + p * TL_BM * 4 + (ih + i) * 64 + aoff]);
+                for (int p = 0; p < NP; ++p) a[i][p] = tl_sm[off + p * TL_BM * 4 + (ih + i) * 64 + aoff];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                f16x8 b[2];
+                u32x4 b[NP];
 #pragma unroll
-                for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(f16x8, tl_sm[off + p * 128 * 4 + boff[j]]);
+                for (int p = 0; p < NP; ++p) b[p] = tl_sm[off + p * 128 * 4 + boff[j]];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (BIO) {
+                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][0]), __builtin_bit_cast(bf16x8, b[0]), acc[ih + i][j], 0, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int x = 0; x < 3; ++x)
-                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][PA3[x]], b[PB3[x]], acc[ih + i][j], 0, 0, 0);
+                        for (int x = 0; x < 3; ++x)
+                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i][PA3[x] % NP]), __builtin_bit_cast(f16x8, b[PB3[x] % NP]), acc[ih + i][j], 0, 0, 0);
+                    }
+                }
             }
         }
     };
@@ -247,9 +289,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // rows up one by one).  Loaded in the epilogue itself these were dependent round trips with the whole CU waiting: the first version
     // of the logit epilogue cost 1.2 ms over 77 blocks per workgroup.
     float* xs = reinterpret_cast<float*>(tl_sm + 2 * BUF);            // [0, 320) scales, [320, 640) bias, [640, 960) embedding row, [960, 1088) row factors
+    constexpr int PITCH = 64 * NTW + 8;                               // BIO: halfwords per staged output row (16-byte aligned rows)
+    uint16_t* stage = reinterpret_cast<uint16_t*>(xs + 1088);
     if (tid < 320) {
-        const float* tail = reinterpret_cast<const float*>(Wp + (int64_t)nbn * ksteps * TL_TILE);
-        xs[tid] = tid < nbn * 128 ? tail[tid] : 0.f;
+        const float* tail = reinterpret_cast<const float*>(Wp + (int64_t)nbn * ksteps * TILE);
+        xs[tid] = BIO ? 1.0f : (tid < nbn * 128 ? tail[tid] : 0.f);     // (the one-piece image has no row scales)
         xs[320 + tid] = (bias && tid < N) ? bias[tid] : 0.f;
     }
     int lg_p0 = -1, lg_pl = -2;                                       // (scalar registers) predicates of the block's first and last row
@@ -263,7 +307,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 p0_reg = ex.row_pred[m0];
                 pl_reg = ex.row_pred[min(m0 + TL_BM, M) - 1];
             }
-            if constexpr (PROD) {
+            if constexpr (PROD && !BIO) {
                 if (tid < TL_BM) stage_reg = ex.rsinv[min(m0 + tid, M - 1)];
             }
         } else if (step == 1) {
@@ -273,7 +317,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 lg_uni = lg_p0 >= 0 && lg_p0 == lg_pl;
                 if (lg_uni && tid < 320) stage_reg = tid < N ? ex.E[(int64_t)lg_p0 * ex.ld_e + tid] : 0.f;
             }
-            if constexpr (PROD) {
+            if constexpr (PROD && !BIO) {
                 if (tid < TL_BM) xs[960 + tid] = stage_reg;
             }
         } else {
@@ -301,7 +345,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const bool row_ok = row < M;
                     const int64_t rc = min(row, M - 1);
                     float rsc = 1.0f;
-                    if constexpr (PROD) rsc = xs[960 + lrow];
+                    if constexpr (PROD && !BIO) rsc = xs[960 + lrow];
                     int pr = -1;
                     if constexpr (LOGIT && !UNI) pr = row_ok ? ex.row_pred[rc] : -1;
                     float sum = 0.f;
@@ -311,11 +355,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         float v = acc[i][j][e] * cs[j];
                         if constexpr (PROD) {
                             v *= rsc;
-                            if (ex.accumulate) v += Y[rc * ldy + min(col, N - 1)];
+                            if (ex.accumulate) {
+                                if constexpr (BIO) v += __uint_as_float((uint32_t)Y[rc * ldy + min(col, N - 1)] << 16);
+                                else v += Y[rc * ldy + min(col, N - 1)];
+                            }
                         } else {
                             v += bv[j];
                         }
-                        if (row_ok && col < N) Y[(int64_t)row * ldy + col] = v;
+                        if constexpr (BIO) {                          // rounded to nearest even, staged for the 8-byte stores below; what follows sees the stored value
+                            const uint32_t hv = tl_rne2(v, 0.f) & 0xffffu;
+                            stage[lrow * PITCH + col] = (uint16_t)hv;
+                            v = __uint_as_float(hv << 16);
+                        } else {
+                            if (row_ok && col < N) Y[(int64_t)row * ldy + col] = v;
+                        }
                         if constexpr (LOGIT) {
                             if constexpr (UNI) sum += tl_sigmoid(v) * le[j];          // (le = 0 in the columns past N)
                             else if (pr >= 0 && col < N) sum += tl_sigmoid(v) * ex.E[(int64_t)pr * ex.ld_e + col];
@@ -331,6 +384,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         if (LOGIT && lg_uni) rows(std::true_type());                  // (uniform)
         else rows(std::false_type());
+        if constexpr (BIO) {
+            __syncthreads();                                          // the block's rows are staged
+            const int q4 = N >> 2;                                    // 8-byte pieces of a row (N % 4 == 0)
+            for (int c = tid; c < TL_BM * q4; c += 512) {
+                const int row = c / q4, q = c - row * q4;
+                if (m0 + row < M)
+                    *reinterpret_cast<u32x2*>(Y + (int64_t)(m0 + row) * ldy + 4 * q) = *reinterpret_cast<const u32x2*>(stage + row * PITCH + 4 * q);
+            }
+        }
     };
 
     // ---- the stream
@@ -382,8 +444,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int MODE>
-static int tall_launch(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+template <int MODE, bool BIO = false>
+static int tall_launch(const void* X, int64_t ldx, const void* W_split, const float* bias, void* Y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                        const TlExtra& ex, void* stream, const char* name) {
     const int ksteps = dfol_cdiv(K, TL_BK), nbn = dfol_cdiv(N, 128);
     const int ntw = dfol_cdiv(N, 64);                                 // 16-column tiles per wavefront: 4 (N <= 256) or 5 (N <= 320)
@@ -398,14 +460,16 @@ static int tall_launch(const float* X, int64_t ldx, const void* W_split, const f
     const int nblocks = dfol_cdiv(M, TL_BM);
     const int grid = std::min(nblocks, cus);
     const int nbn_lds = ntw <= 4 ? 2 : 3;
-    const size_t lds = (size_t)2 * (TL_TILE + nbn_lds * TL_TILE) * 16 + 1088 * 4;
+    constexpr int TILE = (BIO ? 1 : 2) * 128 * 4;
+    const size_t lds = (size_t)2 * (TILE + nbn_lds * TILE) * 16 + 1088 * 4 + (BIO ? (size_t)TL_BM * (64 * (ntw <= 4 ? 4 : 5) + 8) * 2 : 0);
     hipStream_t st = (hipStream_t)stream;
 #define DFOL_TALL(NT)                                                                                                                       \
     {                                                                                                                                      \
-        static const hipError_t ok = hipFuncSetAttribute((const void*)tall_h2_kernel<NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                        (int)((size_t)2 * (TL_TILE + ((64 * NT + 127) / 128) * TL_TILE) * 16 + 1088 * 4)); \
+        static const hipError_t ok = hipFuncSetAttribute((const void*)tall_h2_kernel<NT, MODE, BIO>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                        (int)((size_t)2 * (TILE + ((64 * NT + 127) / 128) * TILE) * 16 + 1088 * 4 +             \
+                                                              (BIO ? (size_t)TL_BM * (64 * NT + 8) * 2 : 0)));                                    \
         DFOL_REQUIRE(ok == hipSuccess, "%s: cannot reserve %zu bytes of LDS (%s)", name, lds, hipGetErrorString(ok));                       \
-        hipLaunchKernelGGL((tall_h2_kernel<NT, MODE>), dim3(grid), dim3(512), lds, st, X, ldx, (const u32x4*)W_split, bias, Y, ldy, M, N, K,  \
+        hipLaunchKernelGGL((tall_h2_kernel<NT, MODE, BIO>), dim3(grid), dim3(512), lds, st, X, ldx, (const u32x4*)W_split, bias, Y, ldy, M, N, K, \
                            ksteps, nbn, ex);                                                                                               \
     }
     if (ntw <= 4) DFOL_TALL(4) else DFOL_TALL(5)
@@ -473,4 +537,34 @@ extern "C" int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const flo
     DFOL_LAUNCH_CHECK("pair_dz_tall (row scales)");
     const TlExtra ex = {gs, rsinv, row_pred, E, ld_e, accumulate, nullptr, 0};
     return tall_launch<1>(pre2, ld_p2, W2t_split, nullptr, dZ, ld_dz, M, H1, H2, ex, stream, "pair_dz_tall");
+}
+
+// The bf16 mode's forms (bf16-STORED activations, one bf16 piece per operand, results rounded to nearest even): bit for bit
+// dfol_linear_act_bf16_bf16 (no activation) resp. dfol_pair_logit_bwd_bf16 followed by it.  N % 4 == 0, rows 8-byte aligned (strides in elements).
+extern "C" int dfol_linear_tall_bf16_bf16(const void* X_bf16, int64_t ldx, const void* W_bf16, const float* bias, void* Y_bf16, int64_t ldy, int32_t M,
+                                          int32_t N, int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp,
+                                          void* stream) {
+    DFOL_REQUIRE(dfol_linear_tall_supported(M, N, K) && N % 4 == 0 && ldx % 4 == 0 && ldx >= K && ldy % 4 == 0 && ldy >= N,
+                 "linear_tall_bf16_bf16: bad sizes M=%d N=%d K=%d (M >= 16384, N <= 320, N, K, strides multiples of 4)", M, N, K);
+    DFOL_REQUIRE(X_bf16 && W_bf16 && Y_bf16, "linear_tall_bf16_bf16: null pointer");
+    DFOL_REQUIRE(((uintptr_t)X_bf16 % 8 == 0) && ((uintptr_t)Y_bf16 % 8 == 0) && ((uintptr_t)W_bf16 % 16 == 0), "linear_tall_bf16_bf16: X, Y must be 8-byte and W 16-byte aligned");
+    if (x_part) {
+        DFOL_REQUIRE(row_pred && E && ld_e >= N && ld_xp >= M, "linear_tall_bf16_bf16: the logit partial sums need row_pred, E [P, >= N] and x_part [4, >= M]");
+        const TlExtra ex = {nullptr, nullptr, row_pred, E, ld_e, 0, x_part, ld_xp};
+        return tall_launch<2, true>(X_bf16, ldx, W_bf16, bias, Y_bf16, ldy, M, N, K, ex, stream, "linear_tall_bf16_bf16 (logit)");
+    }
+    const TlExtra ex = {nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
+    return tall_launch<0, true>(X_bf16, ldx, W_bf16, bias, Y_bf16, ldy, M, N, K, ex, stream, "linear_tall_bf16_bf16");
+}
+
+extern "C" int dfol_pair_dz_tall_bf16(const void* pre2_bf16, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
+                                      const void* W2t_bf16, void* dZ_bf16, int64_t ld_dz, int32_t M, int32_t H1, int32_t H2, int32_t accumulate,
+                                      void* stream) {
+    DFOL_REQUIRE(dfol_linear_tall_supported(M, H1, H2) && H1 % 4 == 0 && ld_p2 % 4 == 0 && ld_p2 >= H2 && ld_e % 4 == 0 && ld_e >= H2 && ld_dz % 4 == 0 && ld_dz >= H1,
+                 "pair_dz_tall_bf16: bad sizes M=%d H1=%d H2=%d", M, H1, H2);
+    DFOL_REQUIRE(pre2_bf16 && dx && row_pred && E && W2t_bf16 && dZ_bf16, "pair_dz_tall_bf16: null pointer");
+    DFOL_REQUIRE(((uintptr_t)pre2_bf16 % 8 == 0) && ((uintptr_t)dZ_bf16 % 8 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)W2t_bf16 % 16 == 0),
+                 "pair_dz_tall_bf16: pre2, dZ must be 8-byte, E and the packed weights 16-byte aligned");
+    const TlExtra ex = {dx, nullptr, row_pred, E, ld_e, accumulate, nullptr, 0};
+    return tall_launch<1, true>(pre2_bf16, ld_p2, W2t_bf16, nullptr, dZ_bf16, ld_dz, M, H1, H2, ex, stream, "pair_dz_tall_bf16");
 }

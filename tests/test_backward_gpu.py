@@ -950,8 +950,9 @@ def test_linear_logit_h2_partial_sums(M, N, K):
     assert torch.equal(got2[lead:], got[lead:]) and float(got2[:lead].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("kinds", [("exist", "verify_rel"), ("choose_rel", "query_attr")])
-def test_deferred_head_backward_equals_the_materialised_one(kinds, monkeypatch):
+@pytest.mark.parametrize("kinds,n_lo,n_hi,count", [(("exist", "verify_rel"), 18, 30, 8), (("choose_rel", "query_attr"), 18, 30, 8),
+                                                    (("exist", "verify_rel"), 2, 34, 12)])      # images of 2 .. 8 objects: predicates of 2 .. 56 rows
+def test_deferred_head_backward_equals_the_materialised_one(kinds, n_lo, n_hi, count, monkeypatch):
     """The full-size model on ragged scenes with programs of one to three relation hops (several readers of one hidden layer: the deferred
     trunk adds their input and weight gradients), relation option lists and no-op tokens (readers that cannot register with the trunk and
     fall back to a second, ordinary evaluation): loss and every parameter gradient with the head's backward rebuilt on the fly
@@ -965,13 +966,14 @@ def test_deferred_head_backward_equals_the_materialised_one(kinds, monkeypatch):
     runs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("DFOL_TRAIN_HEAD_FUSED", fused)
+        monkeypatch.setenv("DFOL_HEAD_SUMS", "1")             # the sums from the weight-gradient pass wherever every predicate is large enough
         torch.manual_seed(3)
         model, ontology, paths, names = bench.build_model(args, DEV, train=True)
         with open(paths["attribute_file"]) as f:
             categories = json.load(f)
         qs = []
         for j, kind in enumerate(kinds):
-            qs += syn.full_size_questions(kind, 8, 18, 30, names, categories, 40 + j)
+            qs += syn.full_size_questions(kind, count, n_lo, n_hi, names, categories, 40 + j)
         if "choose_rel" in kinds:
             qs[0]["program"]["last_op"]["arguments"][0][1] = "_"       # a no-op token inside an option list
         pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate([dict(q) for q in qs])]
@@ -1032,3 +1034,38 @@ def test_tall_products_equal_the_tiled_kernels_bit_for_bit(M, N, K, monkeypatch)
             dz2, _ = _lib.pair_head_products(dx, x, zz, wt, Ek, pred_off, rep, need_dw=False, dz_out=dz.clone())
             outs.append((dz, dz2))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("M,N,K", [(16384 + 77, 300, 256), (9900 * 4, 256, 300)])
+def test_tall_products_bf16_storage_equal_the_tiled_bf16_kernels_bit_for_bit(M, N, K):
+    """The bf16 mode's persistent products (bf16-stored activations, one bf16 piece per operand) against the tiled bf16-storage kernel:
+    the forward product bit for bit, its logit partial sums against dfol_pair_logit_fwd_bf16 on the stored product, and the input gradient
+    with dpre2 produced in the kernel bit for bit dfol_pair_logit_bwd_bf16 -> dfol_linear_act_bf16_bf16 (plain and accumulating)."""
+    from dfol_vqa_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = (torch.randn(M, K, device=DEV, generator=g)).to(torch.bfloat16)
+    w = torch.randn(N, K, device=DEV, generator=g) / 8
+    b = torch.randn(N, device=DEV, generator=g)
+    P = 5
+    E = torch.randn(P, N, device=DEV, generator=g) * 0.3
+    cnt = np.full(P, M // P, np.int64)
+    cnt[-1] += M - cnt.sum()
+    rep = torch.as_tensor(np.repeat(np.arange(P), cnt).astype(np.int32)).to(DEV)
+    pred_off = torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(DEV)
+    with _lib.dense_math("bf16"):
+        y_ref = _lib.linear_act_split(x, w, b, _lib.ACT_NONE)
+        y, none = _lib.linear_tall_h2(x, w, b)
+        y2, xp = _lib.linear_tall_h2(x, w, b, rep, E)
+        assert y_ref.dtype == torch.bfloat16 and none is None and torch.equal(y, y_ref) and torch.equal(y2, y_ref)
+        want = _lib.pair_logit_fwd(y_ref, E, None, pred_off, int(cnt.max()))
+        assert torch.allclose(xp.sum(0), want, rtol=2e-5, atol=2e-5)
+        if N <= 256:
+            Ek = torch.randn(P, K, device=DEV, generator=g) * 0.3
+            dx = torch.randn(M, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (M,), device=DEV, generator=g).float())
+            wt = torch.randn(K, N, device=DEV, generator=g) / 8                            # W2 [HID2, HID1]
+            dp2, _, _ = _lib.pair_logit_bwd(dx, x, Ek, pred_off)
+            dz_ref = _lib.linear_act_split(dp2, wt, None, _lib.ACT_NONE, transpose_w=True)
+            dz = _lib.pair_dz_tall_bf16(dx, x, Ek, rep, wt)
+            assert dz.dtype == torch.bfloat16 and torch.equal(dz, dz_ref)
+            dz2 = _lib.pair_dz_tall_bf16(dx, x, Ek, rep, wt, dz_out=dz.clone())
+            assert torch.allclose(dz2.float(), 2 * dz.float(), rtol=1e-2, atol=0)

@@ -124,6 +124,7 @@ SIGNATURES = {
     "dfol_pair_wgrad_fused_workspace": [_i64, _i32, _i32],
     "dfol_pair_wgrad_fused_sums_workspace": [_i64, _i32, _i32, _i32],
     "dfol_pair_wgrad_fused_sums_f32": [_p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p],
+    "dfol_pair_wgrad_fused_sums_bf16": [_p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p, _p],
     "dfol_pair_wgrad_fused_f32": [_p, _i64, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p],
     "dfol_linear_pack_w_bf16x3": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_split_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
@@ -469,6 +470,11 @@ def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
             raise DfolError("linear_act_split: a bfloat16 input needs the bf16 mode (dense_math('bf16'))")
         if out is None:
             out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        if act == ACT_NONE and N % 4 == 0 and out.stride(0) % 4 == 0 and linear_tall_supported(M, N, K):
+            # the persistent form (csrc/dfol_dense_tall.hip): the same bits, 0.81 ms against 0.89 - 0.95 for the two tall products of a bf16 step
+            call("dfol_linear_tall_bf16_bf16", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, transpose_w, 1), torch.bfloat16), _ptr(bias, F32, True),
+                 _dp(out), out.stride(0), M, N, K, None, None, 0, None, 0, _stream())
+            return out
         call("dfol_linear_act_bf16_bf16", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, transpose_w, 1), torch.bfloat16),
              _ptr(bias, F32, True), _dp(out), out.stride(0), M, N, K, act, _stream())
         return out
@@ -855,6 +861,24 @@ def pair_dz_tall_bf16(dx, p2, e_rows, row_pred, w2, dz_out=None):
     call("dfol_pair_dz_tall_bf16", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(e_rows, F32), e_rows.stride(0),
          _ptr(linear_pack_w_split(w2, True, 1), torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if dz_out is not None else 0, _stream())
     return dz
+
+
+def pair_wgrad_sums_bf16(dx, p2, z, e_rows, pred_off, row_pred, need_bias=True):
+    """(dW2 [HID2, HID1], dE [P, HID2], dbe [P] or None, db2 [HID2]), all fp32, from bfloat16-stored p2 = pre2 and z (the bf16 mode): the weight
+    gradient with dpre2 rebuilt in the kernel (rounded to bfloat16 as dfol_pair_logit_bwd_bf16 stores it) and the logit layer's sums from the
+    same pass.  Every predicate must own >= 64 pair rows or none."""
+    M, H2 = p2.shape
+    H1 = z.shape[1]
+    P = e_rows.shape[0]
+    dev = p2.device
+    ws = torch.empty(load().dfol_pair_wgrad_fused_sums_workspace(M, H2, H1, P), dtype=F32, device=dev)
+    dw = torch.empty(H2, H1, dtype=F32, device=dev)
+    de = torch.empty(P, H2, dtype=F32, device=dev)
+    dbe = torch.empty(P, dtype=F32, device=dev) if need_bias else None
+    db2 = torch.empty(H2, dtype=F32, device=dev)
+    call("dfol_pair_wgrad_fused_sums_bf16", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(pred_off, torch.int64), P, _ptr(e_rows, F32),
+         e_rows.stride(0), _dp(z), z.stride(0), M, H2, H1, _ptr(ws), _ptr(dw), _ptr(de), de.stride(0), _ptr(dbe, F32, True), _ptr(db2), _stream())
+    return dw, de, dbe, db2
 
 
 def pair_head_sums(dx, p2, e_rows, pred_off, need_bias=True):

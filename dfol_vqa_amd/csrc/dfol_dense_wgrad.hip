@@ -762,6 +762,10 @@ extern "C" int dfol_linear_wgrad_bias_bf16_bf16(const void* dY_bf16, int64_t ld_
 // A row's gradient has no natural scale and the contraction runs over the rows, so ONE power of two S for the whole launch (from the
 // caller: S max_r |dx[r]| max|E[p(r)]| / 4 in [2^13, 2^14)) scales dpre2 into fp16's range: an element's error is
 // max(2^-23 |a|, 2^-39 max_r(|dx[r]| max|E[p(r)]|)) - rows that far below the largest do not move the sum.  Z is split unscaled (ELU outputs).
+// one fp32 -> its bfloat16 (round to nearest even) as the bits of the fp32 it widens back to
+__device__ __forceinline__ uint32_t w3_pack1(float x) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(w3_f32x2{x, 0.f}, w3_bf16x2)) << 16;
+}
 typedef _Float16 pw_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 pw_f16x8 __attribute__((ext_vector_type(8)));
 
@@ -804,17 +808,26 @@ typedef uint32_t w3_u32x3 __attribute__((ext_vector_type(3)));
 // next predicate - its own first row past the boundary, or, for threads whose rows of the boundary step all lie before it, the step
 // after - into partials indexed by (slab + predicate, row octet), which pair_sums_reduce_kernel adds in a fixed order.  Needs every
 // predicate to own at least 32 rows (or none): a macro step then holds at most one boundary (the launcher's caller checks 64).
-template <int CPT, bool SUMS>
+// BIO (the bf16 mode): pre2 and Z are rows of bfloat16 (8-byte aligned rows, strides in elements), four columns of dpre2 per thread, ONE
+// bf16 piece per operand and one product on v_mfma_f32_32x32x16_bf16; dpre2 is rounded to bfloat16 exactly as dfol_pair_logit_bwd_bf16
+// stores it (no scaling: bf16 has fp32's exponent range; `scale` is not read).
+template <int CPT, bool SUMS, bool BIO = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_wgrad_fused_kernel(
-    const float* __restrict__ P2, int64_t ld_p2, const float* __restrict__ G, const int32_t* __restrict__ RP, const int64_t* __restrict__ pred_off,
-    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ scale, const float* __restrict__ Z, int64_t ld_z, int M, int H2, int H1,
+    const void* __restrict__ P2v, int64_t ld_p2, const float* __restrict__ G, const int32_t* __restrict__ RP, const int64_t* __restrict__ pred_off,
+    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ scale, const void* __restrict__ Zv, int64_t ld_z, int M, int H2, int H1,
     int rows_per_slab, float* __restrict__ part, float* __restrict__ de_part, float* __restrict__ db_part) {
+    static_assert(!BIO || CPT == 4, "bf16 storage: four columns (8 bytes) per thread and row");
+    typedef typename std::conditional<BIO, uint16_t, float>::type TIN;
+    const TIN* __restrict__ P2 = reinterpret_cast<const TIN*>(P2v);
+    const TIN* __restrict__ Z = reinterpret_cast<const TIN*>(Zv);
+    constexpr int EB = sizeof(TIN), NPC = BIO ? 1 : 2;                // bytes per stored element; pieces per operand
+    constexpr int A_ENT = 2 * NPC * PW_TA * 64, B_ENT = 2 * NPC * PW_TB * 64, BUFK = A_ENT + B_ENT;      // 16-byte entries: [k-step][piece][tile][lane]
     extern __shared__ __attribute__((aligned(16))) w3_u32x4 pw_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m_begin = blockIdx.x * rows_per_slab, m_end = min(M, m_begin + rows_per_slab);
     const int steps = (m_end - m_begin + 31) >> 5;
     const int QA = H2 / CPT, QB = H1 >> 1;
-    const float S = scale[0], invS = scale[1];
+    const float S = BIO ? 1.0f : scale[0], invS = BIO ? 1.0f : scale[1];
 
     // Roles per macro step of 32 rows.  dpre2: thread (column group ca, row octet oa) for tid < 4 QA - eight rows x CPT columns, the
     // expensive part (a Sigmoid derivative per element).  Z: thread (column pair cz, row octet oz) for tid < 4 QB - eight rows x two columns.
@@ -823,7 +836,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool is_z = tid < 4 * QB;
     const int cz = is_z ? tid % QB : 0, oz = is_z ? tid / QB : 0;
 
-    for (int i = tid; i < 2 * PW_BUF; i += 512) pw_lds[i] = w3_u32x4{0u, 0u, 0u, 0u};      // (columns past the matrices stay zero for good)
+    for (int i = tid; i < 2 * BUFK; i += 512) pw_lds[i] = w3_u32x4{0u, 0u, 0u, 0u};      // (columns past the matrices stay zero for good)
 
     f32x16 acc[5][2];
 #pragma unroll
@@ -836,8 +849,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // The rows of a macro step come through buffer descriptors rebuilt per step from wave-uniform values (base = the step's first row,
     // size = what is left of the slab), with per-lane byte offsets that never change and the row within the octet as the scalar offset:
     // no 64-bit address arithmetic on the vector ALU, and rows past the slab read as zero (dx = 0 switches such a row off).
-    typename std::conditional<CPT == 3, w3_u32x3, w3_u32x4>::type xa[8];
-    w3_u32x2 xz[8];
+    typename std::conditional<BIO, w3_u32x2, typename std::conditional<CPT == 3, w3_u32x3, w3_u32x4>::type>::type xa[8];
+    typename std::conditional<BIO, uint32_t, w3_u32x2>::type xz[8];
     // The predicate of the step's first row and the row its range ends at, wave-uniform (the rows of a predicate are contiguous and
     // row_pred is non-decreasing): an octet that ends before that row reads the predicate's embedding columns through a uniform base; the
     // few octets at a boundary look their rows up one by one.
@@ -848,37 +861,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // The thread's constants (byte offsets of its loads, its columns) live in LDS and are re-read where they are used: registers that would
     // otherwise sit idle under the MFMAs, where accumulators + operand fragments + the row ring fill the 256 of a wavefront.
-    int* cst = reinterpret_cast<int*>(pw_lds + 2 * PW_BUF) + tid;      // [2][512] words, then (SUMS) the threads' running sums [2 CPT][512]
-    const int rs_p = (int)(ld_p2 * 4), rs_z = (int)(ld_z * 4);
+    int* cst = reinterpret_cast<int*>(pw_lds + 2 * BUFK) + tid;       // [2][512] words, then (SUMS) the threads' running sums [2 CPT][512]
+    const int rs_p = (int)(ld_p2 * EB), rs_z = (int)(ld_z * EB);
     // the 16-byte LDS entry of column `col` (tile col >> 5, row col & 31 of the MFMA operand) for the eight rows of octet o
-    auto entry = [&](int col, int o, int tiles) __attribute__((always_inline)) { return ((o >> 1) * 2 * tiles + (col >> 5)) * 64 + (col & 31) + 32 * (o & 1); };
+    auto entry = [&](int col, int o, int tiles) __attribute__((always_inline)) { return ((o >> 1) * NPC * tiles + (col >> 5)) * 64 + (col & 31) + 32 * (o & 1); };
     cst[0] = ca | (oa << 16);                                          // (two words per thread; everything else is derived where it is used)
     cst[512] = cz | (oz << 16);
     auto k_oa = [&]() __attribute__((always_inline)) { return cst[0] >> 16; };
     auto k_col0 = [&]() __attribute__((always_inline)) { return CPT * (cst[0] & 0xffff); };                    // the thread's first column of dpre2
     auto k_goff = [&]() __attribute__((always_inline)) { return 32 * (cst[0] >> 16); };                        // byte offset of its octet's dx
-    auto k_voff_a = [&]() __attribute__((always_inline)) { const int w = cst[0]; return (8 * (w >> 16) * (int)ld_p2 + CPT * (w & 0xffff)) * 4; };
-    auto k_voff_z = [&]() __attribute__((always_inline)) { const int w = cst[512]; return (8 * (w >> 16) * (int)ld_z + 2 * (w & 0xffff)) * 4; };
-    auto k_at_z = [&]() __attribute__((always_inline)) { const int w = cst[512]; return PW_A_ENT + entry(2 * (w & 0xffff), w >> 16, PW_TB); };   // entry of its first Z column
+    auto k_voff_a = [&]() __attribute__((always_inline)) { const int w = cst[0]; return (8 * (w >> 16) * (int)ld_p2 + CPT * (w & 0xffff)) * EB; };
+    auto k_voff_z = [&]() __attribute__((always_inline)) { const int w = cst[512]; return (8 * (w >> 16) * (int)ld_z + 2 * (w & 0xffff)) * EB; };
+    auto k_at_z = [&]() __attribute__((always_inline)) { const int w = cst[512]; return A_ENT + entry(2 * (w & 0xffff), w >> 16, PW_TB); };   // entry of its first Z column
 
     struct Desc { __amdgpu_buffer_rsrc_t p, z, g; };
     auto descriptors = [&](int s) __attribute__((always_inline)) {     // step s (past the slab: empty ranges, every load returns zero)
         const int first = m_begin + 32 * s, left = max(m_end - first, 0);
         Desc d;
-        d.p = w3_descriptor(P2 + (int64_t)first * ld_p2, left > 0 ? ((int64_t)(left - 1) * ld_p2 + H2) * 4 : 0);
-        d.z = w3_descriptor(Z + (int64_t)first * ld_z, left > 0 ? ((int64_t)(left - 1) * ld_z + H1) * 4 : 0);
+        d.p = w3_descriptor(P2 + (int64_t)first * ld_p2, left > 0 ? ((int64_t)(left - 1) * ld_p2 + H2) * EB : 0);
+        d.z = w3_descriptor(Z + (int64_t)first * ld_z, left > 0 ? ((int64_t)(left - 1) * ld_z + H1) * EB : 0);
         d.g = w3_descriptor(G + first, (int64_t)left * 4);
         return d;
     };
     auto load_a = [&](const Desc& d, int i) __attribute__((always_inline)) {           // row i of the thread's octet
         const int voff_a = k_voff_a();
-        if constexpr (CPT == 3) xa[i] = __builtin_amdgcn_raw_buffer_load_b96(d.p, voff_a, i * rs_p, 0);
+        if constexpr (BIO) xa[i] = __builtin_amdgcn_raw_buffer_load_b64(d.p, voff_a, i * rs_p, 0);
+        else if constexpr (CPT == 3) xa[i] = __builtin_amdgcn_raw_buffer_load_b96(d.p, voff_a, i * rs_p, 0);
         else xa[i] = __builtin_amdgcn_raw_buffer_load_b128(d.p, voff_a, i * rs_p, 0);
     };
     auto load_z = [&](const Desc& d) __attribute__((always_inline)) {
         const int voff_z = k_voff_z();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xz[i] = __builtin_amdgcn_raw_buffer_load_b64(d.z, voff_z, i * rs_z, 0);
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (BIO) xz[i] = __builtin_amdgcn_raw_buffer_load_b32(d.z, voff_z, i * rs_z, 0);
+            else xz[i] = __builtin_amdgcn_raw_buffer_load_b64(d.z, voff_z, i * rs_z, 0);
+        }
     };
 
     // ---- building step s (its rows are in xa / xz) into `buf`, a chunk at a time; `next`: the descriptors of step s + 1, whose rows refill
@@ -886,7 +903,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // SUMS: the running sums live in LDS (the accumulators leave no register that survives the MFMAs: held in registers they were
     // spilled to scratch and reloaded four times a step, 2.44 ms against 1.77 for the kernel without them) and are read, added to and
     // written back by every pair of rows
-    float* sums = reinterpret_cast<float*>(pw_lds + 2 * PW_BUF) + 1024 + tid;      // [2 CPT][512]: dE sums, then db2 sums
+    float* sums = reinterpret_cast<float*>(pw_lds + 2 * BUFK) + 1024 + tid;       // [2 CPT][512]: dE sums, then db2 sums
     if constexpr (SUMS) {
 #pragma unroll
         for (int t = 0; t < 2 * CPT; ++t) sums[512 * t] = 0.f;
@@ -948,15 +965,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
 #ifndef PW_SKIP_SG
                 for (int t = 0; t < CPT; ++t) {
-                    const float hh = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * __uint_as_float(xa[i][t])));
-                    v[r][t] = (gs * e[t]) * (hh * (1.0f - hh));
+                    float xv;
+                    if constexpr (BIO) xv = __uint_as_float((t & 1) ? (xa[i][t >> 1] & 0xffff0000u) : (xa[i][t >> 1] << 16));
+                    else xv = __uint_as_float(xa[i][t]);
+                    const float hh = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * xv));
+                    if constexpr (BIO) v[r][t] = __uint_as_float(w3_pack1(gs * e[t] * hh * (1.0f - hh)));      // (the value dfol_pair_logit_bwd_bf16 stores)
+                    else v[r][t] = (gs * e[t]) * (hh * (1.0f - hh));
                     if constexpr (SUMS) {
                         sde[t] = fmaf(gs, hh, sde[t]);
                         sdb[t] += v[r][t];
                     }
                 }
 #else
-                for (int t = 0; t < CPT; ++t) v[r][t] = (gs * e[t]) * __uint_as_float(xa[i][t]);
+                for (int t = 0; t < CPT; ++t) v[r][t] = gs * e[t];
 #endif
             }
             if constexpr (SUMS) {
@@ -968,15 +989,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             load_a(next, 2 * k + 1);
 #pragma unroll
             for (int t = 0; t < CPT; ++t) {
-                uint32_t h, l;
-                pw_split2(v[0][t], v[1][t], h, l);
                 const int at = entry(col0 + t, o, PW_TA) * 4 + k;      // 4-byte piece k of the entry: rows 2 k, 2 k + 1
+                if constexpr (BIO) {
+                    buf32[at] = (__float_as_uint(v[0][t]) >> 16) | (__float_as_uint(v[1][t]) & 0xffff0000u);      // (rounded above: the high halves are the bf16 bits)
+                } else {
+                    uint32_t h, l;
+                    pw_split2(v[0][t], v[1][t], h, l);
 #ifndef PW_SKIP_AW
-                buf32[at] = h;
-                buf32[at + PW_TA * 64 * 4] = l;
+                    buf32[at] = h;
+                    buf32[at + PW_TA * 64 * 4] = l;
 #else
-                if (h == 0x12345678u) buf32[at] = h + l;
+                    if (h == 0x12345678u) buf32[at] = h + l;
 #endif
+                }
             }
         }
     };
@@ -985,13 +1010,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int at = k_at_z();
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float v[8];
+                if constexpr (BIO) {                                   // eight rows' halfword c of one word each -> the entry's four words (row 2 j in the low half)
+                    w3_u32x4 en;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(xz[i][c]);
-                w3_u32x4 h, l;
-                pw_split8(v, h, l);
-                buf[at + c] = h;
-                buf[at + c + PW_TB * 64] = l;
+                    for (int j = 0; j < 4; ++j)
+                        en[j] = c ? ((xz[2 * j] >> 16) | (xz[2 * j + 1] & 0xffff0000u)) : ((xz[2 * j] & 0xffffu) | (xz[2 * j + 1] << 16));
+                    buf[at + c] = en;
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(xz[i][c]);
+                    w3_u32x4 h, l;
+                    pw_split8(v, h, l);
+                    buf[at + c] = h;
+                    buf[at + c + PW_TB * 64] = l;
+                }
             }
             load_z(next);
         }
@@ -999,12 +1032,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ta0 = 5 * (wave >> 2), tb0 = 2 * (wave & 3);
     // one tile row of the step's MFMAs: k-step ks, A tile t against both B tiles (fragments read just before)
     auto tile_row = [&](const w3_u32x4* __restrict__ buf, int ks, int t) __attribute__((always_inline)) {
-        const w3_u32x4* Ab = buf + ks * 2 * PW_TA * 64 + lane;
-        const w3_u32x4* Bb = buf + PW_A_ENT + ks * 2 * PW_TB * 64 + lane;
-        const pw_f16x8 ah = __builtin_bit_cast(pw_f16x8, Ab[(ta0 + t) * 64]), al = __builtin_bit_cast(pw_f16x8, Ab[(PW_TA + ta0 + t) * 64]);
+        const w3_u32x4* Ab = buf + ks * NPC * PW_TA * 64 + lane;
+        const w3_u32x4* Bb = buf + A_ENT + ks * NPC * PW_TB * 64 + lane;
+        if constexpr (BIO) {
+            const w3_bf16x8 a = __builtin_bit_cast(w3_bf16x8, Ab[(ta0 + t) * 64]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(w3_bf16x8, Bb[(tb0 + u) * 64]), acc[t][u], 0, 0, 0);
+            return;
+        }
+        const pw_f16x8 ah = __builtin_bit_cast(pw_f16x8, Ab[(ta0 + t) * 64]), al = __builtin_bit_cast(pw_f16x8, Ab[((NPC - 1) * PW_TA + ta0 + t) * 64]);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                                  // smallest terms first
-            const pw_f16x8 bh = __builtin_bit_cast(pw_f16x8, Bb[(tb0 + u) * 64]), bl = __builtin_bit_cast(pw_f16x8, Bb[(PW_TB + tb0 + u) * 64]);
+            const pw_f16x8 bh = __builtin_bit_cast(pw_f16x8, Bb[(tb0 + u) * 64]), bl = __builtin_bit_cast(pw_f16x8, Bb[((NPC - 1) * PW_TB + tb0 + u) * 64]);
 #ifndef PW_SKIP_MM
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][u], 0, 0, 0);
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][u], 0, 0, 0);
@@ -1031,8 +1071,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
-        const w3_u32x4* cur = pw_lds + (s & 1) * PW_BUF;
-        w3_u32x4* nxt = pw_lds + ((s + 1) & 1) * PW_BUF;
+        const w3_u32x4* cur = pw_lds + (s & 1) * BUFK;
+        w3_u32x4* nxt = pw_lds + ((s + 1) & 1) * BUFK;
         uint32_t* nxt32 = reinterpret_cast<uint32_t*>(nxt);
         const bool more = s + 1 < steps;                               // (uniform) is there a step s + 1 to build
         const int p_old = p_cur, end_old = end_cur;
@@ -1160,9 +1200,9 @@ extern "C" int64_t dfol_pair_wgrad_fused_sums_workspace(int64_t M, int32_t H2, i
     return slabs * ((((int64_t)H2 * H1) + 3) & ~(int64_t)3) + (2 * slabs + P) * 4 * (int64_t)H2;
 }
 
-static int pw_launch(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P, const float* E,
-                     int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t H2, int32_t H1, float* workspace, float* dW,
-                     float* dE, int64_t ld_de, float* dbe, float* db2, bool sums, void* stream);
+static int pw_launch(const void* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P, const float* E,
+                     int64_t ld_e, const float* scale, const void* Z, int64_t ld_z, int64_t M, int32_t H2, int32_t H1, float* workspace, float* dW,
+                     float* dE, int64_t ld_de, float* dbe, float* db2, bool sums, void* stream, bool bio = false);
 
 // scale: device pointer to {S, 1 / S}, S a power of two with S max_r(|dx[r]| max|E[row_pred[r]]|) / 4 <= 2^14 (see above)
 // row_pred [M]: NON-DECREASING valid rows of E (the pair rows of a predicate are contiguous), pred_off [P + 1]: the first pair row of every
@@ -1185,18 +1225,27 @@ extern "C" int dfol_pair_wgrad_fused_sums_f32(const float* pre2, int64_t ld_p2, 
     return pw_launch(pre2, ld_p2, dx, row_pred, pred_off, P, E, ld_e, scale, Z, ld_z, M, H2, H1, workspace, dW, dE, ld_de, dbe, db2, true, stream);
 }
 
-static int pw_launch(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P, const float* E,
-                     int64_t ld_e, const float* scale, const float* Z, int64_t ld_z, int64_t M, int32_t H2, int32_t H1, float* workspace, float* dW,
-                     float* dE, int64_t ld_de, float* dbe, float* db2, bool sums, void* stream) {
+// ... over bf16-STORED pre2 and Z (the bf16 mode; strides in elements, multiples of 4, 8-byte aligned rows): one bf16 piece per operand,
+// dpre2 rounded as dfol_pair_logit_bwd_bf16 stores it; db2 = the column sums of those rounded values.  HID2 % 4 == 0 is enough here.
+extern "C" int dfol_pair_wgrad_fused_sums_bf16(const void* pre2_bf16, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off,
+                                               int32_t P, const float* E, int64_t ld_e, const void* Z_bf16, int64_t ld_z, int64_t M, int32_t H2,
+                                               int32_t H1, float* workspace, float* dW, float* dE, int64_t ld_de, float* dbe, float* db2, void* stream) {
+    DFOL_REQUIRE(P > 0 && dE && db2 && ld_de >= H2 && H2 <= 320, "pair_wgrad_fused_sums_bf16: bad arguments P=%d", P);
+    return pw_launch(pre2_bf16, ld_p2, dx, row_pred, pred_off, P, E, ld_e, nullptr, Z_bf16, ld_z, M, H2, H1, workspace, dW, dE, ld_de, dbe, db2, true, stream, true);
+}
+
+static int pw_launch(const void* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P, const float* E,
+                     int64_t ld_e, const float* scale, const void* Z, int64_t ld_z, int64_t M, int32_t H2, int32_t H1, float* workspace, float* dW,
+                     float* dE, int64_t ld_de, float* dbe, float* db2, bool sums, void* stream, bool bio) {
     DFOL_REQUIRE(M > 0 && M < (1ll << 31) - 64 && H2 >= 4 && H1 >= 4 && H2 % 4 == 0 && H1 % 4 == 0 && H2 <= 32 * PW_TA && H1 <= 32 * PW_TB,
                  "pair_wgrad_fused: bad sizes M=%lld H2=%d H1=%d (multiples of 4, H2 <= %d, H1 <= %d)", (long long)M, H2, H1, 32 * PW_TA, 32 * PW_TB);
-    DFOL_REQUIRE(pre2 && dx && row_pred && pred_off && E && scale && Z && workspace && dW, "pair_wgrad_fused: null pointer");
-    DFOL_REQUIRE(ld_p2 % 4 == 0 && ld_z % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)pre2 % 16 == 0) && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)E % 16 == 0),
-                 "pair_wgrad_fused: rows of pre2, Z and E must be 16-byte aligned");
+    DFOL_REQUIRE(pre2 && dx && row_pred && pred_off && E && (scale || bio) && Z && workspace && dW, "pair_wgrad_fused: null pointer");
+    DFOL_REQUIRE(ld_p2 % 4 == 0 && ld_z % 4 == 0 && ld_e % 4 == 0 && ((uintptr_t)pre2 % (bio ? 8 : 16) == 0) && ((uintptr_t)Z % (bio ? 8 : 16) == 0) &&
+                 ((uintptr_t)E % 16 == 0), "pair_wgrad_fused: rows of pre2, Z and E must be 16-byte (bf16 storage: 8-byte) aligned");
     DFOL_REQUIRE(8 * std::max(ld_p2, ld_z) * 4 * 4 < (1ll << 31), "pair_wgrad_fused: row stride too large (%lld)", (long long)std::max(ld_p2, ld_z));
     const int slabs = pw_slabs(M);
     const int rows_per_slab = (dfol_cdiv(M, slabs) + 31) & ~31;
-    const size_t lds = (size_t)2 * PW_BUF * 16 + (2 + 6) * 512 * 4;          // (CPT = 4 with the sums: 2 + 8 words per thread - see DFOL_PW)
+    size_t lds = (size_t)2 * PW_BUF * 16 + (2 + 6) * 512 * 4;                // (fp32 storage with CPT = 4 and the sums - 2 + 8 words per thread - does not fit)
     const int64_t elems = (int64_t)H2 * H1;
     float* de_part = workspace + (int64_t)slabs * ((elems + 3) & ~(int64_t)3);
     float* db_part = de_part + ((int64_t)slabs + P) * 4 * H2;
@@ -1209,7 +1258,14 @@ static int pw_launch(const float* pre2, int64_t ld_p2, const float* dx, const in
         hipLaunchKernelGGL((pair_wgrad_fused_kernel<C, S>), dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z, \
                            ld_z, (int)M, H2, H1, rows_per_slab, workspace, de_part, db_part);                                                   \
     }
-    if (H2 % 3 == 0) {                                                 // (4 (H2 / 3) <= 427 threads build dpre2)
+    if (bio) {
+        lds = (size_t)PW_BUF * 16 + (2 + 8) * 512 * 4;                  // (one piece per operand: the two buffers are half the size)
+        static const hipError_t ok = hipFuncSetAttribute((const void*)pair_wgrad_fused_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)((size_t)PW_BUF * 16 + (2 + 8) * 512 * 4));
+        DFOL_REQUIRE(ok == hipSuccess && sums, "pair_wgrad_fused (bf16 storage): cannot reserve %zu bytes of LDS (%s)", lds, hipGetErrorString(ok));
+        hipLaunchKernelGGL((pair_wgrad_fused_kernel<4, true, true>), dim3(slabs), dim3(512), lds, st, pre2, ld_p2, dx, row_pred, pred_off, E, ld_e, scale, Z,
+                           ld_z, (int)M, H2, H1, rows_per_slab, workspace, de_part, db_part);
+    } else if (H2 % 3 == 0) {                                          // (4 (H2 / 3) <= 427 threads build dpre2)
         if (sums) DFOL_PW(3, true) else DFOL_PW(3, false)
     } else {
         DFOL_REQUIRE(!sums, "pair_wgrad_fused_sums: HID2=%d must be a multiple of 3 (the running sums of four columns per thread do not fit the LDS)", H2);

@@ -317,7 +317,9 @@ class _PairTrunk(torch.autograd.Function):
         w = w if w.is_contiguous() else w.contiguous()
         b = None if bias is None else bias.detach()
         f16x2 = _lib._dense_math() == "f16x2"
-        if f16x2 and L.linear_tall_supported(z.shape[0], w.shape[0], w.shape[1]):
+        if z.dtype == torch.bfloat16:                         # the bf16 mode's stored activations: the persistent product over them (the logit layer keeps its own pass: its
+            pre2, x_part = L.linear_tall_h2(z, w, b)[0], z.new_zeros(0, dtype=torch.float32)      # epilogue form is the slower one at half the bytes)
+        elif f16x2 and L.linear_tall_supported(z.shape[0], w.shape[0], w.shape[1]):
             # one persistent workgroup per CU over the row blocks (csrc/dfol_dense_tall.hip): the same bits, 1.9 ms against 2.6 at 256 x 100 objects
             pre2, x_part = L.linear_tall_h2(z, w, b, *((first[1], first[0]) if first is not None else ()))
             x_part = z.new_zeros(0) if x_part is None else x_part
@@ -329,6 +331,7 @@ class _PairTrunk(torch.autograd.Function):
                      need_db=bias is not None and ctx.needs_input_grad[2], dz=None, dw=None, db=None)
         ctx.state, ctx.shapes = state, (z.shape, weight.shape)
         ctx.mark_non_differentiable(pre2, x_part)
+        ctx.set_materialize_grads(False)                     # (or the engine fills a [pairs, HID2] zero gradient for pre2 on the way in: 3 GB, 0.4 - 0.6 ms)
         return pre2, z.new_zeros(1), x_part
 
     @staticmethod
@@ -337,7 +340,7 @@ class _PairTrunk(torch.autograd.Function):
         dz, dw, db = st["dz"], st["dw"], st["db"]
         dev = st["w"].device
         if st["need_dz"] and dz is None:
-            dz = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+            dz = torch.zeros(ctx.shapes[0], dtype=st["z"].dtype, device=dev)
         if st["need_dw"] and dw is None:
             dw = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
         if st["need_db"] and db is None:
@@ -353,6 +356,7 @@ class _HeadUse(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, token, pre2, e_rows, be_rows, pred_off, row_pred, max_rows, state, x_part, sums_ok):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(pre2, e_rows, pred_off, row_pred)
         ctx.state, ctx.sums_ok = state, bool(sums_ok)
         if x_part is not None:                                # the trunk's epilogue has this reader's partial sums already
@@ -363,9 +367,13 @@ class _HeadUse(torch.autograd.Function):
     def backward(ctx, dx):
         pre2, e_rows, pred_off, row_pred = ctx.saved_tensors
         st = ctx.state
+        if dx is None:                                        # (this reader's logits did not reach the loss)
+            return (None,) * 10
         dx = dx.contiguous()
         e_rows = e_rows if e_rows.is_contiguous() else e_rows.contiguous()
         need_be = ctx.needs_input_grad[3]
+        if pre2.dtype == torch.bfloat16:
+            return _HeadUse._backward_bf16(ctx, st, dx, pre2, e_rows, pred_off, row_pred, need_be)
         mode = os.environ.get("DFOL_HEAD_SUMS", "auto")       # "1" / "0": always / never take the sums from the weight-gradient pass (where it can)
         if ctx.sums_ok and st["need_dw"] and pre2.shape[1] % 3 == 0 and mode != "0" and (mode == "1" or pre2.shape[0] >= (1 << 20)):
             dz, dw, de, dbe, db2 = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], True, dz_out=st["dz"],
@@ -376,6 +384,33 @@ class _HeadUse(torch.autograd.Function):
             dz, dw = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], st["need_dw"], dz_out=st["dz"])
         if st["need_dz"]:
             st["dz"] = dz                                     # (a later reader adds into it)
+        if st["need_dw"]:
+            st["dw"] = dw if st["dw"] is None else st["dw"] + dw
+        if st["need_db"]:
+            st["db"] = db2 if st["db"] is None else st["db"] + db2
+        return dx.new_zeros(1), None, de, dbe, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_bf16(ctx, st, dx, pre2, e_rows, pred_off, row_pred, need_be):
+        """The bf16 mode (bf16-stored pre2 / Z): dz in bfloat16 from the persistent product with dpre2 rebuilt and rounded as the materialised
+        route stores it, dW2 and the sums from one pass; predicates too small for that pass go the materialised way, locally."""
+        with _lib.dense_math("bf16"):
+            if ctx.sums_ok and st["need_dw"]:
+                dz = L.pair_dz_tall_bf16(dx, pre2, e_rows, row_pred, st["w"], dz_out=st["dz"]) if st["need_dz"] else None
+                dw, de, dbe, db2 = L.pair_wgrad_sums_bf16(dx, pre2, st["z"], e_rows, pred_off, row_pred, need_bias=need_be)
+            else:
+                dp2, de, dbe = L.pair_logit_bwd(dx, pre2, e_rows, pred_off, need_bias=need_be)
+                dz = None
+                if st["need_dz"]:
+                    dz = L.linear_act_split(dp2, st["w"], None, L.ACT_NONE, transpose_w=True)
+                    dz = dz if st["dz"] is None else st["dz"] + dz
+                dw = db2 = None
+                if st["need_dw"]:
+                    dw, db2 = L.linear_wgrad(dp2, st["z"], bias=True)
+                elif st["need_db"]:
+                    db2 = dp2.float().sum(0)
+        if st["need_dz"]:
+            st["dz"] = dz
         if st["need_dw"]:
             st["dw"] = dw if st["dw"] is None else st["dw"] + dw
         if st["need_db"]:
@@ -619,9 +654,17 @@ class ClassifierOracle(OracleBase):
     def _head_fused(self, world, z, lin1, lin2):
         """The deferred head backward applies: fused training kernels, fp32-stored activations on the split-operand pipes, widths the one-workgroup
         weight-gradient kernel takes, and not switched off (DFOL_TRAIN_HEAD_FUSED=0)."""
-        return os.environ.get("DFOL_TRAIN_HEAD_FUSED", "1") != "0" and self._fused_training(world) and z.is_cuda and z.dtype == torch.float32 and \
-            _lib._dense_math() in ("f16x2", "bf16x3") and L.pair_head_fused_supported(lin1.weight.shape[0], lin2.weight.shape[0]) and \
-            z.shape[0] >= 4096 and torch.is_grad_enabled()
+        if os.environ.get("DFOL_TRAIN_HEAD_FUSED", "1") == "0" or not (self._fused_training(world) and z.is_cuda and torch.is_grad_enabled()):
+            return False
+        if not L.pair_head_fused_supported(lin1.weight.shape[0], lin2.weight.shape[0]):
+            return False
+        if z.dtype == torch.bfloat16:
+            # the bf16 mode with bf16-stored activations: built and pinned (tests), but NOT faster than the materialised route there - at half
+            # the bytes the two products that rebuild dpre2 are bound by its arithmetic, done twice (6.98 against 7.01 ms per step): opt-in
+            return os.environ.get("DFOL_TRAIN_HEAD_FUSED_BF16", "0") == "1" and _lib._dense_math() == "bf16" and lin2.weight.shape[0] % 4 == 0 and \
+                L.linear_tall_supported(z.shape[0], lin2.weight.shape[0], lin2.weight.shape[1]) and \
+                L.linear_tall_supported(z.shape[0], lin2.weight.shape[1], lin2.weight.shape[0])
+        return z.dtype == torch.float32 and _lib._dense_math() in ("f16x2", "bf16x3") and z.shape[0] >= 4096
 
     def _pair_hidden_autograd(self, world):
         """h = Sigmoid(pre2) [pairs, HID2]; shared by all relation operators of the scene."""

@@ -456,6 +456,17 @@ int dfol_linear_tall_h2_f32(const float* X, int64_t ldx, const void* W_split, co
 int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
                           const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t HID1, int32_t HID2,
                           int32_t accumulate, float* workspace, void* stream);
+/* The bf16 mode's forms of the same (bf16-STORED activations: `void*` rows of bfloat16, strides in elements, multiples of 4; one bf16 piece
+ * per operand, fp32 accumulation, bfloat16 results rounded to nearest even): bit for bit dfol_linear_act_bf16_bf16 resp.
+ * dfol_pair_logit_bwd_bf16 followed by it; wgrad_fused_sums_bf16 always yields the sums (every predicate >= 64 rows or none), needs no
+ * scale (bf16 has fp32's exponent range) and only HID2 % 4 == 0; workspace as dfol_pair_wgrad_fused_sums_workspace. */
+int dfol_linear_tall_bf16_bf16(const void* X_bf16, int64_t ldx, const void* W_bf16, const float* bias, void* Y_bf16, int64_t ldy, int32_t M, int32_t N,
+                               int32_t K, const int32_t* row_pred, const float* E, int64_t ld_e, float* x_part, int64_t ld_xp, void* stream);
+int dfol_pair_dz_tall_bf16(const void* pre2_bf16, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
+                           const void* W2t_bf16, void* dZ_bf16, int64_t ld_dz, int32_t M, int32_t HID1, int32_t HID2, int32_t accumulate, void* stream);
+int dfol_pair_wgrad_fused_sums_bf16(const void* pre2_bf16, int64_t ld_p2, const float* dx, const int32_t* row_pred, const int64_t* pred_off, int32_t P,
+                                    const float* E, int64_t ld_e, const void* Z_bf16, int64_t ld_z, int64_t M, int32_t HID2, int32_t HID1,
+                                    float* workspace, float* dW, float* dE, int64_t ld_de, float* dbe, float* db2, void* stream);
 int dfol_pair_logit_bwd_sums_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,
                                  const int64_t* pred_off, int32_t P, float* dE, int64_t ld_de, float* dbe, float* dB2, int64_t ld_db2, void* stream);
 int dfol_pair_dz_fused_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,

@@ -1069,3 +1069,33 @@ def test_tall_products_bf16_storage_equal_the_tiled_bf16_kernels_bit_for_bit(M, 
             assert dz.dtype == torch.bfloat16 and torch.equal(dz, dz_ref)
             dz2 = _lib.pair_dz_tall_bf16(dx, x, Ek, rep, wt, dz_out=dz.clone())
             assert torch.allclose(dz2.float(), 2 * dz.float(), rtol=1e-2, atol=0)
+
+
+@pytest.mark.parametrize("counts,hid1,hid2", [([9900, 5112, 3540], 256, 300), ([64, 0, 71, 4000, 65, 0, 0, 1560, 97, 64 * 3 + 5], 256, 300), ([2450] * 9, 128, 64)])
+def test_pair_wgrad_sums_bf16_storage_against_the_materialised_bf16_route(counts, hid1, hid2):
+    """dfol_pair_wgrad_fused_sums_bf16 (pre2 and Z stored in bfloat16, dpre2 rebuilt and rounded in the kernel) against the bf16 mode's
+    materialised route on the same tensors: dfol_pair_logit_bwd_bf16 (dpre2 stored in bfloat16, dE, dbe) and the bf16-storage weight gradient
+    with its bias sums - equal up to the order of the fp32 accumulation; two runs are bit-identical."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(len(counts) + hid2)
+    counts = np.asarray(counts, np.int64)
+    M, P = int(counts.sum()), len(counts)
+    dev = lambda a: torch.as_tensor(a).to(DEV)
+    pred_off = dev(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64))
+    rep = dev(np.repeat(np.arange(P), counts).astype(np.int32))
+    p2 = dev((rng.normal(size=(M, hid2)) * 2.5).astype(np.float32)).to(torch.bfloat16)
+    z = dev(np.where(rng.uniform(size=(M, hid1)) < 0.5, rng.uniform(-1, 0, (M, hid1)), rng.uniform(0, 6, (M, hid1))).astype(np.float32)).to(torch.bfloat16)
+    E = dev((rng.normal(size=(P, hid2)) * 0.1).astype(np.float32))
+    dx = dev((rng.normal(size=M) * 10.0 ** rng.randint(-2, 3, M)).astype(np.float32))
+    with _lib.dense_math("bf16"):
+        dp2, de_ref, dbe_ref = _lib.pair_logit_bwd(dx, p2, E, pred_off)
+        dw_ref, db_ref = _lib.linear_wgrad(dp2, z, bias=True)
+        dw, de, dbe, db2 = _lib.pair_wgrad_sums_bf16(dx, p2, z, E, pred_off, rep)
+        again = _lib.pair_wgrad_sums_bf16(dx, p2, z, E, pred_off, rep)
+    for a, b in zip((dw, de, dbe, db2), again):
+        assert torch.equal(a, b)
+    mag = (dp2.float().abs().t() @ z.float().abs())
+    assert ((dw - dw_ref).abs() <= 4e-6 * mag + 1e-30).all()
+    assert ((db2 - db_ref).abs() <= 4e-6 * dp2.float().abs().sum(0) + 1e-30).all()
+    assert torch.allclose(de, de_ref, rtol=2e-5, atol=2e-5 * float(de_ref.abs().max()))
+    assert torch.allclose(dbe, dbe_ref, rtol=2e-5, atol=2e-5 * float(dbe_ref.abs().max()))

@@ -990,6 +990,8 @@ def train_kernel_rooflines(args, per_step):
         pairs * (4.0 * H2 + 4 * H1 + 8), "pairs x (4 HID2 + 4 HID1 + 8) B", extra=lambda r: mm(r, 4.0 * H2 + 4 * H1 + 8))
     add("dfol_pair_wgrad_fused_f32", "pair_wgrad_fused_kernel<3> (dW2 = dpre2^T Z, pre2 and Z read once) + reduce", "hbm",
         pairs * (4.0 * H2 + 4 * H1 + 8), "pairs x (4 HID2 + 4 HID1 + 8) B", extra=lambda r: mm(r, 4.0 * H2 + 4 * H1 + 8))
+    add("dfol_pair_wgrad_fused_sums_f32", "pair_wgrad_fused_kernel<3, true> (dW2 = dpre2^T Z and the logit layer's sums dE, dbe, db2; pre2 and Z read once) + reduces", "hbm",
+        pairs * (4.0 * H2 + 4 * H1 + 8), "pairs x (4 HID2 + 4 HID1 + 8) B", extra=lambda r: mm(r, 4.0 * H2 + 4 * H1 + 8))
     add("dfol_pair_logit_bwd_sums_f32", "pair_logit_bwd4_kernel (dE, dbe, db2 sums; no dpre2 written)", "hbm", pairs * (4.0 * H2 + 4), "pairs x (4 HID2 + 4) B")
     add("dfol_relate_bwd_f32", "relate_bwd (tile read twice, gradient tile written)", "hbm", Q * (12.0 * N * N + 24 * N), "P x (12 N^2 + 24 N) B")
     add("dfol_filter_bwd_f32", "filter_bwd", "hbm", per_step.get("dfol_filter_bwd_f32", (1, 1))[0] * Q * 16.0 * N, "launches x P x 16 N B")

@@ -33,7 +33,7 @@ def algorithmic(name, mode):
     if "pair_hidden1_fwd" in name: return pairs * (b * H1 + 16)
     if "pair_hidden1_bwd" in name: return pairs * (2 * b * H1 + 16)
     if "pair_logit_fwd" in name: return pairs * (b * H2 + 4)
-    if "pair_logit_bwd" in name: return pairs * ((2 if mode == "bf16" else 1) * b * H2 + 4)     # (fp32 mode, round 4: the sums only - dpre2 is not written)
+    if "pair_logit_bwd" in name: return pairs * (2 * b * H2 + 4)
     if "tall_h2_kernel" in name or "pair_wgrad_fused_kernel" in name: return pairs * (H1 + H2) * b
     return None
 print("# HBM traffic of the train step's kernels, round 4 (N = 100, 256 questions; rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of")

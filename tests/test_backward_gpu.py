@@ -951,7 +951,8 @@ def test_linear_logit_h2_partial_sums(M, N, K):
 
 
 @pytest.mark.parametrize("kinds,n_lo,n_hi,count", [(("exist", "verify_rel"), 18, 30, 8), (("choose_rel", "query_attr"), 18, 30, 8),
-                                                    (("exist", "verify_rel"), 2, 34, 12)])      # images of 2 .. 8 objects: predicates of 2 .. 56 rows
+                                                    (("exist", "verify_rel"), 2, 34, 12),       # images of 2 .. 8 objects: predicates of 2 .. 56 rows
+                                                    (("exist", "verify_rel"), 34, 44, 8)])      # > 16384 pair rows: the persistent products
 def test_deferred_head_backward_equals_the_materialised_one(kinds, n_lo, n_hi, count, monkeypatch):
     """The full-size model on ragged scenes with programs of one to three relation hops (several readers of one hidden layer: the deferred
     trunk adds their input and weight gradients), relation option lists and no-op tokens (readers that cannot register with the trunk and

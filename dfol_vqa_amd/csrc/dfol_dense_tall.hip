@@ -32,7 +32,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TL_BM = 128, TL_BK = 32, TL_XD = 4;                     // rows of a block, k of a step, steps of X rows in flight
-constexpr int TL_TILE = 2 * 128 * 4;                                  // 16-byte pieces of one [2 pieces][128 rows][4 k-groups] tile (16 KB)
 
 __device__ __forceinline__ int tl_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 __device__ __forceinline__ void tl_split2h(float x0, float x1, uint32_t& h, uint32_t& l) {

@@ -996,19 +996,23 @@ def train_kernel_rooflines(args, per_step):
     add("dfol_relate_bwd_f32", "relate_bwd (tile read twice, gradient tile written)", "hbm", Q * (12.0 * N * N + 24 * N), "P x (12 N^2 + 24 N) B")
     add("dfol_filter_bwd_f32", "filter_bwd", "hbm", per_step.get("dfol_filter_bwd_f32", (1, 1))[0] * Q * 16.0 * N, "launches x P x 16 N B")
     add("dfol_quantify_bwd_f32", "quantify_bwd", "hbm", Q * (8.0 * N + 4), "P x (8 N + 4) B")
-    wflops = 2.0 * (pairs * H2 * H1 + O * (512 * 2048 + 2 * H1 * 516 + 256 * 516 + H2 * 256))
+    # (round 4: the pair layer's three products have entry points of their own - rows above - when the deferred head runs; the rows below
+    # then count the per-object layers only)
+    head = any(k in per_step for k in ("dfol_pair_wgrad_fused_sums_f32", "dfol_pair_wgrad_fused_f32"))
+    tall_fwd = "dfol_linear_tall_h2_f32" in per_step
+    wflops = 2.0 * ((0 if head else pairs * H2 * H1) + O * (512 * 2048 + 2 * H1 * 516 + 256 * 516 + H2 * 256))
     # fp32 results from the bf16 pipe: six bf16 MFMA flops are executed per algorithmic flop (three-way operand split), so `frac` against the
     # bf16 dense peak is bounded by 1/6; `executed` is the pipe-side rate (as for the pair kernel of the inference line)
     for entry, pieces in (("dfol_linear_wgrad_bias_f32", 6), ("dfol_linear_wgrad_bias_bf16", 1)):
-        add(entry, "wgrad_tn3_kernel (dW = dY^T X and db: pair layer 300 x 256 over all pairs + the five per-object layers)", "mfma", wflops,
-            "2 (pairs HID2 HID1 + O (512 2048 + 2 256 516 + 256 516 + 300 256)) flops", peak=BF16_MFMA_PEAK,
+        add(entry, "wgrad_tn3_kernel (dW = dY^T X and db: %sthe five per-object layers)" % ("" if head else "pair layer 300 x 256 over all pairs + "), "mfma", wflops,
+            "2 (%sO (512 2048 + 2 256 516 + 256 516 + 300 256)) flops" % ("" if head else "pairs HID2 HID1 + "), peak=BF16_MFMA_PEAK,
             extra=lambda rate, pieces=pieces: {"executed": {"mfma_flops_per_algorithmic_flop": pieces, "achieved": pieces * rate / 1e12,
                                                             "frac": pieces * rate / BF16_MFMA_PEAK},
                                                "vs_f32_mfma_peak": {"peak": F32_MFMA_PEAK / 1e12, "frac": rate / F32_MFMA_PEAK}})
     # the split-kernel GEMMs of the step: forward of the four per-object layers and of the pair layer (two fp16 pieces, three products - in the
     # bf16 mode one bf16 piece), input gradients of all but the featurizer (three bf16 pieces, six products: operands of any magnitude)
-    fwd = 2.0 * (pairs * H2 * H1 + O * (512 * 2048 + 2 * H1 * 516 + 256 * 516 + H2 * 256))
-    bwd = 2.0 * (pairs * H2 * H1 + O * (2 * H1 * 516 + 256 * 516 + H2 * 256))
+    fwd = 2.0 * ((0 if tall_fwd else pairs * H2 * H1) + O * (512 * 2048 + 2 * H1 * 516 + 256 * 516 + H2 * 256))
+    bwd = 2.0 * ((0 if head else pairs * H2 * H1) + O * (2 * H1 * 516 + 256 * 516 + H2 * 256))
     h2_runs = "dfol_linear_act_h2_f32" in per_step
     for entry, what, work, note in (
             ("dfol_linear_act_h2_f32", "linear_act_split_kernel, two fp16 pieces (the forward products: pair layer [pairs,256]->300, the per-object layers)", fwd,

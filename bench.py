@@ -1015,10 +1015,10 @@ def train_kernel_rooflines(args, per_step):
     bwd = 2.0 * ((0 if head else pairs * H2 * H1) + O * (2 * H1 * 516 + 256 * 516 + H2 * 256))
     h2_runs = "dfol_linear_act_h2_f32" in per_step
     for entry, what, work, note in (
-            ("dfol_linear_act_h2_f32", "linear_act_split_kernel, two fp16 pieces (the forward products: pair layer [pairs,256]->300, the per-object layers)", fwd,
-             "2 (pairs HID2 HID1 + O (512 2048 + 2 256 516 + 256 516 + 300 256)) flops"),
+            ("dfol_linear_act_h2_f32", "linear_act_split_kernel, two fp16 pieces (the forward products: %sthe per-object layers)" % ("" if tall_fwd else "pair layer [pairs,256]->300, "), fwd,
+             "2 (%sO (512 2048 + 2 256 516 + 256 516 + 300 256)) flops" % ("" if tall_fwd else "pairs HID2 HID1 + ")),
             ("dfol_linear_act_split_f32", "linear_act_split_kernel, three bf16 pieces (the input-gradient products%s)" % ("" if h2_runs else " and the forward products"),
-             bwd if h2_runs else fwd + bwd, "2 (pairs HID2 HID1 + O (2 256 516 + 256 516 + 300 256)) flops" + ("" if h2_runs else " + the forward products'")),
+             bwd if h2_runs else fwd + bwd, "2 (%sO (2 256 516 + 256 516 + 300 256)) flops" % ("" if head else "pairs HID2 HID1 + ") + ("" if h2_runs else " + the forward products'")),
             ("dfol_linear_act_bf16_f32", "linear_act_split_kernel, one bf16 piece (forward and input-gradient products)", fwd + bwd,
              "2 (2 pairs HID2 HID1 + O (512 2048 + 2 (2 256 516 + 256 516 + 300 256))) flops")):
         pieces = {"dfol_linear_act_split_f32": 6, "dfol_linear_act_h2_f32": 3}.get(entry, 1)

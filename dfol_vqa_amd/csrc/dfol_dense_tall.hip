@@ -31,9 +31,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef TL_ANTIPHASE
-#define TL_ANTIPHASE 0
-#endif
 constexpr int TL_BM = 128, TL_BK = 32, TL_XD = 4;                     // rows of a block, k of a step, steps of X rows in flight
 
 __device__ __forceinline__ int tl_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -426,26 +423,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         store_b(nxt);                                                 // (the weight tiles of step g + 1, requested a step ago)
         load_w();
         __builtin_amdgcn_sched_barrier(0);
-#if TL_ANTIPHASE
-        // the two wavefronts of a SIMD (w and w + 4: wm = 0 and 1) take the step's two halves in opposite order - one splits / builds the
-        // next step's rows while the other multiplies (the halves are independent: they touch different LDS buffers)
-        if (wm == 0) {
-            multiply(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            store_a(next_tag, nxt);
-            load_x(next_tag);
-        } else {
-            store_a(next_tag, nxt);
-            load_x(next_tag);
-            __builtin_amdgcn_sched_barrier(0);
-            multiply(cur);
-        }
-#else
         multiply(cur);
         __builtin_amdgcn_sched_barrier(0);
+        // (the SIMD's two wavefronts taking these two halves in opposite order - a branch on wm around both orders - was measured at 5.4 ms
+        // against 1.4: the doubled body no longer fits the instruction cache / the register budget)
         store_a(next_tag, nxt);                                       // under the tail of the MFMAs; frees the register set ...
         load_x(next_tag);                                             // ... for the rows four steps on
-#endif
         __syncthreads();                                              // buffer nxt complete, buffer cur fully read
         ++g;
         if (++cks == ksteps) {                                        // (uniform) the block is done

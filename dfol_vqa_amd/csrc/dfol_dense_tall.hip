@@ -437,6 +437,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             cb += stride;
         }
     };
+    // (Code size: with the epilogue inlined behind each of the four bodies the forward-with-logits kernel is 109 KB, more than the 64 KB
+    // instruction cache.  Two ways to have it once were measured and lost: a scalar switch around the four bodies, one step per trip - the
+    // allocator then spills 140 - 580 bytes per lane; the epilogue behind the fourth body only, for step counts that are multiples of
+    // four - 96 bytes of spills, 2.39 ms against 1.9.)
     while (g < T) {
         body(S1);
         if (g < T) body(S2);

@@ -426,7 +426,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         multiply(cur);
         __builtin_amdgcn_sched_barrier(0);
         // (the SIMD's two wavefronts taking these two halves in opposite order - a branch on wm around both orders - was measured at 5.4 ms
-        // against 1.4: the doubled body no longer fits the instruction cache / the register budget)
+        // against 1.4: the doubled body no longer fits the instruction cache / the register budget; one scheduling region for both halves with
+        // a sched_group_barrier pattern of one MFMA, 2 - 4 vector instructions, one LDS read: no change, 1.85 -> 1.88 ms)
         store_a(next_tag, nxt);                                       // under the tail of the MFMAs; frees the register set ...
         load_x(next_tag);                                             // ... for the rows four steps on
         __syncthreads();                                              // buffer nxt complete, buffer cur fully read

@@ -57,6 +57,22 @@ class OperatorBatch(object):
             self._mask = torch.from_numpy(mask).float() if isinstance(mask, np.ndarray) else mask
             self._mask._host = self._mask.tolist()
 
+    # -- pickling (collate worker processes hand ProgramBatches to the process that launches): tensors lose python attributes on the way ---
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_mask_host"] = getattr(self._mask, "_host", None) if self._mask is not None else None
+        pqm = self._predicate_question_map
+        d["_pqm_host"] = getattr(pqm, "_host", None) if pqm is not None else None
+        return d
+
+    def __setstate__(self, d):
+        mask_host, pqm_host = d.pop("_mask_host", None), d.pop("_pqm_host", None)
+        self.__dict__.update(d)
+        if self._mask is not None and mask_host is not None:
+            self._mask._host = mask_host
+        if self._predicate_question_map is not None and pqm_host is not None:
+            self._predicate_question_map._host = pqm_host
+
     # -- lowering --------------------------------------------------------------------------------
     def lower(self, ontology):
         """Resolve the token arguments of select / filter / relate / verify_rel against the ontology."""

@@ -773,17 +773,22 @@ def pair_hidden1_fwd(u, v, pos, wg, obj_off, pair_off, n_obj, max_n, pairs, stor
     return z, geo
 
 
-def pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, max_n, total_obj):
-    """(dU [O, HID1], dV [O, HID1], dWg [HID1, 4]) from dZ; deterministic (no atomics)."""
+def pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, max_n, total_obj, joined=False):
+    """(dU [O, HID1], dV [O, HID1], dWg [HID1, 4]) from dZ; deterministic (no atomics).  joined: dU and dV are the two column halves of one
+    [O, 2 HID1] buffer (the gradient of a joined U|V product - visual_oracle._pair_pre2_autograd)."""
     Q, hid1 = n_obj.shape[0], z.shape[1]
-    du = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)             # objects of images with < 2 objects get no row written
-    dv = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)
+    if joined:
+        duv = torch.zeros(total_obj, 2 * hid1, dtype=F32, device=z.device)
+        du, dv = duv[:, :hid1], duv[:, hid1:]
+    else:
+        du = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)         # objects of images with < 2 objects get no row written
+        dv = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)
     part = torch.zeros(Q, hid1, 4, dtype=F32, device=z.device)
     if z.dtype == torch.bfloat16 and dz.dtype != torch.bfloat16:
         dz = dz.to(torch.bfloat16)
     call("dfol_pair_hidden1_bwd_bf16" if z.dtype == torch.bfloat16 else "dfol_pair_hidden1_bwd_f32", _ptr(dz, z.dtype), _ptr(z, z.dtype), _ptr(geo, F32), _ptr(obj_off, I32), _ptr(pair_off, torch.int64),
-         _ptr(n_obj, I32), Q, max_n, hid1, _ptr(du), du.stride(0), _ptr(dv), dv.stride(0), _ptr(part), _stream())
-    return du, dv, part.sum(0)
+         _ptr(n_obj, I32), Q, max_n, hid1, _dp(du), du.stride(0), _dp(dv), dv.stride(0), _ptr(part), _stream())
+    return (duv, None, part.sum(0)) if joined else (du, dv, part.sum(0))
 
 
 def pair_logit_fwd(p2, e_rows, be_rows, pred_off, max_rows):

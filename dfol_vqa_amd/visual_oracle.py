@@ -269,6 +269,10 @@ class _FusedHidden1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, U, V, Wg, pos, world, store=torch.float32):
+        ctx.joined = V is None                                  # U is [O, 2 HID1]: U | V, one product of the object features
+        if ctx.joined:
+            h = U.shape[1] // 2
+            U, V = U[:, :h], U[:, h:]
         max_n = max(world._n_list)
         z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num, store)
         # (the world itself must not hang on the graph: world -> cached activations -> graph -> world would be a reference cycle that
@@ -280,7 +284,7 @@ class _FusedHidden1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         z, geo, obj_off, pair_off, n_obj = ctx.saved_tensors
-        du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj)
+        du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj, ctx.joined)
         return du, dv, dwg, None, None, None
 
 
@@ -618,18 +622,28 @@ class ClassifierOracle(OracleBase):
             obj = world._obj
             D = (lin1.weight.shape[1] - 4) // 2
             assert obj.shape[1] == D, "object feature width does not match the relation network"
-            if obj.is_cuda and obj.dtype == torch.float32:
+            pos = obj[:, D - 4:].detach()                       # batch_gqa_boxfeatures_pipeline.py:263-279
+            hid1 = lin1.weight.shape[0]
+            fused = self._fused_training(world) and hid1 % 4 == 0
+            if fused and obj.is_cuda and obj.dtype == torch.float32 and os.environ.get("DFOL_TRAIN_UV_JOINED", "1") != "0":
+                # U | V as ONE product of the object features ([2 HID1, D] weight: the subject block over the object block; the bias
+                # belongs to U alone): the features are read once forward, their gradient is one K = 2 HID1 product backward instead
+                # of two products and an add, and the pair layer's backward writes dU | dV into one buffer
+                wuv = torch.cat([lin1.weight[:, :D], lin1.weight[:, D:2 * D]], 0)
+                buv = torch.cat([lin1.bias, lin1.bias.new_zeros(hid1)])
+                U, V = L.linear_act(obj, wuv, buv, L.ACT_NONE), None
+            elif obj.is_cuda and obj.dtype == torch.float32:
                 U = L.linear_act(obj, lin1.weight[:, :D], lin1.bias, L.ACT_NONE)          # forward and both gradients on the HIP kernels
                 V = L.linear_act(obj, lin1.weight[:, D:2 * D], None, L.ACT_NONE)
             else:
                 U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias)
                 V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
-            pos = obj[:, D - 4:].detach()                       # batch_gqa_boxfeatures_pipeline.py:263-279
-            if self._fused_training(world) and U.shape[1] % 4 == 0:
+            if fused:
                 # bf16 mode: Z, pre2 and their gradients live in bfloat16 (what autocast stores; half the bytes of the step's streams and
                 # of the two tall products' operands) - csrc/dfol_pair_train.hip, dfol_linear_act_bf16_bf16, dfol_linear_wgrad_bias_bf16_bf16
                 store = torch.bfloat16 if L.bf16_store(lin1.weight.shape[0], lin2.weight.shape[0]) else torch.float32
-                z = _FusedHidden1.apply(U.contiguous(), V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(), pos, world, store)
+                z = _FusedHidden1.apply(U.contiguous(), None if V is None else V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(),
+                                        pos, world, store)
             else:
                 s_idx, o_idx = world.pair_index()
                 ps, po = pos.index_select(0, s_idx), pos.index_select(0, o_idx)

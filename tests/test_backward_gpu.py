@@ -325,7 +325,8 @@ def test_calibrator_gradients_native_backward_equals_torch_autograd(ontology, mo
         assert (gh - gt).abs().max().item() <= 2e-4 * scale + 1e-7, (n_, (gh - gt).abs().max().item(), scale)
 
 
-@pytest.mark.parametrize("n_list,hid1,hid2", [([7, 1, 13, 2, 30, 5], 64, 50), ([40, 33], 256, 300), ([3, 3, 3], 16, 7), ([100, 12], 256, 300)])
+@pytest.mark.parametrize("n_list,hid1,hid2", [([7, 1, 13, 2, 30, 5], 64, 50), ([40, 33], 256, 300), ([3, 3, 3], 16, 7), ([100, 12], 256, 300),
+                                              ([70, 1, 9, 71], 256, 20), ([100, 150, 1, 37], 128, 32)])       # (three slot batches per subject)
 def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
     """csrc/dfol_pair_train.hip against the tensor-op formulation it replaces (gathers, adds, ELU, Sigmoid, embedding product, row sums
     and their autograd): forward values and all five gradients, ragged scenes incl. images with one object, fp64 reference."""
@@ -355,7 +356,9 @@ def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
     dy = ps[:, 1] + ps[:, 3] / 2.0 - po[:, 1] - po[:, 3] / 2.0
     dist = np.sqrt(dx * dx + dy * dy)
     g = geo.cpu().numpy().astype(np.float64)
-    assert np.allclose(g[:, 0], dist, rtol=1e-5, atol=1e-6) and np.allclose(np.sin(g[:, 1]), dy / np.maximum(dist, 1e-10), atol=2e-6)
+    assert np.allclose(g[:, 0], dist, rtol=1e-5, atol=1e-6)
+    # (dy is a float32 difference of coordinates of order 1: its rounding, 2e-7 at most, is divided by the distance)
+    assert (np.abs(np.sin(g[:, 1]) - dy / np.maximum(dist, 1e-10)) <= 2e-6 + 2e-7 / np.maximum(dist, 1e-10)).all()
     assert np.array_equal(g[:, 2], np.sign(po[:, 0] - ps[:, 0])) and np.array_equal(g[:, 3], np.sign(po[:, 1] - ps[:, 1]))
     # ... and everything downstream of them against float64 autograd on the same geometry
     Ut, Vt, Wt = (torch.tensor(a.astype(np.float64), requires_grad=True) for a in (U, V, Wg))

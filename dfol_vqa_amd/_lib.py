@@ -111,6 +111,8 @@ SIGNATURES = {
                                 _i32, _p, _p],
     "dfol_pair_hidden1_fwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
     "dfol_pair_hidden1_bwd_f32": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _p],
+    "dfol_pair_hidden1_bwd_recompute_supported": [_i32, _i32],
+    "dfol_pair_hidden1_bwd_recompute_f32": [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_pair_logit_fwd_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i32, _i64, _i64, _p, _p],
     "dfol_pair_logit_bwd_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i64, _p, _p],
     "dfol_pair_logit_bwd_sums_f32": [_p, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _p, _i64, _p],
@@ -773,22 +775,34 @@ def pair_hidden1_fwd(u, v, pos, wg, obj_off, pair_off, n_obj, max_n, pairs, stor
     return z, geo
 
 
-def pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, max_n, total_obj, joined=False):
+def pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, max_n, total_obj, joined=False, uvw=None):
     """(dU [O, HID1], dV [O, HID1], dWg [HID1, 4]) from dZ; deterministic (no atomics).  joined: dU and dV are the two column halves of one
-    [O, 2 HID1] buffer (the gradient of a joined U|V product - visual_oracle._pair_pre2_autograd)."""
-    Q, hid1 = n_obj.shape[0], z.shape[1]
+    [O, 2 HID1] buffer (the gradient of a joined U|V product - visual_oracle._pair_pre2_autograd).  uvw = (U, V, Wg), fp32 storage: z is
+    rebuilt from them inside the kernel instead of being read (`z` may be None; DFOL_H1B_RECOMPUTE=0 reads it)."""
+    Q, hid1 = n_obj.shape[0], dz.shape[1]
     if joined:
-        duv = torch.zeros(total_obj, 2 * hid1, dtype=F32, device=z.device)
+        duv = torch.zeros(total_obj, 2 * hid1, dtype=F32, device=dz.device)
         du, dv = duv[:, :hid1], duv[:, hid1:]
     else:
-        du = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)         # objects of images with < 2 objects get no row written
-        dv = torch.zeros(total_obj, hid1, dtype=F32, device=z.device)
-    part = torch.zeros(Q, hid1, 4, dtype=F32, device=z.device)
+        du = torch.zeros(total_obj, hid1, dtype=F32, device=dz.device)        # objects of images with < 2 objects get no row written
+        dv = torch.zeros(total_obj, hid1, dtype=F32, device=dz.device)
+    part = torch.zeros(Q, hid1, 4, dtype=F32, device=dz.device)
+    if hidden1_recompute(uvw, dz, max_n, hid1) or z is None:
+        u, v, wg = uvw
+        call("dfol_pair_hidden1_bwd_recompute_f32", _ptr(dz, F32), _dp(u), u.stride(0), _dp(v), v.stride(0), _ptr(wg, F32), _ptr(geo, F32), _ptr(obj_off, I32),
+             _ptr(pair_off, torch.int64), _ptr(n_obj, I32), Q, max_n, hid1, _dp(du), du.stride(0), _dp(dv), dv.stride(0), _ptr(part), _stream())
+        return (duv, None, part.sum(0)) if joined else (du, dv, part.sum(0))
     if z.dtype == torch.bfloat16 and dz.dtype != torch.bfloat16:
         dz = dz.to(torch.bfloat16)
     call("dfol_pair_hidden1_bwd_bf16" if z.dtype == torch.bfloat16 else "dfol_pair_hidden1_bwd_f32", _ptr(dz, z.dtype), _ptr(z, z.dtype), _ptr(geo, F32), _ptr(obj_off, I32), _ptr(pair_off, torch.int64),
          _ptr(n_obj, I32), Q, max_n, hid1, _dp(du), du.stride(0), _dp(dv), dv.stride(0), _ptr(part), _stream())
     return (duv, None, part.sum(0)) if joined else (du, dv, part.sum(0))
+
+
+def hidden1_recompute(uvw, dz, max_n, hid1):
+    """True when the pair layer's first-stage backward rebuilds z instead of reading it (fp32 storage, the image fits the 512-thread form)."""
+    return uvw is not None and dz.dtype == F32 and os.environ.get("DFOL_H1B_RECOMPUTE", "1") != "0" and \
+        bool(load().dfol_pair_hidden1_bwd_recompute_supported(int(max_n), int(hid1)))
 
 
 def pair_logit_fwd(p2, e_rows, be_rows, pred_off, max_rows):

@@ -149,16 +149,26 @@ constexpr int HB_MAXO = 16;                                   // objects per lan
 // trip (s_waitcnt vmcnt(0) in each: seven in a row per subject at 100 objects) and only the 16 wavefronts of the CU overlap them; 128
 // registers per lane leave no room for more (batching the loads there spills in the loop: 1.95 ms against 0.8).  THREADS = 512 (images of up
 // to MAXO * G = 128 objects at HID1 = 256): 256 registers per lane, the loads of BATCH slots are issued together without branches (rows that do
-// not exist are clamped to one that does and masked out of the sums).  (Recomputing z from U[s], V[o] and the geometry instead of reading it -
-// half the HBM bytes - was built and measured: no faster in fp32 storage, 0.15 ms SLOWER per step in bf16 storage; the kernel is bound by its
-// chain of round trips and the VALU work per element, not by bytes.)
-template <typename TZ, int THREADS, int MAXO, int BATCH>
+// not exist are clamped to one that does and masked out of the sums).  Recomputing z from U[s], V[o] and the geometry instead of reading it
+// (half the HBM bytes) did not pay while every batch was a full round trip (round 3: no faster in fp32 storage, 0.15 ms slower per step in
+// bf16 storage); with the loads pipelined the fp32 pass sits at 5.9 - 6.0 TB/s and the rebuilt form (RECOMP below) takes 664 against 864 us
+// at 256 x 100 objects, HID1 = 256 - bound by its VALU work (about 24 lane operations per element), like the bf16-storage pass (658 us).
+// RECOMP (fp32 storage, BATCH > 1): Z is not read.  z = ELU(U[s] + V[o] + Wg geo) is rebuilt with the forward kernel's own expression from the
+// image's V rows (staged in LDS once: 128 KB at most), the subject's U row, the lane's four rows of Wg and the geometry the pass reads
+// anyway: the pass reads dZ alone, half the bytes.
+struct HbRecompute {
+    const float* U; int64_t ld_u;
+    const float* V; int64_t ld_v;
+    const float* Wg;
+};
+template <typename TZ, int THREADS, int MAXO, int BATCH, bool RECOMP = false>
 __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __restrict__ dZ, const TZ* __restrict__ Z,
                                                                     const float* __restrict__ geo, const int32_t* __restrict__ obj_off,
                                                                     const int64_t* __restrict__ pair_off, const int32_t* __restrict__ n_obj,
                                                                     int H1, float* __restrict__ dU, int64_t ld_du, float* __restrict__ dV,
-                                                                    int64_t ld_dv, float* __restrict__ dWg_partial) {
-    extern __shared__ __attribute__((aligned(16))) float red[];            // [2][G][H1] floats
+                                                                    int64_t ld_dv, float* __restrict__ dWg_partial, HbRecompute rc) {
+    static_assert(!RECOMP || (BATCH > 1 && sizeof(TZ) == 4), "hidden1_bwd: z is rebuilt in the batched fp32 form only");
+    extern __shared__ __attribute__((aligned(16))) float red[];            // [2][G][H1] floats (+ RECOMP: [n][H1] rows of V)
     const int q = blockIdx.x, n = n_obj[q], lpr = H1 >> 2, G = THREADS / lpr;
     const int g = (int)threadIdx.x / lpr, k = ((int)threadIdx.x % lpr) * 4, first = obj_off[q];
     const int64_t base = pair_off[q];
@@ -215,9 +225,17 @@ __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __r
         // subjects per pass).  Before: issue, wait, sum per batch - the loaded latency of HBM 2 n times in a row per image.  Measured,
         // 256 images, HID1 = 256 (tools/lab/time_hidden1.py): 36 objects 168 -> 138 us fp32, 142 -> 109 us bf16 storage; 100 objects
         // 889 -> 889 us fp32 (5.9 TB/s read either way: the stream is at the chip's bandwidth there), 685 -> 696 us bf16.
-        typename pt_raw<TZ>::type dzr[2][BATCH], zr[2][BATCH];
-        float4 ger[2][BATCH];
+        typename pt_raw<TZ>::type dzr[2][BATCH], zr[RECOMP ? 1 : 2][RECOMP ? 1 : BATCH];
+        float4 ger[2][BATCH], ur[2], wg4[4];
+        float* vs = red + 2 * G * H1;
+        if constexpr (RECOMP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wg4[t] = ld4(rc.Wg + (k + t) * 4);
+            for (int o = g; o < n; o += G) st4(&vs[o * H1 + k], ld4(rc.V + (int64_t)(first + o) * rc.ld_v + k));
+            __syncthreads();
+        }
         auto issue = [&](auto SET, auto BI, int s) __attribute__((always_inline)) {
+            if constexpr (RECOMP) ur[decltype(SET)::value] = ld4(rc.U + (int64_t)(first + s) * rc.ld_u + k);
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
                 const int slot = decltype(BI)::value * BATCH + j;       // (static once unrolled)
@@ -225,7 +243,8 @@ __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __r
                     const int o = g + slot * G;
                     // (a lane without a pair in this slot reads the image's first pair row; n >= 2 here: slot 0 of n == 1 has s == o)
                     const int64_t row = (o < n && o != s) ? base + (int64_t)s * (n - 1) + (o - (o > s)) : (n >= 2 ? base : 0);
-                    dzr[decltype(SET)::value][j] = ld4_stream_raw(dZ + row * H1 + k), zr[decltype(SET)::value][j] = ld4_stream_raw(Z + row * H1 + k);
+                    dzr[decltype(SET)::value][j] = ld4_stream_raw(dZ + row * H1 + k);
+                    if constexpr (!RECOMP) zr[decltype(SET)::value][j] = ld4_stream_raw(Z + row * H1 + k);
                     ger[decltype(SET)::value][j] = ld4(geo + row * 4);
                 }
             }
@@ -237,8 +256,20 @@ __global__ __launch_bounds__(THREADS) void pair_hidden1_bwd_kernel(const TZ* __r
                 if (slot * G < n) {
                     const int o = g + slot * G;
                     const float m = (o < n && o != s) ? 1.f : 0.f;                  // (a lane without a pair adds exact zeros)
-                    const float4 d = pt_widen(dzr[decltype(SET)::value][j]);
-                    add(slot, make_float4(m * d.x, m * d.y, m * d.z, m * d.w), pt_widen(zr[decltype(SET)::value][j]), ger[decltype(SET)::value][j], du);
+                    const float4 d = pt_widen(dzr[decltype(SET)::value][j]), ge = ger[decltype(SET)::value][j];
+                    float4 z;
+                    if constexpr (RECOMP) {                      // (pair_hidden1_fwd_kernel's expression, term for term)
+                        const float4 u = ur[decltype(SET)::value], v = ld4(&vs[min(o, n - 1) * H1 + k]);
+                        const float uv[4] = {u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+                        float out[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            out[t] = pt_elu(uv[t] + (wg4[t].x * ge.x + wg4[t].y * ge.y + wg4[t].z * ge.z + wg4[t].w * ge.w));
+                        z = make_float4(out[0], out[1], out[2], out[3]);
+                    } else {
+                        z = pt_widen(zr[decltype(SET)::value][j]);
+                    }
+                    add(slot, make_float4(m * d.x, m * d.y, m * d.z, m * d.w), z, ge, du);
                 }
             }
         };
@@ -537,11 +568,36 @@ static int hidden1_bwd_launch(const TZ* dZ, const TZ* Z, const float* geo, const
     const int G5 = 512 / (H1 / 4);
     if (force != 1024 && H1 / 4 <= 512 && G5 >= 1 && max_n <= HB_MAXO * G5)
         hipLaunchKernelGGL((pair_hidden1_bwd_kernel<TZ, 512, HB_MAXO, 4>), dim3(Q), dim3(512), (size_t)2 * G5 * H1 * sizeof(float), (hipStream_t)stream, dZ, Z,
-                           geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
+                           geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial, HbRecompute{});
     else
         hipLaunchKernelGGL((pair_hidden1_bwd_kernel<TZ, 1024, HB_MAXO, 1>), dim3(Q), dim3(1024), (size_t)2 * G * H1 * sizeof(float), (hipStream_t)stream, dZ, Z,
-                           geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial);
+                           geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV, ld_dv, dWg_partial, HbRecompute{});
     DFOL_LAUNCH_CHECK("pair_hidden1_bwd");
+    return 0;
+}
+
+// The same sums WITHOUT reading Z (fp32 storage): z is rebuilt from U, V, Wg and the geometry - see HbRecompute.  Images of up to
+// 16 * (512 / (HID1 / 4)) objects (the 512-thread form: dfol_pair_hidden1_bwd_recompute_supported).
+extern "C" int dfol_pair_hidden1_bwd_recompute_supported(int32_t max_n, int32_t H1) {
+    return hidden_width_ok(H1) && H1 / 4 <= 512 && max_n <= HB_MAXO * (512 / (H1 / 4));
+}
+extern "C" int dfol_pair_hidden1_bwd_recompute_f32(const float* dZ, const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* Wg,
+                                                   const float* geo, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj,
+                                                   int32_t Q, int32_t max_n, int32_t H1, float* dU, int64_t ld_du, float* dV, int64_t ld_dv,
+                                                   float* dWg_partial, void* stream) {
+    DFOL_REQUIRE(dfol_pair_hidden1_bwd_recompute_supported(max_n, H1), "pair_hidden1_bwd_recompute: HID1=%d, max_n=%d not supported", H1, max_n);
+    DFOL_REQUIRE(ld_du % 4 == 0 && ld_dv % 4 == 0 && ld_u % 4 == 0 && ld_v % 4 == 0, "pair_hidden1_bwd_recompute: rows of U, V, dU and dV must be 16-byte aligned");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(dZ && U && V && Wg && geo && obj_off && pair_off && n_obj && dU && dV && dWg_partial, "pair_hidden1_bwd_recompute: null pointer");
+    DFOL_REQUIRE(((uintptr_t)U % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)Wg % 16 == 0), "pair_hidden1_bwd_recompute: U, V and Wg must be 16-byte aligned");
+    const int G5 = 512 / (H1 / 4);
+    const size_t lds = ((size_t)2 * G5 + (size_t)max_n) * H1 * sizeof(float);              // <= 16 KB + 128 KB
+    auto kern = pair_hidden1_bwd_kernel<float, 512, HB_MAXO, 4, true>;
+    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    DFOL_REQUIRE(lds_ok == hipSuccess && lds <= 144 * 1024, "pair_hidden1_bwd_recompute: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(kern, dim3(Q), dim3(512), lds, (hipStream_t)stream, dZ, (const float*)nullptr, geo, obj_off, pair_off, n_obj, H1, dU, ld_du, dV,
+                       ld_dv, dWg_partial, HbRecompute{U, ld_u, V, ld_v, Wg});
+    DFOL_LAUNCH_CHECK("pair_hidden1_bwd_recompute");
     return 0;
 }
 

@@ -277,14 +277,17 @@ class _FusedHidden1(torch.autograd.Function):
         z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num, store)
         # (the world itself must not hang on the graph: world -> cached activations -> graph -> world would be a reference cycle that
         # only the garbage collector frees, 3 GB per step)
-        ctx.save_for_backward(z, geo, world._obj_off, world._pair_off, world._n_obj)
+        # fp32 storage: the backward rebuilds z from U, V, Wg and the geometry instead of reading it (dfol_pair_hidden1_bwd_recompute_f32)
+        ctx.recompute = store == torch.float32 and L.hidden1_recompute((U, V, Wg), z, max_n, z.shape[1])
+        ctx.save_for_backward(z, geo, world._obj_off, world._pair_off, world._n_obj, *((U, V, Wg) if ctx.recompute else ()))
         ctx.max_n, ctx.total_obj = max_n, U.shape[0]
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        z, geo, obj_off, pair_off, n_obj = ctx.saved_tensors
-        du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj, ctx.joined)
+        z, geo, obj_off, pair_off, n_obj = ctx.saved_tensors[:5]
+        du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj, ctx.joined,
+                                         uvw=ctx.saved_tensors[5:] if ctx.recompute else None)
         return du, dv, dwg, None, None, None
 
 

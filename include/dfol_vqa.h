@@ -424,6 +424,16 @@ int dfol_pair_hidden1_fwd_f32(const float* U, int64_t ld_u, const float* V, int6
 int dfol_pair_hidden1_bwd_f32(const float* dZ, const float* Z, const float* geo, const int32_t* obj_off, const int64_t* pair_off,
                               const int32_t* n_obj, int32_t Q, int32_t max_n, int32_t HID1, float* dU, int64_t ld_du, float* dV,
                               int64_t ld_dv, float* dWg_partial, void* stream);
+
+/* The same three sums without reading Z (fp32 storage): z is rebuilt inside the kernel from U [O, HID1], V [O, HID1] (rows 16-byte
+ * aligned; the image's V rows are staged in LDS), Wg [HID1, 4] and the geometry, with dfol_pair_hidden1_fwd_f32's own expression - the
+ * pass reads dZ alone.  dfol_pair_hidden1_bwd_recompute_supported(max_n, HID1): images of up to 16 * (512 / (HID1 / 4)) objects.
+ * Replaces the same autograd nodes as dfol_pair_hidden1_bwd_f32 (oracle.py:304-316 backward). */
+int dfol_pair_hidden1_bwd_recompute_supported(int32_t max_n, int32_t H1);
+int dfol_pair_hidden1_bwd_recompute_f32(const float* dZ, const float* U, int64_t ld_u, const float* V, int64_t ld_v, const float* Wg,
+                                        const float* geo, const int32_t* obj_off, const int64_t* pair_off, const int32_t* n_obj,
+                                        int32_t Q, int32_t max_n, int32_t H1, float* dU, int64_t ld_du, float* dV, int64_t ld_dv,
+                                        float* dWg_partial, void* stream);
 int dfol_pair_logit_fwd_f32(const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e, const float* be,
                             const int64_t* pred_off, int32_t P, int64_t rows, int64_t max_rows, float* x, void* stream);
 int dfol_pair_logit_bwd_f32(const float* dx, const float* P2, int64_t ld_p2, int32_t HID2, const float* E, int64_t ld_e,

@@ -372,6 +372,13 @@ def test_fused_pair_training_kernels_against_autograd(n_list, hid1, hid2):
         assert np.abs(got.cpu().numpy() - want).max() <= 5e-5 * scale, tag
     du2, dv2, dw2 = _lib.pair_hidden1_bwd(dev(gz), z, geo, geom[0], geom[1], geom[2], geom[3], O)
     assert torch.equal(du, du2) and torch.equal(dv, dv2) and torch.equal(dw, dw2)          # no atomics: bitwise repeatable
+    # the form that rebuilds z from U, V, Wg instead of reading it, into the two halves of a joined [O, 2 HID1] buffer: the same bits
+    # (same expression as the forward kernel, same order of the sums)
+    UV = dev(np.concatenate([U, V], 1))
+    uvw = (UV[:, :hid1], UV[:, hid1:], dev(Wg))
+    assert _lib.hidden1_recompute(uvw, dev(gz), geom[3], hid1)
+    duv, none, dw3 = _lib.pair_hidden1_bwd(dev(gz), None, geo, geom[0], geom[1], geom[2], geom[3], O, joined=True, uvw=uvw)
+    assert none is None and torch.equal(duv[:, :hid1], du) and torch.equal(duv[:, hid1:], dv) and torch.equal(dw3, dw)
 
     # logit stage: two predicates on image 0 are not expressible (one contiguous row range per predicate), so one predicate per image
     P2 = rng.normal(size=(pairs, hid2)).astype(np.float32) * 2

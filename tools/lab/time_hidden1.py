@@ -39,5 +39,8 @@ for store in (torch.float32, torch.bfloat16):
     b = z.element_size()
     tf = timed(lambda: _lib.pair_hidden1_fwd(U, V, pos, Wg, obj_off, pair_off, n_obj, N, pairs, store))
     tb = timed(lambda: _lib.pair_hidden1_bwd(dz, z, geo, obj_off, pair_off, n_obj, N, O))
+    if store == torch.float32:
+        tr = timed(lambda: _lib.pair_hidden1_bwd(dz, None, geo, obj_off, pair_off, n_obj, N, O, uvw=(U, V, Wg)))
+        print(f"  bwd rebuilding z: {tr * 1e3:7.1f} us ({pairs * (H1 * b + 16) / tr / 1e9:5.2f} TB/s read)")
     print(f"{str(store):16s} N={N} Q={Q} HID1={H1}: fwd {tf * 1e3:7.1f} us ({pairs * (H1 * b + 16) / tf / 1e9:5.2f} TB/s written)   "
           f"bwd {tb * 1e3:7.1f} us ({pairs * (2 * H1 * b + 16) / tb / 1e9:5.2f} TB/s read)")

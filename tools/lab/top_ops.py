@@ -23,7 +23,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 rows = prof.key_averages(group_by_input_shape=True)
 rows = sorted(rows, key=lambda r: -getattr(r, "self_device_time_total", getattr(r, "self_cuda_time_total", 0)))
-for r in rows[:45]:
+rows = [r for r in rows if r.key.startswith("aten::") or r.key.startswith("dfol")]
+for r in rows[:60]:
     t = getattr(r, "self_device_time_total", getattr(r, "self_cuda_time_total", 0))
-    if r.key.startswith("aten::") or r.key.startswith("dfol"):
+    if t > 0:
         print("%8.1f us  x%-3d %-32s %s" % (t, r.count, r.key[:32], str(r.input_shapes)[:150]))

@@ -113,22 +113,24 @@ extern "C" int dfol_filter_bwd_f32(const float* g_out, const float* ll, const in
 //   G1[r,c] = gR[r] F_C'(S[r]) F_C'(l'+pC[c]) ; G2[r,c] = gC[c] F_R'(T[c]) F_R'(l'+pR[r])    (off-diagonal)
 //   d l' = G1 + G2 ;  d pR[r] = gR[r] + sum_c G2 ;  d pC[c] = gC[c] + sum_r G1
 // ---------------------------------------------------------------------------------------------------
-// One workgroup per predicate, its four wavefronts on rows r = w, w + 4, ...: a row's sums are taken by the wavefront that owns the row,
-// a column's partial sums of the four wavefronts are added in wavefront order (no atomics).  (One wavefront per predicate, round 1: 0.25 ms
-// for the 256 predicates of a train step, all of it the latency of 2 x 100 dependent row iterations.)
-__global__ __launch_bounds__(256) void relate_bwd_kernel(
+// One workgroup per predicate, its RB_WAVES wavefronts on rows r = w, w + RB_WAVES, ...: a row's sums are taken by the wavefront that owns the
+// row, a column's partial sums of the wavefronts are added in wavefront order (no atomics).  The kernel is the latency of its dependent row
+// iterations (one wavefront per predicate, round 1: 0.25 ms for the 256 predicates of a train step at 100 objects; four: 79 us; sixteen - a
+// predicate per CU still - see DESIGN 3.5).
+constexpr int RB_WAVES = 16;                                      // (four when the (3 + waves) NS floats of LDS would pass 48 KB)
+__global__ __launch_bounds__(64 * RB_WAVES) void relate_bwd_kernel(
     const float* __restrict__ prior_R, const float* __restrict__ prior_C, const float* __restrict__ tile,
     const int32_t* __restrict__ pred_q, const int32_t* __restrict__ n_obj, const float* __restrict__ quant_R,
     const float* __restrict__ quant_C, const uint8_t* __restrict__ neg, int any_neg, const uint8_t* __restrict__ active,
     const float* __restrict__ g_post_R, const float* __restrict__ g_post_C, int P, int NS, int identity_forall,
     float* __restrict__ g_prior_R, float* __restrict__ g_prior_C, float* __restrict__ g_tile) {
-    extern __shared__ float relate_bwd_lds[];                         // 7 NS floats: row sums / outer derivatives / per-wavefront column partials
+    extern __shared__ float relate_bwd_lds[];                         // (3 + RB_WAVES) NS floats: row sums / outer derivatives / per-wavefront column partials
     float* sS = relate_bwd_lds;
     float* sGR = sS + NS;
     float* sGC = sGR + NS;
     float* part_base = sGC + NS;
     auto part = [&](int wave, int c) -> float& { return part_base[wave * NS + c]; };
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x, nw = (int)blockDim.x >> 6, nt = (int)blockDim.x;
     const int p = blockIdx.x;
     const int q = pred_q[p];
     const int n = n_obj[q];
@@ -140,12 +142,12 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
     const float* gC = g_post_C ? g_post_C + (int64_t)p * NS : nullptr;
 
     if (active && !active[p]) {                            // posterior = prior: the gradient passes straight through
-        for (int c = tid; c < NS; c += 256) {
+        for (int c = tid; c < NS; c += nt) {
             if (g_prior_R) g_prior_R[(int64_t)p * NS + c] = (gR && c < n) ? gR[c] : 0.f;
             if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = (gC && c < n) ? gC[c] : 0.f;
         }
         if (gt)
-            for (int e = tid; e < NS * NS; e += 256) gt[e] = 0.f;
+            for (int e = tid; e < NS * NS; e += nt) gt[e] = 0.f;
         return;
     }
     const float alpha_n = (any_neg && neg[p]) ? 1.f : 0.f, cn = 1.f - 2.f * alpha_n;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
         const int c = c0 + lane;
         float t_acc = 0.f;
         const float pc = c < n ? pC[c] : 0.f;
-        for (int r = w; r < n; r += 4) {
+        for (int r = w; r < n; r += nw) {
             float s_part = 0.f;
             if (c < n && c != r) {
                 const float v = dfol_prep(tp[(int64_t)r * NS + c], any_neg, alpha_n, cn);
@@ -172,8 +174,9 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
     }
     __syncthreads();
     // outer derivatives (T[c]: the four partials in wavefront order)
-    for (int i = tid; i < n; i += 256) {
-        const float T = ((part(0, i) + part(1, i)) + part(2, i)) + part(3, i);
+    for (int i = tid; i < n; i += nt) {
+        float T = part(0, i);
+        for (int j = 1; j < nw; ++j) T += part(j, i);
         sGR[i] = gR ? gR[i] * (idC ? 1.f : dfol_dpnot(sS[i], qC, kC)) : 0.f;
         sGC[i] = gC ? gC[i] * (idR ? 1.f : dfol_dpnot(T, qR, kR)) : 0.f;
     }
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
         float dpc = 0.f;
         const float pc = c < n ? pC[c] : 0.f;
         const float gcc = c < n ? sGC[c] : 0.f;
-        for (int r = w; r < NS; r += 4) {
+        for (int r = w; r < NS; r += nw) {
             float dl = 0.f, dpr_part = 0.f;
             if (r < n && c < n && c != r) {
                 const float raw = tp[(int64_t)r * NS + c];
@@ -204,8 +207,12 @@ __global__ __launch_bounds__(256) void relate_bwd_kernel(
         if (c < NS) part(w, c) = dpc;
     }
     __syncthreads();
-    for (int c = tid; c < NS; c += 256) {
-        if (g_prior_C) g_prior_C[(int64_t)p * NS + c] = c < n ? (((part(0, c) + part(1, c)) + part(2, c)) + part(3, c)) + (gC ? gC[c] : 0.f) : 0.f;
+    for (int c = tid; c < NS; c += nt) {
+        if (g_prior_C) {
+            float t = part(0, c);
+            for (int j = 1; j < nw; ++j) t += part(j, c);
+            g_prior_C[(int64_t)p * NS + c] = c < n ? t + (gC ? gC[c] : 0.f) : 0.f;
+        }
         if (g_prior_R) g_prior_R[(int64_t)p * NS + c] = c < n ? sS[c] : 0.f;
     }
 }
@@ -221,7 +228,8 @@ extern "C" int dfol_relate_bwd_f32(const float* prior_s, const float* prior_o, c
     DFOL_REQUIRE(prior_s && prior_o && tile && pred_q && n_obj && quant_s && quant_o && (g_post_s || g_post_o), "relate_bwd: null pointer");
     DFOL_REQUIRE(!any_neg || neg, "relate_bwd: any_neg set but neg is NULL");
     const bool sr = orientation == DFOL_TILE_SUBJECT_ROWS;
-    hipLaunchKernelGGL(relate_bwd_kernel, dim3(P), dim3(256), (size_t)7 * NS * sizeof(float), (hipStream_t)stream, sr ? prior_s : prior_o,
+    const int waves = (size_t)(3 + RB_WAVES) * NS * sizeof(float) <= 48 * 1024 ? RB_WAVES : 4;
+    hipLaunchKernelGGL(relate_bwd_kernel, dim3(P), dim3(64 * waves), (size_t)(3 + waves) * NS * sizeof(float), (hipStream_t)stream, sr ? prior_s : prior_o,
                        sr ? prior_o : prior_s, tile, pred_q, n_obj, sr ? quant_s : quant_o, sr ? quant_o : quant_s, neg, any_neg, active,
                        sr ? g_post_s : g_post_o, sr ? g_post_o : g_post_s, P, NS, lone_forall_identity, sr ? g_prior_s : g_prior_o,
                        sr ? g_prior_o : g_prior_s, g_tile);

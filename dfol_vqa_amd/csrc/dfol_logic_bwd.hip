@@ -116,7 +116,7 @@ extern "C" int dfol_filter_bwd_f32(const float* g_out, const float* ll, const in
 // One workgroup per predicate, its RB_WAVES wavefronts on rows r = w, w + RB_WAVES, ...: a row's sums are taken by the wavefront that owns the
 // row, a column's partial sums of the wavefronts are added in wavefront order (no atomics).  The kernel is the latency of its dependent row
 // iterations (one wavefront per predicate, round 1: 0.25 ms for the 256 predicates of a train step at 100 objects; four: 79 us; sixteen - a
-// predicate per CU still - see DESIGN 3.5).
+// predicate per CU still - 29 us).
 constexpr int RB_WAVES = 16;                                      // (four when the (3 + waves) NS floats of LDS would pass 48 KB)
 __global__ __launch_bounds__(64 * RB_WAVES) void relate_bwd_kernel(
     const float* __restrict__ prior_R, const float* __restrict__ prior_C, const float* __restrict__ tile,

@@ -976,6 +976,8 @@ def train_kernel_rooflines(args, per_step):
 
     add("dfol_pair_hidden1_fwd_f32", "pair_hidden1_fwd (Z = ELU(U[s] + V[o] + Wg geo) written once)", "hbm", pairs * (4.0 * H1 + 16), "pairs x (4 HID1 + 16) B written")
     add("dfol_pair_hidden1_bwd_f32", "pair_hidden1_bwd (dU, dV, dWg reduced per image, no atomics)", "hbm", pairs * (8.0 * H1 + 16), "pairs x (8 HID1 + 16) B read")
+    add("dfol_pair_hidden1_bwd_recompute_f32", "pair_hidden1_bwd, Z rebuilt from U, V, Wg and the geometry instead of read (dU, dV, dWg reduced per image, no atomics)", "hbm",
+        pairs * (4.0 * H1 + 16), "pairs x (4 HID1 + 16) B read")
     add("dfol_pair_logit_fwd_f32", "pair_logit_fwd (Sigmoid . embedding row -> logit)", "hbm", pairs * (4.0 * H2 + 4), "pairs x (4 HID2 + 4) B")
     add("dfol_pair_logit_bwd_f32", "pair_logit_bwd (dP2, dE, db in one pass)", "hbm", pairs * (8.0 * H2 + 4), "pairs x (8 HID2 + 4) B")
     # round 4: the head's backward without dpre2 in memory, and the tall products as one persistent workgroup per CU - all four stream the

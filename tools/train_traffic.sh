@@ -31,7 +31,7 @@ pairs = Q * N * (N - 1)
 def algorithmic(name, mode):
     b = 2 if mode == "bf16" else 4                                  # bytes per stored per-pair activation
     if "pair_hidden1_fwd" in name: return pairs * (b * H1 + 16)
-    if "pair_hidden1_bwd" in name: return pairs * (2 * b * H1 + 16)
+    if "pair_hidden1_bwd" in name: return pairs * ((1 if name.rstrip().endswith("true>") else 2) * b * H1 + 16)      # (RECOMP: dZ and the geometry only)
     if "pair_logit_fwd" in name: return pairs * (b * H2 + 4)
     if "pair_logit_bwd" in name: return pairs * (2 * b * H2 + 4)
     if "tall_h2_kernel" in name or "pair_wgrad_fused_kernel" in name: return pairs * (H1 + H2) * b

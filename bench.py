@@ -657,9 +657,11 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
         for qs in batches[:2]:                               # warm-up: two batches (allocator, weight images)
             one(qs)
         torch.cuda.synchronize()
-        # collate of batch i + 1 runs on a worker thread while the main thread launches and reads back batch i (the reference collates in
-        # DataLoader worker processes, data_pipeline.py:893-898; the forward's wait for the device releases the interpreter lock)
-        from concurrent.futures import ThreadPoolExecutor
+        # One thread, software-pipelined: batch i's launches are enqueued (BatchInterpreterBase.forward_async: no read-back yet), batch
+        # i + 1 is collated and uploaded while the device runs batch i, then batch i's answers are read back and scored.  (The reference
+        # collates in DataLoader worker processes, data_pipeline.py:893-898.  Collating on a worker THREAD was the first form of this leg:
+        # 5.2 ms per batch single-threaded became 6.1 - 8.4 - two Python threads take turns on the interpreter lock, and the launching
+        # thread waits for it with the device idle; worker PROCESSES: 18 - 23 ms per batch)
         host_s = [0.0]
 
         def prepare(qs):
@@ -667,25 +669,23 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             pbs = coll.collate(qs)
             for pb in pbs:
                 pb.create_sparse_tensors()
+            pbs = [pb.to_cuda(device) for pb in pbs]
             host_s[0] += time.perf_counter() - h0
             return pbs
 
-        with ThreadPoolExecutor(1) as pool_ex:
-            t0 = time.perf_counter()
-            nxt = pool_ex.submit(prepare, batches[2])
-            for i in range(n_batches):
-                pbs = nxt.result()
-                if i + 1 < n_batches:
-                    nxt = pool_ex.submit(prepare, batches[3 + i])
-                pbs = [pb.to_cuda(device) for pb in pbs]
-                res = model(pbs, False)
-                training.compute_evaluation_metrics(pbs, res)
-                state["k"] += 1
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pbs = prepare(batches[2])
+        for i in range(n_batches):
+            pending = model.forward_async(pbs, False)
+            state["k"] += 1
+            nxt = prepare(batches[3 + i]) if i + 1 < n_batches else None
+            training.compute_evaluation_metrics(pbs, pending.result())
+            pbs = nxt
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         host = host_s[0]
     return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B,
-            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": "on a worker thread, one batch ahead", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
+            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": "on the launching thread, while the device runs the batch before (forward_async)", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
             "how": "every batch new programs (1..3 hops, mixed terminal operators) and another scene set; collate -> create_sparse_tensors -> lower -> "
                    "eager launches -> answers and error rate read back per batch; object features device-resident"}
 

@@ -201,7 +201,15 @@ def _dp(t):
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream's handle.  (torch.cuda.current_stream() builds a Stream object through four Python layers: 10 us a call,
+    0.35 ms of an eager 256-question batch's 34 launches; the raw accessors behind it are two C calls.)"""
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return _RAW_STREAM(_CUR_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -78,6 +78,23 @@ class _LazyGather(object):
         return gather_results(self.results, self.device, True)
 
 
+class PendingForward(object):
+    """A forward whose launches are enqueued but whose answers have not been read back (`BatchInterpreterBase.forward_async`): the host
+    is free - to collate the next ProgramBatch, say - while the device runs this one; `result()` waits for the device, reads the terminal
+    operators' log-probabilities back and returns what `forward` would have."""
+
+    def __init__(self, lazy, queue):
+        self._lazy, self._queue, self._result = lazy, queue, None
+
+    def result(self):
+        if self._result is None:
+            for fill in self._queue:
+                fill()
+            self._result = self._lazy.gather()
+            self._lazy = self._queue = None
+        return self._result
+
+
 class GraphedForward(object):
     """The inference forward of one fixed list of ProgramBatches as a captured HIP graph (the launch sequence of a program batch is
     static: 16 launches for a 3-hop program).  Replaying it removes the per-launch host work, which is 7-10 % of a step at 36
@@ -209,6 +226,20 @@ class BatchInterpreterBase(nn.Module):
                 fill()
         result = gather_results(all_results, device, True) if outer is None else _LazyGather(all_results, device)
         return (result, all_traces) if return_trace else result
+
+    def forward_async(self, program_batch_list, is_training=False, modulator_switch=True):
+        """`forward` without its device->host synchronisation: enqueues every launch and returns a PendingForward.  The reference's test()
+        loop (trainer.py:685-720) reads the answers of a batch before it collates the next; with this the two overlap on one thread."""
+        from . import gqa_ops
+        if gqa_ops.DEFERRED.queue is not None:
+            raise RuntimeError("forward_async inside a graph capture or another pending forward's launch")
+        queue = []
+        gqa_ops.DEFERRED.queue = queue
+        try:
+            lazy = self.forward(program_batch_list, is_training, modulator_switch=modulator_switch)
+        finally:
+            gqa_ops.DEFERRED.queue = None
+        return PendingForward(lazy, queue)
 
     def _run_batches(self, program_batch_list, is_training, modulator_switch):
         all_traces, all_results = [], []

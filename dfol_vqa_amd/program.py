@@ -20,6 +20,14 @@ _ATTR_SLOT = {"select": 0, "filter": 0}
 _REL_OPS = {"relate": (0, 1, 2), "verify_rel": (0, 1, 2)}          # (relation, is_subject, name) slots
 
 
+def _has_token_lists(column):
+    """True when a question holds more than one token in this argument slot (its predicates then outnumber the questions)."""
+    for el in column:
+        if el.__class__ is list and len(el) > 1:
+            return True
+    return False
+
+
 class OperatorBatch(object):
     """One operator applied across the questions of a batch (data_pipeline.py:31-143)."""
 
@@ -44,7 +52,9 @@ class OperatorBatch(object):
         self._predicate_num = question_num
         self._predicate_question_map = None
         self._question_index = None
-        if len(self._arguments) > 0 and any(isinstance(el, list) and len(el) > 1 for el in self._arguments[0]):
+        if not process_args:
+            self._question_index = question_index              # (a copy, to_cuda: the analysed fields are handed over, `_predicate_num` follows)
+        elif len(self._arguments) > 0 and _has_token_lists(self._arguments[0]):
             flat, batch_index = flatten_list(self._arguments[0])
             self._predicate_num = len(flat)
             if question_index is not None:

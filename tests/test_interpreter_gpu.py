@@ -653,6 +653,39 @@ def test_graphed_forward_equals_eager(tmp_path):
         assert not torch.equal(r2["log_probability"], r["log_probability"])
 
 
+def test_forward_async_equals_forward_with_another_batch_in_between(tmp_path):
+    """forward_async enqueues a batch and hands back a PendingForward; collating, uploading and LAUNCHING another batch before result() is
+    asked for changes nothing (bench.py's `value_fresh_programs` leg pipelines the stream of batches this way)."""
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(5)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+
+    def batch(kind, seed):
+        qs, scenes = _neural_questions(kind, 8, 9, 14, 2048, seed=seed, names=nm)
+        return [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])]
+
+    with torch.no_grad():
+        first, second = batch("choose_attr", 31), batch("verify_rel", 32)
+        want1, want2 = model(first, False), model(second, False)
+        p1 = model.forward_async(first, False)
+        third = batch("exist", 33)                           # host work and uploads behind the pending batch's launches
+        p2 = model.forward_async(second, False)
+        got2, got1 = p2.result(), p1.result()
+        for got, want in ((got1, want1), (got2, want2)):
+            assert torch.equal(got["log_probability"], want["log_probability"]) and got["answer"] == want["answer"]
+            assert got["answer_log_probability"] == want["answer_log_probability"]
+        assert p1.result() is got1
+        model(third, False)
+
+
 @pytest.mark.parametrize("explicit", [True, False])
 @pytest.mark.parametrize("kind", ["choose_attr", "verify_rel", "choose_rel", "exist"])
 def test_graphed_forward_survives_cache_eviction(tmp_path, kind, explicit, monkeypatch):

@@ -112,6 +112,8 @@ class _PinnedRing(object):
 
 
 _ring = None
+_TORCH_DTYPE = {np.dtype(k).str: v for k, v in ((np.float32, torch.float32), (np.int32, torch.int32), (np.int64, torch.int64), (np.uint8, torch.uint8),
+                                                (np.float64, torch.float64), (np.int16, torch.int16), (np.bool_, torch.bool))}
 
 
 def upload(array, device):
@@ -126,7 +128,7 @@ def upload(array, device):
         if dev.type == "cuda" and a.ndim >= 1 and 0 < a.nbytes <= (1 << 20) and not torch.cuda.is_current_stream_capturing():
             if _ring is None:
                 _ring = _PinnedRing()
-            hit = torch.empty(a.shape, dtype=torch.as_tensor(a[:0]).dtype, device=dev)
+            hit = torch.empty(a.shape, dtype=_TORCH_DTYPE.get(a.dtype.str) or torch.as_tensor(a[:0]).dtype, device=dev)
             hit.view(torch.uint8).reshape(-1).copy_(_ring.stage(a), non_blocking=True)
         else:
             hit = torch.as_tensor(a).to(device)

@@ -241,6 +241,36 @@ def accumulate_test_batch(error, total_example_num, data, prediction, first_answ
     return error, total_example_num
 
 
+def test_epoch(model, loader, device, first_answer=False):
+    """The validation / test loop of VQATrainer._test_epoch (trainer.py:444-475): per-operator error rates over a stream of collated
+    batches (lists of ProgramBatches on the host), one thread, software-pipelined - a batch's launches are enqueued with
+    `forward_async`, the NEXT batch is pulled from `loader` (its collate), given its sparse maps and uploaded while the device runs,
+    and only then are the first batch's answers read back and scored.  -> error / total_example_num, ERROR_DIM floats (slot 0 overall)."""
+    import numpy as np
+    import torch
+    error = np.zeros(ERROR_DIM, dtype=np.float32)
+    total = np.zeros(ERROR_DIM, dtype=np.float32)
+
+    def prepared(it):
+        for data in it:
+            if len(data) > 0:
+                for d in data:
+                    d.create_sparse_tensors()
+                yield [d.to_cuda(device) for d in data]
+
+    model.eval()
+    with torch.no_grad():
+        stream = prepared(iter(loader))
+        data = next(stream, None)
+        while data is not None:
+            pending = model.forward_async(data, False)
+            nxt = next(stream, None)                          # host work of the next batch under this batch's kernels
+            accumulate_test_batch(error, total, data, pending.result(), first_answer)
+            data = nxt
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return error / total                                  # (NaN in the slot of an operator no batch ended with, as the reference's)
+
+
 def collect_predictions(program_batch_list, prediction, is_submission=False):
     """The prediction records VQATrainer._print_predictions appends per test batch (trainer.py:320-337): question id, predicted
     answer (the first of the arg-max set for binary questions and submissions, the whole set for QUERY questions), question type

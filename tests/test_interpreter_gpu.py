@@ -684,6 +684,25 @@ def test_forward_async_equals_forward_with_another_batch_in_between(tmp_path):
             assert got["answer_log_probability"] == want["answer_log_probability"]
         assert p1.result() is got1
         model(third, False)
+    # the pipelined test epoch (training.test_epoch, trainer.py:444-475) against the plain loop over the same host batches
+    from dfol_vqa_amd import training
+
+    def host_batch(kind, seed):
+        qs, scenes = _neural_questions(kind, 8, 9, 14, 2048, seed=seed, names=nm)
+        return TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])
+
+    spec = [("choose_attr", 41), ("verify_rel", 42), ("exist", 43), ("choose_attr", 44)]
+    err, tot = np.zeros(training.ERROR_DIM, np.float32), np.zeros(training.ERROR_DIM, np.float32)
+    with torch.no_grad():
+        for kind, seed in spec:
+            data = host_batch(kind, seed)
+            for d in data:
+                d.create_sparse_tensors()
+            data = [d.to_cuda(DEV) for d in data]
+            training.accumulate_test_batch(err, tot, data, model(data, False))
+    got = training.test_epoch(model, [host_batch(k, sd) for k, sd in spec] + [[]], DEV)
+    seen = tot > 0
+    assert seen.sum() == 4 and np.array_equal(got[seen], (err / np.maximum(tot, 1))[seen]) and np.isnan(got[~seen]).all()
 
 
 @pytest.mark.parametrize("explicit", [True, False])

@@ -265,19 +265,23 @@ class ProgramCollaterBase(object):
         B = len(questions)
         ops, deps, last_dep = [], [], []
         cursor = -1
-        branch_num = max(len(q['program']['branches']) for q in questions)
+        filler_op, sep_op = self._filler_op, self._sep_op
+        programs = [q['program'] for q in questions]
+        branches = [p['branches'] for p in programs]
+        branch_num = max(map(len, branches))
         for b in range(branch_num):
-            heads = [q['program']['branches'][b][0] for q in questions]
+            heads = [br[b][0] for br in branches]
             args = [h['arguments'] if h['operator'] == self._starter_op else ['_'] for h in heads]
             ops.append(OperatorBatch(self._starter_op, args, B, False, mask=np.ones(B, dtype=np.float32)))
             deps.append([])
             cursor += 1
             # slot[k] = fillers that run before the k-th separator, then the separator itself
             fillers, seps = [], []
-            for k, q in enumerate(questions):
+            for k, br in enumerate(branches):
                 f_i = s_i = 0
-                for o in q['program']['branches'][b][1:]:
-                    if o['operator'] == self._filler_op:
+                for o in br[b][1:]:
+                    name = o['operator']
+                    if name == filler_op:
                         while len(fillers) <= s_i:
                             fillers.append([])
                             f_i = 0
@@ -286,7 +290,7 @@ class ProgramCollaterBase(object):
                         fillers[s_i][f_i]['mask'][k] = 1.0
                         fillers[s_i][f_i]['arguments'][k] = o['arguments']
                         f_i += 1
-                    elif o['operator'] == self._sep_op:
+                    elif name == sep_op:
                         if s_i >= len(seps):
                             seps.append({'arguments': [None] * B, 'mask': np.zeros(B, dtype=np.float32)})
                         seps[s_i]['mask'][k] = 1.0
@@ -304,8 +308,8 @@ class ProgramCollaterBase(object):
                     cursor += 1
             last_dep.append(cursor)
         terminal = {}
-        for k, q in enumerate(questions):
-            o = q['program']['last_op']
+        for k, p in enumerate(programs):
+            o = p['last_op']
             slot = terminal.setdefault(o['operator'], {'arguments': [None] * B, 'mask': np.zeros(B, dtype=np.float32)})
             slot['arguments'][k] = o['arguments']
             slot['mask'][k] = 1.0

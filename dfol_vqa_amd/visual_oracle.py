@@ -932,12 +932,14 @@ class ClassifierOracle(OracleBase):
             rows_col, rows_tile, rows_orient, invalid, base = [], [], [], [], 0
             for low, pq, orient in entries:
                 P = len(pq)
-                slot = np.zeros(P, np.int64)               # j-th predicate of its question
-                seen = {}
-                for p, q in enumerate(pq):
-                    slot[p] = seen.get(int(q), 0)
-                    seen[int(q)] = slot[p] + 1
-                K = int(slot.max()) + 1
+                pq = np.asarray(pq, np.int64)
+                slot = np.zeros(P, np.int64)               # j-th predicate of its question, in predicate order
+                if P > 1 and not (P == Q and pq[0] == 0 and pq[-1] == Q - 1 and (np.diff(pq) == 1).all()):       # (one predicate per question: all zeros)
+                    order = np.argsort(pq, kind="stable")
+                    sq = pq[order]
+                    start = np.flatnonzero(np.concatenate([[True], sq[1:] != sq[:-1]]))
+                    slot[order] = np.arange(P) - np.repeat(start, np.diff(np.concatenate([start, [P]])))
+                K = int(slot.max()) + 1 if P else 1
                 col = np.full((K, Q), -1, np.int32)
                 til = np.zeros((K, Q), np.int32)
                 ori = np.zeros((K, Q), np.uint8)
@@ -949,9 +951,9 @@ class ClassifierOracle(OracleBase):
                     invalid.append(base + np.nonzero(low.valid == 0)[0])
                 base += P
             dev = world._device
-            plan = (key, torch.as_tensor(np.concatenate(rows_col)).to(dev), torch.as_tensor(np.concatenate(rows_tile)).to(dev),
-                    torch.as_tensor(np.concatenate(rows_orient)).to(dev),
-                    torch.as_tensor(np.concatenate(invalid)).to(dev) if invalid else None)
+            # (through the pinned staging ring: a pageable torch.as_tensor(...).to(dev) makes the host wait for the stream, four times per batch)
+            plan = (key, upload(np.concatenate(rows_col), dev), upload(np.concatenate(rows_tile), dev), upload(np.concatenate(rows_orient), dev),
+                    upload(np.concatenate(invalid), dev) if invalid else None)
             program_batch._dfol_rel_plan = plan
         _, req_col, req_tile, req_orient, invalid = plan
         base = 0

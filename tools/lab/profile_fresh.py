@@ -81,7 +81,7 @@ st.sort_stats("cumulative")
 rows = []
 for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
     rows.append((ct / nb * 1e3, tt / nb * 1e3, nc / nb, "%s:%d %s" % (os.path.basename(fn), line, name)))
-rows.sort(reverse=True)
+rows.sort(reverse=True, key=(lambda r: r[1]) if os.environ.get("SORT") == "own" else None)
 print("cumulative ms / own ms / calls per batch")
 for r in rows[:int(os.environ.get("ROWS", "70"))]:
     print("%8.3f %8.3f %8.1f  %s" % r)

@@ -31,6 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+constexpr int TL_XS = 1408;                                           // floats of per-column / per-row epilogue inputs in LDS (see `xs`)
 constexpr int TL_BM = 128, TL_BK = 32, TL_XD = 4;                     // rows of a block, k of a step, steps of X rows in flight
 
 __device__ __forceinline__ int tl_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -287,9 +288,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // always lies inside one predicate - row_pred is non-decreasing and a predicate owns n (n - 1) rows; a block across a boundary looks its
     // rows up one by one).  Loaded in the epilogue itself these were dependent round trips with the whole CU waiting: the first version
     // of the logit epilogue cost 1.2 ms over 77 blocks per workgroup.
-    float* xs = reinterpret_cast<float*>(tl_sm + 2 * BUF);            // [0, 320) scales, [320, 640) bias, [640, 960) embedding row, [960, 1088) row factors
-    constexpr int PITCH = 64 * NTW + 8;                               // BIO: halfwords per staged output row (16-byte aligned rows)
-    uint16_t* stage = reinterpret_cast<uint16_t*>(xs + 1088);
+    float* xs = reinterpret_cast<float*>(tl_sm + 2 * BUF);            // [0, 320) scales, [320, 640) bias, [640, 960) embedding row, [960, 1088) row factors,
+    constexpr int PITCH = 64 * NTW + 8;                               // [1088, 1408) the embedding row of the block's LAST row; BIO: halfwords per staged output row
+    uint16_t* stage = reinterpret_cast<uint16_t*>(xs + TL_XS);
     if (tid < 320) {
         const float* tail = reinterpret_cast<const float*>(Wp + (int64_t)nbn * ksteps * TILE);
         xs[tid] = BIO ? 1.0f : (tid < nbn * 128 ? tail[tid] : 0.f);     // (the one-piece image has no row scales)
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     int lg_p0 = -1, lg_pl = -2;                                       // (scalar registers) predicates of the block's first and last row
     bool lg_uni = false;
-    float stage_reg = 0.f;
+    float stage_reg = 0.f, stage_reg2 = 0.f;
     int p0_reg = -1, pl_reg = -2;                                     // (requested at step 0, read at step 1: no wait at the request)
     auto epilogue_stage = [&](int b, int step) __attribute__((always_inline)) {      // called at steps 0, 1, 2 of block b (ksteps >= 4)
         const int m0 = b * TL_BM;
@@ -314,25 +315,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 lg_p0 = __builtin_amdgcn_readfirstlane(p0_reg);
                 lg_pl = __builtin_amdgcn_readfirstlane(pl_reg);
                 lg_uni = lg_p0 >= 0 && lg_p0 == lg_pl;
-                if (lg_uni && tid < 320) stage_reg = tid < N ? ex.E[(int64_t)lg_p0 * ex.ld_e + tid] : 0.f;
+                // (a block across ONE predicate boundary - every tenth block at 36 objects per image - reads the two rows it can meet)
+                if (tid < 320) {
+                    stage_reg = (lg_p0 >= 0 && tid < N) ? ex.E[(int64_t)lg_p0 * ex.ld_e + tid] : 0.f;
+                    stage_reg2 = (!lg_uni && lg_pl >= 0 && tid < N) ? ex.E[(int64_t)lg_pl * ex.ld_e + tid] : 0.f;
+                }
             }
             if constexpr (PROD && !BIO) {
                 if (tid < TL_BM) xs[960 + tid] = stage_reg;
             }
         } else {
             if constexpr (LOGIT) {
-                if (lg_uni && tid < 320) xs[640 + tid] = stage_reg;
+                if (tid < 320) xs[640 + tid] = stage_reg, xs[1088 + tid] = stage_reg2;
             }
         }
     };
     auto epilogue = [&](int b) __attribute__((always_inline)) {       // block b's accumulators -> Y (and the logit partial sums), then cleared
         const int m0 = b * TL_BM;
-        float cs[NTW], bv[NTW], le[NTW];
+        float cs[NTW], bv[NTW], le[NTW], le1[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int col = wn * (16 * NTW) + j * 16 + r16;
             cs[j] = xs[col], bv[j] = xs[320 + col];
             le[j] = LOGIT ? xs[640 + col] : 0.f;
+            le1[j] = LOGIT ? xs[1088 + col] : 0.f;
         }
         auto rows = [&](auto uni_tag) __attribute__((always_inline)) {
             constexpr bool UNI = decltype(uni_tag)::value;            // LOGIT: the whole block reads one embedding row (le[])
@@ -347,6 +353,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if constexpr (PROD && !BIO) rsc = xs[960 + lrow];
                     int pr = -1;
                     if constexpr (LOGIT && !UNI) pr = row_ok ? ex.row_pred[rc] : -1;
+                    // (not UNI: the row's embedding row is the block's first row's, its last row's, or - a predicate of fewer than 128
+                    // rows inside the block - one that is read from memory element by element)
+                    const bool at0 = pr == lg_p0, at1 = pr == lg_pl, far = pr >= 0 && !at0 && !at1;
                     float sum = 0.f;
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
@@ -370,7 +379,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                         if constexpr (LOGIT) {
                             if constexpr (UNI) sum += tl_sigmoid(v) * le[j];          // (le = 0 in the columns past N)
-                            else if (pr >= 0 && col < N) sum += tl_sigmoid(v) * ex.E[(int64_t)pr * ex.ld_e + col];
+                            else if (far) {
+                                if (col < N) sum += tl_sigmoid(v) * ex.E[(int64_t)pr * ex.ld_e + col];
+                            } else if (pr >= 0) sum += tl_sigmoid(v) * (at0 ? le[j] : le1[j]);
                         }
                         acc[i][j][e] = 0.f;
                     }
@@ -467,12 +478,12 @@ static int tall_launch(const void* X, int64_t ldx, const void* W_split, const fl
     const int grid = std::min(nblocks, cus);
     const int nbn_lds = ntw <= 4 ? 2 : 3;
     constexpr int TILE = (BIO ? 1 : 2) * 128 * 4;
-    const size_t lds = (size_t)2 * (TILE + nbn_lds * TILE) * 16 + 1088 * 4 + (BIO ? (size_t)TL_BM * (64 * (ntw <= 4 ? 4 : 5) + 8) * 2 : 0);
+    const size_t lds = (size_t)2 * (TILE + nbn_lds * TILE) * 16 + TL_XS * 4 + (BIO ? (size_t)TL_BM * (64 * (ntw <= 4 ? 4 : 5) + 8) * 2 : 0);
     hipStream_t st = (hipStream_t)stream;
 #define DFOL_TALL(NT)                                                                                                                       \
     {                                                                                                                                      \
         static const hipError_t ok = hipFuncSetAttribute((const void*)tall_h2_kernel<NT, MODE, BIO>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                        (int)((size_t)2 * (TILE + ((64 * NT + 127) / 128) * TILE) * 16 + 1088 * 4 +             \
+                                                        (int)((size_t)2 * (TILE + ((64 * NT + 127) / 128) * TILE) * 16 + TL_XS * 4 +             \
                                                               (BIO ? (size_t)TL_BM * (64 * NT + 8) * 2 : 0)));                                    \
         DFOL_REQUIRE(ok == hipSuccess, "%s: cannot reserve %zu bytes of LDS (%s)", name, lds, hipGetErrorString(ok));                       \
         hipLaunchKernelGGL((tall_h2_kernel<NT, MODE, BIO>), dim3(grid), dim3(512), lds, st, X, ldx, (const u32x4*)W_split, bias, Y, ldy, M, N, K, \

@@ -1047,6 +1047,38 @@ def test_tall_products_equal_the_tiled_kernels_bit_for_bit(M, N, K, monkeypatch)
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("N", [300, 256])
+def test_tall_logit_partial_sums_across_predicate_boundaries(N):
+    """The forward product's logit epilogue on 128-row blocks that lie inside one predicate, across ONE boundary (two embedding rows staged
+    in LDS), across several (predicates of fewer than 128 rows: read element by element), with predicates that own no row and rows that
+    have no predicate (-1): the partial sums against float64, the product itself bit for bit the tiled kernel's."""
+    from dfol_vqa_amd import _lib
+    K = 256
+    g = torch.Generator(device=DEV).manual_seed(N)
+    counts = [1260] * 6 + [0, 50, 3, 200, 0, 0, 130, 127, 129, 1, 1, 1, 2450] + [1260] * 5 + [90]
+    lead = 70                                                # rows without a predicate first (row_pred is non-decreasing)
+    M = lead + sum(counts)
+    assert _lib.linear_tall_supported(M, N, K)
+    rep_h = np.concatenate([np.full(lead, -1), np.repeat(np.arange(len(counts)), counts)]).astype(np.int32)
+    rep = torch.as_tensor(rep_h).to(DEV)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / 8
+    b = torch.randn(N, device=DEV, generator=g)
+    E = torch.randn(len(counts), N, device=DEV, generator=g) * 0.3
+    with _lib.dense_math("f16x2"):
+        y_ref = _lib.linear_act_split(x, w, b, _lib.ACT_NONE)
+        y, xp = _lib.linear_tall_h2(x, w, b, rep, E)
+    assert torch.equal(y, y_ref)
+    h = torch.sigmoid(y_ref.double())
+    rows = E.double()[rep.clamp(min=0).long()] * (rep >= 0).double()[:, None]
+    exact, mag = (h * rows).sum(1), (h * rows.abs()).sum(1)
+    got = xp.sum(0).double()
+    assert ((got - exact).abs() <= 4e-6 * mag + 1e-7).all()
+    assert (got[:lead] == 0).all()
+    y2, xp2 = _lib.linear_tall_h2(x, w, b, rep, E)
+    assert torch.equal(xp, xp2)                              # repeatable bit for bit
+
+
 @pytest.mark.parametrize("M,N,K", [(16384 + 77, 300, 256), (9900 * 4, 256, 300)])
 def test_tall_products_bf16_storage_equal_the_tiled_bf16_kernels_bit_for_bit(M, N, K):
     """The bf16 mode's persistent products (bf16-stored activations, one bf16 piece per operand) against the tiled bf16-storage kernel:

@@ -112,6 +112,18 @@ def test_token_lowering(ontology):
     assert rel.cols.tolist() == [ontology._relation_reveresed_index[a2i["on"] - 1], ontology._relation_reveresed_index[a2i["to the left of"] - 1]]
     with pytest.raises(KeyError):
         hu.lower_tokens(["no such concept"], ontology, TokenType.ATTRIBUTE)
+    # the memoised pass (every token met before: one dict.get per token inside numpy.fromiter) gives the same arrays as the first
+    # resolution, also for a list that mixes met and unmet tokens, and an unknown token still raises the second time (it is never memoised)
+    again = hu.lower_tokens(["small", " not(blue) ", None, "red", "red"], ontology, TokenType.ATTRIBUTE)
+    assert again.cols.tolist() == [a2i["small"] - 1, a2i["blue"] - 1, -1, a2i["red"] - 1, a2i["red"] - 1] and again.neg.tolist() == [0, 1, 0, 0, 0]
+    assert again.valid.tolist() == [1, 1, 0, 1, 1] and again.cols.dtype == np.int32 and again.neg.dtype == np.uint8
+    mixed = hu.lower_tokens(["red", "large", "not(large)", ""], ontology, TokenType.ATTRIBUTE)
+    assert mixed.cols.tolist() == [a2i["red"] - 1, a2i["large"] - 1, a2i["large"] - 1, -1] and mixed.neg.tolist() == [0, 0, 1, 0]
+    with pytest.raises(KeyError):
+        hu.lower_tokens(["red", "no such concept"], ontology, TokenType.ATTRIBUTE)
+    same_word = hu.lower_tokens(["on"], ontology, TokenType.ATTRIBUTE) if "on" in ontology._vocabulary["arg_to_idx"] else None
+    if same_word is not None:                                # (the memo is per token TYPE: a relation's column is not an attribute's)
+        assert same_word.cols.tolist() == [a2i["on"] - 1]
     assert hu.detect_negations(["not(red)", "blue"]) == (True, [True, False], ["red", "blue"])
     assert hu.segments_of([0, 0, 1, 2, 2, 2]).tolist() == [0, 2, 3, 6]
 

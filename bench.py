@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--fresh-batches", type=int, default=56, help="batches of the `value_fresh_programs` leg: every step a different ProgramBatch through "
                     "collate -> lower -> eager launches (0 = skip; north_star / c1 workloads, one process)")
+    ap.add_argument("--fresh-workers", type=int, default=2, help="collate worker PROCESSES of the `value_fresh_programs` leg (the reference's DataLoader "
+                    "workers, data_pipeline.py:893-898): they collate and lower, the launching process unpickles, uploads and launches; 0 = collate on "
+                    "the launching thread under the batch before")
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
     ap.add_argument("--graph-collective", type=int, default=0, help="train mode over RCCL: 1 = ONE step graph with the all-reduce captured inside (opt-in: a "
@@ -606,6 +609,32 @@ def data_main(args, rank, world, device, td, share):
         td.destroy_process_group()
 
 
+_FW = {}                                                         # state of a collate worker process of the fresh-programs leg
+
+
+def _fresh_worker_init(paths, names, kinds, B, N, seeds):
+    """A collate worker: its own ontology (no GPU work in this process), and every batch's question dicts generated up front from their
+    seeds - like the launching process, which generates its dicts before the clock starts (a DataLoader worker reads decoded questions)."""
+    import dfol_vqa_amd as D
+    from dfol_vqa_amd import experiment, synthetic as syn
+    ontology = experiment.build_ontology(syn.reference_config(paths))
+    with open(paths["attribute_file"]) as f:
+        cats = json.load(f)
+    _FW["coll"] = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ontology)
+    _FW["qs"] = {b: syn.full_size_questions(kinds[b % len(kinds)], B, N, N, names, cats, seed, with_scene=False) for b, seed in seeds.items()}
+
+
+def _fresh_worker_batch(b):
+    pbs = _FW["coll"].collate(_FW["qs"][b])                       # collate -> lower
+    for pb in pbs:
+        pb.create_sparse_tensors()
+    # (pickled HERE, handed over as bytes: the executor's result thread in the launching process then moves one bytes object instead of
+    # rebuilding 10 k small objects under the interpreter lock while the main thread launches; OperatorBatch.__getstate__ sends the small
+    # tensors as numpy arrays)
+    import pickle
+    return pickle.dumps(pbs, protocol=pickle.HIGHEST_PROTOCOL)
+
+
 def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=56, pool=4):
     """`value_fresh_programs`: the reference's test() loop (trainer.py:685-720) - every step a DIFFERENT ProgramBatch: new programs of mixed
     shapes (eight terminal operators in rotation, 1..3 filter / relate hops, negations, second branches; dfol_vqa_amd.synthetic.full_size_questions)
@@ -661,31 +690,67 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
         # i + 1 is collated and uploaded while the device runs batch i, then batch i's answers are read back and scored.  (The reference
         # collates in DataLoader worker processes, data_pipeline.py:893-898.  Collating on a worker THREAD was the first form of this leg:
         # 5.2 ms per batch single-threaded became 6.1 - 8.4 - two Python threads take turns on the interpreter lock, and the launching
-        # thread waits for it with the device idle; worker PROCESSES: 18 - 23 ms per batch)
+        # thread waits for it with the device idle.  --fresh-workers N > 0 moves collate and lowering into N spawned worker processes)
         host_s = [0.0]
+        workers = max(0, int(getattr(args, "fresh_workers", 0)))
+        executor, futures = None, {}
+        if workers:
+            # collate + lower in worker processes (spawned: no GPU state is inherited), several batches ahead; this process unpickles
+            import multiprocessing
+            import pickle
+            from concurrent.futures import ProcessPoolExecutor
+            seeds = {b: 5000 + 97 * rank + b for b in range(2, n_batches + 3)}
+            try:
+                executor = ProcessPoolExecutor(workers, mp_context=multiprocessing.get_context("spawn"), initializer=_fresh_worker_init,
+                                               initargs=(paths, names, kinds, B, N, seeds))
+                list(executor.map(int, range(workers * 2)))      # the workers are up (and have generated their dicts) before the clock starts
+            except Exception as exc:                             # (a host that cannot start them: this process collates, and the line says so)
+                print("bench: collate workers unavailable (%s); collating on the launching thread" % exc, file=sys.stderr)
+                if executor is not None:
+                    executor.shutdown(wait=False, cancel_futures=True)
+                executor, workers = None, 0
+            meta = {"index": {}, "embedding": torch.zeros(1, 1)}
 
-        def prepare(qs):
+            def request(b):
+                if 2 <= b < n_batches + 2 and b not in futures:
+                    futures[b] = executor.submit(_fresh_worker_batch, b)
+
+        def prepare(b):
+            if workers:
+                for ahead in range(b, b + 2 * workers + 1):
+                    request(ahead)
+                blob = futures.pop(b).result()                   # (not counted as host time of this process while it waits)
             h0 = time.perf_counter()
-            pbs = coll.collate(qs)
-            for pb in pbs:
-                pb.create_sparse_tensors()
+            if workers:
+                pbs = pickle.loads(blob)
+                for pb in pbs:                                   # the scenes never left this process
+                    pb._object_features, pb._object_batch_index = coll.collate_object_features(None)
+                    pb._object_nums, pb._meta_data = [N] * B, meta
+            else:
+                pbs = coll.collate(batches[b])
+                for pb in pbs:
+                    pb.create_sparse_tensors()
             pbs = [pb.to_cuda(device) for pb in pbs]
             host_s[0] += time.perf_counter() - h0
             return pbs
 
-        t0 = time.perf_counter()
-        pbs = prepare(batches[2])
-        for i in range(n_batches):
-            pending = model.forward_async(pbs, False)
-            state["k"] += 1
-            nxt = prepare(batches[3 + i]) if i + 1 < n_batches else None
-            training.compute_evaluation_metrics(pbs, pending.result())
-            pbs = nxt
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        try:
+            t0 = time.perf_counter()
+            pbs = prepare(2)
+            for i in range(n_batches):
+                pending = model.forward_async(pbs, False)
+                state["k"] += 1
+                nxt = prepare(3 + i) if i + 1 < n_batches else None
+                training.compute_evaluation_metrics(pbs, pending.result())
+                pbs = nxt
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            if executor is not None:
+                executor.shutdown(wait=True, cancel_futures=True)
         host = host_s[0]
     return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B,
-            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": "on the launching thread, while the device runs the batch before (forward_async)", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
+            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead" % workers) if workers else "on the launching thread, while the device runs the batch before (forward_async)", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
             "how": "every batch new programs (1..3 hops, mixed terminal operators) and another scene set; collate -> create_sparse_tensors -> lower -> "
                    "eager launches -> answers and error rate read back per batch; object features device-resident"}
 

@@ -67,16 +67,28 @@ class OperatorBatch(object):
             self._mask = torch.from_numpy(mask).float() if isinstance(mask, np.ndarray) else mask
             self._mask._host = self._mask.tolist()
 
-    # -- pickling (collate worker processes hand ProgramBatches to the process that launches): tensors lose python attributes on the way ---
+    # -- pickling (collate worker processes hand ProgramBatches to the process that launches): the small host tensors travel as numpy arrays
+    # (a torch tensor goes through a shared-memory file and a descriptor hand-over, about a millisecond each, 20 per batch) and get their
+    # python attributes back on arrival
+    _TENSOR_FIELDS = ("_mask", "_question_index", "_predicate_question_map")
+
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_mask_host"] = getattr(self._mask, "_host", None) if self._mask is not None else None
         pqm = self._predicate_question_map
         d["_pqm_host"] = getattr(pqm, "_host", None) if pqm is not None else None
+        for f in self._TENSOR_FIELDS:
+            t = d.get(f)
+            if isinstance(t, torch.Tensor) and not t.is_cuda:
+                d[f] = ("__numpy__", t.numpy())
         return d
 
     def __setstate__(self, d):
         mask_host, pqm_host = d.pop("_mask_host", None), d.pop("_pqm_host", None)
+        for f in self._TENSOR_FIELDS:
+            t = d.get(f)
+            if isinstance(t, tuple) and len(t) == 2 and t[0] == "__numpy__":
+                d[f] = torch.from_numpy(t[1])
         self.__dict__.update(d)
         if self._mask is not None and mask_host is not None:
             self._mask._host = mask_host

@@ -137,6 +137,24 @@ def test_collater_lowers_when_given_an_ontology(ontology):
     rel = [ob for ob in pb._op_batch_list if ob._op_name == "relate"][0]
     assert rel._arguments[0].lowered_type == TokenType.RELATION and rel._arguments[2].lowered_type == TokenType.ATTRIBUTE
     assert pb._question_type == D.QuestionType.BINARY
+    # a collate worker process hands the batch over pickled: the operators' small host tensors travel as numpy arrays and come back as
+    # tensors with their host shadows, the token lists keep their lowered forms
+    import pickle
+    pb.create_sparse_tensors()
+    state = pb._op_batch_list[1].__getstate__()
+    assert not any(isinstance(v, torch.Tensor) for v in state.values())
+    back = pickle.loads(pickle.dumps([pb], protocol=pickle.HIGHEST_PROTOCOL))[0]
+    assert [ob._op_name for ob in back._op_batch_list] == [ob._op_name for ob in pb._op_batch_list] and back._dependencies == pb._dependencies
+    for a, b in zip(pb._op_batch_list, back._op_batch_list):
+        assert (a._mask is None) == (b._mask is None) and a._predicate_num == b._predicate_num and a._op_id == b._op_id
+        if a._mask is not None:
+            assert isinstance(b._mask, torch.Tensor) and torch.equal(a._mask, b._mask) and b._mask._host == a._mask._host
+        if a._predicate_question_map is not None:
+            assert torch.equal(a._predicate_question_map, b._predicate_question_map) and b._predicate_question_map._host == a._predicate_question_map._host
+        for ta, tb in zip(a._arguments, b._arguments):
+            assert list(ta) == list(tb) and (ta.lowered is None) == (tb.lowered is None)
+            if ta.lowered is not None:
+                assert tb.lowered_type == ta.lowered_type and np.array_equal(ta.lowered.cols, tb.lowered.cols) and tb.lowered.any_valid == ta.lowered.any_valid
 
 
 def test_find_max_ind_matches_oracle():

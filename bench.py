@@ -1116,7 +1116,8 @@ def attach_traffic(out, args):
 
     same_shape = args.workload == "north_star" and args.objects == 100 and args.batch == 256 and not args.ragged and args.questions_per_image == 1
     if "pair_ll" in out["roofline"]["kernel"] and same_shape:              # (the counters were collected on the default command only)
-        out["roofline"]["traffic"] = total("pair_ll32s_kernel" if "32s" in out["roofline"]["kernel"] else "pair_ll32b_kernel") or total("pair_ll16")
+        # (the kernel of this run by its trace name: pair_ll32h_kernel on two fp16 pieces, pair_ll32s / pair_ll32b / pair_ll16 under the A/B switches)
+        out["roofline"]["traffic"] = total(out["roofline"].get("trace_name") or "pair_ll32h_kernel")
         out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
     for k in out["kernels"]:
         tr = k.get("trace")

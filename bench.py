@@ -693,6 +693,10 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
         # thread waits for it with the device idle.  --fresh-workers N > 0 moves collate and lowering into N spawned worker processes)
         host_s = [0.0]
         workers = max(0, int(getattr(args, "fresh_workers", 0)))
+        # under a profiler (rocprofv3 preloads its tool library into every child too: the workers would become profiled GPU processes
+        # writing their own traces into the same directory) this process collates itself
+        if workers and (any(k.startswith(("ROCPROFILER", "ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")):
+            workers = 0
         executor, futures = None, {}
         if workers:
             # collate + lower in worker processes (spawned: no GPU state is inherited), several batches ahead; this process unpickles
@@ -715,13 +719,20 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                 if 2 <= b < n_batches + 2 and b not in futures:
                     futures[b] = executor.submit(_fresh_worker_batch, b)
 
+        lost = []                                                # (a worker that died mid-run: this process collates from there on, and the line says so)
+
         def prepare(b):
-            if workers:
-                for ahead in range(b, b + 2 * workers + 1):
-                    request(ahead)
-                blob = futures.pop(b).result()                   # (not counted as host time of this process while it waits)
+            blob = None
+            if workers and not lost:
+                try:
+                    for ahead in range(b, b + 2 * workers + 1):
+                        request(ahead)
+                    blob = futures.pop(b).result()               # (not counted as host time of this process while it waits)
+                except Exception as exc:
+                    print("bench: collate worker lost (%s); collating on the launching thread from batch %d" % (exc, b), file=sys.stderr)
+                    lost.append(b)
             h0 = time.perf_counter()
-            if workers:
+            if blob is not None:
                 pbs = pickle.loads(blob)
                 for pb in pbs:                                   # the scenes never left this process
                     pb._object_features, pb._object_batch_index = coll.collate_object_features(None)
@@ -750,7 +761,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                 executor.shutdown(wait=True, cancel_futures=True)
         host = host_s[0]
     return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B,
-            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead" % workers) if workers else "on the launching thread, while the device runs the batch before (forward_async)", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
+            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead%s" % (workers, " (lost at batch %d: this process from there)" % lost[0] if lost else "")) if workers else "on the launching thread, while the device runs the batch before (forward_async)", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
             "how": "every batch new programs (1..3 hops, mixed terminal operators) and another scene set; collate -> create_sparse_tensors -> lower -> "
                    "eager launches -> answers and error rate read back per batch; object features device-resident"}
 

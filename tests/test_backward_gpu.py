@@ -85,7 +85,8 @@ def ref_relate(a, b, l, qs, qo, neg, any_neg):
 
 
 @pytest.mark.parametrize("n_list,k_list,any_neg", [([5, 3, 8], [1, 1, 1], False), ([12, 7], [2, 1], True), ([70, 100], [1, 1], False),
-                                                   ([290, 17], [1, 2], True)])     # NS = 292: beyond the registers-per-row kernels
+                                                   ([290, 17], [1, 2], True),      # NS = 292: beyond the registers-per-row kernels
+                                                   ([650, 9], [1, 1], False)])     # NS = 652: relate_bwd on four wavefronts per predicate (LDS), sixteen below
 def test_relate_filter_quantify_backward(n_list, k_list, any_neg):
     rng = np.random.RandomState(sum(n_list) + int(any_neg))
     Q = len(n_list)

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         store_b(nxt);                                                 // (the weight tiles of step g + 1, requested a step ago)
         load_w();
         __builtin_amdgcn_sched_barrier(0);
-        multiply(cur);
+        multiply(cur);                                                // (the MFMA phase at a raised issue priority - s_setprio 1 or 3 around it - measured: no change, 1.87 - 1.89 ms either way)
         __builtin_amdgcn_sched_barrier(0);
         // (the SIMD's two wavefronts taking these two halves in opposite order - a branch on wm around both orders - was measured at 5.4 ms
         // against 1.4: the doubled body no longer fits the instruction cache / the register budget; one scheduling region for both halves with

@@ -61,6 +61,29 @@ class LRUCache(object):
         self._d.clear()
 
 
+# ---- which route did a step take?  Counters the tests read (and a once-per-route warning when the training dataflow leaves this library's
+# kernels for torch / vendor-library operators: a relation network whose widths the fused kernels do not take trains correctly, but not on
+# the code this library exists for - round 4's reference gradient golden went through such a route unnoticed) -------------------------------
+import collections as _collections
+import warnings as _warnings
+
+PATH_COUNTS = _collections.Counter()
+_WARNED = set()
+
+
+def note(route):
+    PATH_COUNTS[route] += 1
+
+
+def fallback(route, why):
+    """Count a step that left the HIP kernels and say so once per route."""
+    PATH_COUNTS["fallback:" + route] += 1
+    if route not in _WARNED:
+        _WARNED.add(route)
+        _warnings.warn("dfol_vqa_amd: %s runs on torch / vendor-library operators instead of this library's HIP kernels (%s)" % (route, why),
+                       RuntimeWarning, stacklevel=3)
+
+
 _p, _i32, _i64, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
 # name -> argtypes, exactly as declared in include/dfol_vqa.h

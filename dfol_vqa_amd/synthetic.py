@@ -206,3 +206,50 @@ def full_size_questions(kind, count, n_lo, n_hi, names, categories, seed, with_s
         # (with_scene=False: programs only - the caller serves the object features, e.g. from a device-resident pool: bench.py's fresh-programs leg)
         qs.append(question(qid, branches, last, "yes", feature_scene(qid, n, 2048) if with_scene else {"n": n}))
     return qs
+
+
+TRAIN_PARITY_CASES = {"binary_small": ("binary", 8, 20, 40), "query_rel_small": ("query_rel", 8, 20, 40),
+                      "binary_tall": ("binary", 20, 27, 34), "query_rel_tall": ("query_rel", 20, 27, 34)}
+TRAIN_PARITY_WEIGHT_SEED = 19
+
+
+def train_parity_questions(case, names, categories):
+    """Seeded questions for the full-size TRAIN STEP parity cases (golden family g19, tests/test_backward_gpu.py, tests/test_oracle_golden.py):
+    select -> optional filters -> 1..3 relate hops (ragged: the aligned relate batches carry no-op tokens for the shorter programs; an
+    occasional `_` name and a negated token) -> exist (BINARY) or choose_rel (QUERY, two options per question).  The `_small` cases keep the
+    pair rows below the persistent kernels' threshold (16384 rows), the `_tall` cases above it."""
+    kind, count, n_lo, n_hi = TRAIN_PARITY_CASES[case]
+    seed = 1900 + sorted(TRAIN_PARITY_CASES).index(case)
+    rng = np.random.RandomState(seed)
+    nouns, rels = names["nouns"][:8], names["relations"][:5]
+    cats = sorted(categories)[:3]
+    attrs = [a for c in cats for a in categories[c][:4]]
+    pick = lambda xs: xs[rng.randint(len(xs))]
+    qs = []
+    for i in range(count):
+        qid = seed * 1000 + i
+        branch = [op("select", pick(nouns + ["_"]))]
+        hops = 1 + i % 3 if kind == "binary" else i % 3            # the QUERY programs end with a relation operator of their own
+        for _ in range(hops):
+            if rng.uniform() < 0.4:
+                a_ = pick(attrs)
+                branch.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.25 else a_))
+            r_ = pick(rels)
+            branch.append(op("relate", "not(%s)" % r_ if rng.uniform() < 0.15 else r_, bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
+        if kind == "binary":
+            last, answer = op("exist"), ("yes" if rng.uniform() < 0.5 else "no")
+        else:
+            ra, rb = rng.choice(len(rels), 2, replace=False)
+            last = op("choose_rel", [rels[ra], rels[rb]], bool(rng.uniform() < 0.5), pick(nouns))
+            answer = rels[ra] if rng.uniform() < 0.5 else rels[rb]
+        n = int(rng.randint(n_lo, n_hi + 1))
+        qs.append(question(qid, [branch], last, answer, feature_scene(qid, n, 2048)))
+    return qs
+
+
+def gradient_sample_index(name, numel, count=4096):
+    """The fixed flat indices at which golden g19 stores a weight gradient (all of it when the tensor is small)."""
+    import zlib
+    if numel <= count:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31)).choice(numel, count, replace=False))

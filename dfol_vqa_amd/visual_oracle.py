@@ -218,8 +218,11 @@ class _TallLinear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if _TallLinear._split_ok(x2, x2.shape[1]):          # fp32 results from the bf16 matrix pipe (csrc/dfol_dense_split.hip)
             w = weight.detach()
+            _lib.note("tall_linear")
             return L.linear_act_split(x2, w if w.is_contiguous() else w.contiguous(), None if bias is None else bias.detach(),
                                       L.ACT_NONE).view(*x.shape[:-1], weight.shape[0])
+        if x.is_cuda:
+            _lib.fallback("_TallLinear.forward", "rows %d < 4096, K %d %% 4 != 0, a non-contiguous input or dense math 'f32'" % (x2.shape[0], x2.shape[1]))
         if x.dtype != weight.dtype:                          # (a bf16-stored input the kernel cannot take: compute in fp32, store as it came)
             return nn.functional.linear(x.to(weight.dtype), weight, bias).to(x.dtype)
         return nn.functional.linear(x, weight, bias)
@@ -241,6 +244,8 @@ class _TallLinear(torch.autograd.Function):
             if _TallLinear._split_ok(g2c, g2c.shape[1]):
                 gx = L.linear_act_split(g2c, weight.detach(), None, L.ACT_NONE, transpose_w=True).view_as(x)
             else:
+                if g2.is_cuda:
+                    _lib.fallback("_TallLinear.backward (input gradient)", "rows %d < 4096 or width %d %% 4 != 0" % (g2c.shape[0], g2c.shape[1]))
                 gx = (g2.to(weight.dtype) @ weight).to(x.dtype).view_as(x)
         gw = gb = None
         if ctx.needs_input_grad[1]:
@@ -253,7 +258,7 @@ class _TallLinear(torch.autograd.Function):
                     gw, gb = gw
             else:
                 rows = g2.shape[0]
-                S = 64
+                S = 64                                        # (CPU tensors: the gloo tests of the data-parallel step)
                 while S > 1 and rows % S:
                     S //= 2
                 gw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0) if S > 1 else g2.t() @ x2
@@ -383,9 +388,11 @@ class _HeadUse(torch.autograd.Function):
             return _HeadUse._backward_bf16(ctx, st, dx, pre2, e_rows, pred_off, row_pred, need_be)
         mode = os.environ.get("DFOL_HEAD_SUMS", "auto")       # "1" / "0": always / never take the sums from the weight-gradient pass (where it can)
         if ctx.sums_ok and st["need_dw"] and pre2.shape[1] % 3 == 0 and mode != "0" and (mode == "1" or pre2.shape[0] >= (1 << 20)):
+            _lib.note("head_use_backward_sums")
             dz, dw, de, dbe, db2 = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], True, dz_out=st["dz"],
                                                         sums=True, need_bias=need_be)
         else:
+            _lib.note("head_use_backward")
             de, dbe, db2p = L.pair_head_sums(dx, pre2, e_rows, pred_off, need_bias=need_be)
             db2 = db2p.sum(0) if st["need_db"] else None
             dz, dw = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], st["need_dw"], dz_out=st["dz"])
@@ -616,6 +623,14 @@ class ClassifierOracle(OracleBase):
         return os.environ.get("DFOL_TRAIN_FUSED", "1") != "0" and world._pair_num > 0 and \
             L.pair_train_supported(lin1.weight.shape[0], lin2.weight.shape[0], max(world._n_list))
 
+    def _why_not_fused(self, world):
+        lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+        if os.environ.get("DFOL_TRAIN_FUSED", "1") == "0":
+            return "DFOL_TRAIN_FUSED=0"
+        return "the fused pair kernels take hidden widths 16..1024 with width / 4 a power of two, an embedding input <= 512 and images of at most " \
+               "16 * 4096 / width objects; this network is %d -> %d with up to %d objects per image" % (lin1.weight.shape[0], lin2.weight.shape[0],
+                                                                                                     max(world._n_list) if world._n_list else 0)
+
     def _pair_pre2_autograd(self, world, first=None):
         """pre2 = W2 ELU(W1 [obj_s, obj_o, geo] + b1) + b2 for every ordered pair [pairs, HID2] (the hidden layer before its Sigmoid),
         with the first layer split per object exactly as the fused inference kernel does; one evaluation per scene.
@@ -641,10 +656,13 @@ class ClassifierOracle(OracleBase):
             else:
                 U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias)
                 V = nn.functional.linear(obj, lin1.weight[:, D:2 * D])
+            if not fused and obj.is_cuda:
+                _lib.fallback("relation network training (first layer: gathers + torch ELU)", self._why_not_fused(world))
             if fused:
                 # bf16 mode: Z, pre2 and their gradients live in bfloat16 (what autocast stores; half the bytes of the step's streams and
                 # of the two tall products' operands) - csrc/dfol_pair_train.hip, dfol_linear_act_bf16_bf16, dfol_linear_wgrad_bias_bf16_bf16
                 store = torch.bfloat16 if L.bf16_store(lin1.weight.shape[0], lin2.weight.shape[0]) else torch.float32
+                _lib.note("fused_hidden1")
                 z = _FusedHidden1.apply(U.contiguous(), None if V is None else V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(),
                                         pos, world, store)
             else:
@@ -661,6 +679,7 @@ class ClassifierOracle(OracleBase):
             if self._head_fused(world, z, lin1, lin2):
                 # the head's backward without dpre2 in memory: pre2 comes out of the trunk node, its readers register with `uses`
                 state = {}
+                _lib.note("pair_trunk")
                 pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, state, first)
                 world._pair_head = (token, state, x_part)
                 world._pair_pre2 = pre2
@@ -691,6 +710,7 @@ class ClassifierOracle(OracleBase):
                 # the trunk's pre2 carries no autograd edge of its own (its readers register with the trunk); a reader that cannot - rows
                 # gathered out of order, no-op tokens - gets a second, ordinary evaluation of the layer from the kept first hidden layer
                 lin1, lin2 = [m for m in self._relation_network._network if isinstance(m, nn.Linear)]
+                _lib.note("pair_second_evaluation")
                 pre2 = _TallLinear.apply(world._pair_z, lin2.weight, lin2.bias)
             world._pair_h = torch.sigmoid(pre2.float())
         return world._pair_h
@@ -703,6 +723,8 @@ class ClassifierOracle(OracleBase):
             obj, Q = world._obj, world._batch_size
             D = (lin1.weight.shape[1] - 4) // 2
             assert obj.shape[1] == D, "object feature width does not match the relation network"
+            if obj.is_cuda:
+                _lib.fallback("relation network training (uniform batch: dense torch ops)", self._why_not_fused(world))
             U = nn.functional.linear(obj, lin1.weight[:, :D], lin1.bias).view(Q, n, 1, -1)
             V = nn.functional.linear(obj, lin1.weight[:, D:2 * D]).view(Q, 1, n, -1)
             pos = obj[:, D - 4:].detach().view(Q, n, 4)           # batch_gqa_boxfeatures_pipeline.py:263-279
@@ -799,12 +821,19 @@ class ClassifierOracle(OracleBase):
             fresh = getattr(world, "_pair_pre2", None) is None        # this reader creates the trunk: its logits come out of the trunk's epilogue
             pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32))
             head = getattr(world, "_pair_head", None)
+            _lib.note("emb_rows")
             if head is not None:                          # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk
                 x_part = head[2] if (fresh and head[2] is not None and head[2].numel() > 0) else None
+                _lib.note("head_use")
                 x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part, sums_ok)
             else:
+                _lib.note("fused_logit")
                 x = _FusedLogit.apply(pre2, e_rows, be_rows, pred_off, max_rows)
         else:
+            if fused:
+                _lib.note("logit_rows_gathered")          # rows out of order / no-op tokens: the fused first layer, torch ops for this reader's logits
+            elif torch.device(world._device).type == "cuda":
+                _lib.fallback("relation network training (logit layer: torch ops)", self._why_not_fused(world))
             # one pass over all predicates (a loop over concepts would scatter-add into the hidden gradient once per concept; a
             # matrix-vector product would go to rocBLAS gemv, whose backward on a [2.5M, 300] operand takes 11 ms)
             h = self._pair_hidden_autograd(world)

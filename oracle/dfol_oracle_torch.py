@@ -9,8 +9,13 @@ tensors - so its wall time tracks the reference's (validated in the build contai
 ProgramBatch sizes 5 / 10 / 20, outputs equal to 1e-6; profiles/reference_timing.json).  Only tests/, bench.py's cpu_baseline leg and
 tools/ import it; the product never does.
 
-Scope: the operators of bench.py's timed programs - select, filter, relate, exist (+ the implicit `end`).  Everything else raises
-NotImplementedError (the numpy oracle covers all 16 operators for parity).
+Second purpose (round 5): the reference's TRAIN STEP arithmetic under torch autograd (`train_loss`): the same flat-layout operator sequence
+in any dtype with the weights as differentiable leaves, so the fused full-size training kernels are checked end to end against
+d(loss)/d(weight) of the reference's own formulation (tests/test_backward_gpu.py), pinned on golden g19 - the reference's own
+`_train_batch` gradients at full model size (tests/test_oracle_golden.py).
+
+Scope: select, filter, relate, exist, verify_rel, choose_rel (+ the implicit `end`), predicate lists longer than the question list
+(predicate_question_map) included.  Everything else raises NotImplementedError (the numpy oracle covers all 16 operators for parity).
 
 Each function cites the reference lines it restates (paths under /root/reference/src/nsvqa).
 """
@@ -45,6 +50,11 @@ def find_sparse_pair_indices(m1, m2, exclude_self_relations=True):      # util.p
 
 def sparse_map(rows, cols, shape, dtype=torch.float32):                # the legacy torch.sparse.FloatTensor(ind, ones, size) constructor
     return torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(rows.numel(), dtype=dtype), shape)
+
+
+def predicate_question_map(batch_index, question_num, dtype):          # batch_base_ops.py:324-335, 497-508: [P, Q], one 1 per row
+    bi = torch.as_tensor(batch_index, dtype=torch.int64)
+    return sparse_map(torch.arange(bi.numel()), bi, (bi.numel(), question_num), dtype)
 
 
 def detect_negations(a_list):                        # util.py:68-85
@@ -90,23 +100,29 @@ def build_scene(X, img, weights, relation_index):
 class World(object):                                 # nn/interpreter/batch_base_types.py:191-252
     def __init__(self, ontology, A, R, pair, img):
         self.ontology, self.A, self.R, self.pair, self.img = ontology, A, R, pair, img
+        self.dtype = A.dtype
         self.O = img.numel()
         self.Q = int(img.max().item()) + 1
-        self.bom = sparse_map(img, torch.arange(self.O), (self.Q, self.O))                       # _batch_object_map :218-222
+        self.bom = sparse_map(img, torch.arange(self.O), (self.Q, self.O), self.dtype)           # _batch_object_map :218-222
 
 
 class VarSet(object):                                # batch_base_types.py:34-187
-    def __init__(self, names, att, quant, world):
-        self.names, self.att, self.quant, self.world = names, att, quant, world
+    def __init__(self, names, att, quant, world, pqm=None):
+        self.names, self.att, self.quant, self.world, self.pqm = names, att, quant, world, pqm
 
-    def gate(self, other, flag):                     # :149-168
-        g = torch.tensor([0.0 if f is None else float(f) for f in flag])
+    def gate(self, other, flag):                     # :149-168 (the result keeps SELF's predicate_question_map)
+        if isinstance(flag, torch.Tensor):
+            g = flag
+        else:
+            g = torch.tensor([0.0 if f is None else float(f) for f in flag], dtype=self.att.dtype)
         return VarSet([x if f > 0 else y for x, y, f in zip(self.names, other.names, g.tolist())],
-                      self.att * g.unsqueeze(1) + other.att * (1 - g.unsqueeze(1)), self.quant * g + other.quant * (1 - g), self.world)
+                      self.att * g.unsqueeze(1) + other.att * (1 - g.unsqueeze(1)), self.quant * g + other.quant * (1 - g), self.world, self.pqm)
 
     def log_probability(self):                       # :103-125 (soft mode): a full [Q, P] product, then its diagonal
-        t = log_parametric_not(self.att.transpose(0, 1), self.quant.unsqueeze(0), 1)
+        t = log_parametric_not(self.att.transpose(0, 1).contiguous(), self.quant.unsqueeze(0), 1)
         s = torch.sparse.mm(self.world.bom, t)
+        if self.pqm is not None:
+            s = torch.sparse.mm(self.pqm, s)
         return log_parametric_not(s.diag(), self.quant, 1)
 
 
@@ -116,14 +132,14 @@ def _normalize(result, image_map):                   # :22-42, :72-75
     size, num = cl.numel(), int(cl.max().item()) + 1
     if size == num:
         return result
-    cm = sparse_map(cl, torch.arange(size), (num, size))
+    cm = sparse_map(cl, torch.arange(size), (num, size), result.dtype)
     return result - torch.sparse.mm(cm.transpose(0, 1), safe_log(torch.sparse.mm(cm, result.exp())))
 
 
 def attribute_ll(world, tokens, image_map, normalize=True):
     ind = torch.tensor([world.ontology.arg_to_idx[t.strip()] - 1 for t in tokens], dtype=torch.int64)
     _, ind1, ind2 = find_sparse_pair_indices(image_map, world.img, exclude_self_relations=False)
-    result = DEFAULT_LL * torch.ones(len(tokens), world.O)
+    result = DEFAULT_LL * torch.ones(len(tokens), world.O, dtype=world.dtype)
     result[ind1, ind2] = world.A[ind2, ind[ind1]]
     if normalize:
         result = _normalize(result, image_map)
@@ -134,25 +150,30 @@ def relation_ll(world, tokens, image_map, normalize=True):
     ont = world.ontology
     ind = torch.tensor([ont.relation_reversed[ont.arg_to_idx[t.strip()] - 1] for t in tokens], dtype=torch.int64)
     _, ind1, ind2 = find_sparse_pair_indices(image_map, world.pair[0], exclude_self_relations=False)
-    temp = DEFAULT_LL * torch.ones(len(tokens), world.pair[0].numel())
+    temp = DEFAULT_LL * torch.ones(len(tokens), world.pair[0].numel(), dtype=world.dtype)
     temp[ind1, ind2] = world.R[ind2, ind[ind1]]
     if normalize:
         temp = _normalize(temp, image_map)
-    result = DEFAULT_LL * torch.ones(len(tokens), world.O, world.O, 1)
+    result = DEFAULT_LL * torch.ones(len(tokens), world.O, world.O, 1, dtype=world.dtype)
     result[:, world.pair[1], world.pair[2], :] = temp.unsqueeze(2)                               # :134-135
     return result
 
 
-# ---- BatchBayesianLogicCell (nn/interpreter/batch_base_ops.py:62-215), P == Q, dim_order [0, 1] ------------------------------------------
-def logic_cell(prior, ll, quant, bom, is_negated=None):
+# ---- BatchBayesianLogicCell (nn/interpreter/batch_base_ops.py:62-215), dim_order [0, 1] --------------------------------------------------
+def logic_cell(prior, ll, quant, bom, is_negated=None, pqm=None):
+    """prior [Q, arity, O]; ll [P, O(, O), 1]; quant [P, arity]; pqm: sparse [P, Q] when the predicates outnumber the questions."""
     arity, P, O = prior.size(1), ll.size(0), prior.size(2)
     Q = prior.size(0)
     ll = -F.relu(-ll.mean(dim=ll.dim() - 1))                                                     # :194
     if is_negated is not None:
         ll = log_parametric_not(ll, is_negated.view([-1] + arity * [1]), 1)                      # :212-213
-    result = torch.zeros(P, arity, O)
+    if pqm is not None and P != Q:                                                               # :74-77
+        log_p = torch.sparse.mm(pqm, prior.reshape(Q, -1)).view(P, arity, -1)
+    else:
+        log_p = prior
+    result = torch.zeros(P, arity, O, dtype=prior.dtype)
     if arity == 1:
-        result[:, 0, :] = ll + prior[:, 0, :]
+        result[:, 0, :] = ll + log_p[:, 0, :]
         return result
     reshape = [[P, O, 1], [P, 1, O]]                                                             # _reshape_dim :54-55
     coeff = (Q ** (arity - 1) - Q) / (Q - 1) if Q > 1 else 0
@@ -166,13 +187,14 @@ def logic_cell(prior, ll, quant, bom, is_negated=None):
             j = b + 1
             if i == j:
                 continue
-            lp = lp + prior[:, j - 1, :].view(reshape[j - 1])                                    # :102
+            lp = lp + log_p[:, j - 1, :].view(reshape[j - 1])                                    # :102
             lone = quant[:, j - 1].numel() == 1
             if lone:                                                                              # :104-108
                 if quant[0, j - 1] == 1:
                     lp = safe_log(1.0 - lp.exp())
             else:
                 lp = log_parametric_not(lp, quant[:, j - 1].view([-1] + arity * [1]), 1)
+            lp = lp.clone()
             lp[:, diag, diag] = 0                                                                # :112
             s1 = lp.size()
             lp = lp.transpose(0, j)
@@ -185,7 +207,7 @@ def logic_cell(prior, ll, quant, bom, is_negated=None):
                     lp = safe_log(1.0 - lp.exp())
             else:
                 lp = log_parametric_not(lp, quant[:, j - 1].view([-1] + arity * [1]), 1)
-        lp = lp + prior[:, i - 1, :].view(reshape[i - 1])                                        # :138
+        lp = lp + log_p[:, i - 1, :].view(reshape[i - 1])                                        # :138
         lp = lp.transpose(1, i).contiguous().view(P, O, -1)
         if Q > 1:                                                                                 # :142-147
             lp = lp[:, :, ind]
@@ -200,54 +222,66 @@ def _valid(tokens):                                  # batch_base_ops.py:315
     return [t is not None and t.strip() not in ("", "_") for t in tokens]
 
 
-def filter_batch(world, vs, tokens):                 # batch_base_ops.py:311-405, predicate_question_map = None
+def _image_map(pq, P, indb):                         # :352-355, :530-533
+    return (torch.arange(P, dtype=torch.int64) if pq is None else torch.as_tensor(pq, dtype=torch.int64))[indb]
+
+
+def filter_batch(world, vs, tokens, pq=None, normalize=True):           # batch_base_ops.py:311-405; pq: question of every predicate (list) or None
     ind = _valid(tokens)
     if not any(ind):
         return vs
-    P = len(tokens)
+    P, dt = len(tokens), world.dtype
+    pqm = None if pq is None else predicate_question_map(pq, vs.att.size(0), dt)
+    quant = vs.quant.unsqueeze(1)
+    if pqm is not None:
+        quant = torch.sparse.mm(pqm, quant)                                                      # :341-343
     kept = [t for t, k in zip(tokens, ind) if k]
     any_neg, is_neg, names = detect_negations(kept)
     indb = torch.tensor(ind)
-    image_map = torch.arange(P, dtype=torch.int64)[indb]
-    llk = attribute_ll(world, names, image_map)
+    llk = attribute_ll(world, names, _image_map(pq, P, indb), normalize)
     if not all(ind):
-        ll = DEFAULT_LL * torch.ones(P, world.O, 1)                                              # :364
+        ll = DEFAULT_LL * torch.ones(P, world.O, 1, dtype=dt)                                    # :364
         ll[indb] = llk
         negv = None
         if any_neg:
-            negv = torch.zeros(P)
-            negv[indb] = torch.tensor(is_neg, dtype=torch.float32)
-        out = logic_cell(vs.att.unsqueeze(1), ll, vs.quant.unsqueeze(1), world.bom, negv)
+            negv = torch.zeros(P, dtype=dt)
+            negv[indb] = torch.tensor(is_neg, dtype=dt)
+        out = logic_cell(vs.att.unsqueeze(1), ll, quant, world.bom, negv, pqm)
         out[~indb, 0, :] = vs.att[~indb]                                                         # :385
     else:
-        out = logic_cell(vs.att.unsqueeze(1), llk, vs.quant.unsqueeze(1), world.bom, torch.tensor(is_neg, dtype=torch.float32) if any_neg else None)
-    return VarSet(vs.names, out[:, 0, :], vs.quant, world)
+        out = logic_cell(vs.att.unsqueeze(1), llk, quant, world.bom, torch.tensor(is_neg, dtype=dt) if any_neg else None, pqm)
+    q_out = vs.quant if pqm is None else torch.sparse.mm(pqm, vs.quant.unsqueeze(1)).squeeze(1)  # :391-394
+    return VarSet(vs.names, out[:, 0, :], q_out, world, pqm)
 
 
-def relate_batch(world, svs, ovs, tokens):           # batch_base_ops.py:483-596
+def relate_batch(world, svs, ovs, tokens, pq=None, normalize=True):     # batch_base_ops.py:483-596
     ind = _valid(tokens)
     if not any(ind):
         return svs, ovs
-    P = len(tokens)
+    P, dt = len(tokens), world.dtype
+    pqm = None if pq is None else predicate_question_map(pq, world.Q, dt)
     prior = torch.stack([svs.att, ovs.att], 1)
     quant = torch.stack([svs.quant, ovs.quant], 1)
+    if pqm is not None:
+        quant = torch.sparse.mm(pqm, quant)                                                      # :518-521
     kept = [t for t, k in zip(tokens, ind) if k]
     any_neg, is_neg, names = detect_negations(kept)
     indb = torch.tensor(ind)
-    llk = relation_ll(world, names, torch.arange(P, dtype=torch.int64)[indb])
+    llk = relation_ll(world, names, _image_map(pq, P, indb), normalize)
     if not all(ind):
-        ll = DEFAULT_LL * torch.ones(P, world.O, world.O, 1)
+        ll = DEFAULT_LL * torch.ones(P, world.O, world.O, 1, dtype=dt)
         ll[indb] = llk
         negv = None
         if any_neg:
-            negv = torch.zeros(P)
-            negv[indb] = torch.tensor(is_neg, dtype=torch.float32)
-        out = logic_cell(prior, ll, quant, world.bom, negv)
+            negv = torch.zeros(P, dtype=dt)
+            negv[indb] = torch.tensor(is_neg, dtype=dt)
+        out = logic_cell(prior, ll, quant, world.bom, negv, pqm)
         out[~indb, 0, :] = svs.att[~indb]                                                        # :563-564
         out[~indb, 1, :] = ovs.att[~indb]
     else:
-        out = logic_cell(prior, llk, quant, world.bom, torch.tensor(is_neg, dtype=torch.float32) if any_neg else None)
-    return VarSet(svs.names, out[:, 0, :], svs.quant, world), VarSet(ovs.names, out[:, 1, :], svs.quant, world)
+        out = logic_cell(prior, llk, quant, world.bom, torch.tensor(is_neg, dtype=dt) if any_neg else None, pqm)
+    q_out = svs.quant if pqm is None else torch.sparse.mm(pqm, svs.quant.unsqueeze(1)).squeeze(1)  # :568-571 (both take the subject's)
+    return VarSet(svs.names, out[:, 0, :], q_out, world, pqm), VarSet(ovs.names, out[:, 1, :], q_out, world, pqm)
 
 
 # ---- GQA operators (nn/interpreter/batch_gqa_ops.py) ------------------------------------------------------------------------------------
@@ -255,7 +289,7 @@ def gqa_select(world, attribute_list):               # :168-183
     Q = world.Q
     name = ["entity" if a is None or a.lower() in ("_", "scene") else a for a in attribute_list][:Q]
     att = [None if a is None or a.lower() in ("_", "scene") else a for a in attribute_list][:Q]
-    x = VarSet(name, torch.zeros(Q, world.O), torch.ones(Q), world)
+    x = VarSet(name, torch.zeros(Q, world.O, dtype=world.dtype), torch.ones(Q, dtype=world.dtype), world)
     return x if all(a is None for a in att) else filter_batch(world, x, att)
 
 
@@ -265,12 +299,26 @@ def gqa_relate(world, vs, relation_list, is_subject, attribute_list):      # :36
     return subj.gate(obj, is_subject)
 
 
+def gqa_choose_rel(world, vs, relation_list_list, is_subject, attribute_list):   # :246-267 (log-probabilities only)
+    relation_list = [r for rl in relation_list_list for r in rl]                 # util.flatten_list :52-57
+    batch_index = [i for i, rl in enumerate(relation_list_list) for _ in rl]
+    x = gqa_select(world, attribute_list)
+    subj, obj = relate_batch(world, x.gate(vs, is_subject), vs.gate(x, is_subject), relation_list, batch_index)
+    flags = torch.tensor([0.0 if f is None else float(f) for f in is_subject], dtype=world.dtype).unsqueeze(1)
+    flags = torch.sparse.mm(subj.pqm, flags).squeeze(1)                          # :254-255
+    return subj.gate(obj, flags).log_probability(), relation_list_list
+
+
+def _weights_and_index(ontology, weights):
+    w = {k: torch.as_tensor(np.asarray(v, np.float32)) for k, v in weights.items()}
+    return w, torch.as_tensor(np.asarray(ontology.relation_index, np.int64))
+
+
 def run_questions(ontology, questions, scenes, weights, split=1):
     """The reference's inference forward over a list of questions (collate into `split` ProgramBatches -> build_scene -> execute ->
     gather, nn/interpreter/batch_base_interpreter.py:45-183) for select -> (filter | relate)* -> exist programs with ONE branch whose
     operator sequence is the same for every question of the list.  -> {"log_probability": float32 numpy [Q], "answer": [["yes"] | ["no"]]}"""
-    w = {k: torch.as_tensor(np.asarray(v, np.float32)) for k, v in weights.items()}
-    rel_index = torch.as_tensor(np.asarray(ontology.relation_index, np.int64))
+    w, rel_index = _weights_and_index(ontology, weights)
     n, lps = len(questions), []
     split = min(split, n)
     size = math.ceil(n / split)
@@ -302,3 +350,68 @@ def run_questions(ontology, questions, scenes, weights, split=1):
             lps.append(vs.log_probability())
     lp = torch.cat(lps).numpy()
     return {"log_probability": lp, "answer": [["yes"] if x > 0.5 else ["no"] for x in np.exp(lp).tolist()]}
+
+
+# ---- the train step's arithmetic under autograd (train/trainer.py:181-262, 429-442) --------------------------------------------------------
+_YES = ("yes", "yeah", "yep", "yup", "aye", "yea")
+
+
+def execute_collated(world, ops, deps):
+    """The execution loop (batch_base_interpreter.py:145-172) over operator batches collated by oracle.dfol_oracle.collate_programs
+    (data_pipeline.py:647-746): dependency-ordered dispatch, per-question mask gating (:166-167), implicit `end` (:75-76 of
+    batch_gqa_interpreter.py).  -> (log_probability [P], type, options)"""
+    trace = []
+    for i, ob in enumerate(ops):
+        name, args, last = ob["op_name"], ob["arguments"], i == len(ops) - 1
+        inputs = [trace[d] for d in deps[i]]
+        if name == "select":
+            x = gqa_select(world, args[0] if args else ["_"] * world.Q)
+        elif name == "filter":
+            x = filter_batch(world, inputs[0], args[0])
+        elif name in ("relate", "verify_rel"):
+            x = gqa_relate(world, inputs[0], args[0], args[1], args[2])
+            if name == "verify_rel":                                                         # batch_gqa_ops.py:489-501
+                return x.log_probability(), "binary", None
+        elif name == "exist":                                                                 # :399-410
+            return inputs[0].log_probability(), "binary", None
+        elif name == "choose_rel":
+            lp, options = gqa_choose_rel(world, inputs[0], args[0], args[1], args[2])
+            return lp, "query", options
+        else:
+            raise NotImplementedError(name)
+        if inputs and ob["mask"] is not None:
+            x = x.gate(inputs[0], ob["mask"])
+        trace.append(x)
+    return trace[-1].log_probability(), "statement", None                                    # the appended `end` (:768-783)
+
+
+def compute_loss(lp, kind, answers, options):        # trainer.py:181-262 (the fp64 run builds its targets in the run's dtype)
+    if kind == "statement":
+        return -lp.sum()
+    if kind == "binary":                             # :185-194
+        target = torch.tensor([float(a in _YES) for a in answers], dtype=lp.dtype)
+        return F.binary_cross_entropy(lp.exp(), target, reduction="sum")
+    target = [[a == o for o in op] for a, op in zip(answers, options)]                        # :207-230
+    seg = torch.tensor([i for i, t in enumerate(target) for _ in t], dtype=torch.int64)
+    tflat = torch.tensor([float(x) for t in target for x in t], dtype=lp.dtype)
+    qpm = sparse_map(seg, torch.arange(seg.numel()), (len(target), seg.numel()), lp.dtype)
+    return safe_log(torch.sparse.mm(qpm, lp.unsqueeze(1).exp())).sum() - (tflat * lp).sum()
+
+
+def train_loss(ontology, questions, scenes, weights, dtype=torch.float64, collate=None):
+    """_train_batch up to the backward (trainer.py:429-437) for ONE ProgramBatch: forward in training mode (dropout 0), `_compute_loss`,
+    `/ batch size`, `.backward()`.  `weights`: {reference parameter name: array}; -> (loss, log_probability, {name: gradient}) as numpy, the
+    whole computation in `dtype`.  `collate`: oracle.dfol_oracle.collate_programs (passed in so this module stays importable alone)."""
+    if collate is None:
+        from oracle.dfol_oracle import collate_programs as collate
+    w = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in weights.items()}
+    rel_index = torch.as_tensor(np.asarray(ontology.relation_index, np.int64))
+    img = torch.as_tensor(np.repeat(np.arange(len(scenes)), [s["n"] for s in scenes]).astype(np.int64))
+    X = torch.tensor(np.concatenate([s["X"] for s in scenes]), dtype=dtype)
+    world = World(ontology, *build_scene(X, img, w, rel_index), img)
+    ops, deps = collate(questions)
+    lp, kind, options = execute_collated(world, ops, deps)
+    loss = compute_loss(lp, kind, [q["answer"] for q in questions], options) / len(questions)
+    loss.backward()
+    grads = {k: (np.zeros(tuple(v.shape), np.float64) if v.grad is None else v.grad.numpy().astype(np.float64)) for k, v in w.items()}
+    return float(loss.detach()), lp.detach().numpy(), grads

@@ -97,3 +97,40 @@ def decided_answers(cm, lp32, lp64):
             out.append(len(top) < 2 or top[0] - top[1] > 4 * np.abs(a32 - a64).max() + 1e-4)
         return out
     return list(np.abs(np.exp(lp64) - 0.5) > 4 * np.abs(np.exp(lp32) - np.exp(lp64)) + 1e-5)
+
+
+G19_CASES = ["binary_small", "query_rel_small", "binary_tall", "query_rel_tall"]
+
+
+def g19_case(name, arrays, meta):
+    """One case of golden family g19 (the reference's `_train_batch` gradients at full model size): questions with their scenes (regenerated
+    from seeds), the reference's loss / log-probabilities and, per weight tensor, gradient norm + sampled values, fp32 and fp64."""
+    from dfol_vqa_amd import synthetic as syn
+    cm = meta["cases"][name]
+    qs = [syn.question(q["question_id"], q["program"]["branches"], q["program"]["last_op"], q["answer"], syn.feature_scene(q["question_id"], q["n"], 2048))
+          for q in cm["questions"]]
+    grads = {}
+    for k in arrays.files:
+        if k.startswith(name + ":gs:") and k.endswith(":f64"):
+            pname = k[len(name) + 4:-4]
+            grads[pname] = {"sample64": arrays[k], "sample32": arrays[k[:-3] + "f32"],
+                            "norm64": float(arrays["%s:gn:%s:f64" % (name, pname)]), "norm32": float(arrays["%s:gn:%s:f32" % (name, pname)])}
+    return qs, cm, {t: (float(arrays["%s:loss_%s" % (name, t)]), arrays["%s:lp_%s" % (name, t)]) for t in ("f32", "f64")}, grads
+
+
+def check_g19_gradients(got, grads, what, rtol=2e-3, K=8.0):
+    """got: {parameter name: full gradient array}.  Sampled values and norm against the reference's fp64 run, with the reference's own
+    fp32-vs-fp64 deviation as the yardstick (the policy of test_backward_gpu.grad_close)."""
+    from dfol_vqa_amd import synthetic as syn
+    assert len(grads) == 12, sorted(grads)
+    for pname, g in grads.items():
+        full = np.asarray(got[pname], np.float64).reshape(-1)
+        smp = full[syn.gradient_sample_index(pname, full.size)]
+        ref64, ref32 = g["sample64"].astype(np.float64), g["sample32"].astype(np.float64)
+        scale = max(np.abs(ref64).max(), g["norm64"] / np.sqrt(full.size)) + 1e-30
+        own = np.abs(ref32 - ref64).max()
+        err = np.abs(smp - ref64).max()
+        assert err <= K * own + rtol * scale, "%s d%s: |dgrad| %.3g vs the reference's own %.3g (scale %.3g)" % (what, pname, err, own, scale)
+        norm = np.sqrt((full ** 2).sum())
+        assert abs(norm - g["norm64"]) <= K * abs(g["norm32"] - g["norm64"]) + rtol * g["norm64"] + 1e-30, \
+            "%s |d%s| %.6g vs %.6g (the reference's own fp32 run %.6g)" % (what, pname, norm, g["norm64"], g["norm32"])

@@ -1143,3 +1143,153 @@ def test_pair_wgrad_sums_bf16_storage_against_the_materialised_bf16_route(counts
     assert ((db2 - db_ref).abs() <= 4e-6 * dp2.float().abs().sum(0) + 1e-30).all()
     assert torch.allclose(de, de_ref, rtol=2e-5, atol=2e-5 * float(de_ref.abs().max()))
     assert torch.allclose(dbe, dbe_ref, rtol=2e-5, atol=2e-5 * float(dbe_ref.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 5: the FULL-SIZE train step end to end against the reference (golden g19) and against the reference's arithmetic restated under
+# autograd in fp64 (oracle/dfol_oracle_torch.train_loss, itself pinned on g19 by tests/test_oracle_golden.py)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g19_setup(tmp_path_factory):
+    import json
+    from dfol_vqa_amd import experiment
+    from oracle import dfol_oracle as orc
+    paths, names = syn.write_synthetic_ontology(str(tmp_path_factory.mktemp("g19")))
+    cfg = syn.reference_config(paths, freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False, freeze_embedding_network=False)
+    ont = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ont)
+    a, meta = gu.load("g19_full_size_train_step")
+    weights = syn.load_seeded_weights(model, meta["weight_seed"])
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    return model.to(DEV).train(), ont, oont, weights, a, meta
+
+
+def _g19_step(model, ont, qs):
+    from dfol_vqa_amd import _lib
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q) for q in qs])]
+    model.zero_grad(set_to_none=True)
+    _lib.PATH_COUNTS.clear()
+    res = model(pbs, True)
+    loss = training.compute_loss(pbs, res) / len(qs)
+    loss.backward()
+    grads = {k: (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu().numpy() for k, p in model.named_parameters()}
+    return float(loss.detach()), res["log_probability"].detach().cpu().numpy(), grads, dict(_lib.PATH_COUNTS)
+
+
+@pytest.mark.parametrize("name,sums", [("binary_small", "auto"), ("query_rel_small", "auto"), ("binary_tall", "auto"), ("query_rel_tall", "auto"),
+                                       ("binary_tall", "1"), ("query_rel_small", "1")])
+def test_g19_full_size_train_step_against_the_reference(g19_setup, name, sums, monkeypatch):
+    """ONE `train_batch` forward + backward of the full-size model (2048 -> 512, 516 / 1036 -> 256 -> 300 -> 2335, dropout 0) on ragged 20..40
+    object scenes with 0..3 relate hops, no-op tokens in the aligned relate batches and choose_rel option lists - through the FUSED training
+    kernels (asserted: `_FusedHidden1`, `_PairTrunk`, `_HeadUse`, `_EmbRows`, the second-evaluation route for readers that cannot register
+    with the trunk; no fallback to torch / vendor operators) - against (1) golden g19 = the reference's own `_train_batch` (loss,
+    log-probabilities, norm and 4096 sampled entries of all twelve weight gradients; trainer.py:181-262, 429-442) and (2) the reference's
+    arithmetic under autograd in fp64 on the CPU (oracle/dfol_oracle_torch.train_loss), full tensors.  `_tall`: >= 16384 pair rows, the
+    persistent tall kernels; sums = "1": the logit layer's sums from the weight-gradient pass."""
+    import warnings
+    from oracle import dfol_oracle_torch as orct
+    model, ont, oont, weights, a, meta = g19_setup
+    monkeypatch.setenv("DFOL_HEAD_SUMS", sums)
+    qs, cm, ref, grads = gu.g19_case(name, a, meta)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)           # a route that leaves the HIP kernels announces itself: here it must not happen
+        loss, lp, got, routes = _g19_step(model, ont, qs)
+    assert not [r for r in routes if r.startswith("fallback:")], routes
+    assert routes.get("fused_hidden1", 0) == 1 and routes.get("pair_trunk", 0) == 1, routes
+    assert routes.get("head_use", 0) >= 1 and routes.get("emb_rows", 0) >= 1, routes
+    assert routes.get("head_use_backward_sums" if sums == "1" else "head_use_backward", 0) >= 1, routes
+    if name.startswith("binary"):                                # ragged hop counts: the aligned relate batches hold no-op tokens
+        assert routes.get("pair_second_evaluation", 0) == 1 and routes.get("logit_rows_gathered", 0) >= 1, routes
+    pairs = sum(q["scene"]["n"] * (q["scene"]["n"] - 1) for q in qs)
+    assert (pairs >= 16384) == name.endswith("_tall")
+    l32, l64 = ref["f32"][0], ref["f64"][0]
+    assert abs(loss - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (loss, l32, l64)
+    gu.check_logprob(lp, ref["f32"][1], ref["f64"][1], "g19 " + name)
+    gu.check_g19_gradients(got, grads, "g19 %s (sums=%s)" % (name, sums))
+    # (2) every entry of every gradient against the fp64 autograd of the restated reference
+    o_loss, o_lp, o_g = orct.train_loss(oont, qs, [q["scene"] for q in qs], weights, torch.float64)
+    assert abs(o_loss - l64) <= 1e-9 * max(1.0, abs(l64))       # (the checker itself still agrees with the golden on this machine)
+    for pname, g in grads.items():
+        ref64 = o_g[pname]
+        own = np.abs(g["sample32"].astype(np.float64) - g["sample64"]).max()     # the reference's own fp32 noise on this tensor (sampled)
+        scale = np.abs(ref64).max() + 1e-30
+        err = np.abs(got[pname].astype(np.float64) - ref64).max()
+        assert err <= 16 * own + 2e-3 * scale, "%s d%s: |dgrad| %.3g vs the reference's own %.3g (scale %.3g)" % (name, pname, err, own, scale)
+
+
+def test_g19_detects_a_broken_trunk_accumulation(g19_setup, monkeypatch):
+    """The check above has teeth: with the deferred trunk's accumulation across readers deliberately broken (every reader after the first
+    overwrites the second layer's weight gradient instead of adding to it) the g19 comparison fails."""
+    from dfol_vqa_amd import visual_oracle as vo
+    model, ont, oont, weights, a, meta = g19_setup
+    qs, cm, ref, grads = gu.g19_case("query_rel_small", a, meta)      # choose_rel's two option slots: two readers of one trunk
+    orig = vo._HeadUse.backward
+
+    def broken(ctx, dx):
+        st = ctx.state
+        if dx is not None and st.get("dw") is not None:
+            st["dw"] = torch.zeros_like(st["dw"])               # drop what the earlier readers accumulated
+        return orig(ctx, dx)
+    monkeypatch.setattr(vo._HeadUse, "backward", staticmethod(broken))
+    _, _, got, routes = _g19_step(model, ont, qs)
+    assert routes.get("head_use", 0) >= 2, routes                # several readers: the accumulation matters
+    with pytest.raises(AssertionError):
+        gu.check_g19_gradients(got, grads, "broken")
+
+
+def test_fallback_routes_announce_themselves(ontology):
+    """A relation network the fused training kernels do not take (g12's 8-wide one) trains through torch operators - correctly (golden g12),
+    and no longer silently: a RuntimeWarning names the widths, and `_lib.PATH_COUNTS` records the route."""
+    from dfol_vqa_amd import _lib
+    a, meta = gu.load("g12_weight_gradients")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ontology, meta["config"], weights).train()
+    qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [],
+           "original_dict": None, "question": None, "scene": {"n": q["n"], "X": a["binary:X_%d" % i]}}
+          for i, q in enumerate(meta["sets"]["binary"]["questions"])]
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ontology, "X").collate(qs)]
+    _lib.PATH_COUNTS.clear()
+    _lib._WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="relation network training"):
+        res = model(pbs, True)
+        (training.compute_loss(pbs, res) / len(qs)).backward()
+    assert any(r.startswith("fallback:relation network training") for r in _lib.PATH_COUNTS), dict(_lib.PATH_COUNTS)
+    assert "pair_trunk" not in _lib.PATH_COUNTS
+
+
+@pytest.mark.parametrize("mlp_math", ["fp32", "bf16"])
+def test_train_from_h5_program_files(ontology, golden_dir, mini_ontology_paths, mlp_math):
+    """BASELINE configs[3]'s input path on the GPU: the g18 program-bytecode .h5 files (written by the reference's GQAH5Encoder) and feature
+    chunk files, read by data.ProgramDataset / BatchGQABoxFeaturesCollator (data_pipeline.py:328-367, 391-453), TRAINED for two
+    `train_batch` steps per file (trainer.py:429-442) in the configured `mlp_math`.  The first step's loss equals the oracle's
+    `compute_loss` (trainer.py:181-262) of its own fp64 forward on the same files; the second step runs on updated weights (its loss
+    moves) and stays finite.  Eight terminal operators, BINARY and QUERY."""
+    from oracle import dfol_oracle as orc
+    from test_data_path import g18_batches
+    p = mini_ontology_paths
+    oont = orc.Ontology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["relation_file"])
+    seen = 0
+    for name, fm, items, pbs, lp32, lp64, a, meta in g18_batches(ontology, golden_dir):
+        weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+        model = neural_model(ontology, dict(meta["config"], mlp_math=mlp_math), weights).train()
+        for prm in model.parameters():
+            prm.requires_grad_(prm.dtype.is_floating_point and prm is not model._global_step)
+        if mlp_math == "bf16":
+            model._mlp_math = "bf16"
+        dev_pbs = [pb.to_cuda(DEV) for pb in pbs]
+        opt = torch.optim.Adam([q for q in model.parameters() if q.requires_grad], lr=1e-3)
+        l0, res = training.train_batch(model, opt, dev_pbs, clip_norm=0.65)
+        l1, _ = training.train_batch(model, opt, dev_pbs, clip_norm=0.65)
+        feats = pbs[0]._object_features.numpy()
+        off = np.concatenate([[0], np.cumsum(fm["objects"])])
+        scenes = [{"n": int(n), "X": feats[off[i]:off[i + 1]]} for i, n in enumerate(fm["objects"])]
+        qs = [{"program": it["program"], "answer": it["answer"], "question_id": i, "image_id": it["image_id"]} for i, it in enumerate(items)]
+        r64 = orc.run_questions(oont, qs, scenes, np.float64, weights=weights, give_answer=False)
+        r32 = orc.run_questions(oont, qs, scenes, np.float32, weights=weights, give_answer=False)
+        ref64 = float(orc.compute_loss(r64, [q["answer"] for q in qs]))
+        ref32 = float(orc.compute_loss(r32, [q["answer"] for q in qs]))
+        tol = 8 * abs(ref32 - ref64) + (2e-2 if mlp_math == "bf16" else 2e-5) * max(1.0, abs(ref64))
+        assert abs(l0 - ref64) <= tol, (name, mlp_math, l0, ref32, ref64)
+        assert np.isfinite(l1) and l1 != l0, (name, l0, l1)
+        seen += 1
+    assert seen == 8

@@ -224,6 +224,37 @@ def test_g17_torch_restatement_equals_reference(full_size_oracle):
         orct.run_questions(oont, q2[:2], s2[:2], weights)
 
 
+@pytest.mark.parametrize("name", ["binary_small", "query_rel_small"])
+def test_g19_torch_restatement_train_step_equals_reference(full_size_oracle, name):
+    """oracle/dfol_oracle_torch.train_loss - the reference's train step restated under torch autograd, the checker of the fused full-size
+    training kernels (tests/test_backward_gpu.py) - against the REFERENCE'S OWN `_train_batch` at full model size (golden g19: loss,
+    log-probabilities, norm and 4096 sampled entries of each of the twelve weight gradients; trainer.py:181-262, 429-442).  fp64: the same
+    algorithm, so agreement to 1e-9; fp32: the policy of the gradient goldens.  (The `_tall` cases run on the GPU box, where the product is
+    checked against both; here the two small ones keep the CPU suite short.)"""
+    import torch
+    from dfol_vqa_amd import synthetic as syn
+    from oracle import dfol_oracle_torch as orct
+    oont = full_size_oracle[0]
+    a, meta = gu.load("g19_full_size_train_step")
+    qs, cm, ref, grads = gu.g19_case(name, a, meta)
+    weights = syn.seeded_weights(meta["weight_seed"])
+    scenes = [q["scene"] for q in qs]
+    loss, lp, g = orct.train_loss(oont, qs, scenes, weights, torch.float64)
+    l64, lp64 = ref["f64"]
+    assert abs(loss - l64) <= 1e-9 * max(1.0, abs(l64)), (loss, l64)
+    assert np.abs(lp - lp64).max() <= 1e-8, np.abs(lp - lp64).max()
+    for pname, gr in grads.items():
+        full = g[pname].reshape(-1)
+        smp = full[syn.gradient_sample_index(pname, full.size)]
+        scale = np.abs(gr["sample64"]).max() + 1e-30
+        assert np.abs(smp - gr["sample64"]).max() <= 1e-8 * scale + 1e-14, (pname, np.abs(smp - gr["sample64"]).max(), scale)
+        assert abs(np.sqrt((full ** 2).sum()) - gr["norm64"]) <= 1e-8 * gr["norm64"] + 1e-14, pname
+    loss32, lp32, g32 = orct.train_loss(oont, qs, scenes, weights, torch.float32)
+    l32 = ref["f32"][0]
+    assert abs(loss32 - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (loss32, l32, l64)
+    gu.check_g19_gradients(g32, grads, "torch restatement fp32 " + name)
+
+
 @pytest.mark.parametrize("name", ["g6_loss_binary", "g6_loss_query", "g6_loss_query_rel"])
 def test_g6_loss(ontology, name):
     a, meta = gu.load(name)

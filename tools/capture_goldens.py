@@ -1120,6 +1120,82 @@ def g17():
 
 
 
+# ---------------------------------------------------------------------------------------- g19
+def g19():
+    """The reference's own `_train_batch` gradients (trainer.py:181-262, 429-442) at FULL model size (2048 -> 512, 516 / 1036 -> 256 -> 300 ->
+    2335 concepts; gqa_interpreter_experiments.py:147-167), dropout 0, every weight trainable, for ragged BINARY and QUERY (choose_rel)
+    batches with 0..3 relate hops: loss, log-probabilities, and per weight tensor the gradient's norm plus its values at a fixed sample of
+    4096 flat indices (synthetic.gradient_sample_index) - fp32 and fp64 runs of the reference.  Weights, ontology and scenes are
+    regenerated from their seeds (synthetic.seeded_weights / write_synthetic_ontology / feature_scene)."""
+    import tempfile
+    sys.path.insert(0, ref_harness.REF_SRC)
+    import gqa_interpreter_experiments as gie
+    from nsvqa.train.trainer import VQATrainer
+    tmp = tempfile.mkdtemp(prefix="dfol_g19_")
+    fpaths, names = syn.write_synthetic_ontology(tmp)
+    with open(fpaths["vocabulary_file"]) as f:
+        vocab = json.load(f)
+    with open(fpaths["attribute_file"]) as f:
+        categories = json.load(f)
+    fpaths["word_embedding_file"] = os.path.join(tmp, "glove.txt")
+    rng = np.random.RandomState(3)
+    with open(fpaths["word_embedding_file"], "w") as f:          # build_model wants a GloVe file; every weight is overwritten below
+        for wd in sorted({x for nme in vocab["idx_to_arg"] for x in nme.split()}):
+            f.write(wd + " " + " ".join("%.4f" % x for x in rng.normal(0, 0.3, 300)) + "\n")
+    cfg = syn.reference_config(fpaths, freeze_featurizer=False, freeze_attribute_network=False, freeze_relation_network=False,
+                               freeze_embedding_network=False, dropout=0.0)
+    exp = gie.GQAObjectBoxExperiment()
+    exp._local_rank = 0
+    full_ontology = exp.build_ontology(cfg, None)
+    torch.manual_seed(0)
+    model = exp.build_model(cfg, full_ontology, None)
+    syn.load_seeded_weights(model, syn.TRAIN_PARITY_WEIGHT_SEED)
+    fake = types.SimpleNamespace(_device=torch.device("cpu"), _config={})
+    arrays, meta = {}, {"source": "trainer.py:181-262,429-442; gqa_interpreter_experiments.py:18-77,107-240", "weight_seed": syn.TRAIN_PARITY_WEIGHT_SEED,
+                        "ontology": "synthetic.write_synthetic_ontology (defaults)", "torch": torch.__version__, "cases": {}}
+    for case in sorted(syn.TRAIN_PARITY_CASES):
+        qs = syn.train_parity_questions(case, names, categories)
+        for dt, tag in both_dtypes():
+            m = copy.deepcopy(model).double() if dt == torch.float64 else copy.deepcopy(model)
+            m.train()
+            collater = ref_harness.make_collater(ref, 1, "feature")
+            pbs = collater.collate(copy.deepcopy(qs))
+            for pb in pbs:
+                pb.create_sparse_tensors()
+                if dt == torch.float64:
+                    pb.to(torch.float64)
+                    pb._object_batch_index = pb._object_batch_index.long()
+            res = m(pbs, True, return_trace=False)
+            lp = res["log_probability"]
+            if dt == torch.float64:           # trainer.py:185-194,207-230 restated in fp64 (its targets are built in fp32)
+                if res["type"] == ref.base_types.QuestionType.BINARY:
+                    target = torch.tensor([a == "yes" for pb in pbs for a in pb._answers], dtype=dt)
+                    loss = torch.nn.functional.binary_cross_entropy(lp.exp(), target, reduction="sum")
+                else:
+                    answers = [a for pb in pbs for a in pb._answers]
+                    target = [[a == o for o in opt] for a, opt in zip(answers, res["options"])]
+                    seg = torch.tensor([i for i, t in enumerate(target) for _ in t])
+                    tflat = torch.tensor([x for t in target for x in t], dtype=dt)
+                    denom = torch.zeros(len(target), dtype=dt).index_add(0, seg, lp.exp())
+                    loss = ref.util.safe_log(denom).sum() - (tflat * lp).sum()
+            else:
+                loss = VQATrainer._compute_loss(fake, pbs, res)
+            loss = loss / sum(pb.batch_size() for pb in pbs)
+            loss.backward()
+            arrays["%s:loss_%s" % (case, tag)] = loss.detach().numpy()
+            arrays["%s:lp_%s" % (case, tag)] = lp.detach().numpy()
+            seen = set()
+            for k, prm in m.named_parameters():
+                if (k.startswith("_featurizer.") or k.startswith("_oracle.")) and id(prm) not in seen:
+                    seen.add(id(prm))
+                    g = (torch.zeros_like(prm) if prm.grad is None else prm.grad).detach().numpy().reshape(-1)
+                    arrays["%s:gn:%s:%s" % (case, k, tag)] = np.asarray(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                    arrays["%s:gs:%s:%s" % (case, k, tag)] = g[syn.gradient_sample_index(k, g.size)]
+            print(case, tag, "loss", float(loss), "pairs", sum(q["scene"]["n"] * (q["scene"]["n"] - 1) for q in qs))
+        meta["cases"][case] = {"questions": questions_to_meta(qs), "type": int(res["type"])}
+    save("g19_full_size_train_step", arrays, meta)
+
+
 # ---------------------------------------------------------------------------------------- g18
 def g18():
     """End to end FROM THE REFERENCE'S FILE FORMATS: questions authored here are written as program-bytecode .h5 files by the reference's

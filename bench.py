@@ -410,6 +410,16 @@ def main(argv=None):
         out["value_fresh_programs"] = fp["questions_per_s"] * world
         fp["vs_value"] = "%.2f x the replayed-batch rate `value`" % (out["value_fresh_programs"] / out["value"])
         out["fresh_programs"] = fp
+        # `value_end_to_end`: new programs AND new features every batch - the reference's test() loop as it is (trainer.py:685-720)
+        ee = fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=args.fresh_batches, stream_features=True)
+        if td is not None:
+            t = torch.tensor([ee["ms_per_batch"]], device="cpu" if share else device, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            ee["ms_per_batch"] = float(t.item())
+            ee["questions_per_s"] = args.batch / (ee["ms_per_batch"] * 1e-3)
+        out["value_end_to_end"] = ee["questions_per_s"] * world
+        ee["vs_value"] = "%.2f x the replayed-batch rate `value`" % (out["value_end_to_end"] / out["value"])
+        out["end_to_end"] = ee
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
         # --roofline-reps EAGER steps, one event pair per launch.  They come after every other leg that launches these kernels, so
@@ -612,7 +622,7 @@ def data_main(args, rank, world, device, td, share):
 _FW = {}                                                         # state of a collate worker process of the fresh-programs leg
 
 
-def _fresh_worker_init(paths, names, kinds, B, N, seeds):
+def _fresh_worker_init(paths, names, kinds, B, N, seeds, spec=None):
     """A collate worker: its own ontology (no GPU work in this process), and every batch's question dicts generated up front from their
     seeds - like the launching process, which generates its dicts before the clock starts (a DataLoader worker reads decoded questions)."""
     import dfol_vqa_amd as D
@@ -620,12 +630,17 @@ def _fresh_worker_init(paths, names, kinds, B, N, seeds):
     ontology = experiment.build_ontology(syn.reference_config(paths))
     with open(paths["attribute_file"]) as f:
         cats = json.load(f)
-    _FW["coll"] = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ontology)
+    # (spec: the model's widths, native_exec.model_spec - the worker then also lowers every batch to the native executor's instruction table)
+    _FW["coll"] = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ontology, native_spec=spec)
+    _FW["N"] = N
     _FW["qs"] = {b: syn.full_size_questions(kinds[b % len(kinds)], B, N, N, names, cats, seed, with_scene=False) for b, seed in seeds.items()}
 
 
 def _fresh_worker_batch(b):
-    pbs = _FW["coll"].collate(_FW["qs"][b])                       # collate -> lower
+    coll = _FW["coll"]
+    qs = _FW["qs"][b]
+    coll.collate_object_features = lambda questions: (None, np.repeat(np.arange(len(questions)), _FW["N"]))      # (object counts: the plan's geometry)
+    pbs = coll.collate(qs)                                        # collate -> lower -> plan
     for pb in pbs:
         pb.create_sparse_tensors()
     # (pickled HERE, handed over as bytes: the executor's result thread in the launching process then moves one bytes object instead of
@@ -635,7 +650,7 @@ def _fresh_worker_batch(b):
     return pickle.dumps(pbs, protocol=pickle.HIGHEST_PROTOCOL)
 
 
-def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=56, pool=4):
+def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=56, pool=4, stream_features=False):
     """`value_fresh_programs`: the reference's test() loop (trainer.py:685-720) - every step a DIFFERENT ProgramBatch: new programs of mixed
     shapes (eight terminal operators in rotation, 1..3 filter / relate hops, negations, second branches; dfol_vqa_amd.synthetic.full_size_questions)
     on new scenes, through collate (data_pipeline.py:647-783) -> create_sparse_tensors -> lower -> eager launches -> answers read back, per
@@ -660,12 +675,38 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
     bindex = torch.arange(B, dtype=torch.int64).repeat_interleave(N)
     state = {"k": 0}
 
+    from dfol_vqa_amd import native_exec
+    spec = native_exec.model_spec(model) if native_exec.enabled() else None
+
     class Collater(D.ProgramCollaterBase):
         def __init__(self):
-            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology)
+            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology, native_spec=spec)
 
         def collate_object_features(self, questions):
             return feats[state["k"] % pool], bindex
+
+    # stream_features (`value_end_to_end`): the features of every batch ALSO arrive from the host - a pool of pinned feature sets (the
+    # reference's pin_memory DataLoader, data_pipeline.py:893-898), copied on a copy stream into one of two device buffers while the batch
+    # before runs; the batch's launches wait for its copy, the copy waits for the batch that last read its buffer
+    if stream_features:
+        host_feats = [f.cpu().pin_memory() for f in feats]
+        stage = feats[:2]
+        copy_stream = torch.cuda.Stream(device=device)
+        ready = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+        for e in consumed:
+            e.record()
+        h2d = {"bytes": 0}
+
+        def stage_features(i):
+            """Queue the upload of batch i's features; -> (device tensor, event to wait for)."""
+            b = i & 1
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[b])
+                stage[b].copy_(host_feats[i % pool], non_blocking=True)
+                ready[b].record(copy_stream)
+            h2d["bytes"] += stage[b].numel() * 4
+            return stage[b], ready[b], consumed[b]
 
         def collate_meta_data(self, questions):
             return {"index": {}, "embedding": torch.zeros(1, 1)}
@@ -706,7 +747,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             seeds = {b: 5000 + 97 * rank + b for b in range(2, n_batches + 3)}
             try:
                 executor = ProcessPoolExecutor(workers, mp_context=multiprocessing.get_context("spawn"), initializer=_fresh_worker_init,
-                                               initargs=(paths, names, kinds, B, N, seeds))
+                                               initargs=(paths, names, kinds, B, N, seeds, spec))
                 list(executor.map(int, range(workers * 2)))      # the workers are up (and have generated their dicts) before the clock starts
             except Exception as exc:                             # (a host that cannot start them: this process collates, and the line says so)
                 print("bench: collate workers unavailable (%s); collating on the launching thread" % exc, file=sys.stderr)
@@ -742,28 +783,66 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                 for pb in pbs:
                     pb.create_sparse_tensors()
             pbs = [pb.to_cuda(device) for pb in pbs]
+            sync = None
+            if stream_features:
+                f, rdy, cons = stage_features(b)
+                for pb in pbs:
+                    pb._object_features = f
+                sync = (rdy, cons)
             host_s[0] += time.perf_counter() - h0
-            return pbs
+            return pbs, sync
 
+        def launch(pbs, sync):
+            if sync is not None:
+                torch.cuda.current_stream().wait_event(sync[0])  # this batch's features have landed
+            pending = model.forward_async(pbs, False)
+            if sync is not None:
+                sync[1].record()                                 # its buffer may be overwritten once these launches are done
+            return pending
+
+        _route_counts()
         try:
+            # two batches in flight: batch i + 1 is prepared AND launched before batch i's answers are read back, so the device never waits
+            # for the host's read-back / scoring / next launch (with one in flight it idled ~0.2 ms of every 2.3 ms batch)
             t0 = time.perf_counter()
-            pbs = prepare(2)
+            pbs, sync = prepare(2)
+            pending = launch(pbs, sync)
+            state["k"] += 1
             for i in range(n_batches):
-                pending = model.forward_async(pbs, False)
-                state["k"] += 1
-                nxt = prepare(3 + i) if i + 1 < n_batches else None
+                nxt_pbs, nxt_pending = None, None
+                if i + 1 < n_batches:
+                    nxt_pbs, nxt_sync = prepare(3 + i)
+                    nxt_pending = launch(nxt_pbs, nxt_sync)
+                    state["k"] += 1
                 training.compute_evaluation_metrics(pbs, pending.result())
-                pbs = nxt
+                pbs, pending = nxt_pbs, nxt_pending
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         finally:
             if executor is not None:
                 executor.shutdown(wait=True, cancel_futures=True)
         host = host_s[0]
-    return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B,
-            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead%s" % (workers, " (lost at batch %d: this process from there)" % lost[0] if lost else "")) if workers else "on the launching thread, while the device runs the batch before (forward_async)", "launch": "eager", "graph_cache": {"hits": 0, "of": n_batches},
+    route = _route_counts()
+    extra = {}
+    if stream_features:
+        gbps = h2d["bytes"] / dt / 1e9
+        extra = {"h2d_GBps": gbps, "h2d_bytes_per_question": h2d["bytes"] / (n_batches * B), "pcie_link_GBps": 63.0, "h2d_frac_of_link": gbps / 63.0,
+                 "bound": "the host->device link: %.0f KB of raw object features per question at %.1f GB/s of a 63 GB/s PCIe Gen5 x16 link" % (
+                     h2d["bytes"] / (n_batches * B) / 1e3, gbps) if gbps > 0.6 * 63.0 else "see host_collate_ms_per_batch / ms_per_batch",
+                 "features": "every batch's object features uploaded from pinned host memory on a copy stream (two device buffers), under the batch before"}
+    return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B, "executor": route, **extra,
+            "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead%s" % (workers, " (lost at batch %d: this process from there)" % lost[0] if lost else "")) if workers else "on the launching thread, while the device runs the batch before (forward_async)",
+            "launch": "native executor: one dfol_run_program call per ProgramBatch, lowered at collate time" if route.get("native_program") else "eager (Python operator loop)",
+            "graph_cache": {"hits": 0, "of": n_batches},
             "how": "every batch new programs (1..3 hops, mixed terminal operators) and another scene set; collate -> create_sparse_tensors -> lower -> "
                    "eager launches -> answers and error rate read back per batch; object features device-resident"}
+
+
+def _route_counts():
+    from dfol_vqa_amd import _lib as L
+    c = {k: v for k, v in L.PATH_COUNTS.items() if k == "native_program" or k.startswith("fallback:")}
+    L.PATH_COUNTS.clear()
+    return c
 
 
 def dominant_roofline(args, model, dom, per_step):

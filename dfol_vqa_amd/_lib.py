@@ -174,6 +174,7 @@ SIGNATURES = {
     "dfol_pair_pack_w2_f16x2": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_h2_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                             _i32, _p, _p],
+    "dfol_run_program": [_p, _p, _p, _i32, _p, _p, _p],
 }
 
 

@@ -291,7 +291,7 @@ class GQARelateBatch(GQABatchOperatorBase):
         if not hasattr(oracle, "oriented_tiles") or x.batch_size() != prev.batch_size() or prev._predicate_question_map is not None:
             return None
         low = getattr(relation_list, "lowered", None)
-        tiles = None if low is None else oracle.oriented_tiles(world, low)
+        tiles = None if low is None else oracle.oriented_tiles(world, low, relation_list)
         if tiles is None:
             return None
         _, neg_dev, valid_dev = low.on(world._device)

@@ -107,11 +107,12 @@ class GraphedForward(object):
     weight VERSION it was captured with: rebuild it after an optimizer step or load_state_dict."""
 
     def __init__(self, model, program_batch_list, warmup=2):
-        from . import gqa_ops
+        from . import gqa_ops, native_exec
         self._model, self._pbs = model, program_batch_list
         with torch.no_grad():
-            for _ in range(warmup):                              # fills the host-side caches (geometry, lowered tokens, packed weights)
-                model(program_batch_list, False)
+            with native_exec.suspended():                        # (the capture records the Python operator loop: warm ITS caches)
+                for _ in range(warmup):                          # fills the host-side caches (geometry, lowered tokens, packed weights)
+                    model(program_batch_list, False)
             torch.cuda.synchronize()
             self._queue = []
             self._keep = []                                      # everything the caches handed to the captured launches (host_util.keeping)
@@ -218,7 +219,7 @@ class BatchInterpreterBase(nn.Module):
             # fp32 accumulation (BASELINE configs[3]: "bf16 fwd / fp32 logic"); the logic kernels and everything small stay fp32
             from . import _lib
             with _lib.dense_math(getattr(self, "_mlp_math", None)):
-                all_results, all_traces, device = self._run_batches(program_batch_list, is_training, modulator_switch)
+                all_results, all_traces, device = self._run_batches(program_batch_list, is_training, modulator_switch, return_trace)
         finally:
             gqa_ops.DEFERRED.queue = outer
         if outer is None:
@@ -241,10 +242,33 @@ class BatchInterpreterBase(nn.Module):
             gqa_ops.DEFERRED.queue = None
         return PendingForward(lazy, queue)
 
-    def _run_batches(self, program_batch_list, is_training, modulator_switch):
+    def _native_spec(self, is_training, modulator_switch, return_trace):
+        """The lowering spec when this forward may run on the native executor (native_exec / native_plan: one C call per ProgramBatch instead
+        of one Python dispatch per operator), else None: inference without gradients reaching the oracle, no attention calibration, soft
+        quantifiers, no trace, fp32 tiles, and not inside a graph capture (a capture records the Python loop's launches, as before)."""
+        from . import _lib, native_exec
+        if not native_exec.enabled() or is_training or return_trace or _lib.capturing() or getattr(self, "_hard_mode", False):
+            return None
+        if self._has_modulator and modulator_switch:
+            return None
+        if torch.is_grad_enabled() and any(p.requires_grad for m in (self._oracle, self._featurizer) if isinstance(m, nn.Module) for p in m.parameters()):
+            return None
+        if getattr(self._oracle, "_tile_dtype", torch.float32) != torch.float32 or not hasattr(self, "_ontology"):
+            return None
+        return native_exec.model_spec(self)
+
+    def _run_batches(self, program_batch_list, is_training, modulator_switch, return_trace=False):
         all_traces, all_results = [], []
         device = program_batch_list[0].device
+        spec = self._native_spec(is_training, modulator_switch, return_trace)
         for program_batch in program_batch_list:
+            if spec is not None and isinstance(program_batch._object_features, torch.Tensor) and program_batch._object_features.is_cuda:
+                from . import gqa_ops, native_exec
+                plan = native_exec.plan_for(self, program_batch, spec)
+                if plan is not None:
+                    all_results.append(native_exec.run(self, program_batch, plan, gqa_ops.DEFERRED.queue, give_answer=not is_training))
+                    all_traces.append([])
+                    continue
             world = self.build_scene(program_batch.device, program_batch._object_features, program_batch._object_batch_index,
                                      program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None),
                                      question_image=getattr(program_batch, "_question_image", None))

@@ -1,0 +1,246 @@
+"""Host side of the native executor (include/dfol_vqa.h: dfol_run_program): the model's device pointers as the C structs, one upload of a
+plan's side arrays, one C call per ProgramBatch, one read-back of the results.
+
+The interpreter (interpreter.BatchInterpreterBase._run_batches) takes this route for every ProgramBatch that has a plan
+(native_plan.build_plan: inference, needed-columns oracle, no calibration); everything else runs the Python operator loop.  The result
+dict has the reference's keys (batch_gqa_ops.py: answer, log_probability, options, variable_set, type, cumulative_loss,
+variable_sets_num, answer_log_probability), with `variable_set` None (what data_parallel.gather_results keeps of it anyway).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import native_plan as NP
+
+_p, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+DENSE_F32, DENSE_F16X2, DENSE_BF16X3, DENSE_BF16 = 0, 1, 2, 3
+PAIR_PLAIN, PAIR_PACKED, PAIR_BF16X3, PAIR_F16X2 = 0, 1, 2, 3
+
+
+class DenseLayer(ctypes.Structure):
+    _fields_ = [("kind", _i32), ("act", _i32), ("N", _i32), ("K", _i32), ("weight", _p), ("ldw", _i64), ("packed", _p), ("bias", _p)]
+
+
+class ProgramModel(ctypes.Structure):
+    _fields_ = [("n_featurizer", _i32), ("n_attribute", _i32), ("featurizer", ctypes.POINTER(DenseLayer)), ("attribute", ctypes.POINTER(DenseLayer)),
+                ("uv", DenseLayer), ("pair_kind", _i32), ("hid1", _i32), ("hid2", _i32), ("w2_rows", _i32), ("wg", _p), ("w2", _p), ("ld_w2", _i64),
+                ("b2", _p), ("emb_w", _p), ("ld_e", _i64), ("emb_b", _p), ("emb_in", _i32), ("D", _i32)]
+
+
+class ProgramScene(ctypes.Structure):
+    _fields_ = [("features", _p), ("ld_features", _i64), ("raw_cols", _i32), ("O", _i32), ("NS", _i32), ("max_n", _i32), ("n_obj", _i64),
+                ("img_n_obj", _i64), ("obj_off", _i64)]
+
+
+_SUSPENDED = [0]
+
+
+def enabled():
+    # (per-entry-point HIP-event timing, _lib.enable_kernel_timing, brackets the individual calls of the Python loop: same kernels)
+    return os.environ.get("DFOL_NATIVE", "1") != "0" and not _SUSPENDED[0] and _lib._timed is None
+
+
+class suspended(object):
+    """with suspended(): forwards inside run the Python operator loop (the warm-up of a graph capture: the capture records that loop's
+    launches, so its host-side caches - uploaded index arrays, lowered tokens - must be filled by the same loop)."""
+
+    def __enter__(self):
+        _SUSPENDED[0] += 1
+
+    def __exit__(self, *exc):
+        _SUSPENDED[0] -= 1
+        return False
+
+
+def _layers(seq):
+    """(Linear, activation code) pairs of an nn.Sequential of (Dropout, Linear, activation) triples, as visual_oracle._run_layers walks it."""
+    mods, out, i = list(seq), [], 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Dropout):
+            i += 1
+            continue
+        if not isinstance(m, nn.Linear):
+            return None
+        act, step = _lib.ACT_NONE, 1
+        if i + 1 < len(mods):
+            nxt = mods[i + 1]
+            if isinstance(nxt, nn.ELU):
+                act, step = _lib.ACT_ELU, 2
+            elif isinstance(nxt, nn.Sigmoid):
+                act, step = _lib.ACT_SIGMOID, 2
+            elif isinstance(nxt, nn.LogSigmoid):
+                act, step = _lib.ACT_LOGSIGMOID, 2
+        out.append((m, act))
+        i += step
+    return out
+
+
+def model_spec(model):
+    """native_plan.ModelSpec of an interpreter, or None when its modules are not the shapes the executor drives."""
+    from .interpreter import BatchGQABoxFeaturizer
+    feat, oracle = model._featurizer, model._oracle
+    if not isinstance(feat, BatchGQABoxFeaturizer) or getattr(feat._featurizer_network, "_network", None) is None:
+        return None
+    if not (model._cached and getattr(oracle, "supports_needed_columns", lambda: False)()):
+        return None
+    fl, al = _layers(feat._featurizer_network._network), _layers(oracle._attribute_network._network)
+    if not fl or not al:
+        return None
+    lin1 = [m for m in oracle._relation_network._network if isinstance(m, nn.Linear)][0]
+    return NP.ModelSpec([l.out_features for l, _ in fl], [l.out_features for l, _ in al], lin1.out_features, fl[-1][0].out_features + 4,
+                        oracle._normalize, model._likelihood_threshold, oracle._ontology._relation_index)
+
+
+class NativeModel(object):
+    """The C view of an interpreter's neural modules for ONE weight version and dense-math mode.  Holds every tensor whose address it
+    hands out (raw weights, packed images) for as long as it lives."""
+
+    def __init__(self, model):
+        feat, oracle = model._featurizer, model._oracle
+        self._hold = []
+        math = _lib._dense_math()
+        kind, pieces = {"f16x2": (DENSE_F16X2, 2), "bf16x3": (DENSE_BF16X3, 3), "bf16": (DENSE_BF16, 1), "f32": (DENSE_F32, 0)}[math]
+
+        def dense(weight, bias, act):
+            w = weight.detach()
+            N, K = w.shape
+            d = DenseLayer()
+            d.kind, d.act, d.N, d.K = DENSE_F32, int(act), int(N), int(K)
+            d.weight, d.ldw = w.data_ptr(), w.stride(0)
+            d.packed = None
+            d.bias = None if bias is None else bias.detach().data_ptr()
+            self._hold += [w, bias]
+            if kind != DENSE_F32 and N * K >= _lib.SPLIT_MIN_WEIGHT and w.stride(1) == 1:
+                img = _lib.linear_pack_w_split(weight, False, pieces)
+                d.kind, d.packed = kind, img.data_ptr()
+                self._hold.append(img)
+            return d
+
+        fl, al = _layers(feat._featurizer_network._network), _layers(oracle._attribute_network._network)
+        self._fl = (DenseLayer * len(fl))(*[dense(l.weight, l.bias, a) for l, a in fl])
+        self._al = (DenseLayer * len(al))(*[dense(l.weight, l.bias, a) for l, a in al])
+        wuv, buv, wg, hid1, D = oracle._split_first_layer()
+        w2p, b2, hid2, packed = oracle._padded_second_layer()
+        emb = oracle._embedding_network.linear
+        m = ProgramModel()
+        m.n_featurizer, m.n_attribute = len(fl), len(al)
+        m.featurizer, m.attribute = self._fl, self._al
+        m.uv = dense(wuv, buv, _lib.ACT_NONE)
+        if isinstance(packed, tuple):
+            m.pair_kind, w2 = (PAIR_F16X2 if packed[0] == "f16x2" else PAIR_BF16X3), packed[1]
+        elif packed is not None:
+            m.pair_kind, w2 = PAIR_PACKED, packed
+        else:
+            m.pair_kind, w2 = PAIR_PLAIN, w2p
+        m.hid1, m.hid2, m.w2_rows = int(hid1), int(hid2), int(w2p.shape[0])
+        m.wg, m.w2, m.ld_w2, m.b2 = wg.data_ptr(), w2.data_ptr(), w2p.stride(0), b2.data_ptr()
+        ew = emb.weight.detach()
+        m.emb_w, m.ld_e = ew.data_ptr(), ew.stride(0)
+        m.emb_b = None if emb.bias is None else emb.bias.detach().data_ptr()
+        m.emb_in, m.D = int(ew.shape[1]), int(D)
+        self._hold += [wuv, buv, wg, w2p, b2, w2, ew, emb.bias]
+        self.struct = m
+        self.D = int(D)
+
+    @staticmethod
+    def version_key(model):
+        params = list(model._featurizer.parameters()) + list(model._oracle.parameters())
+        return (tuple((p.data_ptr(), p._version) for p in params), _lib._dense_math(), _lib.pair_math(), str(params[0].device) if params else "")
+
+
+def native_model(model):
+    key = NativeModel.version_key(model)
+    hit = model.__dict__.get("_native_model")
+    if hit is None or hit[0] != key:
+        hit = model.__dict__["_native_model"] = (key, NativeModel(model))
+    return hit[1]
+
+
+# ---- pinned read-back buffers: a small free list (pinned allocations cost ~100 us; a forward needs one per ProgramBatch) -----------------------
+_PINNED = {}
+
+
+def _pinned(nbytes):
+    size = 256
+    while size < nbytes:
+        size *= 2
+    free = _PINNED.setdefault(size, [])
+    return (free.pop() if free else torch.empty(size, dtype=torch.uint8).pin_memory()), size
+
+
+def _release(buf, size):
+    free = _PINNED.setdefault(size, [])
+    if len(free) < 64:
+        free.append(buf)
+
+
+def plan_for(model, program_batch, spec):
+    """The ProgramBatch's plan (built at collate time by a collater that was given the spec, or here on first use), or None."""
+    plan = getattr(program_batch, "_native_plan", False)
+    if plan is False or (plan is not None and plan.key != spec.key()):
+        plan = NP.build_plan(program_batch, model._ontology, spec)
+        program_batch._native_plan = plan
+    return plan
+
+
+def blob_on(plan, device):
+    """The plan's side arrays on the device: one copy through the pinned staging ring, kept with the plan (a batch that runs again pays nothing)."""
+    cache = plan.__dict__.setdefault("_blob_dev", {})
+    key = str(device)
+    hit = cache.get(key)
+    if hit is None:
+        from . import host_util
+        if host_util._ring is None:
+            host_util._ring = host_util._PinnedRing()
+        hit = torch.empty(plan.blob.nbytes, dtype=torch.uint8, device=device)
+        if plan.blob.nbytes <= (1 << 20) and not torch.cuda.is_current_stream_capturing():
+            hit.copy_(host_util._ring.stage(plan.blob), non_blocking=True)
+        else:
+            hit.copy_(torch.from_numpy(plan.blob))
+        cache[key] = hit
+    return hit
+
+
+def run(model, program_batch, plan, queue, give_answer=True):
+    """Enqueue the batch; -> the result dict, its answers filled by a closure appended to `queue` (the interpreter's deferred read-back)."""
+    feats = program_batch._object_features
+    device = feats.device
+    if feats.dtype != torch.float32 or feats.stride(1) != 1 or feats.shape[0] != plan.scene["O"]:
+        raise _lib.DfolError("native executor: object features must be fp32 rows, one per object of the batch")
+    nm = native_model(model)
+    if feats.shape[1] - 6 != nm.struct.featurizer[0].K:
+        raise _lib.DfolError("native executor: feature width %d does not match the featurizer (%d + 6)" % (feats.shape[1], nm.struct.featurizer[0].K))
+    blob = blob_on(plan, device)
+    ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
+    sc = ProgramScene()
+    sc.features, sc.ld_features, sc.raw_cols, sc.O = feats.data_ptr(), feats.stride(0), feats.shape[1], plan.scene["O"]
+    sc.NS, sc.max_n = plan.scene["NS"], plan.scene["max_n"]
+    sc.n_obj, sc.img_n_obj, sc.obj_off = plan.scene["n_obj"], plan.scene["img_n_obj"], plan.scene["obj_off"]
+    instrs = plan.instrs
+    _lib.call("dfol_run_program", ctypes.byref(nm.struct), ctypes.byref(sc), instrs.ctypes.data, instrs.shape[0], blob.data_ptr(), ws.data_ptr(),
+              _lib._stream())
+    r = plan.result
+    lp = ws[r["lp"]:r["lp"] + 4 * r["count"]].view(torch.float32)
+    answer, alp = [], []
+    if give_answer:
+        host, size = _pinned(plan.out_bytes)
+        host[:plan.out_bytes].copy_(ws[:plan.out_bytes], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def fill():
+            done.synchronize()
+            a, l = NP.decode(plan, host.numpy()[:plan.out_bytes], True)
+            answer[:] = a
+            alp[:] = l
+            _release(host, size)
+        queue.append(fill)
+    _lib.note("native_program")
+    return {'answer': answer, 'log_probability': lp, 'options': r["options"], 'variable_set': None, 'type': r["type"], 'cumulative_loss': 0,
+            'variable_sets_num': r["num"], 'answer_log_probability': alp, '_workspace': ws}

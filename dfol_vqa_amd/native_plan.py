@@ -1,0 +1,620 @@
+"""Lowering of a collated ProgramBatch to the instruction table of the native executor (include/dfol_vqa.h: dfol_run_program).
+
+The reference dispatches one Python call per operator of a batch (batch_base_interpreter.py:145-172 -> batch_gqa_interpreter.py:72-78 ->
+batch_gqa_ops.py); this module performs that walk ONCE, symbolically, on the host - in the collate worker, where the reference already
+builds its ProgramBatches (data_pipeline.py:893-898) - and writes down, per launch the operator classes of gqa_ops.py / logic_ops.py /
+visual_oracle.py would issue, one fixed-width instruction: opcode + operands (byte offsets into a blob of small side arrays and into a
+workspace arena).  Everything a launch needs that the Python operators work out per call - concept columns, negation / validity flags,
+predicate -> question maps, option clusters, quantifiers (always host-known: they start as EXISTS constants and are only ever gated by
+host flags), gate flags, pair-kernel requests, names, `variable_sets_num` - is decided here.  The executor then issues the same
+entry points with the same arguments, so its results equal the Python loop's bit for bit (tests/test_native_gpu.py).
+
+Scope: inference (is_training False, no gradients), the needed-columns oracle with fp32 tiles, no attention calibration, soft
+quantifiers (hard_mode False), no trace.  Anything else - and the rare shapes listed at `Unsupported` - returns None and the interpreter
+runs its Python loop.
+"""
+
+import math
+
+import numpy as np
+
+from .fol_types import Quantifier, QuestionType, TokenType
+from .host_util import flatten_list, get_lowered, lower_tokens, segments_of, unflatten_list
+
+# opcodes of include/dfol_vqa.h
+(OP_DENSE, OP_BOX_POSITIONS, OP_FILL, OP_PAIR_LL, OP_ATTR_LL, OP_OPTION_NORMALIZE, OP_FILTER, OP_RELATE_ONE, OP_RELATE, OP_QUANTIFY, OP_GATE,
+ OP_LOGIC, OP_SEGMENT_SUM_ROWS, OP_SEGMENT_OR, OP_IMPLICATION, OP_COMPARE, OP_FIND_MAX_IND, OP_GATHER_TILES) = range(18)
+INSTR_WIDTH = 16
+LOGIC_AND, LOGIC_OR, LOGIC_NOT = 0, 1, 2
+TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
+WANT_SUBJECT, WANT_OBJECT = 1, 2
+RELATE_LONE_FORALL_IDENTITY, RELATE_DIAG_ABSENT = 1, 2
+_NEG30_BITS = int(np.float32(-30.0).view(np.int32))
+_ALIGN = 256
+
+
+class Unsupported(Exception):
+    """A shape the executor does not take (the Python loop does): raised inside the lowering, turned into `None` by build_plan."""
+
+
+class ModelSpec(object):
+    """What the lowering must know about the model: widths (they size the workspace), the oracle's option normalisation and the
+    interpreter's likelihood threshold.  Picklable (collate workers build plans)."""
+
+    def __init__(self, featurizer_widths, attribute_widths, hid1, D, normalize, likelihood_threshold, relation_index):
+        self.featurizer_widths = [int(w) for w in featurizer_widths]      # output width of every featurizer layer (the last = D - 4)
+        self.attribute_widths = [int(w) for w in attribute_widths]        # output width of every attribute-network layer
+        self.hid1, self.D = int(hid1), int(D)
+        self.normalize = bool(normalize)
+        self.likelihood_threshold = float(likelihood_threshold)
+        self.relation_index = np.asarray(relation_index, np.int32)        # 333-column index -> column of the full concept table
+
+    def key(self):
+        return (tuple(self.featurizer_widths), tuple(self.attribute_widths), self.hid1, self.D, self.normalize, self.likelihood_threshold,
+                self.relation_index.tobytes())
+
+
+class _W(object):
+    """A workspace reference: region 'o' (results, at the start of the arena) or 't' (intermediates, behind the results)."""
+    __slots__ = ("region", "off")
+
+    def __init__(self, region, off):
+        self.region, self.off = region, off
+
+    def at(self, nbytes):
+        return _W(self.region, self.off + int(nbytes))
+
+
+class _VS(object):
+    """Symbolic BatchVariableSet: names, attention block [rows, NS] in the workspace, quantifiers on the host, predicate -> question map."""
+    __slots__ = ("names", "att", "rows", "quant", "pq", "prev_num")
+
+    def __init__(self, names, att, rows, quant, pq=None, prev_num=0):
+        self.names, self.att, self.rows, self.quant, self.pq, self.prev_num = names, att, rows, np.asarray(quant, np.float32), pq, prev_num
+
+
+class NativePlan(object):
+    """instrs [n, 16] int64 (host), blob (uint8, one upload), workspace size, the leading `out_bytes` of which the host reads back, the scene
+    header and what the host needs to turn the read-back into the reference's result dict."""
+
+    def __init__(self):
+        self.instrs = None
+        self.blob = None
+        self.ws_bytes = 0
+        self.out_bytes = 0
+        self.scene = None             # dict: O, NS, max_n, n_obj / img_n_obj / obj_off blob offsets, raw_cols
+        self.result = None            # dict: kind, type, lp (offset, count), ...
+        self.key = None
+        self.launches = 0
+
+
+class _Builder(object):
+
+    def __init__(self, pb, ontology, spec):
+        self.pb, self.ont, self.spec = pb, ontology, spec
+        self.instrs = []
+        self._blob_parts, self._blob_size, self._blob_memo = [], 0, {}
+        self._size = {"o": 0, "t": 0}
+        n_list = [int(n) for n in pb._object_nums]
+        if pb._question_image is not None:
+            raise Unsupported("shared scenes")
+        if not n_list or min(n_list) < 1:
+            raise Unsupported("an empty batch or an image without objects")
+        self.n_list, self.Q = n_list, len(n_list)
+        self.O = int(sum(n_list))
+        self.NS = max(4, (max(n_list) + 3) // 4 * 4)
+        self.max_n = max(n_list)
+        n = np.asarray(n_list, np.int64)
+        self.pair_num = int((n * (n - 1)).sum())
+        self.b_n_obj = self.arr(n.astype(np.int32))
+        self.b_obj_off = self.arr(np.concatenate([[0], np.cumsum(n)]).astype(np.int32))
+        self.ident = np.arange(self.Q, dtype=np.int32)
+        self.b_ident = self.arr(self.ident)
+        self._zeros = None
+
+    # ---- blob / arena -----------------------------------------------------------------------------------------------------------------
+    def arr(self, a):
+        a = np.ascontiguousarray(a)
+        key = (a.dtype.str, a.tobytes())
+        hit = self._blob_memo.get(key)
+        if hit is None:
+            pad = (-self._blob_size) % 16
+            if pad:
+                self._blob_parts.append(np.zeros(pad, np.uint8))
+                self._blob_size += pad
+            hit = self._blob_memo[key] = self._blob_size
+            self._blob_parts.append(a.reshape(-1).view(np.uint8))
+            self._blob_size += a.nbytes
+        return hit
+
+    def alloc(self, nbytes, region="t"):
+        off = self._size[region]
+        self._size[region] = off + (int(nbytes) + _ALIGN - 1) // _ALIGN * _ALIGN
+        return _W(region, off)
+
+    def block(self, rows, region="t"):
+        return self.alloc(rows * self.NS * 4, region)
+
+    def emit(self, *ops):
+        assert len(ops) <= INSTR_WIDTH
+        self.instrs.append(list(ops) + [0] * (INSTR_WIDTH - len(ops)))
+
+    def zeros(self):
+        if self._zeros is None:
+            self._zeros = self.block(self.Q)
+            self.emit(OP_FILL, self._zeros, self.Q * self.NS, 0)
+        return self._zeros
+
+    # ---- scene stage (interpreter.build_scene / visual_oracle.prepare_scene) --------------------------------------------------------------
+    def scene_stage(self):
+        sp, O = self.spec, self.O
+        D = sp.D
+        self.obj = self.alloc(O * D * 4)
+        x, ldx, src = 0, 0, 0                                      # the raw features: pointer and row stride come from the scene header
+        for i, w in enumerate(sp.featurizer_widths):
+            last = i == len(sp.featurizer_widths) - 1
+            y, ldy = (self.obj, D) if last else (self.alloc(O * w * 4), w)
+            self.emit(OP_DENSE, 0, i, src, x, ldx, y, ldy, O)
+            x, ldx, src = y, ldy, 1
+        if sp.featurizer_widths[-1] != D - 4:
+            raise Unsupported("featurizer width")
+        self.emit(OP_BOX_POSITIONS, self.obj, D, D - 4)
+        x, ldx = self.obj, D
+        for i, w in enumerate(sp.attribute_widths):
+            y = self.alloc(O * w * 4)
+            self.emit(OP_DENSE, 1, i, 1, x, ldx, y, w, O)
+            x, ldx = y, w
+        self.hidden, self.H = x, ldx
+        self.uv = self.alloc(O * 2 * sp.hid1 * 4)
+        self.emit(OP_DENSE, 2, 0, 1, self.obj, D, self.uv, 2 * sp.hid1, O)
+
+    # ---- relation tiles: ONE pair-kernel launch for every relation operator (visual_oracle.prefetch_relations) ----------------------------
+    def relation_stage(self, ops):
+        Q, NS = self.Q, self.NS
+        entries = []                                               # (op index, lowered tokens, predicate -> question, orientation)
+        for i, ob in enumerate(ops):
+            if not ob._arguments:
+                continue
+            if ob._op_name in ("relate", "verify_rel"):
+                low = get_lowered(ob._arguments[0], self.ont, TokenType.RELATION)
+                if low.any_valid and len(low.cols) == Q:
+                    orient = np.asarray([TILE_OBJECT_ROWS if f else TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8)
+                    entries.append((i, low, np.arange(Q), orient))
+            elif ob._op_name == "choose_rel":
+                flat, batch_index = flatten_list(ob._arguments[0])
+                low = lower_tokens(flat, self.ont, TokenType.RELATION)
+                if low.any_valid:
+                    entries.append((i, low, np.asarray(batch_index, np.int64), np.zeros(len(flat), np.uint8)))
+        self.tiles = {}
+        if not entries:
+            return
+        if self.pair_num == 0:
+            raise Unsupported("relations over images of one object")
+        total = sum(len(e[1].cols) for e in entries)
+        tiles = self.alloc(total * NS * NS * 4)
+        self.emit(OP_FILL, tiles, total * NS * NS, _NEG30_BITS)
+        rows_col, rows_tile, rows_orient, base = [], [], [], 0
+        for i, low, pq, orient in entries:
+            P = len(pq)
+            pq = np.asarray(pq, np.int64)
+            slot = np.zeros(P, np.int64)                           # j-th predicate of its question, in predicate order
+            if P > 1 and not (P == Q and pq[0] == 0 and pq[-1] == Q - 1 and (np.diff(pq) == 1).all()):
+                order = np.argsort(pq, kind="stable")
+                sq = pq[order]
+                start = np.flatnonzero(np.concatenate([[True], sq[1:] != sq[:-1]]))
+                slot[order] = np.arange(P) - np.repeat(start, np.diff(np.concatenate([start, [P]])))
+            K = int(slot.max()) + 1 if P else 1
+            col = np.full((K, Q), -1, np.int32)
+            til = np.zeros((K, Q), np.int32)
+            ori = np.zeros((K, Q), np.uint8)
+            full = np.where(low.cols >= 0, self.spec.relation_index[np.maximum(low.cols, 0)], -1).astype(np.int32)
+            col[slot, pq] = full
+            til[slot, pq] = base + np.arange(P, dtype=np.int32)
+            ori[slot, pq] = orient
+            rows_col.append(col), rows_tile.append(til), rows_orient.append(ori)
+            self.tiles[i] = (tiles.at(base * NS * NS * 4), low)
+            base += P
+        col, til, ori = np.concatenate(rows_col), np.concatenate(rows_tile), np.concatenate(rows_orient)
+        D = self.spec.D
+        self.emit(OP_PAIR_LL, self.uv, 2 * self.spec.hid1, self.obj.at((D - 4) * 4), D, self.arr(col), self.arr(til), self.arr(ori), col.shape[0], tiles, Q)
+
+    # ---- attribute blocks: ONE launch for every attribute token list of the batch ---------------------------------------------------------
+    def attribute_stage(self, requests):
+        """requests: [(key, lowered, predicate -> question int32)] -> self.attr[key] = block [P, NS]."""
+        self.attr = {}
+        todo = [(k, low, pq) for k, low, pq in requests if low.any_valid]
+        if not todo:
+            return
+        total = sum(len(low.cols) for _, low, _ in todo)
+        ll = self.block(total)
+        cols = np.concatenate([low.cols for _, low, _ in todo]).astype(np.int32)
+        pimg = np.concatenate([np.asarray(pq, np.int32) for _, _, pq in todo])
+        self.emit(OP_ATTR_LL, self.hidden, self.H, self.arr(pimg), self.arr(cols), total, ll)
+        base = 0
+        for k, low, pq in todo:
+            self.attr[k] = ll.at(base * self.NS * 4)
+            base += len(low.cols)
+
+    # ---- operators --------------------------------------------------------------------------------------------------------------------
+    def _normalize(self, ll, low, pq, rank, normalized):
+        """The option normalisation of visual_oracle._block_likelihood_needed (classifier_oracle.py:72-75, 124-127), in place."""
+        if not (self.spec.normalize and normalized):
+            return
+        valid = low.valid.astype(bool)
+        seg = segments_of(np.asarray(pq)[valid])
+        if len(seg) - 1 == int(valid.sum()):
+            return
+        if not low.all_valid:
+            raise Unsupported("a no-op token inside an option list")
+        self.emit(OP_OPTION_NORMALIZE, ll, self.arr(seg.astype(np.int32)), len(seg) - 1, self.arr(np.asarray(pq, np.int32)), rank)
+
+    def filter(self, vs, tokens, key, pq=None, normalized=True):
+        """FilterBatch.forward (logic_ops.py; batch_base_ops.py:311-405)."""
+        low = get_lowered(tokens, self.ont, TokenType.ATTRIBUTE)
+        if not low.any_valid:
+            return vs
+        P = len(tokens)
+        if pq is None:
+            if P != vs.rows:
+                raise Unsupported("batch size mismatch")
+            pq_arr, quant = self.ident if vs.rows == self.Q else np.arange(P, dtype=np.int32), vs.quant
+        else:
+            pq_arr = np.asarray(pq, np.int32)
+            if len(pq_arr) != P or vs.rows != self.Q:
+                raise Unsupported("batch size mismatch")
+            quant = vs.quant[pq_arr]
+        if vs.pq is not None:
+            raise Unsupported("a filter over an expanded variable set")
+        ll = self.attr[key]
+        self._normalize(ll, low, pq_arr, 1, normalized)
+        out = self.block(P)
+        self.emit(OP_FILTER, vs.att, ll, self.arr(pq_arr), self.arr(low.neg) if low.any_neg else -1, -1 if low.all_valid else self.arr(low.valid), P, out)
+        return _VS(vs.names, out, P, quant, None if pq is None else pq_arr, vs.prev_num + 1)
+
+    def select(self, tokens, key):
+        """GQASelectBatch.forward (batch_gqa_ops.py:168-183)."""
+        Q = self.Q
+        if tokens is None:
+            names, att = ["entity"] * Q, None
+        else:
+            names = ["entity" if a is None or a.lower() in ("_", "scene") else a for a in tokens][:Q]
+            att = [None if a is None or a.lower() in ("_", "scene") else a for a in tokens][:Q]
+        x = _VS(names, self.zeros(), Q, np.full(Q, float(Quantifier.EXISTS), np.float32))
+        if att is None or all(a is None for a in att):
+            return x
+        return self.filter(x, att, key)
+
+    @staticmethod
+    def select_tokens(tokens, Q):
+        """The token list GQASelectBatch hands its filter (names `_` / `scene` are no-ops)."""
+        if tokens is None:
+            return None
+        return [None if a is None or a.lower() in ("_", "scene") else a for a in tokens][:Q]
+
+    def gate_names(self, x_names, y_names, flags):
+        return [a if f > 0 else b for a, b, f in zip(x_names, y_names, flags)]
+
+    def gate(self, x, y, flags):
+        """BatchVariableSet.gate (fol_types.py; batch_base_types.py:149-168): rows with flag 1 come from x."""
+        flags = [0 if f is None else f for f in flags]
+        names = self.gate_names(x.names, y.names, flags)
+        g = np.asarray([float(f) for f in flags], np.float32)
+        if len(flags) == x.rows and all(f == 1 for f in flags):
+            return _VS(names, x.att, x.rows, x.quant, x.pq, 0)
+        out, outq = self.block(x.rows), self.alloc(x.rows * 4)
+        self.emit(OP_GATE, x.att, y.att, self.arr(x.quant), self.arr(y.quant), self.arr(g), x.rows, out, outq)
+        return _VS(names, out, x.rows, g * x.quant + (1.0 - g) * y.quant, x.pq, 0)
+
+    def mask_gate(self, x, prev, mask, valid):
+        """The interpreter's pass-through for questions lacking an operator (batch_base_interpreter.py:166-167).  Where every masked-out
+        question carries a no-op token (what collate produces), filter_fwd / relate_one_fwd already left the incoming row in place
+        (active == 0 copies the prior row), so no launch is needed - only names and quantifiers follow the mask; otherwise a real gate."""
+        if mask is None or x is prev:
+            return x
+        if len(mask) != x.rows or x.rows != prev.rows or any(m == 0 and v for m, v in zip(mask, valid)) or any(m not in (0, 1) for m in mask):
+            return self.gate(x, prev, mask)
+        names = self.gate_names(x.names, prev.names, mask)
+        g = np.asarray(mask, np.float32)
+        return _VS(names, x.att, x.rows, g * x.quant + (1.0 - g) * prev.quant, x.pq, 0)
+
+    def relate(self, i, prev, relation_list, is_subject, names_tokens, key):
+        """GQARelateBatch.forward on the fused single-posterior kernel (gqa_ops.GQARelateBatch._forward_fused; batch_gqa_ops.py:364-371)."""
+        x = self.select(names_tokens, key)
+        host = [0.0 if f is None else float(f) for f in is_subject]
+        hit = self.tiles.get(i)
+        if hit is None or x.rows != prev.rows or prev.pq is not None or x.rows != self.Q:
+            raise Unsupported("a relate without prefetched tiles")
+        tiles, low = hit
+        out = self.block(self.Q)
+        self.emit(OP_RELATE_ONE, x.att, prev.att, tiles, self.b_ident, self.arr(prev.quant), self.arr(low.neg) if low.any_neg else -1,
+                  -1 if low.all_valid else self.arr(low.valid), self.Q, 1 if self.Q == 1 else 0, out)
+        quant = np.where(np.asarray([f > 0 for f in host]), x.quant, prev.quant).astype(np.float32)
+        return _VS(x.names, out, self.Q, quant, None, x.prev_num + prev.prev_num + 1), low
+
+    def quantify(self, vs, quant=None, region="t"):
+        lp = self.alloc(vs.rows * 4, region)
+        pq = self.ident if vs.pq is None and vs.rows == self.Q else (np.arange(vs.rows, dtype=np.int32) if vs.pq is None else vs.pq)
+        if vs.pq is None and vs.rows != self.Q:
+            raise Unsupported("an unmapped variable set of another size")
+        self.emit(OP_QUANTIFY, vs.att, self.arr(vs.quant if quant is None else quant), self.arr(pq), vs.rows, lp)
+        return lp
+
+    def seg_off(self, batch_index):
+        counts = np.bincount(np.asarray(batch_index, np.int64), minlength=self.Q)
+        return self.arr(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+
+    def find_max(self, lp, batch_index, P):
+        bi = np.asarray(batch_index)
+        if not (len(bi) > 0 and (len(bi) < 2 or bool(np.all(bi[1:] >= bi[:-1]))) and int(bi[-1]) < self.Q):
+            raise Unsupported("an unsorted option list")
+        flags = self.alloc(P, "o")
+        thr = int(np.float32(self.spec.likelihood_threshold).view(np.int32))
+        self.emit(OP_FIND_MAX_IND, lp, self.seg_off(batch_index), self.Q, thr, flags)
+        return flags
+
+    def category_options(self, category_list, names):
+        lists = [self.ont.query(c if c not in ["name", "type"] else n) for c, n in zip(category_list, names)]
+        return lists, flatten_list(lists)
+
+
+def _attribute_requests(b, ops, deps):
+    """Every attribute token list the operators will filter with, keyed (op index, slot): decided before the operators are lowered so that
+    one launch evaluates all of them.  Category options depend on variable NAMES, which flow through selects and gates: a names-only
+    pre-pass of the program mirrors the walk below."""
+    Q, ont = b.Q, b.ont
+    reqs, names_of = [], []
+    ident = b.ident
+
+    def sel_names(tokens):
+        if tokens is None:
+            return ["entity"] * Q
+        return ["entity" if a is None or a.lower() in ("_", "scene") else a for a in tokens][:Q]
+
+    for i, ob in enumerate(ops):
+        name, args, d = ob._op_name, ob._arguments, deps[i]
+        mask = None if ob._mask is None else ob._mask._host
+        prev = names_of[d[0]] if d else None
+        out = prev
+        if name == "select":
+            toks = args[0] if args else None
+            out = sel_names(toks)
+            st = b.select_tokens(toks, Q)
+            if st is not None and any(a is not None for a in st):
+                reqs.append(((i, 0), get_lowered(st, ont, TokenType.ATTRIBUTE), ident))
+        elif name == "filter":
+            reqs.append(((i, 0), get_lowered(args[0], ont, TokenType.ATTRIBUTE), ident))
+        elif name in ("relate", "verify_rel", "choose_rel"):
+            toks = args[2] if len(args) > 2 else None
+            out = sel_names(toks)
+            st = b.select_tokens(toks, Q)
+            if st is not None and any(a is not None for a in st):
+                reqs.append(((i, 0), get_lowered(st, ont, TokenType.ATTRIBUTE), ident))
+        elif name in ("verify_attrs", "choose_attr"):
+            flat, bi = flatten_list(args[0])
+            reqs.append(((i, 0), lower_tokens(flat, ont, TokenType.ATTRIBUTE), np.asarray(bi, np.int32)))
+        elif name in ("query_attr", "all_same", "all_different", "two_same", "two_different"):
+            _, (flat, bi) = b.category_options(args[0], prev)
+            reqs.append(((i, 0), lower_tokens(flat, ont, TokenType.ATTRIBUTE), np.asarray(bi, np.int32)))
+        elif name == "compare":
+            reqs.append(((i, 0), get_lowered(args[0], ont, TokenType.ATTRIBUTE), ident))
+        if name in ("select", "filter", "relate") and d and mask is not None and prev is not None:
+            out = [a if f > 0 else p for a, p, f in zip(out, prev, mask)]
+        names_of.append(out)
+    return reqs
+
+
+def _lower(pb, ontology, spec):
+    b = _Builder(pb, ontology, spec)
+    ops, deps = getattr(pb._op_batch_list, "host", pb._op_batch_list), pb._dependencies      # (a lazily moved batch: the collated operators)
+    if not ops:
+        raise Unsupported("an empty program")
+    b.scene_stage()
+    b.relation_stage(ops)
+    b.attribute_stage(_attribute_requests(b, ops, deps))
+    Q = b.Q
+    trace, result = [], None
+    last = len(ops) - 1
+    for i, ob in enumerate(ops):
+        name, args = ob._op_name, ob._arguments
+        ins = [trace[d] for d in deps[i]]
+        mask = None if ob._mask is None else ob._mask._host
+        if ob._is_terminal and i != last:
+            trace.append(None)                                     # an earlier terminal's result is dropped by the reference's loop too
+            continue
+        if any(v is None for v in ins):
+            raise Unsupported("an operator that reads a terminal operator's result")
+        valid = None
+        if name == "select":
+            x = b.select(args[0] if args else None, (i, 0))
+        elif name == "filter":
+            x = b.filter(ins[0], args[0], (i, 0))
+            valid = get_lowered(args[0], ontology, TokenType.ATTRIBUTE).valid
+        elif name == "relate":
+            x, low = b.relate(i, ins[0], args[0], args[1], args[2] if len(args) > 2 else None, (i, 0))
+            valid = low.valid
+        elif name == "exist":
+            lp = b.quantify(ins[0], region="o")
+            result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=ins[0].prev_num + 1)
+        elif name == "end":
+            lp = b.quantify(ins[0], region="o")
+            result = dict(kind="end", type=QuestionType.STATEMENT, lp=lp, count=ins[0].rows, options=[], num=ins[0].prev_num + 1, names=list(ins[0].names))
+        elif name == "verify_rel":
+            x, _ = b.relate(i, ins[0], args[0], args[1], args[2] if len(args) > 2 else None, (i, 0))
+            lp = b.quantify(x, region="o")
+            result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=x.prev_num + 1)
+        elif name == "verify_attrs":
+            flat, bi = flatten_list(args[0])
+            x = b.filter(ins[0], flat, (i, 0), bi, normalized=False)
+            if x is ins[0]:
+                raise Unsupported("verify_attrs without attributes")
+            summed = b.block(Q)
+            b.emit(OP_SEGMENT_SUM_ROWS, x.att, b.seg_off(bi), Q, b.NS, summed)
+            y = _VS(ins[0].names, summed, Q, ins[0].quant, None, x.prev_num)
+            lp = b.quantify(y, region="o")
+            result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=y.prev_num + 1)
+        elif name in ("choose_attr", "query_attr"):
+            if name == "query_attr":
+                lists, (flat, bi) = b.category_options(args[0], ins[0].names)
+            else:
+                lists, (flat, bi) = args[0], flatten_list(args[0])
+            x = b.filter(ins[0], flat, (i, 0), bi)
+            if x is ins[0]:
+                raise Unsupported("an option list without options")
+            lp = b.quantify(x, region="o")
+            flags = b.find_max(lp, bi, len(flat))
+            result = dict(kind="choose", type=QuestionType.QUERY, lp=lp, count=len(flat), flags=flags, flat=flat, batch_index=bi, options=lists, num=x.prev_num + 1)
+        elif name == "choose_rel":
+            result = _choose_rel(b, i, ins[0], args)
+        elif name in ("and", "or"):
+            lp1, lp2 = b.quantify(ins[0]), b.quantify(ins[1])
+            lp = b.alloc(Q * 4, "o")
+            b.emit(OP_LOGIC, LOGIC_AND if name == "and" else LOGIC_OR, lp1, lp2, Q, lp)
+            result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=ins[0].prev_num + ins[1].prev_num + 2)
+        elif name in ("all_same", "all_different"):
+            _, (flat, bi) = b.category_options(args[0], ins[0].names)
+            x = b.filter(ins[0], flat, (i, 0), bi)
+            if x is ins[0]:
+                raise Unsupported("a category without options")
+            post = b.block(x.rows)
+            b.emit(OP_IMPLICATION, ins[0].att, x.att, b.arr(x.pq), x.rows, post)
+            temp = _VS(x.names, post, x.rows, np.zeros(x.rows, np.float32), x.pq)
+            lp_p = b.quantify(temp)
+            same = name == "all_same"
+            lp = b.alloc(Q * 4, "o" if same else "t")
+            b.emit(OP_SEGMENT_OR, lp_p, b.seg_off(bi), Q, lp)
+            if not same:
+                lp2 = b.alloc(Q * 4, "o")
+                b.emit(OP_LOGIC, LOGIC_NOT, lp, -1, Q, lp2)
+                lp = lp2
+            result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=x.prev_num + 1)
+        elif name in ("two_same", "two_different"):
+            _, (flat, bi) = b.category_options(args[0], ins[0].names)
+            # (the Python operators evaluate and normalise the same blocks twice; once is the same values)
+            x1 = b.filter(ins[0], flat, (i, 0), bi)
+            if x1 is ins[0]:
+                raise Unsupported("a category without options")
+            spec_norm, b.spec.normalize = b.spec.normalize, False          # already normalised in place by the first filter
+            try:
+                x2 = b.filter(ins[1], flat, (i, 0), bi)
+            finally:
+                b.spec.normalize = spec_norm
+            lp1, lp2 = b.quantify(x1), b.quantify(x2)
+            both = b.alloc(x1.rows * 4)
+            b.emit(OP_LOGIC, LOGIC_AND, lp1, lp2, x1.rows, both)
+            same = name == "two_same"
+            lp = b.alloc(Q * 4, "o" if same else "t")
+            b.emit(OP_SEGMENT_OR, both, b.seg_off(bi), Q, lp)
+            if not same:
+                lp2_ = b.alloc(Q * 4, "o")
+                b.emit(OP_LOGIC, LOGIC_NOT, lp, -1, Q, lp2_)
+                lp = lp2_
+            result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=x1.prev_num + x2.prev_num + 2)
+        elif name == "compare":
+            x1 = b.filter(ins[0], args[0], (i, 0))
+            x2 = b.filter(ins[1], args[0], (i, 0))
+            lp1, lp2 = b.quantify(x1), b.quantify(x2)
+            lp = b.alloc(Q * 2 * 4, "o")
+            b.emit(OP_COMPARE, lp1, lp2, b.arr(np.asarray([float(bool(v)) for v in args[1]], np.float32)), Q, lp)
+            result = dict(kind="compare", type=QuestionType.QUERY, lp=lp, count=2 * Q, options=list(zip(ins[0].names, ins[1].names)),
+                          num=x1.prev_num + x2.prev_num + 2)
+        else:
+            raise Unsupported("operator %r" % name)
+        if result is not None:
+            break
+        if i == last:                  # a program that ends without a terminal operator: `end` reads the operator's own (un-gated) result
+            lp = b.quantify(x, region="o")                         # (batch_gqa_interpreter.py:75-76)
+            result = dict(kind="end", type=QuestionType.STATEMENT, lp=lp, count=x.rows, options=[], num=x.prev_num + 1, names=list(x.names))
+            break
+        if ins and mask is not None:
+            x = b.mask_gate(x, ins[0], mask, valid)
+        trace.append(x)
+    if result is None:
+        raise Unsupported("a program without a result")
+    return b, result
+
+
+def _choose_rel(b, i, prev, args):
+    """GQAChooseRelBatch.forward (gqa_ops.py; batch_gqa_ops.py:246-267): the generic two-posterior cell over the flattened option list."""
+    Q = b.Q
+    lists = args[0]
+    flat, bi = flatten_list(lists)
+    x = b.select(args[2] if len(args) > 2 else None, (i, 0))
+    host = [0.0 if f is None else float(f) for f in args[1]]
+    subject_set = b.gate(x, prev, host)
+    object_set = b.gate(prev, x, host)
+    hit = b.tiles.get(i)
+    if hit is None or prev.pq is not None or prev.rows != Q:
+        raise Unsupported("choose_rel without prefetched tiles")
+    tiles, low = hit
+    if not low.all_valid:
+        raise Unsupported("a no-op token inside an option list")
+    P = len(flat)
+    pq = np.asarray(bi, np.int32)
+    q_s, q_o = subject_set.quant[pq], object_set.quant[pq]
+    pred_host = [host[q] for q in bi]
+    want = np.asarray([WANT_SUBJECT if f > 0 else WANT_OBJECT for f in pred_host], np.uint8)
+    b._normalize(tiles, low, pq, 2, True)
+    ps, po = b.block(P), b.block(P)
+    flags = (RELATE_LONE_FORALL_IDENTITY if P == 1 else 0) | RELATE_DIAG_ABSENT
+    b.emit(OP_RELATE, subject_set.att, object_set.att, tiles, b.arr(pq), b.arr(q_s), b.arr(q_o), b.arr(low.neg) if low.any_neg else -1, -1, b.arr(want), P,
+           TILE_SUBJECT_ROWS, flags, ps, po)
+    n_prev = subject_set.prev_num + object_set.prev_num + 1
+    s_set = _VS(subject_set.names, ps, P, q_s, pq, n_prev)
+    o_set = _VS(object_set.names, po, P, q_s, pq, n_prev)
+    xx = b.gate(s_set, o_set, pred_host)
+    lp = b.quantify(xx, region="o")
+    fl = b.find_max(lp, bi, P)
+    return dict(kind="choose", type=QuestionType.QUERY, lp=lp, count=P, flags=fl, flat=flat, batch_index=bi, options=lists, num=xx.prev_num + 1)
+
+
+def build_plan(program_batch, ontology, spec):
+    """-> NativePlan, or None when the batch has a shape the executor does not take."""
+    try:
+        b, result = _lower(program_batch, ontology, spec)
+    except Unsupported:
+        return None
+    plan = NativePlan()
+    out_bytes = b._size["o"]
+    base = {"o": 0, "t": out_bytes}
+
+    def resolve(v):
+        return base[v.region] + v.off if isinstance(v, _W) else int(v)
+
+    plan.instrs = np.asarray([[resolve(v) for v in row] for row in b.instrs], np.int64).reshape(-1, INSTR_WIDTH)
+    plan.blob = np.concatenate(b._blob_parts) if b._blob_parts else np.zeros(16, np.uint8)
+    plan.out_bytes = out_bytes
+    plan.ws_bytes = out_bytes + b._size["t"]
+    plan.scene = dict(O=b.O, Q=b.Q, NS=b.NS, max_n=b.max_n, n_obj=b.b_n_obj, img_n_obj=b.b_n_obj, obj_off=b.b_obj_off)
+    for k in ("lp", "flags"):
+        if k in result:
+            result[k] = resolve(result[k])
+    plan.result = result
+    plan.key = spec.key()
+    plan.launches = len(b.instrs)
+    return plan
+
+
+# ---- answers from the read-back (the host halves of the terminal operators, gqa_ops.py) ----------------------------------------------------
+def decode(plan, out_host, give_answer=True):
+    """out_host: uint8 numpy view of the first plan.out_bytes of the workspace -> (answer, answer_log_probability)."""
+    r = plan.result
+    if not give_answer:
+        return [], []
+    lp = out_host[r["lp"]:r["lp"] + 4 * r["count"]].view(np.float32)
+    kind = r["kind"]
+    if kind == "binary":                                           # gqa_ops._binary_answer (e.g. batch_gqa_ops.py:404-407)
+        probability = np.exp(lp.astype(np.float32)).tolist()
+        answer = [['yes'] if p > 0.5 else ['no'] for p in probability]
+        alp = [[math.log(p)] if p > 0.5 else [math.log(1 - p)] for p in probability]
+        return answer, alp
+    if kind == "end":                                              # batch_gqa_ops.py:768-783
+        return [[n] for n in r["names"]], []
+    if kind == "choose":                                           # gqa_ops._choose_answer (util.py:59-66)
+        flags = out_host[r["flags"]:r["flags"] + r["count"]].tolist()
+        return unflatten_list(r["flat"], r["batch_index"], flags), unflatten_list(lp.tolist(), r["batch_index"], flags)
+    if kind == "compare":                                          # batch_gqa_ops.py:730-758
+        v = lp.reshape(-1, 2)
+        ind = v.argmax(1)
+        opts = r["options"]
+        return [[opts[i][ind[i]]] for i in range(len(opts))], [[float(v[i, ind[i]])] for i in range(len(opts))]
+    raise ValueError(kind)

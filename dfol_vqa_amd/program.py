@@ -172,6 +172,34 @@ class OperatorBatch(object):
         return res
 
 
+class _LazyOps(list):
+    """The operator batches of a ProgramBatch moved to the device on FIRST ACCESS (ProgramBatch.to_cuda of a batch that carries a native plan):
+    an empty list until then, `host` the operator batches as collated."""
+
+    def __init__(self, host_ops, device, non_blocking):
+        super(_LazyOps, self).__init__()
+        self.host, self._device, self._non_blocking, self._moved = host_ops, device, non_blocking, False
+
+    def _move(self):
+        if not self._moved:
+            self._moved = True
+            super(_LazyOps, self).extend(ob.to_cuda(self._device, self._non_blocking) for ob in self.host)
+
+    def __len__(self):
+        return len(self.host)
+
+    def __getitem__(self, i):
+        self._move()
+        return super(_LazyOps, self).__getitem__(i)
+
+    def __iter__(self):
+        self._move()
+        return super(_LazyOps, self).__iter__()
+
+    def __reduce__(self):                                   # (pickled as the plain host list)
+        return (list, (list(self.host),))
+
+
 class ProgramBatch(object):
     """A batch of aligned programs plus its scenes (data_pipeline.py:147-290)."""
 
@@ -221,10 +249,28 @@ class ProgramBatch(object):
             if isinstance(obj, dict):
                 return {k: move(v) for k, v in obj.items()}
             return obj
+        plan = getattr(self, "_native_plan", None)
+        if plan is not None and not isinstance(self._op_batch_list, _LazyOps):
+            # Lowered for the native executor (native_plan.build_plan, at collate time): everything its launches read travels in the plan's
+            # ONE blob, so the ~18 per-operator uploads (masks, maps, flags, lowered token arrays) happen only if somebody asks for the
+            # operator batches after all - the Python operator loop (a trace, a training step, DFOL_NATIVE=0) - and then on first access.
+            ops = _LazyOps(self._op_batch_list, device, non_blocking)
+            pb = ProgramBatch.__new__(ProgramBatch)
+            pb.__dict__.update(self.__dict__)
+            pb._op_batch_list, pb._device = ops, device
+            pb._object_features, pb._object_batch_index, pb._meta_data = move(self._object_features), move(self._object_batch_index), move(self._meta_data)
+            return pb
         pb = ProgramBatch(device, [ob.to_cuda(device, non_blocking) for ob in self._op_batch_list], self._dependencies, self._answers,
                           move(self._object_features), move(self._object_batch_index), self._original_dicts, move(self._meta_data),
                           object_nums=self._object_nums, question_image=self._question_image)
+        if hasattr(self, "_native_plan"):                      # (None: lowered, and found to have a shape the executor does not take)
+            pb._native_plan = self._native_plan
         return pb
+
+    def terminal_op_name(self):
+        """Name of the last operator batch (the metrics' slot, trainer.py:477-485) - without uploading a lazily moved batch's operators."""
+        ops = self._op_batch_list
+        return (ops.host[-1] if isinstance(ops, _LazyOps) else ops[-1])._op_name
 
     def to(self, dtype):
         if dtype != torch.float32:
@@ -262,7 +308,7 @@ class ProgramCollaterBase(object):
     """Aligns ragged per-question programs into one canonical operator sequence (data_pipeline.py:626-783):
     per branch `starter, (filler*, separator)*`, then one terminal operator batch per terminal operator name."""
 
-    def __init__(self, starter_op, sep_op, filler_op, split_num=1, ontology=None, share_scenes=False):
+    def __init__(self, starter_op, sep_op, filler_op, split_num=1, ontology=None, share_scenes=False, native_spec=None):
         self._sep_op = sep_op
         self._filler_op = filler_op
         self._starter_op = starter_op
@@ -272,6 +318,9 @@ class ProgramCollaterBase(object):
         # interpreter, one featurizer pass and one set of relation tiles per (image, concept)).  The reference collates one copy per
         # question (batch_gqa_boxfeatures_pipeline.py:37-73); results are identical either way (tests/test_interpreter_gpu.py).
         self._share_scenes = share_scenes
+        # native_spec (native_exec.model_spec(model), needs `ontology`): every ProgramBatch is also lowered to the native executor's
+        # instruction table here - i.e. in the DataLoader worker - so the process that launches does no per-operator work at all
+        self._native_spec = native_spec
 
     def collate_programs(self, questions):
         B = len(questions)
@@ -365,5 +414,8 @@ class ProgramCollaterBase(object):
                 ob._op_id = str(i) + ':' + ob._op_id            # :775-777
             if self._ontology is not None:
                 pb.lower(self._ontology)
+                if self._native_spec is not None:
+                    from .native_plan import build_plan
+                    pb._native_plan = build_plan(pb, self._ontology, self._native_spec)
             result.append(pb)
         return result

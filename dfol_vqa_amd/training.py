@@ -229,11 +229,17 @@ def compute_evaluation_metrics(program_batch_list, prediction, first_answer=Fals
     return 1.0 - float(np.mean(np.array(match, dtype=np.float32)))
 
 
+def _terminal_name(pb):
+    """The last operator batch's name (without moving a lazily uploaded ProgramBatch's operators to the device)."""
+    name = getattr(pb, "terminal_op_name", None)
+    return name() if name is not None else pb._op_batch_list[-1]._op_name
+
+
 def accumulate_test_batch(error, total_example_num, data, prediction, first_answer=False):
     """trainer.py:477-485: overall error in slot 0, per-terminal-operator error in the operator's slot."""
     b = sum(d.batch_size() for d in data)
     err = b * compute_evaluation_metrics(data, prediction, first_answer)
-    slot = OP_INDEX[data[0]._op_batch_list[-1]._op_name]
+    slot = OP_INDEX[_terminal_name(data[0])]
     error[0] += err
     error[slot] += err
     total_example_num[0] += b
@@ -244,8 +250,8 @@ def accumulate_test_batch(error, total_example_num, data, prediction, first_answ
 def test_epoch(model, loader, device, first_answer=False):
     """The validation / test loop of VQATrainer._test_epoch (trainer.py:444-475): per-operator error rates over a stream of collated
     batches (lists of ProgramBatches on the host), one thread, software-pipelined - a batch's launches are enqueued with
-    `forward_async`, the NEXT batch is pulled from `loader` (its collate), given its sparse maps and uploaded while the device runs,
-    and only then are the first batch's answers read back and scored.  -> error / total_example_num, ERROR_DIM floats (slot 0 overall)."""
+    `forward_async`, the NEXT batch is pulled from `loader` (its collate), given its sparse maps, uploaded AND launched while the device
+    runs, and only then are the first batch's answers read back and scored (two batches in flight: the device never waits for the host).  -> error / total_example_num, ERROR_DIM floats (slot 0 overall)."""
     import numpy as np
     import torch
     error = np.zeros(ERROR_DIM, dtype=np.float32)
@@ -262,11 +268,12 @@ def test_epoch(model, loader, device, first_answer=False):
     with torch.no_grad():
         stream = prepared(iter(loader))
         data = next(stream, None)
+        pending = model.forward_async(data, False) if data is not None else None
         while data is not None:
-            pending = model.forward_async(data, False)
-            nxt = next(stream, None)                          # host work of the next batch under this batch's kernels
+            nxt = next(stream, None)                          # host work of the next batch under this batch's kernels ...
+            nxt_pending = model.forward_async(nxt, False) if nxt is not None else None     # ... and its launches queued behind them
             accumulate_test_batch(error, total, data, pending.result(), first_answer)
-            data = nxt
+            data, pending = nxt, nxt_pending
     with np.errstate(invalid="ignore", divide="ignore"):
         return error / total                                  # (NaN in the slot of an operator no batch ended with, as the reference's)
 
@@ -280,7 +287,7 @@ def collect_predictions(program_batch_list, prediction, is_submission=False):
         return [{'questionId': qid, 'prediction': p[0]} for qid, p in zip(question_ids, prediction['answer'])]
     query = prediction['type'] == QuestionType.QUERY
     answers = [p if query else p[0] for p in prediction['answer']]
-    types = ['open' if pb._op_batch_list[-1]._op_name == 'query_attr' else 'binary' for pb in program_batch_list for _ in range(pb.batch_size())]
+    types = ['open' if _terminal_name(pb) == 'query_attr' else 'binary' for pb in program_batch_list for _ in range(pb.batch_size())]
     if query:
         return [{'questionId': qid, 'prediction': a, 'type': t, 'options': opt} for qid, a, t, opt in zip(question_ids, answers, types, prediction['options'])]
     return [{'questionId': qid, 'prediction': a, 'type': t} for qid, a, t in zip(question_ids, answers, types)]

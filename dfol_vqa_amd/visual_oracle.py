@@ -937,13 +937,13 @@ class ClassifierOracle(OracleBase):
                     # (fused=False: the attentions carry gradients, every relate goes through the generic two-posterior cell,
                     # which reads subject-row tiles)
                     orient = np.asarray([L.TILE_OBJECT_ROWS if (f and fused) else L.TILE_SUBJECT_ROWS for f in ob._arguments[1]], np.uint8)
-                    entries.append((low, np.arange(Q), orient))
+                    entries.append((low, np.arange(Q), orient, toks))
             elif ob._op_name == "choose_rel":
                 flat, batch_index = flatten_list(ob._arguments[0])
                 low = lower_tokens(flat, self._ontology, TokenType.RELATION)
                 ob._arguments[0].flat_lowered = low    # GQAChooseRelBatch hands it to RelateBatch
                 if low.any_valid:
-                    entries.append((low, np.asarray(batch_index, np.int64), np.zeros(len(flat), np.uint8)))
+                    entries.append((low, np.asarray(batch_index, np.int64), np.zeros(len(flat), np.uint8), None))
         if not entries:
             return
         total = sum(len(e[0].cols) for e in entries)
@@ -959,7 +959,7 @@ class ClassifierOracle(OracleBase):
         plan = getattr(program_batch, "_dfol_rel_plan", None)
         if plan is None or plan[0] != key:
             rows_col, rows_tile, rows_orient, invalid, base = [], [], [], [], 0
-            for low, pq, orient in entries:
+            for low, pq, orient, _ in entries:
                 P = len(pq)
                 pq = np.asarray(pq, np.int64)
                 slot = np.zeros(P, np.int64)               # j-th predicate of its question, in predicate order
@@ -986,9 +986,9 @@ class ClassifierOracle(OracleBase):
             program_batch._dfol_rel_plan = plan
         _, req_col, req_tile, req_orient, invalid = plan
         base = 0
-        for low, pq, orient in entries:
+        for low, pq, orient, toks in entries:
             P = len(pq)
-            world._rel_tiles[id(low)] = (tiles[base:base + P], orient, fused)
+            self._remember_tiles(world, low, toks, (tiles[base:base + P], orient, fused))
             base += P
         self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
 
@@ -1031,8 +1031,8 @@ class ClassifierOracle(OracleBase):
         tiles = torch.full((U + 1, world._NS, world._NS), -30.0, dtype=dtype, device=dev)      # tile U: all absent (no-op tokens)
         if U:
             self._launch_pairs(world, req_col, req_tile, tiles, req_orient)
-        for (low, pq, orient), m in zip(entries, maps):
-            world._rel_tiles[id(low)] = (tiles.index_select(0, m), orient, fused)
+        for (low, pq, orient, toks), m in zip(entries, maps):
+            self._remember_tiles(world, low, toks, (tiles.index_select(0, m), orient, fused))
 
     def prefetch_attributes(self, world, program_batch):
         """One attribute-column launch for the simple attribute token lists of the program batch (select names, filter attributes,
@@ -1062,9 +1062,22 @@ class ClassifierOracle(OracleBase):
         ll = L.attr_ll(world._hidden_attr, emb.weight, emb.bias, world._obj_off, pred_img, cols, world._NS, -30.0)
         world._attr_blocks = {id(low): ll[i * Q:(i + 1) * Q] for i, low in enumerate(lows)}
 
-    def oriented_tiles(self, world, low):
+    @staticmethod
+    def _remember_tiles(world, low, toks, entry):
+        """Prefetched tiles are found again by the OPERATOR's own token list (two relate operators of a batch may name the same relations -
+        lowered token lists are memoised by content, so they then share one `low` - with different subject flags, i.e. other orientations:
+        keyed by `low` alone the first would read the second's tiles) and, for readers that only have the lowered list, by `low`."""
+        if toks is not None:
+            world._rel_tiles[("op", id(toks))] = entry
+        world._rel_tiles[id(low)] = entry
+
+    def oriented_tiles(self, world, low, tokens=None):
         """Prefetched tiles of a relate operator, each stored with its summed-out variable along rows (or None)."""
-        hit = world._rel_tiles.get(id(low)) if world._lazy is not None else None
+        if world._lazy is None:
+            return None
+        hit = world._rel_tiles.get(("op", id(tokens))) if tokens is not None else None
+        if hit is None:
+            hit = world._rel_tiles.get(id(low))
         return None if (hit is None or not hit[2]) else hit[0]
 
     def _relation_tiles_now(self, world, low, pred_q_host):

@@ -583,6 +583,91 @@ int dfol_attr_ll_bwd_f32(const float* g, const float* hidden, int64_t ld_hidden,
 int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, const int32_t* seg_off, int32_t S, const int32_t* pred_q,
                                   const int32_t* n_obj, int32_t NS, int32_t rank, float* g_x, void* stream);
 
+/* ---- the native executor of a lowered ProgramBatch (round 5) -------------------------------------------------------------------------
+ * Replaces the reference's per-operator Python dispatch for one ProgramBatch - BatchInterpreterBase.forward's build_scene call and execution
+ * loop, batch_base_interpreter.py:45-70 and :145-172, with BatchGQAInterpreter._execute, batch_gqa_interpreter.py:72-78, and the operator
+ * forwards of batch_gqa_ops.py it reaches (inference: is_training = False, no attention calibration) - by ONE call that enqueues every
+ * launch of the batch.  The host lowers the collated batch once (the reference already runs collate in DataLoader workers,
+ * data_pipeline.py:893-898) into
+ *   instr_host  [n_instr][DFOL_INSTR_WIDTH] int64 on the HOST: opcode + operands (byte offsets into `blob` / `workspace`, -1 = NULL; sizes)
+ *   blob        device copy of the batch's small side arrays (geometry, concept columns, negation / validity flags, predicate -> question
+ *               maps, segment offsets, quantifiers, gate flags, pair-kernel requests): one upload per batch
+ *   workspace   one device arena holding every intermediate and, at its start, the results the host reads back
+ * Each instruction is a call of one entry point of this header with pointers resolved from those offsets, so the results are bit for bit
+ * the Python operator loop's.  Nothing is allocated or synchronised; the call only enqueues on `stream`.
+ */
+#define DFOL_INSTR_WIDTH 16
+#define DFOL_DENSE_F32 0    /* dfol_linear_act_f32 on the raw weight */
+#define DFOL_DENSE_F16X2 1  /* dfol_linear_act_h2_f32 on the dfol_linear_pack_w_f16x2 image */
+#define DFOL_DENSE_BF16X3 2 /* dfol_linear_act_split_f32 on the dfol_linear_pack_w_bf16x3 image */
+#define DFOL_DENSE_BF16 3   /* dfol_linear_act_bf16_f32 on the dfol_linear_pack_w_bf16 image */
+#define DFOL_PAIR_PLAIN 0   /* dfol_pair_ll_f32 */
+#define DFOL_PAIR_PACKED 1  /* dfol_pair_ll_packed_f32 */
+#define DFOL_PAIR_BF16X3 2  /* dfol_pair_ll_split_f32 */
+#define DFOL_PAIR_F16X2 3   /* dfol_pair_ll_h2_f32 */
+
+typedef struct {            /* one nn.Linear + activation of gqa_interpreter_experiments.py:18-36 */
+    int32_t kind;           /* DFOL_DENSE_*: the arithmetic of weights >= 65536 elements; smaller ones always run dfol_linear_act_f32 */
+    int32_t act;            /* DFOL_ACT_* */
+    int32_t N, K;
+    const float* weight;    /* [N, ldw] fp32 */
+    int64_t ldw;
+    const void* packed;     /* the packed image for `kind` (NULL for DFOL_DENSE_F32) */
+    const float* bias;      /* [N] or NULL */
+} DfolDenseLayer;
+
+typedef struct {            /* the neural modules of build_neural_modules, gqa_interpreter_experiments.py:107-198 (device pointers) */
+    int32_t n_featurizer;   /* featurizer_network: raw features [:, :raw_cols - 6] -> [O, D - 4] (written into the object matrix) */
+    int32_t n_attribute;    /* attribute_network: object matrix [O, D] -> hidden [O, emb_in] */
+    const DfolDenseLayer* featurizer;
+    const DfolDenseLayer* attribute;
+    DfolDenseLayer uv;      /* the per-object halves of the relation network's first layer: [O, D] -> U | V [O, 2 hid1] */
+    int32_t pair_kind;      /* DFOL_PAIR_*: which fused pair kernel evaluates the relation tiles */
+    int32_t hid1, hid2, w2_rows;
+    const float* wg;        /* [hid1, 4] geometry columns of the first layer */
+    const void* w2;         /* second layer: raw padded [w2_rows, ld_w2] (PLAIN) or the kernel's packed image */
+    int64_t ld_w2;
+    const float* b2;
+    const float* emb_w;     /* embedding layer [C, ld_e], bias [C] or NULL (gqa_interpreter_experiments.py:60-77) */
+    int64_t ld_e;
+    const float* emb_b;
+    int32_t emb_in;         /* its input width (= hid2 = the attribute network's output width) */
+    int32_t D;              /* object matrix width = featurizer output + 4 box positions */
+} DfolProgramModel;
+
+typedef struct {            /* the scenes of one ProgramBatch (data_pipeline.py:149) */
+    const float* features;  /* [O, ld_features]: raw object features, the last 6 of raw_cols columns are (W, H, x, y, w, h) */
+    int64_t ld_features;
+    int32_t raw_cols, O;
+    int32_t NS, max_n;      /* padded block width (NS % 4 == 0) and the largest object count */
+    int64_t n_obj;          /* byte offsets into `blob`: objects per QUESTION [Q] ... */
+    int64_t img_n_obj;      /* ... per SCENE [scenes] (the same array unless questions share scenes) ... */
+    int64_t obj_off;        /* ... and the first object row of every scene [scenes + 1] (int32) */
+} DfolProgramScene;
+
+/* opcodes (operand lists in csrc/dfol_program.hip, written by dfol_vqa_amd/native_plan.py) */
+#define DFOL_OP_DENSE 0
+#define DFOL_OP_BOX_POSITIONS 1
+#define DFOL_OP_FILL 2
+#define DFOL_OP_PAIR_LL 3
+#define DFOL_OP_ATTR_LL 4
+#define DFOL_OP_OPTION_NORMALIZE 5
+#define DFOL_OP_FILTER 6
+#define DFOL_OP_RELATE_ONE 7
+#define DFOL_OP_RELATE 8
+#define DFOL_OP_QUANTIFY 9
+#define DFOL_OP_GATE 10
+#define DFOL_OP_LOGIC 11
+#define DFOL_OP_SEGMENT_SUM_ROWS 12
+#define DFOL_OP_SEGMENT_OR 13
+#define DFOL_OP_IMPLICATION 14
+#define DFOL_OP_COMPARE 15
+#define DFOL_OP_FIND_MAX_IND 16
+#define DFOL_OP_GATHER_TILES 17
+
+int dfol_run_program(const DfolProgramModel* model, const DfolProgramScene* scene, const int64_t* instr_host, int32_t n_instr,
+                     const void* blob, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

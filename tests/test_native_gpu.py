@@ -1,0 +1,200 @@
+"""The native executor (include/dfol_vqa.h: dfol_run_program; dfol_vqa_amd/native_plan.py + native_exec.py) against the Python operator loop
+it replaces (batch_base_interpreter.py:145-172 restated in interpreter.py): the same kernels with the same arguments, so every output is
+compared BIT FOR BIT - log-probabilities, answers, answer log-probabilities, options, type, variable_sets_num - and, through the golden
+tests of test_interpreter_gpu.py (which now run on the executor by default), against the reference itself."""
+
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu  # noqa: E402
+import dfol_vqa_amd as D  # noqa: E402
+from dfol_vqa_amd import _lib, native_exec, native_plan  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
+from oracle import dfol_oracle as orc  # noqa: E402
+from test_interpreter_gpu import DEV, TableCollater, neural_model  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ALL_KINDS = ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel", "two_same", "two_different", "all_same",
+             "all_different", "compare"]
+
+
+@pytest.fixture(scope="module")
+def full(tmp_path_factory):
+    from dfol_vqa_amd import experiment
+    d = str(tmp_path_factory.mktemp("native"))
+    paths, names = syn.write_synthetic_ontology(d)
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ont)
+    syn.load_seeded_weights(model, 23)
+    with open(paths["attribute_file"]) as f:
+        categories = json.load(f)
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    return model.to(DEV).eval(), ont, oont, names, categories
+
+
+def both_routes(model, ont, qs, split=1, monkeypatch=None, expect_native=True, collater=None):
+    """The same questions through the native executor and through the Python loop (DFOL_NATIVE=0)."""
+    out = []
+    for native in ("1", "0"):
+        monkeypatch.setenv("DFOL_NATIVE", native)
+        pbs = (collater or TableCollater(split, ont, "X")).collate([dict(q) for q in qs])
+        for pb in pbs:
+            pb.create_sparse_tensors()
+        pbs = [pb.to_cuda(DEV) for pb in pbs]
+        _lib.PATH_COUNTS.clear()
+        with torch.no_grad():
+            res = model(pbs, False)
+        taken = _lib.PATH_COUNTS.get("native_program", 0)
+        assert taken == (len(pbs) if (native == "1" and expect_native) else 0), (native, taken, len(pbs))
+        out.append(res)
+    return out
+
+
+def same_results(a, b, what=""):
+    assert torch.equal(a["log_probability"], b["log_probability"]), (what, (a["log_probability"] - b["log_probability"]).abs().max().item())
+    assert a["answer"] == b["answer"], what
+    assert a["answer_log_probability"] == b["answer_log_probability"], what
+    assert [list(o) if isinstance(o, (list, tuple)) else o for o in a["options"]] == [list(o) if isinstance(o, (list, tuple)) else o for o in b["options"]], what
+    assert int(a["type"]) == int(b["type"]) and a["variable_sets_num"] == b["variable_sets_num"] and a["cumulative_loss"] == b["cumulative_loss"], what
+
+
+@pytest.mark.parametrize("kind", ALL_KINDS)
+def test_native_equals_python_loop_full_size(full, kind, monkeypatch):
+    """Every terminal operator, ragged 20..64-object scenes, 1..3 filter / relate hops of differing lengths (masks, no-op tokens), `_`
+    names and negated tokens, two ProgramBatches: executor == Python loop, bit for bit."""
+    model, ont, oont, names, categories = full
+    seed = zlib.crc32(kind.encode()) % 1000 + 77
+    qs = syn.full_size_questions(kind, 10, 20, 64, names, categories, seed)
+    nat, py = both_routes(model, ont, qs, split=2, monkeypatch=monkeypatch)
+    same_results(nat, py, kind)
+
+
+def test_native_bench_workload(full, monkeypatch):
+    """BASELINE configs[1]'s program (select -> filter -> relate -> exist) at 36 objects and a uniform 100-object batch."""
+    model, ont, oont, names, categories = full
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    for n, count in ((36, 32), (100, 16)):
+        qs = []
+        for i in range(count):
+            br, last = syn.three_hop_program(i, nouns, attrs, rels, negate_prob=0.2)
+            qs.append(syn.question(i, br, last, "yes", syn.feature_scene(i, n, 2048)))
+        nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch)
+        same_results(nat, py, "three-hop n=%d" % n)
+
+
+def test_native_open_programs_and_implicit_end(full, monkeypatch):
+    """8-hop open programs (BASELINE configs[4]'s shape at small N) and a program without a terminal operator (the appended `end`)."""
+    model, ont, oont, names, categories = full
+    nouns, attrs, rels, cats = names["nouns"][:8], names["attributes"][:6], names["relations"][:5], sorted(categories)[:3]
+    qs = []
+    for i in range(6):
+        br, last = syn.open_program(i, nouns, attrs, rels, cats, hops=4)
+        qs.append(syn.question(500 + i, br, last, "x", syn.feature_scene(500 + i, 12 + i, 2048)))
+    nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch)
+    same_results(nat, py, "open")
+    # implicit `end`: a ProgramBatch whose last operator batch is a (ragged, masked) relate - the interpreter appends `end` to the operator's own
+    # un-gated result (batch_gqa_interpreter.py:75-76)
+    qs = [syn.question(600 + i, [[syn.op("select", nouns[i]), syn.op("filter", attrs[i])] + ([syn.op("relate", rels[0], True, nouns[2])] if i % 2 else [])],
+                       syn.op("exist"), "yes", syn.feature_scene(600 + i, 7 + i, 2048)) for i in range(4)]
+    out = []
+    for native in ("1", "0"):
+        monkeypatch.setenv("DFOL_NATIVE", native)
+        pb = TableCollater(1, ont, "X").collate([dict(q) for q in qs])[0]
+        pb2 = D.ProgramBatch(pb.device, pb._op_batch_list[:-1], pb._dependencies[:-1], pb._answers, pb._object_features, pb._object_batch_index,
+                             pb._original_dicts, pb._meta_data)
+        pb2.create_sparse_tensors()
+        _lib.PATH_COUNTS.clear()
+        with torch.no_grad():
+            out.append(model([pb2.to_cuda(DEV)], False))
+        assert _lib.PATH_COUNTS.get("native_program", 0) == (1 if native == "1" else 0)
+    same_results(out[0], out[1], "implicit end")
+    assert int(out[0]["type"]) == int(D.QuestionType.STATEMENT)
+
+
+def test_same_relation_with_both_orientations_in_one_batch(full, monkeypatch):
+    """Two relate operators naming the SAME relations with different subject flags (their lowered token lists are one memoised object):
+    each must read tiles of its own orientation.  Both routes against the oracle (round 5 fixed the Python route's tile lookup)."""
+    model, ont, oont, names, categories = full
+    nouns, rels = names["nouns"][:4], names["relations"][:3]
+    qs = [syn.question(700 + i, [[syn.op("select", nouns[i % 4]), syn.op("relate", rels[i % 3], True, nouns[(i + 1) % 4]),
+                                  syn.op("relate", rels[i % 3], False, nouns[(i + 2) % 4])]], syn.op("exist"), "yes", syn.feature_scene(700 + i, 9 + i, 2048))
+          for i in range(3)]
+    nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch)
+    same_results(nat, py, "orientations")
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    plain = [{k: v for k, v in q.items() if k != "scene"} for q in qs]
+    scenes = [q["scene"] for q in qs]
+    r32 = orc.run_questions(oont, plain, scenes, np.float32, weights=weights)
+    r64 = orc.run_questions(oont, plain, scenes, np.float64, weights=weights)
+    for res in (nat, py):
+        gu.check_logprob(res["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "orientations")
+
+
+def test_native_reduced_dims_models(monkeypatch, mini_ontology_paths):
+    """The g5 model (8-wide hidden layers: the fp32 dense kernel and the un-packed pair kernel) - the executor's other dispatch arms."""
+    p = mini_ontology_paths
+    ont = D.GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["word_embedding_file"], relation_json_path=p["relation_file"])
+    a, meta = gu.load("g5_neural_oracle")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ont, meta["config"], weights)
+    qs, scenes = gu.questions_and_scenes(a, meta, "X")
+    qq = [dict(q, scene=s) for q, s in zip(qs, scenes)]
+    nat, py = both_routes(model, ont, qq, monkeypatch=monkeypatch)
+    same_results(nat, py, "g5")
+    gu.check_logprob(nat["log_probability"].cpu().numpy(), a["lp_f32"], a["lp_f64"], "g5 native")
+
+
+def test_plan_built_at_collate_time_travels_through_pickle(full, monkeypatch):
+    """A collater that was given the model's spec lowers every ProgramBatch in the worker; the plan survives pickling (DataLoader workers)
+    and to_cuda, and the interpreter uses it as it is."""
+    import pickle
+    model, ont, oont, names, categories = full
+    spec = native_exec.model_spec(model)
+    assert spec is not None
+    qs = syn.full_size_questions("choose_attr", 8, 10, 30, names, categories, 5)
+    coll = D.ProgramCollaterBase.__new__(TableCollater)
+    TableCollater.__init__(coll, 2, ont, "X")
+    coll._native_spec = spec
+    pbs = pickle.loads(pickle.dumps(coll.collate([dict(q) for q in qs])))
+    assert all(isinstance(pb._native_plan, native_plan.NativePlan) for pb in pbs)
+    plans = [pb._native_plan for pb in pbs]
+    pbs = [pb.to_cuda(DEV) for pb in pbs]
+    assert [pb._native_plan for pb in pbs] == plans
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    _lib.PATH_COUNTS.clear()
+    with torch.no_grad():
+        res = model(pbs, False)
+        pend = model.forward_async(pbs, False)
+        res2 = pend.result()
+    assert _lib.PATH_COUNTS.get("native_program", 0) == 4
+    monkeypatch.setenv("DFOL_NATIVE", "0")
+    with torch.no_grad():
+        ref = model(pbs, False)
+    same_results(res, ref, "collate-time plan")
+    same_results(res2, ref, "collate-time plan, forward_async")
+
+
+def test_native_sees_new_weights(full, monkeypatch):
+    """The C view of the model is keyed on the parameters' versions: an in-place update is seen by the next forward."""
+    model, ont, oont, names, categories = full
+    qs = syn.full_size_questions("exist", 4, 10, 20, names, categories, 9)
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q) for q in qs])]
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    with torch.no_grad():
+        before = model(pbs, False)["log_probability"].clone()
+        lin = model._oracle._attribute_network._network[1]
+        saved = lin.weight.detach().clone()
+        lin.weight.mul_(0.5)
+        after = model(pbs, False)["log_probability"].clone()
+        monkeypatch.setenv("DFOL_NATIVE", "0")
+        ref = model(pbs, False)["log_probability"].clone()
+        lin.weight.copy_(saved)
+    assert not torch.equal(before, after) and torch.equal(after, ref)

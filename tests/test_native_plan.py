@@ -1,0 +1,135 @@
+"""Host logic of the native executor's lowering (dfol_vqa_amd/native_plan.py) - no GPU: every operator kind lowers, operands stay inside
+the blob / the workspace, plans pickle (collate workers), the shapes the executor does not take step aside, answers decode as the Python
+operators decode them.  The executor itself is compared with the Python loop on the GPU (tests/test_native_gpu.py)."""
+
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dfol_vqa_amd as D  # noqa: E402
+from dfol_vqa_amd import native_plan as NP  # noqa: E402
+from dfol_vqa_amd import synthetic as syn  # noqa: E402
+
+KINDS = ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel", "two_same", "two_different", "all_same",
+         "all_different", "compare"]
+W_OPERANDS = {NP.OP_DENSE: [6], NP.OP_BOX_POSITIONS: [1], NP.OP_FILL: [1], NP.OP_PAIR_LL: [1, 3, 9], NP.OP_ATTR_LL: [1, 6], NP.OP_OPTION_NORMALIZE: [1],
+              NP.OP_FILTER: [1, 2, 7], NP.OP_RELATE_ONE: [1, 2, 3, 10], NP.OP_RELATE: [1, 2, 3, 13, 14], NP.OP_QUANTIFY: [1, 5], NP.OP_GATE: [1, 2, 7, 8],
+              NP.OP_LOGIC: [2, 5], NP.OP_SEGMENT_SUM_ROWS: [1, 5], NP.OP_SEGMENT_OR: [1, 4], NP.OP_IMPLICATION: [1, 2, 5], NP.OP_COMPARE: [1, 2, 5],
+              NP.OP_FIND_MAX_IND: [1, 5]}
+B_OPERANDS = {NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
+              NP.OP_RELATE: [4, 5, 6, 7, 8, 9], NP.OP_QUANTIFY: [2, 3], NP.OP_GATE: [3, 4, 5], NP.OP_SEGMENT_SUM_ROWS: [2], NP.OP_SEGMENT_OR: [2],
+              NP.OP_IMPLICATION: [3], NP.OP_COMPARE: [3], NP.OP_FIND_MAX_IND: [2]}
+
+
+class FeatureCollater(D.ProgramCollaterBase):
+    def __init__(self, split, ontology, spec=None):
+        super(FeatureCollater, self).__init__("select", "relate", "filter", split, ontology=ontology, native_spec=spec)
+
+    def collate_object_features(self, questions):
+        feats = torch.cat([torch.as_tensor(q["scene"]["X"]) for q in questions], 0)
+        bi = torch.cat([torch.full((q["scene"]["n"],), i, dtype=torch.int64) for i, q in enumerate(questions)])
+        return feats, bi
+
+    def collate_meta_data(self, questions):
+        return {"index": {}, "embedding": torch.zeros(1, 1)}
+
+
+@pytest.fixture(scope="module")
+def setup(tmp_path_factory):
+    from dfol_vqa_amd import experiment
+    paths, names = syn.write_synthetic_ontology(str(tmp_path_factory.mktemp("plan")))
+    ont = experiment.build_ontology(syn.reference_config(paths))
+    with open(paths["attribute_file"]) as f:
+        categories = json.load(f)
+    spec = NP.ModelSpec([512], [256, 300], 256, 516, True, 0.0, ont._relation_index)
+    return ont, names, categories, spec
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_every_operator_lowers_and_operands_stay_in_bounds(setup, kind):
+    ont, names, categories, spec = setup
+    qs = syn.full_size_questions(kind, 7, 5, 12, names, categories, 3 + KINDS.index(kind))
+    for q in qs:                                                  # small feature width: this test never touches the features
+        q["scene"]["X"] = q["scene"]["X"][:, -22:]
+    pbs = FeatureCollater(2, ont, spec).collate(qs)
+    assert len(pbs) == 2
+    for pb in pickle.loads(pickle.dumps(pbs)):
+        plan = pb._native_plan
+        assert isinstance(plan, NP.NativePlan), kind
+        assert plan.instrs.dtype == np.int64 and plan.instrs.shape[1] == NP.INSTR_WIDTH and plan.launches == plan.instrs.shape[0]
+        assert 0 < plan.out_bytes <= plan.ws_bytes and plan.key == spec.key()
+        for row in plan.instrs:
+            for k in W_OPERANDS.get(int(row[0]), []):
+                assert -1 <= row[k] < plan.ws_bytes, (kind, row)
+            for k in B_OPERANDS.get(int(row[0]), []):
+                assert -1 <= row[k] < plan.blob.nbytes and (row[k] < 0 or row[k] % 16 == 0), (kind, row)
+        r = plan.result
+        assert r["lp"] + 4 * r["count"] <= plan.out_bytes
+        Q = len(pb._answers)
+        assert r["count"] == {"binary": Q, "end": Q, "compare": 2 * Q}.get(r["kind"], r["count"])
+        if kind != "compare":                                     # (compare answers as a QUERY although the batch type list does not name it)
+            assert int(r["type"]) == int(pb._question_type)
+        ops = [int(x) for x in plan.instrs[:, 0]]
+        assert ops[:2] == [NP.OP_DENSE, NP.OP_BOX_POSITIONS] and ops.count(NP.OP_ATTR_LL) <= 1 and ops.count(NP.OP_PAIR_LL) <= 1
+        # the scene header's arrays are the batch's geometry
+        n = np.asarray(pb._object_nums, np.int32)
+        assert np.array_equal(plan.blob[plan.scene["n_obj"]:plan.scene["n_obj"] + 4 * Q].view(np.int32), n)
+        assert np.array_equal(plan.blob[plan.scene["obj_off"]:plan.scene["obj_off"] + 4 * (Q + 1)].view(np.int32), np.concatenate([[0], np.cumsum(n)]))
+
+
+def test_shapes_the_executor_does_not_take_step_aside(setup):
+    ont, names, categories, spec = setup
+    qs = syn.full_size_questions("choose_rel", 4, 5, 9, names, categories, 11)
+    for q in qs:
+        q["scene"]["X"] = q["scene"]["X"][:, -22:]
+    qs[0]["program"]["last_op"]["arguments"][0][1] = "_"          # a no-op token inside an option list: index juggling the executor leaves to Python
+    assert FeatureCollater(1, ont, spec).collate(qs)[0]._native_plan is None
+    shared = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ont, share_scenes=True, native_spec=spec)
+    shared.collate_object_features = FeatureCollater(1, ont).collate_object_features
+    shared.collate_meta_data = FeatureCollater(1, ont).collate_meta_data
+    qs2 = syn.full_size_questions("exist", 4, 5, 9, names, categories, 12)
+    for q in qs2:
+        q["scene"]["X"] = q["scene"]["X"][:, -22:]
+    assert shared.collate(qs2)[0]._native_plan is None             # shared scenes: the Python loop
+
+
+def test_decode_matches_the_python_operators(setup):
+    plan = NP.NativePlan()
+    out = np.zeros(64, np.uint8)
+    lp = np.log(np.asarray([0.9, 0.2, 0.5000001, 0.4], np.float32))
+    out[:16] = lp.view(np.uint8)
+    plan.result = dict(kind="binary", lp=0, count=4)
+    ans, alp = NP.decode(plan, out)
+    assert ans == [["yes"], ["no"], ["yes"], ["no"]]
+    p = np.exp(lp).tolist()
+    assert alp == [[np.log(p[0])], [np.log(1 - p[1])], [np.log(p[2])], [np.log(1 - p[3])]]
+    out[16:20] = np.asarray([1, 0, 0, 1], np.uint8)
+    plan.result = dict(kind="choose", lp=0, count=4, flags=16, flat=["a", "b", "c", "d"], batch_index=[0, 0, 1, 1], options=None)
+    ans, alp = NP.decode(plan, out)
+    assert ans == [["a"], ["d"]] and alp == [[float(lp[0])], [float(lp[3])]]
+    plan.result = dict(kind="compare", lp=0, count=4, options=[("x", "y"), ("u", "v")])
+    ans, alp = NP.decode(plan, out)
+    assert ans == [["x"], ["u"]] and alp == [[float(lp[0])], [float(lp[2])]]
+    plan.result = dict(kind="end", lp=0, count=2, names=["dog", "entity"])
+    assert NP.decode(plan, out) == ([["dog"], ["entity"]], [])
+    assert NP.decode(plan, out, give_answer=False) == ([], [])
+
+
+def test_lazy_operator_upload_keeps_the_host_view(setup):
+    """A ProgramBatch that carries a plan moves its operator batches to the device only when somebody reads them."""
+    from dfol_vqa_amd.program import _LazyOps
+    ont, names, categories, spec = setup
+    qs = syn.full_size_questions("exist", 3, 5, 9, names, categories, 13)
+    for q in qs:
+        q["scene"]["X"] = q["scene"]["X"][:, -22:]
+    pb = FeatureCollater(1, ont, spec).collate(qs)[0]
+    lazy = _LazyOps(pb._op_batch_list, "cpu", True)
+    assert len(lazy) == len(pb._op_batch_list) and list.__len__(lazy) == 0 and not lazy._moved
+    assert pickle.loads(pickle.dumps(lazy)) is not None and isinstance(pickle.loads(pickle.dumps(lazy)), list)
+    assert pb.terminal_op_name() == "exist"

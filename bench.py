@@ -253,11 +253,34 @@ def setup(args):
     return rank, world, device, td, share
 
 
+def host_threads():
+    """What the host side of a rank runs on (N Python hosts share one CPU: where data-parallel inference stops scaling first)."""
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except Exception:
+        aff = []
+    return {"OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"), "torch_num_threads": torch.get_num_threads(), "cpu_affinity_count": len(aff),
+            "cpu_affinity": "%d-%d" % (aff[0], aff[-1]) if aff and aff[-1] - aff[0] + 1 == len(aff) else ",".join(map(str, aff[:64])),
+            "host_cpus": os.cpu_count()}
+
+
+def per_rank_rates(td, world, rank, leg):
+    """Every rank's own rate of a fresh-programs / end-to-end leg (the whole-job value is the slowest rank's): [{rank, questions_per_s,
+    ms_per_batch, host_collate_ms_per_batch}]."""
+    mine = {"rank": rank, "questions_per_s": leg["questions_per_s"], "ms_per_batch": leg["ms_per_batch"],
+            "host_collate_ms_per_batch": leg.get("host_collate_ms_per_batch")}
+    if td is None:
+        return [mine]
+    parts = [None] * world
+    td.all_gather_object(parts, mine)
+    return parts
+
+
 def rank_report(td, share, device, rank, world, elapsed, steps):
     """Proof of what ran where, for the N > 1 lines: every rank's device (index, name, PCI bus id) and its own elapsed time, all-gathered."""
     prop = torch.cuda.get_device_properties(device)
     mine = {"rank": rank, "device_index": device.index, "name": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None),
-            "uuid": str(getattr(prop, "uuid", "")), "ms_per_step": elapsed / max(1, steps) * 1e3, "pid": os.getpid()}
+            "uuid": str(getattr(prop, "uuid", "")), "ms_per_step": elapsed / max(1, steps) * 1e3, "pid": os.getpid(), "host": host_threads()}
     if td is None:
         return {"ranks_seen": [mine], "distinct_devices": 1, "rank_ms_per_step_min": mine["ms_per_step"], "rank_ms_per_step_max": mine["ms_per_step"],
                 "backend": None}
@@ -402,6 +425,7 @@ def main(argv=None):
     if args.fresh_batches > 0 and args.workload in ("north_star", "c1"):
         # every rank runs its own stream of unseen batches (max over ranks of the elapsed time: the whole-job rate)
         fp = fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=args.fresh_batches)
+        fp["per_rank"] = per_rank_rates(td, world, rank, fp)
         if td is not None:
             t = torch.tensor([fp["ms_per_batch"]], device="cpu" if share else device, dtype=torch.float64)
             td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -412,6 +436,7 @@ def main(argv=None):
         out["fresh_programs"] = fp
         # `value_end_to_end`: new programs AND new features every batch - the reference's test() loop as it is (trainer.py:685-720)
         ee = fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=args.fresh_batches, stream_features=True)
+        ee["per_rank"] = per_rank_rates(td, world, rank, ee)
         if td is not None:
             t = torch.tensor([ee["ms_per_batch"]], device="cpu" if share else device, dtype=torch.float64)
             td.all_reduce(t, op=td.ReduceOp.MAX)

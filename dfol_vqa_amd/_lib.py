@@ -175,6 +175,7 @@ SIGNATURES = {
     "dfol_pair_ll_h2_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
                             _i32, _p, _p],
     "dfol_run_program": [_p, _p, _p, _i32, _p, _p, _p],
+    "dfol_set_range_status": [_p],
 }
 
 
@@ -198,6 +199,7 @@ def load():
     lib.dfol_linear_w_f16x2_bytes.restype = ctypes.c_int64
     lib.dfol_pair_wgrad_fused_workspace.restype = ctypes.c_int64
     lib.dfol_pair_wgrad_fused_sums_workspace.restype = ctypes.c_int64
+    lib.dfol_set_range_status.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -272,6 +274,70 @@ def call(name, *args):
 
 
 F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
+
+
+# ---- fp16 range status (include/dfol_vqa.h: dfol_set_range_status) -----------------------------------------------------------------------------
+RANGE_X_OVERFLOW, RANGE_PAIR_SATURATED = 1, 2
+_RANGE_WORDS = {}
+
+
+class RangeWatch(object):
+    """One forward's watch on the fp16-range status word of its device.  The default dense arithmetic ("f16x2") splits activations into two
+    UNSCALED fp16 pieces: an object feature beyond 65504 would come back as NaN log-probabilities, a pair activation beyond 6e4 silently
+    clamped.  The kernels flag both in a device word; `finish()` queues its copy behind the forward's launches (pinned, asynchronous - no
+    extra synchronisation) and returns the closure that, once the answers have been read back, raises DfolError naming the remedy."""
+
+    def __init__(self, device):
+        dev = torch.device(device)
+        key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+        word = _RANGE_WORDS.get(key)
+        if word is None:
+            word = _RANGE_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.word, self.device = word, dev
+        load().dfol_set_range_status(word.data_ptr())           # (thread-local in the library: the launches of THIS thread carry it)
+
+    def finish(self):
+        # (a graph capture must not allocate pinned memory: its owner - GraphedForward / GraphedTrainStep - hands one in before it starts)
+        host = CAPTURE_RANGE_HOST if (capturing() and CAPTURE_RANGE_HOST is not None) else _range_host()
+        if _KEEP is not None:
+            _KEEP.append(host)
+        host.copy_(self.word, non_blocking=True)
+        word, dev = self.word, self.device
+
+        def check(sync=True):
+            """sync=False: look at what has arrived so far (a replayed train step checks the step BEFORE it: no host wait per step)."""
+            if sync:
+                torch.cuda.current_stream(dev).synchronize()
+            v = int(host[0])
+            if v:
+                word.zero_()
+                what = []
+                if v & RANGE_X_OVERFLOW:
+                    what.append("an input of a dense layer (object features, or a hidden activation) is beyond fp16's largest finite value 65504 or NaN")
+                if v & RANGE_PAIR_SATURATED:
+                    what.append("a first-layer activation of the relation network exceeded 6e4")
+                raise DfolError("fp16 range exceeded in the two-piece fp16 arithmetic (dense math 'f16x2', the default): %s. The results of this "
+                                "forward are not valid. Use `mlp_math: bf16x3` (config key; three bf16 pieces, fp32's exponent range) or "
+                                "DFOL_DENSE_MATH=bf16x3 / DFOL_PAIR_MATH=bf16x3, or normalise the features." % "; ".join(what))
+        return check
+
+
+_RANGE_HOSTS = []
+CAPTURE_RANGE_HOST = None
+CAPTURE_RANGE_CHECKS = []            # checks of forwards that ran INSIDE a capture without a deferred queue: the graph's owner runs them after replays
+
+
+def new_range_host():
+    return torch.empty(1, dtype=torch.int32).pin_memory()
+
+
+def _range_host():
+    """A pinned int32 for one forward's copy of the status word (a small ring: forwards in flight at once - forward_async - keep their own)."""
+    if len(_RANGE_HOSTS) < 16:
+        _RANGE_HOSTS.append(torch.empty(1, dtype=torch.int32).pin_memory())
+        return _RANGE_HOSTS[-1]
+    _RANGE_HOSTS.append(_RANGE_HOSTS.pop(0))
+    return _RANGE_HOSTS[-1]
 
 
 # ---- keep-alive registry for captured graphs ---------------------------------------------------------------------------------
@@ -776,7 +842,8 @@ def pair_ll_h2(uv, hid1, pos, wg, w2_h2, b2, hid2, emb_w, emb_b, n_obj, obj_off,
 def pair_math():
     """Arithmetic of the fused pair kernel's second layer: "f16x2" (default: two fp16 pieces, three products), "bf16x3" (round 3's: three
     bf16 pieces, six products) or "f32" (the fp32 matrix pipe) - all with fp32 results; DFOL_PAIR_MATH selects for A/B runs."""
-    m = os.environ.get("DFOL_PAIR_MATH", "f16x2")
+    # (`mlp_math: bf16x3` / dense_math("bf16x3") - the remedy for activations beyond fp16's range - moves the pair kernel along with the dense layers)
+    m = os.environ.get("DFOL_PAIR_MATH") or ("bf16x3" if _dense_math() == "bf16x3" else "f16x2")
     if m not in ("f16x2", "bf16x3", "f32"):
         raise DfolError("DFOL_PAIR_MATH=%r (f16x2, bf16x3 or f32)" % m)
     return m

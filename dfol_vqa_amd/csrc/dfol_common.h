@@ -11,6 +11,7 @@
 #define DFOL_WAVE 64
 
 void dfol_set_error(const char* fmt, ...);
+uint32_t* dfol_range_status_ptr();      // the calling thread's status word for the fp16-range kernels (dfol_set_range_status), or NULL
 
 #define DFOL_REQUIRE(cond, ...)                 \
     do {                                        \

@@ -181,6 +181,9 @@ struct LsProducer {
     // sum_j Sigmoid(Y[r][j]) E[row_pred[r]][j] - the logit layer's forward (csrc/dfol_pair_train.hip, logit_fwd) without its pass over Y
     float* x_part;                  // [2 column blocks of N][ld_xp >= M]
     int64_t ld_xp;
+    // every mode: the caller's fp16-range status word (dfol_set_range_status) or NULL - the two-piece kernels OR DFOL_RANGE_X_OVERFLOW into it
+    // when an X element is beyond fp16's largest finite value (its high piece is inf and the products NaN)
+    uint32_t* status;
 };
 __device__ __forceinline__ float ls_dsigmoid(float x) {
     const float h = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
@@ -268,6 +271,7 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     constexpr int XD = DB ? LS_XRING : 2;                           // X register sets = steps of X in flight
     XR xa[XD][RH][2];                                               // [set][row half][k half]
     float4 ea[PROD ? RH : 1][2];                                    // PROD: the same pieces of the rows' embedding rows - L2 hits, ONE step ahead
+    float xmax = 0.f;                                               // NP = 2: the largest |x| this thread split (one v_max3 per two elements)
     auto load_x = [&](int ks, auto set_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
         const int k = ks * LS_BK + aq * 8;
@@ -331,6 +335,12 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                     As[at] = u32x4{ls_rne2(v0.x, v0.y), ls_rne2(v0.z, v0.w), ls_rne2(v1.x, v1.y), ls_rne2(v1.z, v1.w)};
                 } else if (NP == 2) {
                     u32x4 ph, pl;
+                    if constexpr (!PROD) {                      // (the produced operand is scaled into range by construction)
+                        xmax = fmaxf(fmaxf(xmax, fabsf(v0.x)), fabsf(v0.y));
+                        xmax = fmaxf(fmaxf(xmax, fabsf(v0.z)), fabsf(v0.w));
+                        xmax = fmaxf(fmaxf(xmax, fabsf(v1.x)), fabsf(v1.y));
+                        xmax = fmaxf(fmaxf(xmax, fabsf(v1.z)), fabsf(v1.w));
+                    }
                     ls_split8h(v0, v1, ph, pl);
                     As[at] = ph;
                     As[BM * 4 + at] = pl;
@@ -522,6 +532,9 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 
     // epilogue: lane holds column r16 and rows 4 kh + e of every 16 x 16 tile.  Interior tiles take the branch-free path.
     LTRACE(61);
+    if constexpr (NP == 2 && !PROD) {                               // an X element beyond fp16's range: say so (its products are NaN)
+        if (prod.status != nullptr && !(xmax <= 65504.0f)) atomicOr(prod.status, (uint32_t)DFOL_RANGE_X_OVERFLOW);
+    }
     // LOGIT: the rows of a block nearly always belong to ONE predicate (row_pred is non-decreasing: a predicate owns n (n - 1) consecutive
     // rows) - then every thread needs the same few embedding values for all its rows, requested here, ahead of the epilogue's arithmetic;
     // a block across a boundary looks its rows up one by one.
@@ -797,9 +810,11 @@ static int ls_launch_rows(const float* X, int64_t ldx, const void* W_split, cons
     const int nbm = dfol_cdiv(M, small ? 64 : LS_BM);
     DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_act_split: too many tiles");
     const int nblocks = nbm * nbn;
+    LsProducer plain = LsProducer();
+    plain.status = NP == 2 ? dfol_range_status_ptr() : nullptr;
 #define DFOL_LS_K(A, XVV, RTT)                                                                                                              \
     hipLaunchKernelGGL((linear_act_split_kernel<A, XVV, NP, RTT>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u32x4*)W_split, \
-                       bias, Y, ldy, M, N, K, ksteps, nbn, nblocks, LsProducer())
+                       bias, Y, ldy, M, N, K, ksteps, nbn, nblocks, plain)
 #define DFOL_LS(A)                                                                                                                          \
     if (x16) { if (small) DFOL_LS_K(A, 4, 2); else DFOL_LS_K(A, 4, 4); }                                                                    \
     else { if (small) DFOL_LS_K(A, 2, 2); else DFOL_LS_K(A, 2, 4); }
@@ -909,7 +924,7 @@ extern "C" int dfol_linear_logit_h2_f32(const float* X, int64_t ldx, const void*
     const int nbm = dfol_cdiv(M, small ? 64 : LS_BM);
     DFOL_REQUIRE((int64_t)nbm * nbn < ((int64_t)1 << 31), "linear_logit_h2: too many tiles");
     const int nblocks = nbm * nbn;
-    const LsProducer lg = {nullptr, row_pred, E, ld_e, nullptr, 0, x_part, ld_xp};
+    const LsProducer lg = {nullptr, row_pred, E, ld_e, nullptr, 0, x_part, ld_xp, dfol_range_status_ptr()};
     if (small)
         hipLaunchKernelGGL((linear_act_split_kernel<DFOL_ACT_NONE, 4, 2, 2, false, 2>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, X, ldx,
                            (const u32x4*)W_split, bias, Y, ldy, M, N, K, ksteps, nbn, nblocks, lg);

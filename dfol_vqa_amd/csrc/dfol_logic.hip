@@ -21,6 +21,13 @@ void dfol_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dfol_last_error(void) { return g_err; }
+
+static thread_local uint32_t* g_range_status = nullptr;
+uint32_t* dfol_range_status_ptr() { return g_range_status; }
+extern "C" int dfol_set_range_status(uint32_t* device_word) {
+    g_range_status = device_word;
+    return 0;
+}
 extern "C" int dfol_abi_version(void) { return DFOL_ABI_VERSION; }
 
 // =====================================================================================================

@@ -118,11 +118,14 @@ class GraphedForward(object):
             self._keep = []                                      # everything the caches handed to the captured launches (host_util.keeping)
             self._graph = torch.cuda.CUDAGraph()
             gqa_ops.DEFERRED.queue = self._queue
+            from . import _lib
+            _lib.CAPTURE_RANGE_HOST = self._range_host = _lib.new_range_host()     # (the replay copies the fp16-range status word into it)
             try:
                 with keeping(self._keep), torch.cuda.graph(self._graph):
                     self._lazy = model(program_batch_list, False)
             finally:
                 gqa_ops.DEFERRED.queue = None
+                _lib.CAPTURE_RANGE_HOST = None
 
     def __call__(self):
         self._graph.replay()
@@ -218,8 +221,16 @@ class BatchInterpreterBase(nn.Module):
             # the oracle MLPs - forward, and through the autograd functions' recorded mode their backward - on bf16-rounded operands with
             # fp32 accumulation (BASELINE configs[3]: "bf16 fwd / fp32 logic"); the logic kernels and everything small stay fp32
             from . import _lib
+            dev0 = program_batch_list[0].device if program_batch_list else None
+            watch = _lib.RangeWatch(dev0) if dev0 is not None and torch.device(dev0).type == "cuda" else None
             with _lib.dense_math(getattr(self, "_mlp_math", None)):
                 all_results, all_traces, device = self._run_batches(program_batch_list, is_training, modulator_switch, return_trace)
+            if watch is not None:
+                check = watch.finish()                           # (runs after the answers' read-backs: raises if a kernel left fp16's range)
+                if outer is None and _lib.capturing():
+                    _lib.CAPTURE_RANGE_CHECKS.append(check)      # a captured train step: its owner checks after replays
+                else:
+                    queue.append(check)
         finally:
             gqa_ops.DEFERRED.queue = outer
         if outer is None:

@@ -161,6 +161,9 @@ class GraphedTrainStep(object):
             self._quiesce()
         torch.cuda.empty_cache()                             # the warm-up's activations go back before the graph's private pool is sized
         self._keep = []
+        from . import _lib as _L
+        _L.CAPTURE_RANGE_HOST = self._range_host = _L.new_range_host()      # (pinned memory for the captured copy of the fp16-range status word)
+        _L.CAPTURE_RANGE_CHECKS[:] = []
         # (thread-local capture mode: the check for capture-unsafe calls is restricted to the capturing thread; a process group's watchdog
         # thread may query an event of an earlier collective at any time, which under the default "global" mode invalidates the capture)
         mode = {} if group is None else {"capture_error_mode": "thread_local"}
@@ -178,6 +181,8 @@ class GraphedTrainStep(object):
             self._graph_b = torch.cuda.CUDAGraph()
             with keeping(self._keep), torch.cuda.graph(self._graph_b, pool=self._graph.pool(), **mode):
                 self._back()
+        self._range_checks, _L.CAPTURE_RANGE_CHECKS[:] = list(_L.CAPTURE_RANGE_CHECKS), []
+        _L.CAPTURE_RANGE_HOST = None
 
     @staticmethod
     def _quiesce():
@@ -206,6 +211,8 @@ class GraphedTrainStep(object):
             self._bucket.allreduce(self._group)              # eager, between the two replays, on the replays' stream
             self._graph_b.replay()
         torch.autograd.graph.increment_version(self._params)   # the replay rewrote them: version-keyed weight caches must miss
+        for check in self._range_checks:                       # fp16 range flags of the replay BEFORE this one (no host wait per step)
+            check(sync=False)
         return self.loss, self.result
 
 

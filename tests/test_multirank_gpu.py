@@ -82,6 +82,13 @@ def test_bench_launches_its_own_ranks(mode):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
     assert out["ranks"]["backend"] == "gloo" and [r["rank"] for r in out["ranks"]["ranks_seen"]] == [0, 1]
     assert out["ranks"]["rank_ms_per_step_min"] > 0
+    # every rank reports the threads / cores its Python host runs on, and (inference) its own rate over unseen batches
+    assert all("OMP_NUM_THREADS" in r["host"] and r["host"]["cpu_affinity_count"] >= 1 for r in out["ranks"]["ranks_seen"])
+    if mode == "infer":
+        for leg in ("fresh_programs", "end_to_end"):
+            per = out[leg]["per_rank"]
+            assert [p["rank"] for p in per] == [0, 1] and all(p["questions_per_s"] > 0 for p in per), (leg, per)
+        assert out["value_fresh_programs"] > 0 and out["value_end_to_end"] > 0
     if mode == "train":
         assert out["replicas_equal"] is True
         assert out["allreduce_ms"] > 0

@@ -198,3 +198,32 @@ def test_native_sees_new_weights(full, monkeypatch):
         ref = model(pbs, False)["log_probability"].clone()
         lin.weight.copy_(saved)
     assert not torch.equal(before, after) and torch.equal(after, ref)
+
+
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_fp16_range_overflow_raises_instead_of_nan(full, native, monkeypatch):
+    """An object feature of 1e5 does not fit the two UNSCALED fp16 pieces of the default dense arithmetic: the reference accepts any fp32
+    feature (batch_gqa_boxfeatures_pipeline.py:199-213), so the forward raises - on the executor and on the Python loop, from forward() and
+    from forward_async().result() - instead of answering with NaN; the next clean batch runs normally (the flag is cleared), and
+    `mlp_math: bf16x3` (fp32's exponent range) takes the same features without complaint."""
+    model, ont, oont, names, categories = full
+    monkeypatch.setenv("DFOL_NATIVE", native)
+    qs = syn.full_size_questions("exist", 4, 10, 20, names, categories, 21)
+    good = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q) for q in qs])]
+    bad_qs = [dict(q, scene=dict(q["scene"], X=q["scene"]["X"].copy())) for q in qs]
+    bad_qs[1]["scene"]["X"][3, 100] = 1.0e5
+    bad = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate(bad_qs)]
+    with torch.no_grad():
+        ref = model(good, False)["log_probability"].clone()
+        with pytest.raises(_lib.DfolError, match="bf16x3"):
+            model(bad, False)
+        with pytest.raises(_lib.DfolError, match="fp16 range"):
+            model.forward_async(bad, False).result()
+        again = model(good, False)["log_probability"]
+        assert torch.equal(ref, again)                           # the flag was cleared; a clean batch is a clean batch
+        model._mlp_math = "bf16x3"
+        try:
+            lp = model(bad, False)["log_probability"]
+        finally:
+            model._mlp_math = None
+        assert bool(torch.isfinite(lp).all())

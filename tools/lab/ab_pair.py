@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Times the fused pair kernel inside the north-star step (256 questions x N objects, one relation column per image) for several library
 builds and arithmetic modes, interleaved, each in a fresh process.
-usage: python tools/lab/ab_pair.py spec ...    spec = [lib.so][@math]   ("" = the default library; math = f16x2 | bf16x3 | f32); env LAB_N (default 100)"""
+usage: python tools/lab/ab_pair.py spec ...    spec = [lib.so][@math[+form]]   ("" = the default library; math = f16x2 | bf16x3 | f32; form = pingpong:
+round 4's schedule of the f16x2 kernel); env LAB_N (default 100)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
@@ -30,11 +31,16 @@ res = {s: [] for s in specs}
 for rep in range(3):
     for s in specs:
         lib, _, math = s.partition("@")
-        env = {k: v for k, v in os.environ.items() if k not in ("DFOL_LIB", "DFOL_PAIR_MATH")}
+        form = None
+        if "+" in math:
+            math, _, form = math.partition("+")
+        env = {k: v for k, v in os.environ.items() if k not in ("DFOL_LIB", "DFOL_PAIR_MATH", "DFOL_PAIR_H2_FORM")}
         if lib:
             env["DFOL_LIB"] = lib
         if math:
             env["DFOL_PAIR_MATH"] = math
+        if form:
+            env["DFOL_PAIR_H2_FORM"] = form
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, cwd=ROOT)
         lines = [l for l in out.stdout.strip().splitlines() if l.startswith("ll_")]
         res[s].append(lines[-1] if lines else "ERR " + out.stderr[-300:])

@@ -30,7 +30,6 @@
 #include "dfol_common.h"
 
 #include <stdlib.h>
-#include <string.h>
 
 #include <type_traits>
 
@@ -466,369 +465,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     TRACE(60);
 }
 
-
-// ---- the INTERLEAVED form (round 5) --------------------------------------------------------------------------------------------------------
-// The ping-pong above runs a tick at the SUM of its halves: beside the other wavefront's MFMA chains a build's VALU instructions get one issue
-// slot per MFMA, and neither priorities nor another MFMA order change that inside the kernel (profiles/r05_pair_ab_order_prio.txt).  What the
-// hardware does overlap is a wavefront's VALU with ITS OWN MFMAs (tools/lab/interleave.hip, profiles/r05_interleave_lab.txt: two wavefronts
-// per SIMD, each issuing its 114 MFMAs of a chunk with the next chunk's build and its B-fragment reads in the gaps, reach 16.25 cycles per
-// MFMA per SIMD - the pipe's rate).  So here all eight wavefronts run the same stream: chunk c's MFMAs interleaved (sched_group_barrier)
-// with the build of chunk c + 1's A pieces; ONE barrier per chunk (the W2 chunk buffers' hand-over) instead of two; every wavefront requests
-// an eighth of the next W2 chunk right after that barrier and drains it - and its U / V rows of the chunk after - before the next one.
-// Same arithmetic in the same order per accumulator: results are bit for bit the ping-pong kernel's (tests/test_kernels_gpu.py).
-// the eight element pairs of a build are spread over the column tiles 4 .. NB16 - 1: pair J beside tile 4 + J (NB16 - 5) / 7
-__host__ __device__ constexpr int h2_pair_of_tile(int tile, int nb16) {
-    for (int j = 0; j < 8; ++j)
-        if (4 + (j * (nb16 - 5)) / 7 == tile) return j;
-    return -1;
-}
-
-// one column tile's issue pattern: every MFMA followed by its share of the V VALU / transcendental instructions placed in the same region
-template <int G, int M, int V>
-__device__ __forceinline__ void h2_tile_groups() {
-    if constexpr (G < M) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        constexpr int v = (V * (G + 1)) / M - (V * G) / M;
-        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x402, v, 0);                    // (VALU | TRANS: v_exp_f32 is its own class)
-        h2_tile_groups<G + 1, M, V>();
-    }
-}
-
-// MT slot tiles of 16 per wavefront, WAVES wavefronts per workgroup: 3 x 4 - ONE wavefront per SIMD with the whole 512-entry register file
-// (228 accumulators, both A-piece sets, two sets of U / V rows in flight) and 192 ordered pairs per workgroup.  (2 x 8, two wavefronts per
-// SIMD, was measured first: the two streams of a SIMD take turns on the matrix pipe at ~26 cycles per MFMA - the older wavefront at 28, the
-// younger at 52 - and a trip costs what the ping-pong's two ticks cost, profiles/r05_pair_i_trace.txt.)
-template <int NB16, bool TBF16, int MT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void pair_ll32i_kernel(
-    const float* UV, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
-    const float* __restrict__ Wg, const u32x4* __restrict__ W2h, const float* __restrict__ b2, int HID2,
-    const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
-    const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
-    const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
-    void* __restrict__ tiles_v, uint32_t* __restrict__ status) {
-    constexpr int ROWS = NB16 * 16, T = WAVES * 64, SLOTS = MT * 16 * WAVES;
-    constexpr int NP = MT * 4;                                                    // element pairs of a build: (slot tile, k-tile, half)
-    static_assert(NB16 > 16 && NB16 <= H2_TILES, "geometry");
-    __shared__ __attribute__((aligned(16))) u32x4 Bs[2 * H2_PIECES];
-    __shared__ __attribute__((aligned(16))) u32x4 WgA[(256 / H2_CH) * 2 * 64];
-    constexpr int STAGE_FLOATS = 8192;
-    __shared__ __attribute__((aligned(16))) float stage[STAGE_FLOATS];
-    __shared__ __attribute__((aligned(16))) u32x4 GeoB[WAVES * MT * 64];      // every lane's geometry B fragments (16 KB: eight registers less in the loop)
-    const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
-    const int n = n_obj[q], npairs = n * (n - 1);
-    if (tb * SLOTS >= npairs) return;
-    bool any = false;
-    for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
-    if (!any) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
-#ifdef DFOL_PAIR_TRACE
-    const int trace_blk = ((int)blockIdx.x - 3000) / 500;
-    const bool trace_on = blockIdx.x >= 3000 && (blockIdx.x - 3000) % 500 == 0 && trace_blk < 8;
-#endif
-    TRACE(0);
-    const int nchunk = HID1 / H2_CH, lastc = nchunk - 1;
-    constexpr int H2I_Z = NB16 - NP - 1;                                          // the tile beside which the first layer's sums are formed (tiles before it: MFMAs only)
-    static_assert(H2I_Z >= 1, "one pair of elements per column tile after the geometry tile");
-    constexpr int DMA_N = H2_PIECES / T;                                           // requests per thread and chunk (every wavefront an eighth)
-    const uint32_t dma_lane = (uint32_t)tid * 16u;
-    const uint32_t bs_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0]);
-    // One 1 KiB piece of a W2 chunk, global -> LDS.  Inside the loop the request is INLINE ASM: the compiler orders every later ds_read behind a
-    // global_load_lds it knows about with s_waitcnt vmcnt(0) (the DMA writes LDS, and it does not look at which array) - i.e. it would wait
-    // for the whole request, ~2 k cycles, in front of the next B fragment.  Nobody reads the target buffer before the barrier that follows
-    // this wavefront's own `s_waitcnt vmcnt(0)` at the end of the trip, so the ordering is ours to keep.
-    auto dma_piece = [&](int c, int buf, int i) __attribute__((always_inline)) {
-        // (scalar base + one loop-invariant 32-bit lane offset: per-piece 64-bit lane pointers were induction variables that spilled, and a
-        // scratch reload's vmcnt(0) waits for the pieces in flight)
-        const u32x4* src = W2h + (int64_t)c * H2_PIECES + T * i;
-        const uint32_t dst = bs_base + (uint32_t)(buf * H2_PIECES + T * i + wave * 64) * 16u;      // (scalar arithmetic on a scalar base)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src), "s"(dst) : "memory");
-    };
-    auto dma_chunk = [&](int c, int buf) __attribute__((always_inline)) {          // (the prologue's: the builtin, drained before the first barrier)
-#pragma unroll
-        for (int i = 0; i < DMA_N; ++i)
-            __builtin_amdgcn_global_load_lds(W2h + (int64_t)c * H2_PIECES + T * i + tid,
-                                             (__attribute__((address_space(3))) void*)&Bs[buf * H2_PIECES + T * i + wave * 64], 16, 0, 0);
-    };
-    dma_chunk(0, 0);
-    const float* cf = reinterpret_cast<const float*>(W2h + (int64_t)nchunk * H2_PIECES);
-    const int first = obj_off[q];
-    const char* img_uv = reinterpret_cast<const char*>(UV + (int64_t)first * ld_uv);
-    uint32_t uoff[MT], voff[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int e_slot = tb * SLOTS + wave * (MT * 16) + m * 16 + r16;
-        const bool valid = e_slot < npairs;
-        const int s = valid ? e_slot / (n - 1) : 0, oo_ = valid ? e_slot - s * (n - 1) : 0, o = oo_ + (oo_ >= s);
-        const float* ps = pos + (int64_t)(first + s) * ld_pos;
-        const float* po = pos + (int64_t)(first + o) * ld_pos;
-        const float x1 = ps[0], y1 = ps[1], w1 = ps[2], h1 = ps[3], x2 = po[0], y2 = po[1], w2 = po[2], h2 = po[3];
-        const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
-        const float dist = sqrtf(dx * dx + dy * dy);
-        uint32_t gh01, gl01, gh23, gl23;
-        h2_split2(dist, asinf(dy / fmaxf(dist, 1e-10f)), gh01, gl01);
-        h2_split2((x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f), (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f), gh23, gl23);
-        GeoB[(wave * MT + m) * 64 + lane] = kh == 0 ? u32x4{gh01, gh23, gl01, gl23} : (kh == 1 ? u32x4{gh01, gh23, 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
-        uoff[m] = (uint32_t)(s * (int)ld_uv + 4 * kh) * 4u;
-        voff[m] = (uint32_t)(o * (int)ld_uv + HID1 + 4 * kh) * 4u;
-    }
-    for (int i = tid; i < (HID1 / 16) * 64; i += T) {
-        const int kt = i >> 6, ln = i & 63, khh = ln >> 4;
-        u32x4 frag = {0u, 0u, 0u, 0u};
-        if (khh < 2) {
-            const float4 g = *reinterpret_cast<const float4*>(Wg + (kt * 16 + (ln & 15)) * 4);
-            uint32_t h01, l01, h23, l23;
-            h2_split2(g.x, g.y, h01, l01);
-            h2_split2(g.z, g.w, h23, l23);
-            frag = khh == 0 ? u32x4{h01, h23, h01, h23} : u32x4{l01, l23, 0u, 0u};
-        }
-        WgA[i] = frag;
-    }
-    constexpr int SR = STAGE_FLOATS / ROWS - 2;
-    for (int i = tid; i < ROWS; i += T) {
-        stage[i] = H2_NL2E * (i < HID2 ? b2[i] : -1.0e30f);
-        stage[ROWS + i] = i < HID2 ? cf[i] : 0.f;
-    }
-    const int Kc = K < SR ? K : SR;
-    for (int k = 0; k < Kc; ++k) {
-        const int col = req_col[(int64_t)k * Q + q];
-        for (int i = tid; i < ROWS; i += T) stage[ROWS * (2 + k) + i] = (col >= 0 && i < HID2) ? E[(int64_t)col * ld_e + i] : 0.f;
-    }
-
-    floatx4 acc[MT][NB16];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int i = 0; i < NB16; ++i) acc[m][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    // U[s] + V[o] of the lane's k of a chunk: requested, waited for and added at the END of the trip before the one that builds from them
-    // (sixteen registers across the interleaved region instead of thirty-two)
-    // the U / V rows of a chunk are requested ONE TRIP before the trip that builds from them (2 - 4 k cycles to land when every wavefront asks
-    // at once) into one of two register sets, and added beside the geometry tile
-    struct Rows {
-        floatx4 u[MT][2], v[MT][2];
-    };
-    Rows rowsA, rowsB;
-    floatx4 rsum[MT][2];
-    auto request_uv = [&](int c, Rows& r) __attribute__((always_inline)) {
-        const char* base = img_uv + (uint32_t)__builtin_amdgcn_readfirstlane(H2_CH * 4 * c);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                r.u[m][half] = *reinterpret_cast<const floatx4*>(base + uoff[m] + 64 * half);
-                r.v[m][half] = *reinterpret_cast<const floatx4*>(base + voff[m] + 64 * half);
-            }
-    };
-    auto sum_uv = [&](const Rows& r) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) rsum[m][half] = r.u[m][half] + r.v[m][half];
-    };
-    float zmax = 0.f;
-    // The build of a chunk's A pieces in two stages (the instructions of make_a in the ping-pong kernel): the first layer's sums out of the
-    // matrix pipe - geometry weights as A, the pair geometry as B, U + V as C - and, per pair of elements, the ELU with saturation and the
-    // fp16 split.  build_pair<J> handles elements (2 jp, 2 jp + 1) of k-tile t of slot tile m, J = 4 m + 2 t + jp.
-    floatx4 z[MT][2];
-    auto build_z = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f16x8 wa = __builtin_bit_cast(f16x8, WgA[(2 * c + t) * 64 + lane]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                z[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, __builtin_bit_cast(f16x8, GeoB[(wave * MT + m) * 64 + lane]), rsum[m][t], 0, 0, 0);
-        }
-    };
-    auto build_pair = [&](auto j_tag, u32x4 (&ap)[MT][2]) __attribute__((always_inline)) {
-        constexpr int J = decltype(j_tag)::value, m = J >> 2, t = (J >> 1) & 1, jp = J & 1;
-        static_assert(J < NP, "pair index");
-        const float z0 = z[m][t][2 * jp], z1 = z[m][t][2 * jp + 1];
-        zmax = fmaxf(fmaxf(zmax, z0), z1);
-        const float a0 = __builtin_amdgcn_fmed3f(z0, h2_expm1_neg(z0), H2_AMAX);
-        const float a1 = __builtin_amdgcn_fmed3f(z1, h2_expm1_neg(z1), H2_AMAX);
-        // (the residual in plain arithmetic - exact either way - because an inline-asm v_fma_mix belongs to no scheduling class: the group
-        // barriers could not place it, nor anything behind it)
-        const f16x2 hv = __builtin_convertvector((f32x2){a0, a1}, f16x2);
-        const f32x2 rr = (f32x2){a0, a1} - __builtin_convertvector(hv, f32x2);
-        ap[m][0][2 * t + jp] = __builtin_bit_cast(uint32_t, hv);
-        ap[m][1][2 * t + jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, f16x2));
-    };
-    auto make_a = [&](int c, u32x4 (&ap)[MT][2]) __attribute__((always_inline)) {      // the whole build at once (chunk 0)
-        build_z(c);
-        build_pair(std::integral_constant<int, 0>(), ap), build_pair(std::integral_constant<int, 1>(), ap);
-        build_pair(std::integral_constant<int, 2>(), ap), build_pair(std::integral_constant<int, 3>(), ap);
-        build_pair(std::integral_constant<int, 4>(), ap), build_pair(std::integral_constant<int, 5>(), ap);
-        build_pair(std::integral_constant<int, 6>(), ap), build_pair(std::integral_constant<int, 7>(), ap);
-        if constexpr (NP > 8) {
-            build_pair(std::integral_constant<int, 8 % NP>(), ap), build_pair(std::integral_constant<int, 9 % NP>(), ap);
-            build_pair(std::integral_constant<int, 10 % NP>(), ap), build_pair(std::integral_constant<int, 11 % NP>(), ap);
-        }
-    };
-    const int boff = r16 * 4 + (kh ^ h2_swz(r16));
-    constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
-    f16x8 bq[3][2];                                                 // B fragments: two column tiles ahead of the MFMAs
-    int bbase = boff;
-    auto load_b = [&](int i, f16x8 (&b)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(f16x8, Bs[bbase + i * 64 + p * H2_ROWS * 4]);
-    };
-    // Column tile I of chunk c: its six MFMAs (the three products of an accumulator back to back, as ever) with ONE SLICE of the next chunk's
-    // requests and build in their gaps, as its own scheduling region: tile 0 this wavefront's five pieces of the W2 chunk c + 1 and the U / V rows
-    // of chunk c + 1 (2 - 4 k cycles to land when all eight wavefronts ask at once, profiles/r05_pair_i_trace.txt), tile NB16 - 10 their sums
-    // and the geometry MFMAs, the eight tiles after it one pair of elements each.
-    auto tile = [&](auto i_tag, int c, const u32x4 (&cur)[MT][2], u32x4 (&nxt)[MT][2], const Rows& rows, Rows& rows_next, auto build_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(i_tag)::value;
-        constexpr bool BUILD = decltype(build_tag)::value;
-        if constexpr (BUILD && I == 0) {
-            // this wavefront's pieces of the W2 chunk c + 1 and the U / V rows of chunk c + 2 (the compiler's wait for the rows - a vmcnt(0), one
-            // trip on - finds everything older long landed)
-#pragma unroll
-            for (int i = 0; i < DMA_N; ++i) dma_piece(c + 1, (c + 1) & 1, i);
-            if (c + 2 <= lastc) request_uv(c + 2, rows_next);
-        }
-        if constexpr (I == H2I_Z) TRACE(2 + 6 * c);
-        if constexpr (I == H2I_Z + 1) TRACE(3 + 6 * c);
-        if (I + 2 < NB16) load_b(I + 2, bq[(I + 2) % 3]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int x = 0; x < 3; ++x)
-                acc[m][I] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, cur[m][PA3[x]]), bq[I % 3][PB3[x]], acc[m][I], 0, 0, 0);
-        if constexpr (BUILD && I == H2I_Z) {
-            sum_uv(rows);
-            build_z(c + 1);
-            // (pure register arithmetic is sunk by the IR passes to the block that uses it - the next trip, behind the barrier, in front of that
-            // chunk's MFMAs; the empty asm statements pin the values to THIS tile)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(z[m][t]));
-        }
-        constexpr int J = (I > H2I_Z && I <= H2I_Z + NP) ? I - H2I_Z - 1 : -1;  // the pair built beside this tile
-        if constexpr (BUILD && J >= 0) {
-            constexpr int m = J >> 2, t = (J >> 1) & 1, jp = J & 1;
-            build_pair(std::integral_constant<int, J>(), nxt);
-            asm volatile("" : "+v"(nxt[m][0][2 * t + jp]), "+v"(nxt[m][1][2 * t + jp]), "+v"(zmax));
-            h2_tile_groups<0, MT * 3, 20>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto chunk = [&](int c, const u32x4 (&cur)[MT][2], u32x4 (&nxt)[MT][2], const Rows& rows, Rows& rows_next, auto build_tag) __attribute__((always_inline)) {
-        bbase = boff + (c & 1) * H2_PIECES;
-        load_b(0, bq[0]);
-        load_b(1, bq[1]);
-        __builtin_amdgcn_sched_barrier(0);
-#define DFOL_TILE(I) tile(std::integral_constant<int, I>(), c, cur, nxt, rows, rows_next, build_tag)
-        DFOL_TILE(0); DFOL_TILE(1); DFOL_TILE(2); DFOL_TILE(3); DFOL_TILE(4); DFOL_TILE(5); DFOL_TILE(6); DFOL_TILE(7); DFOL_TILE(8); DFOL_TILE(9);
-        DFOL_TILE(10); DFOL_TILE(11); DFOL_TILE(12); DFOL_TILE(13); DFOL_TILE(14); DFOL_TILE(15); DFOL_TILE(16);
-        if constexpr (NB16 > 17) DFOL_TILE(17);
-        if constexpr (NB16 > 18) DFOL_TILE(18);
-        if constexpr (NB16 > 19) DFOL_TILE(19);
-#undef DFOL_TILE
-    };
-
-    request_uv(0, rowsB);
-    if (nchunk > 1) request_uv(1, rowsA);
-    sum_uv(rowsB);                                          // (the adds wait for the rows of chunk 0: the compiler's counted vmcnt)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): this wavefront's share of chunk 0 (and the rows of chunk 1)
-    __syncthreads();                                        // WgA, GeoB, the staged epilogue rows and chunk 0 visible
-    u32x4 apA[MT][2], apB[MT][2];
-    make_a(0, apA);
-    // chunk c multiplies while chunk c + 1 is built; two chunks per trip of the loop so that the A pieces alternate between two register sets
-    auto trip = [&](int c, const u32x4 (&cur)[MT][2], u32x4 (&nxt)[MT][2], const Rows& rows, Rows& rows_next) __attribute__((always_inline)) {
-        // on entry: `cur` = A pieces of chunk c; chunk c visible in buffer c & 1; buffer (c + 1) & 1 free (everybody is past chunk c - 1)
-        __builtin_amdgcn_sched_barrier(0);
-        TRACE(1 + 6 * c);
-        chunk(c, cur, nxt, rows, rows_next, std::true_type());           // `rows`: of chunk c + 1 (landed); `rows_next`: for chunk c + 2
-        TRACE(4 + 6 * c);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's share of chunk c + 1 has landed
-        TRACE(5 + 6 * c);
-        __syncthreads();                                    // chunk c + 1 visible; nobody reads buffer c & 1 any more
-        TRACE(6 + 6 * c);
-    };
-    int c = 0;
-    for (; c + 1 < lastc; c += 2) {
-        trip(c, apA, apB, rowsA, rowsB);
-        trip(c + 1, apB, apA, rowsB, rowsA);
-    }
-    if (c < lastc) {                                        // (an even number of chunks: one more trip, then the last chunk on the other set)
-        trip(c, apA, apB, rowsA, rowsB);
-        __builtin_amdgcn_sched_barrier(0);
-        chunk(lastc, apB, apA, rowsB, rowsA, std::false_type());
-    } else {
-        __builtin_amdgcn_sched_barrier(0);
-        chunk(lastc, apA, apB, rowsA, rowsB, std::false_type());
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    TRACE(58);
-    if (status != nullptr && !(zmax <= H2_AMAX)) atomicOr(status, (uint32_t)DFOL_RANGE_PAIR_SATURATED);
-    // Epilogue: as the ping-pong kernel's
-    const int64_t tile_sz = (int64_t)NS * NS;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int i = 0; i < NB16; ++i) {
-            const float bv = stage[i * 16 + r16], cm = stage[ROWS + i * 16 + r16];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[m][i][e], cm, bv)));
-        }
-    for (int k = 0; k < K; ++k) {
-        const int col = req_col[(int64_t)k * Q + q];
-        if (col < 0) continue;
-        float vm[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
-            if (k < Kc) {
-                const float* erow = stage + ROWS * (2 + k) + r16;
-#pragma unroll
-                for (int i = 0; i < NB16; ++i) {
-                    const float ev = erow[i * 16];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[m][i][e], ev, part[e]);
-                }
-            } else {
-                const float* erow = E + (int64_t)col * ld_e;
-#pragma unroll
-                for (int i = 0; i < NB16; ++i) {
-                    const float ev = erow[min(i * 16 + r16, HID2 - 1)];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) part[e] = fmaf(acc[m][i][e], ev, part[e]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part[e] = dfol_group_sum<16>(part[e]);
-            vm[m] = r16 == 0 ? part[0] : (r16 == 1 ? part[1] : (r16 == 2 ? part[2] : part[3]));
-        }
-        // one store instruction for the wavefront's MT x 16 slots: the lanes r16 = 4 j .. 4 j + 3 take slot tile j's logits from the lanes r16 - 4 j
-        // (DPP row_shr: 4 j), so a kh group writes slots 4 kh + 0 .. 3 of every tile
-        const float shifted = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vm[1]), 0x114, 0xF, 0xF, false));
-        const float shifted2 = MT > 2 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vm[MT > 2 ? 2 : 0]), 0x118, 0xF, 0xF, false)) : 0.f;
-        if (r16 < 4 * MT) {
-            const int hi = r16 >> 2;
-            const float v = hi == 0 ? vm[0] : (hi == 1 ? shifted : shifted2);
-            const int ee = tb * SLOTS + wave * (MT * 16) + hi * 16 + 4 * kh + (r16 & 3);
-            if (ee < npairs) {
-                const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)(n - 1))), op = ee - ss * (n - 1), oo = op + (op >= ss);
-                const float x = v + (be ? be[col] : 0.f);
-                const float val = fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));
-                const int64_t at = (int64_t)req_tile[(int64_t)k * Q + q] * tile_sz +
-                                   ((req_orient && req_orient[(int64_t)k * Q + q]) ? (int64_t)oo * NS + ss : (int64_t)ss * NS + oo);
-                if (TBF16) {
-                    uint32_t u = __float_as_uint(val);
-                    u += 0x7fffu + ((u >> 16) & 1u);
-                    reinterpret_cast<uint16_t*>(tiles_v)[at] = (uint16_t)(u >> 16);
-                } else {
-                    reinterpret_cast<float*>(tiles_v)[at] = val;
-                }
-            }
-        }
-    }
-    TRACE(60);
-}
-
 }  // namespace
 
 #ifdef DFOL_PAIR_TRACE
@@ -868,19 +504,9 @@ extern "C" int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1,
     DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_h2: too many tiles");
     DFOL_REQUIRE((int64_t)max_n * ld_uv * 4 < ((int64_t)1 << 31), "pair_ll_h2: an image's U / V rows must span less than 2 GB");
     const dim3 grid((unsigned)Q * tpi);
-    const int tpi_i = dfol_cdiv((int64_t)max_n * (max_n - 1), 192);     // the interleaved form: 192 ordered pairs per workgroup
-    DFOL_REQUIRE((int64_t)Q * tpi_i < ((int64_t)1 << 31), "pair_ll_h2: too many tiles");
-    // DFOL_PAIR_H2_FORM=pingpong: round 4's two-halves schedule (A/B runs, and the bit-for-bit check of the interleaved form)
-    const char* form = getenv("DFOL_PAIR_H2_FORM");          // (read per launch: a test flips it inside one process)
-    const bool pingpong = form && !strcmp(form, "pingpong");
 #define DFOL_PAIR32H(NBV, BF)                                                                                                       \
-    if (pingpong)                                                                                                                   \
-        hipLaunchKernelGGL((pair_ll32h_kernel<NBV, BF>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
-                           E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v, dfol_range_status_ptr()); \
-    else                                                                                                                            \
-        hipLaunchKernelGGL((pair_ll32i_kernel<NBV, BF, 3, 4>), dim3((unsigned)Q * tpi_i), dim3(256), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg,        \
-                           (const u32x4*)W2_split, b2, HID2, E, ld_e, be, n_obj, obj_off, Q, tpi_i, req_col, req_tile, req_orient, K, NS, default_ll, \
-                           tiles_v, dfol_range_status_ptr())
+    hipLaunchKernelGGL((pair_ll32h_kernel<NBV, BF>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
+                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v, dfol_range_status_ptr())
     if (HID2 <= 272) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(17, true); else DFOL_PAIR32H(17, false); }
     else if (HID2 <= 288) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(18, true); else DFOL_PAIR32H(18, false); }
     else if (HID2 <= 304) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(19, true); else DFOL_PAIR32H(19, false); }

@@ -975,43 +975,3 @@ def test_act_bwd_equals_autograd_formulas(act, shape):
     assert (dz - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
     (auto,) = torch.autograd.grad(y, x, gy)
     assert (dz - auto).abs().max().item() <= 2e-6 * max(1.0, auto.abs().max().item())
-
-
-@pytest.mark.parametrize("n_list,hid1,hid2,K", [([9, 6, 12, 2, 1, 17], 256, 300, 2), ([100, 64], 256, 300, 1), ([23] * 5, 64, 272, 3), ([40, 33], 128, 320, 2),
-                                               ([30, 8], 32, 289, 1)])
-def test_pair_h2_interleaved_form_equals_the_pingpong_form_bit_for_bit(L, n_list, hid1, hid2, K, monkeypatch):
-    """Round 5's pair kernel (pair_ll32i_kernel: every wavefront interleaves chunk c's MFMAs with the build of chunk c + 1, one barrier per
-    chunk) against round 4's ping-pong of two halves (pair_ll32h_kernel, DFOL_PAIR_H2_FORM=pingpong): the same arithmetic in the same order
-    per accumulator - every tile BIT FOR BIT, over ragged images (one- and two-object images, partly filled last workgroups), one to eight
-    chunks, every column-tile count (17 .. 20), both orientations, fp32 and bf16 tiles; and against float64."""
-    from dfol_vqa_amd import _lib
-    rng = np.random.RandomState(sum(n_list) + hid1 + hid2)
-    Q, O, NS, C = len(n_list), sum(n_list), max(4, (max(n_list) + 7) // 8 * 8), 20
-    off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
-    uv = rng.uniform(-1, 1, (O, 2 * hid1)).astype(np.float32)
-    pos = rng.uniform(0.05, 0.9, (O, 4)).astype(np.float32)
-    wg = rng.uniform(-0.5, 0.5, (hid1, 4)).astype(np.float32)
-    w2 = np.zeros(((hid2 + 31) // 32 * 32, hid1), np.float32)
-    w2[:hid2] = rng.normal(size=(hid2, hid1)).astype(np.float32) / np.sqrt(hid1)
-    b2 = rng.normal(size=hid2).astype(np.float32)
-    E = (rng.normal(size=(C, hid2)) / np.sqrt(hid2)).astype(np.float32)
-    be = rng.normal(size=C).astype(np.float32)
-    req_col = rng.randint(-1, C, (K, Q)).astype(np.int32)
-    req_col[0, 0] = 3
-    req_tile = np.arange(K * Q, dtype=np.int32).reshape(K, Q)
-    orient = (rng.uniform(size=(K, Q)) < 0.5).astype(np.uint8)
-    args = (dev(uv), hid1, dev(pos), dev(wg))
-    tail = (dev(E), dev(be), dev(np.array(n_list, np.int32)), dev(off), max(n_list), dev(req_col), dev(req_tile), dev(orient))
-    packed = _lib.pair_pack_w2_h2(dev(w2), hid2)
-    out = {}
-    for dtype in (torch.float32, torch.bfloat16):
-        for form in ("pingpong", "interleaved"):
-            monkeypatch.setenv("DFOL_PAIR_H2_FORM", form)
-            t = torch.full((K * Q, NS, NS), -30.0, device="cuda", dtype=dtype)
-            out[(dtype, form)] = _lib.pair_ll_h2(*args, packed, dev(b2), hid2, *tail, t).clone()
-            torch.cuda.synchronize()
-        assert torch.equal(out[(dtype, "pingpong")], out[(dtype, "interleaved")]), dtype
-    ref = _pair_ref64(n_list, off, uv, pos, wg, w2, b2, E, be, req_col, req_tile, orient, hid1, hid2, K, NS)
-    got = out[(torch.float32, "interleaved")].cpu().numpy()
-    wanted = ref != -30.0
-    assert np.abs(got - ref)[wanted].max() <= 2e-5 and np.abs(got - ref)[wanted].mean() <= 1e-6 and np.all(got[~wanted] == -30.0)

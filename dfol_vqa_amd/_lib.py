@@ -277,14 +277,13 @@ F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
 
 
 # ---- fp16 range status (include/dfol_vqa.h: dfol_set_range_status) -----------------------------------------------------------------------------
-RANGE_X_OVERFLOW, RANGE_PAIR_SATURATED = 1, 2
+RANGE_X_OVERFLOW = 1
 _RANGE_WORDS = {}
 
 
 class RangeWatch(object):
     """One forward's watch on the fp16-range status word of its device.  The default dense arithmetic ("f16x2") splits activations into two
-    UNSCALED fp16 pieces: an object feature beyond 65504 would come back as NaN log-probabilities, a pair activation beyond 6e4 silently
-    clamped.  The kernels flag both in a device word; `finish()` queues its copy behind the forward's launches (pinned, asynchronous - no
+    UNSCALED fp16 pieces: an object feature beyond 65504 would come back as NaN log-probabilities.  The dense kernels flag that in a device word; `finish()` queues its copy behind the forward's launches (pinned, asynchronous - no
     extra synchronisation) and returns the closure that, once the answers have been read back, raises DfolError naming the remedy."""
 
     def __init__(self, device):
@@ -303,19 +302,26 @@ class RangeWatch(object):
             _KEEP.append(host)
         host.copy_(self.word, non_blocking=True)
         word, dev = self.word, self.device
+        # (an event behind the copy: waiting for the STREAM would also wait for whatever was queued after this forward - the next batch of a
+        # pipelined loop; a captured forward has no event of its own: its replay's owner waits for the stream)
+        done = None
+        if not capturing():
+            done = torch.cuda.Event()
+            done.record()
 
         def check(sync=True):
             """sync=False: look at what has arrived so far (a replayed train step checks the step BEFORE it: no host wait per step)."""
             if sync:
-                torch.cuda.current_stream(dev).synchronize()
+                if done is not None:
+                    done.synchronize()
+                else:
+                    torch.cuda.current_stream(dev).synchronize()
             v = int(host[0])
             if v:
                 word.zero_()
                 what = []
                 if v & RANGE_X_OVERFLOW:
                     what.append("an input of a dense layer (object features, or a hidden activation) is beyond fp16's largest finite value 65504 or NaN")
-                if v & RANGE_PAIR_SATURATED:
-                    what.append("a first-layer activation of the relation network exceeded 6e4")
                 raise DfolError("fp16 range exceeded in the two-piece fp16 arithmetic (dense math 'f16x2', the default): %s. The results of this "
                                 "forward are not valid. Use `mlp_math: bf16x3` (config key; three bf16 pieces, fp32's exponent range) or "
                                 "DFOL_DENSE_MATH=bf16x3 / DFOL_PAIR_MATH=bf16x3, or normalise the features." % "; ".join(what))

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
     const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
     const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
-    void* __restrict__ tiles_v, uint32_t* __restrict__ status) {
+    void* __restrict__ tiles_v) {
     constexpr int MT = 2, WAVES = 8;
     constexpr int ROWS = NB16 * 16, T = WAVES * 64, SLOTS = MT * 16 * WAVES;
     static_assert(NB16 > 16 && NB16 <= H2_TILES, "geometry");
@@ -272,7 +272,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
     };
     u32x4 ap[MT][2];                                                // [slot][piece h, l]
-    float zmax = 0.f;                                               // the largest first-layer sum the lane saw (the ELU saturates beyond H2_AMAX)
     // A pieces of chunk c.  The first layer's sums z = U[s] + V[o] + Wg geo(s, o) come out of the matrix pipe: per k-tile t (16 k) one MFMA
     // per slot tile with the geometry weights as A (rows = k), the pair geometry as B (columns = slots) and U + V as the C operand - twelve
     // contraction slots hold the three piece products wg_h geo_h + wg_h geo_l + wg_l geo_h.  With the k order of h2_kperm its result
@@ -295,7 +294,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     const float z0 = z[m][t][2 * jp], z1 = z[m][t][2 * jp + 1];
-                    zmax = fmaxf(fmaxf(zmax, z0), z1);              // (one v_max3 per two elements)
                     const float a0 = __builtin_amdgcn_fmed3f(z0, h2_expm1_neg(z0), H2_AMAX);
                     const float a1 = __builtin_amdgcn_fmed3f(z1, h2_expm1_neg(z1), H2_AMAX);
                     const uint32_t hh = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a0, a1}, f16x2));
@@ -397,7 +395,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (wave < 4) run_half(std::false_type());
     else run_half(std::true_type());
 
-    if (status != nullptr && !(zmax <= H2_AMAX)) atomicOr(status, (uint32_t)DFOL_RANGE_PAIR_SATURATED);     // an activation left fp16's range
     // Epilogue: Sigmoid of the hidden layer (the row scale of W2 folded into the exponent's multiplier), dot products with the requested
     // embedding rows (16-lane DPP reduction), LogSigmoid, straight into the [s][o] (or [o][s]) tile the Relate kernel reads.
     const int64_t tile_sz = (int64_t)NS * NS;
@@ -506,7 +503,7 @@ extern "C" int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1,
     const dim3 grid((unsigned)Q * tpi);
 #define DFOL_PAIR32H(NBV, BF)                                                                                                       \
     hipLaunchKernelGGL((pair_ll32h_kernel<NBV, BF>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
-                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v, dfol_range_status_ptr())
+                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
     if (HID2 <= 272) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(17, true); else DFOL_PAIR32H(17, false); }
     else if (HID2 <= 288) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(18, true); else DFOL_PAIR32H(18, false); }
     else if (HID2 <= 304) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(19, true); else DFOL_PAIR32H(19, false); }

@@ -584,16 +584,17 @@ int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, const int32_
                                   const int32_t* n_obj, int32_t NS, int32_t rank, float* g_x, void* stream);
 
 /* ---- fp16 range status (round 5) ------------------------------------------------------------------------------------------------
- * The two-piece fp16 kernels split their activations UNSCALED (dfol_linear_act_h2_f32, dfol_linear_logit_h2_f32: |x| > 65504 makes the
- * high piece inf and the row's products NaN; dfol_pair_ll_h2_f32: ELU outputs saturate at 6e4).  The reference accepts any fp32 feature
- * (batch_gqa_boxfeatures_pipeline.py:199-213 feeds them to nn.Linear as they are), so instead of answering with NaN - or with a silently
- * clamped activation - these kernels OR a bit into a caller-owned device word when it happens; the host reads the word with the answers
- * and raises, naming `mlp_math: bf16x3` (three bf16 pieces: fp32's exponent range) as the remedy.  The pointer is a THREAD-LOCAL setting of
- * the calling host thread (like dfol_last_error), picked up by the launches that follow; NULL (the default) disables the check.  Cost:
- * one v_max3 per two elements the kernels convert anyway, one atomic per workgroup in the failing case only.
+ * The two-piece fp16 dense kernels split their activations UNSCALED (dfol_linear_act_h2_f32, dfol_linear_logit_h2_f32: |x| > 65504 makes
+ * the high piece inf and the row's products NaN).  The reference accepts any fp32 feature (batch_gqa_boxfeatures_pipeline.py:199-213 feeds
+ * them to nn.Linear as they are), so instead of answering with NaN these kernels OR a bit into a caller-owned device word when it happens;
+ * the host reads the word with the answers and raises, naming `mlp_math: bf16x3` (three bf16 pieces: fp32's exponent range) as the
+ * remedy.  The pointer is a THREAD-LOCAL setting of the calling host thread (like dfol_last_error), picked up by the launches that
+ * follow; NULL (the default) disables the check.  Cost: one v_max3 per two elements the kernel converts anyway (not measurable: the
+ * dense layers of a step take 0.323 ms with it, 0.33 without), one atomic per workgroup in the failing case only.
+ * (dfol_pair_ll_h2_f32 SATURATES its ELU outputs at 6e4 instead - reaching that needs first-layer weights of magnitude ~58; the same
+ * check there was built and measured at +4 % of the step's dominant kernel - its build tick is paced by its instruction count - and left out.)
  */
 #define DFOL_RANGE_X_OVERFLOW 1u     /* an input element of a two-piece dense product is beyond fp16's largest finite value (or NaN) */
-#define DFOL_RANGE_PAIR_SATURATED 2u /* a first-layer activation of the pair MLP exceeded 6e4 and was clamped (or is NaN) */
 int dfol_set_range_status(uint32_t* device_word);
 
 /* ---- the native executor of a lowered ProgramBatch (round 5) -------------------------------------------------------------------------

@@ -831,10 +831,17 @@ def pair_pack_w2_h2(w2, hid2=None):
     return out
 
 
+LOG2E = 1.4426950408889634
+
+
 def pair_ll_h2(uv, hid1, pos, wg, w2_h2, b2, hid2, emb_w, emb_b, n_obj, obj_off, max_n, req_col, req_tile, req_orient, tiles,
-               default_ll=-30.0):
+               default_ll=-30.0, uv_prescaled=False):
     """As pair_ll_split, with the second layer split by pair_pack_w2_h2: fp16 matrix pipe, three products per fp32 product, fp32 results
-    (csrc/dfol_pair_h2.hip).  Ordered pairs only: `tiles` must be pre-filled with default_ll (diagonal and padding keep the fill)."""
+    (csrc/dfol_pair_h2.hip).  Ordered pairs only: `tiles` must be pre-filled with default_ll (diagonal and padding keep the fill).
+    The kernel takes U | V MULTIPLIED BY log2(e) (include/dfol_vqa.h): uv_prescaled=True says `uv` already is (the oracle scales the stacked
+    first-layer weight once per weight version); otherwise it is scaled here, with one extra pass over it (tests, lab scripts)."""
+    if not uv_prescaled:
+        uv = uv * LOG2E
     K, Q = req_col.shape
     NS = tiles.shape[1]
     bf16 = tiles.dtype == torch.bfloat16

@@ -53,6 +53,14 @@ __device__ long long dfol_h2_trace_buf[8 * 8 * 64];
 #ifndef DFOL_H2_BDEPTH
 #define DFOL_H2_BDEPTH 2
 #endif
+// the U / V rows of the next chunk requested at the END of the build tick (1: as soon as make_a has consumed this chunk's) or after its barrier (0)
+#ifndef DFOL_H2_UV_EARLY
+#define DFOL_H2_UV_EARLY 0
+#endif
+// Y's chunk requests as inline asm (1): in flight across the build tick's closing barrier
+#ifndef DFOL_H2_DMA_ASM
+#define DFOL_H2_DMA_ASM 1
+#endif
 // Y's request for the next W2 chunk: 0 = at the top of its build tick, 1 = after its A pieces are built
 #ifndef DFOL_H2_DMA_LATE
 #define DFOL_H2_DMA_LATE 0
@@ -71,7 +79,9 @@ constexpr float H2_NL2E = -1.44269504088896340736f;         // -log2(e)
 constexpr int H2_CH = 32;                                   // K per chunk = one v_mfma_f32_16x16x32_f16
 constexpr int H2_ROWS = 320, H2_TILES = 20;                 // rows (hidden columns) of the packed image
 constexpr int H2_PIECES = 2 * H2_ROWS * 4;                  // 16-byte pieces per chunk: 2560 = 40 KB
-constexpr float H2_AMAX = 60000.0f;                         // activations saturate here (fp16 max 65504)
+constexpr float H2_AMAX = 60000.0f;                         // activations saturate here (fp16 max 65504); in units of 1 / ln 2 (see make_a): ELU outputs of 41 589
+constexpr float H2_L2E = 1.44269504088896340736f;           // log2(e) = 1 / ln 2
+constexpr float H2_LN2 = 0.69314718055994530942f;
 
 __device__ __forceinline__ int h2_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // {0,3,2,1}[(row>>2)&3]
 
@@ -85,9 +95,14 @@ __device__ __forceinline__ void h2_split2(float x0, float x1, uint32_t& h, uint3
     l = __builtin_bit_cast(uint32_t, ll);
 }
 
-// e^min(z, 0) - 1 on the hardware exponential (min(z, 0) as a v_med3: fminf canonicalises its input with an extra v_max per element)
-__device__ __forceinline__ float h2_expm1_neg(float z) {
-    return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(z, 0.f, -3.0e38f) * 1.44269504088896340736f) - 1.0f;
+// The ELU's negative branch in the kernel's units: z' = z / ln 2 comes in (UV and the geometry weights are pre-multiplied by log2(e)), and
+// (e^min(z, 0) - 1) / ln 2 = (2^min(z', 0) - 1) / ln 2 goes out - the hardware exponential with the CLAMP output modifier (2^z' clamped to
+// [0, 1]: exactly 1 for z' >= 0, +inf included) and one fused multiply-add.  TWO instructions per element where round 4 had four (v_med3 for
+// min(z, 0), v_mul by log2(e), v_exp, v_add -1): a build tick is paced by its instruction COUNT - one issue slot per MFMA of the SIMD's
+// other wavefront - so the sixteen elements of a chunk cost 32 slots less.  The factor ln 2 is folded into W2 by the pack kernel.
+__device__ __forceinline__ float h2_elu_neg(float zs) {
+    const float p = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(zs), 0.0f, 1.0f);        // (folds into v_exp_f32 ... clamp)
+    return fmaf(p, H2_L2E, -H2_L2E);
 }
 
 // The k of a 32-chunk that k-group kq (a lane's kh) holds at position e = 0..7 of its MFMA operand register: 16 (e >> 2) + 4 kq + (e & 3).
@@ -111,7 +126,7 @@ __global__ void h2_row_scale_kernel(const float* __restrict__ W2, int64_t ld_w2,
     if (r >= H2_ROWS) return;
     float m = 0.f;
     if (r < HID2)
-        for (int k = lane; k < HID1; k += 64) m = fmaxf(m, fabsf(W2[(int64_t)r * ld_w2 + k]));
+        for (int k = lane; k < HID1; k += 64) m = fmaxf(m, fabsf(W2[(int64_t)r * ld_w2 + k] * H2_LN2));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
     int e = 0;
@@ -141,8 +156,9 @@ __global__ void h2_pack_w2_kernel(const float* __restrict__ W2, int64_t ld_w2, i
     for (int j = 0; j < 4; ++j) {
         float w0 = 0.f, w1 = 0.f;
         if (r < HID2) {
-            w0 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + h2_kperm(kq, 2 * j)], e);
-            w1 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + h2_kperm(kq, 2 * j + 1)], e);
+            // (times ln 2: the kernel feeds the second layer ELU outputs in units of 1 / ln 2 - see make_a; one rounding per weight)
+            w0 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + h2_kperm(kq, 2 * j)] * H2_LN2, e);
+            w1 = ldexpf(W2[(int64_t)r * ld_w2 + c * H2_CH + h2_kperm(kq, 2 * j + 1)] * H2_LN2, e);
         }
         uint32_t h, l;
         h2_split2(w0, w1, h, l);
@@ -217,9 +233,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         u32x4 frag = {0u, 0u, 0u, 0u};
         if (khh < 2) {
             const float4 g = *reinterpret_cast<const float4*>(Wg + (kt * 16 + (ln & 15)) * 4);
-            uint32_t h01, l01, h23, l23;
-            h2_split2(g.x, g.y, h01, l01);
-            h2_split2(g.z, g.w, h23, l23);
+            uint32_t h01, l01, h23, l23;                        // (times log2(e): the first layer's sums come out in units of ln 2, as UV holds them)
+            h2_split2(g.x * H2_L2E, g.y * H2_L2E, h01, l01);
+            h2_split2(g.z * H2_L2E, g.w * H2_L2E, h23, l23);
             frag = khh == 0 ? u32x4{h01, h23, h01, h23} : u32x4{l01, l23, 0u, 0u};      // [0..3] wg_h, [4..7] wg_h, [8..11] wg_l
         }
         WgA[i] = frag;
@@ -245,12 +261,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // The whole chunk c -> chunk buffer `buf`, requested by the 4 wavefronts of half Y (10 passes of 256 pieces; a wavefront's 64 pieces of a
     // pass are 1 KiB of contiguous LDS: wave-uniform base, the hardware adds lane * 16 bytes)
+    // (a wavefront copies a CONTIGUOUS 10 KiB quarter of the chunk, 1 KiB per request, and the requests use the instruction's immediate
+    // offset - it advances the global and the LDS address alike - so one pointer / M0 setting serves four requests: three settings per chunk
+    // instead of ten.  Y's build tick is paced by its instruction count, and every request used to come with five address instructions.)
     auto dma_chunk = [&](int c, int buf) __attribute__((always_inline)) {
-        const int w = wave - 4, t = tid - 256;
+        const int w = wave - 4;
+        constexpr int PER_WAVE = H2_PIECES / 4;                                 // 16-byte pieces of a wavefront's quarter (640 = ten requests)
+        const u32x4* src = W2h + (int64_t)c * H2_PIECES + w * PER_WAVE + lane;
+        u32x4* dst = &Bs[buf * H2_PIECES + w * PER_WAVE];
 #pragma unroll
-        for (int i = 0; i < H2_PIECES / 256; ++i)
-            __builtin_amdgcn_global_load_lds(W2h + (int64_t)c * H2_PIECES + 256 * i + t,
-                                             (__attribute__((address_space(3))) void*)&Bs[buf * H2_PIECES + 256 * i + w * 64], 16, 0, 0);
+        for (int g = 0; g < PER_WAVE / 64; g += 4) {
+#if DFOL_H2_DMA_ASM
+            // (inline asm: the compiler does not know these requests, so the barrier that closes the build tick does not drain them - they land
+            // under Y's multiply tick, whose closing s_waitcnt vmcnt(0) is theirs)
+            const uint32_t d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(dst + 64 * g);
+            const u32x4* sp = src + 64 * g;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sp), "s"(__builtin_amdgcn_readfirstlane(d)) : "memory");
+            if (g + 1 < PER_WAVE / 64) asm volatile("global_load_lds_dwordx4 %0, off offset:1024" ::"v"(sp) : "memory");
+            if (g + 2 < PER_WAVE / 64) asm volatile("global_load_lds_dwordx4 %0, off offset:2048" ::"v"(sp) : "memory");
+            if (g + 3 < PER_WAVE / 64) asm volatile("global_load_lds_dwordx4 %0, off offset:3072" ::"v"(sp) : "memory");
+#else
+            auto d = (__attribute__((address_space(3))) void*)(dst + 64 * g);
+            __builtin_amdgcn_global_load_lds(src + 64 * g, d, 16, 0, 0);
+            if (g + 1 < PER_WAVE / 64) __builtin_amdgcn_global_load_lds(src + 64 * g, d, 16, 1024, 0);
+            if (g + 2 < PER_WAVE / 64) __builtin_amdgcn_global_load_lds(src + 64 * g, d, 16, 2048, 0);
+            if (g + 3 < PER_WAVE / 64) __builtin_amdgcn_global_load_lds(src + 64 * g, d, 16, 3072, 0);
+#endif
+        }
     };
     // A pieces of a chunk for the lane's slots: k = 32 c + 8 kh + 0..7.  Two ADJACENT k of one slot form every packed-math pair
     // (U, V and the transposed geometry weights are contiguous in k): no register shuffles.
@@ -294,8 +331,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     const float z0 = z[m][t][2 * jp], z1 = z[m][t][2 * jp + 1];
-                    const float a0 = __builtin_amdgcn_fmed3f(z0, h2_expm1_neg(z0), H2_AMAX);
-                    const float a1 = __builtin_amdgcn_fmed3f(z1, h2_expm1_neg(z1), H2_AMAX);
+                    const float a0 = __builtin_amdgcn_fmed3f(z0, h2_elu_neg(z0), H2_AMAX);
+                    const float a1 = __builtin_amdgcn_fmed3f(z1, h2_elu_neg(z1), H2_AMAX);
                     const uint32_t hh = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a0, a1}, f16x2));
                     const uint32_t ll = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){h2_resid<false>(a0, hh), h2_resid<true>(a1, hh)}, f16x2));
                     ap[m][0][2 * t + jp] = hh;
@@ -362,7 +399,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
                 ru[0][0] = t0, ru[0][1] = t1, ru[1][0] = t2, ru[1][1] = t3, rv[0][0] = t4, rv[0][1] = t5, rv[1][0] = t6, rv[1][1] = t7;
             }
+            TRACE(40 + c);
             if (Y && !DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
+            TRACE(50 + c);
             make_a(c);
             // the A pieces are pure register arithmetic: without these fences the compiler sinks them below the barrier, in front of the
             // MFMAs of the multiply tick - the IR-level sinking into the block that uses them (the empty asm pins the values here), and
@@ -373,6 +412,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(ap[m][p]));
             __builtin_amdgcn_sched_barrier(0);
             if (Y && DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
+            if (DFOL_H2_PREFETCH && DFOL_H2_UV_EARLY && c < lastc) load_uv(c + 1);
             TRACE(3 + 4 * c);
             // end of the build tick.  (__syncthreads() carries a release fence, for which the compiler drains the chunk request Y has just
             // issued - vmcnt(0) in front of the barrier.  Two ways around that wait were built and measured slower: the bare s_barrier
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_sched_barrier(0);
             TRACE(4 + 4 * c);
             bbase = boff + (c & 1) * H2_PIECES;
-            if (DFOL_H2_PREFETCH && c < lastc) load_uv(c + 1);      // lands under the MFMAs
+            if (DFOL_H2_PREFETCH && !DFOL_H2_UV_EARLY && c < lastc) load_uv(c + 1);      // lands under the MFMAs
             chunk_mfma();
             if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);      // the chunk requested in the build tick has landed
             TRACE(5 + 4 * c);

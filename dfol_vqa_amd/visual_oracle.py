@@ -564,16 +564,29 @@ class ClassifierOracle(OracleBase):
         """W1 [HID1, 2D+4] -> stacked per-object weight [2 HID1, D] (+ bias [b1, 0]) and the geometry columns [HID1, 4].
         W1 [obj_s, obj_o, geo] + b1 = (W1a obj_s + b1) + W1b obj_o + Wg geo: exact up to fp32 reassociation."""
         lin = [m for m in self._relation_network._network if isinstance(m, nn.Linear)][0]
-        key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version)
+        # The fp16x2 pair kernel (csrc/dfol_pair_h2.hip) takes U | V in units of ln 2, i.e. multiplied by log2(e): its ELU then needs no multiply in
+        # front of the hardware exponential (a build tick of that kernel is paced by its instruction count).  The factor goes into the stacked
+        # weight and bias here, once per weight version; the kernel scales the geometry columns itself and its pack kernel folds ln 2 into W2.
+        scaled = self._pair_kind() == "f16x2"
+        key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version, scaled)
         if self._split_cache is None or self._split_cache[0] != key:
             w = lin.weight.detach()
             hid1, D = w.shape[0], (w.shape[1] - 4) // 2
             wuv = torch.cat([w[:, :D], w[:, D:2 * D]], 0).contiguous()
             b1 = lin.bias.detach() if lin.bias is not None else torch.zeros(hid1, device=w.device)
             buv = torch.cat([b1, torch.zeros_like(b1)]).contiguous()
+            if scaled:
+                wuv, buv = wuv * L.LOG2E, buv * L.LOG2E
             wg = w[:, 2 * D:2 * D + 4].contiguous()
             self._split_cache = (key, wuv, buv, wg, hid1, D)
         return L.keep_alive(self._split_cache)[1:]
+
+    def _pair_kind(self):
+        """Which fused pair kernel evaluates this oracle's relation tiles: "f16x2", "bf16x3", "packed" (fp32 pipe, packed W2) or "plain"."""
+        packed = self._padded_second_layer()[3]
+        if isinstance(packed, tuple):
+            return packed[0]
+        return "plain" if packed is None else "packed"
 
     def _padded_second_layer(self):
         """W2 zero-padded to a multiple of 32 rows, so the fused pair kernel's main loop needs no bounds checks."""
@@ -901,7 +914,7 @@ class ClassifierOracle(OracleBase):
         ro = None if req_orient is None else up(req_orient)
         if isinstance(packed, tuple) and packed[0] == "f16x2":
             L.pair_ll_h2(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._img_n_obj,
-                         world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)
+                         world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0, uv_prescaled=True)
         elif isinstance(packed, tuple):
             L.pair_ll_split(world._uv, hid1, world._obj[:, D - 4:], wg, packed[1], b2, hid2, emb.weight, emb.bias, world._img_n_obj,
                             world._obj_off, max(world._n_list), rc, rt, ro, tiles, -30.0)

@@ -394,6 +394,11 @@ int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const f
  * against float64 the results are as accurate as the fp32-pipe kernel's (tests/test_kernels_gpu.py; profiles/r04_split_accuracy_lab.txt).
  * W2_split is produced once per weight update by dfol_pair_pack_w2_f16x2: dfol_pair_w2_f16x2_bytes(HID1) bytes, 16-byte aligned
  * ((HID1/32) chunks of [2 pieces][320 rows][32] fp16, k-groups swizzled, then 320 floats -log2(e) 2^-e_r and the 320 int32 exponents).
+ * UV IS TAKEN IN UNITS OF ln 2 (round 5): UV[o] = log2(e) x (the per-object halves of the first layer, bias included) - multiply the stacked
+ * weight and bias by log2(e) once per weight update (dfol_vqa_amd/visual_oracle.py:_split_first_layer); Wg is passed as it is (the kernel
+ * scales its 1 K geometry weights itself) and dfol_pair_pack_w2_f16x2 folds the factor ln 2 into W2.  The ELU then costs two instructions per
+ * element - v_exp_f32 with the clamp modifier (2^min(z', 0)) and one fma - instead of four; a build tick of this kernel is paced by its
+ * instruction count (csrc/dfol_pair_h2.hip).  Activations saturate at 6e4 in those units, i.e. at ELU outputs of 4.16e4.
  * All other arguments, the ordered-pairs-only enumeration (pre-fill the tiles with default_ll: the diagonal and the padding keep that
  * fill) and the limits as dfol_pair_ll_split_f32: HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320.
  * Replaces classifier_oracle.py:145-156 for the relation columns a program names (gqa_interpreter_experiments.py:18-36, 60-77). */

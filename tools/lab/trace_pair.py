@@ -26,11 +26,12 @@ print("rc", lib.dfol_pair_h2_trace_read(buf))
 t = np.array(buf[:], dtype=np.int64).reshape(8, 8, 64)
 for blk in range(3):
     base = t[blk, 0, 0]
-    for w in (0, 4):
+    for w in ((0, 4) if blk else range(8)):
         x = t[blk, w]
         if x[0] == 0: continue
         print("block %d wave %d: start %d  prologue->loop %d  total %d  epilogue %d" % (blk, w, x[0] - base, x[2] - x[0], x[60] - x[0], x[60] - x[6 + 4 * 7]))
         for c in range(8):
             prev = x[2] if c == 0 else x[6 + 4 * (c - 1)]
-            print("   chunk %d @%6d: build %5d  barrier %5d  multiply %5d  barrier %5d" % (c, prev - base, x[3 + 4 * c] - prev, x[4 + 4 * c] - x[3 + 4 * c],
-                                                                                       x[5 + 4 * c] - x[4 + 4 * c], x[6 + 4 * c] - x[5 + 4 * c]))
+            print("   chunk %d @%6d: build %5d (rows wait %5d, chunk request %4d, A pieces %5d)  barrier %5d  multiply %5d  barrier %5d" % (
+                c, prev - base, x[3 + 4 * c] - prev, x[40 + c] - prev, x[50 + c] - x[40 + c], x[3 + 4 * c] - x[50 + c], x[4 + 4 * c] - x[3 + 4 * c],
+                x[5 + 4 * c] - x[4 + 4 * c], x[6 + 4 * c] - x[5 + 4 * c]))

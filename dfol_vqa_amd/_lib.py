@@ -334,13 +334,13 @@ CAPTURE_RANGE_CHECKS = []            # checks of forwards that ran INSIDE a capt
 
 
 def new_range_host():
-    return torch.empty(1, dtype=torch.int32).pin_memory()
+    return torch.zeros(1, dtype=torch.int32).pin_memory()        # (zero: a replayed step looks at it before its first copy has arrived)
 
 
 def _range_host():
     """A pinned int32 for one forward's copy of the status word (a small ring: forwards in flight at once - forward_async - keep their own)."""
     if len(_RANGE_HOSTS) < 16:
-        _RANGE_HOSTS.append(torch.empty(1, dtype=torch.int32).pin_memory())
+        _RANGE_HOSTS.append(torch.zeros(1, dtype=torch.int32).pin_memory())
         return _RANGE_HOSTS[-1]
     _RANGE_HOSTS.append(_RANGE_HOSTS.pop(0))
     return _RANGE_HOSTS[-1]

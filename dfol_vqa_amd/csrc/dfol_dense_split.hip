@@ -285,18 +285,12 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                 return make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         };
-#ifdef LS_SKIP_X
-        if (ks > 100000) {
-#endif
         xa[S][0][0] = ld4(xp0 + c0);
         xa[S][0][1] = ld4(xp0 + c1);
         if constexpr (RH == 2) {
             xa[S][1][0] = ld4(xp1 + c0);
             xa[S][1][1] = ld4(xp1 + c1);
         }
-#ifdef LS_SKIP_X
-        }
-#endif
     };
     auto load_e = [&](int ks) __attribute__((always_inline)) {
         if constexpr (PROD) {
@@ -364,9 +358,6 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
     u32x4 wb[TILE_PIECES / 256];
     auto load_w = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-#ifdef LS_SKIP_W
-        if (ks > 100000)
-#endif
         for (int i = 0; i < TILE_PIECES / 256; ++i) wb[i] = wtile[(int64_t)ks * TILE_PIECES + 256 * i + tid];
     };
     auto store_b = [&](int off = 0) __attribute__((always_inline)) {
@@ -409,13 +400,9 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if constexpr (NP == 2) {
-#ifdef LS_SKIP_MM
-                        acc[ih + i][j][0] += (float)(a[i][0][0] + a[i][1][0] + b[0][0] + b[1][0]);
-#else
 #pragma unroll
                         for (int x = 0; x < 3; ++x)         // three dependent MFMAs per accumulator, smallest terms first
                             acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][PA3[x]], b[PB3[x]], acc[ih + i][j], 0, 0, 0);
-#endif
                     } else {
 #pragma unroll
                         for (int x = X0; x < 6; ++x)        // six dependent MFMAs per accumulator, smallest terms first
@@ -668,9 +655,6 @@ __device__ __forceinline__ void ls_tile(u32x4* __restrict__ As, u32x4* __restric
                 }
         }
     }
-#ifdef LS_SKIP_ST
-    if (acc[0][0][0] == 1.2345e-30f)
-#endif
     if (NT == 4 && m0 + BM <= M && n0 + LS_BN <= N) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)

@@ -963,7 +963,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
 #pragma unroll
-#ifndef PW_SKIP_SG
                 for (int t = 0; t < CPT; ++t) {
                     float xv;
                     if constexpr (BIO) xv = __uint_as_float((t & 1) ? (xa[i][t >> 1] & 0xffff0000u) : (xa[i][t >> 1] << 16));
@@ -976,9 +975,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         sdb[t] += v[r][t];
                     }
                 }
-#else
-                for (int t = 0; t < CPT; ++t) v[r][t] = gs * e[t];
-#endif
             }
             if constexpr (SUMS) {
 #pragma unroll
@@ -995,12 +991,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 } else {
                     uint32_t h, l;
                     pw_split2(v[0][t], v[1][t], h, l);
-#ifndef PW_SKIP_AW
                     buf32[at] = h;
                     buf32[at + PW_TA * 64 * 4] = l;
-#else
-                    if (h == 0x12345678u) buf32[at] = h + l;
-#endif
                 }
             }
         }
@@ -1045,13 +1037,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                                  // smallest terms first
             const pw_f16x8 bh = __builtin_bit_cast(pw_f16x8, Bb[(tb0 + u) * 64]), bl = __builtin_bit_cast(pw_f16x8, Bb[((NPC - 1) * PW_TB + tb0 + u) * 64]);
-#ifndef PW_SKIP_MM
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][u], 0, 0, 0);
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][u], 0, 0, 0);
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][u], 0, 0, 0);
-#else
-            acc[t][u][0] += (float)(al[0] + bh[0] + ah[0] + bl[0]);
-#endif
         }
     };
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };

@@ -170,6 +170,8 @@ SIGNATURES = {
     "dfol_linear_w_f16x2_bytes": [_i32, _i32],
     "dfol_linear_pack_w_f16x2": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    "dfol_linear_wide_supported": [_i64, _i32, _i32],
+    "dfol_linear_wide_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_w2_f16x2_bytes": [_i32],
     "dfol_pair_pack_w2_f16x2": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_pair_ll_h2_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f,
@@ -588,6 +590,18 @@ def linear_act_split(x, weight, bias, act, out=None, transpose_w=False):
         out = torch.empty(M, N, dtype=F32, device=x.device)
     call("dfol_linear_act_bf16_f32" if bf16 else ("dfol_linear_act_h2_f32" if h2 else "dfol_linear_act_split_f32"), _dp(x), x.stride(0),
          _ptr(linear_pack_w_split(weight, transpose_w, 1 if bf16 else (2 if h2 else 3)), torch.bfloat16), _ptr(bias, F32, True), _dp(out),
+         out.stride(0), M, N, K, act, _stream())
+    return out
+
+
+def linear_wide(x, weight, bias, act, out=None):
+    """linear_act_split's two-fp16-piece product through the persistent wide kernel (csrc/dfol_dense_wide.hip: 256 < N <= 512, X fetched and
+    split once), whatever M: what dfol_linear_act_h2_f32 forwards to by itself for batches that fill the chip.  Same bits as the tiled kernel."""
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=x.device)
+    call("dfol_linear_wide_h2_f32", _dp(x), x.stride(0), _ptr(linear_pack_w_split(weight, False, 2), torch.bfloat16), _ptr(bias, F32, True), _dp(out),
          out.stride(0), M, N, K, act, _stream())
     return out
 

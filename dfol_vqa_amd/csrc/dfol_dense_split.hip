@@ -776,6 +776,8 @@ static int ls_launch(const float* X, int64_t ldx, const void* W_split, const flo
     if (M == 0) return 0;
     DFOL_REQUIRE(X && W_split && Y, "linear_act_split: null pointer");
     DFOL_REQUIRE(((uintptr_t)X % 8 == 0) && ((uintptr_t)W_split % 16 == 0), "linear_act_split: X must be 8-byte and W_split 16-byte aligned");
+    if (NP == 2 && dfol_linear_wide_supported(M, N, K))            // wide outputs: X fetched and split once (csrc/dfol_dense_wide.hip), same bits
+        return dfol_linear_wide_h2_f32(X, ldx, W_split, bias, Y, ldy, M, N, K, act, stream);
     const int nbn = dfol_cdiv(N, LS_BN);
     // 64-row blocks when 128-row blocks would not even give every CU two workgroups (the block height changes no result bit, see ls_tile);
     // DFOL_DENSE_BM=128 / 64 forces one for A/B runs

@@ -961,6 +961,35 @@ def test_linear_act_split_block_height_changes_no_bit(L):
                 assert torch.equal(y_small, y_big[:m]), (N, K, act, m, (y_small - y_big[:m]).abs().max().item())
 
 
+def test_linear_wide_equals_the_tiled_kernel_bit_for_bit(L):
+    """csrc/dfol_dense_wide.hip (one persistent workgroup per CU over 128 rows x all of 256 < N <= 512 columns: the featurizer and the pair
+    MLP's stacked first layer) against the tiled kernel on the same rows in chunks small enough that dfol_linear_act_h2_f32 does not forward
+    them: equal bit for bit for every activation, both X load widths (16- and 8-byte aligned rows), a k tail (516 = 16 steps + 4), three and
+    four column blocks, ragged M, and a batch of fewer blocks than CUs.  And the fp16-range flag rides in this kernel too."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(33)
+    lib = _lib.load()
+    for (N, K, ld, M) in ((512, 2048, 2054, 25600 + 37), (512, 516, 516, 40000), (384, 132, 136, 33000), (300, 256, 256, 5000), (512, 2048, 2048, 129)):
+        X = torch.tensor(rng.normal(size=(M, ld)).astype(np.float32), device="cuda")
+        W = torch.tensor((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32), device="cuda")
+        b = torch.tensor(rng.normal(size=N).astype(np.float32), device="cuda")
+        assert not lib.dfol_linear_wide_supported(3000, N, K) and (M < 24000 or lib.dfol_linear_wide_supported(M, N, K))
+        for act in (L.ACT_NONE, L.ACT_SIGMOID, L.ACT_ELU, L.ACT_LOGSIGMOID):
+            y = _lib.linear_wide(X[:, :K], W, b, act)
+            ref = torch.cat([_lib.linear_act_split(X[m:m + 3000, :K], W, b, act) for m in range(0, M, 3000)])
+            assert torch.equal(y, ref), (N, K, ld, act, (y - ref).abs().max().item())
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lib.dfol_set_range_status(word.data_ptr())
+    try:
+        _lib.linear_wide(X[:, :K], W, b, L.ACT_NONE)
+        assert int(word.item()) == 0
+        X[77, 5] = 1.0e5
+        _lib.linear_wide(X[:, :K], W, b, L.ACT_NONE)
+        assert int(word.item()) & _lib.RANGE_X_OVERFLOW
+    finally:
+        lib.dfol_set_range_status(None)
+
+
 @pytest.mark.parametrize("act", [1, 2, 3])
 @pytest.mark.parametrize("shape", [(1000, 300), (7, 3), (25600, 512)])
 def test_act_bwd_equals_autograd_formulas(act, shape):

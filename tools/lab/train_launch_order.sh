@@ -33,4 +33,5 @@ for k, (n, s, e) in enumerate(last):
     print("%4d %9.1f us  dur %8.1f  gap %6.1f  %s" % (k, (s - t0) / 1e3, (e - s) / 1e3, gap, short(n)))
 print("busy %.1f us, span %.1f us" % (tot, (last[-1][2] - t0) / 1e3))
 PY
+rm -rf $OUT/trace
 tail -3 $R/gpurun_out/order_$TAG.txt

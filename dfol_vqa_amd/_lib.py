@@ -171,6 +171,11 @@ SIGNATURES = {
     "dfol_linear_pack_w_f16x2": [_p, _i64, _i32, _i32, _p, _p],
     "dfol_linear_act_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_wide_supported": [_i64, _i32, _i32],
+    "dfol_concept_rows_f32": [_p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _i32, _p],
+    "dfol_grad_sqnorm_parts": [],
+    "dfol_clip_adam_chunk": [],
+    "dfol_grad_sqnorm_f32": [_p, _i64, _p, _p],
+    "dfol_clip_adam_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _f, _f, _f, _f, _f, _f, _f, _p, _p],
     "dfol_linear_wide_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_pair_w2_f16x2_bytes": [_i32],
     "dfol_pair_pack_w2_f16x2": [_p, _i64, _i32, _i32, _p, _p],
@@ -494,6 +499,14 @@ def segment_sum_rows(src, seg_off):
     Q, width = seg_off.numel() - 1, src.shape[1]
     out = torch.empty(Q, width, dtype=F32, device=src.device)
     call("dfol_segment_sum_rows_f32", _ptr(src, F32), _ptr(seg_off, I32), Q, width, _ptr(out), _stream())
+    return out
+
+
+def concept_rows(rows, order, seg_off, ucols, out, accumulate):
+    """out[ucols[u]] (+)= sum of rows[order[k]] over segment u, in slot order (csrc/dfol_logic.hip: concept_rows_kernel); rows [P, width]."""
+    rows2, out2 = rows.reshape(rows.shape[0], -1), out.reshape(out.shape[0], -1)
+    call("dfol_concept_rows_f32", _dp(rows2), rows2.stride(0), _ptr(order, I32), _ptr(seg_off, I32), _ptr(ucols, I64), ucols.numel(), rows2.shape[1],
+         _dp(out2), out2.stride(0), 1 if accumulate else 0, _stream())
     return out
 
 

@@ -1361,6 +1361,32 @@ extern "C" int dfol_segment_sum_rows_f32(const float* src, const int32_t* seg_of
     return 0;
 }
 
+// out[ucols[u]][c] (+)= sum over the slots k of segment u of rows[order[k]][c], added in slot order starting from zero - what gather_rows,
+// segment_sum_rows and an index_copy into a zeroed matrix compute in three launches (visual_oracle._combine_concept_rows)
+__global__ void concept_rows_kernel(const float* __restrict__ rows, int64_t ld_rows, const int32_t* __restrict__ order,
+                                    const int32_t* __restrict__ seg_off, const int64_t* __restrict__ ucols, int width, float* __restrict__ out,
+                                    int64_t ld_out, int accumulate) {
+    const int u = blockIdx.x;
+    const int k0 = seg_off[u], k1 = seg_off[u + 1];
+    float* __restrict__ dst = out + ucols[u] * ld_out;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        float s = 0.f;
+        for (int k = k0; k < k1; ++k) s += rows[(int64_t)order[k] * ld_rows + c];
+        dst[c] = accumulate ? dst[c] + s : s;
+    }
+}
+
+extern "C" int dfol_concept_rows_f32(const float* rows, int64_t ld_rows, const int32_t* order, const int32_t* seg_off, const int64_t* ucols, int32_t U,
+                                     int32_t width, float* out, int64_t ld_out, int32_t accumulate, void* stream) {
+    DFOL_REQUIRE(U >= 0 && width > 0 && ld_rows >= width && ld_out >= width, "concept_rows: bad sizes");
+    if (U == 0) return 0;
+    DFOL_REQUIRE(rows && order && seg_off && ucols && out, "concept_rows: null pointer");
+    hipLaunchKernelGGL(concept_rows_kernel, dim3(U), dim3(width >= 256 ? 256 : 64), 0, (hipStream_t)stream, rows, ld_rows, order, seg_off, ucols, width,
+                       out, ld_out, accumulate);
+    DFOL_LAUNCH_CHECK("concept_rows");
+    return 0;
+}
+
 __global__ void logic_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

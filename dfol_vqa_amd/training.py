@@ -64,6 +64,135 @@ def compute_loss(program_batch_list, prediction, l1_lambda=0.0, parameters=None,
     return loss
 
 
+def _direct_grad(on):
+    from .visual_oracle import direct_grad
+    return direct_grad(on)
+
+
+class FusedClipAdam(object):
+    """nn.utils.clip_grad_norm_ + torch.optim.Adam.step() (trainer.py:439-441) over the flat gradient bucket as two launches of this library
+    (three for a capturable optimizer: its step counters live on the device) instead of seventeen of torch's foreach forms
+    (csrc/dfol_optim.hip).  The optimizer object stays the owner of the hyper-parameters and of the state - `exp_avg`, `exp_avg_sq`, `step`
+    are the tensors torch.optim.Adam itself would have created, so `optimizer.state_dict()` / `load_state_dict()` and a later plain
+    `optimizer.step()` keep working.  `FusedClipAdam.make(...)` returns None when the fused form does not apply (another optimizer class,
+    amsgrad / maximize, several hyper-parameter groups, parameters that are not the bucket's, DFOL_FUSED_ADAM=0): callers then take torch's path."""
+
+    @staticmethod
+    def make(optimizer, bucket):
+        import os
+        if bucket is None or os.environ.get("DFOL_FUSED_ADAM", "1") == "0" or type(optimizer) is not torch.optim.Adam:
+            return None
+        groups = optimizer.param_groups
+        g0 = groups[0]
+        keys = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "capturable")
+        if any(any(g.get(k) != g0.get(k) for k in keys) for g in groups) or g0.get("amsgrad") or g0.get("maximize") or g0.get("differentiable"):
+            return None
+        if isinstance(g0["lr"], torch.Tensor):
+            return None
+        params = [p for g in groups for p in g["params"]]
+        if len(params) != len(bucket.params) or any(a is not b for a, b in zip(params, bucket.params)):
+            return None
+        if not params or any((not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous() for p in params) or not bucket.flat.is_cuda:
+            return None
+        return FusedClipAdam(optimizer, bucket, params)
+
+    def __init__(self, optimizer, bucket, params):
+        import numpy as np
+        from . import _lib
+        self._opt, self._bucket, self._params = optimizer, bucket, params
+        g0 = optimizer.param_groups[0]
+        self._capturable = bool(g0.get("capturable", False))
+        dev = bucket.flat.device
+        for p in params:                                     # the state torch.optim.Adam._init_group creates on its first step
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=dev) if self._capturable else torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        lib = _lib.load()
+        chunk = lib.dfol_clip_adam_chunk()
+        self._partials = torch.empty(lib.dfol_grad_sqnorm_parts(), dtype=torch.float32, device=dev)
+        self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        numel = [p.numel() for p in params]
+        goff = np.concatenate([[0], np.cumsum(numel)])[:-1]
+        ct, cs = [], []
+        for t, n in enumerate(numel):
+            for a in range(0, n, chunk):
+                ct.append(t)
+                cs.append(a)
+        up = lambda a, dt: torch.from_numpy(np.asarray(a, dt)).to(dev)
+        self._goff, self._numel = up(goff, np.int64), up(numel, np.int64)
+        self._chunk_tensor, self._chunk_start, self._n_chunks = up(ct, np.int32), up(cs, np.int64), len(ct)
+        self._tables_key, self._tables = None, None
+
+    def _address_tables(self):
+        """Device tables of the parameters' and the state's addresses, rebuilt when any of them moved (load_state_dict, .to())."""
+        import numpy as np
+        st = [self._opt.state[p] for p in self._params]
+        key = tuple((p.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), s["step"].data_ptr()) for p, s in zip(self._params, st))
+        if key != self._tables_key:
+            dev = self._bucket.flat.device
+            cols = [np.asarray([k[i] for k in key], np.int64) for i in range(4)]
+            self._tables = [torch.from_numpy(c).to(dev) for c in cols]
+            self._tables_key = key
+        return self._tables
+
+    def step(self, clip_norm):
+        from . import _lib
+        g0 = self._opt.param_groups[0]
+        bucket = self._bucket
+        if any(p.grad is None or p.grad.data_ptr() != bucket.flat.data_ptr() + 4 * off for p, off in zip(self._params, self._goff_host())):
+            raise _lib.DfolError("FusedClipAdam: a parameter's .grad is no longer its view of the gradient bucket (zero the bucket, not the optimizer)")
+        param, m, v, step = self._address_tables()
+        step_host = 0.0
+        if not self._capturable:                             # host step counters: torch keeps them as 0-d CPU tensors
+            for p in self._params:
+                self._opt.state[p]["step"] += 1
+            step_host = float(self._opt.state[self._params[0]]["step"])
+        _lib.call("dfol_grad_sqnorm_f32", bucket.flat.data_ptr(), bucket.flat.numel(), self._partials.data_ptr(), _lib._stream())
+        _lib.call("dfol_clip_adam_f32", bucket.flat.data_ptr(), self._partials.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(),
+                  self._goff.data_ptr(), self._numel.data_ptr(), len(self._params), self._chunk_tensor.data_ptr(), self._chunk_start.data_ptr(),
+                  self._n_chunks, step.data_ptr() if self._capturable else None, step_host, float(g0["lr"]), float(g0["betas"][0]),
+                  float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(clip_norm) if clip_norm else 0.0,
+                  self.total_norm.data_ptr(), _lib._stream())
+        _lib.keep_alive((self._partials, param, m, v, step, self._goff, self._numel, self._chunk_tensor, self._chunk_start, self.total_norm))
+        torch.autograd.graph.increment_version(self._params)  # (written behind autograd's back: version-keyed weight images must miss)
+        return self.total_norm
+
+    def _goff_host(self):
+        if getattr(self, "_goff_h", None) is None:
+            off, acc = [], 0
+            for p in self._params:
+                off.append(acc)
+                acc += p.numel()
+            self._goff_h = off
+        return self._goff_h
+
+
+def clip_and_step(model, optimizer, clip_norm, bucket=None, fused=None):
+    """trainer.py:439-441.  `fused`: a FusedClipAdam (or None: torch's clip_grad_norm_ + optimizer.step())."""
+    if fused is not None:
+        fused.step(clip_norm)
+    else:
+        nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+        optimizer.step()
+
+
+_FUSED_OF = {}
+
+
+def _fused_for(optimizer, bucket):
+    """One FusedClipAdam per (optimizer, bucket) pair, made on first use."""
+    key = (id(optimizer), id(bucket))
+    hit = _FUSED_OF.get(key)
+    if hit is None or hit[0]() is not optimizer or hit[1]() is not bucket:
+        import weakref
+        if len(_FUSED_OF) > 64:
+            _FUSED_OF.clear()
+        hit = _FUSED_OF[key] = (weakref.ref(optimizer), weakref.ref(bucket) if bucket is not None else (lambda: None), FusedClipAdam.make(optimizer, bucket))
+    return hit[2]
+
+
 def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group=None, l1_lambda=0.0, bucket=None, sync_loss=True):
     """trainer.py:429-442: zero_grad -> forward -> loss / B -> backward -> clip_grad_norm_ -> step.
 
@@ -87,14 +216,14 @@ def train_batch(model, optimizer, data, clip_norm, global_batch_size=None, group
     local_b = sum(d.batch_size() for d in data)
     b = global_batch_size if global_batch_size is not None else local_b
     loss = loss / b
-    loss.backward()
+    with _direct_grad(bucket is not None):
+        loss.backward()
     if group is not None:
         if bucket is not None:
             bucket.allreduce(group)
         else:
             parallel.allreduce_gradients(model.parameters(), group)
-    nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
-    optimizer.step()
+    clip_and_step(model, optimizer, clip_norm, bucket, _fused_for(optimizer, bucket) if bucket is not None else None)
     return (float(loss.detach()) * b if sync_loss else loss.detach() * b), result
 
 
@@ -198,12 +327,12 @@ class GraphedTrainStep(object):
             self._opt.zero_grad(set_to_none=False)
         result = self._model(self._data, True)
         loss = compute_loss(self._data, result, self._l1, list(self._model.parameters()), l1_scale=1.0 / self._world) / self._batch
-        loss.backward()
+        with _direct_grad(self._bucket is not None):
+            loss.backward()
         return loss.detach() * self._batch, result
 
     def _back(self):
-        nn.utils.clip_grad_norm_(self._model.parameters(), self._clip)
-        self._opt.step()
+        clip_and_step(self._model, self._opt, self._clip, self._bucket, _fused_for(self._opt, self._bucket) if self._bucket is not None else None)
 
     def __call__(self):
         self._graph.replay()

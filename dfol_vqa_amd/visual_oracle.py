@@ -450,16 +450,48 @@ def _concept_plan(cols, device, cache):
     return hit
 
 
-def _combine_concept_rows(rows, plan, out_shape):
-    """rows [P, ...] per predicate -> dense gradient of `out_shape` (one row per concept), deterministic."""
+def _combine_concept_rows(rows, plan, out_shape, leaf=None):
+    """rows [P, ...] per predicate -> gradient of `out_shape` (one row per concept), deterministic: one launch (dfol_concept_rows_f32).
+    leaf: the weight itself.  When it carries a persistent fp32 gradient (the views of parallel.GradBucket; any preallocated .grad), the rows
+    are added straight into it and None is returned - the dense, mostly zero [concepts, width] intermediate (2.8 MB for the embedding
+    layer: a fill, and an add of the whole matrix by autograd's accumulation, per call and four calls per step) never exists.  The sum per
+    concept is formed in predicate order before it meets the gradient, as autograd's accumulation of the dense form did."""
     order, seg_off, ucols = plan
+    direct = leaf is not None and DIRECT_GRAD[0] and leaf.is_leaf and leaf.grad is not None and leaf.grad.dtype == torch.float32 \
+        and leaf.grad.is_contiguous() and rows.is_cuda and tuple(leaf.grad.shape) == tuple(out_shape)
+    if direct:
+        if order.numel():
+            L.concept_rows(rows, order, seg_off, ucols, leaf.grad, True)
+        return None
     out = torch.zeros(out_shape, dtype=rows.dtype, device=rows.device)
     if order.numel() == 0:
         return out
+    if rows.is_cuda:
+        return L.concept_rows(rows, order, seg_off, ucols, out, False)
     flat = rows.reshape(rows.shape[0], -1)
     summed = L.segment_sum_rows(L.gather_rows(flat, order), seg_off)
     out.reshape(out_shape[0], -1).index_copy_(0, ucols, summed)          # unique rows: no accumulation, no atomics
     return out
+
+
+# Off unless a caller that owns the parameters' gradients switches it on around ITS backward pass (training.train_batch / GraphedTrainStep with a
+# gradient bucket): torch.autograd.grad(...) with respect to such a weight, or a hook on its gradient, must keep seeing the gradient as a
+# returned value.  DFOL_DIRECT_GRAD=0 keeps it off everywhere (A/B runs).
+DIRECT_GRAD = [False]
+
+
+class direct_grad(object):
+    """with direct_grad(): backward passes inside add embedding-layer gradient rows straight into the weights' persistent .grad."""
+
+    def __init__(self, on=True):
+        self._on = bool(on) and os.environ.get("DFOL_DIRECT_GRAD", "1") != "0"
+
+    def __enter__(self):
+        self._old, DIRECT_GRAD[0] = DIRECT_GRAD[0], self._on
+
+    def __exit__(self, *exc):
+        DIRECT_GRAD[0] = self._old
+        return False
 
 
 class _AttrLL(torch.autograd.Function):
@@ -478,8 +510,8 @@ class _AttrLL(torch.autograd.Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         d_hidden, dE, db = L.attr_ll_bwd(g.contiguous(), hidden, emb_w, emb_b if ctx.has_bias else None, obj_off, pred_q, pred_col,
                                          ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_b)
-        gw = _combine_concept_rows(dE, ctx.plan, emb_w.shape) if ctx.needs_input_grad[1] else None
-        gb = _combine_concept_rows(db, ctx.plan, emb_b.shape) if need_b else None
+        gw = _combine_concept_rows(dE, ctx.plan, emb_w.shape, emb_w) if ctx.needs_input_grad[1] else None
+        gb = _combine_concept_rows(db, ctx.plan, emb_b.shape, emb_b) if need_b else None
         return d_hidden, gw, gb, None, None, None, None, None
 
 
@@ -489,12 +521,14 @@ class _EmbRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb_w, emb_b, cols_dev, plan):
         ctx.plan, ctx.shapes = plan, (emb_w.shape, emb_b.shape)
+        ctx.save_for_backward(emb_w, emb_b)                  # (the leaves: their persistent gradients can take the rows directly)
         return emb_w.index_select(0, cols_dev), emb_b.index_select(0, cols_dev)
 
     @staticmethod
     def backward(ctx, gw_rows, gb_rows):
-        gw = _combine_concept_rows(gw_rows.contiguous(), ctx.plan, ctx.shapes[0]) if ctx.needs_input_grad[0] else None
-        gb = _combine_concept_rows(gb_rows.contiguous(), ctx.plan, ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        emb_w, emb_b = ctx.saved_tensors
+        gw = _combine_concept_rows(gw_rows.contiguous(), ctx.plan, ctx.shapes[0], emb_w) if ctx.needs_input_grad[0] else None
+        gb = _combine_concept_rows(gb_rows.contiguous(), ctx.plan, ctx.shapes[1], emb_b) if ctx.needs_input_grad[1] else None
         return gw, gb, None, None
 
 

@@ -201,6 +201,12 @@ int dfol_gather_rows_f32(const float* src, const int32_t* idx, int32_t P, int32_
 /* Segmented row sum: out[q][:] = sum_{p in seg q} src[p][:]   (mm(pqm^T, X), batch_gqa_ops.py:457). */
 int dfol_segment_sum_rows_f32(const float* src, const int32_t* seg_off, int32_t Q, int32_t width, float* out,
                               void* stream);
+/* Per-predicate gradient rows of the embedding layer combined per concept (visual_oracle._combine_concept_rows: gather_rows +
+ * segment_sum_rows + index_copy in one launch): out[ucols[u]][c] (accumulate: +)= sum over the slots k in [seg_off[u], seg_off[u + 1]) of
+ * rows[order[k]][c], added in slot order (predicates naming the same concept in predicate order: repeatable bit for bit, no atomics);
+ * ucols unique.  With accumulate = 1 and `out` the weight's gradient itself, the dense zero-filled intermediate never exists. */
+int dfol_concept_rows_f32(const float* rows, int64_t ld_rows, const int32_t* order, const int32_t* seg_off, const int64_t* ucols, int32_t U,
+                          int32_t width, float* out, int64_t ld_out, int32_t accumulate, void* stream);
 
 /* Elementwise log-space logic on vectors: util.py:29-36.  b is ignored for DFOL_LOGIC_NOT. */
 int dfol_logic_f32(int32_t op, const float* a, const float* b, int64_t n, float* out, void* stream);
@@ -595,6 +601,27 @@ int dfol_attr_ll_bwd_f32(const float* g, const float* hidden, int64_t ld_hidden,
 /* from the NORMALISED values y (the softmax weight of option p is exp(y_p)). */
 int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, const int32_t* seg_off, int32_t S, const int32_t* pred_q,
                                   const int32_t* n_obj, int32_t NS, int32_t rank, float* g_x, void* stream);
+
+/* ---- the tail of a train step over the flat gradient bucket (round 5; csrc/dfol_optim.hip) -------------------------------------------------
+ * Replaces nn.utils.clip_grad_norm_ + torch.optim.Adam.step() of trainer.py:439-441 (seventeen launches of their foreach forms) when every
+ * gradient is a view into ONE contiguous fp32 buffer `g` (parallel.GradBucket).  Deterministic, no atomics; equal to torch's result to a few
+ * ulp per step (another summation order of the norm, fused multiply-adds).
+ * grad_sqnorm: partials[dfol_grad_sqnorm_parts()] <- per-workgroup sums of g^2 (g 16-byte aligned).
+ * clip_adam:   total = sqrt(sum partials); coef = min(1, max_norm / (total + 1e-6)) (max_norm <= 0: 1); for tensor t of n_tensors -
+ *              param[t], exp_avg[t], exp_avg_sq[t]: device ADDRESSES of its fp32 arrays (numel[t] elements), its gradient at g + goff[t] -
+ *              g <- g coef (left behind, as clip_grad_norm_ does), [g += weight_decay p], exp_avg <- lerp(exp_avg, g, 1 - beta1),
+ *              exp_avg_sq <- beta2 exp_avg_sq + (1 - beta2) g^2, p <- p - lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).
+ *              The work is cut into n_chunks chunks of dfol_clip_adam_chunk() elements: chunk c covers tensor chunk_tensor[c] from element
+ *              chunk_start[c].  step: step_ptr[t] = address of tensor t's fp32 step counter on the device (read, +1, written back by a
+ *              one-workgroup launch behind the update: torch's capturable Adam), or step_ptr NULL and step_host = the count of THIS update
+ *              (>= 1).  norm_out (or NULL) <- total. */
+int32_t dfol_grad_sqnorm_parts(void);
+int32_t dfol_clip_adam_chunk(void);
+int dfol_grad_sqnorm_f32(const float* g, int64_t n, float* partials, void* stream);
+int dfol_clip_adam_f32(float* g, const float* partials, const int64_t* param, const int64_t* exp_avg, const int64_t* exp_avg_sq, const int64_t* goff,
+                       const int64_t* numel, int32_t n_tensors, const int32_t* chunk_tensor, const int64_t* chunk_start, int32_t n_chunks,
+                       const int64_t* step_ptr, float step_host, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                       float* norm_out, void* stream);
 
 /* ---- fp16 range status (round 5) ------------------------------------------------------------------------------------------------
  * The two-piece fp16 dense kernels split their activations UNSCALED (dfol_linear_act_h2_f32, dfol_linear_logit_h2_f32: |x| > 65504 makes

@@ -40,7 +40,7 @@ def test_binding_table_matches_header(lib):
     for name, argtypes in lib.SIGNATURES.items():
         m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, text, flags=re.S)
         assert m, name
-        assert len([a for a in m.group(1).split(",") if a.strip()]) == len(argtypes), name
+        assert len([a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]) == len(argtypes), name
 
 
 def test_abi_version_and_error_channel(lib):

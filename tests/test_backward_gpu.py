@@ -538,6 +538,78 @@ def test_attr_ll_backward_against_autograd(n_list, k_list, H):
         assert (got.double() - want).abs().max().item() <= 2e-5 * scale, name
 
 
+def test_concept_rows_one_launch_equals_the_three_kernel_form():
+    """dfol_concept_rows_f32 (per-predicate gradient rows of the embedding layer combined per concept, one launch) against gather_rows +
+    segment_sum_rows + index_copy into a zeroed matrix, bit for bit; and the direct form - rows added straight into a persistent gradient -
+    against the dense intermediate followed by autograd's add."""
+    from dfol_vqa_amd import _lib, visual_oracle as VO
+    rng = np.random.RandomState(8)
+    for width, P, C in ((300, 768, 2335), (1, 768, 2335), (12, 5, 9)):
+        cols = rng.randint(0, C, size=P)
+        cols[rng.rand(P) < 0.1] = -1
+        plan = VO._concept_plan(cols, torch.device(DEV), _lib.LRUCache(4))
+        order, seg_off, ucols = plan
+        rows = torch.tensor(rng.normal(size=(P, width)).astype(np.float32), device=DEV)
+        shape = (C, width) if width > 1 else (C,)
+        rr = rows if width > 1 else rows[:, 0].contiguous()
+        old = torch.zeros(C, width, device=DEV)
+        old.index_copy_(0, ucols, _lib.segment_sum_rows(_lib.gather_rows(rows, order), seg_off))
+        new = VO._combine_concept_rows(rr, plan, shape)
+        assert torch.equal(new.reshape(C, width), old)
+        leaf = torch.nn.Parameter(torch.zeros(shape, device=DEV))
+        leaf.grad = torch.tensor(rng.normal(size=shape).astype(np.float32), device=DEV)
+        want = leaf.grad + old.reshape(shape)
+        with VO.direct_grad():
+            assert VO._combine_concept_rows(rr, plan, shape, leaf) is None
+        assert torch.equal(leaf.grad, want)
+        assert VO._combine_concept_rows(rr, plan, shape, leaf) is not None          # outside the context: a returned value
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_clip_adam_equals_torch(capturable):
+    """training.FusedClipAdam (csrc/dfol_optim.hip: the norm of the flat gradient bucket + one update pass, 2 - 3 launches) against
+    nn.utils.clip_grad_norm_ + torch.optim.Adam.step() (trainer.py:439-441): parameters, both moments, the clipped gradients left behind, the
+    step counters and the total norm over three steps - with gradients above and below the clip threshold, weight decay, a tensor shorter
+    than a chunk and a bucket whose length is not a multiple of four.  The state lives in the torch optimizer object: a plain
+    optimizer.step() afterwards continues from it."""
+    from dfol_vqa_amd import parallel, training
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(300, 256), (300,), (512, 2048), (7,), (333, 300), (3,)]
+    for wd, scale in ((0.0, 3.0), (1e-2, 1e-3)):
+        ref = [torch.nn.Parameter(torch.randn(*s, device=DEV, generator=g)) for s in shapes]
+        mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+        o_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd, capturable=capturable)
+        o_mine = torch.optim.Adam(mine, lr=1e-2, weight_decay=wd, capturable=capturable)
+        bucket = parallel.GradBucket(mine)
+        fused = training.FusedClipAdam.make(o_mine, bucket)
+        assert fused is not None and training.FusedClipAdam.make(torch.optim.AdamW(mine), bucket) is None
+        for step in range(3):
+            grads = [torch.randn(*s, device=DEV, generator=g) * scale * (step + 1) for s in shapes]
+            bucket.zero_()
+            for p, q, gr in zip(ref, mine, grads):
+                p.grad = gr.clone()
+                q.grad.copy_(gr)
+            norm_ref = torch.nn.utils.clip_grad_norm_(ref, 0.65)
+            o_ref.step()
+            norm = fused.step(0.65)
+            assert abs(float(norm) - float(norm_ref)) <= 1e-5 * float(norm_ref)
+            for p, q in zip(ref, mine):
+                close = lambda a, b, what: (a - b).abs().max().item() <= 2e-6 * max(1e-3, b.abs().max().item()) or pytest.fail("%s step %d" % (what, step))
+                close(q.detach(), p.detach(), "parameter")
+                close(q.grad, p.grad, "clipped gradient")
+                close(o_mine.state[q]["exp_avg"], o_ref.state[p]["exp_avg"], "exp_avg")
+                close(o_mine.state[q]["exp_avg_sq"], o_ref.state[p]["exp_avg_sq"], "exp_avg_sq")
+                assert float(o_mine.state[q]["step"]) == float(o_ref.state[p]["step"]) == step + 1
+                assert o_mine.state[q]["step"].device == o_ref.state[p]["step"].device
+        for p, q in zip(ref, mine):                                  # torch's own step continues from the fused steps' state
+            p.grad = torch.ones_like(p)
+            q.grad.fill_(1.0)
+        o_ref.step()
+        o_mine.step()
+        for p, q in zip(ref, mine):
+            assert (q.detach() - p.detach()).abs().max().item() <= 5e-6 * max(1e-3, p.detach().abs().max().item())
+
+
 def test_train_step_is_bitwise_repeatable(ontology):
     """One train step (forward, loss, backward, clip, Adam) on the needed-columns dataflow, twice from the same state: identical
     loss, gradients and updated weights, bit for bit - the backward kernels sum in a fixed order instead of using atomics.

@@ -557,7 +557,14 @@ def linear_pack_w_split(weight, transpose=False, pieces=3):
     transpose=True packs weight^T (the operand of the backward product g @ W) under the ORIGINAL parameter's key, so a train step
     finds it by the parameter's version instead of inserting one dead entry per temporary transposed copy."""
     key = (_dp(weight), weight._version, tuple(weight.shape), weight.stride(0), bool(transpose), pieces)
+    if weight.grad_fn is not None:
+        # a TEMPORARY built from parameters inside a train step (the joined U | V weight: torch.cat of two column blocks): a new tensor every
+        # step, so keyed by address it left one dead 4 - 6 MB entry per step and pushed live parameters out of the FIFO.  One slot per shape
+        # instead, valid only for the very tensor it was packed from.
+        key = ("temporary", 0, tuple(weight.shape), weight.stride(0), bool(transpose), pieces)
     hit = _SPLIT_W_CACHE.get(key)
+    if hit is not None and hit[0] is not weight and weight.grad_fn is not None:
+        hit = None
     if hit is None:
         src = weight.detach().t().contiguous() if transpose else weight
         N, K = src.shape

@@ -7,6 +7,8 @@ kernels instead of doing dictionary look-ups and regular-expression matches per 
 
 import re
 
+import threading
+
 import numpy as np
 import torch
 
@@ -91,27 +93,51 @@ _upload_cache = LRUCache(1024)
 
 
 class _PinnedRing(object):
-    """Host staging for small uploads: slices of ONE pinned buffer, copied with non_blocking=True.  A pageable host-to-device copy makes the
-    host wait for the stream (~20 us each, ~60 per fresh 256-question batch); from pinned memory the copy is queued behind the stream's work
-    and the host moves on.  A slice is reused only after the ring has wrapped, and wrapping waits for the stream once."""
+    """Host staging for small uploads: slices of ONE pinned buffer per device, copied with non_blocking=True.  A pageable host-to-device copy
+    makes the host wait for the stream (~20 us each, ~60 per fresh 256-question batch); from pinned memory the copy is queued behind the
+    stream's work and the host moves on.  A slice is reused only after the ring has wrapped, and wrapping waits for the DEVICE the ring
+    belongs to (every stream of it: the copies were queued on whatever stream was current).  `copy_to` stages and queues the copy under one
+    lock: collate / prefetch threads upload too."""
 
-    def __init__(self, nbytes=8 << 20):
+    def __init__(self, device=None, nbytes=8 << 20):
         self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self.view = self.buf.numpy()
         self.pos = 0
+        self.device = device
+        self.lock = threading.Lock()
 
     def stage(self, a):
         n = a.nbytes
         start = (self.pos + 15) & ~15
         if start + n > self.buf.numel():
-            torch.cuda.synchronize()                         # every copy queued from the ring so far has been consumed
+            torch.cuda.synchronize(self.device)              # every copy queued from the ring so far has been consumed
             start = 0
         self.view[start:start + n] = a.reshape(-1).view(np.uint8)
         self.pos = start + n
         return self.buf[start:start + n]
 
+    def copy_to(self, dst_bytes, a):
+        """dst_bytes (a flat uint8 device tensor of a.nbytes) <- a, through the ring, asynchronously."""
+        with self.lock:
+            dst_bytes.copy_(self.stage(a), non_blocking=True)
 
-_ring = None
+
+_rings = {}
+_rings_lock = threading.Lock()
+
+
+def ring_for(device):
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring = _rings.get(key)
+    if ring is None:
+        with _rings_lock:
+            ring = _rings.get(key)
+            if ring is None:
+                ring = _rings[key] = _PinnedRing(key)
+    return ring
+
+
 _TORCH_DTYPE = {np.dtype(k).str: v for k, v in ((np.float32, torch.float32), (np.int32, torch.int32), (np.int64, torch.int64), (np.uint8, torch.uint8),
                                                 (np.float64, torch.float64), (np.int16, torch.int16), (np.bool_, torch.bool))}
 
@@ -119,17 +145,14 @@ _TORCH_DTYPE = {np.dtype(k).str: v for k, v in ((np.float32, torch.float32), (np
 def upload(array, device):
     """Small host index arrays (segment offsets, keep lists, predicate -> question maps) as device tensors, uploaded once per
     content: the same arrays recur on every forward of a batch.  New content goes through a pinned staging ring (no host wait per copy)."""
-    global _ring
     a = np.ascontiguousarray(array)
     key = (str(device), a.dtype.str, a.shape, a.tobytes())
     hit = _upload_cache.get(key)
     if hit is None:
         dev = torch.device(device)
         if dev.type == "cuda" and a.ndim >= 1 and 0 < a.nbytes <= (1 << 20) and not torch.cuda.is_current_stream_capturing():
-            if _ring is None:
-                _ring = _PinnedRing()
             hit = torch.empty(a.shape, dtype=_TORCH_DTYPE.get(a.dtype.str) or torch.as_tensor(a[:0]).dtype, device=dev)
-            hit.view(torch.uint8).reshape(-1).copy_(_ring.stage(a), non_blocking=True)
+            ring_for(dev).copy_to(hit.view(torch.uint8).reshape(-1), a)
         else:
             hit = torch.as_tensor(a).to(device)
         _upload_cache[key] = hit

@@ -196,11 +196,9 @@ def blob_on(plan, device):
     hit = cache.get(key)
     if hit is None:
         from . import host_util
-        if host_util._ring is None:
-            host_util._ring = host_util._PinnedRing()
         hit = torch.empty(plan.blob.nbytes, dtype=torch.uint8, device=device)
         if plan.blob.nbytes <= (1 << 20) and not torch.cuda.is_current_stream_capturing():
-            hit.copy_(host_util._ring.stage(plan.blob), non_blocking=True)
+            host_util.ring_for(device).copy_to(hit, plan.blob)
         else:
             hit.copy_(torch.from_numpy(plan.blob))
         cache[key] = hit

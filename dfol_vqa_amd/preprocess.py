@@ -92,7 +92,11 @@ def pattern_singularize(word):
         return word
     for x in _SINGULAR_IE:
         if w.endswith(x + "s"):
-            return w[:-1]
+            # pattern 3.x returns the lower-cased word UNCHANGED here (`return w`: the loop variable of pattern 2.6, the singular, became the
+            # word when the function was refactored).  Not confirmable in this image - the library is absent - but the reference's own
+            # `irregulars` table (parse_utils.py:14) lists 'cookies' and 'brownies', two entries of this list, which it would not need if
+            # the library singularised them; its setup.py pins pattern >= 3.6.  Vocabularies built by the reference carry the quirk.
+            return w
     for x, singular in _SINGULAR_IRREGULAR.items():
         if w.endswith(x):
             return re.sub('(?i)' + x + '$', singular, word)

@@ -28,6 +28,9 @@ def _has_token_lists(column):
     return False
 
 
+_COPY = object()            # OperatorBatch(question_index=_COPY, process_args=False): a field-by-field copy, no token analysis
+
+
 class OperatorBatch(object):
     """One operator applied across the questions of a batch (data_pipeline.py:31-143)."""
 
@@ -52,9 +55,10 @@ class OperatorBatch(object):
         self._predicate_num = question_num
         self._predicate_question_map = None
         self._question_index = None
-        if not process_args:
-            self._question_index = question_index              # (a copy, to_cuda: the analysed fields are handed over, `_predicate_num` follows)
-        elif len(self._arguments) > 0 and _has_token_lists(self._arguments[0]):
+        if not process_args and question_index is _COPY:
+            # (to_cuda's internal copy: the analysed fields - `_question_index`, `_predicate_num` - are handed over by the caller)
+            pass
+        elif len(self._arguments) > 0 and _has_token_lists(self._arguments[0]):       # (also for pre-transposed arguments: data_pipeline.py:55-62)
             flat, batch_index = flatten_list(self._arguments[0])
             self._predicate_num = len(flat)
             if question_index is not None:
@@ -123,8 +127,8 @@ class OperatorBatch(object):
             self._predicate_question_map._host = self._question_index.tolist()
 
     def to_cuda(self, device, non_blocking=True):
-        res = OperatorBatch(self._op_name, self._arguments, self._question_num, self._is_terminal, mask=None,
-                            question_index=self._question_index, process_args=False)
+        res = OperatorBatch(self._op_name, self._arguments, self._question_num, self._is_terminal, mask=None, question_index=_COPY, process_args=False)
+        res._question_index = self._question_index
         # the small per-operator tensors (masks, predicate -> question maps, subject flags) go through the content-keyed upload: masks recur
         # from batch to batch (all ones, the same ragged patterns), and a new one is staged in pinned memory instead of a pageable,
         # stream-synchronising copy each (18 of them per fresh 256-question batch: 1.2 ms of host time)

@@ -2,8 +2,8 @@
 # Copies what tools/measure_all.sh <tag> left under gpurun_out/<tag>/ into profiles/ (tracked), named per round.  A source that is missing
 # or empty (a leg of measure_all that failed or timed out) is SKIPPED and reported - it never overwrites committed evidence - and the
 # script then exits non-zero.
-# usage: tools/collect_profiles.sh [tag]     (default r04)
-TAG=${1:-r04}
+# usage: tools/collect_profiles.sh [tag]     (default r05)
+TAG=${1:-r05}
 O=gpurun_out/$TAG
 missing=0
 take() {          # take <source> <destination> [filter]: copy (or, with "json", keep the last JSON line; "lines": all JSON lines; "clean": drop the amdgpu.ids noise)
@@ -35,4 +35,5 @@ take $O/traffic.json profiles/traffic.json
 take $O/roofline_rocprof.json profiles/roofline_rocprof.json
 take $O/train_traffic.md profiles/${TAG}_train_traffic.md
 for f in pmc_train_fetch_fp32 pmc_train_write_fp32 pmc_train_fetch_bf16 pmc_train_write_bf16; do take $O/$f.txt profiles/${TAG}_$f.txt; done
+for f in wide_kernel pmc_fetch_wide pmc_fetch_tiled train_launch_order_fp32 train_launch_order_bf16 train_tail_ab; do take $O/$f.txt profiles/${TAG}_$f.txt clean; done
 if [ $missing -gt 0 ]; then echo "collect_profiles: $missing source(s) skipped"; exit 1; fi

@@ -2,8 +2,8 @@
 # Round-end measurement pass (runs on the GPU box): rocprofv3 stats + HBM counters of the default bench command, the bench lines of
 # every configuration, kernel / operator / training / calibrated-forward benchmarks, per-step launch breakdowns and the PMC passes of
 # the two MFMA kernels.  Copy what should be judged from gpurun_out/ into profiles/ (named per round).
-# usage: tools/measure_all.sh [tag]      (default tag r04)
-TAG=${1:-r04}
+# usage: tools/measure_all.sh [tag]      (default tag r05)
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=gpurun_out/$TAG
@@ -50,6 +50,14 @@ bash tools/pmc_run.sh ${TAG}_insts "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD
 bash tools/pmc_run.sh ${TAG}_fetch "FETCH_SIZE" tools/bench_kernels.py > $O/pmc_fetch_microbench.txt 2>&1
 bash tools/pmc_run.sh ${TAG}_write "WRITE_SIZE" tools/bench_kernels.py > $O/pmc_write_microbench.txt 2>&1
 bash tools/train_traffic.sh $TAG > $O/train_traffic.log 2>&1
+# round 5: the wide dense kernel against the tiled one (time, and the bytes it fetches per launch), the launches of a train step in order,
+# the pair kernel's per-tick trace, the A/B of the train step's fused tail
+timeout 200 python tools/lab/time_wide.py > $O/wide_kernel.txt 2>&1
+DFOL_DENSE_WIDE=1 bash tools/pmc_run.sh ${TAG}_fetch_wide "FETCH_SIZE" tools/lab/time_wide.py child 25600 > $O/pmc_fetch_wide.txt 2>&1
+DFOL_DENSE_WIDE=0 bash tools/pmc_run.sh ${TAG}_fetch_tiled "FETCH_SIZE" tools/lab/time_wide.py child 25600 > $O/pmc_fetch_tiled.txt 2>&1
+bash tools/lab/train_launch_order.sh ${TAG}_fp32 --graph 0 > /dev/null 2>&1; cp gpurun_out/order_${TAG}_fp32.txt $O/train_launch_order_fp32.txt 2>/dev/null
+bash tools/lab/train_launch_order.sh ${TAG}_bf16 --graph 0 --mlp-math bf16 > /dev/null 2>&1; cp gpurun_out/order_${TAG}_bf16.txt $O/train_launch_order_bf16.txt 2>/dev/null
+bash tools/lab/ab_train.sh > $O/train_tail_ab.txt 2>&1
 tail -1 $O/bench_n100.json | cut -c1-300
 tail -1 $O/bench_c1_n36.json | cut -c1-200
 tail -1 $O/bench_c4_n256.json | cut -c1-200

@@ -74,7 +74,7 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--fresh-batches", type=int, default=56, help="batches of the `value_fresh_programs` leg: every step a different ProgramBatch through "
                     "collate -> lower -> eager launches (0 = skip; north_star / c1 workloads, one process)")
-    ap.add_argument("--fresh-workers", type=int, default=2, help="collate worker PROCESSES of the `value_fresh_programs` leg (the reference's DataLoader "
+    ap.add_argument("--fresh-workers", type=int, default=4, help="collate worker PROCESSES of the `value_fresh_programs` leg (the reference's DataLoader "
                     "workers, data_pipeline.py:893-898): they collate and lower, the launching process unpickles, uploads and launches; 0 = collate on "
                     "the launching thread under the batch before")
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
@@ -826,6 +826,8 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             return pending
 
         _route_counts()
+        kept, device_ms = [], [None]
+        phases = {"prepare_incl_wait_for_worker": 0.0, "launch": 0.0, "wait_for_answers": 0.0, "score": 0.0}
         try:
             # two batches in flight: batch i + 1 is prepared AND launched before batch i's answers are read back, so the device never waits
             # for the host's read-back / scoring / next launch (with one in flight it idled ~0.2 ms of every 2.3 ms batch)
@@ -836,13 +838,40 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             for i in range(n_batches):
                 nxt_pbs, nxt_pending = None, None
                 if i + 1 < n_batches:
+                    h0 = time.perf_counter()
                     nxt_pbs, nxt_sync = prepare(3 + i)
+                    h1 = time.perf_counter()
                     nxt_pending = launch(nxt_pbs, nxt_sync)
+                    h2 = time.perf_counter()
+                    phases["prepare_incl_wait_for_worker"] += h1 - h0
+                    phases["launch"] += h2 - h1
                     state["k"] += 1
-                training.compute_evaluation_metrics(pbs, pending.result())
+                h3 = time.perf_counter()
+                res = pending.result()
+                h4 = time.perf_counter()
+                training.compute_evaluation_metrics(pbs, res)
+                phases["wait_for_answers"] += h4 - h3
+                phases["score"] += time.perf_counter() - h4
+                if len(kept) < 16:
+                    kept.append(pbs)
                 pbs, pending = nxt_pbs, nxt_pending
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            # what the DEVICE needs for batches of this mix (more operators per question than the north-star program, two or three relation
+            # columns per image): the first 16 batches of the leg again, launched back to back with nothing read in between - their plans and
+            # side arrays are resident by now - between two HIP events
+            if kept and not stream_features:
+                for x in [model.forward_async(p, False) for p in kept[:2]]:
+                    x.result()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                again = [model.forward_async(p, False) for p in kept]
+                e1.record()
+                torch.cuda.synchronize()
+                device_ms[0] = e0.elapsed_time(e1) / len(kept)
+                for x in again:
+                    x.result()
         finally:
             if executor is not None:
                 executor.shutdown(wait=True, cancel_futures=True)
@@ -855,6 +884,10 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                  "bound": "the host->device link: %.0f KB of raw object features per question at %.1f GB/s of a 63 GB/s PCIe Gen5 x16 link" % (
                      h2d["bytes"] / (n_batches * B) / 1e3, gbps) if gbps > 0.6 * 63.0 else "see host_collate_ms_per_batch / ms_per_batch",
                  "features": "every batch's object features uploaded from pinned host memory on a copy stream (two device buffers), under the batch before"}
+    extra = dict(extra, launching_thread_ms_per_batch={k: v / n_batches * 1e3 for k, v in phases.items()})
+    if device_ms[0]:
+        extra = dict(extra, device_ms_per_batch=device_ms[0], vs_device_bound="%.2f x what the device alone needs for these batches (%.3f ms each, 16 of them "
+                     "launched back to back from resident plans)" % (device_ms[0] / (dt / n_batches * 1e3), device_ms[0]))
     return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B, "executor": route, **extra,
             "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead%s" % (workers, " (lost at batch %d: this process from there)" % lost[0] if lost else "")) if workers else "on the launching thread, while the device runs the batch before (forward_async)",
             "launch": "native executor: one dfol_run_program call per ProgramBatch, lowered at collate time" if route.get("native_program") else "eager (Python operator loop)",

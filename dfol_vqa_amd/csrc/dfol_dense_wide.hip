@@ -273,7 +273,10 @@ int wd_cus() {
 extern "C" int dfol_linear_wide_supported(int64_t M, int32_t N, int32_t K) {
     static const int on = getenv("DFOL_DENSE_WIDE") ? atoi(getenv("DFOL_DENSE_WIDE")) : 1;
     if (!on || N <= 256 || N > WD_NMAX || K < 4 * WD_BK || K % 4 != 0 || M >= (1ll << 31) - 256) return 0;
-    return on == 2 || (M + WD_BM - 1) / WD_BM >= (int64_t)wd_cus() * 3 / 4;
+    // (a block per CU and round: 25600 rows are 200 blocks = 0.78 of one round of 256 CUs; 40000 rows would be 313 blocks = 0.61 of two
+    // rounds, and there the tiled kernel's 1252 smaller tiles balance better: 307 us against 339)
+    const int64_t blocks = (M + WD_BM - 1) / WD_BM, rounds = (blocks + wd_cus() - 1) / wd_cus();
+    return on == 2 || 4 * blocks >= 3 * rounds * wd_cus();
 }
 
 extern "C" int dfol_linear_wide_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M, int32_t N,

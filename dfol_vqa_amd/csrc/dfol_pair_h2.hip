@@ -53,10 +53,6 @@ __device__ long long dfol_h2_trace_buf[8 * 8 * 64];
 #ifndef DFOL_H2_BDEPTH
 #define DFOL_H2_BDEPTH 2
 #endif
-// the U / V rows of the next chunk requested at the END of the build tick (1: as soon as make_a has consumed this chunk's) or after its barrier (0)
-#ifndef DFOL_H2_UV_EARLY
-#define DFOL_H2_UV_EARLY 0
-#endif
 // Y's chunk requests as inline asm (1): in flight across the build tick's closing barrier
 #ifndef DFOL_H2_DMA_ASM
 #define DFOL_H2_DMA_ASM 1
@@ -412,7 +408,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(ap[m][p]));
             __builtin_amdgcn_sched_barrier(0);
             if (Y && DFOL_H2_DMA_LATE && c >= 1 && c < lastc) dma_chunk(c + 1, (c + 1) & 1);
-            if (DFOL_H2_PREFETCH && DFOL_H2_UV_EARLY && c < lastc) load_uv(c + 1);
             TRACE(3 + 4 * c);
             // end of the build tick.  (__syncthreads() carries a release fence, for which the compiler drains the chunk request Y has just
             // issued - vmcnt(0) in front of the barrier.  Two ways around that wait were built and measured slower: the bare s_barrier
@@ -424,7 +419,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_sched_barrier(0);
             TRACE(4 + 4 * c);
             bbase = boff + (c & 1) * H2_PIECES;
-            if (DFOL_H2_PREFETCH && !DFOL_H2_UV_EARLY && c < lastc) load_uv(c + 1);      // lands under the MFMAs
+            if (DFOL_H2_PREFETCH && c < lastc) load_uv(c + 1);      // lands under the MFMAs
             chunk_mfma();
             if (Y) __builtin_amdgcn_s_waitcnt(0x0F70);      // the chunk requested in the build tick has landed
             TRACE(5 + 4 * c);
@@ -432,6 +427,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             TRACE(6 + 4 * c);
         }
     };
+    // (Round 5 also measured the form WITHOUT ping-pong - all eight wavefronts build a chunk, barrier, all eight multiply it: 1167 - 1184 us
+    // against 1144 - 1150; the SIMD's two wavefronts then multiply one after the other - the older one is served first - at 20.6 cycles per
+    // MFMA, profiles/r05_pair_h2_trace.txt.)
     if (wave < 4) run_half(std::false_type());
     else run_half(std::true_type());
 

@@ -3,7 +3,8 @@
 // workgroup per CU that owns 128 rows x ALL columns (256 < N <= 512), gfx950.
 //
 // csrc/dfol_dense_split.hip runs these shapes as 128 x 128 output tiles: with four column blocks every row of X is fetched and split into
-// its fp16 pieces FOUR times (counters: 3.2 x the 210 MB of the feature matrix per featurizer launch), and every tile pays a cold start.
+// its fp16 pieces FOUR times (three of the fetches are cache hits: the counters show 302 MB from memory for the 210 MB feature matrix of a
+// featurizer launch; this kernel: 247 MB, profiles/r05_pmc_fetch_*.txt), and every tile pays a cold start.
 // Here a workgroup of eight wavefronts reads and splits its X rows once per k-step and multiplies them with the weight tiles of all four
 // column blocks, staged through LDS as two column HALVES per k-step (2 x 32 KB; all four would not fit beside two A buffers):
 //

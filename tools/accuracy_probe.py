@@ -160,14 +160,17 @@ def main():
     S["obj"] = {"hip": stats(world._obj.cpu().numpy(), s64["obj"]), "numpy32": stats(s32["obj"], s64["obj"]), "torch32": stats(st["obj"], s64["obj"])}
     S["hidden_attr"] = {"hip": stats(world._hidden_attr.cpu().numpy(), s64["hidden_attr"]), "numpy32": stats(s32["hidden_attr"], s64["hidden_attr"]),
                         "torch32": stats(st["hidden_attr"], s64["hidden_attr"])}
-    S["uv"] = {"hip": stats(world._uv.cpu().numpy(), s64["uv"]), "numpy32": stats(s32["uv"], s64["uv"])}
+    # (the fp16x2 pair kernel takes U | V in units of ln 2: the oracle scales the stacked first-layer weight by log2 e)
+    uv_hip = world._uv.cpu().numpy() / (1.4426950408889634 if model._oracle._pair_kind() == "f16x2" else 1.0)
+    S["uv"] = {"hip": stats(uv_hip, s64["uv"]), "numpy32": stats(s32["uv"], s64["uv"])}
     S["hidden_rel"] = {"numpy32": stats(s32["hidden_rel"], s64["hidden_rel"]), "torch32": stats(st["hidden_rel"], s64["hidden_rel"])}
 
     # requested relation tiles: LogSigmoid(hidden_rel . E[col] + b[col]) in the tile layout
     n = args.objects
     NS = world._NS
     ridx = np.asarray(oont.relation_index)
-    (tiles, orient, fused), = list(world._rel_tiles.values())
+    entries = {id(e[0]): e for e in world._rel_tiles.values()}          # (an entry is filed under its operator's token list AND its lowered tokens)
+    (tiles, orient, fused), = [e[:3] for e in entries.values()]
     tiles = tiles.float().cpu().numpy()
     relate_op = [ob for ob in pbs[0]._op_batch_list if ob._op_name == "relate"][0]
     from dfol_vqa_amd.fol_types import TokenType

@@ -268,12 +268,15 @@ int wd_cus() {
 
 }  // namespace
 
-// The shapes the persistent wide kernel takes AND pays for: more than two column blocks (X would be split three or four times by the tiled
+// The shapes the persistent wide kernel takes AND pays for: four column blocks (X would be split three or four times by the tiled
 // kernel), at least four k-steps, and enough 128-row blocks to give three quarters of the CUs one (fewer: the tiled kernel's 64-row blocks
 // fill the chip better).  Both kernels return the same bits, so the choice may depend on M.  DFOL_DENSE_WIDE=0 switches it off (A/B runs).
 extern "C" int dfol_linear_wide_supported(int64_t M, int32_t N, int32_t K) {
     static const int on = getenv("DFOL_DENSE_WIDE") ? atoi(getenv("DFOL_DENSE_WIDE")) : 1;
+    // (N <= 384: the kernel would spend a full second half's MFMAs on a few columns - the 256 -> 300 attribute layer took 34.8 us here
+    // against 28 us tiled - so it leaves three-block outputs to the tiled kernel unless forced)
     if (!on || N <= 256 || N > WD_NMAX || K < 4 * WD_BK || K % 4 != 0 || M >= (1ll << 31) - 256) return 0;
+    if (on != 2 && N <= 384) return 0;
     // (a block per CU and round: 25600 rows are 200 blocks = 0.78 of one round of 256 CUs; 40000 rows would be 313 blocks = 0.61 of two
     // rounds, and there the tiled kernel's 1252 smaller tiles balance better: 307 us against 339)
     const int64_t blocks = (M + WD_BM - 1) / WD_BM, rounds = (blocks + wd_cus() - 1) / wd_cus();

@@ -256,8 +256,9 @@ int dfol_linear_act_h2_f32(const float* X, int64_t ldx, const void* W_split, con
 /* The same product for WIDE outputs (256 < N <= 512: the featurizer's 2048 -> 512, the pair MLP's stacked first layer 516 -> 512) as ONE
  * persistent workgroup per CU that owns 128 rows x all columns (csrc/dfol_dense_wide.hip): X is fetched and split into its pieces once
  * instead of once per 128-column block.  Same image, same limits on X (8-byte aligned rows, ldx % 2 == 0, K % 4 == 0; K >= 128), results
- * bit for bit those of dfol_linear_act_h2_f32 - which forwards here by itself when dfol_linear_wide_supported says the shape pays (enough
- * 128-row blocks for three quarters of the CUs; DFOL_DENSE_WIDE=0 never, =2 whenever the shape is taken). */
+ * bit for bit those of dfol_linear_act_h2_f32 - which forwards here by itself when dfol_linear_wide_supported says the shape pays (four
+ * column blocks: N > 384, and 128-row blocks that fill at least three quarters of the CUs in every round; DFOL_DENSE_WIDE=0 never, =2
+ * whenever the shape is taken). */
 int dfol_linear_wide_supported(int64_t M, int32_t N, int32_t K);
 int dfol_linear_wide_h2_f32(const float* X, int64_t ldx, const void* W_split, const float* bias, float* Y, int64_t ldy, int32_t M,
                             int32_t N, int32_t K, int32_t act, void* stream);

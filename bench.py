@@ -74,7 +74,8 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--fresh-batches", type=int, default=56, help="batches of the `value_fresh_programs` leg: every step a different ProgramBatch through "
                     "collate -> lower -> eager launches (0 = skip; north_star / c1 workloads, one process)")
-    ap.add_argument("--fresh-workers", type=int, default=4, help="collate worker PROCESSES of the `value_fresh_programs` leg (the reference's DataLoader "
+    ap.add_argument("--fresh-depth", type=int, default=2, help="batches queued on the device before the oldest one's answers are waited for (`value_fresh_programs`)")
+    ap.add_argument("--fresh-workers", type=int, default=6, help="collate worker PROCESSES of the `value_fresh_programs` leg (the reference's DataLoader "
                     "workers, data_pipeline.py:893-898): they collate and lower, the launching process unpickles, uploads and launches; 0 = collate on "
                     "the launching thread under the batch before")
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
@@ -832,20 +833,20 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             # two batches in flight: batch i + 1 is prepared AND launched before batch i's answers are read back, so the device never waits
             # for the host's read-back / scoring / next launch (with one in flight it idled ~0.2 ms of every 2.3 ms batch)
             t0 = time.perf_counter()
-            pbs, sync = prepare(2)
-            pending = launch(pbs, sync)
-            state["k"] += 1
+            import collections
+            depth = 2 if stream_features else max(2, int(getattr(args, "fresh_depth", 2)))       # (the streamed form owns two feature buffers)
+            inflight, launched = collections.deque(), 0
             for i in range(n_batches):
-                nxt_pbs, nxt_pending = None, None
-                if i + 1 < n_batches:
+                while len(inflight) < depth and launched < n_batches:      # keep `depth` batches queued on the device before any answer is waited for
                     h0 = time.perf_counter()
-                    nxt_pbs, nxt_sync = prepare(3 + i)
+                    p, sy = prepare(2 + launched)
                     h1 = time.perf_counter()
-                    nxt_pending = launch(nxt_pbs, nxt_sync)
-                    h2 = time.perf_counter()
+                    inflight.append((p, launch(p, sy)))
                     phases["prepare_incl_wait_for_worker"] += h1 - h0
-                    phases["launch"] += h2 - h1
+                    phases["launch"] += time.perf_counter() - h1
+                    launched += 1
                     state["k"] += 1
+                pbs, pending = inflight.popleft()
                 h3 = time.perf_counter()
                 res = pending.result()
                 h4 = time.perf_counter()
@@ -854,7 +855,6 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                 phases["score"] += time.perf_counter() - h4
                 if len(kept) < 16:
                     kept.append(pbs)
-                pbs, pending = nxt_pbs, nxt_pending
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             # what the DEVICE needs for batches of this mix (more operators per question than the north-star program, two or three relation

@@ -311,10 +311,10 @@ class _Builder(object):
         (active == 0 copies the prior row), so no launch is needed - only names and quantifiers follow the mask; otherwise a real gate."""
         if mask is None or x is prev:
             return x
-        if len(mask) != x.rows or x.rows != prev.rows or any(m == 0 and v for m, v in zip(mask, valid)) or any(m not in (0, 1) for m in mask):
+        g = np.asarray(mask, np.float32)
+        if len(mask) != x.rows or x.rows != prev.rows or bool(((g == 0) & np.asarray(valid, bool)[:len(mask)]).any()) or not bool(((g == 0) | (g == 1)).all()):
             return self.gate(x, prev, mask)
         names = self.gate_names(x.names, prev.names, mask)
-        g = np.asarray(mask, np.float32)
         return _VS(names, x.att, x.rows, g * x.quant + (1.0 - g) * prev.quant, x.pq, 0)
 
     def relate(self, i, prev, relation_list, is_subject, names_tokens, key):

@@ -204,8 +204,54 @@ class _LazyOps(list):
         return (list, (list(self.host),))
 
 
+class _PickledOps(list):
+    """The operator batches of a ProgramBatch that crossed a process boundary WITH a native plan: kept as pickled bytes until somebody
+    reads them (the Python operator loop, a trace).  The launching process of a stream of unseen batches needs the plan, the answers and the
+    terminal operator's name - rebuilding ~11 operator batches of 256 token lists each was 0.5 ms of its ~1 ms per batch."""
+
+    def __init__(self, blob, count, last_name):
+        super(_PickledOps, self).__init__()
+        self._blob, self._count, self.last_name, self._loaded = blob, count, last_name, False
+
+    def _load(self):
+        if not self._loaded:
+            import pickle
+            self._loaded = True
+            super(_PickledOps, self).extend(pickle.loads(self._blob))
+            self._blob = None
+
+    def __len__(self):
+        return self._count
+
+    def __getitem__(self, i):
+        self._load()
+        return super(_PickledOps, self).__getitem__(i)
+
+    def __iter__(self):
+        self._load()
+        return super(_PickledOps, self).__iter__()
+
+    def __reduce__(self):
+        if self._loaded:
+            return (list, (list(super(_PickledOps, self).__iter__()),))
+        return (_PickledOps, (self._blob, self._count, self.last_name))
+
+
 class ProgramBatch(object):
     """A batch of aligned programs plus its scenes (data_pipeline.py:147-290)."""
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        ops = d.get("_op_batch_list")
+        if d.get("_native_plan") is not None and ops is not None and not isinstance(ops, _PickledOps):
+            import pickle
+            host = list(getattr(ops, "host", ops))
+            if host:
+                d["_op_batch_list"] = _PickledOps(pickle.dumps(host, protocol=pickle.HIGHEST_PROTOCOL), len(host), host[-1]._op_name)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
 
     def __init__(self, device, op_batch_list, dependencies, answers, object_features, object_batch_index=None, original_dicts=None,
                  meta_data=None, object_nums=None, question_image=None):
@@ -274,7 +320,8 @@ class ProgramBatch(object):
     def terminal_op_name(self):
         """Name of the last operator batch (the metrics' slot, trainer.py:477-485) - without uploading a lazily moved batch's operators."""
         ops = self._op_batch_list
-        return (ops.host[-1] if isinstance(ops, _LazyOps) else ops[-1])._op_name
+        host = ops.host if isinstance(ops, _LazyOps) else ops
+        return getattr(host, "last_name", None) or host[-1]._op_name
 
     def to(self, dtype):
         if dtype != torch.float32:

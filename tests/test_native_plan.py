@@ -133,3 +133,39 @@ def test_lazy_operator_upload_keeps_the_host_view(setup):
     assert len(lazy) == len(pb._op_batch_list) and list.__len__(lazy) == 0 and not lazy._moved
     assert pickle.loads(pickle.dumps(lazy)) is not None and isinstance(pickle.loads(pickle.dumps(lazy)), list)
     assert pb.terminal_op_name() == "exist"
+
+
+def test_operator_batches_travel_as_bytes_beside_a_plan(setup):
+    """A ProgramBatch pickled WITH a plan (collate worker -> launching process) carries its operator batches as bytes: length and the
+    terminal operator's name are there without opening them, the first read opens them, and a batch without a plan pickles as before."""
+    from dfol_vqa_amd.program import _PickledOps
+    ont, names, categories, spec = setup
+    qs = syn.full_size_questions("verify_rel", 5, 5, 9, names, categories, 21)
+    for q in qs:
+        q["scene"]["X"] = q["scene"]["X"][:, -22:]
+    pb = FeatureCollater(1, ont, spec).collate(qs)[0]
+    want = [ob._op_name for ob in pb._op_batch_list]
+    got = pickle.loads(pickle.dumps(pb))
+    ops = got._op_batch_list
+    assert isinstance(ops, _PickledOps) and len(ops) == len(want) and got.terminal_op_name() == want[-1] and not ops._loaded
+    assert isinstance(got._native_plan, NP.NativePlan) and got._answers == pb._answers and got.batch_size() == pb.batch_size()
+    again = pickle.loads(pickle.dumps(got))                                  # unopened: the bytes travel on as they are
+    assert isinstance(again._op_batch_list, _PickledOps) and not again._op_batch_list._loaded
+    assert [ob._op_name for ob in ops] == want and ops._loaded and ops[-1]._op_name == want[-1]
+    assert [ob._op_name for ob in pickle.loads(pickle.dumps(got))._op_batch_list] == want
+    plain = pickle.loads(pickle.dumps(FeatureCollater(1, ont).collate(qs)[0]))
+    assert type(plain._op_batch_list) is list and [ob._op_name for ob in plain._op_batch_list] == want
+
+
+def test_fused_clip_adam_steps_aside_without_a_gpu_bucket():
+    """training.FusedClipAdam.make -> None for CPU parameters (and train_batch then runs torch's clip_grad_norm_ + Adam.step())."""
+    from dfol_vqa_amd import parallel, training
+    params = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(4))]
+    opt = torch.optim.Adam(params, lr=1e-2)
+    bucket = parallel.GradBucket(params)
+    assert training.FusedClipAdam.make(opt, bucket) is None and training.FusedClipAdam.make(opt, None) is None
+    before = [p.detach().clone() for p in params]
+    for p in params:
+        p.grad.fill_(1.0)
+    training.clip_and_step(torch.nn.ParameterList(params), opt, 0.65, bucket, training._fused_for(opt, bucket))
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(before, params))

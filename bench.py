@@ -648,17 +648,21 @@ def data_main(args, rank, world, device, td, share):
 _FW = {}                                                         # state of a collate worker process of the fresh-programs leg
 
 
-def _fresh_worker_init(paths, names, kinds, B, N, seeds, spec=None):
+def _fresh_worker_init(paths, names, kinds, B, N, seeds, spec=None, drop_dir=None):
     """A collate worker: its own ontology (no GPU work in this process), and every batch's question dicts generated up front from their
     seeds - like the launching process, which generates its dicts before the clock starts (a DataLoader worker reads decoded questions)."""
     import dfol_vqa_amd as D
     from dfol_vqa_amd import experiment, synthetic as syn
+    # a collate worker runs index bookkeeping on tiny tensors: ONE thread (torch's default is every hardware thread of the box - 256 here -
+    # per process, and a pool of workers then fights over the cores with its own idle OpenMP teams)
+    torch.set_num_threads(1)
     ontology = experiment.build_ontology(syn.reference_config(paths))
     with open(paths["attribute_file"]) as f:
         cats = json.load(f)
     # (spec: the model's widths, native_exec.model_spec - the worker then also lowers every batch to the native executor's instruction table)
     _FW["coll"] = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ontology, native_spec=spec)
     _FW["N"] = N
+    _FW["drop_dir"] = drop_dir
     _FW["qs"] = {b: syn.full_size_questions(kinds[b % len(kinds)], B, N, N, names, cats, seed, with_scene=False) for b, seed in seeds.items()}
 
 
@@ -673,7 +677,16 @@ def _fresh_worker_batch(b):
     # rebuilding 10 k small objects under the interpreter lock while the main thread launches; OperatorBatch.__getstate__ sends the small
     # tensors as numpy arrays)
     import pickle
-    return pickle.dumps(pbs, protocol=pickle.HIGHEST_PROTOCOL)
+    blob = pickle.dumps(pbs, protocol=pickle.HIGHEST_PROTOCOL)
+    if _FW.get("drop_dir"):
+        # ~330 KB per batch: through the executor's result pipe they are read by a thread of the launching process that needs the interpreter
+        # lock the launching thread holds most of the time - the writers then block on a full pipe, and MORE workers made the leg SLOWER
+        # (12 workers: 88 - 114 k questions/s against 125 - 147 k with 6).  A file in memory instead; the path goes through the pipe.
+        path = os.path.join(_FW["drop_dir"], "batch_%d.bin" % b)
+        with open(path, "wb") as f:
+            f.write(blob)
+        return path
+    return blob
 
 
 def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_batches=56, pool=4, stream_features=False):
@@ -771,9 +784,11 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             import pickle
             from concurrent.futures import ProcessPoolExecutor
             seeds = {b: 5000 + 97 * rank + b for b in range(2, n_batches + 3)}
+            import tempfile
+            drop_dir = tempfile.mkdtemp(prefix="dfol_fresh_%d_" % rank, dir="/dev/shm") if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
             try:
                 executor = ProcessPoolExecutor(workers, mp_context=multiprocessing.get_context("spawn"), initializer=_fresh_worker_init,
-                                               initargs=(paths, names, kinds, B, N, seeds, spec))
+                                               initargs=(paths, names, kinds, B, N, seeds, spec, drop_dir))
                 list(executor.map(int, range(workers * 2)))      # the workers are up (and have generated their dicts) before the clock starts
             except Exception as exc:                             # (a host that cannot start them: this process collates, and the line says so)
                 print("bench: collate workers unavailable (%s); collating on the launching thread" % exc, file=sys.stderr)
@@ -795,6 +810,11 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                     for ahead in range(b, b + 2 * workers + 1):
                         request(ahead)
                     blob = futures.pop(b).result()               # (not counted as host time of this process while it waits)
+                    if isinstance(blob, str):                    # (a path under /dev/shm: see _fresh_worker_batch)
+                        with open(blob, "rb") as f:
+                            data = f.read()
+                        os.unlink(blob)
+                        blob = data
                 except Exception as exc:
                     print("bench: collate worker lost (%s); collating on the launching thread from batch %d" % (exc, b), file=sys.stderr)
                     lost.append(b)
@@ -875,6 +895,9 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
         finally:
             if executor is not None:
                 executor.shutdown(wait=True, cancel_futures=True)
+            if workers and drop_dir:
+                import shutil
+                shutil.rmtree(drop_dir, ignore_errors=True)
         host = host_s[0]
     route = _route_counts()
     extra = {}

@@ -1369,11 +1369,19 @@ __global__ void concept_rows_kernel(const float* __restrict__ rows, int64_t ld_r
     const int u = blockIdx.x;
     const int k0 = seg_off[u], k1 = seg_off[u + 1];
     float* __restrict__ dst = out + ucols[u] * ld_out;
-    for (int c = threadIdx.x; c < width; c += blockDim.x) {
-        float s = 0.f;
-        for (int k = k0; k < k1; ++k) s += rows[(int64_t)order[k] * ld_rows + c];
-        dst[c] = accumulate ? dst[c] + s : s;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    // four rows' loads in flight, added in slot order (the chain of a segment's rows is latency-bound: a load per row, each behind its index)
+    float s = 0.f;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        const int r0 = order[k], r1 = order[k + 1], r2 = order[k + 2], r3 = order[k + 3];
+        const float v0 = rows[(int64_t)r0 * ld_rows + c], v1 = rows[(int64_t)r1 * ld_rows + c], v2 = rows[(int64_t)r2 * ld_rows + c],
+                    v3 = rows[(int64_t)r3 * ld_rows + c];
+        s = (((s + v0) + v1) + v2) + v3;
     }
+    for (; k < k1; ++k) s += rows[(int64_t)order[k] * ld_rows + c];
+    dst[c] = accumulate ? dst[c] + s : s;
 }
 
 extern "C" int dfol_concept_rows_f32(const float* rows, int64_t ld_rows, const int32_t* order, const int32_t* seg_off, const int64_t* ucols, int32_t U,
@@ -1381,7 +1389,7 @@ extern "C" int dfol_concept_rows_f32(const float* rows, int64_t ld_rows, const i
     DFOL_REQUIRE(U >= 0 && width > 0 && ld_rows >= width && ld_out >= width, "concept_rows: bad sizes");
     if (U == 0) return 0;
     DFOL_REQUIRE(rows && order && seg_off && ucols && out, "concept_rows: null pointer");
-    hipLaunchKernelGGL(concept_rows_kernel, dim3(U), dim3(width >= 256 ? 256 : 64), 0, (hipStream_t)stream, rows, ld_rows, order, seg_off, ucols, width,
+    hipLaunchKernelGGL(concept_rows_kernel, dim3(U, dfol_cdiv(width, 64)), dim3(64), 0, (hipStream_t)stream, rows, ld_rows, order, seg_off, ucols, width,
                        out, ld_out, accumulate);
     DFOL_LAUNCH_CHECK("concept_rows");
     return 0;

@@ -838,10 +838,16 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             host_s[0] += time.perf_counter() - h0
             return pbs, sync
 
+        marks = []                                               # (first launch, last launch) of every batch on the device's clock
+
         def launch(pbs, sync):
             if sync is not None:
                 torch.cuda.current_stream().wait_event(sync[0])  # this batch's features have landed
+            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            m0.record()
             pending = model.forward_async(pbs, False)
+            m1.record()
+            marks.append((m0, m1))
             if sync is not None:
                 sync[1].record()                                 # its buffer may be overwritten once these launches are done
             return pending
@@ -877,6 +883,10 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                     kept.append(pbs)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            # the device's own clock over the loop: time inside the batches (first to last launch of each) and idle time between them
+            inside = sum(a.elapsed_time(b) for a, b in marks)
+            between = sum(max(0.0, marks[i][1].elapsed_time(marks[i + 1][0])) for i in range(len(marks) - 1))
+            loop_clock = {"inside_batches_ms_per_batch": inside / len(marks), "idle_between_batches_ms_per_batch": between / len(marks)}
             # what the DEVICE needs for batches of this mix (more operators per question than the north-star program, two or three relation
             # columns per image): the first 16 batches of the leg again, launched back to back with nothing read in between - their plans and
             # side arrays are resident by now - between two HIP events
@@ -907,7 +917,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                  "bound": "the host->device link: %.0f KB of raw object features per question at %.1f GB/s of a 63 GB/s PCIe Gen5 x16 link" % (
                      h2d["bytes"] / (n_batches * B) / 1e3, gbps) if gbps > 0.6 * 63.0 else "see host_collate_ms_per_batch / ms_per_batch",
                  "features": "every batch's object features uploaded from pinned host memory on a copy stream (two device buffers), under the batch before"}
-    extra = dict(extra, launching_thread_ms_per_batch={k: v / n_batches * 1e3 for k, v in phases.items()})
+    extra = dict(extra, launching_thread_ms_per_batch={k: v / n_batches * 1e3 for k, v in phases.items()}, device_clock_in_the_loop=loop_clock)
     if device_ms[0]:
         extra = dict(extra, device_ms_per_batch=device_ms[0], vs_device_bound="%.2f x what the device alone needs for these batches (%.3f ms each, 16 of them "
                      "launched back to back from resident plans)" % (device_ms[0] / (dt / n_batches * 1e3), device_ms[0]))

@@ -186,6 +186,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 3      # include/dfol_vqa.h: DFOL_ABI_VERSION
+
+
 def load():
     """Load the library once; raise loudly if it has not been built."""
     global _lib
@@ -197,6 +200,9 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.dfol_last_error.restype = ctypes.c_char_p
     lib.dfol_abi_version.restype = ctypes.c_int
+    if lib.dfol_abi_version() != ABI_VERSION:        # a stale build answers wrongly without a message (UV units changed between 2 and 3)
+        raise DfolError("%s has ABI version %d, this host side needs %d: rebuild it (make -C dfol_vqa_amd/csrc)"
+                        % (LIB_PATH, lib.dfol_abi_version(), ABI_VERSION))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -285,6 +291,7 @@ F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
 
 # ---- fp16 range status (include/dfol_vqa.h: dfol_set_range_status) -----------------------------------------------------------------------------
 RANGE_X_OVERFLOW = 1
+RANGE_PAIR_SATURATED = 2
 _RANGE_WORDS = {}
 
 
@@ -308,6 +315,11 @@ class RangeWatch(object):
         if _KEEP is not None:
             _KEEP.append(host)
         host.copy_(self.word, non_blocking=True)
+        # cleared ON THE STREAM behind the copy: the next forward queued behind this one (test_epoch and the bench keep two or more in flight)
+        # starts from a clean word instead of inheriting this one's flag until the host gets round to its check
+        self.word.zero_()
+        # the library's pointer is a thread-local of THIS thread: later direct calls - possibly on another device - must not OR into this word
+        load().dfol_set_range_status(None)
         word, dev = self.word, self.device
         # (an event behind the copy: waiting for the STREAM would also wait for whatever was queued after this forward - the next batch of a
         # pipelined loop; a captured forward has no event of its own: its replay's owner waits for the stream)
@@ -329,6 +341,8 @@ class RangeWatch(object):
                 what = []
                 if v & RANGE_X_OVERFLOW:
                     what.append("an input of a dense layer (object features, or a hidden activation) is beyond fp16's largest finite value 65504 or NaN")
+                if v & RANGE_PAIR_SATURATED:
+                    what.append("a first-layer sum of the relation MLP reaches the fused pair kernel's saturation point (ELU outputs beyond 4.16e4) or is NaN")
                 raise DfolError("fp16 range exceeded in the two-piece fp16 arithmetic (dense math 'f16x2', the default): %s. The results of this "
                                 "forward are not valid. Use `mlp_math: bf16x3` (config key; three bf16 pieces, fp32's exponent range) or "
                                 "DFOL_DENSE_MATH=bf16x3 / DFOL_PAIR_MATH=bf16x3, or normalise the features." % "; ".join(what))

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ g, c
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
     const float total = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
-    const float coef = h.max_norm > 0.f ? fminf(h.max_norm / (total + 1e-6f), 1.0f) : 1.0f;
+    // torch's clip_grad_norm_: clamp(max_norm / (total + 1e-6), max = 1) - a NaN norm gives a NaN coefficient that poisons every gradient
+    // (fminf would drop the NaN and step on), max_norm = 0 zeroes the gradients; max_norm < 0 = no clipping at all
+    const float coef = h.max_norm >= 0.f ? ((total != total) ? total : fminf(h.max_norm / (total + 1e-6f), 1.0f)) : 1.0f;
     const int t = chunk_tensor[blockIdx.x];
     // the step count of this update: a device counter per tensor (capturable optimizers) or a host value
     float step = step_host;

@@ -272,10 +272,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // under Y's multiply tick, whose closing s_waitcnt vmcnt(0) is theirs)
             const uint32_t d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(dst + 64 * g);
             const u32x4* sp = src + 64 * g;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sp), "s"(__builtin_amdgcn_readfirstlane(d)) : "memory");
-            if (g + 1 < PER_WAVE / 64) asm volatile("global_load_lds_dwordx4 %0, off offset:1024" ::"v"(sp) : "memory");
-            if (g + 2 < PER_WAVE / 64) asm volatile("global_load_lds_dwordx4 %0, off offset:2048" ::"v"(sp) : "memory");
-            if (g + 3 < PER_WAVE / 64) asm volatile("global_load_lds_dwordx4 %0, off offset:3072" ::"v"(sp) : "memory");
+            // (ONE asm block per group, M0 in its clobber list: the compiler may write M0 itself - the builtin form at the kernel's top, readlane /
+            // movrel - and must neither place such a write between the group's requests nor assume M0 keeps its earlier value: ADVICE r5)
+            // (the target keeps M0 reserved - the compiler sets it right before each of its own uses - so clang warns about the clobber; it is still
+            // recorded as a definition of M0, which is what the pass that merges identical M0 settings looks at)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(d);
+            const int rem = PER_WAVE / 64 - g;                      // requests of this group (compile-time after unrolling): 4, 4, 2
+            if (rem >= 4)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" ::"v"(sp), "s"(m0v) : "memory", "m0");
+            else if (rem == 3)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048" ::"v"(sp), "s"(m0v) : "memory", "m0");
+            else if (rem == 2)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024" ::"v"(sp), "s"(m0v) : "memory", "m0");
+            else
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sp), "s"(m0v) : "memory", "m0");
+#pragma clang diagnostic pop
 #else
             auto d = (__attribute__((address_space(3))) void*)(dst + 64 * g);
             __builtin_amdgcn_global_load_lds(src + 64 * g, d, 16, 0, 0);
@@ -500,6 +515,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     TRACE(60);
 }
 
+// The range check of pair_ll32h_kernel, outside it (its build tick is paced by its instruction count: the same test inside cost 4 %).  A pair's
+// ELU input z[k] = U[s][k] + V[o][k] + Wg[k] . geo(s, o) saturates above H2_AMAX (units of 1 / ln 2).  Per image and hidden unit k this kernel
+// bounds it from above by  max_s U[s][k] + max_o V[o][k] + |Wg[k]| . (dmax, pi / 2, 1, 1),  dmax = the diagonal of the box that holds the
+// image's centres - reached by a real pair unless the two maxima belong to the same object - and ORs DFOL_RANGE_PAIR_SATURATED into the
+// caller's status word when the bound passes H2_AMAX or is NaN.  One workgroup per image, thread t owns column t of the U|V rows (coalesced
+// 2 KB rows; the pair kernel reads the same rows next, so this pass also warms L2 / MALL for it): ~6 us at 256 x 100 objects.
+__global__ __launch_bounds__(512) void h2_uv_range_kernel(const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos,
+                                                          int64_t ld_pos, const float* __restrict__ Wg, const int32_t* __restrict__ n_obj,
+                                                          const int32_t* __restrict__ obj_off, uint32_t* __restrict__ status) {
+    __shared__ float colmax[512];
+    __shared__ float box[4][8];
+    const int q = blockIdx.x, n = n_obj[q], first = obj_off[q], t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (n < 2) return;
+    float m = -INFINITY;
+    bool nan = false;
+    if (t < 2 * HID1) {
+        const float* col = UV + (int64_t)first * ld_uv + t;
+        int o = 0;
+        for (; o + 4 <= n; o += 4) {
+            const float a = col[(int64_t)o * ld_uv], b = col[(int64_t)(o + 1) * ld_uv], c = col[(int64_t)(o + 2) * ld_uv], d = col[(int64_t)(o + 3) * ld_uv];
+            nan |= (a != a) | (b != b) | (c != c) | (d != d);
+            m = fmaxf(fmaxf(m, fmaxf(a, b)), fmaxf(c, d));
+        }
+        for (; o < n; ++o) {
+            const float a = col[(int64_t)o * ld_uv];
+            nan |= a != a;
+            m = fmaxf(m, a);
+        }
+    }
+    colmax[t] = nan ? NAN : m;
+    float lox = INFINITY, hix = -INFINITY, loy = INFINITY, hiy = -INFINITY;
+    for (int o = t; o < n; o += 512) {
+        const float* p = pos + (int64_t)(first + o) * ld_pos;
+        const float cx = p[0] + p[2] / 2.0f, cy = p[1] + p[3] / 2.0f;
+        lox = fminf(lox, cx), hix = fmaxf(hix, cx), loy = fminf(loy, cy), hiy = fmaxf(hiy, cy);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        lox = fminf(lox, __shfl_xor(lox, s, 64)), hix = fmaxf(hix, __shfl_xor(hix, s, 64));
+        loy = fminf(loy, __shfl_xor(loy, s, 64)), hiy = fmaxf(hiy, __shfl_xor(hiy, s, 64));
+    }
+    if (lane == 0) box[0][wave] = lox, box[1][wave] = hix, box[2][wave] = loy, box[3][wave] = hiy;
+    __syncthreads();
+    if (t < HID1) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) lox = fminf(lox, box[0][w]), hix = fmaxf(hix, box[1][w]), loy = fminf(loy, box[2][w]), hiy = fmaxf(hiy, box[3][w]);
+        const float dmax = sqrtf((hix - lox) * (hix - lox) + (hiy - loy) * (hiy - loy));
+        const float4 g = *reinterpret_cast<const float4*>(Wg + t * 4);
+        const float geo = H2_L2E * (fabsf(g.x) * dmax + fabsf(g.y) * 1.57079632679489661923f + fabsf(g.z) + fabsf(g.w));
+        const float bound = colmax[t] + colmax[HID1 + t] + geo;
+        if (!(bound <= H2_AMAX)) atomicOr(status, (uint32_t)DFOL_RANGE_PAIR_SATURATED);
+    }
+}
+
 }  // namespace
 
 #ifdef DFOL_PAIR_TRACE
@@ -539,6 +608,8 @@ extern "C" int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1,
     DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_ll_h2: too many tiles");
     DFOL_REQUIRE((int64_t)max_n * ld_uv * 4 < ((int64_t)1 << 31), "pair_ll_h2: an image's U / V rows must span less than 2 GB");
     const dim3 grid((unsigned)Q * tpi);
+    if (uint32_t* status = dfol_range_status_ptr())           // (dfol_set_range_status: saturated ELU outputs are reported, not answered with)
+        hipLaunchKernelGGL(h2_uv_range_kernel, dim3((unsigned)Q), dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, n_obj, obj_off, status);
 #define DFOL_PAIR32H(NBV, BF)                                                                                                       \
     hipLaunchKernelGGL((pair_ll32h_kernel<NBV, BF>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
                        E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)

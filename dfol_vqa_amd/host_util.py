@@ -95,8 +95,8 @@ _upload_cache = LRUCache(1024)
 class _PinnedRing(object):
     """Host staging for small uploads: slices of ONE pinned buffer per device, copied with non_blocking=True.  A pageable host-to-device copy
     makes the host wait for the stream (~20 us each, ~60 per fresh 256-question batch); from pinned memory the copy is queued behind the
-    stream's work and the host moves on.  A slice is reused only after the ring has wrapped, and wrapping waits for the DEVICE the ring
-    belongs to (every stream of it: the copies were queued on whatever stream was current).  `copy_to` stages and queues the copy under one
+    stream's work and the host moves on.  A slice is reused only after the ring has wrapped, and then waits for the events of the copies that
+    read it (one event per copy, recorded on the stream the copy was queued on).  `copy_to` stages and queues the copy under one
     lock: collate / prefetch threads upload too."""
 
     def __init__(self, device=None, nbytes=8 << 20):
@@ -105,21 +105,54 @@ class _PinnedRing(object):
         self.pos = 0
         self.device = device
         self.lock = threading.Lock()
+        self.pending = []                                    # [start, end, event or None, stream] of the copies queued from the ring, oldest first
+        self.unmarked = 0                                    # bytes queued since the last recorded event
+
+    def _mark(self):
+        """One event per stream covers every copy queued on that stream before it (an event per 100-byte upload would cost more host time
+        than the copy): the entries still without an event get one recorded NOW on their stream."""
+        events = {}
+        for e in self.pending:
+            if e[2] is None:
+                ev = events.get(e[3])
+                if ev is None:
+                    ev = events[e[3]] = torch.cuda.Event()
+                    ev.record(e[3])
+                e[2] = ev
+        self.unmarked = 0
 
     def stage(self, a):
         n = a.nbytes
         start = (self.pos + 15) & ~15
         if start + n > self.buf.numel():
-            torch.cuda.synchronize(self.device)              # every copy queued from the ring so far has been consumed
             start = 0
+        # a slice is rewritten only after the copies that read it have run: wait for THEIR events (a device-wide synchronize from a collate
+        # thread would invalidate a graph capture running on the main thread, and waits for every other stream's work as well)
+        hit = [i for i, e in enumerate(self.pending) if e[0] < start + n and start < e[1]]
+        if hit:
+            self._mark()
+            for i in hit:
+                self.pending[i][2].synchronize()
+            gone = set(hit)
+            self.pending = [e for i, e in enumerate(self.pending) if i not in gone]
         self.view[start:start + n] = a.reshape(-1).view(np.uint8)
         self.pos = start + n
-        return self.buf[start:start + n]
+        return self.buf[start:start + n], start
 
     def copy_to(self, dst_bytes, a):
         """dst_bytes (a flat uint8 device tensor of a.nbytes) <- a, through the ring, asynchronously."""
         with self.lock:
-            dst_bytes.copy_(self.stage(a), non_blocking=True)
+            src, start = self.stage(a)
+            dst_bytes.copy_(src, non_blocking=True)
+            st = torch.cuda.current_stream(dst_bytes.device)
+            last = self.pending[-1] if self.pending else None
+            if last is not None and last[2] is None and last[3] == st and last[1] <= start:
+                last[1] = start + a.nbytes                   # (a run of copies on one stream is one entry: the list stays a few dozen long)
+            else:
+                self.pending.append([start, start + a.nbytes, None, st])
+            self.unmarked += a.nbytes
+            if self.unmarked >= (256 << 10):
+                self._mark()
 
 
 _rings = {}

@@ -216,6 +216,7 @@ class BatchInterpreterBase(nn.Module):
         outer = gqa_ops.DEFERRED.queue
         queue = [] if outer is None else outer                 # (a graph capture installs its own queue, see GraphedForward)
         gqa_ops.DEFERRED.queue = queue
+        watch = None
         try:
             # `_mlp_math` (config key `mlp_math`, experiment.build_interpreter): "bf16" runs the large dense products of the featurizer and
             # the oracle MLPs - forward, and through the autograd functions' recorded mode their backward - on bf16-rounded operands with
@@ -233,6 +234,8 @@ class BatchInterpreterBase(nn.Module):
                     queue.append(check)
         finally:
             gqa_ops.DEFERRED.queue = outer
+            if watch is not None:
+                _lib.load().dfol_set_range_status(None)          # (also when the forward raised before watch.finish())
         if outer is None:
             for fill in queue:
                 fill()

@@ -63,6 +63,8 @@ def _layers(seq):
     while i < len(mods):
         m = mods[i]
         if isinstance(m, nn.Dropout):
+            if m.training and m.p > 0:               # a model left in train(): the Python loop raises there (visual_oracle._run_layers), the
+                return None                          # reference would drop activations - the executor must not silently run without it
             i += 1
             continue
         if not isinstance(m, nn.Linear):

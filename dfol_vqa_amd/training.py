@@ -146,6 +146,13 @@ class FusedClipAdam(object):
         param, m, v, step = self._address_tables()
         step_host = 0.0
         if not self._capturable:                             # host step counters: torch keeps them as 0-d CPU tensors
+            steps = set(float(self._opt.state[p]["step"]) for p in self._params)
+            if len(steps) > 1:
+                # per-parameter counts differ (a partial load_state_dict): the kernel takes ONE host step for its bias corrections
+                if clip_norm is not None:
+                    nn.utils.clip_grad_norm_(self._params, clip_norm)
+                self._opt.step()
+                return None
             for p in self._params:
                 self._opt.state[p]["step"] += 1
             step_host = float(self._opt.state[self._params[0]]["step"])
@@ -153,7 +160,7 @@ class FusedClipAdam(object):
         _lib.call("dfol_clip_adam_f32", bucket.flat.data_ptr(), self._partials.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(),
                   self._goff.data_ptr(), self._numel.data_ptr(), len(self._params), self._chunk_tensor.data_ptr(), self._chunk_start.data_ptr(),
                   self._n_chunks, step.data_ptr() if self._capturable else None, step_host, float(g0["lr"]), float(g0["betas"][0]),
-                  float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(clip_norm) if clip_norm else 0.0,
+                  float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), -1.0 if clip_norm is None else float(clip_norm),
                   self.total_norm.data_ptr(), _lib._stream())
         _lib.keep_alive((self._partials, param, m, v, step, self._goff, self._numel, self._chunk_tensor, self._chunk_start, self.total_norm))
         torch.autograd.graph.increment_version(self._params)  # (written behind autograd's back: version-keyed weight images must miss)

@@ -37,7 +37,10 @@
 extern "C" {
 #endif
 
-#define DFOL_ABI_VERSION 2
+/* 3 (round 6): dfol_pair_ll_h2_f32 takes UV in units of ln 2 and dfol_pair_pack_w2_f16x2 folds ln 2 into W2 (the round-5 change of contract that
+ * kept version 2: a caller written against 2 passes unscaled UV and must be refused, not answered wrongly); dfol_pair_ll_h2_f32 reports saturated
+ * ELU outputs through the dfol_set_range_status word (DFOL_RANGE_PAIR_SATURATED); dfol_run_program knows the calibration instructions. */
+#define DFOL_ABI_VERSION 3
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int dfol_abi_version(void);
@@ -413,7 +416,8 @@ int dfol_pair_ll_split_f32(const float* UV, int64_t ld_uv, int32_t HID1, const f
  * weight and bias by log2(e) once per weight update (dfol_vqa_amd/visual_oracle.py:_split_first_layer); Wg is passed as it is (the kernel
  * scales its 1 K geometry weights itself) and dfol_pair_pack_w2_f16x2 folds the factor ln 2 into W2.  The ELU then costs two instructions per
  * element - v_exp_f32 with the clamp modifier (2^min(z', 0)) and one fma - instead of four; a build tick of this kernel is paced by its
- * instruction count (csrc/dfol_pair_h2.hip).  Activations saturate at 6e4 in those units, i.e. at ELU outputs of 4.16e4.
+ * instruction count (csrc/dfol_pair_h2.hip).  Activations saturate at 6e4 in those units, i.e. at ELU outputs of 4.16e4; with a status
+ * word set (dfol_set_range_status) a saturating batch is flagged DFOL_RANGE_PAIR_SATURATED.
  * All other arguments, the ordered-pairs-only enumeration (pre-fill the tiles with default_ll: the diagonal and the padding keep that
  * fill) and the limits as dfol_pair_ll_split_f32: HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320.
  * Replaces classifier_oracle.py:145-156 for the relation columns a program names (gqa_interpreter_experiments.py:18-36, 60-77). */
@@ -608,7 +612,7 @@ int dfol_option_normalize_bwd_f32(const float* g_y, const float* y, const int32_
  * gradient is a view into ONE contiguous fp32 buffer `g` (parallel.GradBucket).  Deterministic, no atomics; equal to torch's result to a few
  * ulp per step (another summation order of the norm, fused multiply-adds).
  * grad_sqnorm: partials[dfol_grad_sqnorm_parts()] <- per-workgroup sums of g^2 (g 16-byte aligned).
- * clip_adam:   total = sqrt(sum partials); coef = min(1, max_norm / (total + 1e-6)) (max_norm <= 0: 1); for tensor t of n_tensors -
+ * clip_adam:   total = sqrt(sum partials); coef = min(1, max_norm / (total + 1e-6)) as torch.nn.utils.clip_grad_norm_ (a NaN total gives a NaN coef; max_norm = 0 zeroes the gradients; max_norm < 0: no clipping, coef 1); for tensor t of n_tensors -
  *              param[t], exp_avg[t], exp_avg_sq[t]: device ADDRESSES of its fp32 arrays (numel[t] elements), its gradient at g + goff[t] -
  *              g <- g coef (left behind, as clip_grad_norm_ does), [g += weight_decay p], exp_avg <- lerp(exp_avg, g, 1 - beta1),
  *              exp_avg_sq <- beta2 exp_avg_sq + (1 - beta2) g^2, p <- p - lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).
@@ -632,10 +636,14 @@ int dfol_clip_adam_f32(float* g, const float* partials, const int64_t* param, co
  * remedy.  The pointer is a THREAD-LOCAL setting of the calling host thread (like dfol_last_error), picked up by the launches that
  * follow; NULL (the default) disables the check.  Cost: one v_max3 per two elements the kernel converts anyway (not measurable: the
  * dense layers of a step take 0.323 ms with it, 0.33 without), one atomic per workgroup in the failing case only.
- * (dfol_pair_ll_h2_f32 SATURATES its ELU outputs at 6e4 instead - reaching that needs first-layer weights of magnitude ~58; the same
- * check there was built and measured at +4 % of the step's dominant kernel - its build tick is paced by its instruction count - and left out.)
+ * dfol_pair_ll_h2_f32 SATURATES its ELU outputs at 6e4 (units of 1 / ln 2; reaching that needs first-layer weights of magnitude ~58).  The
+ * test inside the kernel cost 4 % (its build tick is paced by its instruction count), so since round 6 a small kernel in front of it bounds
+ * every image's first-layer sums from above - max_s U[s][k] + max_o V[o][k] + |Wg[k]| . (largest centre distance, pi / 2, 1, 1), reached by
+ * a real pair unless both maxima sit on one object - and ORs DFOL_RANGE_PAIR_SATURATED when the bound passes the saturation point or is NaN
+ * (launched only while a status word is set; ~6 us at 256 x 100 objects, and it leaves the U|V rows in L2 for the pair kernel).
  */
 #define DFOL_RANGE_X_OVERFLOW 1u     /* an input element of a two-piece dense product is beyond fp16's largest finite value (or NaN) */
+#define DFOL_RANGE_PAIR_SATURATED 2u /* dfol_pair_ll_h2_f32: a first-layer sum may exceed the ELU saturation point 6e4 / log2(e) = 4.16e4 (or is NaN) */
 int dfol_set_range_status(uint32_t* device_word);
 
 /* ---- the native executor of a lowered ProgramBatch (round 5) -------------------------------------------------------------------------

@@ -45,7 +45,7 @@ def test_binding_table_matches_header(lib):
 
 def test_abi_version_and_error_channel(lib):
     h = lib.load()
-    assert h.dfol_abi_version() == 2
+    assert h.dfol_abi_version() == 3
     # argument errors are reported without touching a device (no GPU needed): NS not a multiple of 4
     rc = h.dfol_filter_fwd_f32(None, None, None, None, None, 0, None, 3, 6, None, None)
     assert rc != 0 and b"filter_fwd" in h.dfol_last_error()

@@ -610,6 +610,65 @@ def test_fused_clip_adam_equals_torch(capturable):
             assert (q.detach() - p.detach()).abs().max().item() <= 5e-6 * max(1e-3, p.detach().abs().max().item())
 
 
+def test_fused_clip_adam_edge_cases_follow_torch():
+    """a NaN gradient norm poisons gradients and parameters as clip_grad_norm_'s NaN coefficient does (fminf would have dropped
+    it and stepped on); clip_norm = 0 zeroes the gradients as the reference's call would (trainer.py:438), None means no clipping; and with
+    per-parameter step counts that differ (a partial load_state_dict) the step goes to torch's own, whose bias corrections are per tensor."""
+    from dfol_vqa_amd import parallel, training
+    g = torch.Generator(device=DEV).manual_seed(9)
+    shapes = [(64, 32), (32,), (5,)]
+
+    def pair():
+        ref = [torch.nn.Parameter(torch.randn(*s, device=DEV, generator=g)) for s in shapes]
+        mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+        o_ref, o_mine = torch.optim.Adam(ref, lr=1e-2), torch.optim.Adam(mine, lr=1e-2)
+        bucket = parallel.GradBucket(mine)
+        return ref, mine, o_ref, o_mine, bucket, training.FusedClipAdam.make(o_mine, bucket)
+
+    # NaN norm
+    ref, mine, o_ref, o_mine, bucket, fused = pair()
+    for p, q in zip(ref, mine):
+        p.grad = torch.ones_like(p)
+        q.grad.fill_(1.0)
+    ref[1].grad[3] = float("nan")
+    mine[1].grad[3] = float("nan")
+    torch.nn.utils.clip_grad_norm_(ref, 0.65)
+    o_ref.step()
+    fused.step(0.65)
+    for p, q in zip(ref, mine):
+        assert bool(torch.isnan(p.detach()).all()) and bool(torch.isnan(q.detach()).all())
+    # clip_norm = 0 and None
+    for clip in (0.0, None):
+        ref, mine, o_ref, o_mine, bucket, fused = pair()
+        for p, q in zip(ref, mine):
+            gr = torch.randn(*p.shape, device=DEV, generator=g)
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(ref, clip)
+        o_ref.step()
+        fused.step(clip)
+        for p, q in zip(ref, mine):
+            assert (q.detach() - p.detach()).abs().max().item() <= 2e-6 * max(1e-3, p.detach().abs().max().item()), clip
+            assert (q.grad - p.grad).abs().max().item() <= 1e-6, clip
+    # differing step counts
+    ref, mine, o_ref, o_mine, bucket, fused = pair()
+    for o, params in ((o_ref, ref), (o_mine, mine)):
+        for i, p in enumerate(params):
+            o.state[p]["step"] = torch.tensor(float(3 * i + 1))
+            o.state[p]["exp_avg"] = torch.full_like(p, 0.1)
+            o.state[p]["exp_avg_sq"] = torch.full_like(p, 0.2)
+    for p, q in zip(ref, mine):
+        gr = torch.randn(*p.shape, device=DEV, generator=g)
+        p.grad = gr.clone()
+        q.grad.copy_(gr)
+    torch.nn.utils.clip_grad_norm_(ref, 0.65)
+    o_ref.step()
+    fused.step(0.65)
+    for i, (p, q) in enumerate(zip(ref, mine)):
+        assert torch.equal(q.detach(), p.detach()) and float(o_mine.state[q]["step"]) == 3 * i + 2
+
+
 def test_train_step_is_bitwise_repeatable(ontology):
     """One train step (forward, loss, backward, clip, Adam) on the needed-columns dataflow, twice from the same state: identical
     loss, gradients and updated weights, bit for bit - the backward kernels sum in a fixed order instead of using atomics.

@@ -227,3 +227,46 @@ def test_fp16_range_overflow_raises_instead_of_nan(full, native, monkeypatch):
         finally:
             model._mlp_math = None
         assert bool(torch.isfinite(lp).all())
+
+
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_pair_kernel_saturation_raises(full, native, monkeypatch):
+    """the fused pair kernel clamps its ELU outputs at 4.16e4 (fp16 pieces).  First-layer sums scaled to ~1e5 used to come back
+    as a silently wrong relation tile; now the bound kernel in front of it flags DFOL_RANGE_PAIR_SATURATED and the forward raises.  A model
+    whose sums stay in range is not flagged (the same batch, unscaled), on either route."""
+    from torch import nn
+    model, ont, oont, names, categories = full
+    monkeypatch.setenv("DFOL_NATIVE", native)
+    qs = syn.full_size_questions("exist", 4, 10, 20, names, categories, 33)
+    pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q) for q in qs])]
+    lin1 = [m for m in model._oracle._relation_network._network if isinstance(m, nn.Linear)][0]
+    with torch.no_grad():
+        ref = model(pbs, False)["log_probability"].clone()
+        saved_w, saved_b = lin1.weight.clone(), lin1.bias.clone()
+        try:
+            lin1.weight.mul_(3.0e4)                              # sums of ~1e5 (the features are Sigmoid outputs: within fp16's range themselves)
+            lin1.bias.mul_(3.0e4)
+            with pytest.raises(_lib.DfolError, match="saturation"):
+                model(pbs, False)
+        finally:
+            lin1.weight.copy_(saved_w)
+            lin1.bias.copy_(saved_b)
+        assert torch.equal(model(pbs, False)["log_probability"], ref)
+
+
+def test_range_flag_belongs_to_its_own_forward(full, monkeypatch):
+    """with two forwards in flight the status word is cleared on the stream behind each forward's copy, so an overflow flagged by
+    batch A does not also condemn batch B queued behind it."""
+    model, ont, oont, names, categories = full
+    qs = syn.full_size_questions("exist", 4, 10, 20, names, categories, 21)
+    good = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q) for q in qs])]
+    bad_qs = [dict(q, scene=dict(q["scene"], X=q["scene"]["X"].copy())) for q in qs]
+    bad_qs[1]["scene"]["X"][3, 100] = 1.0e5
+    bad = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate(bad_qs)]
+    with torch.no_grad():
+        ref = model(good, False)["log_probability"].clone()
+        a = model.forward_async(bad, False)
+        b = model.forward_async(good, False)
+        with pytest.raises(_lib.DfolError, match="fp16 range"):
+            a.result()
+        assert torch.equal(b.result()["log_probability"], ref)

@@ -488,11 +488,51 @@ def main(argv=None):
                 if "policy" in out["parity"]:
                     out["parity"]["policy"] = {"applies": False, "why": "the fp32 tolerance policy does not apply to the opt-in bf16 tile storage"}
                 out["dtype"] = "f32 logic arithmetic on bf16 relation tiles"
+        out["config"]["legs"] = legs_summary(out)
         emit(json.dumps(out))
         sys.stdout.flush()
     if td is not None:
         td.barrier()
         td.destroy_process_group()
+
+
+def legs_summary(out):
+    """The honest loop rates, NUMBERS ONLY, inside a key the driver keeps (BENCH_rNN.json stores `config`, `roofline` and
+    `cpu_baseline` in full but only the NAMES of other top-level keys): questions/s of every leg, its ratio to `value`, the executor's route
+    counts of the fresh-programs loop and the logic kernels' HBM fractions (the north star's >= 0.5 bar on Relate / Filter)."""
+    v = float(out["value"])
+    legs = {"value": v}
+    for key, short in (("value_sustained", "sustained"), ("value_streamed", "streamed"), ("value_fresh_programs", "fresh"), ("value_end_to_end", "end_to_end")):
+        if out.get(key):
+            legs[short] = float(out[key])
+            legs[short + "_over_value"] = float(out[key]) / v
+    fp = out.get("fresh_programs") or {}
+    route = fp.get("executor") or {}
+    if fp:
+        legs["native_batches"] = int(route.get("native_program", 0))
+        legs["python_batches"] = int(route.get("python_program", 0))
+        if fp.get("device_ms_per_batch"):
+            legs["fresh_device_ms_per_batch"] = float(fp["device_ms_per_batch"])
+        legs["fresh_ms_per_batch"] = float(fp.get("ms_per_batch", 0.0))
+    ee = out.get("end_to_end") or {}
+    if ee.get("h2d_GBps"):
+        legs["end_to_end_h2d_GBps"] = float(ee["h2d_GBps"])
+    for row in out.get("kernels") or []:
+        name = str(row.get("kernel", ""))
+        for tag, short in (("relate_one_fwd (fused single-posterior", "hbm_frac_relate_one"), ("relate_fwd (both posteriors, RelateBatch", "hbm_frac_relate_both"),
+                           ("filter_fwd", "hbm_frac_filter"), ("quantify", "hbm_frac_quantify")):
+            if name.startswith(tag) and short not in legs and row.get("frac") is not None:
+                legs[short] = float(row["frac"])
+    par = out.get("parity") or {}
+    for k in ("questions_checked", "max_abs_dlp_well_conditioned", "max_abs_dp_vs_fp64", "max_abs_dp"):
+        if isinstance(par.get(k), (int, float)) and not isinstance(par.get(k), bool):
+            legs["parity_" + k] = par[k]
+    if isinstance(par.get("answers_agree"), str) and "/" in par["answers_agree"]:
+        a, b = par["answers_agree"].split("/")
+        legs["parity_answers_agree"], legs["parity_answers_of"] = int(a), int(b)
+    if isinstance(par.get("policy"), dict) and "pass" in par["policy"]:
+        legs["parity_policy_pass"] = int(bool(par["policy"]["pass"]))
+    return legs
 
 
 def data_main(args, rank, world, device, td, share):
@@ -931,7 +971,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
 
 def _route_counts():
     from dfol_vqa_amd import _lib as L
-    c = {k: v for k, v in L.PATH_COUNTS.items() if k == "native_program" or k.startswith("fallback:")}
+    c = {k: v for k, v in L.PATH_COUNTS.items() if k in ("native_program", "python_program") or k.startswith("fallback:")}
     L.PATH_COUNTS.clear()
     return c
 
@@ -1485,7 +1525,7 @@ def cpu_baseline(model, paths, questions, gpu_result, sample, parity_all=True, f
             if best_t is None or dtt < best_t[0]:
                 best_t = (dtt, rt, pb_size)
         dtt, rt, pbs_t = best_t
-        base = {"value": sample / dtt, "unit": "questions/s", "cores": th, "kind": "restatement",
+        base = {"value": sample / dtt, "unit": "questions/s", "cores": th, "kind": "port",
                 "sample": "%d questions of the same workload (N<=%d), torch-CPU restatement of the reference's flat-layout forward incl. full "
                           "[pairs,2335] tables (oracle/dfol_oracle_torch.py), %d threads (best of %s on this %d-thread host), ProgramBatch size %d, %.1f s"
                           % (sample, max(q["scene"]["n"] for q in head), th, sorted(timing), ncpu, pbs_t, dtt),

@@ -519,35 +519,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ELU input z[k] = U[s][k] + V[o][k] + Wg[k] . geo(s, o) saturates above H2_AMAX (units of 1 / ln 2).  Per image and hidden unit k this kernel
 // bounds it from above by  max_s U[s][k] + max_o V[o][k] + |Wg[k]| . (dmax, pi / 2, 1, 1),  dmax = the diagonal of the box that holds the
 // image's centres - reached by a real pair unless the two maxima belong to the same object - and ORs DFOL_RANGE_PAIR_SATURATED into the
-// caller's status word when the bound passes H2_AMAX or is NaN.  One workgroup per image, thread t owns column t of the U|V rows (coalesced
-// 2 KB rows; the pair kernel reads the same rows next, so this pass also warms L2 / MALL for it): ~6 us at 256 x 100 objects.
+// caller's status word when the bound passes H2_AMAX or is NaN.  One workgroup per image; 16-byte loads, four row groups side by side and four
+// rows of each in flight (the pair kernel reads the same rows next, so this pass also warms L2 / MALL for it).
 __global__ __launch_bounds__(512) void h2_uv_range_kernel(const float* __restrict__ UV, int64_t ld_uv, int HID1, const float* __restrict__ pos,
                                                           int64_t ld_pos, const float* __restrict__ Wg, const int32_t* __restrict__ n_obj,
                                                           const int32_t* __restrict__ obj_off, uint32_t* __restrict__ status) {
-    __shared__ float colmax[512];
+    // thread t: four columns 4 (t % G) .. of the rows t / G, t / G + R, ... (G = 2 HID1 / 4 threads cover a 2 HID1-float row with 16-byte loads,
+    // R = 512 / G row groups walk the image's rows side by side: 128 threads x 4 row groups at HID1 = 256)
+    __shared__ float4 part[512];
     __shared__ float box[4][8];
     const int q = blockIdx.x, n = n_obj[q], first = obj_off[q], t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (n < 2) return;
-    float m = -INFINITY;
+    const int G = (2 * HID1) / 4, R = 512 / G, cg = t % G, rg = t / G;          // (HID1 a multiple of 32, <= 256: G in {16, .., 128} divides 512)
+    float4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     bool nan = false;
-    if (t < 2 * HID1) {
-        const float* col = UV + (int64_t)first * ld_uv + t;
-        int o = 0;
-        for (; o + 4 <= n; o += 4) {
-            const float a = col[(int64_t)o * ld_uv], b = col[(int64_t)(o + 1) * ld_uv], c = col[(int64_t)(o + 2) * ld_uv], d = col[(int64_t)(o + 3) * ld_uv];
-            nan |= (a != a) | (b != b) | (c != c) | (d != d);
-            m = fmaxf(fmaxf(m, fmaxf(a, b)), fmaxf(c, d));
-        }
-        for (; o < n; ++o) {
-            const float a = col[(int64_t)o * ld_uv];
-            nan |= a != a;
-            m = fmaxf(m, a);
-        }
+    const float* base = UV + (int64_t)first * ld_uv + 4 * cg;
+    auto take = [&](const float4 a) {
+        nan |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w);
+        m.x = fmaxf(m.x, a.x), m.y = fmaxf(m.y, a.y), m.z = fmaxf(m.z, a.z), m.w = fmaxf(m.w, a.w);
+    };
+    int o = rg;
+    for (; o + 3 * R < n; o += 4 * R) {
+        const float4 a = *reinterpret_cast<const float4*>(base + (int64_t)o * ld_uv), b = *reinterpret_cast<const float4*>(base + (int64_t)(o + R) * ld_uv);
+        const float4 c = *reinterpret_cast<const float4*>(base + (int64_t)(o + 2 * R) * ld_uv), d = *reinterpret_cast<const float4*>(base + (int64_t)(o + 3 * R) * ld_uv);
+        take(a), take(b), take(c), take(d);
     }
-    colmax[t] = nan ? NAN : m;
+    for (; o < n; o += R) take(*reinterpret_cast<const float4*>(base + (int64_t)o * ld_uv));
+    if (nan) m.x = NAN;
+    part[t] = m;
     float lox = INFINITY, hix = -INFINITY, loy = INFINITY, hiy = -INFINITY;
-    for (int o = t; o < n; o += 512) {
-        const float* p = pos + (int64_t)(first + o) * ld_pos;
+    for (int i = t; i < n; i += 512) {
+        const float* p = pos + (int64_t)(first + i) * ld_pos;
         const float cx = p[0] + p[2] / 2.0f, cy = p[1] + p[3] / 2.0f;
         lox = fminf(lox, cx), hix = fmaxf(hix, cx), loy = fminf(loy, cy), hiy = fmaxf(hiy, cy);
     }
@@ -558,14 +560,23 @@ __global__ __launch_bounds__(512) void h2_uv_range_kernel(const float* __restric
     }
     if (lane == 0) box[0][wave] = lox, box[1][wave] = hix, box[2][wave] = loy, box[3][wave] = hiy;
     __syncthreads();
-    if (t < HID1) {
+    if (t < HID1) {                                                              // hidden unit k = t: U column k, V column HID1 + k
 #pragma unroll
         for (int w = 0; w < 8; ++w) lox = fminf(lox, box[0][w]), hix = fmaxf(hix, box[1][w]), loy = fminf(loy, box[2][w]), hiy = fmaxf(hiy, box[3][w]);
+        const float* pf = reinterpret_cast<const float*>(part);
+        float mu = -INFINITY, mv = -INFINITY;
+        bool bad = false;
+        for (int r = 0; r < R; ++r) {                                            // (a NaN travels in component x of its thread's partial)
+            const float u = pf[(r * G + t / 4) * 4 + (t & 3)], v = pf[(r * G + (HID1 + t) / 4) * 4 + (t & 3)];
+            const float ux = pf[(r * G + t / 4) * 4], vx = pf[(r * G + (HID1 + t) / 4) * 4];
+            bad |= (ux != ux) | (vx != vx);
+            mu = fmaxf(mu, u), mv = fmaxf(mv, v);
+        }
         const float dmax = sqrtf((hix - lox) * (hix - lox) + (hiy - loy) * (hiy - loy));
         const float4 g = *reinterpret_cast<const float4*>(Wg + t * 4);
         const float geo = H2_L2E * (fabsf(g.x) * dmax + fabsf(g.y) * 1.57079632679489661923f + fabsf(g.z) + fabsf(g.w));
-        const float bound = colmax[t] + colmax[HID1 + t] + geo;
-        if (!(bound <= H2_AMAX)) atomicOr(status, (uint32_t)DFOL_RANGE_PAIR_SATURATED);
+        const float bound = mu + mv + geo;
+        if (bad || !(bound <= H2_AMAX)) atomicOr(status, (uint32_t)DFOL_RANGE_PAIR_SATURATED);
     }
 }
 

@@ -272,6 +272,7 @@ class BatchInterpreterBase(nn.Module):
         return native_exec.model_spec(self)
 
     def _run_batches(self, program_batch_list, is_training, modulator_switch, return_trace=False):
+        from . import _lib
         all_traces, all_results = [], []
         device = program_batch_list[0].device
         spec = self._native_spec(is_training, modulator_switch, return_trace)
@@ -283,6 +284,7 @@ class BatchInterpreterBase(nn.Module):
                     all_results.append(native_exec.run(self, program_batch, plan, gqa_ops.DEFERRED.queue, give_answer=not is_training))
                     all_traces.append([])
                     continue
+            _lib.note("python_program")                         # (route counter: a ProgramBatch that ran the Python operator loop)
             world = self.build_scene(program_batch.device, program_batch._object_features, program_batch._object_batch_index,
                                      program_batch._meta_data, object_nums=getattr(program_batch, "_object_nums", None),
                                      question_image=getattr(program_batch, "_question_image", None))

@@ -208,18 +208,26 @@ def full_size_questions(kind, count, n_lo, n_hi, names, categories, seed, with_s
     return qs
 
 
-TRAIN_PARITY_CASES = {"binary_small": ("binary", 8, 20, 40), "query_rel_small": ("query_rel", 8, 20, 40),
-                      "binary_tall": ("binary", 20, 27, 34), "query_rel_tall": ("query_rel", 20, 27, 34)}
+# case -> (kind, questions, fewest objects, most objects, seed).  (The four round-5 cases keep the seeds they were captured with.)
+TRAIN_PARITY_CASES = {"binary_small": ("binary", 8, 20, 40, 1900), "binary_tall": ("binary", 20, 27, 34, 1901),
+                      "query_rel_small": ("query_rel", 8, 20, 40, 1902), "query_rel_tall": ("query_rel", 20, 27, 34, 1903),
+                      # round 6: the attribute-side terminals and the two-branch ones
+                      "query_attr_small": ("query_attr", 8, 20, 40, 1910), "choose_attr_small": ("choose_attr", 8, 20, 40, 1911),
+                      "verify_attrs_small": ("verify_attrs", 8, 20, 40, 1912), "and_small": ("and", 8, 20, 40, 1913),
+                      "compare_small": ("compare", 8, 20, 40, 1914), "two_same_small": ("two_same", 6, 20, 32, 1915),
+                      "all_different_small": ("all_different", 6, 20, 32, 1916), "and_tall": ("and", 20, 27, 34, 1917),
+                      "or_small": ("or", 8, 20, 40, 1918)}
 TRAIN_PARITY_WEIGHT_SEED = 19
 
 
 def train_parity_questions(case, names, categories):
     """Seeded questions for the full-size TRAIN STEP parity cases (golden family g19, tests/test_backward_gpu.py, tests/test_oracle_golden.py):
     select -> optional filters -> 1..3 relate hops (ragged: the aligned relate batches carry no-op tokens for the shorter programs; an
-    occasional `_` name and a negated token) -> exist (BINARY) or choose_rel (QUERY, two options per question).  The `_small` cases keep the
-    pair rows below the persistent kernels' threshold (16384 rows), the `_tall` cases above it."""
-    kind, count, n_lo, n_hi = TRAIN_PARITY_CASES[case]
-    seed = 1900 + sorted(TRAIN_PARITY_CASES).index(case)
+    occasional `_` name and a negated token) -> exist (BINARY), choose_rel (QUERY, two options per question) or - round 6 - one of the
+    attribute-side / two-branch terminals: query_attr (a 26-option category per question: the QUERY loss of trainer.py:207-230 over
+    208 predicates), choose_attr, verify_attrs, and / or, compare, two_same, all_different.  The `_small` cases keep the pair rows below the
+    persistent kernels' threshold (16384 rows), the `_tall` cases above it."""
+    kind, count, n_lo, n_hi, seed = TRAIN_PARITY_CASES[case]
     rng = np.random.RandomState(seed)
     nouns, rels = names["nouns"][:8], names["relations"][:5]
     cats = sorted(categories)[:3]
@@ -229,21 +237,50 @@ def train_parity_questions(case, names, categories):
     for i in range(count):
         qid = seed * 1000 + i
         branch = [op("select", pick(nouns + ["_"]))]
-        hops = 1 + i % 3 if kind == "binary" else i % 3            # the QUERY programs end with a relation operator of their own
+        hops = i % 3 if kind == "query_rel" else 1 + i % 3        # the choose_rel programs end with a relation operator of their own
         for _ in range(hops):
             if rng.uniform() < 0.4:
                 a_ = pick(attrs)
                 branch.append(op("filter", "not(%s)" % a_ if rng.uniform() < 0.25 else a_))
             r_ = pick(rels)
             branch.append(op("relate", "not(%s)" % r_ if rng.uniform() < 0.15 else r_, bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
+        branches = [branch]
         if kind == "binary":
             last, answer = op("exist"), ("yes" if rng.uniform() < 0.5 else "no")
-        else:
+        elif kind == "query_rel":
             ra, rb = rng.choice(len(rels), 2, replace=False)
             last = op("choose_rel", [rels[ra], rels[rb]], bool(rng.uniform() < 0.5), pick(nouns))
             answer = rels[ra] if rng.uniform() < 0.5 else rels[rb]
+        else:
+            if kind in ("and", "or", "compare", "two_same"):
+                # the second branch: select (a real name: compare's options are the two names) -> filter, every other one with a relate
+                b2 = [op("select", nouns[(nouns.index(branch[0]["arguments"][0]) + 1 + i % 3) % len(nouns)] if branch[0]["arguments"][0] != "_" else pick(nouns)),
+                      op("filter", pick(attrs))]
+                if i % 2:
+                    b2.append(op("relate", pick(rels), bool(rng.uniform() < 0.5), pick(nouns + ["_"])))
+                branches.append(b2)
+            cat = pick(cats)
+            yes_no = "yes" if rng.uniform() < 0.5 else "no"
+            if kind == "query_attr":
+                last, answer = op("query_attr", cat), categories[cat][rng.randint(len(categories[cat]))]
+            elif kind == "choose_attr":
+                ia, ib = rng.choice(len(categories[cat]), 2, replace=False)
+                last, answer = op("choose_attr", [categories[cat][ia], categories[cat][ib]]), categories[cat][ia if rng.uniform() < 0.5 else ib]
+            elif kind == "verify_attrs":
+                k = 1 + i % 2                                       # one or two attributes per question (the h5 encoder stores <= 2)
+                last, answer = op("verify_attrs", [pick(attrs) for _ in range(k)]), yes_no
+            elif kind in ("and", "or"):
+                last, answer = op(kind), yes_no
+            elif kind == "compare":
+                last = op("compare", pick(attrs), bool(rng.uniform() < 0.5))
+                n1 = branch[0]["arguments"][0]
+                answer = (n1 if n1 != "_" else "entity") if rng.uniform() < 0.5 else b2[0]["arguments"][0]
+            elif kind in ("two_same", "all_different"):
+                last, answer = op(kind, cat), yes_no
+            else:
+                raise ValueError(kind)
         n = int(rng.randint(n_lo, n_hi + 1))
-        qs.append(question(qid, [branch], last, answer, feature_scene(qid, n, 2048)))
+        qs.append(question(qid, branches, last, answer, feature_scene(qid, n, 2048)))
     return qs
 
 

@@ -898,8 +898,12 @@ class ClassifierOracle(OracleBase):
         if os.environ.get("DFOL_TRAIN_FUSED", "1") != "0" and world._hidden_attr.shape[1] <= 512 and emb.bias is not None and \
                 (len(pq) < 2 or bool(np.all(pq[1:] >= pq[:-1]))):
             plan = _concept_plan(cols, dev, self._index_cache)
+            _lib.note("attr_ll_fused")
             return _AttrLL.apply(world._hidden_attr, emb.weight, emb.bias, world._obj_off, upload(pq.astype(np.int32), dev),
                                  low.on(dev)[0], NS, plan)
+        if torch.device(dev).type == "cuda":
+            _lib.fallback("attribute columns in training (gathers + torch ops)",
+                          "DFOL_TRAIN_FUSED=0, a hidden width above 512, an embedding layer without bias or an unsorted predicate -> question map")
         n = np.asarray(world._n_list, np.int64)
         obj_off = np.concatenate([[0], np.cumsum(n)])
         flat = torch.full((P * NS,), -30.0, dtype=torch.float32, device=dev)

@@ -14,8 +14,10 @@ in any dtype with the weights as differentiable leaves, so the fused full-size t
 d(loss)/d(weight) of the reference's own formulation (tests/test_backward_gpu.py), pinned on golden g19 - the reference's own
 `_train_batch` gradients at full model size (tests/test_oracle_golden.py).
 
-Scope: select, filter, relate, exist, verify_rel, choose_rel (+ the implicit `end`), predicate lists longer than the question list
-(predicate_question_map) included.  Everything else raises NotImplementedError (the numpy oracle covers all 16 operators for parity).
+Scope of `run_questions` (the timed inference leg): select, filter, relate, exist.  Scope of `train_loss` / `execute_collated` since round 6:
+all 16 program operators + the implicit `end` (select, filter, relate, exist, verify_rel, choose_rel, verify_attrs, choose_attr,
+query_attr, and, or, all_same, all_different, two_same, two_different, compare), predicate lists longer than the question list
+(predicate_question_map) included.
 
 Each function cites the reference lines it restates (paths under /root/reference/src/nsvqa).
 """
@@ -356,6 +358,22 @@ def run_questions(ontology, questions, scenes, weights, split=1):
 _YES = ("yes", "yeah", "yep", "yup", "aye", "yea")
 
 
+def log_not(op):                                     # util.py:35-36
+    return safe_log(1.0 - op.exp())
+
+
+def log_or(a, b):                                    # util.py:32-33
+    return safe_log(1.0 - (1.0 - a.exp()) * (1.0 - b.exp()))
+
+
+def _flatten(list_of_lists):                         # util.flatten_list :52-57
+    return [x for l in list_of_lists for x in l], [i for i, l in enumerate(list_of_lists) for _ in l]
+
+
+def _category_options(world, category_list, names):  # batch_gqa_ops.py:305 (GQAOntology.query :114-124)
+    return [list(world.ontology.query(c if c not in ("name", "type") else n)) for c, n in zip(category_list, names)]
+
+
 def execute_collated(world, ops, deps):
     """The execution loop (batch_base_interpreter.py:145-172) over operator batches collated by oracle.dfol_oracle.collate_programs
     (data_pipeline.py:647-746): dependency-ordered dispatch, per-question mask gating (:166-167), implicit `end` (:75-76 of
@@ -377,6 +395,36 @@ def execute_collated(world, ops, deps):
         elif name == "choose_rel":
             lp, options = gqa_choose_rel(world, inputs[0], args[0], args[1], args[2])
             return lp, "query", options
+        elif name in ("choose_attr", "query_attr"):                                           # :215-228, :304-306
+            lists = args[0] if name == "choose_attr" else _category_options(world, args[0], inputs[0].names)
+            flat, bi = _flatten(lists)
+            return filter_batch(world, inputs[0], flat, bi).log_probability(), "query", lists
+        elif name == "verify_attrs":                                                          # :452-473
+            flat, bi = _flatten(args[0])
+            x = filter_batch(world, inputs[0], flat, bi, normalize=False)
+            att = torch.sparse.mm(x.pqm.transpose(0, 1), x.att)                               # the prior is counted once per attribute (:457)
+            return VarSet(inputs[0].names, att, inputs[0].quant, world).log_probability(), "binary", None
+        elif name in ("and", "or"):                                                           # :513-567
+            v1, v2 = inputs[0].log_probability(), inputs[1].log_probability()
+            return (v1 + v2 if name == "and" else log_or(v1, v2)), "binary", None
+        elif name in ("all_same", "all_different"):                                           # :582-608, :627-639
+            flat, bi = _flatten(_category_options(world, args[0], inputs[0].names))
+            x = filter_batch(world, inputs[0], flat, bi)
+            post = log_not(torch.sparse.mm(x.pqm, inputs[0].att) + log_not(x.att))           # (pre-condition ==> the same), before aggregation
+            lp = VarSet(x.names, post, torch.zeros(len(flat), dtype=world.dtype), world, x.pqm).log_probability()      # FOR_ALL
+            lp = log_not(torch.sparse.mm(x.pqm.transpose(0, 1), log_not(lp.unsqueeze(1))).squeeze(1))
+            return (lp if name == "all_same" else log_not(lp)), "binary", None
+        elif name in ("two_same", "two_different"):                                           # :654-681, :702-714
+            flat, bi = _flatten(_category_options(world, args[0], inputs[0].names))
+            x1, x2 = filter_batch(world, inputs[0], flat, bi), filter_batch(world, inputs[1], flat, bi)
+            lp = x1.log_probability() + x2.log_probability()
+            lp = log_not(torch.sparse.mm(x1.pqm.transpose(0, 1), log_not(lp.unsqueeze(1))).squeeze(1))
+            return (lp if name == "two_same" else log_not(lp)), "binary", None
+        elif name == "compare":                                                               # :730-758
+            x1, x2 = filter_batch(world, inputs[0], args[0]), filter_batch(world, inputs[1], args[0])
+            lp = F.log_softmax(torch.stack([x1.log_probability(), x2.log_probability()]).transpose(0, 1).contiguous(), dim=1)
+            alpha = torch.tensor([float(bool(v)) for v in args[1]], dtype=world.dtype).unsqueeze(1)
+            return log_parametric_not(lp, alpha, 1).view(-1), "query", list(zip(inputs[0].names, inputs[1].names))
         else:
             raise NotImplementedError(name)
         if inputs and ob["mask"] is not None:

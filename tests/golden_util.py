@@ -100,6 +100,10 @@ def decided_answers(cm, lp32, lp64):
 
 
 G19_CASES = ["binary_small", "query_rel_small", "binary_tall", "query_rel_tall"]
+# round 6: the attribute-side and two-branch terminals (QUERY loss over a category's 26 options, choose_attr, verify_attrs, and / or,
+# compare, two_same, all_different) - VERDICT r5 #1
+G19_ATTR_CASES = ["query_attr_small", "choose_attr_small", "verify_attrs_small", "and_small", "and_tall", "or_small", "compare_small", "two_same_small",
+                  "all_different_small"]
 
 
 def g19_case(name, arrays, meta):

@@ -1308,10 +1308,12 @@ def _g19_step(model, ont, qs):
 
 
 @pytest.mark.parametrize("name,sums", [("binary_small", "auto"), ("query_rel_small", "auto"), ("binary_tall", "auto"), ("query_rel_tall", "auto"),
-                                       ("binary_tall", "1"), ("query_rel_small", "1")])
+                                       ("binary_tall", "1"), ("query_rel_small", "1")] + [(n, "auto") for n in gu.G19_ATTR_CASES] + [("and_tall", "1")])
 def test_g19_full_size_train_step_against_the_reference(g19_setup, name, sums, monkeypatch):
     """ONE `train_batch` forward + backward of the full-size model (2048 -> 512, 516 / 1036 -> 256 -> 300 -> 2335, dropout 0) on ragged 20..40
-    object scenes with 0..3 relate hops, no-op tokens in the aligned relate batches and choose_rel option lists - through the FUSED training
+    object scenes with 0..3 relate hops, no-op tokens in the aligned relate batches and choose_rel option lists - and, round 6, the attribute-side
+    and two-branch terminals (query_attr over 26-option categories, choose_attr, verify_attrs, and / or, compare, two_same, all_different;
+    trainer.py:207-230's QUERY loss over <= 208 predicates) - through the FUSED training
     kernels (asserted: `_FusedHidden1`, `_PairTrunk`, `_HeadUse`, `_EmbRows`, the second-evaluation route for readers that cannot register
     with the trunk; no fallback to torch / vendor operators) - against (1) golden g19 = the reference's own `_train_batch` (loss,
     log-probabilities, norm and 4096 sampled entries of all twelve weight gradients; trainer.py:181-262, 429-442) and (2) the reference's
@@ -1331,6 +1333,8 @@ def test_g19_full_size_train_step_against_the_reference(g19_setup, name, sums, m
     assert routes.get("head_use_backward_sums" if sums == "1" else "head_use_backward", 0) >= 1, routes
     if name.startswith("binary"):                                # ragged hop counts: the aligned relate batches hold no-op tokens
         assert routes.get("pair_second_evaluation", 0) == 1 and routes.get("logit_rows_gathered", 0) >= 1, routes
+    if name in gu.G19_ATTR_CASES:                                # round 6: the attribute-side terminals read their columns through the fused
+        assert routes.get("attr_ll_fused", 0) >= 1, routes       # attribute-column function (visual_oracle._AttrLL), not gathers + tensor ops
     pairs = sum(q["scene"]["n"] * (q["scene"]["n"] - 1) for q in qs)
     assert (pairs >= 16384) == name.endswith("_tall")
     l32, l64 = ref["f32"][0], ref["f64"][0]

@@ -869,6 +869,74 @@ def test_g17_full_size_reference_goldens(g17_model, name):
         assert res["options"] == cm["options"]
 
 
+def _round_bf16(x):
+    """float32 array rounded to the nearest bf16 (ties to even), as csrc/dfol_pair_h2.hip stores a relation tile element."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+@pytest.mark.parametrize("tiles", ["f32", "bf16"])
+def test_g20_configs4_open_programs_against_the_reference(g17_model, tiles, tmp_path):
+    """BASELINE configs[4] verbatim against the REFERENCE ITSELF (golden g20, tools/capture_goldens.py g20: the imported reference at full
+    model size on 3 questions x 256-object scenes, select -> (filter -> relate) x 4 -> query_attr over a 26-option category).
+    fp32 tiles: the policy's defaults (K = 2, p_tol 1e-6, lp_tol 1e-4), decided answers and option lists equal.
+    bf16 tiles (configs[4]'s "bf16"): two bounds, both stated here.  (a) Against the reference's fp64 run: a stored log-likelihood l becomes
+    l (1 + d), |d| <= 2^-9; a relate hop's aggregate is a (soft) maximum / sum of terms l + prior over the pairs, whose log-domain value
+    moves by at most 2^-9 max|l| per hop, so after the program's four relates |lp - lp64| <= 4 x 2^-9 x L + 2 x the reference's own
+    fp32-vs-fp64 deviation + 1e-4, L = the largest |log-likelihood| in the relation columns the programs name (taken from the oracle's
+    tables).  (b) Against the oracle run in fp64 ON the bf16-rounded relation table - the same arithmetic as the kernels' up to fp32
+    rounding of the MLP in front of the rounding step - |dlp| <= 2e-3 and |dp| <= 1e-5 (an element whose fp32 value sits on a bf16
+    rounding boundary may round the other way: one 2^-9 relative step on one of 65 280 pairs)."""
+    model, ont, _, _ = g17_model
+    a, meta = gu.load("g20_c4_open_programs")
+    assert meta["weight_seed"] == 17
+    cm = meta["cases"]["c4_n256"]
+    qs = [syn.question(q["question_id"], q["program"]["branches"], q["program"]["last_op"], q["answer"]) for q in cm["questions"]]
+    scenes = [syn.feature_scene(q["question_id"], q["n"], meta["feature_dim"]) for q in cm["questions"]]
+    assert [s["n"] for s in scenes] == [256, 256, 256] and all(len(q["program"]["branches"][0]) == 9 for q in qs)
+    lp32, lp64 = a["c4_n256:lp_f32"], a["c4_n256:lp_f64"]
+    assert lp32.shape == (78,)                                             # 3 questions x 26 options
+    saved = model._oracle._tile_dtype
+    try:
+        model._oracle._tile_dtype = torch.bfloat16 if tiles == "bf16" else torch.float32
+        res, _ = run(model, qs, scenes, ont, split=1, key="X")
+    finally:
+        model._oracle._tile_dtype = saved
+    lp = res["log_probability"].cpu().numpy()
+    assert int(res["type"]) == cm["type"] and res["options"] == cm["options"]
+    decided = gu.decided_answers(cm, lp32, lp64)
+    if tiles == "f32":
+        gu.check_logprob(lp, lp32, lp64, "g20 c4_n256")
+        assert [x for x, d in zip(res["answer"], decided) if d] == [x for x, d in zip(cm["answer"], decided) if d]
+        return
+    # the oracle's tables for the same weights and scenes; the relation table rounded to bf16, the logic in fp64
+    from dfol_vqa_amd import synthetic as syn_
+    paths, _ = syn_.write_synthetic_ontology(str(tmp_path))
+    oont = orc.Ontology(paths["attribute_file"], paths["class_file"], paths["vocabulary_file"], paths["relation_file"])
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    img = np.repeat(np.arange(3), 256)
+    A, R = orc.tables_from_features(np.concatenate([s_["X"] for s_ in scenes]).astype(np.float32), img, weights, oont, np.float32)
+    Rb = _round_bf16(R)
+    per = 256 * 255
+    tabled = [{"n": 256, "A": A[256 * i:256 * (i + 1)].astype(np.float64), "R": Rb[per * i:per * (i + 1)].astype(np.float64)} for i in range(3)]
+    rb = orc.run_questions(oont, qs, tabled, np.float64)
+    got64 = np.asarray(lp, np.float64)
+    assert np.abs(got64 - rb["log_probability"]).max() <= 2e-3, np.abs(got64 - rb["log_probability"]).max()
+    assert np.abs(np.exp(got64) - np.exp(rb["log_probability"])).max() <= 1e-5
+    L = float(np.abs(R).max())                                            # (every column: an upper bound of the named columns' largest |l|)
+    bound = 4 * 2.0 ** -9 * L + 2 * np.abs(lp32.astype(np.float64) - lp64).max() + 1e-4
+    assert np.abs(got64 - lp64).max() <= bound, (np.abs(got64 - lp64).max(), bound, L)
+    assert not np.array_equal(lp, lp32)
+    margins = []
+    sizes = [len(o) for o in cm["options"]]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for i in range(len(sizes)):
+        top = np.sort(lp64[off[i]:off[i + 1]])[::-1]
+        margins.append(top[0] - top[1] > 2 * bound)
+    assert [x for x, d in zip(res["answer"], margins) if d] == [x for x, d in zip(cm["answer"], margins) if d]
+
+
 @pytest.mark.parametrize("kind", ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel",
                                   "two_same", "two_different", "all_same", "all_different", "compare"])
 def test_all_ops_full_size_model_ragged_60_to_100(full_size, kind):

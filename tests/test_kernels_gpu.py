@@ -758,6 +758,60 @@ def test_pair_h2_rows_of_any_scale_and_large_activations(L):
     assert np.all(got[~wanted] == -30.0)
 
 
+@pytest.mark.parametrize("hid1", [256, 64])
+def test_pair_h2_saturation_flag(L, hid1):
+    """dfol_pair_ll_h2_f32 with a status word set (dfol_set_range_status): the bound kernel in front of the pair kernel flags
+    DFOL_RANGE_PAIR_SATURATED exactly when max_s U[s][k] + max_o V[o][k] + the geometry bound passes 6e4 (units of 1 / ln 2) for some image
+    and hidden unit, or a U|V entry is NaN; large NEGATIVE sums (ELU -> -1), an image of one object and a call without a status word are
+    not flagged."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(5)
+    hid2, K, n_list = 300, 1, [9, 1, 12, 37]
+    Q, O, NS, C = len(n_list), sum(n_list), 40, 8
+    off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int32)
+    pos = rng.uniform(0.05, 0.9, (O, 4)).astype(np.float32)
+    wg = rng.uniform(-0.5, 0.5, (hid1, 4)).astype(np.float32)
+    w2 = np.zeros((320, hid1), np.float32)
+    w2[:hid2] = rng.normal(size=(hid2, hid1)).astype(np.float32) / np.sqrt(hid1)
+    packed = _lib.pair_pack_w2_h2(dev(w2), hid2)
+    b2 = dev(rng.normal(size=hid2).astype(np.float32))
+    E, be = dev((rng.normal(size=(C, hid2)) / np.sqrt(hid2)).astype(np.float32)), dev(rng.normal(size=C).astype(np.float32))
+    req_col, req_tile = dev(rng.randint(0, C, (K, Q)).astype(np.int32)), dev(np.arange(K * Q, dtype=np.int32).reshape(K, Q))
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def flagged(uv, with_word=True):
+        word.zero_()
+        _lib.load().dfol_set_range_status(word.data_ptr() if with_word else None)
+        try:
+            t = torch.full((K * Q, NS, NS), -30.0, device="cuda")
+            _lib.pair_ll_h2(dev(uv), hid1, dev(pos), dev(wg), packed, b2, hid2, E, be, dev(np.array(n_list, np.int32)), dev(off), max(n_list), req_col, req_tile,
+                            None, t, uv_prescaled=True)          # (the values below are in the kernel's units of 1 / ln 2)
+        finally:
+            _lib.load().dfol_set_range_status(None)
+        return int(word.item())
+
+    base = rng.uniform(-1, 1, (O, 2 * hid1)).astype(np.float32)
+    assert flagged(base) == 0
+    neg = base.copy(); neg[:, 3] = -5.0e5                          # ELU(-huge) = -1: nothing saturates
+    assert flagged(neg) == 0
+    lone = base.copy(); lone[int(off[1])] = 9.0e4                  # the image of ONE object has no pairs
+    assert flagged(lone) == 0
+    for k in (0, hid1 - 1, hid1 // 2 + 1):
+        hot = base.copy()
+        hot[int(off[3]) + 5, k] = 4.0e4                            # U[s][k] + V[o][k] = 7e4 > 6e4 for s = 5, o = 20 of the last image
+        hot[int(off[3]) + 20, hid1 + k] = 3.0e4
+        assert flagged(hot) == _lib.RANGE_PAIR_SATURATED, k
+        assert flagged(hot, with_word=False) == 0
+        under = hot.copy(); under[int(off[3]) + 20, hid1 + k] = 1.0e4        # 5e4 + geometry (< 4) stays below
+        assert flagged(under) == 0, k
+        apart = base.copy()                                        # the two large values sit in DIFFERENT images: no pair sees both
+        apart[int(off[3]) + 5, k] = 4.0e4
+        apart[int(off[2]) + 2, hid1 + k] = 3.0e4
+        assert flagged(apart) == 0, k
+    nan = base.copy(); nan[int(off[2]) + 7, hid1 + 9] = np.nan
+    assert flagged(nan) == _lib.RANGE_PAIR_SATURATED
+
+
 @pytest.mark.parametrize("n_list", [[8, 3, 5, 1], [40, 33, 17, 8], [100, 104, 64, 2], [130, 256]])
 def test_relate_one_bf16_equals_fp32_kernel_on_rounded_tiles(L, n_list):
     """The bf16-tile kernel does the same fp32 arithmetic as the fp32-tile kernel: on tiles that are exactly representable in bf16 the

@@ -231,7 +231,7 @@ def test_fp16_range_overflow_raises_instead_of_nan(full, native, monkeypatch):
 
 @pytest.mark.parametrize("native", ["1", "0"])
 def test_pair_kernel_saturation_raises(full, native, monkeypatch):
-    """the fused pair kernel clamps its ELU outputs at 4.16e4 (fp16 pieces).  First-layer sums scaled to ~1e5 used to come back
+    """the fused pair kernel clamps its ELU outputs at 4.16e4 (fp16 pieces).  First-layer sums scaled to ~3e5 used to come back
     as a silently wrong relation tile; now the bound kernel in front of it flags DFOL_RANGE_PAIR_SATURATED and the forward raises.  A model
     whose sums stay in range is not flagged (the same batch, unscaled), on either route."""
     from torch import nn
@@ -244,8 +244,8 @@ def test_pair_kernel_saturation_raises(full, native, monkeypatch):
         ref = model(pbs, False)["log_probability"].clone()
         saved_w, saved_b = lin1.weight.clone(), lin1.bias.clone()
         try:
-            lin1.weight.mul_(3.0e4)                              # sums of ~1e5 (the features are Sigmoid outputs: within fp16's range themselves)
-            lin1.bias.mul_(3.0e4)
+            lin1.weight.mul_(1.0e6)                              # sums of ~3e5 (the features are Sigmoid outputs: within fp16's range themselves)
+            lin1.bias.mul_(1.0e6)
             with pytest.raises(_lib.DfolError, match="saturation"):
                 model(pbs, False)
         finally:

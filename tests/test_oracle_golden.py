@@ -224,7 +224,8 @@ def test_g17_torch_restatement_equals_reference(full_size_oracle):
         orct.run_questions(oont, q2[:2], s2[:2], weights)
 
 
-@pytest.mark.parametrize("name", ["binary_small", "query_rel_small"])
+@pytest.mark.parametrize("name", ["binary_small", "query_rel_small", "query_attr_small", "verify_attrs_small", "compare_small", "two_same_small",
+                                  "all_different_small", "or_small"])
 def test_g19_torch_restatement_train_step_equals_reference(full_size_oracle, name):
     """oracle/dfol_oracle_torch.train_loss - the reference's train step restated under torch autograd, the checker of the fused full-size
     training kernels (tests/test_backward_gpu.py) - against the REFERENCE'S OWN `_train_batch` at full model size (golden g19: loss,
@@ -246,7 +247,7 @@ def test_g19_torch_restatement_train_step_equals_reference(full_size_oracle, nam
     for pname, gr in grads.items():
         full = g[pname].reshape(-1)
         smp = full[syn.gradient_sample_index(pname, full.size)]
-        scale = np.abs(gr["sample64"]).max() + 1e-30
+        scale = max(np.abs(gr["sample64"]).max(), gr["norm64"] / np.sqrt(full.size)) + 1e-30
         assert np.abs(smp - gr["sample64"]).max() <= 1e-8 * scale + 1e-14, (pname, np.abs(smp - gr["sample64"]).max(), scale)
         assert abs(np.sqrt((full ** 2).sum()) - gr["norm64"]) <= 1e-8 * gr["norm64"] + 1e-14, pname
     loss32, lp32, g32 = orct.train_loss(oont, qs, scenes, weights, torch.float32)
@@ -293,3 +294,21 @@ def test_g8_gather():
     assert res["answer"] == ref["answer"] and res["options"] == ref["options"] and res["type"] == ref["type"]
     assert np.allclose(res["log_probability"], ref["log_probability"])
     assert res["answer_log_probability"] == ref["answer_log_probability"]
+
+
+def test_g20_configs4_open_programs(full_size_oracle):
+    """The oracle against the REFERENCE on BASELINE configs[4] verbatim (golden g20: 3 questions x 256-object scenes, select -> (filter ->
+    relate) x 4 -> query_attr over a 26-option category, full model size): fp64 to 1e-9, the answers and the option lists."""
+    from dfol_vqa_amd import synthetic as syn
+    oont, weights, _, _ = full_size_oracle
+    a, meta = gu.load("g20_c4_open_programs")
+    assert meta["weight_seed"] == 17
+    cm = meta["cases"]["c4_n256"]
+    qs = [syn.question(q["question_id"], q["program"]["branches"], q["program"]["last_op"], q["answer"]) for q in cm["questions"]]
+    scenes = [syn.feature_scene(q["question_id"], q["n"], meta["feature_dim"]) for q in cm["questions"]]
+    lp32, lp64 = a["c4_n256:lp_f32"], a["c4_n256:lp_f64"]
+    r64 = orc.run_questions(oont, qs, scenes, np.float64, split=1, weights=weights)
+    assert np.abs(r64["log_probability"] - lp64).max() <= 1e-9
+    assert int(r64["type"]) == cm["type"] and r64["options"] == cm["options"]
+    decided = gu.decided_answers(cm, lp32, lp64)
+    assert [x for x, d in zip(r64["answer"], decided) if d] == [x for x, d in zip(cm["answer"], decided) if d]

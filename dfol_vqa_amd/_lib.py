@@ -103,6 +103,7 @@ SIGNATURES = {
     "dfol_logic_f32": [_i32, _p, _p, _i64, _p, _p],
     "dfol_parametric_not_f32": [_p, _p, _i32, _i32, _p, _p],
     "dfol_segment_or_f32": [_p, _p, _i32, _p, _p],
+    "dfol_segment_or_ref_f32": [_p, _p, _i32, _p, _p],
     "dfol_implication_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_compare_f32": [_p, _p, _p, _i32, _p, _p],
     "dfol_linear_act_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
@@ -537,10 +538,11 @@ def parametric_not(x, alpha):
     return out.reshape(x.shape)
 
 
-def segment_or(lp, seg_off):
+def segment_or(lp, seg_off, as_written=False):
+    """as_written: the reference's fp32 formula instead of the complement form (callers that negate the aggregate: include/dfol_vqa.h)."""
     Q = seg_off.numel() - 1
     out = torch.empty(Q, dtype=F32, device=lp.device)
-    call("dfol_segment_or_f32", _ptr(lp, F32), _ptr(seg_off, I32), Q, _ptr(out), _stream())
+    call("dfol_segment_or_ref_f32" if as_written else "dfol_segment_or_f32", _ptr(lp, F32), _ptr(seg_off, I32), Q, _ptr(out), _stream())
     return out
 
 

@@ -1441,6 +1441,29 @@ __global__ void segment_or_kernel(const float* __restrict__ lp, const int32_t* _
     out[q] = dfol_slog(q1);
 }
 
+// The same aggregate AS THE REFERENCE WRITES IT, log_not(sum_p log_not(lp_p)) in fp32 (batch_gqa_ops.py:597-598, 664-665), for the two callers
+// that NEGATE it next (all_different :631, two_different :706).  The complement form above is accurate in q; the negation needs 1 - q, which no
+// fp32 form of q holds when q -> 1.  There the reference's arithmetic SATURATES - 1 - e^S rounds to exactly 1 once S < -17.3, the aggregate
+// is exactly 0, its negation exactly log(1e-20) and the clamp's gradient exactly 0 - while q = 1 - 2^-24 from the complement form turned into
+// log(2^-24) = -16.6 with a gradient of order one into the saturated option (golden g19 all_different_small: loss 3.52 against the
+// reference's 8.42, fp32 and fp64 alike).  Same rounding behaviour as the reference is the parity that matters for that pair of operators.
+__global__ void segment_or_ref_kernel(const float* __restrict__ lp, const int32_t* __restrict__ seg_off, int Q, float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float s = 0.f;
+    for (int p = seg_off[q]; p < seg_off[q + 1]; ++p) s += dfol_lnot(lp[p]);
+    out[q] = dfol_lnot(s);
+}
+
+extern "C" int dfol_segment_or_ref_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream) {
+    DFOL_REQUIRE(Q >= 0, "segment_or_ref: bad sizes");
+    if (Q == 0) return 0;
+    DFOL_REQUIRE(lp && seg_off && out, "segment_or_ref: null pointer");
+    hipLaunchKernelGGL(segment_or_ref_kernel, dim3(dfol_cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, lp, seg_off, Q, out);
+    DFOL_LAUNCH_CHECK("segment_or_ref");
+    return 0;
+}
+
 extern "C" int dfol_segment_or_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream) {
     DFOL_REQUIRE(Q >= 0, "segment_or: bad sizes");
     if (Q == 0) return 0;

@@ -146,9 +146,9 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                 rc = dfol_segment_sum_rows_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const int32_t*>(at(blob, a[2])), static_cast<int32_t>(a[3]),
                                                static_cast<int32_t>(a[4]), static_cast<float*>(at(workspace, a[5])), stream);
                 break;
-            case DFOL_OP_SEGMENT_OR:     // lp, seg_off, Q, out
-                rc = dfol_segment_or_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const int32_t*>(at(blob, a[2])), static_cast<int32_t>(a[3]),
-                                         static_cast<float*>(at(workspace, a[4])), stream);
+            case DFOL_OP_SEGMENT_OR:     // lp, seg_off, Q, out, as the reference writes it (1) or in the complement form (0)
+                rc = (a[5] ? dfol_segment_or_ref_f32 : dfol_segment_or_f32)(static_cast<const float*>(at(workspace, a[1])), static_cast<const int32_t*>(at(blob, a[2])),
+                                                                            static_cast<int32_t>(a[3]), static_cast<float*>(at(workspace, a[4])), stream);
                 break;
             case DFOL_OP_IMPLICATION:    // prior, x, pred_q, P, out
                 rc = dfol_implication_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])),

@@ -522,7 +522,8 @@ class GQAAllSameBatch(GQABatchOperatorBase):
         temp = BatchVariableSet(x._name, variable_set.device, x.object_num(), batch_size=len(attribute_list), quantifiers=Quantifier.FOR_ALL,
                                 log_attention=log_posterior, world=world, predicate_question_map=pred_q)
         log_probability = temp.log_probability(give_answer and hard_mode)
-        log_probability = L.segment_or(log_probability, _seg_off(batch_index, variable_set.batch_size(), world._device))   # :597-598
+        log_probability = L.segment_or(log_probability, _seg_off(batch_index, variable_set.batch_size(), world._device),
+                                       as_written=getattr(self, "_or_as_written", False))                                   # :597-598
         answer, alp = _binary_answer(log_probability, variable_set.batch_size(), give_answer)
         return _result(answer, log_probability, ['no', 'yes'], None, QuestionType.BINARY, x.cumulative_loss(), x._prev_variable_sets_num + 1, alp)
 
@@ -533,6 +534,7 @@ class GQAAllDifferentBatch(GQABatchOperatorBase):
     def __init__(self, oracle, ontology, **kw):
         super(GQAAllDifferentBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=1, fan_out=0)
         self._gqa_all_same = GQAAllSameBatch(oracle, ontology, **kw)
+        self._gqa_all_same._or_as_written = True              # its aggregate is negated next: the reference's fp32 formula (dfol_segment_or_ref_f32)
 
     def forward(self, op_id, world, variable_set, category_list, give_answer=True, predicate_question_map=None, likelihood_threshold=0,
                 hard_mode=False):
@@ -557,7 +559,8 @@ class GQATwoSameBatch(GQABatchOperatorBase):
         x2 = self._filter(op_id + ':1', world, variable_set2, attribute_list, batch_index)
         hard = give_answer and hard_mode
         log_probability = L.logic(L.LOGIC_AND, x1.log_probability(hard), x2.log_probability(hard))
-        log_probability = L.segment_or(log_probability, _seg_off(batch_index, variable_set1.batch_size(), world._device))   # :664-665
+        log_probability = L.segment_or(log_probability, _seg_off(batch_index, variable_set1.batch_size(), world._device),
+                                       as_written=getattr(self, "_or_as_written", False))                                   # :664-665
         answer, alp = _binary_answer(log_probability, variable_set1.batch_size(), give_answer)
         return _result(answer, log_probability, ['no', 'yes'], None, QuestionType.BINARY, x1.cumulative_loss() + x2.cumulative_loss(),
                        x1._prev_variable_sets_num + x2._prev_variable_sets_num + 2, alp)
@@ -569,6 +572,7 @@ class GQATwoDifferentBatch(GQABatchOperatorBase):
     def __init__(self, oracle, ontology, **kw):
         super(GQATwoDifferentBatch, self).__init__(oracle, ontology, is_terminal=True, fan_in=2, fan_out=0)
         self._gqa_two_same = GQATwoSameBatch(oracle, ontology, **kw)
+        self._gqa_two_same._or_as_written = True              # negated next, as all_different's
 
     def forward(self, op_id, world, variable_set1, variable_set2, category_list, give_answer=True, predicate_question_map=None,
                 likelihood_threshold=0, hard_mode=False):

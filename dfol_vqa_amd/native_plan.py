@@ -481,7 +481,7 @@ def _lower(pb, ontology, spec):
             lp_p = b.quantify(temp)
             same = name == "all_same"
             lp = b.alloc(Q * 4, "o" if same else "t")
-            b.emit(OP_SEGMENT_OR, lp_p, b.seg_off(bi), Q, lp)
+            b.emit(OP_SEGMENT_OR, lp_p, b.seg_off(bi), Q, lp, 0 if same else 1)      # (negated next: the reference's fp32 formula)
             if not same:
                 lp2 = b.alloc(Q * 4, "o")
                 b.emit(OP_LOGIC, LOGIC_NOT, lp, -1, Q, lp2)
@@ -503,7 +503,7 @@ def _lower(pb, ontology, spec):
             b.emit(OP_LOGIC, LOGIC_AND, lp1, lp2, x1.rows, both)
             same = name == "two_same"
             lp = b.alloc(Q * 4, "o" if same else "t")
-            b.emit(OP_SEGMENT_OR, both, b.seg_off(bi), Q, lp)
+            b.emit(OP_SEGMENT_OR, both, b.seg_off(bi), Q, lp, 0 if same else 1)
             if not same:
                 lp2_ = b.alloc(Q * 4, "o")
                 b.emit(OP_LOGIC, LOGIC_NOT, lp, -1, Q, lp2_)

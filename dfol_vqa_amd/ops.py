@@ -168,9 +168,9 @@ def segment_sum_rows(src, seg_off):
 
 class _SegmentOr(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lp, seg_off):
+    def forward(ctx, lp, seg_off, as_written=False):
         ctx.save_for_backward(lp, seg_off)
-        return _lib.segment_or(lp, seg_off)
+        return _lib.segment_or(lp, seg_off, as_written)
 
     @staticmethod
     def backward(ctx, g):
@@ -180,13 +180,13 @@ class _SegmentOr(torch.autograd.Function):
         one = torch.ones((), device=lp.device)
         inner = torch.log((1 - torch.exp(lp)).clamp_min(_EPS))
         s = _lib.segment_sum_rows(inner.unsqueeze(1).contiguous(), seg_off).squeeze(1)     # (index_add_ would be atomic: not repeatable)
-        return (g * _dpnot(s, one))[idx] * _dpnot(lp, one), None
+        return (g * _dpnot(s, one))[idx] * _dpnot(lp, one), None, None
 
 
-def segment_or(lp, seg_off):
+def segment_or(lp, seg_off, as_written=False):
     if _needs_grad(lp):
-        return _SegmentOr.apply(lp, seg_off)
-    return _lib.segment_or(lp, seg_off)
+        return _SegmentOr.apply(lp, seg_off, as_written)
+    return _lib.segment_or(lp, seg_off, as_written)
 
 
 class _Implication(torch.autograd.Function):

@@ -209,7 +209,8 @@ class _TallLinear(torch.autograd.Function):
     def _split_ok(x2, k):
         if x2.dtype == torch.bfloat16:                       # bf16-stored activations exist in the bf16 mode only, and only this kernel takes them
             return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and _lib._dense_math() == "bf16"
-        return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 4096 and x2.dtype == torch.float32 and _lib._dense_math() != "f32"
+        # (any row count since round 6: the last batch of an epoch, or 20 questions per GPU on small scenes, used to leave for the vendor GEMM below 4096 rows)
+        return x2.is_cuda and x2.is_contiguous() and k % 4 == 0 and x2.shape[0] >= 1 and x2.dtype == torch.float32 and _lib._dense_math() != "f32"
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -222,7 +223,7 @@ class _TallLinear(torch.autograd.Function):
             return L.linear_act_split(x2, w if w.is_contiguous() else w.contiguous(), None if bias is None else bias.detach(),
                                       L.ACT_NONE).view(*x.shape[:-1], weight.shape[0])
         if x.is_cuda:
-            _lib.fallback("_TallLinear.forward", "rows %d < 4096, K %d %% 4 != 0, a non-contiguous input or dense math 'f32'" % (x2.shape[0], x2.shape[1]))
+            _lib.fallback("_TallLinear.forward", "rows %d, K %d %% 4 != 0, a non-contiguous input or dense math 'f32'" % (x2.shape[0], x2.shape[1]))
         if x.dtype != weight.dtype:                          # (a bf16-stored input the kernel cannot take: compute in fp32, store as it came)
             return nn.functional.linear(x.to(weight.dtype), weight, bias).to(x.dtype)
         return nn.functional.linear(x, weight, bias)
@@ -245,7 +246,7 @@ class _TallLinear(torch.autograd.Function):
                 gx = L.linear_act_split(g2c, weight.detach(), None, L.ACT_NONE, transpose_w=True).view_as(x)
             else:
                 if g2.is_cuda:
-                    _lib.fallback("_TallLinear.backward (input gradient)", "rows %d < 4096 or width %d %% 4 != 0" % (g2c.shape[0], g2c.shape[1]))
+                    _lib.fallback("_TallLinear.backward (input gradient)", "rows %d, width %d %% 4 != 0 or dense math 'f32'" % (g2c.shape[0], g2c.shape[1]))
                 gx = (g2.to(weight.dtype) @ weight).to(x.dtype).view_as(x)
         gw = gb = None
         if ctx.needs_input_grad[1]:
@@ -747,7 +748,7 @@ class ClassifierOracle(OracleBase):
             return os.environ.get("DFOL_TRAIN_HEAD_FUSED_BF16", "0") == "1" and _lib._dense_math() == "bf16" and lin2.weight.shape[0] % 4 == 0 and \
                 L.linear_tall_supported(z.shape[0], lin2.weight.shape[0], lin2.weight.shape[1]) and \
                 L.linear_tall_supported(z.shape[0], lin2.weight.shape[1], lin2.weight.shape[0])
-        return z.dtype == torch.float32 and _lib._dense_math() in ("f16x2", "bf16x3") and z.shape[0] >= 4096
+        return z.dtype == torch.float32 and _lib._dense_math() in ("f16x2", "bf16x3") and z.shape[0] >= 1
 
     def _pair_hidden_autograd(self, world):
         """h = Sigmoid(pre2) [pairs, HID2]; shared by all relation operators of the scene."""

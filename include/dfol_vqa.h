@@ -219,6 +219,10 @@ int dfol_parametric_not_f32(const float* x, const float* alpha, int32_t rows, in
 
 /* Segmented log-OR: out[q] = log_not( sum_{p in seg q} log_not(lp[p]) ), batch_gqa_ops.py:597-598, :664-665. */
 int dfol_segment_or_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream);
+/* The same aggregate evaluated as the reference writes it - log_not(sum log_not(lp_p)) in fp32, not the complement form - for the two
+ * operators that negate it next (all_different batch_gqa_ops.py:631, two_different :706): where the aggregate approaches log 1 the
+ * reference's arithmetic saturates to exactly 0 (and its negation to log 1e-20 with zero gradient); see csrc/dfol_logic.hip. */
+int dfol_segment_or_ref_f32(const float* lp, const int32_t* seg_off, int32_t Q, float* out, void* stream);
 
 /* all_same implication, batch_gqa_ops.py:588-589:  out = log_not(prior[pred_q[p]] + log_not(x))  on [P, NS]. */
 int dfol_implication_f32(const float* prior, const float* x, const int32_t* pred_q, const int32_t* n_obj, int32_t P,

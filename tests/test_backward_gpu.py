@@ -1352,6 +1352,38 @@ def test_g19_full_size_train_step_against_the_reference(g19_setup, name, sums, m
         assert err <= 16 * own + 2e-3 * scale, "%s d%s: |dgrad| %.3g vs the reference's own %.3g (scale %.3g)" % (name, pname, err, own, scale)
 
 
+@pytest.mark.parametrize("n_list", [[5, 7], [2, 1, 9], [30]])
+def test_small_batches_train_inside_the_library(g19_setup, n_list):
+    """below 4096 pair rows the full-size model's tall products used to leave for nn.functional.linear / `@` (vendor GEMM,
+    announced).  The split-operand and the TN weight-gradient kernels take any row count: 2 - 3 questions on 1 - 30 objects (34 - 870
+    pair rows; an image of ONE object among them) train through the same fused routes - no fallback announced - and agree with the fp64
+    autograd of the restated reference on every gradient entry."""
+    import warnings
+    from oracle import dfol_oracle_torch as orct
+    model, ont, oont, weights, a, meta = g19_setup
+    import tempfile
+    names_ = syn.write_synthetic_ontology(tempfile.mkdtemp())[1]
+    rels, nouns = names_["relations"][:5], names_["nouns"][:8]
+    qs = []
+    for i, n in enumerate(n_list):
+        qid = 777000 + 10 * len(n_list) + i
+        branch = [syn.op("select", nouns[i]), syn.op("relate", rels[i], bool(i % 2), nouns[i + 1]), syn.op("relate", "not(%s)" % rels[i + 1], not bool(i % 2), "_")]
+        qs.append(syn.question(qid, [branch], syn.op("exist"), "yes" if i % 2 else "no", syn.feature_scene(qid, n, 2048)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        loss, lp, got, routes = _g19_step(model, ont, qs)
+    assert not [r for r in routes if r.startswith("fallback:")], routes
+    assert routes.get("fused_hidden1", 0) == 1 and routes.get("pair_trunk", 0) == 1 and routes.get("head_use", 0) >= 1, routes
+    o_loss, o_lp, o_g = orct.train_loss(oont, qs, [q["scene"] for q in qs], weights, torch.float64)
+    l32 = orct.train_loss(oont, qs, [q["scene"] for q in qs], weights, torch.float32)
+    assert abs(loss - o_loss) <= 8 * abs(l32[0] - o_loss) + 2e-5 * max(1.0, abs(o_loss)), (loss, l32[0], o_loss)
+    for pname, ref64 in o_g.items():
+        own = np.abs(l32[2][pname] - ref64).max()
+        scale = np.abs(ref64).max() + 1e-30
+        err = np.abs(got[pname].astype(np.float64) - ref64).max()
+        assert err <= 16 * own + 2e-3 * scale, "%s d%s: |dgrad| %.3g vs the fp32 restatement's own %.3g (scale %.3g)" % (n_list, pname, err, own, scale)
+
+
 def test_g19_detects_a_broken_trunk_accumulation(g19_setup, monkeypatch):
     """The check above has teeth: with the deferred trunk's accumulation across readers deliberately broken (every reader after the first
     overwrites the second layer's weight gradient instead of adding to it) the g19 comparison fails."""

@@ -286,6 +286,19 @@ def test_small_vector_ops(L):
     r32 = np.array([orc.log_not(orc.log_not(a[seg_off[i]:seg_off[i + 1]]).sum(keepdims=True))[0] for i in range(Q)])
     r64 = np.array([orc.log_not(orc.log_not(a64[seg_off[i]:seg_off[i + 1]]).sum(keepdims=True))[0] for i in range(Q)])
     gu.check_logprob(so, r32, r64, "segment_or")
+    # the same aggregate as the reference writes it (dfol_segment_or_ref_f32: the callers that negate it next) - the reference's fp32 values to
+    # rounding, and its SATURATION: one option at log 1 - 1e-9 makes the aggregate exactly 0 and its negation exactly log(1e-20)
+    sr = L.segment_or(dev(a), dev(seg_off), as_written=True).cpu().numpy()
+    assert np.abs(np.exp(sr.astype(np.float64)) - np.exp(r32.astype(np.float64))).max() <= 2e-7
+    sat = np.array([-1e-9, -3.0, -0.5, -2.0, -1e-9], np.float32)
+    sat_off = np.array([0, 2, 5], np.int32)
+    sw = L.segment_or(dev(sat), dev(sat_off), as_written=True)
+    assert np.array_equal(sw.cpu().numpy(), np.zeros(2, np.float32))
+    assert np.allclose(L.logic(L.LOGIC_NOT, sw).cpu().numpy(), np.log(1e-20), atol=1e-4)
+    g = torch.tensor(sat, device="cuda", requires_grad=True)          # and the zero gradient of the reference's clamp
+    from dfol_vqa_amd import ops as OPS
+    OPS.logic(L.LOGIC_NOT, OPS.segment_or(g, dev(sat_off), as_written=True)).sum().backward()
+    assert float(g.grad.abs().max()) == 0.0
     pq = rng.randint(0, Q, P).astype(np.int32)
     n_obj = rng.randint(1, NS + 1, Q).astype(np.int32)
     prior = -rng.gamma(1.0, 1.0, (Q, NS)).astype(np.float32)

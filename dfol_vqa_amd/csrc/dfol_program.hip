@@ -68,26 +68,27 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                 }
                 break;
             }
-            case DFOL_OP_PAIR_LL: {      // uv, ld_uv, pos, ld_pos, req_col, req_tile, req_orient, K, tiles, scenes
+            case DFOL_OP_PAIR_LL: {      // uv, ld_uv, pos, ld_pos, req_col, req_tile, req_orient, K, tiles, scenes, tile dtype (DFOL_TILE_*)
                 const float* uv = static_cast<const float*>(at(workspace, a[1]));
                 const float* pos = static_cast<const float*>(at(workspace, a[3]));
                 const int32_t* rc_ = static_cast<const int32_t*>(at(blob, a[5]));
                 const int32_t* rt = static_cast<const int32_t*>(at(blob, a[6]));
                 const uint8_t* ro = static_cast<const uint8_t*>(at(blob, a[7]));
                 void* tiles = at(workspace, a[9]);
-                const int32_t K = static_cast<int32_t>(a[8]), Qimg = static_cast<int32_t>(a[10]);
+                const int32_t K = static_cast<int32_t>(a[8]), Qimg = static_cast<int32_t>(a[10]), tdt = static_cast<int32_t>(a[11]);
+                DFOL_REQUIRE(tdt == DFOL_TILE_F32 || model->pair_kind != DFOL_PAIR_PLAIN, "run_program[%d]: bf16 tiles need a packed second layer", i);
                 switch (model->pair_kind) {
                     case DFOL_PAIR_F16X2:
                         rc = dfol_pair_ll_h2_f32(uv, a[2], model->hid1, pos, a[4], model->wg, model->w2, model->b2, model->hid2, model->emb_w, model->ld_e, model->emb_b,
-                                                 img_n_obj, obj_off, Qimg, scene->max_n, rc_, rt, ro, K, NS, -30.0f, DFOL_TILE_F32, tiles, stream);
+                                                 img_n_obj, obj_off, Qimg, scene->max_n, rc_, rt, ro, K, NS, -30.0f, tdt, tiles, stream);
                         break;
                     case DFOL_PAIR_BF16X3:
                         rc = dfol_pair_ll_split_f32(uv, a[2], model->hid1, pos, a[4], model->wg, model->w2, model->b2, model->hid2, model->emb_w, model->ld_e, model->emb_b,
-                                                    img_n_obj, obj_off, Qimg, scene->max_n, rc_, rt, ro, K, NS, -30.0f, DFOL_TILE_F32, tiles, stream);
+                                                    img_n_obj, obj_off, Qimg, scene->max_n, rc_, rt, ro, K, NS, -30.0f, tdt, tiles, stream);
                         break;
                     case DFOL_PAIR_PACKED:
                         rc = dfol_pair_ll_packed_f32(uv, a[2], model->hid1, pos, a[4], model->wg, static_cast<const float*>(model->w2), model->b2, model->hid2, model->emb_w,
-                                                     model->ld_e, model->emb_b, img_n_obj, obj_off, Qimg, scene->max_n, rc_, rt, ro, K, NS, -30.0f, DFOL_TILE_F32, tiles, stream);
+                                                     model->ld_e, model->emb_b, img_n_obj, obj_off, Qimg, scene->max_n, rc_, rt, ro, K, NS, -30.0f, tdt, tiles, stream);
                         break;
                     case DFOL_PAIR_PLAIN:
                         rc = dfol_pair_ll_f32(uv, a[2], model->hid1, pos, a[4], model->wg, static_cast<const float*>(model->w2), model->ld_w2, model->w2_rows, model->b2,
@@ -114,7 +115,15 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                                          static_cast<const int32_t*>(at(blob, a[3])), n_obj, static_cast<const uint8_t*>(at(blob, a[4])), a[4] >= 0 ? 1 : 0,
                                          static_cast<const uint8_t*>(at(blob, a[5])), static_cast<int32_t>(a[6]), NS, static_cast<float*>(at(workspace, a[7])), stream);
                 break;
-            case DFOL_OP_RELATE_ONE:     // x, prev, tile, pred_q, quant_prev, neg, active, P, lone_forall_identity, out
+            case DFOL_OP_RELATE_ONE:     // x, prev, tile, pred_q, quant_prev, neg, active, P, lone_forall_identity, out, tile dtype (DFOL_TILE_*)
+                if (a[11] == DFOL_TILE_BF16) {
+                    rc = dfol_relate_one_fwd_bf16(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])),
+                                                  static_cast<const uint16_t*>(at(workspace, a[3])), static_cast<const int32_t*>(at(blob, a[4])), n_obj,
+                                                  static_cast<const float*>(at(blob, a[5])), static_cast<const uint8_t*>(at(blob, a[6])), a[6] >= 0 ? 1 : 0,
+                                                  static_cast<const uint8_t*>(at(blob, a[7])), static_cast<int32_t>(a[8]), NS, static_cast<int32_t>(a[9]),
+                                                  static_cast<float*>(at(workspace, a[10])), stream);
+                    break;
+                }
                 rc = dfol_relate_one_fwd_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])),
                                              static_cast<const float*>(at(workspace, a[3])), static_cast<const int32_t*>(at(blob, a[4])), n_obj,
                                              static_cast<const float*>(at(blob, a[5])), static_cast<const uint8_t*>(at(blob, a[6])), a[6] >= 0 ? 1 : 0,
@@ -166,9 +175,10 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                                            static_cast<uint8_t*>(at(workspace, a[5])), stream);
                 break;
             }
-            case DFOL_OP_GATHER_TILES:   // src tiles, index, count, dst tiles: dst[p] = src[index[p]] (shared scenes: one tile per distinct (scene, concept, orientation))
-                rc = dfol_gather_rows_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const int32_t*>(at(blob, a[2])), static_cast<int32_t>(a[3]), NS * NS,
-                                          static_cast<float*>(at(workspace, a[4])), stream);
+            case DFOL_OP_GATHER_TILES:   // src rows, index, count, dst rows, width in 32-bit words (0: NS * NS): dst[p] = src[index[p]] - shared scenes (one tile per distinct
+                                         // (scene, concept, orientation); bf16 tiles are NS * NS / 2 words), compacted option lists, LSTM states by question
+                rc = dfol_gather_rows_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const int32_t*>(at(blob, a[2])), static_cast<int32_t>(a[3]),
+                                          a[5] > 0 ? static_cast<int32_t>(a[5]) : NS * NS, static_cast<float*>(at(workspace, a[4])), stream);
                 break;
             default:
                 dfol_set_error("run_program[%d]: unknown opcode %lld", i, (long long)a[0]);

@@ -267,7 +267,7 @@ class BatchInterpreterBase(nn.Module):
             return None
         if torch.is_grad_enabled() and any(p.requires_grad for m in (self._oracle, self._featurizer) if isinstance(m, nn.Module) for p in m.parameters()):
             return None
-        if getattr(self._oracle, "_tile_dtype", torch.float32) != torch.float32 or not hasattr(self, "_ontology"):
+        if not hasattr(self, "_ontology"):
             return None
         return native_exec.model_spec(self)
 

@@ -94,9 +94,13 @@ def model_spec(model):
     fl, al = _layers(feat._featurizer_network._network), _layers(oracle._attribute_network._network)
     if not fl or not al:
         return None
-    lin1 = [m for m in oracle._relation_network._network if isinstance(m, nn.Linear)][0]
+    lin1, lin2 = [m for m in oracle._relation_network._network if isinstance(m, nn.Linear)][:2]
+    # bf16 tile storage (config key relation_tile_dtype: bf16): the pair kernels that write bf16 tiles are the packed ones over a second layer of
+    # more than 256 rows (visual_oracle.prefetch_relations' rule; the weight's shape decides, not its values)
+    tile_bf16 = getattr(oracle, "_tile_dtype", torch.float32) == torch.bfloat16 and 256 < lin2.out_features <= 320 and lin1.out_features <= 256 and \
+        lin1.out_features % 16 == 0 and os.environ.get("DFOL_PAIR_PACKED", "1") != "0"
     return NP.ModelSpec([l.out_features for l, _ in fl], [l.out_features for l, _ in al], lin1.out_features, fl[-1][0].out_features + 4,
-                        oracle._normalize, model._likelihood_threshold, oracle._ontology._relation_index)
+                        oracle._normalize, model._likelihood_threshold, oracle._ontology._relation_index, tile_bf16=tile_bf16)
 
 
 class NativeModel(object):

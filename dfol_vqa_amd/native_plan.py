@@ -30,6 +30,8 @@ TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
 WANT_SUBJECT, WANT_OBJECT = 1, 2
 RELATE_LONE_FORALL_IDENTITY, RELATE_DIAG_ABSENT = 1, 2
 _NEG30_BITS = int(np.float32(-30.0).view(np.int32))
+_NEG30_BF16X2 = int(np.array([0xC1F0C1F0], np.uint32).view(np.int32)[0])             # two bf16 -30.0 per 32-bit word (bf16 relation tiles)
+TILE_F32, TILE_BF16 = 0, 1
 _ALIGN = 256
 
 
@@ -37,21 +39,48 @@ class Unsupported(Exception):
     """A shape the executor does not take (the Python loop does): raised inside the lowering, turned into `None` by build_plan."""
 
 
+def shared_requests(q_img, n_img, items):
+    """Shared scenes: the distinct (scene, relation column, orientation) triples among `items` = [(full columns, predicate -> question,
+    orientation)], as pair-kernel request arrays [K', scenes] over the IMAGE-level geometry, plus, per item, the index of every
+    predicate's tile among the distinct ones (`U` = the extra all-absent tile for no-op tokens).  One definition for the Python operators
+    (visual_oracle._prefetch_relations_shared) and the lowering below."""
+    uniq, per_item = {}, []
+    for full, pq, orient in items:
+        idx = np.empty(len(pq), np.int64)
+        for p in range(len(pq)):
+            idx[p] = -1 if full[p] < 0 else uniq.setdefault((int(q_img[pq[p]]), int(full[p]), int(orient[p])), len(uniq))
+        per_item.append(idx)
+    U = len(uniq)
+    slot_of, keys = np.zeros(n_img, np.int64), sorted(uniq, key=uniq.get)
+    slots = np.empty(U, np.int64)
+    for u, (img, _, _) in enumerate(keys):
+        slots[u] = slot_of[img]
+        slot_of[img] += 1
+    K = int(slot_of.max()) if U else 1
+    col, til, ori = np.full((K, n_img), -1, np.int32), np.zeros((K, n_img), np.int32), np.zeros((K, n_img), np.uint8)
+    for u, (img, c, o) in enumerate(keys):
+        col[slots[u], img], til[slots[u], img], ori[slots[u], img] = c, u, o
+    return U, col, til, ori, [np.where(i < 0, U, i) for i in per_item]
+
+
 class ModelSpec(object):
     """What the lowering must know about the model: widths (they size the workspace), the oracle's option normalisation and the
     interpreter's likelihood threshold.  Picklable (collate workers build plans)."""
 
-    def __init__(self, featurizer_widths, attribute_widths, hid1, D, normalize, likelihood_threshold, relation_index):
+    def __init__(self, featurizer_widths, attribute_widths, hid1, D, normalize, likelihood_threshold, relation_index, tile_bf16=False):
         self.featurizer_widths = [int(w) for w in featurizer_widths]      # output width of every featurizer layer (the last = D - 4)
         self.attribute_widths = [int(w) for w in attribute_widths]        # output width of every attribute-network layer
         self.hid1, self.D = int(hid1), int(D)
         self.normalize = bool(normalize)
         self.likelihood_threshold = float(likelihood_threshold)
         self.relation_index = np.asarray(relation_index, np.int32)        # 333-column index -> column of the full concept table
+        # relation tiles stored as bf16 where every consumer reads them directly (relation_tile_dtype: bf16 with a packed second layer of > 256 rows:
+        # visual_oracle.prefetch_relations' rule); decided per batch below (NS % 8 == 0, no choose_rel)
+        self.tile_bf16 = bool(tile_bf16)
 
     def key(self):
         return (tuple(self.featurizer_widths), tuple(self.attribute_widths), self.hid1, self.D, self.normalize, self.likelihood_threshold,
-                self.relation_index.tobytes())
+                self.relation_index.tobytes(), self.tile_bf16)
 
 
 class _W(object):
@@ -95,18 +124,28 @@ class _Builder(object):
         self.instrs = []
         self._blob_parts, self._blob_size, self._blob_memo = [], 0, {}
         self._size = {"o": 0, "t": 0}
-        n_list = [int(n) for n in pb._object_nums]
-        if pb._question_image is not None:
-            raise Unsupported("shared scenes")
-        if not n_list or min(n_list) < 1:
+        if getattr(pb, "_object_nums", None) is None:
+            raise Unsupported("a ProgramBatch without per-image object counts")
+        # two geometries, as fol_types.BatchWorld keeps them: per IMAGE (object rows, pair kernel, attribute columns) and per QUESTION (attention
+        # rows, logic kernels); they coincide unless the collater shared scenes (`_question_image`: question -> image)
+        img_n = [int(n) for n in pb._object_nums]
+        qi = getattr(pb, "_question_image", None)
+        self.shared = qi is not None
+        self.q_img = np.arange(len(img_n), dtype=np.int64) if qi is None else np.asarray(qi, np.int64)
+        if not img_n or min(img_n) < 1 or len(self.q_img) == 0 or self.q_img.min() < 0 or self.q_img.max() >= len(img_n):
             raise Unsupported("an empty batch or an image without objects")
+        n_list = [img_n[i] for i in self.q_img]
         self.n_list, self.Q = n_list, len(n_list)
-        self.O = int(sum(n_list))
+        self.img_n, self.n_img = img_n, len(img_n)
+        self.O = int(sum(img_n))
         self.NS = max(4, (max(n_list) + 3) // 4 * 4)
         self.max_n = max(n_list)
-        n = np.asarray(n_list, np.int64)
+        if max(img_n) > self.NS:
+            raise Unsupported("a scene no question looks at is larger than the batch's blocks")
+        n = np.asarray(img_n, np.int64)
         self.pair_num = int((n * (n - 1)).sum())
-        self.b_n_obj = self.arr(n.astype(np.int32))
+        self.b_img_n_obj = self.arr(n.astype(np.int32))
+        self.b_n_obj = self.arr(np.asarray(n_list, np.int32))
         self.b_obj_off = self.arr(np.concatenate([[0], np.cumsum(n)]).astype(np.int32))
         self.ident = np.arange(self.Q, dtype=np.int32)
         self.b_ident = self.arr(self.ident)
@@ -186,13 +225,38 @@ class _Builder(object):
                 if low.any_valid:
                     entries.append((i, low, np.asarray(batch_index, np.int64), np.zeros(len(flat), np.uint8)))
         self.tiles = {}
+        self.tile_dtype = TILE_F32
         if not entries:
             return
-        if self.pair_num == 0:
-            raise Unsupported("relations over images of one object")
+        # (images of one object have no pairs: the tiles keep their absent fill and the pair kernel, which returns at once for max_n < 2, is not
+        # even requested - the Python operators' route does the same through dfol_pair_ll_*'s early return)
+        bf16 = self.spec.tile_bf16 and NS % 8 == 0 and all(ob._op_name != "choose_rel" for ob in ops)
+        self.tile_dtype = TILE_BF16 if bf16 else TILE_F32
+        esz = 2 if bf16 else 4
+        fill_words = lambda count: (count * NS * NS * esz // 4, _NEG30_BF16X2 if bf16 else _NEG30_BITS)
+        D = self.spec.D
+        if self.shared:
+            # one tile per distinct (scene, concept, orientation) from the pair kernel, then every operator's per-predicate tiles are row gathers
+            # of those (visual_oracle._prefetch_relations_shared)
+            items = []
+            for i, low, pq, orient in entries:
+                full = np.where(low.cols >= 0, self.spec.relation_index[np.maximum(low.cols, 0)], -1).astype(np.int32)
+                items.append((full, np.asarray(pq, np.int64), orient))
+            U, col, til, ori, maps = shared_requests(self.q_img, self.n_img, items)
+            distinct = self.alloc((U + 1) * NS * NS * esz)                # tile U: all absent (no-op tokens)
+            self.emit(OP_FILL, distinct, *fill_words(U + 1))
+            if U and self.pair_num > 0:
+                self.emit(OP_PAIR_LL, self.uv, 2 * self.spec.hid1, self.obj.at((D - 4) * 4), D, self.arr(col), self.arr(til), self.arr(ori), col.shape[0], distinct,
+                          self.n_img, self.tile_dtype)
+            for (i, low, pq, orient), m in zip(entries, maps):
+                P = len(pq)
+                mine = self.alloc(P * NS * NS * esz)
+                self.emit(OP_GATHER_TILES, distinct, self.arr(m.astype(np.int32)), P, mine, NS * NS * esz // 4)
+                self.tiles[i] = (mine, low)
+            return
         total = sum(len(e[1].cols) for e in entries)
-        tiles = self.alloc(total * NS * NS * 4)
-        self.emit(OP_FILL, tiles, total * NS * NS, _NEG30_BITS)
+        tiles = self.alloc(total * NS * NS * esz)
+        self.emit(OP_FILL, tiles, *fill_words(total))
         rows_col, rows_tile, rows_orient, base = [], [], [], 0
         for i, low, pq, orient in entries:
             P = len(pq)
@@ -212,11 +276,12 @@ class _Builder(object):
             til[slot, pq] = base + np.arange(P, dtype=np.int32)
             ori[slot, pq] = orient
             rows_col.append(col), rows_tile.append(til), rows_orient.append(ori)
-            self.tiles[i] = (tiles.at(base * NS * NS * 4), low)
+            self.tiles[i] = (tiles.at(base * NS * NS * esz), low)
             base += P
         col, til, ori = np.concatenate(rows_col), np.concatenate(rows_tile), np.concatenate(rows_orient)
-        D = self.spec.D
-        self.emit(OP_PAIR_LL, self.uv, 2 * self.spec.hid1, self.obj.at((D - 4) * 4), D, self.arr(col), self.arr(til), self.arr(ori), col.shape[0], tiles, Q)
+        if self.pair_num > 0:
+            self.emit(OP_PAIR_LL, self.uv, 2 * self.spec.hid1, self.obj.at((D - 4) * 4), D, self.arr(col), self.arr(til), self.arr(ori), col.shape[0], tiles, Q,
+                      self.tile_dtype)
 
     # ---- attribute blocks: ONE launch for every attribute token list of the batch ---------------------------------------------------------
     def attribute_stage(self, requests):
@@ -228,7 +293,7 @@ class _Builder(object):
         total = sum(len(low.cols) for _, low, _ in todo)
         ll = self.block(total)
         cols = np.concatenate([low.cols for _, low, _ in todo]).astype(np.int32)
-        pimg = np.concatenate([np.asarray(pq, np.int32) for _, _, pq in todo])
+        pimg = np.concatenate([self.q_img[np.asarray(pq, np.int64)].astype(np.int32) for _, _, pq in todo])        # predicate -> scene
         self.emit(OP_ATTR_LL, self.hidden, self.H, self.arr(pimg), self.arr(cols), total, ll)
         base = 0
         for k, low, pq in todo:
@@ -236,7 +301,7 @@ class _Builder(object):
             base += len(low.cols)
 
     # ---- operators --------------------------------------------------------------------------------------------------------------------
-    def _normalize(self, ll, low, pq, rank, normalized):
+    def _normalize(self, ll, low, pq, rank, normalized, esz=4):
         """The option normalisation of visual_oracle._block_likelihood_needed (classifier_oracle.py:72-75, 124-127), in place."""
         if not (self.spec.normalize and normalized):
             return
@@ -244,9 +309,24 @@ class _Builder(object):
         seg = segments_of(np.asarray(pq)[valid])
         if len(seg) - 1 == int(valid.sum()):
             return
-        if not low.all_valid:
-            raise Unsupported("a no-op token inside an option list")
-        self.emit(OP_OPTION_NORMALIZE, ll, self.arr(seg.astype(np.int32)), len(seg) - 1, self.arr(np.asarray(pq, np.int32)), rank)
+        pq = np.asarray(pq, np.int32)
+        if low.all_valid:
+            self.emit(OP_OPTION_NORMALIZE, ll, self.arr(seg.astype(np.int32)), len(seg) - 1, self.arr(pq), rank)
+            return
+        # no-op tokens inside an option list: the compressed list is normalised and the default blocks put back (classifier_oracle.py:56-60,
+        # 72-75; visual_oracle._block_likelihood_needed) - here: gather the valid rows, normalise them, gather back through a map whose no-op
+        # rows point at one extra all-default row
+        if rank == 2 and esz != 4:
+            raise Unsupported("option lists over bf16 tiles")
+        keep = np.flatnonzero(valid).astype(np.int32)
+        width = self.NS if rank == 1 else self.NS * self.NS            # 32-bit words per row
+        compact = self.alloc((len(keep) + 1) * width * 4)
+        self.emit(OP_GATHER_TILES, ll, self.arr(keep), len(keep), compact, width)
+        self.emit(OP_FILL, compact.at(len(keep) * width * 4), width, _NEG30_BITS)
+        self.emit(OP_OPTION_NORMALIZE, compact, self.arr(seg.astype(np.int32)), len(seg) - 1, self.arr(pq[keep]), rank)
+        back = np.full(len(pq), len(keep), np.int32)
+        back[keep] = np.arange(len(keep), dtype=np.int32)
+        self.emit(OP_GATHER_TILES, compact, self.arr(back), len(pq), ll, width)
 
     def filter(self, vs, tokens, key, pq=None, normalized=True):
         """FilterBatch.forward (logic_ops.py; batch_base_ops.py:311-405)."""
@@ -327,7 +407,7 @@ class _Builder(object):
         tiles, low = hit
         out = self.block(self.Q)
         self.emit(OP_RELATE_ONE, x.att, prev.att, tiles, self.b_ident, self.arr(prev.quant), self.arr(low.neg) if low.any_neg else -1,
-                  -1 if low.all_valid else self.arr(low.valid), self.Q, 1 if self.Q == 1 else 0, out)
+                  -1 if low.all_valid else self.arr(low.valid), self.Q, 1 if self.Q == 1 else 0, out, self.tile_dtype)
         quant = np.where(np.asarray([f > 0 for f in host]), x.quant, prev.quant).astype(np.float32)
         return _VS(x.names, out, self.Q, quant, None, x.prev_num + prev.prev_num + 1), low
 
@@ -546,8 +626,6 @@ def _choose_rel(b, i, prev, args):
     if hit is None or prev.pq is not None or prev.rows != Q:
         raise Unsupported("choose_rel without prefetched tiles")
     tiles, low = hit
-    if not low.all_valid:
-        raise Unsupported("a no-op token inside an option list")
     P = len(flat)
     pq = np.asarray(bi, np.int32)
     q_s, q_o = subject_set.quant[pq], object_set.quant[pq]
@@ -556,7 +634,8 @@ def _choose_rel(b, i, prev, args):
     b._normalize(tiles, low, pq, 2, True)
     ps, po = b.block(P), b.block(P)
     flags = (RELATE_LONE_FORALL_IDENTITY if P == 1 else 0) | RELATE_DIAG_ABSENT
-    b.emit(OP_RELATE, subject_set.att, object_set.att, tiles, b.arr(pq), b.arr(q_s), b.arr(q_o), b.arr(low.neg) if low.any_neg else -1, -1, b.arr(want), P,
+    b.emit(OP_RELATE, subject_set.att, object_set.att, tiles, b.arr(pq), b.arr(q_s), b.arr(q_o), b.arr(low.neg) if low.any_neg else -1,
+           -1 if low.all_valid else b.arr(low.valid), b.arr(want), P,
            TILE_SUBJECT_ROWS, flags, ps, po)
     n_prev = subject_set.prev_num + object_set.prev_num + 1
     s_set = _VS(subject_set.names, ps, P, q_s, pq, n_prev)
@@ -584,7 +663,7 @@ def build_plan(program_batch, ontology, spec):
     plan.blob = np.concatenate(b._blob_parts) if b._blob_parts else np.zeros(16, np.uint8)
     plan.out_bytes = out_bytes
     plan.ws_bytes = out_bytes + b._size["t"]
-    plan.scene = dict(O=b.O, Q=b.Q, NS=b.NS, max_n=b.max_n, n_obj=b.b_n_obj, img_n_obj=b.b_n_obj, obj_off=b.b_obj_off)
+    plan.scene = dict(O=b.O, Q=b.Q, NS=b.NS, max_n=b.max_n, n_obj=b.b_n_obj, img_n_obj=b.b_img_n_obj, obj_off=b.b_obj_off)
     for k in ("lp", "flags"):
         if k in result:
             result[k] = resolve(result[k])

@@ -1048,24 +1048,8 @@ class ClassifierOracle(OracleBase):
         """Shared scenes: the distinct (scene, relation column, orientation) triples among `items` = [(full columns, predicate ->
         question, orientation)], as pair-kernel request arrays [K', scenes] over the IMAGE-level geometry, plus, per item, the index of
         every predicate's tile among the distinct ones (`U` = the extra all-absent tile for no-op tokens)."""
-        n_img = len(world._img_n_list)
-        uniq, per_item = {}, []
-        for full, pq, orient in items:
-            idx = np.empty(len(pq), np.int64)
-            for p in range(len(pq)):
-                idx[p] = -1 if full[p] < 0 else uniq.setdefault((int(world._q_img[pq[p]]), int(full[p]), int(orient[p])), len(uniq))
-            per_item.append(idx)
-        U = len(uniq)
-        slot_of, keys = np.zeros(n_img, np.int64), sorted(uniq, key=uniq.get)
-        slots = np.empty(U, np.int64)
-        for u, (img, _, _) in enumerate(keys):
-            slots[u] = slot_of[img]
-            slot_of[img] += 1
-        K = int(slot_of.max()) if U else 1
-        col, til, ori = np.full((K, n_img), -1, np.int32), np.zeros((K, n_img), np.int32), np.zeros((K, n_img), np.uint8)
-        for u, (img, c, o) in enumerate(keys):
-            col[slots[u], img], til[slots[u], img], ori[slots[u], img] = c, u, o
-        return U, col, til, ori, [np.where(i < 0, U, i) for i in per_item]
+        from . import native_plan
+        return native_plan.shared_requests(world._q_img, len(world._img_n_list), items)     # (one definition: the native executor's lowering builds the same arrays)
 
     def _prefetch_relations_shared(self, world, program_batch, entries, dtype, fused):
         """prefetch_relations for a batch whose questions share scenes: one tile per distinct (scene, concept, orientation) from the pair

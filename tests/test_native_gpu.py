@@ -270,3 +270,88 @@ def test_range_flag_belongs_to_its_own_forward(full, monkeypatch):
         with pytest.raises(_lib.DfolError, match="fp16 range"):
             a.result()
         assert torch.equal(b.result()["log_probability"], ref)
+
+
+# ---- round 6: what real runs look like stays on the executor -----------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "choose_attr", "query_attr", "two_same"])
+def test_native_shared_scenes(full, kind, monkeypatch):
+    """24 questions on 4 images collated with share_scenes=True (one copy of every image; image-level pair-kernel requests, per-operator tile
+    gathers): executor == Python loop bit for bit, also split over two ProgramBatches, and == the per-question layout."""
+    model, ont, oont, names, categories = full
+    qs = syn.full_size_questions(kind, 24, 10, 20, names, categories, 300 + ALL_KINDS.index(kind))
+    images = [syn.feature_scene(9100 + i, n, 2048) for i, n in enumerate((17, 40, 9, 28))]
+    pick = np.random.RandomState(7).randint(0, 4, size=len(qs))
+    for q, i in zip(qs, pick):
+        q["image_id"], q["scene"] = "img%d" % i, images[i]
+    for split in (1, 2):
+        nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch, collater=TableCollater(split, ont, "X", share_scenes=True))
+        same_results(nat, py, "shared %s split %d" % (kind, split))
+        monkeypatch.setenv("DFOL_NATIVE", "1")
+        per_q = [pb.to_cuda(DEV) for pb in TableCollater(split, ont, "X").collate([dict(q) for q in qs])]
+        with torch.no_grad():
+            ref = model(per_q, False)
+        same_results(nat, ref, "shared vs per-question %s" % kind)
+
+
+@pytest.mark.parametrize("kind", ["exist", "verify_rel", "choose_rel", "and"])
+@pytest.mark.parametrize("n_list", [[1, 9, 14, 1, 6], [1, 1, 1]])
+def test_native_one_object_images(full, kind, n_list, monkeypatch):
+    """Real GQA scenes have 1..100 objects: an image of ONE object has no pairs (its relate posteriors come from absent tiles); a batch of
+    such images requests no pair kernel at all.  Executor == Python loop, and against the oracle."""
+    model, ont, oont, names, categories = full
+    qs = syn.full_size_questions(kind, len(n_list), 10, 20, names, categories, 410 + ALL_KINDS.index(kind))
+    for q, n in zip(qs, n_list):
+        q["scene"] = syn.feature_scene(q["question_id"], n, 2048)
+    nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch)
+    same_results(nat, py, "one-object %s %s" % (kind, n_list))
+    weights = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("_featurizer.") or k.startswith("_oracle.")}
+    plain = [{k: v for k, v in q.items() if k != "scene"} for q in qs]
+    scenes = [q["scene"] for q in qs]
+    r32 = orc.run_questions(oont, plain, scenes, np.float32, weights=weights)
+    r64 = orc.run_questions(oont, plain, scenes, np.float64, weights=weights)
+    gu.check_logprob(nat["log_probability"].cpu().numpy(), r32["log_probability"], r64["log_probability"], "one-object %s" % kind)
+
+
+@pytest.mark.parametrize("kind", ["choose_rel", "choose_attr", "verify_attrs"])
+def test_native_noop_token_inside_an_option_list(full, kind, monkeypatch):
+    """A no-op token (`_`) among a question's options.  (The reference itself cannot run this shape: with more predicates than questions its
+    row restore indexes the [Q, O] attention with a [P] mask, batch_base_ops.py:385 / :563-564, an IndexError - so there is no oracle to
+    compare with.)  The Python operators normalise the COMPRESSED list and put default blocks back (classifier_oracle.py:56-60, 72-75 read
+    that way); the executor does the same with two row gathers around the normalisation: == Python loop bit for bit, and finite."""
+    model, ont, oont, names, categories = full
+    qs = syn.full_size_questions(kind, 6, 10, 20, names, categories, 520 + ALL_KINDS.index(kind))
+    qs[0]["program"]["last_op"]["arguments"][0][1] = "_"
+    qs[3]["program"]["last_op"]["arguments"][0][0] = "_"
+    nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch)
+    same_results(nat, py, "no-op option %s" % kind)
+    assert bool(torch.isfinite(nat["log_probability"]).all())
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_native_bf16_relation_tiles(full, shared, monkeypatch):
+    """relation_tile_dtype: bf16 (BASELINE configs[4]) on the executor: the pair kernel writes bf16 tiles, dfol_relate_one_fwd_bf16 reads them -
+    NS % 8 == 0 batches; others, and batches with a choose_rel, keep fp32 tiles - bit for bit the Python loop, per question and shared."""
+    model, ont, oont, names, categories = full
+    saved = model._oracle._tile_dtype
+    model._oracle._tile_dtype = torch.bfloat16
+    model.__dict__.pop("_native_model", None)
+    try:
+        for kind, n_lo, n_hi, expect_bf16 in (("exist", 40, 40, True), ("verify_rel", 33, 40, True), ("exist", 30, 36, False), ("choose_rel", 40, 40, False)):
+            qs = syn.full_size_questions(kind, 8, n_lo, n_hi, names, categories, 630 + ALL_KINDS.index(kind))
+            qs[0]["scene"] = syn.feature_scene(qs[0]["question_id"], n_hi, 2048)       # (the largest image fixes NS)
+            if shared:
+                for i, q in enumerate(qs):
+                    q["image_id"], q["scene"] = "img%d" % (i % 3), qs[i % 3]["scene"]
+            coll = TableCollater(1, ont, "X", share_scenes=True) if shared else None
+            nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch, collater=coll)
+            same_results(nat, py, "bf16 tiles %s" % kind)
+            model._oracle._tile_dtype = torch.float32
+            monkeypatch.setenv("DFOL_NATIVE", "1")
+            pbs = [pb.to_cuda(DEV) for pb in (coll or TableCollater(1, ont, "X")).collate([dict(q) for q in qs])]
+            with torch.no_grad():
+                f32 = model(pbs, False)
+            model._oracle._tile_dtype = torch.bfloat16
+            assert torch.equal(f32["log_probability"], nat["log_probability"]) != expect_bf16, (kind, n_lo, n_hi)
+            assert (f32["log_probability"] - nat["log_probability"]).abs().max().item() <= 5e-2
+    finally:
+        model._oracle._tile_dtype = saved

@@ -19,10 +19,11 @@ from dfol_vqa_amd import synthetic as syn  # noqa: E402
 KINDS = ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel", "two_same", "two_different", "all_same",
          "all_different", "compare"]
 W_OPERANDS = {NP.OP_DENSE: [6], NP.OP_BOX_POSITIONS: [1], NP.OP_FILL: [1], NP.OP_PAIR_LL: [1, 3, 9], NP.OP_ATTR_LL: [1, 6], NP.OP_OPTION_NORMALIZE: [1],
+              NP.OP_GATHER_TILES: [1, 4],
               NP.OP_FILTER: [1, 2, 7], NP.OP_RELATE_ONE: [1, 2, 3, 10], NP.OP_RELATE: [1, 2, 3, 13, 14], NP.OP_QUANTIFY: [1, 5], NP.OP_GATE: [1, 2, 7, 8],
               NP.OP_LOGIC: [2, 5], NP.OP_SEGMENT_SUM_ROWS: [1, 5], NP.OP_SEGMENT_OR: [1, 4], NP.OP_IMPLICATION: [1, 2, 5], NP.OP_COMPARE: [1, 2, 5],
               NP.OP_FIND_MAX_IND: [1, 5]}
-B_OPERANDS = {NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
+B_OPERANDS = {NP.OP_GATHER_TILES: [2], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
               NP.OP_RELATE: [4, 5, 6, 7, 8, 9], NP.OP_QUANTIFY: [2, 3], NP.OP_GATE: [3, 4, 5], NP.OP_SEGMENT_SUM_ROWS: [2], NP.OP_SEGMENT_OR: [2],
               NP.OP_IMPLICATION: [3], NP.OP_COMPARE: [3], NP.OP_FIND_MAX_IND: [2]}
 
@@ -83,20 +84,78 @@ def test_every_operator_lowers_and_operands_stay_in_bounds(setup, kind):
         assert np.array_equal(plan.blob[plan.scene["obj_off"]:plan.scene["obj_off"] + 4 * (Q + 1)].view(np.int32), np.concatenate([[0], np.cumsum(n)]))
 
 
-def test_shapes_the_executor_does_not_take_step_aside(setup):
+def _in_bounds(plan):
+    for row in plan.instrs:
+        for k in W_OPERANDS.get(int(row[0]), []):
+            assert -1 <= row[k] < plan.ws_bytes, row
+        for k in B_OPERANDS.get(int(row[0]), []):
+            assert -1 <= row[k] < plan.blob.nbytes and (row[k] < 0 or row[k] % 16 == 0), row
+
+
+def test_round6_shapes_lower(setup):
+    """What used to step aside to the Python loop and lowers since round 6: a no-op token inside an option list (the
+    compressed list is normalised through two row gathers), shared scenes (image-level requests + per-operator tile gathers; the scene
+    header keeps the two geometries apart), an image of ONE object (no pair-kernel request), bf16 relation tiles."""
     ont, names, categories, spec = setup
     qs = syn.full_size_questions("choose_rel", 4, 5, 9, names, categories, 11)
     for q in qs:
         q["scene"]["X"] = q["scene"]["X"][:, -22:]
-    qs[0]["program"]["last_op"]["arguments"][0][1] = "_"          # a no-op token inside an option list: index juggling the executor leaves to Python
-    assert FeatureCollater(1, ont, spec).collate(qs)[0]._native_plan is None
+    qs[0]["program"]["last_op"]["arguments"][0][1] = "_"          # a no-op token inside an option list
+    plan = FeatureCollater(1, ont, spec).collate(qs)[0]._native_plan
+    assert isinstance(plan, NP.NativePlan)
+    _in_bounds(plan)
+    ops = [int(x) for x in plan.instrs[:, 0]]
+    assert ops.count(NP.OP_GATHER_TILES) == 2 and ops.count(NP.OP_OPTION_NORMALIZE) == 1
+    # shared scenes: 6 questions on 2 images
     shared = D.ProgramCollaterBase("select", "relate", "filter", 1, ontology=ont, share_scenes=True, native_spec=spec)
     shared.collate_object_features = FeatureCollater(1, ont).collate_object_features
     shared.collate_meta_data = FeatureCollater(1, ont).collate_meta_data
-    qs2 = syn.full_size_questions("exist", 4, 5, 9, names, categories, 12)
-    for q in qs2:
+    qs2 = syn.full_size_questions("exist", 6, 5, 9, names, categories, 12)
+    for i, q in enumerate(qs2):
+        q["scene"] = qs2[i % 2]["scene"] if i >= 2 else dict(q["scene"], X=q["scene"]["X"][:, -22:])
+        q["image_id"] = "shared%d" % (i % 2)
+    pb = shared.collate(qs2)[0]
+    assert pb._question_image is not None and len(pb._object_nums) == 2
+    plan = pb._native_plan
+    assert isinstance(plan, NP.NativePlan)
+    _in_bounds(plan)
+    sc = plan.scene
+    n_q = plan.blob[sc["n_obj"]:sc["n_obj"] + 4 * 6].view(np.int32)
+    n_i = plan.blob[sc["img_n_obj"]:sc["img_n_obj"] + 4 * 2].view(np.int32)
+    assert list(n_i) == [int(n) for n in pb._object_nums] and list(n_q) == [int(pb._object_nums[i]) for i in pb._question_image]
+    assert sc["O"] == int(sum(pb._object_nums)) and sc["Q"] == 6
+    pair = plan.instrs[[int(x) == NP.OP_PAIR_LL for x in plan.instrs[:, 0]]]
+    assert len(pair) == 1 and int(pair[0][10]) == 2               # requests over the two IMAGES
+    assert NP.OP_GATHER_TILES in [int(x) for x in plan.instrs[:, 0]]
+    # an image of one object next to larger ones, and a batch of one-object images only (no pair kernel)
+    for n_list in ([1, 5, 7], [1, 1]):
+        qs3 = syn.full_size_questions("verify_rel", len(n_list), 5, 9, names, categories, 13)
+        for q, n in zip(qs3, n_list):
+            q["scene"] = {"n": n, "X": q["scene"]["X"][:n, -22:]}
+        plan = FeatureCollater(1, ont, spec).collate(qs3)[0]._native_plan
+        assert isinstance(plan, NP.NativePlan), n_list
+        assert [int(x) for x in plan.instrs[:, 0]].count(NP.OP_PAIR_LL) == (1 if max(n_list) > 1 else 0)
+    # bf16 relation tiles: NS % 8 == 0 and no choose_rel in the batch
+    bspec = NP.ModelSpec([512], [256, 300], 256, 516, True, 0.0, ont._relation_index, tile_bf16=True)
+    assert bspec.key() != spec.key()
+    for n_list, want in (([8, 5, 7], NP.TILE_BF16), ([9, 5, 12], NP.TILE_F32)):
+        qs4 = syn.full_size_questions("verify_rel", len(n_list), 5, 9, names, categories, 14)
+        for q, n in zip(qs4, n_list):
+            q["scene"] = {"n": n, "X": syn.feature_scene(q["question_id"], n, 16)["X"]}
+        plan = FeatureCollater(1, ont, bspec).collate(qs4)[0]._native_plan
+        rel = plan.instrs[[int(x) == NP.OP_RELATE_ONE for x in plan.instrs[:, 0]]]
+        assert len(rel) >= 1 and all(int(r[11]) == want for r in rel), n_list
+        _in_bounds(plan)
+
+
+def test_shapes_the_executor_does_not_take_step_aside(setup):
+    ont, names, categories, spec = setup
+    qs = syn.full_size_questions("exist", 3, 5, 9, names, categories, 15)
+    for q in qs:
         q["scene"]["X"] = q["scene"]["X"][:, -22:]
-    assert shared.collate(qs2)[0]._native_plan is None             # shared scenes: the Python loop
+    pb = FeatureCollater(1, ont).collate(qs)[0]
+    pb._object_nums = None                                       # (ADVICE r5: used to raise TypeError out of build_plan instead of stepping aside)
+    assert NP.build_plan(pb, ont, spec) is None
 
 
 def test_decode_matches_the_python_operators(setup):

@@ -104,6 +104,9 @@ SIGNATURES = {
     "dfol_parametric_not_f32": [_p, _p, _i32, _i32, _p, _p],
     "dfol_segment_or_f32": [_p, _p, _i32, _p, _p],
     "dfol_segment_or_ref_f32": [_p, _p, _i32, _p, _p],
+    "dfol_select_rows_f32": [_p, _p, _p, _i32, _i32, _p, _p],
+    "dfol_calib_features_f32": [_p, _i32, _p, _i32, _p, _i32, _p, _p],
+    "dfol_attention_modulations_f32": [_p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _p],
     "dfol_implication_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_compare_f32": [_p, _p, _p, _i32, _p, _p],
     "dfol_linear_act_f32": [_p, _i64, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
@@ -1247,6 +1250,27 @@ def option_normalize_bwd(g_y, y, seg_off, pred_q, n_obj, NS):
     call("dfol_option_normalize_bwd_f32", _ptr(g_y, F32), _ptr(y, F32), _ptr(seg_off, I32), seg_off.numel() - 1, _ptr(pred_q, I32),
          _ptr(n_obj, I32), NS, y.dim() - 1, _ptr(g_x), _stream())
     return g_x
+
+
+def select_rows(x, y, flags_u8):
+    """out[p] = flags[p] ? x[p] : y[p] (rows of floats; flags uint8 [P] on the device)."""
+    x, y = x.contiguous(), y.contiguous()
+    out = torch.empty_like(x)
+    call("dfol_select_rows_f32", _ptr(x, F32), _ptr(y, F32), _ptr(flags_u8, U8), x.shape[0], x.shape[1], _ptr(out), _stream())
+    return out
+
+
+def attention_modulations(fs, bs, weight, bias):
+    """Sigmoid(Linear([fs | bs])) of the attention-output network in one launch; fs / bs [P, S] (either may be None = zeros), weight [N, 2 S]."""
+    ref = fs if fs is not None else bs
+    P, S = ref.shape
+    N = weight.shape[0]
+    w = weight.detach()
+    w = w if w.stride(1) == 1 else w.contiguous()
+    out = torch.empty(P, N, dtype=F32, device=ref.device)
+    call("dfol_attention_modulations_f32", _ptr(None if fs is None else fs.contiguous(), F32, True), _ptr(None if bs is None else bs.contiguous(), F32, True),
+         _dp(w), w.stride(0), _ptr(None if bias is None else bias.detach(), F32, True), P, S, N, _ptr(out), _stream())
+    return out
 
 
 def modulate(att, mods, pred_q, n_obj):

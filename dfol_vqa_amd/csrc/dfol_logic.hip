@@ -1340,6 +1340,72 @@ extern "C" int dfol_gather_rows_f32(const float* src, const int32_t* idx, int32_
     return 0;
 }
 
+// ---- small pieces of the attention-calibration passes (batch_base_interpreter.py:87-140), for the native executor and the Python operators alike ------
+// out[p] = flags[p] ? x[p] : y[p]  (BatchAttentionState.gate with 0 / 1 flags, batch_base_types.py:279-298: g x + (1 - g) y is a row select there)
+__global__ void select_rows_kernel(const float* __restrict__ x, const float* __restrict__ y, const uint8_t* __restrict__ flags, int width,
+                                   float* __restrict__ out) {
+    const int p = blockIdx.x;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c < width) out[(int64_t)p * width + c] = (flags[p] ? x : y)[(int64_t)p * width + c];
+}
+
+extern "C" int dfol_select_rows_f32(const float* x, const float* y, const uint8_t* flags, int32_t P, int32_t width, float* out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && width > 0, "select_rows: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE(x && y && flags && out, "select_rows: null pointer");
+    hipLaunchKernelGGL(select_rows_kernel, dim3(P, dfol_cdiv(width, 64)), dim3(64), 0, (hipStream_t)stream, x, y, flags, width, out);
+    DFOL_LAUNCH_CHECK("select_rows");
+    return 0;
+}
+
+// LSTM input rows of an operator's tokens (batch_base_ops.py:265-273, 437-446, 628-637): out[p] = [head (n_head floats: the operator's one-hot and the
+// token-type flag) | table[idx[p]] (E floats: the token's embedding)], or an all-zero row for a no-op token (idx[p] < 0)
+__global__ void calib_features_kernel(const float* __restrict__ head, int n_head, const float* __restrict__ table, int E, const int32_t* __restrict__ idx,
+                                      float* __restrict__ out) {
+    const int p = blockIdx.x, F = n_head + E;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    const int t = idx[p];
+    out[(int64_t)p * F + c] = t < 0 ? 0.f : (c < n_head ? head[c] : table[(int64_t)t * E + (c - n_head)]);
+}
+
+extern "C" int dfol_calib_features_f32(const float* head, int32_t n_head, const float* table, int32_t E, const int32_t* idx, int32_t P, float* out,
+                                       void* stream) {
+    DFOL_REQUIRE(P >= 0 && n_head >= 0 && E >= 0 && n_head + E > 0, "calib_features: bad sizes");
+    if (P == 0) return 0;
+    DFOL_REQUIRE((head || n_head == 0) && (table || E == 0) && idx && out, "calib_features: null pointer");
+    hipLaunchKernelGGL(calib_features_kernel, dim3(P, dfol_cdiv(n_head + E, 64)), dim3(64), 0, (hipStream_t)stream, head, n_head, table, E, idx, out);
+    DFOL_LAUNCH_CHECK("calib_features");
+    return 0;
+}
+
+// The attention-output network on the two LSTM states of an operator (BatchOperatorBase._compute_attention_modulations, batch_base_ops.py:275-286, with
+// the Linear(2 S -> N) + Sigmoid of gqa_interpreter_experiments.py:119-132): out[p][j] = Sigmoid(b[j] + W[j][:S] . fs[p] + W[j][S:] . bs[p]); a NULL
+// state counts as zeros (the reference substitutes zeros_like).  One thread per output, terms added in k order.
+__global__ void attention_modulations_kernel(const float* __restrict__ fs, const float* __restrict__ bs, const float* __restrict__ W, int64_t ld_w,
+                                             const float* __restrict__ b, int P, int S, int N, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * N) return;
+    const int p = i / N, j = i - p * N;
+    const float* w = W + (int64_t)j * ld_w;
+    float acc = b ? b[j] : 0.f;
+    if (fs)
+        for (int k = 0; k < S; ++k) acc = fmaf(w[k], fs[(int64_t)p * S + k], acc);
+    if (bs)
+        for (int k = 0; k < S; ++k) acc = fmaf(w[S + k], bs[(int64_t)p * S + k], acc);
+    out[i] = 1.0f / (1.0f + expf(-acc));
+}
+
+extern "C" int dfol_attention_modulations_f32(const float* fs, const float* bs, const float* W, int64_t ld_w, const float* b, int32_t P, int32_t S,
+                                              int32_t N, float* out, void* stream) {
+    DFOL_REQUIRE(P >= 0 && S > 0 && N > 0 && ld_w >= 2 * S, "attention_modulations: bad sizes P=%d S=%d N=%d", P, S, N);
+    if (P == 0) return 0;
+    DFOL_REQUIRE(W && out, "attention_modulations: null pointer");
+    hipLaunchKernelGGL(attention_modulations_kernel, dim3(dfol_cdiv((int64_t)P * N, 256)), dim3(256), 0, (hipStream_t)stream, fs, bs, W, ld_w, b, P, S, N, out);
+    DFOL_LAUNCH_CHECK("attention_modulations");
+    return 0;
+}
+
 __global__ void segment_sum_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ seg_off, int width,
                                         float* __restrict__ out) {
     const int q = blockIdx.x;

@@ -180,6 +180,36 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                 rc = dfol_gather_rows_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const int32_t*>(at(blob, a[2])), static_cast<int32_t>(a[3]),
                                           a[5] > 0 ? static_cast<int32_t>(a[5]) : NS * NS, static_cast<float*>(at(workspace, a[4])), stream);
                 break;
+            case DFOL_OP_CALIB_FEATURES: // head, n_head, table, E, idx, P, out
+                rc = dfol_calib_features_f32(static_cast<const float*>(at(blob, a[1])), static_cast<int32_t>(a[2]), static_cast<const float*>(at(blob, a[3])),
+                                             static_cast<int32_t>(a[4]), static_cast<const int32_t*>(at(blob, a[5])), static_cast<int32_t>(a[6]),
+                                             static_cast<float*>(at(workspace, a[7])), stream);
+                break;
+            case DFOL_OP_LSTM_CELL: {    // which, x, h, c, rows, h_out, c_out
+                const int w = a[1] ? 1 : 0;
+                DFOL_REQUIRE(model->lstm_wih_t[w] && model->lstm_whh_t[w] && model->lstm_h > 0 && model->lstm_kx > 0, "run_program[%d]: the model has no calibration LSTM", i);
+                rc = dfol_lstm_cell_f32(static_cast<const float*>(at(workspace, a[2])), model->lstm_kx, model->lstm_kx, static_cast<const float*>(at(workspace, a[3])),
+                                        model->lstm_h, static_cast<const float*>(at(workspace, a[4])), model->lstm_wih_t[w], model->lstm_ld_wih[w], model->lstm_whh_t[w],
+                                        model->lstm_ld_whh[w], model->lstm_bih[w], model->lstm_bhh[w], static_cast<int32_t>(a[5]), model->lstm_h,
+                                        static_cast<float*>(at(workspace, a[6])), static_cast<float*>(at(workspace, a[7])), stream);
+                break;
+            }
+            case DFOL_OP_SELECT_ROWS:    // x, y, flags, P, width, out
+                rc = dfol_select_rows_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])),
+                                          static_cast<const uint8_t*>(at(blob, a[3])), static_cast<int32_t>(a[4]), static_cast<int32_t>(a[5]),
+                                          static_cast<float*>(at(workspace, a[6])), stream);
+                break;
+            case DFOL_OP_ATT_MODULATIONS: // fs, bs, P, out
+                DFOL_REQUIRE(model->att_out_w && model->att_out_n > 0, "run_program[%d]: the model has no attention-output network", i);
+                rc = dfol_attention_modulations_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])), model->att_out_w,
+                                                    model->ld_att_out, model->att_out_b, static_cast<int32_t>(a[3]), model->lstm_h, model->att_out_n,
+                                                    static_cast<float*>(at(workspace, a[4])), stream);
+                break;
+            case DFOL_OP_MODULATE:       // att, mods, pred_q, P, out
+                DFOL_REQUIRE(model->att_out_n == 4, "run_program[%d]: dfol_modulate_f32 takes 4-column modulations", i);
+                rc = dfol_modulate_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])),
+                                       static_cast<const int32_t*>(at(blob, a[3])), n_obj, static_cast<int32_t>(a[4]), NS, static_cast<float*>(at(workspace, a[5])), stream);
+                break;
             default:
                 dfol_set_error("run_program[%d]: unknown opcode %lld", i, (long long)a[0]);
                 return 1;

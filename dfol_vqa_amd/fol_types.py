@@ -412,8 +412,19 @@ class BatchAttentionState(object):
         idx = predicate_question_map.to(torch.int64)
         return BatchAttentionState(self._name, self._device, (self._state[0][idx], self._state[1][idx]))
 
-    def squeeze(self, predicate_question_map, question_num=None):   # mm(pqm^T, state)  :306-310
+    def squeeze(self, predicate_question_map, question_num=None, host=None):   # mm(pqm^T, state)  :306-310
         idx = predicate_question_map.to(torch.int64)
         Q = int(question_num if question_num is not None else int(idx.max()) + 1)
+        host = host if host is not None else getattr(predicate_question_map, "_host", None)
+        host = None if host is None else list(host)
+        s0 = self._state[0]
+        if host is not None and s0.is_cuda and s0.dtype == torch.float32 and not (torch.is_grad_enabled() and (s0.requires_grad or self._state[1].requires_grad)) \
+                and all(b >= a for a, b in zip(host, host[1:])):
+            # the predicates of a question are consecutive (what flatten_list produces): a segmented row sum in a FIXED order - index_add_ on
+            # the device is an atomic add, its rounding differs from run to run (and from the native executor's, which takes this kernel)
+            from .host_util import upload
+            counts = np.bincount(np.asarray(host, np.int64), minlength=Q)
+            seg = upload(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), s0.device)
+            return BatchAttentionState(self._name, self._device, (L.segment_sum_rows(s0.contiguous(), seg), L.segment_sum_rows(self._state[1].contiguous(), seg)))
         z = lambda s: torch.zeros(Q, s.shape[1], dtype=s.dtype, device=s.device).index_add_(0, idx, s)
         return BatchAttentionState(self._name, self._device, (z(self._state[0]), z(self._state[1])))

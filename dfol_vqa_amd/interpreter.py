@@ -258,18 +258,18 @@ class BatchInterpreterBase(nn.Module):
 
     def _native_spec(self, is_training, modulator_switch, return_trace):
         """The lowering spec when this forward may run on the native executor (native_exec / native_plan: one C call per ProgramBatch instead
-        of one Python dispatch per operator), else None: inference without gradients reaching the oracle, no attention calibration, soft
-        quantifiers, no trace, fp32 tiles, and not inside a graph capture (a capture records the Python loop's launches, as before)."""
+        of one Python dispatch per operator), else None: inference without gradients reaching the oracle or the calibrator, soft quantifiers, no
+        trace, and not inside a graph capture (a capture records the Python loop's launches, as before).  Since round 6 the calibrated forward
+        (activate_attention_transfer, the reference's default), shared scenes and bf16 relation tiles stay on the executor."""
         from . import _lib, native_exec
         if not native_exec.enabled() or is_training or return_trace or _lib.capturing() or getattr(self, "_hard_mode", False):
             return None
-        if self._has_modulator and modulator_switch:
-            return None
-        if torch.is_grad_enabled() and any(p.requires_grad for m in (self._oracle, self._featurizer) if isinstance(m, nn.Module) for p in m.parameters()):
-            return None
+        calibrate = bool(self._has_modulator and modulator_switch)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return None                                      # gradients reach the oracle or the calibrator: the differentiable Python operators
         if not hasattr(self, "_ontology"):
             return None
-        return native_exec.model_spec(self)
+        return native_exec.model_spec(self, calibrate)
 
     def _run_batches(self, program_batch_list, is_training, modulator_switch, return_trace=False):
         from . import _lib

@@ -122,9 +122,18 @@ class BatchOperatorBase(nn.Module):
         return full.index_copy_(0, upload(np.nonzero(ind)[0].astype(np.int64), world._device), feats)    # (a mask assignment synchronises)
 
     def _compute_attention_modulations(self, forward_state, backward_state):    # :275-286
+        net = self._attention_output_network
+        ref = backward_state[0] if forward_state is None else forward_state[0]
+        plain = isinstance(net, nn.Sequential) and len(net) == 2 and isinstance(net[0], nn.Linear) and isinstance(net[1], nn.Sigmoid)
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in net.parameters()) or
+                                                  any(t is not None and t[0].requires_grad for t in (forward_state, backward_state)))
+        if plain and ref.is_cuda and ref.dtype == torch.float32 and not needs_grad:
+            # inference: Linear(2 S -> 4) + Sigmoid on the two states in ONE launch, no concatenation (the kernel the native executor calls too)
+            return L.attention_modulations(None if forward_state is None else forward_state[0], None if backward_state is None else backward_state[0],
+                                           net[0].weight, net[0].bias)
         fs = torch.zeros_like(backward_state[0]) if forward_state is None else forward_state[0]
         bs = torch.zeros_like(forward_state[0]) if backward_state is None else backward_state[0]
-        return self._attention_output_network(torch.cat([fs, bs], dim=1))
+        return net(torch.cat([fs, bs], dim=1))
 
 
 class SelectBatch(BatchOperatorBase):
@@ -216,7 +225,7 @@ def _filter_transform_attention(self, op_id, is_forward, world, attention_state,
         self._modulations[op_id] = self._compute_attention_modulations(self._forward_state[op_id], attention_state._state)
     self._forward_state.pop(op_id, None)
     new_state = BatchAttentionState(attention_state._name, world._device, self._backward_attention_network(features, attention_state._state))
-    return new_state.squeeze(pred_q, question_num) if pred_q is not None else new_state
+    return new_state.squeeze(pred_q, question_num, host=host_map) if pred_q is not None else new_state
 
 
 FilterBatch.transform_attention = _filter_transform_attention
@@ -307,7 +316,7 @@ def _relate_transform_attention(self, op_id, is_forward, world, subject_attentio
     new_s = BatchAttentionState(subject_attention_state._name, dev, new)
     new_o = BatchAttentionState(object_attention_state._name, dev, (new[0].clone(), new[1].clone()))
     if pred_q is not None:
-        new_s, new_o = new_s.squeeze(pred_q, question_num), new_o.squeeze(pred_q, question_num)
+        new_s, new_o = new_s.squeeze(pred_q, question_num, host=host_map), new_o.squeeze(pred_q, question_num, host=host_map)
     return new_s, new_o
 
 

@@ -29,7 +29,9 @@ class DenseLayer(ctypes.Structure):
 class ProgramModel(ctypes.Structure):
     _fields_ = [("n_featurizer", _i32), ("n_attribute", _i32), ("featurizer", ctypes.POINTER(DenseLayer)), ("attribute", ctypes.POINTER(DenseLayer)),
                 ("uv", DenseLayer), ("pair_kind", _i32), ("hid1", _i32), ("hid2", _i32), ("w2_rows", _i32), ("wg", _p), ("w2", _p), ("ld_w2", _i64),
-                ("b2", _p), ("emb_w", _p), ("ld_e", _i64), ("emb_b", _p), ("emb_in", _i32), ("D", _i32)]
+                ("b2", _p), ("emb_w", _p), ("ld_e", _i64), ("emb_b", _p), ("emb_in", _i32), ("D", _i32),
+                ("lstm_wih_t", _p * 2), ("lstm_whh_t", _p * 2), ("lstm_ld_wih", _i64 * 2), ("lstm_ld_whh", _i64 * 2), ("lstm_bih", _p * 2), ("lstm_bhh", _p * 2),
+                ("lstm_kx", _i32), ("lstm_h", _i32), ("att_out_w", _p), ("ld_att_out", _i64), ("att_out_b", _p), ("att_out_n", _i32)]
 
 
 class ProgramScene(ctypes.Structure):
@@ -83,8 +85,28 @@ def _layers(seq):
     return out
 
 
-def model_spec(model):
-    """native_plan.ModelSpec of an interpreter, or None when its modules are not the shapes the executor drives."""
+def calibrator(model):
+    """(forward LSTM cell, backward LSTM cell, output Linear) of an interpreter whose attention calibrator the executor can run - the modules
+    every operator shares (batch_base_ops.py:251-254) - or None: no calibrator, or shapes the one-launch kernels do not take."""
+    from .visual_oracle import CalibrationLSTMCell
+    if not getattr(model, "_has_modulator", False):
+        return None
+    flt = model._ops['filter']._filter
+    fwd, bwd, out = (getattr(flt, n, None) for n in ("_forward_attention_network", "_backward_attention_network", "_attention_output_network"))
+    if not (isinstance(fwd, CalibrationLSTMCell) and isinstance(bwd, CalibrationLSTMCell) and isinstance(out, nn.Sequential) and len(out) == 2
+            and isinstance(out[0], nn.Linear) and isinstance(out[1], nn.Sigmoid)):
+        return None
+    S, KX = fwd.hidden_size, fwd.input_size
+    if (bwd.hidden_size, bwd.input_size) != (S, KX) or out[0].in_features != 2 * S or out[0].out_features != 4 or 4 * (KX + 5 * S) * 4 > 65536:
+        return None
+    if not all(p.is_cuda and p.dtype == torch.float32 for m in (fwd, bwd, out) for p in m.parameters()):
+        return None
+    return fwd, bwd, out[0]
+
+
+def model_spec(model, calibrate=False):
+    """native_plan.ModelSpec of an interpreter, or None when its modules are not the shapes the executor drives.  calibrate: the forward runs
+    the attention-calibration passes (activate_attention_transfer, modulator_switch on)."""
     from .interpreter import BatchGQABoxFeaturizer
     feat, oracle = model._featurizer, model._oracle
     if not isinstance(feat, BatchGQABoxFeaturizer) or getattr(feat._featurizer_network, "_network", None) is None:
@@ -99,8 +121,14 @@ def model_spec(model):
     # more than 256 rows (visual_oracle.prefetch_relations' rule; the weight's shape decides, not its values)
     tile_bf16 = getattr(oracle, "_tile_dtype", torch.float32) == torch.bfloat16 and 256 < lin2.out_features <= 320 and lin1.out_features <= 256 and \
         lin1.out_features % 16 == 0 and os.environ.get("DFOL_PAIR_PACKED", "1") != "0"
+    calib = None
+    if calibrate:
+        nets = calibrator(model)
+        if nets is None:
+            return None
+        calib = dict(state_dim=int(nets[0].hidden_size), lstm_in=int(nets[0].input_size), ops_index=dict(model._OPS_INDEX))
     return NP.ModelSpec([l.out_features for l, _ in fl], [l.out_features for l, _ in al], lin1.out_features, fl[-1][0].out_features + 4,
-                        oracle._normalize, model._likelihood_threshold, oracle._ontology._relation_index, tile_bf16=tile_bf16)
+                        oracle._normalize, model._likelihood_threshold, oracle._ontology._relation_index, tile_bf16=tile_bf16, calib=calib)
 
 
 class NativeModel(object):
@@ -151,12 +179,30 @@ class NativeModel(object):
         m.emb_b = None if emb.bias is None else emb.bias.detach().data_ptr()
         m.emb_in, m.D = int(ew.shape[1]), int(D)
         self._hold += [wuv, buv, wg, w2p, b2, w2, ew, emb.bias]
+        nets = calibrator(model)
+        if nets is not None:
+            for k, cell in enumerate(nets[:2]):
+                _, wih_t, whh_t = cell._transposed()
+                m.lstm_wih_t[k], m.lstm_whh_t[k] = wih_t.data_ptr(), whh_t.data_ptr()
+                m.lstm_ld_wih[k], m.lstm_ld_whh[k] = wih_t.stride(0), whh_t.stride(0)
+                m.lstm_bih[k] = None if cell.bias_ih is None else cell.bias_ih.detach().data_ptr()
+                m.lstm_bhh[k] = None if cell.bias_hh is None else cell.bias_hh.detach().data_ptr()
+                self._hold += [wih_t, whh_t, cell.bias_ih, cell.bias_hh]
+            m.lstm_kx, m.lstm_h = int(nets[0].input_size), int(nets[0].hidden_size)
+            ow = nets[2].weight.detach()
+            ow = ow if ow.stride(1) == 1 else ow.contiguous()
+            m.att_out_w, m.ld_att_out, m.att_out_n = ow.data_ptr(), ow.stride(0), int(ow.shape[0])
+            m.att_out_b = None if nets[2].bias is None else nets[2].bias.detach().data_ptr()
+            self._hold += [ow, nets[2].bias]
         self.struct = m
         self.D = int(D)
 
     @staticmethod
     def version_key(model):
         params = list(model._featurizer.parameters()) + list(model._oracle.parameters())
+        nets = calibrator(model)
+        if nets is not None:
+            params += [p for m in nets for p in m.parameters()]
         return (tuple((p.data_ptr(), p._version) for p in params), _lib._dense_math(), _lib.pair_math(), str(params[0].device) if params else "")
 
 

@@ -23,7 +23,8 @@ from .host_util import flatten_list, get_lowered, lower_tokens, segments_of, unf
 
 # opcodes of include/dfol_vqa.h
 (OP_DENSE, OP_BOX_POSITIONS, OP_FILL, OP_PAIR_LL, OP_ATTR_LL, OP_OPTION_NORMALIZE, OP_FILTER, OP_RELATE_ONE, OP_RELATE, OP_QUANTIFY, OP_GATE,
- OP_LOGIC, OP_SEGMENT_SUM_ROWS, OP_SEGMENT_OR, OP_IMPLICATION, OP_COMPARE, OP_FIND_MAX_IND, OP_GATHER_TILES) = range(18)
+ OP_LOGIC, OP_SEGMENT_SUM_ROWS, OP_SEGMENT_OR, OP_IMPLICATION, OP_COMPARE, OP_FIND_MAX_IND, OP_GATHER_TILES, OP_CALIB_FEATURES, OP_LSTM_CELL,
+ OP_SELECT_ROWS, OP_ATT_MODULATIONS, OP_MODULATE) = range(23)
 INSTR_WIDTH = 16
 LOGIC_AND, LOGIC_OR, LOGIC_NOT = 0, 1, 2
 TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
@@ -67,7 +68,7 @@ class ModelSpec(object):
     """What the lowering must know about the model: widths (they size the workspace), the oracle's option normalisation and the
     interpreter's likelihood threshold.  Picklable (collate workers build plans)."""
 
-    def __init__(self, featurizer_widths, attribute_widths, hid1, D, normalize, likelihood_threshold, relation_index, tile_bf16=False):
+    def __init__(self, featurizer_widths, attribute_widths, hid1, D, normalize, likelihood_threshold, relation_index, tile_bf16=False, calib=None):
         self.featurizer_widths = [int(w) for w in featurizer_widths]      # output width of every featurizer layer (the last = D - 4)
         self.attribute_widths = [int(w) for w in attribute_widths]        # output width of every attribute-network layer
         self.hid1, self.D = int(hid1), int(D)
@@ -77,10 +78,14 @@ class ModelSpec(object):
         # relation tiles stored as bf16 where every consumer reads them directly (relation_tile_dtype: bf16 with a packed second layer of > 256 rows:
         # visual_oracle.prefetch_relations' rule); decided per batch below (NS % 8 == 0, no choose_rel)
         self.tile_bf16 = bool(tile_bf16)
+        # attention calibration (activate_attention_transfer with the modulator switched on): None, or {"state_dim": S, "lstm_in": 18 + token
+        # embedding width, "ops_index": operator -> one-hot position (batch_gqa_interpreter.py:67-70)}
+        self.calib = None if calib is None else dict(state_dim=int(calib["state_dim"]), lstm_in=int(calib["lstm_in"]), ops_index=dict(calib["ops_index"]))
 
     def key(self):
         return (tuple(self.featurizer_widths), tuple(self.attribute_widths), self.hid1, self.D, self.normalize, self.likelihood_threshold,
-                self.relation_index.tobytes(), self.tile_bf16)
+                self.relation_index.tobytes(), self.tile_bf16,
+                None if self.calib is None else (self.calib["state_dim"], self.calib["lstm_in"], tuple(sorted(self.calib["ops_index"].items()))))
 
 
 class _W(object):
@@ -100,6 +105,14 @@ class _VS(object):
 
     def __init__(self, names, att, rows, quant, pq=None, prev_num=0):
         self.names, self.att, self.rows, self.quant, self.pq, self.prev_num = names, att, rows, np.asarray(quant, np.float32), pq, prev_num
+
+
+class _AS(object):
+    """Symbolic BatchAttentionState (fol_types.py; batch_base_types.py:256-310): names and the LSTM state (h, c) [rows, S] in the workspace."""
+    __slots__ = ("names", "h", "c", "rows")
+
+    def __init__(self, names, h, c, rows):
+        self.names, self.h, self.c, self.rows = names, h, c, rows
 
 
 class NativePlan(object):
@@ -122,6 +135,7 @@ class _Builder(object):
     def __init__(self, pb, ontology, spec):
         self.pb, self.ont, self.spec = pb, ontology, spec
         self.instrs = []
+        self.calibration = None
         self._blob_parts, self._blob_size, self._blob_memo = [], 0, {}
         self._size = {"o": 0, "t": 0}
         if getattr(pb, "_object_nums", None) is None:
@@ -328,8 +342,17 @@ class _Builder(object):
         back[keep] = np.arange(len(keep), dtype=np.int32)
         self.emit(OP_GATHER_TILES, compact, self.arr(back), len(pq), ll, width)
 
-    def filter(self, vs, tokens, key, pq=None, normalized=True):
-        """FilterBatch.forward (logic_ops.py; batch_base_ops.py:311-405)."""
+    def modulate(self, att, mkey, pq_arr, P):
+        """BatchVariableSet.apply_modulations (batch_base_types.py:170-187) when the calibration passes left modulations for this operator."""
+        mods = None if self.calibration is None else self.calibration.mods.pop(mkey, None)
+        if mods is None:
+            return att
+        out = self.block(P)
+        self.emit(OP_MODULATE, att, mods, self.arr(np.asarray(pq_arr, np.int32)), P, out)
+        return out
+
+    def filter(self, vs, tokens, key, pq=None, normalized=True, mkey=None):
+        """FilterBatch.forward (logic_ops.py; batch_base_ops.py:311-405).  mkey: the (operator index, role) its modulations were left under."""
         low = get_lowered(tokens, self.ont, TokenType.ATTRIBUTE)
         if not low.any_valid:
             return vs
@@ -349,9 +372,11 @@ class _Builder(object):
         self._normalize(ll, low, pq_arr, 1, normalized)
         out = self.block(P)
         self.emit(OP_FILTER, vs.att, ll, self.arr(pq_arr), self.arr(low.neg) if low.any_neg else -1, -1 if low.all_valid else self.arr(low.valid), P, out)
+        if mkey is not None:
+            out = self.modulate(out, mkey, pq_arr, P)                                  # :401-403
         return _VS(vs.names, out, P, quant, None if pq is None else pq_arr, vs.prev_num + 1)
 
-    def select(self, tokens, key):
+    def select(self, tokens, key, mkey=None):
         """GQASelectBatch.forward (batch_gqa_ops.py:168-183)."""
         Q = self.Q
         if tokens is None:
@@ -362,7 +387,7 @@ class _Builder(object):
         x = _VS(names, self.zeros(), Q, np.full(Q, float(Quantifier.EXISTS), np.float32))
         if att is None or all(a is None for a in att):
             return x
-        return self.filter(x, att, key)
+        return self.filter(x, att, key, mkey=mkey)
 
     @staticmethod
     def select_tokens(tokens, Q):
@@ -392,6 +417,10 @@ class _Builder(object):
         if mask is None or x is prev:
             return x
         g = np.asarray(mask, np.float32)
+        # (a calibrated operator modulated EVERY row of its result, the pass-through rows included - apply_modulations knows no mask - so the
+        # incoming rows must really be put back)
+        if self.calibration is not None and bool((g == 0).any()):
+            return self.gate(x, prev, mask)
         if len(mask) != x.rows or x.rows != prev.rows or bool(((g == 0) & np.asarray(valid, bool)[:len(mask)]).any()) or not bool(((g == 0) | (g == 1)).all()):
             return self.gate(x, prev, mask)
         names = self.gate_names(x.names, prev.names, mask)
@@ -399,7 +428,7 @@ class _Builder(object):
 
     def relate(self, i, prev, relation_list, is_subject, names_tokens, key):
         """GQARelateBatch.forward on the fused single-posterior kernel (gqa_ops.GQARelateBatch._forward_fused; batch_gqa_ops.py:364-371)."""
-        x = self.select(names_tokens, key)
+        x = self.select(names_tokens, key, mkey=(i, "sel"))
         host = [0.0 if f is None else float(f) for f in is_subject]
         hit = self.tiles.get(i)
         if hit is None or x.rows != prev.rows or prev.pq is not None or x.rows != self.Q:
@@ -408,6 +437,20 @@ class _Builder(object):
         out = self.block(self.Q)
         self.emit(OP_RELATE_ONE, x.att, prev.att, tiles, self.b_ident, self.arr(prev.quant), self.arr(low.neg) if low.any_neg else -1,
                   -1 if low.all_valid else self.arr(low.valid), self.Q, 1 if self.Q == 1 else 0, out, self.tile_dtype)
+        if self.calibration is not None and (i, "rel_s") in self.calibration.mods:
+            # RelateBatch.forward calibrates both posteriors (batch_base_ops.py:588-594) and GQARelateBatch keeps one per question: the kept one
+            # with that side's modulations (gqa_ops.GQARelateBatch._forward_fused)
+            ms, mo = self.calibration.mods.pop((i, "rel_s")), self.calibration.mods.pop((i, "rel_o"))
+            if all(f > 0 for f in host):
+                mods = ms
+            elif not any(f > 0 for f in host):
+                mods = mo
+            else:
+                mods = self.alloc(self.Q * 4 * 4)
+                self.emit(OP_SELECT_ROWS, ms, mo, self.arr(np.asarray([1 if f > 0 else 0 for f in host], np.uint8)), self.Q, 4, mods)
+            out2 = self.block(self.Q)
+            self.emit(OP_MODULATE, out, mods, self.b_ident, self.Q, out2)
+            out = out2
         quant = np.where(np.asarray([f > 0 for f in host]), x.quant, prev.quant).astype(np.float32)
         return _VS(x.names, out, self.Q, quant, None, x.prev_num + prev.prev_num + 1), low
 
@@ -435,6 +478,300 @@ class _Builder(object):
     def category_options(self, category_list, names):
         lists = [self.ont.query(c if c not in ["name", "type"] else n) for c, n in zip(category_list, names)]
         return lists, flatten_list(lists)
+
+
+# ---- attention calibration: the LSTM walks the aligned program forward and backward before it is executed (batch_base_interpreter.py:87-140) ------
+class _Calibration(object):
+    """The symbolic walk of interpreter._calibration_passes and of every operator's transform_attention (gqa_ops.py / logic_ops.py;
+    batch_gqa_ops.py and batch_base_ops.py:407-467, 598-684): emits the LSTM cells, state gates and attention-output products of both passes and
+    leaves, per (operator index, role), the workspace reference of the [P, 4] modulations the execution pass applies.  Roles: "sel" (the filter of
+    an operator's select), "flt" / "flt:0" / "flt:1" (its own filter[s]), "rel_s" / "rel_o" (its relate's two posteriors)."""
+
+    def __init__(self, b, pb):
+        self.b, self.c = b, b.spec.calib
+        self.S = self.c["state_dim"]
+        self.mods, self.fwd = {}, {}
+        self._zero, self._feat_memo, self._table, self._table_rows = {}, {}, {}, []
+        md = pb._meta_data if isinstance(getattr(pb, "_meta_data", None), dict) else {}
+        self.index, self.embedding = md.get("index"), md.get("embedding")
+        self.E = None
+
+    # -- token embeddings: a plan-local table in the blob (the rows get_embedding would hand the LSTM: base_oracle.py:45-55) -------------------------
+    def _embedding_rows(self, names):
+        try:
+            ind = [self.index[t] for t in names]
+            emb = self.embedding
+            rows = emb[ind, :] if not hasattr(emb, "detach") else emb.detach().cpu()[ind, :].numpy()
+            return np.asarray(rows, np.float32).reshape(len(names), -1), "i"
+        except (KeyError, TypeError, IndexError):
+            rows = self.b.ont.get_embeddings(names)
+            if rows is None:
+                raise Unsupported("tokens without an embedding (no index entry, no embedding file)")
+            return np.asarray(rows, np.float32).reshape(len(names), -1), "o"
+
+    def features(self, tokens, op_name, type_flag):
+        """-> workspace [P, lstm_in]: rows [operator one-hot, type flag, token embedding], zero rows for no-op tokens."""
+        from .host_util import detect_negations, is_valid_token
+        key = (tuple(str(t) for t in tokens), float(type_flag), op_name)
+        hit = self._feat_memo.get(key)
+        if hit is not None:
+            return hit
+        ind = [is_valid_token(v) for v in tokens]
+        kept = [t for t, k in zip(tokens, ind) if k]
+        _, _, names = detect_negations(kept)
+        rows, src = self._embedding_rows(list(names))
+        if self.E is None:
+            self.E = rows.shape[1]
+        head = np.zeros(len(self.c["ops_index"]) + 1, np.float32)
+        head[self.c["ops_index"][op_name]] = 1.0
+        head[-1] = type_flag
+        if rows.shape[1] != self.E or len(head) + self.E != self.c["lstm_in"]:
+            raise Unsupported("token embeddings of another width than the calibration LSTM's input")
+        idx, j = np.full(len(tokens), -1, np.int32), 0
+        for p, k in enumerate(ind):
+            if k:
+                tk = (src, names[j])
+                if tk not in self._table:
+                    self._table[tk] = len(self._table_rows)
+                    self._table_rows.append(rows[j])
+                idx[p] = self._table[tk]
+                j += 1
+        out = self.b.alloc(len(tokens) * self.c["lstm_in"] * 4)
+        # (the table's blob offset is patched in by finish(): rows keep arriving while the passes are walked)
+        self.b.emit(OP_CALIB_FEATURES, self.b.arr(head), len(head), ("table", self), self.E, self.b.arr(idx), len(tokens), out)
+        self._feat_memo[key] = out
+        return out
+
+    def finish(self):
+        off = self.b.arr(np.stack(self._table_rows)) if self._table_rows else -1
+        for row in self.b.instrs:
+            for k, v in enumerate(row):
+                if isinstance(v, tuple) and v[0] == "table" and v[1] is self:
+                    row[k] = off
+
+    # -- attention states ---------------------------------------------------------------------------------------------------------------------
+    def zero_state(self, names, rows):
+        z = self._zero.get(rows)
+        if z is None:
+            z = self._zero[rows] = self.b.alloc(rows * self.S * 4)
+            self.b.emit(OP_FILL, z, rows * self.S, 0)
+        return _AS(list(names), z, z, rows)
+
+    def gate(self, x, y, flags):
+        """BatchAttentionState.gate (:279-298) with host flags: rows whose flag is > 0 come from x."""
+        host = [0 if f is None else f for f in flags]
+        names = [a if f > 0 else c for a, c, f in zip(x.names, y.names, host)]
+        if not all(f in (0, 1, 0.0, 1.0, True, False) for f in host):
+            raise Unsupported("a fractional state gate")
+        if all(f > 0 for f in host):
+            return _AS(names, x.h, x.c, x.rows)
+        if not any(f > 0 for f in host):
+            return _AS(names, y.h, y.c, y.rows)
+        if x.rows != y.rows or len(host) != x.rows:
+            raise Unsupported("a state gate over differing batch sizes")
+        same = lambda u, v: u.region == v.region and u.off == v.off
+        if same(x.h, y.h) and same(x.c, y.c):                    # both sides are one state (two zero states, a relate's twin posteriors): no launch
+            return _AS(names, x.h, x.c, x.rows)
+        pick = self.b.arr(np.asarray([1 if f > 0 else 0 for f in host], np.uint8))
+        h, c = self.b.alloc(x.rows * self.S * 4), self.b.alloc(x.rows * self.S * 4)
+        self.b.emit(OP_SELECT_ROWS, x.h, y.h, pick, x.rows, self.S, h)
+        self.b.emit(OP_SELECT_ROWS, x.c, y.c, pick, x.rows, self.S, c)
+        return _AS(names, h, c, x.rows)
+
+    def expand(self, x, pq):
+        P = len(pq)
+        idx = self.b.arr(np.asarray(pq, np.int32))
+        h, c = self.b.alloc(P * self.S * 4), self.b.alloc(P * self.S * 4)
+        self.b.emit(OP_GATHER_TILES, x.h, idx, P, h, self.S)
+        self.b.emit(OP_GATHER_TILES, x.c, idx, P, c, self.S)
+        return _AS(x.names, h, c, P)
+
+    def squeeze(self, x, pq):
+        pq = np.asarray(pq, np.int64)
+        if len(pq) > 1 and not bool(np.all(pq[1:] >= pq[:-1])):
+            raise Unsupported("an unsorted option list")
+        Q = self.b.Q
+        seg = self.b.seg_off(pq)
+        h, c = self.b.alloc(Q * self.S * 4), self.b.alloc(Q * self.S * 4)
+        self.b.emit(OP_SEGMENT_SUM_ROWS, x.h, seg, Q, self.S, h)
+        self.b.emit(OP_SEGMENT_SUM_ROWS, x.c, seg, Q, self.S, c)
+        return _AS(x.names, h, c, Q)
+
+    def add(self, x, y):
+        if x.rows != y.rows:
+            raise Unsupported("states of differing batch sizes")
+        h, c = self.b.alloc(x.rows * self.S * 4), self.b.alloc(x.rows * self.S * 4)
+        self.b.emit(OP_LOGIC, LOGIC_AND, x.h, y.h, x.rows * self.S, h)
+        self.b.emit(OP_LOGIC, LOGIC_AND, x.c, y.c, x.rows * self.S, c)
+        return _AS(x.names, h, c, x.rows)
+
+    def lstm(self, which, feats, state, rows):
+        if state.rows != rows:
+            raise Unsupported("an LSTM state of another batch size than its tokens")
+        h, c = self.b.alloc(rows * self.S * 4), self.b.alloc(rows * self.S * 4)
+        self.b.emit(OP_LSTM_CELL, which, feats, state.h, state.c, rows, h, c)
+        return _AS(state.names, h, c, rows)
+
+    def modulations(self, fwd, bwd, rows):
+        if fwd.rows != rows or bwd.rows != rows:
+            raise Unsupported("modulations over differing batch sizes")
+        out = self.b.alloc(rows * 4 * 4)
+        self.b.emit(OP_ATT_MODULATIONS, fwd.h, bwd.h, rows, out)
+        return out
+
+    # -- FilterBatch / RelateBatch.transform_attention (logic_ops.py; batch_base_ops.py:407-467, 598-684) ----------------------------------------
+    def filter_ta(self, key, is_forward, state, tokens, op_name, pq=None):
+        from .host_util import is_valid_token
+        tokens = tokens if isinstance(tokens, (list, tuple)) else [tokens]
+        if not any(is_valid_token(v) for v in tokens):
+            return state
+        P = len(tokens)
+        if pq is None and P != self.b.Q:
+            raise Unsupported("batch size mismatch")
+        feats = self.features(tokens, op_name, 0.0)
+        if is_forward:
+            old = self.expand(state, pq) if pq is not None else state
+            new = self.lstm(0, feats, old, P)
+            self.fwd[key] = new
+            return _AS(state.names, new.h, new.c, P)
+        if key not in self.fwd:
+            raise Unsupported("a backward step without its forward state")
+        self.mods[key] = self.modulations(self.fwd.pop(key), state, P)
+        new = self.lstm(1, feats, state, P)
+        new = _AS(state.names, new.h, new.c, P)
+        return self.squeeze(new, pq) if pq is not None else new
+
+    def relate_ta(self, i, is_forward, s_state, o_state, tokens, op_name, pq=None):
+        from .host_util import is_valid_token
+        tokens = tokens if isinstance(tokens, (list, tuple)) else [tokens]
+        if not any(is_valid_token(v) for v in tokens):
+            return s_state, o_state
+        P = len(tokens)
+        if pq is None and P != self.b.Q:
+            raise Unsupported("batch size mismatch")
+        feats = self.features(tokens, op_name, 1.0)
+        if is_forward:
+            s_old = self.expand(s_state, pq) if pq is not None else s_state
+            o_old = self.expand(o_state, pq) if pq is not None else o_state
+            new = self.lstm(0, feats, self.add(s_old, o_old), P)
+            self.fwd[(i, "rel_s")] = self.fwd[(i, "rel_o")] = new
+            return _AS(s_state.names, new.h, new.c, P), _AS(o_state.names, new.h, new.c, P)
+        if (i, "rel_s") not in self.fwd:
+            raise Unsupported("a backward step without its forward state")
+        self.mods[(i, "rel_s")] = self.modulations(self.fwd.pop((i, "rel_s")), s_state, P)
+        self.mods[(i, "rel_o")] = self.modulations(self.fwd.pop((i, "rel_o")), o_state, P)
+        new = self.lstm(1, feats, self.add(s_state, o_state), P)
+        new_s, new_o = _AS(s_state.names, new.h, new.c, P), _AS(o_state.names, new.h, new.c, P)
+        if pq is not None:
+            sq = self.squeeze(new_s, pq)
+            new_s, new_o = sq, _AS(o_state.names, sq.h, sq.c, sq.rows)
+        return new_s, new_o
+
+    # -- the operators (gqa_ops.py `_*_ta`; batch_gqa_ops.py) ---------------------------------------------------------------------------------------
+    def select_ta(self, i, is_forward, state, tokens, op_name):
+        Q = self.b.Q
+        if tokens is None:
+            names, att = ["entity"] * Q, None
+        else:
+            names = ["entity" if a is None or a.lower() in ("_", "scene") else a for a in tokens][:Q]
+            att = [None if a is None or a.lower() in ("_", "scene") else a for a in tokens][:Q]
+        plain = att is None or all(a is None for a in att)
+        if is_forward:
+            x = self.zero_state(names, Q)
+            return x if plain else self.filter_ta((i, "sel"), True, x, att, op_name)
+        return state if plain else self.filter_ta((i, "sel"), False, state, att, op_name)
+
+    def gqa_relate_ta(self, i, is_forward, state, relation_list, is_subject, attribute_list, op_name):
+        if is_forward:
+            x = self.select_ta(i, True, None, attribute_list, op_name)
+            s, o = self.relate_ta(i, True, self.gate(x, state, is_subject), self.gate(state, x, is_subject), relation_list, op_name)
+            return self.gate(s, o, is_subject)
+        x = self.zero_state(state.names, state.rows)
+        o_set = self.gate(x, state, is_subject)
+        s_set = self.gate(state, x, is_subject)
+        s_set, o_set = self.relate_ta(i, False, s_set, o_set, relation_list, op_name)
+        self.select_ta(i, False, self.gate(s_set, o_set, is_subject), attribute_list, op_name)
+        return self.gate(o_set, s_set, is_subject)
+
+    def choose_rel_ta(self, i, is_forward, state, lists, is_subject, attribute_list, op_name):
+        flat, bi = flatten_list(lists)
+        host = [0.0 if f is None else float(f) for f in is_subject]
+        pred_flags = [host[q] for q in bi]
+        if is_forward:
+            x = self.select_ta(i, True, None, attribute_list, op_name)
+            s, o = self.relate_ta(i, True, self.gate(x, state, is_subject), self.gate(state, x, is_subject), flat, op_name, bi)
+            return self.gate(s, o, pred_flags)
+        x = self.zero_state(state.names, state.rows)
+        o_set = self.gate(x, state, pred_flags)
+        s_set = self.gate(state, x, pred_flags)
+        s_set, o_set = self.relate_ta(i, False, s_set, o_set, flat, op_name, bi)
+        self.select_ta(i, False, self.gate(s_set, o_set, is_subject), attribute_list, op_name)
+        return self.gate(o_set, s_set, is_subject)
+
+    def transform(self, i, ob, is_forward, ins):
+        """BatchGQAInterpreter._transform_attention (interpreter.py; batch_gqa_interpreter.py:80-86) for operator batch i."""
+        name, args = ob._op_name, ob._arguments
+        if name == "select":
+            return self.select_ta(i, is_forward, ins[0], args[0] if args else None, name)
+        if name == "filter":
+            return self.filter_ta((i, "flt"), is_forward, ins[0], args[0], name)
+        if name in ("relate", "verify_rel"):
+            return self.gqa_relate_ta(i, is_forward, ins[0], args[0], args[1], args[2] if len(args) > 2 else None, name)
+        if name in ("exist", "end"):
+            return ins[0]
+        if name in ("verify_attrs", "choose_attr"):
+            flat, bi = flatten_list(args[0])
+            return self.filter_ta((i, "flt"), is_forward, ins[0], flat, name, bi)
+        if name in ("query_attr", "all_same", "all_different"):
+            _, (flat, bi) = self.b.category_options(args[0], ins[0].names)
+            return self.filter_ta((i, "flt"), is_forward, ins[0], flat, name, bi)
+        if name == "choose_rel":
+            return self.choose_rel_ta(i, is_forward, ins[0], args[0], args[1], args[2] if len(args) > 2 else None, name)
+        if name in ("and", "or"):
+            return (ins[0], ins[1])
+        if name in ("two_same", "two_different"):
+            _, (flat, bi) = self.b.category_options(args[0], ins[0].names)
+            return (self.filter_ta((i, "flt:0"), is_forward, ins[0], flat, name, bi), self.filter_ta((i, "flt:1"), is_forward, ins[1], flat, name, bi))
+        if name == "compare":
+            return (self.filter_ta((i, "flt:0"), is_forward, ins[0], args[0], name), self.filter_ta((i, "flt:1"), is_forward, ins[1], args[0], name))
+        raise Unsupported("operator %r" % name)
+
+    def run(self, ops, deps_all):
+        """interpreter._calibration_passes (batch_base_interpreter.py:92-140)."""
+        from .host_util import reverse_dependencies
+        last = len(ops) - 1
+        trace = []
+        for i, ob in enumerate(ops):
+            deps = deps_all[i]
+            ins = tuple(trace[d] for d in deps) if deps else (None,)
+            if any(isinstance(v, tuple) for v in ins):
+                raise Unsupported("an operator that reads a terminal operator's states")
+            mask = None if ob._mask is None else ob._mask._host
+            x = self.transform(i, ob, True, ins)
+            if i < last and ins[0] is not None and mask is not None:
+                if isinstance(x, tuple):
+                    raise Unsupported("a masked two-branch operator")
+                x = self.gate(x, ins[0], mask)
+            trace.append(x)
+        rev = reverse_dependencies(deps_all)
+        final = trace[-1]
+        first = tuple(self.zero_state(a.names, a.rows) for a in final) if isinstance(final, tuple) else (self.zero_state(final.names, final.rows),)
+        trace = [None] * len(ops)
+        for i in reversed(range(len(ops))):
+            ob = ops[i]
+            if len(rev[i]) == 1:
+                temp = trace[rev[i][0]]
+                ins = ((temp[1],) if i == len(ops) - 2 else (temp[0],)) if isinstance(temp, tuple) else (temp,)
+            else:
+                ins = first
+            mask = None if ob._mask is None else ob._mask._host
+            if ins[0] is None:
+                raise Unsupported("a backward step without an incoming state")
+            x = self.transform(i, ob, False, ins)
+            if len(deps_all[i]) > 0 and mask is not None and isinstance(x, _AS) and i != last:
+                x = self.gate(x, ins[0], mask)
+            trace[i] = x
+        self.finish()
 
 
 def _attribute_requests(b, ops, deps):
@@ -491,6 +828,9 @@ def _lower(pb, ontology, spec):
     b.scene_stage()
     b.relation_stage(ops)
     b.attribute_stage(_attribute_requests(b, ops, deps))
+    if spec.calib is not None:
+        b.calibration = _Calibration(b, pb)
+        b.calibration.run(ops, deps)
     Q = b.Q
     trace, result = [], None
     last = len(ops) - 1
@@ -505,9 +845,9 @@ def _lower(pb, ontology, spec):
             raise Unsupported("an operator that reads a terminal operator's result")
         valid = None
         if name == "select":
-            x = b.select(args[0] if args else None, (i, 0))
+            x = b.select(args[0] if args else None, (i, 0), mkey=(i, "sel"))
         elif name == "filter":
-            x = b.filter(ins[0], args[0], (i, 0))
+            x = b.filter(ins[0], args[0], (i, 0), mkey=(i, "flt"))
             valid = get_lowered(args[0], ontology, TokenType.ATTRIBUTE).valid
         elif name == "relate":
             x, low = b.relate(i, ins[0], args[0], args[1], args[2] if len(args) > 2 else None, (i, 0))
@@ -524,7 +864,7 @@ def _lower(pb, ontology, spec):
             result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=x.prev_num + 1)
         elif name == "verify_attrs":
             flat, bi = flatten_list(args[0])
-            x = b.filter(ins[0], flat, (i, 0), bi, normalized=False)
+            x = b.filter(ins[0], flat, (i, 0), bi, normalized=False, mkey=(i, "flt"))
             if x is ins[0]:
                 raise Unsupported("verify_attrs without attributes")
             summed = b.block(Q)
@@ -537,7 +877,7 @@ def _lower(pb, ontology, spec):
                 lists, (flat, bi) = b.category_options(args[0], ins[0].names)
             else:
                 lists, (flat, bi) = args[0], flatten_list(args[0])
-            x = b.filter(ins[0], flat, (i, 0), bi)
+            x = b.filter(ins[0], flat, (i, 0), bi, mkey=(i, "flt"))
             if x is ins[0]:
                 raise Unsupported("an option list without options")
             lp = b.quantify(x, region="o")
@@ -552,7 +892,7 @@ def _lower(pb, ontology, spec):
             result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=ins[0].prev_num + ins[1].prev_num + 2)
         elif name in ("all_same", "all_different"):
             _, (flat, bi) = b.category_options(args[0], ins[0].names)
-            x = b.filter(ins[0], flat, (i, 0), bi)
+            x = b.filter(ins[0], flat, (i, 0), bi, mkey=(i, "flt"))
             if x is ins[0]:
                 raise Unsupported("a category without options")
             post = b.block(x.rows)
@@ -570,12 +910,12 @@ def _lower(pb, ontology, spec):
         elif name in ("two_same", "two_different"):
             _, (flat, bi) = b.category_options(args[0], ins[0].names)
             # (the Python operators evaluate and normalise the same blocks twice; once is the same values)
-            x1 = b.filter(ins[0], flat, (i, 0), bi)
+            x1 = b.filter(ins[0], flat, (i, 0), bi, mkey=(i, "flt:0"))
             if x1 is ins[0]:
                 raise Unsupported("a category without options")
             spec_norm, b.spec.normalize = b.spec.normalize, False          # already normalised in place by the first filter
             try:
-                x2 = b.filter(ins[1], flat, (i, 0), bi)
+                x2 = b.filter(ins[1], flat, (i, 0), bi, mkey=(i, "flt:1"))
             finally:
                 b.spec.normalize = spec_norm
             lp1, lp2 = b.quantify(x1), b.quantify(x2)
@@ -590,8 +930,8 @@ def _lower(pb, ontology, spec):
                 lp = lp2_
             result = dict(kind="binary", type=QuestionType.BINARY, lp=lp, count=Q, options=["no", "yes"], num=x1.prev_num + x2.prev_num + 2)
         elif name == "compare":
-            x1 = b.filter(ins[0], args[0], (i, 0))
-            x2 = b.filter(ins[1], args[0], (i, 0))
+            x1 = b.filter(ins[0], args[0], (i, 0), mkey=(i, "flt:0"))
+            x2 = b.filter(ins[1], args[0], (i, 0), mkey=(i, "flt:1"))
             lp1, lp2 = b.quantify(x1), b.quantify(x2)
             lp = b.alloc(Q * 2 * 4, "o")
             b.emit(OP_COMPARE, lp1, lp2, b.arr(np.asarray([float(bool(v)) for v in args[1]], np.float32)), Q, lp)
@@ -618,7 +958,7 @@ def _choose_rel(b, i, prev, args):
     Q = b.Q
     lists = args[0]
     flat, bi = flatten_list(lists)
-    x = b.select(args[2] if len(args) > 2 else None, (i, 0))
+    x = b.select(args[2] if len(args) > 2 else None, (i, 0), mkey=(i, "sel"))
     host = [0.0 if f is None else float(f) for f in args[1]]
     subject_set = b.gate(x, prev, host)
     object_set = b.gate(prev, x, host)
@@ -637,6 +977,8 @@ def _choose_rel(b, i, prev, args):
     b.emit(OP_RELATE, subject_set.att, object_set.att, tiles, b.arr(pq), b.arr(q_s), b.arr(q_o), b.arr(low.neg) if low.any_neg else -1,
            -1 if low.all_valid else b.arr(low.valid), b.arr(want), P,
            TILE_SUBJECT_ROWS, flags, ps, po)
+    ps = b.modulate(ps, (i, "rel_s"), pq, P)                      # RelateBatch.forward :588-594
+    po = b.modulate(po, (i, "rel_o"), pq, P)
     n_prev = subject_set.prev_num + object_set.prev_num + 1
     s_set = _VS(subject_set.names, ps, P, q_s, pq, n_prev)
     o_set = _VS(object_set.names, po, P, q_s, pq, n_prev)

@@ -320,6 +320,18 @@ int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, const float* h,
                        int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
                        float* h_out, float* c_out, void* stream);
 
+/* Small pieces of the calibration passes, shared by the Python operators and the native executor (round 6):
+ * select_rows: out[p] = flags[p] ? x[p] : y[p] over rows of `width` floats - BatchAttentionState.gate with 0 / 1 flags (batch_base_types.py:279-298).
+ * calib_features: the LSTM input rows of an operator's tokens (batch_base_ops.py:265-273, 437-446, 628-637): out[p] = [head (n_head floats: operator
+ *   one-hot, token-type flag) | table[idx[p]] (E floats: token embedding)], all zeros where idx[p] < 0 (no-op token); out [P, n_head + E].
+ * attention_modulations: BatchOperatorBase._compute_attention_modulations (batch_base_ops.py:275-286) with the Linear(2 S -> N) + Sigmoid output
+ *   network (gqa_interpreter_experiments.py:119-132): out[p][j] = Sigmoid(b[j] + W[j][:S] . fs[p] + W[j][S:] . bs[p]); fs / bs [P, S] or NULL (= zeros).
+ */
+int dfol_select_rows_f32(const float* x, const float* y, const uint8_t* flags, int32_t P, int32_t width, float* out, void* stream);
+int dfol_calib_features_f32(const float* head, int32_t n_head, const float* table, int32_t E, const int32_t* idx, int32_t P, float* out, void* stream);
+int dfol_attention_modulations_f32(const float* fs, const float* bs, const float* W, int64_t ld_w, const float* b, int32_t P, int32_t S, int32_t N,
+                                   float* out, void* stream);
+
 /* Training of the attention calibrator (the curriculum's cur6-7 phases: oracle frozen, the two LSTM cells and the attention output
  * layer train; trainer.py:429-442 over batch_base_interpreter.py:87-140).  dfol_lstm_cell_train_f32 is dfol_lstm_cell_f32 that also
  * stores the ACTIVATED gates [rows, 4H] (sigmoid(i), sigmoid(f), tanh(g), sigmoid(o)); dfol_lstm_cell_bwd_f32 is the backward of the
@@ -700,6 +712,18 @@ typedef struct {            /* the neural modules of build_neural_modules, gqa_i
     const float* emb_b;
     int32_t emb_in;         /* its input width (= hid2 = the attribute network's output width) */
     int32_t D;              /* object matrix width = featurizer output + 4 box positions */
+    /* attention calibration (round 6; all NULL / 0 when the interpreter has no calibrator): the forward [0] and backward [1] nn.LSTMCell of
+     * gqa_interpreter_experiments.py:115-138 as dfol_lstm_cell_f32 takes them (TRANSPOSED weights) and the attention-output Linear + Sigmoid */
+    const float* lstm_wih_t[2]; /* W_ih^T [lstm_kx, ld >= 4 lstm_h] */
+    const float* lstm_whh_t[2]; /* W_hh^T [lstm_h, ld >= 4 lstm_h] */
+    int64_t lstm_ld_wih[2], lstm_ld_whh[2];
+    const float* lstm_bih[2];   /* [4 lstm_h] or NULL */
+    const float* lstm_bhh[2];
+    int32_t lstm_kx, lstm_h;    /* input width (17 operator one-hot + 1 type flag + token embedding) and state width */
+    const float* att_out_w;     /* [att_out_n, ld_att_out >= 2 lstm_h] */
+    int64_t ld_att_out;
+    const float* att_out_b;     /* [att_out_n] or NULL */
+    int32_t att_out_n;          /* 4 (dfol_modulate_f32's modulations) */
 } DfolProgramModel;
 
 typedef struct {            /* the scenes of one ProgramBatch (data_pipeline.py:149) */
@@ -731,6 +755,11 @@ typedef struct {            /* the scenes of one ProgramBatch (data_pipeline.py:
 #define DFOL_OP_COMPARE 15
 #define DFOL_OP_FIND_MAX_IND 16
 #define DFOL_OP_GATHER_TILES 17
+#define DFOL_OP_CALIB_FEATURES 18   /* head (blob), n_head, table (blob), E, idx (blob), P, out */
+#define DFOL_OP_LSTM_CELL 19        /* which (0 forward, 1 backward network), x, h, c, rows, h_out, c_out */
+#define DFOL_OP_SELECT_ROWS 20      /* x, y, flags (blob, uint8), P, width, out */
+#define DFOL_OP_ATT_MODULATIONS 21  /* forward state h (or -1), backward state h (or -1), P, out [P, att_out_n] */
+#define DFOL_OP_MODULATE 22         /* att, mods, pred_q (blob), P, out */
 
 int dfol_run_program(const DfolProgramModel* model, const DfolProgramScene* scene, const int64_t* instr_host, int32_t n_instr,
                      const void* blob, void* workspace, void* stream);

@@ -355,3 +355,147 @@ def test_native_bf16_relation_tiles(full, shared, monkeypatch):
             assert (f32["log_probability"] - nat["log_probability"]).abs().max().item() <= 5e-2
     finally:
         model._oracle._tile_dtype = saved
+
+
+# ---- the calibrated forward (activate_attention_transfer: the reference's default, sample_config.yaml) on the executor ---------------------------
+from test_interpreter_gpu import CalibrationCollater  # noqa: E402
+
+
+def _no_state_left(model):
+    for mod in model.modules():
+        for attr in ("_modulations", "_subject_modulations", "_object_modulations", "_forward_state", "_forward_subject_state", "_forward_object_state"):
+            assert not getattr(mod, attr, None), (type(mod).__name__, attr)
+
+
+@pytest.mark.parametrize("name", ["exist", "verify_attrs", "choose_attr", "query_attr", "verify_rel", "choose_rel", "and", "two_same", "all_same", "compare"])
+def test_native_calibrated_forward_g10(mini_ontology_paths, name, monkeypatch):
+    """The attention-calibration passes (forward / backward LSTM walks over the aligned program + apply_modulations around every operator:
+    batch_base_interpreter.py:87-140, batch_base_types.py:170-187) lowered into the executor's plan: golden g10's questions (the reference's
+    own calibrated runs) through dfol_run_program == the Python operator loop BIT FOR BIT, == the reference (golden), also on shared scenes."""
+    p = mini_ontology_paths
+    ont = D.GQAOntology(p["attribute_file"], p["class_file"], p["vocabulary_file"], p["word_embedding_file"], relation_json_path=p["relation_file"])
+    a, meta = gu.load("g10_calibration")
+    weights = {k[2:]: a[k] for k in a.files if k.startswith("w:")}
+    model = neural_model(ont, meta["config"], weights)
+    assert model._has_modulator and native_exec.calibrator(model) is not None
+    run_meta = meta["runs"][name]
+    qs = [{"program": q["program"], "answer": q["answer"], "question_id": q["question_id"], "image_id": "img000", "tokens": [], "original_dict": None,
+           "question": None, "scene": {"n": q["n"], "X": a["%s:X_%d" % (name, i)]}} for i, q in enumerate(run_meta["questions"])]
+    nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch, collater=CalibrationCollater(ont))
+    same_results(nat, py, "calibrated " + name)
+    gu.check_logprob(nat["log_probability"].cpu().numpy(), a[name + ":lp_f32"], a[name + ":lp_f64"], name + " (calibrated, executor)")
+    assert nat["answer"] == run_meta["answer"]
+    _no_state_left(model)
+    # shared scenes: every question three times on two or three images
+    scenes = [q["scene"] for q in qs]
+    rep = []
+    for r in range(3):
+        for i, q in enumerate(qs):
+            img = (i + r) % min(3, len(scenes))
+            rep.append(dict(q, image_id="img%d" % img, scene=scenes[img]))
+    coll = CalibrationCollater(ont)
+    coll._share_scenes = True
+    nat2, py2 = both_routes(model, ont, rep, monkeypatch=monkeypatch, collater=coll)
+    same_results(nat2, py2, "calibrated shared " + name)
+    # tokens missing from the batch's embedding index: both routes fall back to the ontology's word embeddings (base_oracle.py:45-55)
+    nat3, py3 = both_routes(model, ont, qs, monkeypatch=monkeypatch, collater=TableCollater(1, ont, "X"))
+    same_results(nat3, py3, "calibrated, ontology embeddings " + name)
+    # the switch off (the reference's test loop switches it off for QUERY batches, trainer.py:97): another plan, the uncalibrated numbers
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ont).collate([dict(q) for q in qs])]
+    _lib.PATH_COUNTS.clear()
+    with torch.no_grad():
+        off = model(pbs, False, modulator_switch=False)
+        on = model(pbs, False, modulator_switch=True)
+    assert _lib.PATH_COUNTS.get("native_program", 0) == 2 * len(pbs)
+    gu.check_logprob(off["log_probability"].cpu().numpy(), a[name + ":lp_off_f32"], a[name + ":lp_off_f64"], name + " (switch off, executor)")
+    assert torch.equal(on["log_probability"], nat["log_probability"])
+
+
+@pytest.fixture(scope="module")
+def calibrated_full(tmp_path_factory):
+    from dfol_vqa_amd import experiment
+    d = str(tmp_path_factory.mktemp("native_calib"))
+    paths, names = syn.write_synthetic_ontology(d)
+    cfg = syn.reference_config(paths, activate_attention_transfer=True)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(5)
+    model = experiment.build_model(cfg, ont)
+    syn.load_seeded_weights(model, 23)
+    with torch.no_grad():                                        # (the reference initialises the output layer's weight to zero: every modulation would be Sigmoid(bias))
+        out = model._ops['filter']._filter._attention_output_network[0]
+        out.weight.normal_(0.0, 0.5)
+        out.bias.normal_(0.0, 0.5)
+    with open(paths["attribute_file"]) as f:
+        categories = json.load(f)
+    return model.to(DEV).eval(), ont, names, categories
+
+
+class _FullCalibrationCollater(TableCollater):
+    """The GQA collator's meta data (batch_gqa_boxfeatures_pipeline.py:88-92): token -> row of an embedding table of the batch's tokens."""
+
+    def __init__(self, split, ont, share=False, spec=None):
+        super(_FullCalibrationCollater, self).__init__(split, ont, "X", share_scenes=share)
+        self._ont = ont
+        self._native_spec = spec
+
+    def collate_meta_data(self, questions):
+        toks = set()
+        for q in questions:
+            for o in [o for br in q["program"]["branches"] for o in br] + [q["program"]["last_op"]]:
+                for arg in o["arguments"]:
+                    for t in (arg if isinstance(arg, list) else [arg]):
+                        if isinstance(t, str):
+                            toks.add(t[4:-1] if t.startswith("not(") else t)
+                            toks.update(self._ont.query(t) if t in getattr(self._ont, "_attribute_dict", {}) else [])
+        names = sorted(t for t in toks if t not in ("_", ""))
+        rng = np.random.RandomState(len(names))
+        return {"index": {t: i for i, t in enumerate(names)}, "embedding": torch.from_numpy(rng.normal(0, 0.3, (len(names), 300)).astype(np.float32))}
+
+
+@pytest.mark.parametrize("kind", ALL_KINDS)
+def test_native_calibrated_full_size_ragged_1_to_100(calibrated_full, kind, monkeypatch):
+    """VERDICT r5 #2's bar: a ragged 1..100-object stream with activate_attention_transfer: True at FULL model size (LSTMCell(318 -> 50) x 2,
+    Linear(100 -> 4)) - every ProgramBatch on the executor (`native_program` == the batch count), bit for bit the Python loop, per question and
+    with shared scenes, for every terminal operator."""
+    model, ont, names, categories = calibrated_full
+    qs = syn.full_size_questions(kind, 12, 1, 100, names, categories, 900 + ALL_KINDS.index(kind))
+    qs[0]["scene"] = syn.feature_scene(qs[0]["question_id"], 1, 2048)            # one image of ONE object for sure
+    qs[1]["scene"] = syn.feature_scene(qs[1]["question_id"], 100, 2048)
+    nat, py = both_routes(model, ont, qs, split=2, monkeypatch=monkeypatch, collater=_FullCalibrationCollater(2, ont))
+    same_results(nat, py, "calibrated full-size " + kind)
+    _no_state_left(model)
+    for i, q in enumerate(qs):
+        q["image_id"], q["scene"] = "img%d" % (i % 4), qs[i % 4]["scene"]
+    nat, py = both_routes(model, ont, qs, split=1, monkeypatch=monkeypatch, collater=_FullCalibrationCollater(1, ont, share=True))
+    same_results(nat, py, "calibrated full-size shared " + kind)
+    # the modulations do something (the calibrator is not the identity)
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    pbs = [pb.to_cuda(DEV) for pb in _FullCalibrationCollater(1, ont, share=True).collate([dict(q) for q in qs])]
+    with torch.no_grad():
+        off = model(pbs, False, modulator_switch=False)
+    assert not torch.equal(off["log_probability"], nat["log_probability"])
+
+
+def test_native_calibrated_plan_from_the_collate_worker(calibrated_full, monkeypatch):
+    """The calibrated plan is built where the reference builds its ProgramBatches (the collate worker: CPU meta data), travels through pickle
+    and runs as it is."""
+    import pickle
+    model, ont, names, categories = calibrated_full
+    spec = native_exec.model_spec(model, calibrate=True)
+    assert spec is not None and spec.calib["state_dim"] == 50 and spec.calib["lstm_in"] == 318
+    qs = syn.full_size_questions("query_attr", 8, 10, 30, names, categories, 77)
+    pbs = pickle.loads(pickle.dumps(_FullCalibrationCollater(2, ont, spec=spec).collate([dict(q) for q in qs])))
+    assert all(isinstance(pb._native_plan, native_plan.NativePlan) for pb in pbs)
+    ops = [int(x) for x in pbs[0]._native_plan.instrs[:, 0]]
+    assert ops.count(native_plan.OP_LSTM_CELL) >= 4 and native_plan.OP_MODULATE in ops and native_plan.OP_ATT_MODULATIONS in ops
+    pbs = [pb.to_cuda(DEV) for pb in pbs]
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    _lib.PATH_COUNTS.clear()
+    with torch.no_grad():
+        res = model(pbs, False)
+    assert _lib.PATH_COUNTS.get("native_program", 0) == 2
+    monkeypatch.setenv("DFOL_NATIVE", "0")
+    with torch.no_grad():
+        ref = model(pbs, False)
+    same_results(res, ref, "collate-time calibrated plan")

@@ -54,3 +54,42 @@ for calib in (False, True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print("calibration", calib, "graph replay ms/step %.3f" % (dt * 1e3), "q/s %.0f" % (args.batch / dt))
+    replay_ms = dt * 1e3
+    # fresh programs: every step ANOTHER ProgramBatch (plans lowered at collate time, as a DataLoader worker would; features device-resident),
+    # two batches in flight (forward_async) - the native executor against the Python operator loop
+    from dfol_vqa_amd import native_exec, _lib
+    spec = native_exec.model_spec(model, calibrate=calib)
+    class FreshCollater(Collater):
+        def __init__(self, spec_):
+            super(FreshCollater, self).__init__()
+            self._native_spec = spec_
+    for route in ("1", "0"):
+        os.environ["DFOL_NATIVE"] = route
+        fresh = []
+        for k in range(24):
+            qk = []
+            for i in range(args.batch):
+                br, last = syn.three_hop_program(100000 * (k + 1) + i, nouns, attrs, rels)
+                qk.append(syn.question(100000 * (k + 1) + i, br, last, "yes", qs[i]["scene"]))
+            pb = FreshCollater(spec if route == "1" else None).collate(qk)[0]
+            pb.create_sparse_tensors()
+            pb = pb.to_cuda(device)
+            pb._object_features = pbs[0]._object_features          # (the same resident features: the leg times programs, not uploads)
+            fresh.append([pb])
+        _lib.PATH_COUNTS.clear()
+        with torch.no_grad():
+            for pbk in fresh[:4]:
+                model(pbk, False)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            pend = []
+            for pbk in fresh[4:]:
+                pend.append(model.forward_async(pbk, False))
+                if len(pend) > 2:
+                    pend.pop(0).result()
+            for x in pend:
+                x.result()
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (len(fresh) - 4)
+        print("calibration", calib, "fresh programs, %s: ms/batch %.3f" % ("native executor" if route == "1" else "Python loop", dt * 1e3), "q/s %.0f" % (args.batch / dt),
+              "= %.2f x the graph-replay rate" % (replay_ms / (dt * 1e3)), dict(_lib.PATH_COUNTS))
+    os.environ["DFOL_NATIVE"] = "1"

@@ -571,13 +571,16 @@ def data_main(args, rank, world, device, td, share):
     if td is not None:
         from dfol_vqa_amd import parallel
         parallel.broadcast_parameters(model, 0)
-    batches, per_file = [], {}
-    for path in progs:
-        ds = data.ProgramDataset(path, ontology, in_memory=True, shuffle_options=False)
-        items = [ds[i] for i in range(len(ds))]
-        per_file[os.path.basename(path)] = len(items)
-        for a in range(0, len(items), args.batch):
-            batches.append((os.path.basename(path), items[a:a + args.batch]))
+    # the reference's epoch driver (data_pipeline.py:787-900): one ProgramDataset per program file, batches that never mix files, here in the
+    # sequential order its test() loop uses (MultiSetSequencialSampler)
+    datasets = [data.ProgramDataset(path, ontology, in_memory=True, shuffle_options=False) for path in progs]
+    concat = torch.utils.data.ConcatDataset(datasets)
+    bounds = np.cumsum([len(ds) for ds in datasets])
+    per_file = {os.path.basename(path): len(ds) for path, ds in zip(progs, datasets)}
+    batches = []
+    for idx in data.MultiSetSequencialSampler(datasets, args.batch, drop_last=False):
+        k = int(np.searchsorted(bounds, idx[0], side="right"))
+        batches.append((os.path.basename(progs[k]), [concat[i] for i in idx]))
     if len(batches) < world:
         sys.exit("bench.py --data: %d batches for %d ranks" % (len(batches), world))
     mine = batches[rank * len(batches) // world:(rank + 1) * len(batches) // world]

@@ -13,5 +13,6 @@ from .gqa_ops import GQAOntology  # noqa: F401
 from .visual_oracle import ClassifierOracle, EmbeddingLayer, OracleBase, RegularMLP  # noqa: F401
 from .interpreter import BatchGQABoxFeaturizer, BatchGQAInterpreter, BatchInterpreterBase, gather_results  # noqa: F401
 from .program import OperatorBatch, ProgramBatch, ProgramCollaterBase  # noqa: F401
-from .data import BatchGQABoxFeaturesCollator, GQAProgramVerifier, ParserError, ProgramCodec, ProgramDataset  # noqa: F401
+from .data import (BatchGQABoxFeaturesCollator, GQADataManager, GQAProgramVerifier, MultiSetSampler, MultiSetSequencialSampler,  # noqa: F401
+                   ParserError, ProgramCodec, ProgramDataset)
 from .preprocess import GQAPreprocessor, normalize  # noqa: F401

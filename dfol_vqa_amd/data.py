@@ -331,6 +331,125 @@ class BatchGQABoxFeaturesCollator(ProgramCollaterBase):
 # ---------------------------------------------------------------------------------------------------------------------
 # Program verifier (the part that guards the interpreter's input): nn/parser/parse_utils.py:24-240
 # ---------------------------------------------------------------------------------------------------------------------
+# ---- the epoch driver's batching: one batch = questions of ONE file = one terminal operator (data_pipeline.py:787-900) ---------------------------
+class _FileBatches(object):
+    """Batches of one dataset's indices: its own order or a random permutation (torch's BatchSampler over a Sequential / RandomSampler), or,
+    distributed, this rank's strided share of them (DistributedSampler: padded by wrapping around to a multiple of the world size)."""
+
+    def __init__(self, length, batch_size, drop_last, shuffle, replacement, distributed, rank, world, seed):
+        self.length, self.batch_size, self.drop_last = int(length), int(batch_size), bool(drop_last)
+        self.shuffle, self.replacement, self.distributed = bool(shuffle), bool(replacement), bool(distributed)
+        self.rank, self.world, self.seed, self.epoch = int(rank), int(world), int(seed), 0
+        self.samples = -(-self.length // self.world) if self.distributed else self.length
+
+    def indices(self):
+        g = torch.Generator()
+        if self.distributed:
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.length, generator=g).tolist() if self.shuffle else list(range(self.length))
+            total = self.samples * self.world
+            while len(order) < total:                          # (pad by wrapping around, as DistributedSampler does)
+                order += order[:total - len(order)]
+            return order[self.rank:total:self.world]
+        if not self.shuffle:
+            return list(range(self.length))
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        if self.replacement:                                   # (torch's RandomSampler draws in chunks of 32, then the remainder)
+            out = []
+            for _ in range(self.length // 32):
+                out += torch.randint(high=self.length, size=(32,), dtype=torch.int64, generator=g).tolist()
+            return out + torch.randint(high=self.length, size=(self.length % 32,), dtype=torch.int64, generator=g).tolist()
+        return torch.randperm(self.length, generator=g).tolist()
+
+    def __iter__(self):
+        idx = self.indices()
+        for a in range(0, len(idx), self.batch_size):
+            b = idx[a:a + self.batch_size]
+            if len(b) == self.batch_size or not self.drop_last:
+                yield b
+
+
+class MultiSetSampler(torch.utils.data.Sampler):
+    """data_pipeline.py:787-826: a batch sampler over SEVERAL datasets (one per program file, i.e. per terminal operator) that never mixes
+    files inside a batch.  Every step draws the file with probability proportional to the questions it has left, takes that file's next
+    batch of a random permutation and hands out indices into the concatenation of the datasets."""
+
+    sequential = False
+
+    def __init__(self, dataset_list, batch_size, drop_last, replacement=False, distributed=False, rank=None, world_size=None, seed=0):
+        self._datasets = list(dataset_list)
+        self._distributed = distributed
+        if distributed and (rank is None or world_size is None):
+            import torch.distributed as td
+            rank, world_size = td.get_rank(), td.get_world_size()
+        self._files = [_FileBatches(len(ds), batch_size, drop_last, not self.sequential, replacement, distributed, rank or 0, world_size or 1, seed)
+                       for ds in self._datasets]
+        self._lengths = [f.samples for f in self._files]
+        self._cumulative_lengths = np.cumsum([len(ds) for ds in self._datasets]).tolist()
+        self._num_samples = sum(self._lengths)
+
+    def __len__(self):                                          # (the reference's length is in questions, not batches: :806-807)
+        return self._num_samples
+
+    def _offset(self, dataset_index, batch):
+        return batch if dataset_index == 0 else [self._cumulative_lengths[dataset_index - 1] + i for i in batch]
+
+    def __iter__(self):
+        left = torch.tensor(self._lengths, dtype=torch.float32)
+        iterators = [iter(f) for f in self._files]
+        while float(left.sum()) > 0:
+            k = int(torch.multinomial(left, 1)[0])
+            try:
+                batch = next(iterators[k])
+            except StopIteration:                               # (drop_last: a file's remainder is never handed out)
+                left[k] = 0
+                continue
+            left[k] = max(float(left[k]) - len(batch), 0.0)
+            yield self._offset(k, batch)
+
+    def set_epoch(self, epoch):
+        if self._distributed:
+            for f in self._files:
+                f.epoch = int(epoch)
+
+
+class MultiSetSequencialSampler(MultiSetSampler):
+    """data_pipeline.py:830-871 (the reference's spelling): the files one after the other, each in its own order (test / predict)."""
+
+    sequential = True
+
+    def __init__(self, dataset_list, batch_size, drop_last, distributed=False, rank=None, world_size=None):
+        super(MultiSetSequencialSampler, self).__init__(dataset_list, batch_size, drop_last, False, distributed, rank, world_size)
+
+    def __iter__(self):
+        for k, f in enumerate(self._files):
+            for batch in f:
+                yield self._offset(k, batch)
+
+
+class GQADataManager(object):
+    """data_pipeline.py:875-900: one ProgramDataset per question file of a directory (or one over a list of questions), and the DataLoader whose
+    batches are single-file ProgramBatches collated in worker processes."""
+
+    def __init__(self, data_path, ontology, in_memory, max_cache_size=100000, keep_original_dict=False):
+        if isinstance(data_path, (list, tuple)):
+            datasets = [ProgramDataset(data_path, ontology, in_memory, max_cache_size, keep_original_dict)]
+        else:
+            names = sorted(f for f in os.listdir(data_path) if os.path.isfile(os.path.join(data_path, f)) and f.endswith((".json", ".h5", ".npz")))
+            datasets = [ProgramDataset(os.path.join(data_path, f), ontology, in_memory, max_cache_size, keep_original_dict) for f in names]
+        self._dataset = torch.utils.data.ConcatDataset(datasets)
+
+    def get_sampler(self, batch_size, drop_last=False, replacement=False, is_random=True, distributed=False, rank=None, world_size=None):
+        if is_random:
+            return MultiSetSampler(self._dataset.datasets, batch_size, drop_last, replacement, distributed=distributed, rank=rank, world_size=world_size)
+        return MultiSetSequencialSampler(self._dataset.datasets, batch_size, drop_last, distributed=distributed, rank=rank, world_size=world_size)
+
+    def get_loader(self, batch_size, collater, num_workers, use_cuda, drop_last=False, replacement=False, is_random=True, distributed=False):
+        sampler = self.get_sampler(batch_size, drop_last, replacement, is_random, distributed)
+        return torch.utils.data.DataLoader(dataset=self._dataset, batch_sampler=sampler, num_workers=num_workers, collate_fn=collater.collate,
+                                           pin_memory=use_cuda)
+
+
 class ParserError(Exception):
     pass
 

@@ -352,3 +352,48 @@ def test_g18_files_to_answers_oracle(ontology, golden_dir, mini_ontology_paths):
             assert r64["options"] == fm["options"], name
         seen += 1
     assert seen == 8
+
+
+def test_g21_batch_samplers_match_the_reference():
+    """data.MultiSetSequencialSampler / MultiSetSampler against the reference's own samplers (golden g21, data_pipeline.py:787-871): the same
+    batches - single-file, offsets into the concatenation, drop_last - and, under the same torch seed, the same random epoch (file draws by
+    torch.multinomial over what is left, one random permutation per file)."""
+    import json
+    import torch
+    from dfol_vqa_amd import data
+    with open(os.path.join(gu.GOLDEN, "g21_samplers.json")) as f:
+        meta = json.load(f)
+    for case in meta["cases"]:
+        dss = [list(range(n)) for n in case["lengths"]]
+        seq = [list(b) for b in data.MultiSetSequencialSampler(dss, case["batch_size"], case["drop_last"])]
+        if case["sequential"] is None:          # drop_last with a remainder: the reference's generator runs off the file's end (RuntimeError);
+            assert all(len(b) == case["batch_size"] for b in seq)      # here the remainders are dropped, as torch's BatchSampler means it
+        else:
+            assert seq == case["sequential"], case["lengths"]
+        bounds = np.cumsum(case["lengths"])
+        for r in case["random"]:
+            torch.manual_seed(r["seed"])
+            smp = data.MultiSetSampler(dss, case["batch_size"], case["drop_last"], replacement=r["replacement"])
+            got = [list(b) for b in smp]
+            assert len(smp) == r["len"]
+            if r["batches"] is not None:
+                assert got == r["batches"], (case["lengths"], r["seed"])
+            for b in got:                                      # never two files in one batch
+                assert len({int(np.searchsorted(bounds, i, side="right")) for i in b}) == 1
+            if not r["replacement"] and not case["drop_last"]:
+                assert sorted(i for b in got for i in b) == list(range(int(bounds[-1])))
+
+
+def test_distributed_sampler_shards_cover_every_question():
+    """The distributed form (DistributedSampler semantics per file: a seeded permutation, padded by wrapping to a multiple of the world size,
+    rank r takes every world-th index): the ranks' shards are disjoint up to the padding and together cover every question of every file."""
+    from dfol_vqa_amd import data
+    dss = [list(range(n)) for n in (10, 3, 7)]
+    seen = []
+    for rank in range(4):
+        smp = data.MultiSetSampler(dss, 2, False, distributed=True, rank=rank, world_size=4, seed=3)
+        smp.set_epoch(1)
+        got = [i for b in smp for i in b]
+        assert len(got) == sum(-(-n // 4) for n in (10, 3, 7)) == len(smp)
+        seen += got
+    assert set(seen) == set(range(20))

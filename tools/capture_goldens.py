@@ -1120,6 +1120,33 @@ def g17():
 
 
 
+# ---------------------------------------------------------------------------------------- g21
+def g21():
+    """The reference's batch samplers (data_pipeline.py:787-871): batches never mix files; MultiSetSequencialSampler walks the files in order,
+    MultiSetSampler draws the next file with probability proportional to what it has left (torch.multinomial) and a random permutation per
+    file - reproducible under torch.manual_seed (CPU generator).  Stored: file lengths, batch size, drop_last, replacement, seed and the
+    batches (indices into the concatenation) the reference hands out."""
+    dp = ref.data_pipeline
+    cases = []
+    for lengths, bs, drop in (([5, 3, 7], 3, False), ([5, 3, 7], 3, True), ([1, 40, 2, 9], 4, False), ([64], 10, False)):
+        dss = [list(range(n)) for n in lengths]
+        def run(make):                # (with drop_last and a remainder the reference's generators run off their file's end: RuntimeError)
+            try:
+                return [list(map(int, b)) for b in make()]
+            except RuntimeError:
+                return None
+        seq = run(lambda: dp.MultiSetSequencialSampler(dss, bs, drop))
+        case = {"lengths": lengths, "batch_size": bs, "drop_last": drop, "sequential": seq, "random": []}
+        for seed, repl in ((0, False), (7, False), (11, True)):
+            torch.manual_seed(seed)
+            smp = dp.MultiSetSampler(dss, bs, drop, replacement=repl)
+            case["random"].append({"seed": seed, "replacement": repl, "batches": run(lambda: smp), "len": len(smp)})
+        cases.append(case)
+    with open(os.path.join(OUT, "g21_samplers.json"), "w") as f:
+        json.dump({"source": "data_pipeline.py:787-871", "torch": torch.__version__, "cases": cases}, f, indent=1, sort_keys=True)
+    print("wrote g21_samplers", sum(len(c["sequential"] or []) for c in cases), "sequential batches")
+
+
 # ---------------------------------------------------------------------------------------- g20
 G20_QUESTIONS = 3
 

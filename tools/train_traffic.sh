@@ -11,7 +11,7 @@ for m in fp32 bf16; do
   bash tools/pmc_run.sh ${TAG}_train_fetch_$m "FETCH_SIZE" bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 --cpu-sample 0 --mlp-math $m > $O/pmc_train_fetch_$m.txt 2>&1
   bash tools/pmc_run.sh ${TAG}_train_write_$m "WRITE_SIZE" bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 --cpu-sample 0 --mlp-math $m > $O/pmc_train_write_$m.txt 2>&1
 done
-python3 - $O <<'PY' > $O/train_traffic.md
+python3 - $O $TAG <<'PY' > $O/train_traffic.md
 import re, sys, os
 O = sys.argv[1]
 def parse(path):
@@ -36,7 +36,7 @@ def algorithmic(name, mode):
     if "pair_logit_bwd" in name: return pairs * (2 * b * H2 + 4)
     if "tall_h2_kernel" in name or "pair_wgrad_fused_kernel" in name: return pairs * (H1 + H2) * b
     return None
-print("# HBM traffic of the train step's kernels, round 4 (N = 100, 256 questions; rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of")
+print("# HBM traffic of the train step's kernels, measurement pass " + sys.argv[2] + " (N = 100, 256 questions; rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of")
 print("# `bench.py --mode train --objects 100 --steps 3 --warmup 1 --graph 0 [--mlp-math bf16]`; FETCH_SIZE in KiB x 2 as MI355X_MICROARCH.md prescribes")
 print("# for gfx950, WRITE_SIZE in KiB; per launch).  The two tall products and the pair layer's weight gradient: algorithmic = operands read once + result written.")
 for mode in ("fp32", "bf16"):

@@ -816,6 +816,11 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
         # thread waits for it with the device idle.  --fresh-workers N > 0 moves collate and lowering into N spawned worker processes)
         host_s = [0.0]
         workers = max(0, int(getattr(args, "fresh_workers", 0)))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if workers and world > 1:
+            # N ranks share the host: every rank takes its share of the cores (one stays with the launching thread), so 8 ranks x 6 workers do not
+            # become 48 collate processes on a 32-core host
+            workers = max(1, min(workers, (os.cpu_count() or 8) // world - 1))
         # under a profiler (rocprofv3 preloads its tool library into every child too: the workers would become profiled GPU processes
         # writing their own traces into the same directory) this process collates itself
         if workers and (any(k.startswith(("ROCPROFILER", "ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")):
@@ -964,6 +969,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
     if device_ms[0]:
         extra = dict(extra, device_ms_per_batch=device_ms[0], vs_device_bound="%.2f x what the device alone needs for these batches (%.3f ms each, 16 of them "
                      "launched back to back from resident plans)" % (device_ms[0] / (dt / n_batches * 1e3), device_ms[0]))
+    extra = dict(extra, collate_workers=int(workers))
     return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B, "executor": route, **extra,
             "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead%s" % (workers, " (lost at batch %d: this process from there)" % lost[0] if lost else "")) if workers else "on the launching thread, while the device runs the batch before (forward_async)",
             "launch": "native executor: one dfol_run_program call per ProgramBatch, lowered at collate time" if route.get("native_program") else "eager (Python operator loop)",

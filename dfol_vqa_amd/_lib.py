@@ -104,6 +104,7 @@ SIGNATURES = {
     "dfol_parametric_not_f32": [_p, _p, _i32, _i32, _p, _p],
     "dfol_segment_or_f32": [_p, _p, _i32, _p, _p],
     "dfol_segment_or_ref_f32": [_p, _p, _i32, _p, _p],
+    "dfol_pair_train_fwd_h2_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i32, _i32, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p],
     "dfol_select_rows_f32": [_p, _p, _p, _i32, _i32, _p, _p],
     "dfol_calib_features_f32": [_p, _i32, _p, _i32, _p, _i32, _p, _p],
     "dfol_attention_modulations_f32": [_p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _p],
@@ -903,6 +904,23 @@ def pair_ll_h2(uv, hid1, pos, wg, w2_h2, b2, hid2, emb_w, emb_b, n_obj, obj_off,
          _ptr(obj_off, I32), Q, max_n, _ptr(req_col, I32), _ptr(req_tile, I32), _ptr(req_orient, U8, True), K, NS, default_ll,
          TILE_BF16 if bf16 else TILE_F32, _ptr(tiles, torch.bfloat16 if bf16 else F32), _stream())
     return tiles
+
+
+def pair_train_fwd_h2(uv_scaled, hid1, pos, wg, w2_h2, b2, hid2, n_obj, obj_off, pair_off, max_n, pairs, e_rows=None, req_row=None):
+    """The forward of a train step's pair MLP in one launch (include/dfol_vqa.h: dfol_pair_train_fwd_h2_f32).  uv_scaled: U | V times log2(e).
+    -> (Z [pairs, hid1], pre2 [pairs, hid2], geo [pairs, 4], x [K, pairs] or None).  req_row [K, Q] int32 (device): the row of e_rows
+    every image's reader uses in slot k (-1: none)."""
+    Q = n_obj.shape[0]
+    dev = uv_scaled.device
+    z = torch.empty(pairs, hid1, dtype=F32, device=dev)
+    pre2 = torch.empty(pairs, hid2, dtype=F32, device=dev)
+    geo = torch.empty(pairs, 4, dtype=F32, device=dev)
+    K = 0 if req_row is None else req_row.shape[0]
+    x = torch.zeros(K, pairs, dtype=F32, device=dev) if K else None
+    call("dfol_pair_train_fwd_h2_f32", _dp(uv_scaled), uv_scaled.stride(0), hid1, _dp(pos), pos.stride(0), _ptr(wg, F32), _ptr(w2_h2, torch.float16), _ptr(b2, F32),
+         hid2, None if e_rows is None else _dp(e_rows), 0 if e_rows is None else e_rows.stride(0), _ptr(n_obj, I32), _ptr(obj_off, I32), _ptr(pair_off, torch.int64),
+         Q, max_n, _ptr(req_row, I32, True), K, _ptr(z), _ptr(pre2), pre2.stride(0), _ptr(geo), _ptr(x, F32, True), pairs, _stream())
+    return z, pre2, geo, x
 
 
 def pair_math():

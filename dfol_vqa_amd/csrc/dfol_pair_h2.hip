@@ -57,6 +57,10 @@ __device__ long long dfol_h2_trace_buf[8 * 8 * 64];
 #ifndef DFOL_H2_DMA_ASM
 #define DFOL_H2_DMA_ASM 1
 #endif
+// lab switch for the TRAIN variant (tools/lab/time_train_fwd.py): bit 0 = no Z stores, bit 1 = no pre2 stores (what each costs)
+#ifndef DFOL_H2T_SKIP
+#define DFOL_H2T_SKIP 0
+#endif
 // Y's request for the next W2 chunk: 0 = at the top of its build tick, 1 = after its A pieces are built
 #ifndef DFOL_H2_DMA_LATE
 #define DFOL_H2_DMA_LATE 0
@@ -163,16 +167,29 @@ __global__ void h2_pack_w2_kernel(const float* __restrict__ W2, int64_t ld_w2, i
     out[idx] = u32x4{piece[0], piece[1], piece[2], piece[3]};
 }
 
+// TRAIN (round 6): the same kernel as the FORWARD of a train step's pair MLP (trainer.py:429-442 over classifier_oracle.py:145-156) - what the
+// backward needs leaves the registers on the way: the first hidden layer Z (multiplied back from the kernel's units of 1 / ln 2: one v_mul per
+// element of the build), the pair geometry, the second layer's pre-activations pre2 and the first reader's raw logits; no relation tile is written.  Replaces dfol_pair_hidden1_fwd_f32 + the tall product over Z (Z written, then read again: 5.2 GB).
+struct H2Train {
+    float* Z;                       // [pairs, HID1]
+    float* pre2;                    // [pairs, ld_pre2]
+    int64_t ld_pre2;
+    float* geo;                     // [pairs, 4]
+    float* x;                       // [K, ld_x]: x[k][row] = Sigmoid(pre2[row]) . E[req_col[k][image(row)]]  (no bias)
+    int64_t ld_x;
+    const int64_t* pair_off;        // [Q]: first pair row of every image
+};
+
 // One 8-wavefront workgroup per CU owns 256 ordered pairs (s != o, row-major in s: util.py:87-103) of one image; a wavefront owns 32
 // of them (two 16-slot tiles) and all NB16 column tiles (2 x NB16 accumulator tiles: 152 registers at NB16 = 19).
-template <int NB16, bool TBF16>
+template <int NB16, bool TBF16, bool TRAIN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_ll32h_kernel(
     const float* UV /* not __restrict__: see load_uv */, int64_t ld_uv, int HID1, const float* __restrict__ pos, int64_t ld_pos,
     const float* __restrict__ Wg, const u32x4* __restrict__ W2h, const float* __restrict__ b2, int HID2,
     const float* __restrict__ E, int64_t ld_e, const float* __restrict__ be, const int32_t* __restrict__ n_obj,
     const int32_t* __restrict__ obj_off, int Q, int tiles_per_image, const int32_t* __restrict__ req_col,
     const int32_t* __restrict__ req_tile, const uint8_t* __restrict__ req_orient, int K, int NS, float dflt,
-    void* __restrict__ tiles_v) {
+    void* __restrict__ tiles_v, H2Train tr) {
     constexpr int MT = 2, WAVES = 8;
     constexpr int ROWS = NB16 * 16, T = WAVES * 64, SLOTS = MT * 16 * WAVES;
     static_assert(NB16 > 16 && NB16 <= H2_TILES, "geometry");
@@ -183,9 +200,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int q = blockIdx.x / tiles_per_image, tb = blockIdx.x - q * tiles_per_image;
     const int n = n_obj[q], npairs = n * (n - 1);
     if (tb * SLOTS >= npairs) return;
-    bool any = false;
+    bool any = TRAIN;                                           // (training keeps every pair's activations, requested or not)
     for (int k = 0; k < K; ++k) any |= req_col[(int64_t)k * Q + q] >= 0;
     if (!any) return;
+    const int64_t prow0 = TRAIN ? tr.pair_off[q] : 0;           // the image's first pair row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kh = lane >> 4, r16 = lane & 15;
 #ifdef DFOL_PAIR_TRACE
@@ -207,10 +225,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // pointers cost 16 registers that the prefetched rows need)
     const char* img_uv = reinterpret_cast<const char*>(UV + (int64_t)first * ld_uv);
     uint32_t uoff[MT], voff[MT];
+    uint32_t zoff[MT];                                          // TRAIN: byte offset of the slot's Z row piece from the image's first row (~0: no such pair)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int e_slot = tb * SLOTS + wave * (MT * 16) + m * 16 + r16;
         const bool valid = e_slot < npairs;
+        zoff[m] = (TRAIN && valid) ? (uint32_t)(e_slot * HID1 + 4 * kh) * 4u : 0xffffffffu;
         const int s = valid ? e_slot / (n - 1) : 0, oo_ = valid ? e_slot - s * (n - 1) : 0, o = oo_ + (oo_ >= s);      // (n >= 2 here)
         const float* ps = pos + (int64_t)(first + s) * ld_pos;
         const float* po = pos + (int64_t)(first + o) * ld_pos;
@@ -218,8 +238,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float dx = x1 + w1 / 2.0f - x2 - w2 / 2.0f, dy = y1 + h1 / 2.0f - y2 - h2 / 2.0f;
         const float dist = sqrtf(dx * dx + dy * dy);
         uint32_t gh01, gl01, gh23, gl23;
-        h2_split2(dist, asinf(dy / fmaxf(dist, 1e-10f)), gh01, gl01);
-        h2_split2((x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f), (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f), gh23, gl23);
+        const float ang = asinf(dy / fmaxf(dist, 1e-10f));
+        const float sgx = (x2 - x1 > 0.f) ? 1.f : ((x2 - x1 < 0.f) ? -1.f : 0.f), sgy = (y2 - y1 > 0.f) ? 1.f : ((y2 - y1 < 0.f) ? -1.f : 0.f);
+        h2_split2(dist, ang, gh01, gl01);
+        h2_split2(sgx, sgy, gh23, gl23);
+        if (TRAIN && valid && kh == 0) *reinterpret_cast<floatx4*>(tr.geo + (prow0 + e_slot) * 4) = floatx4{dist, ang, sgx, sgy};      // (dfol_pair_train.hip: pair_geometry)
         geoB[m] = kh == 0 ? u32x4{gh01, gh23, gl01, gl23} : (kh == 1 ? u32x4{gh01, gh23, 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
         uoff[m] = (uint32_t)(s * (int)ld_uv + 4 * kh) * 4u;          // the lane's k of a chunk: 16 t + 4 kh + 0..3, t = 0, 1 (h2_kperm)
         voff[m] = (uint32_t)(o * (int)ld_uv + HID1 + 4 * kh) * 4u;
@@ -348,7 +371,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const uint32_t ll = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){h2_resid<false>(a0, hh), h2_resid<true>(a1, hh)}, f16x2));
                     ap[m][0][2 * t + jp] = hh;
                     ap[m][1][2 * t + jp] = ll;
+                    if (TRAIN) z[m][t][2 * jp] = a0 * H2_LN2, z[m][t][2 * jp + 1] = a1 * H2_LN2;       // the activations themselves, back in plain units
                 }
+        if (TRAIN && !(DFOL_H2T_SKIP & 1)) {
+            // the lane's four consecutive k of k-tile t of chunk c (h2_kperm: 32 c + 16 t + 4 kh + 0..3): one 16-byte store; the sixteen lanes
+            // kh = 0..3 x t = 0, 1 of a slot cover 128 contiguous bytes of its row per chunk
+            char* zimg = reinterpret_cast<char*>(tr.Z + prow0 * HID1) + (uint32_t)__builtin_amdgcn_readfirstlane(H2_CH * 4 * c);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (zoff[m] != 0xffffffffu) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) *reinterpret_cast<floatx4*>(zimg + zoff[m] + 64 * t) = z[m][t];
+                }
+        }
     };
     const int boff = r16 * 4 + (kh ^ h2_swz(r16));                  // the lane's 16-byte piece inside a 16-row block
     int bbase = boff;                                               // + the chunk buffer's offset
@@ -456,6 +491,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < NB16; ++i) {
             const float bv = stage[i * 16 + r16], cm = stage[ROWS + i * 16 + r16];
+            if (TRAIN && !(DFOL_H2T_SKIP & 2)) {
+                // pre2 = acc 2^-e_r + b2 = -ln 2 (acc cm + bv): column 16 i + r16 of the rows 4 kh + e of slot tile m (sixteen lanes = 64 contiguous
+                // bytes of a row; the next column tile's store continues them).  (Staged through the free chunk buffers for 16-byte stores along the
+                // rows, two forms: 2.28 and 2.06 ms per launch against 1.97 for these dword stores - tools/lab/time_train_fwd.py.)
+                const int colp = i * 16 + r16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ee = tb * SLOTS + wave * (MT * 16) + m * 16 + 4 * kh + e;
+                    // (a scalar base per image + a 32-bit lane offset: the saddr form of the store, no 64-bit multiply per element)
+                    if (colp < HID2 && ee < npairs)
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(tr.pre2 + prow0 * tr.ld_pre2) + (uint32_t)(ee * (int)tr.ld_pre2 + colp) * 4u) =
+                            -H2_LN2 * fmaf(acc[m][i][e], cm, bv);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[m][i][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[m][i][e], cm, bv)));
         }
@@ -497,6 +546,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int ee = tb * SLOTS + wave * (MT * 16) + hi * 16 + 4 * kh + (r16 & 3);
             if (ee < npairs) {
                 // ee / (n - 1) without the integer-division sequence: (ee + 0.5) / (n - 1) is at least 0.5 / (n - 1) away from an integer
+                if (TRAIN) {                                          // the reader's raw logit of this pair row (its bias and LogSigmoid stay with the caller)
+                    tr.x[(int64_t)k * tr.ld_x + prow0 + ee] = v;
+                    continue;
+                }
                 const int ss = (int)(((float)ee + 0.5f) * __builtin_amdgcn_rcpf((float)(n - 1))), op = ee - ss * (n - 1), oo = op + (op >= ss);
                 const float x = v + (be ? be[col] : 0.f);
                 const float val = fminf(x, 0.f) - dfol_log(1.0f + dfol_exp(-fabsf(x)));        // nn.LogSigmoid (the diagonal keeps the caller's fill)
@@ -621,14 +674,52 @@ extern "C" int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1,
     const dim3 grid((unsigned)Q * tpi);
     if (uint32_t* status = dfol_range_status_ptr())           // (dfol_set_range_status: saturated ELU outputs are reported, not answered with)
         hipLaunchKernelGGL(h2_uv_range_kernel, dim3((unsigned)Q), dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, n_obj, obj_off, status);
+    const H2Train none = {nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr};
 #define DFOL_PAIR32H(NBV, BF)                                                                                                       \
     hipLaunchKernelGGL((pair_ll32h_kernel<NBV, BF>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
-                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v)
+                       E, ld_e, be, n_obj, obj_off, Q, tpi, req_col, req_tile, req_orient, K, NS, default_ll, tiles_v, none)
     if (HID2 <= 272) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(17, true); else DFOL_PAIR32H(17, false); }
     else if (HID2 <= 288) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(18, true); else DFOL_PAIR32H(18, false); }
     else if (HID2 <= 304) { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(19, true); else DFOL_PAIR32H(19, false); }
     else { if (tile_dtype == DFOL_TILE_BF16) DFOL_PAIR32H(20, true); else DFOL_PAIR32H(20, false); }
 #undef DFOL_PAIR32H
     DFOL_LAUNCH_CHECK("pair_ll_h2");
+    return 0;
+}
+
+
+// The forward of a train step's pair MLP in ONE launch (round 6): per ordered pair of every image, Z = ELU(U[s] + V[o] + Wg geo), pre2 = W2 Z + b2, the pair geometry and, for K reader slots, the raw logits
+// x[k][row] = Sigmoid(pre2[row]) . E[req_row[k][image]] (req_row < 0: that image has no reader in slot k; its x entries are left alone).
+// Same arithmetic as dfol_pair_ll_h2_f32 (two fp16 pieces per operand, three products, fp32 accumulation).
+extern "C" int dfol_pair_train_fwd_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                                          const void* W2_split, const float* b2, int32_t HID2, const float* E, int64_t ld_e, const int32_t* n_obj,
+                                          const int32_t* obj_off, const int64_t* pair_off, int32_t Q, int32_t max_n, const int32_t* req_row, int32_t K,
+                                          float* Z, float* pre2, int64_t ld_pre2, float* geo, float* x, int64_t ld_x, void* stream) {
+    DFOL_REQUIRE(Q >= 0 && K >= 0 && max_n >= 0, "pair_train_fwd_h2: bad sizes Q=%d K=%d max_n=%d", Q, K, max_n);
+    DFOL_REQUIRE(HID1 > 0 && HID1 <= 256 && HID1 % H2_CH == 0 && ld_uv % 4 == 0, "pair_train_fwd_h2: HID1=%d must be a multiple of %d, <= 256, UV rows 16-byte aligned", HID1, H2_CH);
+    DFOL_REQUIRE(HID2 > 256 && HID2 <= 320 && ld_pre2 >= HID2, "pair_train_fwd_h2: HID2=%d must be in (256, 320], ld_pre2 >= HID2", HID2);
+    if (Q == 0 || max_n < 2) return 0;
+    DFOL_REQUIRE(UV && pos && Wg && W2_split && b2 && n_obj && obj_off && pair_off && Z && pre2 && geo && (K == 0 || (E && req_row && x)), "pair_train_fwd_h2: null pointer");
+    DFOL_REQUIRE(((uintptr_t)UV % 16 == 0) && ((uintptr_t)W2_split % 16 == 0) && ((uintptr_t)Wg % 16 == 0) && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)geo % 16 == 0),
+                 "pair_train_fwd_h2: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int tpi = dfol_cdiv((int64_t)max_n * (max_n - 1), 256);
+    DFOL_REQUIRE((int64_t)Q * tpi < ((int64_t)1 << 31), "pair_train_fwd_h2: too many tiles");
+    DFOL_REQUIRE((int64_t)max_n * ld_uv * 4 < ((int64_t)1 << 31) && (int64_t)max_n * (max_n - 1) * HID1 * 4 < ((int64_t)1 << 32) - 1,
+                 "pair_train_fwd_h2: an image's rows must span less than 2 GB (U | V) / 4 GB (Z)");
+    if (uint32_t* status = dfol_range_status_ptr())
+        hipLaunchKernelGGL(h2_uv_range_kernel, dim3((unsigned)Q), dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, n_obj, obj_off, status);
+    const H2Train tr = {Z, pre2, ld_pre2, geo, x, ld_x, pair_off};
+    const dim3 grid((unsigned)Q * tpi);
+#define DFOL_PAIR32T(NBV)                                                                                                                    \
+    hipLaunchKernelGGL((pair_ll32h_kernel<NBV, false, true>), grid, dim3(512), 0, st, UV, ld_uv, HID1, pos, ld_pos, Wg, (const u32x4*)W2_split, b2, HID2, \
+                       E, ld_e, (const float*)nullptr, n_obj, obj_off, Q, tpi, req_row, (const int32_t*)nullptr, (const uint8_t*)nullptr, K, 4, 0.f,      \
+                       (void*)nullptr, tr)
+    if (HID2 <= 272) DFOL_PAIR32T(17);
+    else if (HID2 <= 288) DFOL_PAIR32T(18);
+    else if (HID2 <= 304) DFOL_PAIR32T(19);
+    else DFOL_PAIR32T(20);
+#undef DFOL_PAIR32T
+    DFOL_LAUNCH_CHECK("pair_train_fwd_h2");
     return 0;
 }

@@ -274,13 +274,28 @@ class _FusedHidden1(torch.autograd.Function):
     backward, instead of the scatter-adds of the gathers (the largest single item of a ragged train step)."""
 
     @staticmethod
-    def forward(ctx, U, V, Wg, pos, world, store=torch.float32):
+    def forward(ctx, U, V, Wg, pos, world, store=torch.float32, fwd=None):
+        """fwd (round 6): None, or a dict {"w2h": the second layer's dfol_pair_pack_w2_f16x2 image, "b2", "hid2", "first"} - the WHOLE forward of the
+        pair MLP then runs as one launch of the fused pair kernel (dfol_pair_train_fwd_h2_f32: Z, pre2, the geometry and the first reader's logits
+        leave its registers; Z is not read back for the second layer) and pre2 / the logits are left in fwd["out"] for _PairTrunk."""
         ctx.joined = V is None                                  # U is [O, 2 HID1]: U | V, one product of the object features
+        UV = U
         if ctx.joined:
             h = U.shape[1] // 2
             U, V = U[:, :h], U[:, h:]
         max_n = max(world._n_list)
-        z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num, store)
+        if fwd is not None:
+            first = fwd["first"]
+            e_rows = req = None
+            if first is not None and len(first) > 2:
+                req_host = np.full((1, world._batch_size), -1, np.int32)
+                req_host[0, np.asarray(first[2], np.int64)] = np.arange(len(first[2]), dtype=np.int32)
+                e_rows, req = first[0], upload(req_host, U.device)
+            z, pre2, geo, x = L.pair_train_fwd_h2(UV.detach() * L.LOG2E, h, pos, Wg.detach(), fwd["w2h"], fwd["b2"], fwd["hid2"], world._img_n_obj,
+                                                  world._obj_off, world._pair_off, max_n, world._pair_num, e_rows, req)
+            fwd["out"] = (pre2, x)
+        else:
+            z, geo = L.pair_hidden1_fwd(U, V, pos, Wg, world._obj_off, world._pair_off, world._n_obj, max_n, world._pair_num, store)
         # (the world itself must not hang on the graph: world -> cached activations -> graph -> world would be a reference cycle that
         # only the garbage collector frees, 3 GB per step)
         # fp32 storage: the backward rebuilds z from U, V, Wg and the geometry instead of reading it (dfol_pair_hidden1_bwd_recompute_f32)
@@ -294,7 +309,7 @@ class _FusedHidden1(torch.autograd.Function):
         z, geo, obj_off, pair_off, n_obj = ctx.saved_tensors[:5]
         du, dv, dwg = L.pair_hidden1_bwd(dz.contiguous(), z, geo, obj_off, pair_off, n_obj, ctx.max_n, ctx.total_obj, ctx.joined,
                                          uvw=ctx.saved_tensors[5:] if ctx.recompute else None)
-        return du, dv, dwg, None, None, None
+        return du, dv, dwg, None, None, None, None
 
 
 class _FusedLogit(torch.autograd.Function):
@@ -323,14 +338,17 @@ class _PairTrunk(torch.autograd.Function):
     read less per step at 256 x 100 objects."""
 
     @staticmethod
-    def forward(ctx, z, weight, bias, state, first):
+    def forward(ctx, z, weight, bias, state, first, pre=None):
         """first: None, or the first reader's (embedding rows [P, HID2] (detached), row -> embedding row [pairs] int32): its logit layer's
-        forward then comes out of the product's epilogue as partial sums [slots, pairs] (no second pass over pre2)."""
+        forward then comes out of the product's epilogue as partial sums [slots, pairs] (no second pass over pre2).
+        pre: (pre2, x_part or None) when the fused forward kernel (_FusedHidden1 with `fwd`) has computed the product already."""
         w = weight.detach()
         w = w if w.is_contiguous() else w.contiguous()
         b = None if bias is None else bias.detach()
         f16x2 = _lib._dense_math() == "f16x2"
-        if z.dtype == torch.bfloat16:                         # the bf16 mode's stored activations: the persistent product over them (the logit layer keeps its own pass: its
+        if pre is not None:
+            pre2, x_part = pre[0], (z.new_zeros(0) if pre[1] is None else pre[1])
+        elif z.dtype == torch.bfloat16:                         # the bf16 mode's stored activations: the persistent product over them (the logit layer keeps its own pass: its
             pre2, x_part = L.linear_tall_h2(z, w, b)[0], z.new_zeros(0, dtype=torch.float32)      # epilogue form is the slower one at half the bytes)
         elif f16x2 and L.linear_tall_supported(z.shape[0], w.shape[0], w.shape[1]):
             # one persistent workgroup per CU over the row blocks (csrc/dfol_dense_tall.hip): the same bits, 1.9 ms against 2.6 at 256 x 100 objects
@@ -359,7 +377,7 @@ class _PairTrunk(torch.autograd.Function):
         if st["need_db"] and db is None:
             db = torch.zeros(ctx.shapes[1][0], dtype=torch.float32, device=dev)
         st.clear()                                           # (the activations must not outlive the step through this dictionary)
-        return dz, dw, db, None, None
+        return dz, dw, db, None, None, None
 
 
 class _HeadUse(torch.autograd.Function):
@@ -711,8 +729,9 @@ class ClassifierOracle(OracleBase):
                 # of the two tall products' operands) - csrc/dfol_pair_train.hip, dfol_linear_act_bf16_bf16, dfol_linear_wgrad_bias_bf16_bf16
                 store = torch.bfloat16 if L.bf16_store(lin1.weight.shape[0], lin2.weight.shape[0]) else torch.float32
                 _lib.note("fused_hidden1")
+                fwd = self._fused_forward(world, U, V, store, lin1, lin2, first)
                 z = _FusedHidden1.apply(U.contiguous(), None if V is None else V.contiguous(), lin1.weight[:, 2 * D:2 * D + 4].contiguous(),
-                                        pos, world, store)
+                                        pos, world, store, fwd)
             else:
                 s_idx, o_idx = world.pair_index()
                 ps, po = pos.index_select(0, s_idx), pos.index_select(0, o_idx)
@@ -728,12 +747,34 @@ class ClassifierOracle(OracleBase):
                 # the head's backward without dpre2 in memory: pre2 comes out of the trunk node, its readers register with `uses`
                 state = {}
                 _lib.note("pair_trunk")
-                pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, state, first)
+                pre = None
+                if fused and fwd is not None:
+                    pre = fwd.pop("out")
+                    _lib.note("pair_forward_fused")
+                pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, state, first, pre)
                 world._pair_head = (token, state, x_part)
                 world._pair_pre2 = pre2
             else:
                 world._pair_pre2 = _TallLinear.apply(z, lin2.weight, lin2.bias)
         return world._pair_pre2
+
+    def _fused_forward(self, world, U, V, store, lin1, lin2, first):
+        """The fused forward kernel's operands when the whole pair MLP's forward can run as one launch (round 6), else None: fp32
+        storage on the two-piece fp16 pipes, the joined U | V product, widths the fused pair kernel takes (HID1 <= 256, 256 < HID2 <= 320), the
+        deferred head (whose readers take pre2 from the trunk) and a backward that rebuilds Z from U | V instead of reading it."""
+        if os.environ.get("DFOL_TRAIN_FWD_FUSED", "1") == "0" or V is not None or store != torch.float32 or not U.is_cuda:
+            return None
+        hid1, hid2 = lin1.weight.shape[0], lin2.weight.shape[0]
+        if _lib._dense_math() != "f16x2" or L.pair_math() != "f16x2" or not L.pair_split_supported(hid1, hid2):
+            return None
+        if os.environ.get("DFOL_TRAIN_HEAD_FUSED", "1") == "0" or not L.pair_head_fused_supported(hid1, hid2) or not torch.is_grad_enabled():
+            return None
+        if not bool(L.load().dfol_pair_hidden1_bwd_recompute_supported(int(max(world._n_list)), int(hid1))) or os.environ.get("DFOL_H1B_RECOMPUTE", "1") == "0":
+            return None
+        packed = self._padded_second_layer()[3]
+        if not (isinstance(packed, tuple) and packed[0] == "f16x2"):
+            return None
+        return {"w2h": packed[1], "b2": lin2.bias.detach().contiguous(), "hid2": int(hid2), "first": first}
 
     def _head_fused(self, world, z, lin1, lin2):
         """The deferred head backward applies: fused training kernels, fp32-stored activations on the split-operand pipes, widths the one-workgroup
@@ -867,7 +908,7 @@ class ClassifierOracle(OracleBase):
             plan = _concept_plan(full[preds], dev, self._index_cache)
             e_rows, be_rows = _EmbRows.apply(emb.weight, emb.bias, cols, plan)
             fresh = getattr(world, "_pair_pre2", None) is None        # this reader creates the trunk: its logits come out of the trunk's epilogue
-            pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32))
+            pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32, q))
             head = getattr(world, "_pair_head", None)
             _lib.note("emb_rows")
             if head is not None:                          # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk

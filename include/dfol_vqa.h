@@ -445,6 +445,19 @@ int dfol_pair_ll_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1, const floa
                         const int32_t* req_tile, const uint8_t* req_orient, int32_t K, int32_t NS, float default_ll,
                         int32_t tile_dtype, void* tiles, void* stream);
 
+/* The FORWARD of a train step's pair MLP in one launch (round 6; csrc/dfol_pair_h2.hip, the kernel of dfol_pair_ll_h2_f32 with its operands'
+ * layout: UV in units of ln 2, W2_split from dfol_pair_pack_w2_f16x2): per ordered pair row (image-major, subject-major: util.py:87-103;
+ * pair_off[q] = first row of image q)
+ *   Z    [pairs, HID1]    ELU(U[s] + V[o] + Wg geo)
+ *   pre2 [pairs, ld_pre2] W2 ELU(..) + b2 (the hidden layer before its Sigmoid)          geo [pairs, 4] the pair geometry
+ *   x    [K, ld_x]        x[k][row] = Sigmoid(pre2[row]) . E[req_row[k][image(row)]] for reader slot k (req_row [K, Q] int32, < 0: none; no bias)
+ * Replaces dfol_pair_hidden1_fwd_f32 + the tall product over Z + the first reader's dfol_pair_logit_fwd_f32 (classifier_oracle.py:145-156 under
+ * trainer.py:429-442).  HID1 <= 256 and a multiple of 32, 256 < HID2 <= 320. */
+int dfol_pair_train_fwd_h2_f32(const float* UV, int64_t ld_uv, int32_t HID1, const float* pos, int64_t ld_pos, const float* Wg,
+                               const void* W2_split, const float* b2, int32_t HID2, const float* E, int64_t ld_e, const int32_t* n_obj,
+                               const int32_t* obj_off, const int64_t* pair_off, int32_t Q, int32_t max_n, const int32_t* req_row, int32_t K,
+                               float* Z, float* pre2, int64_t ld_pre2, float* geo, float* x, int64_t ld_x, void* stream);
+
 /* ---- training path of the pair MLP: the stages around its two tall GEMMs, fused (dfol_vqa_amd/csrc/dfol_pair_train.hip) ----------
  * Rows are the reference's ordered pairs (util.py:87-103): image-major, subject-major, the diagonal left out; pair_off[q] = first row of
  * image q ([Q] int64), obj_off[q] = its first object ([Q] int32), n_obj [Q].

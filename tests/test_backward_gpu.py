@@ -739,6 +739,8 @@ def test_bf16_mode_train_step_close_to_fp32_and_repeatable(store, objects, batch
     from dfol_vqa_amd import ops as dops                  # (visual_oracle calls the wrappers through this namespace)
     stores, real = [], dops.pair_hidden1_fwd
     monkeypatch.setattr(dops, "pair_hidden1_fwd", lambda *a, **k: (stores.append(a[9] if len(a) > 9 else k.get("store", torch.float32)), real(*a, **k))[1])
+    real_fused = dops.pair_train_fwd_h2                   # (round 6: the fp32-storage forward is the fused pair kernel, which stores fp32)
+    monkeypatch.setattr(dops, "pair_train_fwd_h2", lambda *a, **k: (stores.append(torch.float32), real_fused(*a, **k))[1])
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)

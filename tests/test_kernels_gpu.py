@@ -1071,3 +1071,45 @@ def test_act_bwd_equals_autograd_formulas(act, shape):
     assert (dz - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
     (auto,) = torch.autograd.grad(y, x, gy)
     assert (dz - auto).abs().max().item() <= 2e-6 * max(1.0, auto.abs().max().item())
+
+
+@pytest.mark.parametrize("n_list", [[9, 1, 12, 37], [100, 64], [2]])
+def test_pair_train_forward_fused_kernel(L, n_list):
+    """dfol_pair_train_fwd_h2_f32 (round 6: the forward of a train step's pair MLP in one launch - Z, pre2, the pair geometry and the first
+    reader's logits leave the fused pair kernel's registers) against the kernels it replaces (dfol_pair_hidden1_fwd_f32, the split-operand
+    product over Z, dfol_pair_logit_fwd_f32) and against float64: Z and the geometry to fp32 rounding, pre2 and the logits as close to
+    float64 as the replaced route."""
+    from dfol_vqa_amd import _lib
+    rng = np.random.RandomState(sum(n_list) + 11)
+    hid1, hid2 = 256, 300
+    Q, O = len(n_list), sum(n_list)
+    n = np.asarray(n_list, np.int64)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    pair_off = np.concatenate([[0], np.cumsum(n * (n - 1))]).astype(np.int64)
+    pairs = int(pair_off[-1])
+    uv = rng.normal(0, 1.0, (O, 2 * hid1)).astype(np.float32)
+    pos = rng.uniform(0.05, 0.9, (O, 4)).astype(np.float32)
+    wg = rng.uniform(-0.5, 0.5, (hid1, 4)).astype(np.float32)
+    w2 = (rng.normal(size=(hid2, hid1)) / np.sqrt(hid1)).astype(np.float32)
+    b2 = rng.normal(size=hid2).astype(np.float32)
+    P = sum(1 for x in n_list if x > 1)
+    e_rows = (rng.normal(size=(max(P, 1), hid2)) / np.sqrt(hid2)).astype(np.float32)
+    req = np.full((1, Q), -1, np.int32)
+    req[0, [i for i, x in enumerate(n_list) if x > 1]] = np.arange(P, dtype=np.int32)
+    wp = np.zeros((320, hid1), np.float32); wp[:hid2] = w2
+    img = _lib.pair_pack_w2_h2(dev(wp), hid2)
+    geom = (dev(np.asarray(n_list, np.int32)), dev(off), dev(pair_off)[:Q].contiguous())
+    z, pre2, geo, x = _lib.pair_train_fwd_h2(dev(uv) * _lib.LOG2E, hid1, dev(pos), dev(wg), img, dev(b2), hid2, *geom, max(n_list), pairs, dev(e_rows), dev(req))
+    z0, geo0 = _lib.pair_hidden1_fwd(dev(uv[:, :hid1].copy()), dev(uv[:, hid1:].copy()), dev(pos), dev(wg), geom[1], geom[2], geom[0], max(n_list), pairs)
+    assert torch.equal(geo, geo0)
+    assert (z - z0).abs().max().item() <= 2e-6 * max(1.0, z0.abs().max().item())
+    # float64 reference of pre2 and the logits from the replaced route's Z
+    z64 = z0.double().cpu().numpy()
+    p64 = z64 @ w2.astype(np.float64).T + b2
+    with _lib.dense_math("f16x2"):
+        p0 = _lib.linear_act_split(z0, dev(w2), dev(b2), _lib.ACT_NONE).cpu().numpy()
+    e_new, e_old = np.abs(pre2.cpu().numpy() - p64), np.abs(p0 - p64)
+    assert e_new.max() <= 4 * e_old.max() + 1e-6, (e_new.max(), e_old.max())
+    rowp = np.concatenate([np.full(int(n[i] * (n[i] - 1)), req[0, i]) for i in range(Q)]) if pairs else np.zeros(0, np.int64)
+    x64 = (1.0 / (1.0 + np.exp(-p64)) * e_rows.astype(np.float64)[np.maximum(rowp, 0)]).sum(1)
+    assert np.abs(x[0].cpu().numpy() - x64).max() <= 2e-5

@@ -218,3 +218,42 @@ def test_bench_on_files_in_the_reference_formats(tmp_path):
     assert out["data"].startswith("files: ") and "g18_exist.h5 6" in out["config"]["workload"] and out["config"]["batches"] == 16
     assert out["value"] > 0 and out["parity"]["policy"]["pass"] and len(out["parity"]["program_files_checked"]) == 8
     assert out["parity"]["questions_checked"] == 32 and out["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("mode", ["infer", "train", "c3"])
+def test_bench_eight_ranks_share_one_gpu(mode):
+    """8-GPU readiness without 8 GPUs (no scaling curve exists - SCALE was skipped every round): `bench.py --gpus 8` with its
+    own launcher, eight ranks on cuda:0 over gloo - inference, the train step and the ragged c3 workload.  Eight rank reports, every rank its
+    own OMP_NUM_THREADS share and a capped number of collate workers (8 x 6 worker processes would oversubscribe the host), replicas equal
+    after the all-reduced train steps, question shards balanced by the sum of n^2 within 5 %."""
+    env = dict(os.environ, DFOL_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--stress-preds", "0",
+           "--sustain", "0.2"]
+    if mode == "c3":
+        cmd += ["--workload", "c3", "--batch", "64", "--objects", "40", "--questions-per-image", "1", "--streamed", "0"]
+    else:
+        cmd += ["--batch", "16", "--objects", "20", "--fresh-batches", "3", "--mode", mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    ranks = out["ranks"]["ranks_seen"]
+    assert out["n_gpus"] == 8 and out["ranks"]["backend"] == "gloo" and [x["rank"] for x in ranks] == list(range(8)) and out["value"] > 0
+    cores = os.cpu_count() or 8
+    for x in ranks:
+        assert int(x["host"]["OMP_NUM_THREADS"]) == max(1, cores // 8), x["host"]
+    if mode == "infer":
+        assert out["config"]["global_batch"] == 128
+        per = out["fresh_programs"]["per_rank"]
+        assert [p["rank"] for p in per] == list(range(8)) and all(p["questions_per_s"] > 0 for p in per)
+        assert out["fresh_programs"]["collate_workers"] <= max(1, cores // 8 - 1)
+        assert out["config"]["legs"]["fresh"] > 0 and out["config"]["legs"]["native_batches"] > 0
+    elif mode == "train":
+        assert out["replicas_equal"] is True and out["allreduce_ms"] > 0 and out["config"]["global_batch"] == 128
+    else:
+        sh = out["shard"]
+        assert len(sh["questions_per_rank"]) == 8 and sum(sh["questions_per_rank"]) == 512
+        assert 1.0 <= sh["imbalance_max_over_mean"] <= 1.05, sh

@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--graph-collective", type=int, default=0, help="train mode over RCCL: 1 = ONE step graph with the all-reduce captured inside (opt-in: a "
                     "failure of that path - capture error or an abort from the process group's watchdog - ends THIS process with a non-zero exit, "
                     "there is no in-process fallback); 0 (default) = two graphs with the all-reduce issued eagerly between the replays")
+    ap.add_argument("--calibrated-leg", type=int, default=1, help="1: also time the CALIBRATED forward (activate_attention_transfer: True, the reference's "
+                    "default config) - graph replay of a resident batch and a stream of unseen batches on the native executor / the Python loop "
+                    "(north_star workload, one GPU): `calibrated` and config.legs.calibrated_*")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of back-to-back steps AFTER the --steps region for `value_sustained` (0 = skip)")
     ap.add_argument("--roofline-reps", type=int, default=20, help="eager steps of the roofline leg (per-launch HIP events); they are the LAST launches "
                                                                   "of the dominant kernel in the process, so a rocprofv3 trace of the same command can average the same launches")
@@ -446,6 +449,8 @@ def main(argv=None):
         out["value_end_to_end"] = ee["questions_per_s"] * world
         ee["vs_value"] = "%.2f x the replayed-batch rate `value`" % (out["value_end_to_end"] / out["value"])
         out["end_to_end"] = ee
+    if args.calibrated_leg and world == 1 and args.workload == "north_star" and args.fresh_batches > 0:
+        out["calibrated"] = calibrated_leg(args, device)          # (before the roofline leg: that one's launches must be the process's last)
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ------
         # --roofline-reps EAGER steps, one event pair per launch.  They come after every other leg that launches these kernels, so
@@ -496,6 +501,113 @@ def main(argv=None):
         td.destroy_process_group()
 
 
+def calibrated_leg(args, device, n_batches=24):
+    """The forward with the attention calibrator ON - config/sample_config.yaml's default and what the reference's final (cur6-7) model runs:
+    the LSTM walks over the aligned program + apply_modulations around every operator (batch_base_interpreter.py:87-140).  Same workload as
+    `value` (256 questions x N objects, select -> filter -> relate -> exist, full-size model + LSTMCell(318 -> 50) x 2 + Linear(100 -> 4)):
+    (a) one resident batch replayed as a HIP graph, (b) a stream of UNSEEN batches - plans lowered at collate time, two batches in flight -
+    on the native executor (round 6: the calibration passes are part of the plan) and (c) the same stream on the Python operator loop."""
+    import gc
+    import dfol_vqa_amd as D
+    from dfol_vqa_amd import _lib as L
+    from dfol_vqa_amd import experiment, native_exec
+    from dfol_vqa_amd import synthetic as syn
+    from dfol_vqa_amd.interpreter import GraphedForward
+    tmp = tempfile.mkdtemp(prefix="dfol_bench_calib_")
+    paths, names = syn.write_synthetic_ontology(tmp)
+    cfg = syn.reference_config(paths, activate_attention_transfer=True)
+    ontology = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ontology)
+    init_weights(model)
+    with torch.no_grad():                                        # (the reference zero-initialises the output layer: every modulation would be Sigmoid(bias))
+        o = model._ops['filter']._filter._attention_output_network[0]
+        o.weight.normal_(0.0, 0.5)
+        o.bias.normal_(0.0, 0.5)
+    model = model.to(device).eval()
+    voc = list(ontology._vocabulary["idx_to_arg"])
+    emb = torch.randn(len(voc), 300, generator=torch.Generator().manual_seed(3)) * 0.1
+    index = {t: i for i, t in enumerate(voc)}
+    N, B = args.objects, args.batch
+
+    class Collater(D.ProgramCollaterBase):
+        def __init__(self, spec=None):
+            super(Collater, self).__init__("select", "relate", "filter", 1, ontology=ontology, native_spec=spec)
+
+        def collate_object_features(self, qs):
+            return torch.cat([torch.from_numpy(q["scene"]["X"]) for q in qs], 0), torch.cat([torch.full((q["scene"]["n"],), i, dtype=torch.int64) for i, q in enumerate(qs)])
+
+        def collate_meta_data(self, qs):                        # (batch_gqa_boxfeatures_pipeline.py:88-92: token -> embedding row)
+            return {"index": index, "embedding": emb}
+
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    scenes = [syn.feature_scene(i, N, 2048) for i in range(B)]
+
+    def batch(k, spec=None):
+        qs = []
+        for i in range(B):
+            br, last = syn.three_hop_program(100000 * k + i, nouns, attrs, rels)
+            qs.append(syn.question(100000 * k + i, br, last, "yes", scenes[i]))
+        pb = Collater(spec).collate(qs)[0]
+        pb.create_sparse_tensors()
+        return pb
+
+    base = batch(0).to_cuda(device)
+    res = {"questions_per_batch": B, "objects": N}
+    with torch.no_grad():
+        eager = model([base], False)
+        g = GraphedForward(model, [base])
+        r = g()
+        res["graph_equals_eager"] = bool(torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g()
+        torch.cuda.synchronize()
+        res["replay_ms_per_step"] = (time.perf_counter() - t0) / 20 * 1e3
+        spec = native_exec.model_spec(model, calibrate=True)
+        saved = os.environ.get("DFOL_NATIVE")
+        try:
+            for route, nb in (("1", n_batches), ("0", max(8, n_batches // 3))):
+                os.environ["DFOL_NATIVE"] = route
+                fresh = []
+                for k in range(1, nb + 5):
+                    pb = batch(k, spec if route == "1" else None).to_cuda(device)
+                    pb._object_features = base._object_features       # (resident features: the leg times programs, not uploads)
+                    fresh.append([pb])
+                L.PATH_COUNTS.clear()
+                for pbk in fresh[:4]:
+                    model(pbk, False)
+                torch.cuda.synchronize()
+                # (the prepared batches are tens of thousands of long-lived Python objects: a generation-2 collection in the middle of the loop
+                # walks all of them - 2 ms pauses, seen as a 256-element list comprehension taking 2 ms; a serving process freezes what it keeps)
+                gc.collect()
+                gc.freeze()
+                t0 = time.perf_counter()
+                pend = []
+                for pbk in fresh[4:]:
+                    pend.append(model.forward_async(pbk, False))
+                    if len(pend) > 2:
+                        pend.pop(0).result()
+                for x in pend:
+                    x.result()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / nb * 1e3
+                gc.unfreeze()
+                key = "fresh_native" if route == "1" else "fresh_python_loop"
+                res[key + "_ms_per_batch"] = ms
+                res[key + "_routes"] = {k: v for k, v in L.PATH_COUNTS.items() if k in ("native_program", "python_program")}
+        finally:
+            if saved is None:
+                os.environ.pop("DFOL_NATIVE", None)
+            else:
+                os.environ["DFOL_NATIVE"] = saved
+    res["replay_questions_per_s"] = B / (res["replay_ms_per_step"] * 1e-3)
+    res["fresh_native_questions_per_s"] = B / (res["fresh_native_ms_per_batch"] * 1e-3)
+    res["fresh_python_loop_questions_per_s"] = B / (res["fresh_python_loop_ms_per_batch"] * 1e-3)
+    res["fresh_native_over_replay"] = res["fresh_native_questions_per_s"] / res["replay_questions_per_s"]
+    return res
+
+
 def legs_summary(out):
     """The honest loop rates, NUMBERS ONLY, inside a key the driver keeps (BENCH_rNN.json stores `config`, `roofline` and
     `cpu_baseline` in full but only the NAMES of other top-level keys): questions/s of every leg, its ratio to `value`, the executor's route
@@ -514,6 +626,13 @@ def legs_summary(out):
         if fp.get("device_ms_per_batch"):
             legs["fresh_device_ms_per_batch"] = float(fp["device_ms_per_batch"])
         legs["fresh_ms_per_batch"] = float(fp.get("ms_per_batch", 0.0))
+    cal = out.get("calibrated") or {}
+    if cal:
+        legs["calibrated_replay"] = float(cal["replay_questions_per_s"])
+        legs["calibrated_fresh"] = float(cal["fresh_native_questions_per_s"])
+        legs["calibrated_fresh_over_replay"] = float(cal["fresh_native_over_replay"])
+        legs["calibrated_fresh_python_loop"] = float(cal["fresh_python_loop_questions_per_s"])
+        legs["calibrated_native_batches"] = int((cal.get("fresh_native_routes") or {}).get("native_program", 0))
     ee = out.get("end_to_end") or {}
     if ee.get("h2d_GBps"):
         legs["end_to_end_h2d_GBps"] = float(ee["h2d_GBps"])
@@ -906,7 +1025,10 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
         try:
             # two batches in flight: batch i + 1 is prepared AND launched before batch i's answers are read back, so the device never waits
             # for the host's read-back / scoring / next launch (with one in flight it idled ~0.2 ms of every 2.3 ms batch)
-            t0 = time.perf_counter()
+            import gc
+            gc.collect()
+            gc.freeze()                                          # (what the process keeps - model, ontology, question dicts - leaves the collector's
+            t0 = time.perf_counter()                             # generations: a full collection inside the loop is a 2 ms pause, see calibrated_leg)
             import collections
             depth = 2 if stream_features else max(2, int(getattr(args, "fresh_depth", 2)))       # (the streamed form owns two feature buffers)
             inflight, launched = collections.deque(), 0
@@ -931,6 +1053,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
                     kept.append(pbs)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            gc.unfreeze()
             # the device's own clock over the loop: time inside the batches (first to last launch of each) and idle time between them
             inside = sum(a.elapsed_time(b) for a, b in marks)
             between = sum(max(0.0, marks[i][1].elapsed_time(marks[i + 1][0])) for i in range(len(marks) - 1))

@@ -267,7 +267,10 @@ def run(model, program_batch, plan, queue, give_answer=True):
     if feats.shape[1] - 6 != nm.struct.featurizer[0].K:
         raise _lib.DfolError("native executor: feature width %d does not match the featurizer (%d + 6)" % (feats.shape[1], nm.struct.featurizer[0].K))
     blob = blob_on(plan, device)
-    ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
+    # (sizes in coarse buckets: every fresh batch's plan has its own arena size, and a request that fits no cached block of the caching
+    # allocator costs a hipMalloc - ~0.4 ms on the launching thread, more than the C call itself)
+    gran = (1 << 25) if plan.ws_bytes >= (1 << 25) else (1 << 20)
+    ws = torch.empty((plan.ws_bytes + gran - 1) // gran * gran, dtype=torch.uint8, device=device)
     sc = ProgramScene()
     sc.features, sc.ld_features, sc.raw_cols, sc.O = feats.data_ptr(), feats.stride(0), feats.shape[1], plan.scene["O"]
     sc.NS, sc.max_n = plan.scene["NS"], plan.scene["max_n"]

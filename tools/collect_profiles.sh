@@ -3,7 +3,7 @@
 # or empty (a leg of measure_all that failed or timed out) is SKIPPED and reported - it never overwrites committed evidence - and the
 # script then exits non-zero.
 # usage: tools/collect_profiles.sh [tag]     (default r05)
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/$TAG
 missing=0
 take() {          # take <source> <destination> [filter]: copy (or, with "json", keep the last JSON line; "lines": all JSON lines; "clean": drop the amdgpu.ids noise)

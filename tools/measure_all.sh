@@ -3,7 +3,7 @@
 # every configuration, kernel / operator / training / calibrated-forward benchmarks, per-step launch breakdowns and the PMC passes of
 # the two MFMA kernels.  Copy what should be judged from gpurun_out/ into profiles/ (named per round).
 # usage: tools/measure_all.sh [tag]      (default tag r05)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=gpurun_out/$TAG

@@ -494,14 +494,16 @@ class _Calibration(object):
         self._zero, self._feat_memo, self._table, self._table_rows = {}, {}, {}, []
         md = pb._meta_data if isinstance(getattr(pb, "_meta_data", None), dict) else {}
         self.index, self.embedding = md.get("index"), md.get("embedding")
-        self.E = None
+        self.E, self._emb_host = None, None
 
     # -- token embeddings: a plan-local table in the blob (the rows get_embedding would hand the LSTM: base_oracle.py:45-55) -------------------------
     def _embedding_rows(self, names):
         try:
             ind = [self.index[t] for t in names]
-            emb = self.embedding
-            rows = emb[ind, :] if not hasattr(emb, "detach") else emb.detach().cpu()[ind, :].numpy()
+            if self._emb_host is None:                            # (one host copy per plan: a device tensor when the plan is built after to_cuda)
+                emb = self.embedding
+                self._emb_host = np.asarray(emb if not hasattr(emb, "detach") else emb.detach().cpu().numpy())
+            rows = self._emb_host[ind, :]
             return np.asarray(rows, np.float32).reshape(len(names), -1), "i"
         except (KeyError, TypeError, IndexError):
             rows = self.b.ont.get_embeddings(names)

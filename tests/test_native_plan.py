@@ -19,11 +19,12 @@ from dfol_vqa_amd import synthetic as syn  # noqa: E402
 KINDS = ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel", "two_same", "two_different", "all_same",
          "all_different", "compare"]
 W_OPERANDS = {NP.OP_DENSE: [6], NP.OP_BOX_POSITIONS: [1], NP.OP_FILL: [1], NP.OP_PAIR_LL: [1, 3, 9], NP.OP_ATTR_LL: [1, 6], NP.OP_OPTION_NORMALIZE: [1],
-              NP.OP_GATHER_TILES: [1, 4],
+              NP.OP_GATHER_TILES: [1, 4], NP.OP_CALIB_FEATURES: [7], NP.OP_LSTM_CELL: [2, 3, 4, 6, 7], NP.OP_SELECT_ROWS: [1, 2, 6],
+              NP.OP_ATT_MODULATIONS: [1, 2, 4], NP.OP_MODULATE: [1, 2, 5],
               NP.OP_FILTER: [1, 2, 7], NP.OP_RELATE_ONE: [1, 2, 3, 10], NP.OP_RELATE: [1, 2, 3, 13, 14], NP.OP_QUANTIFY: [1, 5], NP.OP_GATE: [1, 2, 7, 8],
               NP.OP_LOGIC: [2, 5], NP.OP_SEGMENT_SUM_ROWS: [1, 5], NP.OP_SEGMENT_OR: [1, 4], NP.OP_IMPLICATION: [1, 2, 5], NP.OP_COMPARE: [1, 2, 5],
               NP.OP_FIND_MAX_IND: [1, 5]}
-B_OPERANDS = {NP.OP_GATHER_TILES: [2], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
+B_OPERANDS = {NP.OP_GATHER_TILES: [2], NP.OP_CALIB_FEATURES: [1, 3, 5], NP.OP_SELECT_ROWS: [3], NP.OP_MODULATE: [3], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
               NP.OP_RELATE: [4, 5, 6, 7, 8, 9], NP.OP_QUANTIFY: [2, 3], NP.OP_GATE: [3, 4, 5], NP.OP_SEGMENT_SUM_ROWS: [2], NP.OP_SEGMENT_OR: [2],
               NP.OP_IMPLICATION: [3], NP.OP_COMPARE: [3], NP.OP_FIND_MAX_IND: [2]}
 
@@ -146,6 +147,43 @@ def test_round6_shapes_lower(setup):
         rel = plan.instrs[[int(x) == NP.OP_RELATE_ONE for x in plan.instrs[:, 0]]]
         assert len(rel) >= 1 and all(int(r[11]) == want for r in rel), n_list
         _in_bounds(plan)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_calibrated_programs_lower(setup, kind):
+    """The attention-calibration passes in the plan (round 6): with a calibration spec every operator kind lowers, the LSTM walks are there
+    (as many backward cells as forward cells, a modulation per calibrated Filter / Relate output), operands stay in bounds, token embeddings
+    travel in the blob (index entries where the batch has them, the ontology's embeddings otherwise - none here: the plan steps aside), and
+    the uncalibrated plan of the same batch is another plan (another key)."""
+    ont, names, categories, spec = setup
+    cspec = NP.ModelSpec([512], [256, 300], 256, 516, True, 0.0, ont._relation_index,
+                         calib=dict(state_dim=50, lstm_in=18 + 300, ops_index=D.BatchGQAInterpreter._OPS_INDEX))
+    assert cspec.key() != spec.key()
+    qs = syn.full_size_questions(kind, 6, 5, 12, names, categories, 40 + KINDS.index(kind))
+    for q in qs:
+        q["scene"]["X"] = q["scene"]["X"][:, -22:]
+    voc = list(ont._vocabulary["idx_to_arg"])
+
+    class Coll(FeatureCollater):
+        def collate_meta_data(self, questions):
+            return {"index": {t: i for i, t in enumerate(voc)}, "embedding": torch.arange(len(voc) * 300, dtype=torch.float32).view(len(voc), 300)}
+
+    pb = Coll(1, ont, cspec).collate(qs)[0]
+    plan = pickle.loads(pickle.dumps(pb._native_plan))
+    assert isinstance(plan, NP.NativePlan), kind
+    _in_bounds(plan)
+    ops = [int(x) for x in plan.instrs[:, 0]]
+    lstm = plan.instrs[[o == NP.OP_LSTM_CELL for o in ops]]
+    assert len(lstm) >= 2 and int((lstm[:, 1] == 0).sum()) == int((lstm[:, 1] == 1).sum())
+    assert ops.count(NP.OP_ATT_MODULATIONS) >= ops.count(NP.OP_MODULATE) >= 1
+    feats = plan.instrs[[o == NP.OP_CALIB_FEATURES for o in ops]]
+    assert all(int(r[2]) == 18 and int(r[4]) == 300 for r in feats)
+    table_off = int(feats[0][3])
+    row0 = plan.blob[table_off:table_off + 1200].view(np.float32)
+    assert row0[1] - row0[0] == 1.0 and int(row0[0]) % 300 == 0                       # a row of the batch's embedding table
+    # the same batch without an embedding for its tokens (the synthetic ontology has no embedding file): the Python loop's business
+    assert FeatureCollater(1, ont, cspec).collate(qs)[0]._native_plan is None
+    assert isinstance(FeatureCollater(1, ont, spec).collate(qs)[0]._native_plan, NP.NativePlan)
 
 
 def test_shapes_the_executor_does_not_take_step_aside(setup):

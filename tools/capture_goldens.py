@@ -1120,6 +1120,19 @@ def g17():
 
 
 
+# ---------------------------------------------------------------------------------------- g22
+def g22():
+    """The argument vocabulary the reference ships (data/metadata/gqa_vocab.json: idx_to_arg, 2335 names - the table columns of SURVEY 8(a) a3):
+    the names its authors' preprocessing produced WITH the `pattern` library, which neither container has.  Stored as a plain list: the input
+    vectors of the singulariser's consistency test (tests/test_data_path.py: the restated `pattern_singularize` must leave the vocabulary fixed,
+    and must still 'need' every entry of the reference's own exception tables, parse_utils.py:9-20)."""
+    with open(os.path.join(ref_harness.REF_SRC, "nsvqa", "data", "metadata", "gqa_vocab.json")) as f:
+        v = json.load(f)
+    with open(os.path.join(OUT, "g22_vocabulary_args.json"), "w") as f:
+        json.dump({"source": "src/nsvqa/data/metadata/gqa_vocab.json: idx_to_arg", "args": list(v["idx_to_arg"])}, f)
+    print("wrote g22_vocabulary_args", len(v["idx_to_arg"]))
+
+
 # ---------------------------------------------------------------------------------------- g21
 def g21():
     """The reference's batch samplers (data_pipeline.py:787-871): batches never mix files; MultiSetSequencialSampler walks the files in order,

@@ -499,3 +499,52 @@ def test_native_calibrated_plan_from_the_collate_worker(calibrated_full, monkeyp
     with torch.no_grad():
         ref = model(pbs, False)
     same_results(res, ref, "collate-time calibrated plan")
+
+
+def test_calibrated_full_batch_properties(calibrated_full, monkeypatch):
+    """BASELINE-size batch (256 questions x 100 objects, full-size model, calibrator ON) on the executor through size-independent properties:
+    (1) permuting the objects of every scene leaves every log-probability unchanged to rounding (the calibrator reads tokens and LSTM states,
+    never the scene geometry); (2) reversing the question order reverses the outputs bit for bit; (3) the batch run in four ProgramBatches
+    equals the batch run at once bit for bit; (4) the Python operator loop gives the same bits; (5) the calibrator is not the identity."""
+    model, ont, names, categories = calibrated_full
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    Q, N = 256, 100
+    qs = []
+    for i in range(Q):
+        br, last = syn.three_hop_program(8000 + i, nouns, attrs, rels, negate_prob=0.1)
+        qs.append(syn.question(8000 + i, br, last, "yes", syn.feature_scene(8000 + i, N, 2048)))
+
+    def go(questions, split=1, native="1", switch=True):
+        monkeypatch.setenv("DFOL_NATIVE", native)
+        pbs = [pb.to_cuda(DEV) for pb in _FullCalibrationCollater(split, ont).collate([dict(q) for q in questions])]
+        _lib.PATH_COUNTS.clear()
+        with torch.no_grad():
+            res = model(pbs, False, modulator_switch=switch)
+        assert _lib.PATH_COUNTS.get("native_program", 0) == (len(pbs) if native == "1" else 0)
+        return res["log_probability"].cpu().numpy()
+
+    # the reference's initial calibrator (alpha = beta = c = 1, d = 0.5: gqa_interpreter_experiments.py:119-132) with small weights on top, so that
+    # the modulations differ from question to question without driving every attention to the floor (the fixture's N(0, 0.5) weights do, at
+    # 100 objects and three hops)
+    import math
+    out = model._ops['filter']._filter._attention_output_network[0]
+    saved_w, saved_b = out.weight.detach().clone(), out.bias.detach().clone()
+    try:
+        with torch.no_grad():
+            out.weight.normal_(0.0, 0.05, generator=torch.Generator(device=out.weight.device).manual_seed(4))
+            out.bias.copy_(torch.tensor([-math.log(9.0)] * 3 + [0.0], device=out.bias.device))
+        lp = go(qs)
+        assert lp.shape == (Q,) and np.all(np.isfinite(lp)) and np.all(lp <= 1e-6)
+        assert 0.02 < np.mean(np.exp(lp) > 0.5) < 0.98, "degenerate batch: every answer the same"
+        rng = np.random.RandomState(0)
+        permuted = [dict(q, scene=dict(q["scene"], X=q["scene"]["X"][rng.permutation(N)])) for q in qs]
+        lp_perm = go(permuted)
+        assert np.abs(np.exp(lp_perm) - np.exp(lp)).max() <= 2e-5 and np.abs(lp_perm - lp).max() <= 1e-3 * max(1.0, np.abs(lp).max())
+        assert np.array_equal(go(qs[::-1])[::-1], lp)
+        assert np.array_equal(go(qs, split=4), lp)
+        assert np.array_equal(go(qs, native="0"), lp)
+        assert not np.array_equal(go(qs, switch=False), lp)
+    finally:
+        with torch.no_grad():
+            out.weight.copy_(saved_w)
+            out.bias.copy_(saved_b)

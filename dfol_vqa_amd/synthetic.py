@@ -126,6 +126,39 @@ def write_synthetic_ontology(directory, concept_num=2335, relation_num=333, seed
     return paths, {"nouns": nouns, "attributes": attrs, "relations": rels, "categories": cats}
 
 
+def write_synthetic_glove(path, idx_to_arg, seed=3, dim=300):
+    """A GloVe-format text file (`word v1 ... v300` per line) with one seeded N(0, 0.3) row per WORD of the vocabulary's names, sorted - what
+    `GQAOntology.get_embeddings` (batch_gqa_ops.py:135-148) reads: a multi-word name's embedding is the sum of its words' rows.  Deterministic
+    (numpy RandomState, values printed with four decimals): the capture tool and the tests regenerate the same file."""
+    rng = np.random.RandomState(seed)
+    with open(path, "w") as f:
+        for wd in sorted({x for name in idx_to_arg for x in name.split()}):
+            f.write(wd + " " + " ".join("%.4f" % x for x in rng.normal(0, 0.3, dim)) + "\n")
+    return path
+
+
+def load_seeded_calibrator(model, seed):
+    """Numpy-seeded weights for the attention calibrator of an interpreter - the two LSTM cells and the attention-output layer every operator
+    shares (batch_base_ops.py:251-254; built at gqa_interpreter_experiments.py:115-138) - written into the model in place; works on the
+    reference's model and on this repository's alike (same attribute names).  LSTM weights U(-1/sqrt(H), 1/sqrt(H)) like torch's default; the
+    output layer keeps the reference's bias (alpha = beta = c = 1, d = 0.5) and gets N(0, 0.05) weights instead of zeros, so that the
+    modulations depend on the LSTM states."""
+    import math
+    import torch
+    flt = model._ops['filter']._filter
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for net in (flt._forward_attention_network, flt._backward_attention_network):
+            k = 1.0 / math.sqrt(net.hidden_size)
+            for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                p = getattr(net, name)
+                p.copy_(torch.as_tensor(rng.uniform(-k, k, tuple(p.shape))).to(p.dtype))
+        lin = flt._attention_output_network[0]
+        lin.weight.copy_(torch.as_tensor(rng.normal(0.0, 0.05, tuple(lin.weight.shape))).to(lin.weight.dtype))
+        lin.bias.copy_(torch.as_tensor(np.asarray([-math.log(9.0)] * 3 + [0.0])).to(lin.bias.dtype))
+    return model
+
+
 def reference_config(paths, **over):
     """config/sample_config.yaml's model section (reference config/sample_config.yaml:37-60), with the calibrator off."""
     cfg = dict(model_name="bench", version="v0", box_features_dim=2048, oracle_input_dim=512, oracle_output_dim=1, word_embedding_dim=300,

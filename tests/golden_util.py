@@ -138,3 +138,15 @@ def check_g19_gradients(got, grads, what, rtol=2e-3, K=8.0):
         norm = np.sqrt((full ** 2).sum())
         assert abs(norm - g["norm64"]) <= K * abs(g["norm32"] - g["norm64"]) + rtol * g["norm64"] + 1e-30, \
             "%s |d%s| %.6g vs %.6g (the reference's own fp32 run %.6g)" % (what, pname, norm, g["norm64"], g["norm32"])
+
+
+G23_KINDS = ["exist", "verify_attrs", "verify_rel", "choose_rel", "query_attr", "and", "two_same", "compare"]
+
+
+def g23_case(kind, arrays, meta):
+    """One case of golden family g23 (the reference's CALIBRATED forward at full model size): questions with their scenes regenerated from seeds."""
+    from dfol_vqa_amd import synthetic as syn
+    cm = meta["cases"][kind]
+    qs = [syn.question(q["question_id"], q["program"]["branches"], q["program"]["last_op"], q["answer"], syn.feature_scene(q["question_id"], q["n"], meta["feature_dim"]))
+          for q in cm["questions"]]
+    return qs, cm

@@ -548,3 +548,51 @@ def test_calibrated_full_batch_properties(calibrated_full, monkeypatch):
         with torch.no_grad():
             out.weight.copy_(saved_w)
             out.bias.copy_(saved_b)
+
+
+@pytest.fixture(scope="module")
+def g23_model(tmp_path_factory):
+    """This repository's interpreter as golden g23's reference model: full size, calibrator on, numpy-seeded oracle and calibrator weights, the
+    synthetic GloVe file the capture tool wrote (regenerated from its seed)."""
+    from dfol_vqa_amd import experiment
+    d = str(tmp_path_factory.mktemp("g23"))
+    paths, names = syn.write_synthetic_ontology(d)
+    with open(paths["vocabulary_file"]) as f:
+        vocab = json.load(f)
+    paths["word_embedding_file"] = syn.write_synthetic_glove(os.path.join(d, "glove.txt"), vocab["idx_to_arg"])
+    cfg = syn.reference_config(paths, activate_attention_transfer=True)
+    ont = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ont)
+    a, meta = gu.load("g23_calibrated_full_size")
+    syn.load_seeded_weights(model, meta["weight_seed"])
+    syn.load_seeded_calibrator(model, meta["calibrator_seed"])
+    return model.to(DEV).eval(), ont, a, meta
+
+
+@pytest.mark.parametrize("kind", gu.G23_KINDS)
+def test_g23_calibrated_full_size_against_the_reference(g23_model, kind, monkeypatch):
+    """The calibrated forward at FULL model size against the REFERENCE ITSELF (golden g23: the imported reference with
+    activate_attention_transfer: True - LSTMCell(318 -> 50) x 2 + Linear(100 -> 4) around the full-size oracle - on ragged 10..40-object
+    scenes, eight terminal operators; g10 pins the calibration at reduced dims).  Executor and Python loop, calibrated and with the switch
+    off, at the policy's defaults; the two routes bit for bit."""
+    model, ont, a, meta = g23_model
+    assert model._has_modulator and native_exec.calibrator(model) is not None
+    qs, cm = gu.g23_case(kind, a, meta)
+    nat, py = both_routes(model, ont, qs, monkeypatch=monkeypatch, collater=CalibrationCollater(ont))
+    same_results(nat, py, "g23 " + kind)
+    lp32, lp64 = a[kind + ":lp_f32"], a[kind + ":lp_f64"]
+    lp = nat["log_probability"].cpu().numpy()
+    if kind == "compare":                                          # (renormalises two aggregations: the named exception of the policy, DESIGN 5)
+        assert np.abs(np.exp(lp.astype(np.float64)) - np.exp(lp64)).max() <= 4 * np.abs(np.exp(lp32.astype(np.float64)) - np.exp(lp64)).max() + 4e-6
+    else:
+        gu.check_logprob(lp, lp32, lp64, "g23 " + kind)
+    assert int(nat["type"]) == cm["type"]
+    decided = gu.decided_answers(cm, lp32, lp64)
+    assert [x for x, dd in zip(nat["answer"], decided) if dd] == [x for x, dd in zip(cm["answer"], decided) if dd], kind
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ont).collate([dict(q) for q in qs])]
+    with torch.no_grad():
+        off = model(pbs, False, modulator_switch=False)["log_probability"].cpu().numpy()
+    if kind != "compare":
+        gu.check_logprob(off, a[kind + ":lp_off_f32"], a[kind + ":lp_off_f64"], "g23 " + kind + " (switch off)")
+    assert np.abs(off - lp).max() > 0.1                            # the calibrator moves the answers

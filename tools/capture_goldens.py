@@ -1120,6 +1120,55 @@ def g17():
 
 
 
+# ---------------------------------------------------------------------------------------- g23
+G23_KINDS = ["exist", "verify_attrs", "verify_rel", "choose_rel", "query_attr", "and", "two_same", "compare"]
+G23_CALIBRATOR_SEED = 29
+
+
+def g23():
+    """The CALIBRATED forward of the reference at FULL model size (activate_attention_transfer: True, config/sample_config.yaml's default: the
+    LSTMCell(318 -> 50) walks + Linear(100 -> 4) modulations of batch_base_interpreter.py:87-140 around the full-size oracle) - g10 pins the
+    calibration at reduced dims only.  Eight terminal operators x 6 questions on ragged 10..40-object scenes, fp32 + fp64; everything but the
+    reference's outputs is regenerated from seeds (synthetic.seeded_weights, load_seeded_calibrator, write_synthetic_glove, feature_scene)."""
+    import zlib
+    model, names, categories = _full_size_reference("g23", activate_attention_transfer=True)
+    ont_full = model._dfol_ontology
+    syn.load_seeded_weights(model, G17_WEIGHT_SEED)
+    syn.load_seeded_calibrator(model, G23_CALIBRATOR_SEED)
+    model.eval()
+    model64 = copy.deepcopy(model).double()
+    arrays, meta = {}, {"source": "batch_base_interpreter.py:87-140; batch_base_ops.py:407-467,598-684; batch_base_types.py:170-187; "
+                                  "gqa_interpreter_experiments.py:115-138", "weight_seed": G17_WEIGHT_SEED, "calibrator_seed": G23_CALIBRATOR_SEED,
+                        "glove": "synthetic.write_synthetic_glove (seed 3)", "feature_dim": 2048, "torch": torch.__version__, "cases": {}}
+    for kind in G23_KINDS:
+        seed = zlib.crc32(kind.encode()) % 1000 + 2300
+        qs = syn.full_size_questions(kind, 6, 10, 40, names, categories, seed)
+        cm = {"questions": questions_to_meta(qs), "split": 1}
+        for dt, tag in both_dtypes():
+            m = model64 if dt == torch.float64 else model
+            collater = ref_harness.make_collater(ref, 1, "feature", ont_full)
+            pbs = collater.collate(copy.deepcopy(qs))
+            for pb in pbs:
+                pb.create_sparse_tensors()
+                if dt == torch.float64:
+                    pb.to(torch.float64)
+                    pb._object_batch_index = pb._object_batch_index.long()
+                    pb._meta_data["embedding"] = pb._meta_data["embedding"].double()
+            with torch.no_grad():
+                res = m(pbs, False, return_trace=False, modulator_switch=True)
+                off = m(pbs, False, return_trace=False, modulator_switch=False)
+            arrays["%s:lp_%s" % (kind, tag)] = res["log_probability"].detach().numpy()
+            arrays["%s:lp_off_%s" % (kind, tag)] = off["log_probability"].detach().numpy()
+            if tag == "f32":
+                cm["answer"], cm["options"], cm["type"] = res["answer"], res["options"], int(res["type"])
+        e = np.abs(arrays[kind + ":lp_f32"] - arrays[kind + ":lp_f64"])
+        d = np.abs(arrays[kind + ":lp_f64"] - arrays[kind + ":lp_off_f64"])
+        print(kind, "lp range %.3f .. %.3f" % (arrays[kind + ":lp_f64"].min(), arrays[kind + ":lp_f64"].max()), "ref32 vs ref64 max %.2e" % e.max(),
+              "calibrated vs not: max %.3f" % d.max())
+        meta["cases"][kind] = cm
+    save("g23_calibrated_full_size", arrays, meta)
+
+
 # ---------------------------------------------------------------------------------------- g22
 def g22():
     """The argument vocabulary the reference ships (data/metadata/gqa_vocab.json: idx_to_arg, 2335 names - the table columns of SURVEY 8(a) a3):
@@ -1176,17 +1225,15 @@ def _full_size_reference(tag, **cfg_over):
         vocab = json.load(f)
     with open(fpaths["attribute_file"]) as f:
         categories = json.load(f)
-    fpaths["word_embedding_file"] = os.path.join(tmp, "glove.txt")
-    rng = np.random.RandomState(3)
-    with open(fpaths["word_embedding_file"], "w") as f:          # build_model wants a GloVe file; every weight is overwritten by the caller
-        for wd in sorted({x for nme in vocab["idx_to_arg"] for x in nme.split()}):
-            f.write(wd + " " + " ".join("%.4f" % x for x in rng.normal(0, 0.3, 300)) + "\n")
+    # build_model wants a GloVe file (the oracle's weights are overwritten by the caller; the calibrator's token embeddings are read from it)
+    fpaths["word_embedding_file"] = syn.write_synthetic_glove(os.path.join(tmp, "glove.txt"), vocab["idx_to_arg"])
     cfg = syn.reference_config(fpaths, **cfg_over)
     exp = gie.GQAObjectBoxExperiment()
     exp._local_rank = 0
     full_ontology = exp.build_ontology(cfg, None)
     torch.manual_seed(0)
     model = exp.build_model(cfg, full_ontology, None)
+    model._dfol_ontology = full_ontology
     return model, names, categories
 
 

@@ -1462,3 +1462,76 @@ def test_train_from_h5_program_files(ontology, golden_dir, mini_ontology_paths, 
         assert np.isfinite(l1) and l1 != l0, (name, l0, l1)
         seen += 1
     assert seen == 8
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 6: the CALIBRATOR phases of the curriculum at FULL model size against the reference (golden g24)
+# ---------------------------------------------------------------------------------------------------
+G24_KINDS = ["exist", "verify_rel", "choose_rel", "query_attr", "and"]
+
+
+@pytest.fixture(scope="module")
+def g24_setup(tmp_path_factory):
+    import json
+    from dfol_vqa_amd import experiment
+    d = str(tmp_path_factory.mktemp("g24"))
+    paths, names = syn.write_synthetic_ontology(d)
+    with open(paths["vocabulary_file"]) as f:
+        vocab = json.load(f)
+    paths["word_embedding_file"] = syn.write_synthetic_glove(os.path.join(d, "glove.txt"), vocab["idx_to_arg"])
+    cfg = syn.reference_config(paths, activate_attention_transfer=True, dropout=0.0)
+    ont = experiment.build_ontology(cfg)
+    model = experiment.build_model(cfg, ont)
+    a, meta = gu.load("g24_calibrator_train_step")
+    syn.load_seeded_weights(model, meta["weight_seed"])
+    syn.load_seeded_calibrator(model, meta["calibrator_seed"])
+    return model.to(DEV).train(), ont, a, meta
+
+
+@pytest.mark.parametrize("backward", ["hip", "autograd"])
+@pytest.mark.parametrize("kind", G24_KINDS)
+def test_g24_calibrator_phase_train_step_against_the_reference(g24_setup, kind, backward, monkeypatch):
+    """ONE train-mode forward + loss + backward of the full-size model in the curriculum's CALIBRATOR phases (cur6-7: oracle frozen,
+    LSTMCell(318 -> 50) x 2 + Linear(100 -> 4) train) against the REFERENCE's own `_train_batch` (golden g24: loss, log-probabilities, norm +
+    sampled entries of all ten calibrator gradients, fp32 and fp64; trainer.py:181-262, 429-442 over batch_base_ops.py:407-467, 598-684) on
+    ragged 10..40-object scenes, BINARY and QUERY losses.  `hip`: the hand-written LSTM-cell and modulate backward kernels (the defaults);
+    `autograd`: the same forward with torch's autograd through those two ops."""
+    from test_interpreter_gpu import CalibrationCollater
+    model, ont, a, meta = g24_setup
+    for k in ("DFOL_LSTM_BWD", "DFOL_MODULATE_BWD"):
+        monkeypatch.setenv(k, "hip" if backward == "hip" else "torch")
+    trainable = sorted(k for k, p in model.named_parameters() if p.requires_grad)
+    assert len(trainable) == 10 and all("attention" in k for k in trainable), trainable
+    cm = meta["cases"][kind]
+    qs = [syn.question(q["question_id"], q["program"]["branches"], q["program"]["last_op"], q["answer"],
+                       syn.feature_scene(q["question_id"], q["n"], meta["feature_dim"])) for q in cm["questions"]]
+    pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ont).collate([dict(q) for q in qs])]
+    model.zero_grad(set_to_none=True)
+    res = model(pbs, True)
+    assert int(res["type"]) == cm["type"]
+    loss = training.compute_loss(pbs, res) / len(qs)
+    loss.backward()
+    l32, l64, got_loss = float(a[kind + ":loss_f32"]), float(a[kind + ":loss_f64"]), float(loss.detach())
+    assert abs(got_loss - l64) <= 8 * abs(l32 - l64) + 2e-5 * max(1.0, abs(l64)), (got_loss, l32, l64)
+    gu.check_logprob(res["log_probability"].detach().cpu().numpy(), a[kind + ":lp_f32"], a[kind + ":lp_f64"], "g24 " + kind)
+    got = {}
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            short = k[k.index("_filter.") + len("_filter."):]
+            got.setdefault(short, (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu().numpy())
+    grads = {}
+    for key in a.files:
+        if key.startswith(kind + ":gs:") and key.endswith(":f64"):
+            pname = key[len(kind) + 4:-4]
+            grads[pname] = {"sample64": a[key], "sample32": a[key[:-3] + "f32"], "norm64": float(a["%s:gn:%s:f64" % (kind, pname)]),
+                            "norm32": float(a["%s:gn:%s:f32" % (kind, pname)])}
+    assert sorted(grads) == sorted(got), (sorted(grads), sorted(got))
+    for pname, g in grads.items():
+        full = got[pname].astype(np.float64).reshape(-1)
+        smp = full[syn.gradient_sample_index(pname, full.size)]
+        ref64, ref32 = g["sample64"].astype(np.float64), g["sample32"].astype(np.float64)
+        scale = max(np.abs(ref64).max(), g["norm64"] / np.sqrt(full.size)) + 1e-30
+        own, err = np.abs(ref32 - ref64).max(), np.abs(smp - ref64).max()
+        assert err <= 8 * own + 2e-3 * scale, "g24 %s d%s: |dgrad| %.3g vs the reference's own %.3g (scale %.3g)" % (kind, pname, err, own, scale)
+        norm = np.sqrt((full ** 2).sum())
+        assert abs(norm - g["norm64"]) <= 8 * abs(g["norm32"] - g["norm64"]) + 2e-3 * g["norm64"] + 1e-30, (kind, pname, norm, g["norm64"], g["norm32"])

@@ -1169,6 +1169,80 @@ def g23():
     save("g23_calibrated_full_size", arrays, meta)
 
 
+# ---------------------------------------------------------------------------------------- g24
+G24_KINDS = ["exist", "verify_rel", "choose_rel", "query_attr", "and"]
+
+
+def g24():
+    """The reference's `_train_batch` in the CALIBRATOR phases of its curriculum (cur6-7: everything frozen but the two LSTM cells and the
+    attention-output layer; trainer.py:181-262, 429-442 over batch_base_interpreter.py:87-140) at FULL model size: loss, log-probabilities and the
+    gradient of every calibrator tensor (ten of them; norm + the g19 sample of 4096 entries), fp32 + fp64, for BINARY and QUERY batches on ragged
+    10..40-object scenes.  Weights / GloVe / scenes regenerate from seeds as for g23."""
+    import zlib
+    from nsvqa.train.trainer import VQATrainer
+    model, names, categories = _full_size_reference("g24", activate_attention_transfer=True, dropout=0.0)
+    ont_full = model._dfol_ontology
+    syn.load_seeded_weights(model, G17_WEIGHT_SEED)
+    syn.load_seeded_calibrator(model, G23_CALIBRATOR_SEED)
+    trainable = sorted(k for k, p in model.named_parameters() if p.requires_grad)
+    assert trainable and all("attention" in k for k in trainable), trainable
+    fake = types.SimpleNamespace(_device=torch.device("cpu"), _config={})
+    arrays, meta = {}, {"source": "trainer.py:181-262,429-442; batch_base_interpreter.py:87-140; batch_base_ops.py:407-467,598-684", "weight_seed": G17_WEIGHT_SEED,
+                        "calibrator_seed": G23_CALIBRATOR_SEED, "feature_dim": 2048, "torch": torch.__version__, "cases": {}}
+    flt_prefix = "_ops.select._filter."
+    for kind in G24_KINDS:
+        seed = zlib.crc32(kind.encode()) % 1000 + 2400
+        qs = syn.full_size_questions(kind, 6, 10, 40, names, categories, seed)
+        rng = np.random.RandomState(seed)
+        for q in qs:                                            # answers the loss can score: yes / no, or one of the question's options
+            last = q["program"]["last_op"]
+            if kind == "choose_rel":
+                q["answer"] = last["arguments"][0][rng.randint(2)]
+            elif kind == "query_attr":
+                q["answer"] = categories[last["arguments"][0]][rng.randint(len(categories[last["arguments"][0]]))]
+            else:
+                q["answer"] = "yes" if rng.uniform() < 0.5 else "no"
+        for dt, tag in both_dtypes():
+            m = copy.deepcopy(model).double() if dt == torch.float64 else copy.deepcopy(model)
+            m.train()
+            collater = ref_harness.make_collater(ref, 1, "feature", ont_full)
+            pbs = collater.collate(copy.deepcopy(qs))
+            for pb in pbs:
+                pb.create_sparse_tensors()
+                if dt == torch.float64:
+                    pb.to(torch.float64)
+                    pb._object_batch_index = pb._object_batch_index.long()
+                    pb._meta_data["embedding"] = pb._meta_data["embedding"].double()
+            res = m(pbs, True, return_trace=False)
+            lp = res["log_probability"]
+            if dt == torch.float64:
+                if res["type"] == ref.base_types.QuestionType.BINARY:
+                    target = torch.tensor([a_ == "yes" for pb in pbs for a_ in pb._answers], dtype=dt)
+                    loss = torch.nn.functional.binary_cross_entropy(lp.exp(), target, reduction="sum")
+                else:
+                    answers = [a_ for pb in pbs for a_ in pb._answers]
+                    target = [[a_ == o for o in opt] for a_, opt in zip(answers, res["options"])]
+                    seg = torch.tensor([i for i, t in enumerate(target) for _ in t])
+                    tflat = torch.tensor([x for t in target for x in t], dtype=dt)
+                    denom = torch.zeros(len(target), dtype=dt).index_add(0, seg, lp.exp())
+                    loss = ref.util.safe_log(denom).sum() - (tflat * lp).sum()
+            else:
+                loss = VQATrainer._compute_loss(fake, pbs, res)
+            loss = loss / sum(pb.batch_size() for pb in pbs)
+            loss.backward()
+            arrays["%s:loss_%s" % (kind, tag)] = loss.detach().numpy()
+            arrays["%s:lp_%s" % (kind, tag)] = lp.detach().numpy()
+            for k, prm in m.named_parameters():
+                if k.startswith(flt_prefix) and "attention" in k:
+                    g = (torch.zeros_like(prm) if prm.grad is None else prm.grad).detach().numpy()
+                    pname = k[len(flt_prefix):]
+                    arrays["%s:gn:%s:%s" % (kind, pname, tag)] = np.sqrt((g.astype(np.float64) ** 2).sum())
+                    arrays["%s:gs:%s:%s" % (kind, pname, tag)] = g.reshape(-1)[syn.gradient_sample_index(pname, g.size)]
+            print(kind, tag, "loss", float(loss), "|g out.weight|", float(arrays["%s:gn:_attention_output_network.0.weight:%s" % (kind, tag)]))
+        meta["cases"][kind] = {"questions": questions_to_meta(qs), "type": int(res["type"])}
+    save("g24_calibrator_train_step", arrays, meta)
+
+
 # ---------------------------------------------------------------------------------------- g22
 def g22():
     """The argument vocabulary the reference ships (data/metadata/gqa_vocab.json: idx_to_arg, 2335 names - the table columns of SURVEY 8(a) a3):

@@ -127,6 +127,7 @@ SIGNATURES = {
     "dfol_option_normalize_bwd_f32": [_p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
     "dfol_modulate_f32": [_p, _p, _p, _p, _i32, _i32, _p, _p],
     "dfol_lstm_cell_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p],
+    "dfol_lstm_cell_tokens_f32": [_p, _i32, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_lstm_pointwise_f32": [_p, _p, _p, _i32, _i32, _p, _p, _p],
     "dfol_lstm_cell_train_f32": [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p],
     "dfol_lstm_cell_bwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p],
@@ -752,6 +753,16 @@ def lstm_cell(x, h, c, w_ih_t, w_hh_t, b_ih, b_hh):
     call("dfol_lstm_cell_f32", _dp(x), x.stride(0), x.shape[1], _dp(h), h.stride(0), _ptr(c, F32), _ptr(w_ih_t, F32),
          w_ih_t.stride(0), _ptr(w_hh_t, F32), w_hh_t.stride(0), _ptr(b_ih, F32, True), _ptr(b_hh, F32, True), rows, H, _ptr(hy), _ptr(cy),
          _stream())
+    return hy, cy
+
+
+def lstm_cell_tokens(head, table, idx, h, c, w_ih_t, w_hh_t, b_ih, b_hh):
+    """lstm_cell on rows built from tokens: x[p] = [head | table[idx[p]]] (zeros where idx[p] < 0) - calib_features + lstm_cell in one launch."""
+    rows, H = c.shape
+    hy, cy = torch.empty_like(c), torch.empty_like(c)
+    call("dfol_lstm_cell_tokens_f32", _ptr(head, F32), head.numel(), _ptr(table, F32), table.shape[1], _ptr(idx, I32), _dp(h), h.stride(0), _ptr(c, F32),
+         _ptr(w_ih_t, F32), w_ih_t.stride(0), _ptr(w_hh_t, F32), w_hh_t.stride(0), _ptr(b_ih, F32, True), _ptr(b_hh, F32, True), rows, H, _ptr(hy),
+         _ptr(cy), _stream())
     return hy, cy
 
 

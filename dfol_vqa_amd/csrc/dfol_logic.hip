@@ -1381,22 +1381,41 @@ extern "C" int dfol_calib_features_f32(const float* head, int32_t n_head, const 
 
 // The attention-output network on the two LSTM states of an operator (BatchOperatorBase._compute_attention_modulations, batch_base_ops.py:275-286, with
 // the Linear(2 S -> N) + Sigmoid of gqa_interpreter_experiments.py:119-132): out[p][j] = Sigmoid(b[j] + W[j][:S] . fs[p] + W[j][S:] . bs[p]); a NULL
-// state counts as zeros (the reference substitutes zeros_like).  One thread per output, products added in k order, then the bias.
-__global__ void attention_modulations_kernel(const float* __restrict__ fs, const float* __restrict__ bs, const float* __restrict__ W, int64_t ld_w,
-                                             const float* __restrict__ b, int P, int S, int N, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P * N) return;
-    const int p = i / N, j = i - p * N;
-    const float* w = W + (int64_t)j * ld_w;
-    // the products first, the bias LAST: the bias is -log 9 (gqa_interpreter_experiments.py:124-126) and the hundred products are ~1e-2 each -
-    // added one by one onto the bias they are each rounded at ulp(2.2), 4e-6 of systematic error in a modulation of 0.1 (found by golden g23)
-    float acc = 0.f;
-    if (fs)
-        for (int k = 0; k < S; ++k) acc = fmaf(w[k], fs[(int64_t)p * S + k], acc);
-    if (bs)
-        for (int k = 0; k < S; ++k) acc = fmaf(w[S + k], bs[(int64_t)p * S + k], acc);
-    if (b) acc += b[j];
-    out[i] = 1.0f / (1.0f + expf(-acc));
+// state counts as zeros (the reference substitutes zeros_like).  Sixteen lanes per row: lane l takes the inputs l, l + 16, ... (coalesced loads, all in
+// flight at once) for up to AM_N outputs, the lanes meet in a butterfly, then the bias.  (First version: one thread per output walking its hundred
+// inputs one load after the other, 9 - 14 us per launch at 256 rows; five launches per calibrated forward.)
+// The products first, the bias LAST: the bias is -log 9 (gqa_interpreter_experiments.py:124-126) and the hundred products are ~1e-2 each - added one
+// by one onto the bias they are each rounded at ulp(2.2), 4e-6 of systematic error in a modulation of 0.1 (found by golden g23).
+constexpr int AM_N = 8;
+__global__ __launch_bounds__(256) void attention_modulations_kernel(const float* __restrict__ fs, const float* __restrict__ bs, const float* __restrict__ W,
+                                                                    int64_t ld_w, const float* __restrict__ b, int P, int S, int N, float* __restrict__ out) {
+    const int l = threadIdx.x & 15, p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int pc = min(p, P - 1);
+    for (int j0 = 0; j0 < N; j0 += AM_N) {
+        float acc[AM_N];
+#pragma unroll
+        for (int j = 0; j < AM_N; ++j) acc[j] = 0.f;
+        for (int half = 0; half < 2; ++half) {
+            const float* st = half ? bs : fs;
+            if (!st) continue;
+            for (int k = l; k < S; k += 16) {
+                const float v = st[(int64_t)pc * S + k];
+#pragma unroll
+                for (int j = 0; j < AM_N; ++j)
+                    if (j0 + j < N) acc[j] = fmaf(W[(int64_t)(j0 + j) * ld_w + half * S + k], v, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AM_N; ++j) {
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 16);
+        }
+        if (l == 0 && p < P) {
+#pragma unroll
+            for (int j = 0; j < AM_N; ++j)
+                if (j0 + j < N) out[(int64_t)p * N + j0 + j] = 1.0f / (1.0f + expf(-(acc[j] + (b ? b[j0 + j] : 0.f))));
+        }
+    }
 }
 
 extern "C" int dfol_attention_modulations_f32(const float* fs, const float* bs, const float* W, int64_t ld_w, const float* b, int32_t P, int32_t S,
@@ -1404,7 +1423,7 @@ extern "C" int dfol_attention_modulations_f32(const float* fs, const float* bs, 
     DFOL_REQUIRE(P >= 0 && S > 0 && N > 0 && ld_w >= 2 * S, "attention_modulations: bad sizes P=%d S=%d N=%d", P, S, N);
     if (P == 0) return 0;
     DFOL_REQUIRE(W && out, "attention_modulations: null pointer");
-    hipLaunchKernelGGL(attention_modulations_kernel, dim3(dfol_cdiv((int64_t)P * N, 256)), dim3(256), 0, (hipStream_t)stream, fs, bs, W, ld_w, b, P, S, N, out);
+    hipLaunchKernelGGL(attention_modulations_kernel, dim3(dfol_cdiv(P, 16)), dim3(256), 0, (hipStream_t)stream, fs, bs, W, ld_w, b, P, S, N, out);
     DFOL_LAUNCH_CHECK("attention_modulations");
     return 0;
 }
@@ -1687,57 +1706,101 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ ig, const float*
     hy[idx] = so * tanhf(cn);
 }
 
-// The whole cell in one launch: a workgroup takes LC_ROWS rows, stages their x and h in LDS, thread g < 4H accumulates gate g for all of
-// them (the weights come TRANSPOSED, [K, 4H], so the threads of a wavefront read consecutive floats; the x / h reads are LDS
-// broadcasts), then the pointwise stage.
-constexpr int LC_ROWS = 4;
-__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ x, int64_t ld_x, int KX, const float* __restrict__ h,
-                                                        int64_t ld_h, const float* __restrict__ c, const float* __restrict__ Wih,
-                                                        int64_t ld_wih, const float* __restrict__ Whh, int64_t ld_whh,
-                                                        const float* __restrict__ bih, const float* __restrict__ bhh, int rows, int H,
-                                                        float* __restrict__ hy, float* __restrict__ cy, float* __restrict__ gates_out) {
-    extern __shared__ float lc_s[];                          // [LC_ROWS][KX + H] inputs, then [LC_ROWS][4H] gates
-    const int r0 = blockIdx.x * LC_ROWS, K = KX + H, tid = threadIdx.x;
+// The whole cell in one launch: a workgroup (512 threads) takes LC_ROWS rows and stages their x and h in LDS (row-interleaved: one 16-byte LDS
+// broadcast hands a weight's four inputs over); thread (gate g, K slice ks) accumulates gate g of all four rows over its slice of K (the weights
+// come TRANSPOSED, [K, 4H], so the threads of a wavefront read consecutive floats), sixteen weight loads in flight and the next sixteen requested
+// under their products; the slices meet in LDS, then the pointwise stage.  (First version: 256 threads, one K slice, eight loads in flight - a
+// chain of 46 L2 round trips, 16 us per cell at 256 rows x (318 + 50) -> 200 where the launch floor is ~5 us; eight cells per calibrated forward.)
+// LcTokens: the rows of x built in the staging loop from an operator's tokens (what dfol_calib_features_f32 would write: [head | table[idx[row]]], or
+// zeros for a no-op token) instead of read - x == nullptr.
+constexpr int LC_ROWS = 4, LC_THREADS = 512, LC_BATCH = 16;
+struct LcTokens {
+    const float* head; int n_head;
+    const float* table; int E;
+    const int32_t* idx;
+};
+__device__ __forceinline__ void lc_dot(const float* __restrict__ w, int64_t ld, const float* __restrict__ in4, int kb, int ke, float (&acc)[LC_ROWS]) {
+    float wa[LC_BATCH], wb[LC_BATCH];
+    int k = kb;
+    if (k + LC_BATCH <= ke) {
+#pragma unroll
+        for (int u = 0; u < LC_BATCH; ++u) wa[u] = w[(int64_t)(k + u) * ld];
+    }
+    for (; k + LC_BATCH <= ke; k += LC_BATCH) {
+        const bool more = k + 2 * LC_BATCH <= ke;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < LC_BATCH; ++u) wb[u] = w[(int64_t)(k + LC_BATCH + u) * ld];
+        }
+#pragma unroll
+        for (int u = 0; u < LC_BATCH; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(in4 + 4 * (k + u));
+            acc[0] = fmaf(wa[u], v.x, acc[0]), acc[1] = fmaf(wa[u], v.y, acc[1]), acc[2] = fmaf(wa[u], v.z, acc[2]), acc[3] = fmaf(wa[u], v.w, acc[3]);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < LC_BATCH; ++u) wa[u] = wb[u];
+        }
+    }
+    for (; k < ke; ++k) {
+        const float wv = w[(int64_t)k * ld];
+        const float4 v = *reinterpret_cast<const float4*>(in4 + 4 * k);
+        acc[0] = fmaf(wv, v.x, acc[0]), acc[1] = fmaf(wv, v.y, acc[1]), acc[2] = fmaf(wv, v.z, acc[2]), acc[3] = fmaf(wv, v.w, acc[3]);
+    }
+}
+__global__ __launch_bounds__(LC_THREADS) void lstm_cell_kernel(const float* __restrict__ x, int64_t ld_x, int KX, const float* __restrict__ h,
+                                                               int64_t ld_h, const float* __restrict__ c, const float* __restrict__ Wih,
+                                                               int64_t ld_wih, const float* __restrict__ Whh, int64_t ld_whh,
+                                                               const float* __restrict__ bih, const float* __restrict__ bhh, int rows, int H,
+                                                               float* __restrict__ hy, float* __restrict__ cy, float* __restrict__ gates_out, LcTokens tk,
+                                                               int GP, int KS) {
+    extern __shared__ __attribute__((aligned(16))) float lc_s[];   // [KX + H][LC_ROWS] inputs, then [KS][2][LC_ROWS][4H] partial gates
+    static_assert(LC_ROWS == 4, "lstm_cell: the staged inputs are read four rows at a time");
+    const int r0 = blockIdx.x * LC_ROWS, K = KX + H, tid = threadIdx.x, G = 4 * H;
     float* in_s = lc_s;
-    float* gate_s = lc_s + LC_ROWS * K;
-    for (int i = tid; i < LC_ROWS * K; i += 256) {
+    float* part_s = lc_s + LC_ROWS * K;
+    for (int i = tid; i < LC_ROWS * K; i += LC_THREADS) {
         const int r = i / K, k = i - r * K, row = min(r0 + r, rows - 1);
-        in_s[i] = k < KX ? x[(int64_t)row * ld_x + k] : h[(int64_t)row * ld_h + (k - KX)];
+        float v;
+        if (k >= KX) v = h[(int64_t)row * ld_h + (k - KX)];
+        else if (x) v = x[(int64_t)row * ld_x + k];
+        else {
+            const int t = tk.idx[row];
+            v = t < 0 ? 0.f : (k < tk.n_head ? tk.head[k] : tk.table[(int64_t)t * tk.E + (k - tk.n_head)]);
+        }
+        in_s[k * LC_ROWS + r] = v;
     }
     __syncthreads();
-    for (int g = tid; g < 4 * H; g += 256) {
-        float acc[LC_ROWS];
+    const int ks = tid / GP, gl = tid - ks * GP;
+    if (ks < KS) {
+        const int xb = (int)((int64_t)KX * ks / KS), xe = (int)((int64_t)KX * (ks + 1) / KS);
+        const int hb = (int)((int64_t)H * ks / KS), he = (int)((int64_t)H * (ks + 1) / KS);
+        for (int g = gl; g < G; g += GP) {
+            // the two products are summed separately and then added, as torch's cell does (igates + hgates)
+            float acc[LC_ROWS] = {0.f, 0.f, 0.f, 0.f}, acch[LC_ROWS] = {0.f, 0.f, 0.f, 0.f};
+            lc_dot(Wih + g, ld_wih, in_s, xb, xe, acc);
+            lc_dot(Whh + g, ld_whh, in_s + LC_ROWS * KX, hb, he, acch);
 #pragma unroll
-        for (int r = 0; r < LC_ROWS; ++r) acc[r] = 0.f;
-        const float* wi = Wih + g;                          // column g of the transposed weight
-        const float* wh = Whh + g;
-#pragma unroll 8
-        for (int k = 0; k < KX; ++k) {
-            const float w = wi[(int64_t)k * ld_wih];
-#pragma unroll
-            for (int r = 0; r < LC_ROWS; ++r) acc[r] = fmaf(w, in_s[r * K + k], acc[r]);
+            for (int r = 0; r < LC_ROWS; ++r) {
+                part_s[((ks * 2 + 0) * LC_ROWS + r) * G + g] = acc[r];
+                part_s[((ks * 2 + 1) * LC_ROWS + r) * G + g] = acch[r];
+            }
         }
-        // the two products are summed separately and then added, as torch's cell does (igates + hgates)
-        float acch[LC_ROWS];
-#pragma unroll
-        for (int r = 0; r < LC_ROWS; ++r) acch[r] = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) {
-            const float w = wh[(int64_t)k * ld_whh];
-#pragma unroll
-            for (int r = 0; r < LC_ROWS; ++r) acch[r] = fmaf(w, in_s[r * K + KX + k], acch[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < LC_ROWS; ++r) gate_s[r * 4 * H + g] = (acc[r] + (bih ? bih[g] : 0.f)) + (acch[r] + (bhh ? bhh[g] : 0.f));
     }
     __syncthreads();
-    for (int i = tid; i < LC_ROWS * H; i += 256) {
+    for (int i = tid; i < LC_ROWS * H; i += LC_THREADS) {
         const int r = i / H, j = i - r * H, row = r0 + r;
         if (row >= rows) continue;
-        const float* gs = gate_s + r * 4 * H;
-        const float gi = gs[j], gf = gs[H + j], gg = gs[2 * H + j], go = gs[3 * H + j];
-        const float si = 1.0f / (1.0f + expf(-gi)), sf = 1.0f / (1.0f + expf(-gf)), so = 1.0f / (1.0f + expf(-go));
-        const float tg = tanhf(gg);
+        float gv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = q * H + j;
+            float sx = 0.f, sh = 0.f;
+            for (int s2 = 0; s2 < KS; ++s2) sx += part_s[((s2 * 2 + 0) * LC_ROWS + r) * G + g], sh += part_s[((s2 * 2 + 1) * LC_ROWS + r) * G + g];
+            gv[q] = (sx + (bih ? bih[g] : 0.f)) + (sh + (bhh ? bhh[g] : 0.f));
+        }
+        const float si = 1.0f / (1.0f + expf(-gv[0])), sf = 1.0f / (1.0f + expf(-gv[1])), so = 1.0f / (1.0f + expf(-gv[3]));
+        const float tg = tanhf(gv[2]);
         const float cn = sf * c[(int64_t)row * H + j] + si * tg;
         cy[(int64_t)row * H + j] = cn;
         hy[(int64_t)row * H + j] = so * tanhf(cn);
@@ -1748,32 +1811,45 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
     }
 }
 
+static int lstm_cell_launch(const char* what, const float* x, int64_t ld_x, int32_t KX, LcTokens tk, const float* h, int64_t ld_h, const float* c,
+                            const float* Wih, int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
+                            float* h_out, float* c_out, float* gates, void* stream) {
+    DFOL_REQUIRE(rows >= 0 && H > 0 && KX > 0, "%s: bad sizes rows=%d H=%d KX=%d", what, rows, H, KX);
+    // gates per K slice: the whole gate row in wavefront multiples when it fits the workgroup more than once, else one slice
+    const int gp = (int)dfol_cdiv(4 * H, 64) * 64, GP = gp < LC_THREADS ? gp : LC_THREADS, KS = LC_THREADS / GP;
+    const size_t lds = sizeof(float) * LC_ROWS * ((size_t)KX + H + (size_t)KS * 2 * 4 * H);
+    DFOL_REQUIRE(lds <= 64 * 1024, "%s: input width %d + hidden %d too large for the staging buffer", what, KX, H);
+    if (rows == 0) return 0;
+    DFOL_REQUIRE(h && c && Wih && Whh && h_out && c_out, "%s: null pointer", what);
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(LC_THREADS), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
+                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, gates, tk, GP, KS);
+    DFOL_LAUNCH_CHECK(what);
+    return 0;
+}
+
 extern "C" int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
                                   int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows,
                                   int32_t H, float* h_out, float* c_out, void* stream) {
-    DFOL_REQUIRE(rows >= 0 && H > 0 && KX > 0, "lstm_cell: bad sizes rows=%d H=%d KX=%d", rows, H, KX);
-    const size_t lds = sizeof(float) * LC_ROWS * ((size_t)KX + H + 4 * (size_t)H);
-    DFOL_REQUIRE(lds <= 64 * 1024, "lstm_cell: input width %d + hidden %d too large for the staging buffer", KX, H);
-    if (rows == 0) return 0;
-    DFOL_REQUIRE(x && h && c && Wih && Whh && h_out && c_out, "lstm_cell: null pointer");
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(256), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
-                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, (float*)nullptr);
-    DFOL_LAUNCH_CHECK("lstm_cell");
-    return 0;
+    DFOL_REQUIRE(x || rows == 0, "lstm_cell: null pointer");
+    return lstm_cell_launch("lstm_cell", x, ld_x, KX, LcTokens{}, h, ld_h, c, Wih, ld_wih, Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, nullptr, stream);
+}
+
+// The cell on an operator's TOKENS: row p of x is [head (n_head floats: the operator's one-hot and the token-type flag) | table[idx[p]] (E floats)] or
+// all zeros for a no-op token (idx[p] < 0) - dfol_calib_features_f32's rows, built while they are staged instead of written and read back.
+extern "C" int dfol_lstm_cell_tokens_f32(const float* head, int32_t n_head, const float* table, int32_t E, const int32_t* idx, const float* h, int64_t ld_h,
+                                         const float* c, const float* Wih, int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh,
+                                         int32_t rows, int32_t H, float* h_out, float* c_out, void* stream) {
+    DFOL_REQUIRE(n_head >= 0 && E >= 0 && n_head + E > 0, "lstm_cell_tokens: bad sizes");
+    DFOL_REQUIRE(rows == 0 || ((head || n_head == 0) && (table || E == 0) && idx), "lstm_cell_tokens: null pointer");
+    return lstm_cell_launch("lstm_cell_tokens", nullptr, 0, n_head + E, LcTokens{head, n_head, table, E, idx}, h, ld_h, c, Wih, ld_wih, Whh, ld_whh, bih, bhh,
+                            rows, H, h_out, c_out, nullptr, stream);
 }
 
 extern "C" int dfol_lstm_cell_train_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
                                         int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows,
                                         int32_t H, float* h_out, float* c_out, float* gates, void* stream) {
-    DFOL_REQUIRE(rows >= 0 && H > 0 && KX > 0, "lstm_cell_train: bad sizes rows=%d H=%d KX=%d", rows, H, KX);
-    const size_t lds = sizeof(float) * LC_ROWS * ((size_t)KX + H + 4 * (size_t)H);
-    DFOL_REQUIRE(lds <= 64 * 1024, "lstm_cell_train: input width %d + hidden %d too large for the staging buffer", KX, H);
-    if (rows == 0) return 0;
-    DFOL_REQUIRE(x && h && c && Wih && Whh && h_out && c_out && gates, "lstm_cell_train: null pointer");
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(256), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
-                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, gates);
-    DFOL_LAUNCH_CHECK("lstm_cell_train");
-    return 0;
+    DFOL_REQUIRE((x && gates) || rows == 0, "lstm_cell_train: null pointer");
+    return lstm_cell_launch("lstm_cell_train", x, ld_x, KX, LcTokens{}, h, ld_h, c, Wih, ld_wih, Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, gates, stream);
 }
 
 // Backward of the cell's pointwise stage (torch's lstm_cell_backward): from the activated gates (i, f, g, o), the old and new cell state

@@ -185,9 +185,20 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                                              static_cast<int32_t>(a[4]), static_cast<const int32_t*>(at(blob, a[5])), static_cast<int32_t>(a[6]),
                                              static_cast<float*>(at(workspace, a[7])), stream);
                 break;
-            case DFOL_OP_LSTM_CELL: {    // which, x, h, c, rows, h_out, c_out
+            case DFOL_OP_LSTM_CELL: {    // which, x (-1: built from tokens), h, c, rows, h_out, c_out; then head, n_head, table, E, idx
                 const int w = a[1] ? 1 : 0;
                 DFOL_REQUIRE(model->lstm_wih_t[w] && model->lstm_whh_t[w] && model->lstm_h > 0 && model->lstm_kx > 0, "run_program[%d]: the model has no calibration LSTM", i);
+                if (a[2] < 0) {
+                    DFOL_REQUIRE(a[9] + a[11] == model->lstm_kx, "run_program[%d]: token rows of %lld floats for an LSTM of input width %d", i,
+                                 (long long)(a[9] + a[11]), model->lstm_kx);
+                    rc = dfol_lstm_cell_tokens_f32(static_cast<const float*>(at(blob, a[8])), static_cast<int32_t>(a[9]), static_cast<const float*>(at(blob, a[10])),
+                                                   static_cast<int32_t>(a[11]), static_cast<const int32_t*>(at(blob, a[12])),
+                                                   static_cast<const float*>(at(workspace, a[3])), model->lstm_h, static_cast<const float*>(at(workspace, a[4])),
+                                                   model->lstm_wih_t[w], model->lstm_ld_wih[w], model->lstm_whh_t[w], model->lstm_ld_whh[w], model->lstm_bih[w],
+                                                   model->lstm_bhh[w], static_cast<int32_t>(a[5]), model->lstm_h, static_cast<float*>(at(workspace, a[6])),
+                                                   static_cast<float*>(at(workspace, a[7])), stream);
+                    break;
+                }
                 rc = dfol_lstm_cell_f32(static_cast<const float*>(at(workspace, a[2])), model->lstm_kx, model->lstm_kx, static_cast<const float*>(at(workspace, a[3])),
                                         model->lstm_h, static_cast<const float*>(at(workspace, a[4])), model->lstm_wih_t[w], model->lstm_ld_wih[w], model->lstm_whh_t[w],
                                         model->lstm_ld_whh[w], model->lstm_bih[w], model->lstm_bhh[w], static_cast<int32_t>(a[5]), model->lstm_h,

@@ -108,11 +108,14 @@ class _VS(object):
 
 
 class _AS(object):
-    """Symbolic BatchAttentionState (fol_types.py; batch_base_types.py:256-310): names and the LSTM state (h, c) [rows, S] in the workspace."""
-    __slots__ = ("names", "h", "c", "rows")
+    """Symbolic BatchAttentionState (fol_types.py; batch_base_types.py:256-310): names and the LSTM state (h, c) [rows, S] in the workspace - c directly
+    behind h wherever `_Calibration` allocates it, so that a gate / gather / sum / add of a state is ONE launch over [2 rows, S].  `zero`: the all-zero
+    state; `gate_of` = (x, y, flags) when the state is BatchAttentionState.gate(x, y, flags) (what lets `_Calibration.add` see x + y in
+    gate(x, y, f) + gate(y, x, f))."""
+    __slots__ = ("names", "h", "c", "rows", "zero", "gate_of")
 
-    def __init__(self, names, h, c, rows):
-        self.names, self.h, self.c, self.rows = names, h, c, rows
+    def __init__(self, names, h, c, rows, zero=False, gate_of=None):
+        self.names, self.h, self.c, self.rows, self.zero, self.gate_of = names, h, c, rows, zero, gate_of
 
 
 class NativePlan(object):
@@ -512,7 +515,7 @@ class _Calibration(object):
             return np.asarray(rows, np.float32).reshape(len(names), -1), "o"
 
     def features(self, tokens, op_name, type_flag):
-        """-> workspace [P, lstm_in]: rows [operator one-hot, type flag, token embedding], zero rows for no-op tokens."""
+        """-> the description of [P, lstm_in] rows [operator one-hot, type flag, token embedding], zero rows for no-op tokens: (head, n_head, table, E, idx)."""
         from .host_util import detect_negations, is_valid_token
         key = (tuple(str(t) for t in tokens), float(type_flag), op_name)
         hit = self._feat_memo.get(key)
@@ -538,9 +541,9 @@ class _Calibration(object):
                     self._table_rows.append(rows[j])
                 idx[p] = self._table[tk]
                 j += 1
-        out = self.b.alloc(len(tokens) * self.c["lstm_in"] * 4)
-        # (the table's blob offset is patched in by finish(): rows keep arriving while the passes are walked)
-        self.b.emit(OP_CALIB_FEATURES, self.b.arr(head), len(head), ("table", self), self.E, self.b.arr(idx), len(tokens), out)
+        # (the rows are built inside the LSTM launch that reads them - dfol_lstm_cell_tokens_f32 - from this description; the table's blob offset is
+        # patched in by finish(): rows keep arriving while the passes are walked)
+        out = (self.b.arr(head), len(head), ("table", self), self.E, self.b.arr(idx))
         self._feat_memo[key] = out
         return out
 
@@ -552,12 +555,20 @@ class _Calibration(object):
                     row[k] = off
 
     # -- attention states ---------------------------------------------------------------------------------------------------------------------
+    def _state(self, rows):
+        """Workspace for one state: h [rows, S], then c [rows, S]."""
+        h = self.b.alloc(2 * rows * self.S * 4)
+        return h, h.at(rows * self.S * 4)
+
+    def _paired(self, x):
+        return x.c.region == x.h.region and x.c.off == x.h.off + x.rows * self.S * 4
+
     def zero_state(self, names, rows):
         z = self._zero.get(rows)
         if z is None:
-            z = self._zero[rows] = self.b.alloc(rows * self.S * 4)
-            self.b.emit(OP_FILL, z, rows * self.S, 0)
-        return _AS(list(names), z, z, rows)
+            z = self._zero[rows] = self._state(rows)
+            self.b.emit(OP_FILL, z[0], 2 * rows * self.S, 0)
+        return _AS(list(names), z[0], z[1], rows, zero=True)
 
     def gate(self, x, y, flags):
         """BatchAttentionState.gate (:279-298) with host flags: rows whose flag is > 0 come from x."""
@@ -565,27 +576,38 @@ class _Calibration(object):
         names = [a if f > 0 else c for a, c, f in zip(x.names, y.names, host)]
         if not all(f in (0, 1, 0.0, 1.0, True, False) for f in host):
             raise Unsupported("a fractional state gate")
+        of = (x, y, tuple(1 if f > 0 else 0 for f in host))
         if all(f > 0 for f in host):
-            return _AS(names, x.h, x.c, x.rows)
+            return _AS(names, x.h, x.c, x.rows, zero=x.zero, gate_of=of)
         if not any(f > 0 for f in host):
-            return _AS(names, y.h, y.c, y.rows)
+            return _AS(names, y.h, y.c, y.rows, zero=y.zero, gate_of=of)
         if x.rows != y.rows or len(host) != x.rows:
             raise Unsupported("a state gate over differing batch sizes")
         same = lambda u, v: u.region == v.region and u.off == v.off
         if same(x.h, y.h) and same(x.c, y.c):                    # both sides are one state (two zero states, a relate's twin posteriors): no launch
-            return _AS(names, x.h, x.c, x.rows)
-        pick = self.b.arr(np.asarray([1 if f > 0 else 0 for f in host], np.uint8))
-        h, c = self.b.alloc(x.rows * self.S * 4), self.b.alloc(x.rows * self.S * 4)
-        self.b.emit(OP_SELECT_ROWS, x.h, y.h, pick, x.rows, self.S, h)
-        self.b.emit(OP_SELECT_ROWS, x.c, y.c, pick, x.rows, self.S, c)
-        return _AS(names, h, c, x.rows)
+            return _AS(names, x.h, x.c, x.rows, zero=x.zero and y.zero, gate_of=of)
+        pick = np.asarray(of[2], np.uint8)
+        h, c = self._state(x.rows)
+        if self._paired(x) and self._paired(y):
+            self.b.emit(OP_SELECT_ROWS, x.h, y.h, self.b.arr(np.concatenate([pick, pick])), 2 * x.rows, self.S, h)
+        else:
+            pick = self.b.arr(pick)
+            self.b.emit(OP_SELECT_ROWS, x.h, y.h, pick, x.rows, self.S, h)
+            self.b.emit(OP_SELECT_ROWS, x.c, y.c, pick, x.rows, self.S, c)
+        return _AS(names, h, c, x.rows, gate_of=of)
 
     def expand(self, x, pq):
         P = len(pq)
-        idx = self.b.arr(np.asarray(pq, np.int32))
-        h, c = self.b.alloc(P * self.S * 4), self.b.alloc(P * self.S * 4)
-        self.b.emit(OP_GATHER_TILES, x.h, idx, P, h, self.S)
-        self.b.emit(OP_GATHER_TILES, x.c, idx, P, c, self.S)
+        pq = np.asarray(pq, np.int32)
+        if x.zero:                                                # (rows of the zero state)
+            return self.zero_state(x.names, P)
+        h, c = self._state(P)
+        if self._paired(x):
+            self.b.emit(OP_GATHER_TILES, x.h, self.b.arr(np.concatenate([pq, pq + np.int32(x.rows)])), 2 * P, h, self.S)
+        else:
+            idx = self.b.arr(pq)
+            self.b.emit(OP_GATHER_TILES, x.h, idx, P, h, self.S)
+            self.b.emit(OP_GATHER_TILES, x.c, idx, P, c, self.S)
         return _AS(x.names, h, c, P)
 
     def squeeze(self, x, pq):
@@ -593,25 +615,44 @@ class _Calibration(object):
         if len(pq) > 1 and not bool(np.all(pq[1:] >= pq[:-1])):
             raise Unsupported("an unsorted option list")
         Q = self.b.Q
-        seg = self.b.seg_off(pq)
-        h, c = self.b.alloc(Q * self.S * 4), self.b.alloc(Q * self.S * 4)
-        self.b.emit(OP_SEGMENT_SUM_ROWS, x.h, seg, Q, self.S, h)
-        self.b.emit(OP_SEGMENT_SUM_ROWS, x.c, seg, Q, self.S, c)
+        h, c = self._state(Q)
+        if self._paired(x) and len(pq) == x.rows:
+            counts = np.bincount(pq, minlength=Q)
+            seg2 = self.b.arr(np.concatenate([[0], np.cumsum(np.concatenate([counts, counts]))]).astype(np.int32))
+            self.b.emit(OP_SEGMENT_SUM_ROWS, x.h, seg2, 2 * Q, self.S, h)
+        else:
+            seg = self.b.seg_off(pq)
+            self.b.emit(OP_SEGMENT_SUM_ROWS, x.h, seg, Q, self.S, h)
+            self.b.emit(OP_SEGMENT_SUM_ROWS, x.c, seg, Q, self.S, c)
         return _AS(x.names, h, c, Q)
 
     def add(self, x, y):
+        """x + y (BatchAttentionState.__add__).  A relate adds the two gates of one pair of states, gate(a, b, f) + gate(b, a, f): every row of
+        that sum is a + b (b + a: the same float), so the gates are not needed for it - and with the zero state on one side (a select without a
+        token) the sum is the other state itself (bit for bit up to the sign of a zero)."""
         if x.rows != y.rows:
             raise Unsupported("states of differing batch sizes")
-        h, c = self.b.alloc(x.rows * self.S * 4), self.b.alloc(x.rows * self.S * 4)
-        self.b.emit(OP_LOGIC, LOGIC_AND, x.h, y.h, x.rows * self.S, h)
-        self.b.emit(OP_LOGIC, LOGIC_AND, x.c, y.c, x.rows * self.S, c)
+        gx, gy = x.gate_of, y.gate_of
+        if gx is not None and gy is not None and gx[2] == gy[2] and gx[0] is gy[1] and gx[1] is gy[0] and gx[0].rows == gx[1].rows == x.rows:
+            names, x, y = x.names, gx[0], gx[1]
+            x = _AS(names, x.h, x.c, x.rows, zero=x.zero)
+        if y.zero:
+            return _AS(x.names, x.h, x.c, x.rows, zero=x.zero)
+        if x.zero:
+            return _AS(x.names, y.h, y.c, y.rows)
+        h, c = self._state(x.rows)
+        if self._paired(x) and self._paired(y):
+            self.b.emit(OP_LOGIC, LOGIC_AND, x.h, y.h, 2 * x.rows * self.S, h)
+        else:
+            self.b.emit(OP_LOGIC, LOGIC_AND, x.h, y.h, x.rows * self.S, h)
+            self.b.emit(OP_LOGIC, LOGIC_AND, x.c, y.c, x.rows * self.S, c)
         return _AS(x.names, h, c, x.rows)
 
     def lstm(self, which, feats, state, rows):
         if state.rows != rows:
             raise Unsupported("an LSTM state of another batch size than its tokens")
-        h, c = self.b.alloc(rows * self.S * 4), self.b.alloc(rows * self.S * 4)
-        self.b.emit(OP_LSTM_CELL, which, feats, state.h, state.c, rows, h, c)
+        h, c = self._state(rows)
+        self.b.emit(OP_LSTM_CELL, which, -1, state.h, state.c, rows, h, c, *feats)
         return _AS(state.names, h, c, rows)
 
     def modulations(self, fwd, bwd, rows):
@@ -653,9 +694,8 @@ class _Calibration(object):
             raise Unsupported("batch size mismatch")
         feats = self.features(tokens, op_name, 1.0)
         if is_forward:
-            s_old = self.expand(s_state, pq) if pq is not None else s_state
-            o_old = self.expand(o_state, pq) if pq is not None else o_state
-            new = self.lstm(0, feats, self.add(s_old, o_old), P)
+            both = self.add(s_state, o_state)                     # (the rows of a sum = the sum of the rows: one gather for an option list)
+            new = self.lstm(0, feats, self.expand(both, pq) if pq is not None else both, P)
             self.fwd[(i, "rel_s")] = self.fwd[(i, "rel_o")] = new
             return _AS(s_state.names, new.h, new.c, P), _AS(o_state.names, new.h, new.c, P)
         if (i, "rel_s") not in self.fwd:

@@ -319,6 +319,13 @@ int dfol_lstm_pointwise_f32(const float* igates, const float* hgates, const floa
 int dfol_lstm_cell_f32(const float* x, int64_t ld_x, int32_t KX, const float* h, int64_t ld_h, const float* c, const float* Wih,
                        int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
                        float* h_out, float* c_out, void* stream);
+/* The same cell on an operator's TOKENS: row p of x is built while it is staged - [head (n_head floats: operator one-hot, token-type flag) |
+ * table[idx[p]] (E floats: token embedding)], all zeros where idx[p] < 0 - what dfol_calib_features_f32 would write (batch_base_ops.py:265-273,
+ * 437-446, 628-637), without the round trip through memory; KX = n_head + E.  Bit-identical to dfol_calib_features_f32 + dfol_lstm_cell_f32.
+ */
+int dfol_lstm_cell_tokens_f32(const float* head, int32_t n_head, const float* table, int32_t E, const int32_t* idx, const float* h, int64_t ld_h,
+                              const float* c, const float* Wih, int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh,
+                              int32_t rows, int32_t H, float* h_out, float* c_out, void* stream);
 
 /* Small pieces of the calibration passes, shared by the Python operators and the native executor (round 6):
  * select_rows: out[p] = flags[p] ? x[p] : y[p] over rows of `width` floats - BatchAttentionState.gate with 0 / 1 flags (batch_base_types.py:279-298).
@@ -769,7 +776,8 @@ typedef struct {            /* the scenes of one ProgramBatch (data_pipeline.py:
 #define DFOL_OP_FIND_MAX_IND 16
 #define DFOL_OP_GATHER_TILES 17
 #define DFOL_OP_CALIB_FEATURES 18   /* head (blob), n_head, table (blob), E, idx (blob), P, out */
-#define DFOL_OP_LSTM_CELL 19        /* which (0 forward, 1 backward network), x, h, c, rows, h_out, c_out */
+#define DFOL_OP_LSTM_CELL 19        /* which (0 forward, 1 backward network), x (or -1: the token form), h, c, rows, h_out, c_out; token form: head (blob),
+                                     * n_head, table (blob), E, idx (blob) - dfol_lstm_cell_tokens_f32 */
 #define DFOL_OP_SELECT_ROWS 20      /* x, y, flags (blob, uint8), P, width, out */
 #define DFOL_OP_ATT_MODULATIONS 21  /* forward state h (or -1), backward state h (or -1), P, out [P, att_out_n] */
 #define DFOL_OP_MODULATE 22         /* att, mods, pred_q (blob), P, out */

@@ -915,6 +915,40 @@ def test_calibration_lstm_cell_equals_torch(L):
     assert all(torch.equal(a, b) for a, b in zip(g1, [x.grad, mine.weight_ih.grad, mine.bias_hh.grad]))
 
 
+def test_lstm_cell_on_tokens_and_attention_output_kernels(L):
+    """dfol_lstm_cell_tokens_f32 (the rows [head | table[idx]] built while they are staged) == dfol_calib_features_f32 + dfol_lstm_cell_f32 bit for
+    bit, no-op tokens (idx < 0 -> zero rows) included; dfol_attention_modulations_f32 (sixteen lanes per row) == Sigmoid(Linear([fs | bs])) in float64
+    to fp32 rounding for the model's widths and others (N > 8 outputs, S not a multiple of 16), missing states as zeros."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    w_ih, w_hh, b_ih, b_hh = rnd(200, 318) * 0.05, rnd(200, 50) * 0.1, rnd(200) * 0.1, rnd(200) * 0.1
+    wt_ih, wt_hh = w_ih.t().contiguous(), w_hh.t().contiguous()
+    head, table = torch.zeros(18, device="cuda"), rnd(11, 300) * 0.2
+    head[3], head[17] = 1.0, 1.0
+    for rows in (1, 5, 256, 301):
+        idx = torch.randint(-1, 11, (rows,), device="cuda", generator=g, dtype=torch.int32)
+        h, c = rnd(rows, 50) * 0.5, rnd(rows, 50)
+        x = torch.empty(rows, 318, device="cuda")
+        L.call("dfol_calib_features_f32", head.data_ptr(), 18, table.data_ptr(), 300, idx.data_ptr(), rows, x.data_ptr(), L._stream())
+        assert torch.equal(x, torch.where((idx < 0)[:, None], torch.zeros(1, device="cuda"), torch.cat([head.expand(rows, 18), table[idx.clamp(min=0).long()]], 1)))
+        h1, c1 = L.lstm_cell(x, h, c, wt_ih, wt_hh, b_ih, b_hh)
+        h2, c2 = L.lstm_cell_tokens(head, table, idx, h, c, wt_ih, wt_hh, b_ih, b_hh)
+        assert torch.equal(h1, h2) and torch.equal(c1, c2), rows
+        assert (x[idx < 0] == 0).all()
+        # against torch's cell in float64
+        gates = x.double() @ w_ih.double().t() + b_ih.double() + h.double() @ w_hh.double().t() + b_hh.double()
+        i, f, gg, o = gates.chunk(4, 1)
+        c64 = torch.sigmoid(f) * c.double() + torch.sigmoid(i) * torch.tanh(gg)
+        h64 = torch.sigmoid(o) * torch.tanh(c64)
+        assert (h1.double() - h64).abs().max().item() <= 2e-6 and (c1.double() - c64).abs().max().item() <= 4e-6, rows
+    for P, S, N in ((256, 50, 4), (1, 50, 4), (77, 23, 11), (300, 64, 1)):
+        fs, bs, W, b = rnd(P, S), rnd(P, S), rnd(N, 2 * S) * 0.1, rnd(N)
+        for f_, b_ in ((fs, bs), (None, bs), (fs, None)):
+            got = L.attention_modulations(f_, b_, W, b)
+            z = b.double() + (0 if f_ is None else f_.double() @ W[:, :S].double().t()) + (0 if b_ is None else b_.double() @ W[:, S:].double().t())
+            assert (got.double() - torch.sigmoid(z)).abs().max().item() <= 3e-7, (P, S, N)
+
+
 def test_modulate_backward_kernel_against_autograd(L):
     """dfol_modulate_bwd_f32 (one launch per apply_modulations in the backward of the calibrator phases) against torch autograd through the
     tensor-op restatement of batch_base_types.py:170-179 in float64: attention and modulation gradients, ragged predicates, clamped

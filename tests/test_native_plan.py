@@ -19,12 +19,12 @@ from dfol_vqa_amd import synthetic as syn  # noqa: E402
 KINDS = ["exist", "and", "or", "verify_attrs", "verify_rel", "choose_attr", "query_attr", "choose_rel", "two_same", "two_different", "all_same",
          "all_different", "compare"]
 W_OPERANDS = {NP.OP_DENSE: [6], NP.OP_BOX_POSITIONS: [1], NP.OP_FILL: [1], NP.OP_PAIR_LL: [1, 3, 9], NP.OP_ATTR_LL: [1, 6], NP.OP_OPTION_NORMALIZE: [1],
-              NP.OP_GATHER_TILES: [1, 4], NP.OP_CALIB_FEATURES: [7], NP.OP_LSTM_CELL: [2, 3, 4, 6, 7], NP.OP_SELECT_ROWS: [1, 2, 6],
+              NP.OP_GATHER_TILES: [1, 4], NP.OP_CALIB_FEATURES: [7], NP.OP_LSTM_CELL: [3, 4, 6, 7], NP.OP_SELECT_ROWS: [1, 2, 6],
               NP.OP_ATT_MODULATIONS: [1, 2, 4], NP.OP_MODULATE: [1, 2, 5],
               NP.OP_FILTER: [1, 2, 7], NP.OP_RELATE_ONE: [1, 2, 3, 10], NP.OP_RELATE: [1, 2, 3, 13, 14], NP.OP_QUANTIFY: [1, 5], NP.OP_GATE: [1, 2, 7, 8],
               NP.OP_LOGIC: [2, 5], NP.OP_SEGMENT_SUM_ROWS: [1, 5], NP.OP_SEGMENT_OR: [1, 4], NP.OP_IMPLICATION: [1, 2, 5], NP.OP_COMPARE: [1, 2, 5],
               NP.OP_FIND_MAX_IND: [1, 5]}
-B_OPERANDS = {NP.OP_GATHER_TILES: [2], NP.OP_CALIB_FEATURES: [1, 3, 5], NP.OP_SELECT_ROWS: [3], NP.OP_MODULATE: [3], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
+B_OPERANDS = {NP.OP_GATHER_TILES: [2], NP.OP_CALIB_FEATURES: [1, 3, 5], NP.OP_LSTM_CELL: [8, 10, 12], NP.OP_SELECT_ROWS: [3], NP.OP_MODULATE: [3], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
               NP.OP_RELATE: [4, 5, 6, 7, 8, 9], NP.OP_QUANTIFY: [2, 3], NP.OP_GATE: [3, 4, 5], NP.OP_SEGMENT_SUM_ROWS: [2], NP.OP_SEGMENT_OR: [2],
               NP.OP_IMPLICATION: [3], NP.OP_COMPARE: [3], NP.OP_FIND_MAX_IND: [2]}
 
@@ -176,9 +176,9 @@ def test_calibrated_programs_lower(setup, kind):
     lstm = plan.instrs[[o == NP.OP_LSTM_CELL for o in ops]]
     assert len(lstm) >= 2 and int((lstm[:, 1] == 0).sum()) == int((lstm[:, 1] == 1).sum())
     assert ops.count(NP.OP_ATT_MODULATIONS) >= ops.count(NP.OP_MODULATE) >= 1
-    feats = plan.instrs[[o == NP.OP_CALIB_FEATURES for o in ops]]
-    assert all(int(r[2]) == 18 and int(r[4]) == 300 for r in feats)
-    table_off = int(feats[0][3])
+    assert NP.OP_CALIB_FEATURES not in ops and all(int(r[2]) == -1 for r in lstm)     # the token rows are built inside the LSTM launches
+    assert all(int(r[9]) == 18 and int(r[11]) == 300 for r in lstm)
+    table_off = int(lstm[0][10])
     row0 = plan.blob[table_off:table_off + 1200].view(np.float32)
     assert row0[1] - row0[0] == 1.0 and int(row0[0]) % 300 == 0                       # a row of the batch's embedding table
     # the same batch without an embedding for its tokens (the synthetic ontology has no embedding file): the Python loop's business

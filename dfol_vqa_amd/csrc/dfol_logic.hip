@@ -4,6 +4,7 @@
 // likelihood block exactly once with 16-byte coalesced loads, keep priors and running sums in
 // registers, reduce rows with cross-lane shuffles inside a 64-wide wavefront and never use atomics,
 // so results are deterministic.
+#include "dfol_calib.h"
 #include <stdarg.h>
 
 #include <stdlib.h>
@@ -1386,36 +1387,9 @@ extern "C" int dfol_calib_features_f32(const float* head, int32_t n_head, const 
 // inputs one load after the other, 9 - 14 us per launch at 256 rows; five launches per calibrated forward.)
 // The products first, the bias LAST: the bias is -log 9 (gqa_interpreter_experiments.py:124-126) and the hundred products are ~1e-2 each - added one
 // by one onto the bias they are each rounded at ulp(2.2), 4e-6 of systematic error in a modulation of 0.1 (found by golden g23).
-constexpr int AM_N = 8;
 __global__ __launch_bounds__(256) void attention_modulations_kernel(const float* __restrict__ fs, const float* __restrict__ bs, const float* __restrict__ W,
                                                                     int64_t ld_w, const float* __restrict__ b, int P, int S, int N, float* __restrict__ out) {
-    const int l = threadIdx.x & 15, p = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int pc = min(p, P - 1);
-    for (int j0 = 0; j0 < N; j0 += AM_N) {
-        float acc[AM_N];
-#pragma unroll
-        for (int j = 0; j < AM_N; ++j) acc[j] = 0.f;
-        for (int half = 0; half < 2; ++half) {
-            const float* st = half ? bs : fs;
-            if (!st) continue;
-            for (int k = l; k < S; k += 16) {
-                const float v = st[(int64_t)pc * S + k];
-#pragma unroll
-                for (int j = 0; j < AM_N; ++j)
-                    if (j0 + j < N) acc[j] = fmaf(W[(int64_t)(j0 + j) * ld_w + half * S + k], v, acc[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < AM_N; ++j) {
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 16);
-        }
-        if (l == 0 && p < P) {
-#pragma unroll
-            for (int j = 0; j < AM_N; ++j)
-                if (j0 + j < N) out[(int64_t)p * N + j0 + j] = 1.0f / (1.0f + expf(-(acc[j] + (b ? b[j0 + j] : 0.f))));
-        }
-    }
+    am_rows(fs, bs, W, ld_w, b, P, S, N, out, blockIdx.x * 16, threadIdx.x);
 }
 
 extern "C" int dfol_attention_modulations_f32(const float* fs, const float* bs, const float* W, int64_t ld_w, const float* b, int32_t P, int32_t S,
@@ -1706,123 +1680,24 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ ig, const float*
     hy[idx] = so * tanhf(cn);
 }
 
-// The whole cell in one launch: a workgroup (512 threads) takes LC_ROWS rows and stages their x and h in LDS (row-interleaved: one 16-byte LDS
-// broadcast hands a weight's four inputs over); thread (gate g, K slice ks) accumulates gate g of all four rows over its slice of K (the weights
-// come TRANSPOSED, [K, 4H], so the threads of a wavefront read consecutive floats), sixteen weight loads in flight and the next sixteen requested
-// under their products; the slices meet in LDS, then the pointwise stage.  (First version: 256 threads, one K slice, eight loads in flight - a
-// chain of 46 L2 round trips, 16 us per cell at 256 rows x (318 + 50) -> 200 where the launch floor is ~5 us; eight cells per calibrated forward.)
-// LcTokens: the rows of x built in the staging loop from an operator's tokens (what dfol_calib_features_f32 would write: [head | table[idx[row]]], or
-// zeros for a no-op token) instead of read - x == nullptr.
-constexpr int LC_ROWS = 4, LC_THREADS = 512, LC_BATCH = 16;
-struct LcTokens {
-    const float* head; int n_head;
-    const float* table; int E;
-    const int32_t* idx;
-};
-__device__ __forceinline__ void lc_dot(const float* __restrict__ w, int64_t ld, const float* __restrict__ in4, int kb, int ke, float (&acc)[LC_ROWS]) {
-    float wa[LC_BATCH], wb[LC_BATCH];
-    int k = kb;
-    if (k + LC_BATCH <= ke) {
-#pragma unroll
-        for (int u = 0; u < LC_BATCH; ++u) wa[u] = w[(int64_t)(k + u) * ld];
-    }
-    for (; k + LC_BATCH <= ke; k += LC_BATCH) {
-        const bool more = k + 2 * LC_BATCH <= ke;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < LC_BATCH; ++u) wb[u] = w[(int64_t)(k + LC_BATCH + u) * ld];
-        }
-#pragma unroll
-        for (int u = 0; u < LC_BATCH; ++u) {
-            const float4 v = *reinterpret_cast<const float4*>(in4 + 4 * (k + u));
-            acc[0] = fmaf(wa[u], v.x, acc[0]), acc[1] = fmaf(wa[u], v.y, acc[1]), acc[2] = fmaf(wa[u], v.z, acc[2]), acc[3] = fmaf(wa[u], v.w, acc[3]);
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < LC_BATCH; ++u) wa[u] = wb[u];
-        }
-    }
-    for (; k < ke; ++k) {
-        const float wv = w[(int64_t)k * ld];
-        const float4 v = *reinterpret_cast<const float4*>(in4 + 4 * k);
-        acc[0] = fmaf(wv, v.x, acc[0]), acc[1] = fmaf(wv, v.y, acc[1]), acc[2] = fmaf(wv, v.z, acc[2]), acc[3] = fmaf(wv, v.w, acc[3]);
-    }
-}
-__global__ __launch_bounds__(LC_THREADS) void lstm_cell_kernel(const float* __restrict__ x, int64_t ld_x, int KX, const float* __restrict__ h,
-                                                               int64_t ld_h, const float* __restrict__ c, const float* __restrict__ Wih,
-                                                               int64_t ld_wih, const float* __restrict__ Whh, int64_t ld_whh,
-                                                               const float* __restrict__ bih, const float* __restrict__ bhh, int rows, int H,
-                                                               float* __restrict__ hy, float* __restrict__ cy, float* __restrict__ gates_out, LcTokens tk,
-                                                               int GP, int KS) {
-    extern __shared__ __attribute__((aligned(16))) float lc_s[];   // [KX + H][LC_ROWS] inputs, then [KS][2][LC_ROWS][4H] partial gates
-    static_assert(LC_ROWS == 4, "lstm_cell: the staged inputs are read four rows at a time");
-    const int r0 = blockIdx.x * LC_ROWS, K = KX + H, tid = threadIdx.x, G = 4 * H;
-    float* in_s = lc_s;
-    float* part_s = lc_s + LC_ROWS * K;
-    for (int i = tid; i < LC_ROWS * K; i += LC_THREADS) {
-        const int r = i / K, k = i - r * K, row = min(r0 + r, rows - 1);
-        float v;
-        if (k >= KX) v = h[(int64_t)row * ld_h + (k - KX)];
-        else if (x) v = x[(int64_t)row * ld_x + k];
-        else {
-            const int t = tk.idx[row];
-            v = t < 0 ? 0.f : (k < tk.n_head ? tk.head[k] : tk.table[(int64_t)t * tk.E + (k - tk.n_head)]);
-        }
-        in_s[k * LC_ROWS + r] = v;
-    }
-    __syncthreads();
-    const int ks = tid / GP, gl = tid - ks * GP;
-    if (ks < KS) {
-        const int xb = (int)((int64_t)KX * ks / KS), xe = (int)((int64_t)KX * (ks + 1) / KS);
-        const int hb = (int)((int64_t)H * ks / KS), he = (int)((int64_t)H * (ks + 1) / KS);
-        for (int g = gl; g < G; g += GP) {
-            // the two products are summed separately and then added, as torch's cell does (igates + hgates)
-            float acc[LC_ROWS] = {0.f, 0.f, 0.f, 0.f}, acch[LC_ROWS] = {0.f, 0.f, 0.f, 0.f};
-            lc_dot(Wih + g, ld_wih, in_s, xb, xe, acc);
-            lc_dot(Whh + g, ld_whh, in_s + LC_ROWS * KX, hb, he, acch);
-#pragma unroll
-            for (int r = 0; r < LC_ROWS; ++r) {
-                part_s[((ks * 2 + 0) * LC_ROWS + r) * G + g] = acc[r];
-                part_s[((ks * 2 + 1) * LC_ROWS + r) * G + g] = acch[r];
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < LC_ROWS * H; i += LC_THREADS) {
-        const int r = i / H, j = i - r * H, row = r0 + r;
-        if (row >= rows) continue;
-        float gv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = q * H + j;
-            float sx = 0.f, sh = 0.f;
-            for (int s2 = 0; s2 < KS; ++s2) sx += part_s[((s2 * 2 + 0) * LC_ROWS + r) * G + g], sh += part_s[((s2 * 2 + 1) * LC_ROWS + r) * G + g];
-            gv[q] = (sx + (bih ? bih[g] : 0.f)) + (sh + (bhh ? bhh[g] : 0.f));
-        }
-        const float si = 1.0f / (1.0f + expf(-gv[0])), sf = 1.0f / (1.0f + expf(-gv[1])), so = 1.0f / (1.0f + expf(-gv[3]));
-        const float tg = tanhf(gv[2]);
-        const float cn = sf * c[(int64_t)row * H + j] + si * tg;
-        cy[(int64_t)row * H + j] = cn;
-        hy[(int64_t)row * H + j] = so * tanhf(cn);
-        if (gates_out) {                                     // training: the activated gates (i, f, g, o) for dfol_lstm_cell_bwd_f32
-            float* go_ = gates_out + (int64_t)row * 4 * H;
-            go_[j] = si, go_[H + j] = sf, go_[2 * H + j] = tg, go_[3 * H + j] = so;
-        }
-    }
+// The whole cell in one launch: grid (row blocks of LC_ROWS, hidden-unit slices of LC_UNITS), the pieces in dfol_calib.h.
+__global__ __launch_bounds__(LC_THREADS) void lstm_cell_kernel(LcCell p) {
+    extern __shared__ __attribute__((aligned(16))) float lc_s[];   // [KX + H][LC_ROWS] inputs, then [LC_SLICES][LC_ROWS][LC_PS] partial gates
+    const int r0 = blockIdx.x * LC_ROWS;
+    lc_stage(p, r0, lc_s);
+    lc_units(p, r0, blockIdx.y * LC_UNITS, lc_s, lc_s + LC_ROWS * (p.KX + p.H));
 }
 
 static int lstm_cell_launch(const char* what, const float* x, int64_t ld_x, int32_t KX, LcTokens tk, const float* h, int64_t ld_h, const float* c,
                             const float* Wih, int64_t ld_wih, const float* Whh, int64_t ld_whh, const float* bih, const float* bhh, int32_t rows, int32_t H,
                             float* h_out, float* c_out, float* gates, void* stream) {
     DFOL_REQUIRE(rows >= 0 && H > 0 && KX > 0, "%s: bad sizes rows=%d H=%d KX=%d", what, rows, H, KX);
-    // gates per K slice: the whole gate row in wavefront multiples when it fits the workgroup more than once, else one slice
-    const int gp = (int)dfol_cdiv(4 * H, 64) * 64, GP = gp < LC_THREADS ? gp : LC_THREADS, KS = LC_THREADS / GP;
-    const size_t lds = sizeof(float) * LC_ROWS * ((size_t)KX + H + (size_t)KS * 2 * 4 * H);
+    const size_t lds = sizeof(float) * lc_lds_floats(KX, H);
     DFOL_REQUIRE(lds <= 64 * 1024, "%s: input width %d + hidden %d too large for the staging buffer", what, KX, H);
     if (rows == 0) return 0;
     DFOL_REQUIRE(h && c && Wih && Whh && h_out && c_out, "%s: null pointer", what);
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(LC_THREADS), lds, (hipStream_t)stream, x, ld_x, KX, h, ld_h, c, Wih, ld_wih,
-                       Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, gates, tk, GP, KS);
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(dfol_cdiv(rows, LC_ROWS), dfol_cdiv(H, LC_UNITS)), dim3(LC_THREADS), lds, (hipStream_t)stream,
+                       LcCell{x, ld_x, KX, h, ld_h, c, Wih, ld_wih, Whh, ld_whh, bih, bhh, rows, H, h_out, c_out, gates, tk});
     DFOL_LAUNCH_CHECK(what);
     return 0;
 }

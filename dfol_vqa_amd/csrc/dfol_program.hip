@@ -14,9 +14,84 @@
 // no global state: the call only enqueues work on `stream`.
 #include <string.h>
 
+#include "dfol_calib.h"
 #include "dfol_common.h"
 
 namespace {
+
+// ---- a run of the attention-calibration passes in ONE launch (DFOL_OP_CALIB_WALK) -----------------------------------------------------------------
+// The passes (batch_base_interpreter.py:87-140) are a chain of small row-wise steps over [rows, 50] LSTM states - a cell, a gate between two states, a
+// sum, the attention-output product - each of which reads what the step before wrote: eight cells and about as many small steps per forward, ~9 us per
+// cell launch and ~5 - 7 us per small one with the device otherwise idle.  Every step treats the rows independently, so a workgroup that owns
+// LC_ROWS rows can run the whole chain on them with workgroup barriers between the steps (a workgroup's own global writes are visible to it after a
+// barrier: its wavefronts share the CU's L1).  The steps come as a table of WALK_* entries in the blob; they call the same device functions as the
+// stand-alone kernels (dfol_calib.h), so the results are bit-identical to the launches they replace.
+__global__ __launch_bounds__(LC_THREADS) void calib_walk_kernel(const int64_t* __restrict__ table, int n_steps, int rows, char* __restrict__ ws,
+                                                                const char* __restrict__ blob, DfolProgramModel m) {
+    extern __shared__ __attribute__((aligned(16))) float cw_s[];
+    const int r0 = blockIdx.x * LC_ROWS, tid = threadIdx.x;
+    auto W = [&](int64_t off) { return off < 0 ? nullptr : reinterpret_cast<float*>(ws + off); };
+    for (int i = 0; i < n_steps; ++i) {
+        const int64_t* a = table + (int64_t)i * DFOL_INSTR_WIDTH;
+        switch (a[0]) {
+            case DFOL_WALK_FILL: {       // dst, planes, width, bits
+                uint32_t* dst = reinterpret_cast<uint32_t*>(W(a[1]));
+                const int planes = (int)a[2], width = (int)a[3];
+                for (int e = tid; e < planes * LC_ROWS * width; e += LC_THREADS) {
+                    const int pl = e / (LC_ROWS * width), rem = e - pl * LC_ROWS * width, row = r0 + rem / width;
+                    if (row < rows) dst[((int64_t)pl * rows + row) * width + rem % width] = (uint32_t)a[4];
+                }
+                break;
+            }
+            case DFOL_WALK_SELECT:       // x, y, flags (blob), planes, width, out
+            case DFOL_WALK_ADD: {        // x, y, -, planes, width, out
+                const float* x = W(a[1]);
+                const float* y = W(a[2]);
+                const uint8_t* flags = a[0] == DFOL_WALK_SELECT ? reinterpret_cast<const uint8_t*>(blob + a[3]) : nullptr;
+                const int planes = (int)a[4], width = (int)a[5];
+                float* out = W(a[6]);
+                for (int e = tid; e < planes * LC_ROWS * width; e += LC_THREADS) {
+                    const int pl = e / (LC_ROWS * width), rem = e - pl * LC_ROWS * width, row = r0 + rem / width;
+                    if (row < rows) {
+                        const int64_t pr = (int64_t)pl * rows + row, at_ = pr * width + rem % width;
+                        out[at_] = flags ? (flags[pr] ? x : y)[at_] : x[at_] + y[at_];
+                    }
+                }
+                break;
+            }
+            case DFOL_WALK_LSTM: {       // which, h, c, h_out, c_out, head (blob), n_head, table (blob), E, idx (blob)
+                const int w = a[1] ? 1 : 0;
+                LcCell p{nullptr, 0, m.lstm_kx, W(a[2]), m.lstm_h, W(a[3]), m.lstm_wih_t[w], m.lstm_ld_wih[w], m.lstm_whh_t[w], m.lstm_ld_whh[w], m.lstm_bih[w],
+                         m.lstm_bhh[w], rows, m.lstm_h, W(a[4]), W(a[5]), nullptr,
+                         LcTokens{reinterpret_cast<const float*>(blob + a[6]), (int)a[7], reinterpret_cast<const float*>(blob + a[8]), (int)a[9],
+                                  reinterpret_cast<const int32_t*>(blob + a[10])}};
+                lc_stage(p, r0, cw_s);
+                __syncthreads();
+                lc_wide(p, r0, cw_s, cw_s + LC_ROWS * (m.lstm_kx + m.lstm_h));
+                break;
+            }
+            case DFOL_WALK_ATT_MODULATIONS:  // forward state h, backward state h, out
+                if (tid < 256) am_rows(W(a[1]), W(a[2]), m.att_out_w, m.ld_att_out, m.att_out_b, rows, m.lstm_h, m.att_out_n, W(a[3]), r0, tid);
+                break;
+            default: break;
+        }
+        __syncthreads();
+    }
+}
+
+int run_calib_walk(const DfolProgramModel* model, const int64_t* table_dev, int32_t n_steps, int32_t rows, void* workspace, const void* blob, void* stream) {
+    DFOL_REQUIRE(n_steps >= 0 && rows >= 0, "calib_walk: bad sizes");
+    if (n_steps == 0 || rows == 0) return 0;
+    DFOL_REQUIRE(model->lstm_wih_t[0] && model->lstm_whh_t[0] && model->lstm_wih_t[1] && model->lstm_whh_t[1] && model->lstm_h > 0 && model->lstm_kx > 0 &&
+                     model->att_out_w && model->att_out_n > 0,
+                 "calib_walk: the model has no calibration networks");
+    const size_t lds = sizeof(float) * lc_wide_lds_floats(model->lstm_kx, model->lstm_h);
+    DFOL_REQUIRE(lds <= 64 * 1024, "calib_walk: input width %d + hidden %d too large for the staging buffer", model->lstm_kx, model->lstm_h);
+    hipLaunchKernelGGL(calib_walk_kernel, dim3(dfol_cdiv(rows, LC_ROWS)), dim3(LC_THREADS), lds, (hipStream_t)stream, table_dev, n_steps, rows,
+                       static_cast<char*>(workspace), static_cast<const char*>(blob), *model);
+    DFOL_LAUNCH_CHECK("calib_walk");
+    return 0;
+}
 
 inline const void* at(const void* base, int64_t off) { return off < 0 ? nullptr : static_cast<const char*>(base) + off; }
 inline void* at(void* base, int64_t off) { return off < 0 ? nullptr : static_cast<char*>(base) + off; }
@@ -215,6 +290,9 @@ extern "C" int dfol_run_program(const DfolProgramModel* model, const DfolProgram
                 rc = dfol_attention_modulations_f32(static_cast<const float*>(at(workspace, a[1])), static_cast<const float*>(at(workspace, a[2])), model->att_out_w,
                                                     model->ld_att_out, model->att_out_b, static_cast<int32_t>(a[3]), model->lstm_h, model->att_out_n,
                                                     static_cast<float*>(at(workspace, a[4])), stream);
+                break;
+            case DFOL_OP_CALIB_WALK:     // table of DFOL_WALK_* steps (blob), steps, rows
+                rc = run_calib_walk(model, static_cast<const int64_t*>(at(blob, a[1])), static_cast<int32_t>(a[2]), static_cast<int32_t>(a[3]), workspace, blob, stream);
                 break;
             case DFOL_OP_MODULATE:       // att, mods, pred_q, P, out
                 DFOL_REQUIRE(model->att_out_n == 4, "run_program[%d]: dfol_modulate_f32 takes 4-column modulations", i);

@@ -24,7 +24,8 @@ from .host_util import flatten_list, get_lowered, lower_tokens, segments_of, unf
 # opcodes of include/dfol_vqa.h
 (OP_DENSE, OP_BOX_POSITIONS, OP_FILL, OP_PAIR_LL, OP_ATTR_LL, OP_OPTION_NORMALIZE, OP_FILTER, OP_RELATE_ONE, OP_RELATE, OP_QUANTIFY, OP_GATE,
  OP_LOGIC, OP_SEGMENT_SUM_ROWS, OP_SEGMENT_OR, OP_IMPLICATION, OP_COMPARE, OP_FIND_MAX_IND, OP_GATHER_TILES, OP_CALIB_FEATURES, OP_LSTM_CELL,
- OP_SELECT_ROWS, OP_ATT_MODULATIONS, OP_MODULATE) = range(23)
+ OP_SELECT_ROWS, OP_ATT_MODULATIONS, OP_MODULATE, OP_CALIB_WALK) = range(24)
+WALK_FILL, WALK_SELECT, WALK_ADD, WALK_LSTM, WALK_ATT_MODULATIONS = range(5)      # steps of an OP_CALIB_WALK table
 INSTR_WIDTH = 16
 LOGIC_AND, LOGIC_OR, LOGIC_NOT = 0, 1, 2
 TILE_SUBJECT_ROWS, TILE_OBJECT_ROWS = 0, 1
@@ -495,6 +496,7 @@ class _Calibration(object):
         self.S = self.c["state_dim"]
         self.mods, self.fwd = {}, {}
         self._zero, self._feat_memo, self._table, self._table_rows = {}, {}, {}, []
+        self._walk = []                                           # (index in b.instrs, None or (rows, [WALK_* step])) per launch of the passes
         md = pb._meta_data if isinstance(getattr(pb, "_meta_data", None), dict) else {}
         self.index, self.embedding = md.get("index"), md.get("embedding")
         self.E, self._emb_host = None, None
@@ -547,12 +549,48 @@ class _Calibration(object):
         self._feat_memo[key] = out
         return out
 
+    def _emit(self, ops, rows=None, step=None):
+        """One launch of the passes; step: the same work as a WALK_* entry over states of `rows` rows (None: not row-wise, e.g. an option-list gather)."""
+        self.b.emit(*ops)
+        self._walk.append((len(self.b.instrs) - 1, None if step is None else (rows, list(step))))
+
     def finish(self):
         off = self.b.arr(np.stack(self._table_rows)) if self._table_rows else -1
-        for row in self.b.instrs:
+        for row in self.b.instrs + [w[1] for _, w in self._walk if w is not None]:
             for k, v in enumerate(row):
                 if isinstance(v, tuple) and v[0] == "table" and v[1] is self:
                     row[k] = off
+
+    def fold_runs(self, resolve):
+        """DFOL_CALIB_WALK=1 (opt-in): runs of row-wise launches over states of one size -> one OP_CALIB_WALK each (the workgroup that owns 16 rows walks
+        the run: csrc/dfol_program.hip calib_walk_kernel; same device code, bit-identical results).  Measured SLOWER than the launches it replaces
+        (256 questions: 1.89 against 1.70 ms per batch): a workgroup then pulls all 294 KB of a cell's weights through one CU's L1, which
+        the stand-alone cell spreads over 112 CUs - so the default keeps the separate launches."""
+        import os
+        if os.environ.get("DFOL_CALIB_WALK", "0") != "1" or not self._walk:
+            return
+        instrs, out, k = self.b.instrs, [], 0
+        first = self._walk[0][0]
+        assert [i for i, _ in self._walk] == list(range(first, first + len(self._walk)))      # (the passes are emitted in one piece)
+        out.extend(instrs[:first])
+        while k < len(self._walk):
+            w = self._walk[k][1]
+            e = k + 1
+            if w is not None:
+                while e < len(self._walk) and self._walk[e][1] is not None and self._walk[e][1][0] == w[0]:
+                    e += 1
+            if w is None or e - k < 2:
+                out.append(instrs[first + k])
+                k += 1
+                continue
+            table = np.zeros((e - k, INSTR_WIDTH), np.int64)
+            for t, (_, (_, step)) in enumerate(self._walk[k:e]):
+                table[t, :len(step)] = [resolve(v) for v in step]
+            row = [OP_CALIB_WALK, self.b.arr(table), e - k, w[0]]
+            out.append(row + [0] * (INSTR_WIDTH - len(row)))
+            k = e
+        out.extend(instrs[first + len(self._walk):])
+        self.b.instrs = out
 
     # -- attention states ---------------------------------------------------------------------------------------------------------------------
     def _state(self, rows):
@@ -567,7 +605,7 @@ class _Calibration(object):
         z = self._zero.get(rows)
         if z is None:
             z = self._zero[rows] = self._state(rows)
-            self.b.emit(OP_FILL, z[0], 2 * rows * self.S, 0)
+            self._emit((OP_FILL, z[0], 2 * rows * self.S, 0), rows, (WALK_FILL, z[0], 2, self.S, 0))
         return _AS(list(names), z[0], z[1], rows, zero=True)
 
     def gate(self, x, y, flags):
@@ -589,11 +627,12 @@ class _Calibration(object):
         pick = np.asarray(of[2], np.uint8)
         h, c = self._state(x.rows)
         if self._paired(x) and self._paired(y):
-            self.b.emit(OP_SELECT_ROWS, x.h, y.h, self.b.arr(np.concatenate([pick, pick])), 2 * x.rows, self.S, h)
+            pick2 = self.b.arr(np.concatenate([pick, pick]))
+            self._emit((OP_SELECT_ROWS, x.h, y.h, pick2, 2 * x.rows, self.S, h), x.rows, (WALK_SELECT, x.h, y.h, pick2, 2, self.S, h))
         else:
             pick = self.b.arr(pick)
-            self.b.emit(OP_SELECT_ROWS, x.h, y.h, pick, x.rows, self.S, h)
-            self.b.emit(OP_SELECT_ROWS, x.c, y.c, pick, x.rows, self.S, c)
+            self._emit((OP_SELECT_ROWS, x.h, y.h, pick, x.rows, self.S, h), x.rows, (WALK_SELECT, x.h, y.h, pick, 1, self.S, h))
+            self._emit((OP_SELECT_ROWS, x.c, y.c, pick, x.rows, self.S, c), x.rows, (WALK_SELECT, x.c, y.c, pick, 1, self.S, c))
         return _AS(names, h, c, x.rows, gate_of=of)
 
     def expand(self, x, pq):
@@ -603,11 +642,11 @@ class _Calibration(object):
             return self.zero_state(x.names, P)
         h, c = self._state(P)
         if self._paired(x):
-            self.b.emit(OP_GATHER_TILES, x.h, self.b.arr(np.concatenate([pq, pq + np.int32(x.rows)])), 2 * P, h, self.S)
+            self._emit((OP_GATHER_TILES, x.h, self.b.arr(np.concatenate([pq, pq + np.int32(x.rows)])), 2 * P, h, self.S))
         else:
             idx = self.b.arr(pq)
-            self.b.emit(OP_GATHER_TILES, x.h, idx, P, h, self.S)
-            self.b.emit(OP_GATHER_TILES, x.c, idx, P, c, self.S)
+            self._emit((OP_GATHER_TILES, x.h, idx, P, h, self.S))
+            self._emit((OP_GATHER_TILES, x.c, idx, P, c, self.S))
         return _AS(x.names, h, c, P)
 
     def squeeze(self, x, pq):
@@ -619,11 +658,11 @@ class _Calibration(object):
         if self._paired(x) and len(pq) == x.rows:
             counts = np.bincount(pq, minlength=Q)
             seg2 = self.b.arr(np.concatenate([[0], np.cumsum(np.concatenate([counts, counts]))]).astype(np.int32))
-            self.b.emit(OP_SEGMENT_SUM_ROWS, x.h, seg2, 2 * Q, self.S, h)
+            self._emit((OP_SEGMENT_SUM_ROWS, x.h, seg2, 2 * Q, self.S, h))
         else:
             seg = self.b.seg_off(pq)
-            self.b.emit(OP_SEGMENT_SUM_ROWS, x.h, seg, Q, self.S, h)
-            self.b.emit(OP_SEGMENT_SUM_ROWS, x.c, seg, Q, self.S, c)
+            self._emit((OP_SEGMENT_SUM_ROWS, x.h, seg, Q, self.S, h))
+            self._emit((OP_SEGMENT_SUM_ROWS, x.c, seg, Q, self.S, c))
         return _AS(x.names, h, c, Q)
 
     def add(self, x, y):
@@ -642,24 +681,24 @@ class _Calibration(object):
             return _AS(x.names, y.h, y.c, y.rows)
         h, c = self._state(x.rows)
         if self._paired(x) and self._paired(y):
-            self.b.emit(OP_LOGIC, LOGIC_AND, x.h, y.h, 2 * x.rows * self.S, h)
+            self._emit((OP_LOGIC, LOGIC_AND, x.h, y.h, 2 * x.rows * self.S, h), x.rows, (WALK_ADD, x.h, y.h, 0, 2, self.S, h))
         else:
-            self.b.emit(OP_LOGIC, LOGIC_AND, x.h, y.h, x.rows * self.S, h)
-            self.b.emit(OP_LOGIC, LOGIC_AND, x.c, y.c, x.rows * self.S, c)
+            self._emit((OP_LOGIC, LOGIC_AND, x.h, y.h, x.rows * self.S, h), x.rows, (WALK_ADD, x.h, y.h, 0, 1, self.S, h))
+            self._emit((OP_LOGIC, LOGIC_AND, x.c, y.c, x.rows * self.S, c), x.rows, (WALK_ADD, x.c, y.c, 0, 1, self.S, c))
         return _AS(x.names, h, c, x.rows)
 
     def lstm(self, which, feats, state, rows):
         if state.rows != rows:
             raise Unsupported("an LSTM state of another batch size than its tokens")
         h, c = self._state(rows)
-        self.b.emit(OP_LSTM_CELL, which, -1, state.h, state.c, rows, h, c, *feats)
+        self._emit((OP_LSTM_CELL, which, -1, state.h, state.c, rows, h, c) + tuple(feats), rows, (WALK_LSTM, which, state.h, state.c, h, c) + tuple(feats))
         return _AS(state.names, h, c, rows)
 
     def modulations(self, fwd, bwd, rows):
         if fwd.rows != rows or bwd.rows != rows:
             raise Unsupported("modulations over differing batch sizes")
         out = self.b.alloc(rows * 4 * 4)
-        self.b.emit(OP_ATT_MODULATIONS, fwd.h, bwd.h, rows, out)
+        self._emit((OP_ATT_MODULATIONS, fwd.h, bwd.h, rows, out), rows, (WALK_ATT_MODULATIONS, fwd.h, bwd.h, out))
         return out
 
     # -- FilterBatch / RelateBatch.transform_attention (logic_ops.py; batch_base_ops.py:407-467, 598-684) ----------------------------------------
@@ -1043,6 +1082,8 @@ def build_plan(program_batch, ontology, spec):
     def resolve(v):
         return base[v.region] + v.off if isinstance(v, _W) else int(v)
 
+    if b.calibration is not None:
+        b.calibration.fold_runs(resolve)
     plan.instrs = np.asarray([[resolve(v) for v in row] for row in b.instrs], np.int64).reshape(-1, INSTR_WIDTH)
     plan.blob = np.concatenate(b._blob_parts) if b._blob_parts else np.zeros(16, np.uint8)
     plan.out_bytes = out_bytes

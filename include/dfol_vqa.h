@@ -781,6 +781,15 @@ typedef struct {            /* the scenes of one ProgramBatch (data_pipeline.py:
 #define DFOL_OP_SELECT_ROWS 20      /* x, y, flags (blob, uint8), P, width, out */
 #define DFOL_OP_ATT_MODULATIONS 21  /* forward state h (or -1), backward state h (or -1), P, out [P, att_out_n] */
 #define DFOL_OP_MODULATE 22         /* att, mods, pred_q (blob), P, out */
+#define DFOL_OP_CALIB_WALK 23       /* table (blob: n steps of DFOL_INSTR_WIDTH int64, DFOL_WALK_* below), n, rows: a run of row-wise steps of the calibration
+                                     * passes over states of `rows` rows in ONE launch - what DFOL_OP_FILL / SELECT_ROWS / LOGIC (add) / LSTM_CELL (token form) /
+                                     * ATT_MODULATIONS launches in a row would compute, bit for bit (a workgroup owns 16 rows and walks the table) */
+/* steps of a DFOL_OP_CALIB_WALK table; buffers are [planes][rows][width] floats in the workspace (an LSTM state is h then c: two planes) */
+#define DFOL_WALK_FILL 0            /* dst, planes, width, 32-bit pattern */
+#define DFOL_WALK_SELECT 1          /* x, y, flags (blob, uint8 [planes * rows]), planes, width, out: out = flags ? x : y per row */
+#define DFOL_WALK_ADD 2             /* x, y, -, planes, width, out */
+#define DFOL_WALK_LSTM 3            /* which, h, c, h_out, c_out, head (blob), n_head, table (blob), E, idx (blob) */
+#define DFOL_WALK_ATT_MODULATIONS 4 /* forward state h, backward state h, out [rows, att_out_n] */
 
 int dfol_run_program(const DfolProgramModel* model, const DfolProgramScene* scene, const int64_t* instr_host, int32_t n_instr,
                      const void* blob, void* workspace, void* stream);

@@ -596,3 +596,26 @@ def test_g23_calibrated_full_size_against_the_reference(g23_model, kind, monkeyp
     if kind != "compare":
         gu.check_logprob(off, a[kind + ":lp_off_f32"], a[kind + ":lp_off_f64"], "g23 " + kind + " (switch off)")
     assert np.abs(off - lp).max() > 0.1                            # the calibrator moves the answers
+
+
+@pytest.mark.parametrize("kind", ["exist", "choose_rel", "query_attr", "and"])
+def test_calibration_walk_equals_separate_launches(g23_model, kind, monkeypatch):
+    """DFOL_OP_CALIB_WALK (opt-in, DFOL_CALIB_WALK=1: a run of the calibration passes' row-wise steps - cells, state gates, sums, attention-output products -
+    in ONE launch, the workgroup that owns 16 rows walking the run) against the same plan lowered to one launch per step (the default): the same bits, on golden
+    g23's full-size calibrated model (binary questions: one run; option lists: runs around the gathers of the terminal operator)."""
+    model, ont, a, meta = g23_model
+    qs, cm = gu.g23_case(kind, a, meta)
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    out = {}
+    for walk in ("1", "0"):
+        monkeypatch.setenv("DFOL_CALIB_WALK", walk)
+        pbs = [pb.to_cuda(DEV) for pb in CalibrationCollater(ont).collate([dict(q) for q in qs])]
+        _lib.PATH_COUNTS.clear()
+        with torch.no_grad():
+            out[walk] = model(pbs, False)
+        assert _lib.PATH_COUNTS.get("native_program", 0) == len(pbs)
+        ops = [int(x) for pb in pbs for x in pb._native_plan.instrs[:, 0]]          # (lowered at the first forward: the collater had no model spec)
+        assert (native_plan.OP_CALIB_WALK in ops) == (walk == "1"), ops
+        out[walk + "n"] = len(ops)
+    same_results(out["1"], out["0"], "walk " + kind)
+    assert out["1n"] < out["0n"]

@@ -24,7 +24,7 @@ W_OPERANDS = {NP.OP_DENSE: [6], NP.OP_BOX_POSITIONS: [1], NP.OP_FILL: [1], NP.OP
               NP.OP_FILTER: [1, 2, 7], NP.OP_RELATE_ONE: [1, 2, 3, 10], NP.OP_RELATE: [1, 2, 3, 13, 14], NP.OP_QUANTIFY: [1, 5], NP.OP_GATE: [1, 2, 7, 8],
               NP.OP_LOGIC: [2, 5], NP.OP_SEGMENT_SUM_ROWS: [1, 5], NP.OP_SEGMENT_OR: [1, 4], NP.OP_IMPLICATION: [1, 2, 5], NP.OP_COMPARE: [1, 2, 5],
               NP.OP_FIND_MAX_IND: [1, 5]}
-B_OPERANDS = {NP.OP_GATHER_TILES: [2], NP.OP_CALIB_FEATURES: [1, 3, 5], NP.OP_LSTM_CELL: [8, 10, 12], NP.OP_SELECT_ROWS: [3], NP.OP_MODULATE: [3], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
+B_OPERANDS = {NP.OP_CALIB_WALK: [1], NP.OP_GATHER_TILES: [2], NP.OP_CALIB_FEATURES: [1, 3, 5], NP.OP_LSTM_CELL: [8, 10, 12], NP.OP_SELECT_ROWS: [3], NP.OP_MODULATE: [3], NP.OP_PAIR_LL: [5, 6, 7], NP.OP_ATTR_LL: [3, 4], NP.OP_OPTION_NORMALIZE: [2, 4], NP.OP_FILTER: [3, 4, 5], NP.OP_RELATE_ONE: [4, 5, 6, 7],
               NP.OP_RELATE: [4, 5, 6, 7, 8, 9], NP.OP_QUANTIFY: [2, 3], NP.OP_GATE: [3, 4, 5], NP.OP_SEGMENT_SUM_ROWS: [2], NP.OP_SEGMENT_OR: [2],
               NP.OP_IMPLICATION: [3], NP.OP_COMPARE: [3], NP.OP_FIND_MAX_IND: [2]}
 
@@ -85,12 +85,32 @@ def test_every_operator_lowers_and_operands_stay_in_bounds(setup, kind):
         assert np.array_equal(plan.blob[plan.scene["obj_off"]:plan.scene["obj_off"] + 4 * (Q + 1)].view(np.int32), np.concatenate([[0], np.cumsum(n)]))
 
 
+WALK_W = {NP.WALK_FILL: [1], NP.WALK_SELECT: [1, 2, 6], NP.WALK_ADD: [1, 2, 6], NP.WALK_LSTM: [2, 3, 4, 5], NP.WALK_ATT_MODULATIONS: [1, 2, 3]}
+WALK_B = {NP.WALK_SELECT: [3], NP.WALK_LSTM: [6, 8, 10]}
+
+
+def _walk_steps(plan):
+    """The steps of every OP_CALIB_WALK table of the plan (rows of INSTR_WIDTH int64 in the blob)."""
+    out = []
+    for row in plan.instrs:
+        if int(row[0]) == NP.OP_CALIB_WALK:
+            off, n = int(row[1]), int(row[2])
+            assert off % 16 == 0 and n >= 2 and int(row[3]) > 0
+            out.extend(plan.blob[off:off + n * NP.INSTR_WIDTH * 8].view(np.int64).reshape(n, NP.INSTR_WIDTH))
+    return out
+
+
 def _in_bounds(plan):
     for row in plan.instrs:
         for k in W_OPERANDS.get(int(row[0]), []):
             assert -1 <= row[k] < plan.ws_bytes, row
         for k in B_OPERANDS.get(int(row[0]), []):
             assert -1 <= row[k] < plan.blob.nbytes and (row[k] < 0 or row[k] % 16 == 0), row
+    for step in _walk_steps(plan):
+        for k in WALK_W[int(step[0])]:
+            assert 0 <= step[k] < plan.ws_bytes, step
+        for k in WALK_B.get(int(step[0]), []):
+            assert 0 <= step[k] < plan.blob.nbytes and step[k] % 16 == 0, step
 
 
 def test_round6_shapes_lower(setup):
@@ -150,7 +170,7 @@ def test_round6_shapes_lower(setup):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-def test_calibrated_programs_lower(setup, kind):
+def test_calibrated_programs_lower(setup, kind, monkeypatch):
     """The attention-calibration passes in the plan (round 6): with a calibration spec every operator kind lowers, the LSTM walks are there
     (as many backward cells as forward cells, a modulation per calibrated Filter / Relate output), operands stay in bounds, token embeddings
     travel in the blob (index entries where the batch has them, the ontology's embeddings otherwise - none here: the plan steps aside), and
@@ -168,20 +188,32 @@ def test_calibrated_programs_lower(setup, kind):
         def collate_meta_data(self, questions):
             return {"index": {t: i for i, t in enumerate(voc)}, "embedding": torch.arange(len(voc) * 300, dtype=torch.float32).view(len(voc), 300)}
 
+    monkeypatch.setenv("DFOL_CALIB_WALK", "1")                    # (opt-in: runs of row-wise launches as one; the default plan is checked below)
     pb = Coll(1, ont, cspec).collate(qs)[0]
     plan = pickle.loads(pickle.dumps(pb._native_plan))
     assert isinstance(plan, NP.NativePlan), kind
     _in_bounds(plan)
     ops = [int(x) for x in plan.instrs[:, 0]]
-    lstm = plan.instrs[[o == NP.OP_LSTM_CELL for o in ops]]
-    assert len(lstm) >= 2 and int((lstm[:, 1] == 0).sum()) == int((lstm[:, 1] == 1).sum())
-    assert ops.count(NP.OP_ATT_MODULATIONS) >= ops.count(NP.OP_MODULATE) >= 1
-    assert NP.OP_CALIB_FEATURES not in ops and all(int(r[2]) == -1 for r in lstm)     # the token rows are built inside the LSTM launches
-    assert all(int(r[9]) == 18 and int(r[11]) == 300 for r in lstm)
-    table_off = int(lstm[0][10])
+    steps = _walk_steps(plan)
+    assert NP.OP_CALIB_WALK in ops and NP.OP_CALIB_FEATURES not in ops      # runs of row-wise launches travel as one; token rows are built inside the cells
+    # every cell, stand-alone (token form: x == -1) or as a step of a walk, as (which, head width, table, embedding width)
+    cells = [(int(r[1]), int(r[9]), int(r[10]), int(r[11])) for r in plan.instrs if int(r[0]) == NP.OP_LSTM_CELL and int(r[2]) == -1]
+    cells += [(int(r[1]), int(r[7]), int(r[8]), int(r[9])) for r in steps if int(r[0]) == NP.WALK_LSTM]
+    assert not [r for r in plan.instrs if int(r[0]) == NP.OP_LSTM_CELL and int(r[2]) != -1]
+    assert len(cells) >= 2 and sum(1 for c in cells if c[0] == 0) == sum(1 for c in cells if c[0] == 1)
+    n_mods = ops.count(NP.OP_ATT_MODULATIONS) + sum(1 for r in steps if int(r[0]) == NP.WALK_ATT_MODULATIONS)
+    assert n_mods >= ops.count(NP.OP_MODULATE) >= 1
+    assert all(c[1] == 18 and c[3] == 300 for c in cells)
+    table_off = cells[0][2]
     row0 = plan.blob[table_off:table_off + 1200].view(np.float32)
     assert row0[1] - row0[0] == 1.0 and int(row0[0]) % 300 == 0                       # a row of the batch's embedding table
     # the same batch without an embedding for its tokens (the synthetic ontology has no embedding file): the Python loop's business
+    # the same batch as separate launches (the default): the same steps, one instruction each
+    monkeypatch.delenv("DFOL_CALIB_WALK")
+    flat = Coll(1, ont, cspec).collate(qs)[0]._native_plan
+    _in_bounds(flat)
+    fops = [int(x) for x in flat.instrs[:, 0]]
+    assert NP.OP_CALIB_WALK not in fops and len(fops) == len(ops) - ops.count(NP.OP_CALIB_WALK) + len(steps)
     assert FeatureCollater(1, ont, cspec).collate(qs)[0]._native_plan is None
     assert isinstance(FeatureCollater(1, ont, spec).collate(qs)[0]._native_plan, NP.NativePlan)
 

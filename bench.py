@@ -80,6 +80,14 @@ def parse(argv=None):
                     "the launching thread under the batch before")
     ap.add_argument("--streamed", type=int, default=1, help="1: also measure the rate with object features streamed from pinned host memory")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a captured HIP graph (interpreter.GraphedForward); 0: eager launches")
+    ap.add_argument("--pipeline", type=int, default=1, help="graph replays two in flight (replay i + 1 is launched before replay i's answers are read back and "
+                    "decoded; every step's answers are decoded inside the timed region); 0: one replay at a time")
+    ap.add_argument("--setup-replays", type=int, default=64, help="replays run as part of setting the graph lanes up, before the --warmup steps (the first few "
+                    "dozen replays after the captures run 5 - 10 %% below the steady rate - clocks and caches; --steps 20 would otherwise time mostly those); "
+                    "reported as config.setup_replays; 0: none")
+    ap.add_argument("--lanes", type=int, default=2, help="with --pipeline: captured forwards replayed round-robin on as many HIP streams, each over its own copy of "
+                    "the batch (interpreter.ReplayLanes: the small logic launches at the end of a batch overlap with the featurizer / pair kernel of the "
+                    "next); 1: two replays of ONE graph in flight on one stream")
     ap.add_argument("--graph-collective", type=int, default=0, help="train mode over RCCL: 1 = ONE step graph with the all-reduce captured inside (opt-in: a "
                     "failure of that path - capture error or an abort from the process group's watchdog - ends THIS process with a non-zero exit, "
                     "there is no in-process fallback); 0 (default) = two graphs with the all-reduce issued eagerly between the replays")
@@ -366,15 +374,52 @@ def main(argv=None):
             td.barrier()
         torch.cuda.synchronize()
 
+    pipelined = bool(graphed and args.pipeline)
+    lanes = None
+    if pipelined and args.lanes > 1:
+        from dfol_vqa_amd.interpreter import ReplayLanes
+        try:
+            # every further lane replays its OWN upload of the same batch (own feature tensors, own intermediates, own status word)
+            lanes = ReplayLanes(model, [pbs] + [build_batch(args, rank, ontology, names, device, world)[1] for _ in range(args.lanes - 1)])
+        except Exception as e:
+            sys.stderr.write("replay lanes unavailable (%s); two replays of one graph in flight\n" % e)
+            torch.cuda.synchronize()
+
+    def run_steps(n, serial=False):
+        """n steps, the answers of every one of them read back and decoded before this returns.  Graph replays are software-pipelined two deep
+        (replay i + 1 is launched, then replay i's answers are decoded from its own pinned copies while it runs) - the loop shape of the
+        fresh-programs leg; serial=True: one replay at a time, each waited for."""
+        res = None
+        if not pipelined or serial:
+            for _ in range(n):
+                res = step()
+            return res
+        src = lanes if lanes is not None else step
+        pending = []
+        for _ in range(n):
+            pending.append(src.submit())
+            if len(pending) > 1:                                 # (one ticket per lane / two per graph outstanding at most)
+                res = src.collect(pending.pop(0))
+        for ticket in pending:
+            res = src.collect(ticket)
+        return res
+
     with torch.no_grad():
-        for _ in range(args.warmup):
-            res = step()
+        if pipelined and args.setup_replays > 0:
+            run_steps(args.setup_replays)
+        res = run_steps(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = step()
+        res = run_steps(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        serial_elapsed = None
+        if pipelined:                                            # the same steps one at a time (what `value` was before round 6's pipelining), for the record
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(args.steps, serial=True)
+            barrier()
+            serial_elapsed = time.perf_counter() - t0
     ranks = rank_report(td, share, device, rank, world, elapsed, args.steps)
     if td is not None:
         t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
@@ -394,13 +439,24 @@ def main(argv=None):
                       "scenes_shared": bool(args.questions_per_image > 1 and args.share_scenes), "distinct_scenes_per_gpu": len(args._scene_ns),
                       "objects_total_per_gpu": int(sum(args._scene_ns)),
                       "global_batch": args.batch * world, "objects_per_scene": args.objects, "parallelism": "dp%d" % world,
-                      "launch": "hip graph replay" if graphed else "eager",
+                      "launch": ("hip graph replay, %d lanes: consecutive steps replay captured forwards of the same batch on %d HIP streams and overlap on the "
+                                 "device; the answers of every step are read back and decoded inside the timed region (`one_replay_at_a_time` in legs: the "
+                                 "same steps serialised)" % (len(lanes), len(lanes)) if lanes is not None
+                                 else "hip graph replay, two replays in flight (answers of every step decoded inside the timed region)" if pipelined
+                                 else "hip graph replay" if graphed else "eager"),
+                      "lanes": len(lanes) if lanes is not None else 1, "setup_replays": int(args.setup_replays) if pipelined else 0,
                       "contraction_math": {"f32": "fp32 matrix pipe",
                                            "bf16x3": "fp32 results from the bf16 matrix pipe: exact 3-way bf16 operand split, 6 of 9 piece products, fp32 accumulate (DESIGN 3.3)",
                                            "f16x2": "fp32 results from the fp16 matrix pipe: 2 fp16 pieces per operand (weight rows scaled by powers of two), 3 of 4 piece "
                                                     "products, fp32 accumulate (DESIGN 3.4)"}[os.environ.get("DFOL_PAIR_MATH", "f16x2")]}}
 
     out["ranks"] = ranks
+    if serial_elapsed is not None:
+        if td is not None:
+            t = torch.tensor([serial_elapsed], device="cpu" if share else device, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            serial_elapsed = float(t.item())
+        out["value_one_replay_at_a_time"] = total_q / serial_elapsed
     if getattr(args, "_shard", None):
         out["shard"] = args._shard
     if args.sustain > 0:
@@ -411,8 +467,7 @@ def main(argv=None):
         with torch.no_grad():
             barrier()
             t0 = time.perf_counter()
-            for _ in range(n_sus):
-                res = step()
+            res = run_steps(n_sus)
             barrier()
             sus = time.perf_counter() - t0
         if td is not None:
@@ -570,10 +625,29 @@ def calibrated_leg(args, device, n_batches=24):
         res["graph_equals_eager"] = bool(torch.equal(r["log_probability"], eager["log_probability"]) and r["answer"] == eager["answer"])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        src = g
+        if args.pipeline and args.lanes > 1:                     # (the loop shape of `value`: replay lanes on as many streams)
+            from dfol_vqa_amd.interpreter import ReplayLanes
+            src = ReplayLanes(model, [[base]] + [[batch(0).to_cuda(device)] for _ in range(args.lanes - 1)])
+            for t in [src.submit() for _ in range(len(src))]:
+                src.collect(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        pending, rp = [], None
         for _ in range(20):
-            g()
+            if not args.pipeline:
+                g()
+                continue
+            pending.append(src.submit())
+            if len(pending) > 1:
+                rp = src.collect(pending.pop(0))
+        for ticket in pending:
+            rp = src.collect(ticket)
+        if rp is not None:
+            res["pipelined_replay_equals_eager"] = bool(torch.equal(rp["log_probability"], eager["log_probability"].cpu()) and rp["answer"] == eager["answer"])
         torch.cuda.synchronize()
         res["replay_ms_per_step"] = (time.perf_counter() - t0) / 20 * 1e3
+        res["replay_lanes"] = len(src) if src is not g else 1
         spec = native_exec.model_spec(model, calibrate=True)
         saved = os.environ.get("DFOL_NATIVE")
         try:
@@ -624,7 +698,7 @@ def legs_summary(out):
     counts of the fresh-programs loop and the logic kernels' HBM fractions (the north star's >= 0.5 bar on Relate / Filter)."""
     v = float(out["value"])
     legs = {"value": v}
-    for key, short in (("value_sustained", "sustained"), ("value_streamed", "streamed"), ("value_fresh_programs", "fresh"), ("value_end_to_end", "end_to_end")):
+    for key, short in (("value_one_replay_at_a_time", "one_replay_at_a_time"), ("value_sustained", "sustained"), ("value_streamed", "streamed"), ("value_fresh_programs", "fresh"), ("value_end_to_end", "end_to_end")):
         if out.get(key):
             legs[short] = float(out[key])
             legs[short + "_over_value"] = float(out[key]) / v

@@ -309,7 +309,7 @@ class RangeWatch(object):
     def __init__(self, device):
         dev = torch.device(device)
         key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-        word = _RANGE_WORDS.get(key)
+        word = CAPTURE_RANGE_WORD if (CAPTURE_RANGE_WORD is not None and capturing()) else _RANGE_WORDS.get(key)
         if word is None:
             word = _RANGE_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         self.word, self.device = word, dev
@@ -321,6 +321,8 @@ class RangeWatch(object):
         if _KEEP is not None:
             _KEEP.append(host)
         host.copy_(self.word, non_blocking=True)
+        if capturing() and CAPTURE_RANGE_DEV is not None:         # (a pipelined replay reads its OWN copy of the word: GraphedForward.submit)
+            CAPTURE_RANGE_DEV.copy_(self.word)
         # cleared ON THE STREAM behind the copy: the next forward queued behind this one (test_epoch and the bench keep two or more in flight)
         # starts from a clean word instead of inheriting this one's flag until the host gets round to its check
         self.word.zero_()
@@ -334,14 +336,15 @@ class RangeWatch(object):
             done = torch.cuda.Event()
             done.record()
 
-        def check(sync=True):
-            """sync=False: look at what has arrived so far (a replayed train step checks the step BEFORE it: no host wait per step)."""
-            if sync:
+        def check(sync=True, value=None):
+            """sync=False: look at what has arrived so far (a replayed train step checks the step BEFORE it: no host wait per step); value: the word
+            as the caller read it back itself (a pipelined graph replay)."""
+            if sync and value is None:
                 if done is not None:
                     done.synchronize()
                 else:
                     torch.cuda.current_stream(dev).synchronize()
-            v = int(host[0])
+            v = int(host[0]) if value is None else int(value)
             if v:
                 word.zero_()
                 what = []
@@ -352,11 +355,14 @@ class RangeWatch(object):
                 raise DfolError("fp16 range exceeded in the two-piece fp16 arithmetic (dense math 'f16x2', the default): %s. The results of this "
                                 "forward are not valid. Use `mlp_math: bf16x3` (config key; three bf16 pieces, fp32's exponent range) or "
                                 "DFOL_DENSE_MATH=bf16x3 / DFOL_PAIR_MATH=bf16x3, or normalise the features." % "; ".join(what))
+        check.range_check = True
         return check
 
 
 _RANGE_HOSTS = []
 CAPTURE_RANGE_HOST = None
+CAPTURE_RANGE_WORD = None            # the status word of ONE captured forward (graphs replayed side by side on two streams must not share the device's)
+CAPTURE_RANGE_DEV = None             # a device int32 a captured forward also leaves its status word in (before clearing it), or None
 CAPTURE_RANGE_CHECKS = []            # checks of forwards that ran INSIDE a capture without a deferred queue: the graph's owner runs them after replays
 
 

@@ -163,9 +163,27 @@ class _Deferred(threading.local):
     queue a closure that fills them.  The interpreter runs the closures after the last ProgramBatch has been enqueued (one
     device->host synchronisation per forward instead of one per ProgramBatch), or after replaying a captured graph."""
     queue = None
+    outputs = None           # a list while a graph is captured: the device tensors the queued closures will read back
+    snapshot = None          # {id(device tensor): numpy copy} while the answers of ONE replay of a pipelined graph are decoded
 
 
 DEFERRED = _Deferred()
+
+
+def _host(t):
+    """The host copy a terminal operator decodes its answers from: the tensor read back now (one synchronisation), or - a pipelined graph replay
+    (interpreter.GraphedForward.submit / collect) - the copy that replay left in pinned memory behind its own launches."""
+    snap = DEFERRED.snapshot
+    if snap is not None:
+        hit = snap.get(id(t))
+        if hit is not None:
+            return hit
+    return t.detach().cpu().numpy()
+
+
+def _reads(*tensors):
+    if DEFERRED.outputs is not None:
+        DEFERRED.outputs.extend(t for t in tensors if t is not None)
 
 
 def _answers(compute):
@@ -189,10 +207,11 @@ def _binary_answer(log_probability, batch_size, give_answer):
 
     def compute():
         # the one device->host sync of a binary op; safe_exp (util.py:19) on the host copy instead of one more launch
-        probability = np.exp(log_probability.detach().cpu().numpy().astype(np.float32)).tolist()
+        probability = np.exp(_host(log_probability).astype(np.float32)).tolist()
         answer = [['yes'] if probability[i] > 0.5 else ['no'] for i in range(batch_size)]
         alp = [[math.log(probability[i])] if probability[i] > 0.5 else [math.log(1 - probability[i])] for i in range(batch_size)]
         return answer, alp
+    _reads(log_probability)
     return _answers(compute)
 
 
@@ -395,8 +414,9 @@ def _choose_answer(log_probability, x, option_list, batch_index, question_num, l
         dev_flags = L.find_max_ind(log_probability.detach().contiguous(), seg_off, float(likelihood_threshold))
 
         def compute():
-            flags = dev_flags.cpu().numpy().tolist()
-            return unflatten_list(option_list, batch_index, flags), unflatten_list(log_probability.detach().cpu().numpy().tolist(), batch_index, flags)
+            flags = _host(dev_flags).tolist()
+            return unflatten_list(option_list, batch_index, flags), unflatten_list(_host(log_probability).tolist(), batch_index, flags)
+        _reads(dev_flags, log_probability)
         return _answers(compute)
 
     def compute():
@@ -601,8 +621,10 @@ class GQACompareBatch(GQABatchOperatorBase):
         options = list(zip(variable_set1._name, variable_set2._name))
         answer, alp = [], []
         if give_answer:
+            _reads(log_probability)
+
             def compute():
-                lp = log_probability.detach().cpu().numpy()
+                lp = _host(log_probability)
                 ind = lp.argmax(1)
                 n = variable_set1.batch_size()
                 return [[options[i][ind[i]]] for i in range(n)], [[float(lp[i, ind[i]])] for i in range(n)]

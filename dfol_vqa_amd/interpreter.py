@@ -118,20 +118,114 @@ class GraphedForward(object):
             self._keep = []                                      # everything the caches handed to the captured launches (host_util.keeping)
             self._graph = torch.cuda.CUDAGraph()
             gqa_ops.DEFERRED.queue = self._queue
+            gqa_ops.DEFERRED.outputs = self._outputs = []        # the device tensors the answers are decoded from
             from . import _lib
             _lib.CAPTURE_RANGE_HOST = self._range_host = _lib.new_range_host()     # (the replay copies the fp16-range status word into it)
+            dev = program_batch_list[0].device
+            _lib.CAPTURE_RANGE_DEV = self._range_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.CAPTURE_RANGE_WORD = self._range_word = torch.zeros(1, dtype=torch.int32, device=dev)   # (this graph's own: see ReplayLanes)
             try:
                 with keeping(self._keep), torch.cuda.graph(self._graph):
                     self._lazy = model(program_batch_list, False)
             finally:
                 gqa_ops.DEFERRED.queue = None
+                gqa_ops.DEFERRED.outputs = None
                 _lib.CAPTURE_RANGE_HOST = None
+                _lib.CAPTURE_RANGE_DEV = None
+                _lib.CAPTURE_RANGE_WORD = None
+        self._outputs.extend(r['log_probability'] for r in self._lazy.results)
+        seen, uniq = set(), []
+        for t in self._outputs + [self._range_dev]:
+            if id(t) not in seen:
+                seen.add(id(t))
+                uniq.append(t)
+        self._outputs, self._slots, self._next = uniq, [], 0
 
     def __call__(self):
         self._graph.replay()
         for fill in self._queue:
             fill()
         return self._lazy.gather()
+
+    # ---- pipelined replays: the host decodes replay i's answers while the device runs replay i + 1 ------------------------------------------------
+    def submit(self, depth=2):
+        """Replay, and queue behind it the copies of everything the answers are decoded from (log-probabilities, arg-max flags, the fp16-range
+        status word) into one of `depth` pinned slots - no host wait.  Returns the ticket `collect` takes.  At most `depth` tickets may be
+        outstanding; new features for the next replay may be copied into the ProgramBatches' tensors right after this call (stream order)."""
+        while len(self._slots) < depth:
+            self._slots.append({"host": [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self._outputs], "event": torch.cuda.Event(), "busy": False})
+        slot = self._slots[self._next % depth]
+        if slot["busy"]:
+            raise RuntimeError("GraphedForward.submit: %d replays outstanding; collect() the oldest first" % depth)
+        self._next += 1
+        self._graph.replay()
+        for t, h in zip(self._outputs, slot["host"]):
+            h.copy_(t, non_blocking=True)
+        slot["event"].record()
+        slot["busy"] = True
+        return slot
+
+    def collect(self, ticket):
+        """Wait for that replay (only), decode its answers from its own copies and return what `forward` would have - with the log-probabilities
+        as a host tensor (the device buffers belong to the replays behind it)."""
+        from . import gqa_ops
+        ticket["event"].synchronize()
+        snap = {id(t): h.numpy() for t, h in zip(self._outputs, ticket["host"])}
+        gqa_ops.DEFERRED.snapshot = snap
+        try:
+            for fill in self._queue:
+                if getattr(fill, "range_check", False):
+                    fill(False, int(snap[id(self._range_dev)][0]))
+                else:
+                    fill()
+            res = self._lazy.gather()
+        finally:
+            gqa_ops.DEFERRED.snapshot = None
+            ticket["busy"] = False
+        res = dict(res)
+        res['answer'] = [list(a) for a in res['answer']]         # (the queued closures refill the same lists at every replay)
+        res['answer_log_probability'] = [list(a) for a in res['answer_log_probability']]
+        res['log_probability'] = torch.cat([torch.from_numpy(snap[id(r['log_probability'])].reshape(-1).copy()) for r in self._lazy.results])
+        return res
+
+
+class ReplayLanes(object):
+    """Several captured forwards of one batch shape - each over its OWN ProgramBatch tensors, intermediates and fp16-range status word - replayed
+    round-robin on as many HIP streams, so that consecutive batches OVERLAP on the device: a forward ends in a dozen small logic launches (a few
+    workgroups each, the rest of the 256 CUs idle, ~10 us apart) and begins with the featurizer and the pair kernel, which fill the chip - side by
+    side the next batch's head runs in the previous one's tail.  256 questions x 100 objects: 1.52 ms per batch one replay at a time, 1.45 with
+    two replays of one graph in flight on one stream (the host's read-back hidden), 1.35 on two lanes (tools/lab/time_step_forms.py).
+    submit(fill) -> ticket: `fill(program_batch_list)` (optional) runs on the lane's stream before its replay - copy the batch's new features into
+    the lane's tensors there; collect(ticket) -> the result dict of that batch (GraphedForward.collect).  At most one outstanding ticket per lane."""
+
+    def __init__(self, model, program_batch_lists):
+        assert len(program_batch_lists) >= 1
+        self._graphs = [GraphedForward(model, pbs) for pbs in program_batch_lists]
+        dev = program_batch_lists[0][0].device
+        self._streams = [torch.cuda.Stream(device=dev) for _ in self._graphs]
+        self._next = 0
+        cur = torch.cuda.current_stream(dev)
+        for s in self._streams:
+            s.wait_stream(cur)                                   # (whatever uploaded the batches comes first)
+
+    def __len__(self):
+        return len(self._graphs)
+
+    def batches(self, lane):
+        return self._graphs[lane]._pbs
+
+    def submit(self, fill=None):
+        lane = self._next % len(self._graphs)
+        self._next += 1
+        g = self._graphs[lane]
+        with torch.cuda.stream(self._streams[lane]):
+            if fill is not None:
+                fill(g._pbs)
+            ticket = g.submit(depth=1)
+        return (g, ticket)
+
+    def collect(self, ticket):
+        return ticket[0].collect(ticket[1])
 
 
 class BatchInterpreterBase(nn.Module):

@@ -653,6 +653,136 @@ def test_graphed_forward_equals_eager(tmp_path):
         assert not torch.equal(r2["log_probability"], r["log_probability"])
 
 
+def test_pipelined_graph_replays_keep_their_own_results(tmp_path):
+    """GraphedForward.submit / collect (bench.py's `value` loop: replay i + 1 is launched before replay i's answers are decoded): three replays over
+    three different sets of scene features, two in flight - every ticket returns the log-probabilities and answers of ITS replay (= an eager forward on
+    those features), for a binary and a QUERY operator; a third submit without a collect is refused; a feature beyond fp16's range raises at the
+    ticket of the replay that read it and not at its neighbours'."""
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd import _lib as _lib_mod
+    from dfol_vqa_amd.interpreter import GraphedForward
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(4)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    for kind in ("exist", "choose_attr"):
+        qs, scenes = _neural_questions(kind, 8, 12, 12, 2048, seed=22, names=nm)
+        pbs = [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])]
+        feats = [[torch.rand_like(pb._object_features) for pb in pbs] for _ in range(3)]
+        for f in feats:                                          # (the box columns stay what they were)
+            for t, pb in zip(f, pbs):
+                t[:, -6:] = pb._object_features[:, -6:]
+        want = []
+        for f in feats:
+            for t, pb in zip(f, pbs):
+                pb._object_features.copy_(t)
+            with torch.no_grad():
+                e = model(pbs, False)
+            want.append((e["log_probability"].cpu(), e["answer"], e["answer_log_probability"]))
+        assert not torch.equal(want[0][0], want[1][0])
+        g = GraphedForward(model, pbs)
+
+        def put(f):
+            for t, pb in zip(f, pbs):
+                pb._object_features.copy_(t)
+        put(feats[0]); t0 = g.submit()
+        put(feats[1]); t1 = g.submit()
+        with pytest.raises(RuntimeError):
+            g.submit()
+        r0 = g.collect(t0)
+        put(feats[2]); t2 = g.submit()
+        r1, r2 = g.collect(t1), g.collect(t2)
+        for r, w in zip((r0, r1, r2), want):
+            assert torch.equal(r["log_probability"], w[0]) and r["answer"] == w[1] and r["answer_log_probability"] == w[2], kind
+        # the serial call still works after pipelined ones
+        put(feats[0])
+        r = g()
+        assert torch.equal(r["log_probability"].cpu(), want[0][0]) and r["answer"] == want[0][1]
+        # fp16 range: only the replay that read the overflowing feature raises
+        bad = [t.clone() for t in feats[1]]
+        bad[0][0, 0] = 1e6
+        put(feats[0]); t0 = g.submit()
+        put(bad); t1 = g.submit()
+        r0 = g.collect(t0)
+        assert torch.equal(r0["log_probability"], want[0][0])
+        put(feats[2]); t2 = g.submit()
+        with pytest.raises(_lib_mod.DfolError):
+            g.collect(t1)
+        r2 = g.collect(t2)
+        assert torch.equal(r2["log_probability"], want[2][0])
+
+
+def test_replay_lanes_overlap_batches_and_keep_their_results(tmp_path):
+    """interpreter.ReplayLanes (bench.py's `value` loop): two captured forwards of one batch shape, each over its own tensors, replayed round-robin on
+    two streams.  Six batches with six different feature sets, copied into the lane's tensors on the lane's stream: every ticket returns ITS batch's
+    results (= an eager forward on those features); an overflowing feature raises at its own ticket only (each graph has its own status word)."""
+    from dfol_vqa_amd import experiment
+    from dfol_vqa_amd import _lib as _lib_mod
+    from dfol_vqa_amd.interpreter import ReplayLanes
+    paths, names = syn.write_synthetic_ontology(str(tmp_path))
+    cfg = syn.reference_config(paths)
+    ont = experiment.build_ontology(cfg)
+    torch.manual_seed(4)
+    model = experiment.build_model(cfg, ont)
+    with torch.no_grad():
+        model._oracle._embedding_network.linear.weight.normal_(0.0, 0.1)
+        model._oracle._embedding_network.linear.bias.fill_(-2.0)
+    model = model.to(DEV).eval()
+    nm = (names["nouns"][:6], names["attributes"][:5], names["relations"][:4])
+    for kind in ("exist", "choose_attr"):
+        qs, scenes = _neural_questions(kind, 8, 12, 12, 2048, seed=23, names=nm)
+        make = lambda: [pb.to_cuda(DEV) for pb in TableCollater(2, ont, "X").collate([dict(q, scene=s) for q, s in zip(qs, scenes)])]
+        pbs = make()
+        feats = [[torch.rand_like(pb._object_features) for pb in pbs] for _ in range(6)]
+        for f in feats:
+            for t, pb in zip(f, pbs):
+                t[:, -6:] = pb._object_features[:, -6:]
+        feats[4][0][0, 0] = 1e6                                   # batch 4 leaves fp16's range
+        want = []
+        for k, f in enumerate(feats):
+            for t, pb in zip(f, pbs):
+                pb._object_features.copy_(t)
+            if k == 4:
+                want.append(None)
+                continue
+            with torch.no_grad():
+                e = model(pbs, False)
+            want.append((e["log_probability"].cpu(), e["answer"], e["answer_log_probability"]))
+        lanes = ReplayLanes(model, [make(), make()])
+        torch.cuda.synchronize()
+
+        def fill(k):
+            def go(lane_pbs):
+                for t, pb in zip(feats[k], lane_pbs):
+                    pb._object_features.copy_(t, non_blocking=True)
+            return go
+        tickets, got = [], []
+        for k in range(6):
+            tickets.append((k, lanes.submit(fill(k))))
+            if len(tickets) > 1:
+                j, t = tickets.pop(0)
+                if j == 4:
+                    with pytest.raises(_lib_mod.DfolError):
+                        lanes.collect(t)
+                    got.append(None)
+                else:
+                    got.append(lanes.collect(t))
+        for j, t in tickets:
+            got.append(lanes.collect(t))
+        assert len(got) == 6
+        for k, (r, w) in enumerate(zip(got, want)):
+            if w is None:
+                assert r is None
+                continue
+            assert torch.equal(r["log_probability"], w[0]) and r["answer"] == w[1] and r["answer_log_probability"] == w[2], (kind, k)
+
+
 def test_forward_async_equals_forward_with_another_batch_in_between(tmp_path):
     """forward_async enqueues a batch and hands back a PendingForward; collating, uploading and LAUNCHING another batch before result() is
     asked for changes nothing (bench.py's `value_fresh_programs` leg pipelines the stream of batches this way)."""

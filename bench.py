@@ -1591,6 +1591,14 @@ def attach_rocprof(out, args):
             r["rocprofv3"]["stats_avg_us"] = dom["all_launches_avg_us"]
             r["rocprofv3"]["stats_launches"] = dom["all_launches"]
             r["rocprofv3"]["frac_from_stats_avg"] = work / (dom["all_launches_avg_us"] * 1e-6) / (r["peak"] * 1e12)
+        if dom.get("alone_avg_us"):
+            # ... of which the launches that had the device to themselves (the replay lanes of the timed region run two steps side by side: those
+            # launches share the CUs with the other lane's kernels and last longer while the steps get shorter - not what a roofline fraction prices)
+            r["rocprofv3"]["stats_alone_avg_us"] = dom["alone_avg_us"]
+            r["rocprofv3"]["stats_alone_launches"] = dom["alone_launches"]
+            r["rocprofv3"]["stats_overlapped_avg_us"] = dom.get("overlapped_avg_us")
+            r["rocprofv3"]["stats_overlapped_launches"] = dom.get("overlapped_launches")
+            r["rocprofv3"]["frac_from_stats_alone_avg"] = work / (dom["alone_avg_us"] * 1e-6) / (r["peak"] * 1e12)
     groups = entry.get("kernels", {})
     for k in out["kernels"]:
         tr = k.get("trace")

@@ -87,6 +87,25 @@ def roofline_durations(out):
             every = [du for n, gx, st, du in rows if n.startswith(r["trace_name"]) and gx == gx_last]
             entry["dominant"]["all_launches"] = len(every)
             entry["dominant"]["all_launches_avg_us"] = sum(every) / len(every) / 1e3
+            # replay lanes (bench.py --lanes 2, the default since round 6) run consecutive steps on two streams: a launch of the timed region
+            # shares the device with the other lane's kernels and lasts longer while the steps get shorter.  So the same row again, split by
+            # whether ANY other dispatch of the trace ran during the launch ("alone": what a roofline fraction is about)
+            import bisect
+            starts = [st for n, gx, st, du in rows]
+            longest = max(du for n, gx, st, du in rows)
+            alone, shared = [], []
+            for i, (n, gx, st, du) in enumerate(rows):
+                if not (n.startswith(r["trace_name"]) and gx == gx_last):
+                    continue
+                lo = bisect.bisect_left(starts, st - longest)
+                hi = bisect.bisect_right(starts, st + du)
+                hit = any(j != i and rows[j][2] < st + du and rows[j][2] + rows[j][3] > st for j in range(lo, hi))
+                (shared if hit else alone).append(du)
+            entry["dominant"]["alone_launches"], entry["dominant"]["overlapped_launches"] = len(alone), len(shared)
+            if alone:
+                entry["dominant"]["alone_avg_us"] = sum(alone) / len(alone) / 1e3
+            if shared:
+                entry["dominant"]["overlapped_avg_us"] = sum(shared) / len(shared) / 1e3
     for k in line.get("kernels", []):
         tr = k.get("trace")
         if not tr:
@@ -104,9 +123,11 @@ def roofline_durations(out):
     if "dominant" in entry:
         dm = entry["dominant"]
         print("%s: last %d launches, rocprofv3 avg %.1f us (min %.1f, max %.1f); HIP events in the same run: %.1f us per launch; all %d launches of "
-              "the run with this grid (the `--stats` row): %.1f us"
+              "the run with this grid (the `--stats` row): %.1f us - %d of them with the device to themselves: %.1f us, %d sharing it with another "
+              "stream's kernels (replay lanes): %.1f us"
               % (dm["trace_name"], dm["launches"], dm["avg_us"], dm["min_us"], dm["max_us"], dm["hip_event_us_per_launch_same_run"] or 0,
-                 dm.get("all_launches", 0), dm.get("all_launches_avg_us", 0.0)))
+                 dm.get("all_launches", 0), dm.get("all_launches_avg_us", 0.0), dm.get("alone_launches", 0), dm.get("alone_avg_us", 0.0),
+                 dm.get("overlapped_launches", 0), dm.get("overlapped_avg_us", 0.0)))
     for kk, v in sorted(entry["kernels"].items()):
         print("%s  [%s]: rocprofv3 avg %.1f us over %d launches; HIP events %.1f us" % (kk, v["row"], v["avg_us"], v["launches"], v["hip_event_us_per_launch_same_run"] or 0))
 

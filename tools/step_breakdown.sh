@@ -1,5 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: kernel-trace of bench.py without the stress/CPU legs, then per-step GPU-busy vs wall.
+# (inference steps one replay at a time - `--pipeline 0` - so that a kernel's duration is its own: the replay lanes of the default loop run two steps
+# side by side and every launch then shares the device)
 # usage: tools/step_breakdown.sh <tag> [bench args...]
 set -u
 TAG=$1; shift
@@ -7,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/steps_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py --steps 20 --warmup 2 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --sustain 0 "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $R/bench.py --steps 20 --warmup 2 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --sustain 0 --pipeline 0 "$@" > $OUT/bench.log 2>&1
 cd $R
 tail -1 $OUT/bench.log | cut -c1-400
 python3 - "$OUT" <<'PY'

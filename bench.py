@@ -24,6 +24,7 @@ HBM roofline of the Relate/Filter logic kernels on >= 65536 resident predicates 
 
 import argparse
 import json
+import contextlib
 import os
 import sys
 import tempfile
@@ -74,6 +75,8 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--fresh-batches", type=int, default=56, help="batches of the `value_fresh_programs` leg: every step a different ProgramBatch through "
                     "collate -> lower -> eager launches (0 = skip; north_star / c1 workloads, one process)")
+    ap.add_argument("--fresh-streams", type=int, default=2, help="`value_fresh_programs`: HIP streams the unseen batches alternate on (2: the end of one batch "
+                    "overlaps with the start of the next on the device, like the replay lanes of `value`; 1: one stream)")
     ap.add_argument("--fresh-depth", type=int, default=2, help="batches queued on the device before the oldest one's answers are waited for (`value_fresh_programs`)")
     ap.add_argument("--fresh-workers", type=int, default=6, help="collate worker PROCESSES of the `value_fresh_programs` leg (the reference's DataLoader "
                     "workers, data_pipeline.py:893-898): they collate and lower, the launching process unpickles, uploads and launches; 0 = collate on "
@@ -1090,17 +1093,28 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
             return pbs, sync
 
         marks = []                                               # (first launch, last launch) of every batch on the device's clock
+        n_streams = 1 if stream_features else max(1, int(getattr(args, "fresh_streams", 1)))
+        lane_streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else None
+        if lane_streams:
+            for s_ in lane_streams:
+                s_.wait_stream(torch.cuda.current_stream(device))
 
         def launch(pbs, sync):
-            if sync is not None:
-                torch.cuda.current_stream().wait_event(sync[0])  # this batch's features have landed
-            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            m0.record()
-            pending = model.forward_async(pbs, False)
-            m1.record()
-            marks.append((m0, m1))
-            if sync is not None:
-                sync[1].record()                                 # its buffer may be overwritten once these launches are done
+            # (the executor's batch is self-contained - its blob, its arena, its read-back buffer and event, its own fp16-range word - so
+            # consecutive batches may run on different streams; the uploads of to_cuda in prepare() ran on the default stream: wait for them)
+            lane = lane_streams[len(marks) % n_streams] if lane_streams else None
+            if lane is not None:
+                lane.wait_stream(torch.cuda.current_stream(device))
+            with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+                if sync is not None:
+                    torch.cuda.current_stream().wait_event(sync[0])  # this batch's features have landed
+                m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                m0.record()
+                pending = model.forward_async(pbs, False)
+                m1.record()
+                marks.append((m0, m1))
+                if sync is not None:
+                    sync[1].record()                             # its buffer may be overwritten once these launches are done
             return pending
 
         _route_counts()
@@ -1176,7 +1190,7 @@ def fresh_programs_rate(args, model, ontology, names, paths, device, rank, n_bat
     if device_ms[0]:
         extra = dict(extra, device_ms_per_batch=device_ms[0], vs_device_bound="%.2f x what the device alone needs for these batches (%.3f ms each, 16 of them "
                      "launched back to back from resident plans)" % (device_ms[0] / (dt / n_batches * 1e3), device_ms[0]))
-    extra = dict(extra, collate_workers=int(workers))
+    extra = dict(extra, collate_workers=int(workers), streams=int(n_streams))
     return {"questions_per_s": n_batches * B / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "questions_per_batch": B, "executor": route, **extra,
             "terminal_operators": kinds, "host_collate_ms_per_batch": host / n_batches * 1e3, "collate": ("in %d worker processes, batches ahead%s" % (workers, " (lost at batch %d: this process from there)" % lost[0] if lost else "")) if workers else "on the launching thread, while the device runs the batch before (forward_async)",
             "launch": "native executor: one dfol_run_program call per ProgramBatch, lowered at collate time" if route.get("native_program") else "eager (Python operator loop)",

@@ -299,6 +299,7 @@ F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
 RANGE_X_OVERFLOW = 1
 RANGE_PAIR_SATURATED = 2
 _RANGE_WORDS = {}
+_RANGE_RING = 8
 
 
 class RangeWatch(object):
@@ -309,9 +310,16 @@ class RangeWatch(object):
     def __init__(self, device):
         dev = torch.device(device)
         key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-        word = CAPTURE_RANGE_WORD if (CAPTURE_RANGE_WORD is not None and capturing()) else _RANGE_WORDS.get(key)
-        if word is None:
-            word = _RANGE_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        if CAPTURE_RANGE_WORD is not None and capturing():
+            word = CAPTURE_RANGE_WORD
+        else:
+            # a small ring of words per device: forwards in flight at once on DIFFERENT streams (bench.py's fresh-programs loop alternates two)
+            # must not share one - each clears its word on its own stream behind its copy
+            ring = _RANGE_WORDS.get(key)
+            if ring is None:
+                ring = _RANGE_WORDS[key] = [torch.zeros(_RANGE_RING, dtype=torch.int32, device=dev), 0]
+            word = ring[0][ring[1] % _RANGE_RING:ring[1] % _RANGE_RING + 1]
+            ring[1] += 1
         self.word, self.device = word, dev
         load().dfol_set_range_status(word.data_ptr())           # (thread-local in the library: the launches of THIS thread carry it)
 

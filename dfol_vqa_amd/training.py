@@ -299,6 +299,7 @@ class GraphedTrainStep(object):
         self._keep = []
         from . import _lib as _L
         _L.CAPTURE_RANGE_HOST = self._range_host = _L.new_range_host()      # (pinned memory for the captured copy of the fp16-range status word)
+        _L.CAPTURE_RANGE_WORD = self._range_word = torch.zeros(1, dtype=torch.int32, device=next(model.parameters()).device)   # (this graph's own word)
         _L.CAPTURE_RANGE_CHECKS[:] = []
         # (thread-local capture mode: the check for capture-unsafe calls is restricted to the capturing thread; a process group's watchdog
         # thread may query an event of an earlier collective at any time, which under the default "global" mode invalidates the capture)
@@ -319,6 +320,7 @@ class GraphedTrainStep(object):
                 self._back()
         self._range_checks, _L.CAPTURE_RANGE_CHECKS[:] = list(_L.CAPTURE_RANGE_CHECKS), []
         _L.CAPTURE_RANGE_HOST = None
+        _L.CAPTURE_RANGE_WORD = None
 
     @staticmethod
     def _quiesce():

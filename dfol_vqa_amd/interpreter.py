@@ -152,11 +152,11 @@ class GraphedForward(object):
         """Replay, and queue behind it the copies of everything the answers are decoded from (log-probabilities, arg-max flags, the fp16-range
         status word) into one of `depth` pinned slots - no host wait.  Returns the ticket `collect` takes.  At most `depth` tickets may be
         outstanding; new features for the next replay may be copied into the ProgramBatches' tensors right after this call (stream order)."""
-        while len(self._slots) < depth:
+        while len(self._slots) < max(1, depth):
             self._slots.append({"host": [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self._outputs], "event": torch.cuda.Event(), "busy": False})
-        slot = self._slots[self._next % depth]
+        slot = self._slots[self._next % len(self._slots)]
         if slot["busy"]:
-            raise RuntimeError("GraphedForward.submit: %d replays outstanding; collect() the oldest first" % depth)
+            raise RuntimeError("GraphedForward.submit: %d replays outstanding; collect() the oldest first" % len(self._slots))
         self._next += 1
         self._graph.replay()
         for t, h in zip(self._outputs, slot["host"]):

@@ -669,10 +669,17 @@ def calibrated_leg(args, device, n_batches=24):
                 # walks all of them - 2 ms pauses, seen as a 256-element list comprehension taking 2 ms; a serving process freezes what it keeps)
                 gc.collect()
                 gc.freeze()
+                # (the executor's batches are self-contained - blob, arena, read-back buffer, range word: they alternate two streams like the
+                # `value_fresh_programs` loop; the Python loop's cached side arrays are uploaded on the stream that first needs them: one stream)
+                lanes_ = [torch.cuda.Stream(device=device) for _ in range(2)] if (route == "1" and getattr(args, "fresh_streams", 1) > 1) else None
+                if lanes_:
+                    for s_ in lanes_:
+                        s_.wait_stream(torch.cuda.current_stream(device))
                 t0 = time.perf_counter()
                 pend = []
-                for pbk in fresh[4:]:
-                    pend.append(model.forward_async(pbk, False))
+                for j, pbk in enumerate(fresh[4:]):
+                    with (torch.cuda.stream(lanes_[j % 2]) if lanes_ else contextlib.nullcontext()):
+                        pend.append(model.forward_async(pbk, False))
                     if len(pend) > 2:
                         pend.pop(0).result()
                 for x in pend:

@@ -619,3 +619,54 @@ def test_calibration_walk_equals_separate_launches(g23_model, kind, monkeypatch)
         out[walk + "n"] = len(ops)
     same_results(out["1"], out["0"], "walk " + kind)
     assert out["1n"] < out["0n"]
+
+
+def test_executor_batches_on_two_streams_keep_their_results_and_flags(full, monkeypatch):
+    """bench.py's unseen-batch loops alternate two HIP streams (the executor's batch is self-contained: its blob, arena, read-back buffer and
+    event, and - from a ring per device - its own fp16-range word).  Six batches launched alternately on two streams with at most two pending:
+    everyone returns the bits of its own serial forward, and the one batch with a feature beyond fp16's range raises at ITS result() only."""
+    model, ont, oont, names, categories = full
+    monkeypatch.setenv("DFOL_NATIVE", "1")
+    kinds = ["exist", "verify_rel", "choose_attr", "query_attr", "and", "exist"]
+    batches, want = [], []
+    for k, kind in enumerate(kinds):
+        qs = syn.full_size_questions(kind, 6, 12, 30, names, categories, 900 + k)
+        pbs = TableCollater(1, ont, "X").collate([dict(q) for q in qs])
+        for pb in pbs:
+            pb.create_sparse_tensors()
+        pbs = [pb.to_cuda(DEV) for pb in pbs]
+        if k == 3:
+            pbs[0]._object_features[0, 0] = 1e6
+            want.append(None)
+        else:
+            with torch.no_grad():
+                r = model(pbs, False)
+            want.append((r["log_probability"].clone(), r["answer"], r["answer_log_probability"]))
+        batches.append(pbs)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+    _lib.PATH_COUNTS.clear()
+    pend, got = [], []
+
+    def take(k, p):
+        if want[k] is None:
+            with pytest.raises(_lib.DfolError):
+                p.result()
+            got.append(None)
+        else:
+            got.append(p.result())
+    with torch.no_grad():
+        for k, pbs in enumerate(batches):
+            with torch.cuda.stream(streams[k % 2]):
+                pend.append((k, model.forward_async(pbs, False)))
+            if len(pend) > 2:
+                take(*pend.pop(0))
+        for k, p in pend:
+            take(k, p)
+    torch.cuda.synchronize()
+    assert _lib.PATH_COUNTS.get("native_program", 0) == len(batches)
+    for k, (r, w) in enumerate(zip(got, want)):
+        if w is None:
+            assert r is None
+            continue
+        assert torch.equal(r["log_probability"], w[0]) and r["answer"] == w[1] and r["answer_log_probability"] == w[2], kinds[k]

@@ -1620,6 +1620,12 @@ def attach_rocprof(out, args):
             r["rocprofv3"]["stats_overlapped_avg_us"] = dom.get("overlapped_avg_us")
             r["rocprofv3"]["stats_overlapped_launches"] = dom.get("overlapped_launches")
             r["rocprofv3"]["frac_from_stats_alone_avg"] = work / (dom["alone_avg_us"] * 1e-6) / (r["peak"] * 1e12)
+        ser = dom.get("serial_run")
+        if ser and ser.get("all_launches_avg_us"):
+            # ... and the `--stats` row of the same command run with --pipeline 0 (profiles/r06_rocprof_summary_serial.md): every launch alone on the device
+            r["rocprofv3"]["stats_serial_run_avg_us"] = ser["all_launches_avg_us"]
+            r["rocprofv3"]["stats_serial_run_launches"] = ser["all_launches"]
+            r["rocprofv3"]["frac_from_stats_serial_run_avg"] = work / (ser["all_launches_avg_us"] * 1e-6) / (r["peak"] * 1e12)
     groups = entry.get("kernels", {})
     for k in out["kernels"]:
         tr = k.get("trace")

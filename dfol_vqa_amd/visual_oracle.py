@@ -7,6 +7,7 @@ cached tables by csrc/dfol_logic.hip.  Parameter names match the reference's sta
 (`_network.1.weight`, ...) so its checkpoints load with strict=False.
 """
 
+import contextlib
 import os
 
 import numpy as np
@@ -266,6 +267,21 @@ class _TallLinear(torch.autograd.Function):
         if gb is None and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb
+
+
+_PAIR_STREAMS = {}
+
+
+def _pair_side_stream(dev):
+    """The side stream of the pair branch in training (None: not used - no gradients, a CPU device, or DFOL_TRAIN_PAIR_STREAM=0)."""
+    dev = torch.device(dev)
+    if dev.type != "cuda" or not torch.is_grad_enabled() or os.environ.get("DFOL_TRAIN_PAIR_STREAM", "1") == "0":
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _PAIR_STREAMS.get(key)
+    if s is None:
+        s = _PAIR_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
 
 
 class _FusedHidden1(torch.autograd.Function):
@@ -908,16 +924,31 @@ class ClassifierOracle(OracleBase):
             plan = _concept_plan(full[preds], dev, self._index_cache)
             e_rows, be_rows = _EmbRows.apply(emb.weight, emb.bias, cols, plan)
             fresh = getattr(world, "_pair_pre2", None) is None        # this reader creates the trunk: its logits come out of the trunk's epilogue
-            pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32, q))
-            head = getattr(world, "_pair_head", None)
-            _lib.note("emb_rows")
-            if head is not None:                          # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk
-                x_part = head[2] if (fresh and head[2] is not None and head[2].numel() > 0) else None
-                _lib.note("head_use")
-                x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part, sums_ok)
-            else:
-                _lib.note("fused_logit")
-                x = _FusedLogit.apply(pre2, e_rows, be_rows, pred_off, max_rows)
+            # The pair branch (U | V product, the pair MLP, this reader's logits) on a SIDE stream: autograd runs a node's backward on the stream
+            # its forward ran on, so the branch's backward - the step's three large kernels - runs beside the attribute branch's backward (a chain
+            # of ~60 small launches with most CUs idle) instead of in front of it.  Same kernels, same arithmetic, no shared accumulators (the
+            # two branches' concept rows are different rows of the embedding gradient); joined right here in the forward.
+            side = _pair_side_stream(dev)
+            cur = torch.cuda.current_stream(dev) if side is not None else None
+            if side is not None:
+                side.wait_stream(cur)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32, q))
+                head = getattr(world, "_pair_head", None)
+                _lib.note("emb_rows")
+                if head is not None:                      # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk
+                    x_part = head[2] if (fresh and head[2] is not None and head[2].numel() > 0) else None
+                    _lib.note("head_use")
+                    x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part, sums_ok)
+                else:
+                    _lib.note("fused_logit")
+                    x = _FusedLogit.apply(pre2, e_rows, be_rows, pred_off, max_rows)
+            if side is not None:
+                cur.wait_stream(side)
+                x.record_stream(cur)                      # (allocated on the side stream, read on this one)
+                if torch.is_tensor(pre2):
+                    pre2.record_stream(cur)
+                _lib.note("pair_branch_side_stream")
         else:
             if fused:
                 _lib.note("logit_rows_gathered")          # rows out of order / no-op tokens: the fused first layer, torch ops for this reader's logits

@@ -1354,6 +1354,51 @@ def test_g19_full_size_train_step_against_the_reference(g19_setup, name, sums, m
         assert err <= 16 * own + 2e-3 * scale, "%s d%s: |dgrad| %.3g vs the reference's own %.3g (scale %.3g)" % (name, pname, err, own, scale)
 
 
+def test_pair_branch_on_its_side_stream_changes_no_bit(g19_setup, monkeypatch):
+    """The pair branch of a train step is issued on a side stream (visual_oracle._pair_side_stream: its backward's large kernels then run beside the
+    attribute branch's small launches).  Same kernels, same arithmetic, no shared accumulators: `training.train_batch` at FULL model size on the
+    bench's program (select -> filter -> relate -> exist for every question: every route deterministic - ragged hop counts would bring torch's
+    atomic index_select backward in, side stream or not) from the same state gives the same loss, gradients and updated weights bit for bit
+    with the side stream (twice) and without it (DFOL_TRAIN_PAIR_STREAM=0); the route is taken by default."""
+    from dfol_vqa_amd import _lib
+    model, ont, oont, weights, a, meta = g19_setup
+    voc = ont._vocabulary["idx_to_arg"]
+    nouns = [t for t in voc if t.startswith("noun")][:8]
+    attrs = [t for t in voc if t.startswith("attr")][:6]
+    rels = [t for t in voc if t.startswith("rel ")][:5]
+    assert nouns and attrs and rels
+    qs = []
+    for i in range(24):
+        br, last = syn.three_hop_program(7100 + i, nouns, attrs, rels)
+        qs.append(syn.question(7100 + i, br, last, "yes" if i % 2 else "no", syn.feature_scene(7100 + i, 14 + i % 9, 2048)))
+    start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    runs = []
+    try:
+        for flag in ("1", "0", "1", "0"):
+            monkeypatch.setenv("DFOL_TRAIN_PAIR_STREAM", flag)
+            model.load_state_dict(start)
+            model.zero_grad(set_to_none=True)
+            pbs = [pb.to_cuda(DEV) for pb in TableCollater(1, ont, "X").collate([dict(q) for q in qs])]
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+            _lib.PATH_COUNTS.clear()
+            loss, _ = training.train_batch(model, opt, pbs, clip_norm=0.65)
+            torch.cuda.synchronize()
+            routes = dict(_lib.PATH_COUNTS)
+            assert (routes.get("pair_branch_side_stream", 0) >= 1) == (flag == "1") and not [r for r in routes if r.startswith("fallback:")], routes
+            runs.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+                         {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    finally:
+        model.load_state_dict(start)
+        model.zero_grad(set_to_none=True)
+    assert len(runs[0][1]) >= 12 and all(float(g.abs().sum()) > 0 for g in runs[0][1].values())
+    for other in runs[1:]:
+        assert runs[0][0] == other[0]
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], other[1][k]), ("gradient", k)
+        for k in runs[0][2]:
+            assert torch.equal(runs[0][2][k], other[2][k]), ("weights", k)
+
+
 @pytest.mark.parametrize("n_list", [[5, 7], [2, 1, 9], [30]])
 def test_small_batches_train_inside_the_library(g19_setup, n_list):
     """below 4096 pair rows the full-size model's tall products used to leave for nn.functional.linear / `@` (vendor GEMM,

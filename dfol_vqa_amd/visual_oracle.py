@@ -883,6 +883,20 @@ class ClassifierOracle(OracleBase):
         if len(preds) == 0 or (n[pq[preds]] * (n[pq[preds]] - 1)).sum() == 0:
             return flat.view(P, NS, NS)
         groups = [preds]
+        keep_pred = None
+        if fused and len(preds) < P and P == world._batch_size and np.array_equal(pq, np.arange(P)):
+            # no-op tokens (questions whose program has no operator at this step - the normal case of a batch of programs of differing lengths):
+            # the fused logit kernels want every pair row of the batch under exactly one predicate, in order.  So the idle questions ride
+            # along under a borrowed concept - their logits are computed and dropped, their rows carry a zero gradient (what the kernels'
+            # contract calls "a row without a gradient") - instead of sending this reader through tensor ops: a gather of the [pairs, HID2]
+            # hidden layer, a second evaluation of the trunk to hang its gradient on and torch's atomic index_select backward (34.7 ms per step
+            # at 256 questions x 100 objects with 1..3 hops, against 9.4 for the aligned program: tools/lab/time_train_ragged_hops.py)
+            keep_pred = np.zeros(P, bool)
+            keep_pred[preds] = True
+            full = full.copy()
+            full[~keep_pred] = full[preds[0]]
+            groups = [np.arange(P)]
+            _lib.note("idle_questions_ride_along")
         if fused and len(preds) > world._batch_size:
             # several predicates per question (choose_rel's options): the j-th predicates of all questions form a group in which every
             # pair row belongs to exactly one predicate, in order - the shape the fused logit kernels take (no gathers of the
@@ -894,6 +908,11 @@ class ClassifierOracle(OracleBase):
             groups = [preds[slot == j] for j in range(int(slot.max()) + 1)]
         for grp in groups:
             dst, val = self._relation_group_autograd(world, full, pq, grp, n, pair_off, NS, fused)
+            if keep_pred is not None:                             # (the idle questions' rows: computed, not used)
+                rows = np.repeat(keep_pred[grp], n[pq[grp]] * (n[pq[grp]] - 1))
+                if not rows.all():
+                    sel = upload(np.nonzero(rows)[0].astype(np.int64), dev)
+                    dst, val = dst.index_select(0, sel), val.index_select(0, sel)
             flat = flat.index_put((dst,), val)
         return flat.view(P, NS, NS)
 

@@ -42,3 +42,16 @@ for name, qs in (("uniform three-hop exist", uniform()), ("ragged 1..3 hops exis
     ms = (time.perf_counter() - t0) / 5 * 1e3
     r = {k: v // 5 for k, v in _lib.PATH_COUNTS.items() if k in ("pair_trunk", "head_use", "pair_second_evaluation", "logit_rows_gathered", "fused_hidden1", "pair_forward_fused") or k.startswith("fallback")}
     print("%-30s %.2f ms per eager step, peak %.1f GB, routes per step %s" % (name, ms, torch.cuda.max_memory_allocated() / 1e9, r))
+    _lib.enable_kernel_timing(list(_lib.SIGNATURES))
+    for _ in range(3):
+        training.train_batch(model, opt, pbs, clip_norm=0.65, sync_loss=False)
+    torch.cuda.synchronize()
+    tm = _lib.disable_kernel_timing()
+    top = sorted(((t / 3 * 1e3, n // 3, k) for k, (n, t) in tm.items() if n), reverse=True)[:12]
+    print("    library launches per step %d, %.2f ms: %s" % (sum(n for _, n, _ in top), sum(t for t, _, _ in top), ", ".join("%s x%d %.2f" % (k.replace("dfol_", "").replace("_f32", ""), n, t) for t, n, k in top)))
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        training.train_batch(model, opt, pbs, clip_norm=0.65, sync_loss=False)
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:10]
+    print("    device time by kernel (one step): " + "; ".join("%s x%d %.2f ms" % (e.key[:38], e.count, e.device_time_total / 1e3) for e in rows))

@@ -148,6 +148,7 @@ SIGNATURES = {
     "dfol_linear_tall_supported": [_i64, _i32, _i32],
     "dfol_linear_tall_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "dfol_pair_dz_tall_f32": [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p],
+    "dfol_pair_dz_tall_multi_f32": [_p, _i64, _p, _i64, _i32, _p, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p],
     "dfol_linear_tall_bf16_bf16": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     "dfol_pair_dz_tall_bf16": [_p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     "dfol_linear_logit_h2_f32": [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
@@ -1166,6 +1167,32 @@ def pair_head_products(dx, p2, z, w2, e_rows, pred_off, row_pred, need_dz=True, 
         call("dfol_pair_wgrad_fused_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), _ptr(row_pred, I32), _ptr(pred_off, torch.int64), _ptr(e_rows, F32),
              e_rows.stride(0), _dp(scale), _dp(z), z.stride(0), M, H2, H1, _ptr(ws), _ptr(dw), _stream())
     return dz, dw
+
+
+PAIR_DZ_MULTI_MAX = 4
+
+
+def pair_dz_tall_multi(dx_list, p2, e_rows_list, row_pred, w2, dz_out=None):
+    """dz (+)= dpre2 W2 for SEVERAL readers of one hidden layer in one pass (csrc/dfol_dense_tall.hip, dfol_pair_dz_tall_multi_f32):
+    dpre2[r, j] = h (1 - h) sum_k dx_k[r] E_k[row_pred[r], j].  The readers share row_pred [M] (int32) and P; up to PAIR_DZ_MULTI_MAX per launch
+    (more: further launches that add).  -> dz [M, HID1]."""
+    M, H2 = p2.shape
+    H1 = w2.shape[1]
+    dev = p2.device
+    dz = dz_out if dz_out is not None else torch.empty(M, H1, dtype=F32, device=dev)
+    acc = dz_out is not None
+    wp = linear_pack_w_split(w2, True, 2)
+    for i in range(0, len(dx_list), PAIR_DZ_MULTI_MAX):
+        dxs, es = dx_list[i:i + PAIR_DZ_MULTI_MAX], e_rows_list[i:i + PAIR_DZ_MULTI_MAX]
+        nr, P = len(dxs), es[0].shape[0]
+        dx = torch.stack([d.reshape(-1) for d in dxs]).contiguous()
+        E = torch.stack([e if e.is_contiguous() else e.contiguous() for e in es]).contiguous()      # [nr, P, HID2]
+        emax = E.abs().amax(2).contiguous()
+        ws = torch.empty((nr + 1) * M, dtype=F32, device=dev)
+        call("dfol_pair_dz_tall_multi_f32", _dp(p2), p2.stride(0), _ptr(dx, F32), dx.stride(0), nr, _ptr(row_pred, I32), _ptr(E, F32), E.stride(1), P,
+             _ptr(emax, F32), _ptr(wp, torch.bfloat16), _dp(dz), dz.stride(0), M, H1, H2, 1 if acc else 0, _ptr(ws), _stream())
+        acc = True
+    return dz
 
 
 def pair_head_bwd(dx, p2, z, w2, e_rows, pred_off, row_pred, need_bias=True, dz_out=None, sums=False):

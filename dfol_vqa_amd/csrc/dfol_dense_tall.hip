@@ -76,7 +76,12 @@ struct TlExtra {
     int accumulate;                 // MODE 1: Y += instead of Y =
     float* x_part;                  // MODE 2: [4][ld_xp]
     int64_t ld_xp;
+    // MODE 1, MULTI (several readers of one trunk in ONE pass: dpre2[r][j] = h (1 - h) sum_k dx_k[r] E_k[row_pred[r]][j]): reader k's scaled dx at
+    // gs + k gs_stride, its embedding rows at E + k e_stride; the rows share one scale (the bound of the sum) and one row -> embedding row map
+    int nr;
+    int64_t gs_stride, e_stride;
 };
+constexpr int TL_MAXR = 4;          // readers per MULTI launch
 
 // MODE 1's per-row scaling: e_r puts the bound |dx[r]| max|E[p]| / 4 into [2^13, 2^14)  (the rule of csrc/dfol_dense_split.hip, LsProducer)
 // bound_max (or null): the largest bound of the launch, as the bits of a non-negative float (their order is the integers' order, and a
@@ -118,11 +123,12 @@ __global__ __launch_bounds__(256) void tall_row_scale_kernel(const float* __rest
 // bit for bit dfol_linear_act_bf16_bf16.  MODE 1 then needs no row scaling (bf16 has fp32's exponent range): gs = dx, and dpre2 is
 // rounded to bf16 exactly as dfol_pair_logit_bwd_bf16 stores it.  The output block leaves through LDS (2-byte stores straight from the
 // accumulator layout cost a third of the tiled kernel): a staging array behind the buffers, one extra barrier per block.
-template <int NTW, int MODE, bool BIO = false>
+template <int NTW, int MODE, bool BIO = false, bool MULTI = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void tall_h2_kernel(
     const void* __restrict__ Xv, int64_t ldx, const u32x4* __restrict__ Wp, const float* __restrict__ bias, void* __restrict__ Yv, int64_t ldy,
     int M, int N, int K, int ksteps, int nbn, TlExtra ex) {
     constexpr bool PROD = MODE == 1, LOGIT = MODE == 2;
+    static_assert(!MULTI || (PROD && !BIO), "several readers: the fp32 dZ product only");
     typedef typename std::conditional<BIO, uint16_t, float>::type TX;
     const TX* __restrict__ X = reinterpret_cast<const TX*>(Xv);
     TX* __restrict__ Y = reinterpret_cast<TX*>(Yv);
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // ---- MODE 1: the producer's state for the block whose steps are being stored; the next block's row values are prefetched a block ahead
     float gs_cur = 0.f, gs_next = 0.f;
+    float gsm_cur[MULTI ? TL_MAXR : 1], gsm_next[MULTI ? TL_MAXR : 1];           // MULTI: the readers' scaled dx of the row
     int p_next = -1;
     const float* ep = ex.E;
     float4 ea[2];
@@ -189,12 +196,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int64_t r = min((int64_t)b * TL_BM + arow, (int64_t)M - 1);
             const bool live = (int64_t)b * TL_BM + arow < M;
             p_next = live ? ex.row_pred[r] : -1;
-            gs_next = live ? ex.gs[r] : 0.f;
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int q = 0; q < TL_MAXR; ++q) gsm_next[q] = (live && q < ex.nr) ? ex.gs[(int64_t)q * ex.gs_stride + r] : 0.f;
+            } else {
+                gs_next = live ? ex.gs[r] : 0.f;
+            }
         }
     };
     auto switch_row_state = [&]() __attribute__((always_inline)) {   // at the first step of a block
         if constexpr (PROD) {
-            gs_cur = p_next >= 0 ? gs_next : 0.f;
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int q = 0; q < TL_MAXR; ++q) gsm_cur[q] = p_next >= 0 ? gsm_next[q] : 0.f;
+            } else {
+                gs_cur = p_next >= 0 ? gs_next : 0.f;
+            }
             ep = ex.E + (int64_t)max(p_next, 0) * ex.ld_e + aq * 8;
             fetch_row_state(sb + stride);
         }
@@ -203,8 +220,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (PROD) {
             const int k = sks * TL_BK + aq * 8;
             const int c0 = min(k, K - 4) - aq * 8, c1 = min(k + 4, K - 4) - aq * 8;
-            ea[0] = *reinterpret_cast<const float4*>(ep + c0);
-            ea[1] = *reinterpret_cast<const float4*>(ep + c1);
+            if constexpr (MULTI) {                                    // the row's combined coefficients sum_k (2^e dx_k) E_k: the factor of h (1 - h)
+                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll
+                for (int q = 0; q < TL_MAXR; ++q) {
+                    if (q < ex.nr) {
+                        const float g = gsm_cur[q];
+                        const float4 e0 = *reinterpret_cast<const float4*>(ep + (int64_t)q * ex.e_stride + c0);
+                        const float4 e1 = *reinterpret_cast<const float4*>(ep + (int64_t)q * ex.e_stride + c1);
+                        s0.x = fmaf(g, e0.x, s0.x), s0.y = fmaf(g, e0.y, s0.y), s0.z = fmaf(g, e0.z, s0.z), s0.w = fmaf(g, e0.w, s0.w);
+                        s1.x = fmaf(g, e1.x, s1.x), s1.y = fmaf(g, e1.y, s1.y), s1.z = fmaf(g, e1.z, s1.z), s1.w = fmaf(g, e1.w, s1.w);
+                    }
+                }
+                ea[0] = s0, ea[1] = s1;
+            } else {
+                ea[0] = *reinterpret_cast<const float4*>(ep + c0);
+                ea[1] = *reinterpret_cast<const float4*>(ep + c1);
+            }
         }
     };
     auto store_a = [&](auto set_tag, int off) __attribute__((always_inline)) {
@@ -230,8 +262,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float4 v0 = k < K ? xa[S][0] : z, v1 = k + 4 < K ? xa[S][1] : z;
             if constexpr (PROD) {
                 auto dp = [&](const float4& x, const float4& e) __attribute__((always_inline)) {
-                    return make_float4((gs_cur * e.x) * tl_dsigmoid(x.x), (gs_cur * e.y) * tl_dsigmoid(x.y), (gs_cur * e.z) * tl_dsigmoid(x.z),
-                                       (gs_cur * e.w) * tl_dsigmoid(x.w));
+                    if constexpr (MULTI)                              // (the readers' dx are inside e already: load_e)
+                        return make_float4(e.x * tl_dsigmoid(x.x), e.y * tl_dsigmoid(x.y), e.z * tl_dsigmoid(x.z), e.w * tl_dsigmoid(x.w));
+                    else
+                        return make_float4((gs_cur * e.x) * tl_dsigmoid(x.x), (gs_cur * e.y) * tl_dsigmoid(x.y), (gs_cur * e.z) * tl_dsigmoid(x.z),
+                                           (gs_cur * e.w) * tl_dsigmoid(x.w));
                 };
                 v0 = k < K ? dp(xa[S][0], ea[0]) : z;
                 v1 = k + 4 < K ? dp(xa[S][1], ea[1]) : z;
@@ -461,7 +496,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int MODE, bool BIO = false>
+template <int MODE, bool BIO = false, bool MULTI = false>
 static int tall_launch(const void* X, int64_t ldx, const void* W_split, const float* bias, void* Y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                        const TlExtra& ex, void* stream, const char* name) {
     const int ksteps = dfol_cdiv(K, TL_BK), nbn = dfol_cdiv(N, 128);
@@ -482,11 +517,11 @@ static int tall_launch(const void* X, int64_t ldx, const void* W_split, const fl
     hipStream_t st = (hipStream_t)stream;
 #define DFOL_TALL(NT)                                                                                                                       \
     {                                                                                                                                      \
-        static const hipError_t ok = hipFuncSetAttribute((const void*)tall_h2_kernel<NT, MODE, BIO>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        static const hipError_t ok = hipFuncSetAttribute((const void*)tall_h2_kernel<NT, MODE, BIO, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                         (int)((size_t)2 * (TILE + ((64 * NT + 127) / 128) * TILE) * 16 + TL_XS * 4 +             \
                                                               (BIO ? (size_t)TL_BM * (64 * NT + 8) * 2 : 0)));                                    \
         DFOL_REQUIRE(ok == hipSuccess, "%s: cannot reserve %zu bytes of LDS (%s)", name, lds, hipGetErrorString(ok));                       \
-        hipLaunchKernelGGL((tall_h2_kernel<NT, MODE, BIO>), dim3(grid), dim3(512), lds, st, X, ldx, (const u32x4*)W_split, bias, Y, ldy, M, N, K, \
+        hipLaunchKernelGGL((tall_h2_kernel<NT, MODE, BIO, MULTI>), dim3(grid), dim3(512), lds, st, X, ldx, (const u32x4*)W_split, bias, Y, ldy, M, N, K, \
                            ksteps, nbn, ex);                                                                                               \
     }
     if (ntw <= 4) DFOL_TALL(4) else DFOL_TALL(5)
@@ -554,6 +589,54 @@ extern "C" int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const flo
     DFOL_LAUNCH_CHECK("pair_dz_tall (row scales)");
     const TlExtra ex = {gs, rsinv, row_pred, E, ld_e, accumulate, nullptr, 0};
     return tall_launch<1>(pre2, ld_p2, W2t_split, nullptr, dZ, ld_dz, M, H1, H2, ex, stream, "pair_dz_tall");
+}
+
+// Several readers of one trunk (relate hops of a program, option slots of choose_rel) in ONE pass: dZ (+)= dpre2 W2 with
+// dpre2[r][j] = h (1 - h) sum_k dx_k[r] E_k[row_pred[r]][j] - each reader on its own costs a pass over pre2 and, from the second on, a read-modify-write
+// of dZ (3.1 ms against 1.8 at 256 x 100 objects).  The readers share the row -> embedding row map (every pair row of the batch under one predicate per
+// reader, in order); the row's scale is that of the bound sum_k |dx_k[r]| max|E_k[p]| / 4.
+__global__ __launch_bounds__(256) void tall_row_scale_multi_kernel(const float* __restrict__ dx, int64_t dx_stride, const int32_t* __restrict__ row_pred,
+                                                                   const float* __restrict__ emax, int P, int nr, int M, float* __restrict__ gs,
+                                                                   float* __restrict__ rsinv) {
+    for (int r = blockIdx.x * 256 + (int)threadIdx.x; r < M; r += gridDim.x * 256) {
+        const int p = row_pred[r];
+        float g[TL_MAXR], bound = 0.f;
+#pragma unroll
+        for (int q = 0; q < TL_MAXR; ++q) {
+            g[q] = (p >= 0 && q < nr) ? dx[(int64_t)q * dx_stride + r] : 0.f;
+            bound += fabsf(g[q]) * (q < nr ? emax[(int64_t)q * P + max(p, 0)] : 0.f) * 0.25f;
+        }
+        int e = 0;
+        if (bound > 0.f && bound < 3.0e38f) {
+            int x;
+            (void)frexpf(bound, &x);
+            e = 14 - x;
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        }
+#pragma unroll
+        for (int q = 0; q < TL_MAXR; ++q)
+            if (q < nr) gs[(int64_t)q * M + r] = ldexpf(g[q], e);
+        rsinv[r] = ldexpf(1.0f, -e);
+    }
+}
+
+// dx [nr][dx_stride >= M], E [nr][P][ld_e] (reader k's rows at E + k P ld_e), emax [nr][P] = max_j |E_k[p][j]|; workspace: (nr + 1) M floats
+extern "C" int dfol_pair_dz_tall_multi_f32(const float* pre2, int64_t ld_p2, const float* dx, int64_t dx_stride, int32_t nr, const int32_t* row_pred,
+                                           const float* E, int64_t ld_e, int32_t P, const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz,
+                                           int32_t M, int32_t H1, int32_t H2, int32_t accumulate, float* workspace, void* stream) {
+    DFOL_REQUIRE(nr >= 1 && nr <= TL_MAXR && P >= 1 && dx_stride >= M, "pair_dz_tall_multi: %d readers (1..%d), P=%d", nr, TL_MAXR, P);
+    DFOL_REQUIRE(dfol_linear_tall_supported(M, H1, H2) && ld_p2 % 4 == 0 && ld_p2 >= H2 && ld_e % 4 == 0 && ld_e >= H2 && ld_dz >= H1,
+                 "pair_dz_tall_multi: bad sizes M=%d H1=%d H2=%d", M, H1, H2);
+    DFOL_REQUIRE(pre2 && dx && row_pred && E && emax && W2t_split && dZ && workspace, "pair_dz_tall_multi: null pointer");
+    DFOL_REQUIRE(((uintptr_t)pre2 % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)W2t_split % 16 == 0),
+                 "pair_dz_tall_multi: pre2, E and the packed weights must be 16-byte aligned");
+    float* gs = workspace;
+    float* rsinv = workspace + (int64_t)nr * M;
+    hipLaunchKernelGGL(tall_row_scale_multi_kernel, dim3(std::min(dfol_cdiv(M, 256), 1024)), dim3(256), 0, (hipStream_t)stream, dx, dx_stride, row_pred, emax, P, nr,
+                       M, gs, rsinv);
+    DFOL_LAUNCH_CHECK("pair_dz_tall_multi (row scales)");
+    const TlExtra ex = {gs, rsinv, row_pred, E, ld_e, accumulate, nullptr, 0, nr, (int64_t)M, (int64_t)P * ld_e};
+    return tall_launch<1, false, true>(pre2, ld_p2, W2t_split, nullptr, dZ, ld_dz, M, H1, H2, ex, stream, "pair_dz_tall_multi");
 }
 
 // The bf16 mode's forms (bf16-STORED activations, one bf16 piece per operand, results rounded to nearest even): bit for bit

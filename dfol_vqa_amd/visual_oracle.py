@@ -384,6 +384,15 @@ class _PairTrunk(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g_pre2, _g_token, _g_part):
         st = ctx.state
+        jobs = st.get("dz_jobs")
+        if jobs:                                             # the readers' dZ shares in one pass (several readers: see _HeadUse.backward)
+            if len(jobs) == 1:
+                dxj, ej, rpj = jobs[0]
+                pred_off = None
+                st["dz"], _ = L.pair_head_products(dxj, st["pre2"], st["z"], st["w"], ej, pred_off, rpj, True, False, dz_out=st["dz"])
+            else:
+                st["dz"] = L.pair_dz_tall_multi([j[0] for j in jobs], st["pre2"], [j[1] for j in jobs], jobs[0][2], st["w"], dz_out=st["dz"])
+                _lib.note("pair_dz_multi")
         dz, dw, db = st["dz"], st["dw"], st["db"]
         dev = st["w"].device
         if st["need_dz"] and dz is None:
@@ -406,6 +415,7 @@ class _HeadUse(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(pre2, e_rows, pred_off, row_pred)
         ctx.state, ctx.sums_ok = state, bool(sums_ok)
+        state["readers"] = state.get("readers", 0) + 1            # (several: their dZ shares are taken in ONE pass by the trunk's backward)
         if x_part is not None:                                # the trunk's epilogue has this reader's partial sums already
             return x_part.sum(0) + be_rows.index_select(0, row_pred)
         return L.pair_logit_fwd(pre2, e_rows, be_rows, pred_off, max_rows)
@@ -422,16 +432,27 @@ class _HeadUse(torch.autograd.Function):
         if pre2.dtype == torch.bfloat16:
             return _HeadUse._backward_bf16(ctx, st, dx, pre2, e_rows, pred_off, row_pred, need_be)
         mode = os.environ.get("DFOL_HEAD_SUMS", "auto")       # "1" / "0": always / never take the sums from the weight-gradient pass (where it can)
+        # several readers of the trunk (relate hops of a program, option slots): their dZ shares - a pass over pre2 each and, from the second on,
+        # a read-modify-write of dZ - are left to ONE pass in the trunk's backward (_PairTrunk.backward, dfol_pair_dz_tall_multi_f32); the readers
+        # of a trunk share one row -> predicate map when each covers every pair row of the batch (P predicates = the batch's questions)
+        defer = (st["need_dz"] and st.get("readers", 1) >= 2 and os.environ.get("DFOL_DZ_MULTI", "1") != "0" and pre2.dtype == torch.float32
+                 and e_rows.shape[0] == st.get("dz_P", e_rows.shape[0]) and int(pred_off.shape[0]) - 1 == e_rows.shape[0]
+                 and L.linear_tall_supported(pre2.shape[0], st["w"].shape[1], pre2.shape[1]) and row_pred is not None and row_pred.shape[0] == pre2.shape[0])
+        need_dz_now = st["need_dz"] and not defer
+        if defer:
+            st["dz_P"] = e_rows.shape[0]
+            st.setdefault("dz_jobs", []).append((dx, e_rows, row_pred))
+            _lib.note("head_use_dz_deferred")
         if ctx.sums_ok and st["need_dw"] and pre2.shape[1] % 3 == 0 and mode != "0" and (mode == "1" or pre2.shape[0] >= (1 << 20)):
             _lib.note("head_use_backward_sums")
-            dz, dw, de, dbe, db2 = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], True, dz_out=st["dz"],
+            dz, dw, de, dbe, db2 = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, need_dz_now, True, dz_out=st["dz"],
                                                         sums=True, need_bias=need_be)
         else:
             _lib.note("head_use_backward")
             de, dbe, db2p = L.pair_head_sums(dx, pre2, e_rows, pred_off, need_bias=need_be)
             db2 = db2p.sum(0) if st["need_db"] else None
-            dz, dw = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, st["need_dz"], st["need_dw"], dz_out=st["dz"])
-        if st["need_dz"]:
+            dz, dw = L.pair_head_products(dx, pre2, st["z"], st["w"], e_rows, pred_off, row_pred, need_dz_now, st["need_dw"], dz_out=st["dz"])
+        if need_dz_now:
             st["dz"] = dz                                     # (a later reader adds into it)
         if st["need_dw"]:
             st["dw"] = dw if st["dw"] is None else st["dw"] + dw

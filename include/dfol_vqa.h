@@ -526,6 +526,13 @@ int dfol_linear_tall_h2_f32(const float* X, int64_t ldx, const void* W_split, co
 int dfol_pair_dz_tall_f32(const float* pre2, int64_t ld_p2, const float* dx, const int32_t* row_pred, const float* E, int64_t ld_e,
                           const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t HID1, int32_t HID2,
                           int32_t accumulate, float* workspace, void* stream);
+/* Several readers of one trunk (the relate hops of a program, choose_rel's option slots) in ONE such pass:
+ * dZ (+)= dpre2 W2 with dpre2[r][j] = h (1 - h) sum_k dx_k[r] E_k[row_pred[r]][j], k < nr <= 4 - on its own every reader pays a pass over pre2 and,
+ * from the second on, a read-modify-write of dZ.  The readers share row_pred (every pair row of the batch under one predicate per reader, in
+ * order); dx [nr][dx_stride >= M], E [nr][P][ld_e], emax [nr][P] (max_j |E_k[p][j]|); workspace: (nr + 1) M floats. */
+int dfol_pair_dz_tall_multi_f32(const float* pre2, int64_t ld_p2, const float* dx, int64_t dx_stride, int32_t nr, const int32_t* row_pred, const float* E,
+                                int64_t ld_e, int32_t P, const float* emax, const void* W2t_split, float* dZ, int64_t ld_dz, int32_t M, int32_t HID1,
+                                int32_t HID2, int32_t accumulate, float* workspace, void* stream);
 /* The bf16 mode's forms of the same (bf16-STORED activations: `void*` rows of bfloat16, strides in elements, multiples of 4; one bf16 piece
  * per operand, fp32 accumulation, bfloat16 results rounded to nearest even): bit for bit dfol_linear_act_bf16_bf16 resp.
  * dfol_pair_logit_bwd_bf16 followed by it; wgrad_fused_sums_bf16 always yields the sums (every predicate >= 64 rows or none), needs no

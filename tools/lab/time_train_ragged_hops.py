@@ -42,6 +42,20 @@ for name, qs in (("uniform three-hop exist", uniform()), ("ragged 1..3 hops exis
     ms = (time.perf_counter() - t0) / 5 * 1e3
     r = {k: v // 5 for k, v in _lib.PATH_COUNTS.items() if k in ("pair_trunk", "head_use", "pair_second_evaluation", "logit_rows_gathered", "fused_hidden1", "pair_forward_fused") or k.startswith("fallback")}
     print("%-30s %.2f ms per eager step, peak %.1f GB, routes per step %s" % (name, ms, torch.cuda.max_memory_allocated() / 1e9, r))
+    if os.environ.get("RAGGED_GRAPH", "1") == "1":              # the same step replayed as a HIP graph (what bench.py --mode train times)
+        from dfol_vqa_amd import parallel
+        params = [p for p in model.parameters() if p.requires_grad]
+        gopt = torch.optim.Adam(params, lr=1e-4, capturable=True)
+        gstep = training.GraphedTrainStep(model, gopt, pbs, 0.65, bucket=parallel.GradBucket(params), warmup=1)
+        for _ in range(3):
+            gstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            gstep()
+        torch.cuda.synchronize()
+        print("    replayed as a graph: %.2f ms per step" % ((time.perf_counter() - t0) / 10 * 1e3))
+        del gstep
     _lib.enable_kernel_timing(list(_lib.SIGNATURES))
     for _ in range(3):
         training.train_batch(model, opt, pbs, clip_norm=0.65, sync_loss=False)

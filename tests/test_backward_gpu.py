@@ -1058,6 +1058,54 @@ def test_pair_head_backward_without_dpre2(counts, hid1, hid2, decades):
     assert np.allclose(dp_dev.cpu().numpy(), dp, rtol=2e-5, atol=1e-30 + 2e-6 * np.abs(dp).max())
 
 
+@pytest.mark.parametrize("counts,nr,decades", [([9900, 5112, 3540], 2, 2), ([2450] * 9, 3, 1), ([1260] * 37 + [380, 0, 3906], 4, 3), ([870] * 30, 6, 1)])
+def test_pair_dz_of_several_readers_in_one_pass(counts, nr, decades):
+    """dfol_pair_dz_tall_multi_f32: dZ = (h (1 - h) sum_k dx_k E_k[p(r)]) W2 for nr readers of one hidden layer in ONE pass over pre2, against float64
+    with the single-reader kernel's operand-model tolerance (the row's scale is that of the bound sum_k |dx_k| max|E_k|), against the sum of the
+    readers' single passes, bit-repeatable, adding into a previous dZ; more than four readers go in two launches."""
+    from dfol_vqa_amd import _lib
+    hid1, hid2 = 256, 300
+    rng = np.random.RandomState(len(counts) * 100 + nr)
+    counts = np.asarray(counts, np.int64)
+    M, P = int(counts.sum()), len(counts)
+    assert _lib.linear_tall_supported(M, hid1, hid2)
+    rep = np.repeat(np.arange(P), counts).astype(np.int32)
+    p2 = (rng.normal(size=(M, hid2)) * 2.5).astype(np.float32)
+    w2 = (rng.normal(size=(hid2, hid1)) / 16).astype(np.float32)
+    Es = [(rng.normal(size=(P, hid2)) * 0.1 * 3.0 ** k).astype(np.float32) for k in range(nr)]
+    dxs = []
+    for k in range(nr):
+        dx = (rng.normal(size=M) * 10.0 ** rng.randint(-decades, decades + 1, M)).astype(np.float32)
+        dx[rng.uniform(size=M) < 0.3] = 0.0                       # (a reader's idle rows carry no gradient)
+        dxs.append(dx)
+    dev = lambda a: torch.as_tensor(a).to(DEV)
+    p2_t, w2_t, rep_t = dev(p2), dev(w2), dev(rep)
+    dz = _lib.pair_dz_tall_multi([dev(d) for d in dxs], p2_t, [dev(e) for e in Es], rep_t, w2_t)
+    assert torch.equal(dz, _lib.pair_dz_tall_multi([dev(d) for d in dxs], p2_t, [dev(e) for e in Es], rep_t, w2_t))
+    p64, w64 = p2.astype(np.float64), w2.astype(np.float64)
+    h = 1.0 / (1.0 + np.exp(-p64))
+    coef = sum(d.astype(np.float64)[:, None] * e.astype(np.float64)[rep] for d, e in zip(dxs, Es))
+    dp = coef * h * (1.0 - h)
+    groups = [range(i, min(i + _lib.PAIR_DZ_MULTI_MAX, nr)) for i in range(0, nr, _lib.PAIR_DZ_MULTI_MAX)]     # (one row scale per launch)
+    tol = np.zeros((M, hid1))
+    for grp in groups:
+        dpg = sum(dxs[k].astype(np.float64)[:, None] * Es[k].astype(np.float64)[rep] for k in grp) * h * (1.0 - h)
+        bound = sum(np.abs(dxs[k].astype(np.float64)) * np.abs(Es[k].astype(np.float64)).max(1)[rep] for k in grp) * 0.25
+        absdp = sum(np.abs(dxs[k].astype(np.float64))[:, None] * np.abs(Es[k].astype(np.float64))[rep] for k in grp) * h * (1.0 - h)
+        tol += 2.0 ** -20 * (absdp @ np.abs(w64)) + hid2 * 2.0 ** -37 * bound[:, None] * np.abs(w64).max() + 1e-30
+    err = np.abs(dz.cpu().numpy() - dp @ w64)
+    assert (err <= tol).all(), float((err / tol).max())
+    # the readers one by one (each a pass of its own, adding into dZ): the same numbers to the kernels' tolerance
+    z0 = torch.zeros(M, hid1, device=DEV)
+    one = None
+    for d, e in zip(dxs, Es):
+        one, _ = _lib.pair_head_products(dev(d), p2_t, z0, w2_t, dev(e), None, rep_t, True, False, dz_out=one)
+    assert (np.abs(one.cpu().numpy() - dz.cpu().numpy()) <= 2 * tol).all()
+    # adding into an earlier dZ
+    twice = _lib.pair_dz_tall_multi([dev(d) for d in dxs], p2_t, [dev(e) for e in Es], rep_t, w2_t, dz_out=dz.clone())
+    assert np.allclose(twice.cpu().numpy(), 2.0 * dz.cpu().numpy(), rtol=1e-6, atol=2e-6 * float(dz.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K", [(9900 * 3 + 77, 300, 256), (1000, 300, 256), (70000, 256, 64), (129, 44, 32)])
 def test_linear_logit_h2_partial_sums(M, N, K):
     """dfol_linear_logit_h2_f32: the product is bit for bit dfol_linear_act_h2_f32's, and the partial sums its epilogue leaves add up to the
@@ -1333,6 +1381,8 @@ def test_g19_full_size_train_step_against_the_reference(g19_setup, name, sums, m
     assert routes.get("fused_hidden1", 0) == 1 and routes.get("pair_trunk", 0) == 1, routes
     assert routes.get("head_use", 0) >= 1 and routes.get("emb_rows", 0) >= 1, routes
     assert routes.get("head_use_backward_sums" if sums == "1" else "head_use_backward", 0) >= 1, routes
+    if name in ("binary_tall", "query_rel_tall"):                # several readers of the trunk (>= 16384 pair rows: the persistent kernels): their dZ shares in one pass
+        assert routes.get("pair_dz_multi", 0) == 1 and routes.get("head_use_dz_deferred", 0) >= 2, routes
     if name.startswith("binary"):                                # ragged hop counts: the aligned relate batches hold no-op tokens - their idle
         # questions ride along under a borrowed concept on the fused kernels (late round 6; before: tensor ops + a second evaluation of the trunk)
         assert routes.get("idle_questions_ride_along", 0) >= 1 and routes.get("head_use", 0) >= 2, routes

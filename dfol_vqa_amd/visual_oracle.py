@@ -304,9 +304,16 @@ class _FusedHidden1(torch.autograd.Function):
             first = fwd["first"]
             e_rows = req = None
             if first is not None and len(first) > 2:
-                req_host = np.full((1, world._batch_size), -1, np.int32)
+                extras = first[3] if len(first) > 3 else []
+                req_host = np.full((1 + len(extras), world._batch_size), -1, np.int32)
                 req_host[0, np.asarray(first[2], np.int64)] = np.arange(len(first[2]), dtype=np.int32)
-                e_rows, req = first[0], upload(req_host, U.device)
+                e_rows = first[0]
+                if extras:                                        # the other readers' embedding rows, behind the first reader's
+                    P0 = e_rows.shape[0]
+                    e_rows = torch.cat([e_rows] + [first[4].index_select(0, upload(c, U.device)) for c in extras], 0)
+                    for i, c in enumerate(extras):
+                        req_host[1 + i, :] = P0 + i * world._batch_size + np.arange(world._batch_size, dtype=np.int32)
+                req = upload(req_host, U.device)
             z, pre2, geo, x = L.pair_train_fwd_h2(UV.detach() * L.LOG2E, h, pos, Wg.detach(), fwd["w2h"], fwd["b2"], fwd["hid2"], world._img_n_obj,
                                                   world._obj_off, world._pair_off, max_n, world._pair_num, e_rows, req)
             fwd["out"] = (pre2, x)
@@ -790,6 +797,7 @@ class ClassifierOracle(OracleBase):
                     _lib.note("pair_forward_fused")
                 pre2, token, x_part = _PairTrunk.apply(z, lin2.weight, lin2.bias, state, first, pre)
                 world._pair_head = (token, state, x_part)
+                world._pair_x_rows = pre is not None             # x_part: one row of raw logits per reader (the fused forward) / partial sums of one reader
                 world._pair_pre2 = pre2
             else:
                 world._pair_pre2 = _TallLinear.apply(z, lin2.weight, lin2.bias)
@@ -973,11 +981,26 @@ class ClassifierOracle(OracleBase):
             if side is not None:
                 side.wait_stream(cur)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32, q))
+                own = np.asarray(full[preds], np.int64)
+                extras = []
+                if fresh and len(q) == world._batch_size and np.array_equal(q, np.arange(len(q))):
+                    extras = [c for c in getattr(world, "_train_rel_readers", []) if not np.array_equal(c, own)]
+                pre2 = self._pair_pre2_autograd(world, first=(e_rows.detach().contiguous(), rep32, q, extras, emb.weight.detach()))
                 head = getattr(world, "_pair_head", None)
                 _lib.note("emb_rows")
                 if head is not None:                      # the deferred backward: no [pairs, HID2] gradient between this layer and the trunk
-                    x_part = head[2] if (fresh and head[2] is not None and head[2].numel() > 0) else None
+                    x_part = None
+                    if head[2] is not None and head[2].numel() > 0 and not getattr(world, "_pair_x_rows", False):
+                        x_part = head[2] if fresh else None      # (the tall product's epilogue: the first reader's partial sums)
+                    elif head[2] is not None and head[2].numel() > 0:
+                        if fresh:
+                            world._pair_x_slots = {own.tobytes(): 0, **{c.tobytes(): 1 + i for i, c in enumerate(extras)}} if head[2].shape[0] == 1 + len(extras) else {own.tobytes(): 0}
+                            x_part = head[2][0:1]
+                        else:                             # a later reader whose logits the trunk's one launch left behind
+                            slot = getattr(world, "_pair_x_slots", {}).get(own.tobytes())
+                            if slot is not None and slot < head[2].shape[0] and len(q) == world._batch_size:
+                                x_part = head[2][slot:slot + 1]
+                                _lib.note("head_use_logits_from_trunk")
                     _lib.note("head_use")
                     x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part, sums_ok)
                 else:
@@ -1080,9 +1103,31 @@ class ClassifierOracle(OracleBase):
         # the pair kernels write the real ordered pairs (the bf16x3 kernel not even the diagonal): absent everywhere else
         return torch.full((count, world._NS, world._NS), -30.0, dtype=dtype, device=world._device)
 
+    def _collect_relation_readers(self, world, program_batch):
+        """Training: the embedding columns every relate / verify_rel of the program batch will ask the pair branch for (one per question; an idle
+        question borrows the first valid one, as _relation_tiles_autograd does), so that the fused forward kernel leaves ALL readers' raw logits behind
+        in its one launch - a reader that finds its columns there skips its own pass over pre2 (dfol_pair_logit_fwd_f32: 0.58 ms at 256 x 100 objects)."""
+        world._train_rel_readers = []
+        if os.environ.get("DFOL_TRAIN_ALL_LOGITS", "1") == "0":
+            return
+        Q = world._batch_size
+        for ob in program_batch._op_batch_list:
+            if ob._op_name in ("relate", "verify_rel") and ob._arguments:
+                low = get_lowered(ob._arguments[0], self._ontology, TokenType.RELATION)
+                if not (low.any_valid and len(low.cols) == Q):
+                    continue
+                full = self._relation_full_columns(low.cols)
+                ok = full >= 0
+                full = full.copy()
+                full[~ok] = full[np.nonzero(ok)[0][0]]
+                if not any(np.array_equal(full, c) for c in world._train_rel_readers) and len(world._train_rel_readers) < 8:
+                    world._train_rel_readers.append(full.astype(np.int64))
+
     def prefetch_relations(self, world, program_batch, fused=True):
         """One fused pair-kernel launch for every relation operator of the program batch (relate / verify_rel /
         choose_rel): the pair MLP's hidden layer is then evaluated once per object pair, whatever the number of hops."""
+        if world._lazy is not None and getattr(world, "_train", False):
+            self._collect_relation_readers(world, program_batch)
         if world._lazy is None or getattr(world, "_train", False):
             return
         Q = world._batch_size

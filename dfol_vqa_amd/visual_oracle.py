@@ -1118,6 +1118,8 @@ class ClassifierOracle(OracleBase):
                     continue
                 full = self._relation_full_columns(low.cols)
                 ok = full >= 0
+                if not ok.any():
+                    continue
                 full = full.copy()
                 full[~ok] = full[np.nonzero(ok)[0][0]]
                 if not any(np.array_equal(full, c) for c in world._train_rel_readers) and len(world._train_rel_readers) < 8:

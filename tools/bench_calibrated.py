@@ -14,6 +14,8 @@ from dfol_vqa_amd import experiment
 from dfol_vqa_amd import synthetic as syn
 class A: pass
 args = A(); args.objects = int(sys.argv[1]) if len(sys.argv) > 1 else 100; args.batch = 256
+MIXED = len(sys.argv) > 2 and sys.argv[2].startswith("mixed")   # fresh batches: 1..3-hop programs, eight terminal operators in turn (default: the bench's
+ONLY = sys.argv[2].split(":")[1] if MIXED and ":" in sys.argv[2] else None      # program); mixed:<kind>: that terminal operator only
 device = torch.device("cuda", 0)
 tmp = tempfile.mkdtemp()
 paths, names = syn.write_synthetic_ontology(tmp)
@@ -68,7 +70,14 @@ for calib in (False, True):
         fresh = []
         for k in range(24):
             qk = []
-            for i in range(args.batch):
+            if MIXED:                                           # programs of differing lengths and terminal operators (what GQA's files hold)
+                import json as _json
+                cats_ = _json.load(open(paths["attribute_file"]))
+                kinds_ = [ONLY] if ONLY else ["exist", "verify_rel", "choose_attr", "and", "query_attr", "verify_attrs", "or", "choose_rel"]
+                qk = syn.full_size_questions(kinds_[k % len(kinds_)], args.batch, args.objects, args.objects, names, cats_, 5000 + k, with_scene=False)
+                for i, q in enumerate(qk):
+                    q["scene"] = qs[i]["scene"]
+            for i in range(0 if MIXED else args.batch):
                 br, last = syn.three_hop_program(100000 * (k + 1) + i, nouns, attrs, rels)
                 qk.append(syn.question(100000 * (k + 1) + i, br, last, "yes", qs[i]["scene"]))
             pb = FreshCollater(spec if route == "1" else None).collate(qk)[0]
@@ -82,8 +91,14 @@ for calib in (False, True):
                 model(pbk, False)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             pend = []
-            for pbk in fresh[4:]:
-                pend.append(model.forward_async(pbk, False))
+            import contextlib
+            lanes_ = [torch.cuda.Stream(device=device) for _ in range(2)] if (route == "1" and os.environ.get("CALIB_STREAMS", "1") == "2") else None
+            if lanes_:                                          # CALIB_STREAMS=2: the executor's batches alternate two streams (bench.py's loops)
+                for s_ in lanes_:
+                    s_.wait_stream(torch.cuda.current_stream(device))
+            for j, pbk in enumerate(fresh[4:]):
+                with (torch.cuda.stream(lanes_[j % 2]) if lanes_ else contextlib.nullcontext()):
+                    pend.append(model.forward_async(pbk, False))
                 if len(pend) > 2:
                     pend.pop(0).result()
             for x in pend:

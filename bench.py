@@ -75,6 +75,9 @@ def parse(argv=None):
     ap.add_argument("--stress-preds", type=int, default=65536)
     ap.add_argument("--fresh-batches", type=int, default=56, help="batches of the `value_fresh_programs` leg: every step a different ProgramBatch through "
                     "collate -> lower -> eager launches (0 = skip; north_star / c1 workloads, one process)")
+    ap.add_argument("--hops", choices=["aligned", "ragged"], default="aligned", help="ragged: every question its own program length (select -> 1..3 filter / relate "
+                    "hops -> exist; collate pads with no-op tokens) instead of the headline's select -> filter -> relate -> exist for all - what files of GQA "
+                    "programs look like; reported as config.hops")
     ap.add_argument("--fresh-streams", type=int, default=2, help="`value_fresh_programs`: HIP streams the unseen batches alternate on (2: the end of one batch "
                     "overlaps with the start of the next on the device, like the replay lanes of `value`; 1: one stream)")
     ap.add_argument("--fresh-depth", type=int, default=2, help="batches queued on the device before the oldest one's answers are waited for (`value_fresh_programs`)")
@@ -184,6 +187,9 @@ def build_batch(args, rank, ontology, names, device, world=1):
         if getattr(args, "workload", "north_star") == "c4":
             br, last = syn.open_program(qid, nouns, attrs, rels, names["categories"], hops=4)
             q = syn.question(qid, br, last, attrs[qid % len(attrs)], scene_of[img])
+        elif getattr(args, "hops", "aligned") == "ragged":
+            br, last = syn.ragged_hop_program(qid, nouns, attrs, rels)
+            q = syn.question(qid, br, last, "yes", scene_of[img])
         else:
             br, last = syn.three_hop_program(qid, nouns, attrs, rels)
             q = syn.question(qid, br, last, "yes", scene_of[img])
@@ -1443,11 +1449,13 @@ def train_main(args, rank, world, device, td, share):
                "value": gb * args.steps / elapsed, "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16" if args.mlp_math == "bf16" else "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[3]'s step on synthetic scenes: select->filter->relate->exist, BCE loss, %s phase, "
-                                      "%d questions/GPU/step%s" % ("calibrator (cur6-7)" if args.calibrator else "oracle (cur1-5)", args.batch,
+               "config": {"workload": "BASELINE configs[3]'s step on synthetic scenes: %s, BCE loss, %s phase, "
+                                      "%d questions/GPU/step%s" % ("select -> 1..3 filter / relate hops -> exist, a program length per question (no-op tokens after collate)"
+                                                                   if args.hops == "ragged" else "select->filter->relate->exist",
+                                                                   "calibrator (cur6-7)" if args.calibrator else "oracle (cur1-5)", args.batch,
                                                                    ", mlp_math bf16 (dense products on bf16 operands, fp32 accumulation and logic)"
                                                                    if args.mlp_math == "bf16" else ""),
-                          "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
+                          "hops": args.hops, "global_batch": gb, "parallelism": "dp%d" % world, "gradient_bucket_bytes": bucket.nbytes(),
                           "launch": ("eager" if not graphed else "hip graph replay of the whole step (training.GraphedTrainStep)" if td is None else
                                      "hip graph replay of the whole step, the all-reduce captured inside (training.GraphedTrainStep, graph_collective)"
                                      if graph_collective else

@@ -83,6 +83,19 @@ def three_hop_program(qid, nouns, attributes, relations, negate_prob=0.0):
     return [[op("select", n1), op("filter", a), op("relate", r, subj, n2)]], op("exist")
 
 
+def ragged_hop_program(qid, nouns, attributes, relations):
+    """select(n) -> 1..3 hops, each filter(a) or relate(r, is_subject, n') -> exist: programs of DIFFERING lengths (collate pads the shorter ones with
+    no-op tokens) - what a file of GQA programs holds; bench.py --mode train --hops ragged."""
+    rng = _rng(qid, 5)
+    branch = [op("select", nouns[rng.randint(len(nouns))])]
+    for _ in range(rng.randint(1, 4)):
+        if rng.uniform() < 0.5:
+            branch.append(op("filter", attributes[rng.randint(len(attributes))]))
+        else:
+            branch.append(op("relate", relations[rng.randint(len(relations))], bool(rng.uniform() < 0.5), nouns[rng.randint(len(nouns))]))
+    return [branch], op("exist")
+
+
 def open_program(qid, nouns, attributes, relations, categories, hops=4):
     """select(n) -> (filter(a) -> relate(r, is_subject, n')) x hops -> query_attr(category): the 8-hop open (QUERY) programs of
     BASELINE.json configs[4]."""

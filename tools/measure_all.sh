@@ -22,7 +22,7 @@ timeout 300 python tools/bench_kernels.py > $O/kernel_microbench.jsonl 2> $O/kb.
 DFOL_PAIR_MATH=bf16x3 DFOL_DENSE_MATH=bf16x3 timeout 300 python bench.py --steps 50 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --streamed 0 --sustain 0 > $O/bench_n100_bf16x3.json 2>> $O/bench_n100.err
 DFOL_PAIR_MATH=f32 DFOL_DENSE_MATH=f32 timeout 300 python bench.py --steps 50 --cpu-sample 0 --stress-preds 0 --fresh-batches 0 --streamed 0 --sustain 0 > $O/bench_n100_f32pipe.json 2>> $O/bench_n100.err
 timeout 300 python tools/bench_ops.py > $O/ops_throughput.jsonl 2> $O/ops.err
-for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1" "--objects 100 --mlp-math bf16" "--objects 100 --graph 0" "--objects 100 --calibrator 1 --graph 0"; do
+for a in "--objects 36" "--objects 100" "--objects 100 --ragged 10" "--objects 100 --calibrator 1" "--objects 100 --mlp-math bf16" "--objects 100 --graph 0" "--objects 100 --calibrator 1 --graph 0" "--objects 100 --hops ragged" "--objects 100 --hops ragged --mlp-math bf16"; do
   timeout 300 python bench.py --mode train --steps 10 $a >> $O/train_step.jsonl 2>> $O/train.err
 done
 DFOL_BF16_STORE=0 timeout 300 python bench.py --mode train --steps 10 --objects 100 --mlp-math bf16 >> $O/train_step_bf16_fp32_storage.jsonl 2>> $O/train.err

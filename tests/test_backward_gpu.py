@@ -1632,3 +1632,42 @@ def test_g24_calibrator_phase_train_step_against_the_reference(g24_setup, kind, 
         assert err <= 8 * own + 2e-3 * scale, "g24 %s d%s: |dgrad| %.3g vs the reference's own %.3g (scale %.3g)" % (kind, pname, err, own, scale)
         norm = np.sqrt((full ** 2).sum())
         assert abs(norm - g["norm64"]) <= 8 * abs(g["norm32"] - g["norm64"]) + 2e-3 * g["norm64"] + 1e-30, (kind, pname, norm, g["norm64"], g["norm32"])
+
+
+def test_train_step_over_programs_of_differing_lengths_graph_equals_eager():
+    """bench.py --mode train --hops ragged (select -> 1..3 filter / relate hops -> exist: a program length per question, no-op tokens after collate) at
+    full model size and >= 16384 pair rows: every relate reader stays on the fused kernels - the idle questions ride along, ONE dZ pass for all readers
+    (dfol_pair_dz_tall_multi_f32), the later readers' logits out of the fused forward - with no fallback; the step replayed as a HIP graph leaves the
+    same weights as the eager step, bit for bit, and the loss falls."""
+    import importlib.util
+    from dfol_vqa_amd import parallel, _lib
+    spec = importlib.util.spec_from_file_location("bench_for_test_ragged", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    finals = []
+    for graphed in (False, True):
+        args = bench.parse(["--mode", "train", "--objects", "30", "--batch", "48", "--hops", "ragged"])
+        torch.manual_seed(9)
+        model, ontology, paths, names = bench.build_model(args, DEV, train=True)
+        qs, pbs = bench.build_batch(args, 0, ontology, names, DEV)
+        hops = [sum(1 for o in q["program"]["branches"][0] if o["operator"] == "relate") for q in qs]
+        assert max(hops) >= 2 and len(set(len(q["program"]["branches"][0]) for q in qs)) >= 3      # differing lengths, several relate steps
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+        bucket = parallel.GradBucket(params)
+        _lib.PATH_COUNTS.clear()
+        if graphed:
+            step = training.GraphedTrainStep(model, opt, pbs, 0.65, bucket=bucket, warmup=1)
+            losses = [float(step()[0]) for _ in range(3)]
+        else:
+            losses = [float(training.train_batch(model, opt, pbs, 0.65, bucket=bucket, sync_loss=False)[0]) for _ in range(4)][1:]
+            routes = dict(_lib.PATH_COUNTS)
+            assert not [r for r in routes if r.startswith("fallback:")], routes
+            assert routes.get("idle_questions_ride_along", 0) >= 4 and routes.get("pair_dz_multi", 0) == 4 and routes.get("head_use_logits_from_trunk", 0) >= 4, routes
+            assert routes.get("pair_second_evaluation", 0) == 0 and routes.get("logit_rows_gathered", 0) == 0, routes
+        torch.cuda.synchronize()
+        assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], losses
+        finals.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    assert finals[0][0] == finals[1][0]
+    for k in finals[0][1]:
+        assert torch.equal(finals[0][1][k], finals[1][1][k]), k

@@ -444,7 +444,8 @@ class _HeadUse(torch.autograd.Function):
         # of a trunk share one row -> predicate map when each covers every pair row of the batch (P predicates = the batch's questions)
         defer = (st["need_dz"] and st.get("readers", 1) >= 2 and os.environ.get("DFOL_DZ_MULTI", "1") != "0" and pre2.dtype == torch.float32
                  and e_rows.shape[0] == st.get("dz_P", e_rows.shape[0]) and int(pred_off.shape[0]) - 1 == e_rows.shape[0]
-                 and L.linear_tall_supported(pre2.shape[0], st["w"].shape[1], pre2.shape[1]) and row_pred is not None and row_pred.shape[0] == pre2.shape[0])
+                 and L.linear_tall_supported(pre2.shape[0], st["w"].shape[1], pre2.shape[1]) and row_pred is not None and row_pred.shape[0] == pre2.shape[0]
+                 and row_pred.data_ptr() in st.get("allq", ()))
         need_dz_now = st["need_dz"] and not defer
         if defer:
             st["dz_P"] = e_rows.shape[0]
@@ -1002,6 +1003,10 @@ class ClassifierOracle(OracleBase):
                                 x_part = head[2][slot:slot + 1]
                                 _lib.note("head_use_logits_from_trunk")
                     _lib.note("head_use")
+                    if len(q) == world._batch_size and np.array_equal(q, np.arange(len(q))):
+                        # (a reader with one predicate per question, in order: all such readers map the pair rows to predicates the same way -
+                        # what lets the trunk take their dZ shares in one pass, _HeadUse.backward)
+                        head[1].setdefault("allq", set()).add(rep32.data_ptr())
                     x = _HeadUse.apply(head[0], pre2, e_rows, be_rows, pred_off, rep32, max_rows, head[1], x_part, sums_ok)
                 else:
                     _lib.note("fused_logit")

@@ -86,6 +86,11 @@ def main():
         for pb in pbs:
             pb.create_sparse_tensors()
         pbs = [pb.to_cuda(device) for pb in pbs]
+        # (a forward over 6656 predicates - query_attr - creates tens of thousands of small host objects; with the question dicts of every kind
+        # alive, the collector's full passes turned that into 8.5 ms per eager step against 1.45 replayed: what a process keeps is frozen, as in bench.py)
+        import gc
+        gc.collect()
+        gc.freeze()
         with torch.no_grad():
             for _ in range(4):                                 # (the first launches of a kernel variant load its code object)
                 res = model(pbs, False)

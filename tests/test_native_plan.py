@@ -218,6 +218,32 @@ def test_calibrated_programs_lower(setup, kind, monkeypatch):
     assert isinstance(FeatureCollater(1, ont, spec).collate(qs)[0]._native_plan, NP.NativePlan)
 
 
+def test_programs_of_differing_lengths_lower(setup):
+    """synthetic.ragged_hop_program (bench.py --hops ragged: select -> 1..3 filter / relate hops -> exist, a length per question): seeded by the
+    question id, lengths 2..4, and a collated batch - shorter programs padded with no-op tokens - lowers to ONE plan (with and without the
+    calibration passes) whose operands stay in bounds."""
+    ont, names, categories, spec = setup
+    nouns, attrs, rels = names["nouns"][:8], names["attributes"][:6], names["relations"][:5]
+    progs = [syn.ragged_hop_program(900 + i, nouns, attrs, rels) for i in range(40)]
+    assert progs == [syn.ragged_hop_program(900 + i, nouns, attrs, rels) for i in range(40)]
+    lengths = sorted(set(len(br[0]) for br, last in progs))
+    assert lengths == [2, 3, 4] and all(last["operator"] == "exist" for br, last in progs)
+    qs = [syn.question(900 + i, br, last, "yes", syn.feature_scene(900 + i, 5 + i % 7, 22)) for i, (br, last) in enumerate(progs)]
+    pb = FeatureCollater(1, ont, spec).collate(qs)[0]
+    assert isinstance(pb._native_plan, NP.NativePlan)
+    _in_bounds(pb._native_plan)
+    voc = list(ont._vocabulary["idx_to_arg"])
+    cspec = NP.ModelSpec([512], [256, 300], 256, 516, True, 0.0, ont._relation_index,
+                         calib=dict(state_dim=50, lstm_in=18 + 300, ops_index=D.BatchGQAInterpreter._OPS_INDEX))
+
+    class Coll(FeatureCollater):
+        def collate_meta_data(self, questions):
+            return {"index": {t: i for i, t in enumerate(voc)}, "embedding": torch.zeros(len(voc), 300)}
+    cal = Coll(1, ont, cspec).collate(qs)[0]._native_plan
+    assert isinstance(cal, NP.NativePlan) and cal.launches > pb._native_plan.launches
+    _in_bounds(cal)
+
+
 def test_shapes_the_executor_does_not_take_step_aside(setup):
     ont, names, categories, spec = setup
     qs = syn.full_size_questions("exist", 3, 5, 9, names, categories, 15)
